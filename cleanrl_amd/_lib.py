@@ -1,0 +1,83 @@
+"""ctypes binding of ``libmi355ppo.so`` (C ABI declared in ``include/mi355ppo.h``).
+
+The HIP library is mandatory for every GPU code path of this package: if it is missing and cannot
+be built, loading raises -- there is no silent eager/PyTorch fallback for CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmi355ppo.so")
+
+_P = c_void_p  # every tensor argument is a raw device pointer
+
+# name -> (restype, argtypes); must list every MI355PPO_API symbol of include/mi355ppo.h
+SIGNATURES = {
+    "mi355ppo_version": (c_int, []),
+    "mi355ppo_last_error": (c_char_p, []),
+    "mi355ppo_gae_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P]),
+    "mi355ppo_gae_f32_variant": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_int, _P]),
+    "mi355ppo_categorical_sample_f32": (c_int, [_P, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_int, _P]),
+    "mi355ppo_categorical_logprob_entropy_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "mi355ppo_normal_sample_f32": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, _P, c_int, c_int, _P]),
+    "mi355ppo_normal_logprob_entropy_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "mi355ppo_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mi355ppo_loss_categorical_fwd_bwd_f32": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int,
+                _P, _P, _P, _P, c_size_t, _P]),
+    "mi355ppo_loss_normal_fwd_bwd_f32": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int,
+                _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mi355ppo_obs_u8_to_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P]),
+    "mi355ppo_clip_adam_workspace_bytes": (c_size_t, [c_int64]),
+    "mi355ppo_clip_adam_f32": (
+        c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, c_double, c_int64,
+                _P, _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+class Mi355PpoError(RuntimeError):
+    """A libmi355ppo entry point returned a negative status."""
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load (once) and return the library with all prototypes declared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch first: its bundled libamdhip64.so.7 must be the HIP runtime this library binds to.
+    import torch  # noqa: F401
+
+    if not os.path.exists(LIB_PATH) and build_if_missing:
+        try:
+            from . import build as _build
+
+            _build.build(verbose=True)
+        except Exception as e:  # pragma: no cover - depends on the toolchain
+            raise RuntimeError(
+                f"libmi355ppo.so is missing at {LIB_PATH} and could not be built ({e}); run "
+                "`python -m cleanrl_amd.build` (needs hipcc). The HIP library is mandatory: there is no fallback."
+            ) from e
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"libmi355ppo.so is missing at {LIB_PATH}; run `python -m cleanrl_amd.build`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.mi355ppo_version()
+    if v // 100 != 1:
+        raise RuntimeError(f"libmi355ppo.so reports version {v}; this binding expects 1xx -- rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(status: int, fn: str) -> None:
+    if status != 0:
+        msg = load().mi355ppo_last_error()
+        raise Mi355PpoError(f"{fn} failed with status {status}: {msg.decode() if msg else ''}")

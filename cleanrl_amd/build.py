@@ -1,0 +1,58 @@
+"""Build ``cleanrl_amd/csrc/libmi355ppo.so`` (HIP, gfx950 only) in-tree.
+
+``python -m cleanrl_amd.build`` or ``__graft_entry__.build()``.  hipcc cross-compiles without a GPU.
+The library links only against the HIP runtime (``libamdhip64.so.7``); when it is loaded into a
+process that already imported torch, the loader binds that soname to the copy torch bundles, so the
+two share one runtime (streams and device pointers are interchangeable).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libmi355ppo.so")
+SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "optim.hip"]
+HEADERS = ["common.h", "catrow.h", os.path.join("..", "..", "include", "mi355ppo.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: every f32 multiply/add rounds separately, as the reference's un-fused torch ops do.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, jobs = [], []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [os.path.join(CSRC, src)] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    if jobs:
+        if verbose:
+            print(f"[cleanrl_amd.build] compiling {len(jobs)} HIP source(s) for gfx950", file=sys.stderr)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(_run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs)
+        if verbose:
+            print(f"[cleanrl_amd.build] linked {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,96 @@
+// Shared host/device helpers for libmi355ppo (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mi355ppo.h"
+
+#define MI355_WAVE 64
+
+namespace mi355ppo {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Launch-site check.  hipGetLastError is cheap, does not synchronise, and is legal during capture.
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MI355PPO_EHIP;
+    }
+    return MI355PPO_OK;
+}
+
+#define MI355_REQUIRE(cond, code, ...)          \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::mi355ppo::set_error(__VA_ARGS__); \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ device
+#ifdef __HIPCC__
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, MI355_WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, MI355_WAVE);
+    return v;
+}
+
+// Sum `v` over a block of NWAVES*64 threads in a fixed order; result valid in thread 0.
+// `lds` must hold NWAVES doubles.  Ends with a barrier-safe state (callers may reuse `lds` after
+// the next __syncthreads()).
+template <int NWAVES>
+__device__ __forceinline__ double block_sum(double v, double* lds) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) r += lds[w];
+    }
+    __syncthreads();
+    return r;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11).  Counter-based: the caller chooses the counter so that the
+// stream does not depend on the launch geometry.
+struct Philox {
+    uint32_t k0, k1;
+    __device__ __forceinline__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __device__ __forceinline__ uint4 operator()(uint64_t ctr_lo, uint64_t ctr_hi) const {
+        uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            const uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+
+// uint32 -> uniform in (0,1): (x + 0.5) * 2^-32 computed so that neither 0 nor 1 is produced.
+__device__ __forceinline__ float u32_to_unit_open(uint32_t x) {
+    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+#endif  // __HIPCC__
+}  // namespace mi355ppo

@@ -1,0 +1,89 @@
+// K5 -- observation path: uint8 rollout storage -> f32 network input, gather + convert fused (gfx950).
+//
+// Replaces `b_obs[mb_inds]` (an f32 index-gather of (M,4,84,84)) followed by `x / 255.0`
+// (cleanrl/ppo_atari_multigpu.py:320,154): the reference reads 4 B + writes 4 B per pixel for the
+// gather and again for the division (16 B/pixel of HBM traffic per minibatch row).  Here a pixel costs
+// 1 B read + 4 B written: rows are gathered straight from the uint8 rollout buffer and converted in
+// registers.  Algorithmic bytes per row = row_bytes * 5; at M=32768 rows of 28,224 B that is 4.62 GB
+// per minibatch -- by far the largest byte mover of the PPO update and purely HBM-bound.
+//
+// Mapping: grid = (rows, ceil(dwords_per_row / 1024)); a workgroup owns 1024 consecutive source dwords
+// of ONE row, so the row index (and mb_inds[row]) is wave-uniform (SGPR) and there is no per-lane
+// division.  A lane loads 4 independent dwords (256 B per wave-instruction, contiguous) and issues 4
+// float4 stores (1 KiB per wave-instruction, contiguous): every global instruction is fully coalesced.
+//
+// x/255.0f must be the correctly-rounded IEEE quotient to stay bit-equal to torch.  A reciprocal
+// multiply is wrong for 126 of the 256 byte values; one Newton residual step fixes all of them
+// (q = x*r; e = fma(-q, 255, x); q' = fma(e, r, q)), verified exhaustively in tests/test_gpu_obs.py.
+#include "common.h"
+
+namespace mi355ppo {
+
+__device__ __forceinline__ float u8_div255(float x) {
+    const float r = 1.0f / 255.0f;
+    const float q = x * r;
+    const float e = fmaf(-q, 255.0f, x);
+    return fmaf(e, r, q);
+}
+
+template <bool SCALE>
+__device__ __forceinline__ float4 convert4(uint32_t w) {
+    float4 o;
+    o.x = (float)(w & 0xffu);
+    o.y = (float)((w >> 8) & 0xffu);
+    o.z = (float)((w >> 16) & 0xffu);
+    o.w = (float)(w >> 24);
+    if (SCALE) {
+        o.x = u8_div255(o.x); o.y = u8_div255(o.y); o.z = u8_div255(o.z); o.w = u8_div255(o.w);
+    }
+    return o;
+}
+
+constexpr int kObsUnroll = 4;
+
+template <bool SCALE>
+__global__ __launch_bounds__(256) void obs_u8_to_f32_kernel(const uint8_t* __restrict__ src,
+                                                            const int64_t* __restrict__ inds,
+                                                            float* __restrict__ dst, int64_t row_bytes,
+                                                            int dwords_per_row) {
+    const int64_t r = blockIdx.x;
+    const int64_t sr = inds ? inds[r] : r;
+    const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(src + sr * row_bytes);
+    float4* __restrict__ d = reinterpret_cast<float4*>(dst + r * row_bytes);
+    const int base = blockIdx.y * (256 * kObsUnroll) + threadIdx.x;
+    uint32_t w[kObsUnroll];
+#pragma unroll
+    for (int u = 0; u < kObsUnroll; ++u) {
+        const int k = base + u * 256;
+        w[u] = (k < dwords_per_row) ? s[k] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kObsUnroll; ++u) {
+        const int k = base + u * 256;
+        if (k < dwords_per_row) d[k] = convert4<SCALE>(w[u]);
+    }
+}
+
+}  // namespace mi355ppo
+
+using namespace mi355ppo;
+
+extern "C" MI355PPO_API int mi355ppo_obs_u8_to_f32(const uint8_t* src_u8, const int64_t* inds, float* dst_f32, int64_t rows,
+                                      int64_t row_bytes, int scale_255, void* stream) {
+    const char* fn = "mi355ppo_obs_u8_to_f32";
+    MI355_REQUIRE(src_u8 && dst_f32, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(rows > 0 && rows <= 2147483647LL, MI355PPO_EINVAL, "%s: rows=%lld out of range", fn, (long long)rows);
+    MI355_REQUIRE(row_bytes > 0 && row_bytes % 4 == 0 && row_bytes / 4 <= (int64_t)65535 * 1024, MI355PPO_EINVAL,
+                  "%s: row_bytes=%lld must be a positive multiple of 4 (<= 256 MiB)", fn, (long long)row_bytes);
+    MI355_REQUIRE(aligned(src_u8, 4) && aligned(dst_f32, 16) && aligned(inds, 8), MI355PPO_EALIGN,
+                  "%s: src must be 4-byte, dst 16-byte, inds 8-byte aligned", fn);
+    const int dpr = (int)(row_bytes / 4);
+    const dim3 grid((unsigned)rows, (unsigned)((dpr + 256 * kObsUnroll - 1) / (256 * kObsUnroll)));
+    if (scale_255)
+        hipLaunchKernelGGL((obs_u8_to_f32_kernel<true>), grid, dim3(256), 0, as_stream(stream), src_u8, inds, dst_f32,
+                           row_bytes, dpr);
+    else
+        hipLaunchKernelGGL((obs_u8_to_f32_kernel<false>), grid, dim3(256), 0, as_stream(stream), src_u8, inds, dst_f32,
+                           row_bytes, dpr);
+    return check_launch("obs_u8_to_f32_kernel");
+}

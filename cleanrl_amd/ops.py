@@ -1,0 +1,326 @@
+"""Tensor-level operators over ``libmi355ppo.so`` -- the Python host side of the C ABI.
+
+Each function mirrors one seam of the reference's inline PPO code (cited per function) and takes
+CUDA (=HIP) ``torch`` tensors only: torch is plumbing here (device memory + the current stream), the
+computation is the HIP kernels.  Passing a CPU tensor raises; there is no CPU fallback in this module.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "gae", "categorical_sample", "categorical_logprob_entropy", "normal_sample", "normal_logprob_entropy",
+    "ppo_loss_categorical", "ppo_loss_normal", "obs_u8_to_f32", "clip_adam_", "PPOLossCategorical", "PPOLossNormal",
+    "LOSS_SCALAR_NAMES",
+]
+
+LOSS_SCALAR_NAMES = ("loss", "pg_loss", "v_loss", "entropy", "old_approx_kl", "approx_kl", "clipfrac")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(dev: torch.device):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype, name: str, shape=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA/HIP tensor (libmi355ppo has no CPU path), got "
+                        f"{type(t).__name__}{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+_workspaces: dict = {}
+
+
+def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-(device, stream) scratch; calls ordered on one stream may share it (see mi355ppo.h)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------------------------------- K1
+def gae(rewards, dones, values, next_done, next_value, gamma: float, gae_lambda: float, advantages=None, returns=None,
+        variant: int = 0):
+    """Fused GAE (reference: ppo_atari_multigpu.py:290-301).  Returns ``(advantages, returns)`` (T,N)."""
+    lib = _lib.load()
+    T, N = rewards.shape
+    _chk(rewards, torch.float32, "rewards", (T, N))
+    _chk(dones, torch.float32, "dones", (T, N))
+    _chk(values, torch.float32, "values", (T, N))
+    next_done = _chk(next_done.reshape(-1), torch.float32, "next_done", (N,))
+    next_value = _chk(next_value.reshape(-1), torch.float32, "next_value", (N,))
+    if advantages is None:
+        advantages = torch.empty_like(rewards)
+    if returns is None:
+        returns = torch.empty_like(rewards)
+    _chk(advantages, torch.float32, "advantages", (T, N))
+    _chk(returns, torch.float32, "returns", (T, N))
+    with torch.cuda.device(rewards.device):
+        st = lib.mi355ppo_gae_f32_variant(_ptr(rewards), _ptr(dones), _ptr(values), _ptr(next_done), _ptr(next_value),
+                                          _ptr(advantages), _ptr(returns), T, N, float(gamma), float(gae_lambda),
+                                          int(variant), _stream(rewards.device))
+    _lib.check(st, "mi355ppo_gae_f32")
+    return advantages, returns
+
+
+# ------------------------------------------------------------------------------------------- K2
+def categorical_sample(logits, noise_exp1=None, seed: int = 0, offset: int = 0, action_f32_out=None,
+                       logprob_out=None, want_entropy: bool = True, want_i64: bool = True):
+    """``Categorical(logits=logits)``: sample, log_prob, entropy (ppo_atari_multigpu.py:156-159).
+
+    ``noise_exp1`` (B,A) Exponential(1) draws reproduces torch's multinomial draw for that noise
+    (parity mode); otherwise a Philox stream keyed by ``(seed, offset)`` is used.
+    Returns ``(action_i64 | None, action_f32 | None, logprob, entropy | None)``.
+    """
+    lib = _lib.load()
+    B, A = logits.shape
+    _chk(logits, torch.float32, "logits", (B, A))
+    if noise_exp1 is not None:
+        _chk(noise_exp1, torch.float32, "noise_exp1", (B, A))
+    dev = logits.device
+    a64 = torch.empty(B, dtype=torch.int64, device=dev) if want_i64 else None
+    af = action_f32_out
+    if af is not None:
+        _chk(af, torch.float32, "action_f32_out", (B,))
+    elif not want_i64:
+        af = torch.empty(B, dtype=torch.float32, device=dev)
+    lp = logprob_out if logprob_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    _chk(lp, torch.float32, "logprob_out", (B,))
+    ent = torch.empty(B, dtype=torch.float32, device=dev) if want_entropy else None
+    with torch.cuda.device(dev):
+        st = lib.mi355ppo_categorical_sample_f32(_ptr(logits), _ptr(noise_exp1), int(seed) & (2**64 - 1),
+                                                 int(offset) & (2**64 - 1), _ptr(a64), _ptr(af), _ptr(lp), _ptr(ent),
+                                                 B, A, _stream(dev))
+    _lib.check(st, "mi355ppo_categorical_sample_f32")
+    return a64, af, lp, ent
+
+
+def categorical_logprob_entropy(logits, action):
+    """log_prob / entropy of given actions (int64 or the reference's f32 storage)."""
+    lib = _lib.load()
+    B, A = logits.shape
+    _chk(logits, torch.float32, "logits", (B, A))
+    dev = logits.device
+    if action.dtype == torch.int64:
+        a64, af = _chk(action, torch.int64, "action", (B,)), None
+    else:
+        a64, af = None, _chk(action, torch.float32, "action", (B,))
+    lp = torch.empty(B, dtype=torch.float32, device=dev)
+    ent = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = lib.mi355ppo_categorical_logprob_entropy_f32(_ptr(logits), _ptr(a64), _ptr(af), _ptr(lp), _ptr(ent), B, A,
+                                                          _stream(dev))
+    _lib.check(st, "mi355ppo_categorical_logprob_entropy_f32")
+    return lp, ent
+
+
+def normal_sample(mean, logstd, noise=None, seed: int = 0, offset: int = 0, action_out=None, logprob_out=None):
+    """``Normal(mean, exp(logstd))`` sample + summed log_prob/entropy (ppo_continuous_action.py:134-141)."""
+    lib = _lib.load()
+    B, D = mean.shape
+    _chk(mean, torch.float32, "mean", (B, D))
+    logstd = _chk(logstd.reshape(-1), torch.float32, "logstd", (D,))
+    if noise is not None:
+        _chk(noise, torch.float32, "noise", (B, D))
+    dev = mean.device
+    act = action_out if action_out is not None else torch.empty_like(mean)
+    _chk(act, torch.float32, "action_out", (B, D))
+    lp = logprob_out if logprob_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    ent = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = lib.mi355ppo_normal_sample_f32(_ptr(mean), _ptr(logstd), _ptr(noise), int(seed) & (2**64 - 1),
+                                            int(offset) & (2**64 - 1), _ptr(act), _ptr(lp), _ptr(ent), B, D,
+                                            _stream(dev))
+    _lib.check(st, "mi355ppo_normal_sample_f32")
+    return act, lp, ent
+
+
+def normal_logprob_entropy(mean, logstd, action):
+    lib = _lib.load()
+    B, D = mean.shape
+    _chk(mean, torch.float32, "mean", (B, D))
+    logstd = _chk(logstd.reshape(-1), torch.float32, "logstd", (D,))
+    _chk(action, torch.float32, "action", (B, D))
+    dev = mean.device
+    lp = torch.empty(B, dtype=torch.float32, device=dev)
+    ent = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = lib.mi355ppo_normal_logprob_entropy_f32(_ptr(mean), _ptr(logstd), _ptr(action), _ptr(lp), _ptr(ent), B, D,
+                                                     _stream(dev))
+    _lib.check(st, "mi355ppo_normal_logprob_entropy_f32")
+    return lp, ent
+
+
+# ------------------------------------------------------------------------------------------- K3
+def _flat_batch(b_logprobs, b_advantages, b_returns, b_values):
+    Bf = b_logprobs.numel()
+    return (Bf, _chk(b_logprobs.reshape(-1), torch.float32, "b_logprobs"),
+            _chk(b_advantages.reshape(-1), torch.float32, "b_advantages", (Bf,)),
+            _chk(b_returns.reshape(-1), torch.float32, "b_returns", (Bf,)),
+            _chk(b_values.reshape(-1), torch.float32, "b_values", (Bf,)))
+
+
+def ppo_loss_categorical(new_logits, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values,
+                         clip_coef: float, ent_coef: float, vf_coef: float, norm_adv: bool = True,
+                         clip_vloss: bool = True, scalars_out=None, dlogits_out=None, dvalue_out=None):
+    """Fused minibatch loss fwd+bwd (ppo_atari_multigpu.py:320-355 + autograd backward).
+
+    Returns ``(scalars7, dlogits, dvalue)``; ``scalars7`` = LOSS_SCALAR_NAMES order, on device.
+    """
+    lib = _lib.load()
+    M, A = new_logits.shape
+    _chk(new_logits, torch.float32, "new_logits", (M, A))
+    new_value = _chk(new_value.reshape(-1), torch.float32, "new_value", (M,))
+    dev = new_logits.device
+    if mb_inds is not None:
+        _chk(mb_inds, torch.int64, "mb_inds", (M,))
+    Bf, b_logprobs, b_advantages, b_returns, b_values = _flat_batch(b_logprobs, b_advantages, b_returns, b_values)
+    b_actions = _chk(b_actions.reshape(-1), torch.float32, "b_actions (f32 storage, as the reference)", (Bf,))
+    scalars = scalars_out if scalars_out is not None else torch.empty(7, dtype=torch.float32, device=dev)
+    dlogits = dlogits_out if dlogits_out is not None else torch.empty_like(new_logits)
+    dvalue = dvalue_out if dvalue_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    need = lib.mi355ppo_loss_workspace_bytes(M, 0)
+    ws = _workspace(dev, need)
+    with torch.cuda.device(dev):
+        st = lib.mi355ppo_loss_categorical_fwd_bwd_f32(
+            _ptr(new_logits), _ptr(new_value), _ptr(mb_inds), _ptr(b_actions), _ptr(b_logprobs), _ptr(b_advantages),
+            _ptr(b_returns), _ptr(b_values), M, A, float(clip_coef), float(ent_coef), float(vf_coef), int(bool(norm_adv)),
+            int(bool(clip_vloss)), _ptr(scalars), _ptr(dlogits), _ptr(dvalue), _ptr(ws), ws.numel(), _stream(dev))
+    _lib.check(st, "mi355ppo_loss_categorical_fwd_bwd_f32")
+    return scalars, dlogits, dvalue
+
+
+def ppo_loss_normal(new_mean, logstd, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values,
+                    clip_coef: float, ent_coef: float, vf_coef: float, norm_adv: bool = True, clip_vloss: bool = True):
+    """Continuous-action loss fwd+bwd (ppo_continuous_action.py:265-300).
+    Returns ``(scalars7, dmean, dlogstd, dvalue)``."""
+    lib = _lib.load()
+    M, D = new_mean.shape
+    _chk(new_mean, torch.float32, "new_mean", (M, D))
+    logstd_flat = _chk(logstd.reshape(-1), torch.float32, "logstd", (D,))
+    new_value = _chk(new_value.reshape(-1), torch.float32, "new_value", (M,))
+    dev = new_mean.device
+    if mb_inds is not None:
+        _chk(mb_inds, torch.int64, "mb_inds", (M,))
+    Bf, b_logprobs, b_advantages, b_returns, b_values = _flat_batch(b_logprobs, b_advantages, b_returns, b_values)
+    b_actions = _chk(b_actions.reshape(Bf, D), torch.float32, "b_actions", (Bf, D))
+    scalars = torch.empty(7, dtype=torch.float32, device=dev)
+    dmean = torch.empty_like(new_mean)
+    dlogstd = torch.empty(D, dtype=torch.float32, device=dev)
+    dvalue = torch.empty(M, dtype=torch.float32, device=dev)
+    need = lib.mi355ppo_loss_workspace_bytes(M, D)
+    ws = _workspace(dev, need)
+    with torch.cuda.device(dev):
+        st = lib.mi355ppo_loss_normal_fwd_bwd_f32(
+            _ptr(new_mean), _ptr(logstd_flat), _ptr(new_value), _ptr(mb_inds), _ptr(b_actions), _ptr(b_logprobs),
+            _ptr(b_advantages), _ptr(b_returns), _ptr(b_values), M, D, float(clip_coef), float(ent_coef), float(vf_coef),
+            int(bool(norm_adv)), int(bool(clip_vloss)), _ptr(scalars), _ptr(dmean), _ptr(dlogstd), _ptr(dvalue), _ptr(ws),
+            ws.numel(), _stream(dev))
+    _lib.check(st, "mi355ppo_loss_normal_fwd_bwd_f32")
+    return scalars, dmean, dlogstd, dvalue
+
+
+class PPOLossCategorical(torch.autograd.Function):
+    """``loss = PPOLossCategorical.apply(logits, value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns,
+    b_values, clip_coef, ent_coef, vf_coef, norm_adv, clip_vloss)`` -> (loss, scalars7).  ``loss.backward()``
+    feeds the precomputed dlogits / dvalue into the network's autograd graph."""
+
+    @staticmethod
+    def forward(ctx, logits, value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values, clip_coef,
+                ent_coef, vf_coef, norm_adv, clip_vloss):
+        scalars, dlogits, dvalue = ppo_loss_categorical(
+            logits.detach().contiguous(), value.detach().contiguous(), mb_inds, b_actions, b_logprobs, b_advantages,
+            b_returns, b_values, clip_coef, ent_coef, vf_coef, norm_adv, clip_vloss)
+        ctx.save_for_backward(dlogits, dvalue)
+        ctx.value_shape = value.shape
+        ctx.mark_non_differentiable(scalars)
+        return scalars[0].clone(), scalars
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_scalars):
+        dlogits, dvalue = ctx.saved_tensors
+        return (grad_loss * dlogits, (grad_loss * dvalue).reshape(ctx.value_shape)) + (None,) * 11
+
+
+class PPOLossNormal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, logstd, value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values, clip_coef,
+                ent_coef, vf_coef, norm_adv, clip_vloss):
+        scalars, dmean, dlogstd, dvalue = ppo_loss_normal(
+            mean.detach().contiguous(), logstd.detach().contiguous(), value.detach().contiguous(), mb_inds, b_actions,
+            b_logprobs, b_advantages, b_returns, b_values, clip_coef, ent_coef, vf_coef, norm_adv, clip_vloss)
+        ctx.save_for_backward(dmean, dlogstd, dvalue)
+        ctx.value_shape, ctx.logstd_shape = value.shape, logstd.shape
+        ctx.mark_non_differentiable(scalars)
+        return scalars[0].clone(), scalars
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_scalars):
+        dmean, dlogstd, dvalue = ctx.saved_tensors
+        return (grad_loss * dmean, (grad_loss * dlogstd).reshape(ctx.logstd_shape),
+                (grad_loss * dvalue).reshape(ctx.value_shape)) + (None,) * 11
+
+
+# ------------------------------------------------------------------------------------------- K5
+def obs_u8_to_f32(src_u8, inds=None, out=None, scale_255: bool = True):
+    """Gather rows of a uint8 observation buffer and convert to f32 (``b_obs[mb_inds]`` then ``x / 255.0``,
+    ppo_atari_multigpu.py:320,154).  ``src_u8``: (R, ...) uint8; ``inds``: (rows,) int64 or None."""
+    lib = _lib.load()
+    _chk(src_u8, torch.uint8, "src_u8")
+    dev = src_u8.device
+    row_shape = tuple(src_u8.shape[1:])
+    row_bytes = 1
+    for s in row_shape:
+        row_bytes *= s
+    if inds is not None:
+        _chk(inds, torch.int64, "inds")
+        rows = inds.numel()
+    else:
+        rows = src_u8.shape[0]
+    if out is None:
+        out = torch.empty((rows,) + row_shape, dtype=torch.float32, device=dev)
+    _chk(out, torch.float32, "out", (rows,) + row_shape)
+    with torch.cuda.device(dev):
+        st = lib.mi355ppo_obs_u8_to_f32(_ptr(src_u8), _ptr(inds), _ptr(out), rows, row_bytes, int(bool(scale_255)),
+                                        _stream(dev))
+    _lib.check(st, "mi355ppo_obs_u8_to_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------- a8/a9
+def clip_adam_(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, max_grad_norm: float, grad_scale: float = 1.0,
+               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-5, total_norm_out=None):
+    """In-place fused ``grads*grad_scale -> clip_grad_norm_ -> Adam.step`` on flat f32 buffers
+    (ppo_atari_multigpu.py:368-377).  Zeroes ``grads`` for the next backward.  ``step`` is 1-based."""
+    lib = _lib.load()
+    n = params.numel()
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, torch.float32, nm, (n,))
+    dev = params.device
+    if total_norm_out is None:
+        total_norm_out = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.mi355ppo_clip_adam_workspace_bytes(n))
+    with torch.cuda.device(dev):
+        st = lib.mi355ppo_clip_adam_f32(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), n, float(grad_scale),
+                                        float(max_grad_norm), float(lr), float(beta1), float(beta2), float(eps),
+                                        int(step), _ptr(total_norm_out), _ptr(ws), ws.numel(), _stream(dev))
+    _lib.check(st, "mi355ppo_clip_adam_f32")
+    return total_norm_out

@@ -1,0 +1,183 @@
+/*
+ * mi355ppo.h -- C ABI of libmi355ppo.so: the MI355X (gfx950 / CDNA4) PPO hot path.
+ *
+ * The reference (vwxyzjn/cleanrl) has no FFI, plugin or operator boundary: its PPO scripts are
+ * executed, never imported, and the hot path is inline tensor code.  This header therefore DEFINES
+ * the drop-in boundary at the tensor seams of that inline code; every entry point cites the
+ * reference lines (cleanrl/<file>:<lines>) whose op chain it replaces.  A maintainer binds it with
+ * ctypes (the reference is Python) -- see INTEGRATION.md for the stub.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor .data_ptr()),
+ *     contiguous, row-major, never retained past the call;
+ *   - no allocation, no hipMalloc/hipFree, no host<->device copy, no device synchronisation inside:
+ *     work is only enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream),
+ *     so every call is legal inside a hipGraph stream capture;
+ *   - scratch memory is caller-provided (`workspace`, sized by the *_workspace_bytes query) and is
+ *     written before it is read in every call: it needs no initialisation and may be shared by
+ *     calls that are ordered on one stream;
+ *   - hyper-parameters are `double` because the reference holds them as Python floats and torch
+ *     rounds them to f32 at each scalar-tensor op; the kernels reproduce that rounding;
+ *   - return 0 on success, a negative MI355PPO_E* code otherwise; mi355ppo_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - re-entrant and thread-safe: no global mutable state.
+ */
+#ifndef MI355PPO_H_
+#define MI355PPO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355PPO_VERSION 100 /* 0.1.0 */
+
+#if defined(__GNUC__)
+#define MI355PPO_API __attribute__((visibility("default")))
+#else
+#define MI355PPO_API
+#endif
+
+#define MI355PPO_OK 0
+#define MI355PPO_EINVAL (-1)     /* null pointer, non-positive or unsupported shape            */
+#define MI355PPO_EALIGN (-2)     /* a pointer is not aligned to its element size               */
+#define MI355PPO_EHIP (-3)       /* a HIP runtime call / kernel launch failed                  */
+#define MI355PPO_EWORKSPACE (-4) /* workspace NULL or smaller than *_workspace_bytes()         */
+
+MI355PPO_API int mi355ppo_version(void);
+MI355PPO_API const char* mi355ppo_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  Generalised Advantage Estimation, fused reverse scan.
+ * Replaces cleanrl/ppo_atari_multigpu.py:290-301 (== ppo.py:220-231, ppo_atari.py:237-248,
+ * ppo_atari_envpool.py:252-263, ppo_continuous_action.py:235-246): ~10 elementwise torch kernels
+ * per time step x T steps, plus `returns = advantages + values`.
+ *   rewards, dones, values : (T,N) f32, time-major (N contiguous)      [in]
+ *   next_done, next_value  : (N)   f32                                  [in]
+ *   advantages, returns    : (T,N) f32                                  [out]
+ * Bit-exact with the reference's f32 op order: ((g*nv)*nnt), ((r+.)-v), (((g*l)*nnt)*last), where
+ * g*l is formed in double and then rounded to f32 (no FMA contraction).
+ * `variant`: 0 = auto, 1 = column-streaming kernel, 2 = LDS-staged tile kernel (tuning/testing).
+ */
+MI355PPO_API int mi355ppo_gae_f32(const float* rewards, const float* dones, const float* values,
+                     const float* next_done, const float* next_value,
+                     float* advantages, float* returns,
+                     int T, int N, double gamma, double gae_lambda, void* stream);
+MI355PPO_API int mi355ppo_gae_f32_variant(const float* rewards, const float* dones, const float* values,
+                             const float* next_done, const float* next_value,
+                             float* advantages, float* returns,
+                             int T, int N, double gamma, double gae_lambda, int variant, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  Categorical(logits): sample + log_prob + entropy in one launch.
+ * Replaces Agent.get_action_and_value's distribution ops, cleanrl/ppo_atari_multigpu.py:156-159
+ * (== ppo.py:122-126, ppo_atari_envpool.py:134-139): logits - logsumexp, softmax,
+ * multinomial(probs,1) [= argmax(probs / Exp(1)) in ATen], gather, entropy.
+ *   logits      : (B,A) f32                                             [in]
+ *   noise_exp1  : (B,A) f32 Exponential(1) draws, or NULL               [in]
+ *                 NULL => draws come from an internal Philox4x32-10 stream keyed by (seed, offset);
+ *                 counter = row*A + column, so results do not depend on the launch geometry.
+ *   action_i64  : (B) int64, may be NULL                                [out]
+ *   action_f32  : (B) f32,   may be NULL  (the reference stores Discrete actions in an f32 rollout
+ *                 tensor, ppo_atari_multigpu.py:236,265)                [out]
+ *   logprob     : (B) f32                                               [out]
+ *   entropy     : (B) f32, may be NULL                                  [out]
+ */
+MI355PPO_API int mi355ppo_categorical_sample_f32(const float* logits, const float* noise_exp1,
+                                    uint64_t seed, uint64_t offset,
+                                    int64_t* action_i64, float* action_f32,
+                                    float* logprob, float* entropy,
+                                    int B, int A, void* stream);
+
+/* log_prob / entropy of GIVEN actions (the `action is not None` branch, :157-159).
+ * Exactly one of action_i64 / action_f32 must be non-NULL. */
+MI355PPO_API int mi355ppo_categorical_logprob_entropy_f32(const float* logits,
+                                             const int64_t* action_i64, const float* action_f32,
+                                             float* logprob, float* entropy,
+                                             int B, int A, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2' Normal(mean, exp(logstd)): sample + summed log_prob + summed entropy.
+ * Replaces cleanrl/ppo_continuous_action.py:134-141.
+ *   mean (B,D), logstd (D), noise_std_normal (B,D) or NULL (=> Philox + Box-Muller),
+ *   action (B,D) out, logprob_sum (B) out, entropy_sum (B) out or NULL.
+ * action = noise * exp(logstd) + mean (mul then add, as torch.normal); log_prob uses
+ * log(exp(logstd)) for log_scale exactly as torch.distributions.Normal does.
+ */
+MI355PPO_API int mi355ppo_normal_sample_f32(const float* mean, const float* logstd, const float* noise_std_normal,
+                               uint64_t seed, uint64_t offset,
+                               float* action, float* logprob_sum, float* entropy_sum,
+                               int B, int D, void* stream);
+MI355PPO_API int mi355ppo_normal_logprob_entropy_f32(const float* mean, const float* logstd, const float* action,
+                                        float* logprob_sum, float* entropy_sum,
+                                        int B, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  Minibatch PPO loss, forward + backward fused (clipped surrogate + value loss + entropy).
+ * Replaces cleanrl/ppo_atari_multigpu.py:320(b_actions.long()[mb_inds])-355 and the autograd
+ * backward of those ops down to the network outputs (== ppo.py:250-285, ppo_atari.py:267-302,
+ * ppo_atari_envpool.py:282-317).
+ *   new_logits (M,A), new_value (M)        : network outputs for the minibatch rows  [in]
+ *   mb_inds (M) int64 or NULL (= identity) : rows of the flat batch                  [in]
+ *   b_actions_f32, b_logprobs, b_advantages, b_returns, b_values : (Bflat) f32       [in]
+ *   scalars7 : loss, pg_loss, v_loss, entropy, old_approx_kl, approx_kl, clipfrac    [out, 7 f32]
+ *   dlogits (M,A), dvalue (M) : d loss / d new_logits, d loss / d new_value          [out]
+ * Reductions are computed in a fixed order (deterministic); advantage mean / unbiased std are
+ * accumulated in f64.  Tolerances vs the reference are stated in tests/test_gpu_loss.py.
+ */
+MI355PPO_API size_t mi355ppo_loss_workspace_bytes(int M, int D);
+MI355PPO_API int mi355ppo_loss_categorical_fwd_bwd_f32(const float* new_logits, const float* new_value,
+                                          const int64_t* mb_inds, const float* b_actions_f32,
+                                          const float* b_logprobs, const float* b_advantages,
+                                          const float* b_returns, const float* b_values,
+                                          int M, int A,
+                                          double clip_coef, double ent_coef, double vf_coef,
+                                          int norm_adv, int clip_vloss,
+                                          float* scalars7, float* dlogits, float* dvalue,
+                                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Continuous-action variant, cleanrl/ppo_continuous_action.py:265-300:
+ *   new_mean (M,D), logstd (D), b_actions (Bflat,D) -> dmean (M,D), dlogstd (D), dvalue (M). */
+MI355PPO_API int mi355ppo_loss_normal_fwd_bwd_f32(const float* new_mean, const float* logstd, const float* new_value,
+                                     const int64_t* mb_inds, const float* b_actions,
+                                     const float* b_logprobs, const float* b_advantages,
+                                     const float* b_returns, const float* b_values,
+                                     int M, int D,
+                                     double clip_coef, double ent_coef, double vf_coef,
+                                     int norm_adv, int clip_vloss,
+                                     float* scalars7, float* dmean, float* dlogstd, float* dvalue,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  Observation path: uint8 rollout storage -> f32 network input, gather + convert fused.
+ * Replaces `b_obs[mb_inds]` followed by `x / 255.0` (cleanrl/ppo_atari_multigpu.py:320,154) and,
+ * with inds == NULL, the per-step `x / 255.0` of :151,154.  The reference stores observations as
+ * f32 (:235); uint8 storage is exact because frames are integers 0..255.
+ *   src_u8 : (rows_total, row_bytes) u8;  inds : (rows) int64 or NULL;  dst_f32 : (rows, row_bytes)
+ *   scale_255 != 0 => dst = (float)src / 255.0f, correctly rounded (bit-equal to torch's division);
+ *   scale_255 == 0 => dst = (float)src.
+ * row_bytes must be a multiple of 4; src rows must be 4-byte aligned, dst 16-byte aligned.
+ */
+MI355PPO_API int mi355ppo_obs_u8_to_f32(const uint8_t* src_u8, const int64_t* inds, float* dst_f32,
+                           int64_t rows, int64_t row_bytes, int scale_255, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a8/a9  Flat-buffer optimiser step: (grad * grad_scale) -> global-norm clip -> Adam, fused.
+ * Replaces the unpack-and-divide of cleanrl/ppo_atari_multigpu.py:368-374 (grad_scale =
+ * 1/world_size), nn.utils.clip_grad_norm_ (:376) and optim.Adam(eps=1e-5).step() (:377) on a
+ * persistent flat parameter/gradient buffer.
+ *   params, grads, exp_avg, exp_avg_sq : (n) f32 ; grads is scaled+clipped in place
+ *   step : 1-based Adam step count ; total_norm_out : (1) f32 pre-clip norm, may be NULL
+ */
+MI355PPO_API size_t mi355ppo_clip_adam_workspace_bytes(int64_t n);
+MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                           double grad_scale, double max_grad_norm, double lr,
+                           double beta1, double beta2, double eps, int64_t step,
+                           float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355PPO_H_ */

@@ -1,0 +1,352 @@
+"""Mint ``tests/golden/*.npz`` by executing the reference's own source lines.
+
+TEST INFRASTRUCTURE.  Run in the build container only (needs ``/root/reference``):
+
+    python -m oracle.mint_goldens
+
+Every array written here is either a seeded synthetic *input* or an *output of the
+reference's verbatim lines* (``oracle/ref_extract.py``) under the installed
+torch 2.10.0 on CPU (reference pin: torch 2.4.1).  The fixtures are small (a few MB in
+total) and are committed; the GPU box has no ``/root/reference`` and only reads them.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from cleanrl_amd import synthetic  # noqa: E402  (input generators only)
+from oracle import ref_extract as R  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+torch.set_num_threads(1)
+torch.use_deterministic_algorithms(True)
+
+
+def _np(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    return out
+
+
+def _save(name, cases):
+    flat = {}
+    for case, d in cases.items():
+        for k, v in _np(d).items():
+            flat[f"{case}/{k}"] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"{name}: {len(cases)} cases, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+# ---------------------------------------------------------------------------------- GAE
+def mint_gae():
+    cases = {}
+
+    def run(name, script, rewards, dones, values, next_done, next_value, gamma, lam):
+        adv, ret = R.run_gae(script, rewards, dones, values, next_done, next_value, gamma, lam)
+        cases[name] = dict(rewards=rewards, dones=dones, values=values, next_done=next_done, next_value=next_value,
+                           gamma=np.float64(gamma), gae_lambda=np.float64(lam), advantages=adv, returns=ret,
+                           script=np.bytes_(script))
+
+    # the shape/distributions of the reference's only numeric test (tests/test_jax_compute_gae.py:66-88)
+    g = torch.Generator().manual_seed(42)
+    T, N = 123, 7
+    run("jaxtest_123x7", "ppo_atari_envpool.py",
+        torch.rand(T, N, generator=g) * 2 - 1, torch.randint(0, 2, (T, N), generator=g).float(),
+        torch.rand(T, N, generator=g), torch.randint(0, 2, (N,), generator=g).float(), torch.rand(N, generator=g),
+        0.99, 0.95)
+    # BASELINE.json configs A, B (full), C/D/E (narrow slices of the same generators)
+    for name, script, (T, N), A in [
+        ("A_128x4", "ppo.py", (128, 4), 2),
+        ("B_128x128", "ppo_atari_envpool.py", (128, 128), 4),
+        ("C_128x1024", "ppo_atari.py", (128, 1024), 4),
+        ("D_128x256", "ppo_atari_multigpu.py", (128, 256), 4),
+        ("E_2048x16", "ppo_continuous_action.py", (2048, 16), 4),
+    ]:
+        s = synthetic.rollout_scalars(T, N, A, seed=1)
+        run(name, script, s["rewards"], s["dones"], s["values"], s["next_done"], s["next_value"], 0.99, 0.95)
+    # edges: T=1, N=1, ragged N, every step terminal, no terminal, gamma=lambda=1, next_done set
+    g = torch.Generator().manual_seed(7)
+    for name, (T, N), dmode, gam, lam in [
+        ("edge_1x1", (1, 1), "rand", 0.99, 0.95), ("edge_1x5", (1, 5), "rand", 0.99, 0.95),
+        ("edge_5x1", (5, 1), "rand", 0.99, 0.95), ("edge_33x67", (33, 67), "rand", 0.99, 0.95),
+        ("edge_alldone_16x9", (16, 9), "ones", 0.99, 0.95), ("edge_nodone_16x9", (16, 9), "zeros", 0.99, 0.95),
+        ("edge_gamma1_40x13", (40, 13), "rand", 1.0, 1.0), ("edge_g09_l08_40x13", (40, 13), "rand", 0.9, 0.8),
+        ("edge_lam0_40x13", (40, 13), "rand", 0.99, 0.0),
+    ]:
+        rewards = torch.randn(T, N, generator=g)
+        values = torch.randn(T, N, generator=g) * 3
+        if dmode == "rand":
+            dones = (torch.rand(T, N, generator=g) < 0.2).float()
+            nd = (torch.rand(N, generator=g) < 0.5).float()
+        else:
+            dones = torch.ones(T, N) if dmode == "ones" else torch.zeros(T, N)
+            nd = torch.ones(N) if dmode == "ones" else torch.zeros(N)
+        run(name, "ppo.py", rewards, dones, values, nd, torch.randn(N, generator=g), gam, lam)
+    _save("gae", cases)
+
+
+# ----------------------------------------------------------------------- distributions
+def mint_categorical():
+    """``Agent.get_action_and_value`` sampling path with the reference's Categorical (torch)."""
+    from torch.distributions.categorical import Categorical
+
+    cases = {}
+    g = torch.Generator().manual_seed(11)
+    for name, B, A, scale in [("B1_A4", 1, 4, 1.0), ("B7_A2", 7, 2, 1.0), ("B1024_A4", 1024, 4, 1.0),
+                              ("B1000_A6", 1000, 6, 3.0), ("B513_A18", 513, 18, 1.0),
+                              ("B256_A4_peaked", 256, 4, 30.0), ("B256_A9_tiny", 256, 9, 0.01)]:
+        logits = torch.randn(B, A, generator=g) * scale
+        probs = Categorical(logits=logits)
+        torch.manual_seed(1234)
+        action = probs.sample()                       # ppo_atari_multigpu.py:158
+        torch.manual_seed(1234)
+        noise = torch.empty_like(probs.probs).exponential_(1)   # the q of multinomial's one-draw fast path
+        assert torch.equal(action, torch.argmax(probs.probs / noise, -1))
+        cases[name] = dict(logits=logits, noise_exp1=noise, action=action, logprob=probs.log_prob(action),
+                           entropy=probs.entropy(), probs=probs.probs)
+    _save("categorical", cases)
+
+
+def mint_normal():
+    from torch.distributions.normal import Normal
+
+    cases = {}
+    g = torch.Generator().manual_seed(13)
+    for name, B, D in [("B1_D1", 1, 1), ("B64_D6", 64, 6), ("B1000_D17", 1000, 17), ("B333_D3", 333, 3)]:
+        mean = torch.randn(B, D, generator=g)
+        logstd = torch.randn(1, D, generator=g) * 0.5
+        std = torch.exp(logstd.expand_as(mean))       # ppo_continuous_action.py:135-137
+        probs = Normal(mean, std)
+        torch.manual_seed(99)
+        action = probs.sample()
+        torch.manual_seed(99)
+        z = torch.empty_like(mean).normal_()
+        assert torch.equal(action, z * std + mean)
+        cases[name] = dict(mean=mean, logstd=logstd.reshape(-1), noise=z, action=action,
+                           logprob_sum=probs.log_prob(action).sum(1), entropy_sum=probs.entropy().sum(1))
+    _save("normal", cases)
+
+
+# ------------------------------------------------------------------------------- loss
+def _behaviour_batch(g, new_lp, new_value, B):
+    """Old-policy tensors around the fresh policy so that ratios land inside AND outside the clip range."""
+    s = torch.where(torch.rand(B, generator=g) < 0.5, torch.tensor(0.03), torch.tensor(0.6))
+    b_logprobs = (new_lp + torch.randn(B, generator=g) * s).detach()
+    sv = torch.where(torch.rand(B, generator=g) < 0.5, torch.tensor(0.05), torch.tensor(0.5))
+    b_values = (new_value + torch.randn(B, generator=g) * sv).detach()
+    b_advantages = torch.randn(B, generator=g) * 1.7 + 0.3
+    b_returns = b_values + b_advantages
+    return b_logprobs, b_advantages, b_returns, b_values
+
+
+def _hooked(module):
+    box = {}
+
+    def hook(_m, _inp, out):
+        out.retain_grad()
+        box["out"] = out
+
+    module.register_forward_hook(hook)
+    return box
+
+
+def mint_loss_categorical():
+    cases = {}
+    g = torch.Generator().manual_seed(21)
+    specs = [
+        ("mlp_A2", "ppo.py", (4,), 2, 512, 128, dict(clip_coef=0.2)),
+        ("mlp_A2_noadvnorm", "ppo.py", (4,), 2, 512, 128, dict(clip_coef=0.2, norm_adv=False)),
+        ("mlp_A2_novclip", "ppo.py", (4,), 2, 512, 128, dict(clip_coef=0.2, clip_vloss=False)),
+        ("mlp_A2_plain", "ppo.py", (4,), 2, 512, 128, dict(clip_coef=0.2, clip_vloss=False, norm_adv=False, ent_coef=0.0)),
+        ("cnn_A4", "ppo_atari_envpool.py", (4, 84, 84), 4, 256, 64, {}),
+        ("cnn_A18", "ppo_atari.py", (4, 84, 84), 18, 96, 32, {}),
+        ("cnn_A4_multigpu", "ppo_atari_multigpu.py", (4, 84, 84), 4, 256, 64, {}),
+    ]
+    for name, script, obs_shape, A, B, M, kw in specs:
+        torch.manual_seed(5)
+        Agent, _ = R.load_agent_class(script)
+        agent = Agent(R.fake_envs(obs_shape, n_actions=A))
+        args = R.make_args(**kw)
+        if len(obs_shape) == 3:
+            b_obs = torch.randint(0, 256, (B,) + obs_shape, generator=g).float()
+        else:
+            b_obs = torch.randn((B,) + obs_shape, generator=g)
+        b_actions = torch.randint(0, A, (B,), generator=g).float()        # stored as f32 (:236)
+        with torch.no_grad():
+            _, lp_all, _, v_all = agent.get_action_and_value(b_obs, b_actions.long())
+        b_logprobs, b_advantages, b_returns, b_values = _behaviour_batch(g, lp_all, v_all.view(-1), B)
+        mb_inds = np.random.RandomState(3).permutation(B)[:M]
+        actor_last = agent.actor if isinstance(agent.actor, torch.nn.Linear) else agent.actor[-1]
+        critic_last = agent.critic if isinstance(agent.critic, torch.nn.Linear) else agent.critic[-1]
+        lbox, vbox = _hooked(actor_last), _hooked(critic_last)
+        ns = R.run_loss(script, agent, args, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, mb_inds)
+        ns["loss"].backward()
+        cases[name] = dict(
+            new_logits=lbox["out"], new_value=vbox["out"].view(-1), mb_inds=mb_inds.astype(np.int64),
+            b_actions=b_actions, b_logprobs=b_logprobs, b_advantages=b_advantages, b_returns=b_returns, b_values=b_values,
+            clip_coef=np.float64(args.clip_coef), ent_coef=np.float64(args.ent_coef), vf_coef=np.float64(args.vf_coef),
+            norm_adv=np.int32(args.norm_adv), clip_vloss=np.int32(args.clip_vloss),
+            loss=ns["loss"], pg_loss=ns["pg_loss"], v_loss=ns["v_loss"], entropy=ns["entropy_loss"],
+            old_approx_kl=ns["old_approx_kl"], approx_kl=ns["approx_kl"], clipfrac=np.float32(ns["clipfracs"][0]),
+            newlogprob=ns["newlogprob"], dlogits=lbox["out"].grad, dvalue=vbox["out"].grad.view(-1),
+            script=np.bytes_(script))
+    _save("loss_categorical", cases)
+
+
+def mint_loss_normal():
+    cases = {}
+    g = torch.Generator().manual_seed(23)
+    script = "ppo_continuous_action.py"
+    for name, obs_dim, D, B, M, kw in [
+        ("halfcheetah_D6", 17, 6, 1024, 256, dict(clip_coef=0.2, ent_coef=0.0)),
+        ("halfcheetah_D6_ent", 17, 6, 1024, 256, dict(clip_coef=0.2, ent_coef=0.01)),
+        ("hopper_D3_noadvnorm", 11, 3, 512, 128, dict(clip_coef=0.2, ent_coef=0.0, norm_adv=False)),
+        ("d1_novclip", 3, 1, 256, 64, dict(clip_coef=0.2, ent_coef=0.02, clip_vloss=False)),
+    ]:
+        torch.manual_seed(9)
+        Agent, _ = R.load_agent_class(script)
+        agent = Agent(R.fake_envs((obs_dim,), action_shape=(D,)))
+        with torch.no_grad():
+            agent.actor_logstd.copy_(torch.randn(1, D, generator=g) * 0.3)
+        args = R.make_args(**kw)
+        b_obs = torch.randn(B, obs_dim, generator=g)
+        with torch.no_grad():
+            mean_all = agent.actor_mean(b_obs)
+            b_actions = mean_all + torch.randn(B, D, generator=g) * torch.exp(agent.actor_logstd)
+            _, lp_all, _, v_all = agent.get_action_and_value(b_obs, b_actions)
+        b_logprobs, b_advantages, b_returns, b_values = _behaviour_batch(g, lp_all, v_all.view(-1), B)
+        mb_inds = np.random.RandomState(4).permutation(B)[:M]
+        mbox, vbox = _hooked(agent.actor_mean[-1]), _hooked(agent.critic[-1])
+        ns = R.run_loss(script, agent, args, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, mb_inds)
+        ns["loss"].backward()
+        cases[name] = dict(
+            new_mean=mbox["out"], logstd=agent.actor_logstd.detach().reshape(-1), new_value=vbox["out"].view(-1),
+            mb_inds=mb_inds.astype(np.int64), b_actions=b_actions, b_logprobs=b_logprobs, b_advantages=b_advantages,
+            b_returns=b_returns, b_values=b_values,
+            clip_coef=np.float64(args.clip_coef), ent_coef=np.float64(args.ent_coef), vf_coef=np.float64(args.vf_coef),
+            norm_adv=np.int32(args.norm_adv), clip_vloss=np.int32(args.clip_vloss),
+            loss=ns["loss"], pg_loss=ns["pg_loss"], v_loss=ns["v_loss"], entropy=ns["entropy_loss"],
+            old_approx_kl=ns["old_approx_kl"], approx_kl=ns["approx_kl"], clipfrac=np.float32(ns["clipfracs"][0]),
+            newlogprob=ns["newlogprob"], dmean=mbox["out"].grad, dlogstd=agent.actor_logstd.grad.reshape(-1),
+            dvalue=vbox["out"].grad.view(-1), script=np.bytes_(script))
+    _save("loss_normal", cases)
+
+
+# --------------------------------------------------------------- full update step (a7+a8+a9)
+def _flat(params):
+    return torch.cat([p.detach().reshape(-1) for p in params])
+
+
+class _FakeDist:
+    """Stand-in for ``torch.distributed`` inside ppo_atari_multigpu.py:360-374: a 2-rank SUM all-reduce
+    whose other rank's flat gradient was computed beforehand."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, other_flat_grad):
+        self.other = other_flat_grad
+
+    def all_reduce(self, tensor, op=None):
+        tensor.add_(self.other)
+
+
+def mint_update_step():
+    cases = {}
+    g = torch.Generator().manual_seed(31)
+    # (1) ppo.py MLP: 3 consecutive minibatch updates (loss + backward + clip_grad_norm_ + Adam)
+    script = "ppo.py"
+    torch.manual_seed(1)
+    Agent, _ = R.load_agent_class(script)
+    agent = Agent(R.fake_envs((4,), n_actions=2))
+    args = R.make_args(clip_coef=0.2)
+    opt = R.make_optimizer(agent, 2.5e-4)
+    B, M = 512, 128
+    b_obs = torch.randn(B, 4, generator=g)
+    b_actions = torch.randint(0, 2, (B,), generator=g).float()
+    with torch.no_grad():
+        _, lp_all, _, v_all = agent.get_action_and_value(b_obs, b_actions.long())
+    b_logprobs, b_advantages, b_returns, b_values = _behaviour_batch(g, lp_all, v_all.view(-1), B)
+    perm = np.random.RandomState(5).permutation(B)
+    d = dict(init_params=_flat(agent.parameters()), b_obs=b_obs, b_actions=b_actions, b_logprobs=b_logprobs,
+             b_advantages=b_advantages, b_returns=b_returns, b_values=b_values, perm=perm.astype(np.int64),
+             lr=np.float64(2.5e-4), clip_coef=np.float64(0.2), ent_coef=np.float64(0.01), vf_coef=np.float64(0.5),
+             max_grad_norm=np.float64(0.5), shapes=np.array([p.numel() for p in agent.parameters()], np.int64))
+    losses, gnorm = [], []
+    for k in range(3):
+        ns = R.run_loss(script, agent, args, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values,
+                        perm[k * M:(k + 1) * M], step=True, optimizer=opt)
+        losses.append(ns["loss"].item())
+        d[f"params_after_{k + 1}"] = _flat(agent.parameters())
+    d["losses"] = np.array(losses, np.float32)
+    cases["ppo_mlp_3steps"] = d
+
+    # (2) ppo_atari_multigpu.py NatureCNN, world_size=2: flat-grad all-reduce SUM, /world_size, clip, Adam
+    script = "ppo_atari_multigpu.py"
+    torch.manual_seed(1)
+    Agent, _ = R.load_agent_class(script)
+    agent = Agent(R.fake_envs((4, 84, 84), n_actions=4))
+    args = R.make_args(world_size=2)
+    opt = R.make_optimizer(agent, 2.5e-4)
+    B, M = 64, 32
+    ranks = []
+    for r in range(2):
+        b_obs = torch.randint(0, 256, (B, 4, 84, 84), generator=g).float()
+        b_actions = torch.randint(0, 4, (B,), generator=g).float()
+        with torch.no_grad():
+            _, lp_all, _, v_all = agent.get_action_and_value(b_obs, b_actions.long())
+        ranks.append((b_obs, b_actions) + _behaviour_batch(g, lp_all, v_all.view(-1), B))
+    mb = np.random.RandomState(6).permutation(B)[:M]
+    # rank 1's local gradient (no step)
+    ns1 = R.run_loss(script, agent, args, *ranks[1], mb)
+    agent.zero_grad()
+    ns1["loss"].backward()
+    g1 = _flat([p.grad for p in agent.parameters()]).clone()
+    agent.zero_grad()
+    init = _flat(agent.parameters()).clone()
+    # rank 0 executes :320-377 including the collective block against the fake dist
+    ns0 = R.run_loss(script, agent, args, *ranks[0], mb)
+    lines = R._read(script)
+    lo = R._find(lines, "optimizer.zero_grad()")
+    hi = R._find(lines, "optimizer.step()", lo)
+    import textwrap
+    ns0["dist"] = _FakeDist(g1)
+    ns0["optimizer"] = opt
+    exec(textwrap.dedent("\n".join(lines[lo:hi + 1])), ns0)       # ppo_atari_multigpu.py:357-377
+    final = _flat(agent.parameters())
+    sub = slice(0, None, 53)
+    cases["multigpu_cnn_world2"] = dict(
+        obs_u8_rank0=ranks[0][0].to(torch.uint8), obs_u8_rank1=ranks[1][0].to(torch.uint8),
+        **{f"{k}_rank{r}": ranks[r][i + 1] for r in range(2)
+           for i, k in enumerate(["b_actions", "b_logprobs", "b_advantages", "b_returns", "b_values"])},
+        mb_inds=mb.astype(np.int64), init_params_sub=init[sub], final_params_sub=final[sub],
+        delta_sub=(final - init)[sub], loss_rank0=ns0["loss"].detach(), loss_rank1=ns1["loss"].detach(),
+        init_seed=np.int64(1), stride=np.int64(53), lr=np.float64(2.5e-4),
+        init_checksum=np.float64(init.double().sum().item()), final_checksum=np.float64(final.double().sum().item()))
+    _save("update_step", cases)
+
+
+def main():
+    assert R.available(), "needs /root/reference (build container only)"
+    os.makedirs(OUT, exist_ok=True)
+    for script in ["ppo.py", "ppo_atari.py", "ppo_atari_envpool.py", "ppo_atari_multigpu.py", "ppo_continuous_action.py"]:
+        print(script, R.line_ranges(script))
+    mint_gae()
+    mint_categorical()
+    mint_normal()
+    mint_loss_categorical()
+    mint_loss_normal()
+    mint_update_step()
+
+
+if __name__ == "__main__":
+    main()

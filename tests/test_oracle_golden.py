@@ -1,0 +1,146 @@
+"""Pin every oracle implementation against the goldens minted from the reference's own lines.
+
+CPU only.  GAE must be bit-exact (pure mul/add/sub); the distribution and loss restatements are the
+same torch ops in the same order, so they are compared at 1-2 ulp tolerances.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import c_oracle, torch_oracle as TO
+
+T = torch.from_numpy
+
+
+@pytest.mark.parametrize("case", sorted(load_golden("gae")))
+def test_gae_torch_and_c_oracle_bit_exact(case):
+    g = load_golden("gae")[case]
+    adv, ret = TO.gae(T(g["rewards"]), T(g["dones"]), T(g["values"]), T(g["next_done"]), T(g["next_value"]),
+                      float(g["gamma"]), float(g["gae_lambda"]))
+    assert np.array_equal(adv.numpy(), g["advantages"])
+    assert np.array_equal(ret.numpy(), g["returns"])
+    adv_c, ret_c = c_oracle.gae(g["rewards"], g["dones"], g["values"], g["next_done"], g["next_value"],
+                                float(g["gamma"]), float(g["gae_lambda"]))
+    assert np.array_equal(adv_c, g["advantages"])
+    assert np.array_equal(ret_c, g["returns"])
+
+
+@pytest.mark.parametrize("case", sorted(load_golden("categorical")))
+def test_categorical_oracles(case):
+    g = load_golden("categorical")[case]
+    logits, noise = T(g["logits"]), T(g["noise_exp1"])
+    act = TO.categorical_sample_from_noise(logits, noise)
+    assert np.array_equal(act.numpy(), g["action"])
+    lp, ent = TO.categorical_logprob_entropy(logits, T(g["action"]))
+    assert np.array_equal(lp.numpy(), g["logprob"])
+    assert np.array_equal(ent.numpy(), g["entropy"])
+    act_c, lp_c, ent_c = c_oracle.categorical_sample(g["logits"], g["noise_exp1"])
+    # libm expf/logf vs torch's vectorised kernels: a few ulp; argmax may flip only on near-ties
+    mism = act_c != g["action"]
+    if mism.any():
+        p = g["probs"] / g["noise_exp1"]
+        top2 = np.sort(p[mism], axis=-1)[:, -2:]
+        assert np.all(top2[:, 1] / top2[:, 0] < 1 + 1e-5), "C oracle sample differs on a non-tie"
+    np.testing.assert_allclose(lp_c[~mism], g["logprob"][~mism], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ent_c, g["entropy"], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", sorted(load_golden("normal")))
+def test_normal_oracle(case):
+    g = load_golden("normal")[case]
+    mean, logstd = T(g["mean"]), T(g["logstd"]).reshape(1, -1)
+    act = TO.normal_sample_from_noise(mean, logstd, T(g["noise"]))
+    assert np.array_equal(act.numpy(), g["action"])
+    lp, ent = TO.normal_logprob_entropy(mean, logstd, act)
+    assert np.array_equal(lp.numpy(), g["logprob_sum"])
+    assert np.array_equal(ent.numpy(), g["entropy_sum"])
+
+
+SCALARS = ["loss", "pg_loss", "v_loss", "entropy", "old_approx_kl", "approx_kl", "clipfrac"]
+
+
+@pytest.mark.parametrize("case", sorted(load_golden("loss_categorical")))
+def test_loss_categorical_oracles(case):
+    g = load_golden("loss_categorical")[case]
+    kw = dict(clip_coef=float(g["clip_coef"]), ent_coef=float(g["ent_coef"]), vf_coef=float(g["vf_coef"]),
+              norm_adv=bool(g["norm_adv"]), clip_vloss=bool(g["clip_vloss"]))
+    r = TO.loss_categorical_seam(T(g["new_logits"]), T(g["new_value"]), g["mb_inds"], T(g["b_actions"]),
+                                 T(g["b_logprobs"]), T(g["b_advantages"]), T(g["b_returns"]), T(g["b_values"]), **kw)
+    for k in SCALARS:
+        np.testing.assert_allclose(r[k].numpy(), g[k], rtol=1e-6, atol=1e-7, err_msg=k)
+    gmax = np.abs(g["dlogits"]).max()
+    np.testing.assert_allclose(r["dlogits"].numpy(), g["dlogits"], rtol=1e-5, atol=1e-6 * gmax)
+    np.testing.assert_allclose(r["dvalue"].numpy(), g["dvalue"], rtol=1e-5, atol=1e-6 * np.abs(g["dvalue"]).max())
+    # C oracle: closed-form gradients, an independent derivation
+    sc, dl, dv = c_oracle.loss_categorical(g["new_logits"], g["new_value"], g["mb_inds"], g["b_actions"], g["b_logprobs"],
+                                           g["b_advantages"], g["b_returns"], g["b_values"], **kw)
+    for i, k in enumerate(SCALARS):
+        np.testing.assert_allclose(sc[i], g[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(dl, g["dlogits"], rtol=2e-4, atol=2e-5 * gmax)
+    np.testing.assert_allclose(dv, g["dvalue"], rtol=2e-4, atol=2e-5 * np.abs(g["dvalue"]).max())
+
+
+@pytest.mark.parametrize("case", sorted(load_golden("loss_normal")))
+def test_loss_normal_oracle(case):
+    g = load_golden("loss_normal")[case]
+    kw = dict(clip_coef=float(g["clip_coef"]), ent_coef=float(g["ent_coef"]), vf_coef=float(g["vf_coef"]),
+              norm_adv=bool(g["norm_adv"]), clip_vloss=bool(g["clip_vloss"]))
+    r = TO.loss_normal_seam(T(g["new_mean"]), T(g["logstd"]), T(g["new_value"]), g["mb_inds"], T(g["b_actions"]),
+                            T(g["b_logprobs"]), T(g["b_advantages"]), T(g["b_returns"]), T(g["b_values"]), **kw)
+    for k in SCALARS:
+        np.testing.assert_allclose(r[k].numpy(), g[k], rtol=1e-6, atol=1e-7, err_msg=k)
+    for k in ("dmean", "dlogstd", "dvalue"):
+        np.testing.assert_allclose(r[k].numpy(), g[k], rtol=1e-5, atol=1e-6 * np.abs(g[k]).max(), err_msg=k)
+
+
+def test_update_step_clip_adam_flat_oracle():
+    """a8: the flat clip+Adam restatement reproduces the reference's clip_grad_norm_ + Adam.step (ppo.py:287-290)."""
+    g = load_golden("update_step")["ppo_mlp_3steps"]
+    shapes = g["shapes"].tolist()
+    segs, off = [], 0
+    for n in shapes:
+        segs.append((off, n))
+        off += n
+    # rebuild the MLP functionally from the flat vector (ppo.py:100-126 layout: critic then actor)
+    def unflat(p):
+        out, o = [], 0
+        dims = [(64, 4), (64,), (64, 64), (64,), (1, 64), (1,), (64, 4), (64,), (64, 64), (64,), (2, 64), (2,)]
+        for d in dims:
+            n = int(np.prod(d))
+            out.append(p[o:o + n].reshape(d))
+            o += n
+        assert o == p.numel()
+        return out
+
+    def forward(p, x):
+        w = unflat(p)
+        h = torch.tanh(x @ w[0].T + w[1]); h = torch.tanh(h @ w[2].T + w[3]); v = h @ w[4].T + w[5]
+        a = torch.tanh(x @ w[6].T + w[7]); a = torch.tanh(a @ w[8].T + w[9]); logits = a @ w[10].T + w[11]
+        return logits, v.reshape(-1)
+
+    p = T(g["init_params"]).clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    M = 128
+    for k in range(3):
+        idx = T(g["perm"][k * M:(k + 1) * M])
+        pp = p.clone().requires_grad_(True)
+        logits, val = forward(pp, T(g["b_obs"])[idx])
+        lp, ent = TO.categorical_logprob_entropy(logits, T(g["b_actions"])[idx])
+        out = TO.ppo_loss(lp, ent, val, T(g["b_logprobs"])[idx], T(g["b_advantages"])[idx], T(g["b_returns"])[idx],
+                          T(g["b_values"])[idx], 0.2, 0.01, 0.5, True, True)
+        out["loss"].backward()
+        np.testing.assert_allclose(out["loss"].item(), g["losses"][k], rtol=1e-5)
+        p, m, v, _ = TO.clip_adam_flat(p, pp.grad, m, v, k + 1, float(g["lr"]), 0.5, segs)
+        np.testing.assert_allclose(p.numpy(), g[f"params_after_{k + 1}"], rtol=1e-5, atol=1e-7)
+
+
+def test_c_oracle_obs_convert_exact():
+    rs = np.random.RandomState(0)
+    src = rs.randint(0, 256, size=(9, 4, 6, 6), dtype=np.uint8)
+    src[0].reshape(-1)[:144] = np.arange(144)
+    src[1].reshape(-1)[:112] = np.arange(144, 256)
+    inds = np.array([3, 0, 8, 1, 1], np.int64)
+    out = c_oracle.obs_u8_to_f32(src, inds)
+    ref = (T(src).float()[T(inds)] / 255.0).numpy()      # the reference's b_obs[mb_inds] ; x / 255.0
+    assert np.array_equal(out, ref)
