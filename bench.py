@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/sec of the MI355X-native PPO actor-learner (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE full PPO iteration of the hot path on synthetic input: a rollout of ``num_steps`` x
+``local_num_envs`` (policy forward, Categorical sample, storage writes), bootstrap + GAE, and
+``update_epochs x num_minibatches`` minibatch updates (uint8 gather+convert, network forward, fused loss
+forward+backward, network backward, gradient all-reduce when N>1, fused clip+Adam).  Workload = BASELINE.json
+configs[2]: ppo_atari Breakout, num_envs=1024 per GPU, num_steps=128, synthetic 84x84x4 uint8 observations,
+NatureCNN with 4 actions, f32 everywhere (the reference's precision).  Observations come from a
+device-resident generator, so inputs are already in HBM when the timed region starts (no PCIe inside it).
+
+Weak scaling: every rank (one process per GPU, RCCL over xGMI) keeps 1024 envs; ``value`` is the whole-job
+env-steps/sec = N * 1024 * 128 * K / max-over-ranks(time).
+
+The JSON line also carries
+  ``roofline``      for the dominant HIP kernel of the path by bytes moved -- the uint8 gather+convert
+                    (K5: 28,224 B read + 112,896 B written per minibatch row, HBM-bound) -- timed live with
+                    HIP events on the learner's stream around each of its launches inside the timed region;
+  ``kernels``       the same accounting for the GAE and fused-loss kernels (latency-bound at this size);
+  ``cpu_baseline``  the oracle's CPU port of the reference loop (oracle/cpu_ppo_port.py), rank 0, N=1 only,
+                    on a bounded sample (64 envs x 128 steps, >=1 iteration), on the box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# MIOpen (the conv library behind torch's Conv2d -- plumbing, not the product): pick kernels from its
+# heuristics instead of benchmarking every solver on a cold cache, which costs minutes on a fresh box.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured achievable
+OBS_ROW_BYTES = 4 * 84 * 84   # 28,224
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--local-num-envs", type=int, default=1024)
+    p.add_argument("--num-steps", type=int, default=128)
+    p.add_argument("--n-actions", type=int, default=4)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-envs", type=int, default=64)
+    p.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets (pure SPS run)")
+    return p.parse_args()
+
+
+class KernelTimer:
+    """HIP-event brackets around chosen kernel launches on the learner's stream (torch.cuda.Event records on
+    the current stream, which is the stream every libmi355ppo launch is enqueued on)."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def wrap(self, name, fn):
+        def timed(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.pairs.setdefault(name, []).append((e0, e1))
+            return out
+
+        return timed
+
+    def reset(self):
+        self.pairs = {}
+
+    def mean_us(self, name):
+        ps = self.pairs.get(name, [])
+        if not ps:
+            return None, 0
+        return float(np.mean([a.elapsed_time(b) for a, b in ps])) * 1e3, len(ps)
+
+
+def main():
+    cli = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == cli.gpus or world == 1, f"--gpus {cli.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path and needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from cleanrl_amd import _lib, learner_smoke, ops
+    from cleanrl_amd.agents import AtariAgent
+    from cleanrl_amd.envs import DeviceSyntheticAtariVecEnv
+    from cleanrl_amd.learner import PPOLearner
+
+    _lib.load(build_if_missing=True)
+    N, T = cli.local_num_envs, cli.num_steps
+    args = learner_smoke.default_args(num_steps=T, num_minibatches=4, update_epochs=4, learning_rate=2.5e-4, clip_coef=0.1,
+                                      ent_coef=0.01, vf_coef=0.5)        # ppo_atari.py defaults
+    # seeding protocol of ppo_atari_multigpu.py:206-212,231
+    seed = cli.seed + rank
+    np.random.seed(seed)
+    torch.manual_seed(cli.seed)
+    env = DeviceSyntheticAtariVecEnv(N, device, seed=seed, n_actions=cli.n_actions)
+    agent = AtariAgent(env).to(device)
+    torch.manual_seed(seed)
+    learner = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, device, world_size=world,
+                         sample_seed=seed)
+    timer = KernelTimer()
+    if not cli.no_kernel_timing:
+        real_obs, real_gae, real_loss = ops.obs_u8_to_f32, ops.gae, ops.ppo_loss_categorical
+
+        def obs_hook(src, inds=None, out=None, scale_255=True):
+            if inds is not None:
+                return timer.wrap("obs_gather", real_obs)(src, inds, out, scale_255)
+            return real_obs(src, inds, out, scale_255)
+
+        ops.obs_u8_to_f32 = obs_hook
+        ops.gae = timer.wrap("gae", real_gae)
+        ops.ppo_loss_categorical = timer.wrap("loss", real_loss)
+    env.obs_into(learner.obs[0])
+    total_iters = cli.warmup + cli.steps
+
+    def one_step(i):
+        lr = (1.0 - i / max(total_iters, 1)) * args.learning_rate           # annealed as in :251-254
+        learner_smoke.rollout(learner, env)
+        m = learner.update(lr)
+        learner.start_iteration()
+        return m
+
+    for i in range(cli.warmup):
+        one_step(i)
+    timer.reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(cli.steps):
+        metrics = one_step(cli.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    learner.flat.check_views()
+    assert np.isfinite(metrics["loss"]), metrics
+
+    if rank == 0:
+        env_steps = world * N * T * cli.steps
+        M = learner.minibatch_size
+        out = {
+            "metric": "env-steps/sec (SPS) PPO Breakout num_envs=1024 @1/2/4/8 MI355X; GAE HBM GB/s",
+            "value": env_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": cli.steps,
+            "warmup": cli.warmup,
+            "ms_per_step": elapsed / cli.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[2]: ppo_atari Breakout num_envs=1024/GPU num_steps=128, synthetic 84x84x4 uint8 "
+                            "observations resident in HBM, NatureCNN A=4, 4 epochs x 4 minibatches",
+                "local_num_envs": N, "num_steps": T, "global_num_envs": world * N, "minibatch_rows": M,
+                "parallelism": f"dp{world} (one learner per GPU, RCCL all-reduce of the flat f32 gradient)",
+                "env": "device-resident synthetic generator (no PCIe in the timed region)",
+            },
+            "final_loss": metrics["loss"],
+        }
+        if not cli.no_kernel_timing:
+            us, n = timer.mean_us("obs_gather")
+            alg = OBS_ROW_BYTES * 5 * M
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("obs_u8_to_f32_kernel", {}).get("hbm_bytes_per_launch")
+            out["roofline"] = {
+                "kernel": "obs_u8_to_f32_kernel<true> (K5 uint8 gather + /255 convert, minibatch launch)",
+                "bound": "hbm", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": alg / us / 1e3 / HBM_PEAK_GBPS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg, "avg_launch_us": us, "launches_timed": n,
+                "frac_of_measured_achievable_6290": alg / us / 1e3 / 6290.0,
+            }
+            gus, gn = timer.mean_us("gae")
+            lus, ln = timer.mean_us("loss")
+            gae_bytes = 20 * T * N + 8 * N
+            loss_bytes = (8 * cli.n_actions + 28 + 8) * M
+            out["kernels"] = {
+                "gae": {"algorithmic_bytes": gae_bytes, "avg_us_event_bracket": gus, "GBps": gae_bytes / gus / 1e3,
+                        "launches_timed": gn, "note": "128x1024 is launch/latency-bound: see profiles/ for the kernel time"},
+                "loss_fwd_bwd": {"algorithmic_bytes": loss_bytes, "avg_us_event_bracket_3_launches": lus,
+                                 "GBps": loss_bytes / lus / 1e3, "launches_timed": ln},
+            }
+        if world == 1 and not cli.no_cpu_baseline:
+            from oracle import cpu_ppo_port
+
+            cb = cpu_ppo_port.run(num_envs=cli.cpu_baseline_envs, num_steps=T, iterations=2, warmup_iterations=0,
+                                  seed=cli.seed, n_actions=cli.n_actions, max_seconds=12.0)
+            out["cpu_baseline"] = {
+                "value": cb["sps"], "unit": "env-steps/s", "cores": cb["cores"], "kind": "port",
+                "sample": f"{cb['iterations']} full PPO iteration(s) of the reference loop (oracle/cpu_ppo_port.py, stock "
+                          f"torch CPU ops, f32) at num_envs={cb['num_envs']} x num_steps={cb['num_steps']} = "
+                          f"{cb['env_steps']} env-steps in {cb['seconds']:.1f} s; host cpu_count={os.cpu_count()}",
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

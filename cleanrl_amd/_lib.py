@@ -22,6 +22,8 @@ SIGNATURES = {
     "mi355ppo_gae_f32_variant": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_int, _P]),
     "mi355ppo_categorical_sample_f32": (c_int, [_P, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_int, _P]),
     "mi355ppo_categorical_logprob_entropy_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "mi355ppo_categorical_logprob_entropy_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "mi355ppo_normal_logprob_entropy_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "mi355ppo_normal_sample_f32": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, _P, c_int, c_int, _P]),
     "mi355ppo_normal_logprob_entropy_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "mi355ppo_loss_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -1,0 +1,184 @@
+"""The reference's three ``Agent`` networks with identical structure, parameter names, initialisation
+order (hence identical weights for a given torch seed) and method surface:
+
+* ``AtariAgent``      -- NatureCNN, ppo_atari_multigpu.py:133-159 (== ppo_atari.py, ppo_atari_envpool.py)
+* ``MlpAgent``        -- 64-64 tanh actor/critic, ppo.py:100-126
+* ``ContinuousAgent`` -- 64-64 tanh + state-independent logstd, ppo_continuous_action.py:112-141
+
+``get_value`` / ``get_action_and_value`` keep the reference signatures.  On a CUDA (HIP) device the
+distribution math (sample / log_prob / entropy) runs in the libmi355ppo kernels; on an explicit CPU
+device (``--no-cuda``, config A plumbing, gloo tests) it is ``torch.distributions`` exactly as in the
+reference.  The learner's update does not go through these methods: it feeds the network outputs to the
+fused loss kernel (``heads``/``dist_params`` below are the seam).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions.categorical import Categorical
+from torch.distributions.normal import Normal
+
+from . import ops
+
+
+def layer_init(layer, std=np.sqrt(2), bias_const=0.0):
+    torch.nn.init.orthogonal_(layer.weight, std)
+    torch.nn.init.constant_(layer.bias, bias_const)
+    return layer
+
+
+class _SampleCounter:
+    """(seed, offset) for the Philox streams of the sampling kernels: one fresh offset per call."""
+
+    def __init__(self):
+        self.seed, self.offset = 0, 0
+
+    def next(self):
+        self.offset += 1
+        return self.seed, self.offset
+
+
+class _DiscreteMixin:
+    discrete = True
+
+    def _dist(self, logits, action):
+        if logits.is_cuda:
+            if action is None:
+                seed, off = self.rng.next()
+                a64, _, lp, ent = ops.categorical_sample(logits.contiguous(), seed=seed, offset=off)
+                return a64, lp, ent
+            if torch.is_grad_enabled() and logits.requires_grad:
+                lp, ent = ops.CategoricalLogProbEntropy.apply(logits, action)
+            else:
+                lp, ent = ops.categorical_logprob_entropy(logits.contiguous(), action.contiguous())
+            return action, lp, ent
+        probs = Categorical(logits=logits)
+        if action is None:
+            action = probs.sample()
+        return action, probs.log_prob(action), probs.entropy()
+
+
+class AtariAgent(_DiscreteMixin, nn.Module):
+    obs_is_image = True
+
+    def __init__(self, envs):
+        super().__init__()
+        self.network = nn.Sequential(
+            layer_init(nn.Conv2d(4, 32, 8, stride=4)),
+            nn.ReLU(),
+            layer_init(nn.Conv2d(32, 64, 4, stride=2)),
+            nn.ReLU(),
+            layer_init(nn.Conv2d(64, 64, 3, stride=1)),
+            nn.ReLU(),
+            nn.Flatten(),
+            layer_init(nn.Linear(64 * 7 * 7, 512)),
+            nn.ReLU(),
+        )
+        self.actor = layer_init(nn.Linear(512, envs.single_action_space.n), std=0.01)
+        self.critic = layer_init(nn.Linear(512, 1), std=1)
+        self.n_actions = envs.single_action_space.n
+        self.rng = _SampleCounter()
+
+    def _normalise(self, x):
+        if x.dtype == torch.uint8:
+            return ops.obs_u8_to_f32(x.contiguous()) if x.is_cuda else x.float() / 255.0
+        return x / 255.0
+
+    def heads(self, xn):
+        """xn: already-normalised f32 observations -> (logits (B,A), value (B,1))."""
+        hidden = self.network(xn)
+        return self.actor(hidden), self.critic(hidden)
+
+    def get_value(self, x):
+        return self.critic(self.network(self._normalise(x)))
+
+    def get_action_and_value(self, x, action=None):
+        logits, value = self.heads(self._normalise(x))
+        action, lp, ent = self._dist(logits, action)
+        return action, lp, ent, value
+
+
+class MlpAgent(_DiscreteMixin, nn.Module):
+    obs_is_image = False
+
+    def __init__(self, envs):
+        super().__init__()
+        obs_dim = int(np.array(envs.single_observation_space.shape).prod())
+        self.critic = nn.Sequential(
+            layer_init(nn.Linear(obs_dim, 64)),
+            nn.Tanh(),
+            layer_init(nn.Linear(64, 64)),
+            nn.Tanh(),
+            layer_init(nn.Linear(64, 1), std=1.0),
+        )
+        self.actor = nn.Sequential(
+            layer_init(nn.Linear(obs_dim, 64)),
+            nn.Tanh(),
+            layer_init(nn.Linear(64, 64)),
+            nn.Tanh(),
+            layer_init(nn.Linear(64, envs.single_action_space.n), std=0.01),
+        )
+        self.n_actions = envs.single_action_space.n
+        self.rng = _SampleCounter()
+
+    def heads(self, x):
+        return self.actor(x), self.critic(x)
+
+    def get_value(self, x):
+        return self.critic(x)
+
+    def get_action_and_value(self, x, action=None):
+        logits, value = self.heads(x)
+        action, lp, ent = self._dist(logits, action)
+        return action, lp, ent, value
+
+
+class ContinuousAgent(nn.Module):
+    obs_is_image = False
+    discrete = False
+
+    def __init__(self, envs):
+        super().__init__()
+        obs_dim = int(np.array(envs.single_observation_space.shape).prod())
+        act_dim = int(np.prod(envs.single_action_space.shape))
+        self.critic = nn.Sequential(
+            layer_init(nn.Linear(obs_dim, 64)),
+            nn.Tanh(),
+            layer_init(nn.Linear(64, 64)),
+            nn.Tanh(),
+            layer_init(nn.Linear(64, 1), std=1.0),
+        )
+        self.actor_mean = nn.Sequential(
+            layer_init(nn.Linear(obs_dim, 64)),
+            nn.Tanh(),
+            layer_init(nn.Linear(64, 64)),
+            nn.Tanh(),
+            layer_init(nn.Linear(64, act_dim), std=0.01),
+        )
+        self.actor_logstd = nn.Parameter(torch.zeros(1, act_dim))
+        self.act_dim = act_dim
+        self.rng = _SampleCounter()
+
+    def heads(self, x):
+        return self.actor_mean(x), self.critic(x)
+
+    def get_value(self, x):
+        return self.critic(x)
+
+    def get_action_and_value(self, x, action=None):
+        mean, value = self.heads(x)
+        if mean.is_cuda:
+            if action is None:
+                seed, off = self.rng.next()
+                action, lp, ent = ops.normal_sample(mean.contiguous(), self.actor_logstd, seed=seed, offset=off)
+            elif torch.is_grad_enabled() and (mean.requires_grad or self.actor_logstd.requires_grad):
+                lp, ent = ops.NormalLogProbEntropy.apply(mean, self.actor_logstd, action)
+            else:
+                lp, ent = ops.normal_logprob_entropy(mean.contiguous(), self.actor_logstd, action.contiguous())
+            return action, lp, ent, value
+        action_logstd = self.actor_logstd.expand_as(mean)
+        probs = Normal(mean, torch.exp(action_logstd))
+        if action is None:
+            action = probs.sample()
+        return action, probs.log_prob(action).sum(1), probs.entropy().sum(1), value

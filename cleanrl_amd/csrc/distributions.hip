@@ -146,6 +146,52 @@ __global__ __launch_bounds__(256) void normal_kernel(const float* __restrict__ m
     if (entropy_sum) entropy_sum[row] = ent;
 }
 
+
+// ---- backward of (log_prob, entropy) w.r.t. the distribution parameters --------------------------
+// For user code that differentiates Agent.get_action_and_value(x, action) itself (the learner's update
+// uses the fused loss kernel instead).  dlogits_j = g_lp*(1[j==a] - p_j) - g_ent * p_j * (lp_j + H).
+template <int AMAX>
+__global__ __launch_bounds__(256) void categorical_bwd_kernel(const float* __restrict__ logits,
+                                                              const int64_t* __restrict__ action_i64,
+                                                              const float* __restrict__ action_f32,
+                                                              const float* __restrict__ g_lp,
+                                                              const float* __restrict__ g_ent,
+                                                              float* __restrict__ dlogits, int B, int A) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= B) return;
+    float x[AMAX];
+    load_row<AMAX>(x, logits + (int64_t)row * A, A);
+    CatRow<AMAX> c;
+    categorical_row<AMAX>(x, A, c);
+    const int a = action_i64 ? (int)action_i64[row] : (int)action_f32[row];
+    const float gl = g_lp ? g_lp[row] : 0.0f, ge = g_ent ? g_ent[row] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < AMAX; ++j) {
+        if (j < A) {
+            const float onehot = (j == a) ? 1.0f : 0.0f;
+            dlogits[(int64_t)row * A + j] = gl * (onehot - c.p[j]) - ge * (c.p[j] * (fmaxf(c.lp[j], -FLT_MAX) + c.H));
+        }
+    }
+}
+
+// dmean = g_lp*(a-mu)/var ; per-row dlogstd contribution = g_lp*((a-mu)^2/var - 1) + g_ent (summed by the caller)
+__global__ __launch_bounds__(256) void normal_bwd_kernel(const float* __restrict__ mean, const float* __restrict__ logstd,
+                                                         const float* __restrict__ action,
+                                                         const float* __restrict__ g_lp, const float* __restrict__ g_ent,
+                                                         float* __restrict__ dmean, float* __restrict__ dlogstd_rows,
+                                                         int B, int D) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= B) return;
+    const float gl = g_lp ? g_lp[row] : 0.0f, ge = g_ent ? g_ent[row] : 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float sd = expf(logstd[d]);
+        const float var = sd * sd;
+        const float diff = action[(int64_t)row * D + d] - mean[(int64_t)row * D + d];
+        dmean[(int64_t)row * D + d] = gl * (diff / var);
+        dlogstd_rows[(int64_t)row * D + d] = gl * ((diff * diff) / var - 1.0f) + ge;
+    }
+}
+
 static inline int grid_for(int B, int block) { return (B + block - 1) / block; }
 static inline int block_for(int B) { return B >= 65536 ? 256 : 64; }   // small B: spread rows over more CUs
 
@@ -227,4 +273,41 @@ extern "C" MI355PPO_API int mi355ppo_normal_logprob_entropy_f32(const float* mea
     hipLaunchKernelGGL((normal_kernel<false>), dim3(grid_for(B, block)), dim3(block), 0, as_stream(stream), mean, logstd,
                        (const float*)nullptr, 0ull, 0ull, (float*)nullptr, action, logprob_sum, entropy_sum, B, D);
     return check_launch("normal_kernel<eval>");
+}
+
+extern "C" MI355PPO_API int mi355ppo_categorical_logprob_entropy_bwd_f32(const float* logits, const int64_t* action_i64,
+                                                                         const float* action_f32, const float* g_logprob,
+                                                                         const float* g_entropy, float* dlogits, int B,
+                                                                         int A, void* stream) {
+    const char* fn = "mi355ppo_categorical_logprob_entropy_bwd_f32";
+    MI355_REQUIRE(logits && dlogits, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE((action_i64 != nullptr) != (action_f32 != nullptr), MI355PPO_EINVAL,
+                  "%s: exactly one of action_i64/action_f32 must be given", fn);
+    MI355_REQUIRE(B > 0 && A > 0 && A <= 64, MI355PPO_EINVAL, "%s: B=%d must be >0 and A=%d in 1..64", fn, B, A);
+    MI355_REQUIRE(aligned(logits, 4) && aligned(dlogits, 4) && aligned(action_i64, 8) && aligned(action_f32, 4) &&
+                      aligned(g_logprob, 4) && aligned(g_entropy, 4),
+                  MI355PPO_EALIGN, "%s: misaligned pointer", fn);
+    const int block = block_for(B);
+#define LAUNCH(AMAX, ...)                                                                                    \
+    hipLaunchKernelGGL((categorical_bwd_kernel<AMAX>), dim3(grid_for(B, block)), dim3(block), 0,             \
+                       as_stream(stream), logits, action_i64, action_f32, g_logprob, g_entropy, dlogits, B, A)
+    MI355_DISPATCH_AMAX(A, LAUNCH, 0);
+#undef LAUNCH
+    return check_launch("categorical_bwd_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_normal_logprob_entropy_bwd_f32(const float* mean, const float* logstd,
+                                                                    const float* action, const float* g_logprob,
+                                                                    const float* g_entropy, float* dmean,
+                                                                    float* dlogstd_rows, int B, int D, void* stream) {
+    const char* fn = "mi355ppo_normal_logprob_entropy_bwd_f32";
+    MI355_REQUIRE(mean && logstd && action && dmean && dlogstd_rows, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(B > 0 && D > 0, MI355PPO_EINVAL, "%s: B=%d D=%d must be positive", fn, B, D);
+    MI355_REQUIRE(aligned(mean, 4) && aligned(logstd, 4) && aligned(action, 4) && aligned(dmean, 4) &&
+                      aligned(dlogstd_rows, 4) && aligned(g_logprob, 4) && aligned(g_entropy, 4),
+                  MI355PPO_EALIGN, "%s: misaligned pointer", fn);
+    const int block = block_for(B);
+    hipLaunchKernelGGL(normal_bwd_kernel, dim3(grid_for(B, block)), dim3(block), 0, as_stream(stream), mean, logstd,
+                       action, g_logprob, g_entropy, dmean, dlogstd_rows, B, D);
+    return check_launch("normal_bwd_kernel");
 }

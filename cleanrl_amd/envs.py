@@ -1,0 +1,340 @@
+"""Host-side vector environments.
+
+Environment stepping stays on the host, as in the reference (``gym.vector.SyncVectorEnv``,
+ppo_atari_multigpu.py:225-227; ``envpool.make``, ppo_atari_envpool.py:185-196).  This image has no
+gymnasium / gym / envpool / ale_py / mujoco (and no network), so besides thin adapters for the real
+packages (used when importable) this module provides self-contained vector envs with the same
+``reset()/step()`` contracts:
+
+* ``CartPoleVecEnv``            -- CartPole-v1 dynamics in vectorised numpy (a real control task: PPO must
+                                   learn it, which is how tests check end-to-end learning without gym).
+* ``SyntheticAtariVecEnv``      -- (N,4,84,84) uint8 frame-stacked observations, sign-clipped rewards,
+                                   Bernoulli episode ends: the byte streams of a wrapped Atari env
+                                   (cleanrl_utils/atari_wrappers.py) without an emulator.
+* ``SyntheticContinuousVecEnv`` -- (N,17) observations / (N,6) actions (HalfCheetah-v4 shapes).
+* ``DeviceSyntheticAtariVecEnv``-- the Atari byte streams generated directly in HBM (bench.py's
+                                   "inputs already resident in HBM" mode; no PCIe in the timed region).
+
+All follow gymnasium 0.29's vector API (5-tuple ``step``, autoreset, ``final_info``); ``api="gym"``
+switches to the old 4-tuple + ``info["lives"]/["r"]/["l"]`` layout that ``ppo_atari_envpool.py`` consumes.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+
+
+class Discrete:
+    def __init__(self, n: int):
+        self.n = int(n)
+        self.shape = ()
+        self.dtype = np.int64
+
+    def __repr__(self):
+        return f"Discrete({self.n})"
+
+
+class Box:
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+    def __repr__(self):
+        return f"Box({self.low}, {self.high}, {self.shape}, {np.dtype(self.dtype).name})"
+
+
+class _EpisodeStats:
+    """What ``gym.wrappers.RecordEpisodeStatistics`` (ppo.py:80) / the local wrapper of
+    ppo_atari_envpool.py:83-114 record: running return/length per env, reported when an episode ends."""
+
+    def __init__(self, n):
+        self.returns = np.zeros(n, np.float32)
+        self.lengths = np.zeros(n, np.int32)
+
+    def update(self, reward, done):
+        self.returns += reward
+        self.lengths += 1
+        r, l = self.returns.copy(), self.lengths.copy()
+        self.returns *= 1 - done
+        self.lengths *= 1 - done
+        return r, l
+
+
+def _final_info(done, r, l):
+    if not done.any():
+        return {}
+    fi = np.empty(len(done), dtype=object)
+    for i in np.flatnonzero(done):
+        fi[i] = {"episode": {"r": np.array([r[i]], np.float32), "l": np.array([l[i]], np.int32)}}
+    return {"final_info": fi, "_final_info": done.copy()}
+
+
+class CartPoleVecEnv:
+    """CartPole-v1 (Barto, Sutton & Anderson 1983 cart-pole; constants and termination of gymnasium's
+    ``CartPole-v1``: 12 degree / 2.4 m limits, 500-step truncation, reward 1 per step), vectorised."""
+
+    gravity, masscart, masspole, length, force_mag, tau = 9.8, 1.0, 0.1, 0.5, 10.0, 0.02
+    theta_threshold = 12 * 2 * math.pi / 360
+    x_threshold = 2.4
+    max_episode_steps = 500
+
+    def __init__(self, num_envs: int, seed: int = 0):
+        self.num_envs = num_envs
+        self.single_observation_space = Box(-np.inf, np.inf, (4,))
+        self.single_action_space = Discrete(2)
+        self.rng = np.random.RandomState(seed)
+        self.state = np.zeros((num_envs, 4), np.float64)
+        self.steps = np.zeros(num_envs, np.int32)
+        self.stats = _EpisodeStats(num_envs)
+
+    def _reset_rows(self, rows):
+        self.state[rows] = self.rng.uniform(-0.05, 0.05, size=(len(rows), 4))
+        self.steps[rows] = 0
+
+    def reset(self, seed: Optional[int] = None):
+        if seed is not None:
+            self.rng = np.random.RandomState(seed)
+        self._reset_rows(np.arange(self.num_envs))
+        self.stats = _EpisodeStats(self.num_envs)
+        return self.state.astype(np.float32), {}
+
+    def step(self, action):
+        action = np.asarray(action).reshape(self.num_envs)
+        x, x_dot, th, th_dot = self.state.T
+        force = np.where(action == 1, self.force_mag, -self.force_mag)
+        total_mass = self.masspole + self.masscart
+        pml = self.masspole * self.length
+        cos, sin = np.cos(th), np.sin(th)
+        temp = (force + pml * th_dot**2 * sin) / total_mass
+        thacc = (self.gravity * sin - cos * temp) / (self.length * (4.0 / 3.0 - self.masspole * cos**2 / total_mass))
+        xacc = temp - pml * thacc * cos / total_mass
+        x = x + self.tau * x_dot
+        x_dot = x_dot + self.tau * xacc
+        th = th + self.tau * th_dot
+        th_dot = th_dot + self.tau * thacc
+        self.state = np.stack([x, x_dot, th, th_dot], 1)
+        self.steps += 1
+        terminated = (np.abs(x) > self.x_threshold) | (np.abs(th) > self.theta_threshold)
+        truncated = (self.steps >= self.max_episode_steps) & ~terminated
+        done = terminated | truncated
+        reward = np.ones(self.num_envs, np.float64)
+        r, l = self.stats.update(reward.astype(np.float32), done)
+        infos = _final_info(done, r, l)
+        if done.any():
+            self._reset_rows(np.flatnonzero(done))      # autoreset: the returned obs is the new episode's first
+        return self.state.astype(np.float32), reward, terminated, truncated, infos
+
+    def close(self):
+        pass
+
+
+class SyntheticAtariVecEnv:
+    """Byte-stream stand-in for a wrapped Atari vector env (NoopReset/MaxAndSkip/EpisodicLife/ClipReward/
+    Resize84/GrayScale/FrameStack4, ppo_atari_multigpu.py:105-124): deterministic per seed.
+
+    Observation n at time t is planes[c_n+t .. c_n+t+3] of a fixed random plane pool (so consecutive
+    observations share 3 of 4 channels, like FrameStack); reward in {-1,0,+1} with P=(.05,.9,.05);
+    episode ends Bernoulli(1/200) (then the cursor jumps).  Actions are accepted and ignored.
+    """
+
+    def __init__(self, num_envs: int, seed: int = 0, n_actions: int = 4, pool_planes: int = 2048, api: str = "gymnasium",
+                 done_p: float = 1.0 / 200.0):
+        self.num_envs, self.api, self.done_p = num_envs, api, done_p
+        self.single_observation_space = Box(0, 255, (4, 84, 84), np.uint8)
+        self.single_action_space = Discrete(n_actions)
+        self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
+        self.rng = np.random.RandomState(seed)
+        self.planes = np.random.RandomState(seed + 12345).randint(0, 256, size=(pool_planes, 84, 84), dtype=np.uint8)
+        self.cursor = np.zeros(num_envs, np.int64)
+        self.stats = _EpisodeStats(num_envs)
+        self._win = np.arange(4)[None, :]
+
+    def _obs(self, out=None):
+        idx = (self.cursor[:, None] + self._win) % len(self.planes)
+        if out is not None:
+            np.take(self.planes, idx, axis=0, out=out)
+            return out
+        return self.planes[idx]
+
+    def reset(self, seed: Optional[int] = None, out=None):
+        if seed is not None:
+            self.rng = np.random.RandomState(seed)
+        self.cursor = self.rng.randint(0, len(self.planes), size=self.num_envs).astype(np.int64)
+        self.stats = _EpisodeStats(self.num_envs)
+        obs = self._obs(out)
+        return obs if self.api == "gym" else (obs, {})
+
+    def step(self, action, out=None):
+        n = self.num_envs
+        reward = self.rng.choice(np.array([-1.0, 0.0, 1.0]), size=n, p=[0.05, 0.9, 0.05])
+        done = self.rng.random_sample(n) < self.done_p
+        self.cursor += 1
+        jump = self.rng.randint(0, len(self.planes), size=n)
+        self.cursor = np.where(done, jump, self.cursor)
+        r, l = self.stats.update(reward.astype(np.float32), done)
+        obs = self._obs(out)
+        if self.api == "gym":       # envpool gym-style 4-tuple (ppo_atari_envpool.py:237-247)
+            info = {"lives": np.where(done, 0, 3).astype(np.int32), "r": r, "l": l, "reward": reward,
+                    "terminated": done.astype(np.int32)}
+            return obs, reward, done, info
+        return obs, reward, done, np.zeros(n, bool), _final_info(done, r, l)
+
+    def close(self):
+        pass
+
+
+class SyntheticContinuousVecEnv:
+    """HalfCheetah-v4-shaped task (obs 17, act 6): a stable random linear system driven by the action,
+    reward = forward velocity proxy - 0.1*|a|^2, 1000-step truncation.  Deterministic per seed."""
+
+    def __init__(self, num_envs: int, seed: int = 0, obs_dim: int = 17, act_dim: int = 6):
+        self.num_envs, self.obs_dim, self.act_dim = num_envs, obs_dim, act_dim
+        self.single_observation_space = Box(-np.inf, np.inf, (obs_dim,))
+        self.single_action_space = Box(-1.0, 1.0, (act_dim,))
+        rs = np.random.RandomState(seed + 777)
+        a = rs.standard_normal((obs_dim, obs_dim)) / math.sqrt(obs_dim)
+        self.A = 0.9 * a / max(1.0, np.abs(np.linalg.eigvals(a)).max())
+        self.B = rs.standard_normal((act_dim, obs_dim)) * 0.3
+        self.w = rs.standard_normal(obs_dim) / math.sqrt(obs_dim)
+        self.rng = np.random.RandomState(seed)
+        self.state = np.zeros((num_envs, obs_dim))
+        self.steps = np.zeros(num_envs, np.int32)
+        self.stats = _EpisodeStats(num_envs)
+
+    def reset(self, seed: Optional[int] = None):
+        if seed is not None:
+            self.rng = np.random.RandomState(seed)
+        self.state = self.rng.standard_normal((self.num_envs, self.obs_dim)) * 0.1
+        self.steps[:] = 0
+        self.stats = _EpisodeStats(self.num_envs)
+        return self.state.astype(np.float32), {}
+
+    def step(self, action):
+        a = np.clip(np.asarray(action, np.float64).reshape(self.num_envs, self.act_dim), -1, 1)   # ClipAction (:96)
+        self.state = self.state @ self.A.T + a @ self.B + 0.01 * self.rng.standard_normal(self.state.shape)
+        reward = self.state @ self.w - 0.1 * (a**2).sum(1)
+        self.steps += 1
+        truncated = self.steps >= 1000
+        terminated = np.zeros(self.num_envs, bool)
+        r, l = self.stats.update(reward.astype(np.float32), truncated)
+        infos = _final_info(truncated, r, l)
+        if truncated.any():
+            rows = np.flatnonzero(truncated)
+            self.state[rows] = self.rng.standard_normal((len(rows), self.obs_dim)) * 0.1
+            self.steps[rows] = 0
+        return self.state.astype(np.float32), reward, terminated, truncated, infos
+
+    def close(self):
+        pass
+
+
+class DeviceSyntheticAtariVecEnv:
+    """The ``SyntheticAtariVecEnv`` byte streams produced directly in HBM with torch ops on the learner's
+    stream: ``step_into(obs_u8_row, reward_row, done_row)`` writes the next (N,4,84,84) uint8 observation,
+    rewards and dones straight into rollout-storage rows.  Used by ``bench.py`` so that the timed region
+    starts with inputs resident in HBM (no PCIe), and by GPU smoke tests."""
+
+    def __init__(self, num_envs: int, device, seed: int = 0, n_actions: int = 4, pool_planes: int = 4096,
+                 done_p: float = 1.0 / 200.0):
+        import torch
+
+        self.torch = torch
+        self.num_envs, self.device, self.done_p = num_envs, device, done_p
+        self.single_observation_space = Box(0, 255, (4, 84, 84), np.uint8)
+        self.single_action_space = Discrete(n_actions)
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+        self.planes = torch.randint(0, 256, (pool_planes, 84, 84), dtype=torch.uint8, device=device, generator=self.gen)
+        self.cursor = torch.randint(0, pool_planes, (num_envs,), device=device, generator=self.gen)
+        self._win = torch.arange(4, device=device)[None, :]
+        self.pool = pool_planes
+
+    def obs_into(self, out):
+        idx = ((self.cursor[:, None] + self._win) % self.pool).reshape(-1)
+        self.torch.index_select(self.planes, 0, idx, out=out.view(self.num_envs * 4, 84, 84))
+        return out
+
+    def step_into(self, obs_out, reward_out, done_out):
+        t = self.torch
+        u = t.rand(self.num_envs, device=self.device, generator=self.gen)
+        reward_out.copy_((u > 0.95).float() - (u < 0.05).float())
+        done = t.rand(self.num_envs, device=self.device, generator=self.gen) < self.done_p
+        done_out.copy_(done.float())
+        jump = t.randint(0, self.pool, (self.num_envs,), device=self.device, generator=self.gen)
+        self.cursor = t.where(done, jump, self.cursor + 1)
+        return self.obs_into(obs_out)
+
+    def close(self):
+        pass
+
+
+def have_gymnasium() -> bool:
+    try:
+        import gymnasium  # noqa: F401
+
+        return True
+    except Exception:
+        return False
+
+
+def have_envpool() -> bool:
+    try:
+        import envpool  # noqa: F401
+
+        return True
+    except Exception:
+        return False
+
+
+class _RunningMeanStd:
+    """Per-env running mean/variance with the parallel-variance update (Chan et al.), the statistic
+    behind gymnasium's NormalizeObservation / NormalizeReward (count starts at 1e-4)."""
+
+    def __init__(self, shape):
+        self.mean = np.zeros(shape, np.float64)
+        self.var = np.ones(shape, np.float64)
+        self.count = 1e-4
+
+    def update(self, x):
+        """``x`` is one new sample per env (the reference wraps each sub-env separately, so every env
+        has its own statistics; batch size is 1 -> batch variance 0)."""
+        delta = x - self.mean
+        tot = self.count + 1.0
+        self.mean = self.mean + delta / tot
+        self.var = (self.var * self.count + delta**2 * self.count / tot) / tot
+        self.count = tot
+
+
+class NormalizeVecEnv:
+    """ClipAction + NormalizeObservation + clip(-10,10) + NormalizeReward(gamma) + clip(-10,10) around a
+    vector env: the per-env wrapper stack of ppo_continuous_action.py:94-100, vectorised."""
+
+    def __init__(self, env, gamma: float):
+        self.env, self.gamma = env, gamma
+        self.num_envs = env.num_envs
+        self.single_observation_space, self.single_action_space = env.single_observation_space, env.single_action_space
+        n = self.num_envs
+        self.obs_rms = _RunningMeanStd((n,) + tuple(env.single_observation_space.shape))
+        self.ret_rms = _RunningMeanStd((n,))
+        self.ret = np.zeros(n, np.float64)
+
+    def _norm_obs(self, obs):
+        self.obs_rms.update(obs.astype(np.float64))
+        o = (obs - self.obs_rms.mean) / np.sqrt(self.obs_rms.var + 1e-8)
+        return np.clip(o, -10, 10).astype(np.float32)
+
+    def reset(self, seed=None):
+        obs, info = self.env.reset(seed=seed)
+        self.ret[:] = 0
+        return self._norm_obs(obs), info
+
+    def step(self, action):
+        lo, hi = self.single_action_space.low, self.single_action_space.high
+        obs, reward, term, trunc, info = self.env.step(np.clip(action, lo, hi))
+        self.ret = self.ret * self.gamma * (1 - term.astype(np.float64)) + reward
+        self.ret_rms.update(self.ret)
+        reward = np.clip(reward / np.sqrt(self.ret_rms.var + 1e-8), -10, 10)
+        return self._norm_obs(obs), reward, term, trunc, info
+
+    def close(self):
+        self.env.close()

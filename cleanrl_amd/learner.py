@@ -1,0 +1,301 @@
+"""The PPO actor-learner: rollout storage -> GAE -> minibatch update.
+
+One ``PPOLearner`` is one rank.  The drop-in scripts (``ppo.py`` ...) own the CLI, seeding, env
+construction and logging -- the reference's script skeleton -- and call into this class at the
+positions of the reference's inline blocks:
+
+====================================  ==========================================================
+reference (ppo_atari_multigpu.py)      here
+====================================  ==========================================================
+:235-240  storage tensors              ``__init__`` (observations kept as uint8 for image envs)
+:258-259  obs[step]/dones[step] store  ``observe``
+:262-266  action logic + stores        ``act``           (K5 convert, network, K2 sample kernel)
+:271      rewards[step] store          ``store_reward``
+:288-301  bootstrap + GAE              ``finish_rollout`` (K1 kernel)
+:304-309  flatten                      views, no copy
+:312-380  epochs x minibatches         ``update``         (K5 gather, network fwd, K3 fused loss
+                                                            fwd+bwd, autograd through the network,
+                                                            RCCL all-reduce, fused clip+Adam)
+:382-384  explained variance           ``update`` (host numpy, as the reference)
+====================================  ==========================================================
+
+Device selection is explicit: a CUDA device runs the HIP kernels (and raises if the library is
+missing); a CPU device (``--no-cuda``) runs ``host_ops`` with the reference's torch semantics.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.optim as optim
+
+from . import host_ops
+
+
+class PPOLearner:
+    def __init__(self, agent: nn.Module, args, obs_space, act_space, num_envs: int, device: torch.device,
+                 world_size: int = 1, sample_seed: int = 0):
+        self.agent, self.args, self.device = agent, args, device
+        self.T, self.N = int(args.num_steps), int(num_envs)
+        self.world_size = world_size
+        self.hip = device.type == "cuda"
+        self.discrete = getattr(agent, "discrete", True)
+        self.image = bool(getattr(agent, "obs_is_image", False))
+        self.obs_shape = tuple(obs_space.shape)
+        self.act_shape = tuple(act_space.shape)
+        T, N = self.T, self.N
+        if self.hip:
+            from . import _lib, ops            # the HIP library is mandatory on a GPU: fail here, loudly
+            from .flat import FlatParams
+
+            _lib.load()
+            self.ops = ops
+            self.flat = FlatParams(agent)
+            self.optimizer = None
+            agent.rng.seed = int(sample_seed)
+        else:
+            self.ops = None
+            self.flat = None
+            self.optimizer = optim.Adam(agent.parameters(), lr=args.learning_rate, eps=1e-5)   # ppo.py:168
+        # ALGO Logic: Storage setup (ppo.py:171-176).  Image observations are stored as uint8 on the GPU:
+        # frames are integers 0..255, so this is exact and 4x smaller than the reference's f32 tensor.
+        obs_dtype = torch.uint8 if (self.image and self.hip) else torch.float32
+        self.obs = torch.zeros((T, N) + self.obs_shape, dtype=obs_dtype, device=device)
+        self.actions = torch.zeros((T, N) + self.act_shape, device=device)
+        self.logprobs = torch.zeros((T, N), device=device)
+        self.rewards = torch.zeros((T, N), device=device)
+        self.dones = torch.zeros((T, N), device=device)
+        self.values = torch.zeros((T, N), device=device)
+        self.advantages = torch.zeros((T, N), device=device)
+        self.returns = torch.zeros((T, N), device=device)
+        self.boot_obs = torch.zeros((N,) + self.obs_shape, dtype=obs_dtype, device=device)
+        self.boot_done = torch.zeros(N, device=device)
+        self.batch_size = T * N
+        self.minibatch_size = self.batch_size // int(args.num_minibatches)
+        if self.hip:
+            self._h2d = torch.cuda.Stream(device=device)
+            self._h2d_evt = torch.cuda.Event()
+            self._pin_obs = torch.zeros((N,) + self.obs_shape, dtype=obs_dtype).pin_memory()
+            self._pin_rd = torch.zeros((2, N), dtype=torch.float32).pin_memory()
+            self._x_roll = torch.empty((N,) + self.obs_shape, device=device) if self.image else None
+            self._x_mb = None
+            n_upd = int(args.update_epochs) * int(args.num_minibatches)
+            self._scalars = torch.zeros((n_upd, 7), device=device)
+            self._inds_dev = torch.empty(self.batch_size, dtype=torch.int64, device=device)
+            self._inds_pin = torch.empty(self.batch_size, dtype=torch.int64).pin_memory()
+            self._total_norm = torch.zeros(1, device=device)
+
+    # ------------------------------------------------------------------ rollout (a2)
+    def _slot(self, step: int):
+        return (self.obs[step], self.dones[step]) if step < self.T else (self.boot_obs, self.boot_done)
+
+    def observe(self, step: int, next_obs, next_done) -> None:
+        """``obs[step] = next_obs; dones[step] = next_done`` (:258-259).  ``step == T`` addresses the
+        bootstrap slot (the observation after the last step).  Host arrays are staged through pinned
+        memory and copied on a side stream as uint8 -- 4x fewer PCIe bytes than the reference's
+        ``torch.Tensor(next_obs).to(device)`` of f32 (:272)."""
+        obs_dst, done_dst = self._slot(step)
+        if isinstance(next_obs, torch.Tensor):
+            if next_obs.data_ptr() != obs_dst.data_ptr():
+                obs_dst.copy_(next_obs)
+            if next_done.data_ptr() != done_dst.data_ptr():
+                done_dst.copy_(next_done)
+            return
+        if not self.hip:
+            obs_dst.copy_(torch.as_tensor(np.asarray(next_obs), dtype=obs_dst.dtype))
+            done_dst.copy_(torch.as_tensor(np.asarray(next_done), dtype=torch.float32))
+            return
+        self._h2d_evt.synchronize()                    # the pinned staging buffers are free again
+        self._pin_obs.copy_(torch.from_numpy(np.ascontiguousarray(next_obs)))
+        self._pin_rd[0].copy_(torch.from_numpy(np.asarray(next_done, dtype=np.float32)))
+        with torch.cuda.stream(self._h2d):
+            obs_dst.copy_(self._pin_obs, non_blocking=True)
+            done_dst.copy_(self._pin_rd[0], non_blocking=True)
+            self._h2d_evt.record(self._h2d)
+        torch.cuda.current_stream(self.device).wait_event(self._h2d_evt)
+
+    def start_iteration(self) -> None:
+        """Carry the bootstrap observation of the previous rollout into slot 0 (the reference keeps it in
+        ``next_obs`` across iterations, :245-247,272)."""
+        self.obs[0].copy_(self.boot_obs)
+        self.dones[0].copy_(self.boot_done)
+
+    def _features(self, obs_rows):
+        """uint8 image rows -> normalised f32 (K5, no gather); other observations pass through."""
+        if self.image and self.hip:
+            return self.ops.obs_u8_to_f32(obs_rows, None, self._x_roll)
+        if self.image:
+            return obs_rows / 255.0
+        return obs_rows
+
+    @torch.no_grad()
+    def act(self, step: int):
+        """Action logic (:262-266): network forward on ``obs[step]``, sample, store action / logprob / value."""
+        x = self._features(self.obs[step])
+        if self.hip:
+            p, value = self.agent.heads(x)
+            seed, off = self.agent.rng.next()
+            if self.discrete:
+                a64, _, _, _ = self.ops.categorical_sample(p.contiguous(), seed=seed, offset=off,
+                                                            action_f32_out=self.actions[step],
+                                                            logprob_out=self.logprobs[step], want_entropy=False)
+                action = a64
+            else:
+                action, _, _ = self.ops.normal_sample(p.contiguous(), self.agent.actor_logstd, seed=seed, offset=off,
+                                                      action_out=self.actions[step], logprob_out=self.logprobs[step])
+            self.values[step].copy_(value.view(-1))
+            return action
+        action, logprob, _, value = self.agent.get_action_and_value(self.obs[step] if not self.image else self.obs[step])
+        self.values[step] = value.flatten()
+        self.actions[step] = action
+        self.logprobs[step] = logprob
+        return action
+
+    def store_reward(self, step: int, reward) -> None:
+        """``rewards[step] = torch.tensor(reward).to(device).view(-1)`` (:271)."""
+        if isinstance(reward, torch.Tensor):
+            if reward.data_ptr() != self.rewards[step].data_ptr():
+                self.rewards[step].copy_(reward.view(-1))
+        else:
+            self.rewards[step].copy_(torch.as_tensor(np.asarray(reward, dtype=np.float32)).view(-1),
+                                     non_blocking=self.hip)
+
+    # ------------------------------------------------------------------ GAE (a4)
+    @torch.no_grad()
+    def finish_rollout(self) -> None:
+        """Bootstrap value of the observation in the bootstrap slot, then GAE (:288-301)."""
+        a = self.args
+        if self.hip:
+            _, next_value = self.agent.heads(self._features(self.boot_obs))
+            self.ops.gae(self.rewards, self.dones, self.values, self.boot_done, next_value.reshape(-1).contiguous(),
+                         a.gamma, a.gae_lambda, self.advantages, self.returns)
+        else:
+            x = self.boot_obs
+            next_value = self.agent.get_value(x).reshape(1, -1)
+            adv, ret = host_ops.gae(self.rewards, self.dones, self.values, self.boot_done, next_value, a.gamma,
+                                    a.gae_lambda)
+            self.advantages.copy_(adv)
+            self.returns.copy_(ret)
+
+    # ------------------------------------------------------------------ update (a5-a9)
+    def update(self, lr: float) -> dict:
+        """Epochs x minibatches of the clipped-surrogate update (:311-380) + explained variance (:382-384).
+        Returns the scalars the reference logs (values of the LAST minibatch, clipfrac averaged)."""
+        a = self.args
+        B, M = self.batch_size, self.minibatch_size
+        b_inds = np.arange(B)                                             # :312
+        b_obs = self.obs.reshape((-1,) + self.obs_shape)                  # :304-309, views
+        b_actions = self.actions.reshape((-1,) + self.act_shape)
+        b_logprobs, b_advantages = self.logprobs.reshape(-1), self.advantages.reshape(-1)
+        b_returns, b_values = self.returns.reshape(-1), self.values.reshape(-1)
+        k = 0
+        stop = False
+        clipfracs = []
+        last = None
+        for epoch in range(int(a.update_epochs)):
+            np.random.shuffle(b_inds)                                     # :315 host MT19937, per-rank seed
+            if self.hip:
+                self._inds_pin.copy_(torch.from_numpy(b_inds))
+                self._inds_dev.copy_(self._inds_pin, non_blocking=True)
+            for start in range(0, B, M):
+                end = start + M
+                if self.hip:
+                    self._minibatch_hip(self._inds_dev[start:end], b_obs, b_actions, b_logprobs, b_advantages, b_returns,
+                                        b_values, lr, self._scalars[k])
+                else:
+                    last = self._minibatch_host(b_inds[start:end], b_obs, b_actions, b_logprobs, b_advantages, b_returns,
+                                                b_values, lr)
+                    clipfracs.append(last[6].item())                      # :328
+                k += 1
+            if a.target_kl is not None:                                   # :379-380 (local approx_kl, as the reference)
+                approx_kl = (self._scalars[k - 1, 5] if self.hip else last[5]).item()
+                if approx_kl > a.target_kl:
+                    stop = True
+            if stop:
+                break
+        y_pred, y_true = b_values.cpu().numpy(), b_returns.cpu().numpy()  # :382-384
+        var_y = np.var(y_true)
+        explained_var = np.nan if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y
+        if self.hip:
+            sc = self._scalars[:k].cpu().numpy()
+            last_np, clipfrac = sc[-1], float(np.mean(sc[:, 6]))
+        else:
+            last_np, clipfrac = last.numpy(), float(np.mean(clipfracs))
+        return dict(loss=float(last_np[0]), policy_loss=float(last_np[1]), value_loss=float(last_np[2]),
+                    entropy=float(last_np[3]), old_approx_kl=float(last_np[4]), approx_kl=float(last_np[5]),
+                    clipfrac=clipfrac, explained_variance=float(explained_var), num_updates=k)
+
+    def _minibatch_hip(self, idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, lr, scalars_out):
+        self.forward_backward_hip(idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, scalars_out)
+        if self.world_size > 1:
+            dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM)        # :367 on the persistent flat buffer (RCCL)
+        self.optimizer_step_hip(lr)
+
+    def forward_backward_hip(self, idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, scalars_out):
+        """K5 gather -> network forward -> K3 fused loss fwd+bwd -> autograd through the network only (:320-358).
+        Gradients land in the persistent flat buffer (``.grad`` of every parameter is a view of it)."""
+        a, ops = self.args, self.ops
+        if self.image:
+            if self._x_mb is None or self._x_mb.shape[0] != idx.numel():
+                self._x_mb = torch.empty((idx.numel(),) + self.obs_shape, device=self.device)
+            x = ops.obs_u8_to_f32(b_obs, idx, self._x_mb)                 # K5: b_obs[mb_inds] ; x / 255.0
+        else:
+            x = b_obs.index_select(0, idx)
+        p, value = self.agent.heads(x)                                    # :320 network forward
+        value = value.view(-1)
+        if self.discrete:
+            _, dp, dvalue = ops.ppo_loss_categorical(p.detach().contiguous(), value.detach().contiguous(), idx, b_actions,
+                                                     b_logprobs, b_advantages, b_returns, b_values, a.clip_coef,
+                                                     a.ent_coef, a.vf_coef, a.norm_adv, a.clip_vloss,
+                                                     scalars_out=scalars_out)
+            torch.autograd.backward([p, value], [dp, dvalue])             # :358
+        else:
+            _, dmean, dlogstd, dvalue = ops.ppo_loss_normal(p.detach().contiguous(), self.agent.actor_logstd.detach(),
+                                                            value.detach().contiguous(), idx, b_actions, b_logprobs,
+                                                            b_advantages, b_returns, b_values, a.clip_coef, a.ent_coef,
+                                                            a.vf_coef, a.norm_adv, a.clip_vloss, scalars_out=scalars_out)
+            torch.autograd.backward([p, value], [dmean, dvalue])
+            self.agent.actor_logstd.grad.add_(dlogstd.view_as(self.agent.actor_logstd))
+
+    def optimizer_step_hip(self, lr: float) -> None:
+        """(sum of grads) / world_size -> clip_grad_norm_ -> Adam (:368-377), one fused kernel pair on the
+        flat buffers; also zeroes the gradient buffer for the next backward."""
+        a = self.args
+        self.flat.step += 1
+        self.ops.clip_adam_(self.flat.params, self.flat.grads, self.flat.exp_avg, self.flat.exp_avg_sq, self.flat.step, lr,
+                            a.max_grad_norm, grad_scale=1.0 / self.world_size, total_norm_out=self._total_norm)
+
+    def _minibatch_host(self, mb_inds, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, lr):
+        """The reference's minibatch body on CPU tensors (ppo.py:250-290; multigpu :360-374 when world_size>1)."""
+        a = self.args
+        self.optimizer.param_groups[0]["lr"] = lr
+        x = b_obs[mb_inds]
+        if self.image:
+            x = x / 255.0
+        p, newvalue = self.agent.heads(x)
+        acts = b_actions.long()[mb_inds] if self.discrete else b_actions[mb_inds]
+        if self.discrete:
+            probs = torch.distributions.Categorical(logits=p)
+            newlogprob, entropy = probs.log_prob(acts), probs.entropy()
+        else:
+            probs = torch.distributions.Normal(p, torch.exp(self.agent.actor_logstd.expand_as(p)))
+            newlogprob, entropy = probs.log_prob(acts).sum(1), probs.entropy().sum(1)
+        loss, scalars = host_ops.ppo_loss(newlogprob, entropy, newvalue, b_logprobs[mb_inds], b_advantages[mb_inds],
+                                          b_returns[mb_inds], b_values[mb_inds], a.clip_coef, a.ent_coef, a.vf_coef,
+                                          a.norm_adv, a.clip_vloss)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.world_size > 1:
+            all_grads = torch.cat([p_.grad.view(-1) for p_ in self.agent.parameters() if p_.grad is not None])
+            dist.all_reduce(all_grads, op=dist.ReduceOp.SUM)
+            offset = 0
+            for p_ in self.agent.parameters():
+                if p_.grad is not None:
+                    p_.grad.data.copy_(all_grads[offset:offset + p_.numel()].view_as(p_.grad.data) / self.world_size)
+                    offset += p_.numel()
+        nn.utils.clip_grad_norm_(self.agent.parameters(), a.max_grad_norm)
+        self.optimizer.step()
+        return scalars

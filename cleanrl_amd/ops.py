@@ -16,7 +16,7 @@ from . import _lib
 __all__ = [
     "gae", "categorical_sample", "categorical_logprob_entropy", "normal_sample", "normal_logprob_entropy",
     "ppo_loss_categorical", "ppo_loss_normal", "obs_u8_to_f32", "clip_adam_", "PPOLossCategorical", "PPOLossNormal",
-    "LOSS_SCALAR_NAMES",
+    "CategoricalLogProbEntropy", "NormalLogProbEntropy", "LOSS_SCALAR_NAMES",
 ]
 
 LOSS_SCALAR_NAMES = ("loss", "pg_loss", "v_loss", "entropy", "old_approx_kl", "approx_kl", "clipfrac")
@@ -169,6 +169,59 @@ def normal_logprob_entropy(mean, logstd, action):
     return lp, ent
 
 
+class CategoricalLogProbEntropy(torch.autograd.Function):
+    """Differentiable ``(log_prob, entropy)`` of given actions: forward and backward are HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, logits, action):
+        logits_c = logits.detach().contiguous()
+        action = action.contiguous()
+        lp, ent = categorical_logprob_entropy(logits_c, action)
+        ctx.save_for_backward(logits_c, action)
+        return lp, ent
+
+    @staticmethod
+    def backward(ctx, g_lp, g_ent):
+        logits, action = ctx.saved_tensors
+        lib = _lib.load()
+        B, A = logits.shape
+        dlogits = torch.empty_like(logits)
+        a64, af = (action, None) if action.dtype == torch.int64 else (None, action)
+        g_lp = None if g_lp is None else _chk(g_lp.contiguous(), torch.float32, "g_logprob", (B,))
+        g_ent = None if g_ent is None else _chk(g_ent.contiguous(), torch.float32, "g_entropy", (B,))
+        with torch.cuda.device(logits.device):
+            st = lib.mi355ppo_categorical_logprob_entropy_bwd_f32(_ptr(logits), _ptr(a64), _ptr(af), _ptr(g_lp),
+                                                                  _ptr(g_ent), _ptr(dlogits), B, A,
+                                                                  _stream(logits.device))
+        _lib.check(st, "mi355ppo_categorical_logprob_entropy_bwd_f32")
+        return dlogits, None
+
+
+class NormalLogProbEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, logstd, action):
+        mean_c, action = mean.detach().contiguous(), action.contiguous()
+        ls = logstd.detach().reshape(-1).contiguous()
+        lp, ent = normal_logprob_entropy(mean_c, ls, action)
+        ctx.save_for_backward(mean_c, ls, action)
+        ctx.logstd_shape = logstd.shape
+        return lp, ent
+
+    @staticmethod
+    def backward(ctx, g_lp, g_ent):
+        mean, ls, action = ctx.saved_tensors
+        lib = _lib.load()
+        B, D = mean.shape
+        dmean, drows = torch.empty_like(mean), torch.empty_like(mean)
+        g_lp = None if g_lp is None else _chk(g_lp.contiguous(), torch.float32, "g_logprob", (B,))
+        g_ent = None if g_ent is None else _chk(g_ent.contiguous(), torch.float32, "g_entropy", (B,))
+        with torch.cuda.device(mean.device):
+            st = lib.mi355ppo_normal_logprob_entropy_bwd_f32(_ptr(mean), _ptr(ls), _ptr(action), _ptr(g_lp), _ptr(g_ent),
+                                                             _ptr(dmean), _ptr(drows), B, D, _stream(mean.device))
+        _lib.check(st, "mi355ppo_normal_logprob_entropy_bwd_f32")
+        return dmean, drows.sum(0).reshape(ctx.logstd_shape), None
+
+
 # ------------------------------------------------------------------------------------------- K3
 def _flat_batch(b_logprobs, b_advantages, b_returns, b_values):
     Bf = b_logprobs.numel()
@@ -209,7 +262,8 @@ def ppo_loss_categorical(new_logits, new_value, mb_inds, b_actions, b_logprobs, 
 
 
 def ppo_loss_normal(new_mean, logstd, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values,
-                    clip_coef: float, ent_coef: float, vf_coef: float, norm_adv: bool = True, clip_vloss: bool = True):
+                    clip_coef: float, ent_coef: float, vf_coef: float, norm_adv: bool = True, clip_vloss: bool = True,
+                    scalars_out=None):
     """Continuous-action loss fwd+bwd (ppo_continuous_action.py:265-300).
     Returns ``(scalars7, dmean, dlogstd, dvalue)``."""
     lib = _lib.load()
@@ -222,7 +276,7 @@ def ppo_loss_normal(new_mean, logstd, new_value, mb_inds, b_actions, b_logprobs,
         _chk(mb_inds, torch.int64, "mb_inds", (M,))
     Bf, b_logprobs, b_advantages, b_returns, b_values = _flat_batch(b_logprobs, b_advantages, b_returns, b_values)
     b_actions = _chk(b_actions.reshape(Bf, D), torch.float32, "b_actions", (Bf, D))
-    scalars = torch.empty(7, dtype=torch.float32, device=dev)
+    scalars = scalars_out if scalars_out is not None else torch.empty(7, dtype=torch.float32, device=dev)
     dmean = torch.empty_like(new_mean)
     dlogstd = torch.empty(D, dtype=torch.float32, device=dev)
     dvalue = torch.empty(M, dtype=torch.float32, device=dev)

@@ -1,0 +1,99 @@
+"""Drop-in for ``cleanrl/ppo_atari_envpool.py`` (Atari through EnvPool's C++ vector env).
+
+    python cleanrl_amd/ppo_atari_envpool.py --env-id Breakout-v5 --num-envs 128 --num-steps 128 --seed 1
+
+EnvPool's old-gym API is kept (``reset()`` -> obs, ``step()`` -> 4-tuple, episode statistics keyed on
+``info["lives"] == 0``, ppo_atari_envpool.py:214,237-247).  Without envpool the synthetic Atari stand-in
+speaks the same API.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from cleanrl_amd import cli, envs as E, runner  # noqa: E402
+from cleanrl_amd.agents import AtariAgent as Agent  # noqa: E402
+from cleanrl_amd.args import PPOArgs  # noqa: E402
+
+
+@dataclass
+class Args(PPOArgs):
+    exp_name: str = os.path.basename(__file__)[: -len(".py")]
+    env_id: str = "Breakout-v5"
+    total_timesteps: int = 10000000
+    num_envs: int = 8
+    clip_coef: float = 0.1
+
+
+class RecordEpisodeStatistics:
+    """Vector-env episode statistics for EnvPool (role of ppo_atari_envpool.py:83-114): accumulates the
+    raw ``info["reward"]`` and zeroes the accumulators where ``info["terminated"]``."""
+
+    def __init__(self, env):
+        self.env = env
+        self.num_envs = getattr(env, "num_envs", 1)
+        for k in ("single_action_space", "single_observation_space", "action_space", "observation_space"):
+            if hasattr(env, k):
+                setattr(self, k, getattr(env, k))
+
+    def reset(self, **kwargs):
+        observations = self.env.reset(**kwargs)
+        self.episode_returns = np.zeros(self.num_envs, dtype=np.float32)
+        self.episode_lengths = np.zeros(self.num_envs, dtype=np.int32)
+        return observations
+
+    def step(self, action):
+        observations, rewards, dones, infos = self.env.step(action)
+        self.episode_returns += infos["reward"]
+        self.episode_lengths += 1
+        infos["r"] = self.episode_returns.copy()
+        infos["l"] = self.episode_lengths.copy()
+        self.episode_returns *= 1 - infos["terminated"]
+        self.episode_lengths *= 1 - infos["terminated"]
+        return observations, rewards, dones, infos
+
+    def close(self):
+        self.env.close()
+
+
+def make_envs(args):
+    if E.have_envpool() and not args.synthetic_env:
+        import envpool
+
+        envs = envpool.make(args.env_id, env_type="gym", num_envs=args.num_envs, episodic_life=True, reward_clip=True,
+                            seed=args.seed)                                     # ppo_atari_envpool.py:185-192
+        envs.num_envs = args.num_envs
+        envs.single_action_space = envs.action_space
+        envs.single_observation_space = envs.observation_space
+        return RecordEpisodeStatistics(envs)
+    print("[cleanrl_amd] envpool not installed: using the synthetic (N,4,84,84) uint8 Atari stand-in (gym API)",
+          file=sys.stderr)
+    return E.SyntheticAtariVecEnv(args.num_envs, seed=args.seed, n_actions=4, api="gym")
+
+
+def main(argv=None):
+    args = cli.parse(Args, argv)
+    args.batch_size = int(args.num_envs * args.num_steps)
+    args.minibatch_size = int(args.batch_size // args.num_minibatches)
+    args.num_iterations = args.total_timesteps // args.batch_size
+    run_name = f"{args.env_id}__{args.exp_name}__{args.seed}__{int(time.time())}"
+    writer = runner.open_writer(args, run_name)
+    runner.seed_everything(args)
+    device = runner.select_device(args)
+    envs = make_envs(args)
+    assert hasattr(envs.single_action_space, "n"), "only discrete action space is supported"
+    agent = Agent(envs).to(device)
+    learner = runner.train(args, envs, agent, device, writer, env_api="gym")
+    envs.close()
+    writer.close()
+    return learner
+
+
+if __name__ == "__main__":
+    main()

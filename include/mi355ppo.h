@@ -98,6 +98,15 @@ MI355PPO_API int mi355ppo_categorical_logprob_entropy_f32(const float* logits,
                                              float* logprob, float* entropy,
                                              int B, int A, void* stream);
 
+/* Backward of the two outputs above w.r.t. logits, for code that differentiates
+ * Agent.get_action_and_value(x, action) itself (autograd of torch categorical.py log_prob/entropy):
+ *   dlogits[b,j] = g_logprob[b]*(1[j==a_b] - p_bj) - g_entropy[b]*p_bj*(logp_bj + H_b).
+ * g_logprob / g_entropy (B) may be NULL (= zeros). */
+MI355PPO_API int mi355ppo_categorical_logprob_entropy_bwd_f32(const float* logits,
+                                             const int64_t* action_i64, const float* action_f32,
+                                             const float* g_logprob, const float* g_entropy,
+                                             float* dlogits, int B, int A, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2' Normal(mean, exp(logstd)): sample + summed log_prob + summed entropy.
  * Replaces cleanrl/ppo_continuous_action.py:134-141.
@@ -113,6 +122,12 @@ MI355PPO_API int mi355ppo_normal_sample_f32(const float* mean, const float* logs
 MI355PPO_API int mi355ppo_normal_logprob_entropy_f32(const float* mean, const float* logstd, const float* action,
                                         float* logprob_sum, float* entropy_sum,
                                         int B, int D, void* stream);
+
+/* Backward of (logprob_sum, entropy_sum): dmean (B,D) and the per-row contributions to dlogstd
+ * (B,D), which the caller sums over rows. */
+MI355PPO_API int mi355ppo_normal_logprob_entropy_bwd_f32(const float* mean, const float* logstd, const float* action,
+                                        const float* g_logprob, const float* g_entropy,
+                                        float* dmean, float* dlogstd_rows, int B, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  Minibatch PPO loss, forward + backward fused (clipped surrogate + value loss + entropy).
