@@ -64,6 +64,40 @@ __global__ __launch_bounds__(256) void obs_u8_to_f32_kernel(const uint8_t* __res
     }
 }
 
+
+// ---- planar (C,H*W) uint8 frames -> interleaved (H*W,C): the store-time relayout of the rollout buffer ----
+// Env frames arrive channel-planar (FrameStack: (4,84,84)).  Keeping the rollout buffer pixel-interleaved
+// ((84,84,4), "NHWC") lets the gather+convert kernel above stay a pure streaming copy AND hands the conv
+// stack channels-last activations, which removes every layout transpose MIOpen otherwise inserts around its
+// NHWC implicit-GEMM kernels (18% of an iteration when measured).  The relayout touches uint8 data once per
+// env step (29 MB at N=1024), 4x cheaper than doing it on f32.
+// C == 4: a lane reads one dword (4 pixels) from each of the 4 planes, transposes the 4x4 byte block in
+// registers and writes 16 contiguous bytes: all loads and the store are fully coalesced, no LDS.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_u8_c4_kernel(const uint8_t* __restrict__ src,
+                                                                 uint8_t* __restrict__ dst, int quads_per_row) {
+    const int64_t r = blockIdx.x;
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= quads_per_row) return;
+    const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(src + r * (int64_t)quads_per_row * 16);
+    const uint32_t w0 = s[q], w1 = s[quads_per_row + q], w2 = s[2 * quads_per_row + q], w3 = s[3 * quads_per_row + q];
+    uint4 o;
+    o.x = (w0 & 0xffu) | ((w1 & 0xffu) << 8) | ((w2 & 0xffu) << 16) | (w3 << 24);
+    o.y = ((w0 >> 8) & 0xffu) | (w1 & 0xff00u) | ((w2 & 0xff00u) << 8) | ((w3 & 0xff00u) << 16);
+    o.z = ((w0 >> 16) & 0xffu) | ((w1 >> 8) & 0xff00u) | (w2 & 0xff0000u) | ((w3 & 0xff0000u) << 8);
+    o.w = (w0 >> 24) | ((w1 >> 16) & 0xff00u) | ((w2 >> 8) & 0xff0000u) | (w3 & 0xff000000u);
+    reinterpret_cast<uint4*>(dst + r * (int64_t)quads_per_row * 16)[q] = o;
+}
+
+// generic C (slow path, byte granularity)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_u8_generic_kernel(const uint8_t* __restrict__ src,
+                                                                      uint8_t* __restrict__ dst, int C, int HW) {
+    const int64_t r = blockIdx.x;
+    const int i = blockIdx.y * 256 + threadIdx.x;     // output byte index within the row: pixel*C + c
+    if (i >= C * HW) return;
+    const int pix = i / C, c = i % C;
+    dst[r * (int64_t)C * HW + i] = src[r * (int64_t)C * HW + (int64_t)c * HW + pix];
+}
+
 }  // namespace mi355ppo
 
 using namespace mi355ppo;
@@ -86,4 +120,21 @@ extern "C" MI355PPO_API int mi355ppo_obs_u8_to_f32(const uint8_t* src_u8, const 
         hipLaunchKernelGGL((obs_u8_to_f32_kernel<false>), grid, dim3(256), 0, as_stream(stream), src_u8, inds, dst_f32,
                            row_bytes, dpr);
     return check_launch("obs_u8_to_f32_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_obs_nchw_to_nhwc_u8(const uint8_t* src, uint8_t* dst, int64_t rows, int C, int HW,
+                                                         void* stream) {
+    const char* fn = "mi355ppo_obs_nchw_to_nhwc_u8";
+    MI355_REQUIRE(src && dst && src != dst, MI355PPO_EINVAL, "%s: null or aliased pointers", fn);
+    MI355_REQUIRE(rows > 0 && rows <= 2147483647LL && C > 0 && HW > 0 && (int64_t)C * HW <= (int64_t)65535 * 256,
+                  MI355PPO_EINVAL, "%s: rows=%lld C=%d HW=%d out of range", fn, (long long)rows, C, HW);
+    if (C == 4 && HW % 4 == 0 && aligned(src, 4) && aligned(dst, 16)) {
+        const int quads = HW / 4;
+        hipLaunchKernelGGL(nchw_to_nhwc_u8_c4_kernel, dim3((unsigned)rows, (unsigned)((quads + 255) / 256)), dim3(256), 0,
+                           as_stream(stream), src, dst, quads);
+        return check_launch("nchw_to_nhwc_u8_c4_kernel");
+    }
+    hipLaunchKernelGGL(nchw_to_nhwc_u8_generic_kernel, dim3((unsigned)rows, (unsigned)((C * HW + 255) / 256)), dim3(256),
+                       0, as_stream(stream), src, dst, C, HW);
+    return check_launch("nchw_to_nhwc_u8_generic_kernel");
 }

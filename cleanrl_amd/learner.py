@@ -24,6 +24,7 @@ missing); a CPU device (``--no-cuda``) runs ``host_ops`` with the reference's to
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import numpy as np
@@ -61,8 +62,16 @@ class PPOLearner:
             self.flat = None
             self.optimizer = optim.Adam(agent.parameters(), lr=args.learning_rate, eps=1e-5)   # ppo.py:168
         # ALGO Logic: Storage setup (ppo.py:171-176).  Image observations are stored as uint8 on the GPU:
-        # frames are integers 0..255, so this is exact and 4x smaller than the reference's f32 tensor.
+        # frames are integers 0..255, so this is exact and 4x smaller than the reference's f32 tensor.  They
+        # are also stored pixel-interleaved ((H,W,C), "NHWC"): the gather+convert kernel then emits
+        # channels-last f32 activations and the conv stack runs without any layout transposes.
         obs_dtype = torch.uint8 if (self.image and self.hip) else torch.float32
+        self.nhwc = self.image and self.hip
+        self.frame_shape = self.obs_shape                                   # what the env delivers: (C,H,W)
+        if self.nhwc:
+            c, h, w = self.obs_shape
+            self.obs_shape = (h, w, c)                                      # how rollout rows are laid out
+            os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
         self.obs = torch.zeros((T, N) + self.obs_shape, dtype=obs_dtype, device=device)
         self.actions = torch.zeros((T, N) + self.act_shape, device=device)
         self.logprobs = torch.zeros((T, N), device=device)
@@ -78,7 +87,9 @@ class PPOLearner:
         if self.hip:
             self._h2d = torch.cuda.Stream(device=device)
             self._h2d_evt = torch.cuda.Event()
-            self._pin_obs = torch.zeros((N,) + self.obs_shape, dtype=obs_dtype).pin_memory()
+            self._pin_obs = torch.zeros((N,) + self.frame_shape, dtype=obs_dtype).pin_memory()
+            # device staging for incoming channel-planar frames (H2D target / device-env output)
+            self.stage_obs = torch.zeros((N,) + self.frame_shape, dtype=obs_dtype, device=device) if self.nhwc else None
             self._pin_rd = torch.zeros((2, N), dtype=torch.float32).pin_memory()
             self._x_roll = torch.empty((N,) + self.obs_shape, device=device) if self.image else None
             self._x_mb = None
@@ -96,10 +107,13 @@ class PPOLearner:
         """``obs[step] = next_obs; dones[step] = next_done`` (:258-259).  ``step == T`` addresses the
         bootstrap slot (the observation after the last step).  Host arrays are staged through pinned
         memory and copied on a side stream as uint8 -- 4x fewer PCIe bytes than the reference's
-        ``torch.Tensor(next_obs).to(device)`` of f32 (:272)."""
+        ``torch.Tensor(next_obs).to(device)`` of f32 (:272).  Image frames arrive channel-planar (C,H,W)
+        and are re-laid out to the buffer's (H,W,C) rows by the uint8 relayout kernel."""
         obs_dst, done_dst = self._slot(step)
         if isinstance(next_obs, torch.Tensor):
-            if next_obs.data_ptr() != obs_dst.data_ptr():
+            if self.nhwc:
+                self.ops.obs_nchw_to_nhwc_u8(next_obs, obs_dst)
+            elif next_obs.data_ptr() != obs_dst.data_ptr():
                 obs_dst.copy_(next_obs)
             if next_done.data_ptr() != done_dst.data_ptr():
                 done_dst.copy_(next_done)
@@ -111,11 +125,14 @@ class PPOLearner:
         self._h2d_evt.synchronize()                    # the pinned staging buffers are free again
         self._pin_obs.copy_(torch.from_numpy(np.ascontiguousarray(next_obs)))
         self._pin_rd[0].copy_(torch.from_numpy(np.asarray(next_done, dtype=np.float32)))
+        h2d_dst = self.stage_obs if self.nhwc else obs_dst
         with torch.cuda.stream(self._h2d):
-            obs_dst.copy_(self._pin_obs, non_blocking=True)
+            h2d_dst.copy_(self._pin_obs, non_blocking=True)
             done_dst.copy_(self._pin_rd[0], non_blocking=True)
             self._h2d_evt.record(self._h2d)
         torch.cuda.current_stream(self.device).wait_event(self._h2d_evt)
+        if self.nhwc:
+            self.ops.obs_nchw_to_nhwc_u8(self.stage_obs, obs_dst)
 
     def start_iteration(self) -> None:
         """Carry the bootstrap observation of the previous rollout into slot 0 (the reference keeps it in
@@ -126,7 +143,8 @@ class PPOLearner:
     def _features(self, obs_rows):
         """uint8 image rows -> normalised f32 (K5, no gather); other observations pass through."""
         if self.image and self.hip:
-            return self.ops.obs_u8_to_f32(obs_rows, None, self._x_roll)
+            # (N,H,W,C) f32 storage viewed as a channels-last (N,C,H,W) tensor
+            return self.ops.obs_u8_to_f32(obs_rows, None, self._x_roll).permute(0, 3, 1, 2)
         if self.image:
             return obs_rows / 255.0
         return obs_rows
@@ -241,7 +259,7 @@ class PPOLearner:
         if self.image:
             if self._x_mb is None or self._x_mb.shape[0] != idx.numel():
                 self._x_mb = torch.empty((idx.numel(),) + self.obs_shape, device=self.device)
-            x = ops.obs_u8_to_f32(b_obs, idx, self._x_mb)                 # K5: b_obs[mb_inds] ; x / 255.0
+            x = ops.obs_u8_to_f32(b_obs, idx, self._x_mb).permute(0, 3, 1, 2)   # K5: b_obs[mb_inds] ; x / 255.0
         else:
             x = b_obs.index_select(0, idx)
         p, value = self.agent.heads(x)                                    # :320 network forward

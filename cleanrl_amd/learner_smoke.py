@@ -25,8 +25,9 @@ def rollout(learner: PPOLearner, env: DeviceSyntheticAtariVecEnv) -> None:
     T = learner.T
     for step in range(T):
         learner.act(step)
-        obs_dst, done_dst = learner._slot(step + 1)
-        env.step_into(obs_dst, learner.rewards[step], done_dst)
+        _, done_dst = learner._slot(step + 1)
+        frames = env.step_into(learner.stage_obs, learner.rewards[step], done_dst)   # channel-planar uint8 in HBM
+        learner.observe(step + 1, frames, done_dst)                                  # relayout into the rollout row
     learner.finish_rollout()
 
 
@@ -38,7 +39,7 @@ def run(device, num_envs: int = 16, seed: int = 1, verbose: bool = True):
     args = default_args()
     learner = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, num_envs, device,
                          sample_seed=seed)
-    env.obs_into(learner.obs[0])
+    learner.observe(0, env.obs_into(learner.stage_obs), learner.dones[0])
     rollout(learner, env)
     before = learner.flat.params.clone()
     metrics = learner.update(args.learning_rate)

@@ -15,7 +15,7 @@ from . import _lib
 
 __all__ = [
     "gae", "categorical_sample", "categorical_logprob_entropy", "normal_sample", "normal_logprob_entropy",
-    "ppo_loss_categorical", "ppo_loss_normal", "obs_u8_to_f32", "clip_adam_", "PPOLossCategorical", "PPOLossNormal",
+    "ppo_loss_categorical", "ppo_loss_normal", "obs_u8_to_f32", "obs_nchw_to_nhwc_u8", "clip_adam_", "PPOLossCategorical", "PPOLossNormal",
     "CategoricalLogProbEntropy", "NormalLogProbEntropy", "LOSS_SCALAR_NAMES",
 ]
 
@@ -356,6 +356,20 @@ def obs_u8_to_f32(src_u8, inds=None, out=None, scale_255: bool = True):
         st = lib.mi355ppo_obs_u8_to_f32(_ptr(src_u8), _ptr(inds), _ptr(out), rows, row_bytes, int(bool(scale_255)),
                                         _stream(dev))
     _lib.check(st, "mi355ppo_obs_u8_to_f32")
+    return out
+
+
+def obs_nchw_to_nhwc_u8(src, out=None):
+    """(rows, C, H, W) uint8 -> (rows, H, W, C) uint8, the rollout buffer's pixel-interleaved layout."""
+    lib = _lib.load()
+    _chk(src, torch.uint8, "src")
+    rows, C, H, W = src.shape
+    if out is None:
+        out = torch.empty((rows, H, W, C), dtype=torch.uint8, device=src.device)
+    _chk(out, torch.uint8, "out", (rows, H, W, C))
+    with torch.cuda.device(src.device):
+        st = lib.mi355ppo_obs_nchw_to_nhwc_u8(_ptr(src), _ptr(out), rows, C, H * W, _stream(src.device))
+    _lib.check(st, "mi355ppo_obs_nchw_to_nhwc_u8")
     return out
 
 

@@ -178,6 +178,13 @@ MI355PPO_API int mi355ppo_loss_normal_fwd_bwd_f32(const float* new_mean, const f
 MI355PPO_API int mi355ppo_obs_u8_to_f32(const uint8_t* src_u8, const int64_t* inds, float* dst_f32,
                            int64_t rows, int64_t row_bytes, int scale_255, void* stream);
 
+/* Store-time relayout of incoming frames: channel-planar (rows, C, HW) uint8 -> pixel-interleaved
+ * (rows, HW, C) uint8 ("NHWC").  Replaces nothing in the reference (it stores f32 NCHW, :235,258); it lets
+ * the rollout buffer feed the conv stack channels-last so that no layout transposes run on f32 data.
+ * C == 4 with HW % 4 == 0 (FrameStack(4) of 84x84) takes the coalesced register-transpose path. */
+MI355PPO_API int mi355ppo_obs_nchw_to_nhwc_u8(const uint8_t* src, uint8_t* dst, int64_t rows, int C, int HW,
+                                              void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a8/a9  Flat-buffer optimiser step: (grad * grad_scale) -> global-norm clip -> Adam, fused.
  * Replaces the unpack-and-divide of cleanrl/ppo_atari_multigpu.py:368-374 (grad_scale =

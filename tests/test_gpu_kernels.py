@@ -339,3 +339,14 @@ def test_kernels_are_stream_capturable():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(adv, expect[0]) and torch.equal(sc, expect[1]) and torch.equal(dl, expect[2])
+
+
+def test_obs_relayout_nchw_to_nhwc_u8():
+    frames = torch.from_numpy(synthetic.atari_frames(37, seed=9)).to(DEV)
+    out = ops.obs_nchw_to_nhwc_u8(frames)
+    assert out.shape == (37, 84, 84, 4) and torch.equal(out, frames.permute(0, 2, 3, 1).contiguous())
+    odd = torch.randint(0, 256, (5, 3, 7, 9), dtype=torch.uint8, device=DEV)      # generic-C path
+    assert torch.equal(ops.obs_nchw_to_nhwc_u8(odd), odd.permute(0, 2, 3, 1).contiguous())
+    # the relayout followed by the streaming convert is exactly the reference's x/255 on a channels-last view
+    x = ops.obs_u8_to_f32(out).permute(0, 3, 1, 2)
+    assert x.is_contiguous(memory_format=torch.channels_last) and torch.equal(x, frames.float() / 255.0)

@@ -26,10 +26,11 @@ def test_rollout_gae_and_update_seam_against_oracle():
     agent = AtariAgent(env).to(DEV)
     args = learner_smoke.default_args(num_steps=16, num_minibatches=4)
     L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=3)
-    env.obs_into(L.obs[0])
+    L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
     learner_smoke.rollout(L, env)
     # a2/a3: what was stored is what the network + the oracle distribution produce for the stored observations
-    x = (L.obs.reshape(-1, 4, 84, 84).float() / 255.0)
+    assert L.obs.shape[2:] == (84, 84, 4), "image rollout rows are stored pixel-interleaved (H,W,C) uint8"
+    x = (L.obs.reshape(-1, 84, 84, 4).permute(0, 3, 1, 2).float() / 255.0)
     with torch.no_grad():
         logits, value = agent.heads(x)
     lp_o, _ = TO.categorical_logprob_entropy(logits.cpu(), L.actions.reshape(-1).cpu())
@@ -38,7 +39,7 @@ def test_rollout_gae_and_update_seam_against_oracle():
     assert L.actions.min() >= 0 and L.actions.max() <= 3 and L.dones.sum() > 0
     # a4: GAE bit-exact vs the C oracle on the stored tensors
     with torch.no_grad():
-        nv = agent.get_value(L.boot_obs).reshape(-1)
+        nv = agent.heads(L._features(L.boot_obs))[1].reshape(-1)
     adv_o, ret_o = c_oracle.gae(L.rewards.cpu().numpy(), L.dones.cpu().numpy(), L.values.cpu().numpy(),
                                 L.boot_done.cpu().numpy(), nv.cpu().numpy(), args.gamma, args.gae_lambda)
     assert np.array_equal(L.advantages.cpu().numpy(), adv_o) and np.array_equal(L.returns.cpu().numpy(), ret_o)
@@ -46,10 +47,10 @@ def test_rollout_gae_and_update_seam_against_oracle():
     idx = torch.randperm(L.batch_size, device=DEV)[:L.minibatch_size]
     sc = torch.empty(7, device=DEV)
     b = [t.reshape(-1) for t in (L.actions, L.logprobs, L.advantages, L.returns, L.values)]
-    L.forward_backward_hip(idx, L.obs.reshape(-1, 4, 84, 84), *b, sc)
+    L.forward_backward_hip(idx, L.obs.reshape(-1, 84, 84, 4), *b, sc)
     cpu_agent = AtariAgent(env)
     cpu_agent.load_state_dict({k: v.cpu() for k, v in agent.state_dict().items()})
-    xc = L.obs.reshape(-1, 4, 84, 84)[idx].cpu().float() / 255.0
+    xc = L.obs.reshape(-1, 84, 84, 4)[idx].permute(0, 3, 1, 2).cpu().float() / 255.0
     lg, vv = cpu_agent.heads(xc)
     lp, ent = TO.categorical_logprob_entropy(lg, b[0][idx].cpu())
     ref = TO.ppo_loss(lp, ent, vv, b[1][idx].cpu(), b[2][idx].cpu(), b[3][idx].cpu(), b[4][idx].cpu(), args.clip_coef,
@@ -84,7 +85,7 @@ def test_dp_step_matches_reference_collective_block_golden():
     grads = []
     for r in (1, 0):
         L.flat.grads.zero_()
-        L.forward_backward_hip(idx, G(f"obs_u8_rank{r}"), G(f"b_actions_rank{r}"), G(f"b_logprobs_rank{r}"),
+        L.forward_backward_hip(idx, ops.obs_nchw_to_nhwc_u8(G(f"obs_u8_rank{r}")), G(f"b_actions_rank{r}"), G(f"b_logprobs_rank{r}"),
                                G(f"b_advantages_rank{r}"), G(f"b_returns_rank{r}"), G(f"b_values_rank{r}"), sc)
         np.testing.assert_allclose(sc[0].item(), g[f"loss_rank{r}"], rtol=1e-4)
         grads.append(L.flat.grads.clone())
