@@ -6,6 +6,7 @@ import dataclasses
 import importlib
 import os
 import subprocess
+import re
 import sys
 
 import pytest
@@ -115,10 +116,10 @@ def test_ppo_atari_multigpu_two_ranks_gloo():
                 "--local-addr", "127.0.0.1", "cleanrl_amd/ppo_atari_multigpu.py", "--no-cuda", "--local-num-envs", "4",
                 "--num-steps", "8", "--num-envs", "8", "--total-timesteps", "128"])
     sums = {}
-    for line in out.splitlines():
-        if line.startswith("local_rank:"):
-            parts = dict(kv.split(": ") for kv in line.split(", "))
-            sums.setdefault(parts["iteration"], {})[parts["local_rank"]] = parts["agent.actor.weight.sum()"]
+    # two ranks share one stdout pipe and their lines can interleave: match whole records, not lines
+    pat = r"local_rank: (\d+), action\.sum\(\): -?\d+, iteration: (\d+), agent\.actor\.weight\.sum\(\): (-?[\d.eE+-]+)"
+    for lr, it, w in re.findall(pat, out):
+        sums.setdefault(it, {})[lr] = w
     assert len(sums) == 2
     for it, by_rank in sums.items():
         assert len(by_rank) == 2 and by_rank["0"] == by_rank["1"], f"replicas diverged at iteration {it}: {by_rank}"
