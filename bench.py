@@ -71,6 +71,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured achievable
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= the f32 vector peak), same guide
 OBS_ROW_BYTES = 4 * 84 * 84   # 28,224
 
 
@@ -149,8 +150,29 @@ def main():
     learner = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, device, world_size=world,
                          sample_seed=seed)
     timer = KernelTimer()
+    conv_flops = {}
     if not cli.no_kernel_timing:
         real_obs, real_gae, real_loss = ops.obs_u8_to_f32, ops.gae, ops.ppo_loss_categorical
+        if learner.fused_cnn:
+            from cleanrl_amd import cnn
+
+            def conv_hook(kind, real, images_of):
+                def hooked(*a, **kw):
+                    layer = a[3] if kind != "wgrad" else a[2]
+                    images = images_of(*a, **kw)
+                    cin, cout, k, _, _, hout = cnn.LAYERS[layer]
+                    key = f"conv{layer}_{kind}@{images}"
+                    conv_flops[key] = 2.0 * images * hout * hout * cout * cin * k * k
+                    return timer.wrap(key, real)(*a, **kw)
+
+                return hooked
+
+            def fwd_images(src, Bt, bias, layer, inds=None, out=None):
+                return src.shape[0] if inds is None else inds.numel()
+
+            cnn.conv_fwd = conv_hook("fwd", cnn.conv_fwd, fwd_images)
+            cnn.conv_dgrad = conv_hook("dgrad", cnn.conv_dgrad, lambda dz, *a, **kw: dz.shape[0])
+            cnn.conv_wgrad = conv_hook("wgrad", cnn.conv_wgrad, lambda src, dz, *a, **kw: dz.shape[0])
 
         def obs_hook(src, inds=None, out=None, scale_255=True):
             if inds is not None:
@@ -213,10 +235,40 @@ def main():
                 "local_num_envs": N, "num_steps": T, "global_num_envs": world * N, "minibatch_rows": M,
                 "parallelism": f"dp{world} (one learner per GPU, RCCL all-reduce of the flat f32 gradient)",
                 "env": "device-resident synthetic generator (no PCIe in the timed region)",
+                "cnn": "f32-MFMA implicit-GEMM kernels (csrc/conv.hip)" if learner.fused_cnn else "torch Conv2d (MIOpen)",
             },
             "final_loss": metrics["loss"],
         }
-        if not cli.no_kernel_timing:
+        if not cli.no_kernel_timing and learner.fused_cnn:
+            # dominant kernel of the path = the conv launch with the largest total time inside the timed region
+            tot = {k: timer.mean_us(k)[0] * timer.mean_us(k)[1] for k in conv_flops}
+            dom = max(tot, key=tot.get)
+            us, n = timer.mean_us(dom)
+            tf = conv_flops[dom] / us / 1e6
+            out["roofline"] = {
+                "kernel": f"{dom}: conv_gemm_kernel / conv_wgrad_kernel (f32-MFMA implicit GEMM, csrc/conv.hip); the fused "
+                          "uint8 gather+/255 (K5), bias, ReLU and ReLU-backward passes have no kernels of their own any more",
+                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "algorithmic_flops_per_launch": conv_flops[dom], "avg_launch_us": us, "launches_timed": n,
+                "share_of_step_time": tot[dom] / (elapsed * 1e6),
+            }
+            gus, gn = timer.mean_us("gae")
+            lus, ln = timer.mean_us("loss")
+            gae_bytes = 20 * T * N + 8 * N
+            loss_bytes = (8 * cli.n_actions + 28 + 8) * M
+            out["kernels"] = {
+                "gae": {"algorithmic_bytes": gae_bytes, "avg_us_event_bracket": gus, "GBps": gae_bytes / gus / 1e3,
+                        "launches_timed": gn, "note": "128x1024 is launch/latency-bound: see profiles/ for the kernel time"},
+                "loss_fwd_bwd": {"algorithmic_bytes": loss_bytes, "avg_us_event_bracket_3_launches": lus,
+                                 "GBps": loss_bytes / lus / 1e3, "launches_timed": ln},
+            }
+            for k in sorted(conv_flops):
+                kus, kn = timer.mean_us(k)
+                out["kernels"][k] = {"avg_us": kus, "launches_timed": kn, "TFLOPs": conv_flops[k] / kus / 1e6,
+                                     "frac_of_f32_mfma_peak": conv_flops[k] / kus / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                                     "ms_per_step": kus * kn / cli.steps / 1e3}
+        elif not cli.no_kernel_timing:
             us, n = timer.mean_us("obs_gather")
             alg = OBS_ROW_BYTES * 5 * M
             traffic = None

@@ -39,6 +39,11 @@ SIGNATURES = {
     "mi355ppo_clip_adam_f32": (
         c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, c_double, c_int64,
                 _P, _P, c_size_t, _P]),
+    "mi355ppo_cnn_repack_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
+    "mi355ppo_cnn_conv_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
+    "mi355ppo_cnn_conv_dgrad_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "mi355ppo_cnn_conv_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "mi355ppo_cnn_conv_wgrad_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_size_t, _P]),
 }
 
 _lib = None

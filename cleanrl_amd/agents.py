@@ -79,6 +79,7 @@ class AtariAgent(_DiscreteMixin, nn.Module):
         self.critic = layer_init(nn.Linear(512, 1), std=1)
         self.n_actions = envs.single_action_space.n
         self.rng = _SampleCounter()
+        self._trunk = None
 
     def _normalise(self, x):
         if x.dtype == torch.uint8:
@@ -88,6 +89,20 @@ class AtariAgent(_DiscreteMixin, nn.Module):
     def heads(self, xn):
         """xn: already-normalised f32 observations -> (logits (B,A), value (B,1))."""
         hidden = self.network(xn)
+        return self.actor(hidden), self.critic(hidden)
+
+    def heads_u8(self, obs_rows, inds=None):
+        """The learner's fast path: ``obs_rows`` is the uint8 rollout buffer in its pixel-interleaved layout
+        (rows, 84, 84, 4) and ``inds`` optionally gathers rows (``b_obs[mb_inds]``).  Same function as
+        ``heads(obs / 255.0)`` with the three convolutions on the libmi355ppo f32-MFMA kernels (gather, /255, bias,
+        ReLU and the ReLU / bias backward fused; cleanrl_amd/cnn.py); the two Linear layers stay on hipBLASLt."""
+        from . import cnn
+
+        if self._trunk is None:
+            self._trunk = cnn.NatureTrunk()
+        net = self.network
+        feats = self._trunk(obs_rows, inds, net[0], net[2], net[4])
+        hidden = torch.relu(torch.nn.functional.linear(feats, cnn.fc_weight_hwc(net[7].weight), net[7].bias))
         return self.actor(hidden), self.critic(hidden)
 
     def get_value(self, x):

@@ -1,0 +1,170 @@
+"""NatureCNN convolution stack on the libmi355ppo f32-MFMA kernels (``csrc/conv.hip``).
+
+Host side of ``mi355ppo_cnn_*``: tensor-level wrappers, and ``NatureTrunk`` -- the autograd node that replaces
+``Agent.network[0:6]`` (cleanrl/ppo_atari_multigpu.py:136-142: three Conv2d + ReLU) for uint8 channels-last rollout
+rows.  Everything the reference runs as separate passes around the convolutions is fused into them:
+``b_obs[mb_inds]`` and ``x / 255.0`` (:320,154) into conv1's loader, bias + ReLU into every forward epilogue, ReLU
+backward into the data-gradient epilogues, bias gradients into the weight-gradient kernels.
+
+Activations are (images, H, W, C) f32; parameters keep torch's (Cout, Cin, KH, KW) layout (they are views of the
+flat parameter buffer) and are repacked into the kernels' matrix layouts on use (<= 147 KB each).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .ops import _chk, _ptr, _stream, _workspace
+
+# layer -> (Cin, Cout, K, stride, Hin, Hout)
+LAYERS = {1: (4, 32, 8, 4, 84, 20), 2: (32, 64, 4, 2, 20, 9), 3: (64, 64, 3, 1, 9, 7)}
+MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2 = 0, 1, 2
+
+
+def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch.Tensor | None = None) -> torch.Tensor:
+    lib = _lib.load()
+    cin, cout, k, _, _, _ = LAYERS[layer]
+    _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
+    if out is None:
+        out = torch.empty(W.numel(), dtype=torch.float32, device=W.device)
+    _chk(out, torch.float32, "Bt", (W.numel(),))
+    with torch.cuda.device(W.device):
+        st = lib.mi355ppo_cnn_repack_weights_f32(_ptr(W), _ptr(out), layer, mode, _stream(W.device))
+    _lib.check(st, "mi355ppo_cnn_repack_weights_f32")
+    return out
+
+
+def conv_fwd(src: torch.Tensor, Bt: torch.Tensor, bias: torch.Tensor, layer: int, inds: torch.Tensor | None = None,
+             out: torch.Tensor | None = None) -> torch.Tensor:
+    """``relu(conv(src) + bias)``; layer 1 takes the uint8 rollout rows (+ optional int64 row gather)."""
+    lib = _lib.load()
+    cin, cout, k, _, hin, hout = LAYERS[layer]
+    if layer == 1:
+        _chk(src, torch.uint8, "src")
+        assert tuple(src.shape[1:]) == (hin, hin, cin), f"layer 1 source rows must be (84,84,4) uint8, got {tuple(src.shape)}"
+        images = src.shape[0] if inds is None else inds.numel()
+        if inds is not None:
+            _chk(inds, torch.int64, "inds")
+    else:
+        assert inds is None
+        images = src.shape[0]
+        _chk(src, torch.float32, "src", (images, hin, hin, cin))
+    _chk(Bt, torch.float32, "Bt", (cout * cin * k * k,))
+    _chk(bias, torch.float32, "bias", (cout,))
+    if out is None:
+        out = torch.empty((images, hout, hout, cout), dtype=torch.float32, device=src.device)
+    _chk(out, torch.float32, "out", (images, hout, hout, cout))
+    with torch.cuda.device(src.device):
+        st = lib.mi355ppo_cnn_conv_fwd_f32(_ptr(src), _ptr(inds), _ptr(Bt), _ptr(bias), _ptr(out), images, layer,
+                                           _stream(src.device))
+    _lib.check(st, "mi355ppo_cnn_conv_fwd_f32")
+    return out
+
+
+def conv_dgrad(dz: torch.Tensor, Bt: torch.Tensor, act_in: torch.Tensor, layer: int,
+               out: torch.Tensor | None = None) -> torch.Tensor:
+    """Gradient w.r.t. the layer's input activation, masked by ``act_in > 0`` (ReLU backward fused)."""
+    lib = _lib.load()
+    cin, cout, k, _, hin, hout = LAYERS[layer]
+    images = dz.shape[0]
+    _chk(dz, torch.float32, "dz", (images, hout, hout, cout))
+    _chk(act_in, torch.float32, "act_in", (images, hin, hin, cin))
+    _chk(Bt, torch.float32, "Bt", (cout * cin * k * k,))
+    if out is None:
+        out = torch.empty_like(act_in)
+    _chk(out, torch.float32, "out", (images, hin, hin, cin))
+    with torch.cuda.device(dz.device):
+        st = lib.mi355ppo_cnn_conv_dgrad_f32(_ptr(dz), _ptr(Bt), _ptr(act_in), _ptr(out), images, layer, _stream(dz.device))
+    _lib.check(st, "mi355ppo_cnn_conv_dgrad_f32")
+    return out
+
+
+def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tensor | None = None):
+    """``(dW (Cout,Cin,K,K), db (Cout))`` from the layer input and the pre-activation gradient."""
+    lib = _lib.load()
+    cin, cout, k, _, hin, hout = LAYERS[layer]
+    images = dz.shape[0]
+    _chk(dz, torch.float32, "dz", (images, hout, hout, cout))
+    if layer == 1:
+        _chk(src, torch.uint8, "src")
+        if inds is not None:
+            _chk(inds, torch.int64, "inds", (images,))
+        else:
+            assert src.shape[0] == images
+    else:
+        assert inds is None
+        _chk(src, torch.float32, "src", (images, hin, hin, cin))
+    dev = dz.device
+    dW = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
+    db = torch.empty(cout, dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.mi355ppo_cnn_conv_wgrad_workspace_bytes(images, layer))
+    with torch.cuda.device(dev):
+        st = lib.mi355ppo_cnn_conv_wgrad_f32(_ptr(src), _ptr(inds), _ptr(dz), _ptr(dW), _ptr(db), images, layer, _ptr(ws),
+                                             ws.numel(), _stream(dev))
+    _lib.check(st, "mi355ppo_cnn_conv_wgrad_f32")
+    return dW, db
+
+
+class _Buffers:
+    """Activation / gradient buffers reused across calls of one batch size (no allocator traffic in the loop)."""
+
+    def __init__(self):
+        self.by_m = {}
+
+    def get(self, m: int, dev, grads: bool):
+        key = (m, dev, grads)
+        b = self.by_m.get(key)
+        if b is None:
+            shapes = [(m, 20, 20, 32), (m, 9, 9, 64), (m, 7, 7, 64)]
+            b = [torch.empty(s, dtype=torch.float32, device=dev) for s in shapes]
+            self.by_m[key] = b
+        return b
+
+
+class NatureTrunkFn(torch.autograd.Function):
+    """a3 = relu(conv3(relu(conv2(relu(conv1(obs[inds] / 255)))))) as one autograd node; a3 is (M, 7, 7, 64)."""
+
+    @staticmethod
+    def forward(ctx, obs_u8, inds, W1, b1, W2, b2, W3, b3, bufs):
+        m = obs_u8.shape[0] if inds is None else inds.numel()
+        a1, a2, a3 = bufs.get(m, obs_u8.device, False)
+        bt1, bt2, bt3 = (repack_weights(W.detach(), l) for l, W in ((1, W1), (2, W2), (3, W3)))
+        conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1)
+        conv_fwd(a1, bt2, b2.detach(), 2, None, a2)
+        conv_fwd(a2, bt3, b3.detach(), 3, None, a3)
+        ctx.obs, ctx.inds, ctx.acts, ctx.bufs = obs_u8, inds, (a1, a2, a3), bufs
+        ctx.save_for_backward(W2, W3)
+        return a3
+
+    @staticmethod
+    def backward(ctx, da3):
+        W2, W3 = ctx.saved_tensors
+        a1, a2, a3 = ctx.acts
+        m = a3.shape[0]
+        dz1, dz2, _ = ctx.bufs.get(m, a3.device, True)
+        dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)        # ReLU backward of the last conv
+        dW3, db3 = conv_wgrad(a2, dz3, 3)
+        conv_dgrad(dz3, repack_weights(W3.detach(), 3, MODE_DGRAD_S1), a2, 3, dz2)
+        dW2, db2 = conv_wgrad(a1, dz2, 2)
+        conv_dgrad(dz2, repack_weights(W2.detach(), 2, MODE_DGRAD_S2), a1, 2, dz1)
+        dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds)
+        return None, None, dW1, db1, dW2, db2, dW3, db3, None
+
+
+class NatureTrunk:
+    """Callable wrapper owning the reusable buffers: ``trunk(obs_u8, inds, conv1, conv2, conv3) -> (M, 3136)`` with
+    features in (h, w, c) order (use ``fc_weight_hwc`` for the Linear that follows)."""
+
+    def __init__(self):
+        self.bufs = _Buffers()
+
+    def __call__(self, obs_u8, inds, conv1, conv2, conv3):
+        a3 = NatureTrunkFn.apply(obs_u8, inds, conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight,
+                                 conv3.bias, self.bufs)
+        return a3.reshape(a3.shape[0], -1)
+
+
+def fc_weight_hwc(weight: torch.Tensor) -> torch.Tensor:
+    """Linear(64*7*7, 512) weight with its input features re-ordered from the reference's flatten order (c, h, w)
+    to the trunk's (h, w, c); differentiable (the gradient flows back into the original layout)."""
+    return weight.view(weight.shape[0], 64, 7, 7).permute(0, 2, 3, 1).reshape(weight.shape[0], 64 * 7 * 7)

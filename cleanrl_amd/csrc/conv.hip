@@ -1,0 +1,520 @@
+// NatureCNN convolutions as f32-MFMA implicit GEMMs on channels-last tensors (gfx950).
+//
+// Replaces the conv stack of Agent.network (cleanrl/ppo_atari_multigpu.py:136-147: Conv2d(4,32,8,s4) ReLU
+// Conv2d(32,64,4,s2) ReLU Conv2d(64,64,3,s1) ReLU) -- forward, data gradient and weight gradient -- and fuses
+// into it what the reference runs as separate passes over the largest tensors of the update:
+//   * `b_obs[mb_inds]` + `x / 255.0` (:320,154): conv1 reads the uint8 rollout rows through mb_inds and
+//     converts in registers (the 3.7 GB f32 staging tensor of the K5 path is never written);
+//   * bias add + ReLU (epilogue of every forward kernel);
+//   * ReLU backward (epilogue mask of the data-gradient kernel that PRODUCES the gradient) and the bias
+//     gradient (side sum of the weight-gradient kernel).
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, exact f32 products with one rounding per
+// fma, 157 TFLOP/s chip peak (the same rate as the f32 vector unit).  No reduced precision anywhere.
+//
+// Kernel G (conv_gemm_kernel): C[m][n] = sum_k A[m][k] * Bt[n][k]
+//   m  = a destination pixel (img, gy, gx);  n = output channel;  k = (r, c, ch) tap-major, channel-minor.
+//   A[m][k] = src[img, gy*SS + OFF + r, gx*SS + OFF + c, ch] (0 outside the tensor): with channels-last
+//   storage a (pixel, r) pair is ONE contiguous run of KW*C elements, so the tile loader is a coalesced
+//   16-byte-per-lane stream with no im2col buffer.  The same kernel is the forward conv (SS = stride,
+//   OFF = 0), the stride-1 data gradient (OFF = -(K-1), flipped weights) and the stride-2 data gradient
+//   (four parity classes of destination pixels, each a 2x2-tap stride-1 problem with its own weight matrix).
+//   256 threads own a 128-pixel x BN-channel tile; K is walked in 32-element stages through a double-buffered
+//   LDS ring (row stride 36 floats: the ds_read_b128 fragment reads and ds_write_b128 stage writes are
+//   bank-conflict free); wave w multiplies pixels [32w, 32w+32) by all BN channels.
+//   An MFMA k-pair is {kk*8 + e, kk*8 + 4 + e}: lanes 0-31 / 32-63 each fetch FOUR consecutive k with one
+//   ds_read_b128 (A and B use the same k permutation, so the product is unchanged).
+//
+// Kernel W (conv_wgrad_kernel): dWt[n][k] = sum_m dz[m][n] * A[m][k]; a persistent workgroup stages one
+//   image (source + dz) in LDS at a time, keeps the WHOLE dWt tile set in accumulators (Cout x K / 1024
+//   MFMA tiles per wave), reads the patches straight out of the staged image (implicit im2col in LDS) and
+//   writes one partial per workgroup; conv_wgrad_reduce sums the partials in a fixed order (deterministic)
+//   and scatters into torch's (Cout, Cin, KH, KW) layout.
+#include "common.h"
+
+namespace mi355ppo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvGeom {
+    int H, W, C;          // source tensor per image: (H, W, C) channels-last
+    int KH, KW;           // taps
+    int GY, GX;           // destination grid enumerated by the GEMM rows (per image GY*GX rows)
+    int SS, OFF;          // source y = gy*SS + OFF + r, x = gx*SS + OFF + c
+    int DH, DW, DC;       // destination tensor per image (DH, DW, DC); DC = channels per pixel (row stride)
+    int DM, DAY, DAX;     // destination pixel = (gy*DM + DAY, gx*DM + DAX)
+    int K;                // KH*KW*C
+    int N;                // output channels computed (== BN)
+    int classes;          // 1, or 4 = stride-2 data-gradient parity classes (blockIdx.y)
+    int logC;             // log2(C) (f32 sources)
+    long long P;          // total GEMM rows = images * GY * GX
+};
+
+__device__ __forceinline__ float u8_div255_c(float x) {   // correctly rounded x/255 (see obs.hip)
+    const float r = 1.0f / 255.0f;
+    const float q = x * r;
+    const float e = __builtin_fmaf(-q, 255.0f, x);
+    return __builtin_fmaf(e, r, q);
+}
+
+constexpr int kBM = 128;      // pixels per workgroup tile
+constexpr int kBK = 32;       // k elements per stage
+constexpr int kLd = 36;       // LDS row stride in floats (32 + 4 pad)
+
+enum { EPI_BIAS_RELU = 0, EPI_MASK = 1, EPI_RAW = 2 };
+
+template <int BN, bool U8IN, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const void* __restrict__ src_v,
+                                                           const int64_t* __restrict__ inds,
+                                                           const float* __restrict__ Bt_all,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ mask_src,
+                                                           float* __restrict__ dst, ConvGeom g) {
+    constexpr int NJT = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[2][kBM * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLd];
+    __shared__ long long s_dstoff[kBM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int cls = blockIdx.y;
+    const float* __restrict__ Bt = Bt_all + (size_t)cls * BN * g.K;
+    const int day = g.classes == 4 ? (cls >> 1) : g.DAY;
+    const int dax = g.classes == 4 ? (cls & 1) : g.DAX;
+    const long long tile0 = (long long)blockIdx.x * kBM;
+    const int per_img = g.GY * g.GX;
+
+    // destination offsets of the tile's 128 rows (element index of channel 0), -1 = beyond P
+    if (tid < kBM) {
+        const long long p = tile0 + tid;
+        long long off = -1;
+        if (p < g.P) {
+            const long long img = p / per_img;
+            const int rem = (int)(p - img * per_img);
+            const int gy = rem / g.GX, gx = rem - gy * g.GX;
+            off = ((img * g.DH + (gy * g.DM + day)) * g.DW + (gx * g.DM + dax)) * (long long)g.DC;
+        }
+        s_dstoff[tid] = off;
+    }
+
+    // this thread's four A rows: lrow + 32*q
+    const int lrow = tid >> 3, c4 = tid & 7;
+    long long abase[4];
+    int asy[4], asx[4];
+    bool arow_ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long p = tile0 + lrow + 32 * q;
+        arow_ok[q] = p < g.P;
+        const long long pp = arow_ok[q] ? p : 0;
+        const long long img = pp / per_img;
+        const int rem = (int)(pp - img * per_img);
+        const int gy = rem / g.GX, gx = rem - gy * g.GX;
+        asy[q] = gy * g.SS + g.OFF;
+        asx[q] = gx * g.SS + g.OFF;
+        const long long simg = (U8IN && inds) ? inds[img] : img;
+        abase[q] = ((simg * g.H + asy[q]) * g.W + asx[q]) * (long long)g.C;
+    }
+    const int runlen = g.KW * g.C;
+    const int rowpitch = g.W * g.C;
+    const int nstages = g.K / kBK;
+
+    float4 areg[4];
+    float4 breg[NJT];
+    int st_r = 0, st_rem = 0;    // position of the NEXT stage to load: tap row r, offset within the run
+
+    auto load_stage = [&](int s) {
+        const int k0 = s * kBK;
+        const int cx = U8IN ? 0 : (st_rem >> g.logC);     // tap column of this stage (f32 sources: one pixel per stage)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long off = abase[q] + (long long)st_r * rowpitch + st_rem + c4 * 4;
+            if (U8IN) {
+                uint32_t w = 0;
+                if (arow_ok[q]) w = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(src_v) + off);
+                areg[q].x = u8_div255_c((float)(w & 0xffu));
+                areg[q].y = u8_div255_c((float)((w >> 8) & 0xffu));
+                areg[q].z = u8_div255_c((float)((w >> 16) & 0xffu));
+                areg[q].w = u8_div255_c((float)(w >> 24));
+            } else {
+                const int sy = asy[q] + st_r, sx = asx[q] + cx;
+                const bool ok = arow_ok[q] && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
+                areg[q] = ok ? *reinterpret_cast<const float4*>(static_cast<const float*>(src_v) + off)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+            breg[jt] = *reinterpret_cast<const float4*>(Bt + (size_t)(lrow + 32 * jt) * g.K + k0 + c4 * 4);
+        st_rem += kBK;
+        if (st_rem == runlen) { st_rem = 0; ++st_r; }
+    };
+    auto write_stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * q) * kLd + c4 * 4]) = areg[q];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+            *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * jt) * kLd + c4 * 4]) = breg[jt];
+    };
+
+    f32x16 acc[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[jt][e] = 0.0f;
+
+    load_stage(0);
+    write_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstages) load_stage(s + 1);
+        const float* __restrict__ Ap = &As[buf][(32 * wave + li) * kLd + 4 * lh];
+        const float* __restrict__ Bp = &Bs[buf][li * kLd + 4 * lh];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 a = *reinterpret_cast<const float4*>(Ap + kk * 8);
+            float4 b[NJT];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) b[jt] = *reinterpret_cast<const float4*>(Bp + jt * 32 * kLd + kk * 8);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[jt].x, acc[jt], 0, 0, 0);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[jt].y, acc[jt], 0, 0, 0);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[jt].z, acc[jt], 0, 0, 0);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[jt].w, acc[jt], 0, 0, 0);
+        }
+        if (s + 1 < nstages) write_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[row = (e&3) + 8*(e>>2) + 4*lh][col = li]
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const int n = jt * 32 + li;
+        const float bv = (EPI == EPI_BIAS_RELU) ? bias[n] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const long long off = s_dstoff[row];
+            if (off >= 0) {
+                float v = acc[jt][e];
+                if (EPI == EPI_BIAS_RELU) {
+                    v = v + bv;
+                    v = v > 0.0f ? v : 0.0f;          // torch.relu / clamp_min(0): NaN propagates either way
+                } else if (EPI == EPI_MASK) {
+                    v = mask_src[off + n] > 0.0f ? v : 0.0f;   // ReLU backward: grad * (out > 0)
+                }
+                dst[off + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+struct WgradGeom {
+    int H, W, C;       // source per image
+    int KH, KW, SS;    // taps, stride (no padding)
+    int GY, GX;        // dz grid per image
+    int N;             // Cout
+    int K;             // KH*KW*C
+    int images;
+    int src_bytes;     // bytes of one source image as stored (u8: H*W*C, f32: 4*H*W*C)
+};
+
+// NCI = Cout/32 (1 or 2); TPW = MFMA tiles per wave = (N/32)*(K/32)/4.
+template <int NCI, int TPW, bool U8IN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const void* __restrict__ src_v,
+                                                            const int64_t* __restrict__ inds,
+                                                            const float* __restrict__ dz,
+                                                            float* __restrict__ part_w,     // [grid][N][K]
+                                                            float* __restrict__ part_b,     // [grid][N]
+                                                            WgradGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int npix = g.GY * g.GX;
+    const int npairs = (npix + 1) >> 1;
+    // layout: [src image][dz image: (2*npairs) x N floats][pixbase: 2*npairs ints][bias scratch 256 float4]
+    unsigned char* s_src = smem;
+    float* s_dz = reinterpret_cast<float*>(smem + ((g.src_bytes + 15) & ~15));
+    int* s_pixbase = reinterpret_cast<int*>(s_dz + (size_t)2 * npairs * g.N);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ci = wave % NCI, jgroup = wave / NCI;
+
+    for (int p = tid; p < 2 * npairs; p += 256) {
+        int v = 0;
+        if (p < npix) {
+            const int gy = p / g.GX, gx = p - gy * g.GX;
+            v = ((gy * g.SS) * g.W + gx * g.SS) * g.C;
+        }
+        s_pixbase[p] = v;
+    }
+    // zero the pad pixel of dz once (odd pixel counts)
+    for (int e = npix * g.N + tid; e < 2 * npairs * g.N; e += 256) s_dz[e] = 0.0f;
+
+    // patch offsets of this wave's tiles (element offset inside the staged source image)
+    const int runlen = g.KW * g.C, rowpitch = g.W * g.C;
+    int patch_off[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int e0 = (jgroup * TPW + t) * 32;
+        patch_off[t] = (e0 / runlen) * rowpitch + (e0 % runlen) + li;
+    }
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int dz4 = npix * g.N / 4;            // float4 per dz image
+    const int src16 = g.src_bytes / 16;        // 16-byte chunks per source image
+    for (int img = blockIdx.x; img < g.images; img += gridDim.x) {
+        __syncthreads();                       // previous image fully consumed
+        const long long simg = (U8IN && inds) ? inds[img] : img;
+        const uint4* gsrc = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(src_v) + simg * (long long)g.src_bytes);
+        for (int e = tid; e < src16; e += 256) reinterpret_cast<uint4*>(s_src)[e] = gsrc[e];
+        const float4* gdz = reinterpret_cast<const float4*>(dz + (long long)img * npix * g.N);
+        for (int e = tid; e < dz4; e += 256) {
+            const float4 v = gdz[e];
+            reinterpret_cast<float4*>(s_dz)[e] = v;
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+        }
+        __syncthreads();
+        for (int pr = 0; pr < npairs; ++pr) {
+            const int p = 2 * pr + lh;
+            const float a = s_dz[p * g.N + ci * 32 + li];
+            const int pb = s_pixbase[p];
+            float b[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                if (U8IN) b[t] = u8_div255_c((float)s_src[pb + patch_off[t]]);
+                else b[t] = reinterpret_cast<const float*>(s_src)[pb + patch_off[t]];
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+        }
+    }
+
+    // partial weights: D[row i = cout within ci][col j = patch element within tile]
+    float* pw = part_w + (size_t)blockIdx.x * g.N * g.K;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int kcol = (jgroup * TPW + t) * 32 + li;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = ci * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            pw[(size_t)n * g.K + kcol] = acc[t][e];
+        }
+    }
+    // partial bias gradient: thread t always loaded channels (4t % N) .. +3
+    __syncthreads();
+    float4* s_b = reinterpret_cast<float4*>(s_dz);     // reuse (256 float4 = 4 KiB <= dz image)
+    s_b[tid] = bsum;
+    __syncthreads();
+    if (tid < g.N) {
+        const int grp = tid >> 2, comp = tid & 3, ngrp = g.N >> 2;
+        float s = 0.0f;
+        for (int t = grp; t < 256; t += ngrp) s += reinterpret_cast<const float*>(&s_b[t])[comp];
+        part_b[(size_t)blockIdx.x * g.N + tid] = s;
+    }
+}
+
+// dW (torch layout (N, C, KH, KW)) and db from the per-workgroup partials, fixed summation order.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ part_w, const float* __restrict__ part_b,
+                                                         int nparts, int N, int C, int KH, int KW,
+                                                         float* __restrict__ dW, float* __restrict__ db) {
+    const int K = KH * KW * C;
+    const int e = blockIdx.x * 256 + threadIdx.x;     // index into [N][K] (tap-major, channel-minor)
+    if (e < N * K) {
+        float s = 0.0f;
+        for (int p = 0; p < nparts; ++p) s += part_w[(size_t)p * N * K + e];
+        const int n = e / K, k = e - n * K;
+        const int r = k / (KW * C), rem = k - r * (KW * C), c = rem / C, ch = rem - c * C;
+        dW[((n * C + ch) * KH + r) * KW + c] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < N && db) {
+        float s = 0.0f;
+        for (int p = 0; p < nparts; ++p) s += part_b[(size_t)p * N + threadIdx.x];
+        db[threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ weight repack
+// mode 0 (forward):           Bt[n=cout][(r,c,cin)]          = W[cout][cin][r][c]
+// mode 1 (dgrad, stride 1):   Bt[n=cin][(r,c,cout)]          = W[cout][cin][KH-1-r][KW-1-c]
+// mode 2 (dgrad, stride 2):   Bt[cls][n=cin][(r,c,cout)]     = W[cout][cin][ph+2-2r][pw+2-2c], cls = 2*ph+pw, r,c in {0,1}
+__global__ __launch_bounds__(256) void conv_repack_kernel(const float* __restrict__ W, float* __restrict__ Bt, int Cout,
+                                                          int Cin, int KH, int KW, int mode) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (mode == 0) {
+        const int K = KH * KW * Cin;
+        if (e >= Cout * K) return;
+        const int n = e / K, k = e - n * K;
+        const int r = k / (KW * Cin), rem = k - r * (KW * Cin), c = rem / Cin, ch = rem - c * Cin;
+        Bt[e] = W[((n * Cin + ch) * KH + r) * KW + c];
+    } else if (mode == 1) {
+        const int K = KH * KW * Cout;
+        if (e >= Cin * K) return;
+        const int n = e / K, k = e - n * K;
+        const int r = k / (KW * Cout), rem = k - r * (KW * Cout), c = rem / Cout, co = rem - c * Cout;
+        Bt[e] = W[((co * Cin + n) * KH + (KH - 1 - r)) * KW + (KW - 1 - c)];
+    } else {
+        const int K = 4 * Cout;                      // 2x2 taps
+        if (e >= 4 * Cin * K) return;
+        const int cls = e / (Cin * K), e2 = e - cls * (Cin * K);
+        const int n = e2 / K, k = e2 - n * K;
+        const int r = k / (2 * Cout), rem = k - r * (2 * Cout), c = rem / Cout, co = rem - c * Cout;
+        const int ph = cls >> 1, pw = cls & 1;
+        Bt[e] = W[((co * Cin + n) * KH + (ph + 2 - 2 * r)) * KW + (pw + 2 - 2 * c)];
+    }
+}
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+}  // namespace mi355ppo
+
+using namespace mi355ppo;
+
+// layer: 1 = Conv2d(4,32,8,s4) on 84x84, 2 = Conv2d(32,64,4,s2) on 20x20, 3 = Conv2d(64,64,3,s1) on 9x9
+static bool layer_dims(int layer, int* Cin, int* Cout, int* KH, int* SS, int* Hin, int* Hout) {
+    switch (layer) {
+        case 1: *Cin = 4; *Cout = 32; *KH = 8; *SS = 4; *Hin = 84; *Hout = 20; return true;
+        case 2: *Cin = 32; *Cout = 64; *KH = 4; *SS = 2; *Hin = 20; *Hout = 9; return true;
+        case 3: *Cin = 64; *Cout = 64; *KH = 3; *SS = 1; *Hin = 9; *Hout = 7; return true;
+    }
+    return false;
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, float* Bt, int layer, int mode, void* stream) {
+    const char* fn = "mi355ppo_cnn_repack_weights_f32";
+    int Cin, Cout, KH, SS, Hin, Hout;
+    MI355_REQUIRE(W && Bt, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
+    MI355_REQUIRE(mode == 0 || (mode == 1 && layer == 3) || (mode == 2 && layer == 2), MI355PPO_EINVAL,
+                  "%s: mode %d is not defined for layer %d", fn, mode, layer);
+    const int total = Cout * Cin * KH * KH;
+    hipLaunchKernelGGL(conv_repack_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), W, Bt, Cout, Cin, KH,
+                       KH, mode);
+    return check_launch("conv_repack_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds, const float* Bt, const float* bias,
+                                                      float* dst, int64_t images, int layer, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_fwd_f32";
+    int Cin, Cout, KH, SS, Hin, Hout;
+    MI355_REQUIRE(src && Bt && bias && dst, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
+    MI355_REQUIRE(images > 0 && images <= (1 << 24), MI355PPO_EINVAL, "%s: images=%lld out of range", fn, (long long)images);
+    MI355_REQUIRE(layer == 1 || inds == nullptr, MI355PPO_EINVAL, "%s: inds (row gather) is only defined for layer 1", fn);
+    MI355_REQUIRE(aligned(src, 16) && aligned(Bt, 16) && aligned(dst, 16) && aligned(inds, 8), MI355PPO_EALIGN,
+                  "%s: src/Bt/dst must be 16-byte aligned", fn);
+    ConvGeom g;
+    g.H = g.W = Hin; g.C = Cin; g.KH = g.KW = KH; g.GY = g.GX = Hout; g.SS = SS; g.OFF = 0;
+    g.DH = g.DW = Hout; g.DC = Cout; g.DM = 1; g.DAY = g.DAX = 0; g.K = KH * KH * Cin; g.N = Cout; g.classes = 1;
+    g.logC = ilog2(Cin); g.P = (long long)images * Hout * Hout;
+    const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 1);
+    hipStream_t s = as_stream(stream);
+    if (layer == 1)
+        hipLaunchKernelGGL((conv_gemm_kernel<32, true, EPI_BIAS_RELU>), grid, dim3(256), 0, s, src, inds, Bt, bias,
+                           (const float*)nullptr, dst, g);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<64, false, EPI_BIAS_RELU>), grid, dim3(256), 0, s, src, inds, Bt, bias,
+                           (const float*)nullptr, dst, g);
+    return check_launch("conv_gemm_kernel(fwd)");
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32(const float* dz, const float* Bt, const float* act_in, float* dsrc,
+                                                        int64_t images, int layer, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_dgrad_f32";
+    int Cin, Cout, KH, SS, Hin, Hout;
+    MI355_REQUIRE(dz && Bt && act_in && dsrc, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE((layer == 2 || layer == 3) && layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL,
+                  "%s: layer=%d must be 2 or 3 (conv1's input needs no gradient)", fn, layer);
+    MI355_REQUIRE(images > 0 && images <= (1 << 24), MI355PPO_EINVAL, "%s: images=%lld out of range", fn, (long long)images);
+    MI355_REQUIRE(aligned(dz, 16) && aligned(Bt, 16) && aligned(act_in, 16) && aligned(dsrc, 16), MI355PPO_EALIGN,
+                  "%s: pointers must be 16-byte aligned", fn);
+    ConvGeom g;
+    g.H = g.W = Hout; g.C = Cout;                  // the "source" of this GEMM is dz: (Hout, Hout, Cout)
+    g.DH = g.DW = Hin; g.DC = Cin; g.N = Cin; g.logC = ilog2(Cout);
+    hipStream_t s = as_stream(stream);
+    if (layer == 3) {
+        g.KH = g.KW = 3; g.GY = g.GX = Hin; g.SS = 1; g.OFF = -2; g.DM = 1; g.DAY = g.DAX = 0; g.classes = 1;
+        g.K = 9 * Cout; g.P = (long long)images * Hin * Hin;
+        const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 1);
+        hipLaunchKernelGGL((conv_gemm_kernel<64, false, EPI_MASK>), grid, dim3(256), 0, s, (const void*)dz,
+                           (const int64_t*)nullptr, Bt, (const float*)nullptr, act_in, dsrc, g);
+    } else {
+        g.KH = g.KW = 2; g.GY = g.GX = Hin / 2; g.SS = 1; g.OFF = -1; g.DM = 2; g.DAY = g.DAX = 0; g.classes = 4;
+        g.K = 4 * Cout; g.P = (long long)images * (Hin / 2) * (Hin / 2);
+        const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 4);
+        hipLaunchKernelGGL((conv_gemm_kernel<32, false, EPI_MASK>), grid, dim3(256), 0, s, (const void*)dz,
+                           (const int64_t*)nullptr, Bt, (const float*)nullptr, act_in, dsrc, g);
+    }
+    return check_launch("conv_gemm_kernel(dgrad)");
+}
+
+static size_t wgrad_smem(int src_bytes, int npix, int N) {
+    const int npairs = (npix + 1) / 2;
+    return (size_t)((src_bytes + 15) & ~15) + (size_t)2 * npairs * N * 4 + (size_t)2 * npairs * 4;
+}
+static int wgrad_grid(int64_t images) { return images < 512 ? (int)images : 512; }
+
+extern "C" MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t images, int layer) {
+    int Cin, Cout, KH, SS, Hin, Hout;
+    if (images <= 0 || !layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout)) return 0;
+    return (size_t)wgrad_grid(images) * ((size_t)Cout * KH * KH * Cin + Cout) * sizeof(float);
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW,
+                                                        float* db, int64_t images, int layer, void* workspace,
+                                                        size_t workspace_bytes, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_wgrad_f32";
+    int Cin, Cout, KH, SS, Hin, Hout;
+    MI355_REQUIRE(src && dz && dW && db, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
+    MI355_REQUIRE(images > 0 && images <= (1 << 24), MI355PPO_EINVAL, "%s: images=%lld out of range", fn, (long long)images);
+    MI355_REQUIRE(layer == 1 || inds == nullptr, MI355PPO_EINVAL, "%s: inds (row gather) is only defined for layer 1", fn);
+    const size_t need = mi355ppo_cnn_conv_wgrad_workspace_bytes(images, layer);
+    MI355_REQUIRE(workspace && workspace_bytes >= need, MI355PPO_EWORKSPACE, "%s: workspace %zu bytes < required %zu", fn,
+                  workspace ? workspace_bytes : (size_t)0, need);
+    MI355_REQUIRE(aligned(src, 16) && aligned(dz, 16) && aligned(dW, 4) && aligned(db, 4) && aligned(workspace, 16) &&
+                      aligned(inds, 8), MI355PPO_EALIGN, "%s: src/dz/workspace must be 16-byte aligned", fn);
+    WgradGeom g;
+    g.H = g.W = Hin; g.C = Cin; g.KH = g.KW = KH; g.SS = SS; g.GY = g.GX = Hout; g.N = Cout; g.K = KH * KH * Cin;
+    g.images = (int)images; g.src_bytes = Hin * Hin * Cin * (layer == 1 ? 1 : 4);
+    const int grid = wgrad_grid(images);
+    float* part_w = static_cast<float*>(workspace);
+    float* part_b = part_w + (size_t)grid * Cout * g.K;
+    const size_t smem = wgrad_smem(g.src_bytes, Hout * Hout, Cout);
+    hipStream_t s = as_stream(stream);
+    hipError_t e = hipSuccess;
+    if (layer == 1) {
+        auto k = conv_wgrad_kernel<1, 2, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
+    } else if (layer == 2) {
+        auto k = conv_wgrad_kernel<2, 8, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
+    } else {
+        auto k = conv_wgrad_kernel<2, 9, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
+    }
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(%zu bytes of LDS): %s", fn, smem, hipGetErrorString(e));
+        return MI355PPO_EHIP;
+    }
+    int rc = check_launch("conv_wgrad_kernel");
+    if (rc) return rc;
+    const int total = Cout * g.K;
+    hipLaunchKernelGGL(conv_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, part_w, part_b, grid, Cout, Cin, KH, KH,
+                       dW, db);
+    return check_launch("conv_wgrad_reduce");
+}

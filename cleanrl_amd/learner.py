@@ -67,6 +67,10 @@ class PPOLearner:
         # channels-last f32 activations and the conv stack runs without any layout transposes.
         obs_dtype = torch.uint8 if (self.image and self.hip) else torch.float32
         self.nhwc = self.image and self.hip
+        # NatureCNN convolutions on the f32-MFMA kernels (cnn.py); MI355PPO_CNN=miopen keeps torch's Conv2d (MIOpen)
+        # behind the K5 gather+convert kernel -- same results within f32 round-off, used for A/B timing.
+        self.fused_cnn = (self.nhwc and hasattr(agent, "heads_u8") and tuple(obs_space.shape) == (4, 84, 84)
+                          and os.environ.get("MI355PPO_CNN", "mfma") != "miopen")
         self.frame_shape = self.obs_shape                                   # what the env delivers: (C,H,W)
         if self.nhwc:
             c, h, w = self.obs_shape
@@ -91,7 +95,7 @@ class PPOLearner:
             # device staging for incoming channel-planar frames (H2D target / device-env output)
             self.stage_obs = torch.zeros((N,) + self.frame_shape, dtype=obs_dtype, device=device) if self.nhwc else None
             self._pin_rd = torch.zeros((2, N), dtype=torch.float32).pin_memory()
-            self._x_roll = torch.empty((N,) + self.obs_shape, device=device) if self.image else None
+            self._x_roll = torch.empty((N,) + self.obs_shape, device=device) if (self.image and not self.fused_cnn) else None
             self._x_mb = None
             n_upd = int(args.update_epochs) * int(args.num_minibatches)
             self._scalars = torch.zeros((n_upd, 7), device=device)
@@ -140,6 +144,12 @@ class PPOLearner:
         self.obs[0].copy_(self.boot_obs)
         self.dones[0].copy_(self.boot_done)
 
+    def _heads_rollout(self, obs_rows):
+        """Policy/value heads on one slot of the rollout buffer (HIP path)."""
+        if self.image and self.fused_cnn:
+            return self.agent.heads_u8(obs_rows)
+        return self.agent.heads(self._features(obs_rows))
+
     def _features(self, obs_rows):
         """uint8 image rows -> normalised f32 (K5, no gather); other observations pass through."""
         if self.image and self.hip:
@@ -152,9 +162,8 @@ class PPOLearner:
     @torch.no_grad()
     def act(self, step: int):
         """Action logic (:262-266): network forward on ``obs[step]``, sample, store action / logprob / value."""
-        x = self._features(self.obs[step])
         if self.hip:
-            p, value = self.agent.heads(x)
+            p, value = self._heads_rollout(self.obs[step])
             seed, off = self.agent.rng.next()
             if self.discrete:
                 a64, _, _, _ = self.ops.categorical_sample(p.contiguous(), seed=seed, offset=off,
@@ -187,7 +196,7 @@ class PPOLearner:
         """Bootstrap value of the observation in the bootstrap slot, then GAE (:288-301)."""
         a = self.args
         if self.hip:
-            _, next_value = self.agent.heads(self._features(self.boot_obs))
+            _, next_value = self._heads_rollout(self.boot_obs)
             self.ops.gae(self.rewards, self.dones, self.values, self.boot_done, next_value.reshape(-1).contiguous(),
                          a.gamma, a.gae_lambda, self.advantages, self.returns)
         else:
@@ -256,13 +265,16 @@ class PPOLearner:
         """K5 gather -> network forward -> K3 fused loss fwd+bwd -> autograd through the network only (:320-358).
         Gradients land in the persistent flat buffer (``.grad`` of every parameter is a view of it)."""
         a, ops = self.args, self.ops
-        if self.image:
-            if self._x_mb is None or self._x_mb.shape[0] != idx.numel():
-                self._x_mb = torch.empty((idx.numel(),) + self.obs_shape, device=self.device)
-            x = ops.obs_u8_to_f32(b_obs, idx, self._x_mb).permute(0, 3, 1, 2)   # K5: b_obs[mb_inds] ; x / 255.0
+        if self.image and self.fused_cnn:
+            p, value = self.agent.heads_u8(b_obs, idx)                    # :320 gather + /255 fused into conv1
         else:
-            x = b_obs.index_select(0, idx)
-        p, value = self.agent.heads(x)                                    # :320 network forward
+            if self.image:
+                if self._x_mb is None or self._x_mb.shape[0] != idx.numel():
+                    self._x_mb = torch.empty((idx.numel(),) + self.obs_shape, device=self.device)
+                x = ops.obs_u8_to_f32(b_obs, idx, self._x_mb).permute(0, 3, 1, 2)   # K5: b_obs[mb_inds] ; x / 255.0
+            else:
+                x = b_obs.index_select(0, idx)
+            p, value = self.agent.heads(x)                                # :320 network forward
         value = value.view(-1)
         if self.discrete:
             _, dp, dvalue = ops.ppo_loss_categorical(p.detach().contiguous(), value.detach().contiguous(), idx, b_actions,

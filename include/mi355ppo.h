@@ -199,6 +199,45 @@ MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_
                            double beta1, double beta2, double eps, int64_t step,
                            float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * CNN  NatureCNN convolution stack (Agent.network convs, cleanrl/ppo_atari_multigpu.py:136-142) as
+ * f32-MFMA implicit GEMMs on channels-last tensors: forward with fused uint8 gather + /255 + bias +
+ * ReLU, data gradient with the ReLU-backward mask fused, weight + bias gradient.  f32 in, f32
+ * accumulate (v_mfma_f32_32x32x2_f32): same precision class as the reference's f32 convolutions;
+ * results differ from a CPU/MIOpen convolution only by summation order (tolerance in
+ * tests/test_gpu_cnn.py).
+ *   layer 1: Conv2d(4,32,8,stride 4)  on (84,84,4)  -> (20,20,32)
+ *   layer 2: Conv2d(32,64,4,stride 2) on (20,20,32) -> (9,9,64)
+ *   layer 3: Conv2d(64,64,3,stride 1) on (9,9,64)   -> (7,7,64)
+ * Activations are (images, H, W, C) row-major ("NHWC").  Weights enter the kernels as repacked
+ * matrices Bt (produced by mi355ppo_cnn_repack_weights_f32 from torch's (Cout,Cin,KH,KW) tensor):
+ *   mode 0  forward / weight-gradient order  Bt[Cout][(kh,kw,cin)]
+ *   mode 1  layer-3 data gradient            Bt[Cin][(r,c,cout)]   (taps flipped)
+ *   mode 2  layer-2 data gradient            Bt[4][Cin][(r,c,cout)] (one 2x2-tap matrix per parity class)
+ * every Bt has Cout*Cin*KH*KW floats.
+ */
+MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, float* Bt, int layer, int mode, void* stream);
+
+/* dst = relu(conv(src) + bias).  layer 1: src is the uint8 rollout buffer (rows_total, 84,84,4) and
+ * `inds` (images) int64 optionally gathers rows (b_obs[mb_inds]); the /255 is applied in registers,
+ * correctly rounded.  layers 2,3: src is f32, inds must be NULL. */
+MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds, const float* Bt, const float* bias,
+                                           float* dst, int64_t images, int layer, void* stream);
+
+/* dsrc = conv_transpose(dz) * (act_in > 0): gradient w.r.t. the layer's INPUT activation act_in
+ * (itself a ReLU output), i.e. the pre-activation gradient of the previous layer.  layer = 2 or 3;
+ * Bt in mode 2 / mode 1. */
+MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32(const float* dz, const float* Bt, const float* act_in, float* dsrc,
+                                             int64_t images, int layer, void* stream);
+
+/* dW (torch layout (Cout,Cin,KH,KW)) and db (Cout) from the layer input `src` (layer 1: uint8 + inds
+ * as above) and the pre-activation gradient dz (images, Hout, Wout, Cout).  Overwrites dW / db.
+ * Deterministic: per-workgroup partials in `workspace`, summed in a fixed order. */
+MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t images, int layer);
+MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW, float* db,
+                                             int64_t images, int layer, void* workspace, size_t workspace_bytes,
+                                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

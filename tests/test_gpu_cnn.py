@@ -1,0 +1,151 @@
+"""Parity of the f32-MFMA NatureCNN kernels (csrc/conv.hip) with a float64 CPU convolution of the reference's
+conv stack (cleanrl/ppo_atari_multigpu.py:136-142).  Tolerance: the kernels are f32-in / f32-accumulate, so results
+differ from the float64 truth by f32 summation round-off only: |err| <= 2e-5 * max|ref| (K <= 576 terms; measured
+~1e-6) -- the same class as torch's own f32 convolution, which is checked against the same bound for calibration."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from cleanrl_amd import cnn, synthetic
+
+DEV = torch.device("cuda:0")
+SPEC = {1: (4, 32, 8, 4, 84, 20), 2: (32, 64, 4, 2, 20, 9), 3: (64, 64, 3, 1, 9, 7)}
+
+
+def _close(got, ref, what, tol=2e-5):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale + 1e-30, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / max(scale, 1e-30):.2e})"
+
+
+def _params(layer, seed):
+    cin, cout, k, _, _, _ = SPEC[layer]
+    g = torch.Generator().manual_seed(seed)
+    W = torch.randn(cout, cin, k, k, generator=g) * (1.0 / np.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g) * 0.1
+    return W, b
+
+
+def _nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("layer,mode", [(1, 0), (2, 0), (3, 0), (3, 1), (2, 2)])
+def test_repack_layouts(layer, mode):
+    cin, cout, k, _, _, _ = SPEC[layer]
+    W = torch.arange(cout * cin * k * k, dtype=torch.float32).reshape(cout, cin, k, k)   # asymmetric on purpose
+    got = cnn.repack_weights(W.to(DEV), layer, mode).cpu()
+    if mode == 0:
+        ref = W.permute(0, 2, 3, 1).reshape(-1)                                # [cout][(kh,kw,cin)]
+    elif mode == 1:
+        ref = W.flip(2, 3).permute(1, 2, 3, 0).reshape(-1)                     # [cin][(r,c,cout)], taps flipped
+    else:
+        parts = []
+        for ph in (0, 1):
+            for pw in (0, 1):
+                sub = W[:, :, [ph + 2, ph], :][:, :, :, [pw + 2, pw]]           # r=0 -> kh=ph+2, r=1 -> kh=ph
+                parts.append(sub.permute(1, 2, 3, 0).reshape(-1))
+        ref = torch.cat(parts)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("images", [1, 37, 256])
+def test_conv1_fwd_u8_gather(images):
+    frames = torch.from_numpy(synthetic.atari_frames(images + 5, seed=3))            # (R,4,84,84) uint8
+    rows = _nhwc(frames).to(DEV)
+    inds = torch.from_numpy(np.random.RandomState(0).randint(0, images + 5, size=images)).to(DEV)
+    W, b = _params(1, 1)
+    ref = F.relu(F.conv2d(frames[inds.cpu()].double() / 255.0, W.double(), b.double(), stride=4))
+    got = cnn.conv_fwd(rows, cnn.repack_weights(W.to(DEV), 1), b.to(DEV), 1, inds)
+    _close(got, _nhwc(ref), "conv1 fwd (gather)")
+    got2 = cnn.conv_fwd(rows[:images].contiguous(), cnn.repack_weights(W.to(DEV), 1), b.to(DEV), 1, None)
+    ref2 = F.relu(F.conv2d(frames[:images].double() / 255.0, W.double(), b.double(), stride=4))
+    _close(got2, _nhwc(ref2), "conv1 fwd (identity rows)")
+    # calibration: torch's own f32 GPU convolution meets the same bound
+    t32 = F.relu(F.conv2d((frames[:images].float() / 255.0).to(DEV), W.to(DEV), b.to(DEV), stride=4))
+    _close(_nhwc(t32), _nhwc(ref2), "torch f32 conv1 (calibration)")
+
+
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("images", [1, 19, 128])
+def test_conv_fwd_f32(layer, images):
+    cin, cout, k, s, hin, hout = SPEC[layer]
+    g = torch.Generator().manual_seed(10 + layer)
+    x = torch.relu(torch.randn(images, cin, hin, hin, generator=g))
+    W, b = _params(layer, 2)
+    ref = F.relu(F.conv2d(x.double(), W.double(), b.double(), stride=s))
+    got = cnn.conv_fwd(_nhwc(x).to(DEV), cnn.repack_weights(W.to(DEV), layer), b.to(DEV), layer)
+    assert got.shape == (images, hout, hout, cout)
+    _close(got, _nhwc(ref), f"conv{layer} fwd")
+
+
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("images", [1, 19, 128])
+def test_conv_dgrad_with_relu_mask(layer, images):
+    cin, cout, k, s, hin, hout = SPEC[layer]
+    g = torch.Generator().manual_seed(20 + layer)
+    pre = torch.randn(images, cin, hin, hin, generator=g).double().requires_grad_(True)
+    act = torch.relu(pre)                                                            # the layer's input activation
+    W, _ = _params(layer, 3)
+    dz = torch.randn(images, cout, hout, hout, generator=g)
+    out = F.conv2d(act, W.double(), None, stride=s)
+    (ref,) = torch.autograd.grad(out, pre, dz.double())                              # conv_transpose * (act > 0)
+    mode = cnn.MODE_DGRAD_S1 if layer == 3 else cnn.MODE_DGRAD_S2
+    got = cnn.conv_dgrad(_nhwc(dz).to(DEV), cnn.repack_weights(W.to(DEV), layer, mode),
+                         _nhwc(act.detach().float()).to(DEV), layer)
+    _close(got, _nhwc(ref), f"conv{layer} dgrad")
+
+
+@pytest.mark.parametrize("layer", [1, 2, 3])
+@pytest.mark.parametrize("images", [1, 7, 600])
+def test_conv_wgrad(layer, images):
+    cin, cout, k, s, hin, hout = SPEC[layer]
+    g = torch.Generator().manual_seed(30 + layer)
+    W, b = _params(layer, 4)
+    Wd, bd = W.double().requires_grad_(True), b.double().requires_grad_(True)
+    dz = torch.randn(images, cout, hout, hout, generator=g)
+    if layer == 1:
+        frames = torch.from_numpy(synthetic.atari_frames(images + 3, seed=5))
+        inds = torch.from_numpy(np.random.RandomState(1).randint(0, images + 3, size=images))
+        x = frames[inds].double() / 255.0
+        src, idx = _nhwc(frames).to(DEV), inds.to(DEV)
+    else:
+        x = torch.relu(torch.randn(images, cin, hin, hin, generator=g)).double()
+        src, idx = _nhwc(x.float()).to(DEV), None
+    out = F.conv2d(x, Wd, bd, stride=s)
+    refW, refb = torch.autograd.grad(out, (Wd, bd), dz.double())
+    dW, db = cnn.conv_wgrad(src, _nhwc(dz).to(DEV), layer, idx)
+    _close(dW, refW, f"conv{layer} wgrad dW")
+    _close(db, refb, f"conv{layer} wgrad db")
+    dW2, db2 = cnn.conv_wgrad(src, _nhwc(dz).to(DEV), layer, idx)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2), "weight gradient must be deterministic"
+
+
+def test_trunk_matches_reference_network_forward_backward():
+    """The whole conv stack + Linear(3136,512) against the reference's nn.Sequential in float64 (same weights)."""
+    images = 48
+    torch.manual_seed(0)
+    frames = torch.from_numpy(synthetic.atari_frames(images, seed=11))
+    net = torch.nn.Sequential(torch.nn.Conv2d(4, 32, 8, stride=4), torch.nn.ReLU(), torch.nn.Conv2d(32, 64, 4, stride=2),
+                              torch.nn.ReLU(), torch.nn.Conv2d(64, 64, 3, stride=1), torch.nn.ReLU(), torch.nn.Flatten(),
+                              torch.nn.Linear(64 * 7 * 7, 512), torch.nn.ReLU())
+    import copy
+
+    ref_net = copy.deepcopy(net).double()
+    gout = torch.randn(images, 512)
+    ref_h = ref_net(frames.double() / 255.0)
+    ref_h.backward(gout.double())
+
+    gnet = copy.deepcopy(net).to(DEV)
+    trunk = cnn.NatureTrunk()
+    feats = trunk(_nhwc(frames).to(DEV), None, gnet[0], gnet[2], gnet[4])
+    h = F.relu(F.linear(feats, cnn.fc_weight_hwc(gnet[7].weight), gnet[7].bias))
+    _close(h, ref_h, "trunk+fc forward", tol=5e-5)
+    h.backward(gout.to(DEV))
+    for (name, p), (_, pr) in zip(gnet.named_parameters(), ref_net.named_parameters()):
+        _close(p.grad, pr.grad, f"grad of {name}", tol=5e-5)

@@ -39,7 +39,7 @@ def test_rollout_gae_and_update_seam_against_oracle():
     assert L.actions.min() >= 0 and L.actions.max() <= 3 and L.dones.sum() > 0
     # a4: GAE bit-exact vs the C oracle on the stored tensors
     with torch.no_grad():
-        nv = agent.heads(L._features(L.boot_obs))[1].reshape(-1)
+        nv = L._heads_rollout(L.boot_obs)[1].reshape(-1)      # the learner's own (deterministic) bootstrap path
     adv_o, ret_o = c_oracle.gae(L.rewards.cpu().numpy(), L.dones.cpu().numpy(), L.values.cpu().numpy(),
                                 L.boot_done.cpu().numpy(), nv.cpu().numpy(), args.gamma, args.gae_lambda)
     assert np.array_equal(L.advantages.cpu().numpy(), adv_o) and np.array_equal(L.returns.cpu().numpy(), ret_o)
