@@ -42,6 +42,8 @@ SIGNATURES = {
     "mi355ppo_cnn_repack_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "mi355ppo_cnn_conv_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_cnn_conv_dgrad_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "mi355ppo_cnn_conv_fwd_f32_variant": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "mi355ppo_cnn_conv_dgrad_f32_variant": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "mi355ppo_cnn_conv_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mi355ppo_cnn_conv_wgrad_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_size_t, _P]),
 }

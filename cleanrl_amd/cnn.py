@@ -35,7 +35,7 @@ def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch
 
 
 def conv_fwd(src: torch.Tensor, Bt: torch.Tensor, bias: torch.Tensor, layer: int, inds: torch.Tensor | None = None,
-             out: torch.Tensor | None = None) -> torch.Tensor:
+             out: torch.Tensor | None = None, variant: int = 0) -> torch.Tensor:
     """``relu(conv(src) + bias)``; layer 1 takes the uint8 rollout rows (+ optional int64 row gather)."""
     lib = _lib.load()
     cin, cout, k, _, hin, hout = LAYERS[layer]
@@ -55,14 +55,14 @@ def conv_fwd(src: torch.Tensor, Bt: torch.Tensor, bias: torch.Tensor, layer: int
         out = torch.empty((images, hout, hout, cout), dtype=torch.float32, device=src.device)
     _chk(out, torch.float32, "out", (images, hout, hout, cout))
     with torch.cuda.device(src.device):
-        st = lib.mi355ppo_cnn_conv_fwd_f32(_ptr(src), _ptr(inds), _ptr(Bt), _ptr(bias), _ptr(out), images, layer,
-                                           _stream(src.device))
+        st = lib.mi355ppo_cnn_conv_fwd_f32_variant(_ptr(src), _ptr(inds), _ptr(Bt), _ptr(bias), _ptr(out), images, layer,
+                                                   int(variant), _stream(src.device))
     _lib.check(st, "mi355ppo_cnn_conv_fwd_f32")
     return out
 
 
 def conv_dgrad(dz: torch.Tensor, Bt: torch.Tensor, act_in: torch.Tensor, layer: int,
-               out: torch.Tensor | None = None) -> torch.Tensor:
+               out: torch.Tensor | None = None, variant: int = 0) -> torch.Tensor:
     """Gradient w.r.t. the layer's input activation, masked by ``act_in > 0`` (ReLU backward fused)."""
     lib = _lib.load()
     cin, cout, k, _, hin, hout = LAYERS[layer]
@@ -74,7 +74,8 @@ def conv_dgrad(dz: torch.Tensor, Bt: torch.Tensor, act_in: torch.Tensor, layer: 
         out = torch.empty_like(act_in)
     _chk(out, torch.float32, "out", (images, hin, hin, cin))
     with torch.cuda.device(dz.device):
-        st = lib.mi355ppo_cnn_conv_dgrad_f32(_ptr(dz), _ptr(Bt), _ptr(act_in), _ptr(out), images, layer, _stream(dz.device))
+        st = lib.mi355ppo_cnn_conv_dgrad_f32_variant(_ptr(dz), _ptr(Bt), _ptr(act_in), _ptr(out), images, layer, int(variant),
+                                                     _stream(dz.device))
     _lib.check(st, "mi355ppo_cnn_conv_dgrad_f32")
     return out
 

@@ -214,6 +214,208 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const void* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------ kernel S
+// conv_stream_kernel: the same GEMM as conv_gemm_kernel with the roles of the memories swapped.  The whole
+// weight matrix Bt (N x K, <= 148 KB) is loaded ONCE per workgroup into LDS and stays there; every wave then
+// streams its own 32-pixel tiles: a lane fetches its A fragments (16 bytes = 4 consecutive k of ITS pixel, or 16
+// uint8 taps) straight from global memory into a register ring that runs D chunks ahead -- across tile
+// boundaries -- so HBM latency is covered by D x (4..16) MFMAs.  No LDS traffic for A, no workgroup barriers in
+// the main loop, waves drift freely; the matrix pipe sees an MFMA stream interrupted only by the per-tile
+// epilogue.  Tiles are handed out round-robin over all waves of the grid (persistent workgroups).
+constexpr int kRing = 8;
+
+template <int NJT, bool U8IN, int EPI, bool PAD>
+__global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict__ src_v, const int64_t* __restrict__ inds,
+                                                          const float* __restrict__ Bt_all, const float* __restrict__ bias,
+                                                          const float* __restrict__ mask_src, float* __restrict__ dst,
+                                                          ConvGeom g, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float Bs[];       // [32*NJT][K + 4] (+ 8 floats of slack)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int cls = blockIdx.y;
+    const int ldb = g.K + 4;
+    const int day = g.classes == 4 ? (cls >> 1) : g.DAY;
+    const int dax = g.classes == 4 ? (cls & 1) : g.DAX;
+    {
+        const float4* __restrict__ Bt4 = reinterpret_cast<const float4*>(Bt_all + (size_t)cls * (32 * NJT) * g.K);
+        const unsigned k4 = (unsigned)g.K >> 2, total = (unsigned)(32 * NJT) * k4;
+        for (unsigned e = tid; e < total; e += 512) {
+            const unsigned row = e / k4, c = e - row * k4;
+            *reinterpret_cast<float4*>(&Bs[row * ldb + c * 4]) = Bt4[e];
+        }
+        // bias goes through LDS too: a value that arrives by a global load and is first used inside the tile loop
+        // makes hipcc guard every epilogue store with s_waitcnt vmcnt(1), which drains the prefetch ring
+        if (EPI == EPI_BIAS_RELU && tid < 32 * NJT) Bs[(32 * NJT) * ldb + 8 + tid] = bias[tid];
+    }
+    __syncthreads();
+
+    const unsigned per_img = (unsigned)(g.GY * g.GX), GX = (unsigned)g.GX;
+    const unsigned P = (unsigned)g.P;
+    const int runlen = g.KW * g.C, rowpitch = g.W * g.C;
+    const int nwv = gridDim.x * 8;
+    const int nblocks = U8IN ? (g.KH / kRing) : (g.K / 8 / kRing);       // ring rounds per tile
+
+    // ---- load cursor (runs kRing chunks ahead of the MFMAs)
+    int l_tile = blockIdx.x * 8 + wave;
+    int l_r = 0, l_rem = 0, l_koff = 0;
+    long long l_base = 0;
+    int l_sy0 = 0, l_sx0 = 0;
+    bool l_ok = false;
+    auto setup = [&]() {
+        const unsigned p = (unsigned)l_tile * 32u + (unsigned)li;
+        l_ok = (l_tile < ntiles) && (p < P);
+        const unsigned pp = l_ok ? p : 0u;
+        const unsigned img = pp / per_img, rem = pp - img * per_img;
+        const unsigned gy = rem / GX, gx = rem - gy * GX;
+        l_sy0 = (int)gy * g.SS + g.OFF;
+        l_sx0 = (int)gx * g.SS + g.OFF;
+        const long long simg = (U8IN && inds) ? inds[img] : (long long)img;
+        l_base = ((simg * g.H + l_sy0) * g.W + l_sx0) * (long long)g.C + (U8IN ? 16 : 4) * lh;
+    };
+    auto advance = [&](bool may_wrap) {
+        if (U8IN) {
+            ++l_r;
+            l_koff += rowpitch;
+        } else {
+            l_rem += 8;
+            l_koff += 8;
+            if (l_rem == runlen) { l_rem = 0; ++l_r; l_koff = l_r * rowpitch; }
+        }
+        if (may_wrap && l_r == g.KH) {
+            l_r = 0; l_rem = 0; l_koff = 0;
+            l_tile += nwv;
+            setup();
+        }
+    };
+
+    // The ring is loaded UNCONDITIONALLY (invalid taps read a clamped, always-mapped address and are zeroed when
+    // consumed, bit d of `vmask`), and slot d is refilled only after its MFMAs have been issued: the slots then
+    // keep fixed registers and the compiler can count the loads (s_waitcnt vmcnt(kRing-1)) instead of draining
+    // the queue at every loop back-edge.
+    uint4 ring[kRing];
+    unsigned vmask = 0u;
+    auto fetch = [&](int d) {
+        bool ok = l_ok;
+        if (!U8IN && PAD) {
+            const int sy = l_sy0 + l_r, sx = l_sx0 + (l_rem >> g.logC);
+            ok = ok && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
+        }
+        const long long off = ok ? (l_base + l_koff) : (long long)((U8IN ? 16 : 4) * lh);
+        if (U8IN) ring[d] = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(src_v) + off);
+        else ring[d] = *reinterpret_cast<const uint4*>(static_cast<const float*>(src_v) + off);
+        if (PAD) vmask = (vmask & ~(1u << d)) | ((ok ? 1u : 0u) << d);
+    };
+    setup();
+#pragma unroll
+    for (int d = 0; d < kRing; ++d) {
+        fetch(d);
+        advance(d == kRing - 1);
+    }
+
+    float bias_r[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) bias_r[jt] = (EPI == EPI_BIAS_RELU) ? Bs[(32 * NJT) * ldb + 8 + jt * 32 + li] : 0.0f;
+    constexpr int NB = U8IN ? 4 : 1;                  // float4 B fragments per chunk and channel tile
+    for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwv) {
+        f32x16 acc[NJT];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jt][e] = 0.0f;
+        const float* __restrict__ Bp = Bs + li * ldb + (U8IN ? 16 : 4) * lh;
+        float4 bcur[NJT][NB], bnxt[NJT][NB];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int q = 0; q < NB; ++q) bcur[jt][q] = *reinterpret_cast<const float4*>(Bp + jt * 32 * ldb + 4 * q);
+        for (int blk = 0; blk < nblocks; ++blk) {
+#pragma unroll
+            for (int d = 0; d < kRing; ++d) {
+                Bp += U8IN ? 32 : 8;                  // B fragments of the NEXT chunk are read under this chunk's MFMAs
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) bnxt[jt][q] = *reinterpret_cast<const float4*>(Bp + jt * 32 * ldb + 4 * q);
+                uint4 A = ring[d];
+                if (PAD && !((vmask >> d) & 1u)) A = make_uint4(0u, 0u, 0u, 0u);
+                if (U8IN) {
+                    const uint32_t w[4] = {A.x, A.y, A.z, A.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a0 = u8_div255_c((float)(w[q] & 0xffu)), a1 = u8_div255_c((float)((w[q] >> 8) & 0xffu));
+                        const float a2 = u8_div255_c((float)((w[q] >> 16) & 0xffu)), a3 = u8_div255_c((float)(w[q] >> 24));
+#pragma unroll
+                        for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[jt][q].x, acc[jt], 0, 0, 0);
+#pragma unroll
+                        for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[jt][q].y, acc[jt], 0, 0, 0);
+#pragma unroll
+                        for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bcur[jt][q].z, acc[jt], 0, 0, 0);
+#pragma unroll
+                        for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bcur[jt][q].w, acc[jt], 0, 0, 0);
+                    }
+                } else {
+                    const float a0 = __uint_as_float(A.x), a1 = __uint_as_float(A.y), a2 = __uint_as_float(A.z),
+                                a3 = __uint_as_float(A.w);
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[jt][0].x, acc[jt], 0, 0, 0);
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[jt][0].y, acc[jt], 0, 0, 0);
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bcur[jt][0].z, acc[jt], 0, 0, 0);
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bcur[jt][0].w, acc[jt], 0, 0, 0);
+                }
+                fetch(d);                            // refill the slot just consumed (kRing chunks ahead)
+                advance(d == kRing - 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: hipcc otherwise sinks all kRing loads to the
+                                                     // loop tail and the first one is awaited one instruction later
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) bcur[jt][q] = bnxt[jt][q];
+            }
+        }
+        // ---- epilogue: destination offset of THIS lane's pixel, fetched per accumulator row by a wave shuffle
+        int myoff = -1;
+        {
+            const unsigned p = (unsigned)tile * 32u + (unsigned)li;
+            if (p < P) {
+                const unsigned img = p / per_img, rem = p - img * per_img;
+                const unsigned gy = rem / GX, gx = rem - gy * GX;
+                myoff = (int)(((img * (unsigned)g.DH + (gy * (unsigned)g.DM + (unsigned)day)) * (unsigned)g.DW +
+                               (gx * (unsigned)g.DM + (unsigned)dax)) * (unsigned)g.DC);
+            }
+        }
+        int offs[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) offs[e] = __shfl(myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64);
+        if (EPI == EPI_MASK) {
+            float mk[NJT][16];                       // all mask loads in flight together, one wait
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) mk[jt][e] = mask_src[(size_t)(offs[e] >= 0 ? offs[e] : 0) + jt * 32 + li];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+                    if (offs[e] >= 0) dst[(size_t)offs[e] + jt * 32 + li] = mk[jt][e] > 0.0f ? acc[jt][e] : 0.0f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    float v = acc[jt][e];
+                    if (EPI == EPI_BIAS_RELU) {
+                        v = v + bias_r[jt];
+                        v = v > 0.0f ? v : 0.0f;
+                    }
+                    if (offs[e] >= 0) dst[(size_t)offs[e] + jt * 32 + li] = v;
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ weight gradient
 struct WgradGeom {
     int H, W, C;       // source per image
@@ -332,8 +534,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
     const int K = KH * KW * C;
     const int e = blockIdx.x * 256 + threadIdx.x;     // index into [N][K] (tap-major, channel-minor)
     if (e < N * K) {
-        float s = 0.0f;
-        for (int p = 0; p < nparts; ++p) s += part_w[(size_t)p * N * K + e];
+        // eight independent partial sums (loads in flight together), combined in a fixed order
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const size_t stride = (size_t)N * K;
+        int p = 0;
+        for (; p + 8 <= nparts; p += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += part_w[(size_t)(p + u) * stride + e];
+        }
+        for (; p < nparts; ++p) s8[p & 7] += part_w[(size_t)p * stride + e];
+        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         const int n = e / K, k = e - n * K;
         const int r = k / (KW * C), rem = k - r * (KW * C), c = rem / C, ch = rem - c * C;
         dW[((n * C + ch) * KH + r) * KW + c] = s;
@@ -375,6 +585,7 @@ __global__ __launch_bounds__(256) void conv_repack_kernel(const float* __restric
     }
 }
 
+constexpr int kDefaultVariant = 2;   // 1 = tile kernel G, 2 = stream kernel S
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 }  // namespace mi355ppo
@@ -404,22 +615,50 @@ extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, floa
     return check_launch("conv_repack_kernel");
 }
 
-extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds, const float* Bt, const float* bias,
-                                                      float* dst, int64_t images, int layer, void* stream) {
+template <int NJT, bool U8IN, int EPI, bool PAD>
+static int launch_stream(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
+                         float* dst, const ConvGeom& g, hipStream_t s) {
+    const size_t smem = ((size_t)(32 * NJT) * (g.K + 4) + 8 + 32 * NJT) * sizeof(float);   // weights + slack + bias
+    auto k = conv_stream_kernel<NJT, U8IN, EPI, PAD>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+        set_error("conv_stream_kernel: hipFuncSetAttribute(%zu bytes of LDS): %s", smem, hipGetErrorString(e));
+        return MI355PPO_EHIP;
+    }
+    const int ntiles = (int)((g.P + 31) / 32);
+    // persistent workgroups of 8 waves: one per CU when the weights fill the LDS, two when they are small
+    int wgs = (smem > 80 * 1024 ? 256 : 512) / g.classes;
+    const int need = (ntiles + 7) / 8;
+    if (wgs > need) wgs = need;
+    hipLaunchKernelGGL(k, dim3((unsigned)wgs, (unsigned)g.classes), dim3(512), smem, s, src, inds, Bt, bias, mask_src, dst, g,
+                       ntiles);
+    return check_launch("conv_stream_kernel");
+}
+
+static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, const float* bias, float* dst,
+                         int64_t images, int layer, int variant, void* stream) {
     const char* fn = "mi355ppo_cnn_conv_fwd_f32";
     int Cin, Cout, KH, SS, Hin, Hout;
     MI355_REQUIRE(src && Bt && bias && dst, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
-    MI355_REQUIRE(images > 0 && images <= (1 << 24), MI355PPO_EINVAL, "%s: images=%lld out of range", fn, (long long)images);
+    MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
+                  (long long)images);
     MI355_REQUIRE(layer == 1 || inds == nullptr, MI355PPO_EINVAL, "%s: inds (row gather) is only defined for layer 1", fn);
+    MI355_REQUIRE(variant >= 0 && variant <= 2, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(src, 16) && aligned(Bt, 16) && aligned(dst, 16) && aligned(inds, 8), MI355PPO_EALIGN,
                   "%s: src/Bt/dst must be 16-byte aligned", fn);
     ConvGeom g;
     g.H = g.W = Hin; g.C = Cin; g.KH = g.KW = KH; g.GY = g.GX = Hout; g.SS = SS; g.OFF = 0;
     g.DH = g.DW = Hout; g.DC = Cout; g.DM = 1; g.DAY = g.DAX = 0; g.K = KH * KH * Cin; g.N = Cout; g.classes = 1;
     g.logC = ilog2(Cin); g.P = (long long)images * Hout * Hout;
-    const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 1);
+    MI355_REQUIRE(g.P * Cout < (1LL << 31), MI355PPO_EINVAL, "%s: destination exceeds 2^31 elements", fn);
     hipStream_t s = as_stream(stream);
+    if (variant == 0) variant = kDefaultVariant;
+    if (variant == 2) {
+        if (layer == 1) return launch_stream<1, true, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g, s);
+        return launch_stream<2, false, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g, s);
+    }
+    const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 1);
     if (layer == 1)
         hipLaunchKernelGGL((conv_gemm_kernel<32, true, EPI_BIAS_RELU>), grid, dim3(256), 0, s, src, inds, Bt, bias,
                            (const float*)nullptr, dst, g);
@@ -429,34 +668,62 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int
     return check_launch("conv_gemm_kernel(fwd)");
 }
 
-extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32(const float* dz, const float* Bt, const float* act_in, float* dsrc,
-                                                        int64_t images, int layer, void* stream) {
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds, const float* Bt, const float* bias,
+                                                      float* dst, int64_t images, int layer, void* stream) {
+    return conv_fwd_impl(src, inds, Bt, bias, dst, images, layer, 0, stream);
+}
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_f32_variant(const void* src, const int64_t* inds, const float* Bt,
+                                                              const float* bias, float* dst, int64_t images, int layer,
+                                                              int variant, void* stream) {
+    return conv_fwd_impl(src, inds, Bt, bias, dst, images, layer, variant, stream);
+}
+
+static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in, float* dsrc, int64_t images, int layer,
+                           int variant, void* stream) {
     const char* fn = "mi355ppo_cnn_conv_dgrad_f32";
     int Cin, Cout, KH, SS, Hin, Hout;
     MI355_REQUIRE(dz && Bt && act_in && dsrc, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE((layer == 2 || layer == 3) && layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL,
                   "%s: layer=%d must be 2 or 3 (conv1's input needs no gradient)", fn, layer);
-    MI355_REQUIRE(images > 0 && images <= (1 << 24), MI355PPO_EINVAL, "%s: images=%lld out of range", fn, (long long)images);
+    MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
+                  (long long)images);
+    MI355_REQUIRE(variant >= 0 && variant <= 2, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(dz, 16) && aligned(Bt, 16) && aligned(act_in, 16) && aligned(dsrc, 16), MI355PPO_EALIGN,
                   "%s: pointers must be 16-byte aligned", fn);
+    MI355_REQUIRE((long long)images * Hin * Hin * Cin < (1LL << 31), MI355PPO_EINVAL, "%s: destination exceeds 2^31 elements", fn);
     ConvGeom g;
     g.H = g.W = Hout; g.C = Cout;                  // the "source" of this GEMM is dz: (Hout, Hout, Cout)
     g.DH = g.DW = Hin; g.DC = Cin; g.N = Cin; g.logC = ilog2(Cout);
     hipStream_t s = as_stream(stream);
+    if (variant == 0) variant = kDefaultVariant;
     if (layer == 3) {
         g.KH = g.KW = 3; g.GY = g.GX = Hin; g.SS = 1; g.OFF = -2; g.DM = 1; g.DAY = g.DAX = 0; g.classes = 1;
         g.K = 9 * Cout; g.P = (long long)images * Hin * Hin;
+        if (variant == 2)
+            return launch_stream<2, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
         const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 1);
         hipLaunchKernelGGL((conv_gemm_kernel<64, false, EPI_MASK>), grid, dim3(256), 0, s, (const void*)dz,
                            (const int64_t*)nullptr, Bt, (const float*)nullptr, act_in, dsrc, g);
     } else {
         g.KH = g.KW = 2; g.GY = g.GX = Hin / 2; g.SS = 1; g.OFF = -1; g.DM = 2; g.DAY = g.DAX = 0; g.classes = 4;
         g.K = 4 * Cout; g.P = (long long)images * (Hin / 2) * (Hin / 2);
+        if (variant == 2)
+            return launch_stream<1, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
         const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 4);
         hipLaunchKernelGGL((conv_gemm_kernel<32, false, EPI_MASK>), grid, dim3(256), 0, s, (const void*)dz,
                            (const int64_t*)nullptr, Bt, (const float*)nullptr, act_in, dsrc, g);
     }
     return check_launch("conv_gemm_kernel(dgrad)");
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32(const float* dz, const float* Bt, const float* act_in, float* dsrc,
+                                                        int64_t images, int layer, void* stream) {
+    return conv_dgrad_impl(dz, Bt, act_in, dsrc, images, layer, 0, stream);
+}
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32_variant(const float* dz, const float* Bt, const float* act_in,
+                                                                float* dsrc, int64_t images, int layer, int variant,
+                                                                void* stream) {
+    return conv_dgrad_impl(dz, Bt, act_in, dsrc, images, layer, variant, stream);
 }
 
 static size_t wgrad_smem(int src_bytes, int npix, int N) {

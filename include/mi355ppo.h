@@ -223,12 +223,18 @@ MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, float* Bt, int 
  * correctly rounded.  layers 2,3: src is f32, inds must be NULL. */
 MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds, const float* Bt, const float* bias,
                                            float* dst, int64_t images, int layer, void* stream);
+/* `variant` (tuning/testing): 0 = auto, 1 = LDS-tiled kernel (A and B staged per 32-k stage),
+ * 2 = streaming kernel (weights resident in LDS, A fragments fetched straight into a register ring). */
+MI355PPO_API int mi355ppo_cnn_conv_fwd_f32_variant(const void* src, const int64_t* inds, const float* Bt, const float* bias,
+                                                   float* dst, int64_t images, int layer, int variant, void* stream);
 
 /* dsrc = conv_transpose(dz) * (act_in > 0): gradient w.r.t. the layer's INPUT activation act_in
  * (itself a ReLU output), i.e. the pre-activation gradient of the previous layer.  layer = 2 or 3;
  * Bt in mode 2 / mode 1. */
 MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32(const float* dz, const float* Bt, const float* act_in, float* dsrc,
                                              int64_t images, int layer, void* stream);
+MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32_variant(const float* dz, const float* Bt, const float* act_in, float* dsrc,
+                                                     int64_t images, int layer, int variant, void* stream);
 
 /* dW (torch layout (Cout,Cin,KH,KW)) and db (Cout) from the layer input `src` (layer 1: uint8 + inds
  * as above) and the pre-activation gradient dz (images, Hout, Wout, Cout).  Overwrites dW / db.

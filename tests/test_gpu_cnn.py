@@ -54,16 +54,17 @@ def test_repack_layouts(layer, mode):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("images", [1, 37, 256])
-def test_conv1_fwd_u8_gather(images):
+def test_conv1_fwd_u8_gather(images, variant):
     frames = torch.from_numpy(synthetic.atari_frames(images + 5, seed=3))            # (R,4,84,84) uint8
     rows = _nhwc(frames).to(DEV)
     inds = torch.from_numpy(np.random.RandomState(0).randint(0, images + 5, size=images)).to(DEV)
     W, b = _params(1, 1)
     ref = F.relu(F.conv2d(frames[inds.cpu()].double() / 255.0, W.double(), b.double(), stride=4))
-    got = cnn.conv_fwd(rows, cnn.repack_weights(W.to(DEV), 1), b.to(DEV), 1, inds)
+    got = cnn.conv_fwd(rows, cnn.repack_weights(W.to(DEV), 1), b.to(DEV), 1, inds, variant=variant)
     _close(got, _nhwc(ref), "conv1 fwd (gather)")
-    got2 = cnn.conv_fwd(rows[:images].contiguous(), cnn.repack_weights(W.to(DEV), 1), b.to(DEV), 1, None)
+    got2 = cnn.conv_fwd(rows[:images].contiguous(), cnn.repack_weights(W.to(DEV), 1), b.to(DEV), 1, None, variant=variant)
     ref2 = F.relu(F.conv2d(frames[:images].double() / 255.0, W.double(), b.double(), stride=4))
     _close(got2, _nhwc(ref2), "conv1 fwd (identity rows)")
     # calibration: torch's own f32 GPU convolution meets the same bound
@@ -71,22 +72,24 @@ def test_conv1_fwd_u8_gather(images):
     _close(_nhwc(t32), _nhwc(ref2), "torch f32 conv1 (calibration)")
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("layer", [2, 3])
-@pytest.mark.parametrize("images", [1, 19, 128])
-def test_conv_fwd_f32(layer, images):
+@pytest.mark.parametrize("images", [1, 19, 128, 700])
+def test_conv_fwd_f32(layer, images, variant):
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(10 + layer)
     x = torch.relu(torch.randn(images, cin, hin, hin, generator=g))
     W, b = _params(layer, 2)
     ref = F.relu(F.conv2d(x.double(), W.double(), b.double(), stride=s))
-    got = cnn.conv_fwd(_nhwc(x).to(DEV), cnn.repack_weights(W.to(DEV), layer), b.to(DEV), layer)
+    got = cnn.conv_fwd(_nhwc(x).to(DEV), cnn.repack_weights(W.to(DEV), layer), b.to(DEV), layer, variant=variant)
     assert got.shape == (images, hout, hout, cout)
     _close(got, _nhwc(ref), f"conv{layer} fwd")
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("layer", [2, 3])
-@pytest.mark.parametrize("images", [1, 19, 128])
-def test_conv_dgrad_with_relu_mask(layer, images):
+@pytest.mark.parametrize("images", [1, 19, 128, 700])
+def test_conv_dgrad_with_relu_mask(layer, images, variant):
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(20 + layer)
     pre = torch.randn(images, cin, hin, hin, generator=g).double().requires_grad_(True)
@@ -97,7 +100,7 @@ def test_conv_dgrad_with_relu_mask(layer, images):
     (ref,) = torch.autograd.grad(out, pre, dz.double())                              # conv_transpose * (act > 0)
     mode = cnn.MODE_DGRAD_S1 if layer == 3 else cnn.MODE_DGRAD_S2
     got = cnn.conv_dgrad(_nhwc(dz).to(DEV), cnn.repack_weights(W.to(DEV), layer, mode),
-                         _nhwc(act.detach().float()).to(DEV), layer)
+                         _nhwc(act.detach().float()).to(DEV), layer, variant=variant)
     _close(got, _nhwc(ref), f"conv{layer} dgrad")
 
 

@@ -46,8 +46,9 @@ def main():
             bt = cnn.repack_weights(W, layer)
             src = acts[layer - 1]
             dst = torch.empty((M, hout, hout, cout), device=DEV)
-            us = bench(lambda: cnn.conv_fwd(src, bt, b, layer, inds if layer == 1 else None, dst))
-            out(k="fwd", layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK)
+            for v in (1, 2):
+                us = bench(lambda: cnn.conv_fwd(src, bt, b, layer, inds if layer == 1 else None, dst, variant=v))
+                out(k="fwd", variant=v, layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK)
             acts[layer] = dst
             dz = torch.randn_like(dst)
             us = bench(lambda: cnn.conv_wgrad(src, dz, layer, inds if layer == 1 else None))
@@ -56,9 +57,12 @@ def main():
                 mode = cnn.MODE_DGRAD_S1 if layer == 3 else cnn.MODE_DGRAD_S2
                 btd = cnn.repack_weights(W, layer, mode)
                 dsrc = torch.empty_like(src)
-                us = bench(lambda: cnn.conv_dgrad(dz, btd, src, layer, dsrc))
-                out(k="dgrad", layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK,
-                    note="flops counted as the forward conv's")
+                for v in (1, 2):
+                    us = bench(lambda: cnn.conv_dgrad(dz, btd, src, layer, dsrc, variant=v))
+                    out(k="dgrad", variant=v, layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK,
+                        note="flops counted as the forward conv's")
+            if os.environ.get("CNNBENCH_TORCH", "0") != "1":
+                continue
             # torch / MIOpen on channels-last f32 for comparison
             if layer == 1:
                 x = (obs.float() / 255.0).permute(0, 3, 1, 2)
