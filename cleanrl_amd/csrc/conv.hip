@@ -35,6 +35,7 @@
 namespace mi355ppo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvGeom {
     int H, W, C;          // source tensor per image: (H, W, C) channels-last
@@ -50,12 +51,13 @@ struct ConvGeom {
     long long P;          // total GEMM rows = images * GY * GX
 };
 
-__device__ __forceinline__ float u8_div255_c(float x) {   // correctly rounded x/255 (see obs.hip)
-    const float r = 1.0f / 255.0f;
-    const float q = x * r;
-    const float e = __builtin_fmaf(-q, 255.0f, x);
-    return __builtin_fmaf(e, r, q);
-}
+// uint8 taps enter the MFMAs as the exact integers 0..255 (one v_cvt_f32_ubyteN each) and the 1/255 of
+// `x / 255.0` (:154) is folded into the layer-1 weight matrix by the repack kernel (forward) or applied once to the
+// reduced sum (weight gradient): sum_k (x_k/255) w_k == sum_k x_k (w_k/255) up to one f32 rounding per term -- the
+// same error class as the summation-order differences between any two f32 convolutions -- and the per-tap VALU work
+// next to each MFMA drops from 5 instructions to 1 (VALU issue on a SIMD comes out of the matrix pipe's time).
+__device__ __forceinline__ float u8_tap(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }
+constexpr float kInv255 = 1.0f / 255.0f;
 
 constexpr int kBM = 128;      // pixels per workgroup tile
 constexpr int kBK = 32;       // k elements per stage
@@ -132,10 +134,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const void* __restric
             if (U8IN) {
                 uint32_t w = 0;
                 if (arow_ok[q]) w = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(src_v) + off);
-                areg[q].x = u8_div255_c((float)(w & 0xffu));
-                areg[q].y = u8_div255_c((float)((w >> 8) & 0xffu));
-                areg[q].z = u8_div255_c((float)((w >> 16) & 0xffu));
-                areg[q].w = u8_div255_c((float)(w >> 24));
+                areg[q].x = u8_tap(w, 0);
+                areg[q].y = u8_tap(w, 1);
+                areg[q].z = u8_tap(w, 2);
+                areg[q].w = u8_tap(w, 3);
             } else {
                 const int sy = asy[q] + st_r, sx = asx[q] + cx;
                 const bool ok = arow_ok[q] && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const void* __restric
 // epilogue.  Tiles are handed out round-robin over all waves of the grid (persistent workgroups).
 constexpr int kRing = 8;
 
-template <int NJT, bool U8IN, int EPI, bool PAD>
+template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4>
 __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict__ src_v, const int64_t* __restrict__ inds,
                                                           const float* __restrict__ Bt_all, const float* __restrict__ bias,
                                                           const float* __restrict__ mask_src, float* __restrict__ dst,
@@ -315,11 +317,14 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
     float bias_r[NJT];
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) bias_r[jt] = (EPI == EPI_BIAS_RELU) ? Bs[(32 * NJT) * ldb + 8 + jt * 32 + li] : 0.0f;
+    constexpr int NACC = NJT == 1 ? 2 : NJT;
     constexpr int NB = U8IN ? 4 : 1;                  // float4 B fragments per chunk and channel tile
     for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwv) {
-        f32x16 acc[NJT];
+        // NJT == 1: two accumulators taking alternate k-pairs, so that consecutive MFMAs of a wave are independent
+        // (a dependent 32x32x2 chain leaves the pipe idle between issue and write-back); summed in the epilogue.
+        f32x16 acc[NACC];
 #pragma unroll
-        for (int jt = 0; jt < NJT; ++jt)
+        for (int jt = 0; jt < NACC; ++jt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[jt][e] = 0.0f;
         const float* __restrict__ Bp = Bs + li * ldb + (U8IN ? 16 : 4) * lh;
@@ -342,28 +347,27 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
                     const uint32_t w[4] = {A.x, A.y, A.z, A.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float a0 = u8_div255_c((float)(w[q] & 0xffu)), a1 = u8_div255_c((float)((w[q] >> 8) & 0xffu));
-                        const float a2 = u8_div255_c((float)((w[q] >> 16) & 0xffu)), a3 = u8_div255_c((float)(w[q] >> 24));
+                        const float a0 = u8_tap(w[q], 0), a1 = u8_tap(w[q], 1), a2 = u8_tap(w[q], 2), a3 = u8_tap(w[q], 3);
 #pragma unroll
-                        for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[jt][q].x, acc[jt], 0, 0, 0);
+                        for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 0 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[jt][q].x, acc[NJT == 1 ? 0 : jt], 0, 0, 0);
 #pragma unroll
-                        for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[jt][q].y, acc[jt], 0, 0, 0);
+                        for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 1 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[jt][q].y, acc[NJT == 1 ? 1 : jt], 0, 0, 0);
 #pragma unroll
-                        for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bcur[jt][q].z, acc[jt], 0, 0, 0);
+                        for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 0 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bcur[jt][q].z, acc[NJT == 1 ? 0 : jt], 0, 0, 0);
 #pragma unroll
-                        for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bcur[jt][q].w, acc[jt], 0, 0, 0);
+                        for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 1 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bcur[jt][q].w, acc[NJT == 1 ? 1 : jt], 0, 0, 0);
                     }
                 } else {
                     const float a0 = __uint_as_float(A.x), a1 = __uint_as_float(A.y), a2 = __uint_as_float(A.z),
                                 a3 = __uint_as_float(A.w);
 #pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[jt][0].x, acc[jt], 0, 0, 0);
+                    for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 0 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[jt][0].x, acc[NJT == 1 ? 0 : jt], 0, 0, 0);
 #pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[jt][0].y, acc[jt], 0, 0, 0);
+                    for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 1 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[jt][0].y, acc[NJT == 1 ? 1 : jt], 0, 0, 0);
 #pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bcur[jt][0].z, acc[jt], 0, 0, 0);
+                    for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 0 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bcur[jt][0].z, acc[NJT == 1 ? 0 : jt], 0, 0, 0);
 #pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bcur[jt][0].w, acc[jt], 0, 0, 0);
+                    for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 1 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bcur[jt][0].w, acc[NJT == 1 ? 1 : jt], 0, 0, 0);
                 }
                 fetch(d);                            // refill the slot just consumed (kRing chunks ahead)
                 advance(d == kRing - 1);
@@ -374,6 +378,10 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
 #pragma unroll
                     for (int q = 0; q < NB; ++q) bcur[jt][q] = bnxt[jt][q];
             }
+        }
+        if (NJT == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][e] += acc[NACC - 1][e];
         }
         // ---- epilogue: destination offset of THIS lane's pixel, fetched per accumulator row by a wave shuffle
         int myoff = -1;
@@ -390,16 +398,17 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
 #pragma unroll
         for (int e = 0; e < 16; ++e) offs[e] = __shfl(myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64);
         if (EPI == EPI_MASK) {
-            float mk[NJT][16];                       // all mask loads in flight together, one wait
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
+            for (int jt = 0; jt < NJT; ++jt) {
+                // CLS4: channel tile jt is parity class (jt>>1, jt&1) of the stride-2 data gradient -> its own pixel
+                const int noff = CLS4 ? ((jt >> 1) * g.DW + (jt & 1)) * g.DC + li : jt * 32 + li;
+                float mk[16];                        // the 16 mask loads of a tile are in flight together
 #pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) mk[jt][e] = mask_src[(size_t)(offs[e] >= 0 ? offs[e] : 0) + jt * 32 + li];
+                for (int e = 0; e < 16; ++e) mk[e] = mask_src[(size_t)(offs[e] >= 0 ? offs[e] : 0) + noff];
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt)
-                    if (offs[e] >= 0) dst[(size_t)offs[e] + jt * 32 + li] = mk[jt][e] > 0.0f ? acc[jt][e] : 0.0f;
+                for (int e = 0; e < 16; ++e)
+                    if (offs[e] >= 0) dst[(size_t)offs[e] + noff] = mk[e] > 0.0f ? acc[jt][e] : 0.0f;
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
@@ -427,9 +436,14 @@ struct WgradGeom {
     int src_bytes;     // bytes of one source image as stored (u8: H*W*C, f32: 4*H*W*C)
 };
 
-// NCI = Cout/32 (1 or 2); TPW = MFMA tiles per wave = (N/32)*(K/32)/4.
-template <int NCI, int TPW, bool U8IN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const void* __restrict__ src_v,
+// NCI = Cout/32 (1 or 2); TPW = MFMA tiles per wave = (N/32)*(K/32)/4; NS / ND = 16-byte chunks of one source /
+// dz image per thread (ceil(bytes / 16 / 256)).  While image i is multiplied out of LDS, image i+1 is already
+// in flight into registers (NS + ND uint4 per thread), so the only exposed memory time is the first image's.
+// SPLIT: every wave owns ALL tiles (TPW = all of them) and a quarter of the pixel pairs instead of a quarter of the
+// tiles and all pairs -- more MFMAs per fragment fetch for the thin conv1 problem (8 tiles); each wave then writes
+// its own partial.
+template <int NCI, int TPW, bool U8IN, int NS, int ND, bool SPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_kernel(const void* __restrict__ src_v,
                                                             const int64_t* __restrict__ inds,
                                                             const float* __restrict__ dz,
                                                             float* __restrict__ part_w,     // [grid][N][K]
@@ -438,14 +452,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const void* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int npix = g.GY * g.GX;
     const int npairs = (npix + 1) >> 1;
-    // layout: [src image][dz image: (2*npairs) x N floats][pixbase: 2*npairs ints][bias scratch 256 float4]
+    // layout: [src image][dz image: (2*npairs) x N floats][pixbase: 2*npairs ints]
     unsigned char* s_src = smem;
     float* s_dz = reinterpret_cast<float*>(smem + ((g.src_bytes + 15) & ~15));
     int* s_pixbase = reinterpret_cast<int*>(s_dz + (size_t)2 * npairs * g.N);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int ci = wave % NCI, jgroup = wave / NCI;
+    const int ci = SPLIT ? 0 : wave % NCI, jgroup = SPLIT ? 0 : wave / NCI;
+    const int P0 = SPLIT ? wave : 0, PS = SPLIT ? 4 : 1;
 
     for (int p = tid; p < 2 * npairs; p += 256) {
         int v = 0;
@@ -455,10 +470,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const void* __restri
         }
         s_pixbase[p] = v;
     }
-    // zero the pad pixel of dz once (odd pixel counts)
-    for (int e = npix * g.N + tid; e < 2 * npairs * g.N; e += 256) s_dz[e] = 0.0f;
+    for (int e = npix * g.N + tid; e < 2 * npairs * g.N; e += 256) s_dz[e] = 0.0f;   // pad pixel of odd grids
 
-    // patch offsets of this wave's tiles (element offset inside the staged source image)
     const int runlen = g.KW * g.C, rowpitch = g.W * g.C;
     int patch_off[TPW];
 #pragma unroll
@@ -476,35 +489,88 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const void* __restri
 
     const int dz4 = npix * g.N / 4;            // float4 per dz image
     const int src16 = g.src_bytes / 16;        // 16-byte chunks per source image
-    for (int img = blockIdx.x; img < g.images; img += gridDim.x) {
-        __syncthreads();                       // previous image fully consumed
+    u32x4 rs[NS];
+    float4 rd[ND];
+    auto prefetch = [&](int img) {
         const long long simg = (U8IN && inds) ? inds[img] : img;
-        const uint4* gsrc = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(src_v) + simg * (long long)g.src_bytes);
-        for (int e = tid; e < src16; e += 256) reinterpret_cast<uint4*>(s_src)[e] = gsrc[e];
+        const u32x4* gsrc = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(src_v) + simg * (long long)g.src_bytes);
         const float4* gdz = reinterpret_cast<const float4*>(dz + (long long)img * npix * g.N);
-        for (int e = tid; e < dz4; e += 256) {
-            const float4 v = gdz[e];
-            reinterpret_cast<float4*>(s_dz)[e] = v;
-            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int e = tid + 256 * q;
+            rs[q] = gsrc[e < src16 ? e : 0];
         }
-        __syncthreads();
-        for (int pr = 0; pr < npairs; ++pr) {
-            const int p = 2 * pr + lh;
-            const float a = s_dz[p * g.N + ci * 32 + li];
-            const int pb = s_pixbase[p];
-            float b[TPW];
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                if (U8IN) b[t] = u8_div255_c((float)s_src[pb + patch_off[t]]);
-                else b[t] = reinterpret_cast<const float*>(s_src)[pb + patch_off[t]];
+        for (int q = 0; q < ND; ++q) {
+            const int e = tid + 256 * q;
+            rd[q] = gdz[e < dz4 ? e : 0];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int e = tid + 256 * q;
+            if (e < src16) reinterpret_cast<u32x4*>(s_src)[e] = rs[q];
+        }
+#pragma unroll
+        for (int q = 0; q < ND; ++q) {
+            const int e = tid + 256 * q;
+            if (e < dz4) {
+                reinterpret_cast<float4*>(s_dz)[e] = rd[q];
+                bsum.x += rd[q].x; bsum.y += rd[q].y; bsum.z += rd[q].z; bsum.w += rd[q].w;
             }
+        }
+    };
+    auto frag_a = [&](int pr) { return s_dz[(2 * pr + lh) * g.N + ci * 32 + li]; };
+    auto frag_b_at = [&](int pb, float (&b)[TPW]) {
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) {
+            if (U8IN) b[t] = (float)s_src[pb + patch_off[t]];
+            else b[t] = reinterpret_cast<const float*>(s_src)[pb + patch_off[t]];
+        }
+    };
+
+    int img = blockIdx.x;
+    if (img < g.images) prefetch(img);
+    for (; img < g.images; img += gridDim.x) {
+        __syncthreads();                       // previous image fully consumed
+        commit();
+        __syncthreads();
+        const int nxt = img + gridDim.x;
+        if (nxt < g.images) prefetch(nxt);      // in flight during the whole multiply phase
+        // Two register sets in ping-pong (no copies), pixbase one pair further ahead, and scheduling fences so that
+        // the LDS reads of pair pr+1 are ISSUED before the MFMAs of pair pr (hipcc otherwise sinks them behind the
+        // MFMAs and every pair pays a dependent ds_read -> ds_read round trip with the matrix pipe idle).
+        const int last = npairs - 1;
+        float a0 = frag_a(P0), a1 = 0.0f;
+        float b0[TPW], b1[TPW];
+        frag_b_at(s_pixbase[2 * P0 + lh], b0);
+        int pb1 = s_pixbase[2 * (P0 + PS < last ? P0 + PS : last) + lh];
+        for (int pr = P0; pr < npairs; pr += 2 * PS) {
+            const int p1 = pr + PS < last ? pr + PS : last, p2 = pr + 2 * PS < last ? pr + 2 * PS : last,
+                      p3 = pr + 3 * PS < last ? pr + 3 * PS : last;
+            int pb2 = s_pixbase[2 * p2 + lh];
+            a1 = frag_a(p1);
+            frag_b_at(pb1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            int pb3 = s_pixbase[2 * p3 + lh];
+            a0 = frag_a(p2);
+            frag_b_at(pb2, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pr + PS < npairs) {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pb1 = pb3;
         }
     }
 
     // partial weights: D[row i = cout within ci][col j = patch element within tile]
-    float* pw = part_w + (size_t)blockIdx.x * g.N * g.K;
+    float* pw = part_w + (size_t)(SPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * g.N * g.K;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int kcol = (jgroup * TPW + t) * 32 + li;
@@ -527,30 +593,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const void* __restri
     }
 }
 
-// dW (torch layout (N, C, KH, KW)) and db from the per-workgroup partials, fixed summation order.
-__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ part_w, const float* __restrict__ part_b,
-                                                         int nparts, int N, int C, int KH, int KW,
-                                                         float* __restrict__ dW, float* __restrict__ db) {
+// dW (torch layout (N, C, KH, KW)) and db from the per-workgroup partials, fixed summation order, two stages so
+// that the first (which reads all partials) has (N*K/256) x nchunks workgroups instead of N*K/256.
+constexpr int kRedChunk = 32;     // partials folded per stage-1 workgroup row
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce1(const float* __restrict__ part_w, int nparts, int NK,
+                                                          float* __restrict__ mid) {       // mid: [nchunks][NK]
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= NK) return;
+    const int p0 = blockIdx.y * kRedChunk;
+    const int p1 = p0 + kRedChunk < nparts ? p0 + kRedChunk : nparts;
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += part_w[(size_t)(p + u) * NK + e];
+    }
+    for (; p < p1; ++p) s8[p & 7] += part_w[(size_t)p * NK + e];
+    mid[(size_t)blockIdx.y * NK + e] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce2(const float* __restrict__ mid, int nchunks,
+                                                          const float* __restrict__ part_b, int nparts_b, int N, int C,
+                                                          int KH, int KW, float scale, float* __restrict__ dW,
+                                                          float* __restrict__ db) {
     const int K = KH * KW * C;
     const int e = blockIdx.x * 256 + threadIdx.x;     // index into [N][K] (tap-major, channel-minor)
     if (e < N * K) {
-        // eight independent partial sums (loads in flight together), combined in a fixed order
-        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const size_t stride = (size_t)N * K;
-        int p = 0;
-        for (; p + 8 <= nparts; p += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] += part_w[(size_t)(p + u) * stride + e];
-        }
-        for (; p < nparts; ++p) s8[p & 7] += part_w[(size_t)p * stride + e];
-        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        float s = 0.0f;
+        for (int c = 0; c < nchunks; ++c) s += mid[(size_t)c * N * K + e];
         const int n = e / K, k = e - n * K;
         const int r = k / (KW * C), rem = k - r * (KW * C), c = rem / C, ch = rem - c * C;
-        dW[((n * C + ch) * KH + r) * KW + c] = s;
+        dW[((n * C + ch) * KH + r) * KW + c] = s * scale;
     }
     if (blockIdx.x == 0 && threadIdx.x < N && db) {
         float s = 0.0f;
-        for (int p = 0; p < nparts; ++p) s += part_b[(size_t)p * N + threadIdx.x];
+        for (int p = 0; p < nparts_b; ++p) s += part_b[(size_t)p * N + threadIdx.x];
         db[threadIdx.x] = s;
     }
 }
@@ -560,14 +638,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict
 // mode 1 (dgrad, stride 1):   Bt[n=cin][(r,c,cout)]          = W[cout][cin][KH-1-r][KW-1-c]
 // mode 2 (dgrad, stride 2):   Bt[cls][n=cin][(r,c,cout)]     = W[cout][cin][ph+2-2r][pw+2-2c], cls = 2*ph+pw, r,c in {0,1}
 __global__ __launch_bounds__(256) void conv_repack_kernel(const float* __restrict__ W, float* __restrict__ Bt, int Cout,
-                                                          int Cin, int KH, int KW, int mode) {
+                                                          int Cin, int KH, int KW, int mode, float scale) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (mode == 0) {
         const int K = KH * KW * Cin;
         if (e >= Cout * K) return;
         const int n = e / K, k = e - n * K;
         const int r = k / (KW * Cin), rem = k - r * (KW * Cin), c = rem / Cin, ch = rem - c * Cin;
-        Bt[e] = W[((n * Cin + ch) * KH + r) * KW + c];
+        Bt[e] = W[((n * Cin + ch) * KH + r) * KW + c] * scale;
     } else if (mode == 1) {
         const int K = KH * KW * Cout;
         if (e >= Cin * K) return;
@@ -611,15 +689,15 @@ extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, floa
                   "%s: mode %d is not defined for layer %d", fn, mode, layer);
     const int total = Cout * Cin * KH * KH;
     hipLaunchKernelGGL(conv_repack_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), W, Bt, Cout, Cin, KH,
-                       KH, mode);
+                       KH, mode, layer == 1 ? kInv255 : 1.0f);     // layer 1 consumes raw uint8 taps
     return check_launch("conv_repack_kernel");
 }
 
-template <int NJT, bool U8IN, int EPI, bool PAD>
+template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4 = false>
 static int launch_stream(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
                          float* dst, const ConvGeom& g, hipStream_t s) {
     const size_t smem = ((size_t)(32 * NJT) * (g.K + 4) + 8 + 32 * NJT) * sizeof(float);   // weights + slack + bias
-    auto k = conv_stream_kernel<NJT, U8IN, EPI, PAD>;
+    auto k = conv_stream_kernel<NJT, U8IN, EPI, PAD, CLS4>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) {
         set_error("conv_stream_kernel: hipFuncSetAttribute(%zu bytes of LDS): %s", smem, hipGetErrorString(e));
@@ -687,7 +765,7 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
                   "%s: layer=%d must be 2 or 3 (conv1's input needs no gradient)", fn, layer);
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
-    MI355_REQUIRE(variant >= 0 && variant <= 2, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
+    MI355_REQUIRE(variant >= 0 && variant <= 3, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(dz, 16) && aligned(Bt, 16) && aligned(act_in, 16) && aligned(dsrc, 16), MI355PPO_EALIGN,
                   "%s: pointers must be 16-byte aligned", fn);
     MI355_REQUIRE((long long)images * Hin * Hin * Cin < (1LL << 31), MI355PPO_EINVAL, "%s: destination exceeds 2^31 elements", fn);
@@ -707,7 +785,11 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
     } else {
         g.KH = g.KW = 2; g.GY = g.GX = Hin / 2; g.SS = 1; g.OFF = -1; g.DM = 2; g.DAY = g.DAX = 0; g.classes = 4;
         g.K = 4 * Cout; g.P = (long long)images * (Hin / 2) * (Hin / 2);
-        if (variant == 2)
+        if (variant == 2) {     // one pass for all four parity classes: they read the SAME dz taps (only weights and
+            g.classes = 1;      // destination pixel differ), so the 4x32 class channels form one 128-wide GEMM
+            return launch_stream<4, false, EPI_MASK, true, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
+        }
+        if (variant == 3)
             return launch_stream<1, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
         const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 4);
         hipLaunchKernelGGL((conv_gemm_kernel<32, false, EPI_MASK>), grid, dim3(256), 0, s, (const void*)dz,
@@ -726,6 +808,7 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32_variant(const float* dz,
     return conv_dgrad_impl(dz, Bt, act_in, dsrc, images, layer, variant, stream);
 }
 
+constexpr bool kWgradSplitLayer1 = false;   // SPLIT variant measured slower (register-bound at 8 tiles + prefetch)
 static size_t wgrad_smem(int src_bytes, int npix, int N) {
     const int npairs = (npix + 1) / 2;
     return (size_t)((src_bytes + 15) & ~15) + (size_t)2 * npairs * N * 4 + (size_t)2 * npairs * 4;
@@ -735,7 +818,9 @@ static int wgrad_grid(int64_t images) { return images < 512 ? (int)images : 512;
 extern "C" MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t images, int layer) {
     int Cin, Cout, KH, SS, Hin, Hout;
     if (images <= 0 || !layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout)) return 0;
-    return (size_t)wgrad_grid(images) * ((size_t)Cout * KH * KH * Cin + Cout) * sizeof(float);
+    const size_t wparts = (size_t)wgrad_grid(images) * (kWgradSplitLayer1 && layer == 1 ? 4 : 1);
+    const size_t nchunks = (wparts + kRedChunk - 1) / kRedChunk;
+    return ((wparts + nchunks) * (size_t)Cout * KH * KH * Cin + (size_t)wgrad_grid(images) * Cout) * sizeof(float);
 }
 
 extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW,
@@ -757,20 +842,21 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     g.images = (int)images; g.src_bytes = Hin * Hin * Cin * (layer == 1 ? 1 : 4);
     const int grid = wgrad_grid(images);
     float* part_w = static_cast<float*>(workspace);
-    float* part_b = part_w + (size_t)grid * Cout * g.K;
+    const int wparts = grid * (kWgradSplitLayer1 && layer == 1 ? 4 : 1);
+    float* part_b = part_w + (size_t)wparts * Cout * g.K;
     const size_t smem = wgrad_smem(g.src_bytes, Hout * Hout, Cout);
     hipStream_t s = as_stream(stream);
     hipError_t e = hipSuccess;
     if (layer == 1) {
-        auto k = conv_wgrad_kernel<1, 2, true>;
+        auto k = conv_wgrad_kernel<1, 2, true, 7, 13, false>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     } else if (layer == 2) {
-        auto k = conv_wgrad_kernel<2, 8, false>;
+        auto k = conv_wgrad_kernel<2, 8, false, 13, 6, false>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     } else {
-        auto k = conv_wgrad_kernel<2, 9, false>;
+        auto k = conv_wgrad_kernel<2, 9, false, 6, 4, false>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     }
@@ -781,7 +867,12 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     int rc = check_launch("conv_wgrad_kernel");
     if (rc) return rc;
     const int total = Cout * g.K;
-    hipLaunchKernelGGL(conv_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, part_w, part_b, grid, Cout, Cin, KH, KH,
-                       dW, db);
-    return check_launch("conv_wgrad_reduce");
+    const int nchunks = (wparts + kRedChunk - 1) / kRedChunk;
+    float* mid = part_b + (size_t)grid * Cout;
+    hipLaunchKernelGGL(conv_wgrad_reduce1, dim3((total + 255) / 256, nchunks), dim3(256), 0, s, part_w, wparts, total, mid);
+    rc = check_launch("conv_wgrad_reduce1");
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_wgrad_reduce2, dim3((total + 255) / 256), dim3(256), 0, s, mid, nchunks, part_b, grid, Cout, Cin, KH,
+                       KH, layer == 1 ? kInv255 : 1.0f, dW, db);
+    return check_launch("conv_wgrad_reduce2");
 }

@@ -42,6 +42,8 @@ def test_repack_layouts(layer, mode):
     got = cnn.repack_weights(W.to(DEV), layer, mode).cpu()
     if mode == 0:
         ref = W.permute(0, 2, 3, 1).reshape(-1)                                # [cout][(kh,kw,cin)]
+        if layer == 1:
+            ref = ref * np.float32(1.0 / 255.0)                                # layer 1 consumes raw uint8 taps
     elif mode == 1:
         ref = W.flip(2, 3).permute(1, 2, 3, 0).reshape(-1)                     # [cin][(r,c,cout)], taps flipped
     else:
@@ -86,7 +88,7 @@ def test_conv_fwd_f32(layer, images, variant):
     _close(got, _nhwc(ref), f"conv{layer} fwd")
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 19, 128, 700])
 def test_conv_dgrad_with_relu_mask(layer, images, variant):
