@@ -31,6 +31,7 @@
 //   writes one partial per workgroup; conv_wgrad_reduce sums the partials in a fixed order (deterministic)
 //   and scatters into torch's (Cout, Cin, KH, KW) layout.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mi355ppo {
 
@@ -49,6 +50,7 @@ struct ConvGeom {
     int classes;          // 1, or 4 = stride-2 data-gradient parity classes (blockIdx.y)
     int logC;             // log2(C) (f32 sources)
     long long P;          // total GEMM rows = images * GY * GX
+    int diag;             // tuning only (MI355PPO_CONV_DIAG): bit0 = no ring refills, bit1 = no B fragment reads, bit2 = no epilogue
 };
 
 // uint8 taps enter the MFMAs as the exact integers 0..255 (one v_cvt_f32_ubyteN each) and the 1/255 of
@@ -226,12 +228,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const void* __restric
 // epilogue.  Tiles are handed out round-robin over all waves of the grid (persistent workgroups).
 constexpr int kRing = 8;
 
-template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4>
-__global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict__ src_v, const int64_t* __restrict__ inds,
+// MT = pixel tiles (of 32) per wave iteration: with MT = 2 every B fragment read from LDS feeds two MFMAs and the
+// per-chunk bookkeeping (addresses, waits, fences) is shared by twice as many MFMAs.
+template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_stream_kernel(const void* __restrict__ src_v, const int64_t* __restrict__ inds,
                                                           const float* __restrict__ Bt_all, const float* __restrict__ bias,
                                                           const float* __restrict__ mask_src, float* __restrict__ dst,
                                                           ConvGeom g, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) float Bs[];       // [32*NJT][K + 4] (+ 8 floats of slack)
+    extern __shared__ __attribute__((aligned(16))) float Bs[];       // [32*NJT][K + 4] (+ 8 floats of slack) [+ bias]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int cls = blockIdx.y;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
     {
         const float4* __restrict__ Bt4 = reinterpret_cast<const float4*>(Bt_all + (size_t)cls * (32 * NJT) * g.K);
         const unsigned k4 = (unsigned)g.K >> 2, total = (unsigned)(32 * NJT) * k4;
-        for (unsigned e = tid; e < total; e += 512) {
+        for (unsigned e = tid; e < total; e += 64 * NW) {
             const unsigned row = e / k4, c = e - row * k4;
             *reinterpret_cast<float4*>(&Bs[row * ldb + c * 4]) = Bt4[e];
         }
@@ -254,25 +258,29 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
     const unsigned per_img = (unsigned)(g.GY * g.GX), GX = (unsigned)g.GX;
     const unsigned P = (unsigned)g.P;
     const int runlen = g.KW * g.C, rowpitch = g.W * g.C;
-    const int nwv = gridDim.x * 8;
+    const int nwv = gridDim.x * NW;
     const int nblocks = U8IN ? (g.KH / kRing) : (g.K / 8 / kRing);       // ring rounds per tile
+    constexpr int TP = 32 * MT;                                          // pixels per wave iteration
 
-    // ---- load cursor (runs kRing chunks ahead of the MFMAs)
-    int l_tile = blockIdx.x * 8 + wave;
+    // ---- load cursor (runs kRing chunks ahead of the MFMAs); (r, rem, koff) are wave-uniform
+    int l_tile = blockIdx.x * NW + wave;
     int l_r = 0, l_rem = 0, l_koff = 0;
-    long long l_base = 0;
-    int l_sy0 = 0, l_sx0 = 0;
-    bool l_ok = false;
+    long long l_base[MT];
+    int l_sy0[MT], l_sx0[MT];
+    bool l_ok[MT];
     auto setup = [&]() {
-        const unsigned p = (unsigned)l_tile * 32u + (unsigned)li;
-        l_ok = (l_tile < ntiles) && (p < P);
-        const unsigned pp = l_ok ? p : 0u;
-        const unsigned img = pp / per_img, rem = pp - img * per_img;
-        const unsigned gy = rem / GX, gx = rem - gy * GX;
-        l_sy0 = (int)gy * g.SS + g.OFF;
-        l_sx0 = (int)gx * g.SS + g.OFF;
-        const long long simg = (U8IN && inds) ? inds[img] : (long long)img;
-        l_base = ((simg * g.H + l_sy0) * g.W + l_sx0) * (long long)g.C + (U8IN ? 16 : 4) * lh;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const unsigned p = (unsigned)l_tile * (unsigned)TP + (unsigned)(32 * m + li);
+            l_ok[m] = (l_tile < ntiles) && (p < P);
+            const unsigned pp = l_ok[m] ? p : 0u;
+            const unsigned img = pp / per_img, rem = pp - img * per_img;
+            const unsigned gy = rem / GX, gx = rem - gy * GX;
+            l_sy0[m] = (int)gy * g.SS + g.OFF;
+            l_sx0[m] = (int)gx * g.SS + g.OFF;
+            const long long simg = (U8IN && inds) ? inds[img] : (long long)img;
+            l_base[m] = ((simg * g.H + l_sy0[m]) * g.W + l_sx0[m]) * (long long)g.C + (U8IN ? 16 : 4) * lh;
+        }
     };
     auto advance = [&](bool may_wrap) {
         if (U8IN) {
@@ -289,23 +297,27 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
             setup();
         }
     };
-
     // The ring is loaded UNCONDITIONALLY (invalid taps read a clamped, always-mapped address and are zeroed when
     // consumed, bit d of `vmask`), and slot d is refilled only after its MFMAs have been issued: the slots then
-    // keep fixed registers and the compiler can count the loads (s_waitcnt vmcnt(kRing-1)) instead of draining
-    // the queue at every loop back-edge.
-    uint4 ring[kRing];
-    unsigned vmask = 0u;
+    // keep fixed registers and the compiler can count the loads (s_waitcnt vmcnt(N)) instead of draining the queue
+    // at every loop back-edge.
+    u32x4 ring[MT][kRing];
+    unsigned vmask[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) vmask[m] = 0u;
     auto fetch = [&](int d) {
-        bool ok = l_ok;
-        if (!U8IN && PAD) {
-            const int sy = l_sy0 + l_r, sx = l_sx0 + (l_rem >> g.logC);
-            ok = ok && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            bool ok = l_ok[m];
+            if (!U8IN && PAD) {
+                const int sy = l_sy0[m] + l_r, sx = l_sx0[m] + (l_rem >> g.logC);
+                ok = ok && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
+            }
+            const long long off = ok ? (l_base[m] + l_koff) : (long long)((U8IN ? 16 : 4) * lh);
+            if (U8IN) ring[m][d] = *reinterpret_cast<const u32x4*>(static_cast<const uint8_t*>(src_v) + off);
+            else ring[m][d] = *reinterpret_cast<const u32x4*>(static_cast<const float*>(src_v) + off);
+            if (PAD) vmask[m] = (vmask[m] & ~(1u << d)) | ((ok ? 1u : 0u) << d);
         }
-        const long long off = ok ? (l_base + l_koff) : (long long)((U8IN ? 16 : 4) * lh);
-        if (U8IN) ring[d] = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(src_v) + off);
-        else ring[d] = *reinterpret_cast<const uint4*>(static_cast<const float*>(src_v) + off);
-        if (PAD) vmask = (vmask & ~(1u << d)) | ((ok ? 1u : 0u) << d);
     };
     setup();
 #pragma unroll
@@ -317,16 +329,15 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
     float bias_r[NJT];
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) bias_r[jt] = (EPI == EPI_BIAS_RELU) ? Bs[(32 * NJT) * ldb + 8 + jt * 32 + li] : 0.0f;
-    constexpr int NACC = NJT == 1 ? 2 : NJT;
     constexpr int NB = U8IN ? 4 : 1;                  // float4 B fragments per chunk and channel tile
-    for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwv) {
-        // NJT == 1: two accumulators taking alternate k-pairs, so that consecutive MFMAs of a wave are independent
-        // (a dependent 32x32x2 chain leaves the pipe idle between issue and write-back); summed in the epilogue.
-        f32x16 acc[NACC];
+    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += nwv) {
+        f32x16 acc[MT][NJT];
 #pragma unroll
-        for (int jt = 0; jt < NACC; ++jt)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[jt][e] = 0.0f;
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][jt][e] = 0.0f;
         const float* __restrict__ Bp = Bs + li * ldb + (U8IN ? 16 : 4) * lh;
         float4 bcur[NJT][NB], bnxt[NJT][NB];
 #pragma unroll
@@ -337,39 +348,34 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
 #pragma unroll
             for (int d = 0; d < kRing; ++d) {
                 Bp += U8IN ? 32 : 8;                  // B fragments of the NEXT chunk are read under this chunk's MFMAs
+                if (!(g.diag & 2)) {
 #pragma unroll
-                for (int jt = 0; jt < NJT; ++jt)
+                    for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-                    for (int q = 0; q < NB; ++q) bnxt[jt][q] = *reinterpret_cast<const float4*>(Bp + jt * 32 * ldb + 4 * q);
-                uint4 A = ring[d];
-                if (PAD && !((vmask >> d) & 1u)) A = make_uint4(0u, 0u, 0u, 0u);
-                if (U8IN) {
-                    const uint32_t w[4] = {A.x, A.y, A.z, A.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float a0 = u8_tap(w[q], 0), a1 = u8_tap(w[q], 1), a2 = u8_tap(w[q], 2), a3 = u8_tap(w[q], 3);
-#pragma unroll
-                        for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 0 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[jt][q].x, acc[NJT == 1 ? 0 : jt], 0, 0, 0);
-#pragma unroll
-                        for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 1 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[jt][q].y, acc[NJT == 1 ? 1 : jt], 0, 0, 0);
-#pragma unroll
-                        for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 0 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bcur[jt][q].z, acc[NJT == 1 ? 0 : jt], 0, 0, 0);
-#pragma unroll
-                        for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 1 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bcur[jt][q].w, acc[NJT == 1 ? 1 : jt], 0, 0, 0);
-                    }
-                } else {
-                    const float a0 = __uint_as_float(A.x), a1 = __uint_as_float(A.y), a2 = __uint_as_float(A.z),
-                                a3 = __uint_as_float(A.w);
-#pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 0 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[jt][0].x, acc[NJT == 1 ? 0 : jt], 0, 0, 0);
-#pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 1 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[jt][0].y, acc[NJT == 1 ? 1 : jt], 0, 0, 0);
-#pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 0 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bcur[jt][0].z, acc[NJT == 1 ? 0 : jt], 0, 0, 0);
-#pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) acc[NJT == 1 ? 1 : jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bcur[jt][0].w, acc[NJT == 1 ? 1 : jt], 0, 0, 0);
+                        for (int q = 0; q < NB; ++q) bnxt[jt][q] = *reinterpret_cast<const float4*>(Bp + jt * 32 * ldb + 4 * q);
                 }
-                fetch(d);                            // refill the slot just consumed (kRing chunks ahead)
+                u32x4 A[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    A[m] = ring[m][d];
+                    if (PAD && !((vmask[m] >> d) & 1u)) A[m] = (u32x4){0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {       // k-pair c of this fragment
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const float a = U8IN ? u8_tap(A[m][q], c) : __uint_as_float(A[m][c]);
+#pragma unroll
+                            for (int jt = 0; jt < NJT; ++jt) {
+                                const float b = c == 0 ? bcur[jt][q].x : c == 1 ? bcur[jt][q].y : c == 2 ? bcur[jt][q].z : bcur[jt][q].w;
+                                acc[m][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m][jt], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                if (!(g.diag & 1)) fetch(d);         // refill the slot just consumed (kRing chunks ahead)
                 advance(d == kRing - 1);
                 __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: hipcc otherwise sinks all kRing loads to the
                                                      // loop tail and the first one is awaited one instruction later
@@ -379,48 +385,51 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(const void* __restrict
                     for (int q = 0; q < NB; ++q) bcur[jt][q] = bnxt[jt][q];
             }
         }
-        if (NJT == 1) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[0][e] += acc[NACC - 1][e];
-        }
         // ---- epilogue: destination offset of THIS lane's pixel, fetched per accumulator row by a wave shuffle
-        int myoff = -1;
-        {
-            const unsigned p = (unsigned)tile * 32u + (unsigned)li;
-            if (p < P) {
-                const unsigned img = p / per_img, rem = p - img * per_img;
-                const unsigned gy = rem / GX, gx = rem - gy * GX;
-                myoff = (int)(((img * (unsigned)g.DH + (gy * (unsigned)g.DM + (unsigned)day)) * (unsigned)g.DW +
-                               (gx * (unsigned)g.DM + (unsigned)dax)) * (unsigned)g.DC);
-            }
+        if (g.diag & 4) {
+            if (acc[0][0][0] == 123.456f) dst[0] = 1.0f;
+            continue;
         }
-        int offs[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) offs[e] = __shfl(myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64);
-        if (EPI == EPI_MASK) {
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                // CLS4: channel tile jt is parity class (jt>>1, jt&1) of the stride-2 data gradient -> its own pixel
-                const int noff = CLS4 ? ((jt >> 1) * g.DW + (jt & 1)) * g.DC + li : jt * 32 + li;
-                float mk[16];                        // the 16 mask loads of a tile are in flight together
-#pragma unroll
-                for (int e = 0; e < 16; ++e) mk[e] = mask_src[(size_t)(offs[e] >= 0 ? offs[e] : 0) + noff];
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (offs[e] >= 0) dst[(size_t)offs[e] + noff] = mk[e] > 0.0f ? acc[jt][e] : 0.0f;
+        for (int m = 0; m < MT; ++m) {
+            int myoff = -1;
+            {
+                const unsigned p = (unsigned)tile * (unsigned)TP + (unsigned)(32 * m + li);
+                if (p < P) {
+                    const unsigned img = p / per_img, rem = p - img * per_img;
+                    const unsigned gy = rem / GX, gx = rem - gy * GX;
+                    myoff = (int)(((img * (unsigned)g.DH + (gy * (unsigned)g.DM + (unsigned)day)) * (unsigned)g.DW +
+                                   (gx * (unsigned)g.DM + (unsigned)dax)) * (unsigned)g.DC);
+                }
             }
-        } else {
+            int offs[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
+            for (int e = 0; e < 16; ++e) offs[e] = __shfl(myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64);
+            if (EPI == EPI_MASK) {
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt) {
-                    float v = acc[jt][e];
-                    if (EPI == EPI_BIAS_RELU) {
-                        v = v + bias_r[jt];
-                        v = v > 0.0f ? v : 0.0f;
-                    }
-                    if (offs[e] >= 0) dst[(size_t)offs[e] + jt * 32 + li] = v;
+                    // CLS4: channel tile jt is parity class (jt>>1, jt&1) of the stride-2 data gradient -> its own pixel
+                    const int noff = CLS4 ? ((jt >> 1) * g.DW + (jt & 1)) * g.DC + li : jt * 32 + li;
+                    float mk[16];                        // the 16 mask loads of a tile are in flight together
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) mk[e] = mask_src[(size_t)(offs[e] >= 0 ? offs[e] : 0) + noff];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (offs[e] >= 0) dst[(size_t)offs[e] + noff] = mk[e] > 0.0f ? acc[m][jt][e] : 0.0f;
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt) {
+                        float v = acc[m][jt][e];
+                        if (EPI == EPI_BIAS_RELU) {
+                            v = v + bias_r[jt];
+                            v = v > 0.0f ? v : 0.0f;
+                        }
+                        if (offs[e] >= 0) dst[(size_t)offs[e] + jt * 32 + li] = v;
+                    }
+            }
         }
     }
 }
@@ -693,24 +702,40 @@ extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, floa
     return check_launch("conv_repack_kernel");
 }
 
-template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4 = false>
-static int launch_stream(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
+template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT, int NW>
+static int launch_stream_cfg(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
                          float* dst, const ConvGeom& g, hipStream_t s) {
     const size_t smem = ((size_t)(32 * NJT) * (g.K + 4) + 8 + 32 * NJT) * sizeof(float);   // weights + slack + bias
-    auto k = conv_stream_kernel<NJT, U8IN, EPI, PAD, CLS4>;
+    auto k = conv_stream_kernel<NJT, U8IN, EPI, PAD, CLS4, MT, NW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) {
         set_error("conv_stream_kernel: hipFuncSetAttribute(%zu bytes of LDS): %s", smem, hipGetErrorString(e));
         return MI355PPO_EHIP;
     }
-    const int ntiles = (int)((g.P + 31) / 32);
+    const int ntiles = (int)((g.P + 32 * MT - 1) / (32 * MT));
+    static const int s_diag = getenv("MI355PPO_CONV_DIAG") ? atoi(getenv("MI355PPO_CONV_DIAG")) : 0;
+    ConvGeom gd = g;
+    gd.diag = s_diag;
     // persistent workgroups of 8 waves: one per CU when the weights fill the LDS, two when they are small
-    int wgs = (smem > 80 * 1024 ? 256 : 512) / g.classes;
-    const int need = (ntiles + 7) / 8;
+    // (one 8-wave workgroup per CU: the kernels use 160-240 VGPRs, so two would not be co-resident anyway)
+    int wgs = 256 / g.classes;
+    const int need = (ntiles + NW - 1) / NW;
     if (wgs > need) wgs = need;
-    hipLaunchKernelGGL(k, dim3((unsigned)wgs, (unsigned)g.classes), dim3(512), smem, s, src, inds, Bt, bias, mask_src, dst, g,
+    hipLaunchKernelGGL(k, dim3((unsigned)wgs, (unsigned)g.classes), dim3(64 * NW), smem, s, src, inds, Bt, bias, mask_src, dst, gd,
                        ntiles);
     return check_launch("conv_stream_kernel");
+}
+
+// MI355PPO_CONV_CFG (tuning): 0 = MT 2 / 8 waves (default), 1 = MT 1 / 16 waves, 2 = MT 1 / 8 waves
+template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4 = false, int MT = 2>
+static int launch_stream(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
+                         float* dst, const ConvGeom& g, hipStream_t s) {
+    static const int cfg = getenv("MI355PPO_CONV_CFG") ? atoi(getenv("MI355PPO_CONV_CFG")) : 0;
+    if (NJT == 4 || MT == 1) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
+    if (cfg == 1) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 16>(src, inds, Bt, bias, mask_src, dst, g, s);
+    // small problems (rollout batches): 32-pixel tiles give every wave of the chip something to do
+    if (cfg == 2 || g.P < 64LL * 2 * 2048) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
+    return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 2, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
 }
 
 static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, const float* bias, float* dst,
@@ -787,7 +812,7 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
         g.K = 4 * Cout; g.P = (long long)images * (Hin / 2) * (Hin / 2);
         if (variant == 2) {     // one pass for all four parity classes: they read the SAME dz taps (only weights and
             g.classes = 1;      // destination pixel differ), so the 4x32 class channels form one 128-wide GEMM
-            return launch_stream<4, false, EPI_MASK, true, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
+            return launch_stream<4, false, EPI_MASK, true, true, 1>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
         }
         if (variant == 3)
             return launch_stream<1, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);

@@ -46,11 +46,13 @@ def main():
             bt = cnn.repack_weights(W, layer)
             src = acts[layer - 1]
             dst = torch.empty((M, hout, hout, cout), device=DEV)
-            for v in (1, 2):
+            for v in ((2,) if os.environ.get("CNNBENCH_ONLY") == "fwd" else (1, 2)):
                 us = bench(lambda: cnn.conv_fwd(src, bt, b, layer, inds if layer == 1 else None, dst, variant=v))
                 out(k="fwd", variant=v, layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK)
             acts[layer] = dst
             dz = torch.randn_like(dst)
+            if os.environ.get("CNNBENCH_ONLY") == "fwd":
+                continue
             us = bench(lambda: cnn.conv_wgrad(src, dz, layer, inds if layer == 1 else None))
             out(k="wgrad", layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK)
             if layer > 1:
