@@ -734,7 +734,7 @@ static int launch_stream(const void* src, const int64_t* inds, const float* Bt, 
     if (NJT == 4 || MT == 1) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
     if (cfg == 1) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 16>(src, inds, Bt, bias, mask_src, dst, g, s);
     // small problems (rollout batches): 32-pixel tiles give every wave of the chip something to do
-    if (cfg == 2 || g.P < 64LL * 2 * 2048) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
+    if (cfg == 2 || g.P < 64LL * 4 * 2048) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
     return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 2, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
 }
 

@@ -213,6 +213,129 @@ __global__ __launch_bounds__(256) void gae_tile(const float* __restrict__ reward
     }
 }
 
+// ------------------------------------------------------------------------------- staged-scan kernel
+// Small N, revisited (BASELINE sizes: 128 x 1024 = 2.6 MB, L2-resident): everything that is NOT on the
+// recurrence's dependency chain is done by all 256 threads, coalesced; the chain itself is two dependent f32 ops
+// per step fed from LDS.
+//   phase 1a  all threads: rewards / values / dones of a (TC rows x CW columns) chunk -> LDS (+ the row above it:
+//             values[t+1], dones[t+1], or next_value / next_done for the last row)
+//   phase 1b  all threads: delta[t] = (r + (g*nv)*nnt) - v  and  coef[t] = gl*nnt   (the reference's op order)
+//   phase 2   CW lanes:    adv[t] = delta[t] + coef[t]*adv[t+1], t descending, carry kept across chunks
+//   phase 3   all threads: returns = adv + values; both outputs stored coalesced
+// CW columns per workgroup (4 / 16 / 64 by N) so that even N = 64 x T = 2048 spreads over 16 CUs.
+constexpr int kStageFloats = 2048;      // elements of one array per chunk
+
+template <int CW>
+__global__ __launch_bounds__(256) void gae_staged(const float* __restrict__ rewards, const float* __restrict__ dones,
+                                                  const float* __restrict__ values, const float* __restrict__ next_done,
+                                                  const float* __restrict__ next_value, float* __restrict__ advantages,
+                                                  float* __restrict__ returns, int T, int N, float gamma, float gl) {
+    constexpr int TC = kStageFloats / CW;                       // rows per chunk
+    constexpr int PER = kStageFloats / 256;                     // elements per thread per array (8)
+    __shared__ float sR[TC * CW];                               // rewards -> delta -> advantages
+    __shared__ float sV[(TC + 1) * CW];                         // values, row TC = the row above the chunk
+    __shared__ float sD[(TC + 1) * CW];                         // dones, same
+    __shared__ float sC[TC * CW];                               // coef = gl * nnt
+    const int tid = threadIdx.x;
+    const int col0 = blockIdx.x * CW;
+    const int ncols = min(CW, N - col0);
+    float last = 0.0f;                                          // lastgaelam = 0 (Python int in the reference)
+    for (int hi = T; hi > 0; hi -= TC) {
+        const int lo = max(0, hi - TC), rows = hi - lo;
+        // ---- 1a
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + 256 * q, j = e / CW, c = e % CW;
+            if (j < rows && c < ncols) {
+                const int64_t off = (int64_t)(lo + j) * N + col0 + c;
+                sR[e] = rewards[off];
+                sV[e] = values[off];
+                sD[e] = dones[off];
+            }
+        }
+        if (tid < ncols) {                                      // the row above the chunk
+            const int c = tid;
+            sV[rows * CW + c] = hi == T ? next_value[col0 + c] : values[(int64_t)hi * N + col0 + c];
+            sD[rows * CW + c] = hi == T ? next_done[col0 + c] : dones[(int64_t)hi * N + col0 + c];
+        }
+        __syncthreads();
+        // ---- 1b
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + 256 * q, j = e / CW, c = e % CW;
+            if (j < rows && c < ncols) {
+                const float nnt = 1.0f - sD[e + CW];
+                float x = gamma * sV[e + CW];
+                x = x * nnt;
+                x = sR[e] + x;
+                sR[e] = x - sV[e];                               // delta
+                sC[e] = gl * nnt;
+            }
+        }
+        __syncthreads();
+        // ---- 2
+        if (tid < ncols) {
+            // groups of 8 steps; the LDS reads of the next group are issued before the current group's chain runs
+            int j = rows - 1;
+            float dl[8], cf[8], dn[8], cn[8];
+            if (j >= 7) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    dl[u] = sR[(j - u) * CW + tid];
+                    cf[u] = sC[(j - u) * CW + tid];
+                }
+            }
+            for (; j >= 7; j -= 8) {
+                const bool more = j - 8 >= 7;
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        dn[u] = sR[(j - 8 - u) * CW + tid];
+                        cn[u] = sC[(j - 8 - u) * CW + tid];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float c = cf[u] * last;
+                    last = dl[u] + c;
+                    sR[(j - u) * CW + tid] = last;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    dl[u] = dn[u];
+                    cf[u] = cn[u];
+                }
+            }
+            for (; j >= 0; --j) {
+                const float c = sC[j * CW + tid] * last;
+                last = sR[j * CW + tid] + c;
+                sR[j * CW + tid] = last;
+            }
+        }
+        __syncthreads();
+        // ---- 3
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + 256 * q, j = e / CW, c = e % CW;
+            if (j < rows && c < ncols) {
+                const int64_t off = (int64_t)(lo + j) * N + col0 + c;
+                const float a = sR[e];
+                advantages[off] = a;
+                returns[off] = a + sV[e];
+            }
+        }
+        __syncthreads();                                        // LDS is rewritten by the next chunk
+    }
+}
+
+template <int CW>
+static int launch_staged(const float* r, const float* d, const float* v, const float* nd, const float* nv, float* adv,
+                         float* ret, int T, int N, float gamma, float gl, hipStream_t s) {
+    const int grid = (N + CW - 1) / CW;
+    hipLaunchKernelGGL((gae_staged<CW>), dim3(grid), dim3(256), 0, s, r, d, v, nd, nv, adv, ret, T, N, gamma, gl);
+    return check_launch("gae_staged");
+}
+
 template <int CW>
 static int launch_tile(const float* r, const float* d, const float* v, const float* nd, const float* nv, float* adv,
                        float* ret, int T, int N, float gamma, float gl, hipStream_t s) {
@@ -245,7 +368,7 @@ extern "C" MI355PPO_API int mi355ppo_gae_f32_variant(const float* rewards, const
     MI355_REQUIRE(aligned(rewards, 4) && aligned(dones, 4) && aligned(values, 4) && aligned(next_done, 4) &&
                       aligned(next_value, 4) && aligned(advantages, 4) && aligned(returns, 4),
                   MI355PPO_EALIGN, "mi355ppo_gae_f32: pointers must be 4-byte aligned");
-    MI355_REQUIRE(variant >= 0 && variant <= 5, MI355PPO_EINVAL, "mi355ppo_gae_f32: unknown variant %d", variant);
+    MI355_REQUIRE(variant >= 0 && variant <= 6, MI355PPO_EINVAL, "mi355ppo_gae_f32: unknown variant %d", variant);
     const float g = (float)gamma;
     const float gl = (float)(gamma * gae_lambda);   // double product, one rounding (see header)
     hipStream_t s = as_stream(stream);
@@ -254,7 +377,7 @@ extern "C" MI355PPO_API int mi355ppo_gae_f32_variant(const float* rewards, const
                       aligned(returns, 16);
     if (variant == 0) {
         // auto: tile kernel while the column kernel could not even put one wave on every SIMD
-        if (N < 16384) variant = 2;
+        if (N < 16384) variant = 6;
         else if (vec4 && N >= 262144) variant = 3;
         else variant = 1;
     }
@@ -269,6 +392,10 @@ extern "C" MI355PPO_API int mi355ppo_gae_f32_variant(const float* rewards, const
             return launch_cols<4, 4>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
         case 4: return launch_tile<64>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
         case 5: return launch_tile<32>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
+        case 6:
+            if (N <= 256) return launch_staged<4>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
+            if (N <= 4096) return launch_staged<16>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
+            return launch_staged<64>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
     }
     return MI355PPO_EINVAL;
 }

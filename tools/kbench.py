@@ -62,15 +62,18 @@ def out(**kw):
 
 
 def bench_gae():
-    for T, N in [(128, 128), (128, 256), (128, 1024), (2048, 64), (128, 4096), (128, 16384), (128, 65536), (128, 262144),
-                 (128, 1 << 20), (128, 1 << 22)]:
+    sizes = [(128, 128), (128, 256), (128, 1024), (2048, 64), (128, 4096), (128, 16384), (128, 65536), (128, 262144),
+             (128, 1 << 20), (128, 1 << 22)]
+    if __import__("os").environ.get("KBENCH_GAE_SIZES"):
+        sizes = [tuple(int(x) for x in t.split("x")) for t in __import__("os").environ["KBENCH_GAE_SIZES"].split(",")]
+    for T, N in sizes:
         s = {k: v.to(DEV) for k, v in synthetic.rollout_scalars(T, min(N, 4096), 4, seed=1).items()}
         if N > 4096:
             rep = N // 4096
             s = {k: (v.repeat(1, rep) if v.dim() == 2 else v.repeat(rep)).contiguous() for k, v in s.items()}
         adv, ret = torch.empty_like(s["rewards"]), torch.empty_like(s["rewards"])
         nbytes = 20 * T * N + 8 * N
-        for variant in [1, 2, 3, 4, 5]:
+        for variant in [1, 2, 3, 4, 5, 6]:
             f = lambda: ops.gae(s["rewards"], s["dones"], s["values"], s["next_done"], s["next_value"], 0.99, 0.95, adv, ret, variant=variant)
             med, mn = timeit(f, iters=30)
             cold, _ = timeit(f, iters=10, flush=flush_caches) if nbytes < (1 << 28) else (med, mn)
