@@ -102,7 +102,7 @@ class AtariAgent(_DiscreteMixin, nn.Module):
             self._trunk = cnn.NatureTrunk()
         net = self.network
         feats = self._trunk(obs_rows, inds, net[0], net[2], net[4])
-        hidden = torch.relu(torch.nn.functional.linear(feats, cnn.fc_weight_hwc(net[7].weight), net[7].bias))
+        hidden = cnn.LinearReLUHwcFn.apply(feats, net[7].weight, net[7].bias)
         return self.actor(hidden), self.critic(hidden)
 
     def get_value(self, x):

@@ -169,3 +169,33 @@ def fc_weight_hwc(weight: torch.Tensor) -> torch.Tensor:
     """Linear(64*7*7, 512) weight with its input features re-ordered from the reference's flatten order (c, h, w)
     to the trunk's (h, w, c); differentiable (the gradient flows back into the original layout)."""
     return weight.view(weight.shape[0], 64, 7, 7).permute(0, 2, 3, 1).reshape(weight.shape[0], 64 * 7 * 7)
+
+
+class LinearReLUHwcFn(torch.autograd.Function):
+    """``relu(a @ fc_weight_hwc(W).T + b)`` for the trunk's (h, w, c)-ordered features -- Agent.network[7:9]
+    (Linear(3136, 512) + ReLU, cleanrl/ppo_atari_multigpu.py:144-145).  Plain library GEMMs (hipBLASLt), arranged so
+    that the ReLU rides in the forward GEMM's epilogue and the weight gradient -- a (512 x M)(M x 3136) product whose
+    98 output tiles cannot fill 256 CUs -- is split over M into a batched GEMM plus a small sum."""
+
+    SPLIT = 16
+
+    @staticmethod
+    def forward(ctx, a, W, b):
+        Wp = fc_weight_hwc(W.detach()).contiguous()
+        h = torch._addmm_activation(b.detach(), a, Wp.t())                     # bias + ReLU fused into the GEMM epilogue
+        ctx.save_for_backward(a, h, Wp)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        a, h, Wp = ctx.saved_tensors
+        dz = torch.ops.aten.threshold_backward(dh.contiguous(), h, 0.0)
+        da = dz @ Wp if ctx.needs_input_grad[0] else None
+        m, n = dz.shape
+        s = LinearReLUHwcFn.SPLIT
+        if m % s == 0 and m >= 4096:
+            dWp = torch.bmm(dz.view(s, m // s, n).transpose(1, 2), a.view(s, m // s, a.shape[1])).sum(0)
+        else:
+            dWp = dz.t() @ a
+        dW = dWp.view(n, 7, 7, 64).permute(0, 3, 1, 2).reshape(n, 64 * 7 * 7)     # back to the (c, h, w) feature order
+        return da, dW, dz.sum(0)

@@ -607,7 +607,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 constexpr int kRedChunk = 32;     // partials folded per stage-1 workgroup row
 
 __global__ __launch_bounds__(256) void conv_wgrad_reduce1(const float* __restrict__ part_w, int nparts, int NK,
-                                                          float* __restrict__ mid) {       // mid: [nchunks][NK]
+                                                          float* __restrict__ mid,          // mid: [nchunks][NK]
+                                                          const float* __restrict__ part_b, int nparts_b, int N,
+                                                          float* __restrict__ mid_b) {      // mid_b: [nchunks][N]
+    if (blockIdx.x == gridDim.x - 1) {                // the extra block column folds the bias partials of this chunk
+        const int n = threadIdx.x;
+        if (n >= N) return;
+        const int p0 = blockIdx.y * kRedChunk;
+        const int p1 = p0 + kRedChunk < nparts_b ? p0 + kRedChunk : nparts_b;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = p0; p < p1; ++p) s4[p & 3] += part_b[(size_t)p * N + n];
+        mid_b[blockIdx.y * N + n] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        return;
+    }
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= NK) return;
     const int p0 = blockIdx.y * kRedChunk;
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce1(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void conv_wgrad_reduce2(const float* __restrict__ mid, int nchunks,
-                                                          const float* __restrict__ part_b, int nparts_b, int N, int C,
+                                                          const float* __restrict__ mid_b, int nchunks_b, int N, int C,
                                                           int KH, int KW, float scale, float* __restrict__ dW,
                                                           float* __restrict__ db) {
     const int K = KH * KW * C;
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce2(const float* __restric
     }
     if (blockIdx.x == 0 && threadIdx.x < N && db) {
         float s = 0.0f;
-        for (int p = 0; p < nparts_b; ++p) s += part_b[(size_t)p * N + threadIdx.x];
+        for (int c = 0; c < nchunks_b; ++c) s += mid_b[c * N + threadIdx.x];
         db[threadIdx.x] = s;
     }
 }
@@ -845,7 +857,7 @@ extern "C" MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t i
     if (images <= 0 || !layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout)) return 0;
     const size_t wparts = (size_t)wgrad_grid(images) * (kWgradSplitLayer1 && layer == 1 ? 4 : 1);
     const size_t nchunks = (wparts + kRedChunk - 1) / kRedChunk;
-    return ((wparts + nchunks) * (size_t)Cout * KH * KH * Cin + (size_t)wgrad_grid(images) * Cout) * sizeof(float);
+    return ((wparts + nchunks) * (size_t)Cout * KH * KH * Cin + ((size_t)wgrad_grid(images) + nchunks) * Cout) * sizeof(float);
 }
 
 extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW,
@@ -891,13 +903,16 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     }
     int rc = check_launch("conv_wgrad_kernel");
     if (rc) return rc;
-    const int total = Cout * g.K;
-    const int nchunks = (wparts + kRedChunk - 1) / kRedChunk;
+    const int total_w = Cout * g.K;
+    const int nchunks = (wparts + kRedChunk - 1) / kRedChunk;          // >= the bias partials' chunk count (grid <= wparts)
+    const int nchunks_b = (grid + kRedChunk - 1) / kRedChunk;
     float* mid = part_b + (size_t)grid * Cout;
-    hipLaunchKernelGGL(conv_wgrad_reduce1, dim3((total + 255) / 256, nchunks), dim3(256), 0, s, part_w, wparts, total, mid);
+    float* mid_b = mid + (size_t)nchunks * total_w;
+    hipLaunchKernelGGL(conv_wgrad_reduce1, dim3((total_w + 255) / 256 + 1, nchunks), dim3(256), 0, s, part_w, wparts, total_w, mid,
+                       part_b, grid, Cout, mid_b);
     rc = check_launch("conv_wgrad_reduce1");
     if (rc) return rc;
-    hipLaunchKernelGGL(conv_wgrad_reduce2, dim3((total + 255) / 256), dim3(256), 0, s, mid, nchunks, part_b, grid, Cout, Cin, KH,
-                       KH, layer == 1 ? kInv255 : 1.0f, dW, db);
+    hipLaunchKernelGGL(conv_wgrad_reduce2, dim3((total_w + 255) / 256), dim3(256), 0, s, mid, nchunks, mid_b, nchunks_b, Cout, Cin,
+                       KH, KH, layer == 1 ? kInv255 : 1.0f, dW, db);
     return check_launch("conv_wgrad_reduce2");
 }

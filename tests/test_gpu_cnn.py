@@ -131,9 +131,9 @@ def test_conv_wgrad(layer, images):
     assert torch.equal(dW, dW2) and torch.equal(db, db2), "weight gradient must be deterministic"
 
 
-def test_trunk_matches_reference_network_forward_backward():
+@pytest.mark.parametrize("images", [48, 4096])
+def test_trunk_matches_reference_network_forward_backward(images):
     """The whole conv stack + Linear(3136,512) against the reference's nn.Sequential in float64 (same weights)."""
-    images = 48
     torch.manual_seed(0)
     frames = torch.from_numpy(synthetic.atari_frames(images, seed=11))
     net = torch.nn.Sequential(torch.nn.Conv2d(4, 32, 8, stride=4), torch.nn.ReLU(), torch.nn.Conv2d(32, 64, 4, stride=2),
@@ -149,8 +149,17 @@ def test_trunk_matches_reference_network_forward_backward():
     gnet = copy.deepcopy(net).to(DEV)
     trunk = cnn.NatureTrunk()
     feats = trunk(_nhwc(frames).to(DEV), None, gnet[0], gnet[2], gnet[4])
-    h = F.relu(F.linear(feats, cnn.fc_weight_hwc(gnet[7].weight), gnet[7].bias))
+    h = cnn.LinearReLUHwcFn.apply(feats, gnet[7].weight, gnet[7].bias)
     _close(h, ref_h, "trunk+fc forward", tol=5e-5)
     h.backward(gout.to(DEV))
-    for (name, p), (_, pr) in zip(gnet.named_parameters(), ref_net.named_parameters()):
-        _close(p.grad, pr.grad, f"grad of {name}", tol=5e-5)
+    # calibration: torch's own f32 network on the same device.  Gradients of parameters are sums over images x pixels
+    # (1.6 M f32 terms for conv1 at 4096 images), so the bound is the larger of 5e-5 of the gradient's scale and
+    # 4x the error torch's f32 backward shows against the same float64 reference.
+    tnet = copy.deepcopy(net).to(DEV)
+    th = tnet((frames.float() / 255.0).to(DEV))
+    th.backward(gout.to(DEV))
+    for (name, p), (_, pr), (_, pt) in zip(gnet.named_parameters(), ref_net.named_parameters(), tnet.named_parameters()):
+        scale = pr.grad.abs().max().item()
+        err = (p.grad.cpu().double() - pr.grad).abs().max().item()
+        err_torch = (pt.grad.cpu().double() - pr.grad).abs().max().item()
+        assert err <= max(5e-5 * scale, 4.0 * err_torch), f"grad of {name}: err {err:.3e}, torch f32 err {err_torch:.3e}, scale {scale:.3e}"
