@@ -18,7 +18,7 @@ SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "op
 HEADERS = ["common.h", "catrow.h", os.path.join("..", "..", "include", "mi355ppo.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every f32 multiply/add rounds separately, as the reference's un-fused torch ops do.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _stale(target: str, deps: list[str]) -> bool:

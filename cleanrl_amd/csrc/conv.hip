@@ -32,6 +32,8 @@
 //   and scatters into torch's (Cout, Cin, KH, KW) layout.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace mi355ppo {
 
@@ -434,6 +436,228 @@ __global__ __launch_bounds__(64 * NW) void conv_stream_kernel(const void* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------ kernel F
+// conv_fixed_kernel: kernel S with the layer geometry as template constants and buffer (bounds-checked, 32-bit
+// offset) memory instructions -- what remains between two MFMAs is one buffer_load per 4*NJT*MT MFMAs and the LDS
+// fragment reads; all tap addressing is immediates / SGPR offsets:
+//   * the chunk loop of a tile is fully unrolled (8 .. 72 chunks), so tap row r, offset within the run and ring slot
+//     are compile-time; the refill of chunk c+8 comes from this tile or, past its end, from the next tile whose
+//     per-lane base offsets were computed one tile ahead;
+//   * zero padding of the data-gradient problems is the hardware's range check: an invalid tap loads from offset
+//     0xFFFFF000 (> num_records) and returns 0 -- no masks, no selects when the fragment is consumed;
+//   * the epilogue stores through a buffer resource as well: rows beyond P get the same out-of-range offset and are
+//     dropped by the range check, so there is no per-row predication.
+// f32 sources and every destination must be < 4 GiB (checked by the launcher).  The uint8 source of layer 1 (the
+// whole rollout buffer, which may exceed 4 GiB) keeps 64-bit global loads; it needs no padding.
+template <int H_, int W_, int C_, int KH_, int KW_, int GY_, int GX_, int SS_, int OFF_, int DH_, int DW_, int DC_, int DM_>
+struct FixedGeom {
+    static constexpr int H = H_, W = W_, C = C_, KH = KH_, KW = KW_, GY = GY_, GX = GX_, SS = SS_, OFF = OFF_, DH = DH_,
+                         DW = DW_, DC = DC_, DM = DM_;
+    static constexpr int K = KH_ * KW_ * C_, RUN = KW_ * C_, PITCH = W_ * C_, PER_IMG = GY_ * GX_;
+};
+using GeomConv1 = FixedGeom<84, 84, 4, 8, 8, 20, 20, 4, 0, 20, 20, 32, 1>;
+using GeomConv2 = FixedGeom<20, 20, 32, 4, 4, 9, 9, 2, 0, 9, 9, 64, 1>;
+using GeomConv3 = FixedGeom<9, 9, 64, 3, 3, 7, 7, 1, 0, 7, 7, 64, 1>;
+using GeomDgrad3 = FixedGeom<7, 7, 64, 3, 3, 9, 9, 1, -2, 9, 9, 64, 1>;       // source = dz3, destination = da2
+using GeomDgrad2 = FixedGeom<9, 9, 64, 2, 2, 10, 10, 1, -1, 20, 20, 32, 2>;   // source = dz2, destination = da1 (4 classes)
+
+constexpr unsigned kOob = 0xFFFFF000u;      // buffer offset that is out of range for every tensor < 4 GiB - 4 KiB
+constexpr int kRsrcWord3 = 0x00020000;      // raw buffer, 32-bit elements (gfx9 / CDNA resource format)
+
+template <class G, int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT>
+__global__ __launch_bounds__(512) void conv_fixed_kernel(const void* __restrict__ src_v, const int64_t* __restrict__ inds,
+                                                         const float* __restrict__ Bt_all, const float* __restrict__ bias,
+                                                         const float* __restrict__ mask_src, float* __restrict__ dst,
+                                                         unsigned P, int ntiles, unsigned src_bytes, unsigned dst_bytes) {
+    constexpr int K = G::K, LDB = K + 4;
+    constexpr int CH = U8IN ? G::KH : K / 8;          // chunks per tile (uint8: one 32-byte tap row per chunk)
+    constexpr int RPC = U8IN ? 1 : G::RUN / 8;        // chunks per contiguous run
+    constexpr int TP = 32 * MT;
+    constexpr int NB = U8IN ? 4 : 1;
+    static_assert(CH % kRing == 0, "chunk count must be a multiple of the ring depth");
+    extern __shared__ __attribute__((aligned(16))) float Bs[];       // [32*NJT][K + 4] (+ 8 slack) [+ bias]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    {
+        const float4* __restrict__ Bt4 = reinterpret_cast<const float4*>(Bt_all);
+        constexpr unsigned k4 = K / 4, total = (unsigned)(32 * NJT) * k4;
+        for (unsigned e = tid; e < total; e += 512) {
+            const unsigned row = e / k4, c = e - row * k4;
+            *reinterpret_cast<float4*>(&Bs[row * LDB + c * 4]) = Bt4[e];
+        }
+        if (EPI == EPI_BIAS_RELU && tid < 32 * NJT) Bs[(32 * NJT) * LDB + 8 + tid] = bias[tid];
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rsrc_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src_v), 0, (int)src_bytes, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsrc_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsrc_msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mask_src), 0,
+                                                                              EPI == EPI_MASK ? (int)dst_bytes : 0, kRsrcWord3);
+    const int nwv = gridDim.x * 8;
+
+    // per lane and pixel tile: byte offset of tap (0,0) of the lane's pixel (+16 bytes for the upper half-wave), or the
+    // 64-bit pointer for uint8 sources; PAD: validity bit r*KW + c
+    struct Pix {
+        unsigned voff[MT];
+        const uint8_t* ptr[MT];
+        unsigned vm[MT];
+    };
+    auto setup = [&](int tile, Pix& px) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const unsigned p = (unsigned)tile * (unsigned)TP + (unsigned)(32 * m + li);
+            const bool ok = (tile < ntiles) && (p < P);
+            const unsigned pp = ok ? p : 0u;
+            const unsigned img = pp / (unsigned)G::PER_IMG, rem = pp - img * (unsigned)G::PER_IMG;
+            const unsigned gy = rem / (unsigned)G::GX, gx = rem - gy * (unsigned)G::GX;
+            const int sy0 = (int)gy * G::SS + G::OFF, sx0 = (int)gx * G::SS + G::OFF;
+            if (U8IN) {
+                const long long simg = inds ? inds[img] : (long long)img;
+                px.ptr[m] = static_cast<const uint8_t*>(src_v) + ((simg * G::H + sy0) * G::W + sx0) * (long long)G::C + 16 * lh;
+                px.voff[m] = 0u;
+            } else {
+                px.ptr[m] = nullptr;
+                px.voff[m] = (unsigned)((((int)img * G::H + sy0) * G::W + sx0) * G::C * 4 + 16 * lh);   // may wrap for PAD taps
+            }
+            unsigned vm = 0u;
+            if constexpr (PAD) {
+                static_assert(G::KH * G::KW <= 32, "validity mask is 32 bits");
+#pragma unroll
+                for (int r = 0; r < G::KH; ++r)
+#pragma unroll
+                    for (int c = 0; c < G::KW; ++c) {
+                        const int sy = sy0 + r, sx = sx0 + c;
+                        if (ok && sy >= 0 && sy < G::H && sx >= 0 && sx < G::W) vm |= 1u << (r * G::KW + c);
+                    }
+            }
+            px.vm[m] = vm;
+        }
+    };
+    u32x4 ring[MT][kRing];
+    // chunk c (compile-time) of the tile described by px -> ring slot c % kRing
+    auto fetch = [&](const Pix& px, auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int r = c / RPC, rem = (c % RPC) * 8;                 // tap row, element offset within the run
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (U8IN) {
+                ring[m][c % kRing] = *reinterpret_cast<const u32x4*>(px.ptr[m] + r * G::PITCH);
+            } else if constexpr (PAD) {
+                constexpr int tc = rem / G::C;                            // tap column of this chunk
+                const bool ok = (px.vm[m] >> (r * G::KW + tc)) & 1u;
+                const unsigned vo = ok ? px.voff[m] + (unsigned)((r * G::PITCH + rem) * 4) : kOob;
+                ring[m][c % kRing] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_src, vo, 0, 0);
+            } else {
+                ring[m][c % kRing] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_src, px.voff[m] + (unsigned)(rem * 4), r * G::PITCH * 4, 0);
+            }
+        }
+    };
+
+    Pix cur, nxt;
+    int tile = blockIdx.x * 8 + wave;
+    setup(tile, cur);
+    setup(tile + nwv, nxt);
+    // prologue: chunks 0 .. kRing-1 of the first tile
+    [&]<int... I>(std::integer_sequence<int, I...>) { (fetch(cur, std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, kRing>{});
+
+    float bias_r[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) bias_r[jt] = (EPI == EPI_BIAS_RELU) ? Bs[(32 * NJT) * LDB + 8 + jt * 32 + li] : 0.0f;
+    const float* __restrict__ Bp0 = Bs + li * LDB + (U8IN ? 16 : 4) * lh;
+
+    for (; tile < ntiles; tile += nwv) {
+        f32x16 acc[MT][NJT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][jt][e] = 0.0f;
+        float4 bcur[NJT][NB], bnxt[NJT][NB];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int q = 0; q < NB; ++q) bcur[jt][q] = *reinterpret_cast<const float4*>(Bp0 + jt * 32 * LDB + 4 * q);
+
+        auto chunk = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int cn = c + 1 < CH ? c + 1 : c;                   // B fragments of the next chunk (clamped at the end)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+                    bnxt[jt][q] = *reinterpret_cast<const float4*>(Bp0 + jt * 32 * LDB + cn * (U8IN ? 32 : 8) + 4 * q);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float a = U8IN ? u8_tap(ring[m][c % kRing][q], kp) : __uint_as_float(ring[m][c % kRing][kp]);
+#pragma unroll
+                        for (int jt = 0; jt < NJT; ++jt) {
+                            const float b = kp == 0 ? bcur[jt][q].x : kp == 1 ? bcur[jt][q].y : kp == 2 ? bcur[jt][q].z : bcur[jt][q].w;
+                            acc[m][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m][jt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if constexpr (U8IN) {
+                if constexpr (c + kRing < CH) fetch(cur, std::integral_constant<int, c + kRing>{});
+                else fetch(nxt, std::integral_constant<int, c + kRing - CH>{});
+            } else if constexpr (c % 4 == 3) {
+                // f32: four consecutive chunks of a lane pair are ONE 128-byte line.  Refill them back to back (slots
+                // c-3 .. c, just consumed) so that the line is requested from L2 once and the other three loads hit it
+                // while it is still pending / resident; spread over four chunk times the L1 (32 KiB, 8 waves x 64 lines
+                // in flight) evicts it in between and every 16-byte read becomes its own L2 request.
+                [&]<int... J>(std::integer_sequence<int, J...>) {
+                    ((c - 3 + J + kRing < CH ? fetch(cur, std::integral_constant<int, (c - 3 + J + kRing < CH ? c - 3 + J + kRing : 0)>{})
+                                             : fetch(nxt, std::integral_constant<int, (c - 3 + J + kRing < CH ? 0 : c - 3 + J + kRing - CH)>{})), ...);
+                }(std::make_integer_sequence<int, 4>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int q = 0; q < NB; ++q) bcur[jt][q] = bnxt[jt][q];
+        };
+        [&]<int... I>(std::integer_sequence<int, I...>) { (chunk(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, CH>{});
+
+        // ---- epilogue
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            unsigned myoff = kOob;                   // BYTE offset of channel 0 of this lane's destination pixel
+            {
+                const unsigned p = (unsigned)tile * (unsigned)TP + (unsigned)(32 * m + li);
+                if (p < P) {
+                    const unsigned img = p / (unsigned)G::PER_IMG, rem = p - img * (unsigned)G::PER_IMG;
+                    const unsigned gy = rem / (unsigned)G::GX, gx = rem - gy * (unsigned)G::GX;
+                    myoff = ((img * (unsigned)G::DH + gy * (unsigned)G::DM) * (unsigned)G::DW + gx * (unsigned)G::DM) * (unsigned)(G::DC * 4);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned off = (unsigned)__shfl((int)myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64) + (unsigned)(li * 4);
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    // CLS4: channel tile jt is parity class (jt>>1, jt&1) of the stride-2 data gradient -> its own pixel
+                    const int noff = CLS4 ? ((jt >> 1) * G::DW + (jt & 1)) * G::DC * 4 : jt * 128;
+                    float v = acc[m][jt][e];
+                    if (EPI == EPI_BIAS_RELU) {
+                        v = v + bias_r[jt];
+                        v = v > 0.0f ? v : 0.0f;
+                    } else if (EPI == EPI_MASK) {
+                        const unsigned mk = __builtin_amdgcn_raw_buffer_load_b32(rsrc_msk, off, noff, 0);   // 0 when out of range
+                        v = __uint_as_float(mk) > 0.0f ? v : 0.0f;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_dst, off, noff, 0);   // dropped when out of range
+                }
+            }
+        }
+        cur = nxt;
+        setup(tile + 2 * nwv, nxt);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ weight gradient
 struct WgradGeom {
     int H, W, C;       // source per image
@@ -738,6 +962,39 @@ static int launch_stream_cfg(const void* src, const int64_t* inds, const float* 
     return check_launch("conv_stream_kernel");
 }
 
+template <class G, int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT>
+static int launch_fixed_cfg(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
+                            float* dst, long long P, long long src_bytes, long long dst_bytes, hipStream_t s) {
+    const long long lim = (1LL << 32) - 8192;
+    if ((!U8IN && src_bytes > lim) || dst_bytes > lim) {
+        set_error("conv_fixed_kernel: tensors must stay below 4 GiB (source %lld, destination %lld bytes): split the batch",
+                  src_bytes, dst_bytes);
+        return MI355PPO_EINVAL;
+    }
+    const size_t smem = ((size_t)(32 * NJT) * (G::K + 4) + 8 + 32 * NJT) * sizeof(float);
+    auto k = conv_fixed_kernel<G, NJT, U8IN, EPI, PAD, CLS4, MT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+        set_error("conv_fixed_kernel: hipFuncSetAttribute(%zu bytes of LDS): %s", smem, hipGetErrorString(e));
+        return MI355PPO_EHIP;
+    }
+    const int ntiles = (int)((P + 32 * MT - 1) / (32 * MT));
+    int wgs = 256;
+    const int need = (ntiles + 7) / 8;
+    if (wgs > need) wgs = need;
+    hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3(512), smem, s, src, inds, Bt, bias, mask_src, dst, (unsigned)P, ntiles,
+                       (unsigned)(U8IN ? 0 : src_bytes), (unsigned)dst_bytes);
+    return check_launch("conv_fixed_kernel");
+}
+// 64-pixel wave tiles for minibatch-sized problems, 32-pixel tiles when that leaves waves of the chip idle (rollout)
+template <class G, int NJT, bool U8IN, int EPI, bool PAD, bool CLS4 = false, int MTBIG = 2>
+static int launch_fixed(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
+                        float* dst, long long P, long long src_bytes, long long dst_bytes, hipStream_t s) {
+    if (MTBIG == 1 || P < 64LL * 4 * 2048)
+        return launch_fixed_cfg<G, NJT, U8IN, EPI, PAD, CLS4, 1>(src, inds, Bt, bias, mask_src, dst, P, src_bytes, dst_bytes, s);
+    return launch_fixed_cfg<G, NJT, U8IN, EPI, PAD, CLS4, MTBIG>(src, inds, Bt, bias, mask_src, dst, P, src_bytes, dst_bytes, s);
+}
+
 // MI355PPO_CONV_CFG (tuning): 0 = MT 2 / 8 waves (default), 1 = MT 1 / 16 waves, 2 = MT 1 / 8 waves
 template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4 = false, int MT = 2>
 static int launch_stream(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
@@ -759,7 +1016,7 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
     MI355_REQUIRE(layer == 1 || inds == nullptr, MI355PPO_EINVAL, "%s: inds (row gather) is only defined for layer 1", fn);
-    MI355_REQUIRE(variant >= 0 && variant <= 2, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
+    MI355_REQUIRE(variant >= 0 && variant <= 4, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(src, 16) && aligned(Bt, 16) && aligned(dst, 16) && aligned(inds, 8), MI355PPO_EALIGN,
                   "%s: src/Bt/dst must be 16-byte aligned", fn);
     ConvGeom g;
@@ -770,6 +1027,12 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
     hipStream_t s = as_stream(stream);
     if (variant == 0) variant = kDefaultVariant;
     if (variant == 2) {
+        const long long srcb = (long long)images * Hin * Hin * Cin * 4, dstb = g.P * Cout * 4;
+        if (layer == 1) return launch_fixed<GeomConv1, 1, true, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, 0, dstb, s);
+        if (layer == 2) return launch_fixed<GeomConv2, 2, false, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, srcb, dstb, s);
+        return launch_fixed<GeomConv3, 2, false, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, srcb, dstb, s);
+    }
+    if (variant == 4) {
         if (layer == 1) return launch_stream<1, true, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g, s);
         return launch_stream<2, false, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g, s);
     }
@@ -802,7 +1065,7 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
                   "%s: layer=%d must be 2 or 3 (conv1's input needs no gradient)", fn, layer);
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
-    MI355_REQUIRE(variant >= 0 && variant <= 3, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
+    MI355_REQUIRE(variant >= 0 && variant <= 4, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(dz, 16) && aligned(Bt, 16) && aligned(act_in, 16) && aligned(dsrc, 16), MI355PPO_EALIGN,
                   "%s: pointers must be 16-byte aligned", fn);
     MI355_REQUIRE((long long)images * Hin * Hin * Cin < (1LL << 31), MI355PPO_EINVAL, "%s: destination exceeds 2^31 elements", fn);
@@ -814,7 +1077,10 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
     if (layer == 3) {
         g.KH = g.KW = 3; g.GY = g.GX = Hin; g.SS = 1; g.OFF = -2; g.DM = 1; g.DAY = g.DAX = 0; g.classes = 1;
         g.K = 9 * Cout; g.P = (long long)images * Hin * Hin;
+        const long long srcb3 = (long long)images * Hout * Hout * Cout * 4, dstb3 = (long long)images * Hin * Hin * Cin * 4;
         if (variant == 2)
+            return launch_fixed<GeomDgrad3, 2, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g.P, srcb3, dstb3, s);
+        if (variant == 4)
             return launch_stream<2, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
         const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 1);
         hipLaunchKernelGGL((conv_gemm_kernel<64, false, EPI_MASK>), grid, dim3(256), 0, s, (const void*)dz,
@@ -822,8 +1088,12 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
     } else {
         g.KH = g.KW = 2; g.GY = g.GX = Hin / 2; g.SS = 1; g.OFF = -1; g.DM = 2; g.DAY = g.DAX = 0; g.classes = 4;
         g.K = 4 * Cout; g.P = (long long)images * (Hin / 2) * (Hin / 2);
-        if (variant == 2) {     // one pass for all four parity classes: they read the SAME dz taps (only weights and
-            g.classes = 1;      // destination pixel differ), so the 4x32 class channels form one 128-wide GEMM
+        const long long srcb2 = (long long)images * Hout * Hout * Cout * 4, dstb2 = (long long)images * Hin * Hin * Cin * 4;
+        if (variant == 2)       // one pass for all four parity classes: they read the SAME dz taps (only weights and
+                                // destination pixel differ), so the 4x32 class channels form one 128-wide GEMM
+            return launch_fixed<GeomDgrad2, 4, false, EPI_MASK, true, true, 1>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g.P, srcb2, dstb2, s);
+        if (variant == 4) {
+            g.classes = 1;
             return launch_stream<4, false, EPI_MASK, true, true, 1>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
         }
         if (variant == 3)

@@ -56,8 +56,8 @@ def test_repack_layouts(layer, mode):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-@pytest.mark.parametrize("images", [1, 37, 256])
+@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("images", [1, 37, 256, 1100])
 def test_conv1_fwd_u8_gather(images, variant):
     frames = torch.from_numpy(synthetic.atari_frames(images + 5, seed=3))            # (R,4,84,84) uint8
     rows = _nhwc(frames).to(DEV)
@@ -74,9 +74,9 @@ def test_conv1_fwd_u8_gather(images, variant):
     _close(_nhwc(t32), _nhwc(ref2), "torch f32 conv1 (calibration)")
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 @pytest.mark.parametrize("layer", [2, 3])
-@pytest.mark.parametrize("images", [1, 19, 128, 700])
+@pytest.mark.parametrize("images", [1, 19, 128, 700, 7000])
 def test_conv_fwd_f32(layer, images, variant):
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(10 + layer)
@@ -88,9 +88,9 @@ def test_conv_fwd_f32(layer, images, variant):
     _close(got, _nhwc(ref), f"conv{layer} fwd")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("layer", [2, 3])
-@pytest.mark.parametrize("images", [1, 19, 128, 700])
+@pytest.mark.parametrize("images", [1, 19, 128, 700, 7000])
 def test_conv_dgrad_with_relu_mask(layer, images, variant):
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(20 + layer)

@@ -46,7 +46,7 @@ def main():
             bt = cnn.repack_weights(W, layer)
             src = acts[layer - 1]
             dst = torch.empty((M, hout, hout, cout), device=DEV)
-            for v in ((2,) if os.environ.get("CNNBENCH_ONLY") == "fwd" else (1, 2)):
+            for v in ((2,) if os.environ.get("CNNBENCH_ONLY") == "fwd" else (2, 4)):
                 us = bench(lambda: cnn.conv_fwd(src, bt, b, layer, inds if layer == 1 else None, dst, variant=v))
                 out(k="fwd", variant=v, layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK)
             acts[layer] = dst
@@ -59,7 +59,7 @@ def main():
                 mode = cnn.MODE_DGRAD_S1 if layer == 3 else cnn.MODE_DGRAD_S2
                 btd = cnn.repack_weights(W, layer, mode)
                 dsrc = torch.empty_like(src)
-                for v in ((1, 2, 3) if layer == 2 else (1, 2)):
+                for v in (2, 4):
                     us = bench(lambda: cnn.conv_dgrad(dz, btd, src, layer, dsrc, variant=v))
                     out(k="dgrad", variant=v, layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK,
                         note="flops counted as the forward conv's")
