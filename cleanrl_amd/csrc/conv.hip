@@ -667,6 +667,7 @@ struct WgradGeom {
     int K;             // KH*KW*C
     int images;
     int src_bytes;     // bytes of one source image as stored (u8: H*W*C, f32: 4*H*W*C)
+    int diag;          // tuning only (MI355PPO_CONV_DIAG): bit0 no prefetch, bit1 no LDS commit, bit2 no MFMA loop
 };
 
 // NCI = Cout/32 (1 or 2); TPW = MFMA tiles per wave = (N/32)*(K/32)/4; NS / ND = 16-byte chunks of one source /
@@ -675,7 +676,7 @@ struct WgradGeom {
 // SPLIT: every wave owns ALL tiles (TPW = all of them) and a quarter of the pixel pairs instead of a quarter of the
 // tiles and all pairs -- more MFMAs per fragment fetch for the thin conv1 problem (8 tiles); each wave then writes
 // its own partial.
-template <int NCI, int TPW, bool U8IN, int NS, int ND, bool SPLIT>
+template <int NCI, int TPW, bool U8IN, int NS, int ND, bool SPLIT, int RD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_kernel(const void* __restrict__ src_v,
                                                             const int64_t* __restrict__ inds,
                                                             const float* __restrict__ dz,
@@ -758,7 +759,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto frag_b_at = [&](int pb, float (&b)[TPW]) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            if (U8IN) b[t] = (float)s_src[pb + patch_off[t]];
+            if (U8IN) b[t] = __uint_as_float((unsigned)s_src[pb + patch_off[t]]);   // raw byte; converted when consumed (a
+                                                                                    // cvt here would wait for the ds_read at once)
             else b[t] = reinterpret_cast<const float*>(s_src)[pb + patch_off[t]];
         }
     };
@@ -767,38 +769,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (img < g.images) prefetch(img);
     for (; img < g.images; img += gridDim.x) {
         __syncthreads();                       // previous image fully consumed
-        commit();
+        if (!(g.diag & 2)) commit();
         __syncthreads();
         const int nxt = img + gridDim.x;
-        if (nxt < g.images) prefetch(nxt);      // in flight during the whole multiply phase
-        // Two register sets in ping-pong (no copies), pixbase one pair further ahead, and scheduling fences so that
-        // the LDS reads of pair pr+1 are ISSUED before the MFMAs of pair pr (hipcc otherwise sinks them behind the
-        // MFMAs and every pair pays a dependent ds_read -> ds_read round trip with the matrix pipe idle).
+        if (nxt < g.images && !(g.diag & 1)) prefetch(nxt);      // in flight during the whole multiply phase
+        if (g.diag & 4) continue;
+        // Operand ring of RD pixel pairs (fixed registers per slot), pixbase one pair further ahead, and scheduling
+        // fences so that the LDS reads of pair q+RD are ISSUED right after the MFMAs of pair q -- (RD-1) pairs of MFMA
+        // time before they are needed (hipcc otherwise sinks them behind the MFMAs and every pair pays a dependent
+        // ds_read -> ds_read round trip with the matrix pipe idle).  RD = 4 for the thin layer-1 problem (2 MFMAs per
+        // pair and wave), 2 otherwise.
         const int last = npairs - 1;
-        float a0 = frag_a(P0), a1 = 0.0f;
-        float b0[TPW], b1[TPW];
-        frag_b_at(s_pixbase[2 * P0 + lh], b0);
-        int pb1 = s_pixbase[2 * (P0 + PS < last ? P0 + PS : last) + lh];
-        for (int pr = P0; pr < npairs; pr += 2 * PS) {
-            const int p1 = pr + PS < last ? pr + PS : last, p2 = pr + 2 * PS < last ? pr + 2 * PS : last,
-                      p3 = pr + 3 * PS < last ? pr + 3 * PS : last;
-            int pb2 = s_pixbase[2 * p2 + lh];
-            a1 = frag_a(p1);
-            frag_b_at(pb1, b1);
-            __builtin_amdgcn_sched_barrier(0);
+        float ra[RD];
+        float rb[RD][TPW];
+        int pbn;                                   // pixbase of the next pair to be fetched
+        {
+            int q = P0;
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            int pb3 = s_pixbase[2 * p3 + lh];
-            a0 = frag_a(p2);
-            frag_b_at(pb2, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (pr + PS < npairs) {
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
+            for (int sl = 0; sl < RD; ++sl) {
+                const int qq = q < last ? q : last;
+                ra[sl] = q <= last ? frag_a(qq) : 0.0f;
+                frag_b_at(s_pixbase[2 * qq + lh], rb[sl]);
+                q += PS;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            pb1 = pb3;
+            pbn = s_pixbase[2 * (q < last ? q : last) + lh];
+        }
+        for (int pr = P0; pr < npairs; pr += RD * PS) {
+#pragma unroll
+            for (int sl = 0; sl < RD; ++sl) {
+                // pairs past the end were fetched from the (clamped) last pair with their dz fragment forced to 0, so the
+                // MFMAs stay unconditional (a branch around them makes hipcc copy all accumulators at the join)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[sl], U8IN ? (float)__float_as_uint(rb[sl][t]) : rb[sl][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int q = pr + (sl + RD) * PS, qq = q < last ? q : last, q1 = q + PS < last ? q + PS : last;
+                if (!(g.diag & 8)) {
+                    ra[sl] = q <= last ? frag_a(qq) : 0.0f;
+                    frag_b_at(pbn, rb[sl]);
+                    pbn = s_pixbase[2 * q1 + lh];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
@@ -1115,7 +1127,7 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32_variant(const float* dz,
     return conv_dgrad_impl(dz, Bt, act_in, dsrc, images, layer, variant, stream);
 }
 
-constexpr bool kWgradSplitLayer1 = false;   // SPLIT variant measured slower (register-bound at 8 tiles + prefetch)
+constexpr bool kWgradSplitLayer1 = false;   // SPLIT (every wave owns all 8 tiles, a quarter of the pairs) measured equal: off
 static size_t wgrad_smem(int src_bytes, int npix, int N) {
     const int npairs = (npix + 1) / 2;
     return (size_t)((src_bytes + 15) & ~15) + (size_t)2 * npairs * N * 4 + (size_t)2 * npairs * 4;
@@ -1147,6 +1159,8 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     WgradGeom g;
     g.H = g.W = Hin; g.C = Cin; g.KH = g.KW = KH; g.SS = SS; g.GY = g.GX = Hout; g.N = Cout; g.K = KH * KH * Cin;
     g.images = (int)images; g.src_bytes = Hin * Hin * Cin * (layer == 1 ? 1 : 4);
+    static const int s_wdiag = getenv("MI355PPO_CONV_DIAG") ? atoi(getenv("MI355PPO_CONV_DIAG")) : 0;
+    g.diag = s_wdiag;
     const int grid = wgrad_grid(images);
     float* part_w = static_cast<float*>(workspace);
     const int wparts = grid * (kWgradSplitLayer1 && layer == 1 ? 4 : 1);
@@ -1155,15 +1169,15 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     hipStream_t s = as_stream(stream);
     hipError_t e = hipSuccess;
     if (layer == 1) {
-        auto k = conv_wgrad_kernel<1, 2, true, 7, 13, false>;
+        auto k = conv_wgrad_kernel<1, 2, true, 7, 13, false, 2>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     } else if (layer == 2) {
-        auto k = conv_wgrad_kernel<2, 8, false, 13, 6, false>;
+        auto k = conv_wgrad_kernel<2, 8, false, 13, 6, false, 2>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     } else {
-        auto k = conv_wgrad_kernel<2, 9, false, 6, 4, false>;
+        auto k = conv_wgrad_kernel<2, 9, false, 6, 4, false, 2>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     }
