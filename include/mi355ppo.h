@@ -224,8 +224,10 @@ MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, float* Bt, int 
  * correctly rounded.  layers 2,3: src is f32, inds must be NULL. */
 MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds, const float* Bt, const float* bias,
                                            float* dst, int64_t images, int layer, void* stream);
-/* `variant` (tuning/testing): 0 = auto, 1 = LDS-tiled kernel (A and B staged per 32-k stage),
- * 2 = streaming kernel (weights resident in LDS, A fragments fetched straight into a register ring). */
+/* `variant` (tuning/testing): 0 = auto (= 2), 1 = LDS-tiled kernel (A and B staged per 32-k stage),
+ * 2 = fixed-geometry streaming kernel (weights resident in LDS, A fragments fetched straight into a register ring,
+ *     taps as compile-time immediates, buffer loads/stores; tensors must be < 4 GiB), 4 = its run-time-geometry
+ *     predecessor; data gradient only: 3 = one launch per stride-parity class (layer 2). */
 MI355PPO_API int mi355ppo_cnn_conv_fwd_f32_variant(const void* src, const int64_t* inds, const float* Bt, const float* bias,
                                                    float* dst, int64_t images, int layer, int variant, void* stream);
 
