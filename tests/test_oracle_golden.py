@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from oracle import c_oracle, torch_oracle as TO
+from oracle import c_oracle, numpy_oracle as NO, torch_oracle as TO
 
 T = torch.from_numpy
 
@@ -144,3 +144,28 @@ def test_c_oracle_obs_convert_exact():
     out = c_oracle.obs_u8_to_f32(src, inds)
     ref = (T(src).float()[T(inds)] / 255.0).numpy()      # the reference's b_obs[mb_inds] ; x / 255.0
     assert np.array_equal(out, ref)
+
+
+
+@pytest.mark.parametrize("case", sorted(load_golden("gae")))
+def test_numpy_float64_gae_agrees_with_reference(case):
+    """Independent float64 derivation vs the reference's f32 output: f32 round-off of a T-step recurrence."""
+    g = load_golden("gae")[case]
+    adv, ret = NO.gae(g["rewards"], g["dones"], g["values"], g["next_done"], g["next_value"], float(g["gamma"]),
+                      float(g["gae_lambda"]))
+    np.testing.assert_allclose(g["advantages"], adv, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(g["returns"], ret, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", sorted(load_golden("loss_categorical")))
+def test_numpy_float64_closed_form_loss_gradients_agree_with_reference_autograd(case):
+    """the closed-form gradients the fused kernel implements, derived independently in float64, against
+    the gradients torch autograd produced for the reference's own loss lines."""
+    g = load_golden("loss_categorical")[case]
+    sc, dl, dv = NO.loss_categorical(g["new_logits"], g["new_value"], g["mb_inds"], g["b_actions"], g["b_logprobs"],
+                                     g["b_advantages"], g["b_returns"], g["b_values"], float(g["clip_coef"]),
+                                     float(g["ent_coef"]), float(g["vf_coef"]), bool(g["norm_adv"]), bool(g["clip_vloss"]))
+    ref = np.array([float(g[k]) for k in SCALARS])
+    np.testing.assert_allclose(sc, ref, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dl, g["dlogits"], rtol=1e-4, atol=1e-5 * np.abs(g["dlogits"]).max())
+    np.testing.assert_allclose(dv, g["dvalue"].reshape(-1), rtol=1e-4, atol=1e-5 * np.abs(g["dvalue"]).max())
