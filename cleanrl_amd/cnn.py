@@ -18,16 +18,18 @@ from .ops import _chk, _ptr, _stream, _workspace
 
 # layer -> (Cin, Cout, K, stride, Hin, Hout)
 LAYERS = {1: (4, 32, 8, 4, 84, 20), 2: (32, 64, 4, 2, 20, 9), 3: (64, 64, 3, 1, 9, 7)}
-MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2 = 0, 1, 2
+MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2, MODE_DGRAD_S1_CLASSES = 0, 1, 2, 3
+BT_CLASSES_NUMEL = 81 * 4096
 
 
 def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch.Tensor | None = None) -> torch.Tensor:
     lib = _lib.load()
     cin, cout, k, _, _, _ = LAYERS[layer]
     _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
+    numel = BT_CLASSES_NUMEL if mode == MODE_DGRAD_S1_CLASSES else W.numel()
     if out is None:
-        out = torch.empty(W.numel(), dtype=torch.float32, device=W.device)
-    _chk(out, torch.float32, "Bt", (W.numel(),))
+        out = torch.empty(numel, dtype=torch.float32, device=W.device)
+    _chk(out, torch.float32, "Bt", (numel,))
     with torch.cuda.device(W.device):
         st = lib.mi355ppo_cnn_repack_weights_f32(_ptr(W), _ptr(out), layer, mode, _stream(W.device))
     _lib.check(st, "mi355ppo_cnn_repack_weights_f32")
@@ -69,7 +71,7 @@ def conv_dgrad(dz: torch.Tensor, Bt: torch.Tensor, act_in: torch.Tensor, layer: 
     images = dz.shape[0]
     _chk(dz, torch.float32, "dz", (images, hout, hout, cout))
     _chk(act_in, torch.float32, "act_in", (images, hin, hin, cin))
-    _chk(Bt, torch.float32, "Bt", (cout * cin * k * k,))
+    _chk(Bt, torch.float32, "Bt", (BT_CLASSES_NUMEL if variant == 5 else cout * cin * k * k,))
     if out is None:
         out = torch.empty_like(act_in)
     _chk(out, torch.float32, "out", (images, hin, hin, cin))
@@ -145,7 +147,7 @@ class NatureTrunkFn(torch.autograd.Function):
         dz1, dz2, _ = ctx.bufs.get(m, a3.device, True)
         dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)        # ReLU backward of the last conv
         dW3, db3 = conv_wgrad(a2, dz3, 3)
-        conv_dgrad(dz3, repack_weights(W3.detach(), 3, MODE_DGRAD_S1), a2, 3, dz2)
+        conv_dgrad(dz3, repack_weights(W3.detach(), 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # border classes: no padding zeros
         dW2, db2 = conv_wgrad(a1, dz2, 2)
         conv_dgrad(dz2, repack_weights(W2.detach(), 2, MODE_DGRAD_S2), a1, 2, dz1)
         dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds)

@@ -461,14 +461,26 @@ using GeomConv3 = FixedGeom<9, 9, 64, 3, 3, 7, 7, 1, 0, 7, 7, 64, 1>;
 using GeomDgrad3 = FixedGeom<7, 7, 64, 3, 3, 9, 9, 1, -2, 9, 9, 64, 1>;       // source = dz3, destination = da2
 using GeomDgrad2 = FixedGeom<9, 9, 64, 2, 2, 10, 10, 1, -1, 20, 20, 32, 2>;   // source = dz2, destination = da1 (4 classes)
 
+constexpr int kC3_total = 81 * 4096;         // floats of the per-class layer-3 data-gradient matrices: (1+2+3+2+1)^2 * 64 * 64
 constexpr unsigned kOob = 0xFFFFF000u;      // buffer offset that is out of range for every tensor < 4 GiB - 4 KiB
 constexpr int kRsrcWord3 = 0x00020000;      // raw buffer, 32-bit elements (gfx9 / CDNA resource format)
+
+// Up to four problem classes per launch (blockIdx.y): same tap shape and grid, different source window origin,
+// destination origin and weight matrix -- the border classes of the layer-3 data gradient (see launch_dgrad3_classes).
+struct ClsParams {
+    int offy[4], offx[4];      // source y = gy*SS + offy + r, x = gx*SS + offx + c
+    int day[4], dax[4];        // destination pixel = (gy*DM + day, gx*DM + dax)
+    int bt_off[4];             // element offset of the class's weight matrix in Bt_all
+};
 
 template <class G, int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT>
 __global__ __launch_bounds__(512) void conv_fixed_kernel(const void* __restrict__ src_v, const int64_t* __restrict__ inds,
                                                          const float* __restrict__ Bt_all, const float* __restrict__ bias,
                                                          const float* __restrict__ mask_src, float* __restrict__ dst,
-                                                         unsigned P, int ntiles, unsigned src_bytes, unsigned dst_bytes) {
+                                                         unsigned P, int ntiles, unsigned src_bytes, unsigned dst_bytes,
+                                                         ClsParams cp) {
+    const int cls = blockIdx.y;
+    const int offy = cp.offy[cls], offx = cp.offx[cls], day = cp.day[cls], dax = cp.dax[cls];
     constexpr int K = G::K, LDB = K + 4;
     constexpr int CH = U8IN ? G::KH : K / 8;          // chunks per tile (uint8: one 32-byte tap row per chunk)
     constexpr int RPC = U8IN ? 1 : G::RUN / 8;        // chunks per contiguous run
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(512) void conv_fixed_kernel(const void* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     {
-        const float4* __restrict__ Bt4 = reinterpret_cast<const float4*>(Bt_all);
+        const float4* __restrict__ Bt4 = reinterpret_cast<const float4*>(Bt_all + cp.bt_off[cls]);
         constexpr unsigned k4 = K / 4, total = (unsigned)(32 * NJT) * k4;
         for (unsigned e = tid; e < total; e += 512) {
             const unsigned row = e / k4, c = e - row * k4;
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(512) void conv_fixed_kernel(const void* __restrict_
             const unsigned pp = ok ? p : 0u;
             const unsigned img = pp / (unsigned)G::PER_IMG, rem = pp - img * (unsigned)G::PER_IMG;
             const unsigned gy = rem / (unsigned)G::GX, gx = rem - gy * (unsigned)G::GX;
-            const int sy0 = (int)gy * G::SS + G::OFF, sx0 = (int)gx * G::SS + G::OFF;
+            const int sy0 = (int)gy * G::SS + offy, sx0 = (int)gx * G::SS + offx;
             if (U8IN) {
                 const long long simg = inds ? inds[img] : (long long)img;
                 px.ptr[m] = static_cast<const uint8_t*>(src_v) + ((simg * G::H + sy0) * G::W + sx0) * (long long)G::C + 16 * lh;
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(512) void conv_fixed_kernel(const void* __restrict_
                 if (p < P) {
                     const unsigned img = p / (unsigned)G::PER_IMG, rem = p - img * (unsigned)G::PER_IMG;
                     const unsigned gy = rem / (unsigned)G::GX, gx = rem - gy * (unsigned)G::GX;
-                    myoff = ((img * (unsigned)G::DH + gy * (unsigned)G::DM) * (unsigned)G::DW + gx * (unsigned)G::DM) * (unsigned)(G::DC * 4);
+                    myoff = ((img * (unsigned)G::DH + gy * (unsigned)G::DM + (unsigned)day) * (unsigned)G::DW + gx * (unsigned)G::DM + (unsigned)dax) * (unsigned)(G::DC * 4);
                 }
             }
 #pragma unroll
@@ -909,6 +921,22 @@ __global__ __launch_bounds__(256) void conv_repack_kernel(const float* __restric
         const int n = e / K, k = e - n * K;
         const int r = k / (KW * Cout), rem = k - r * (KW * Cout), c = rem / Cout, co = rem - c * Cout;
         Bt[e] = W[((co * Cin + n) * KH + (KH - 1 - r)) * KW + (KW - 1 - c)];
+    } else if (mode == 3) {
+        // per-class matrices of the layer-3 data gradient: class (a,b), [n=cin][(r',c',cout)], taps flipped as in mode 1
+        const int r0t[5] = {2, 1, 0, 0, 0}, nrt[5] = {1, 2, 3, 2, 1};
+        int off = 0;
+        for (int a = 0; a < 5; ++a)
+            for (int b = 0; b < 5; ++b) {
+                const int K = nrt[a] * nrt[b] * Cout, sz = Cin * K;
+                if (e >= off && e < off + sz) {
+                    const int e2 = e - off, n = e2 / K, k = e2 - n * K;
+                    const int rr = k / (nrt[b] * Cout), rem = k - rr * (nrt[b] * Cout), cc = rem / Cout, co = rem - cc * Cout;
+                    const int r = r0t[a] + rr, c = r0t[b] + cc;
+                    Bt[e] = W[((co * Cin + n) * KH + (KH - 1 - r)) * KW + (KW - 1 - c)];
+                    return;
+                }
+                off += sz;
+            }
     } else {
         const int K = 4 * Cout;                      // 2x2 taps
         if (e >= 4 * Cin * K) return;
@@ -942,9 +970,9 @@ extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, floa
     int Cin, Cout, KH, SS, Hin, Hout;
     MI355_REQUIRE(W && Bt, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
-    MI355_REQUIRE(mode == 0 || (mode == 1 && layer == 3) || (mode == 2 && layer == 2), MI355PPO_EINVAL,
+    MI355_REQUIRE(mode == 0 || ((mode == 1 || mode == 3) && layer == 3) || (mode == 2 && layer == 2), MI355PPO_EINVAL,
                   "%s: mode %d is not defined for layer %d", fn, mode, layer);
-    const int total = Cout * Cin * KH * KH;
+    const int total = mode == 3 ? kC3_total : Cout * Cin * KH * KH;
     hipLaunchKernelGGL(conv_repack_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), W, Bt, Cout, Cin, KH,
                        KH, mode, layer == 1 ? kInv255 : 1.0f);     // layer 1 consumes raw uint8 taps
     return check_launch("conv_repack_kernel");
@@ -976,7 +1004,11 @@ static int launch_stream_cfg(const void* src, const int64_t* inds, const float* 
 
 template <class G, int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT>
 static int launch_fixed_cfg(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
-                            float* dst, long long P, long long src_bytes, long long dst_bytes, hipStream_t s) {
+                            float* dst, long long P, long long src_bytes, long long dst_bytes, hipStream_t s,
+                            const ClsParams* cpp = nullptr, int ncls = 1) {
+    ClsParams cp{};
+    if (cpp) cp = *cpp;
+    else { cp.offy[0] = cp.offx[0] = G::OFF; }
     const long long lim = (1LL << 32) - 8192;
     if ((!U8IN && src_bytes > lim) || dst_bytes > lim) {
         set_error("conv_fixed_kernel: tensors must stay below 4 GiB (source %lld, destination %lld bytes): split the batch",
@@ -991,11 +1023,11 @@ static int launch_fixed_cfg(const void* src, const int64_t* inds, const float* B
         return MI355PPO_EHIP;
     }
     const int ntiles = (int)((P + 32 * MT - 1) / (32 * MT));
-    int wgs = 256;
+    int wgs = 256 / ncls;
     const int need = (ntiles + 7) / 8;
     if (wgs > need) wgs = need;
-    hipLaunchKernelGGL(k, dim3((unsigned)wgs), dim3(512), smem, s, src, inds, Bt, bias, mask_src, dst, (unsigned)P, ntiles,
-                       (unsigned)(U8IN ? 0 : src_bytes), (unsigned)dst_bytes);
+    hipLaunchKernelGGL(k, dim3((unsigned)wgs, (unsigned)ncls), dim3(512), smem, s, src, inds, Bt, bias, mask_src, dst, (unsigned)P,
+                       ntiles, (unsigned)(U8IN ? 0 : src_bytes), (unsigned)dst_bytes, cp);
     return check_launch("conv_fixed_kernel");
 }
 // 64-pixel wave tiles for minibatch-sized problems, 32-pixel tiles when that leaves waves of the chip idle (rollout)
@@ -1005,6 +1037,57 @@ static int launch_fixed(const void* src, const int64_t* inds, const float* Bt, c
     if (MTBIG == 1 || P < 64LL * 4 * 2048)
         return launch_fixed_cfg<G, NJT, U8IN, EPI, PAD, CLS4, 1>(src, inds, Bt, bias, mask_src, dst, P, src_bytes, dst_bytes, s);
     return launch_fixed_cfg<G, NJT, U8IN, EPI, PAD, CLS4, MTBIG>(src, inds, Bt, bias, mask_src, dst, P, src_bytes, dst_bytes, s);
+}
+
+// ---- layer-3 data gradient without its structural zeros.  da2 (9x9) = full correlation of dz3 (7x7) with the flipped
+// 3x3 taps: a destination row iy only has the taps r with 0 <= iy-2+r < 7, so 288 of the 729 (pixel, tap) products of an
+// image are zeros of the padding.  Destination rows / columns fall into five classes {0},{1},{2..6},{7},{8} with tap
+// windows of 1,2,3,2,1 taps; a (row class, column class) pair is a dense, un-padded convolution with its own tap
+// window.  Classes with the same window SHAPE share a kernel instantiation and go into one launch (blockIdx.y).
+static const int kC3_r0[5] = {2, 1, 0, 0, 0}, kC3_nr[5] = {1, 2, 3, 2, 1}, kC3_p0[5] = {0, 1, 2, 7, 8}, kC3_np[5] = {1, 1, 5, 1, 1};
+static int c3_bt_offset(int a, int b) {      // element offset of class (a,b)'s matrix [64][nr*nc*64] in the mode-3 repack
+    int off = 0;
+    for (int aa = 0; aa < 5; ++aa)
+        for (int bb = 0; bb < 5; ++bb) {
+            if (aa == a && bb == b) return off;
+            off += 64 * kC3_nr[aa] * kC3_nr[bb] * 64;
+        }
+    return off;
+}
+
+template <int NR, int NC, int GY, int GX>
+static int launch_dgrad3_group(const float* dz, const float* Bt, const float* act_in, float* dsrc, long long images,
+                               long long srcb, long long dstb, hipStream_t s) {
+    using G = FixedGeom<7, 7, 64, NR, NC, GY, GX, 1, 0, 9, 9, 64, 1>;
+    ClsParams cp{};
+    int n = 0;
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b)
+            if (kC3_nr[a] == NR && kC3_nr[b] == NC) {
+                cp.offy[n] = kC3_p0[a] - 2 + kC3_r0[a];
+                cp.offx[n] = kC3_p0[b] - 2 + kC3_r0[b];
+                cp.day[n] = kC3_p0[a];
+                cp.dax[n] = kC3_p0[b];
+                cp.bt_off[n] = c3_bt_offset(a, b);
+                ++n;
+            }
+    const long long P = images * GY * GX;
+    if (GY * GX >= 5 && P >= 64LL * 4 * 2048 / n)
+        return launch_fixed_cfg<G, 2, false, EPI_MASK, false, false, 2>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, P, srcb, dstb, s, &cp, n);
+    return launch_fixed_cfg<G, 2, false, EPI_MASK, false, false, 1>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, P, srcb, dstb, s, &cp, n);
+}
+static int launch_dgrad3_classes(const float* dz, const float* Bt, const float* act_in, float* dsrc, long long images,
+                                 long long srcb, long long dstb, hipStream_t s) {
+    int rc;
+    if ((rc = launch_dgrad3_group<3, 3, 5, 5>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    if ((rc = launch_dgrad3_group<2, 3, 1, 5>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    if ((rc = launch_dgrad3_group<3, 2, 5, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    if ((rc = launch_dgrad3_group<1, 3, 1, 5>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    if ((rc = launch_dgrad3_group<3, 1, 5, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    if ((rc = launch_dgrad3_group<2, 2, 1, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    if ((rc = launch_dgrad3_group<1, 2, 1, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    if ((rc = launch_dgrad3_group<2, 1, 1, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    return launch_dgrad3_group<1, 1, 1, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s);
 }
 
 // MI355PPO_CONV_CFG (tuning): 0 = MT 2 / 8 waves (default), 1 = MT 1 / 16 waves, 2 = MT 1 / 8 waves
@@ -1077,7 +1160,7 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
                   "%s: layer=%d must be 2 or 3 (conv1's input needs no gradient)", fn, layer);
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
-    MI355_REQUIRE(variant >= 0 && variant <= 4, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
+    MI355_REQUIRE(variant >= 0 && variant <= 5 && (variant != 5 || layer == 3), MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(dz, 16) && aligned(Bt, 16) && aligned(act_in, 16) && aligned(dsrc, 16), MI355PPO_EALIGN,
                   "%s: pointers must be 16-byte aligned", fn);
     MI355_REQUIRE((long long)images * Hin * Hin * Cin < (1LL << 31), MI355PPO_EINVAL, "%s: destination exceeds 2^31 elements", fn);
@@ -1090,6 +1173,8 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
         g.KH = g.KW = 3; g.GY = g.GX = Hin; g.SS = 1; g.OFF = -2; g.DM = 1; g.DAY = g.DAX = 0; g.classes = 1;
         g.K = 9 * Cout; g.P = (long long)images * Hin * Hin;
         const long long srcb3 = (long long)images * Hout * Hout * Cout * 4, dstb3 = (long long)images * Hin * Hin * Cin * 4;
+        if (variant == 5)   // Bt must be the mode-3 (per-class) repack
+            return launch_dgrad3_classes(dz, Bt, act_in, dsrc, images, srcb3, dstb3, s);
         if (variant == 2)
             return launch_fixed<GeomDgrad3, 2, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g.P, srcb3, dstb3, s);
         if (variant == 4)

@@ -377,7 +377,7 @@ extern "C" MI355PPO_API int mi355ppo_gae_f32_variant(const float* rewards, const
                       aligned(returns, 16);
     if (variant == 0) {
         // auto: tile kernel while the column kernel could not even put one wave on every SIMD
-        if (N < 16384) variant = 6;
+        if (N < 65536) variant = 6;     // measured (profiles/r01_kbench_gae_staged_sweep.jsonl): staged wins up to ~32K columns
         else if (vec4 && N >= 262144) variant = 3;
         else variant = 1;
     }

@@ -215,7 +215,9 @@ MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_
  *   mode 0  forward / weight-gradient order  Bt[Cout][(kh,kw,cin)]
  *   mode 1  layer-3 data gradient            Bt[Cin][(r,c,cout)]   (taps flipped)
  *   mode 2  layer-2 data gradient            Bt[4][Cin][(r,c,cout)] (one 2x2-tap matrix per parity class)
- * every Bt has Cout*Cin*KH*KW floats.
+ *   mode 3  layer-3 data gradient, per border class: 25 matrices [Cin][(r',c',cout)] for the 5x5 (row class,
+ *           column class) tap windows (mi355ppo_cnn_conv_dgrad_f32_variant(..., variant 5)); 81*4096 floats
+ * modes 0-2 have Cout*Cin*KH*KW floats.
  */
 MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, float* Bt, int layer, int mode, void* stream);
 
@@ -227,7 +229,8 @@ MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds,
 /* `variant` (tuning/testing): 0 = auto (= 2), 1 = LDS-tiled kernel (A and B staged per 32-k stage),
  * 2 = fixed-geometry streaming kernel (weights resident in LDS, A fragments fetched straight into a register ring,
  *     taps as compile-time immediates, buffer loads/stores; tensors must be < 4 GiB), 4 = its run-time-geometry
- *     predecessor; data gradient only: 3 = one launch per stride-parity class (layer 2). */
+ *     predecessor; data gradient only: 3 = one launch per stride-parity class (layer 2), 5 = layer 3 split into
+ *     its 25 border classes so that no padding zeros are multiplied (needs the mode-3 repack). */
 MI355PPO_API int mi355ppo_cnn_conv_fwd_f32_variant(const void* src, const int64_t* inds, const float* Bt, const float* bias,
                                                    float* dst, int64_t images, int layer, int variant, void* stream);
 
