@@ -109,10 +109,28 @@ def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tens
 
 
 class _Buffers:
-    """Activation / gradient buffers reused across calls of one batch size (no allocator traffic in the loop)."""
+    """Activation / gradient buffers reused across calls of one batch size (no allocator traffic in the loop), and the
+    repacked weight matrices.  The matrices are re-derived from the parameters on every use unless the owner opts in to
+    caching (``cache_weights = True``) and promises to bump ``weights_version`` whenever it changes the parameters
+    behind torch's back -- the learner does, after each fused clip+Adam step, which writes the flat buffer through raw
+    pointers; in-place torch updates are caught through the tensors' own version counters."""
 
     def __init__(self):
         self.by_m = {}
+        self.cache_weights = False
+        self.weights_version = 0
+        self._bt = {}
+
+    def weights(self, W: torch.Tensor, layer: int, mode: int) -> torch.Tensor:
+        if not self.cache_weights:
+            return repack_weights(W.detach(), layer, mode)
+        key = (layer, mode)
+        tag = (self.weights_version, W._version, W.data_ptr())
+        hit = self._bt.get(key)
+        if hit is None or hit[0] != tag:
+            hit = (tag, repack_weights(W.detach(), layer, mode, hit[1] if hit is not None else None))
+            self._bt[key] = hit
+        return hit[1]
 
     def get(self, m: int, dev, grads: bool):
         key = (m, dev, grads)
@@ -131,7 +149,7 @@ class NatureTrunkFn(torch.autograd.Function):
     def forward(ctx, obs_u8, inds, W1, b1, W2, b2, W3, b3, bufs):
         m = obs_u8.shape[0] if inds is None else inds.numel()
         a1, a2, a3 = bufs.get(m, obs_u8.device, False)
-        bt1, bt2, bt3 = (repack_weights(W.detach(), l) for l, W in ((1, W1), (2, W2), (3, W3)))
+        bt1, bt2, bt3 = (bufs.weights(W, l, MODE_FWD) for l, W in ((1, W1), (2, W2), (3, W3)))
         conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1)
         conv_fwd(a1, bt2, b2.detach(), 2, None, a2)
         conv_fwd(a2, bt3, b3.detach(), 3, None, a3)
@@ -147,9 +165,9 @@ class NatureTrunkFn(torch.autograd.Function):
         dz1, dz2, _ = ctx.bufs.get(m, a3.device, True)
         dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)        # ReLU backward of the last conv
         dW3, db3 = conv_wgrad(a2, dz3, 3)
-        conv_dgrad(dz3, repack_weights(W3.detach(), 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # border classes: no padding zeros
+        conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # border classes: no padding zeros
         dW2, db2 = conv_wgrad(a1, dz2, 2)
-        conv_dgrad(dz2, repack_weights(W2.detach(), 2, MODE_DGRAD_S2), a1, 2, dz1)
+        conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
         dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds)
         return None, None, dW1, db1, dW2, db2, dW3, db3, None
 

@@ -978,12 +978,28 @@ extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, floa
     return check_launch("conv_repack_kernel");
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) and calling thread: the launch path itself
+// then consists of nothing but the launch (legal inside a stream capture).
+static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes) {
+    struct Seen { const void* fn; int dev; size_t bytes; };
+    static thread_local Seen seen[64];
+    static thread_local int nseen = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i].fn == fn && seen[i].dev == dev && seen[i].bytes >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && nseen < 64) seen[nseen++] = Seen{fn, dev, bytes};
+    return e;
+}
+
 template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT, int NW>
 static int launch_stream_cfg(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
                          float* dst, const ConvGeom& g, hipStream_t s) {
     const size_t smem = ((size_t)(32 * NJT) * (g.K + 4) + 8 + 32 * NJT) * sizeof(float);   // weights + slack + bias
     auto k = conv_stream_kernel<NJT, U8IN, EPI, PAD, CLS4, MT, NW>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
     if (e != hipSuccess) {
         set_error("conv_stream_kernel: hipFuncSetAttribute(%zu bytes of LDS): %s", smem, hipGetErrorString(e));
         return MI355PPO_EHIP;
@@ -1017,7 +1033,7 @@ static int launch_fixed_cfg(const void* src, const int64_t* inds, const float* B
     }
     const size_t smem = ((size_t)(32 * NJT) * (G::K + 4) + 8 + 32 * NJT) * sizeof(float);
     auto k = conv_fixed_kernel<G, NJT, U8IN, EPI, PAD, CLS4, MT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
     if (e != hipSuccess) {
         set_error("conv_fixed_kernel: hipFuncSetAttribute(%zu bytes of LDS): %s", smem, hipGetErrorString(e));
         return MI355PPO_EHIP;
@@ -1255,15 +1271,15 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     hipError_t e = hipSuccess;
     if (layer == 1) {
         auto k = conv_wgrad_kernel<1, 2, true, 7, 13, false, 2>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     } else if (layer == 2) {
         auto k = conv_wgrad_kernel<2, 8, false, 13, 6, false, 2>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     } else {
         auto k = conv_wgrad_kernel<2, 9, false, 6, 4, false, 2>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     }
     if (e != hipSuccess) {

@@ -147,6 +147,11 @@ class PPOLearner:
     def _heads_rollout(self, obs_rows):
         """Policy/value heads on one slot of the rollout buffer (HIP path)."""
         if self.image and self.fused_cnn:
+            if self.agent._trunk is None:
+                from . import cnn
+
+                self.agent._trunk = cnn.NatureTrunk()
+            self.agent._trunk.bufs.cache_weights = True      # this learner bumps weights_version after every optimiser step
             return self.agent.heads_u8(obs_rows)
         return self.agent.heads(self._features(obs_rows))
 
@@ -297,6 +302,9 @@ class PPOLearner:
         self.flat.step += 1
         self.ops.clip_adam_(self.flat.params, self.flat.grads, self.flat.exp_avg, self.flat.exp_avg_sq, self.flat.step, lr,
                             a.max_grad_norm, grad_scale=1.0 / self.world_size, total_norm_out=self._total_norm)
+        trunk = getattr(self.agent, "_trunk", None)
+        if trunk is not None:                       # the kernel rewrote the parameters through raw pointers
+            trunk.bufs.weights_version += 1
 
     def _minibatch_host(self, mb_inds, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, lr):
         """The reference's minibatch body on CPU tensors (ppo.py:250-290; multigpu :360-374 when world_size>1)."""
