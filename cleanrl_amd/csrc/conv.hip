@@ -850,6 +850,131 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- weight gradient, second generation (kernel D).  Kernel W staged the source image AND the dz image of every
+// image through LDS; the dz image (up to 51 KB f32) was most of that traffic, and needs no staging at all: a dz
+// fragment is 32 consecutive channels of one pixel per half-wave -- perfectly coalesced as it lies.  Here only the source
+// image goes through LDS (its patches overlap, so it is read 4-9x), while the dz fragments come straight from global
+// memory into a register ring that runs across image boundaries (the loads are issued in exactly the order they are
+// consumed, RING pixel pairs ahead).  The bias gradient is the running sum of the dz fragments a lane sees.
+//   PSPLIT (layer 1: 8 tiles): every wave owns ALL tiles and a quarter of the pixel pairs -> one partial per wave;
+//   otherwise (layers 2, 3: 32 / 36 tiles): wave w owns channel half w % NCI and tile group w / NCI, all pixel pairs.
+// STEPS = pixel pairs per wave and image, padded to a multiple of RING (padding pairs carry dz = 0).
+template <class G, int NCI, int TPW, bool U8IN, bool PSPLIT, int STEPS, int RING, int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_direct_kernel(
+    const void* __restrict__ src_v, const int64_t* __restrict__ inds, const float* __restrict__ dz,
+    float* __restrict__ part_w,      // [parts][N][K]
+    float* __restrict__ part_b,      // [parts][N]
+    int images) {
+    constexpr int kSrcBytes = G::H * G::W * G::C * (U8IN ? 1 : 4), kN = G::DC, kK = G::K, kNpix = G::GY * G::GX;
+    static_assert(STEPS % RING == 0, "steps per image must be a multiple of the ring depth");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* s_src = smem;
+    int* s_pixbase = reinterpret_cast<int*>(smem + ((kSrcBytes + 15) & ~15));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ci = PSPLIT ? 0 : wave % NCI, jgroup = PSPLIT ? 0 : wave / NCI;
+    const int P0 = PSPLIT ? wave : 0, PS = PSPLIT ? 4 : 1;
+    constexpr int npix = kNpix;
+    const int ntab = 2 * (P0 + PS * STEPS) + 2;                  // pixel indices the steps can touch (clamped table)
+    for (int p = tid; p < ntab; p += 256) {
+        const int pp = p < npix ? p : npix - 1;
+        const int gy = pp / G::GX, gx = pp - gy * G::GX;
+        s_pixbase[p] = ((gy * G::SS) * G::W + gx * G::SS) * G::C;
+    }
+    constexpr int runlen = G::RUN, rowpitch = G::PITCH;
+    int patch_off[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int e0 = (jgroup * TPW + t) * 32;
+        patch_off[t] = (e0 / runlen) * rowpitch + (e0 % runlen) + li;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    float bsum = 0.0f;
+
+    // dz ring: element (image, step) = dz[image][pixel 2*(P0 + PS*step) + lh][ci*32 + li], 0 for padding pixels
+    float ring[RING];
+    int l_img = blockIdx.x, l_step = 0;
+    auto dzload = [&](int slot) {
+        const int p = 2 * (P0 + PS * l_step) + lh;
+        const bool ok = l_img < images && p < npix;
+        const long long idx = ok ? ((long long)l_img * npix + p) * kN + ci * 32 + li : (long long)li;
+        const float v = dz[idx];
+        ring[slot] = ok ? v : 0.0f;
+        if (++l_step == STEPS) { l_step = 0; l_img += gridDim.x; }
+    };
+#pragma unroll
+    for (int j = 0; j < RING; ++j) dzload(j);
+
+    constexpr int src16 = kSrcBytes / 16;
+    u32x4 rs[NS];
+    auto prefetch = [&](int img) {
+        const long long simg = (U8IN && inds) ? inds[img] : img;
+        const u32x4* gs = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(src_v) + simg * (long long)kSrcBytes);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int e = tid + 256 * q;
+            rs[q] = gs[e < src16 ? e : 0];
+        }
+    };
+    auto frag_b = [&](int pb, float (&b)[TPW]) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            if (U8IN) b[t] = __uint_as_float((unsigned)s_src[pb + patch_off[t]]);     // raw byte, converted when consumed
+            else b[t] = reinterpret_cast<const float*>(s_src)[pb + patch_off[t]];
+        }
+    };
+    auto pix = [&](int step) { return s_pixbase[2 * (P0 + PS * step) + lh]; };
+
+    int img = blockIdx.x;
+    if (img < images) prefetch(img);
+    for (; img < images; img += gridDim.x) {
+        __syncthreads();                       // previous image fully consumed
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int e = tid + 256 * q;
+            if (e < src16) reinterpret_cast<u32x4*>(s_src)[e] = rs[q];
+        }
+        __syncthreads();
+        if (img + (int)gridDim.x < images) prefetch(img + gridDim.x);      // in flight during the whole multiply phase
+        float rb[2][TPW];
+        frag_b(pix(0), rb[0]);
+        frag_b(pix(1), rb[1]);
+        int pbn = pix(2);
+        for (int s0 = 0; s0 < STEPS; s0 += RING) {
+#pragma unroll
+            for (int j = 0; j < RING; ++j) {
+                const float a = ring[j];
+                bsum += a;
+                const int sl = (RING % 2 == 0) ? (j & 1) : ((s0 + j) & 1);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, U8IN ? (float)__float_as_uint(rb[sl][t]) : rb[sl][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                dzload(j);                                        // (image, step + RING) -- or the next image's first steps
+                frag_b(pbn, rb[sl]);                               // step + 2 (slots refilled past the last step are never consumed)
+                const int s3 = s0 + j + 3;
+                pbn = pix(s3 < STEPS ? s3 : STEPS - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    float* pw = part_w + (size_t)(PSPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * kN * kK;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int kcol = (jgroup * TPW + t) * 32 + li;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pw[(size_t)(ci * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * kK + kcol] = acc[t][e];
+    }
+    const float both = bsum + __shfl_xor(bsum, 32, 64);
+    if (lh == 0 && (PSPLIT || jgroup == 0))
+        part_b[(size_t)(PSPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * kN + ci * 32 + li] = both;
+}
+
 // dW (torch layout (N, C, KH, KW)) and db from the per-workgroup partials, fixed summation order, two stages so
 // that the first (which reads all partials) has (N*K/256) x nchunks workgroups instead of N*K/256.
 constexpr int kRedChunk = 32;     // partials folded per stage-1 workgroup row
@@ -1060,7 +1185,7 @@ static int launch_fixed(const void* src, const int64_t* inds, const float* Bt, c
 // image are zeros of the padding.  Destination rows / columns fall into five classes {0},{1},{2..6},{7},{8} with tap
 // windows of 1,2,3,2,1 taps; a (row class, column class) pair is a dense, un-padded convolution with its own tap
 // window.  Classes with the same window SHAPE share a kernel instantiation and go into one launch (blockIdx.y).
-static const int kC3_r0[5] = {2, 1, 0, 0, 0}, kC3_nr[5] = {1, 2, 3, 2, 1}, kC3_p0[5] = {0, 1, 2, 7, 8}, kC3_np[5] = {1, 1, 5, 1, 1};
+static const int kC3_r0[5] = {2, 1, 0, 0, 0}, kC3_nr[5] = {1, 2, 3, 2, 1}, kC3_p0[5] = {0, 1, 2, 7, 8};   // rows per class: 1,1,5,1,1
 static int c3_bt_offset(int a, int b) {      // element offset of class (a,b)'s matrix [64][nr*nc*64] in the mode-3 repack
     int off = 0;
     for (int aa = 0; aa < 5; ++aa)
@@ -1228,7 +1353,6 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32_variant(const float* dz,
     return conv_dgrad_impl(dz, Bt, act_in, dsrc, images, layer, variant, stream);
 }
 
-constexpr bool kWgradSplitLayer1 = false;   // SPLIT (every wave owns all 8 tiles, a quarter of the pairs) measured equal: off
 static size_t wgrad_smem(int src_bytes, int npix, int N) {
     const int npairs = (npix + 1) / 2;
     return (size_t)((src_bytes + 15) & ~15) + (size_t)2 * npairs * N * 4 + (size_t)2 * npairs * 4;
@@ -1238,9 +1362,9 @@ static int wgrad_grid(int64_t images) { return images < 512 ? (int)images : 512;
 extern "C" MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t images, int layer) {
     int Cin, Cout, KH, SS, Hin, Hout;
     if (images <= 0 || !layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout)) return 0;
-    const size_t wparts = (size_t)wgrad_grid(images) * (kWgradSplitLayer1 && layer == 1 ? 4 : 1);
+    const size_t wparts = (size_t)wgrad_grid(images) * (layer == 1 ? 4 : 1);      // layer 1: one partial per wave
     const size_t nchunks = (wparts + kRedChunk - 1) / kRedChunk;
-    return ((wparts + nchunks) * (size_t)Cout * KH * KH * Cin + ((size_t)wgrad_grid(images) + nchunks) * Cout) * sizeof(float);
+    return ((wparts + nchunks) * (size_t)Cout * KH * KH * Cin + (wparts + nchunks) * Cout) * sizeof(float);
 }
 
 extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW,
@@ -1264,12 +1388,21 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     g.diag = s_wdiag;
     const int grid = wgrad_grid(images);
     float* part_w = static_cast<float*>(workspace);
-    const int wparts = grid * (kWgradSplitLayer1 && layer == 1 ? 4 : 1);
-    float* part_b = part_w + (size_t)wparts * Cout * g.K;
+    static const int s_wk = getenv("MI355PPO_WGRAD") ? atoi(getenv("MI355PPO_WGRAD")) : 2;     // tuning: 1 = kernel W, 2 = kernel D (direct dz)
+    const bool direct = s_wk == 2 && layer == 1;
+    const int wparts = (direct && layer == 1) ? grid * 4 : grid;       // partials actually written
+    const int bparts = wparts;
+    float* part_b = part_w + (size_t)grid * (layer == 1 ? 4 : 1) * Cout * g.K;
     const size_t smem = wgrad_smem(g.src_bytes, Hout * Hout, Cout);
     hipStream_t s = as_stream(stream);
     hipError_t e = hipSuccess;
-    if (layer == 1) {
+    if (direct) {       // layer 1 only (measured: equal on layer 2, slower on layer 3 whose 25 pairs per image leave the
+                        // ring no room); LDS: source image + pixbase table (2*(3 + 4*50) + 2 ints)
+        auto k = conv_wgrad_direct_kernel<GeomConv1, 1, 8, true, true, 50, 10, 7>;
+        const size_t sm = ((size_t)(g.src_bytes + 15) & ~(size_t)15) + (2 * (3 + 4 * 50) + 2) * sizeof(int);
+        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), sm);
+        if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, (int)images);
+    } else if (layer == 1) {
         auto k = conv_wgrad_kernel<1, 2, true, 7, 13, false, 2>;
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
@@ -1289,12 +1422,12 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     int rc = check_launch("conv_wgrad_kernel");
     if (rc) return rc;
     const int total_w = Cout * g.K;
-    const int nchunks = (wparts + kRedChunk - 1) / kRedChunk;          // >= the bias partials' chunk count (grid <= wparts)
-    const int nchunks_b = (grid + kRedChunk - 1) / kRedChunk;
-    float* mid = part_b + (size_t)grid * Cout;
-    float* mid_b = mid + (size_t)nchunks * total_w;
+    const int nchunks = (wparts + kRedChunk - 1) / kRedChunk;
+    const int nchunks_b = (bparts + kRedChunk - 1) / kRedChunk;        // == nchunks
+    float* mid = part_b + (size_t)grid * (layer == 1 ? 4 : 1) * Cout;
+    float* mid_b = mid + (size_t)((grid * (layer == 1 ? 4 : 1) + kRedChunk - 1) / kRedChunk) * total_w;
     hipLaunchKernelGGL(conv_wgrad_reduce1, dim3((total_w + 255) / 256 + 1, nchunks), dim3(256), 0, s, part_w, wparts, total_w, mid,
-                       part_b, grid, Cout, mid_b);
+                       part_b, bparts, Cout, mid_b);
     rc = check_launch("conv_wgrad_reduce1");
     if (rc) return rc;
     hipLaunchKernelGGL(conv_wgrad_reduce2, dim3((total_w + 255) / 256), dim3(256), 0, s, mid, nchunks, mid_b, nchunks_b, Cout, Cin,
