@@ -246,8 +246,10 @@ def main():
             us, n = timer.mean_us(dom)
             tf = conv_flops[dom] / us / 1e6
             out["roofline"] = {
-                "kernel": f"{dom}: conv_gemm_kernel / conv_wgrad_kernel (f32-MFMA implicit GEMM, csrc/conv.hip); the fused "
-                          "uint8 gather+/255 (K5), bias, ReLU and ReLU-backward passes have no kernels of their own any more",
+                "kernel": f"{dom}: " + ("conv_wgrad_direct_kernel" if dom.startswith("conv1_wgrad") else
+                                        "conv_wgrad_kernel" if "_wgrad" in dom else "conv_fixed_kernel") +
+                          " (f32-MFMA implicit GEMM, csrc/conv.hip); the uint8 gather + /255 (K5), bias, ReLU, ReLU-backward and "
+                          "bias-gradient passes are fused into the conv kernels and have none of their own",
                 "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                 "algorithmic_flops_per_launch": conv_flops[dom], "avg_launch_us": us, "launches_timed": n,
