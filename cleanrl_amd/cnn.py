@@ -165,7 +165,10 @@ class NatureTrunkFn(torch.autograd.Function):
         dz1, dz2, _ = ctx.bufs.get(m, a3.device, True)
         dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)        # ReLU backward of the last conv
         dW3, db3 = conv_wgrad(a2, dz3, 3)
-        conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # border classes: no padding zeros
+        if a2.numel() * 4 < (1 << 32) - 8192:     # the border-class kernels address tensors with 32-bit buffer offsets
+            conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # no padding zeros
+        else:
+            conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1), a2, 3, dz2)
         dW2, db2 = conv_wgrad(a1, dz2, 2)
         conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
         dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds)

@@ -1073,7 +1073,8 @@ __global__ __launch_bounds__(256) void conv_repack_kernel(const float* __restric
     }
 }
 
-constexpr int kDefaultVariant = 2;   // 1 = tile kernel G, 2 = stream kernel S
+constexpr int kDefaultVariant = 2;
+constexpr long long kBufLimit = (1LL << 32) - 8192;   // largest tensor kernel F's 32-bit buffer offsets can address
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 }  // namespace mi355ppo
@@ -1150,8 +1151,7 @@ static int launch_fixed_cfg(const void* src, const int64_t* inds, const float* B
     ClsParams cp{};
     if (cpp) cp = *cpp;
     else { cp.offy[0] = cp.offx[0] = G::OFF; }
-    const long long lim = (1LL << 32) - 8192;
-    if ((!U8IN && src_bytes > lim) || dst_bytes > lim) {
+    if ((!U8IN && src_bytes > kBufLimit) || dst_bytes > kBufLimit) {
         set_error("conv_fixed_kernel: tensors must stay below 4 GiB (source %lld, destination %lld bytes): split the batch",
                   src_bytes, dst_bytes);
         return MI355PPO_EINVAL;
@@ -1261,9 +1261,10 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
     g.logC = ilog2(Cin); g.P = (long long)images * Hout * Hout;
     MI355_REQUIRE(g.P * Cout < (1LL << 31), MI355PPO_EINVAL, "%s: destination exceeds 2^31 elements", fn);
     hipStream_t s = as_stream(stream);
-    if (variant == 0) variant = kDefaultVariant;
+    const long long srcb = (long long)images * Hin * Hin * Cin * 4, dstb = g.P * Cout * 4;
+    if (variant == 0)   // kernel F addresses f32 tensors with 32-bit buffer offsets; beyond 4 GiB fall back to kernel S
+        variant = ((layer > 1 && srcb > kBufLimit) || dstb > kBufLimit) ? 4 : kDefaultVariant;
     if (variant == 2) {
-        const long long srcb = (long long)images * Hin * Hin * Cin * 4, dstb = g.P * Cout * 4;
         if (layer == 1) return launch_fixed<GeomConv1, 1, true, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, 0, dstb, s);
         if (layer == 2) return launch_fixed<GeomConv2, 2, false, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, srcb, dstb, s);
         return launch_fixed<GeomConv3, 2, false, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, srcb, dstb, s);
@@ -1309,7 +1310,8 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
     g.H = g.W = Hout; g.C = Cout;                  // the "source" of this GEMM is dz: (Hout, Hout, Cout)
     g.DH = g.DW = Hin; g.DC = Cin; g.N = Cin; g.logC = ilog2(Cout);
     hipStream_t s = as_stream(stream);
-    if (variant == 0) variant = kDefaultVariant;
+    if (variant == 0)
+        variant = ((long long)images * Hout * Hout * Cout * 4 > kBufLimit || (long long)images * Hin * Hin * Cin * 4 > kBufLimit) ? 4 : kDefaultVariant;
     if (layer == 3) {
         g.KH = g.KW = 3; g.GY = g.GX = Hin; g.SS = 1; g.OFF = -2; g.DM = 1; g.DAY = g.DAX = 0; g.classes = 1;
         g.K = 9 * Cout; g.P = (long long)images * Hin * Hin;
