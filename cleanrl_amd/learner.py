@@ -95,6 +95,7 @@ class PPOLearner:
             # device staging for incoming channel-planar frames (H2D target / device-env output)
             self.stage_obs = torch.zeros((N,) + self.frame_shape, dtype=obs_dtype, device=device) if self.nhwc else None
             self._pin_rd = torch.zeros((2, N), dtype=torch.float32).pin_memory()
+            self._pin_obs_np, self._pin_rd_np = self._pin_obs.numpy(), self._pin_rd.numpy()   # views of the pinned buffers
             self._x_roll = torch.empty((N,) + self.obs_shape, device=device) if (self.image and not self.fused_cnn) else None
             self._x_mb = None
             n_upd = int(args.update_epochs) * int(args.num_minibatches)
@@ -127,8 +128,8 @@ class PPOLearner:
             done_dst.copy_(torch.as_tensor(np.asarray(next_done), dtype=torch.float32))
             return
         self._h2d_evt.synchronize()                    # the pinned staging buffers are free again
-        self._pin_obs.copy_(torch.from_numpy(np.ascontiguousarray(next_obs)))
-        self._pin_rd[0].copy_(torch.from_numpy(np.asarray(next_done, dtype=np.float32)))
+        np.copyto(self._pin_obs_np, next_obs, casting="unsafe")      # one host memcpy straight into pinned memory
+        np.copyto(self._pin_rd_np[0], next_done, casting="unsafe")
         h2d_dst = self.stage_obs if self.nhwc else obs_dst
         with torch.cuda.stream(self._h2d):
             h2d_dst.copy_(self._pin_obs, non_blocking=True)
