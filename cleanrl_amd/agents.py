@@ -153,8 +153,9 @@ class ContinuousAgent(nn.Module):
     obs_is_image = False
     discrete = False
 
-    def __init__(self, envs):
+    def __init__(self, envs, rpo_alpha=None):
         super().__init__()
+        self.rpo_alpha = rpo_alpha      # rpo_continuous_action.py:109-111: perturb the mean when re-evaluating actions
         obs_dim = int(np.array(envs.single_observation_space.shape).prod())
         act_dim = int(np.prod(envs.single_action_space.shape))
         self.critic = nn.Sequential(
@@ -181,8 +182,16 @@ class ContinuousAgent(nn.Module):
     def get_value(self, x):
         return self.critic(x)
 
+    def perturb_mean(self, mean):
+        """rpo_continuous_action.py:138-142: ``action_mean + U(-alpha, alpha)`` (only when actions are re-evaluated)."""
+        if self.rpo_alpha is None:
+            return mean
+        return mean + torch.empty_like(mean).uniform_(-self.rpo_alpha, self.rpo_alpha)
+
     def get_action_and_value(self, x, action=None):
         mean, value = self.heads(x)
+        if action is not None:
+            mean = self.perturb_mean(mean)
         if mean.is_cuda:
             if action is None:
                 seed, off = self.rng.next()

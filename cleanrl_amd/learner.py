@@ -289,7 +289,11 @@ class PPOLearner:
                                                      scalars_out=scalars_out)
             torch.autograd.backward([p, value], [dp, dvalue])             # :358
         else:
-            _, dmean, dlogstd, dvalue = ops.ppo_loss_normal(p.detach().contiguous(), self.agent.actor_logstd.detach(),
+            if getattr(self.agent, "rpo_alpha", None) is not None:       # RPO: loss on the perturbed mean, d/dmean unchanged
+                p_eff = self.agent.perturb_mean(p.detach())
+            else:
+                p_eff = p.detach()
+            _, dmean, dlogstd, dvalue = ops.ppo_loss_normal(p_eff.contiguous(), self.agent.actor_logstd.detach(),
                                                             value.detach().contiguous(), idx, b_actions, b_logprobs,
                                                             b_advantages, b_returns, b_values, a.clip_coef, a.ent_coef,
                                                             a.vf_coef, a.norm_adv, a.clip_vloss, scalars_out=scalars_out)
@@ -320,6 +324,7 @@ class PPOLearner:
             probs = torch.distributions.Categorical(logits=p)
             newlogprob, entropy = probs.log_prob(acts), probs.entropy()
         else:
+            p = self.agent.perturb_mean(p) if getattr(self.agent, "rpo_alpha", None) is not None else p
             probs = torch.distributions.Normal(p, torch.exp(self.agent.actor_logstd.expand_as(p)))
             newlogprob, entropy = probs.log_prob(acts).sum(1), probs.entropy().sum(1)
         loss, scalars = host_ops.ppo_loss(newlogprob, entropy, newvalue, b_logprobs[mb_inds], b_advantages[mb_inds],

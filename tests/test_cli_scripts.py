@@ -109,6 +109,13 @@ def test_ppo_continuous_action_script_cpu():
     assert "model saved to" in out
 
 
+def test_rpo_continuous_action_script_cpu():
+    """rpo_continuous_action.py: the same blocks with a perturbed re-evaluated mean."""
+    out = _run([sys.executable, "cleanrl_amd/rpo_continuous_action.py", "--no-cuda", "--num-envs", "2", "--num-steps", "64",
+                "--total-timesteps", "256", "--rpo-alpha", "0.1"])
+    assert out.count("SPS:") == 2
+
+
 def test_ppo_atari_multigpu_two_ranks_gloo():
     """The reference's distributed test: torchrun, 2 CPU processes over gloo (tests/test_atari_multigpu.py:4-9).
     Replicas must stay in lock-step: both ranks print the same actor weight sum after every update."""

@@ -158,3 +158,41 @@ def test_agent_api_on_device_matches_torch_distributions():
     (dn.log_prob(act).sum(1).sum() + 0.5 * dn.entropy().sum(1).sum()).backward()
     np.testing.assert_allclose(g_ls.cpu().numpy(), cagent.actor_logstd.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(g_w.cpu().numpy(), cagent.actor_mean[-1].weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_rpo_perturbed_mean_update_matches_cpu_oracle():
+    """rpo_continuous_action.py:138-142 through the HIP learner: the loss kernel sees mean + z, the gradient flows into
+    the unperturbed mean.  z is pinned (same tensor on both sides) so the step is comparable with the CPU oracle."""
+    torch.manual_seed(5)
+    np.random.seed(5)
+    N, T, D, OBS = 8, 16, 3, 5
+    cenv = SimpleNamespace(single_observation_space=E.Box(-1, 1, (OBS,)), single_action_space=E.Box(-1, 1, (D,)))
+    agent = ContinuousAgent(cenv, rpo_alpha=0.5).to(DEV)
+    args = learner_smoke.default_args(num_steps=T, num_minibatches=2, clip_coef=0.2, ent_coef=0.0)
+    L = PPOLearner(agent, args, cenv.single_observation_space, cenv.single_action_space, N, DEV, sample_seed=5)
+    B = T * N
+    L.obs.copy_(torch.randn(T, N, OBS))
+    L.actions.copy_(torch.randn(T, N, D))
+    L.logprobs.copy_(torch.randn(T, N) - 3)
+    L.advantages.copy_(torch.randn(T, N))
+    L.values.copy_(torch.randn(T, N))
+    L.returns.copy_(L.advantages + L.values)
+    M = L.minibatch_size
+    idx = torch.randperm(B, device=DEV)[:M]
+    z = (torch.rand(M, D, device=DEV) * 2 - 1) * 0.5
+    agent.perturb_mean = lambda mean: mean + z                         # pin the perturbation
+    sc = torch.empty(7, device=DEV)
+    b = [L.actions.reshape(B, D)] + [t.reshape(-1) for t in (L.logprobs, L.advantages, L.returns, L.values)]
+    L.forward_backward_hip(idx, L.obs.reshape(B, OBS), *b, sc)
+    cpu = ContinuousAgent(cenv, rpo_alpha=0.5)
+    cpu.load_state_dict({k: v.cpu() for k, v in agent.state_dict().items()})
+    mean, vv = cpu.heads(L.obs.reshape(B, OBS)[idx].cpu())
+    lp, ent = TO.normal_logprob_entropy(mean + z.cpu(), cpu.actor_logstd, b[0][idx].cpu())
+    ref = TO.ppo_loss(lp, ent, vv, b[1][idx].cpu(), b[2][idx].cpu(), b[3][idx].cpu(), b[4][idx].cpu(), args.clip_coef,
+                      args.ent_coef, args.vf_coef, True, True)
+    ref["loss"].backward()
+    names = ["loss", "pg_loss", "v_loss", "entropy", "old_approx_kl", "approx_kl", "clipfrac"]
+    np.testing.assert_allclose(sc.cpu().numpy(), [ref[k].item() for k in names], rtol=1e-4, atol=1e-5)
+    g_ref = torch.cat([p.grad.reshape(-1) for p in cpu.parameters()])
+    g_hip = L.flat.grads.cpu()
+    assert (g_hip - g_ref).abs().max().item() <= 1e-4 * g_ref.abs().max().item() + 1e-7
