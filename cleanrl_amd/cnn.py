@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .ops import _chk, _ptr, _stream, _workspace
+from .ops import _chk, _on, _ptr, _stream, _workspace
 
 # layer -> (Cin, Cout, K, stride, Hin, Hout)
 LAYERS = {1: (4, 32, 8, 4, 84, 20), 2: (32, 64, 4, 2, 20, 9), 3: (64, 64, 3, 1, 9, 7)}
@@ -30,7 +30,7 @@ def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch
     if out is None:
         out = torch.empty(numel, dtype=torch.float32, device=W.device)
     _chk(out, torch.float32, "Bt", (numel,))
-    with torch.cuda.device(W.device):
+    with _on(W.device):
         st = lib.mi355ppo_cnn_repack_weights_f32(_ptr(W), _ptr(out), layer, mode, _stream(W.device))
     _lib.check(st, "mi355ppo_cnn_repack_weights_f32")
     return out
@@ -56,7 +56,7 @@ def conv_fwd(src: torch.Tensor, Bt: torch.Tensor, bias: torch.Tensor, layer: int
     if out is None:
         out = torch.empty((images, hout, hout, cout), dtype=torch.float32, device=src.device)
     _chk(out, torch.float32, "out", (images, hout, hout, cout))
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         st = lib.mi355ppo_cnn_conv_fwd_f32_variant(_ptr(src), _ptr(inds), _ptr(Bt), _ptr(bias), _ptr(out), images, layer,
                                                    int(variant), _stream(src.device))
     _lib.check(st, "mi355ppo_cnn_conv_fwd_f32")
@@ -75,7 +75,7 @@ def conv_dgrad(dz: torch.Tensor, Bt: torch.Tensor, act_in: torch.Tensor, layer: 
     if out is None:
         out = torch.empty_like(act_in)
     _chk(out, torch.float32, "out", (images, hin, hin, cin))
-    with torch.cuda.device(dz.device):
+    with _on(dz.device):
         st = lib.mi355ppo_cnn_conv_dgrad_f32_variant(_ptr(dz), _ptr(Bt), _ptr(act_in), _ptr(out), images, layer, int(variant),
                                                      _stream(dz.device))
     _lib.check(st, "mi355ppo_cnn_conv_dgrad_f32")
@@ -101,11 +101,24 @@ def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tens
     dW = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
     db = torch.empty(cout, dtype=torch.float32, device=dev)
     ws = _workspace(dev, lib.mi355ppo_cnn_conv_wgrad_workspace_bytes(images, layer))
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.mi355ppo_cnn_conv_wgrad_f32(_ptr(src), _ptr(inds), _ptr(dz), _ptr(dW), _ptr(db), images, layer, _ptr(ws),
                                              ws.numel(), _stream(dev))
     _lib.check(st, "mi355ppo_cnn_conv_wgrad_f32")
     return dW, db
+
+
+def trunk_fwd(obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3):
+    """conv1 -> conv2 -> conv3 (each with bias + ReLU) in one library call; buffers as produced by ``_Buffers``."""
+    lib = _lib.load()
+    _chk(obs_u8, torch.uint8, "obs_u8")
+    images = a1.shape[0]
+    dev = obs_u8.device
+    with _on(dev):
+        st = lib.mi355ppo_cnn_trunk_fwd_f32(_ptr(obs_u8), _ptr(inds), _ptr(bt1), _ptr(b1), _ptr(bt2), _ptr(b2), _ptr(bt3), _ptr(b3),
+                                            _ptr(a1), _ptr(a2), _ptr(a3), images, _stream(dev))
+    _lib.check(st, "mi355ppo_cnn_trunk_fwd_f32")
+    return a3
 
 
 class _Buffers:
@@ -120,6 +133,17 @@ class _Buffers:
         self.cache_weights = False
         self.weights_version = 0
         self._bt = {}
+
+    def fc_weight(self, W: torch.Tensor) -> torch.Tensor:
+        """Linear(3136,512) weight with (h,w,c)-ordered input features, cached like the conv matrices."""
+        if not self.cache_weights:
+            return fc_weight_hwc(W.detach()).contiguous()
+        tag = (self.weights_version, W._version, W.data_ptr())
+        hit = self._bt.get("fc")
+        if hit is None or hit[0] != tag:
+            hit = (tag, fc_weight_hwc(W.detach()).contiguous())
+            self._bt["fc"] = hit
+        return hit[1]
 
     def weights(self, W: torch.Tensor, layer: int, mode: int) -> torch.Tensor:
         if not self.cache_weights:
@@ -150,9 +174,12 @@ class NatureTrunkFn(torch.autograd.Function):
         m = obs_u8.shape[0] if inds is None else inds.numel()
         a1, a2, a3 = bufs.get(m, obs_u8.device, False)
         bt1, bt2, bt3 = (bufs.weights(W, l, MODE_FWD) for l, W in ((1, W1), (2, W2), (3, W3)))
-        conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1)
-        conv_fwd(a1, bt2, b2.detach(), 2, None, a2)
-        conv_fwd(a2, bt3, b3.detach(), 3, None, a3)
+        if not torch.is_grad_enabled() and obs_u8.is_contiguous() and tuple(obs_u8.shape[1:]) == (84, 84, 4):
+            trunk_fwd(obs_u8, inds, bt1, b1.detach(), bt2, b2.detach(), bt3, b3.detach(), a1, a2, a3)   # inference: one call
+        else:
+            conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1)
+            conv_fwd(a1, bt2, b2.detach(), 2, None, a2)
+            conv_fwd(a2, bt3, b3.detach(), 3, None, a3)
         ctx.obs, ctx.inds, ctx.acts, ctx.bufs = obs_u8, inds, (a1, a2, a3), bufs
         ctx.save_for_backward(W2, W3)
         return a3
@@ -203,8 +230,8 @@ class LinearReLUHwcFn(torch.autograd.Function):
     SPLIT = 16
 
     @staticmethod
-    def forward(ctx, a, W, b):
-        Wp = fc_weight_hwc(W.detach()).contiguous()
+    def forward(ctx, a, W, b, bufs=None):
+        Wp = bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()).contiguous()
         h = torch._addmm_activation(b.detach(), a, Wp.t())                     # bias + ReLU fused into the GEMM epilogue
         ctx.save_for_backward(a, h, Wp)
         return h
@@ -221,4 +248,49 @@ class LinearReLUHwcFn(torch.autograd.Function):
         else:
             dWp = dz.t() @ a
         dW = dWp.view(n, 7, 7, 64).permute(0, 3, 1, 2).reshape(n, 64 * 7 * 7)     # back to the (c, h, w) feature order
-        return da, dW, dz.sum(0)
+        return da, dW, dz.sum(0), None
+
+
+def heads_supported(actor: torch.nn.Linear, critic: torch.nn.Linear) -> bool:
+    return actor.in_features == 512 and critic.in_features == 512 and critic.out_features == 1 and 1 <= actor.out_features <= 7
+
+
+class HeadsFn(torch.autograd.Function):
+    """``(actor(h), critic(h))`` -- Agent's two output Linear layers (ppo_atari_multigpu.py:148-149) -- as one
+    bandwidth-bound pass over ``h`` forward and one backward (``csrc/heads.hip``) instead of six degenerate GEMMs."""
+
+    @staticmethod
+    def forward(ctx, h, Wa, ba, Wc, bc):
+        lib = _lib.load()
+        M, H = h.shape
+        A = Wa.shape[0]
+        h = _chk(h.contiguous(), torch.float32, "h", (M, H))
+        _chk(Wa, torch.float32, "actor.weight", (A, H))
+        _chk(Wc, torch.float32, "critic.weight", (1, H))
+        logits = torch.empty((M, A), dtype=torch.float32, device=h.device)
+        value = torch.empty((M, 1), dtype=torch.float32, device=h.device)
+        with _on(h.device):
+            st = lib.mi355ppo_heads_fwd_f32(_ptr(h), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), _ptr(logits), _ptr(value), M, A, H,
+                                            _stream(h.device))
+        _lib.check(st, "mi355ppo_heads_fwd_f32")
+        ctx.save_for_backward(h, Wa, Wc)
+        return logits, value
+
+    @staticmethod
+    def backward(ctx, dlogits, dvalue):
+        lib = _lib.load()
+        h, Wa, Wc = ctx.saved_tensors
+        M, H = h.shape
+        A = Wa.shape[0]
+        dev = h.device
+        dlogits = dlogits.contiguous() if dlogits is not None else torch.zeros((M, A), device=dev)
+        dvalue = dvalue.contiguous() if dvalue is not None else torch.zeros((M, 1), device=dev)
+        dh = torch.empty_like(h)
+        dWa, dba = torch.empty_like(Wa), torch.empty(A, dtype=torch.float32, device=dev)
+        dWc, dbc = torch.empty_like(Wc), torch.empty(1, dtype=torch.float32, device=dev)
+        ws = _workspace(dev, lib.mi355ppo_heads_bwd_workspace_bytes(M, A))
+        with _on(dev):
+            st = lib.mi355ppo_heads_bwd_f32(_ptr(h), _ptr(Wa), _ptr(Wc), _ptr(dlogits), _ptr(dvalue), _ptr(dh), _ptr(dWa),
+                                            _ptr(dba), _ptr(dWc), _ptr(dbc), M, A, H, _ptr(ws), ws.numel(), _stream(dev))
+        _lib.check(st, "mi355ppo_heads_bwd_f32")
+        return dh, dWa, dba, dWc, dbc

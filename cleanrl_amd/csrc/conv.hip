@@ -1293,6 +1293,17 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_f32_variant(const void* src, c
     return conv_fwd_impl(src, inds, Bt, bias, dst, images, layer, variant, stream);
 }
 
+// The three forward layers in one call (rollout inference: the host-side cost of a launch matters there).
+extern "C" MI355PPO_API int mi355ppo_cnn_trunk_fwd_f32(const void* obs_u8, const int64_t* inds, const float* bt1, const float* b1,
+                                                       const float* bt2, const float* b2, const float* bt3, const float* b3,
+                                                       float* a1, float* a2, float* a3, int64_t images, void* stream) {
+    int rc = conv_fwd_impl(obs_u8, inds, bt1, b1, a1, images, 1, 0, stream);
+    if (rc) return rc;
+    rc = conv_fwd_impl(a1, nullptr, bt2, b2, a2, images, 2, 0, stream);
+    if (rc) return rc;
+    return conv_fwd_impl(a2, nullptr, bt3, b3, a3, images, 3, 0, stream);
+}
+
 static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in, float* dsrc, int64_t images, int layer,
                            int variant, void* stream) {
     const char* fn = "mi355ppo_cnn_conv_dgrad_f32";

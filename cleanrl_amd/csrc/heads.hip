@@ -1,0 +1,213 @@
+// Policy / value heads of the NatureCNN agent: actor = Linear(512, A), critic = Linear(512, 1)
+// (cleanrl/ppo_atari_multigpu.py:148-149,157-159), forward and backward, as two bandwidth-bound kernels (gfx950).
+//
+// As GEMMs these are degenerate (N = A + 1 <= 8 columns forward, K = A + 1 backward): hipBLASLt spends ~100 us forward and
+// ~250 us backward per 32,768-row minibatch on six launches.  What they really are is one pass over the hidden
+// activations h (M x 512 f32 = 67 MB at M = 32,768):
+//   forward : logits[m][a] = h[m] . Wa[a] + ba[a],  value[m] = h[m] . Wc + bc      (read h once)
+//   backward: dh[m][j] = sum_a dlogits[m][a] Wa[a][j] + dvalue[m] Wc[j]            (read h once, write dh once)
+//             dWa[a][j] = sum_m dlogits[m][a] h[m][j],  dWc[j] = sum_m dvalue[m] h[m][j],  db = column sums
+// A wave owns a row at a time: lane l holds h[m][8l .. 8l+7] (two float4: the 2 KB row is one contiguous read) and
+// the matching slices of all NA = A + 1 weight rows in registers.  The weight-gradient accumulators (NA x 8 per lane)
+// stay in registers over all rows a wave visits; waves -> workgroup (LDS, wave order) -> grid partials are folded in a
+// fixed order (deterministic).  Algorithmic bytes: forward 2048*M + 4*NA*M, backward 4096*M + 4*NA*M (+ partials).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace mi355ppo {
+
+constexpr int kHid = 512;
+constexpr int kHeadsBlocks = 512;       // persistent workgroups of 4 waves (2 per CU)
+
+template <int NA>
+__device__ __forceinline__ void load_w(float (&w)[NA][8], const float* __restrict__ Wa, const float* __restrict__ Wc, int A,
+                                       int lane) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const float* row = a < A ? Wa + (size_t)a * kHid : Wc;
+        const float4 x = *reinterpret_cast<const float4*>(row + lane * 8), y = *reinterpret_cast<const float4*>(row + lane * 8 + 4);
+        w[a][0] = x.x; w[a][1] = x.y; w[a][2] = x.z; w[a][3] = x.w; w[a][4] = y.x; w[a][5] = y.y; w[a][6] = y.z; w[a][7] = y.w;
+    }
+}
+
+template <int NA>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ h, const float* __restrict__ Wa,
+                                                        const float* __restrict__ ba, const float* __restrict__ Wc,
+                                                        const float* __restrict__ bc, float* __restrict__ logits,
+                                                        float* __restrict__ value, int M, int A) {
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
+    float w[NA][8];
+    load_w<NA>(w, Wa, Wc, A, lane);
+    float bias = 0.0f;
+    if (lane < A) bias = ba[lane];
+    else if (lane == A) bias = bc[0];
+    for (int m = wv; m < M; m += nwv) {
+        const float* hr = h + (size_t)m * kHid + lane * 8;
+        const float4 x = *reinterpret_cast<const float4*>(hr), y = *reinterpret_cast<const float4*>(hr + 4);
+        const float hv[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        float out = 0.0f;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += hv[i] * w[a][i];
+            s = wave_sum(s);
+            if (lane == a) out = s;
+        }
+        out = out + bias;
+        if (lane < A) logits[(size_t)m * A + lane] = out;
+        else if (lane == A) value[m] = out;
+    }
+}
+
+template <int NA>
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ h, const float* __restrict__ Wa,
+                                                        const float* __restrict__ Wc, const float* __restrict__ dlogits,
+                                                        const float* __restrict__ dvalue, float* __restrict__ dh,
+                                                        float* __restrict__ part,      // [grid][NA][512 + 1]
+                                                        int M, int A) {
+    __shared__ float red[NA][kHid + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wv = blockIdx.x * 4 + wave, nwv = gridDim.x * 4;
+    float w[NA][8], acc[NA][8], accb[NA];
+    load_w<NA>(w, Wa, Wc, A, lane);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        accb[a] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[a][i] = 0.0f;
+    }
+    for (int m = wv; m < M; m += nwv) {
+        float g = 0.0f;                                   // lane a holds the row's a-th output gradient
+        if (lane < A) g = dlogits[(size_t)m * A + lane];
+        else if (lane == A) g = dvalue[m];
+        const float* hr = h + (size_t)m * kHid + lane * 8;
+        const float4 x = *reinterpret_cast<const float4*>(hr), y = *reinterpret_cast<const float4*>(hr + 4);
+        const float hv[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const float ga = __shfl(g, a, 64);
+            accb[a] += ga;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                d[i] += ga * w[a][i];
+                acc[a][i] += ga * hv[i];
+            }
+        }
+        float* dr = dh + (size_t)m * kHid + lane * 8;
+        *reinterpret_cast<float4*>(dr) = make_float4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<float4*>(dr + 4) = make_float4(d[4], d[5], d[6], d[7]);
+    }
+    // waves fold into one LDS accumulator in wave order (fixed), then one partial per workgroup
+    for (int wsel = 0; wsel < 4; ++wsel) {
+        if (wave == wsel) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float* r = &red[a][lane * 8 + i];
+                    *r = wsel == 0 ? acc[a][i] : *r + acc[a][i];
+                }
+                if (lane == 0) red[a][kHid] = wsel == 0 ? accb[a] : red[a][kHid] + accb[a];
+            }
+        }
+        __syncthreads();
+    }
+    float* out = part + (size_t)blockIdx.x * NA * (kHid + 1);
+    for (int e = threadIdx.x; e < NA * (kHid + 1); e += 256) out[e] = red[e / (kHid + 1)][e % (kHid + 1)];
+}
+
+// dWa (A,512), dba (A), dWc (512), dbc (1) from the workgroup partials, fixed order.
+__global__ __launch_bounds__(256) void heads_bwd_reduce(const float* __restrict__ part, int nparts, int NA, int A,
+                                                        float* __restrict__ dWa, float* __restrict__ dba,
+                                                        float* __restrict__ dWc, float* __restrict__ dbc) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= NA * (kHid + 1)) return;
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)NA * (kHid + 1);
+    int p = 0;
+    for (; p + 8 <= nparts; p += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += part[(size_t)(p + u) * stride + e];
+    }
+    for (; p < nparts; ++p) s8[p & 7] += part[(size_t)p * stride + e];
+    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    const int a = e / (kHid + 1), j = e - a * (kHid + 1);
+    if (a < A) {
+        if (j < kHid) dWa[(size_t)a * kHid + j] = s;
+        else dba[a] = s;
+    } else {
+        if (j < kHid) dWc[j] = s;
+        else dbc[0] = s;
+    }
+}
+
+static int heads_grid(int M) { return M < kHeadsBlocks * 4 ? (M + 3) / 4 : kHeadsBlocks; }
+
+}  // namespace mi355ppo
+
+using namespace mi355ppo;
+
+static int heads_check(const char* fn, int M, int A, int H) {
+    MI355_REQUIRE(M > 0, MI355PPO_EINVAL, "%s: M=%d must be positive", fn, M);
+    MI355_REQUIRE(A >= 1 && A <= 7, MI355PPO_EINVAL, "%s: A=%d must be in 1..7 (use a library GEMM for wider heads)", fn, A);
+    MI355_REQUIRE(H == kHid, MI355PPO_EINVAL, "%s: hidden width %d is not supported (NatureCNN: 512)", fn, H);
+    return MI355PPO_OK;
+}
+
+extern "C" MI355PPO_API int mi355ppo_heads_fwd_f32(const float* h, const float* Wa, const float* ba, const float* Wc,
+                                                   const float* bc, float* logits, float* value, int M, int A, int H,
+                                                   void* stream) {
+    const char* fn = "mi355ppo_heads_fwd_f32";
+    MI355_REQUIRE(h && Wa && ba && Wc && bc && logits && value, MI355PPO_EINVAL, "%s: null pointer", fn);
+    int rc = heads_check(fn, M, A, H);
+    if (rc) return rc;
+    MI355_REQUIRE(aligned(h, 16) && aligned(Wa, 16) && aligned(Wc, 16) && aligned(ba, 4) && aligned(bc, 4) && aligned(logits, 4) &&
+                      aligned(value, 4), MI355PPO_EALIGN, "%s: h / Wa / Wc must be 16-byte aligned", fn);
+    const dim3 grid(heads_grid(M));
+    hipStream_t s = as_stream(stream);
+#define LAUNCH(NA) hipLaunchKernelGGL((heads_fwd_kernel<NA>), grid, dim3(256), 0, s, h, Wa, ba, Wc, bc, logits, value, M, A)
+    switch (A + 1) {
+        case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break;
+        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;
+    }
+#undef LAUNCH
+    return check_launch("heads_fwd_kernel");
+}
+
+extern "C" MI355PPO_API size_t mi355ppo_heads_bwd_workspace_bytes(int M, int A) {
+    if (M <= 0 || A < 1 || A > 7) return 0;
+    return (size_t)heads_grid(M) * (A + 1) * (kHid + 1) * sizeof(float);
+}
+
+extern "C" MI355PPO_API int mi355ppo_heads_bwd_f32(const float* h, const float* Wa, const float* Wc, const float* dlogits,
+                                                   const float* dvalue, float* dh, float* dWa, float* dba, float* dWc,
+                                                   float* dbc, int M, int A, int H, void* workspace, size_t workspace_bytes,
+                                                   void* stream) {
+    const char* fn = "mi355ppo_heads_bwd_f32";
+    MI355_REQUIRE(h && Wa && Wc && dlogits && dvalue && dh && dWa && dba && dWc && dbc, MI355PPO_EINVAL, "%s: null pointer", fn);
+    int rc = heads_check(fn, M, A, H);
+    if (rc) return rc;
+    const size_t need = mi355ppo_heads_bwd_workspace_bytes(M, A);
+    MI355_REQUIRE(workspace && workspace_bytes >= need, MI355PPO_EWORKSPACE, "%s: workspace %zu bytes < required %zu", fn,
+                  workspace ? workspace_bytes : (size_t)0, need);
+    MI355_REQUIRE(aligned(h, 16) && aligned(Wa, 16) && aligned(Wc, 16) && aligned(dh, 16) && aligned(workspace, 4) &&
+                      aligned(dlogits, 4) && aligned(dvalue, 4), MI355PPO_EALIGN, "%s: h / Wa / Wc / dh must be 16-byte aligned", fn);
+    const int nb = heads_grid(M);
+    float* part = static_cast<float*>(workspace);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH(NA) hipLaunchKernelGGL((heads_bwd_kernel<NA>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A)
+    switch (A + 1) {
+        case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break;
+        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;
+    }
+#undef LAUNCH
+    rc = check_launch("heads_bwd_kernel");
+    if (rc) return rc;
+    const int total = (A + 1) * (kHid + 1);
+    hipLaunchKernelGGL(heads_bwd_reduce, dim3((total + 255) / 256), dim3(256), 0, s, part, nb, A + 1, A, dWa, dba, dWc, dbc);
+    return check_launch("heads_bwd_reduce");
+}

@@ -30,6 +30,26 @@ def _stream(dev: torch.device):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+class _NoSwitch:
+    """Context manager that does nothing (the tensor's device is already the current one)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(dev: torch.device):
+    """``with _on(dev):`` == ``with _on(dev):`` without the get/set-device round trips when ``dev`` is
+    already current -- the normal case (one process per GPU); the wrappers sit on the rollout's per-step critical path,
+    which is host-bound."""
+    return _NO_SWITCH if dev.index is None or torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
 def _chk(t: torch.Tensor, dtype, name: str, shape=None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TypeError(f"{name}: expected a CUDA/HIP tensor (libmi355ppo has no CPU path), got "
@@ -73,7 +93,7 @@ def gae(rewards, dones, values, next_done, next_value, gamma: float, gae_lambda:
         returns = torch.empty_like(rewards)
     _chk(advantages, torch.float32, "advantages", (T, N))
     _chk(returns, torch.float32, "returns", (T, N))
-    with torch.cuda.device(rewards.device):
+    with _on(rewards.device):
         st = lib.mi355ppo_gae_f32_variant(_ptr(rewards), _ptr(dones), _ptr(values), _ptr(next_done), _ptr(next_value),
                                           _ptr(advantages), _ptr(returns), T, N, float(gamma), float(gae_lambda),
                                           int(variant), _stream(rewards.device))
@@ -105,7 +125,7 @@ def categorical_sample(logits, noise_exp1=None, seed: int = 0, offset: int = 0, 
     lp = logprob_out if logprob_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
     _chk(lp, torch.float32, "logprob_out", (B,))
     ent = torch.empty(B, dtype=torch.float32, device=dev) if want_entropy else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.mi355ppo_categorical_sample_f32(_ptr(logits), _ptr(noise_exp1), int(seed) & (2**64 - 1),
                                                  int(offset) & (2**64 - 1), _ptr(a64), _ptr(af), _ptr(lp), _ptr(ent),
                                                  B, A, _stream(dev))
@@ -125,7 +145,7 @@ def categorical_logprob_entropy(logits, action):
         a64, af = None, _chk(action, torch.float32, "action", (B,))
     lp = torch.empty(B, dtype=torch.float32, device=dev)
     ent = torch.empty(B, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.mi355ppo_categorical_logprob_entropy_f32(_ptr(logits), _ptr(a64), _ptr(af), _ptr(lp), _ptr(ent), B, A,
                                                           _stream(dev))
     _lib.check(st, "mi355ppo_categorical_logprob_entropy_f32")
@@ -145,7 +165,7 @@ def normal_sample(mean, logstd, noise=None, seed: int = 0, offset: int = 0, acti
     _chk(act, torch.float32, "action_out", (B, D))
     lp = logprob_out if logprob_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
     ent = torch.empty(B, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.mi355ppo_normal_sample_f32(_ptr(mean), _ptr(logstd), _ptr(noise), int(seed) & (2**64 - 1),
                                             int(offset) & (2**64 - 1), _ptr(act), _ptr(lp), _ptr(ent), B, D,
                                             _stream(dev))
@@ -162,7 +182,7 @@ def normal_logprob_entropy(mean, logstd, action):
     dev = mean.device
     lp = torch.empty(B, dtype=torch.float32, device=dev)
     ent = torch.empty(B, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.mi355ppo_normal_logprob_entropy_f32(_ptr(mean), _ptr(logstd), _ptr(action), _ptr(lp), _ptr(ent), B, D,
                                                      _stream(dev))
     _lib.check(st, "mi355ppo_normal_logprob_entropy_f32")
@@ -189,7 +209,7 @@ class CategoricalLogProbEntropy(torch.autograd.Function):
         a64, af = (action, None) if action.dtype == torch.int64 else (None, action)
         g_lp = None if g_lp is None else _chk(g_lp.contiguous(), torch.float32, "g_logprob", (B,))
         g_ent = None if g_ent is None else _chk(g_ent.contiguous(), torch.float32, "g_entropy", (B,))
-        with torch.cuda.device(logits.device):
+        with _on(logits.device):
             st = lib.mi355ppo_categorical_logprob_entropy_bwd_f32(_ptr(logits), _ptr(a64), _ptr(af), _ptr(g_lp),
                                                                   _ptr(g_ent), _ptr(dlogits), B, A,
                                                                   _stream(logits.device))
@@ -215,7 +235,7 @@ class NormalLogProbEntropy(torch.autograd.Function):
         dmean, drows = torch.empty_like(mean), torch.empty_like(mean)
         g_lp = None if g_lp is None else _chk(g_lp.contiguous(), torch.float32, "g_logprob", (B,))
         g_ent = None if g_ent is None else _chk(g_ent.contiguous(), torch.float32, "g_entropy", (B,))
-        with torch.cuda.device(mean.device):
+        with _on(mean.device):
             st = lib.mi355ppo_normal_logprob_entropy_bwd_f32(_ptr(mean), _ptr(ls), _ptr(action), _ptr(g_lp), _ptr(g_ent),
                                                              _ptr(dmean), _ptr(drows), B, D, _stream(mean.device))
         _lib.check(st, "mi355ppo_normal_logprob_entropy_bwd_f32")
@@ -252,7 +272,7 @@ def ppo_loss_categorical(new_logits, new_value, mb_inds, b_actions, b_logprobs, 
     dvalue = dvalue_out if dvalue_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
     need = lib.mi355ppo_loss_workspace_bytes(M, 0)
     ws = _workspace(dev, need)
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.mi355ppo_loss_categorical_fwd_bwd_f32(
             _ptr(new_logits), _ptr(new_value), _ptr(mb_inds), _ptr(b_actions), _ptr(b_logprobs), _ptr(b_advantages),
             _ptr(b_returns), _ptr(b_values), M, A, float(clip_coef), float(ent_coef), float(vf_coef), int(bool(norm_adv)),
@@ -282,7 +302,7 @@ def ppo_loss_normal(new_mean, logstd, new_value, mb_inds, b_actions, b_logprobs,
     dvalue = torch.empty(M, dtype=torch.float32, device=dev)
     need = lib.mi355ppo_loss_workspace_bytes(M, D)
     ws = _workspace(dev, need)
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.mi355ppo_loss_normal_fwd_bwd_f32(
             _ptr(new_mean), _ptr(logstd_flat), _ptr(new_value), _ptr(mb_inds), _ptr(b_actions), _ptr(b_logprobs),
             _ptr(b_advantages), _ptr(b_returns), _ptr(b_values), M, D, float(clip_coef), float(ent_coef), float(vf_coef),
@@ -352,7 +372,7 @@ def obs_u8_to_f32(src_u8, inds=None, out=None, scale_255: bool = True):
     if out is None:
         out = torch.empty((rows,) + row_shape, dtype=torch.float32, device=dev)
     _chk(out, torch.float32, "out", (rows,) + row_shape)
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.mi355ppo_obs_u8_to_f32(_ptr(src_u8), _ptr(inds), _ptr(out), rows, row_bytes, int(bool(scale_255)),
                                         _stream(dev))
     _lib.check(st, "mi355ppo_obs_u8_to_f32")
@@ -367,7 +387,7 @@ def obs_nchw_to_nhwc_u8(src, out=None):
     if out is None:
         out = torch.empty((rows, H, W, C), dtype=torch.uint8, device=src.device)
     _chk(out, torch.uint8, "out", (rows, H, W, C))
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         st = lib.mi355ppo_obs_nchw_to_nhwc_u8(_ptr(src), _ptr(out), rows, C, H * W, _stream(src.device))
     _lib.check(st, "mi355ppo_obs_nchw_to_nhwc_u8")
     return out
@@ -386,7 +406,7 @@ def clip_adam_(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, max_gra
     if total_norm_out is None:
         total_norm_out = torch.empty(1, dtype=torch.float32, device=dev)
     ws = _workspace(dev, lib.mi355ppo_clip_adam_workspace_bytes(n))
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.mi355ppo_clip_adam_f32(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), n, float(grad_scale),
                                         float(max_grad_norm), float(lr), float(beta1), float(beta2), float(eps),
                                         int(step), _ptr(total_norm_out), _ptr(ws), ws.numel(), _stream(dev))

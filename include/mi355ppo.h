@@ -234,6 +234,12 @@ MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds,
 MI355PPO_API int mi355ppo_cnn_conv_fwd_f32_variant(const void* src, const int64_t* inds, const float* Bt, const float* bias,
                                                    float* dst, int64_t images, int layer, int variant, void* stream);
 
+/* The three forward layers back to back (a1 (images,20,20,32), a2 (images,9,9,64), a3 (images,7,7,64) out): one call
+ * for inference-sized batches, where the host-side cost of a launch matters. */
+MI355PPO_API int mi355ppo_cnn_trunk_fwd_f32(const void* obs_u8, const int64_t* inds, const float* bt1, const float* b1,
+                                            const float* bt2, const float* b2, const float* bt3, const float* b3,
+                                            float* a1, float* a2, float* a3, int64_t images, void* stream);
+
 /* dsrc = conv_transpose(dz) * (act_in > 0): gradient w.r.t. the layer's INPUT activation act_in
  * (itself a ReLU output), i.e. the pre-activation gradient of the previous layer.  layer = 2 or 3;
  * Bt in mode 2 / mode 1. */
@@ -249,6 +255,21 @@ MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t images, int 
 MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW, float* db,
                                              int64_t images, int layer, void* workspace, size_t workspace_bytes,
                                              void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Heads  actor = Linear(H, A) and critic = Linear(H, 1) of Agent (cleanrl/ppo_atari_multigpu.py:148-149,
+ * used at :151,157-159), forward and backward.  Degenerate as GEMMs (A + 1 <= 8 columns); here one
+ * bandwidth-bound pass over the hidden activations each.  H must be 512 (NatureCNN), 1 <= A <= 7.
+ *   h (M,H); Wa (A,H), ba (A); Wc (H) [= critic.weight (1,H)], bc (1)   ->   logits (M,A), value (M)
+ *   backward: dlogits (M,A), dvalue (M)  ->  dh (M,H), dWa (A,H), dba (A), dWc (H), dbc (1)
+ * Weight gradients are summed in a fixed order (deterministic); all outputs are overwritten.
+ */
+MI355PPO_API int mi355ppo_heads_fwd_f32(const float* h, const float* Wa, const float* ba, const float* Wc, const float* bc,
+                                        float* logits, float* value, int M, int A, int H, void* stream);
+MI355PPO_API size_t mi355ppo_heads_bwd_workspace_bytes(int M, int A);
+MI355PPO_API int mi355ppo_heads_bwd_f32(const float* h, const float* Wa, const float* Wc, const float* dlogits,
+                                        const float* dvalue, float* dh, float* dWa, float* dba, float* dWc, float* dbc,
+                                        int M, int A, int H, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -165,3 +165,35 @@ def test_trunk_matches_reference_network_forward_backward(images):
         err = (p.grad.cpu().double() - pr.grad).abs().max().item()
         err_torch = (pt.grad.cpu().double() - pr.grad).abs().max().item()
         assert err <= max(5e-5 * scale, 4.0 * err_torch), f"grad of {name}: err {err:.3e}, torch f32 err {err_torch:.3e}, scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("M,A", [(1, 4), (37, 4), (1024, 6), (4096, 1), (32768, 4), (300, 7)])
+def test_heads_forward_backward(M, A):
+    """actor + critic heads (ppo_atari_multigpu.py:148-149) as one pass each way vs float64 Linear layers; the weight
+    gradients are sums over M rows, so their bound scales like the f32 error of torch's own GEMM (calibrated)."""
+    g = torch.Generator().manual_seed(M + A)
+    h = torch.relu(torch.randn(M, 512, generator=g))
+    actor, critic = torch.nn.Linear(512, A), torch.nn.Linear(512, 1)
+    gl, gv = torch.randn(M, A, generator=g), torch.randn(M, 1, generator=g)
+    import copy
+    a64, c64 = copy.deepcopy(actor).double(), copy.deepcopy(critic).double()
+    h64 = h.double().requires_grad_(True)
+    l_ref, v_ref = a64(h64), c64(h64)
+    torch.autograd.backward([l_ref, v_ref], [gl.double(), gv.double()])
+    ad, cd = copy.deepcopy(actor).to(DEV), copy.deepcopy(critic).to(DEV)
+    hd = h.to(DEV).requires_grad_(True)
+    assert cnn.heads_supported(ad, cd)
+    logits, value = cnn.HeadsFn.apply(hd, ad.weight, ad.bias, cd.weight, cd.bias)
+    _close(logits, l_ref, "logits", tol=1e-5)
+    _close(value, v_ref, "value", tol=1e-5)
+    torch.autograd.backward([logits, value], [gl.to(DEV), gv.to(DEV)])
+    _close(hd.grad, h64.grad, "dh", tol=1e-5)
+    at, ct = copy.deepcopy(actor).to(DEV), copy.deepcopy(critic).to(DEV)          # torch f32 on the device, for calibration
+    ht = h.to(DEV)
+    torch.autograd.backward([at(ht), ct(ht)], [gl.to(DEV), gv.to(DEV)])
+    for name, got, ref, cal in (("dWa", ad.weight.grad, a64.weight.grad, at.weight.grad), ("dba", ad.bias.grad, a64.bias.grad, at.bias.grad),
+                                ("dWc", cd.weight.grad, c64.weight.grad, ct.weight.grad), ("dbc", cd.bias.grad, c64.bias.grad, ct.bias.grad)):
+        scale = ref.abs().max().item()
+        err = (got.cpu().double() - ref).abs().max().item()
+        err_t = (cal.cpu().double() - ref).abs().max().item()
+        assert err <= max(2e-5 * scale, 4.0 * err_t), f"{name}: err {err:.3e}, torch f32 err {err_t:.3e}, scale {scale:.3e}"
