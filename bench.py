@@ -182,7 +182,7 @@ def main():
                 key = f"trunk_fwd(conv1+2+3)@{images}"
                 conv_flops[key] = sum(2.0 * images * c[5] * c[5] * c[1] * c[0] * c[2] * c[2] for c in cnn.LAYERS.values())
                 seen[key] = seen.get(key, 0) + 1
-                if seen[key] % 16:
+                if images == N and seen[key] % 16:
                     return real_trunk(*a, **kw)
                 return timer.wrap(key, real_trunk)(*a, **kw)
 

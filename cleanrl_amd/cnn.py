@@ -174,8 +174,8 @@ class NatureTrunkFn(torch.autograd.Function):
         m = obs_u8.shape[0] if inds is None else inds.numel()
         a1, a2, a3 = bufs.get(m, obs_u8.device, False)
         bt1, bt2, bt3 = (bufs.weights(W, l, MODE_FWD) for l, W in ((1, W1), (2, W2), (3, W3)))
-        if not torch.is_grad_enabled() and obs_u8.is_contiguous() and tuple(obs_u8.shape[1:]) == (84, 84, 4):
-            trunk_fwd(obs_u8, inds, bt1, b1.detach(), bt2, b2.detach(), bt3, b3.detach(), a1, a2, a3)   # inference: one call
+        if m <= 4096 and obs_u8.is_contiguous() and tuple(obs_u8.shape[1:]) == (84, 84, 4):     # inference-sized: one call
+            trunk_fwd(obs_u8, inds, bt1, b1.detach(), bt2, b2.detach(), bt3, b3.detach(), a1, a2, a3)
         else:
             conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1)
             conv_fwd(a1, bt2, b2.detach(), 2, None, a2)
