@@ -202,11 +202,18 @@ def main():
     learner.observe(0, env.obs_into(learner.stage_obs), learner.dones[0])
     total_iters = cli.warmup + cli.steps
 
+    phase_events = []
+
     def one_step(i):
         lr = (1.0 - i / max(total_iters, 1)) * args.learning_rate           # annealed as in :251-254
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
         learner_smoke.rollout(learner, env)
+        ev[1].record()
         m = learner.update(lr)
         learner.start_iteration()
+        ev[2].record()
+        phase_events.append(ev)
         return m
 
     for i in range(cli.warmup):
@@ -256,6 +263,10 @@ def main():
             },
             "final_loss": metrics["loss"],
         }
+        timed = phase_events[-cli.steps:]
+        out["phases_ms"] = {"rollout_incl_gae": float(np.mean([e[0].elapsed_time(e[1]) for e in timed])),
+                            "update": float(np.mean([e[1].elapsed_time(e[2]) for e in timed])),
+                            "note": "GPU-timeline split of ms_per_step (events on the learner's stream)"}
         if not cli.no_kernel_timing and learner.fused_cnn:
             # dominant kernel of the path = the conv launch with the largest total time inside the timed region
             tot = {k: timer.mean_us(k)[0] * timer.mean_us(k)[1] * (16 if k.endswith(f"@{N}") else 1) for k in conv_flops}
