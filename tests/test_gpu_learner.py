@@ -196,3 +196,36 @@ def test_rpo_perturbed_mean_update_matches_cpu_oracle():
     g_ref = torch.cat([p.grad.reshape(-1) for p in cpu.parameters()])
     g_hip = L.flat.grads.cpu()
     assert (g_hip - g_ref).abs().max().item() <= 1e-4 * g_ref.abs().max().item() + 1e-7
+
+
+def test_cached_weight_matrices_follow_the_fused_optimiser_step():
+    """The repacked conv matrices / permuted FC weight are cached behind a version tag; the fused clip+Adam kernel
+    rewrites the parameters through raw pointers, so the learner must bump the tag.  After a step, the cached path and a
+    fresh non-caching trunk must agree bit for bit."""
+    from cleanrl_amd import cnn
+
+    torch.manual_seed(7)
+    np.random.seed(7)
+    N = 16
+    env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=7)
+    agent = AtariAgent(env).to(DEV)
+    args = learner_smoke.default_args(num_steps=8, num_minibatches=2)
+    L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=7)
+    L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
+    learner_smoke.rollout(L, env)                       # fills the caches (rollout enables caching)
+    assert agent._trunk.bufs.cache_weights
+    L.update(args.learning_rate)                        # several fused optimiser steps
+    with torch.no_grad():
+        cached = [t.clone() for t in agent.heads_u8(L.obs[0])]
+        fresh_agent_trunk, agent._trunk = agent._trunk, cnn.NatureTrunk()       # a trunk that repacks on every call
+        fresh = [t.clone() for t in agent.heads_u8(L.obs[0])]
+        agent._trunk = fresh_agent_trunk
+    assert torch.equal(cached[0], fresh[0]) and torch.equal(cached[1], fresh[1])
+    # and an in-place torch update (e.g. load_state_dict) is caught by the tensors' own version counters
+    with torch.no_grad():
+        agent.network[0].weight.mul_(1.5)
+        a = agent.heads_u8(L.obs[0])[0].clone()
+        agent._trunk, keep = cnn.NatureTrunk(), agent._trunk
+        b = agent.heads_u8(L.obs[0])[0].clone()
+        agent._trunk = keep
+    assert torch.equal(a, b)
