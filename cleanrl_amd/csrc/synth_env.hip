@@ -1,0 +1,56 @@
+// Test / benchmark support (NOT part of the reference path): one step of the device-resident synthetic Atari
+// vector env that bench.py and the GPU tests use in place of envpool / ALE (absent from this image).  Same byte
+// streams as cleanrl_amd/envs.py::SyntheticAtariVecEnv: observation n = planes[cursor_n .. cursor_n + 3] of a fixed
+// random plane pool (consecutive observations share 3 of 4 channels, like FrameStack(4)), reward in {-1, 0, +1} with
+// P = (.05, .9, .05), episode end Bernoulli(done_p) after which the cursor jumps.  As torch ops this was ~14 launches
+// per env step; here it is two: the per-env scalars, and the frame gather (28,224 B per env, 16 B per lane).
+#include "common.h"
+
+namespace mi355ppo {
+
+__global__ __launch_bounds__(256) void synth_env_scalars_kernel(long long* __restrict__ cursor, float* __restrict__ reward,
+                                                                float* __restrict__ done, int N, int pool, float done_p,
+                                                                uint64_t seed, uint64_t step) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const uint4 r = Philox(seed)((uint64_t)n, step);
+    const float u = u32_to_unit_open(r.x), ud = u32_to_unit_open(r.y);
+    reward[n] = (u > 0.95f ? 1.0f : 0.0f) - (u < 0.05f ? 1.0f : 0.0f);
+    const bool d = ud < done_p;
+    done[n] = d ? 1.0f : 0.0f;
+    cursor[n] = d ? (long long)(r.z % (uint32_t)pool) : cursor[n] + 1;
+}
+
+// obs[n][c] = planes[(cursor[n] + c) % pool]; a plane is 84*84 = 7056 B = 441 x 16 B
+__global__ __launch_bounds__(256) void synth_env_frames_kernel(const uint8_t* __restrict__ planes,
+                                                               const long long* __restrict__ cursor,
+                                                               uint8_t* __restrict__ obs, int pool) {
+    const int nc = blockIdx.x;                       // n*4 + c
+    const long long src = (cursor[nc >> 2] + (nc & 3)) % pool;
+    const uint4* s = reinterpret_cast<const uint4*>(planes + src * 7056LL);
+    uint4* d = reinterpret_cast<uint4*>(obs + (long long)nc * 7056LL);
+    for (int e = threadIdx.x; e < 441; e += 256) d[e] = s[e];
+}
+
+}  // namespace mi355ppo
+
+using namespace mi355ppo;
+
+extern "C" MI355PPO_API int mi355ppo_synth_atari_step_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed,
+                                                         uint64_t step, uint8_t* obs, float* reward, float* done, int N,
+                                                         double done_p, int advance, void* stream) {
+    const char* fn = "mi355ppo_synth_atari_step_u8";
+    MI355_REQUIRE(planes && cursor && obs, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(N > 0 && pool > 0, MI355PPO_EINVAL, "%s: N=%d pool=%d must be positive", fn, N, pool);
+    MI355_REQUIRE(!advance || (reward && done), MI355PPO_EINVAL, "%s: reward/done are required when advancing", fn);
+    MI355_REQUIRE(aligned(planes, 16) && aligned(obs, 16) && aligned(cursor, 8), MI355PPO_EALIGN, "%s: planes/obs must be 16-byte aligned", fn);
+    hipStream_t s = as_stream(stream);
+    if (advance) {
+        hipLaunchKernelGGL(synth_env_scalars_kernel, dim3((N + 255) / 256), dim3(256), 0, s, reinterpret_cast<long long*>(cursor),
+                           reward, done, N, pool, (float)done_p, seed, step);
+        int rc = check_launch("synth_env_scalars_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(synth_env_frames_kernel, dim3(N * 4), dim3(256), 0, s, planes, reinterpret_cast<const long long*>(cursor), obs, pool);
+    return check_launch("synth_env_frames_kernel");
+}

@@ -246,23 +246,32 @@ class DeviceSyntheticAtariVecEnv:
         self.gen = torch.Generator(device=device).manual_seed(seed)
         self.planes = torch.randint(0, 256, (pool_planes, 84, 84), dtype=torch.uint8, device=device, generator=self.gen)
         self.cursor = torch.randint(0, pool_planes, (num_envs,), device=device, generator=self.gen)
-        self._win = torch.arange(4, device=device)[None, :]
         self.pool = pool_planes
+        self._seed, self._step = int(seed) & (2**64 - 1), 0
 
-    def obs_into(self, out):
-        idx = ((self.cursor[:, None] + self._win) % self.pool).reshape(-1)
-        self.torch.index_select(self.planes, 0, idx, out=out.view(self.num_envs * 4, 84, 84))
+    def _call(self, out, reward, done, advance):
+        """Two launches per env step (csrc/synth_env.hip) instead of ~14 torch kernels: the rollout is short enough for
+        the stand-in env's own launches to show up in env-steps/sec."""
+        from . import _lib
+
+        lib = _lib.load()
+        t = self.torch
+        assert out.dtype == t.uint8 and out.is_contiguous() and tuple(out.shape) == (self.num_envs, 4, 84, 84)
+        if advance:
+            assert reward.dtype == t.float32 and done.dtype == t.float32 and reward.is_contiguous() and done.is_contiguous()
+            self._step += 1
+        st = lib.mi355ppo_synth_atari_step_u8(
+            self.planes.data_ptr(), self.pool, self.cursor.data_ptr(), self._seed, self._step, out.data_ptr(),
+            reward.data_ptr() if advance else None, done.data_ptr() if advance else None, self.num_envs, float(self.done_p),
+            int(advance), t.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(st, "mi355ppo_synth_atari_step_u8")
         return out
 
+    def obs_into(self, out):
+        return self._call(out, None, None, False)
+
     def step_into(self, obs_out, reward_out, done_out):
-        t = self.torch
-        u = t.rand(self.num_envs, device=self.device, generator=self.gen)
-        reward_out.copy_((u > 0.95).float() - (u < 0.05).float())
-        done = t.rand(self.num_envs, device=self.device, generator=self.gen) < self.done_p
-        done_out.copy_(done.float())
-        jump = t.randint(0, self.pool, (self.num_envs,), device=self.device, generator=self.gen)
-        self.cursor = t.where(done, jump, self.cursor + 1)
-        return self.obs_into(obs_out)
+        return self._call(obs_out, reward_out, done_out, True)
 
     def close(self):
         pass

@@ -271,6 +271,16 @@ MI355PPO_API int mi355ppo_heads_bwd_f32(const float* h, const float* Wa, const f
                                         const float* dvalue, float* dh, float* dWa, float* dba, float* dWc, float* dbc,
                                         int M, int A, int H, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Test / benchmark support -- NOT part of the reference path.  One step of the device-resident synthetic Atari
+ * vector env (cleanrl_amd/envs.py::DeviceSyntheticAtariVecEnv) that stands in for envpool / ALE, which this image
+ * does not have: obs[n] = planes[cursor_n .. cursor_n+3] (mod pool) as (N,4,84,84) uint8; with advance != 0 first
+ * reward in {-1,0,+1} (P = .05,.9,.05), done ~ Bernoulli(done_p), cursor += 1 or jumps on done (Philox(seed; n, step)).
+ */
+MI355PPO_API int mi355ppo_synth_atari_step_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed, uint64_t step,
+                                              uint8_t* obs, float* reward, float* done, int N, double done_p, int advance,
+                                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

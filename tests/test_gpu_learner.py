@@ -229,3 +229,31 @@ def test_cached_weight_matrices_follow_the_fused_optimiser_step():
         b = agent.heads_u8(L.obs[0])[0].clone()
         agent._trunk = keep
     assert torch.equal(a, b)
+
+
+def test_device_synthetic_env_streams():
+    """The stand-in env's two kernels: frames are the plane-pool windows at the cursors, rewards/dones have the stated
+    distributions, cursors advance by one or jump on done."""
+    N = 4096
+    env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=11, done_p=0.1)
+    obs = torch.empty((N, 4, 84, 84), dtype=torch.uint8, device=DEV)
+    rew, done = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    env.obs_into(obs)
+    c0 = env.cursor.clone()
+    idx = ((c0[:, None] + torch.arange(4, device=DEV)[None, :]) % env.pool)
+    assert torch.equal(obs, env.planes[idx])
+    rs, ds = [], []
+    for _ in range(20):
+        before = env.cursor.clone()
+        env.step_into(obs, rew, done)
+        moved = env.cursor - before
+        assert torch.all((moved == 1) | (done == 1.0))
+        idx = ((env.cursor[:, None] + torch.arange(4, device=DEV)[None, :]) % env.pool)
+        assert torch.equal(obs, env.planes[idx])
+        rs.append(rew.clone()); ds.append(done.clone())
+    r, d = torch.cat(rs), torch.cat(ds)
+    assert set(r.unique().tolist()) <= {-1.0, 0.0, 1.0}
+    n = r.numel()
+    for val, p in ((1.0, 0.05), (-1.0, 0.05)):
+        assert abs((r == val).float().mean().item() - p) < 5 * (p * (1 - p) / n) ** 0.5
+    assert abs(d.mean().item() - 0.1) < 5 * (0.1 * 0.9 / n) ** 0.5
