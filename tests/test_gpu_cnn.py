@@ -197,3 +197,42 @@ def test_heads_forward_backward(M, A):
         err = (got.cpu().double() - ref).abs().max().item()
         err_t = (cal.cpu().double() - ref).abs().max().item()
         assert err <= max(2e-5 * scale, 4.0 * err_t), f"{name}: err {err:.3e}, torch f32 err {err_t:.3e}, scale {scale:.3e}"
+
+
+def test_full_minibatch_size_properties():
+    """Config-C minibatch (32,768 images, where a float64 CPU convolution is out of reach): size-independent properties.
+    The data and weight gradients are LINEAR in dz (the ReLU mask depends on the activation only); the forward of a
+    gathered batch equals the forward of the rows gathered beforehand; a zero dz gives exactly zero."""
+    M = 32768
+    g = torch.Generator(device=DEV).manual_seed(5)
+    obs = torch.randint(0, 256, (M, 84, 84, 4), dtype=torch.uint8, device=DEV, generator=g)
+    inds = torch.randperm(M, device=DEV, generator=g)
+    params = {l: tuple(t.to(DEV) for t in _params(l, 40 + l)) for l in (1, 2, 3)}
+    bt = {l: cnn.repack_weights(params[l][0], l) for l in (1, 2, 3)}
+    a1 = cnn.conv_fwd(obs, bt[1], params[1][1], 1, inds)
+    assert torch.equal(a1[:4096], cnn.conv_fwd(obs[inds[:4096]].contiguous(), bt[1], params[1][1], 1))    # gather == pre-gathered rows
+    a2 = cnn.conv_fwd(a1, bt[2], params[2][1], 2)
+    assert a1.min().item() >= 0.0 and a2.min().item() >= 0.0 and torch.isfinite(a2).all()
+    dz_a, dz_b = torch.randn(a2.shape, device=DEV, generator=g), torch.randn(a2.shape, device=DEV, generator=g)
+    btd = cnn.repack_weights(params[2][0], 2, cnn.MODE_DGRAD_S2)
+    da, db_ = cnn.conv_dgrad(dz_a, btd, a1, 2), cnn.conv_dgrad(dz_b, btd, a1, 2)
+    dab = cnn.conv_dgrad(2.0 * dz_a - 0.5 * dz_b, btd, a1, 2)
+    lin = 2.0 * da - 0.5 * db_
+    assert (dab - lin).abs().max().item() <= 2e-5 * lin.abs().max().item()
+    assert torch.equal(da == 0, db_ == 0) or ((a1 > 0) | (da == 0)).all()                      # masked where the activation is 0
+    assert ((a1 > 0) | (dab == 0)).all()
+    Wa, ba = cnn.conv_wgrad(a1, dz_a, 2)
+    Wb, bb = cnn.conv_wgrad(a1, dz_b, 2)
+    Wab, bab = cnn.conv_wgrad(a1, 2.0 * dz_a - 0.5 * dz_b, 2)
+    # sums of 2.65 M f32 terms: linear within f32 accumulation error of the sum's scale
+    scale = (Wa.abs().max() + Wb.abs().max()).item()
+    assert (Wab - (2.0 * Wa - 0.5 * Wb)).abs().max().item() <= 2e-4 * scale
+    assert (bab - (2.0 * ba - 0.5 * bb)).abs().max().item() <= 2e-4 * (ba.abs().max() + bb.abs().max()).item()
+    W0, b0 = cnn.conv_wgrad(a1, torch.zeros_like(dz_a), 2)
+    assert W0.abs().max().item() == 0.0 and b0.abs().max().item() == 0.0
+    # layer 1 weight gradient on the uint8 rows, through the gather: linear as well
+    d1a, d1b = torch.randn(a1.shape, device=DEV, generator=g), torch.randn(a1.shape, device=DEV, generator=g)
+    W1a, _ = cnn.conv_wgrad(obs, d1a, 1, inds)
+    W1b, _ = cnn.conv_wgrad(obs, d1b, 1, inds)
+    W1ab, _ = cnn.conv_wgrad(obs, d1a + d1b, 1, inds)
+    assert (W1ab - (W1a + W1b)).abs().max().item() <= 2e-4 * (W1a.abs().max() + W1b.abs().max()).item()
