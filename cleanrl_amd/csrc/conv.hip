@@ -688,7 +688,10 @@ struct WgradGeom {
 // SPLIT: every wave owns ALL tiles (TPW = all of them) and a quarter of the pixel pairs instead of a quarter of the
 // tiles and all pairs -- more MFMAs per fragment fetch for the thin conv1 problem (8 tiles); each wave then writes
 // its own partial.
-template <int NCI, int TPW, bool U8IN, int NS, int ND, bool SPLIT, int RD>
+// B128 (layer 2: a tap row is 128 floats = 4 tiles): lane l owns patch elements 4l..4l+3 of each of the wave's two tap
+// rows instead of element l of each of its 8 tiles, so two ds_read_b128 replace eight ds_read_b32; tile 4r+c then
+// holds the columns {128r + 4l + c} (a permutation of dW's columns, undone when the partial is written).
+template <int NCI, int TPW, bool U8IN, int NS, int ND, bool SPLIT, int RD, bool B128 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_kernel(const void* __restrict__ src_v,
                                                             const int64_t* __restrict__ inds,
                                                             const float* __restrict__ dz,
@@ -769,6 +772,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto frag_a = [&](int pr) { return s_dz[(2 * pr + lh) * g.N + ci * 32 + li]; };
     auto frag_b_at = [&](int pb, float (&b)[TPW]) {
+        if constexpr (B128) {
+            static_assert(!B128 || (TPW == 8 && !U8IN && !SPLIT), "B128 is the layer-2 configuration");
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_src) + pb + (2 * jgroup + r) * rowpitch + 4 * li);
+                b[4 * r + 0] = v.x; b[4 * r + 1] = v.y; b[4 * r + 2] = v.z; b[4 * r + 3] = v.w;
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             if (U8IN) b[t] = __uint_as_float((unsigned)s_src[pb + patch_off[t]]);   // raw byte; converted when consumed (a
@@ -830,7 +842,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* pw = part_w + (size_t)(SPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * g.N * g.K;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int kcol = (jgroup * TPW + t) * 32 + li;
+        const int kcol = B128 ? 256 * jgroup + 128 * (t >> 2) + 4 * li + (t & 3) : (jgroup * TPW + t) * 32 + li;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int n = ci * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -1420,7 +1432,7 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     } else if (layer == 2) {
-        auto k = conv_wgrad_kernel<2, 8, false, 13, 6, false, 2>;
+        auto k = conv_wgrad_kernel<2, 8, false, 13, 6, false, 2, true>;
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
     } else {
