@@ -932,7 +932,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             rs[q] = gs[e < src16 ? e : 0];
         }
     };
+    // uint8, 8 tiles (layer 1): the 8 x 32 taps of a pixel are 64 dwords; lane l fetches dwords l and l + 32 (tap rows
+    // l/8 and l/8 + 4, columns 4(l%8) .. +3) with two ds_read_b32 instead of eight ds_read_u8.  Tile 4h + c then holds, in
+    // lane l, the tap (row l/8 + 4h, column 4(l%8) + c): a permutation of dW's columns, undone when the partial is written.
+    constexpr bool PACK8 = U8IN && PSPLIT && TPW == 8 && G::RUN == 32;
     auto frag_b = [&](int pb, float (&b)[TPW]) {
+        if constexpr (PACK8) {
+            const int o = pb + (li >> 3) * rowpitch + 4 * (li & 7);
+            b[0] = __uint_as_float(*reinterpret_cast<const uint32_t*>(s_src + o));
+            b[1] = __uint_as_float(*reinterpret_cast<const uint32_t*>(s_src + o + 4 * rowpitch));
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             if (U8IN) b[t] = __uint_as_float((unsigned)s_src[pb + patch_off[t]]);     // raw byte, converted when consumed
@@ -963,8 +973,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 bsum += a;
                 const int sl = (RING % 2 == 0) ? (j & 1) : ((s0 + j) & 1);
 #pragma unroll
-                for (int t = 0; t < TPW; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, U8IN ? (float)__float_as_uint(rb[sl][t]) : rb[sl][t], acc[t], 0, 0, 0);
+                for (int t = 0; t < TPW; ++t) {
+                    float bv;
+                    if constexpr (PACK8) bv = u8_tap(__float_as_uint(rb[sl][t >> 2]), t & 3);
+                    else bv = U8IN ? (float)__float_as_uint(rb[sl][t]) : rb[sl][t];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 dzload(j);                                        // (image, step + RING) -- or the next image's first steps
                 frag_b(pbn, rb[sl]);                               // step + 2 (slots refilled past the last step are never consumed)
@@ -978,7 +992,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* pw = part_w + (size_t)(PSPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * kN * kK;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int kcol = (jgroup * TPW + t) * 32 + li;
+        const int kcol = PACK8 ? ((li >> 3) + 4 * (t >> 2)) * 32 + 4 * (li & 7) + (t & 3) : (jgroup * TPW + t) * 32 + li;
 #pragma unroll
         for (int e = 0; e < 16; ++e) pw[(size_t)(ci * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * kK + kcol] = acc[t][e];
     }
