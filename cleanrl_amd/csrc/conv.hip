@@ -871,7 +871,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   PSPLIT (layer 1: 8 tiles): every wave owns ALL tiles and a quarter of the pixel pairs -> one partial per wave;
 //   otherwise (layers 2, 3: 32 / 36 tiles): wave w owns channel half w % NCI and tile group w / NCI, all pixel pairs.
 // STEPS = pixel pairs per wave and image, padded to a multiple of RING (padding pairs carry dz = 0).
-template <class G, int NCI, int TPW, bool U8IN, bool PSPLIT, int STEPS, int RING, int NS>
+// DMA: the source image goes global -> LDS with global_load_lds (no registers, no commit phase) into the buffer that is not
+// being multiplied from; ONE barrier per image, entered after the wave has waited for its own pieces with s_waitcnt
+// vmcnt(RING) -- the counter is in order and exactly the RING dz fragments issued after the DMA may stay outstanding.
+template <class G, int NCI, int TPW, bool U8IN, bool PSPLIT, int STEPS, int RING, int NS, bool DMA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_direct_kernel(
     const void* __restrict__ src_v, const int64_t* __restrict__ inds, const float* __restrict__ dz,
     float* __restrict__ part_w,      // [parts][N][K]
@@ -880,8 +883,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int kSrcBytes = G::H * G::W * G::C * (U8IN ? 1 : 4), kN = G::DC, kK = G::K, kNpix = G::GY * G::GX;
     static_assert(STEPS % RING == 0, "steps per image must be a multiple of the ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kImgPad = NS * 256 * 16;                       // one LDS image buffer (whole 16-byte chunks per thread)
     unsigned char* s_src = smem;
-    int* s_pixbase = reinterpret_cast<int*>(smem + ((kSrcBytes + 15) & ~15));
+    int* s_pixbase = reinterpret_cast<int*>(smem + (DMA ? 2 * kImgPad : ((kSrcBytes + 15) & ~15)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int ci = PSPLIT ? 0 : wave % NCI, jgroup = PSPLIT ? 0 : wave / NCI;
@@ -908,18 +912,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float bsum = 0.0f;
 
     // dz ring: element (image, step) = dz[image][pixel 2*(P0 + PS*step) + lh][ci*32 + li], 0 for padding pixels
+    // (the fragment is stored raw and masked when it is consumed: a select here would make the wave wait for the load it
+    // has just issued.  Masking is only needed when the padded step grid reaches past the image's pixels.)
+    constexpr bool MASK = 2 * ((PSPLIT ? 3 : 0) + (PSPLIT ? 4 : 1) * (STEPS - 1)) + 1 >= kNpix;
     float ring[RING];
+    unsigned rmask = 0u;
     int l_img = blockIdx.x, l_step = 0;
-    auto dzload = [&](int slot) {
+    // The load cursor runs exactly RING steps ahead and STEPS % RING == 0, so it can only wrap to the next image after
+    // slot RING-1: the check is compiled into that slot alone (a branch in every slot makes hipcc rotate the ring through
+    // register copies at the loop back-edge, which waits for ALL outstanding loads every RING steps).
+    auto dzload = [&](int slot, bool may_wrap) {
         const int p = 2 * (P0 + PS * l_step) + lh;
         const bool ok = l_img < images && p < npix;
         const long long idx = ok ? ((long long)l_img * npix + p) * kN + ci * 32 + li : (long long)li;
-        const float v = dz[idx];
-        ring[slot] = ok ? v : 0.0f;
-        if (++l_step == STEPS) { l_step = 0; l_img += gridDim.x; }
+        ring[slot] = dz[idx];
+        if (MASK) rmask = (rmask & ~(1u << slot)) | ((ok ? 1u : 0u) << slot);
+        ++l_step;
+        if (may_wrap && l_step == STEPS) { l_step = 0; l_img += gridDim.x; }
     };
 #pragma unroll
-    for (int j = 0; j < RING; ++j) dzload(j);
+    for (int j = 0; j < RING; ++j) dzload(j, j == RING - 1);
 
     constexpr int src16 = kSrcBytes / 16;
     u32x4 rs[NS];
@@ -936,32 +948,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // l/8 and l/8 + 4, columns 4(l%8) .. +3) with two ds_read_b32 instead of eight ds_read_u8.  Tile 4h + c then holds, in
     // lane l, the tap (row l/8 + 4h, column 4(l%8) + c): a permutation of dW's columns, undone when the partial is written.
     constexpr bool PACK8 = U8IN && PSPLIT && TPW == 8 && G::RUN == 32;
+    const unsigned char* cur = s_src;                            // LDS image being multiplied from
     auto frag_b = [&](int pb, float (&b)[TPW]) {
         if constexpr (PACK8) {
             const int o = pb + (li >> 3) * rowpitch + 4 * (li & 7);
-            b[0] = __uint_as_float(*reinterpret_cast<const uint32_t*>(s_src + o));
-            b[1] = __uint_as_float(*reinterpret_cast<const uint32_t*>(s_src + o + 4 * rowpitch));
+            b[0] = __uint_as_float(*reinterpret_cast<const uint32_t*>(cur + o));
+            b[1] = __uint_as_float(*reinterpret_cast<const uint32_t*>(cur + o + 4 * rowpitch));
             return;
         }
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            if (U8IN) b[t] = __uint_as_float((unsigned)s_src[pb + patch_off[t]]);     // raw byte, converted when consumed
-            else b[t] = reinterpret_cast<const float*>(s_src)[pb + patch_off[t]];
+            if (U8IN) b[t] = __uint_as_float((unsigned)cur[pb + patch_off[t]]);       // raw byte, converted when consumed
+            else b[t] = reinterpret_cast<const float*>(cur)[pb + patch_off[t]];
         }
     };
     auto pix = [&](int step) { return s_pixbase[2 * (P0 + PS * step) + lh]; };
 
-    int img = blockIdx.x;
-    if (img < images) prefetch(img);
-    for (; img < images; img += gridDim.x) {
-        __syncthreads();                       // previous image fully consumed
+    auto dma = [&](int img, int buf) {                          // this thread's NS chunks of image `img` -> LDS buffer `buf`
+        const long long simg = (U8IN && inds) ? inds[img] : img;
+        const unsigned char* gs = static_cast<const unsigned char*>(src_v) + simg * (long long)kSrcBytes;
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const int e = tid + 256 * q;
-            if (e < src16) reinterpret_cast<u32x4*>(s_src)[e] = rs[q];
+            __builtin_amdgcn_global_load_lds(gs + (size_t)(e < src16 ? e : src16 - 1) * 16,
+                                             (__attribute__((address_space(3))) void*)(smem + buf * kImgPad + (256 * q + 64 * wave) * 16),
+                                             16, 0, 0);
         }
-        __syncthreads();
-        if (img + (int)gridDim.x < images) prefetch(img + gridDim.x);      // in flight during the whole multiply phase
+    };
+    int img = blockIdx.x, buf = 0;
+    if (img < images) {
+        if (DMA) dma(img, 0);
+        else prefetch(img);
+    }
+    for (; img < images; img += gridDim.x) {
+        if (DMA) {
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (RING & 0xF) | ((RING >> 4) << 14));   // vmcnt(RING): my DMA pieces have landed
+            __syncthreads();                   // everyone's pieces have landed; the other buffer is no longer read
+            cur = s_src + buf * kImgPad;
+            if (img + (int)gridDim.x < images) dma(img + gridDim.x, buf ^ 1);
+            buf ^= 1;
+        } else {
+            __syncthreads();                       // previous image fully consumed
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const int e = tid + 256 * q;
+                if (e < src16) reinterpret_cast<u32x4*>(s_src)[e] = rs[q];
+            }
+            __syncthreads();
+            if (img + (int)gridDim.x < images) prefetch(img + gridDim.x);      // in flight during the whole multiply phase
+        }
         float rb[2][TPW];
         frag_b(pix(0), rb[0]);
         frag_b(pix(1), rb[1]);
@@ -969,7 +1004,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int s0 = 0; s0 < STEPS; s0 += RING) {
 #pragma unroll
             for (int j = 0; j < RING; ++j) {
-                const float a = ring[j];
+                const float a = (MASK && !((rmask >> j) & 1u)) ? 0.0f : ring[j];
                 bsum += a;
                 const int sl = (RING % 2 == 0) ? (j & 1) : ((s0 + j) & 1);
 #pragma unroll
@@ -980,7 +1015,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                dzload(j);                                        // (image, step + RING) -- or the next image's first steps
+                dzload(j, j == RING - 1);                          // (image, step + RING) -- or the next image's first steps
                 frag_b(pbn, rb[sl]);                               // step + 2 (slots refilled past the last step are never consumed)
                 const int s3 = s0 + j + 3;
                 pbn = pix(s3 < STEPS ? s3 : STEPS - 1);
@@ -1437,8 +1472,8 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     hipError_t e = hipSuccess;
     if (direct) {       // layer 1 only (measured: equal on layer 2, slower on layer 3 whose 25 pairs per image leave the
                         // ring no room); LDS: source image + pixbase table (2*(3 + 4*50) + 2 ints)
-        auto k = conv_wgrad_direct_kernel<GeomConv1, 1, 8, true, true, 50, 10, 7>;
-        const size_t sm = ((size_t)(g.src_bytes + 15) & ~(size_t)15) + (2 * (3 + 4 * 50) + 2) * sizeof(int);
+        auto k = conv_wgrad_direct_kernel<GeomConv1, 1, 8, true, true, 50, 10, 7, false>;
+        const size_t sm = ((size_t)(g.src_bytes + 15) & ~(size_t)15) + (2 * (3 + 4 * 50) + 2) * sizeof(int);   // image + pixbase (DMA variant: 2 x 28672 + pixbase)
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), sm);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, (int)images);
     } else if (layer == 1) {
