@@ -473,8 +473,8 @@ struct ClsParams {
     int bt_off[4];             // element offset of the class's weight matrix in Bt_all
 };
 
-template <class G, int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT>
-__global__ __launch_bounds__(512) void conv_fixed_kernel(const void* __restrict__ src_v, const int64_t* __restrict__ inds,
+template <class G, int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void conv_fixed_kernel(const void* __restrict__ src_v, const int64_t* __restrict__ inds,
                                                          const float* __restrict__ Bt_all, const float* __restrict__ bias,
                                                          const float* __restrict__ mask_src, float* __restrict__ dst,
                                                          unsigned P, int ntiles, unsigned src_bytes, unsigned dst_bytes,
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(512) void conv_fixed_kernel(const void* __restrict_
     {
         const float4* __restrict__ Bt4 = reinterpret_cast<const float4*>(Bt_all + cp.bt_off[cls]);
         constexpr unsigned k4 = K / 4, total = (unsigned)(32 * NJT) * k4;
-        for (unsigned e = tid; e < total; e += 512) {
+        for (unsigned e = tid; e < total; e += 64 * NW) {
             const unsigned row = e / k4, c = e - row * k4;
             *reinterpret_cast<float4*>(&Bs[row * LDB + c * 4]) = Bt4[e];
         }
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(512) void conv_fixed_kernel(const void* __restrict_
     const __amdgpu_buffer_rsrc_t rsrc_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, kRsrcWord3);
     const __amdgpu_buffer_rsrc_t rsrc_msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mask_src), 0,
                                                                               EPI == EPI_MASK ? (int)dst_bytes : 0, kRsrcWord3);
-    const int nwv = gridDim.x * 8;
+    const int nwv = gridDim.x * NW;
 
     // per lane and pixel tile: byte offset of tap (0,0) of the lane's pixel (+16 bytes for the upper half-wave), or the
     // 64-bit pointer for uint8 sources; PAD: validity bit r*KW + c
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(512) void conv_fixed_kernel(const void* __restrict_
     };
 
     Pix cur, nxt;
-    int tile = blockIdx.x * 8 + wave;
+    int tile = blockIdx.x * NW + wave;
     setup(tile, cur);
     setup(tile + nwv, nxt);
     // prologue: chunks 0 .. kRing-1 of the first tile
@@ -1205,7 +1205,7 @@ static int launch_stream_cfg(const void* src, const int64_t* inds, const float* 
     return check_launch("conv_stream_kernel");
 }
 
-template <class G, int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT>
+template <class G, int NJT, bool U8IN, int EPI, bool PAD, bool CLS4, int MT, int NW = 8, int WGS_PER_CU = 1>
 static int launch_fixed_cfg(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
                             float* dst, long long P, long long src_bytes, long long dst_bytes, hipStream_t s,
                             const ClsParams* cpp = nullptr, int ncls = 1) {
@@ -1218,17 +1218,17 @@ static int launch_fixed_cfg(const void* src, const int64_t* inds, const float* B
         return MI355PPO_EINVAL;
     }
     const size_t smem = ((size_t)(32 * NJT) * (G::K + 4) + 8 + 32 * NJT) * sizeof(float);
-    auto k = conv_fixed_kernel<G, NJT, U8IN, EPI, PAD, CLS4, MT>;
+    auto k = conv_fixed_kernel<G, NJT, U8IN, EPI, PAD, CLS4, MT, NW>;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
     if (e != hipSuccess) {
         set_error("conv_fixed_kernel: hipFuncSetAttribute(%zu bytes of LDS): %s", smem, hipGetErrorString(e));
         return MI355PPO_EHIP;
     }
     const int ntiles = (int)((P + 32 * MT - 1) / (32 * MT));
-    int wgs = 256 / ncls;
-    const int need = (ntiles + 7) / 8;
+    int wgs = 256 * WGS_PER_CU / ncls;
+    const int need = (ntiles + NW - 1) / NW;
     if (wgs > need) wgs = need;
-    hipLaunchKernelGGL(k, dim3((unsigned)wgs, (unsigned)ncls), dim3(512), smem, s, src, inds, Bt, bias, mask_src, dst, (unsigned)P,
+    hipLaunchKernelGGL(k, dim3((unsigned)wgs, (unsigned)ncls), dim3(64 * NW), smem, s, src, inds, Bt, bias, mask_src, dst, (unsigned)P,
                        ntiles, (unsigned)(U8IN ? 0 : src_bytes), (unsigned)dst_bytes, cp);
     return check_launch("conv_fixed_kernel");
 }
@@ -1326,7 +1326,15 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
     if (variant == 0)   // kernel F addresses f32 tensors with 32-bit buffer offsets; beyond 4 GiB fall back to kernel S
         variant = ((layer > 1 && srcb > kBufLimit) || dstb > kBufLimit) ? 4 : kDefaultVariant;
     if (variant == 2) {
-        if (layer == 1) return launch_fixed<GeomConv1, 1, true, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, 0, dstb, s);
+        if (layer == 1) {
+            // layer 1 has the shortest tiles (8 chunks): on gfx9 loads and stores share one out-of-order vmcnt, so the tile
+            // epilogue's stores force a full drain of the prefetch ring at every tile boundary; three 4-wave workgroups per
+            // CU (3 waves per SIMD at 152 VGPRs) give the matrix pipe two other waves to run meanwhile.
+            static const int s_c1 = getenv("MI355PPO_CONV1_WG") ? atoi(getenv("MI355PPO_CONV1_WG")) : 3;
+            if (s_c1 == 3 && g.P >= 64LL * 4 * 2048)
+                return launch_fixed_cfg<GeomConv1, 1, true, EPI_BIAS_RELU, false, false, 2, 4, 3>(src, inds, Bt, bias, nullptr, dst, g.P, 0, dstb, s);
+            return launch_fixed<GeomConv1, 1, true, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, 0, dstb, s);
+        }
         if (layer == 2) return launch_fixed<GeomConv2, 2, false, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, srcb, dstb, s);
         return launch_fixed<GeomConv3, 2, false, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, srcb, dstb, s);
     }
