@@ -78,6 +78,9 @@ def test_conv1_fwd_u8_gather(images, variant):
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 19, 128, 700, 7000])
 def test_conv_fwd_f32(layer, images, variant):
+    if images == 7000 and variant != 2:
+        pytest.skip("the 7000-image case (64-pixel-tile launch path) is checked on the default kernel only: its float64 "
+                    "CPU reference dominates the suite's run time")
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(10 + layer)
     x = torch.relu(torch.randn(images, cin, hin, hin, generator=g))
@@ -94,6 +97,8 @@ def test_conv_fwd_f32(layer, images, variant):
 def test_conv_dgrad_with_relu_mask(layer, images, variant):
     if variant == 5 and layer != 3:
         pytest.skip("variant 5 (border classes) is the layer-3 data gradient")
+    if images == 7000 and variant not in (2, 5):
+        pytest.skip("the 7000-image case is checked on the default kernels only (CPU reference time)")
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(20 + layer)
     pre = torch.randn(images, cin, hin, hin, generator=g).double().requires_grad_(True)
