@@ -65,3 +65,64 @@ def test_ops_refuse_cpu_tensors_there_is_no_fallback():
         ops.categorical_sample(x)
     with pytest.raises(TypeError, match="CUDA/HIP"):
         ops.obs_u8_to_f32(torch.zeros(2, 8, dtype=torch.uint8))
+
+
+def test_cnn_and_heads_entry_points_validate_before_any_launch():
+    """The convolution / heads entry points: bad layer, variant, sizes, pointers and workspaces fail with a code and a
+    message, without touching a device."""
+    lib = _lib.load()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.mi355ppo_cnn_repack_weights_f32(p, p, 4, 0, None) == -1                 # no such layer
+    assert lib.mi355ppo_cnn_repack_weights_f32(p, p, 1, 1, None) == -1                 # mode 1 is a layer-3 layout
+    assert lib.mi355ppo_cnn_repack_weights_f32(p, p, 2, 3, None) == -1                 # mode 3 likewise
+    assert lib.mi355ppo_cnn_conv_fwd_f32(None, None, p, p, p, 8, 1, None) == -1
+    assert b"null" in lib.mi355ppo_last_error()
+    assert lib.mi355ppo_cnn_conv_fwd_f32(p, p, p, p, p, 8, 2, None) == -1              # row gather only exists for layer 1
+    assert b"inds" in lib.mi355ppo_last_error()
+    assert lib.mi355ppo_cnn_conv_fwd_f32(p, None, p, p, p, 0, 1, None) == -1
+    assert lib.mi355ppo_cnn_conv_fwd_f32_variant(p, None, p, p, p, 8, 1, 9, None) == -1
+    assert b"variant" in lib.mi355ppo_last_error()
+    assert lib.mi355ppo_cnn_conv_dgrad_f32(p, p, p, p, 8, 1, None) == -1               # conv1's input needs no gradient
+    assert lib.mi355ppo_cnn_conv_dgrad_f32_variant(p, p, p, p, 8, 2, 5, None) == -1    # border classes are layer 3 only
+    need = lib.mi355ppo_cnn_conv_wgrad_workspace_bytes(32768, 2)
+    assert need == (512 + 16) * 64 * 512 * 4 + (512 + 16) * 64 * 4
+    assert lib.mi355ppo_cnn_conv_wgrad_workspace_bytes(32768, 1) == (2048 + 64) * 32 * 256 * 4 + (2048 + 64) * 32 * 4
+    assert lib.mi355ppo_cnn_conv_wgrad_workspace_bytes(0, 2) == 0
+    assert lib.mi355ppo_cnn_conv_wgrad_f32(p, None, p, p, p, 8, 2, p, 16, None) == -4
+    assert b"workspace" in lib.mi355ppo_last_error()
+    assert lib.mi355ppo_heads_fwd_f32(p, p, p, p, p, p, p, 8, 8, 512, None) == -1      # A must be 1..7
+    assert lib.mi355ppo_heads_fwd_f32(p, p, p, p, p, p, p, 8, 4, 256, None) == -1      # hidden width is 512
+    assert lib.mi355ppo_heads_bwd_workspace_bytes(32768, 4) == 512 * 5 * 513 * 4
+    assert lib.mi355ppo_heads_bwd_f32(p, p, p, p, p, p, p, p, p, p, 8, 4, 512, None, 0, None) == -4
+    assert lib.mi355ppo_synth_atari_step_u8(p, 0, p, 1, 1, p, p, p, 4, 0.01, 1, None) == -1
+
+
+def test_weight_matrix_cache_invalidation_logic(monkeypatch):
+    """cnn._Buffers: without opting in every use re-derives the matrices; with caching, a new matrix is produced exactly
+    when the owner's version, the tensor's own version counter or its storage changes (no GPU needed: the repack call
+    is replaced by a counter)."""
+    from cleanrl_amd import cnn
+
+    calls = []
+
+    def fake_repack(W, layer, mode=0, out=None):
+        calls.append((layer, mode))
+        return torch.full((1,), float(len(calls)))
+
+    monkeypatch.setattr(cnn, "repack_weights", fake_repack)
+    W = torch.zeros(32, 4, 8, 8)
+    b = cnn._Buffers()
+    b.weights(W, 1, 0); b.weights(W, 1, 0)
+    assert len(calls) == 2                                   # caching is opt-in
+    b.cache_weights = True
+    m1 = b.weights(W, 1, 0); m2 = b.weights(W, 1, 0)
+    assert len(calls) == 3 and m1 is m2
+    b.weights(W, 1, 0); b.weights(W, 2, 0)                  # another (layer, mode) key has its own entry
+    assert len(calls) == 4
+    b.weights_version += 1                                   # the learner's fused optimiser step
+    assert b.weights(W, 1, 0).item() == 5.0 and len(calls) == 5
+    W.add_(1.0)                                              # an in-place torch update bumps W._version
+    assert b.weights(W, 1, 0).item() == 6.0
+    W2 = W.clone()                                           # different storage
+    assert b.weights(W2, 1, 0).item() == 7.0
