@@ -17,10 +17,13 @@ Weak scaling: every rank (one process per GPU, RCCL over xGMI) keeps 1024 envs; 
 env-steps/sec = N * 1024 * 128 * K / max-over-ranks(time).
 
 The JSON line also carries
-  ``roofline``      for the dominant HIP kernel of the path by bytes moved -- the uint8 gather+convert
-                    (K5: 28,224 B read + 112,896 B written per minibatch row, HBM-bound) -- timed live with
-                    HIP events on the learner's stream around each of its launches inside the timed region;
-  ``kernels``       the same accounting for the GAE and fused-loss kernels (latency-bound at this size);
+  ``roofline``      for the dominant HIP kernel of the path = the convolution launch with the largest total time in
+                    the timed region (f32-MFMA implicit GEMMs, csrc/conv.hip; the uint8 gather + /255 of K5 is fused
+                    into them): algorithmic flops / launch duration, timed live with HIP events on the learner's
+                    stream around each launch; ``traffic`` = HBM bytes per launch from the committed PMC passes
+                    (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction);
+  ``kernels``       the same accounting for every conv launch shape, and GB/s for the GAE and fused-loss kernels
+                    (latency-bound at this size);
   ``cpu_baseline``  the oracle's CPU port of the reference loop (oracle/cpu_ppo_port.py), rank 0, N=1 only,
                     on a bounded sample (64 envs x 128 steps, >=1 iteration), on the box's host cores.
 """
@@ -73,6 +76,14 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= the f32 vector peak), same guide
 OBS_ROW_BYTES = 4 * 84 * 84   # 28,224
+
+
+def _traffic_of(key):
+    """HBM bytes per launch of conv launch `key` ("conv1_wgrad@32768") from the committed PMC passes, or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get("hbm_bytes_per_launch", {}).get(key)
 
 
 def parse():
@@ -274,12 +285,12 @@ def main():
             us, n = timer.mean_us(dom)
             tf = conv_flops[dom] / us / 1e6
             out["roofline"] = {
-                "kernel": f"{dom}: " + ("conv_wgrad_direct_kernel" if dom.startswith("conv1_wgrad") else
-                                        "conv_wgrad_kernel" if "_wgrad" in dom else "conv_fixed_kernel") +
+                "kernel": f"{dom}: " + ("conv_wgrad_rows_kernel" if dom.startswith("conv1_wgrad") else
+                                        "conv_wgrad_taps_kernel" if "_wgrad" in dom else "conv_fixed_kernel") +
                           " (f32-MFMA implicit GEMM, csrc/conv.hip); the uint8 gather + /255 (K5), bias, ReLU, ReLU-backward and "
                           "bias-gradient passes are fused into the conv kernels and have none of their own",
                 "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": _traffic_of(dom),
                 "algorithmic_flops_per_launch": conv_flops[dom], "avg_launch_us": us, "launches_timed": n,
                 "share_of_step_time": tot[dom] / (elapsed * 1e6),
             }

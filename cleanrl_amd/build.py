@@ -19,6 +19,10 @@ HEADERS = ["common.h", "catrow.h", os.path.join("..", "..", "include", "mi355ppo
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every f32 multiply/add rounds separately, as the reference's un-fused torch ops do.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# conv.hip: the streaming weight-gradient kernel unrolls a whole image (81 steps x 8 MFMAs); past LLVM's default
+# `#pragma unroll` size limit the loop is only partly unrolled and its register "arrays" stay in scratch.  The other kernels
+# of the file compile to identical code with and without the flag.
+EXTRA_FLAGS = {"conv.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -41,7 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [os.path.join(CSRC, src)] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", src, "-o", obj])
     if jobs:
         if verbose:
             print(f"[cleanrl_amd.build] compiling {len(jobs)} HIP source(s) for gfx950", file=sys.stderr)

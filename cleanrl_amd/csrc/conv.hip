@@ -1036,6 +1036,244 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         part_b[(size_t)(PSPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * kN + ci * 32 + li] = both;
 }
 
+// ---- weight gradient of layer 1, third generation (kernel R, "rows").  Kernel D's waves still met at two barriers per
+// image (stage the shared source image, then multiply) and paid a pixel-table read, an address add and a predicated 64-bit
+// index computation beside every 8 MFMAs.  Here a wave is autonomous:
+//   * wave w owns output rows 5w .. 5w+4 of every image of its workgroup, i.e. the 24 source rows 20w .. 20w+23 (8,064 bytes;
+//     neighbouring waves overlap by 4 rows).  It stages that slab itself, global -> registers -> its own double-buffered
+//     LDS region, so there is NO workgroup barrier anywhere: LDS instructions of one wave execute in order;
+//   * one "round" = one output row = 10 pixel pairs, fully unrolled, 5 rounds per image: every LDS and global address of
+//     the loop body is (per-image base register + compile-time immediate);
+//   * the taps of output row r, tap rows 4-7, are the taps of output row r+1, tap rows 0-3 (stride 4 == half the 8-row
+//     window): the dword a lane fetched as "lower half" of row r+1 is kept and re-used -> one ds_read_b32 per pixel pair
+//     instead of two plus the table read;
+//   * the next image's slab is fetched during round 0 (one 16-byte load per step) and written to the other LDS buffer
+//     during round 3; the dz fragments run one round ahead, straight from global memory, across image boundaries.
+// Lane roles as in kernel D / PACK8: lane (li, lh) supplies, for pixel 2j + lh of the row, the dword of tap row li/8 (+4),
+// tap columns 4(li%8) .. +3; tile 4h + c holds tap (row li/8 + 4h, column 4(li%8) + c) -- undone when the partial is written.
+template <class G>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_rows_kernel(
+    const unsigned char* __restrict__ src, const int64_t* __restrict__ inds, const float* __restrict__ dz,
+    float* __restrict__ part_w,      // [grid * 4][32][256]
+    float* __restrict__ part_b,      // [grid * 4][32]
+    int images) {
+    static_assert(G::C == 4 && G::KH == 8 && G::KW == 8 && G::SS == 4 && G::GX == 20 && G::GY == 20 && G::DC == 32 && G::W == 84,
+                  "kernel R is written for Conv2d(4, 32, 8, stride 4) on 84x84 frames");
+    constexpr int kImg = G::H * G::W * G::C, kPitch = G::PITCH;          // 28,224 / 336 bytes
+    constexpr int kRounds = 5, kPPR = 10;                                // output rows per wave, pixel pairs per output row
+    constexpr int kRowStep = G::SS * kPitch;                             // 1,344 bytes between output rows == 4 tap rows
+    constexpr int kSlab = (G::KH + G::SS * (kRounds - 1)) * kPitch;      // 24 source rows = 8,064 bytes
+    constexpr int kBuf = 8192, kChunks = kSlab / 16, kNS = 8;            // 504 16-byte chunks, 8 per lane (last ones clamped)
+    constexpr int kN = 32, kK = 256, kDzImg = G::PER_IMG * kN;           // floats of one dz image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    unsigned char* const wbuf = smem + wave * (2 * kBuf);                // this wave's two slab buffers
+    const int L0 = lh * (G::SS * G::C) + (li >> 3) * kPitch + 4 * (li & 7);
+    const int lane_dz = (wave * (kRounds * 2 * kPPR) + lh) * kN + li;    // float offset of (pixel lh of the wave's first pair, channel li)
+    const int step_img = gridDim.x;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    float bsum = 0.0f;
+
+    auto row_of = [&](int img) { return inds ? inds[img] : (long long)img; };     // rollout row of minibatch image `img` (scalar load)
+    auto slab = [&](long long simg) { return src + simg * (long long)kImg + wave * (G::SS * kRounds * kPitch); };
+    auto chunk_of = [&](int q) { const int e = lane + 64 * q; return e < kChunks ? e : kChunks - 1; };
+
+    int img = blockIdx.x;
+    if (img >= images) return;                                           // (grid <= images: never taken)
+    u32x4 rs[kNS];
+    {   // first image: straight through the registers into buffer 0
+        const unsigned char* g0 = slab(row_of(img));
+#pragma unroll
+        for (int q = 0; q < kNS; ++q) rs[q] = *reinterpret_cast<const u32x4*>(g0 + chunk_of(q) * 16);
+#pragma unroll
+        for (int q = 0; q < kNS; ++q) *reinterpret_cast<u32x4*>(wbuf + (lane + 64 * q) * 16) = rs[q];
+        __builtin_amdgcn_wave_barrier();
+    }
+    float ring[kPPR];
+    uint32_t row[2][kPPR];
+    {
+        const float* gd = dz + (long long)img * kDzImg;
+#pragma unroll
+        for (int j = 0; j < kPPR; ++j) ring[j] = gd[lane_dz + 2 * j * kN];
+#pragma unroll
+        for (int j = 0; j < kPPR; ++j) {
+            row[0][j] = *reinterpret_cast<const uint32_t*>(wbuf + L0 + 2 * j * (G::SS * G::C));
+            row[1][j] = *reinterpret_cast<const uint32_t*>(wbuf + L0 + kRowStep + 2 * j * (G::SS * G::C));
+        }
+    }
+    int buf = 0;
+    int nimg = img + step_img < images ? img + step_img : img;          // clamped: past the end the refills are never consumed
+    long long snext = row_of(nimg);                                       // fetched a whole image before it is needed
+    for (; img < images; img += step_img) {
+        const unsigned char* const lcur = wbuf + buf * kBuf + L0;
+        const unsigned char* const lnxt = wbuf + (buf ^ 1) * kBuf + L0;
+        unsigned char* const wnxt = wbuf + (buf ^ 1) * kBuf + lane * 16;
+        const float* const gd = dz + (long long)img * kDzImg + lane_dz;
+        const float* const gdn = dz + (long long)nimg * kDzImg + lane_dz;
+        const unsigned char* const gsl = slab(snext);
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+#pragma unroll
+            for (int j = 0; j < kPPR; ++j) {
+                const float a = ring[j];
+                bsum += a;
+                const uint32_t w0 = row[r & 1][j], w1 = row[(r + 1) & 1][j];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w0, 0), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w0, 1), acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w0, 2), acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w0, 3), acc[3], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w1, 0), acc[4], 0, 0, 0);
+                acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w1, 1), acc[5], 0, 0, 0);
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w1, 2), acc[6], 0, 0, 0);
+                acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w1, 3), acc[7], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // refills: dz one round ahead; the tap dwords two output rows ahead (the next image's first two at the end)
+                if (r + 1 < kRounds) {
+                    ring[j] = gd[((r + 1) * 2 * kPPR + 2 * j) * kN];
+                    row[r & 1][j] = *reinterpret_cast<const uint32_t*>(lcur + (r + 2) * kRowStep + 2 * j * (G::SS * G::C));
+                } else {
+                    ring[j] = gdn[2 * j * kN];
+                    row[0][j] = *reinterpret_cast<const uint32_t*>(lnxt + 2 * j * (G::SS * G::C));
+                    row[1][j] = *reinterpret_cast<const uint32_t*>(lnxt + kRowStep + 2 * j * (G::SS * G::C));
+                }
+                if (r == 0 && j < kNS) rs[j] = *reinterpret_cast<const u32x4*>(gsl + chunk_of(j) * 16);
+                if (r == 3 && j < kNS) *reinterpret_cast<u32x4*>(wnxt + 64 * j * 16) = rs[j];
+                if (r == 1 && j == 0) {                                  // the row index of the image after next (used next iteration)
+                    nimg = nimg + step_img < images ? nimg + step_img : nimg;       // (gdn above already holds the old nimg's pointer)
+                    snext = row_of(nimg);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        buf ^= 1;
+    }
+
+    float* pw = part_w + (size_t)(blockIdx.x * 4 + wave) * kN * kK;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int kcol = ((li >> 3) + 4 * (t >> 2)) * 32 + 4 * (li & 7) + (t & 3);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pw[(size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * kK + kcol] = acc[t][e];
+    }
+    const float both = bsum + __shfl_xor(bsum, 32, 64);
+    if (lh == 0) part_b[(size_t)(blockIdx.x * 4 + wave) * kN + li] = both;
+}
+
+// ---- weight gradient of layers 2 and 3, third generation (kernel T, "taps"): no LDS, no barrier, no address table.
+// With 32 or 64 input channels an MFMA tile (32 columns of dW) is ONE tap (kh, kw) x 32 input channels, so the B operand
+// of tile (kh, kw) for an output pixel is the dword `src[y*SS + kh][x*SS + kw][c0 + li]` -- 32 consecutive channels of one
+// source pixel, a whole 128-byte line per half-wave, already in operand layout as it lies in memory.  Consecutive output
+// pixels of a row share KW - SS of their KW source columns, so a wave keeps a sliding window of source columns in registers
+// and loads only the SS new columns (x its tap rows) per step, straight from global memory / L1, D steps ahead of use.
+//   * the two pixels of an MFMA k-pair are the SAME output pixel of TWO images (lh = image parity): no odd-grid padding
+//     pair, and both half-waves use identical compile-time offsets from their own image pointers;
+//   * wave w owns channel half ci = w & 1 of dW's rows and a quarter of the taps x input channels: layer 3 (3x3, 64 ch)
+//     all 9 taps of input-channel half w >> 1; layer 2 (4x4, 32 ch) tap rows 2(w >> 1), 2(w >> 1) + 1, all 4 columns;
+//   * the whole image (49 / 81 steps) is unrolled: every load is (per-image pointer + immediate); the image-pair loop is
+//     unrolled by two so that the prefetch of the next pair lands in the other half of the (logical) register arrays.
+// One partial dW per workgroup as in kernel W (same reduce kernels).
+template <class G, int KHW, int CSPLIT, int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_taps_kernel(
+    const float* __restrict__ src, const float* __restrict__ dz,
+    float* __restrict__ part_w,      // [grid][Cout][K]
+    float* __restrict__ part_b,      // [grid][Cout]
+    int images) {
+    constexpr int S = G::PER_IMG, GX = G::GX, KW = G::KW, SS = G::SS, W = G::W, Cin = G::C, Cout = G::DC, K = G::K;
+    constexpr int TPW = KHW * KW, kSrcImg = G::H * G::W * G::C, kDzImg = S * Cout;
+    static_assert(Cout == 64 && Cin == 32 * CSPLIT && (CSPLIT == 2 ? KHW == G::KH : 2 * KHW == G::KH) && D < GX, "wave -> tile map");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int ci = wave & 1, sub = wave >> 1;
+    const int kh0 = CSPLIT == 1 ? sub * KHW : 0, c0 = CSPLIT == 2 ? sub * 32 : 0;
+    const int npairs = (images + 1) >> 1, gstep = gridDim.x;
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    float bsum = 0.0f;
+
+    auto img_of = [&](int pair) { const int i = 2 * pair + lh; return i < images ? i : images - 1; };
+    auto psrc = [&](int pair) { return src + (long long)img_of(pair) * kSrcImg + (kh0 * W * Cin + c0 + li); };
+    auto pdz = [&](int pair) { return dz + (long long)img_of(pair) * kDzImg + (ci * 32 + li); };
+
+    // Register "arrays" (every index below is a compile-time constant once the loops are unrolled; kept small, or hipcc
+    // leaves them in scratch): the dz ring continues across pairs, which needs 2 S % (D + 1) == 0 with the pair loop
+    // unrolled by two; the window rows alternate by output-row parity, which continues across pairs because GY is odd.
+    constexpr int DR = D + 1;
+    static_assert((2 * S) % DR == 0 && (G::GY & 1) == 1, "ring / row-parity continuity across image pairs");
+    float a[DR];                       // dz fragments: step s of pair parity P lives in a[(s + P * S) % DR]
+    float bw[2][KHW][W];               // source-column window [(output row + P) & 1][tap row][source column]
+    auto issue = [&](int P, int t, const float* ps, const float* pd) {      // the loads step t of a pair needs and step t-1 did not
+        const int gy = t / GX, gx = t % GX;
+        a[(t + P * S) % DR] = pd[t * Cout];
+#pragma unroll
+        for (int r = 0; r < KHW; ++r)
+#pragma unroll
+            for (int c = 0; c < KW; ++c)
+                if (gx == 0 || c >= KW - SS) bw[(gy + P) & 1][r][gx * SS + c] = ps[((gy * SS + r) * W + gx * SS + c) * Cin];
+    };
+    auto run = [&](int P, int pair_raw) {
+        // a workgroup with an odd number of pairs runs one dead pair (all dz fragments forced to 0) rather than leaving the
+        // loop between its two halves: a mid-loop exit makes hipcc shuffle the accumulators through scratch at the join
+        const bool valid = pair_raw < npairs;
+        const int pair = valid ? pair_raw : npairs - 1;
+        const int nxt = pair + gstep < npairs ? pair + gstep : pair;         // clamped: the refills past the end are never consumed
+        const float* const ps = psrc(pair);
+        const float* const pd = pdz(pair);
+        const float* const psn = psrc(nxt);
+        const float* const pdn = pdz(nxt);
+        const bool live = valid && 2 * pair + lh < images;                   // (also: the second image of the last pair of an odd batch)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int gy = s / GX, gx = s % GX;
+            const float av = live ? a[(s + P * S) % DR] : 0.0f;
+            bsum += av;
+#pragma unroll
+            for (int r = 0; r < KHW; ++r)
+#pragma unroll
+                for (int c = 0; c < KW; ++c)
+                    acc[r * KW + c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[(gy + P) & 1][r][gx * SS + c], acc[r * KW + c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + D < S) issue(P, s + D, ps, pd);
+            else issue(P ^ 1, s + D - S, psn, pdn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int pair = blockIdx.x;
+    if (pair >= npairs) return;                                              // (grid <= pairs: never taken)
+    {
+        const float* const ps = psrc(pair);
+        const float* const pd = pdz(pair);
+#pragma unroll
+        for (int t = 0; t < D; ++t) issue(0, t, ps, pd);
+    }
+    for (; pair < npairs; pair += 2 * gstep) {
+        run(0, pair);
+        run(1, pair + gstep);
+    }
+
+    float* pw = part_w + (size_t)blockIdx.x * Cout * K;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int kcol = ((kh0 + t / KW) * KW + t % KW) * Cin + c0 + li;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pw[(size_t)(ci * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * K + kcol] = acc[t][e];
+    }
+    const float both = bsum + __shfl_xor(bsum, 32, 64);
+    if (lh == 0 && sub == 0) part_b[(size_t)blockIdx.x * Cout + ci * 32 + li] = both;
+}
+
 // dW (torch layout (N, C, KH, KW)) and db from the per-workgroup partials, fixed summation order, two stages so
 // that the first (which reads all partials) has (N*K/256) x nchunks workgroups instead of N*K/256.
 constexpr int kRedChunk = 32;     // partials folded per stage-1 workgroup row
@@ -1468,26 +1706,49 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     g.images = (int)images; g.src_bytes = Hin * Hin * Cin * (layer == 1 ? 1 : 4);
     static const int s_wdiag = getenv("MI355PPO_CONV_DIAG") ? atoi(getenv("MI355PPO_CONV_DIAG")) : 0;
     g.diag = s_wdiag;
-    const int grid = wgrad_grid(images);
+    // Workspace layout (sized by mi355ppo_cnn_conv_wgrad_workspace_bytes for the kernel with the most partials):
+    //   part_w [lparts][Cout*K] | part_b [lparts][Cout] | mid [ceil(lparts/32)][Cout*K] | mid_b [ceil(lparts/32)][Cout]
+    const int lparts = wgrad_grid(images) * (layer == 1 ? 4 : 1);
+    const int total_w = Cout * g.K;
     float* part_w = static_cast<float*>(workspace);
-    static const int s_wk = getenv("MI355PPO_WGRAD") ? atoi(getenv("MI355PPO_WGRAD")) : 2;     // tuning: 1 = kernel W, 2 = kernel D (direct dz)
-    const bool direct = s_wk == 2 && layer == 1;
-    const int wparts = (direct && layer == 1) ? grid * 4 : grid;       // partials actually written
-    const int bparts = wparts;
-    float* part_b = part_w + (size_t)grid * (layer == 1 ? 4 : 1) * Cout * g.K;
+    float* part_b = part_w + (size_t)lparts * total_w;
+    float* mid = part_b + (size_t)lparts * Cout;
+    float* mid_b = mid + (size_t)((lparts + kRedChunk - 1) / kRedChunk) * total_w;
+    // Tuning switches.  Layer 1: 3 = kernel R (rows, default), 2 = kernel D (direct dz), 1 = kernel W.
+    // Layers 2, 3: 1 = kernel T (taps, default), 2 = kernel T with the deeper layer-2 prefetch ring, 0 = kernel W.
+    static const int s_wk = getenv("MI355PPO_WGRAD") ? atoi(getenv("MI355PPO_WGRAD")) : 3;
+    static const int s_wt = getenv("MI355PPO_WGRAD_TAPS") ? atoi(getenv("MI355PPO_WGRAD_TAPS")) : 1;
     const size_t smem = wgrad_smem(g.src_bytes, Hout * Hout, Cout);
     hipStream_t s = as_stream(stream);
     hipError_t e = hipSuccess;
-    if (direct) {       // layer 1 only (measured: equal on layer 2, slower on layer 3 whose 25 pairs per image leave the
-                        // ring no room); LDS: source image + pixbase table (2*(3 + 4*50) + 2 ints)
+    int grid = wgrad_grid(images);      // workgroups launched
+    int wparts = grid;                  // partials they write (weights and bias alike)
+    if (layer == 1 && s_wk == 3) {      // kernel R: one partial per wave; LDS = 4 waves x 2 slab buffers of 8 KiB
+        auto k = conv_wgrad_rows_kernel<GeomConv1>;
+        const size_t sm = 4 * 2 * 8192;
+        wparts = grid * 4;
+        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), sm);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images);
+    } else if (layer == 1 && s_wk == 2) {      // kernel D: one partial per wave; LDS = source image + pixel table (2*(3 + 4*50) + 2 ints)
         auto k = conv_wgrad_direct_kernel<GeomConv1, 1, 8, true, true, 50, 10, 7, false>;
-        const size_t sm = ((size_t)(g.src_bytes + 15) & ~(size_t)15) + (2 * (3 + 4 * 50) + 2) * sizeof(int);   // image + pixbase (DMA variant: 2 x 28672 + pixbase)
+        const size_t sm = ((size_t)(g.src_bytes + 15) & ~(size_t)15) + (2 * (3 + 4 * 50) + 2) * sizeof(int);
+        wparts = grid * 4;
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), sm);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, (int)images);
     } else if (layer == 1) {
         auto k = conv_wgrad_kernel<1, 2, true, 7, 13, false, 2>;
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
         if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
+    } else if (s_wt && layer == 2) {    // kernel T: a workgroup walks image PAIRS
+        wparts = grid = wgrad_grid((images + 1) / 2);
+        auto k5 = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 5>;
+        auto k8 = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 8>;
+        hipLaunchKernelGGL(s_wt == 2 ? k8 : k5, dim3(grid), dim3(256), 0, s, static_cast<const float*>(src), dz, part_w, part_b, (int)images);
+    } else if (s_wt && layer == 3) {
+        wparts = grid = wgrad_grid((images + 1) / 2);
+        auto k = conv_wgrad_taps_kernel<GeomConv3, 3, 2, 6>;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, static_cast<const float*>(src), dz, part_w, part_b, (int)images);
     } else if (layer == 2) {
         auto k = conv_wgrad_kernel<2, 8, false, 13, 6, false, 2, true>;
         e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
@@ -1503,16 +1764,12 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     }
     int rc = check_launch("conv_wgrad_kernel");
     if (rc) return rc;
-    const int total_w = Cout * g.K;
     const int nchunks = (wparts + kRedChunk - 1) / kRedChunk;
-    const int nchunks_b = (bparts + kRedChunk - 1) / kRedChunk;        // == nchunks
-    float* mid = part_b + (size_t)grid * (layer == 1 ? 4 : 1) * Cout;
-    float* mid_b = mid + (size_t)((grid * (layer == 1 ? 4 : 1) + kRedChunk - 1) / kRedChunk) * total_w;
     hipLaunchKernelGGL(conv_wgrad_reduce1, dim3((total_w + 255) / 256 + 1, nchunks), dim3(256), 0, s, part_w, wparts, total_w, mid,
-                       part_b, bparts, Cout, mid_b);
+                       part_b, wparts, Cout, mid_b);
     rc = check_launch("conv_wgrad_reduce1");
     if (rc) return rc;
-    hipLaunchKernelGGL(conv_wgrad_reduce2, dim3((total_w + 255) / 256), dim3(256), 0, s, mid, nchunks, mid_b, nchunks_b, Cout, Cin,
+    hipLaunchKernelGGL(conv_wgrad_reduce2, dim3((total_w + 255) / 256), dim3(256), 0, s, mid, nchunks, mid_b, nchunks, Cout, Cin,
                        KH, KH, layer == 1 ? kInv255 : 1.0f, dW, db);
     return check_launch("conv_wgrad_reduce2");
 }

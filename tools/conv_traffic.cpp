@@ -1,0 +1,132 @@
+// Torch-free driver of the conv entry points for HBM-traffic PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE).
+//
+//   hipcc --offload-arch=gfx950 -O2 -Iinclude tools/conv_traffic.cpp -o tools/conv_traffic \
+//         -Lcleanrl_amd/csrc -lmi355ppo -Wl,-rpath,'$ORIGIN/../cleanrl_amd/csrc'
+//   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -o fetch -- tools/conv_traffic [images] [reps] [dump.bin]
+// Also prints the mean duration of every entry point (HIP events on the launch stream, one JSON line) and, with a third
+// argument, dumps dW/db of the three layers and strided samples of the activations / gradients to a file, so that two
+// builds or two tuning-switch settings can be compared with `cmp` (address-only changes must stay bit-identical).
+//
+// Launches, at the minibatch size of config C (32,768 images gathered from a 131,072-row uint8 rollout buffer), the
+// eight conv kernels of one minibatch update in their order of use, `reps` times each, preceded by calibration
+// copies of known byte counts (1 GiB read + 1 GiB written, 16 B and 4 B per lane; sized past the 256 MiB Infinity
+// Cache) -- MI355X_MICROARCH.md asks for FETCH_SIZE / WRITE_SIZE to be calibrated per access width on gfx950.
+// Starts in about a second (no Python, no torch), so a whole pass costs a few seconds of GPU-box time.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include "mi355ppo.h"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); std::exit(2); } } while (0)
+#define ABI(x) do { int rc_ = (x); if (rc_) { std::fprintf(stderr, "%s:%d rc=%d %s\n", __FILE__, __LINE__, rc_, mi355ppo_last_error()); std::exit(3); } } while (0)
+
+__global__ void calib_copy_b128(const uint4* __restrict__ s, uint4* __restrict__ d, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+__global__ void calib_copy_b32(const uint32_t* __restrict__ s, uint32_t* __restrict__ d, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+__global__ void fill_f32(float* p, size_t n, uint32_t salt) {      // signed pseudo-random values in (-1, 1), ~half positive
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u + salt; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (float)(int32_t)h * (1.0f / 2147483648.0f);
+    }
+}
+__global__ void fill_u8(uint32_t* p, size_t n, uint32_t salt) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u + salt; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = h;
+    }
+}
+__global__ void fill_inds(int64_t* p, int64_t n, int64_t rows) {    // a slice of a permutation of the rollout rows
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (i * 40503 + 17) % rows;
+}
+
+template <class T> static T* dalloc(size_t n) { void* p; CHECK(hipMalloc(&p, n * sizeof(T))); return (T*)p; }
+
+int main(int argc, char** argv) {
+    const int64_t M = argc > 1 ? atoll(argv[1]) : 32768;
+    const int reps = argc > 2 ? atoi(argv[2]) : 3;
+    const int64_t rows = 4 * M;                                     // T*N = 131,072 at config C
+    const size_t obs_b = (size_t)rows * 28224, a1n = (size_t)M * 20 * 20 * 32, a2n = (size_t)M * 81 * 64, a3n = (size_t)M * 49 * 64;
+    hipStream_t st; CHECK(hipStreamCreate(&st));
+    uint8_t* obs = dalloc<uint8_t>(obs_b);
+    int64_t* inds = dalloc<int64_t>(M);
+    float *a1 = dalloc<float>(a1n), *a2 = dalloc<float>(a2n), *a3 = dalloc<float>(a3n);
+    float *dz1 = dalloc<float>(a1n), *dz2 = dalloc<float>(a2n), *dz3 = dalloc<float>(a3n);
+    float *W1 = dalloc<float>(8192), *W2 = dalloc<float>(32768), *W3 = dalloc<float>(36864);
+    float *bt1 = dalloc<float>(8192), *bt2 = dalloc<float>(32768), *bt3 = dalloc<float>(36864);
+    float *bt2d = dalloc<float>(32768), *bt3d = dalloc<float>(36864), *bt3c = dalloc<float>(81 * 4096);
+    float *bias = dalloc<float>(64), *dW = dalloc<float>(36864), *db = dalloc<float>(64);
+    size_t wsb = 0;
+    for (int l = 1; l <= 3; l++) { size_t b = mi355ppo_cnn_conv_wgrad_workspace_bytes(M, l); if (b > wsb) wsb = b; }
+    void* ws; CHECK(hipMalloc(&ws, wsb));
+    const size_t cal_b = (size_t)1 << 30;
+    uint4 *c0 = dalloc<uint4>(cal_b / 16), *c1 = dalloc<uint4>(cal_b / 16);
+
+    fill_u8<<<4096, 256, 0, st>>>((uint32_t*)obs, obs_b / 4, 1u);
+    fill_inds<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(inds, M, rows);
+    fill_f32<<<4096, 256, 0, st>>>(dz1, a1n, 2u); fill_f32<<<4096, 256, 0, st>>>(dz2, a2n, 3u); fill_f32<<<4096, 256, 0, st>>>(dz3, a3n, 4u);
+    fill_f32<<<32, 256, 0, st>>>(W1, 8192, 5u); fill_f32<<<128, 256, 0, st>>>(W2, 32768, 6u); fill_f32<<<144, 256, 0, st>>>(W3, 36864, 7u);
+    fill_f32<<<1, 64, 0, st>>>(bias, 64, 8u);
+    fill_u8<<<4096, 256, 0, st>>>((uint32_t*)c0, cal_b / 4, 9u);
+    ABI(mi355ppo_cnn_repack_weights_f32(W1, bt1, 1, 0, st)); ABI(mi355ppo_cnn_repack_weights_f32(W2, bt2, 2, 0, st));
+    ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3, 3, 0, st)); ABI(mi355ppo_cnn_repack_weights_f32(W2, bt2d, 2, 2, st));
+    ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3d, 3, 1, st)); ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3c, 3, 3, st));
+    CHECK(hipStreamSynchronize(st));
+
+    if (getenv("CONV_TRAFFIC_CALIB"))
+        for (int r = 0; r < reps; r++) {
+            calib_copy_b128<<<8192, 256, 0, st>>>(c0, c1, cal_b / 16);
+            calib_copy_b32<<<8192, 256, 0, st>>>((const uint32_t*)c0, (uint32_t*)c1, cal_b / 4);
+        }
+    hipEvent_t ev[9][2];
+    float tot[8] = {0};
+    for (auto& e : ev) { CHECK(hipEventCreate(&e[0])); CHECK(hipEventCreate(&e[1])); }
+    float *dW1 = dalloc<float>(8192), *dW2 = dalloc<float>(32768), *dW3 = dalloc<float>(36864), *db1 = dalloc<float>(64), *db2 = dalloc<float>(64), *db3 = dalloc<float>(64);
+#define TIMED(i, call) do { CHECK(hipEventRecord(ev[i][0], st)); ABI(call); CHECK(hipEventRecord(ev[i][1], st)); } while (0)
+    for (int r = 0; r < reps; r++) {                                // one minibatch update's conv launches, in order
+        TIMED(0, mi355ppo_cnn_conv_fwd_f32(obs, inds, bt1, bias, a1, M, 1, st));
+        TIMED(1, mi355ppo_cnn_conv_fwd_f32(a1, nullptr, bt2, bias, a2, M, 2, st));
+        TIMED(2, mi355ppo_cnn_conv_fwd_f32(a2, nullptr, bt3, bias, a3, M, 3, st));
+        TIMED(3, mi355ppo_cnn_conv_wgrad_f32(a2, nullptr, dz3, dW3, db3, M, 3, ws, wsb, st));
+        TIMED(4, mi355ppo_cnn_conv_dgrad_f32_variant(dz3, bt3c, a2, dz2, M, 3, 5, st));
+        TIMED(5, mi355ppo_cnn_conv_wgrad_f32(a1, nullptr, dz2, dW2, db2, M, 2, ws, wsb, st));
+        TIMED(6, mi355ppo_cnn_conv_dgrad_f32(dz2, bt2d, a1, dz1, M, 2, st));
+        TIMED(7, mi355ppo_cnn_conv_wgrad_f32(obs, inds, dz1, dW1, db1, M, 1, ws, wsb, st));
+        CHECK(hipStreamSynchronize(st));
+        if (r > 0 || reps == 1)
+            for (int i = 0; i < 8; i++) { float ms; CHECK(hipEventElapsedTime(&ms, ev[i][0], ev[i][1])); tot[i] += ms; }
+        if (r + 1 < reps) {   // the gradients the next repetition starts from stay a bounded signal
+            fill_f32<<<4096, 256, 0, st>>>(dz1, a1n, 2u); fill_f32<<<4096, 256, 0, st>>>(dz2, a2n, 3u);
+        }
+    }
+    CHECK(hipStreamSynchronize(st));
+    {
+        const char* nm[8] = {"fwd1", "fwd2", "fwd3", "wgrad3", "dgrad3", "wgrad2", "dgrad2", "wgrad1"};
+        const int nt = reps > 1 ? reps - 1 : 1;
+        float sum = 0;
+        std::printf("{\"images\": %lld, \"timed_reps\": %d", (long long)M, nt);
+        for (int i = 0; i < 8; i++) { std::printf(", \"%s_us\": %.1f", nm[i], tot[i] / nt * 1e3f); sum += tot[i] / nt; }
+        std::printf(", \"sum_ms\": %.3f}\n", sum);
+    }
+    if (argc > 3) {
+        FILE* f = std::fopen(argv[3], "wb");
+        if (!f) { std::perror(argv[3]); return 4; }
+        auto dump = [&](const float* d, size_t n, size_t stride) {
+            const size_t cnt = (n + stride - 1) / stride;
+            float* hbuf = (float*)std::malloc(cnt * 4);
+            CHECK(hipMemcpy2D(hbuf, 4, d, stride * 4, 4, cnt, hipMemcpyDeviceToHost));
+            std::fwrite(hbuf, 4, cnt, f); std::free(hbuf);
+        };
+        dump(dW1, 8192, 1); dump(db1, 32, 1); dump(dW2, 32768, 1); dump(db2, 64, 1); dump(dW3, 36864, 1); dump(db3, 64, 1);
+        dump(a1, a1n, 4099); dump(a2, a2n, 1031); dump(a3, a3n, 1031); dump(dz2, a2n, 1031); dump(dz1, a1n, 4099);
+        std::fclose(f);
+    }
+    dW = dW1;
+    float h[4]; CHECK(hipMemcpy(h, dW, sizeof h, hipMemcpyDeviceToHost));
+    std::printf("conv_traffic: images=%lld reps=%d dW1[0..3]=%g %g %g %g\n", (long long)M, reps, h[0], h[1], h[2], h[3]);
+    return 0;
+}
