@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
 
     fill_u8<<<4096, 256, 0, st>>>((uint32_t*)obs, obs_b / 4, 1u);
     fill_inds<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(inds, M, rows);
+    if (getenv("CONV_TRAFFIC_NOINDS")) inds = nullptr;              // layer 1 then reads rows 0 .. M-1 in order
     fill_f32<<<4096, 256, 0, st>>>(dz1, a1n, 2u); fill_f32<<<4096, 256, 0, st>>>(dz2, a2n, 3u); fill_f32<<<4096, 256, 0, st>>>(dz3, a3n, 4u);
     fill_f32<<<32, 256, 0, st>>>(W1, 8192, 5u); fill_f32<<<128, 256, 0, st>>>(W2, 32768, 6u); fill_f32<<<144, 256, 0, st>>>(W3, 36864, 7u);
     fill_f32<<<1, 64, 0, st>>>(bias, 64, 8u);
