@@ -646,22 +646,47 @@ __global__ __launch_bounds__(64 * NW) void conv_fixed_kernel(const void* __restr
                     myoff = ((img * (unsigned)G::DH + gy * (unsigned)G::DM + (unsigned)day) * (unsigned)G::DW + gx * (unsigned)G::DM + (unsigned)dax) * (unsigned)(G::DC * 4);
                 }
             }
+            // CLS4: channel tile jt is parity class (jt>>1, jt&1) of the stride-2 data gradient -> its own pixel
+            auto noff_of = [](int jt) { return CLS4 ? ((jt >> 1) * G::DW + (jt & 1)) * G::DC * 4 : jt * 128; };
+            if constexpr (EPI == EPI_MASK) {
+                // The ReLU-mask values are loaded in batches of 8 accumulator rows BEFORE the stores of the batch: written
+                // as load -> select -> store per element, every load sits behind a store that may alias it as far as
+                // hipcc can tell, so it emits 16 * NJT dependent load / s_waitcnt vmcnt(0) / store round trips per tile --
+                // a third of the time of the short-K border classes of the layer-3 data gradient.
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const unsigned off = (unsigned)__shfl((int)myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64) + (unsigned)(li * 4);
+                for (int e0 = 0; e0 < 16; e0 += 8) {
+                    unsigned off[8], mk[8][NJT];
 #pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) {
-                    // CLS4: channel tile jt is parity class (jt>>1, jt&1) of the stride-2 data gradient -> its own pixel
-                    const int noff = CLS4 ? ((jt >> 1) * G::DW + (jt & 1)) * G::DC * 4 : jt * 128;
-                    float v = acc[m][jt][e];
-                    if (EPI == EPI_BIAS_RELU) {
-                        v = v + bias_r[jt];
-                        v = v > 0.0f ? v : 0.0f;
-                    } else if (EPI == EPI_MASK) {
-                        const unsigned mk = __builtin_amdgcn_raw_buffer_load_b32(rsrc_msk, off, noff, 0);   // 0 when out of range
-                        v = __uint_as_float(mk) > 0.0f ? v : 0.0f;
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = e0 + u;
+                        off[u] = (unsigned)__shfl((int)myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64) + (unsigned)(li * 4);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_dst, off, noff, 0);   // dropped when out of range
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int jt = 0; jt < NJT; ++jt)
+                            mk[u][jt] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_msk, off[u], noff_of(jt), 0);   // 0 when out of range
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int jt = 0; jt < NJT; ++jt) {
+                            const float v = __uint_as_float(mk[u][jt]) > 0.0f ? acc[m][jt][e0 + u] : 0.0f;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_dst, off[u], noff_of(jt), 0);   // dropped when out of range
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned off = (unsigned)__shfl((int)myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64) + (unsigned)(li * 4);
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt) {
+                        float v = acc[m][jt][e];
+                        if (EPI == EPI_BIAS_RELU) {
+                            v = v + bias_r[jt];
+                            v = v > 0.0f ? v : 0.0f;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_dst, off, noff_of(jt), 0);   // dropped when out of range
+                    }
                 }
             }
         }
