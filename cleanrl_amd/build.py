@@ -58,5 +58,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_tools(verbose: bool = True) -> str:
+    """The torch-free conv driver (tools/conv_traffic.cpp: timing, dump comparison and PMC passes over the C ABI;
+    contains its own small HIP kernels).  Links against the in-tree library through $ORIGIN-relative rpath."""
+    root = os.path.dirname(os.path.dirname(CSRC))
+    src = os.path.join(root, "tools", "conv_traffic.cpp")
+    exe = os.path.join(root, "tools", "conv_traffic")
+    if _stale(exe, [src, LIB, os.path.join(root, "include", "mi355ppo.h")]):
+        _run([HIPCC, "--offload-arch=gfx950", "-O2", "-I" + os.path.join(root, "include"), src, "-o", exe, "-L" + CSRC,
+              "-lmi355ppo", "-Wl,-rpath,$ORIGIN/../cleanrl_amd/csrc"])
+        if verbose:
+            print(f"[cleanrl_amd.build] built {exe}", file=sys.stderr)
+    return exe
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_tools()

@@ -126,3 +126,17 @@ def test_weight_matrix_cache_invalidation_logic(monkeypatch):
     assert b.weights(W, 1, 0).item() == 6.0
     W2 = W.clone()                                           # different storage
     assert b.weights(W2, 1, 0).item() == 7.0
+
+
+def test_torch_free_conv_driver_builds_and_links_the_in_tree_library():
+    """tools/conv_traffic (C++ over the C ABI only: timing / dump comparison / PMC passes on a GPU box in seconds) compiles
+    for gfx950 and resolves libmi355ppo.so through its $ORIGIN-relative rpath."""
+    import subprocess
+
+    from cleanrl_amd import build as b
+
+    _lib.load()
+    exe = b.build_tools(verbose=False)
+    assert os.access(exe, os.X_OK)
+    dyn = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
+    assert "libmi355ppo.so" in dyn and "$ORIGIN/../cleanrl_amd/csrc" in dyn
