@@ -208,3 +208,78 @@ class ContinuousAgent(nn.Module):
         if action is None:
             action = probs.sample()
         return action, probs.log_prob(action).sum(1), probs.entropy().sum(1), value
+
+
+class AtariLSTMAgent(_DiscreteMixin, nn.Module):
+    """ppo_atari_lstm.py:117-165: NatureCNN on ONE 84x84 frame -> Linear(3136,512) -> LSTM(512,128) -> actor / critic.
+    Same construction order as the reference (network layers, ``nn.LSTM`` default init, then bias := 0 and orthogonal
+    weights in ``named_parameters`` order, then actor, critic), hence the same weights for the same torch seed.
+    The recurrent state is reset where ``done`` is 1, one time step at a time, exactly as ``get_states`` (:138-156)."""
+
+    obs_is_image = True
+    recurrent = True
+
+    def __init__(self, envs):
+        super().__init__()
+        self.network = nn.Sequential(
+            layer_init(nn.Conv2d(1, 32, 8, stride=4)),
+            nn.ReLU(),
+            layer_init(nn.Conv2d(32, 64, 4, stride=2)),
+            nn.ReLU(),
+            layer_init(nn.Conv2d(64, 64, 3, stride=1)),
+            nn.ReLU(),
+            nn.Flatten(),
+            layer_init(nn.Linear(64 * 7 * 7, 512)),
+            nn.ReLU(),
+        )
+        self.lstm = nn.LSTM(512, 128)
+        for name, param in self.lstm.named_parameters():
+            if "bias" in name:
+                nn.init.constant_(param, 0)
+            elif "weight" in name:
+                nn.init.orthogonal_(param, 1.0)
+        self.actor = layer_init(nn.Linear(128, envs.single_action_space.n), std=0.01)
+        self.critic = layer_init(nn.Linear(128, 1), std=1)
+        self.n_actions = envs.single_action_space.n
+        self.rng = _SampleCounter()
+
+    def _normalise(self, x):
+        if x.dtype == torch.uint8:
+            return ops.obs_u8_to_f32(x.contiguous()) if x.is_cuda else x.float() / 255.0
+        return x / 255.0
+
+    def initial_state(self, num_envs: int, device):
+        """(:225-228) zero hidden and cell state, (num_layers, N, hidden)."""
+        shape = (self.lstm.num_layers, num_envs, self.lstm.hidden_size)
+        return torch.zeros(shape, device=device), torch.zeros(shape, device=device)
+
+    def states_from_features(self, hidden, lstm_state, done):
+        """The LSTM logic of ``get_states`` (:141-156) on the (T*B, 512) features of T time-major steps of B envs."""
+        batch_size = lstm_state[0].shape[1]
+        hidden = hidden.reshape((-1, batch_size, self.lstm.input_size))
+        done = done.reshape((-1, batch_size))
+        new_hidden = []
+        for h, d in zip(hidden, done):
+            keep = (1.0 - d).view(1, -1, 1)
+            h, lstm_state = self.lstm(h.unsqueeze(0), (keep * lstm_state[0], keep * lstm_state[1]))
+            new_hidden += [h]
+        return torch.flatten(torch.cat(new_hidden), 0, 1), lstm_state
+
+    def heads_seq(self, xn, lstm_state, done):
+        """xn: already-normalised f32 frames, time-major (T*B, 1, 84, 84) -> (logits, value, new state): the seam the
+        learner's update uses (the fused loss kernel consumes logits / value; autograd runs through this function)."""
+        hidden, lstm_state = self.states_from_features(self.network(xn), lstm_state, done)
+        return self.actor(hidden), self.critic(hidden), lstm_state
+
+    def get_states(self, x, lstm_state, done):
+        return self.states_from_features(self.network(self._normalise(x)), lstm_state, done)
+
+    def get_value(self, x, lstm_state, done):
+        hidden, _ = self.get_states(x, lstm_state, done)
+        return self.critic(hidden)
+
+    def get_action_and_value(self, x, lstm_state, done, action=None):
+        hidden, lstm_state = self.get_states(x, lstm_state, done)
+        logits = self.actor(hidden)
+        action, lp, ent = self._dist(logits, action)
+        return action, lp, ent, self.critic(hidden), lstm_state

@@ -139,16 +139,16 @@ class SyntheticAtariVecEnv:
     """
 
     def __init__(self, num_envs: int, seed: int = 0, n_actions: int = 4, pool_planes: int = 2048, api: str = "gymnasium",
-                 done_p: float = 1.0 / 200.0):
+                 done_p: float = 1.0 / 200.0, frames: int = 4):
         self.num_envs, self.api, self.done_p = num_envs, api, done_p
-        self.single_observation_space = Box(0, 255, (4, 84, 84), np.uint8)
+        self.single_observation_space = Box(0, 255, (frames, 84, 84), np.uint8)      # frames = 1: FrameStack(1) of ppo_atari_lstm.py:105
         self.single_action_space = Discrete(n_actions)
         self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
         self.rng = np.random.RandomState(seed)
         self.planes = np.random.RandomState(seed + 12345).randint(0, 256, size=(pool_planes, 84, 84), dtype=np.uint8)
         self.cursor = np.zeros(num_envs, np.int64)
         self.stats = _EpisodeStats(num_envs)
-        self._win = np.arange(4)[None, :]
+        self._win = np.arange(frames)[None, :]
 
     def _obs(self, out=None):
         idx = (self.cursor[:, None] + self._win) % len(self.planes)

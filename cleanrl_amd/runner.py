@@ -87,11 +87,11 @@ def open_writer(args, run_name: str, enabled: bool = True):
 
 
 def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: int = 1, env_api: str = "gymnasium",
-          local_num_envs=None, verbose_rank_line: bool = False):
+          local_num_envs=None, verbose_rank_line: bool = False, learner_cls=PPOLearner):
     """The hot loop of every PPO script (ppo.py:178-309).  Returns the learner (for tests / evaluation)."""
     local_num_envs = local_num_envs or args.num_envs
-    learner = PPOLearner(agent, args, envs.single_observation_space, envs.single_action_space, local_num_envs, device,
-                         world_size=world_size, sample_seed=args.seed)
+    learner = learner_cls(agent, args, envs.single_observation_space, envs.single_action_space, local_num_envs, device,
+                          world_size=world_size, sample_seed=args.seed)
     global_step = 0
     start_time = time.time()
     if env_api == "gym":                                        # envpool: reset() returns obs only (:214)

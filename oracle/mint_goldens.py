@@ -335,6 +335,70 @@ def mint_update_step():
     _save("update_step", cases)
 
 
+# --------------------------------------------------------------- recurrent script: rollout -> GAE -> env-wise update
+def mint_lstm_iteration():
+    """One whole iteration of ppo_atari_lstm.py on synthetic inputs: the reference Agent's own action logic fills the
+    rollout (T=8, N=4), then its GAE lines (:266-283) and its flatten + env-wise minibatch update lines (:285-356) are
+    executed verbatim (2 minibatches x 2 epochs)."""
+    import textwrap
+    from types import SimpleNamespace
+
+    import torch.nn as nn
+
+    script = "ppo_atari_lstm.py"
+    lines = R._read(script)
+    T, N, A = 8, 4, 4
+    torch.manual_seed(7)
+    Agent, _ = R.load_agent_class(script)
+    envs = R.fake_envs((1, 84, 84), n_actions=A)
+    agent = Agent(envs)
+    args = R.make_args(num_steps=T, num_envs=N, num_minibatches=2, update_epochs=2, batch_size=T * N)
+    optimizer = R.make_optimizer(agent, 2.5e-4)
+    init = _flat(agent.parameters()).clone()
+    g = torch.Generator().manual_seed(41)
+    frames = torch.randint(0, 256, (T + 1, N, 1, 84, 84), generator=g, dtype=torch.uint8)
+    step_done = (torch.rand(T + 1, N, generator=g) < 0.25).float()
+    step_done[0] = 0.0
+    rewards = torch.randint(-1, 2, (T, N), generator=g).float()
+    obs = torch.zeros((T, N, 1, 84, 84))
+    actions, logprobs, dones, values = (torch.zeros((T, N)) for _ in range(4))
+    next_lstm_state = (torch.zeros(agent.lstm.num_layers, N, agent.lstm.hidden_size),
+                       torch.zeros(agent.lstm.num_layers, N, agent.lstm.hidden_size))
+    initial_lstm_state = (next_lstm_state[0].clone(), next_lstm_state[1].clone())
+    torch.manual_seed(11)                                     # the sampler's stream (Categorical.sample)
+    for step in range(T):                                      # :240-249, the env replaced by the synthetic stream
+        next_obs, next_done = frames[step].float(), step_done[step]
+        obs[step], dones[step] = next_obs, next_done
+        with torch.no_grad():
+            action, logprob, _, value, next_lstm_state = agent.get_action_and_value(next_obs, next_lstm_state, next_done)
+            values[step] = value.flatten()
+        actions[step], logprobs[step] = action, logprob
+    next_obs, next_done = frames[T].float(), step_done[T]
+    device = torch.device("cpu")
+    ns = dict(args=args, agent=agent, optimizer=optimizer, envs=envs, obs=obs, actions=actions, logprobs=logprobs,
+              rewards=rewards, dones=dones, values=values, next_obs=next_obs, next_done=next_done,
+              next_lstm_state=next_lstm_state, initial_lstm_state=initial_lstm_state, device=device, np=np, torch=torch, nn=nn)
+    g0 = R._find(lines, "# bootstrap value if not done") + 1
+    g1 = R._find(lines, "returns = advantages + values", g0)
+    exec(textwrap.dedent("\n".join(lines[g0:g1 + 1])), ns)              # :266-283
+    u0 = R._find(lines, "# flatten the batch", g1) + 1
+    u1 = R._find(lines, "y_pred, y_true = b_values.cpu().numpy()", u0)
+    np.random.seed(5)                                                   # the env-index shuffle (:302)
+    exec(textwrap.dedent("\n".join(lines[u0:u1])), ns)                  # :285-356
+    final = _flat(agent.parameters())
+    sub = slice(0, None, 97)
+    cases = {"lstm_T8_N4": dict(
+        frames_u8=frames, step_done=step_done, rewards=rewards, actions=actions, logprobs=logprobs, values=values,
+        next_h=next_lstm_state[0], next_c=next_lstm_state[1], advantages=ns["advantages"], returns=ns["returns"],
+        init_params_sub=init[sub], final_params_sub=final[sub], stride=np.int64(97),
+        init_checksum=np.float64(init.double().sum().item()), final_checksum=np.float64(final.double().sum().item()),
+        last_loss=ns["loss"].detach(), last_pg_loss=ns["pg_loss"].detach(), last_v_loss=ns["v_loss"].detach(),
+        last_entropy=ns["entropy_loss"].detach(), last_approx_kl=ns["approx_kl"], clipfracs=np.array(ns["clipfracs"], np.float32),
+        init_seed=np.int64(7), sample_seed=np.int64(11), shuffle_seed=np.int64(5), lr=np.float64(2.5e-4),
+        lines=np.array([g0 + 1, g1 + 1, u0 + 1, u1], np.int64))}
+    _save("lstm_iteration", cases)
+
+
 def main():
     assert R.available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -346,6 +410,7 @@ def main():
     mint_loss_categorical()
     mint_loss_normal()
     mint_update_step()
+    mint_lstm_iteration()
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/cleanrl"
-SCRIPTS = ["ppo", "ppo_atari", "ppo_atari_envpool", "ppo_atari_multigpu", "ppo_continuous_action"]
+SCRIPTS = ["ppo", "ppo_atari", "ppo_atari_envpool", "ppo_atari_multigpu", "ppo_continuous_action", "ppo_atari_lstm"]
 
 # the reference's flag surface (cleanrl/<script>.py Args), recorded so that this test also runs where
 # /root/reference is absent; test_recorded_surface_matches_reference re-derives it when it is present
@@ -27,6 +27,7 @@ REF_DEFAULTS = {
 REF_DEFAULTS["ppo_atari"] = dict(REF_DEFAULTS["ppo"], env_id="BreakoutNoFrameskip-v4", total_timesteps=10000000,
                                  num_envs=8, clip_coef=0.1)
 REF_DEFAULTS["ppo_atari_envpool"] = dict(REF_DEFAULTS["ppo_atari"], env_id="Breakout-v5")
+REF_DEFAULTS["ppo_atari_lstm"] = dict(REF_DEFAULTS["ppo_atari"])
 REF_DEFAULTS["ppo_atari_multigpu"] = dict(REF_DEFAULTS["ppo_atari"], num_envs=0, local_num_envs=8, device_ids=[],
                                           backend="gloo", local_batch_size=0, local_minibatch_size=0, world_size=0)
 REF_DEFAULTS["ppo_continuous_action"] = dict(REF_DEFAULTS["ppo"], save_model=False, upload_model=False, hf_entity="",
