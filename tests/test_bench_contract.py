@@ -1,0 +1,37 @@
+"""bench.py pieces that do not need a GPU: defaults of the driver contract, the committed HBM-traffic table the
+``roofline.traffic`` field is read from, and the refusal to run without a GPU (no silent CPU fallback)."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_defaults_and_traffic_lookup(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    cli = bench.parse()
+    assert (cli.gpus, cli.steps, cli.warmup, cli.local_num_envs, cli.num_steps, cli.n_actions) == (1, 5, 2, 1024, 128, 4)
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    keys = {f"conv{l}_{k}@32768" for l in (1, 2, 3) for k in ("fwd", "wgrad")} | {"conv2_dgrad@32768", "conv3_dgrad@32768"}
+    assert keys <= set(t["hbm_bytes_per_launch"])
+    for k in keys:
+        got = bench._traffic_of(k)
+        alg = t["algorithmic_bytes"][k]
+        assert got == t["hbm_bytes_per_launch"][k] and alg <= got < 2.0 * alg, (k, got, alg)    # never below the algorithmic bytes
+    assert bench._traffic_of("trunk_fwd(conv1+2+3)@1024") is None
+    assert bench.MFMA_F32_PEAK_TFLOPS == 157.3 and bench.HBM_PEAK_GBPS == 8000.0
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "needs a GPU" in out.stderr
+    assert "{" not in out.stdout                                                              # no JSON line from a CPU run
