@@ -283,3 +283,95 @@ class AtariLSTMAgent(_DiscreteMixin, nn.Module):
         logits = self.actor(hidden)
         action, lp, ent = self._dist(logits, action)
         return action, lp, ent, self.critic(hidden), lstm_state
+
+
+class ResidualBlock(nn.Module):
+    """ppo_procgen.py:86-98 (IMPALA-CNN residual block): x + conv1(relu(conv0(relu(x))))."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv0 = nn.Conv2d(in_channels=channels, out_channels=channels, kernel_size=3, padding=1)
+        self.conv1 = nn.Conv2d(in_channels=channels, out_channels=channels, kernel_size=3, padding=1)
+
+    def forward(self, x):
+        inputs = x
+        x = nn.functional.relu(x)
+        x = self.conv0(x)
+        x = nn.functional.relu(x)
+        x = self.conv1(x)
+        return x + inputs
+
+
+class ConvSequence(nn.Module):
+    """ppo_procgen.py:101-124: conv3x3 -> max_pool(3, stride 2, pad 1) -> two residual blocks."""
+
+    def __init__(self, input_shape, out_channels):
+        super().__init__()
+        self._input_shape = input_shape
+        self._out_channels = out_channels
+        self.conv = nn.Conv2d(in_channels=self._input_shape[0], out_channels=self._out_channels, kernel_size=3, padding=1)
+        self.res_block0 = ResidualBlock(self._out_channels)
+        self.res_block1 = ResidualBlock(self._out_channels)
+
+    def forward(self, x):
+        x = self.conv(x)
+        x = nn.functional.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        x = self.res_block0(x)
+        x = self.res_block1(x)
+        assert x.shape[1:] == self.get_output_shape()
+        return x
+
+    def get_output_shape(self):
+        _c, h, w = self._input_shape
+        return (self._out_channels, (h + 1) // 2, (w + 1) // 2)
+
+
+class ProcgenAgent(_DiscreteMixin, nn.Module):
+    """ppo_procgen.py:127-158: IMPALA-CNN [16, 32, 32] on (64, 64, 3) frames that arrive pixel-interleaved ("bhwc") --
+    which is how the rollout buffer stores images anyway, so no relayout kernel runs for this script.  The conv layers
+    keep torch's default initialisation, as in the reference (only actor / critic use ``layer_init``)."""
+
+    obs_is_image = True
+    obs_layout = "hwc"
+
+    def __init__(self, envs):
+        super().__init__()
+        h, w, c = envs.single_observation_space.shape
+        shape = (c, h, w)
+        conv_seqs = []
+        for out_channels in [16, 32, 32]:
+            conv_seq = ConvSequence(shape, out_channels)
+            shape = conv_seq.get_output_shape()
+            conv_seqs.append(conv_seq)
+        conv_seqs += [
+            nn.Flatten(),
+            nn.ReLU(),
+            nn.Linear(in_features=shape[0] * shape[1] * shape[2], out_features=256),
+            nn.ReLU(),
+        ]
+        self.network = nn.Sequential(*conv_seqs)
+        self.actor = layer_init(nn.Linear(256, envs.single_action_space.n), std=0.01)
+        self.critic = layer_init(nn.Linear(256, 1), std=1)
+        self.n_actions = envs.single_action_space.n
+        self.rng = _SampleCounter()
+
+    def _normalise(self, x):
+        """(B, H, W, C) frames -> normalised (B, C, H, W) view ("bhwc" -> "bchw", :147,150)."""
+        if x.dtype == torch.uint8:
+            x = ops.obs_u8_to_f32(x.contiguous()) if x.is_cuda else x.float() / 255.0
+        else:
+            x = x / 255.0
+        return x.permute((0, 3, 1, 2))
+
+    def heads(self, xn):
+        """xn: normalised f32 frames as (B, C, H, W) (any strides) -> (logits, value)."""
+        hidden = self.network(xn)
+        return self.actor(hidden), self.critic(hidden)
+
+    def get_value(self, x):
+        return self.critic(self.network(self._normalise(x)))
+
+    def get_action_and_value(self, x, action=None):
+        logits, value = self.heads(self._normalise(x))
+        action, lp, ent = self._dist(logits, action)
+        return action, lp, ent, value

@@ -347,3 +347,61 @@ class NormalizeVecEnv:
 
     def close(self):
         self.env.close()
+
+
+class _BatchRunningMeanStd:
+    """Scalar running mean/variance updated with a whole batch per call (Chan et al. parallel update) -- the statistic of
+    gym's ``NormalizeReward`` around a *vector* env (``is_vector_env``), as ppo_procgen.py:197 uses it."""
+
+    def __init__(self):
+        self.mean, self.var, self.count = 0.0, 1.0, 1e-4
+
+    def update(self, x):
+        x = np.asarray(x, np.float64)
+        bm, bv, bc = x.mean(), x.var(), x.size
+        delta = bm - self.mean
+        tot = self.count + bc
+        m2 = self.var * self.count + bv * bc + delta**2 * self.count * bc / tot
+        self.mean, self.var, self.count = self.mean + delta * bc / tot, m2 / tot, tot
+
+
+class SyntheticProcgenVecEnv:
+    """Byte-stream stand-in for ``ProcgenEnv(num_envs, env_name, distribution_mode="easy")`` behind
+    ``TransformObservation(obs["rgb"])`` + ``RecordEpisodeStatistics`` + ``NormalizeReward(gamma)`` + clip(-10, 10)
+    (ppo_procgen.py:189-198): (N, 64, 64, 3) uint8 pixel-interleaved frames, 15 discrete actions, the old gym API
+    (``reset() -> obs``, ``step() -> obs, reward, done, [info per env]``).  Deterministic per seed; actions are ignored."""
+
+    def __init__(self, num_envs: int, seed: int = 0, gamma: float = 0.999, n_actions: int = 15, pool_frames: int = 512,
+                 done_p: float = 1.0 / 150.0):
+        self.num_envs, self.gamma, self.done_p = num_envs, gamma, done_p
+        self.single_observation_space = Box(0, 255, (64, 64, 3), np.uint8)
+        self.single_action_space = Discrete(n_actions)
+        self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
+        self.rng = np.random.RandomState(seed)
+        self.frames = np.random.RandomState(seed + 4321).randint(0, 256, size=(pool_frames, 64, 64, 3), dtype=np.uint8)
+        self.cursor = np.zeros(num_envs, np.int64)
+        self.stats = _EpisodeStats(num_envs)
+        self.ret_rms = _BatchRunningMeanStd()
+        self.ret = np.zeros(num_envs, np.float64)
+
+    def reset(self):
+        self.cursor = self.rng.randint(0, len(self.frames), size=self.num_envs).astype(np.int64)
+        self.stats = _EpisodeStats(self.num_envs)
+        self.ret[:] = 0
+        return self.frames[self.cursor]
+
+    def step(self, action):
+        n = self.num_envs
+        raw = self.rng.choice(np.array([0.0, 1.0, 10.0]), size=n, p=[0.9, 0.09, 0.01])
+        done = self.rng.random_sample(n) < self.done_p
+        self.cursor = np.where(done, self.rng.randint(0, len(self.frames), size=n), (self.cursor + 1) % len(self.frames))
+        r, l = self.stats.update(raw.astype(np.float32), done)
+        info = [{"episode": {"r": r[i], "l": l[i]}} if done[i] else {} for i in range(n)]
+        # NormalizeReward (vector form): returns = returns*gamma*(1-done) + reward; reward / sqrt(var + 1e-8); then clip
+        self.ret = self.ret * self.gamma * (1.0 - done.astype(np.float64)) + raw
+        self.ret_rms.update(self.ret)
+        reward = np.clip(raw / np.sqrt(self.ret_rms.var + 1e-8), -10, 10)
+        return self.frames[self.cursor], reward, done, info
+
+    def close(self):
+        pass

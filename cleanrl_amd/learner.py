@@ -71,11 +71,16 @@ class PPOLearner:
         # behind the K5 gather+convert kernel -- same results within f32 round-off, used for A/B timing.
         self.fused_cnn = (self.nhwc and hasattr(agent, "heads_u8") and tuple(obs_space.shape) == (4, 84, 84)
                           and os.environ.get("MI355PPO_CNN", "mfma") != "miopen")
-        self.frame_shape = self.obs_shape                                   # what the env delivers: (C,H,W)
+        self.frame_shape = self.obs_shape                                   # what the env delivers: (C,H,W) ...
+        # ... unless the agent declares pixel-interleaved frames (procgen's "bhwc", ppo_procgen.py:147): then the frames
+        # already are in the rollout buffer's row layout and no relayout runs
+        self.hwc_frames = self.image and getattr(agent, "obs_layout", "chw") == "hwc"
         if self.nhwc:
-            c, h, w = self.obs_shape
-            self.obs_shape = (h, w, c)                                      # how rollout rows are laid out
+            if not self.hwc_frames:
+                c, h, w = self.obs_shape
+                self.obs_shape = (h, w, c)                                  # how rollout rows are laid out
             os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
+        self.relayout = self.nhwc and not self.hwc_frames
         self.obs = torch.zeros((T, N) + self.obs_shape, dtype=obs_dtype, device=device)
         self.actions = torch.zeros((T, N) + self.act_shape, device=device)
         self.logprobs = torch.zeros((T, N), device=device)
@@ -93,7 +98,7 @@ class PPOLearner:
             self._h2d_evt = torch.cuda.Event()
             self._pin_obs = torch.zeros((N,) + self.frame_shape, dtype=obs_dtype).pin_memory()
             # device staging for incoming channel-planar frames (H2D target / device-env output)
-            self.stage_obs = torch.zeros((N,) + self.frame_shape, dtype=obs_dtype, device=device) if self.nhwc else None
+            self.stage_obs = torch.zeros((N,) + self.frame_shape, dtype=obs_dtype, device=device) if self.relayout else None
             self._pin_rd = torch.zeros((2, N), dtype=torch.float32).pin_memory()
             self._pin_obs_np, self._pin_rd_np = self._pin_obs.numpy(), self._pin_rd.numpy()   # views of the pinned buffers
             self._x_roll = torch.empty((N,) + self.obs_shape, device=device) if (self.image and not self.fused_cnn) else None
@@ -116,7 +121,7 @@ class PPOLearner:
         and are re-laid out to the buffer's (H,W,C) rows by the uint8 relayout kernel."""
         obs_dst, done_dst = self._slot(step)
         if isinstance(next_obs, torch.Tensor):
-            if self.nhwc:
+            if self.relayout:
                 self.ops.obs_nchw_to_nhwc_u8(next_obs, obs_dst)
             elif next_obs.data_ptr() != obs_dst.data_ptr():
                 obs_dst.copy_(next_obs)
@@ -130,13 +135,13 @@ class PPOLearner:
         self._h2d_evt.synchronize()                    # the pinned staging buffers are free again
         np.copyto(self._pin_obs_np, next_obs, casting="unsafe")      # one host memcpy straight into pinned memory
         np.copyto(self._pin_rd_np[0], next_done, casting="unsafe")
-        h2d_dst = self.stage_obs if self.nhwc else obs_dst
+        h2d_dst = self.stage_obs if self.relayout else obs_dst
         with torch.cuda.stream(self._h2d):
             h2d_dst.copy_(self._pin_obs, non_blocking=True)
             done_dst.copy_(self._pin_rd[0], non_blocking=True)
             self._h2d_evt.record(self._h2d)
         torch.cuda.current_stream(self.device).wait_event(self._h2d_evt)
-        if self.nhwc:
+        if self.relayout:
             self.ops.obs_nchw_to_nhwc_u8(self.stage_obs, obs_dst)
 
     def start_iteration(self) -> None:
@@ -318,6 +323,8 @@ class PPOLearner:
         x = b_obs[mb_inds]
         if self.image:
             x = x / 255.0
+            if self.hwc_frames:
+                x = x.permute((0, 3, 1, 2))                       # "bhwc" -> "bchw" (ppo_procgen.py:150)
         p, newvalue = self.agent.heads(x)
         acts = b_actions.long()[mb_inds] if self.discrete else b_actions[mb_inds]
         if self.discrete:

@@ -399,10 +399,46 @@ def mint_lstm_iteration():
     _save("lstm_iteration", cases)
 
 
+# --------------------------------------------------------------- procgen: IMPALA-CNN agent, pixel-interleaved frames
+def mint_procgen_update():
+    """ppo_procgen.py: two consecutive minibatch updates (:259-299 loss + backward + clip_grad_norm_ + Adam) of the
+    reference's IMPALA-CNN Agent on (B, 64, 64, 3) frames, plus its GAE lines on the rollout-shaped tensors."""
+    script = "ppo_procgen.py"
+    torch.manual_seed(9)
+    Agent, _ = R.load_agent_class(script)
+    agent = Agent(R.fake_envs((64, 64, 3), n_actions=15))
+    args = R.make_args(clip_coef=0.2)
+    opt = R.make_optimizer(agent, 5e-4)
+    g = torch.Generator().manual_seed(43)
+    B, M = 48, 16
+    b_obs_u8 = torch.randint(0, 256, (B, 64, 64, 3), generator=g, dtype=torch.uint8)
+    b_obs = b_obs_u8.float()
+    b_actions = torch.randint(0, 15, (B,), generator=g).float()
+    with torch.no_grad():
+        _, lp_all, _, v_all = agent.get_action_and_value(b_obs, b_actions.long())
+    b_logprobs, b_advantages, b_returns, b_values = _behaviour_batch(g, lp_all, v_all.view(-1), B)
+    perm = np.random.RandomState(8).permutation(B)
+    init = _flat(agent.parameters()).clone()
+    sub = slice(0, None, 31)
+    d = dict(init_params_sub=init[sub], stride=np.int64(31), init_checksum=np.float64(init.double().sum().item()),
+             b_obs_u8=b_obs_u8, b_actions=b_actions, b_logprobs=b_logprobs, b_advantages=b_advantages, b_returns=b_returns,
+             b_values=b_values, perm=perm.astype(np.int64), lr=np.float64(5e-4), init_seed=np.int64(9),
+             logprob_all=lp_all, value_all=v_all.view(-1))
+    losses = []
+    for k in range(2):
+        ns = R.run_loss(script, agent, args, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values,
+                        perm[k * M:(k + 1) * M], step=True, optimizer=opt)
+        losses.append(ns["loss"].item())
+        d[f"params_sub_after_{k + 1}"] = _flat(agent.parameters())[sub]
+    d["losses"] = np.array(losses, np.float32)
+    d["final_checksum"] = np.float64(_flat(agent.parameters()).double().sum().item())
+    _save("procgen_update", {"impala_2steps": d})
+
+
 def main():
     assert R.available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
-    for script in ["ppo.py", "ppo_atari.py", "ppo_atari_envpool.py", "ppo_atari_multigpu.py", "ppo_continuous_action.py"]:
+    for script in ["ppo.py", "ppo_atari.py", "ppo_atari_envpool.py", "ppo_atari_multigpu.py", "ppo_continuous_action.py", "ppo_procgen.py"]:
         print(script, R.line_ranges(script))
     mint_gae()
     mint_categorical()
@@ -411,6 +447,7 @@ def main():
     mint_loss_normal()
     mint_update_step()
     mint_lstm_iteration()
+    mint_procgen_update()
 
 
 if __name__ == "__main__":

@@ -75,8 +75,9 @@ def load_agent_class(script: str):
     """Compile ``layer_init`` and ``Agent`` of ``cleanrl/<script>`` verbatim."""
     src = "\n".join(_read(script))
     tree = ast.parse(src)
-    wanted = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in ("layer_init", "Agent")]
-    assert {n.name for n in wanted} == {"layer_init", "Agent"}, script
+    names = ("layer_init", "Agent", "ResidualBlock", "ConvSequence")        # the last two: ppo_procgen.py's IMPALA-CNN blocks
+    wanted = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert {n.name for n in wanted} >= {"layer_init", "Agent"}, script
     ns = {"np": np, "torch": torch, "nn": nn, "Categorical": Categorical, "Normal": Normal}
     exec(compile(ast.Module(body=wanted, type_ignores=[]), f"<reference:{script}>", "exec"), ns)
     return ns["Agent"], ns["layer_init"]

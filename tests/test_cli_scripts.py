@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/cleanrl"
-SCRIPTS = ["ppo", "ppo_atari", "ppo_atari_envpool", "ppo_atari_multigpu", "ppo_continuous_action", "ppo_atari_lstm"]
+SCRIPTS = ["ppo", "ppo_atari", "ppo_atari_envpool", "ppo_atari_multigpu", "ppo_continuous_action", "ppo_atari_lstm", "ppo_procgen"]
 
 # the reference's flag surface (cleanrl/<script>.py Args), recorded so that this test also runs where
 # /root/reference is absent; test_recorded_surface_matches_reference re-derives it when it is present
@@ -28,6 +28,8 @@ REF_DEFAULTS["ppo_atari"] = dict(REF_DEFAULTS["ppo"], env_id="BreakoutNoFrameski
                                  num_envs=8, clip_coef=0.1)
 REF_DEFAULTS["ppo_atari_envpool"] = dict(REF_DEFAULTS["ppo_atari"], env_id="Breakout-v5")
 REF_DEFAULTS["ppo_atari_lstm"] = dict(REF_DEFAULTS["ppo_atari"])
+REF_DEFAULTS["ppo_procgen"] = dict(REF_DEFAULTS["ppo"], env_id="starpilot", total_timesteps=int(25e6), learning_rate=5e-4,
+                                   num_envs=64, num_steps=256, anneal_lr=False, gamma=0.999, num_minibatches=8, update_epochs=3)
 REF_DEFAULTS["ppo_atari_multigpu"] = dict(REF_DEFAULTS["ppo_atari"], num_envs=0, local_num_envs=8, device_ids=[],
                                           backend="gloo", local_batch_size=0, local_minibatch_size=0, world_size=0)
 REF_DEFAULTS["ppo_continuous_action"] = dict(REF_DEFAULTS["ppo"], save_model=False, upload_model=False, hf_entity="",
@@ -63,7 +65,11 @@ def test_recorded_surface_matches_reference(script):
             try:
                 ref[b.target.id] = ast.literal_eval(b.value)
             except ValueError:
-                ref[b.target.id] = []          # field(default_factory=lambda: [])
+                v = b.value
+                if isinstance(v, ast.Call) and getattr(v.func, "id", "") == "int" and len(v.args) == 1:
+                    ref[b.target.id] = int(ast.literal_eval(v.args[0]))      # `int(25e6)` (ppo_procgen.py:40)
+                else:
+                    ref[b.target.id] = []          # field(default_factory=lambda: [])
     assert ref == REF_DEFAULTS[script]
 
 

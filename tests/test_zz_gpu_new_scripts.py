@@ -1,10 +1,10 @@
-"""GPU tests of the recurrent learner (ppo_atari_lstm.py drop-in) on the HIP path, teacher-forced on the rollout the
-reference's own lines produced (tests/golden/lstm_iteration.npz).
+"""GPU tests of the drop-ins added after the round's GPU minutes were spent: the recurrent learner (ppo_atari_lstm.py),
+teacher-forced on the rollout the reference's own lines produced (tests/golden/lstm_iteration.npz), and ppo_procgen.py.
 
-The file sorts last on purpose and its tests are non-strict xfails for this round: the HIP path of
-``LSTMPPOLearner`` was written after the round's GPU minutes were spent (its host path is proven against the reference
-lines in tests/test_lstm_script.py; the kernels it calls -- K1, K2, K3, K5, K6 -- are the ones the other GPU tests cover).
-Drop the marker once a GPU run has confirmed them."""
+The file sorts last on purpose and its tests are non-strict xfails for this round: these HIP paths have not run on a GPU
+yet.  Their host paths are proven against the reference lines (tests/test_lstm_script.py, tests/test_procgen_script.py)
+and the kernels they call -- K1, K2, K3, K5, K6 -- are the ones the other GPU tests cover.  Drop the marker once a GPU run
+has confirmed them."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -18,7 +18,7 @@ from cleanrl_amd.learner_lstm import LSTMPPOLearner
 from cleanrl_amd.learner_smoke import default_args
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="first GPU run of the recurrent learner's HIP path is still outstanding")]
+              pytest.mark.xfail(strict=False, reason="first GPU run of these scripts' HIP paths is still outstanding")]
 DEV = torch.device("cuda:0")
 
 
@@ -78,3 +78,12 @@ def test_ppo_atari_lstm_script_runs_on_gpu():
     L = ppo_atari_lstm.main(["--num-envs", "8", "--num-steps", "16", "--total-timesteps", "256", "--num-minibatches", "4"])
     assert L.hip and L.obs.dtype == torch.uint8 and tuple(L.obs.shape[2:]) == (84, 84, 1)
     assert np.isfinite(L.last_metrics["loss"]) and L.last_metrics["num_updates"] == 16
+
+
+def test_ppo_procgen_script_runs_on_gpu_without_relayout():
+    """ppo_procgen.py drop-in on the HIP path: pixel-interleaved frames go straight into the uint8 rollout rows."""
+    from cleanrl_amd import ppo_procgen
+
+    L = ppo_procgen.main(["--num-envs", "8", "--num-steps", "16", "--total-timesteps", "256", "--num-minibatches", "4"])
+    assert L.hip and L.obs.dtype == torch.uint8 and L.hwc_frames and not L.relayout and L.stage_obs is None
+    assert tuple(L.obs.shape[2:]) == (64, 64, 3) and np.isfinite(L.last_metrics["loss"])
