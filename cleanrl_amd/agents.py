@@ -375,3 +375,100 @@ class ProcgenAgent(_DiscreteMixin, nn.Module):
         logits, value = self.heads(self._normalise(x))
         action, lp, ent = self._dist(logits, action)
         return action, lp, ent, value
+
+
+class RNDAgent(_DiscreteMixin, nn.Module):
+    """ppo_rnd_envpool.py:139-185: NatureCNN -> Linear(3136,256) -> Linear(256,448), a 448-448 "extra" layer feeding two
+    value heads (extrinsic / intrinsic) through a residual sum, and a two-layer actor.  Same construction order as the
+    reference."""
+
+    obs_is_image = True
+    two_value_heads = True
+
+    def __init__(self, envs):
+        super().__init__()
+        self.network = nn.Sequential(
+            layer_init(nn.Conv2d(4, 32, 8, stride=4)),
+            nn.ReLU(),
+            layer_init(nn.Conv2d(32, 64, 4, stride=2)),
+            nn.ReLU(),
+            layer_init(nn.Conv2d(64, 64, 3, stride=1)),
+            nn.ReLU(),
+            nn.Flatten(),
+            layer_init(nn.Linear(64 * 7 * 7, 256)),
+            nn.ReLU(),
+            layer_init(nn.Linear(256, 448)),
+            nn.ReLU(),
+        )
+        self.extra_layer = nn.Sequential(layer_init(nn.Linear(448, 448), std=0.1), nn.ReLU())
+        self.actor = nn.Sequential(
+            layer_init(nn.Linear(448, 448), std=0.01),
+            nn.ReLU(),
+            layer_init(nn.Linear(448, envs.single_action_space.n), std=0.01),
+        )
+        self.critic_ext = layer_init(nn.Linear(448, 1), std=0.01)
+        self.critic_int = layer_init(nn.Linear(448, 1), std=0.01)
+        self.n_actions = envs.single_action_space.n
+        self.rng = _SampleCounter()
+
+    def _normalise(self, x):
+        if x.dtype == torch.uint8:
+            return ops.obs_u8_to_f32(x.contiguous()) if x.is_cuda else x.float() / 255.0
+        return x / 255.0
+
+    def heads3(self, xn):
+        """xn: normalised f32 observations (B,4,84,84) -> (logits, extrinsic value, intrinsic value)."""
+        hidden = self.network(xn)
+        logits = self.actor(hidden)
+        features = self.extra_layer(hidden)
+        return logits, self.critic_ext(features + hidden), self.critic_int(features + hidden)
+
+    def get_action_and_value(self, x, action=None):
+        logits, v_ext, v_int = self.heads3(self._normalise(x))
+        action, lp, ent = self._dist(logits, action)
+        return action, lp, ent, v_ext, v_int
+
+    def get_value(self, x):
+        _, v_ext, v_int = self.heads3(self._normalise(x))
+        return v_ext, v_int
+
+
+class RNDModel(nn.Module):
+    """ppo_rnd_envpool.py:188-233: predictor and frozen random target network on ONE normalised 84x84 frame."""
+
+    def __init__(self, input_size, output_size):
+        super().__init__()
+        self.input_size = input_size
+        self.output_size = output_size
+        feature_output = 7 * 7 * 64
+        self.predictor = nn.Sequential(
+            layer_init(nn.Conv2d(in_channels=1, out_channels=32, kernel_size=8, stride=4)),
+            nn.LeakyReLU(),
+            layer_init(nn.Conv2d(in_channels=32, out_channels=64, kernel_size=4, stride=2)),
+            nn.LeakyReLU(),
+            layer_init(nn.Conv2d(in_channels=64, out_channels=64, kernel_size=3, stride=1)),
+            nn.LeakyReLU(),
+            nn.Flatten(),
+            layer_init(nn.Linear(feature_output, 512)),
+            nn.ReLU(),
+            layer_init(nn.Linear(512, 512)),
+            nn.ReLU(),
+            layer_init(nn.Linear(512, 512)),
+        )
+        self.target = nn.Sequential(
+            layer_init(nn.Conv2d(in_channels=1, out_channels=32, kernel_size=8, stride=4)),
+            nn.LeakyReLU(),
+            layer_init(nn.Conv2d(in_channels=32, out_channels=64, kernel_size=4, stride=2)),
+            nn.LeakyReLU(),
+            layer_init(nn.Conv2d(in_channels=64, out_channels=64, kernel_size=3, stride=1)),
+            nn.LeakyReLU(),
+            nn.Flatten(),
+            layer_init(nn.Linear(feature_output, 512)),
+        )
+        for param in self.target.parameters():          # target network is not trainable
+            param.requires_grad = False
+
+    def forward(self, next_obs):
+        target_feature = self.target(next_obs)
+        predict_feature = self.predictor(next_obs)
+        return predict_feature, target_feature

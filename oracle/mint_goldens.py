@@ -435,6 +435,95 @@ def mint_procgen_update():
     _save("procgen_update", {"impala_2steps": d})
 
 
+# --------------------------------------------------------------- RND: two value streams, intrinsic reward, distillation loss
+def mint_rnd_iteration():
+    """One whole iteration of ppo_rnd_envpool.py on synthetic inputs (T=8, N=4): the reference Agent / RNDModel fill the
+    rollout following :345-371, then its lines from the intrinsic-reward scaling through both GAE streams, the flatten,
+    the observation-statistics update and the minibatch loop (:390-524) are executed verbatim (2 minibatches x 1 epoch).
+    ``RunningMeanStd`` is gym 0.23.1's (pyproject.toml:17), which is not installed: the restatement in
+    cleanrl_amd/learner_rnd.py of its published algorithm stands in; ``RewardForwardFilter`` is the reference's own class."""
+    import ast
+    import textwrap
+
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torch.distributions.categorical import Categorical
+
+    from cleanrl_amd.learner_rnd import RunningMeanStd
+
+    script = "ppo_rnd_envpool.py"
+    lines = R._read(script)
+    tree = ast.parse("\n".join(lines))
+    cls_ns = {"np": np, "torch": torch, "nn": nn, "Categorical": Categorical}
+    want = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef))
+            and n.name in ("layer_init", "Agent", "RNDModel", "RewardForwardFilter")]
+    exec(compile(ast.Module(body=want, type_ignores=[]), f"<reference:{script}>", "exec"), cls_ns)
+    T, N, A = 8, 4, 6
+    envs = R.fake_envs((4, 84, 84), n_actions=A)
+    torch.manual_seed(13)
+    agent = cls_ns["Agent"](envs)
+    rnd_model = cls_ns["RNDModel"](4, A)
+    args = R.make_args(num_steps=T, num_envs=N, num_minibatches=2, update_epochs=1, batch_size=T * N, minibatch_size=T * N // 2,
+                       gamma=0.999, int_gamma=0.99, clip_coef=0.1, ent_coef=0.001, update_proportion=0.25, int_coef=1.0,
+                       ext_coef=2.0, learning_rate=1e-4)
+    combined_parameters = list(agent.parameters()) + list(rnd_model.predictor.parameters())
+    optimizer = torch.optim.Adam(combined_parameters, lr=args.learning_rate, eps=1e-5)
+    init = _flat(combined_parameters).clone()
+    g = torch.Generator().manual_seed(47)
+    frames = torch.randint(0, 256, (T + 1, N, 4, 84, 84), generator=g, dtype=torch.uint8)
+    step_done = (torch.rand(T + 1, N, generator=g) < 0.2).float()
+    step_done[0] = 0.0
+    rewards = torch.randint(-1, 2, (T, N), generator=g).float()
+    reward_rms, obs_rms = RunningMeanStd(), RunningMeanStd(shape=(1, 1, 84, 84))
+    obs_rms.update(torch.randint(0, 256, (64, 1, 84, 84), generator=g).double().numpy())       # stands for the init phase
+    obs_mean0, obs_var0, obs_count0 = obs_rms.mean.copy(), obs_rms.var.copy(), obs_rms.count
+    discounted_reward = cls_ns["RewardForwardFilter"](args.int_gamma)
+    device = torch.device("cpu")
+    obs = torch.zeros((T, N, 4, 84, 84))
+    actions, logprobs, curiosity_rewards, dones, ext_values, int_values = (torch.zeros((T, N)) for _ in range(6))
+    torch.manual_seed(17)                                      # the sampler's stream
+    for step in range(T):                                       # :345-371 with the env replaced by the synthetic stream
+        obs[step], dones[step] = frames[step].float(), step_done[step]
+        with torch.no_grad():
+            value_ext, value_int = agent.get_value(obs[step])
+            ext_values[step], int_values[step] = value_ext.flatten(), value_int.flatten()
+            action, logprob, _, _, _ = agent.get_action_and_value(obs[step])
+        actions[step], logprobs[step] = action, logprob
+        next_obs, next_done = frames[step + 1].float(), step_done[step + 1]
+        rnd_next_obs = (((next_obs[:, 3, :, :].reshape(N, 1, 84, 84) - torch.from_numpy(obs_rms.mean).to(device))
+                         / torch.sqrt(torch.from_numpy(obs_rms.var).to(device))).clip(-5, 5)).float()
+        target_next_feature = rnd_model.target(rnd_next_obs)
+        predict_next_feature = rnd_model.predictor(rnd_next_obs)
+        curiosity_rewards[step] = ((target_next_feature - predict_next_feature).pow(2).sum(1) / 2).data
+    raw_curiosity = curiosity_rewards.clone()
+    ns = dict(args=args, agent=agent, rnd_model=rnd_model, optimizer=optimizer, combined_parameters=combined_parameters,
+              envs=envs, obs=obs, actions=actions, logprobs=logprobs, rewards=rewards, curiosity_rewards=curiosity_rewards,
+              dones=dones, ext_values=ext_values, int_values=int_values, next_obs=next_obs, next_done=next_done,
+              reward_rms=reward_rms, obs_rms=obs_rms, discounted_reward=discounted_reward, device=device, np=np, torch=torch,
+              nn=nn, F=F)
+    u0 = R._find(lines, "curiosity_reward_per_env = np.array(")
+    u1 = R._find(lines, "# TRY NOT TO MODIFY: record rewards for plotting purposes", u0)
+    np.random.seed(5)
+    torch.manual_seed(19)                                      # the distillation mask's stream (torch.rand, :472)
+    exec(textwrap.dedent("\n".join(lines[u0:u1])), ns)          # :390-524
+    final = _flat(combined_parameters)
+    sub = slice(0, None, 211)
+    cases = {"rnd_T8_N4": dict(
+        frames_u8=frames, step_done=step_done, rewards=rewards, actions=actions, logprobs=logprobs, ext_values=ext_values,
+        int_values=int_values, raw_curiosity=raw_curiosity, scaled_curiosity=ns["curiosity_rewards"],
+        obs_mean0=obs_mean0, obs_var0=obs_var0, obs_count0=np.float64(obs_count0),
+        obs_mean1=obs_rms.mean, obs_var1=obs_rms.var, reward_var=np.float64(reward_rms.var),
+        ext_advantages=ns["ext_advantages"], int_advantages=ns["int_advantages"], ext_returns=ns["ext_returns"],
+        int_returns=ns["int_returns"], b_advantages=ns["b_advantages"],
+        init_params_sub=init[sub], final_params_sub=final[sub], stride=np.int64(211),
+        init_checksum=np.float64(init.double().sum().item()), final_checksum=np.float64(final.double().sum().item()),
+        last_loss=ns["loss"].detach(), last_pg_loss=ns["pg_loss"].detach(), last_v_loss=ns["v_loss"].detach(),
+        last_entropy=ns["entropy_loss"].detach(), last_fwd_loss=ns["forward_loss"].detach(), last_approx_kl=ns["approx_kl"],
+        init_seed=np.int64(13), sample_seed=np.int64(17), shuffle_seed=np.int64(5), mask_seed=np.int64(19), lr=np.float64(1e-4),
+        n_actions=np.int64(A), lines=np.array([u0 + 1, u1], np.int64))}
+    _save("rnd_iteration", cases)
+
+
 def main():
     assert R.available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -448,6 +537,7 @@ def main():
     mint_update_step()
     mint_lstm_iteration()
     mint_procgen_update()
+    mint_rnd_iteration()
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/cleanrl"
-SCRIPTS = ["ppo", "ppo_atari", "ppo_atari_envpool", "ppo_atari_multigpu", "ppo_continuous_action", "ppo_atari_lstm", "ppo_procgen"]
+SCRIPTS = ["ppo", "ppo_atari", "ppo_atari_envpool", "ppo_atari_multigpu", "ppo_continuous_action", "ppo_atari_lstm", "ppo_procgen", "ppo_rnd_envpool"]
 
 # the reference's flag surface (cleanrl/<script>.py Args), recorded so that this test also runs where
 # /root/reference is absent; test_recorded_surface_matches_reference re-derives it when it is present
@@ -28,6 +28,10 @@ REF_DEFAULTS["ppo_atari"] = dict(REF_DEFAULTS["ppo"], env_id="BreakoutNoFrameski
                                  num_envs=8, clip_coef=0.1)
 REF_DEFAULTS["ppo_atari_envpool"] = dict(REF_DEFAULTS["ppo_atari"], env_id="Breakout-v5")
 REF_DEFAULTS["ppo_atari_lstm"] = dict(REF_DEFAULTS["ppo_atari"])
+REF_DEFAULTS["ppo_rnd_envpool"] = dict(REF_DEFAULTS["ppo"], env_id="MontezumaRevenge-v5", total_timesteps=2000000000,
+                                       learning_rate=1e-4, num_envs=128, gamma=0.999, clip_coef=0.1, ent_coef=0.001,
+                                       update_proportion=0.25, int_coef=1.0, ext_coef=2.0, int_gamma=0.99,
+                                       num_iterations_obs_norm_init=50)
 REF_DEFAULTS["ppo_procgen"] = dict(REF_DEFAULTS["ppo"], env_id="starpilot", total_timesteps=int(25e6), learning_rate=5e-4,
                                    num_envs=64, num_steps=256, anneal_lr=False, gamma=0.999, num_minibatches=8, update_epochs=3)
 REF_DEFAULTS["ppo_atari_multigpu"] = dict(REF_DEFAULTS["ppo_atari"], num_envs=0, local_num_envs=8, device_ids=[],

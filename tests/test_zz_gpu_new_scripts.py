@@ -1,8 +1,9 @@
 """GPU tests of the drop-ins added after the round's GPU minutes were spent: the recurrent learner (ppo_atari_lstm.py),
-teacher-forced on the rollout the reference's own lines produced (tests/golden/lstm_iteration.npz), and ppo_procgen.py.
+teacher-forced on the rollout the reference's own lines produced (tests/golden/lstm_iteration.npz), ppo_procgen.py and
+ppo_rnd_envpool.py.
 
 The file sorts last on purpose and its tests are non-strict xfails for this round: these HIP paths have not run on a GPU
-yet.  Their host paths are proven against the reference lines (tests/test_lstm_script.py, tests/test_procgen_script.py)
+yet.  Their host paths are proven against the reference lines (tests/test_lstm_script.py, tests/test_procgen_script.py, tests/test_rnd_script.py)
 and the kernels they call -- K1, K2, K3, K5, K6 -- are the ones the other GPU tests cover.  Drop the marker once a GPU run
 has confirmed them."""
 from types import SimpleNamespace
@@ -87,3 +88,16 @@ def test_ppo_procgen_script_runs_on_gpu_without_relayout():
     L = ppo_procgen.main(["--num-envs", "8", "--num-steps", "16", "--total-timesteps", "256", "--num-minibatches", "4"])
     assert L.hip and L.obs.dtype == torch.uint8 and L.hwc_frames and not L.relayout and L.stage_obs is None
     assert tuple(L.obs.shape[2:]) == (64, 64, 3) and np.isfinite(L.last_metrics["loss"])
+
+
+def test_ppo_rnd_envpool_script_runs_on_gpu():
+    """ppo_rnd_envpool.py drop-in on the HIP path: two K1 launches per rollout, K3 on the combined advantage, one flat
+    buffer over agent + predictor parameters."""
+    from cleanrl_amd import ppo_rnd_envpool
+
+    L = ppo_rnd_envpool.main(["--num-envs", "8", "--num-steps", "16", "--total-timesteps", "256", "--num-minibatches", "4",
+                              "--num-iterations-obs-norm-init", "1"])
+    assert L.hip and L.obs.dtype == torch.uint8 and L.flat.numel == sum(p.numel() for p in L.combined_parameters)
+    assert np.isfinite(L.last_metrics["loss"]) and np.isfinite(L.last_metrics["fwd_loss"])
+    assert L.int_returns.abs().sum().item() > 0 and L.curiosity_rewards.min().item() >= 0.0
+    L.flat.check_views()
