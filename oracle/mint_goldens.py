@@ -335,6 +335,64 @@ def mint_update_step():
     _save("update_step", cases)
 
 
+# --------------------------------------------------------------- feed-forward Atari script: one whole iteration
+def mint_atari_iteration():
+    """One whole iteration of ppo_atari_envpool.py (config B's script) on synthetic inputs (T=8, N=4): the reference
+    Agent's action logic (:223-232) fills the rollout, then its GAE lines (:251-263) and its flatten + epoch / minibatch
+    update lines (:265-322, 2 minibatches x 2 epochs) are executed verbatim."""
+    import textwrap
+
+    import torch.nn as nn
+
+    script = "ppo_atari_envpool.py"
+    lines = R._read(script)
+    T, N, A = 8, 4, 4
+    torch.manual_seed(21)
+    Agent, _ = R.load_agent_class(script)
+    envs = R.fake_envs((4, 84, 84), n_actions=A)
+    agent = Agent(envs)
+    args = R.make_args(num_steps=T, num_envs=N, num_minibatches=2, update_epochs=2, batch_size=T * N, minibatch_size=T * N // 2)
+    optimizer = R.make_optimizer(agent, 2.5e-4)
+    init = _flat(agent.parameters()).clone()
+    g = torch.Generator().manual_seed(53)
+    frames = torch.randint(0, 256, (T + 1, N, 4, 84, 84), generator=g, dtype=torch.uint8)
+    step_done = (torch.rand(T + 1, N, generator=g) < 0.2).float()
+    step_done[0] = 0.0
+    rewards = torch.randint(-1, 2, (T, N), generator=g).float()
+    obs = torch.zeros((T, N, 4, 84, 84))
+    actions, logprobs, dones, values = (torch.zeros((T, N)) for _ in range(4))
+    torch.manual_seed(23)                                      # the sampler's stream
+    for step in range(T):
+        obs[step], dones[step] = frames[step].float(), step_done[step]
+        with torch.no_grad():
+            action, logprob, _, value = agent.get_action_and_value(obs[step])
+            values[step] = value.flatten()
+        actions[step], logprobs[step] = action, logprob
+    next_obs, next_done = frames[T].float(), step_done[T]
+    device = torch.device("cpu")
+    ns = dict(args=args, agent=agent, optimizer=optimizer, envs=envs, obs=obs, actions=actions, logprobs=logprobs,
+              rewards=rewards, dones=dones, values=values, next_obs=next_obs, next_done=next_done, device=device, np=np,
+              torch=torch, nn=nn)
+    g0 = R._find(lines, "# bootstrap value if not done") + 1
+    g1 = R._find(lines, "returns = advantages + values", g0)
+    exec(textwrap.dedent("\n".join(lines[g0:g1 + 1])), ns)
+    u0 = R._find(lines, "# flatten the batch", g1) + 1
+    u1 = R._find(lines, "y_pred, y_true = b_values.cpu().numpy()", u0)
+    np.random.seed(6)
+    exec(textwrap.dedent("\n".join(lines[u0:u1])), ns)
+    final = _flat(agent.parameters())
+    sub = slice(0, None, 89)
+    cases = {"atari_T8_N4": dict(
+        frames_u8=frames, step_done=step_done, rewards=rewards, actions=actions, logprobs=logprobs, values=values,
+        advantages=ns["advantages"], returns=ns["returns"], init_params_sub=init[sub], final_params_sub=final[sub],
+        stride=np.int64(89), init_checksum=np.float64(init.double().sum().item()),
+        final_checksum=np.float64(final.double().sum().item()), last_loss=ns["loss"].detach(), last_pg_loss=ns["pg_loss"].detach(),
+        last_v_loss=ns["v_loss"].detach(), last_entropy=ns["entropy_loss"].detach(), last_approx_kl=ns["approx_kl"],
+        clipfracs=np.array(ns["clipfracs"], np.float32), init_seed=np.int64(21), sample_seed=np.int64(23),
+        shuffle_seed=np.int64(6), lr=np.float64(2.5e-4), lines=np.array([g0 + 1, g1 + 1, u0 + 1, u1], np.int64))}
+    _save("atari_iteration", cases)
+
+
 # --------------------------------------------------------------- recurrent script: rollout -> GAE -> env-wise update
 def mint_lstm_iteration():
     """One whole iteration of ppo_atari_lstm.py on synthetic inputs: the reference Agent's own action logic fills the
@@ -535,6 +593,7 @@ def main():
     mint_loss_categorical()
     mint_loss_normal()
     mint_update_step()
+    mint_atari_iteration()
     mint_lstm_iteration()
     mint_procgen_update()
     mint_rnd_iteration()

@@ -175,3 +175,41 @@ def test_learner_host_path_learns_cartpole():
         if "final_info" in infos:
             lengths += [fi["episode"]["l"][0] for fi in infos["final_info"] if fi]
     assert len(lengths) > 0 and np.mean(lengths) > 150, f"mean greedy episode length {np.mean(lengths):.1f}"
+
+
+def test_whole_atari_iteration_matches_the_reference_lines():
+    """ppo_atari_envpool.py (config B's script), one whole iteration through the learner's API on CPU: sampled actions,
+    log-probs, values, GAE bit-equal to the reference's own lines (:223-232, :250-263); parameters after the 2 x 2
+    minibatch updates (:266-326) within 1e-7 (tests/golden/atari_iteration.npz)."""
+    g = load_golden("atari_iteration")["atari_T8_N4"]
+    T, N = g["rewards"].shape
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)                       # as when minted
+    try:
+        env = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+        torch.manual_seed(int(g["init_seed"]))
+        agent = AtariAgent(env)
+        stride = int(g["stride"])
+        flat = lambda: torch.cat([p.detach().reshape(-1) for p in agent.parameters()])
+        assert torch.equal(flat()[::stride], torch.from_numpy(g["init_params_sub"]))
+        args = default_args(num_steps=T, num_minibatches=2, update_epochs=2)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, torch.device("cpu"))
+        frames, step_done = g["frames_u8"], g["step_done"]
+        L.observe(0, frames[0], step_done[0])
+        torch.manual_seed(int(g["sample_seed"]))
+        for step in range(T):
+            L.act(step)
+            L.store_reward(step, g["rewards"][step])
+            L.observe(step + 1, frames[step + 1], step_done[step + 1])
+        for mine, gold in ((L.actions, "actions"), (L.logprobs, "logprobs"), (L.values, "values")):
+            assert torch.equal(mine, torch.from_numpy(g[gold])), gold
+        L.finish_rollout()
+        assert torch.equal(L.advantages, torch.from_numpy(g["advantages"])) and torch.equal(L.returns, torch.from_numpy(g["returns"]))
+        np.random.seed(int(g["shuffle_seed"]))
+        m = L.update(float(g["lr"]))
+        assert (flat()[::stride] - torch.from_numpy(g["final_params_sub"])).abs().max().item() <= 1e-7
+        assert abs(flat().double().sum().item() - float(g["final_checksum"])) <= 1e-4
+        assert m["num_updates"] == 4 and abs(m["loss"] - float(g["last_loss"])) <= 1e-6
+        assert abs(m["value_loss"] - float(g["last_v_loss"])) <= 1e-6 and abs(m["entropy"] - float(g["last_entropy"])) <= 1e-6
+    finally:
+        torch.set_num_threads(n)
