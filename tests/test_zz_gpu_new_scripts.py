@@ -6,6 +6,7 @@ The file sorts last on purpose and its tests are non-strict xfails for this roun
 yet.  Their host paths are proven against the reference lines (tests/test_lstm_script.py, tests/test_procgen_script.py, tests/test_rnd_script.py)
 and the kernels they call -- K1, K2, K3, K5, K6 -- are the ones the other GPU tests cover.  Drop the marker once a GPU run
 has confirmed them."""
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -20,6 +21,11 @@ from cleanrl_amd.learner_smoke import default_args
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.xfail(strict=False, reason="first GPU run of these scripts' HIP paths is still outstanding")]
+# The LSTM / procgen / RND scripts run their convolutions on MIOpen with shapes no find-db entry exists for: on a fresh box
+# every new problem is tuned / JIT-compiled (minutes in total).  They are therefore opt-in; the whole-iteration test of the
+# main Atari path (fused conv kernels, no MIOpen) always runs.
+extended = pytest.mark.skipif(os.environ.get("MI355PPO_GPU_EXTENDED") != "1",
+                              reason="set MI355PPO_GPU_EXTENDED=1 to run the MIOpen-heavy new-script GPU tests")
 DEV = torch.device("cuda:0")
 
 
@@ -31,6 +37,7 @@ def _learner(g, T, N):
     return agent, LSTMPPOLearner(agent, args, envs.single_observation_space, envs.single_action_space, N, DEV, sample_seed=1)
 
 
+@extended
 def test_lstm_hip_path_teacher_forced_against_reference_iteration():
     g = load_golden("lstm_iteration")["lstm_T8_N4"]
     T, N = g["rewards"].shape
@@ -73,6 +80,7 @@ def test_lstm_hip_path_teacher_forced_against_reference_iteration():
     L.flat.check_views()
 
 
+@extended
 def test_ppo_atari_lstm_script_runs_on_gpu():
     from cleanrl_amd import ppo_atari_lstm
 
@@ -81,6 +89,7 @@ def test_ppo_atari_lstm_script_runs_on_gpu():
     assert np.isfinite(L.last_metrics["loss"]) and L.last_metrics["num_updates"] == 16
 
 
+@extended
 def test_ppo_procgen_script_runs_on_gpu_without_relayout():
     """ppo_procgen.py drop-in on the HIP path: pixel-interleaved frames go straight into the uint8 rollout rows."""
     from cleanrl_amd import ppo_procgen
@@ -90,6 +99,7 @@ def test_ppo_procgen_script_runs_on_gpu_without_relayout():
     assert tuple(L.obs.shape[2:]) == (64, 64, 3) and np.isfinite(L.last_metrics["loss"])
 
 
+@extended
 def test_ppo_rnd_envpool_script_runs_on_gpu():
     """ppo_rnd_envpool.py drop-in on the HIP path: two K1 launches per rollout, K3 on the combined advantage, one flat
     buffer over agent + predictor parameters."""
