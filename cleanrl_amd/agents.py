@@ -472,3 +472,126 @@ class RNDModel(nn.Module):
         target_feature = self.target(next_obs)
         predict_feature = self.predictor(next_obs)
         return predict_feature, target_feature
+
+
+def layer_init_normed(layer, norm_dim, scale=1.0):
+    """ppg_procgen.py:100-104: rescale every output unit's weight vector to norm ``scale``; zero bias."""
+    with torch.no_grad():
+        layer.weight.data *= scale / layer.weight.norm(dim=norm_dim, p=2, keepdim=True)
+        layer.bias *= 0
+    return layer
+
+
+class ResidualBlockNormed(nn.Module):
+    """ppg_procgen.py:123-139."""
+
+    def __init__(self, channels, scale):
+        super().__init__()
+        scale = np.sqrt(scale)
+        conv0 = nn.Conv2d(in_channels=channels, out_channels=channels, kernel_size=3, padding=1)
+        self.conv0 = layer_init_normed(conv0, norm_dim=(1, 2, 3), scale=scale)
+        conv1 = nn.Conv2d(in_channels=channels, out_channels=channels, kernel_size=3, padding=1)
+        self.conv1 = layer_init_normed(conv1, norm_dim=(1, 2, 3), scale=scale)
+
+    def forward(self, x):
+        inputs = x
+        x = nn.functional.relu(x)
+        x = self.conv0(x)
+        x = nn.functional.relu(x)
+        x = self.conv1(x)
+        return x + inputs
+
+
+class ConvSequenceNormed(nn.Module):
+    """ppg_procgen.py:142-165."""
+
+    def __init__(self, input_shape, out_channels, scale):
+        super().__init__()
+        self._input_shape = input_shape
+        self._out_channels = out_channels
+        conv = nn.Conv2d(in_channels=self._input_shape[0], out_channels=self._out_channels, kernel_size=3, padding=1)
+        self.conv = layer_init_normed(conv, norm_dim=(1, 2, 3), scale=1.0)
+        nblocks = 2
+        scale = scale / np.sqrt(nblocks)
+        self.res_block0 = ResidualBlockNormed(self._out_channels, scale=scale)
+        self.res_block1 = ResidualBlockNormed(self._out_channels, scale=scale)
+
+    def forward(self, x):
+        x = self.conv(x)
+        x = nn.functional.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        x = self.res_block0(x)
+        x = self.res_block1(x)
+        assert x.shape[1:] == self.get_output_shape()
+        return x
+
+    def get_output_shape(self):
+        _c, h, w = self._input_shape
+        return (self._out_channels, (h + 1) // 2, (w + 1) // 2)
+
+
+class PPGAgent(_DiscreteMixin, nn.Module):
+    """ppg_procgen.py:168-211: IMPALA-CNN with norm-scaled initialisation, a policy head, a value head on the DETACHED
+    features (the policy phase's value loss does not shape the encoder) and an auxiliary value head on the live features
+    (the auxiliary phase's does)."""
+
+    obs_is_image = True
+    obs_layout = "hwc"
+
+    def __init__(self, envs):
+        super().__init__()
+        h, w, c = envs.single_observation_space.shape
+        shape = (c, h, w)
+        conv_seqs = []
+        chans = [16, 32, 32]
+        scale = 1 / np.sqrt(len(chans))
+        for out_channels in chans:
+            conv_seq = ConvSequenceNormed(shape, out_channels, scale=scale)
+            shape = conv_seq.get_output_shape()
+            conv_seqs.append(conv_seq)
+        encodertop = nn.Linear(in_features=shape[0] * shape[1] * shape[2], out_features=256)
+        encodertop = layer_init_normed(encodertop, norm_dim=1, scale=1.4)
+        conv_seqs += [
+            nn.Flatten(),
+            nn.ReLU(),
+            encodertop,
+            nn.ReLU(),
+        ]
+        self.network = nn.Sequential(*conv_seqs)
+        self.actor = layer_init_normed(nn.Linear(256, envs.single_action_space.n), norm_dim=1, scale=0.1)
+        self.critic = layer_init_normed(nn.Linear(256, 1), norm_dim=1, scale=0.1)
+        self.aux_critic = layer_init_normed(nn.Linear(256, 1), norm_dim=1, scale=0.1)
+        self.n_actions = envs.single_action_space.n
+        self.rng = _SampleCounter()
+
+    def _normalise(self, x):
+        """(B, H, W, C) frames -> normalised (B, C, H, W) view ("bhwc" -> "bchw")."""
+        if x.dtype == torch.uint8:
+            x = ops.obs_u8_to_f32(x.contiguous()) if x.is_cuda else x.float() / 255.0
+        else:
+            x = x / 255.0
+        return x.permute((0, 3, 1, 2))
+
+    def heads(self, xn):
+        """xn: normalised (B, C, H, W) frames -> (logits, value on the detached features): the policy-phase seam."""
+        hidden = self.network(xn)
+        return self.actor(hidden), self.critic(hidden.detach())
+
+    def heads_aux(self, xn):
+        """-> (logits, value on detached features, auxiliary value on live features): the auxiliary-phase seam."""
+        hidden = self.network(xn)
+        return self.actor(hidden), self.critic(hidden.detach()), self.aux_critic(hidden)
+
+    def get_action_and_value(self, x, action=None):
+        logits, value = self.heads(self._normalise(x))
+        action, lp, ent = self._dist(logits, action)
+        return action, lp, ent, value
+
+    def get_value(self, x):
+        return self.critic(self.network(self._normalise(x)))
+
+    def get_pi_value_and_aux_value(self, x):
+        logits, value, aux = self.heads_aux(self._normalise(x))
+        return Categorical(logits=logits), value, aux
+
+    def get_pi(self, x):
+        return Categorical(logits=self.actor(self.network(self._normalise(x))))

@@ -42,6 +42,7 @@ class PPOLearner:
         self.agent, self.args, self.device = agent, args, device
         self.T, self.N = int(args.num_steps), int(num_envs)
         self.world_size = world_size
+        self.adam_eps = 1e-5                       # optim.Adam(..., eps=1e-5) of the PPO scripts (ppo.py:168); PPG uses 1e-8
         self.hip = device.type == "cuda"
         self.discrete = getattr(agent, "discrete", True)
         self.image = bool(getattr(agent, "obs_is_image", False))
@@ -311,7 +312,8 @@ class PPOLearner:
         a = self.args
         self.flat.step += 1
         self.ops.clip_adam_(self.flat.params, self.flat.grads, self.flat.exp_avg, self.flat.exp_avg_sq, self.flat.step, lr,
-                            a.max_grad_norm, grad_scale=1.0 / self.world_size, total_norm_out=self._total_norm)
+                            a.max_grad_norm, grad_scale=1.0 / self.world_size, eps=self.adam_eps,
+                            total_norm_out=self._total_norm)
         trunk = getattr(self.agent, "_trunk", None)
         if trunk is not None:                       # the kernel rewrote the parameters through raw pointers
             trunk.bufs.weights_version += 1

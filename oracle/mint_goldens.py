@@ -493,6 +493,83 @@ def mint_procgen_update():
     _save("procgen_update", {"impala_2steps": d})
 
 
+# --------------------------------------------------------------- PPG: policy phase with full-batch normalisation + auxiliary phase
+def mint_ppg_phase():
+    """One whole phase of ppg_procgen.py with n_iteration = 1 on synthetic inputs (T=8, N=4): the reference Agent's action
+    logic fills the rollout; its GAE lines, its flatten + full-batch advantage normalisation + policy minibatch lines
+    (:330-392), its aux-buffer storage lines (:411-414) and its whole auxiliary phase (:416-471, 2 epochs x 2 minibatches of
+    2 rollouts) are executed verbatim."""
+    import ast
+    import textwrap
+
+    import torch.distributions as td
+    import torch.nn as nn
+    from torch.distributions.categorical import Categorical
+
+    script = "ppg_procgen.py"
+    lines = R._read(script)
+    tree = ast.parse("\n".join(lines))
+    cls_ns = {"np": np, "torch": torch, "nn": nn, "Categorical": Categorical}
+    want = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef))
+            and n.name in ("layer_init_normed", "flatten01", "unflatten01", "ResidualBlock", "ConvSequence", "Agent")]
+    exec(compile(ast.Module(body=want, type_ignores=[]), f"<reference:{script}>", "exec"), cls_ns)
+    T, N, A = 8, 4, 15
+    envs = R.fake_envs((64, 64, 3), n_actions=A)
+    torch.manual_seed(27)
+    agent = cls_ns["Agent"](envs)
+    args = R.make_args(num_steps=T, num_envs=N, num_minibatches=2, batch_size=T * N, minibatch_size=T * N // 2, gamma=0.999,
+                       clip_coef=0.2, adv_norm_fullbatch=True, e_policy=1, e_auxiliary=2, beta_clone=1.0, num_aux_rollouts=2,
+                       n_aux_grad_accum=1, aux_batch_rollouts=N, n_iteration=1, learning_rate=5e-4)
+    optimizer = torch.optim.Adam(agent.parameters(), lr=args.learning_rate, eps=1e-8)
+    init = _flat(agent.parameters()).clone()
+    g = torch.Generator().manual_seed(59)
+    frames = torch.randint(0, 256, (T + 1, N, 64, 64, 3), generator=g, dtype=torch.uint8)
+    step_done = (torch.rand(T + 1, N, generator=g) < 0.2).float()
+    step_done[0] = 0.0
+    rewards = torch.rand(T, N, generator=g) * 2.0
+    obs = torch.zeros((T, N, 64, 64, 3))
+    actions, logprobs, dones, values = (torch.zeros((T, N)) for _ in range(4))
+    torch.manual_seed(29)
+    for step in range(T):
+        obs[step], dones[step] = frames[step].float(), step_done[step]
+        with torch.no_grad():
+            action, logprob, _, value = agent.get_action_and_value(obs[step])
+            values[step] = value.flatten()
+        actions[step], logprobs[step] = action, logprob
+    next_obs, next_done = frames[T].float(), step_done[T]
+    device = torch.device("cpu")
+    aux_obs = torch.zeros((T, N, 64, 64, 3), dtype=torch.uint8)
+    aux_returns = torch.zeros((T, N))
+    ns = dict(args=args, agent=agent, optimizer=optimizer, envs=envs, obs=obs, actions=actions, logprobs=logprobs, rewards=rewards,
+              dones=dones, values=values, next_obs=next_obs, next_done=next_done, device=device, np=np, torch=torch, nn=nn, td=td,
+              Categorical=Categorical, flatten01=cls_ns["flatten01"], unflatten01=cls_ns["unflatten01"], aux_obs=aux_obs,
+              aux_returns=aux_returns, update=1)
+    g0 = R._find(lines, "# bootstrap value if not done") + 1
+    g1 = R._find(lines, "returns = advantages + values", g0)
+    exec(textwrap.dedent("\n".join(lines[g0:g1 + 1])), ns)
+    u0 = R._find(lines, "# flatten the batch", g1) + 1
+    u1 = R._find(lines, "y_pred, y_true = b_values.cpu().numpy()", u0)
+    np.random.seed(7)
+    exec(textwrap.dedent("\n".join(lines[u0:u1])), ns)                  # policy phase update
+    after_policy = _flat(agent.parameters()).clone()
+    policy_loss = ns["loss"].detach().clone()                           # the auxiliary phase reuses the name `loss`
+    s0 = R._find(lines, "# PPG Storage", u1) + 1
+    exec(textwrap.dedent("\n".join(lines[s0:s0 + 3])), ns)
+    a0 = R._find(lines, "# AUXILIARY PHASE", s0) + 1
+    a1 = R._find(lines, 'writer.add_scalar("losses/aux/kl_loss"', a0)
+    exec(textwrap.dedent("\n".join(lines[a0:a1])), ns)                  # auxiliary phase
+    final = _flat(agent.parameters())
+    sub = slice(0, None, 61)
+    cases = {"ppg_T8_N4": dict(
+        frames_u8=frames, step_done=step_done, rewards=rewards, actions=actions, logprobs=logprobs, values=values,
+        returns=ns["returns"], b_advantages=ns["b_advantages"], init_params_sub=init[sub], policy_params_sub=after_policy[sub],
+        final_params_sub=final[sub], stride=np.int64(61), final_checksum=np.float64(final.double().sum().item()),
+        policy_loss=policy_loss, kl_loss=ns["kl_loss"].detach(), aux_value_loss=ns["aux_value_loss"].detach(),
+        real_value_loss=ns["real_value_loss"].detach(), aux_pi=ns["aux_pi"], init_seed=np.int64(27), sample_seed=np.int64(29),
+        shuffle_seed=np.int64(7), lr=np.float64(5e-4), lines=np.array([u0 + 1, u1, s0 + 1, a0 + 1, a1], np.int64))}
+    _save("ppg_phase", cases)
+
+
 # --------------------------------------------------------------- RND: two value streams, intrinsic reward, distillation loss
 def mint_rnd_iteration():
     """One whole iteration of ppo_rnd_envpool.py on synthetic inputs (T=8, N=4): the reference Agent / RNDModel fill the
@@ -597,6 +674,7 @@ def main():
     mint_lstm_iteration()
     mint_procgen_update()
     mint_rnd_iteration()
+    mint_ppg_phase()
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/cleanrl"
-SCRIPTS = ["ppo", "ppo_atari", "ppo_atari_envpool", "ppo_atari_multigpu", "ppo_continuous_action", "ppo_atari_lstm", "ppo_procgen", "ppo_rnd_envpool"]
+SCRIPTS = ["ppo", "ppo_atari", "ppo_atari_envpool", "ppo_atari_multigpu", "ppo_continuous_action", "ppo_atari_lstm", "ppo_procgen", "ppo_rnd_envpool", "ppg_procgen"]
 
 # the reference's flag surface (cleanrl/<script>.py Args), recorded so that this test also runs where
 # /root/reference is absent; test_recorded_surface_matches_reference re-derives it when it is present
@@ -34,6 +34,9 @@ REF_DEFAULTS["ppo_rnd_envpool"] = dict(REF_DEFAULTS["ppo"], env_id="MontezumaRev
                                        num_iterations_obs_norm_init=50)
 REF_DEFAULTS["ppo_procgen"] = dict(REF_DEFAULTS["ppo"], env_id="starpilot", total_timesteps=int(25e6), learning_rate=5e-4,
                                    num_envs=64, num_steps=256, anneal_lr=False, gamma=0.999, num_minibatches=8, update_epochs=3)
+REF_DEFAULTS["ppg_procgen"] = {k: v for k, v in REF_DEFAULTS["ppo_procgen"].items() if k not in ("update_epochs", "norm_adv")}
+REF_DEFAULTS["ppg_procgen"].update(adv_norm_fullbatch=True, n_iteration=32, e_policy=1, v_value=1, e_auxiliary=6, beta_clone=1.0,
+                                   num_aux_rollouts=4, n_aux_grad_accum=1, num_phases=0, aux_batch_rollouts=0)
 REF_DEFAULTS["ppo_atari_multigpu"] = dict(REF_DEFAULTS["ppo_atari"], num_envs=0, local_num_envs=8, device_ids=[],
                                           backend="gloo", local_batch_size=0, local_minibatch_size=0, world_size=0)
 REF_DEFAULTS["ppo_continuous_action"] = dict(REF_DEFAULTS["ppo"], save_model=False, upload_model=False, hf_entity="",

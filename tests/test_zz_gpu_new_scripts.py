@@ -152,3 +152,16 @@ def test_atari_hip_path_teacher_forced_against_reference_iteration():
     want = g["final_params_sub"] - g["init_params_sub"]
     close = np.isclose(delta, want, rtol=5e-2, atol=2e-5)
     assert close.mean() > 0.98, f"only {close.mean():.4f} of sampled parameters match the reference update"
+
+
+@extended
+def test_ppg_procgen_script_runs_on_gpu():
+    """ppg_procgen.py drop-in on the HIP path: policy phase on K1/K2/K3/K5/K6 with Adam eps 1e-8, the auxiliary buffer in
+    HBM, the auxiliary phase accumulating into the flat gradient buffer."""
+    from cleanrl_amd import ppg_procgen
+
+    L = ppg_procgen.main(["--num-envs", "8", "--num-steps", "16", "--total-timesteps", "512", "--num-minibatches", "4",
+                          "--n-iteration", "2", "--e-auxiliary", "1", "--num-aux-rollouts", "4"])
+    assert L.hip and L.adam_eps == 1e-8 and L.aux_obs.is_cuda and L.aux_obs.dtype == torch.uint8
+    assert np.isfinite(L.last_metrics["loss"]) and all(np.isfinite(v) for v in L.last_aux.values())
+    L.flat.check_views()
