@@ -595,3 +595,55 @@ class PPGAgent(_DiscreteMixin, nn.Module):
 
     def get_pi(self, x):
         return Categorical(logits=self.actor(self.network(self._normalise(x))))
+
+
+class MAAtariAgent(_DiscreteMixin, nn.Module):
+    """ppo_pettingzoo_ma_atari.py:86-118: NatureCNN on (84, 84, 6) pixel-interleaved observations -- four stacked frames plus
+    two agent-indicator planes.  Only the four frame channels are divided by 255 (:104,109)."""
+
+    obs_is_image = True
+    obs_layout = "hwc"
+    frame_channels = 4            # channels [0, 4) are pixels; the rest pass through unscaled
+
+    def __init__(self, envs):
+        super().__init__()
+        self.network = nn.Sequential(
+            layer_init(nn.Conv2d(6, 32, 8, stride=4)),
+            nn.ReLU(),
+            layer_init(nn.Conv2d(32, 64, 4, stride=2)),
+            nn.ReLU(),
+            layer_init(nn.Conv2d(64, 64, 3, stride=1)),
+            nn.ReLU(),
+            nn.Flatten(),
+            layer_init(nn.Linear(64 * 7 * 7, 512)),
+            nn.ReLU(),
+        )
+        self.actor = layer_init(nn.Linear(512, envs.single_action_space.n), std=0.01)
+        self.critic = layer_init(nn.Linear(512, 1), std=1)
+        self.n_actions = envs.single_action_space.n
+        self.rng = _SampleCounter()
+
+    def scale_frames_(self, x):
+        """In place on a (B, H, W, C) f32 tensor holding raw 0..255 values: ``x[:, :, :, [0,1,2,3]] /= 255.0``."""
+        x[..., : self.frame_channels] /= 255.0
+        return x
+
+    def _normalise(self, x):
+        if x.dtype == torch.uint8:
+            x = ops.obs_u8_to_f32(x.contiguous(), scale_255=False) if x.is_cuda else x.float()
+        else:
+            x = x.clone()
+        return self.scale_frames_(x).permute((0, 3, 1, 2))
+
+    def heads(self, xn):
+        """xn: normalised (B, 6, 84, 84) -> (logits, value)."""
+        hidden = self.network(xn)
+        return self.actor(hidden), self.critic(hidden)
+
+    def get_value(self, x):
+        return self.critic(self.network(self._normalise(x)))
+
+    def get_action_and_value(self, x, action=None):
+        logits, value = self.heads(self._normalise(x))
+        action, lp, ent = self._dist(logits, action)
+        return action, lp, ent, value

@@ -52,6 +52,16 @@ def _unwrap_optional(tp):
     return tp
 
 
+def _strtobool(v: str) -> bool:
+    """distutils.util.strtobool's vocabulary."""
+    t = v.strip().lower()
+    if t in ("y", "yes", "t", "true", "on", "1"):
+        return True
+    if t in ("n", "no", "f", "false", "off", "0"):
+        return False
+    raise argparse.ArgumentTypeError(f"invalid truth value {v!r}")
+
+
 def _normalise(argv: Sequence[str]) -> List[str]:
     out = []
     for tok in argv:
@@ -76,7 +86,9 @@ def parse(cls: Type[T], argv: Optional[Sequence[str]] = None, description: Optio
         help_ = docs.get(f.name, "")
         origin = typing.get_origin(tp)
         if tp is bool:
-            parser.add_argument(flag, dest=f.name, action="store_true", default=default, help=help_)
+            # `--flag`, `--no-flag` (tyro) and `--flag False` / `--flag true` (the strtobool flags of the argparse-based
+            # reference scripts, e.g. ppo_pettingzoo_ma_atari.py:24-31)
+            parser.add_argument(flag, dest=f.name, nargs="?", const=True, type=_strtobool, default=default, help=help_)
             parser.add_argument("--no-" + f.name.replace("_", "-"), dest=f.name, action="store_false",
                                 help=argparse.SUPPRESS)
         elif origin in (list, List):

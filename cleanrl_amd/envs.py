@@ -405,3 +405,50 @@ class SyntheticProcgenVecEnv:
 
     def close(self):
         pass
+
+
+class SyntheticMAAtariVecEnv:
+    """Byte-stream stand-in for the supersuit pipeline of ppo_pettingzoo_ma_atari.py:151-165 (two-player PettingZoo Atari:
+    max-pool 2 frames, frame-skip 4, clip reward, colour reduction, 84x84, frame-stack 4, agent indicator, ``num_envs // 2``
+    games concatenated): (N, 84, 84, 6) uint8 pixel-interleaved observations -- channels 0-3 the stacked frames, 4-5 a one-hot
+    player indicator (0 / 255... stored as 0 / 1) --, consecutive envs are the two players of one game (zero-sum rewards,
+    shared episode ends), 6 actions, the old gym API with one info dict per env."""
+
+    def __init__(self, num_envs: int, seed: int = 0, n_actions: int = 6, pool_frames: int = 512, done_p: float = 1.0 / 150.0):
+        assert num_envs % 2 == 0, "two players per game"
+        self.num_envs, self.done_p = num_envs, done_p
+        self.single_observation_space = Box(0, 255, (84, 84, 6), np.uint8)
+        self.single_action_space = Discrete(n_actions)
+        self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
+        self.rng = np.random.RandomState(seed)
+        self.frames = np.random.RandomState(seed + 777).randint(0, 256, size=(pool_frames, 84, 84), dtype=np.uint8)
+        self.cursor = np.zeros(num_envs // 2, np.int64)
+        self.stats = _EpisodeStats(num_envs)
+        self._win = np.arange(4)[None, :]
+        self._indicator = np.zeros((num_envs, 84, 84, 2), np.uint8)
+        self._indicator[0::2, :, :, 0] = 1
+        self._indicator[1::2, :, :, 1] = 1
+
+    def _obs(self):
+        idx = (self.cursor[:, None] + self._win) % len(self.frames)              # (games, 4)
+        stack = np.moveaxis(self.frames[idx], 1, -1)                             # (games, 84, 84, 4)
+        return np.concatenate([np.repeat(stack, 2, axis=0), self._indicator], axis=-1)
+
+    def reset(self):
+        self.cursor = self.rng.randint(0, len(self.frames), size=self.num_envs // 2).astype(np.int64)
+        self.stats = _EpisodeStats(self.num_envs)
+        return self._obs()
+
+    def step(self, action):
+        g = self.num_envs // 2
+        r0 = self.rng.choice(np.array([-1.0, 0.0, 1.0]), size=g, p=[0.05, 0.9, 0.05])
+        reward = np.stack([r0, -r0], axis=1).reshape(-1)
+        gdone = self.rng.random_sample(g) < self.done_p
+        done = np.repeat(gdone, 2)
+        self.cursor = np.where(gdone, self.rng.randint(0, len(self.frames), size=g), self.cursor + 1)
+        r, l = self.stats.update(reward.astype(np.float32), done)
+        info = [{"episode": {"r": r[i], "l": l[i]}} if done[i] else {} for i in range(self.num_envs)]
+        return self._obs(), reward, done, info
+
+    def close(self):
+        pass

@@ -82,6 +82,7 @@ class PPOLearner:
                 self.obs_shape = (h, w, c)                                  # how rollout rows are laid out
             os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
         self.relayout = self.nhwc and not self.hwc_frames
+        self.partial_scale = self.image and hasattr(agent, "scale_frames_")
         self.obs = torch.zeros((T, N) + self.obs_shape, dtype=obs_dtype, device=device)
         self.actions = torch.zeros((T, N) + self.act_shape, device=device)
         self.logprobs = torch.zeros((T, N), device=device)
@@ -166,6 +167,8 @@ class PPOLearner:
         """uint8 image rows -> normalised f32 (K5, no gather); other observations pass through."""
         if self.image and self.hip:
             # (N,H,W,C) f32 storage viewed as a channels-last (N,C,H,W) tensor
+            if self.partial_scale:      # only the agent's pixel channels are divided by 255 (ppo_pettingzoo_ma_atari.py:104)
+                return self.agent.scale_frames_(self.ops.obs_u8_to_f32(obs_rows, None, self._x_roll, False)).permute(0, 3, 1, 2)
             return self.ops.obs_u8_to_f32(obs_rows, None, self._x_roll).permute(0, 3, 1, 2)
         if self.image:
             return obs_rows / 255.0
@@ -283,7 +286,10 @@ class PPOLearner:
             if self.image:
                 if self._x_mb is None or self._x_mb.shape[0] != idx.numel():
                     self._x_mb = torch.empty((idx.numel(),) + self.obs_shape, device=self.device)
-                x = ops.obs_u8_to_f32(b_obs, idx, self._x_mb).permute(0, 3, 1, 2)   # K5: b_obs[mb_inds] ; x / 255.0
+                if self.partial_scale:
+                    x = self.agent.scale_frames_(ops.obs_u8_to_f32(b_obs, idx, self._x_mb, False)).permute(0, 3, 1, 2)
+                else:
+                    x = ops.obs_u8_to_f32(b_obs, idx, self._x_mb).permute(0, 3, 1, 2)   # K5: b_obs[mb_inds] ; x / 255.0
             else:
                 x = b_obs.index_select(0, idx)
             p, value = self.agent.heads(x)                                # :320 network forward
@@ -324,7 +330,7 @@ class PPOLearner:
         self.optimizer.param_groups[0]["lr"] = lr
         x = b_obs[mb_inds]
         if self.image:
-            x = x / 255.0
+            x = self.agent.scale_frames_(x.clone()) if self.partial_scale else x / 255.0
             if self.hwc_frames:
                 x = x.permute((0, 3, 1, 2))                       # "bhwc" -> "bchw" (ppo_procgen.py:150)
         p, newvalue = self.agent.heads(x)

@@ -94,7 +94,7 @@ def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: in
                           world_size=world_size, sample_seed=args.seed)
     global_step = 0
     start_time = time.time()
-    if env_api in ("gym", "procgen"):                           # envpool / procgen: reset() returns obs only (:214)
+    if env_api in ("gym", "procgen", "pettingzoo"):             # envpool / procgen / supersuit: reset() returns obs only (:214)
         next_obs = envs.reset()
     else:
         next_obs, _ = envs.reset(seed=args.seed)
@@ -120,6 +120,15 @@ def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: in
                             writer.add_scalar("charts/avg_episodic_return", np.average(avg_returns), global_step)
                             writer.add_scalar("charts/episodic_return", info["r"][idx], global_step)
                             writer.add_scalar("charts/episodic_length", info["l"][idx], global_step)
+            elif env_api == "pettingzoo":                       # ppo_pettingzoo_ma_atari.py:203-213: envs alternate players
+                next_obs, reward, next_done, info = envs.step(act_np)
+                if writer is not None:
+                    for idx, item in enumerate(info):
+                        player_idx = idx % 2
+                        if "episode" in item.keys():
+                            print(f"global_step={global_step}, {player_idx}-episodic_return={item['episode']['r']}")
+                            writer.add_scalar(f"charts/episodic_return-player{player_idx}", item["episode"]["r"], global_step)
+                            writer.add_scalar(f"charts/episodic_length-player{player_idx}", item["episode"]["l"], global_step)
             elif env_api == "procgen":                          # ppo_procgen.py:241-250: 4-tuple, one info dict per env
                 next_obs, reward, next_done, info = envs.step(act_np)
                 if writer is not None:

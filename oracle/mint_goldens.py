@@ -493,6 +493,45 @@ def mint_procgen_update():
     _save("procgen_update", {"impala_2steps": d})
 
 
+# --------------------------------------------------------------- two-player Atari: 6-channel frames, partial /255
+def mint_ma_atari_update():
+    """ppo_pettingzoo_ma_atari.py: two consecutive minibatch updates (its loss + backward + clip + Adam lines) of the
+    reference Agent on (B, 84, 84, 6) observations whose last two channels are agent-indicator planes."""
+    script = "ppo_pettingzoo_ma_atari.py"
+    torch.manual_seed(33)
+    Agent, _ = R.load_agent_class(script)
+    agent = Agent(R.fake_envs((84, 84, 6), n_actions=6))
+    args = R.make_args(clip_coef=0.1)
+    opt = R.make_optimizer(agent, 2.5e-4)
+    g = torch.Generator().manual_seed(61)
+    B, M = 32, 16
+    frames = torch.randint(0, 256, (B, 84, 84, 4), generator=g, dtype=torch.uint8)
+    ind = torch.zeros((B, 84, 84, 2), dtype=torch.uint8)
+    ind[0::2, :, :, 0] = 1
+    ind[1::2, :, :, 1] = 1
+    b_obs_u8 = torch.cat([frames, ind], dim=-1)
+    b_obs = b_obs_u8.float()
+    b_actions = torch.randint(0, 6, (B,), generator=g).float()
+    with torch.no_grad():
+        _, lp_all, _, v_all = agent.get_action_and_value(b_obs, b_actions.long())
+    b_logprobs, b_advantages, b_returns, b_values = _behaviour_batch(g, lp_all, v_all.view(-1), B)
+    perm = np.random.RandomState(9).permutation(B)
+    init = _flat(agent.parameters()).clone()
+    sub = slice(0, None, 83)
+    d = dict(init_params_sub=init[sub], stride=np.int64(83), b_obs_u8=b_obs_u8, b_actions=b_actions, b_logprobs=b_logprobs,
+             b_advantages=b_advantages, b_returns=b_returns, b_values=b_values, perm=perm.astype(np.int64), lr=np.float64(2.5e-4),
+             init_seed=np.int64(33), logprob_all=lp_all, value_all=v_all.view(-1))
+    losses = []
+    for k in range(2):
+        ns = R.run_loss(script, agent, args, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values,
+                        perm[k * M:(k + 1) * M], step=True, optimizer=opt)
+        losses.append(ns["loss"].item())
+        d[f"params_sub_after_{k + 1}"] = _flat(agent.parameters())[sub]
+    d["losses"] = np.array(losses, np.float32)
+    assert torch.equal(b_obs, b_obs_u8.float()), "the reference must not modify the stored observations"
+    _save("ma_atari_update", {"ma_2steps": d})
+
+
 # --------------------------------------------------------------- PPG: policy phase with full-batch normalisation + auxiliary phase
 def mint_ppg_phase():
     """One whole phase of ppg_procgen.py with n_iteration = 1 on synthetic inputs (T=8, N=4): the reference Agent's action
@@ -675,6 +714,7 @@ def main():
     mint_procgen_update()
     mint_rnd_iteration()
     mint_ppg_phase()
+    mint_ma_atari_update()
 
 
 if __name__ == "__main__":

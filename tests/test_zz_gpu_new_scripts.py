@@ -165,3 +165,13 @@ def test_ppg_procgen_script_runs_on_gpu():
     assert L.hip and L.adam_eps == 1e-8 and L.aux_obs.is_cuda and L.aux_obs.dtype == torch.uint8
     assert np.isfinite(L.last_metrics["loss"]) and all(np.isfinite(v) for v in L.last_aux.values())
     L.flat.check_views()
+
+
+@extended
+def test_ppo_pettingzoo_ma_atari_script_runs_on_gpu():
+    """ppo_pettingzoo_ma_atari.py drop-in on the HIP path: K5 without the /255, frame channels scaled afterwards."""
+    from cleanrl_amd import ppo_pettingzoo_ma_atari
+
+    L = ppo_pettingzoo_ma_atari.main(["--num-envs", "8", "--num-steps", "16", "--total-timesteps", "256", "--num-minibatches", "4"])
+    assert L.hip and L.partial_scale and L.obs.dtype == torch.uint8 and tuple(L.obs.shape[2:]) == (84, 84, 6)
+    assert np.isfinite(L.last_metrics["loss"])
