@@ -1204,7 +1204,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   * the whole image (49 / 81 steps) is unrolled: every load is (per-image pointer + immediate); the image-pair loop is
 //     unrolled by two so that the prefetch of the next pair lands in the other half of the (logical) register arrays.
 // One partial dW per workgroup as in kernel W (same reduce kernels).
-template <class G, int KHW, int CSPLIT, int D>
+//   PAIR (staged for the next round's A/B, MI355PPO_WGRAD_TAPS=3, layer 2 only; not yet run on a GPU): with 32 input channels
+//   two neighbouring source columns are 256 contiguous bytes, so ONE 8-byte load per lane fetches both -- lanes 0-15 hold
+//   channels (2l, 2l+1) of column x, lanes 16-31 of column x+1 -- and the two tiles it feeds are {tap kw, tap kw+1} x
+//   {even, odd channels}: a permutation of dW's columns (both taps multiply the same dz fragment), undone when the partial
+//   is written.  Two loads per step instead of four beside the same 8 MFMAs.
+template <class G, int KHW, int CSPLIT, int D, bool PAIR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_taps_kernel(
     const float* __restrict__ src, const float* __restrict__ dz,
     float* __restrict__ part_w,      // [grid][Cout][K]
@@ -1228,7 +1233,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float bsum = 0.0f;
 
     auto img_of = [&](int pair) { const int i = 2 * pair + lh; return i < images ? i : images - 1; };
-    auto psrc = [&](int pair) { return src + (long long)img_of(pair) * kSrcImg + (kh0 * W * Cin + c0 + li); };
+    static_assert(!PAIR || (CSPLIT == 1 && KW == 4 && SS == 2 && (W & 1) == 0), "PAIR is the layer-2 configuration");
+    auto psrc = [&](int pair) { return src + (long long)img_of(pair) * kSrcImg + (kh0 * W * Cin + c0 + (PAIR ? 2 * li : li)); };
     auto pdz = [&](int pair) { return dz + (long long)img_of(pair) * kDzImg + (ci * 32 + li); };
 
     // Register "arrays" (every index below is a compile-time constant once the loops are unrolled; kept small, or hipcc
@@ -1238,14 +1244,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     static_assert((2 * S) % DR == 0 && (G::GY & 1) == 1, "ring / row-parity continuity across image pairs");
     float a[DR];                       // dz fragments: step s of pair parity P lives in a[(s + P * S) % DR]
     float bw[2][KHW][W];               // source-column window [(output row + P) & 1][tap row][source column]
+    float2 bw2[2][KHW][W / 2];         // PAIR: [..][tap row][source column pair]
     auto issue = [&](int P, int t, const float* ps, const float* pd) {      // the loads step t of a pair needs and step t-1 did not
         const int gy = t / GX, gx = t % GX;
         a[(t + P * S) % DR] = pd[t * Cout];
+        if constexpr (PAIR) {
 #pragma unroll
-        for (int r = 0; r < KHW; ++r)
+            for (int r = 0; r < KHW; ++r)
 #pragma unroll
-            for (int c = 0; c < KW; ++c)
-                if (gx == 0 || c >= KW - SS) bw[(gy + P) & 1][r][gx * SS + c] = ps[((gy * SS + r) * W + gx * SS + c) * Cin];
+                for (int pp = 0; pp < 2; ++pp)
+                    if (gx == 0 || pp == 1)
+                        bw2[(gy + P) & 1][r][gx + pp] = *reinterpret_cast<const float2*>(ps + ((gy * SS + r) * W + 2 * (gx + pp)) * Cin);
+        } else {
+#pragma unroll
+            for (int r = 0; r < KHW; ++r)
+#pragma unroll
+                for (int c = 0; c < KW; ++c)
+                    if (gx == 0 || c >= KW - SS) bw[(gy + P) & 1][r][gx * SS + c] = ps[((gy * SS + r) * W + gx * SS + c) * Cin];
+        }
     };
     auto run = [&](int P, int pair_raw) {
         // a workgroup with an odd number of pairs runs one dead pair (all dz fragments forced to 0) rather than leaving the
@@ -1263,11 +1279,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int gy = s / GX, gx = s % GX;
             const float av = live ? a[(s + P * S) % DR] : 0.0f;
             bsum += av;
+            if constexpr (PAIR) {
 #pragma unroll
-            for (int r = 0; r < KHW; ++r)
+                for (int r = 0; r < KHW; ++r)
 #pragma unroll
-                for (int c = 0; c < KW; ++c)
-                    acc[r * KW + c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[(gy + P) & 1][r][gx * SS + c], acc[r * KW + c], 0, 0, 0);
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const float2 v = bw2[(gy + P) & 1][r][gx + pp];
+                        acc[r * KW + 2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, v.x, acc[r * KW + 2 * pp], 0, 0, 0);
+                        acc[r * KW + 2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, v.y, acc[r * KW + 2 * pp + 1], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < KHW; ++r)
+#pragma unroll
+                    for (int c = 0; c < KW; ++c)
+                        acc[r * KW + c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[(gy + P) & 1][r][gx * SS + c], acc[r * KW + c], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (s + D < S) issue(P, s + D, ps, pd);
             else issue(P ^ 1, s + D - S, psn, pdn);
@@ -1291,7 +1318,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* pw = part_w + (size_t)blockIdx.x * Cout * K;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int kcol = ((kh0 + t / KW) * KW + t % KW) * Cin + c0 + li;
+        // PAIR: tile (r, 2pp + which) holds, in lane li, tap column 2pp + (li >> 4), channel 2 (li & 15) + which
+        const int kcol = PAIR ? ((kh0 + t / KW) * KW + 2 * ((t % KW) >> 1) + (li >> 4)) * Cin + 2 * (li & 15) + (t & 1)
+                              : ((kh0 + t / KW) * KW + t % KW) * Cin + c0 + li;
 #pragma unroll
         for (int e = 0; e < 16; ++e) pw[(size_t)(ci * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * K + kcol] = acc[t][e];
     }
@@ -1740,7 +1769,8 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     float* mid = part_b + (size_t)lparts * Cout;
     float* mid_b = mid + (size_t)((lparts + kRedChunk - 1) / kRedChunk) * total_w;
     // Tuning switches.  Layer 1: 3 = kernel R (rows, default), 2 = kernel D (direct dz), 1 = kernel W.
-    // Layers 2, 3: 1 = kernel T (taps, default), 2 = kernel T with the deeper layer-2 prefetch ring, 0 = kernel W.
+    // Layers 2, 3: 1 = kernel T (taps, default), 2 = kernel T with the deeper layer-2 prefetch ring, 3 = kernel T with paired
+    // 8-byte loads on layer 2 (staged, not yet run on a GPU), 0 = kernel W.
     static const int s_wk = getenv("MI355PPO_WGRAD") ? atoi(getenv("MI355PPO_WGRAD")) : 3;
     static const int s_wt = getenv("MI355PPO_WGRAD_TAPS") ? atoi(getenv("MI355PPO_WGRAD_TAPS")) : 1;
     const size_t smem = wgrad_smem(g.src_bytes, Hout * Hout, Cout);
@@ -1769,7 +1799,8 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
         wparts = grid = wgrad_grid((images + 1) / 2);
         auto k5 = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 5>;
         auto k8 = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 8>;
-        hipLaunchKernelGGL(s_wt == 2 ? k8 : k5, dim3(grid), dim3(256), 0, s, static_cast<const float*>(src), dz, part_w, part_b, (int)images);
+        auto kp = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 5, true>;
+        hipLaunchKernelGGL(s_wt == 3 ? kp : s_wt == 2 ? k8 : k5, dim3(grid), dim3(256), 0, s, static_cast<const float*>(src), dz, part_w, part_b, (int)images);
     } else if (s_wt && layer == 3) {
         wparts = grid = wgrad_grid((images + 1) / 2);
         auto k = conv_wgrad_taps_kernel<GeomConv3, 3, 2, 6>;
