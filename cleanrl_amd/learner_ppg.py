@@ -136,7 +136,7 @@ class PPGLearner(PPOLearner):
                 if (i + 1) % int(a.n_aux_grad_accum) == 0:
                     if self.hip:
                         if self.world_size > 1:
-                            torch.distributed.all_reduce(self.flat.grads, op=torch.distributed.ReduceOp.SUM)
+                            dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM)
                         self.optimizer_step_hip(self._last_lr)   # clip + Adam + zero the gradient buffer
                     else:
                         nn.utils.clip_grad_norm_(self.agent.parameters(), a.max_grad_norm)

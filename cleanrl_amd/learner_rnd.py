@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import numpy as np
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 import torch.optim as optim
@@ -257,7 +258,7 @@ class RNDPPOLearner(PPOLearner):
         rest = int_v_loss * a.vf_coef + forward_loss.view(())
         torch.autograd.backward([logits, v_ext, rest], [dlogits, dv_ext, None])                               # :518
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.flat.grads, op=torch.distributed.ReduceOp.SUM)
+            dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM)
         self.optimizer_step_hip(lr)                                                                           # :519-524
 
     def _minibatch_rnd_host(self, mb_inds, b_obs, rnd_next_obs, b_actions, b_logprobs, b_advantages, b_ext_returns,
