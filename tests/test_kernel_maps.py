@@ -1,0 +1,107 @@
+"""Lane-level emulation (numpy, CPU) of the register-streaming weight-gradient kernel ``conv_wgrad_taps_kernel``
+(cleanrl_amd/csrc/conv.hip, kernel T): who loads which element, which MFMA tile it feeds and where the tile's columns land
+in dW.  The kernel itself is checked on the GPU against float64 convolutions (tests/test_gpu_cnn.py); this restates its
+INDEX MAPS -- including the staged paired-load variant of layer 2, which has not run on a GPU yet -- so that a mapping
+mistake shows up here, on the CPU, as a wrong weight gradient."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+GEOM = {2: dict(H=20, W=20, Cin=32, KH=4, KW=4, SS=2, GY=9, GX=9, KHW=2, CSPLIT=1),
+        3: dict(H=9, W=9, Cin=64, KH=3, KW=3, SS=1, GY=7, GX=7, KHW=3, CSPLIT=2)}
+
+
+def _emulate(layer, src, dz, pair_loads):
+    """src (images, H, W, Cin), dz (images, GY, GX, 64) -> dW (64, Cin, KH, KW), one workgroup, as the kernel walks it."""
+    g = GEOM[layer]
+    H, W, Cin, KH, KW, SS, GY, GX, KHW, CSPLIT = (g[k] for k in ("H", "W", "Cin", "KH", "KW", "SS", "GY", "GX", "KHW", "CSPLIT"))
+    images, K = src.shape[0], KH * KW * Cin
+    npairs = (images + 1) // 2
+    dWt = np.zeros((64, K))                                   # [cout][(kh, kw, cin)]: the partial the kernel writes
+    li = np.arange(32)
+    for wave in range(4):
+        ci, sub = wave & 1, wave >> 1
+        kh0 = sub * KHW if CSPLIT == 1 else 0
+        c0 = sub * 32 if CSPLIT == 2 else 0
+        acc = np.zeros((KHW * KW, 32, 32))                    # [tile][i = cout within ci][j = lane li]
+        for pair in range(npairs):
+            for s in range(GY * GX):
+                gy, gx = divmod(s, GX)
+                # A operand: lane (li, lh) holds dz[image 2*pair + lh][pixel s][ci*32 + li]; 0 for a missing second image
+                a = np.zeros((32, 2))
+                for lh in range(2):
+                    img = 2 * pair + lh
+                    if img < images:
+                        a[:, lh] = dz[img, gy, gx, ci * 32 + li]
+                for r in range(KHW):
+                    y = gy * SS + kh0 + r
+                    if pair_loads:                            # one 8-byte load per lane covers two source columns
+                        for pp in range(2):
+                            for which in range(2):
+                                b = np.zeros((2, 32))
+                                for lh in range(2):
+                                    img = min(2 * pair + lh, images - 1)
+                                    flat = src[img, y, 2 * (gx + pp): 2 * (gx + pp) + 2, :].reshape(-1)     # 64 floats
+                                    b[lh] = flat[2 * li + which]
+                                acc[r * KW + 2 * pp + which] += a @ b
+                    else:
+                        for c in range(KW):
+                            b = np.zeros((2, 32))
+                            for lh in range(2):
+                                img = min(2 * pair + lh, images - 1)
+                                b[lh] = src[img, y, gx * SS + c, c0 + li]
+                            acc[r * KW + c] += a @ b
+        for t in range(KHW * KW):                             # partial write: tile t -> dW columns
+            if pair_loads:
+                kcol = ((kh0 + t // KW) * KW + 2 * ((t % KW) >> 1) + (li >> 4)) * Cin + 2 * (li & 15) + (t & 1)
+            else:
+                kcol = ((kh0 + t // KW) * KW + t % KW) * Cin + c0 + li
+            dWt[ci * 32:(ci + 1) * 32, kcol] = acc[t]
+    return dWt.reshape(64, KH, KW, Cin).transpose(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("layer,pair_loads,images", [(2, False, 3), (2, True, 3), (2, True, 2), (3, False, 3)])
+def test_kernel_T_index_maps_give_the_weight_gradient(layer, pair_loads, images):
+    g = GEOM[layer]
+    rs = np.random.RandomState(layer * 10 + images + int(pair_loads))
+    src = rs.standard_normal((images, g["H"], g["W"], g["Cin"]))
+    dz = rs.standard_normal((images, g["GY"], g["GX"], 64))
+    x = torch.from_numpy(src).permute(0, 3, 1, 2)
+    W = torch.zeros(64, g["Cin"], g["KH"], g["KW"], dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(x, W, None, stride=g["SS"])
+    (ref,) = torch.autograd.grad(out, W, torch.from_numpy(dz).permute(0, 3, 1, 2))
+    got = _emulate(layer, src, dz, pair_loads)
+    assert np.abs(got - ref.numpy()).max() <= 1e-9 * np.abs(ref.numpy()).max()
+
+
+def test_kernel_R_index_maps_give_the_layer1_weight_gradient():
+    """``conv_wgrad_rows_kernel`` (kernel R): wave w owns output rows 5w..5w+4; lane (li, lh) supplies, for pixel 2j + lh of a
+    row, the packed dword of tap row li/8 (+4 for the second dword), tap columns-with-channels 4(li%8)..+3; tile 4h + c holds
+    byte c of dword h.  Emulated on uint8 frames; the 1/255 is applied to the reduced sum, as the reduce kernel does."""
+    rs = np.random.RandomState(5)
+    images = 2
+    frames = rs.randint(0, 256, size=(images, 84, 84, 4)).astype(np.float64)          # (H, W, C) rows of the rollout buffer
+    dz = rs.standard_normal((images, 20, 20, 32))
+    li = np.arange(32)
+    dWt = np.zeros((32, 256))                                                          # [cout][(kh, kw, c)]
+    for wave in range(4):
+        acc = np.zeros((8, 32, 32))
+        for img in range(images):
+            flat = frames[img].reshape(84, 84 * 4)                                     # a source row = 336 bytes
+            for r in range(5):
+                gy = 5 * wave + r
+                for j in range(10):
+                    a = np.stack([dz[img, gy, 2 * j + lh, li] for lh in range(2)], axis=1)          # (32, 2)
+                    for h in range(2):                                                 # dword h: tap rows li/8 + 4h
+                        for c in range(4):                                             # byte c of the dword
+                            b = np.stack([flat[4 * gy + (li >> 3) + 4 * h, 16 * (2 * j + lh) + 4 * (li & 7) + c] for lh in range(2)])
+                            acc[4 * h + c] += a @ b
+        for t in range(8):
+            kcol = ((li >> 3) + 4 * (t >> 2)) * 32 + 4 * (li & 7) + (t & 3)
+            dWt[:, kcol] += acc[t]
+    got = (dWt / 255.0).reshape(32, 8, 8, 4).transpose(0, 3, 1, 2)
+    x = torch.from_numpy(frames / 255.0).permute(0, 3, 1, 2)
+    W = torch.zeros(32, 4, 8, 8, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, W, None, stride=4), W, torch.from_numpy(dz).permute(0, 3, 1, 2))
+    assert np.abs(got - ref.numpy()).max() <= 1e-9 * np.abs(ref.numpy()).max()
