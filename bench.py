@@ -309,7 +309,8 @@ def main():
                 launches = kn * (16 if k.endswith(f"@{N}") else 1)          # rollout-sized launches are sampled 1 in 16
                 out["kernels"][k] = {"avg_us": kus, "launches_timed": kn, "TFLOPs": conv_flops[k] / kus / 1e6,
                                      "frac_of_f32_mfma_peak": conv_flops[k] / kus / 1e6 / MFMA_F32_PEAK_TFLOPS,
-                                     "ms_per_step": kus * launches / cli.steps / 1e3}
+                                     "ms_per_step": kus * launches / cli.steps / 1e3,
+                                     "hbm_bytes_per_launch_pmc": _traffic_of(k)}
         elif not cli.no_kernel_timing:
             us, n = timer.mean_us("obs_gather")
             alg = OBS_ROW_BYTES * 5 * M
