@@ -50,6 +50,7 @@ class PPGLearner(PPOLearner):
         self.aux_returns = torch.zeros((self.T, R), device=aux_dev)
         self._aux_update = 0
         self._capture, self._stale_grads = False, None
+        self._aux_tail_step = 0                         # Adam step count of the auxiliary value head (see _aux_step_hip)
         self._last_lr = float(args.learning_rate)
         self.last_aux = {}
 
@@ -80,6 +81,26 @@ class PPGLearner(PPOLearner):
         return m
 
     # ------------------------------------------------------------------ auxiliary phase
+    def _aux_step_hip(self, lr: float) -> None:
+        """One optimiser step of the auxiliary phase on the flat buffers with ``torch.optim.Adam``'s bookkeeping: the
+        auxiliary value head receives no gradient during the policy phases, so torch never creates its Adam state there
+        and its bias-correction step count only advances here, while every other parameter's advances in both phases.  The
+        fused kernel takes ONE step count per call, hence two calls on the two contiguous ranges of the flat buffer (the
+        head's two tensors are its tail), after one global-norm clip coefficient for both (``clip_grad_norm_`` over all
+        parameters, :466): the coefficient goes in as ``grad_scale`` and the kernel's own clip is switched off."""
+        f, a = self.flat, self.args
+        tail = sum(p.numel() for p in self.agent.aux_critic.parameters())
+        n_main = f.numel - tail
+        assert f._params_list[-1] is self.agent.aux_critic.bias and n_main % 4 == 0
+        scale = 1.0 / self.world_size
+        norm = float(torch.linalg.vector_norm(f.grads)) * scale
+        coef = min(1.0, a.max_grad_norm / (norm + 1e-6))
+        f.step += 1
+        self._aux_tail_step += 1
+        for lo, hi, step in ((0, n_main, f.step), (n_main, f.numel, self._aux_tail_step)):
+            self.ops.clip_adam_(f.params[lo:hi], f.grads[lo:hi], f.exp_avg[lo:hi], f.exp_avg_sq[lo:hi], step, lr, float("inf"),
+                                grad_scale=scale * coef, eps=self.adam_eps)
+
     def _aux_rows(self, cols):
         """Whole rollouts of the stored envs ``cols`` as flat (T * len(cols)) observation rows (:436-438)."""
         if isinstance(cols, np.ndarray):
@@ -137,7 +158,7 @@ class PPGLearner(PPOLearner):
                     if self.hip:
                         if self.world_size > 1:
                             dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM)
-                        self.optimizer_step_hip(self._last_lr)   # clip + Adam + zero the gradient buffer
+                        self._aux_step_hip(self._last_lr)        # clip + Adam + zero the gradient buffer
                     else:
                         nn.utils.clip_grad_norm_(self.agent.parameters(), a.max_grad_norm)
                         self.optimizer.step()

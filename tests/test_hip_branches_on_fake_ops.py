@@ -1,0 +1,301 @@
+"""The HIP-path BRANCHES of the learners (Python side: index plumbing, buffer shapes, argument order, bookkeeping) run on CPU
+against a stand-in for ``cleanrl_amd.ops`` that has the same signatures and the same dtype / shape / contiguity checks as
+the real wrappers but computes with the host formulas.  The kernels themselves are checked on the GPU (tests/test_gpu_*);
+what this catches without one is a wrong argument, a non-contiguous view, a missing buffer or a mis-indexed minibatch in the
+code that calls them -- in particular in the learners added after the round's GPU minutes were spent (LSTM, RND, PPG,
+procgen, two-player Atari).  Each learner is run twice on identical inputs, once on its host path and once on its HIP
+branch over the stand-in ops, and must agree.
+
+Test-side only: the product never imports this module and has no switch that selects it."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from torch.distributions.categorical import Categorical
+
+from cleanrl_amd import envs as E, host_ops
+from cleanrl_amd.agents import AtariLSTMAgent, MAAtariAgent, PPGAgent, ProcgenAgent, RNDAgent, RNDModel
+from cleanrl_amd.flat import FlatParams
+from cleanrl_amd.learner import PPOLearner
+from cleanrl_amd.learner_lstm import LSTMPPOLearner
+from cleanrl_amd.learner_ppg import PPGLearner
+from cleanrl_amd.learner_rnd import RNDPPOLearner, _Combined
+from cleanrl_amd.learner_smoke import default_args
+
+
+def _chk(t, dtype, name, shape=None):
+    assert isinstance(t, torch.Tensor), name
+    assert t.dtype == dtype, f"{name}: dtype {t.dtype}"
+    assert t.is_contiguous(), f"{name}: must be contiguous"
+    if shape is not None:
+        assert tuple(t.shape) == tuple(shape), f"{name}: shape {tuple(t.shape)} != {tuple(shape)}"
+    return t
+
+
+class FakeOps:
+    """Signature-compatible CPU stand-in for the functions of cleanrl_amd/ops.py the learners call."""
+
+    LOSS_SCALAR_NAMES = ("loss", "pg_loss", "v_loss", "entropy", "old_approx_kl", "approx_kl", "clipfrac")
+
+    @staticmethod
+    def gae(rewards, dones, values, next_done, next_value, gamma, gae_lambda, advantages=None, returns=None, variant=0):
+        T, N = rewards.shape
+        for t, n in ((rewards, "rewards"), (dones, "dones"), (values, "values"), (advantages, "advantages"), (returns, "returns")):
+            _chk(t, torch.float32, n, (T, N))
+        _chk(next_done.reshape(-1), torch.float32, "next_done", (N,))
+        _chk(next_value.reshape(-1), torch.float32, "next_value", (N,))
+        adv, ret = host_ops.gae(rewards, dones, values, next_done.reshape(-1), next_value.reshape(1, -1), gamma, gae_lambda)
+        advantages.copy_(adv)
+        returns.copy_(ret)
+        return advantages, returns
+
+    @staticmethod
+    def categorical_sample(logits, noise_exp1=None, seed=0, offset=0, action_f32_out=None, logprob_out=None,
+                           want_entropy=True, want_i64=True):
+        B, A = logits.shape
+        _chk(logits, torch.float32, "logits", (B, A))
+        assert isinstance(seed, int) and isinstance(offset, int) and offset > 0
+        probs = Categorical(logits=logits)
+        a = probs.sample()
+        if action_f32_out is not None:
+            _chk(action_f32_out, torch.float32, "action_f32_out", (B,)).copy_(a.float())
+        lp = probs.log_prob(a)
+        if logprob_out is not None:
+            _chk(logprob_out, torch.float32, "logprob_out", (B,)).copy_(lp)
+        return a, action_f32_out, lp, probs.entropy() if want_entropy else None
+
+    @staticmethod
+    def ppo_loss_categorical(new_logits, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values, clip_coef,
+                             ent_coef, vf_coef, norm_adv=True, clip_vloss=True, scalars_out=None, dlogits_out=None, dvalue_out=None):
+        M, A = new_logits.shape
+        _chk(new_logits, torch.float32, "new_logits", (M, A))
+        _chk(new_value.reshape(-1), torch.float32, "new_value", (M,))
+        _chk(mb_inds, torch.int64, "mb_inds", (M,))
+        Bf = b_logprobs.numel()
+        for t, n in ((b_logprobs, "b_logprobs"), (b_advantages, "b_advantages"), (b_returns, "b_returns"), (b_values, "b_values"),
+                     (b_actions, "b_actions")):
+            _chk(t.reshape(-1), torch.float32, n, (Bf,))
+        assert not new_logits.requires_grad and not new_value.requires_grad, "the kernel takes detached network outputs"
+        logits = new_logits.clone().requires_grad_(True)
+        value = new_value.reshape(-1).clone().requires_grad_(True)
+        probs = Categorical(logits=logits)
+        acts = b_actions.reshape(-1).long()[mb_inds]
+        loss, sc = host_ops.ppo_loss(probs.log_prob(acts), probs.entropy(), value, b_logprobs.reshape(-1)[mb_inds],
+                                     b_advantages.reshape(-1)[mb_inds], b_returns.reshape(-1)[mb_inds],
+                                     b_values.reshape(-1)[mb_inds], clip_coef, ent_coef, vf_coef, norm_adv, clip_vloss)
+        loss.backward()
+        if scalars_out is not None:
+            _chk(scalars_out, torch.float32, "scalars_out", (7,)).copy_(sc)
+        return (scalars_out if scalars_out is not None else sc), logits.grad, value.grad
+
+    @staticmethod
+    def obs_u8_to_f32(src_u8, inds=None, out=None, scale_255=True):
+        _chk(src_u8, torch.uint8, "src_u8")
+        if inds is not None:
+            _chk(inds, torch.int64, "inds")
+        x = (src_u8 if inds is None else src_u8[inds]).float()
+        if scale_255:
+            x = x / 255.0
+        if out is None:
+            return x
+        return _chk(out, torch.float32, "out", tuple(x.shape)).copy_(x)
+
+    @staticmethod
+    def obs_nchw_to_nhwc_u8(src, out=None):
+        _chk(src, torch.uint8, "src")
+        rows, C, H, W = src.shape
+        return _chk(out, torch.uint8, "out", (rows, H, W, C)).copy_(src.permute(0, 2, 3, 1))
+
+    @staticmethod
+    def clip_adam_(params, grads, exp_avg, exp_avg_sq, step, lr, max_grad_norm, grad_scale=1.0, beta1=0.9, beta2=0.999,
+                   eps=1e-5, total_norm_out=None):
+        n = params.numel()
+        for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+            _chk(t, torch.float32, nm, (n,))
+        assert step >= 1
+        with torch.no_grad():
+            g = grads * grad_scale
+            norm = g.norm()
+            g = g * torch.clamp(max_grad_norm / (norm + 1e-6), max=1.0)
+            exp_avg.lerp_(g, 1 - beta1)
+            exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+            bc1, bc2 = 1 - beta1**step, 1 - beta2**step
+            params.addcdiv_(exp_avg, (exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+            grads.zero_()
+            if total_norm_out is not None:
+                total_norm_out.fill_(norm)
+        return total_norm_out
+
+
+def _to_fake_hip(L, flat_module=None):
+    """Put a learner that was built on the CPU into the state its HIP branch expects (what ``__init__`` allocates when
+    ``device.type == 'cuda'``), with the stand-in ops.  Frames are then handed to ``observe`` as uint8 tensors."""
+    dev, T, N = L.device, L.T, L.N
+    L.hip, L.ops, L.optimizer = True, FakeOps, None
+    L.flat = FlatParams(flat_module if flat_module is not None else L.agent)
+    L.agent.rng.seed = 1
+    if L.image:
+        L.nhwc = True
+        if not L.hwc_frames:
+            c, h, w = L.obs_shape
+            L.obs_shape = (h, w, c)
+        L.relayout = not L.hwc_frames
+        L.obs = torch.zeros((T, N) + L.obs_shape, dtype=torch.uint8)
+        L.boot_obs = torch.zeros((N,) + L.obs_shape, dtype=torch.uint8)
+        L.stage_obs = torch.zeros((N,) + L.frame_shape, dtype=torch.uint8) if L.relayout else None
+        L._x_roll = torch.empty((N,) + L.obs_shape)
+    L._x_mb = None
+    n_upd = int(L.args.update_epochs) * int(L.args.num_minibatches)
+    L._scalars = torch.zeros((n_upd, 7))
+    L._inds_dev = torch.empty(L.batch_size, dtype=torch.int64)
+    L._inds_pin = torch.empty(L.batch_size, dtype=torch.int64)
+    L._total_norm = torch.zeros(1)
+    return L
+
+
+def _frames(rs, T, N, shape):
+    return rs.randint(0, 256, size=(T + 1, N) + shape).astype(np.uint8)
+
+
+def _drive(L, frames, dones, rewards, sample_seed, fake, extra_step=None):
+    as_obs = (lambda x: torch.from_numpy(x)) if fake else (lambda x: x)
+    L.observe(0, as_obs(frames[0]), torch.from_numpy(dones[0]) if fake else dones[0])
+    torch.manual_seed(sample_seed)
+    for step in range(L.T):
+        L.act(step)
+        L.store_reward(step, rewards[step])
+        L.observe(step + 1, as_obs(frames[step + 1]), torch.from_numpy(dones[step + 1]) if fake else dones[step + 1])
+        if extra_step is not None:
+            extra_step(L, step)
+    L.finish_rollout()
+
+
+def _params(mods):
+    return torch.cat([p.detach().reshape(-1) for m in mods for p in m.parameters()])
+
+
+def _pair(make_agent, make_learner, flat_module=None):
+    torch.manual_seed(0)
+    host = make_learner(make_agent())
+    torch.manual_seed(0)
+    fake = make_learner(make_agent())
+    return host, _to_fake_hip(fake, flat_module(fake) if flat_module else None)
+
+
+def _episode_streams(rs, T, N):
+    dones = (rs.random_sample((T + 1, N)) < 0.2).astype(np.float32)
+    dones[0] = 0
+    return dones, rs.randint(-1, 2, size=(T, N)).astype(np.float32)
+
+
+def _compare_rollout_and_update(host, fake, frames, dones, rewards, mods_host, mods_fake, update_seed=3, lr=2.5e-4, extra_step=None,
+                                tol=2e-5):
+    _drive(host, frames, dones, rewards, 11, False, extra_step)
+    _drive(fake, frames, dones, rewards, 11, True, extra_step)
+    for name in ("actions", "logprobs", "values", "dones", "rewards", "advantages", "returns"):
+        a, b = getattr(host, name), getattr(fake, name)
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), name
+    np.random.seed(update_seed)
+    torch.manual_seed(update_seed)
+    mh = host.update(lr)
+    np.random.seed(update_seed)
+    torch.manual_seed(update_seed)
+    mf = fake.update(lr)
+    assert mh["num_updates"] == mf["num_updates"]
+    for k in ("loss", "policy_loss", "value_loss", "entropy", "approx_kl", "clipfrac"):
+        assert abs(mh[k] - mf[k]) <= 1e-5 * max(1.0, abs(mh[k])), (k, mh[k], mf[k])
+    d = (_params(mods_host) - _params(mods_fake)).abs()
+    # Adam's first steps move a parameter by ~lr * sign(g): the handful whose gradient is rounding noise may differ by up to
+    # 2 lr between two correct implementations; everything else must agree closely
+    assert (d <= tol).float().mean().item() >= 1.0 - 1e-5 and d.max().item() <= 2.5 * lr, \
+        f"parameters diverge between the host path and the HIP branch: max {d.max().item()}, {(d > tol).sum().item()} above {tol}"
+    fake.flat.check_views()
+    return mh, mf
+
+
+def test_lstm_hip_branch():
+    envs = SimpleNamespace(single_observation_space=E.Box(0, 255, (1, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+    T, N = 6, 4
+    args = lambda: default_args(num_steps=T, num_minibatches=2, update_epochs=2)
+    host, fake = _pair(lambda: AtariLSTMAgent(envs),
+                       lambda ag: LSTMPPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    fake._env_dev, fake._env_pin = torch.empty(N, dtype=torch.int64), torch.empty(N, dtype=torch.int64)
+    rs = np.random.RandomState(1)
+    dones, rewards = _episode_streams(rs, T, N)
+    _compare_rollout_and_update(host, fake, _frames(rs, T, N, (1, 84, 84)), dones, rewards, [host.agent], [fake.agent])
+    assert torch.allclose(host.next_lstm_state[0], fake.next_lstm_state[0], atol=1e-6)
+    assert fake.obs.dtype == torch.uint8 and tuple(fake.obs.shape[2:]) == (84, 84, 1)
+
+
+def test_rnd_hip_branch():
+    envs = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(5))
+    T, N = 4, 4
+    args = lambda: default_args(num_steps=T, num_minibatches=2, update_epochs=1, gamma=0.999, int_gamma=0.99, ent_coef=0.001,
+                                update_proportion=0.25, int_coef=1.0, ext_coef=2.0, learning_rate=1e-4)
+
+    def make(ag):
+        return RNDPPOLearner(ag, RNDModel(4, 5), args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu"))
+
+    host, fake = _pair(lambda: RNDAgent(envs), make, flat_module=lambda L: _Combined(L.agent, L.rnd_model.predictor))
+    fake._extra = torch.zeros((2, 2))
+    fake._zeros_TN, fake._zeros_N = torch.zeros((T, N)), torch.zeros(N)
+    rs = np.random.RandomState(2)
+    warm = rs.randint(0, 256, size=(32, 1, 84, 84)).astype(np.float64)
+    for L in (host, fake):
+        L.obs_rms.update(warm)
+    dones, rewards = _episode_streams(rs, T, N)
+    mh, mf = _compare_rollout_and_update(host, fake, _frames(rs, T, N, (4, 84, 84)), dones, rewards,
+                                         [host.agent, host.rnd_model.predictor], [fake.agent, fake.rnd_model.predictor], lr=1e-4,
+                                         extra_step=lambda L, step: L.curiosity(step))
+    assert torch.allclose(host.int_returns, fake.int_returns, rtol=1e-5, atol=1e-6) and host.int_returns.abs().sum() > 0
+    assert torch.allclose(host.curiosity_rewards, fake.curiosity_rewards, rtol=1e-5, atol=1e-7)
+    assert abs(mh["fwd_loss"] - mf["fwd_loss"]) <= 1e-5 * max(1.0, abs(mh["fwd_loss"]))
+    assert np.allclose(host.obs_rms.mean, fake.obs_rms.mean, atol=1e-4) and np.allclose(host.obs_rms.var, fake.obs_rms.var, rtol=1e-5)
+    assert fake.flat.numel == sum(p.numel() for p in fake.combined_parameters)
+
+
+def test_procgen_and_ppg_hip_branches(capsys):
+    envs = SimpleNamespace(single_observation_space=E.Box(0, 255, (64, 64, 3), np.uint8), single_action_space=E.Discrete(15))
+    T, N = 4, 4
+    rs = np.random.RandomState(3)
+    frames = _frames(rs, T, N, (64, 64, 3))
+    dones, rewards = _episode_streams(rs, T, N)
+    args = lambda: default_args(num_steps=T, num_minibatches=2, update_epochs=2, gamma=0.999, clip_coef=0.2)
+    host, fake = _pair(lambda: ProcgenAgent(envs),
+                       lambda ag: PPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    _compare_rollout_and_update(host, fake, frames, dones, rewards, [host.agent], [fake.agent], lr=5e-4)
+    assert fake.hwc_frames and not fake.relayout and fake.stage_obs is None and tuple(fake.obs.shape[2:]) == (64, 64, 3)
+
+    pargs = lambda: default_args(num_steps=T, num_minibatches=2, gamma=0.999, clip_coef=0.2, adv_norm_fullbatch=True, e_policy=1,
+                                 e_auxiliary=2, beta_clone=1.0, num_aux_rollouts=2, n_aux_grad_accum=1, aux_batch_rollouts=N,
+                                 n_iteration=1, learning_rate=5e-4)
+    host, fake = _pair(lambda: PPGAgent(envs),
+                       lambda ag: PPGLearner(ag, pargs(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    _compare_rollout_and_update(host, fake, frames, dones, rewards, [host.agent], [fake.agent], lr=5e-4)
+    assert fake.adam_eps == 1e-8 and fake._stale_grads is not None            # the last policy update of the phase was captured
+    np.random.seed(4)
+    ah = host.aux_phase()
+    np.random.seed(4)
+    af = fake.aux_phase()
+    capsys.readouterr()
+    for k in ah:
+        assert abs(ah[k] - af[k]) <= 2e-5 * max(1.0, abs(ah[k])), (k, ah[k], af[k])
+    # the rebuilt stale gradient reproduces the reference quirk: both paths end at the same parameters
+    assert (_params([host.agent]) - _params([fake.agent])).abs().max().item() <= 5e-5
+    assert torch.equal(host.aux_obs, fake.aux_obs)
+
+
+def test_two_player_atari_hip_branch():
+    envs = SimpleNamespace(single_observation_space=E.Box(0, 255, (84, 84, 6), np.uint8), single_action_space=E.Discrete(6))
+    T, N = 4, 4
+    rs = np.random.RandomState(5)
+    frames = _frames(rs, T, N, (84, 84, 6))
+    frames[..., 4:] = rs.randint(0, 2, size=frames[..., 4:].shape)
+    dones, rewards = _episode_streams(rs, T, N)
+    args = lambda: default_args(num_steps=T, num_minibatches=2, update_epochs=1)
+    host, fake = _pair(lambda: MAAtariAgent(envs),
+                       lambda ag: PPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    _compare_rollout_and_update(host, fake, frames, dones, rewards, [host.agent], [fake.agent])
+    assert fake.partial_scale and fake.hwc_frames
