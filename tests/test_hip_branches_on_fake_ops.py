@@ -299,3 +299,28 @@ def test_two_player_atari_hip_branch():
                        lambda ag: PPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
     _compare_rollout_and_update(host, fake, frames, dones, rewards, [host.agent], [fake.agent])
     assert fake.partial_scale and fake.hwc_frames
+
+
+def test_core_learner_hip_branch_mlp_and_unfused_atari(monkeypatch):
+    """The same harness on the GPU-validated core: ppo.py's MLP agent (vector observations) and the NatureCNN agent on the
+    library-convolution branch (``MI355PPO_CNN=miopen``: K5 gather + torch Conv2d) -- a CPU regression net for the HIP branch
+    of ``PPOLearner`` itself."""
+    from cleanrl_amd.agents import AtariAgent, MlpAgent
+
+    T, N = 8, 4
+    rs = np.random.RandomState(7)
+    dones, rewards = _episode_streams(rs, T, N)
+    envs = SimpleNamespace(single_observation_space=E.Box(-1, 1, (4,)), single_action_space=E.Discrete(2))
+    args = lambda: default_args(num_steps=T, num_minibatches=2, update_epochs=2, clip_coef=0.2)
+    host, fake = _pair(lambda: MlpAgent(envs),
+                       lambda ag: PPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    obs = rs.standard_normal((T + 1, N, 4)).astype(np.float32)
+    _compare_rollout_and_update(host, fake, obs, dones, rewards, [host.agent], [fake.agent])
+
+    monkeypatch.setenv("MI355PPO_CNN", "miopen")
+    envs = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+    host, fake = _pair(lambda: AtariAgent(envs),
+                       lambda ag: PPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    fake.fused_cnn = False
+    _compare_rollout_and_update(host, fake, _frames(rs, T, N, (4, 84, 84)), dones, rewards, [host.agent], [fake.agent])
+    assert fake.relayout and tuple(fake.obs.shape[2:]) == (84, 84, 4)
