@@ -91,6 +91,44 @@ class FakeOps:
         return (scalars_out if scalars_out is not None else sc), logits.grad, value.grad
 
     @staticmethod
+    def normal_sample(mean, logstd, noise=None, seed=0, offset=0, action_out=None, logprob_out=None):
+        B, D = mean.shape
+        _chk(mean, torch.float32, "mean", (B, D))
+        _chk(logstd.reshape(-1), torch.float32, "logstd", (D,))
+        probs = torch.distributions.Normal(mean, torch.exp(logstd.reshape(1, D).expand_as(mean)))
+        a = probs.sample()
+        lp, ent = probs.log_prob(a).sum(1), probs.entropy().sum(1)
+        if action_out is not None:
+            _chk(action_out, torch.float32, "action_out", (B, D)).copy_(a)
+        if logprob_out is not None:
+            _chk(logprob_out, torch.float32, "logprob_out", (B,)).copy_(lp)
+        return (action_out if action_out is not None else a), lp, ent
+
+    @staticmethod
+    def ppo_loss_normal(new_mean, logstd, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values, clip_coef,
+                        ent_coef, vf_coef, norm_adv=True, clip_vloss=True, scalars_out=None):
+        M, D = new_mean.shape
+        _chk(new_mean, torch.float32, "new_mean", (M, D))
+        _chk(logstd.reshape(-1), torch.float32, "logstd", (D,))
+        _chk(new_value.reshape(-1), torch.float32, "new_value", (M,))
+        _chk(mb_inds, torch.int64, "mb_inds", (M,))
+        Bf = b_logprobs.numel()
+        _chk(b_actions.reshape(Bf, D), torch.float32, "b_actions", (Bf, D))
+        assert not new_mean.requires_grad and not new_value.requires_grad and not logstd.requires_grad
+        mean = new_mean.clone().requires_grad_(True)
+        ls = logstd.reshape(1, D).clone().requires_grad_(True)
+        value = new_value.reshape(-1).clone().requires_grad_(True)
+        probs = torch.distributions.Normal(mean, torch.exp(ls.expand_as(mean)))
+        acts = b_actions.reshape(Bf, D)[mb_inds]
+        loss, sc = host_ops.ppo_loss(probs.log_prob(acts).sum(1), probs.entropy().sum(1), value, b_logprobs.reshape(-1)[mb_inds],
+                                     b_advantages.reshape(-1)[mb_inds], b_returns.reshape(-1)[mb_inds],
+                                     b_values.reshape(-1)[mb_inds], clip_coef, ent_coef, vf_coef, norm_adv, clip_vloss)
+        loss.backward()
+        if scalars_out is not None:
+            _chk(scalars_out, torch.float32, "scalars_out", (7,)).copy_(sc)
+        return (scalars_out if scalars_out is not None else sc), mean.grad, ls.grad.reshape(-1), value.grad
+
+    @staticmethod
     def obs_u8_to_f32(src_u8, inds=None, out=None, scale_255=True):
         _chk(src_u8, torch.uint8, "src_u8")
         if inds is not None:
@@ -324,3 +362,20 @@ def test_core_learner_hip_branch_mlp_and_unfused_atari(monkeypatch):
     fake.fused_cnn = False
     _compare_rollout_and_update(host, fake, _frames(rs, T, N, (4, 84, 84)), dones, rewards, [host.agent], [fake.agent])
     assert fake.relayout and tuple(fake.obs.shape[2:]) == (84, 84, 4)
+
+
+def test_core_learner_hip_branch_continuous_actions():
+    """ppo_continuous_action.py's agent (Normal policy with a state-independent log-std): K2-normal sampling, K3-normal loss,
+    the log-std gradient added onto the flat buffer."""
+    from cleanrl_amd.agents import ContinuousAgent
+
+    T, N = 8, 4
+    rs = np.random.RandomState(9)
+    dones, rewards = _episode_streams(rs, T, N)
+    envs = SimpleNamespace(single_observation_space=E.Box(-10, 10, (17,)), single_action_space=E.Box(-1, 1, (6,)))
+    args = lambda: default_args(num_steps=T, num_minibatches=2, update_epochs=2, clip_coef=0.2, ent_coef=0.0, learning_rate=3e-4)
+    host, fake = _pair(lambda: ContinuousAgent(envs),
+                       lambda ag: PPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    obs = rs.standard_normal((T + 1, N, 17)).astype(np.float32)
+    _compare_rollout_and_update(host, fake, obs, dones, rewards, [host.agent], [fake.agent], lr=3e-4)
+    assert fake.agent.actor_logstd.abs().sum().item() > 0                    # the shared log-std moved
