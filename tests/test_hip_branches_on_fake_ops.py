@@ -379,3 +379,113 @@ def test_core_learner_hip_branch_continuous_actions():
     obs = rs.standard_normal((T + 1, N, 17)).astype(np.float32)
     _compare_rollout_and_update(host, fake, obs, dones, rewards, [host.agent], [fake.agent], lr=3e-4)
     assert fake.agent.actor_logstd.abs().sum().item() > 0                    # the shared log-std moved
+
+
+class FakeCnn:
+    """CPU stand-ins for the conv entry points of cleanrl_amd/cnn.py (same signatures, layouts and layer / mode pairing).  A
+    repacked matrix is represented by its buffer's address -> a snapshot of the weights AT REPACK TIME, so a stale cached
+    matrix (a missed ``weights_version`` bump) computes with stale weights and the comparison with the host path fails."""
+
+    def __init__(self):
+        self.reg = {}
+        self.repacks = 0
+
+    def repack_weights(self, W, layer, mode=0, out=None):
+        from cleanrl_amd import cnn
+
+        cin, cout, k, _, _, _ = cnn.LAYERS[layer]
+        _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
+        assert (layer, mode) in ((1, 0), (2, 0), (3, 0), (3, 1), (2, 2), (3, 3))
+        numel = cnn.BT_CLASSES_NUMEL if mode == 3 else W.numel()
+        if out is None:
+            out = torch.empty(numel)
+        _chk(out, torch.float32, "Bt", (numel,))
+        self.reg[out.data_ptr()] = (W.detach().clone(), layer, mode)
+        self.repacks += 1
+        return out
+
+    def _w(self, Bt, layer, modes):
+        W, l, m = self.reg[Bt.data_ptr()]
+        assert l == layer and m in modes, (l, m, layer, modes)
+        return W
+
+    def conv_fwd(self, src, Bt, bias, layer, inds=None, out=None, variant=0):
+        from cleanrl_amd import cnn
+
+        cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
+        W = self._w(Bt, layer, (0,))
+        x = src if inds is None else src[inds]
+        if layer == 1:
+            _chk(src, torch.uint8, "src")
+            x = x.float() / 255.0
+        else:
+            assert inds is None
+            _chk(src, torch.float32, "src", (src.shape[0], hin, hin, cin))
+        y = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), W, bias, stride=s)).permute(0, 2, 3, 1)
+        if out is None:
+            return y.contiguous()
+        return _chk(out, torch.float32, "out", tuple(y.shape)).copy_(y)
+
+    def conv_dgrad(self, dz, Bt, act_in, layer, out=None, variant=0):
+        from cleanrl_amd import cnn
+
+        cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
+        W = self._w(Bt, layer, (3,) if variant == 5 else ((1,) if layer == 3 else (2,)))
+        _chk(dz, torch.float32, "dz", (dz.shape[0], hout, hout, cout))
+        _chk(act_in, torch.float32, "act_in", (dz.shape[0], hin, hin, cin))
+        gi = torch.nn.functional.conv_transpose2d(dz.permute(0, 3, 1, 2), W, stride=s).permute(0, 2, 3, 1) * (act_in > 0)
+        if out is None:
+            return gi.contiguous()
+        return _chk(out, torch.float32, "out", tuple(gi.shape)).copy_(gi)
+
+    def conv_wgrad(self, src, dz, layer, inds=None):
+        from cleanrl_amd import cnn
+
+        cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
+        _chk(dz, torch.float32, "dz", (dz.shape[0], hout, hout, cout))
+        x = src if inds is None else src[inds]
+        if layer == 1:
+            _chk(src, torch.uint8, "src")
+            x = x.float() / 255.0
+        dW = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (cout, cin, k, k), dz.permute(0, 3, 1, 2), stride=s)
+        return dW, dz.sum((0, 1, 2))
+
+    def trunk_fwd(self, obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3):
+        self.conv_fwd(obs_u8, bt1, b1, 1, inds, a1)
+        self.conv_fwd(a1, bt2, b2, 2, None, a2)
+        return self.conv_fwd(a2, bt3, b3, 3, None, a3)
+
+
+def test_fused_cnn_branch_and_weight_matrix_cache(monkeypatch):
+    """The main path's Python (``AtariAgent.heads_u8`` -> ``cnn.NatureTrunkFn`` / ``LinearReLUHwcFn``, the learner's repacked-
+    matrix cache with its version bumps) over CPU stand-ins for the conv entry points: rollout, GAE and 2 x 2 minibatch
+    updates must agree with the host path, which they only can if every forward after an optimiser step re-derives the
+    matrices."""
+    from cleanrl_amd import cnn
+    from cleanrl_amd.agents import AtariAgent
+
+    fk = FakeCnn()
+    for name in ("repack_weights", "conv_fwd", "conv_dgrad", "conv_wgrad", "trunk_fwd"):
+        monkeypatch.setattr(cnn, name, getattr(fk, name))
+    monkeypatch.setattr(cnn, "heads_supported", lambda actor, critic: False)      # HeadsFn binds the library directly
+    T, N = 6, 4
+    rs = np.random.RandomState(13)
+    dones, rewards = _episode_streams(rs, T, N)
+    envs = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+    args = lambda: default_args(num_steps=T, num_minibatches=2, update_epochs=2)
+    host, fake = _pair(lambda: AtariAgent(envs),
+                       lambda ag: PPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    fake.fused_cnn = True
+    fake._x_roll = None
+    _compare_rollout_and_update(host, fake, _frames(rs, T, N, (4, 84, 84)), dones, rewards, [host.agent], [fake.agent])
+    bufs = fake.agent._trunk.bufs
+    assert bufs.cache_weights and bufs.weights_version == 4                          # one bump per optimiser step
+    # rollout: 3 forward matrices derived once for its T + 1 forwards and still valid for the first minibatch's forward;
+    # then 2 data-gradient matrices, and 3 + 2 after each of the following three optimiser steps: never a stale one (the
+    # comparison above), never a redundant one
+    assert fk.repacks == 3 + 2 + 3 * 5
+    # a second rollout sees the updated weights (the cache was invalidated by the last step)
+    logits_a, _ = fake._heads_rollout(fake.obs[0])
+    with torch.no_grad():
+        logits_b, _ = fake.agent.heads(fake.obs[0].float().permute(0, 3, 1, 2) / 255.0)
+    assert torch.allclose(logits_a, logits_b, atol=1e-5)
