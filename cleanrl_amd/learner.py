@@ -347,14 +347,19 @@ class PPOLearner:
                                           a.norm_adv, a.clip_vloss)
         self.optimizer.zero_grad()
         loss.backward()
-        if self.world_size > 1:
-            all_grads = torch.cat([p_.grad.view(-1) for p_ in self.agent.parameters() if p_.grad is not None])
-            dist.all_reduce(all_grads, op=dist.ReduceOp.SUM)
-            offset = 0
-            for p_ in self.agent.parameters():
-                if p_.grad is not None:
-                    p_.grad.data.copy_(all_grads[offset:offset + p_.numel()].view_as(p_.grad.data) / self.world_size)
-                    offset += p_.numel()
+        self._host_allreduce_grads()
         nn.utils.clip_grad_norm_(self.agent.parameters(), a.max_grad_norm)
         self.optimizer.step()
         return scalars
+
+    def _host_allreduce_grads(self) -> None:
+        """ppo_atari_multigpu.py:360-374 on the host path: pack, all-reduce(SUM), unpack divided by world_size."""
+        if self.world_size <= 1:
+            return
+        all_grads = torch.cat([p_.grad.view(-1) for p_ in self.agent.parameters() if p_.grad is not None])
+        dist.all_reduce(all_grads, op=dist.ReduceOp.SUM)
+        offset = 0
+        for p_ in self.agent.parameters():
+            if p_.grad is not None:
+                p_.grad.data.copy_(all_grads[offset:offset + p_.numel()].view_as(p_.grad.data) / self.world_size)
+                offset += p_.numel()

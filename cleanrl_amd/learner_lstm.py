@@ -23,7 +23,6 @@ from __future__ import annotations
 
 import numpy as np
 import torch
-import torch.distributed as dist
 import torch.nn as nn
 
 from . import host_ops
@@ -159,14 +158,7 @@ class LSTMPPOLearner(PPOLearner):
                                           a.norm_adv, a.clip_vloss)
         self.optimizer.zero_grad()
         loss.backward()
-        if self.world_size > 1:
-            all_grads = torch.cat([p_.grad.view(-1) for p_ in self.agent.parameters() if p_.grad is not None])
-            dist.all_reduce(all_grads, op=dist.ReduceOp.SUM)
-            offset = 0
-            for p_ in self.agent.parameters():
-                if p_.grad is not None:
-                    p_.grad.data.copy_(all_grads[offset:offset + p_.numel()].view_as(p_.grad.data) / self.world_size)
-                    offset += p_.numel()
+        self._host_allreduce_grads()
         nn.utils.clip_grad_norm_(self.agent.parameters(), a.max_grad_norm)
         self.optimizer.step()
         return scalars
