@@ -29,7 +29,14 @@
 //   image (source + dz) in LDS at a time, keeps the WHOLE dWt tile set in accumulators (Cout x K / 1024
 //   MFMA tiles per wave), reads the patches straight out of the staged image (implicit im2col in LDS) and
 //   writes one partial per workgroup; conv_wgrad_reduce sums the partials in a fixed order (deterministic)
-//   and scatters into torch's (Cout, Cin, KH, KW) layout.
+//   and scatters into torch's (Cout, Cin, KH, KW) layout.  First generation; the defaults are now
+//
+// Kernel F (conv_fixed_kernel): forward / data gradient with compile-time geometry, the weight matrix resident in LDS,
+//   A fragments streamed global -> register ring, buffer loads / stores for padding and tails;
+// Kernel R (conv_wgrad_rows_kernel): layer-1 weight gradient, wave-autonomous (private double-buffered LDS slab, no barrier);
+// Kernel T (conv_wgrad_taps_kernel): layer-2/3 weight gradient, operands straight from global memory in MFMA operand
+//   layout, a sliding register window of source columns, no LDS at all.
+// Each is documented where it is defined; DESIGN.md section 3.2 has the measurements and the tuning log.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
