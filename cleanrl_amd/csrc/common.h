@@ -87,9 +87,11 @@ struct Philox {
     }
 };
 
-// uint32 -> uniform in (0,1): (x + 0.5) * 2^-32 computed so that neither 0 nor 1 is produced.
+// uint32 -> uniform in (0,1): the top 23 bits k give (k + 0.5) * 2^-23.  k + 0.5 = (2k+1)/2 needs 24 significand
+// bits, so every value is exact in f32 and lies in [2^-24, 1 - 2^-24]: neither 0 nor 1 can be produced (with 24 bits
+// of x, (2^24-1) + 0.5 would round to 2^24 and return exactly 1).
 __device__ __forceinline__ float u32_to_unit_open(uint32_t x) {
-    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
 #endif  // __HIPCC__

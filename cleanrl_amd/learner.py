@@ -105,10 +105,14 @@ class PPOLearner:
             self._pin_obs_np, self._pin_rd_np = self._pin_obs.numpy(), self._pin_rd.numpy()   # views of the pinned buffers
             self._x_roll = torch.empty((N,) + self.obs_shape, device=device) if (self.image and not self.fused_cnn) else None
             self._x_mb = None
-            n_upd = int(args.update_epochs) * int(args.num_minibatches)
+            # B % num_minibatches != 0 leaves a ragged tail minibatch (range(0, B, M), ppo.py:246): count it
+            n_upd = int(args.update_epochs) * -(-self.batch_size // max(self.minibatch_size, 1))
             self._scalars = torch.zeros((n_upd, 7), device=device)
-            self._inds_dev = torch.empty(self.batch_size, dtype=torch.int64, device=device)
-            self._inds_pin = torch.empty(self.batch_size, dtype=torch.int64).pin_memory()
+            # one row per epoch: the host runs far ahead of the GPU, so epoch e+1's permutation must not land in the
+            # pinned buffer epoch e's (asynchronous) H2D copy is still reading.  Rows are rewritten only by the next
+            # update() call, which starts after this call's closing D2H of the scalars (a stream sync).
+            self._inds_dev = torch.empty((int(args.update_epochs), self.batch_size), dtype=torch.int64, device=device)
+            self._inds_pin = torch.empty((int(args.update_epochs), self.batch_size), dtype=torch.int64).pin_memory()
             self._total_norm = torch.zeros(1, device=device)
 
     # ------------------------------------------------------------------ rollout (a2)
@@ -240,12 +244,11 @@ class PPOLearner:
         for epoch in range(int(a.update_epochs)):
             np.random.shuffle(b_inds)                                     # :315 host MT19937, per-rank seed
             if self.hip:
-                self._inds_pin.copy_(torch.from_numpy(b_inds))
-                self._inds_dev.copy_(self._inds_pin, non_blocking=True)
+                inds_dev = self.upload_permutation(epoch, b_inds)
             for start in range(0, B, M):
                 end = start + M
                 if self.hip:
-                    self._minibatch_hip(self._inds_dev[start:end], b_obs, b_actions, b_logprobs, b_advantages, b_returns,
+                    self._minibatch_hip(inds_dev[start:end], b_obs, b_actions, b_logprobs, b_advantages, b_returns,
                                         b_values, lr, self._scalars[k])
                 else:
                     last = self._minibatch_host(b_inds[start:end], b_obs, b_actions, b_logprobs, b_advantages, b_returns,
@@ -269,6 +272,13 @@ class PPOLearner:
         return dict(loss=float(last_np[0]), policy_loss=float(last_np[1]), value_loss=float(last_np[2]),
                     entropy=float(last_np[3]), old_approx_kl=float(last_np[4]), approx_kl=float(last_np[5]),
                     clipfrac=clipfrac, explained_variance=float(explained_var), num_updates=k)
+
+    def upload_permutation(self, epoch: int, b_inds: np.ndarray) -> torch.Tensor:
+        """Host permutation of this epoch (:315) -> its own pinned row -> its own device row (async H2D)."""
+        pin, dev = self._inds_pin[epoch], self._inds_dev[epoch]
+        pin.copy_(torch.from_numpy(b_inds))
+        dev.copy_(pin, non_blocking=True)
+        return dev
 
     def _minibatch_hip(self, idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, lr, scalars_out):
         self.forward_backward_hip(idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, scalars_out)

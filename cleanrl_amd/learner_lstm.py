@@ -36,8 +36,9 @@ class LSTMPPOLearner(PPOLearner):
         self.next_lstm_state = agent.initial_state(self.N, device)
         self.initial_lstm_state = (self.next_lstm_state[0].clone(), self.next_lstm_state[1].clone())
         if self.hip:
-            self._env_dev = torch.empty(self.N, dtype=torch.int64, device=device)
-            self._env_pin = torch.empty(self.N, dtype=torch.int64).pin_memory()
+            E = int(args.update_epochs)
+            self._env_dev = torch.empty((E, self.N), dtype=torch.int64, device=device)
+            self._env_pin = torch.empty((E, self.N), dtype=torch.int64).pin_memory()
 
     # ------------------------------------------------------------------ rollout
     @torch.no_grad()
@@ -92,12 +93,13 @@ class LSTMPPOLearner(PPOLearner):
         for epoch in range(int(a.update_epochs)):
             np.random.shuffle(envinds)                                     # :302 host MT19937
             if self.hip:
-                self._env_pin.copy_(torch.from_numpy(envinds))
-                self._env_dev.copy_(self._env_pin, non_blocking=True)
+                env_dev = self._env_dev[epoch]                       # one pinned + device row per epoch (no reuse hazard)
+                self._env_pin[epoch].copy_(torch.from_numpy(envinds))
+                env_dev.copy_(self._env_pin[epoch], non_blocking=True)
             for start in range(0, N, envsperbatch):
                 end = start + envsperbatch
                 if self.hip:
-                    env_idx = self._env_dev[start:end]
+                    env_idx = env_dev[start:end]
                     idx = flat_dev.index_select(1, env_idx).reshape(-1)    # :306 "be really careful about the index"
                     self._mb_state = (self.initial_lstm_state[0].index_select(1, env_idx),
                                       self.initial_lstm_state[1].index_select(1, env_idx))

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import numpy as np
 import torch
+import torch.distributed as dist
 import torch.distributions as td
 import torch.nn as nn
 import torch.optim as optim

@@ -89,7 +89,7 @@ class RNDPPOLearner(PPOLearner):
             from .flat import FlatParams
 
             self.flat = FlatParams(_Combined(agent, rnd_model.predictor))    # one flat buffer for the fused clip + Adam
-            n_upd = int(args.update_epochs) * int(args.num_minibatches)
+            n_upd = self._scalars.shape[0]
             self._extra = torch.zeros((n_upd, 2), device=device)             # intrinsic value loss, distillation loss
             self._zeros_TN = torch.zeros((self.T, self.N), device=device)
             self._zeros_N = torch.zeros(self.N, device=device)
@@ -202,12 +202,11 @@ class RNDPPOLearner(PPOLearner):
         for epoch in range(int(a.update_epochs)):
             np.random.shuffle(b_inds)
             if self.hip:
-                self._inds_pin.copy_(torch.from_numpy(b_inds))
-                self._inds_dev.copy_(self._inds_pin, non_blocking=True)
+                inds_dev = self.upload_permutation(epoch, b_inds)
             for start in range(0, B, M):
                 end = start + M
                 if self.hip:
-                    self._minibatch_rnd_hip(self._inds_dev[start:end], b_obs, rnd_next_obs, b_actions, b_logprobs, b_advantages,
+                    self._minibatch_rnd_hip(inds_dev[start:end], b_obs, rnd_next_obs, b_actions, b_logprobs, b_advantages,
                                             b_ext_returns, b_int_returns, b_ext_values, lr, k)
                 else:
                     last = self._minibatch_rnd_host(b_inds[start:end], b_obs, rnd_next_obs, b_actions, b_logprobs, b_advantages,

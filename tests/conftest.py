@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """GPU-marked tests need a real device: on a CPU box they are skipped, not failed (plain `pytest` works here)."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (torch.cuda.is_available() is False)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def load_golden(name):
     """tests/golden/<name>.npz -> {case: {key: ndarray}} (minted by oracle/mint_goldens.py from the
     reference's own source lines)."""

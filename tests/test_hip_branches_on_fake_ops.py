@@ -185,10 +185,11 @@ def _to_fake_hip(L, flat_module=None):
         L.stage_obs = torch.zeros((N,) + L.frame_shape, dtype=torch.uint8) if L.relayout else None
         L._x_roll = torch.empty((N,) + L.obs_shape)
     L._x_mb = None
-    n_upd = int(L.args.update_epochs) * int(L.args.num_minibatches)
+    E_ = int(L.args.update_epochs)
+    n_upd = E_ * -(-L.batch_size // L.minibatch_size)
     L._scalars = torch.zeros((n_upd, 7))
-    L._inds_dev = torch.empty(L.batch_size, dtype=torch.int64)
-    L._inds_pin = torch.empty(L.batch_size, dtype=torch.int64)
+    L._inds_dev = torch.empty((E_, L.batch_size), dtype=torch.int64)
+    L._inds_pin = torch.empty((E_, L.batch_size), dtype=torch.int64)
     L._total_norm = torch.zeros(1)
     return L
 
@@ -259,7 +260,7 @@ def test_lstm_hip_branch():
     args = lambda: default_args(num_steps=T, num_minibatches=2, update_epochs=2)
     host, fake = _pair(lambda: AtariLSTMAgent(envs),
                        lambda ag: LSTMPPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
-    fake._env_dev, fake._env_pin = torch.empty(N, dtype=torch.int64), torch.empty(N, dtype=torch.int64)
+    fake._env_dev, fake._env_pin = torch.empty((2, N), dtype=torch.int64), torch.empty((2, N), dtype=torch.int64)
     rs = np.random.RandomState(1)
     dones, rewards = _episode_streams(rs, T, N)
     _compare_rollout_and_update(host, fake, _frames(rs, T, N, (1, 84, 84)), dones, rewards, [host.agent], [fake.agent])
@@ -489,3 +490,83 @@ def test_fused_cnn_branch_and_weight_matrix_cache(monkeypatch):
     with torch.no_grad():
         logits_b, _ = fake.agent.heads(fake.obs[0].float().permute(0, 3, 1, 2) / 255.0)
     assert torch.allclose(logits_a, logits_b, atol=1e-5)
+
+
+def test_ragged_tail_minibatch_on_the_hip_branch():
+    """B % num_minibatches != 0: ``range(0, B, M)`` yields one more (short) minibatch (ppo.py:246-248); the HIP branch's
+    per-minibatch scalar rows must cover it."""
+    from cleanrl_amd.agents import MlpAgent
+
+    T, N = 5, 3                                          # B = 15, 4 minibatches -> M = 3 -> 5 minibatches per epoch
+    rs = np.random.RandomState(5)
+    dones, rewards = _episode_streams(rs, T, N)
+    envs = SimpleNamespace(single_observation_space=E.Box(-1, 1, (4,)), single_action_space=E.Discrete(2))
+    args = lambda: default_args(num_steps=T, num_minibatches=4, update_epochs=2, clip_coef=0.2)
+    host, fake = _pair(lambda: MlpAgent(envs),
+                       lambda ag: PPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    obs = rs.standard_normal((T + 1, N, 4)).astype(np.float32)
+    mh, mf = _compare_rollout_and_update(host, fake, obs, dones, rewards, [host.agent], [fake.agent])
+    assert mh["num_updates"] == mf["num_updates"] == 10
+
+
+def test_every_epoch_has_its_own_permutation_rows():
+    """The host runs ahead of the GPU: epoch e+1's permutation must not overwrite the pinned row epoch e's asynchronous
+    H2D copy still reads.  Every epoch therefore owns a pinned row and a device row."""
+    from cleanrl_amd.agents import MlpAgent
+
+    T, N = 4, 4
+    envs = SimpleNamespace(single_observation_space=E.Box(-1, 1, (4,)), single_action_space=E.Discrete(2))
+    torch.manual_seed(0)
+    L = _to_fake_hip(PPOLearner(MlpAgent(envs), default_args(num_steps=T, num_minibatches=2, update_epochs=3),
+                                envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    assert tuple(L._inds_pin.shape) == tuple(L._inds_dev.shape) == (3, T * N)
+    perms = [np.random.RandomState(e).permutation(T * N) for e in range(3)]
+    rows = [L.upload_permutation(e, p) for e, p in enumerate(perms)]
+    assert len({r.data_ptr() for r in rows}) == 3 and len({L._inds_pin[e].data_ptr() for e in range(3)}) == 3
+    for e in range(3):                                   # later uploads left the earlier rows alone
+        assert np.array_equal(L._inds_pin[e].numpy(), perms[e]) and np.array_equal(rows[e].numpy(), perms[e])
+
+
+def test_ppg_hip_branch_world_size_two_allreduce(capsys, monkeypatch):
+    """The auxiliary phase's ``dist.all_reduce`` + ``/world_size`` on the HIP branch (round-1 advisor finding: ``dist`` was
+    never imported there).  Two ranks that hold identical data: SUM doubles the flat gradient, ``/world_size`` halves it
+    (both exact in f32), so a world_size=2 learner must end exactly where a world_size=1 learner ends -- through the
+    policy phase (learner.py) and the auxiliary phase (learner_ppg.py), the stale-gradient quirk included."""
+    from cleanrl_amd import learner as learner_mod, learner_ppg as ppg_mod
+
+    calls = []
+
+    def identical_peer_sum(t, op=None):
+        assert op == ppg_mod.dist.ReduceOp.SUM
+        calls.append(t.data_ptr())
+        t.mul_(2.0)
+
+    monkeypatch.setattr(learner_mod.dist, "all_reduce", identical_peer_sum)
+    assert ppg_mod.dist is learner_mod.dist
+    envs = SimpleNamespace(single_observation_space=E.Box(0, 255, (64, 64, 3), np.uint8), single_action_space=E.Discrete(15))
+    T, N = 4, 4
+    rs = np.random.RandomState(3)
+    frames = _frames(rs, T, N, (64, 64, 3))
+    dones, rewards = _episode_streams(rs, T, N)
+    pargs = lambda: default_args(num_steps=T, num_minibatches=2, gamma=0.999, clip_coef=0.2, adv_norm_fullbatch=True, e_policy=1,
+                                 e_auxiliary=2, beta_clone=1.0, num_aux_rollouts=2, n_aux_grad_accum=1, aux_batch_rollouts=N,
+                                 n_iteration=1, learning_rate=5e-4)
+    mk = lambda w: _to_fake_hip(PPGLearner(PPGAgent(envs), pargs(), envs.single_observation_space, envs.single_action_space, N,
+                                           torch.device("cpu"), world_size=w))
+    torch.manual_seed(0)
+    two = mk(2)
+    torch.manual_seed(0)
+    one = mk(1)
+    for L in (two, one):
+        _drive(L, frames, dones, rewards, 11, True)
+        np.random.seed(3)
+        torch.manual_seed(3)
+        L.update(5e-4)
+        np.random.seed(4)
+        L.aux_phase()
+    capsys.readouterr()
+    assert len(calls) == 2 + 4 and set(calls) == {two.flat.grads.data_ptr()}     # 2 policy minibatches + 2 epochs x 2 aux steps
+    d = (_params([two.agent]) - _params([one.agent])).abs().max().item()
+    assert d <= 1e-7, d
+    for k in one.last_aux:
+        assert abs(two.last_aux[k] - one.last_aux[k]) <= 1e-6 * max(1.0, abs(one.last_aux[k]))
