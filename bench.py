@@ -129,13 +129,36 @@ class KernelTimer:
         return float(np.mean([a.elapsed_time(b) for a, b in ps])) * 1e3, len(ps)
 
 
+def self_launch(cli) -> int:
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU,
+    the launch line of the module docstring) and hand their output through.  Refuses -- loudly, non-zero -- when the box
+    has fewer than N GPUs: a one-rank run must never pass for an N-GPU measurement."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < cli.gpus:
+        print(f"bench.py: --gpus {cli.gpus} requested but this box has {have} GPU(s); refusing to run fewer ranks than asked",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as so:                      # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={cli.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     cli = parse()
+    if cli.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(cli))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == cli.gpus or world == 1, f"--gpus {cli.gpus} but WORLD_SIZE={world}"
+    assert world == cli.gpus, f"--gpus {cli.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU"
     assert torch.cuda.is_available(), "bench.py measures the MI355X path and needs a GPU"
+    assert torch.cuda.device_count() > local_rank, f"rank {rank}: no GPU {local_rank} on this box ({torch.cuda.device_count()} visible)"
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     if world > 1:

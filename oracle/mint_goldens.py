@@ -246,6 +246,36 @@ def _flat(params):
     return torch.cat([p.detach().reshape(-1) for p in params])
 
 
+GRAD_STRIDE = 7
+
+
+class _GradSpy:
+    """Wraps the reference's optimizer object inside the exec'ed update lines: records what ``optimizer.step()`` sees in
+    ``.grad`` -- i.e. the gradient after ``loss.backward()``, the collective block (multi-GPU script) and
+    ``clip_grad_norm_`` -- for the first ``keep`` steps.  Everything else is forwarded untouched."""
+
+    def __init__(self, optimizer, params, keep=1):
+        self._opt, self._params, self._keep, self.grads = optimizer, list(params), keep, []
+
+    def __getattr__(self, name):
+        return getattr(self._opt, name)
+
+    def step(self, *a, **kw):
+        if len(self.grads) < self._keep:
+            self.grads.append(_flat([p.grad for p in self._params]).clone())
+        return self._opt.step(*a, **kw)
+
+
+def _grad_record(prefix, g, params):
+    """Strided subsample + norms of a flat gradient (the whole vector is 6.7 MB; the subsample estimates the cosine,
+    the norms pin the scale globally and per parameter tensor)."""
+    sizes = [p.numel() for p in params]
+    per = torch.stack([t.double().norm() for t in torch.split(g, sizes)])
+    return {f"{prefix}_sub": g[::GRAD_STRIDE].clone(), f"{prefix}_norm": np.float64(g.double().norm().item()),
+            f"{prefix}_tensor_norms": per, f"{prefix}_absmax": np.float64(g.abs().max().item()),
+            f"{prefix}_stride": np.int64(GRAD_STRIDE)}
+
+
 class _FakeDist:
     """Stand-in for ``torch.distributed`` inside ppo_atari_multigpu.py:360-374: a 2-rank SUM all-reduce
     whose other rank's flat gradient was computed beforehand."""
@@ -320,7 +350,8 @@ def mint_update_step():
     hi = R._find(lines, "optimizer.step()", lo)
     import textwrap
     ns0["dist"] = _FakeDist(g1)
-    ns0["optimizer"] = opt
+    spy = _GradSpy(opt, agent.parameters())
+    ns0["optimizer"] = spy
     exec(textwrap.dedent("\n".join(lines[lo:hi + 1])), ns0)       # ppo_atari_multigpu.py:357-377
     final = _flat(agent.parameters())
     sub = slice(0, None, 53)
@@ -331,7 +362,9 @@ def mint_update_step():
         mb_inds=mb.astype(np.int64), init_params_sub=init[sub], final_params_sub=final[sub],
         delta_sub=(final - init)[sub], loss_rank0=ns0["loss"].detach(), loss_rank1=ns1["loss"].detach(),
         init_seed=np.int64(1), stride=np.int64(53), lr=np.float64(2.5e-4),
-        init_checksum=np.float64(init.double().sum().item()), final_checksum=np.float64(final.double().sum().item()))
+        init_checksum=np.float64(init.double().sum().item()), final_checksum=np.float64(final.double().sum().item()),
+        # what optimizer.step() saw: (g0 + g1) / world_size after clip_grad_norm_ (:368-376); g1 = rank 1's local gradient
+        **_grad_record("step_grad", spy.grads[0], agent.parameters()), **_grad_record("rank1_grad", g1, agent.parameters()))
     _save("update_step", cases)
 
 
@@ -352,7 +385,7 @@ def mint_atari_iteration():
     envs = R.fake_envs((4, 84, 84), n_actions=A)
     agent = Agent(envs)
     args = R.make_args(num_steps=T, num_envs=N, num_minibatches=2, update_epochs=2, batch_size=T * N, minibatch_size=T * N // 2)
-    optimizer = R.make_optimizer(agent, 2.5e-4)
+    optimizer = _GradSpy(R.make_optimizer(agent, 2.5e-4), agent.parameters())
     init = _flat(agent.parameters()).clone()
     g = torch.Generator().manual_seed(53)
     frames = torch.randint(0, 256, (T + 1, N, 4, 84, 84), generator=g, dtype=torch.uint8)
@@ -389,7 +422,9 @@ def mint_atari_iteration():
         final_checksum=np.float64(final.double().sum().item()), last_loss=ns["loss"].detach(), last_pg_loss=ns["pg_loss"].detach(),
         last_v_loss=ns["v_loss"].detach(), last_entropy=ns["entropy_loss"].detach(), last_approx_kl=ns["approx_kl"],
         clipfracs=np.array(ns["clipfracs"], np.float32), init_seed=np.int64(21), sample_seed=np.int64(23),
-        shuffle_seed=np.int64(6), lr=np.float64(2.5e-4), lines=np.array([g0 + 1, g1 + 1, u0 + 1, u1], np.int64))}
+        shuffle_seed=np.int64(6), lr=np.float64(2.5e-4), lines=np.array([g0 + 1, g1 + 1, u0 + 1, u1], np.int64),
+        # the clipped gradient the FIRST optimizer.step() of the update saw (minibatch 1 of epoch 1)
+        **_grad_record("mb1_grad", optimizer.grads[0], agent.parameters()))}
     _save("atari_iteration", cases)
 
 

@@ -67,6 +67,88 @@ def test_rollout_gae_and_update_seam_against_oracle():
     assert cos > 0.99999, cos
 
 
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def _decile_report(delta, want, gmag, rtol, atol):
+    """Fraction of sampled parameters whose update matches the reference, by decile of |gradient| (smallest first)."""
+    close = np.isclose(delta, want, rtol=rtol, atol=atol)
+    order = np.argsort(gmag)
+    parts = np.array_split(order, 10)
+    return close, [float(close[p].mean()) for p in parts]
+
+
+def _spy_first_step(L):
+    """Capture the flat gradient buffer as the FIRST optimiser step of an update sees it (pre-Adam, pre-clip)."""
+    seen = {}
+    real = L.optimizer_step_hip
+
+    def spy(lr):
+        if "g" not in seen:
+            seen["g"] = L.flat.grads.clone()
+        real(lr)
+
+    L.optimizer_step_hip = spy
+    return seen
+
+
+def test_atari_hip_path_teacher_forced_against_reference_iteration():
+    """The main path (uint8 rows -> f32-MFMA conv kernels -> FC -> heads -> K2/K1/K3/K6) against a whole iteration of
+    ppo_atari_envpool.py's own lines :217-322 (tests/golden/atari_iteration.npz), the reference's sampled actions forced.
+    Strict (no xfail): a regression here is an F."""
+    g = load_golden("atari_iteration")["atari_T8_N4"]
+    T, N = g["rewards"].shape
+    env = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+    torch.manual_seed(int(g["init_seed"]))
+    agent = AtariAgent(env).to(DEV)
+    args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=2)
+    L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=1)
+    assert L.hip and L.fused_cnn
+    stride = int(g["stride"])
+    np.testing.assert_allclose(L.flat.params[::stride].cpu().numpy(), g["init_params_sub"], rtol=1e-5, atol=1e-6)
+    frames, step_done = g["frames_u8"], g["step_done"]
+    L.observe(0, frames[0], step_done[0])
+    for step in range(T):
+        L.act(step)
+        # f32 conv stack with another summation order (and 1/255 folded into the layer-1 weights): 5e-5 of the value scale
+        np.testing.assert_allclose(L.values[step].cpu().numpy(), g["values"][step], rtol=1e-4, atol=5e-5)
+        L.actions[step].copy_(torch.from_numpy(g["actions"][step]))
+        L.logprobs[step].copy_(torch.from_numpy(g["logprobs"][step]))
+        L.values[step].copy_(torch.from_numpy(g["values"][step]))
+        L.store_reward(step, g["rewards"][step])
+        L.observe(step + 1, frames[step + 1], step_done[step + 1])
+    L.finish_rollout()
+    np.testing.assert_allclose(L.advantages.cpu().numpy(), g["advantages"], rtol=1e-4, atol=1e-4)
+    L.advantages.copy_(torch.from_numpy(g["advantages"]))
+    L.returns.copy_(torch.from_numpy(g["returns"]))
+    seen = _spy_first_step(L)
+    np.random.seed(int(g["shuffle_seed"]))
+    m = L.update(float(g["lr"]))
+    assert m["num_updates"] == 4
+    np.testing.assert_allclose(m["loss"], float(g["last_loss"]), rtol=2e-3, atol=2e-4)
+    # pre-Adam: minibatch 1's gradient, clipped as clip_grad_norm_(0.5) does, against what the reference's first
+    # optimizer.step() saw.  Bar: 1e-3 of the largest element, cosine > 0.99999, norms 1e-3.
+    gh = seen["g"].cpu().numpy()
+    n = np.linalg.norm(gh.astype(np.float64))
+    clipped = gh * min(1.0, args.max_grad_norm / (n + 1e-6))
+    s = int(g["mb1_grad_stride"])
+    assert np.abs(clipped[::s] - g["mb1_grad_sub"]).max() <= 1e-3 * float(g["mb1_grad_absmax"])
+    assert _cos(clipped[::s], g["mb1_grad_sub"]) > 0.99999
+    np.testing.assert_allclose(np.linalg.norm(clipped.astype(np.float64)), float(g["mb1_grad_norm"]), rtol=1e-3)
+    sizes = [p.numel() for p in agent.parameters()]
+    per = np.array([np.linalg.norm(c.astype(np.float64)) for c in np.split(clipped, np.cumsum(sizes)[:-1])])
+    np.testing.assert_allclose(per, g["mb1_grad_tensor_norms"], rtol=2e-3)
+    # post-Adam (four steps of ~lr * sign-ish): by decile of |g|, so that "ill-conditioned tiny gradients" is a number
+    delta = L.flat.params[::stride].cpu().numpy() - g["init_params_sub"]
+    want = g["final_params_sub"] - g["init_params_sub"]
+    close, deciles = _decile_report(delta, want, np.abs(gh[::stride]), rtol=5e-2, atol=2e-5)
+    assert close.mean() > 0.98, f"only {close.mean():.4f} of sampled parameters match; by |g| decile: {deciles}"
+    assert min(deciles[2:]) > 0.99, f"parameters with non-tiny gradients must follow the reference update: {deciles}"
+    L.flat.check_views()
+
+
 def test_dp_step_matches_reference_collective_block_golden():
     """ppo_atari_multigpu.py:320-377 for world_size=2 (golden from the reference's lines): rank-1 gradient is
     summed into the flat buffer exactly where the RCCL all-reduce acts, then the fused /world -> clip -> Adam."""
@@ -89,12 +171,26 @@ def test_dp_step_matches_reference_collective_block_golden():
                                G(f"b_advantages_rank{r}"), G(f"b_returns_rank{r}"), G(f"b_values_rank{r}"), sc)
         np.testing.assert_allclose(sc[0].item(), g[f"loss_rank{r}"], rtol=1e-4)
         grads.append(L.flat.grads.clone())
+    # rank 1's local gradient against the reference's own backward of rank 1's minibatch
+    s = int(g["rank1_grad_stride"])
+    g1 = grads[0].cpu().numpy()
+    assert np.abs(g1[::s] - g["rank1_grad_sub"]).max() <= 1e-3 * float(g["rank1_grad_absmax"])
+    assert _cos(g1[::s], g["rank1_grad_sub"]) > 0.99999
     L.flat.grads.copy_(grads[0] + grads[1])              # what all_reduce(SUM) leaves in the flat buffer (:367)
+    # pre-Adam: (sum / world) clipped at max_grad_norm = what the reference's optimizer.step() saw (:368-376)
+    avg = (L.flat.grads / 2.0).cpu().numpy()
+    n = np.linalg.norm(avg.astype(np.float64))
+    clipped = avg * min(1.0, args.max_grad_norm / (n + 1e-6))
+    assert np.abs(clipped[::s] - g["step_grad_sub"]).max() <= 1e-3 * float(g["step_grad_absmax"])
+    assert _cos(clipped[::s], g["step_grad_sub"]) > 0.99999
+    np.testing.assert_allclose(np.linalg.norm(clipped.astype(np.float64)), float(g["step_grad_norm"]), rtol=1e-3)
     L.optimizer_step_hip(float(g["lr"]))
+    np.testing.assert_allclose(L._total_norm.item(), n, rtol=1e-5)         # the kernel's norm is of the AVERAGED gradient
     delta = L.flat.params[::stride].cpu().numpy() - g["init_params_sub"]
-    close = np.isclose(delta, g["delta_sub"], rtol=1e-2, atol=1e-5)
-    # the first Adam step is ~lr*g/(|g|+eps): parameters whose gradient is ~1e-6 are ill-conditioned, the rest must match
-    assert close.mean() > 0.99, f"only {close.mean():.4f} of sampled parameters match the reference update"
+    # the first Adam step is ~lr*g/(|g|+eps): quantify by decile of |g| instead of blaming "ill-conditioned" parameters
+    close, deciles = _decile_report(delta, g["delta_sub"], np.abs(avg[::stride]), rtol=1e-2, atol=1e-5)
+    assert close.mean() > 0.99, f"only {close.mean():.4f} of sampled parameters match; by |g| decile: {deciles}"
+    assert min(deciles[2:]) > 0.995, f"parameters with non-tiny gradients must follow the reference update: {deciles}"
 
 
 def test_ppo_learns_cartpole_on_gpu_through_hip_kernels():

@@ -1,0 +1,82 @@
+"""The world_size > 1 HIP path executed by TWO REAL PROCESSES on the one GPU a test box has (SURVEY §8 rows a9 / e).
+
+RCCL refuses two ranks on one device, so the ranks talk over gloo, which accepts device tensors: the code under test --
+``learner.py``'s ``dist.all_reduce(self.flat.grads)`` on the persistent flat buffer, ``grad_scale = 1 / world_size`` in the
+fused clip + Adam kernel, the per-rank seeding protocol of the drop-in script -- is exactly what runs over RCCL on an
+8-GPU node; only the transport differs.  Reference: ppo_atari_multigpu.py:166-177 (rendezvous), :206-212,231 (seeds),
+:360-377 (collective block); its own test is the 2-process gloo run of tests/test_atari_multigpu.py:4-9."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _torchrun(script_and_args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node", "2", "--local-addr",
+           "127.0.0.1"] + script_and_args
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-3000:]
+    return out.stdout + out.stderr
+
+
+def _cos(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def test_two_ranks_execute_the_collective_block_against_the_reference_golden(tmp_path):
+    _torchrun([os.path.join("tests", "dp_gloo_worker.py"), str(tmp_path)])
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in (0, 1))
+    assert int(r0["world"]) == int(r1["world"]) == 2 and bytes(r0["backend"]) == b"gloo"
+    g = load_golden("update_step")["multigpu_cnn_world2"]
+    # each rank's own loss is the reference's for its half of the data
+    np.testing.assert_allclose(float(r0["loss"]), g["loss_rank0"], rtol=1e-4)
+    np.testing.assert_allclose(float(r1["loss"]), g["loss_rank1"], rtol=1e-4)
+    # the collective left the SAME bits in both flat gradient buffers, and the replicas are bit-identical after the step
+    assert np.array_equal(r0["reduced"], r1["reduced"]), "all_reduce(SUM) results differ between the ranks"
+    assert np.array_equal(r0["params"], r1["params"]), "replicas diverged after one data-parallel step"
+    assert float(r0["total_norm"][0]) == float(r1["total_norm"][0])
+    # pre-Adam: (g0 + g1) / world, clipped at 0.5 (:368-376), against what the reference's optimizer.step() saw
+    n = float(r0["total_norm"][0])                                   # the kernel's norm of the averaged gradient
+    avg = r0["reduced"] / 2.0
+    np.testing.assert_allclose(np.linalg.norm(avg.astype(np.float64)), n, rtol=1e-5)
+    clipped = avg * min(1.0, 0.5 / (n + 1e-6))
+    s = int(g["step_grad_stride"])
+    want = g["step_grad_sub"]
+    # tolerance: 1e-3 of the gradient's largest element (f32 conv backward with other summation trees), cosine > 0.99999
+    assert np.abs(clipped[::s] - want).max() <= 1e-3 * float(g["step_grad_absmax"])
+    assert _cos(clipped[::s], want) > 0.99999
+    np.testing.assert_allclose(np.linalg.norm(clipped.astype(np.float64)), float(g["step_grad_norm"]), rtol=1e-3)
+    # post-Adam: the reference's parameter delta
+    stride = int(g["stride"])
+    delta = r0["params"][::stride] - g["init_params_sub"]
+    close = np.isclose(delta, g["delta_sub"], rtol=1e-2, atol=1e-5)
+    assert close.mean() > 0.99, f"only {close.mean():.4f} of sampled parameters match the reference update"
+
+
+def test_ppo_atari_multigpu_script_two_ranks_on_one_gpu():
+    """The drop-in script itself, ``--cuda`` on, both ranks on device 0 (``--device-ids 0 0``), backend gloo: replicas print
+    the same actor weight sum after every update while sampling different actions (per-rank seeds)."""
+    out = _torchrun([os.path.join("cleanrl_amd", "ppo_atari_multigpu.py"), "--cuda", "--backend", "gloo", "--device-ids", "0", "0",
+                     "--local-num-envs", "4", "--num-steps", "8", "--num-envs", "8", "--total-timesteps", "192"])
+    pat = r"local_rank: (\d+), action\.sum\(\): (-?\d+), iteration: (\d+), agent\.actor\.weight\.sum\(\): (-?[\d.eE+-]+)"
+    sums, acts = {}, {}
+    for lr, a, it, w in re.findall(pat, out):
+        sums.setdefault(it, {})[lr] = w
+        acts.setdefault(it, {})[lr] = a
+    assert len(sums) == 3, out[-2000:]
+    for it, by_rank in sums.items():
+        assert len(by_rank) == 2 and by_rank["0"] == by_rank["1"], f"replicas diverged at iteration {it}: {by_rank}"
+    assert len({sums[i]["0"] for i in sums}) == 3                     # the weights move every iteration
+    assert any(acts[i]["0"] != acts[i]["1"] for i in acts)           # different rollouts per rank

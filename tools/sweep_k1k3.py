@@ -1,0 +1,66 @@
+"""K1 (GAE) N-sweep and K3 (fused loss) M-sweep for rocprofv3 kernel-duration evidence (run under
+``rocprofv3 --kernel-trace``; also prints HIP-event timings as JSON lines for cross-checking).
+    python tools/sweep_k1k3.py [reps]"""
+import json
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from cleanrl_amd import ops, synthetic  # noqa: E402
+
+DEV = torch.device("cuda:0")
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+
+
+def ev_us(fn, reps):
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def main():
+    T = 128
+    for N in (1024, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22):
+        base = {k: v.to(DEV) for k, v in synthetic.rollout_scalars(T, min(N, 4096), 4, seed=1).items()}
+        rep = max(N // 4096, 1)
+        s = {k: (v.repeat(1, rep) if v.dim() == 2 else v.repeat(rep)).contiguous() for k, v in base.items()}
+        adv, ret = torch.empty_like(s["rewards"]), torch.empty_like(s["rewards"])
+        f = lambda: ops.gae(s["rewards"], s["dones"], s["values"], s["next_done"], s["next_value"], 0.99, 0.95, adv, ret)
+        us = ev_us(f, REPS)
+        nbytes = 20 * T * N + 8 * N
+        print(json.dumps(dict(kernel="gae", T=T, N=N, algorithmic_bytes=nbytes, event_us_per_call=us, GBps=nbytes / us / 1e3)), flush=True)
+        del s, adv, ret
+    A = 4
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for M in (4096, 32768, 1 << 17, 1 << 20, 1 << 22, 1 << 24):
+        B = M
+        logits = torch.randn(M, A, generator=g).to(DEV)
+        value = torch.randn(M, generator=g).to(DEV)
+        inds = torch.randperm(B, generator=g).to(DEV)
+        b_actions = torch.randint(0, A, (B,), generator=g).float().to(DEV)
+        b_lp = (torch.randn(B, generator=g) * 0.1 - 1.4).to(DEV)
+        b_adv, b_ret, b_val = (torch.randn(B, generator=g).to(DEV) for _ in range(3))
+        sc = torch.empty(7, device=DEV)
+        dl, dv = torch.empty_like(logits), torch.empty_like(value)
+        f = lambda: ops.ppo_loss_categorical(logits, value, inds, b_actions, b_lp, b_adv, b_ret, b_val, 0.1, 0.01, 0.5, True, True,
+                                             scalars_out=sc, dlogits_out=dl, dvalue_out=dv)
+        try:
+            us = ev_us(f, REPS)
+        except TypeError:
+            f = lambda: ops.ppo_loss_categorical(logits, value, inds, b_actions, b_lp, b_adv, b_ret, b_val, 0.1, 0.01, 0.5, True, True,
+                                                 scalars_out=sc)
+            us = ev_us(f, REPS)
+        nbytes = (8 * A + 28 + 8) * M
+        print(json.dumps(dict(kernel="loss_categorical", M=M, algorithmic_bytes=nbytes, event_us_per_call=us, GBps=nbytes / us / 1e3)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
