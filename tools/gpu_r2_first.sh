@@ -5,7 +5,7 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 O=gpurun_out
-( time MI355PPO_GPU_EXTENDED=1 timeout 1500 python -m pytest tests -m gpu -q -rfEs --durations=25 -p no:cacheprovider ) > $O/pytest_gpu.log 2>&1
+( time timeout 1500 python -m pytest tests -m gpu -q -rfEs --durations=25 -p no:cacheprovider ) > $O/pytest_gpu.log 2>&1
 echo "pytest rc=$?"; tail -45 $O/pytest_gpu.log
 timeout 600 python bench.py --steps 5 --warmup 2 > $O/bench.log 2> $O/bench.err; echo "bench rc=$?"; tail -1 $O/bench.log | cut -c1-600
 cd /tmp
