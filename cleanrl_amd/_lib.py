@@ -27,11 +27,14 @@ SIGNATURES = {
     "mi355ppo_normal_sample_f32": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, _P, c_int, c_int, _P]),
     "mi355ppo_normal_logprob_entropy_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "mi355ppo_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mi355ppo_adv_stats_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "mi355ppo_adv_stats_f32": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_size_t, _P]),
+    "mi355ppo_loss_scalars_f32": (c_int, [_P, c_size_t, c_int, _P, _P]),
     "mi355ppo_loss_categorical_fwd_bwd_f32": (
-        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int,
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int, _P,
                 _P, _P, _P, _P, c_size_t, _P]),
     "mi355ppo_loss_normal_fwd_bwd_f32": (
-        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int,
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int, _P,
                 _P, _P, _P, _P, _P, c_size_t, _P]),
     "mi355ppo_obs_u8_to_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P]),
     "mi355ppo_obs_nchw_to_nhwc_u8": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),

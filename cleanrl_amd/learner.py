@@ -114,6 +114,11 @@ class PPOLearner:
             self._inds_dev = torch.empty((int(args.update_epochs), self.batch_size), dtype=torch.int64, device=device)
             self._inds_pin = torch.empty((int(args.update_epochs), self.batch_size), dtype=torch.int64).pin_memory()
             self._total_norm = torch.zeros(1, device=device)
+        self._mb_adv_md = None      # the current minibatch's (mean, std + 1e-8) row of ops.adv_stats, or None
+        self._mb_slot = None        # (LossSlots, k): K3's scalar fold deferred to one launch per update (categorical family)
+        self._loss_slots = None
+        if self.hip and self.discrete and type(self).forward_backward_hip is PPOLearner.forward_backward_hip:
+            self._loss_slots = self.ops.LossSlots(self._scalars.shape[0], device)
 
     # ------------------------------------------------------------------ rollout (a2)
     def _slot(self, step: int):
@@ -238,6 +243,7 @@ class PPOLearner:
         b_logprobs, b_advantages = self.logprobs.reshape(-1), self.advantages.reshape(-1)
         b_returns, b_values = self.returns.reshape(-1), self.values.reshape(-1)
         k = 0
+        folded = 0                       # scalar rows already folded out of the loss slots
         stop = False
         clipfracs = []
         last = None
@@ -245,9 +251,14 @@ class PPOLearner:
             np.random.shuffle(b_inds)                                     # :315 host MT19937, per-rank seed
             if self.hip:
                 inds_dev = self.upload_permutation(epoch, b_inds)
+                # :337-338 hoisted: (mean, std + 1e-8) of every minibatch of this epoch depend only on the permutation and
+                # the GAE output -> one launch per epoch, and K3 runs without its statistics launch
+                adv_md = self.ops.adv_stats(b_advantages, inds_dev, M) if a.norm_adv else None
             for start in range(0, B, M):
                 end = start + M
                 if self.hip:
+                    self._mb_adv_md = adv_md[start // M] if adv_md is not None else None
+                    self._mb_slot = (self._loss_slots, k) if self._loss_slots is not None else None
                     self._minibatch_hip(inds_dev[start:end], b_obs, b_actions, b_logprobs, b_advantages, b_returns,
                                         b_values, lr, self._scalars[k])
                 else:
@@ -256,15 +267,21 @@ class PPOLearner:
                     clipfracs.append(last[6].item())                      # :328
                 k += 1
             if a.target_kl is not None:                                   # :379-380 (local approx_kl, as the reference)
+                if self._loss_slots is not None and self.hip:
+                    self._loss_slots.fold(k - folded, self._scalars, first=folded)
+                    folded = k
                 approx_kl = (self._scalars[k - 1, 5] if self.hip else last[5]).item()
                 if approx_kl > a.target_kl:
                     stop = True
             if stop:
                 break
+        self._mb_adv_md = self._mb_slot = None                            # direct forward_backward_hip calls fold at once
         y_pred, y_true = b_values.cpu().numpy(), b_returns.cpu().numpy()  # :382-384
         var_y = np.var(y_true)
         explained_var = np.nan if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y
         if self.hip:
+            if self._loss_slots is not None and k > folded:
+                self._loss_slots.fold(k - folded, self._scalars, first=folded)   # one launch for every minibatch of the update
             sc = self._scalars[:k].cpu().numpy()
             last_np, clipfrac = sc[-1], float(np.mean(sc[:, 6]))
         else:
@@ -308,7 +325,8 @@ class PPOLearner:
             _, dp, dvalue = ops.ppo_loss_categorical(p.detach().contiguous(), value.detach().contiguous(), idx, b_actions,
                                                      b_logprobs, b_advantages, b_returns, b_values, a.clip_coef,
                                                      a.ent_coef, a.vf_coef, a.norm_adv, a.clip_vloss,
-                                                     scalars_out=scalars_out)
+                                                     scalars_out=scalars_out, adv_mean_den=self._mb_adv_md,
+                                                     slot=self._mb_slot)
             torch.autograd.backward([p, value], [dp, dvalue])             # :358
         else:
             if getattr(self.agent, "rpo_alpha", None) is not None:       # RPO: loss on the perturbed mean, d/dmean unchanged
@@ -318,7 +336,8 @@ class PPOLearner:
             _, dmean, dlogstd, dvalue = ops.ppo_loss_normal(p_eff.contiguous(), self.agent.actor_logstd.detach(),
                                                             value.detach().contiguous(), idx, b_actions, b_logprobs,
                                                             b_advantages, b_returns, b_values, a.clip_coef, a.ent_coef,
-                                                            a.vf_coef, a.norm_adv, a.clip_vloss, scalars_out=scalars_out)
+                                                            a.vf_coef, a.norm_adv, a.clip_vloss, scalars_out=scalars_out,
+                                                            adv_mean_den=self._mb_adv_md)
             torch.autograd.backward([p, value], [dmean, dvalue])
             self.agent.actor_logstd.grad.add_(dlogstd.view_as(self.agent.actor_logstd))
 

@@ -251,12 +251,64 @@ def _flat_batch(b_logprobs, b_advantages, b_returns, b_values):
             _chk(b_values.reshape(-1), torch.float32, "b_values", (Bf,)))
 
 
+class LossSlots:
+    """Workspace slots for the deferred scalar fold of K3: minibatch k of an update runs ``ppo_loss_categorical(..., slot=(slots,
+    k))`` (no fold launch) and ``slots.fold(n, out)`` turns the first n slots into rows of the (n, 7) scalar table in one
+    launch."""
+
+    def __init__(self, n: int, device: torch.device):
+        lib = _lib.load()
+        self.n, self.device = int(n), device
+        self.stride = (lib.mi355ppo_loss_workspace_bytes(1, 0) + 255) // 256 * 256
+        self.buf = torch.empty(self.n * self.stride, dtype=torch.uint8, device=device)
+
+    def ptr(self, k: int):
+        if not 0 <= k < self.n:
+            raise IndexError(f"loss slot {k} out of range 0..{self.n - 1}")
+        return ctypes.c_void_p(self.buf.data_ptr() + k * self.stride)
+
+    def fold(self, n: int, out: torch.Tensor, first: int = 0) -> torch.Tensor:
+        """rows first..first+n-1 of ``out`` (>= first+n, 7) <- slots first..first+n-1."""
+        lib = _lib.load()
+        _chk(out, torch.float32, "out")
+        if out.dim() != 2 or out.shape[1] != 7 or out.shape[0] < first + n or first + n > self.n:
+            raise ValueError(f"fold: out {tuple(out.shape)} / slots {self.n} cannot hold rows {first}..{first + n - 1}")
+        with _on(self.device):
+            st = lib.mi355ppo_loss_scalars_f32(self.ptr(first), self.stride, int(n), ctypes.c_void_p(out.data_ptr() + 28 * first),
+                                               _stream(self.device))
+        _lib.check(st, "mi355ppo_loss_scalars_f32")
+        return out
+
+
+def adv_stats(b_advantages, inds, minibatch_size: int, out=None):
+    """``(mean, unbiased std + 1e-8)`` of ``b_advantages[inds[j*M:(j+1)*M]]`` for every minibatch j of one epoch's permutation,
+    in one launch (ppo_atari_multigpu.py:337-338).  Returns a ``(ceil(len/M), 2)`` f32 tensor whose rows are the
+    ``adv_mean_den`` argument of the loss entry points."""
+    lib = _lib.load()
+    flat = _chk(b_advantages.reshape(-1), torch.float32, "b_advantages")
+    total = flat.numel() if inds is None else inds.numel()
+    if inds is not None:
+        _chk(inds, torch.int64, "inds", (total,))
+    nseg = (total + minibatch_size - 1) // minibatch_size
+    out = out if out is not None else torch.empty(nseg, 2, dtype=torch.float32, device=flat.device)
+    _chk(out, torch.float32, "out", (nseg, 2))
+    ws = _workspace(flat.device, lib.mi355ppo_adv_stats_workspace_bytes(total, int(minibatch_size)))
+    with _on(flat.device):
+        st = lib.mi355ppo_adv_stats_f32(_ptr(flat), _ptr(inds), total, int(minibatch_size), _ptr(out), _ptr(ws), ws.numel(),
+                                        _stream(flat.device))
+    _lib.check(st, "mi355ppo_adv_stats_f32")
+    return out
+
+
 def ppo_loss_categorical(new_logits, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values,
                          clip_coef: float, ent_coef: float, vf_coef: float, norm_adv: bool = True,
-                         clip_vloss: bool = True, scalars_out=None, dlogits_out=None, dvalue_out=None):
+                         clip_vloss: bool = True, scalars_out=None, dlogits_out=None, dvalue_out=None, adv_mean_den=None,
+                         slot=None):
     """Fused minibatch loss fwd+bwd (ppo_atari_multigpu.py:320-355 + autograd backward).
 
-    Returns ``(scalars7, dlogits, dvalue)``; ``scalars7`` = LOSS_SCALAR_NAMES order, on device.
+    Returns ``(scalars7, dlogits, dvalue)``; ``scalars7`` = LOSS_SCALAR_NAMES order, on device.  ``adv_mean_den``: the
+    minibatch's row of :func:`adv_stats` (skips the statistics launch).  ``slot=(LossSlots, k)``: defer the scalar fold
+    (``scalars7`` is then None; ``LossSlots.fold`` produces it later).
     """
     lib = _lib.load()
     M, A = new_logits.shape
@@ -267,23 +319,30 @@ def ppo_loss_categorical(new_logits, new_value, mb_inds, b_actions, b_logprobs, 
         _chk(mb_inds, torch.int64, "mb_inds", (M,))
     Bf, b_logprobs, b_advantages, b_returns, b_values = _flat_batch(b_logprobs, b_advantages, b_returns, b_values)
     b_actions = _chk(b_actions.reshape(-1), torch.float32, "b_actions (f32 storage, as the reference)", (Bf,))
-    scalars = scalars_out if scalars_out is not None else torch.empty(7, dtype=torch.float32, device=dev)
+    if adv_mean_den is not None:
+        _chk(adv_mean_den, torch.float32, "adv_mean_den", (2,))
     dlogits = dlogits_out if dlogits_out is not None else torch.empty_like(new_logits)
     dvalue = dvalue_out if dvalue_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
-    need = lib.mi355ppo_loss_workspace_bytes(M, 0)
-    ws = _workspace(dev, need)
+    if slot is not None:
+        slots, k = slot
+        ws_ptr, ws_bytes, scalars = slots.ptr(k), slots.stride, None
+    else:
+        scalars = scalars_out if scalars_out is not None else torch.empty(7, dtype=torch.float32, device=dev)
+        ws = _workspace(dev, lib.mi355ppo_loss_workspace_bytes(M, 0))
+        ws_ptr, ws_bytes = _ptr(ws), ws.numel()
     with _on(dev):
         st = lib.mi355ppo_loss_categorical_fwd_bwd_f32(
             _ptr(new_logits), _ptr(new_value), _ptr(mb_inds), _ptr(b_actions), _ptr(b_logprobs), _ptr(b_advantages),
             _ptr(b_returns), _ptr(b_values), M, A, float(clip_coef), float(ent_coef), float(vf_coef), int(bool(norm_adv)),
-            int(bool(clip_vloss)), _ptr(scalars), _ptr(dlogits), _ptr(dvalue), _ptr(ws), ws.numel(), _stream(dev))
+            int(bool(clip_vloss)), _ptr(adv_mean_den), _ptr(scalars), _ptr(dlogits), _ptr(dvalue), ws_ptr, ws_bytes,
+            _stream(dev))
     _lib.check(st, "mi355ppo_loss_categorical_fwd_bwd_f32")
     return scalars, dlogits, dvalue
 
 
 def ppo_loss_normal(new_mean, logstd, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values,
                     clip_coef: float, ent_coef: float, vf_coef: float, norm_adv: bool = True, clip_vloss: bool = True,
-                    scalars_out=None):
+                    scalars_out=None, adv_mean_den=None):
     """Continuous-action loss fwd+bwd (ppo_continuous_action.py:265-300).
     Returns ``(scalars7, dmean, dlogstd, dvalue)``."""
     lib = _lib.load()
@@ -296,18 +355,19 @@ def ppo_loss_normal(new_mean, logstd, new_value, mb_inds, b_actions, b_logprobs,
         _chk(mb_inds, torch.int64, "mb_inds", (M,))
     Bf, b_logprobs, b_advantages, b_returns, b_values = _flat_batch(b_logprobs, b_advantages, b_returns, b_values)
     b_actions = _chk(b_actions.reshape(Bf, D), torch.float32, "b_actions", (Bf, D))
+    if adv_mean_den is not None:
+        _chk(adv_mean_den, torch.float32, "adv_mean_den", (2,))
     scalars = scalars_out if scalars_out is not None else torch.empty(7, dtype=torch.float32, device=dev)
     dmean = torch.empty_like(new_mean)
     dlogstd = torch.empty(D, dtype=torch.float32, device=dev)
     dvalue = torch.empty(M, dtype=torch.float32, device=dev)
-    need = lib.mi355ppo_loss_workspace_bytes(M, D)
-    ws = _workspace(dev, need)
+    ws = _workspace(dev, lib.mi355ppo_loss_workspace_bytes(M, D))
     with _on(dev):
         st = lib.mi355ppo_loss_normal_fwd_bwd_f32(
             _ptr(new_mean), _ptr(logstd_flat), _ptr(new_value), _ptr(mb_inds), _ptr(b_actions), _ptr(b_logprobs),
             _ptr(b_advantages), _ptr(b_returns), _ptr(b_values), M, D, float(clip_coef), float(ent_coef), float(vf_coef),
-            int(bool(norm_adv)), int(bool(clip_vloss)), _ptr(scalars), _ptr(dmean), _ptr(dlogstd), _ptr(dvalue), _ptr(ws),
-            ws.numel(), _stream(dev))
+            int(bool(norm_adv)), int(bool(clip_vloss)), _ptr(adv_mean_den), _ptr(scalars), _ptr(dmean), _ptr(dlogstd),
+            _ptr(dvalue), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(st, "mi355ppo_loss_normal_fwd_bwd_f32")
     return scalars, dmean, dlogstd, dvalue
 

@@ -140,8 +140,14 @@ MI355PPO_API int mi355ppo_normal_logprob_entropy_bwd_f32(const float* mean, cons
  *   b_actions_f32, b_logprobs, b_advantages, b_returns, b_values : (Bflat) f32       [in]
  *   scalars7 : loss, pg_loss, v_loss, entropy, old_approx_kl, approx_kl, clipfrac    [out, 7 f32]
  *   dlogits (M,A), dvalue (M) : d loss / d new_logits, d loss / d new_value          [out]
+ *   adv_mean_den : NULL, or 2 f32 = (mean, unbiased std + 1e-8) of b_advantages[mb_inds] from
+ *                  mi355ppo_adv_stats_f32 (then no statistics launch happens here)        [in]
  * Reductions are computed in a fixed order (deterministic); advantage mean / unbiased std are
- * accumulated in f64.  Tolerances vs the reference are stated in tests/test_gpu_loss.py.
+ * accumulated in f64.  Tolerances vs the reference are stated in tests/test_gpu_kernels.py.
+ * Launches per call: statistics (only if norm_adv and adv_mean_den == NULL), row pass, scalar fold
+ * (only if scalars7 != NULL).  scalars7 == NULL defers the fold: the call's partial sums stay in
+ * its workspace, which then must be a slot no other call overwrites until
+ * mi355ppo_loss_scalars_f32 has folded it (categorical family only).
  */
 MI355PPO_API size_t mi355ppo_loss_workspace_bytes(int M, int D);
 MI355PPO_API int mi355ppo_loss_categorical_fwd_bwd_f32(const float* new_logits, const float* new_value,
@@ -150,9 +156,25 @@ MI355PPO_API int mi355ppo_loss_categorical_fwd_bwd_f32(const float* new_logits, 
                                           const float* b_returns, const float* b_values,
                                           int M, int A,
                                           double clip_coef, double ent_coef, double vf_coef,
-                                          int norm_adv, int clip_vloss,
+                                          int norm_adv, int clip_vloss, const float* adv_mean_den,
                                           float* scalars7, float* dlogits, float* dvalue,
                                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Deferred scalar fold: row j of scalars (nslots,7) <- the partial sums that a categorical call
+ * with scalars7 == NULL left in the workspace at workspaces + j*slot_stride_bytes.  One launch for
+ * all minibatches of an update (the scalars are diagnostics: nothing on the device waits for them). */
+MI355PPO_API int mi355ppo_loss_scalars_f32(const void* workspaces, size_t slot_stride_bytes, int nslots,
+                                           float* scalars, void* stream);
+
+/* Advantage statistics of ALL minibatches of one epoch in one call / two launches (`mb_advantages.mean()`,
+ * `mb_advantages.std() + 1e-8`, cleanrl/ppo_atari_multigpu.py:337-338): they depend only on the
+ * epoch's permutation and the GAE output, not on anything the network produces, so the learner
+ * computes them when it uploads the permutation and K3 runs without its statistics launch.
+ *   inds (total) int64 or NULL (= identity); minibatch j = rows [j*M, min((j+1)*M, total));
+ *   mean_den : (ceil(total / M), 2) f32                                                  [out] */
+MI355PPO_API size_t mi355ppo_adv_stats_workspace_bytes(int64_t total, int M);
+MI355PPO_API int mi355ppo_adv_stats_f32(const float* b_advantages, const int64_t* inds, int64_t total, int M,
+                                        float* mean_den, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Continuous-action variant, cleanrl/ppo_continuous_action.py:265-300:
  *   new_mean (M,D), logstd (D), b_actions (Bflat,D) -> dmean (M,D), dlogstd (D), dvalue (M). */
@@ -162,7 +184,7 @@ MI355PPO_API int mi355ppo_loss_normal_fwd_bwd_f32(const float* new_mean, const f
                                      const float* b_returns, const float* b_values,
                                      int M, int D,
                                      double clip_coef, double ent_coef, double vf_coef,
-                                     int norm_adv, int clip_vloss,
+                                     int norm_adv, int clip_vloss, const float* adv_mean_den,
                                      float* scalars7, float* dmean, float* dlogstd, float* dvalue,
                                      void* workspace, size_t workspace_bytes, void* stream);
 

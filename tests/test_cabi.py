@@ -47,12 +47,13 @@ def test_validation_errors_are_loud_and_precede_any_launch():
     # unsupported action count
     assert lib.mi355ppo_categorical_sample_f32(p, None, 0, 0, p, None, p, None, 4, 65, None) == -1
     # workspace too small / missing
-    assert lib.mi355ppo_loss_categorical_fwd_bwd_f32(p, p, None, p, p, p, p, p, 8, 4, 0.1, 0.01, 0.5, 1, 1, p, p, p,
+    assert lib.mi355ppo_loss_categorical_fwd_bwd_f32(p, p, None, p, p, p, p, p, 8, 4, 0.1, 0.01, 0.5, 1, 1, None, p, p, p,
                                                      None, 0, None) == -4
-    assert lib.mi355ppo_loss_categorical_fwd_bwd_f32(p, p, None, p, p, p, p, p, 8, 4, 0.1, 0.01, 0.5, 1, 1, p, p, p,
+    assert lib.mi355ppo_loss_categorical_fwd_bwd_f32(p, p, None, p, p, p, p, p, 8, 4, 0.1, 0.01, 0.5, 1, 1, None, p, p, p,
                                                      p, 8, None) == -4
     assert b"workspace" in lib.mi355ppo_last_error()
-    assert lib.mi355ppo_loss_workspace_bytes(32768, 0) == (2 * 128 + 128 * 6) * 8
+    assert lib.mi355ppo_loss_workspace_bytes(32768, 0) == 64 + (2 * 1024 + 2048 * 6) * 8   # slot head + statistics partials + 6 sums per workgroup
+    assert lib.mi355ppo_loss_workspace_bytes(4096, 6) == 64 + (2 * 1024 + 2048 * 12) * 8
     assert lib.mi355ppo_clip_adam_f32(p, p, p, p, 16, 1.0, 0.5, 1e-3, 0.9, 0.999, 1e-5, 0, None, p, 4096, None) == -1
     assert lib.mi355ppo_obs_u8_to_f32(p, None, p, 4, 6, 1, None) == -1   # row_bytes % 4 != 0
 

@@ -190,9 +190,11 @@ def test_loss_normal_goldens(case):
 
 
 @pytest.mark.parametrize("M,A,flags", [(32768, 4, (1, 1)), (8192, 4, (1, 0)), (4096, 6, (0, 1)), (1000, 18, (1, 1)),
-                                       (257, 2, (0, 0)), (5, 3, (1, 1)), (131072, 4, (1, 1))])
+                                       (257, 2, (0, 0)), (5, 3, (1, 1)), (131072, 4, (1, 1)), (1, 4, (0, 1)),
+                                       (300001, 4, (1, 1)), (1200007, 4, (1, 1)), (900001, 6, (1, 0)), (700003, 18, (1, 1))])
 def test_loss_categorical_vs_c_oracle_at_config_sizes(M, A, flags):
-    """BASELINE config sizes (C: M=32768 of B=131072, D: 8192, B: 4096) against the scalar C oracle."""
+    """BASELINE config sizes (C: M=32768 of B=131072, D: 8192, B: 4096) against the scalar C oracle; the ragged large
+    sizes cover the persistent row pass (more than one sweep per lane) and the 1024-partial statistics."""
     rs = np.random.RandomState(M + A)
     Bf = 4 * M
     logits = rs.standard_normal((M, A)).astype(np.float32)
@@ -219,6 +221,23 @@ def test_loss_categorical_vs_c_oracle_at_config_sizes(M, A, flags):
     sc3, dl3, _ = ops.ppo_loss_categorical(*a_id, **kw)
     sc4, dl4, _ = ops.ppo_loss_categorical(args[0], args[1], ar, *args[3:], **kw)
     assert torch.equal(sc3, sc4) and torch.equal(dl3, dl4)
+    if flags[0]:
+        # statistics hoisted out of the call (one launch for every minibatch of an epoch): same gradients
+        md = ops.adv_stats(args[5], args[2], M)
+        mean, std = float(b_adv[inds].astype(np.float64).mean()), float(b_adv[inds].astype(np.float64).std(ddof=1)) if M > 1 else float("nan")
+        if M > 1:
+            np.testing.assert_allclose(md.cpu().numpy(), [[mean, np.float32(std) + np.float32(1e-8)]], rtol=2e-6, atol=1e-7)
+        sc5, dl5, dv5 = ops.ppo_loss_categorical(*args, adv_mean_den=md[0], **kw)
+        np.testing.assert_allclose(sc5.cpu().numpy(), sc_o, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(dl5.cpu().numpy(), dl_o, rtol=1e-4, atol=1e-5 * np.abs(dl_o).max())
+        # scalar fold deferred: two calls leave their partial sums in two slots, one launch folds both -> the same bits
+        slots = ops.LossSlots(3, DEV)
+        none6, dl6, _ = ops.ppo_loss_categorical(*args, adv_mean_den=md[0], slot=(slots, 2), **kw)
+        ops.ppo_loss_categorical(*args, slot=(slots, 1), **kw)
+        table = torch.zeros(3, 7, device=DEV)
+        slots.fold(2, table, first=1)
+        assert none6 is None and torch.equal(dl6, dl5)
+        assert torch.equal(table[2], sc5) and torch.equal(table[1], sc) and float(table[0].abs().sum()) == 0.0
 
 
 def test_loss_autograd_function_matches_torch_autograd_on_device():

@@ -66,10 +66,43 @@ class FakeOps:
             _chk(logprob_out, torch.float32, "logprob_out", (B,)).copy_(lp)
         return a, action_f32_out, lp, probs.entropy() if want_entropy else None
 
+    class LossSlots:
+        """Deferred scalar fold: a slot holds the 7 scalars of the call that used it until fold() hands them out."""
+
+        def __init__(self, n, device):
+            self.n, self.rows = int(n), [None] * int(n)
+
+        def fold(self, n, out, first=0):
+            _chk(out, torch.float32, "out")
+            assert out.dim() == 2 and out.shape[1] == 7 and first + n <= self.n and first + n <= out.shape[0]
+            for j in range(first, first + n):
+                assert self.rows[j] is not None, f"slot {j} folded before any call filled it"
+                out[j].copy_(self.rows[j])
+                self.rows[j] = None
+            return out
+
+    @staticmethod
+    def adv_stats(b_advantages, inds, minibatch_size, out=None):
+        flat = _chk(b_advantages.reshape(-1), torch.float32, "b_advantages")
+        _chk(inds, torch.int64, "inds")
+        rows = [flat[inds[s:s + minibatch_size]] for s in range(0, inds.numel(), minibatch_size)]
+        return torch.stack([torch.stack([r.mean(), r.std() + 1e-8]) for r in rows])
+
+    @staticmethod
+    def _check_adv_mean_den(adv_mean_den, b_advantages, mb_inds):
+        """A hoisted statistics pair must be THIS minibatch's (a wrong row would silently change the normalisation)."""
+        if adv_mean_den is None:
+            return
+        _chk(adv_mean_den, torch.float32, "adv_mean_den", (2,))
+        mb = b_advantages.reshape(-1)[mb_inds]
+        torch.testing.assert_close(adv_mean_den, torch.stack([mb.mean(), mb.std() + 1e-8]), rtol=1e-5, atol=1e-6)
+
     @staticmethod
     def ppo_loss_categorical(new_logits, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values, clip_coef,
-                             ent_coef, vf_coef, norm_adv=True, clip_vloss=True, scalars_out=None, dlogits_out=None, dvalue_out=None):
+                             ent_coef, vf_coef, norm_adv=True, clip_vloss=True, scalars_out=None, dlogits_out=None, dvalue_out=None,
+                             adv_mean_den=None, slot=None):
         M, A = new_logits.shape
+        FakeOps._check_adv_mean_den(adv_mean_den, b_advantages, mb_inds)
         _chk(new_logits, torch.float32, "new_logits", (M, A))
         _chk(new_value.reshape(-1), torch.float32, "new_value", (M,))
         _chk(mb_inds, torch.int64, "mb_inds", (M,))
@@ -86,6 +119,11 @@ class FakeOps:
                                      b_advantages.reshape(-1)[mb_inds], b_returns.reshape(-1)[mb_inds],
                                      b_values.reshape(-1)[mb_inds], clip_coef, ent_coef, vf_coef, norm_adv, clip_vloss)
         loss.backward()
+        if slot is not None:                      # deferred fold: nothing may be written to scalars_out by this call
+            slots, k = slot
+            assert 0 <= k < slots.n and slots.rows[k] is None, "loss slot reused before it was folded"
+            slots.rows[k] = sc.detach().clone()
+            return None, logits.grad, value.grad
         if scalars_out is not None:
             _chk(scalars_out, torch.float32, "scalars_out", (7,)).copy_(sc)
         return (scalars_out if scalars_out is not None else sc), logits.grad, value.grad
@@ -106,8 +144,9 @@ class FakeOps:
 
     @staticmethod
     def ppo_loss_normal(new_mean, logstd, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values, clip_coef,
-                        ent_coef, vf_coef, norm_adv=True, clip_vloss=True, scalars_out=None):
+                        ent_coef, vf_coef, norm_adv=True, clip_vloss=True, scalars_out=None, adv_mean_den=None):
         M, D = new_mean.shape
+        FakeOps._check_adv_mean_den(adv_mean_den, b_advantages, mb_inds)
         _chk(new_mean, torch.float32, "new_mean", (M, D))
         _chk(logstd.reshape(-1), torch.float32, "logstd", (D,))
         _chk(new_value.reshape(-1), torch.float32, "new_value", (M,))
@@ -188,6 +227,9 @@ def _to_fake_hip(L, flat_module=None):
     E_ = int(L.args.update_epochs)
     n_upd = E_ * -(-L.batch_size // L.minibatch_size)
     L._scalars = torch.zeros((n_upd, 7))
+    from cleanrl_amd.learner import PPOLearner
+    if L.discrete and type(L).forward_backward_hip is PPOLearner.forward_backward_hip:     # as PPOLearner.__init__ on a GPU
+        L._loss_slots = FakeOps.LossSlots(n_upd, dev)
     L._inds_dev = torch.empty((E_, L.batch_size), dtype=torch.int64)
     L._inds_pin = torch.empty((E_, L.batch_size), dtype=torch.int64)
     L._total_norm = torch.zeros(1)

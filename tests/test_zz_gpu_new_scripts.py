@@ -41,7 +41,9 @@ def test_lstm_hip_path_teacher_forced_against_reference_iteration():
     agent, L = _learner(g, T, N)
     assert L.hip and L.obs.dtype == torch.uint8 and not L.fused_cnn
     stride = int(g["stride"])
-    np.testing.assert_allclose(L.flat.params[::stride].cpu().numpy(), g["init_params_sub"], rtol=1e-5, atol=1e-6)
+    # same seed -> same weights, up to LAPACK: orthogonal_'s QR of the LSTM matrices takes another code path on the GPU box's
+    # host CPU than on the minting machine (1 of 20,695 sampled weights off by 2e-6 there)
+    np.testing.assert_allclose(L.flat.params[::stride].cpu().numpy(), g["init_params_sub"], rtol=1e-4, atol=1e-5)
     frames, step_done = g["frames_u8"], g["step_done"]
     # rollout: the reference's actions are forced (the HIP sampler draws from Philox, not from torch's generator), the
     # network outputs along the way must agree with what the reference Agent computed

@@ -40,26 +40,39 @@ def main():
         del s, adv, ret
     A = 4
     g = torch.Generator(device="cpu").manual_seed(3)
-    for M in (4096, 32768, 1 << 17, 1 << 20, 1 << 22, 1 << 24):
-        B = M
-        logits = torch.randn(M, A, generator=g).to(DEV)
-        value = torch.randn(M, generator=g).to(DEV)
-        inds = torch.randperm(B, generator=g).to(DEV)
-        b_actions = torch.randint(0, A, (B,), generator=g).float().to(DEV)
-        b_lp = (torch.randn(B, generator=g) * 0.1 - 1.4).to(DEV)
-        b_adv, b_ret, b_val = (torch.randn(B, generator=g).to(DEV) for _ in range(3))
-        sc = torch.empty(7, device=DEV)
-        dl, dv = torch.empty_like(logits), torch.empty_like(value)
-        f = lambda: ops.ppo_loss_categorical(logits, value, inds, b_actions, b_lp, b_adv, b_ret, b_val, 0.1, 0.01, 0.5, True, True,
-                                             scalars_out=sc, dlogits_out=dl, dvalue_out=dv)
-        try:
-            us = ev_us(f, REPS)
-        except TypeError:
+    # K3 modes: "perm" = mb_inds a random permutation of a flat batch as large as the minibatch (every gather a new line once
+    # the five arrays outgrow L2); "resident" = random rows of a 131,072-row flat batch (config C's: the five arrays stay in L2);
+    # "identity" = mb_inds NULL (pure streaming).
+    for mode in ("perm", "resident", "identity"):
+        for M in (4096, 32768, 1 << 17, 1 << 20, 1 << 22, 1 << 24):
+            B = M if mode != "resident" else 131072
+            logits = torch.randn(M, A, generator=g).to(DEV)
+            value = torch.randn(M, generator=g).to(DEV)
+            if mode == "perm":
+                inds = torch.randperm(B, generator=g).to(DEV)
+            elif mode == "resident":
+                inds = torch.randint(0, B, (M,), generator=g).to(DEV)
+            else:
+                inds = None
+            b_actions = torch.randint(0, A, (B,), generator=g).float().to(DEV)
+            b_lp = (torch.randn(B, generator=g) * 0.1 - 1.4).to(DEV)
+            b_adv, b_ret, b_val = (torch.randn(B, generator=g).to(DEV) for _ in range(3))
+            sc = torch.empty(7, device=DEV)
+            dl, dv = torch.empty_like(logits), torch.empty_like(value)
             f = lambda: ops.ppo_loss_categorical(logits, value, inds, b_actions, b_lp, b_adv, b_ret, b_val, 0.1, 0.01, 0.5, True, True,
-                                                 scalars_out=sc)
+                                                 scalars_out=sc, dlogits_out=dl, dvalue_out=dv)
             us = ev_us(f, REPS)
-        nbytes = (8 * A + 28 + 8) * M
-        print(json.dumps(dict(kernel="loss_categorical", M=M, algorithmic_bytes=nbytes, event_us_per_call=us, GBps=nbytes / us / 1e3)), flush=True)
+            us2 = None
+            if True:                # the learner's mode: statistics hoisted to once per epoch, scalar fold deferred to once per update
+                md = ops.adv_stats(b_adv, inds, M)[0]
+                slots = ops.LossSlots(1, DEV)
+                f2 = lambda: ops.ppo_loss_categorical(logits, value, inds, b_actions, b_lp, b_adv, b_ret, b_val, 0.1, 0.01, 0.5, True, True,
+                                                      dlogits_out=dl, dvalue_out=dv, adv_mean_den=md, slot=(slots, 0))
+                us2 = ev_us(f2, REPS)
+                slots.fold(1, sc.view(1, 7))
+            nbytes = (8 * A + 28 + (8 if inds is not None else 0)) * M
+            print(json.dumps(dict(kernel="loss_categorical", mode=mode, M=M, B=B, algorithmic_bytes=nbytes, event_us_per_call=us,
+                                  GBps=nbytes / us / 1e3, event_us_per_call_learner_mode=us2)), flush=True)
 
 
 if __name__ == "__main__":
