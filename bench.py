@@ -78,6 +78,11 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= the f32 vector peak
 OBS_ROW_BYTES = 4 * 84 * 84   # 28,224
 
 
+def _conv1_fwd_bytes(images):
+    """Algorithmic bytes of a layer-1 forward launch: the uint8 frame read once + the f32 activation written once."""
+    return images * (OBS_ROW_BYTES + 20 * 20 * 32 * 4)
+
+
 def _traffic_of(key):
     """HBM bytes per launch of conv launch `key` ("conv1_wgrad@32768") from the committed PMC passes, or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -206,7 +211,7 @@ def main():
 
                 return hooked
 
-            def fwd_images(src, Bt, bias, layer, inds=None, out=None):
+            def fwd_images(src, Bt, bias, layer, inds=None, out=None, variant=0):
                 return src.shape[0] if inds is None else inds.numel()
 
             real_trunk = cnn.trunk_fwd
@@ -293,7 +298,9 @@ def main():
                 "local_num_envs": N, "num_steps": T, "global_num_envs": world * N, "minibatch_rows": M,
                 "parallelism": f"dp{world} (one learner per GPU, RCCL all-reduce of the flat f32 gradient)",
                 "env": "device-resident synthetic generator (no PCIe in the timed region)",
-                "cnn": "f32-MFMA implicit-GEMM kernels (csrc/conv.hip)" if learner.fused_cnn else "torch Conv2d (MIOpen)",
+                "cnn": "f32-MFMA implicit-GEMM kernels (csrc/conv.hip); layer-1 forward on the int8 MFMA with exact int32 "
+                       "accumulation over 31-bit fixed-point weights (csrc/conv1q.hip): error vs float64 <= the f32 kernel's"
+                       if learner.fused_cnn else "torch Conv2d (MIOpen)",
             },
             "final_loss": metrics["loss"],
         }
@@ -307,16 +314,29 @@ def main():
             dom = max(tot, key=tot.get)
             us, n = timer.mean_us(dom)
             tf = conv_flops[dom] / us / 1e6
-            out["roofline"] = {
-                "kernel": f"{dom}: " + ("conv_wgrad_rows_kernel" if dom.startswith("conv1_wgrad") else
-                                        "conv_wgrad_taps_kernel" if "_wgrad" in dom else "conv_fixed_kernel") +
-                          " (f32-MFMA implicit GEMM, csrc/conv.hip); the uint8 gather + /255 (K5), bias, ReLU, ReLU-backward and "
-                          "bias-gradient passes are fused into the conv kernels and have none of their own",
-                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": _traffic_of(dom),
-                "algorithmic_flops_per_launch": conv_flops[dom], "avg_launch_us": us, "launches_timed": n,
-                "share_of_step_time": tot[dom] / (elapsed * 1e6),
-            }
+            if dom.startswith("conv1_fwd"):
+                # layer-1 forward runs on the integer matrix pipe (kernel Q, csrc/conv1q.hip): 1/8 of the f32 pipe's time,
+                # so the launch is bound by HBM -- uint8 rows in, f32 activations out
+                alg = _conv1_fwd_bytes(int(dom.split("@")[1]))
+                out["roofline"] = {
+                    "kernel": f"{dom}: conv1q_fwd_kernel (int8-digit MFMA, exact int32 accumulation, csrc/conv1q.hip); uint8 gather, "
+                              "/255, bias and ReLU fused",
+                    "bound": "hbm", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": alg / us / 1e3 / HBM_PEAK_GBPS, "traffic": _traffic_of(dom),
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": us, "launches_timed": n,
+                    "share_of_step_time": tot[dom] / (elapsed * 1e6),
+                }
+            else:
+                out["roofline"] = {
+                    "kernel": f"{dom}: " + ("conv_wgrad_rows_kernel" if dom.startswith("conv1_wgrad") else
+                                            "conv_wgrad_taps_kernel" if "_wgrad" in dom else "conv_fixed_kernel") +
+                              " (f32-MFMA implicit GEMM, csrc/conv.hip); the uint8 gather + /255 (K5), bias, ReLU, ReLU-backward and "
+                              "bias-gradient passes are fused into the conv kernels and have none of their own",
+                    "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": _traffic_of(dom),
+                    "algorithmic_flops_per_launch": conv_flops[dom], "avg_launch_us": us, "launches_timed": n,
+                    "share_of_step_time": tot[dom] / (elapsed * 1e6),
+                }
             gus, gn = timer.mean_us("gae")
             lus, ln = timer.mean_us("loss")
             gae_bytes = 20 * T * N + 8 * N
@@ -324,8 +344,9 @@ def main():
             out["kernels"] = {
                 "gae": {"algorithmic_bytes": gae_bytes, "avg_us_event_bracket": gus, "GBps": gae_bytes / gus / 1e3,
                         "launches_timed": gn, "note": "128x1024 is launch/latency-bound: see profiles/ for the kernel time"},
-                "loss_fwd_bwd": {"algorithmic_bytes": loss_bytes, "avg_us_event_bracket_3_launches": lus,
-                                 "GBps": loss_bytes / lus / 1e3, "launches_timed": ln},
+                "loss_fwd_bwd": {"algorithmic_bytes": loss_bytes, "avg_us_event_bracket": lus,
+                                 "GBps": loss_bytes / lus / 1e3, "launches_timed": ln,
+                                 "note": "one launch per minibatch (advantage statistics once per epoch, scalar fold once per update)"},
             }
             for k in sorted(conv_flops):
                 kus, kn = timer.mean_us(k)
@@ -334,6 +355,10 @@ def main():
                                      "frac_of_f32_mfma_peak": conv_flops[k] / kus / 1e6 / MFMA_F32_PEAK_TFLOPS,
                                      "ms_per_step": kus * launches / cli.steps / 1e3,
                                      "hbm_bytes_per_launch_pmc": _traffic_of(k)}
+                if k.startswith("conv1_fwd"):        # kernel Q: HBM-bound, the f32-pipe fraction is > 1 by construction
+                    alg = _conv1_fwd_bytes(int(k.split("@")[1]))
+                    out["kernels"][k].update({"bound": "hbm", "algorithmic_bytes": alg, "GBps": alg / kus / 1e3,
+                                              "frac_of_hbm_peak": alg / kus / 1e3 / HBM_PEAK_GBPS})
         elif not cli.no_kernel_timing:
             us, n = timer.mean_us("obs_gather")
             alg = OBS_ROW_BYTES * 5 * M

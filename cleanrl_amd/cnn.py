@@ -18,15 +18,17 @@ from .ops import _chk, _on, _ptr, _stream, _workspace
 
 # layer -> (Cin, Cout, K, stride, Hin, Hout)
 LAYERS = {1: (4, 32, 8, 4, 84, 20), 2: (32, 64, 4, 2, 20, 9), 3: (64, 64, 3, 1, 9, 7)}
-MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2, MODE_DGRAD_S1_CLASSES = 0, 1, 2, 3
+MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2, MODE_DGRAD_S1_CLASSES, MODE_FWD_Q = 0, 1, 2, 3, 4
 BT_CLASSES_NUMEL = 81 * 4096
+QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 storage elements (kernel Q's integer-digit pack)
+VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
 
 
 def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch.Tensor | None = None) -> torch.Tensor:
     lib = _lib.load()
     cin, cout, k, _, _, _ = LAYERS[layer]
     _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
-    numel = BT_CLASSES_NUMEL if mode == MODE_DGRAD_S1_CLASSES else W.numel()
+    numel = BT_CLASSES_NUMEL if mode == MODE_DGRAD_S1_CLASSES else QPACK_NUMEL if mode == MODE_FWD_Q else W.numel()
     if out is None:
         out = torch.empty(numel, dtype=torch.float32, device=W.device)
     _chk(out, torch.float32, "Bt", (numel,))
@@ -51,7 +53,7 @@ def conv_fwd(src: torch.Tensor, Bt: torch.Tensor, bias: torch.Tensor, layer: int
         assert inds is None
         images = src.shape[0]
         _chk(src, torch.float32, "src", (images, hin, hin, cin))
-    _chk(Bt, torch.float32, "Bt", (cout * cin * k * k,))
+    _chk(Bt, torch.float32, "Bt", (QPACK_NUMEL if variant == VARIANT_Q else cout * cin * k * k,))
     _chk(bias, torch.float32, "bias", (cout,))
     if out is None:
         out = torch.empty((images, hout, hout, cout), dtype=torch.float32, device=src.device)
@@ -108,15 +110,16 @@ def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tens
     return dW, db
 
 
-def trunk_fwd(obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3):
-    """conv1 -> conv2 -> conv3 (each with bias + ReLU) in one library call; buffers as produced by ``_Buffers``."""
+def trunk_fwd(obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3, conv1_variant: int = 0):
+    """conv1 -> conv2 -> conv3 (each with bias + ReLU) in one library call; buffers as produced by ``_Buffers``.
+    ``conv1_variant=VARIANT_Q``: ``bt1`` is the mode-4 pack."""
     lib = _lib.load()
     _chk(obs_u8, torch.uint8, "obs_u8")
     images = a1.shape[0]
     dev = obs_u8.device
     with _on(dev):
         st = lib.mi355ppo_cnn_trunk_fwd_f32(_ptr(obs_u8), _ptr(inds), _ptr(bt1), _ptr(b1), _ptr(bt2), _ptr(b2), _ptr(bt3), _ptr(b3),
-                                            _ptr(a1), _ptr(a2), _ptr(a3), images, _stream(dev))
+                                            _ptr(a1), _ptr(a2), _ptr(a3), images, int(conv1_variant), _stream(dev))
     _lib.check(st, "mi355ppo_cnn_trunk_fwd_f32")
     return a3
 
@@ -173,11 +176,13 @@ class NatureTrunkFn(torch.autograd.Function):
     def forward(ctx, obs_u8, inds, W1, b1, W2, b2, W3, b3, bufs):
         m = obs_u8.shape[0] if inds is None else inds.numel()
         a1, a2, a3 = bufs.get(m, obs_u8.device, False)
-        bt1, bt2, bt3 = (bufs.weights(W, l, MODE_FWD) for l, W in ((1, W1), (2, W2), (3, W3)))
+        # layer 1 runs on the integer matrix pipe (kernel Q): uint8 taps are exact int8 operands, weights four int8 digits
+        bt1 = bufs.weights(W1, 1, MODE_FWD_Q)
+        bt2, bt3 = bufs.weights(W2, 2, MODE_FWD), bufs.weights(W3, 3, MODE_FWD)
         if m <= 4096 and obs_u8.is_contiguous() and tuple(obs_u8.shape[1:]) == (84, 84, 4):     # inference-sized: one call
-            trunk_fwd(obs_u8, inds, bt1, b1.detach(), bt2, b2.detach(), bt3, b3.detach(), a1, a2, a3)
+            trunk_fwd(obs_u8, inds, bt1, b1.detach(), bt2, b2.detach(), bt3, b3.detach(), a1, a2, a3, conv1_variant=VARIANT_Q)
         else:
-            conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1)
+            conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1, variant=VARIANT_Q)
             conv_fwd(a1, bt2, b2.detach(), 2, None, a2)
             conv_fwd(a2, bt3, b3.detach(), 3, None, a3)
         ctx.obs, ctx.inds, ctx.acts, ctx.bufs = obs_u8, inds, (a1, a2, a3), bufs

@@ -1456,6 +1456,7 @@ extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, floa
     int Cin, Cout, KH, SS, Hin, Hout;
     MI355_REQUIRE(W && Bt, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
+    if (mode == 4 && layer == 1) return mi355ppo_cnn_conv1q_pack(W, Bt, stream);   // integer-digit pack of kernel Q (conv1q.hip)
     MI355_REQUIRE(mode == 0 || ((mode == 1 || mode == 3) && layer == 3) || (mode == 2 && layer == 2), MI355PPO_EINVAL,
                   "%s: mode %d is not defined for layer %d", fn, mode, layer);
     const int total = mode == 3 ? kC3_total : Cout * Cin * KH * KH;
@@ -1612,9 +1613,10 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
     MI355_REQUIRE(layer == 1 || inds == nullptr, MI355PPO_EINVAL, "%s: inds (row gather) is only defined for layer 1", fn);
-    MI355_REQUIRE(variant >= 0 && variant <= 4, MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
+    MI355_REQUIRE((variant >= 0 && variant <= 4) || (variant == 6 && layer == 1), MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(src, 16) && aligned(Bt, 16) && aligned(dst, 16) && aligned(inds, 8), MI355PPO_EALIGN,
                   "%s: src/Bt/dst must be 16-byte aligned", fn);
+    if (variant == 6) return mi355ppo_cnn_conv1q_fwd(src, inds, Bt, bias, dst, images, stream);   // Bt = the mode-4 pack
     ConvGeom g;
     g.H = g.W = Hin; g.C = Cin; g.KH = g.KW = KH; g.GY = g.GX = Hout; g.SS = SS; g.OFF = 0;
     g.DH = g.DW = Hout; g.DC = Cout; g.DM = 1; g.DAY = g.DAX = 0; g.K = KH * KH * Cin; g.N = Cout; g.classes = 1;
@@ -1664,8 +1666,9 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_f32_variant(const void* src, c
 // The three forward layers in one call (rollout inference: the host-side cost of a launch matters there).
 extern "C" MI355PPO_API int mi355ppo_cnn_trunk_fwd_f32(const void* obs_u8, const int64_t* inds, const float* bt1, const float* b1,
                                                        const float* bt2, const float* b2, const float* bt3, const float* b3,
-                                                       float* a1, float* a2, float* a3, int64_t images, void* stream) {
-    int rc = conv_fwd_impl(obs_u8, inds, bt1, b1, a1, images, 1, 0, stream);
+                                                       float* a1, float* a2, float* a3, int64_t images, int conv1_variant,
+                                                       void* stream) {
+    int rc = conv_fwd_impl(obs_u8, inds, bt1, b1, a1, images, 1, conv1_variant, stream);
     if (rc) return rc;
     rc = conv_fwd_impl(a1, nullptr, bt2, b2, a2, images, 2, 0, stream);
     if (rc) return rc;

@@ -1,0 +1,227 @@
+// Kernel Q -- layer-1 forward convolution of the NatureCNN on the INTEGER matrix pipe (gfx950).
+//
+// relu(conv1(obs[inds] / 255) + bias), cleanrl/ppo_atari_multigpu.py:136-137,154 (Conv2d(4, 32, 8, stride=4) + ReLU on
+// uint8 frames), the same contract as kernel F's layer-1 forward in conv.hip -- but the source operand of this layer is
+// uint8, i.e. already an exact integer, and gfx950's `v_mfma_i32_32x32x32_i8` runs at 32x the rate of the f32 MFMA
+// (2x bf16), accumulates EXACTLY in int32 and takes a whole 32-byte tap row (8 taps x 4 channels) per instruction:
+//
+//   * weights: each f32 weight is rounded once to a 31-bit signed fixed-point number on its output channel's scale
+//     (q = rint(w * 2^(30-E_n)), 2^(E_n-1) <= max_k |w[k][n]| < 2^E_n: an error of <= 2^(E_n-31), i.e. <= 2^-30 of the
+//     channel's largest weight -- 1/64 of that weight's own f32 ulp and far below the rounding noise of a 256-term f32
+//     sum; the channel's large weights are represented exactly) and written as four signed
+//     radix-256 digits  q = d0*2^24 + d1*2^16 + d2*2^8 + d3,  d in [-128, 127];
+//   * inputs: v - 128 (one `v_xor 0x80808080` per four bytes) is int8; the constant 128 * sum_k d[k][n] is added to the
+//     int32 accumulator, so D_j = sum_k v[k] * d_j[k][n] comes out exact, no cancellation anywhere;
+//   * y = (((D3 * 2^-8 + D2) * 2^-8 + D1) * 2^-8 + D0) * (2^(E_n-6) / 255) + bias: three f32 roundings in the Horner
+//     chain, one for the scale, one for the bias -- instead of 256 roundings in an f32 fma chain.  Measured against a
+//     float64 convolution the result is CLOSER than the f32-MFMA kernel's (tests/test_gpu_cnn.py).
+//
+// Structure: persistent 4-wave workgroups (three per CU), a wave owns 32-pixel x 32-channel tiles.  The four digit
+// matrices sit in LDS in operand layout (32 KB per workgroup).  Holding them in registers was
+// measured first (profiles/r02_*): 128 VGPRs of digits leave two waves per SIMD, and on gfx9 a tile's epilogue stores
+// force the prefetched loads of the next tile to be waited for with vmcnt(0) (loads and stores share one out-of-order
+// counter) -- ~2,000 cycles of store acknowledgement per 1,800-cycle tile that only MORE waves per SIMD can fill
+// (3.6 TB/s with two).  No barrier after the prologue.  Per tile and tap row a lane issues one 16-byte
+// global load (its half of the pixel's 32-byte tap row, straight from the uint8 rollout rows through mb_inds), four LDS
+// reads, four xors and four MFMAs; the eight rows of the next tile are requested as the current ones are consumed.
+// 1024 matrix-pipe cycles per tile against 8192 for the f32 MFMA: the kernel is bound by HBM (28,224 B read + 51,200 B
+// written per image), not by the pipe.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace mi355ppo {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+
+constexpr int kQRows = 8, kQDigits = 4;
+constexpr int kQDigBytes = kQRows * kQDigits * 64 * 16;          // int8 digits in operand layout: [row][digit][lane][16]
+constexpr int kQAccOff = kQDigBytes;                             // int32 [digit][channel]: 128 * sum_k digit
+constexpr int kQScaleOff = kQAccOff + kQDigits * 32 * 4;         // f32 [channel]: 2^(E_n - 6) / 255
+constexpr int kQPackBytes = kQScaleOff + 32 * 4;                 // 33,408
+constexpr int kQH = 84, kQW = 84, kQC = 4, kQG = 20, kQPitch = kQW * kQC, kQPerImg = kQG * kQG;
+constexpr unsigned kQOob = 0xFFFFF000u;
+constexpr int kQRsrcWord3 = 0x00020000;
+
+// One workgroup: W (32,4,8,8) f32 as torch stores it -> the pack.
+__global__ __launch_bounds__(256) void conv1q_pack_kernel(const float* __restrict__ W, unsigned char* __restrict__ pack) {
+    __shared__ int s_E[32];
+    __shared__ int s_sum[kQDigits][32][8];
+    const int tid = threadIdx.x;
+    if (tid < 32) {
+        float m = 0.0f;
+        for (int k = 0; k < 256; ++k) m = fmaxf(m, fabsf(W[tid * 256 + k]));
+        int E = 0;
+        if (m > 0.0f) {
+            (void)frexpf(m, &E);                 // m = f * 2^E, f in [0.5, 1)
+        }
+        s_E[tid] = E;
+    }
+    __syncthreads();
+    // thread -> (channel n, tap row r): the 32 weights W[n][c][r][kw] of one operand row pair
+    const int n = tid >> 3, r = tid & 7;
+    const int E = s_E[n];
+    int sums[kQDigits] = {0, 0, 0, 0};
+    for (int e32 = 0; e32 < 32; ++e32) {         // byte e32 of the pixel's tap row: column kw = e32 / 4, channel c = e32 % 4
+        const int kw = e32 >> 2, c = e32 & 3;
+        const float w = W[((n * kQC + c) * 8 + r) * 8 + kw];
+        long long q = llrint(ldexp((double)w, 30 - E));
+        int dig[kQDigits];
+        for (int d = kQDigits - 1; d >= 0; --d) {
+            const int lo = (int)(((q + 128) & 255) - 128);
+            dig[d] = lo;
+            q = (q - lo) >> 8;
+        }
+        const int lh = e32 >> 4, e = e32 & 15;
+        for (int d = 0; d < kQDigits; ++d) {
+            pack[((r * kQDigits + d) * 64 + lh * 32 + n) * 16 + e] = (unsigned char)(signed char)dig[d];
+            sums[d] += dig[d];
+        }
+    }
+    for (int d = 0; d < kQDigits; ++d) s_sum[d][n][r] = sums[d];
+    __syncthreads();
+    if (tid < kQDigits * 32) {
+        const int d = tid >> 5, nn = tid & 31;
+        int s = 0;
+        for (int rr = 0; rr < 8; ++rr) s += s_sum[d][nn][rr];
+        reinterpret_cast<int*>(pack + kQAccOff)[d * 32 + nn] = 128 * s;
+    }
+    if (tid < 32) reinterpret_cast<float*>(pack + kQScaleOff)[tid] = (float)(ldexp(1.0, s_E[tid] - 6) / 255.0);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv1q_fwd_kernel(const unsigned char* __restrict__ src, const int64_t* __restrict__ inds,
+                                                             const unsigned char* __restrict__ pack, const float* __restrict__ bias,
+                                                             float* __restrict__ dst, unsigned P, int ntiles, unsigned dst_bytes) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    // digit matrices, in operand layout, -> LDS [row][digit][lane]
+    __shared__ i32x4 Bl[kQRows][kQDigits][64];
+    {
+        const i32x4* __restrict__ p4 = reinterpret_cast<const i32x4*>(pack);
+        for (int e = tid; e < kQRows * kQDigits * 64; e += 64 * NW) (&Bl[0][0][0])[e] = p4[e];
+    }
+    __syncthreads();
+    int acc0[kQDigits];
+#pragma unroll
+    for (int d = 0; d < kQDigits; ++d) acc0[d] = reinterpret_cast<const int*>(pack + kQAccOff)[d * 32 + li];
+    const float scale = reinterpret_cast<const float*>(pack + kQScaleOff)[li];
+    const float bias_r = bias[li];
+    const __amdgpu_buffer_rsrc_t rsrc_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, kQRsrcWord3);
+    const int nwv = gridDim.x * NW;
+
+    // pointer to byte 16*lh of tap row 0 of the lane's pixel of `tile` (pixels past P read pixel 0: results dropped).
+    // A 32-pixel tile touches at most two images: their rollout rows are looked up with SCALAR loads (lgkmcnt), so the
+    // address of the next tile never waits behind this tile's vector stores (vmcnt).
+    auto setup = [&](int tile) -> const unsigned char* {
+        const int tu = __builtin_amdgcn_readfirstlane(tile);
+        const bool live = tu < ntiles;
+        const unsigned p0 = live ? (unsigned)tu * 32u : 0u;
+        const unsigned img0 = p0 / (unsigned)kQPerImg;
+        const unsigned last = (P - 1u) / (unsigned)kQPerImg;
+        const unsigned img1 = img0 < last ? img0 + 1u : img0;
+        const long long s0 = inds ? inds[img0] : (long long)img0;
+        const long long s1 = inds ? inds[img1] : (long long)img1;
+        const unsigned p = p0 + (unsigned)li;
+        const unsigned pp = (live && p < P) ? p : p0;
+        const unsigned img = pp / (unsigned)kQPerImg, rem = pp - img * (unsigned)kQPerImg;
+        const unsigned gy = rem / (unsigned)kQG, gx = rem - gy * (unsigned)kQG;
+        const long long simg = img == img0 ? s0 : s1;
+        return src + ((simg * kQH + gy * 4) * kQW + gx * 4) * (long long)kQC + 16 * lh;
+    };
+    u32x4q ring[kQRows];
+    // workgroups are dealt to the 8 XCDs round robin: give each XCD a contiguous range of tile groups, so that the waves
+    // that share source rows (vertical window overlap, neighbouring tiles of one image) also share an L2
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) wg = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    int tile = wg * NW + wave;
+    const unsigned char* cur = setup(tile);
+    const unsigned char* nxt = setup(tile + nwv);
+#pragma unroll
+    for (int r = 0; r < kQRows; ++r) ring[r] = *reinterpret_cast<const u32x4q*>(cur + r * kQPitch);
+
+    for (; tile < ntiles; tile += nwv) {
+        i32x16 acc[kQDigits];
+#pragma unroll
+        for (int d = 0; d < kQDigits; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[d][e] = 0;                  // (the 128 * sum_k digit offsets are added in the epilogue:
+                                                                          //  a zero start is an inline operand, a splat costs 16 VGPRs)
+#pragma unroll
+        for (int r = 0; r < kQRows; ++r) {
+            const u32x4q t = ring[r] ^ 0x80808080u;                       // v - 128 as int8
+            const i32x4 a = {(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+#pragma unroll
+            for (int d = 0; d < kQDigits; ++d) acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bl[r][d][lane], acc[d], 0, 0, 0);
+            ring[r] = *reinterpret_cast<const u32x4q*>(nxt + r * kQPitch);   // the same row of the wave's next tile
+            __builtin_amdgcn_sched_barrier(0);                            // keep the row's four LDS reads in the row
+        }
+        // ---- epilogue: Horner over the digits, scale, bias, ReLU; accumulator row e of the lane is pixel
+        // (e & 3) + 8 * (e >> 2) + 4 * lh of the tile, column = channel li
+        unsigned myoff = kQOob;
+        {
+            const unsigned p = (unsigned)tile * 32u + (unsigned)li;
+            if (p < P) myoff = p * 128u;                                  // pixel-major (N,20,20,32) f32: 128 bytes per pixel
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const unsigned off = (unsigned)__shfl((int)myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64) + (unsigned)(li * 4);
+            float t = (float)(acc[3][e] + acc0[3]);                       // exact integers D_j = sum_k v[k] * d_j[k][n]
+            t = t * 0.00390625f + (float)(acc[2][e] + acc0[2]);           // exact product (power of two), one rounding per step
+            t = t * 0.00390625f + (float)(acc[1][e] + acc0[1]);
+            t = t * 0.00390625f + (float)(acc[0][e] + acc0[0]);
+            float v = t * scale;
+            v = v + bias_r;
+            v = v > 0.0f ? v : 0.0f;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_dst, off, 0, 0);   // dropped when out of range
+        }
+        cur = nxt;
+        nxt = setup(tile + 2 * nwv);
+    }
+}
+
+static int g_q_cus = 0;
+
+}  // namespace mi355ppo
+
+using namespace mi355ppo;
+
+extern "C" MI355PPO_API size_t mi355ppo_cnn_conv1q_pack_bytes(void) { return (size_t)kQPackBytes; }
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_pack(const float* W, void* pack, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv1q_pack";
+    MI355_REQUIRE(W && pack, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(aligned(W, 4) && aligned(pack, 16), MI355PPO_EALIGN, "%s: pack must be 16-byte aligned", fn);
+    hipLaunchKernelGGL(conv1q_pack_kernel, dim3(1), dim3(256), 0, as_stream(stream), W, static_cast<unsigned char*>(pack));
+    return check_launch(fn);
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_fwd(const void* src_u8, const int64_t* inds, const void* pack, const float* bias,
+                                                    float* dst, int64_t images, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv1q_fwd";
+    MI355_REQUIRE(src_u8 && pack && bias && dst, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
+                  (long long)images);
+    MI355_REQUIRE(aligned(src_u8, 16) && aligned(pack, 16) && aligned(dst, 16) && aligned(inds, 8) && aligned(bias, 4),
+                  MI355PPO_EALIGN, "%s: src/pack/dst must be 16-byte aligned", fn);
+    const long long P = (long long)images * kQPerImg, dstb = P * 128;
+    MI355_REQUIRE(dstb <= (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: destination of %lld bytes exceeds the 32-bit buffer range", fn, dstb);
+    if (g_q_cus == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        g_q_cus = cus;
+    }
+    const int ntiles = (int)((P + 31) / 32);
+    constexpr int NW = 4;
+    long long wgs = (long long)g_q_cus * 3;                   // three 4-wave workgroups per CU = three waves per SIMD
+    if (wgs * NW > ntiles) wgs = (ntiles + NW - 1) / NW;
+    hipLaunchKernelGGL((conv1q_fwd_kernel<NW>), dim3((unsigned)wgs), dim3(64 * NW), 0, as_stream(stream),
+                       static_cast<const unsigned char*>(src_u8), inds, static_cast<const unsigned char*>(pack), bias, dst, (unsigned)P,
+                       ntiles, (unsigned)dstb);
+    return check_launch(fn);
+}

@@ -239,9 +239,23 @@ MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_
  *   mode 2  layer-2 data gradient            Bt[4][Cin][(r,c,cout)] (one 2x2-tap matrix per parity class)
  *   mode 3  layer-3 data gradient, per border class: 25 matrices [Cin][(r',c',cout)] for the 5x5 (row class,
  *           column class) tap windows (mi355ppo_cnn_conv_dgrad_f32_variant(..., variant 5)); 81*4096 floats
+ *   mode 4  layer 1 only: the integer-digit pack of kernel Q (csrc/conv1q.hip): every weight as a 31-bit
+ *           fixed-point number on its output channel's scale, four signed radix-256 digits in the operand
+ *           layout of v_mfma_i32_32x32x32_i8, + accumulator start values + per-channel scales;
+ *           mi355ppo_cnn_conv1q_pack_bytes() = 33,408 bytes.  Consumed by forward variant 6.
  * modes 0-2 have Cout*Cin*KH*KW floats.
  */
 MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, float* Bt, int layer, int mode, void* stream);
+
+/* Kernel Q: layer-1 forward on the integer matrix pipe.  The uint8 frame bytes are exact int8 operands
+ * (v - 128), the weights four int8 digits; int32 accumulation is exact, the only roundings are the
+ * weight's one-time rounding to 2^-30 of its channel's largest weight and five f32 roundings per output
+ * (Horner over the digits, scale, bias) -- closer to the float64 convolution than an f32 fma chain of
+ * 256 terms, at 1/8 of its matrix-pipe time.  Same contract as mi355ppo_cnn_conv_fwd_f32(layer 1). */
+MI355PPO_API size_t mi355ppo_cnn_conv1q_pack_bytes(void);
+MI355PPO_API int mi355ppo_cnn_conv1q_pack(const float* W, void* pack, void* stream);
+MI355PPO_API int mi355ppo_cnn_conv1q_fwd(const void* src_u8, const int64_t* inds, const void* pack, const float* bias,
+                                         float* dst, int64_t images, void* stream);
 
 /* dst = relu(conv(src) + bias).  layer 1: src is the uint8 rollout buffer (rows_total, 84,84,4) and
  * `inds` (images) int64 optionally gathers rows (b_obs[mb_inds]); the /255 is applied in registers,
@@ -252,15 +266,18 @@ MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds,
  * 2 = fixed-geometry streaming kernel (weights resident in LDS, A fragments fetched straight into a register ring,
  *     taps as compile-time immediates, buffer loads/stores; tensors must be < 4 GiB), 4 = its run-time-geometry
  *     predecessor; data gradient only: 3 = one launch per stride-parity class (layer 2), 5 = layer 3 split into
- *     its 25 border classes so that no padding zeros are multiplied (needs the mode-3 repack). */
+ *     its 25 border classes so that no padding zeros are multiplied (needs the mode-3 repack);
+ *     forward of layer 1 only: 6 = kernel Q (Bt = the mode-4 pack). */
 MI355PPO_API int mi355ppo_cnn_conv_fwd_f32_variant(const void* src, const int64_t* inds, const float* Bt, const float* bias,
                                                    float* dst, int64_t images, int layer, int variant, void* stream);
 
 /* The three forward layers back to back (a1 (images,20,20,32), a2 (images,9,9,64), a3 (images,7,7,64) out): one call
- * for inference-sized batches, where the host-side cost of a launch matters. */
+ * for inference-sized batches, where the host-side cost of a launch matters.  conv1_variant: 0 (bt1 = mode-0 matrix)
+ * or 6 (bt1 = mode-4 pack, kernel Q). */
 MI355PPO_API int mi355ppo_cnn_trunk_fwd_f32(const void* obs_u8, const int64_t* inds, const float* bt1, const float* b1,
                                             const float* bt2, const float* b2, const float* bt3, const float* b3,
-                                            float* a1, float* a2, float* a3, int64_t images, void* stream);
+                                            float* a1, float* a2, float* a3, int64_t images, int conv1_variant,
+                                            void* stream);
 
 /* dsrc = conv_transpose(dz) * (act_in > 0): gradient w.r.t. the layer's INPUT activation act_in
  * (itself a ReLU output), i.e. the pre-activation gradient of the previous layer.  layer = 2 or 3;

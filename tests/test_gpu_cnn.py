@@ -74,6 +74,90 @@ def test_conv1_fwd_u8_gather(images, variant):
     _close(_nhwc(t32), _nhwc(ref2), "torch f32 conv1 (calibration)")
 
 
+def _unpack_q(pack_f32):
+    """Decode kernel Q's mode-4 pack back into (q (32,4,8,8) int64, acc0 (4,32), scale (32,)): the inverse of conv1q_pack_kernel."""
+    raw = pack_f32.cpu().numpy().view(np.uint8)
+    dig = raw[:8 * 4 * 64 * 16].view(np.int8).reshape(8, 4, 2, 32, 16).astype(np.int64)     # [row][digit][lh][n][e]
+    q = np.zeros((32, 4, 8, 8), np.int64)
+    for r in range(8):
+        for lh in range(2):
+            for e in range(16):
+                e32 = 16 * lh + e
+                kw, c = e32 >> 2, e32 & 3
+                q[:, c, r, kw] = sum(dig[r, d, lh, :, e] << (8 * (3 - d)) for d in range(4))
+    acc0 = raw[32768:32768 + 512].view(np.int32).reshape(4, 32)
+    scale = raw[32768 + 512:].view(np.float32)
+    return q, dig, acc0, scale
+
+
+@pytest.mark.parametrize("kind", ["init", "wide", "zero_channel", "tiny"])
+def test_conv1q_pack_is_the_weights_to_31_bits(kind):
+    """The integer-digit pack of kernel Q decodes to rint(w * 2^(30-E_n)) exactly: every weight is represented to 2^-30 of
+    its channel's largest weight (1/64 of that weight's f32 ulp), digits stay in int8, the accumulator start values and the
+    scales are what the kernel's algebra needs."""
+    W, _ = _params(1, 4)
+    if kind == "wide":
+        W = W * torch.logspace(-6, 0, 256).reshape(1, 4, 8, 8)            # seven decades inside every channel
+    elif kind == "zero_channel":
+        W[5] = 0.0
+        W[9, :, :, :] = 0.0
+        W[9, 0, 0, 0] = -0.75
+    elif kind == "tiny":
+        W = W * 1e-30
+    q, dig, acc0, scale = _unpack_q(cnn.repack_weights(W.to(DEV), 1, cnn.MODE_FWD_Q))
+    Wd = W.double().numpy()
+    m = np.abs(Wd).reshape(32, -1).max(1)
+    E = np.where(m > 0, np.frexp(m)[1], 0)
+    want = np.rint(Wd * np.exp2(30.0 - E).reshape(32, 1, 1, 1)).astype(np.int64)
+    assert np.array_equal(q, want)
+    assert dig.min() >= -128 and dig.max() <= 127 and np.abs(q).max() <= 2 ** 30
+    err = np.abs(q * np.exp2(E - 30.0).reshape(32, 1, 1, 1) - Wd).reshape(32, -1).max(1)
+    assert np.all(err <= np.exp2(E - 31.0))                   # half a unit of 2^(E-30): <= 2^-30 of the channel's largest weight
+    assert np.array_equal(acc0, 128 * dig.sum(axis=(0, 2, 4)).astype(np.int32))           # [digit][channel]
+    np.testing.assert_array_equal(scale, (np.exp2(E - 6.0) / 255.0).astype(np.float32))
+
+
+@pytest.mark.parametrize("images", [1, 37, 256, 1100, 5000])
+def test_conv1q_fwd_matches_float64_and_beats_the_f32_pipe(images):
+    """Kernel Q (integer matrix pipe) against the float64 convolution of the reference's layer: same bound as the f32-MFMA
+    kernels, and its error is not larger than theirs (exact int32 accumulation + 5 roundings vs a 256-term f32 chain)."""
+    frames = torch.from_numpy(synthetic.atari_frames(images + 5, seed=3))
+    rows = _nhwc(frames).to(DEV)
+    inds = torch.from_numpy(np.random.RandomState(0).randint(0, images + 5, size=images)).to(DEV)
+    W, b = _params(1, 1)
+    ref = _nhwc(F.relu(F.conv2d(frames[inds.cpu()].double() / 255.0, W.double(), b.double(), stride=4)))
+    pack = cnn.repack_weights(W.to(DEV), 1, cnn.MODE_FWD_Q)
+    got = cnn.conv_fwd(rows, pack, b.to(DEV), 1, inds, variant=cnn.VARIANT_Q)
+    _close(got, ref, "conv1 fwd, kernel Q (gather)")
+    f32 = cnn.conv_fwd(rows, cnn.repack_weights(W.to(DEV), 1), b.to(DEV), 1, inds, variant=2)
+    e_q = (got.cpu().double() - ref).abs()
+    e_f = (f32.cpu().double() - ref).abs()
+    assert e_q.max() <= e_f.max() * 1.05 + 1e-12 and e_q.mean() <= e_f.mean() * 1.05 + 1e-12, \
+        f"kernel Q err max {e_q.max():.3e} mean {e_q.mean():.3e} vs f32-MFMA max {e_f.max():.3e} mean {e_f.mean():.3e}"
+    # identity rows, bit-identical run to run, inference path of the trunk call
+    got2 = cnn.conv_fwd(rows[:images].contiguous(), pack, b.to(DEV), 1, None, variant=cnn.VARIANT_Q)
+    ref2 = _nhwc(F.relu(F.conv2d(frames[:images].double() / 255.0, W.double(), b.double(), stride=4)))
+    _close(got2, ref2, "conv1 fwd, kernel Q (identity rows)")
+    assert torch.equal(got, cnn.conv_fwd(rows, pack, b.to(DEV), 1, inds, variant=cnn.VARIANT_Q))
+
+
+def test_conv1q_extreme_inputs_and_weights():
+    """All-0 / all-255 frames (the v - 128 offset at both ends), weights spanning seven decades, a zero channel, a large
+    bias: still within the f32 bound of the float64 result."""
+    frames = torch.zeros(6, 4, 84, 84, dtype=torch.uint8)
+    frames[1] = 255
+    frames[2, :, ::2] = 255
+    frames[3:] = torch.from_numpy(synthetic.atari_frames(3, seed=5))
+    W, b = _params(1, 7)
+    W = W * torch.logspace(-6, 0, 256).reshape(1, 4, 8, 8)[:, :, torch.randperm(8)]
+    W[3] = 0.0
+    b[4] = 50.0
+    ref = _nhwc(F.relu(F.conv2d(frames.double() / 255.0, W.double(), b.double(), stride=4)))
+    got = cnn.conv_fwd(_nhwc(frames).to(DEV), cnn.repack_weights(W.to(DEV), 1, cnn.MODE_FWD_Q), b.to(DEV), 1, None, variant=cnn.VARIANT_Q)
+    _close(got, ref, "conv1 fwd, kernel Q (extremes)", tol=1e-6)
+    assert torch.equal(got[..., 3].cpu(), torch.relu(b[3]).expand(6, 20, 20))              # the zero channel is exactly its bias
+
+
 @pytest.mark.parametrize("variant", [1, 2, 4])
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 19, 128, 700, 7000])
@@ -216,6 +300,13 @@ def test_full_minibatch_size_properties():
     bt = {l: cnn.repack_weights(params[l][0], l) for l in (1, 2, 3)}
     a1 = cnn.conv_fwd(obs, bt[1], params[1][1], 1, inds)
     assert torch.equal(a1[:4096], cnn.conv_fwd(obs[inds[:4096]].contiguous(), bt[1], params[1][1], 1))    # gather == pre-gathered rows
+    # kernel Q (integer matrix pipe) at full size: gather == pre-gathered rows bit for bit, and the f32-MFMA kernel's result
+    # within the f32 bound (both are within it of the float64 truth at the sizes the float64 reference can reach)
+    pack = cnn.repack_weights(params[1][0], 1, cnn.MODE_FWD_Q)
+    a1q = cnn.conv_fwd(obs, pack, params[1][1], 1, inds, variant=cnn.VARIANT_Q)
+    assert torch.equal(a1q[-4096:], cnn.conv_fwd(obs[inds[-4096:]].contiguous(), pack, params[1][1], 1, variant=cnn.VARIANT_Q))
+    assert (a1q - a1).abs().max().item() <= 2e-5 * a1.abs().max().item()
+    del a1q
     a2 = cnn.conv_fwd(a1, bt[2], params[2][1], 2)
     assert a1.min().item() >= 0.0 and a2.min().item() >= 0.0 and torch.isfinite(a2).all()
     dz_a, dz_b = torch.randn(a2.shape, device=DEV, generator=g), torch.randn(a2.shape, device=DEV, generator=g)

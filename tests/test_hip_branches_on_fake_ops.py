@@ -438,8 +438,8 @@ class FakeCnn:
 
         cin, cout, k, _, _, _ = cnn.LAYERS[layer]
         _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
-        assert (layer, mode) in ((1, 0), (2, 0), (3, 0), (3, 1), (2, 2), (3, 3))
-        numel = cnn.BT_CLASSES_NUMEL if mode == 3 else W.numel()
+        assert (layer, mode) in ((1, 0), (1, 4), (2, 0), (3, 0), (3, 1), (2, 2), (3, 3))
+        numel = cnn.BT_CLASSES_NUMEL if mode == 3 else cnn.QPACK_NUMEL if mode == 4 else W.numel()
         if out is None:
             out = torch.empty(numel)
         _chk(out, torch.float32, "Bt", (numel,))
@@ -456,7 +456,8 @@ class FakeCnn:
         from cleanrl_amd import cnn
 
         cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
-        W = self._w(Bt, layer, (0,))
+        assert variant in (0, cnn.VARIANT_Q) and (variant == 0 or layer == 1)
+        W = self._w(Bt, layer, (4,) if variant == cnn.VARIANT_Q else (0,))      # the pack and the kernel must belong together
         x = src if inds is None else src[inds]
         if layer == 1:
             _chk(src, torch.uint8, "src")
@@ -493,8 +494,8 @@ class FakeCnn:
         dW = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (cout, cin, k, k), dz.permute(0, 3, 1, 2), stride=s)
         return dW, dz.sum((0, 1, 2))
 
-    def trunk_fwd(self, obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3):
-        self.conv_fwd(obs_u8, bt1, b1, 1, inds, a1)
+    def trunk_fwd(self, obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3, conv1_variant=0):
+        self.conv_fwd(obs_u8, bt1, b1, 1, inds, a1, variant=conv1_variant)
         self.conv_fwd(a1, bt2, b2, 2, None, a2)
         return self.conv_fwd(a2, bt3, b3, 3, None, a3)
 

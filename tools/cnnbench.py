@@ -49,6 +49,12 @@ def main():
             for v in ((2,) if os.environ.get("CNNBENCH_ONLY") == "fwd" else (2, 4)):
                 us = bench(lambda: cnn.conv_fwd(src, bt, b, layer, inds if layer == 1 else None, dst, variant=v))
                 out(k="fwd", variant=v, layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK)
+            if layer == 1:      # kernel Q: the integer matrix pipe (HBM-bound: report GB/s of the algorithmic bytes too)
+                pack = cnn.repack_weights(W, 1, cnn.MODE_FWD_Q)
+                us = bench(lambda: cnn.conv_fwd(src, pack, b, 1, inds, dst, variant=cnn.VARIANT_Q))
+                nbytes = M * (84 * 84 * 4 + 20 * 20 * 32 * 4)
+                out(k="fwd", variant=6, layer=1, M=M, us=us, tflops=flops / us / 1e6, frac_of_f32_peak=flops / us / 1e6 / PEAK,
+                    algorithmic_GBps=nbytes / us / 1e3, frac_of_8TBps=nbytes / us / 1e3 / 8000)
             acts[layer] = dst
             dz = torch.randn_like(dst)
             if os.environ.get("CNNBENCH_ONLY") == "fwd":
