@@ -101,8 +101,10 @@ def parse():
     p.add_argument("--n-actions", type=int, default=4)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-baseline-envs", type=int, default=64)
+    p.add_argument("--cpu-baseline-envs", type=int, default=128)
     p.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets (pure SPS run)")
+    p.add_argument("--no-pcie-inclusive", action="store_true", help="skip the host-env (PCIe-inclusive) leg after the timed region")
+    p.add_argument("--pcie-env-groups", type=int, default=4)
     return p.parse_args()
 
 
@@ -190,8 +192,10 @@ def main():
                          sample_seed=seed)
     timer = KernelTimer()
     conv_flops = {}
+    unhook = []          # (module, name, original) of everything the kernel timing wraps
     if not cli.no_kernel_timing:
         real_obs, real_gae, real_loss = ops.obs_u8_to_f32, ops.gae, ops.ppo_loss_categorical
+        unhook += [(ops, "obs_u8_to_f32", real_obs), (ops, "gae", real_gae), (ops, "ppo_loss_categorical", real_loss)]
         if learner.fused_cnn:
             from cleanrl_amd import cnn
 
@@ -215,6 +219,7 @@ def main():
                 return src.shape[0] if inds is None else inds.numel()
 
             real_trunk = cnn.trunk_fwd
+            unhook += [(cnn, n, getattr(cnn, n)) for n in ("trunk_fwd", "conv_fwd", "conv_dgrad", "conv_wgrad")]
 
             def trunk_hook(*a, **kw):
                 images = a[8].shape[0]
@@ -386,14 +391,35 @@ def main():
         if world == 1 and not cli.no_cpu_baseline:
             from oracle import cpu_ppo_port
 
-            cb = cpu_ppo_port.run(num_envs=cli.cpu_baseline_envs, num_steps=T, iterations=2, warmup_iterations=0,
-                                  seed=cli.seed, n_actions=cli.n_actions, max_seconds=12.0)
+            # warm the host first (thread pool, oneDNN primitives, allocator) with a small untimed iteration, then time ONE
+            # full iteration at BASELINE configs[1]'s size (ppo_atari_envpool: 128 envs x 128 steps)
+            cpu_ppo_port.run(num_envs=8, num_steps=16, iterations=1, seed=cli.seed, n_actions=cli.n_actions)
+            cb = cpu_ppo_port.run(num_envs=cli.cpu_baseline_envs, num_steps=T, iterations=1, warmup_iterations=0,
+                                  seed=cli.seed, n_actions=cli.n_actions)
             out["cpu_baseline"] = {
                 "value": cb["sps"], "unit": "env-steps/s", "cores": cb["cores"], "kind": "port",
-                "sample": f"{cb['iterations']} full PPO iteration(s) of the reference loop (oracle/cpu_ppo_port.py, stock "
-                          f"torch CPU ops, f32) at num_envs={cb['num_envs']} x num_steps={cb['num_steps']} = "
-                          f"{cb['env_steps']} env-steps in {cb['seconds']:.1f} s; host cpu_count={os.cpu_count()}",
+                "sample": f"{cb['iterations']} full PPO iteration of the reference loop body (ppo_atari_envpool.py:217-341 restated in "
+                          f"stock torch CPU ops, f32 observation storage, oracle/cpu_ppo_port.py) at num_envs={cb['num_envs']} x "
+                          f"num_steps={cb['num_steps']} = {cb['env_steps']} env-steps in {cb['seconds']:.1f} s after a small warm-up "
+                          f"iteration; host cpu_count={os.cpu_count()}; the reference script itself cannot run on this box (no "
+                          f"envpool / gym / tyro, and /root/reference does not travel), hence kind=port",
             }
+        if world == 1 and not cli.no_pcie_inclusive:
+            # never `value`: the same learner fed by HOST envs (numpy stand-ins on host threads), actions D2H and frames H2D
+            # every step as in the reference's loop (:269-272), through the overlapped env-group lanes (cleanrl_amd/pipeline.py)
+            del learner, env
+            torch.cuda.empty_cache()
+            for mod, name, orig in unhook:            # no event brackets around this leg's launches
+                setattr(mod, name, orig)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import host_env_bench
+
+            ov = host_env_bench.run(N, T, iters=2, groups=cli.pcie_env_groups, frame_delta=True, device=device)
+            se = host_env_bench.run(N, T, iters=1, groups=1, frame_delta=False, device=device)
+            out["pcie_inclusive_sps"] = ov["sps"]
+            out["pcie_inclusive"] = {"overlapped": ov, "serial_reference_arrangement": se,
+                                     "note": "whole PPO iterations with the envs on the host; not comparable with `value`, whose "
+                                             "inputs are resident in HBM"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

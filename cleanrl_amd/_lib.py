@@ -38,6 +38,7 @@ SIGNATURES = {
                 _P, _P, _P, _P, _P, c_size_t, _P]),
     "mi355ppo_obs_u8_to_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P]),
     "mi355ppo_obs_nchw_to_nhwc_u8": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "mi355ppo_obs_shift_append_u8_c4": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_clip_adam_workspace_bytes": (c_size_t, [c_int64]),
     "mi355ppo_clip_adam_f32": (
         c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, c_double, c_int64,

@@ -38,6 +38,13 @@ class _SampleCounter:
         self.offset += 1
         return self.seed, self.offset
 
+    def reserve(self, n: int) -> int:
+        """Set ``n`` offsets aside and return the first one: the env-group lanes of a rollout (pipeline.py) draw
+        ``first + step * groups + group`` so that their streams do not depend on which lane's thread runs first."""
+        first = self.offset + 1
+        self.offset += int(n)
+        return first
+
 
 class _DiscreteMixin:
     discrete = True

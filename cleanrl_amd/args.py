@@ -75,3 +75,8 @@ class PPOArgs:
     # additions of this implementation (not in the reference)
     synthetic_env: bool = False
     """force the built-in stand-in environment even when gymnasium/envpool are importable"""
+    env_groups: int = 1
+    """split the (local) envs into this many independently stepped vector envs whose host stepping, PCIe copies and GPU
+    work overlap (cleanrl_amd/pipeline.py); 1 = the reference's serial rollout loop"""
+    frame_delta: bool = True
+    """with --env-groups > 1 on FrameStack(4) image envs: send only the newest frame of every env that was not reset"""

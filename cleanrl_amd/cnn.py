@@ -160,7 +160,8 @@ class _Buffers:
         return hit[1]
 
     def get(self, m: int, dev, grads: bool):
-        key = (m, dev, grads)
+        # one set per (batch size, stream): the env-group lanes of a rollout (pipeline.py) run the same batch size concurrently
+        key = (m, dev, grads, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
         b = self.by_m.get(key)
         if b is None:
             shapes = [(m, 20, 20, 32), (m, 9, 9, 64), (m, 7, 7, 64)]

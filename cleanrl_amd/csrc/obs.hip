@@ -88,6 +88,26 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_u8_c4_kernel(const uint8_t* 
     reinterpret_cast<uint4*>(dst + r * (int64_t)quads_per_row * 16)[q] = o;
 }
 
+// ---- FrameStack(4) delta: next row = previous row with its channels shifted down by one + the newest frame ----
+// A frame-stacked Atari env returns obs[t+1][0:3] == obs[t][1:4] for every env that was not reset, so only the newest
+// 84x84 plane has to cross PCIe (7 KB per env and step instead of 28 KB; the reference sends 113 KB of f32,
+// ppo_atari_multigpu.py:272).  Pixel-interleaved rows make the shift one `>> 8` per pixel dword; a lane handles four
+// pixels: 16 bytes of the previous row + 4 bytes of the new plane -> 16 bytes out, all coalesced.
+__global__ __launch_bounds__(256) void shift_append_u8_c4_kernel(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ newest,
+                                                                 uint8_t* __restrict__ dst, int quads_per_row) {
+    const int64_t r = blockIdx.x;
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= quads_per_row) return;
+    const uint4 p = reinterpret_cast<const uint4*>(prev + r * (int64_t)quads_per_row * 16)[q];
+    const uint32_t nw = reinterpret_cast<const uint32_t*>(newest + r * (int64_t)quads_per_row * 4)[q];
+    uint4 o;
+    o.x = (p.x >> 8) | ((nw & 0xffu) << 24);
+    o.y = (p.y >> 8) | ((nw & 0xff00u) << 16);
+    o.z = (p.z >> 8) | ((nw & 0xff0000u) << 8);
+    o.w = (p.w >> 8) | (nw & 0xff000000u);
+    reinterpret_cast<uint4*>(dst + r * (int64_t)quads_per_row * 16)[q] = o;
+}
+
 // generic C (slow path, byte granularity)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_u8_generic_kernel(const uint8_t* __restrict__ src,
                                                                       uint8_t* __restrict__ dst, int C, int HW) {
@@ -137,4 +157,18 @@ extern "C" MI355PPO_API int mi355ppo_obs_nchw_to_nhwc_u8(const uint8_t* src, uin
     hipLaunchKernelGGL(nchw_to_nhwc_u8_generic_kernel, dim3((unsigned)rows, (unsigned)((C * HW + 255) / 256)), dim3(256),
                        0, as_stream(stream), src, dst, C, HW);
     return check_launch("nchw_to_nhwc_u8_generic_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_obs_shift_append_u8_c4(const uint8_t* prev_rows, const uint8_t* newest_planes, uint8_t* dst_rows,
+                                                            int64_t rows, int HW, void* stream) {
+    const char* fn = "mi355ppo_obs_shift_append_u8_c4";
+    MI355_REQUIRE(prev_rows && newest_planes && dst_rows, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(rows > 0 && rows <= 2147483647LL && HW > 0 && HW % 4 == 0 && HW / 4 <= 65535 * 256, MI355PPO_EINVAL,
+                  "%s: rows=%lld HW=%d out of range (HW must be a multiple of 4)", fn, (long long)rows, HW);
+    MI355_REQUIRE(aligned(prev_rows, 16) && aligned(dst_rows, 16) && aligned(newest_planes, 4), MI355PPO_EALIGN,
+                  "%s: rows must be 16-byte, planes 4-byte aligned", fn);
+    const int quads = HW / 4;
+    hipLaunchKernelGGL(shift_append_u8_c4_kernel, dim3((unsigned)rows, (unsigned)((quads + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), prev_rows, newest_planes, dst_rows, quads);
+    return check_launch("shift_append_u8_c4_kernel");
 }

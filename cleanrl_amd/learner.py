@@ -172,6 +172,22 @@ class PPOLearner:
             return self.agent.heads_u8(obs_rows)
         return self.agent.heads(self._features(obs_rows))
 
+    def warm_rollout_caches(self) -> None:
+        """Re-derive the cached forward matrices on the current stream, so that the env-group lanes of a rollout
+        (pipeline.py: several host threads, one stream each) only ever READ the cache."""
+        if not (self.hip and self.image and self.fused_cnn):
+            return
+        from . import cnn
+
+        if self.agent._trunk is None:
+            self.agent._trunk = cnn.NatureTrunk()
+        bufs, net = self.agent._trunk.bufs, self.agent.network
+        bufs.cache_weights = True
+        bufs.weights(net[0].weight, 1, cnn.MODE_FWD_Q)
+        bufs.weights(net[2].weight, 2, cnn.MODE_FWD)
+        bufs.weights(net[4].weight, 3, cnn.MODE_FWD)
+        bufs.fc_weight(net[7].weight)
+
     def _features(self, obs_rows):
         """uint8 image rows -> normalised f32 (K5, no gather); other observations pass through."""
         if self.image and self.hip:
@@ -184,25 +200,28 @@ class PPOLearner:
         return obs_rows
 
     @torch.no_grad()
-    def act(self, step: int):
-        """Action logic (:262-266): network forward on ``obs[step]``, sample, store action / logprob / value."""
+    def act(self, step: int, rows=None, rng_offset=None):
+        """Action logic (:262-266): network forward on ``obs[step]``, sample, store action / logprob / value.
+        ``rows=(lo, hi)`` restricts the call to that slice of the envs (an env-group lane of pipeline.py, on the lane's
+        stream); ``rng_offset`` then is the lane's reserved Philox offset for this step."""
+        lo, hi = (0, self.N) if rows is None else rows
         if self.hip:
-            p, value = self._heads_rollout(self.obs[step])
-            seed, off = self.agent.rng.next()
+            p, value = self._heads_rollout(self.obs[step][lo:hi])
+            seed, off = self.agent.rng.next() if rng_offset is None else (self.agent.rng.seed, int(rng_offset))
             if self.discrete:
                 a64, _, _, _ = self.ops.categorical_sample(p.contiguous(), seed=seed, offset=off,
-                                                            action_f32_out=self.actions[step],
-                                                            logprob_out=self.logprobs[step], want_entropy=False)
+                                                            action_f32_out=self.actions[step][lo:hi],
+                                                            logprob_out=self.logprobs[step][lo:hi], want_entropy=False)
                 action = a64
             else:
                 action, _, _ = self.ops.normal_sample(p.contiguous(), self.agent.actor_logstd, seed=seed, offset=off,
-                                                      action_out=self.actions[step], logprob_out=self.logprobs[step])
-            self.values[step].copy_(value.view(-1))
+                                                      action_out=self.actions[step][lo:hi], logprob_out=self.logprobs[step][lo:hi])
+            self.values[step][lo:hi].copy_(value.view(-1))
             return action
-        action, logprob, _, value = self.agent.get_action_and_value(self.obs[step] if not self.image else self.obs[step])
-        self.values[step] = value.flatten()
-        self.actions[step] = action
-        self.logprobs[step] = logprob
+        action, logprob, _, value = self.agent.get_action_and_value(self.obs[step][lo:hi])
+        self.values[step][lo:hi] = value.flatten()
+        self.actions[step][lo:hi] = action
+        self.logprobs[step][lo:hi] = logprob
         return action
 
     def store_reward(self, step: int, reward) -> None:

@@ -453,6 +453,21 @@ def obs_nchw_to_nhwc_u8(src, out=None):
     return out
 
 
+def obs_shift_append_u8(prev_rows, newest, out):
+    """FrameStack(4) delta store: ``out[r] = concat(prev_rows[r][..., 1:4], newest[r][..., None])`` on (rows, H, W, 4) uint8
+    rows and (rows, H, W) uint8 planes -- the next observation of envs that were not reset."""
+    lib = _lib.load()
+    rows, H, W, C = prev_rows.shape
+    assert C == 4, "the delta store is defined for 4-frame stacks"
+    _chk(prev_rows, torch.uint8, "prev_rows", (rows, H, W, 4))
+    _chk(newest, torch.uint8, "newest", (rows, H, W))
+    _chk(out, torch.uint8, "out", (rows, H, W, 4))
+    with _on(out.device):
+        st = lib.mi355ppo_obs_shift_append_u8_c4(_ptr(prev_rows), _ptr(newest), _ptr(out), rows, H * W, _stream(out.device))
+    _lib.check(st, "mi355ppo_obs_shift_append_u8_c4")
+    return out
+
+
 # ---------------------------------------------------------------------------------------- a8/a9
 def clip_adam_(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, max_grad_norm: float, grad_scale: float = 1.0,
                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-5, total_norm_out=None):

@@ -1,0 +1,186 @@
+"""Overlapped host-env rollout: env stepping on the host, overlapped with the GPU and with PCIe.
+
+The reference's rollout (ppo_atari_multigpu.py:256-272) is strictly serial per step: policy forward -> D2H of the actions
+(sync) -> ``envs.step`` on the host -> H2D of the f32 frames.  Here the local envs are split into K *env groups* (K
+independent vector envs of N/K envs each -- rows [g*N/K, (g+1)*N/K) of every rollout buffer).  Each group gets a LANE: a
+host thread + its own HIP stream + pinned staging buffers, running the reference's serial step sequence for its own rows.
+The lanes interleave by themselves: while lane A's thread is inside ``envs[A].step`` (numpy / envpool release the GIL), the
+GPU runs lane B's policy forward and the copy engine moves lane B's frames -- no hand-written schedule, the same
+trajectories as the serial loop (a group's envs only ever see their own actions, the policy is fixed during a rollout).
+
+PCIe bytes: frames travel as uint8 through pinned memory, and for FrameStack(4) envs only the NEWEST 84x84 plane of every
+env that was not reset (``frame_delta``): the device rebuilds the stack from the previous row (``obs_shift_append_u8``);
+envs flagged done send their full stack.  7 KB per env and step instead of the reference's 113 KB of f32.
+
+Sampling stays deterministic: the Philox offset of (step, group) is reserved up front (``_SampleCounter.reserve``), so the
+action streams do not depend on thread timing.
+"""
+from __future__ import annotations
+
+import threading
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+StepFn = Callable[[int, np.ndarray, int], tuple]      # (group, actions, step) -> (next_obs, reward, next_done) as numpy
+
+
+class _Lane:
+    """One env group's resources: rows [lo, hi) of the learner's buffers, a stream, pinned staging."""
+
+    def __init__(self, learner, g: int, lo: int, hi: int, frame_delta: bool):
+        L = self.L = learner
+        self.g, self.lo, self.hi, self.n = g, lo, hi, hi - lo
+        self.hip = L.hip
+        self.delta = bool(frame_delta and L.hip and L.relayout and tuple(L.frame_shape) == (4, 84, 84))
+        if not self.hip:
+            return
+        dev = L.device
+        self.stream = torch.cuda.Stream(device=dev)
+        self.evt = torch.cuda.Event()
+        n = self.n
+        obs_dtype = L.obs.dtype
+        self.pin_obs = torch.zeros((n,) + tuple(L.frame_shape), dtype=obs_dtype).pin_memory()
+        self.dev_obs = torch.zeros((n,) + tuple(L.frame_shape), dtype=obs_dtype, device=dev) if L.relayout else None
+        self.pin_rd = torch.zeros((2, n), dtype=torch.float32).pin_memory()
+        self.pin_rd_np = self.pin_rd.numpy()
+        self.pin_obs_np = self.pin_obs.numpy()
+        act_shape = (n,) + tuple(L.act_shape)
+        self.pin_act = (torch.zeros(act_shape, dtype=torch.int64) if L.discrete else torch.zeros(act_shape)).pin_memory()
+        self.pin_act_np = self.pin_act.numpy()
+        if self.delta:
+            self.pin_new = torch.zeros((n, 84, 84), dtype=torch.uint8).pin_memory()
+            self.pin_new_np = self.pin_new.numpy()
+            self.dev_new = torch.zeros((n, 84, 84), dtype=torch.uint8, device=dev)
+
+    def rows(self, t):
+        return t[self.lo:self.hi]
+
+    # ---- the reference's per-step sequence for this group's rows ----
+    def act(self, step: int, rng_offset: Optional[int]) -> np.ndarray:
+        L = self.L
+        a = L.act(step, rows=(self.lo, self.hi), rng_offset=rng_offset)
+        if not self.hip:
+            return a.cpu().numpy()
+        self.pin_act.copy_(a.view(self.pin_act.shape), non_blocking=True)     # D2H on the lane's stream (:269)
+        self.evt.record(self.stream)
+        self.evt.synchronize()                    # waits for THIS lane's work only; the other lanes keep the GPU busy
+        return self.pin_act_np
+
+    def observe(self, step: int, obs, done, first: bool = False) -> None:
+        """rows [lo, hi) of slot ``step`` <- this group's next observation / done flags."""
+        L = self.L
+        obs_dst, done_dst = L._slot(step)
+        obs_dst, done_dst = self.rows(obs_dst), self.rows(done_dst)
+        if not self.hip:
+            obs_dst.copy_(torch.as_tensor(np.asarray(obs), dtype=obs_dst.dtype))
+            done_dst.copy_(torch.as_tensor(np.asarray(done), dtype=torch.float32))
+            return
+        np.copyto(self.pin_rd_np[0], done, casting="unsafe")
+        if self.delta and not first:
+            prev_rows = self.rows(L._slot(step - 1)[0])
+            obs = np.asarray(obs)
+            np.copyto(self.pin_new_np, obs[:, 3])                              # the newest plane of every env: 7 KB each
+            reset = np.flatnonzero(np.asarray(done))
+            for j, i in enumerate(reset):
+                np.copyto(self.pin_obs_np[j], obs[i])                          # reset envs: their whole (fresh) stack
+            self.dev_new.copy_(self.pin_new, non_blocking=True)
+            L.ops.obs_shift_append_u8(prev_rows, self.dev_new, obs_dst)
+            if len(reset):
+                k = len(reset)
+                self.dev_obs[:k].copy_(self.pin_obs[:k], non_blocking=True)
+                for j, i in enumerate(reset):
+                    L.ops.obs_nchw_to_nhwc_u8(self.dev_obs[j:j + 1], obs_dst[int(i):int(i) + 1])
+        else:
+            np.copyto(self.pin_obs_np, obs, casting="unsafe")
+            if L.relayout:
+                self.dev_obs.copy_(self.pin_obs, non_blocking=True)
+                L.ops.obs_nchw_to_nhwc_u8(self.dev_obs, obs_dst)
+            else:
+                obs_dst.copy_(self.pin_obs, non_blocking=True)
+        done_dst.copy_(self.pin_rd[0], non_blocking=True)
+
+    def store_reward(self, step: int, reward) -> None:
+        dst = self.rows(self.L.rewards[step])
+        if not self.hip:
+            dst.copy_(torch.as_tensor(np.asarray(reward, dtype=np.float32)).view(-1))
+            return
+        np.copyto(self.pin_rd_np[1], np.asarray(reward).reshape(-1), casting="unsafe")
+        dst.copy_(self.pin_rd[1], non_blocking=True)
+
+
+class GroupedRollout:
+    """``GroupedRollout(learner, K)``; ``first_observation(g, obs)`` once, then ``run(step_fn)`` per iteration."""
+
+    def __init__(self, learner, groups: int, frame_delta: bool = True, threads: bool = True):
+        N = learner.N
+        assert groups >= 1 and N % groups == 0, f"num_envs={N} must be a multiple of the {groups} env groups"
+        per = N // groups
+        self.L, self.K, self.threads = learner, groups, threads and groups > 1
+        self.lanes: List[_Lane] = [_Lane(learner, g, g * per, (g + 1) * per, frame_delta) for g in range(groups)]
+
+    def first_observation(self, g: int, obs, done=None) -> None:
+        lane = self.lanes[g]
+        done = np.zeros(lane.n, np.float32) if done is None else done
+        if lane.hip:
+            with torch.cuda.stream(lane.stream):
+                lane.observe(0, obs, done, first=True)
+            torch.cuda.current_stream(self.L.device).wait_stream(lane.stream)
+        else:
+            lane.observe(0, obs, done, first=True)
+
+    def _lane_loop(self, lane: _Lane, step_fn: StepFn, rng_first: Optional[int], errors: list) -> None:
+        L, K, T = self.L, self.K, self.L.T
+        try:
+            if lane.hip:
+                torch.cuda.set_device(L.device)
+            ctx = torch.cuda.stream(lane.stream) if lane.hip else _null()
+            with ctx:
+                for step in range(T):
+                    off = None if rng_first is None else rng_first + step * K + lane.g
+                    actions = lane.act(step, off)
+                    next_obs, reward, next_done = step_fn(lane.g, actions, step)
+                    lane.store_reward(step, reward)
+                    lane.observe(step + 1, next_obs, next_done)
+        except BaseException as e:          # noqa: BLE001 -- re-raised on the caller's thread
+            errors.append(e)
+
+    def run(self, step_fn: StepFn) -> None:
+        """One rollout of T steps for every group (the learner's ``finish_rollout`` is left to the caller)."""
+        L = self.L
+        rng_first = L.agent.rng.reserve(L.T * self.K) if L.hip else None
+        if L.hip:
+            L.warm_rollout_caches()
+            main = torch.cuda.current_stream(L.device)
+            for lane in self.lanes:
+                lane.stream.wait_stream(main)      # the lanes read the parameters / slot 0 the main stream wrote
+        errors: list = []
+        if self.threads:
+            ts = [threading.Thread(target=self._lane_loop, args=(lane, step_fn, rng_first, errors), daemon=True) for lane in self.lanes]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        else:
+            for lane in self.lanes:
+                self._lane_loop(lane, step_fn, rng_first, errors)
+        if errors:
+            raise errors[0]
+        if L.hip:
+            for lane in self.lanes:
+                main.wait_stream(lane.stream)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def split_env_groups(make_group: Callable[[int, int], object], num_envs: int, groups: int) -> Sequence[object]:
+    """``make_group(g, n)`` -> the g-th vector env of n envs; ``groups`` must divide ``num_envs``."""
+    assert num_envs % groups == 0, f"--num-envs {num_envs} must be a multiple of --env-groups {groups}"
+    return [make_group(g, num_envs // groups) for g in range(groups)]

@@ -64,6 +64,15 @@ def make_atari_envs(args, run_name, num_envs, seed):
     return E.SyntheticAtariVecEnv(num_envs, seed=seed, n_actions=4)
 
 
+def make_atari_env_groups(args, run_name, num_envs, seed):
+    """``--env-groups K`` vector envs of num_envs / K envs each (a list of one = the reference's single vector env); group g
+    is seeded ``seed + g * (num_envs / K)`` so that no two envs of the rank share a seed."""
+    from cleanrl_amd.pipeline import split_env_groups
+
+    k = max(int(getattr(args, "env_groups", 1)), 1)
+    return split_env_groups(lambda g, n: make_atari_envs(args, run_name, n, seed + g * n), num_envs, k)
+
+
 def main(argv=None):
     args = cli.parse(Args, argv)
     args.batch_size = int(args.num_envs * args.num_steps)
@@ -73,11 +82,12 @@ def main(argv=None):
     writer = runner.open_writer(args, run_name)
     runner.seed_everything(args)
     device = runner.select_device(args)
-    envs = make_atari_envs(args, run_name, args.num_envs, args.seed)
-    assert hasattr(envs.single_action_space, "n"), "only discrete action space is supported"
-    agent = Agent(envs).to(device)
+    envs = make_atari_env_groups(args, run_name, args.num_envs, args.seed)
+    assert hasattr(envs[0].single_action_space, "n"), "only discrete action space is supported"
+    agent = Agent(envs[0]).to(device)
     learner = runner.train(args, envs, agent, device, writer)
-    envs.close()
+    for e in envs:
+        e.close()
     writer.close()
     return learner
 

@@ -62,19 +62,21 @@ class RecordEpisodeStatistics:
         self.env.close()
 
 
-def make_envs(args):
+def make_envs(args, num_envs=None, seed=None):
+    num_envs = args.num_envs if num_envs is None else num_envs
+    seed = args.seed if seed is None else seed
     if E.have_envpool() and not args.synthetic_env:
         import envpool
 
-        envs = envpool.make(args.env_id, env_type="gym", num_envs=args.num_envs, episodic_life=True, reward_clip=True,
-                            seed=args.seed)                                     # ppo_atari_envpool.py:185-192
-        envs.num_envs = args.num_envs
+        envs = envpool.make(args.env_id, env_type="gym", num_envs=num_envs, episodic_life=True, reward_clip=True,
+                            seed=seed)                                          # ppo_atari_envpool.py:185-192
+        envs.num_envs = num_envs
         envs.single_action_space = envs.action_space
         envs.single_observation_space = envs.observation_space
         return RecordEpisodeStatistics(envs)
     print("[cleanrl_amd] envpool not installed: using the synthetic (N,4,84,84) uint8 Atari stand-in (gym API)",
           file=sys.stderr)
-    return E.SyntheticAtariVecEnv(args.num_envs, seed=args.seed, n_actions=4, api="gym")
+    return E.SyntheticAtariVecEnv(num_envs, seed=seed, n_actions=4, api="gym")
 
 
 def main(argv=None):
@@ -86,11 +88,14 @@ def main(argv=None):
     writer = runner.open_writer(args, run_name)
     runner.seed_everything(args)
     device = runner.select_device(args)
-    envs = make_envs(args)
-    assert hasattr(envs.single_action_space, "n"), "only discrete action space is supported"
-    agent = Agent(envs).to(device)
+    from cleanrl_amd.pipeline import split_env_groups
+
+    envs = split_env_groups(lambda g, n: make_envs(args, n, args.seed + g * n), args.num_envs, max(int(args.env_groups), 1))
+    assert hasattr(envs[0].single_action_space, "n"), "only discrete action space is supported"
+    agent = Agent(envs[0]).to(device)
     learner = runner.train(args, envs, agent, device, writer, env_api="gym")
-    envs.close()
+    for e in envs:
+        e.close()
     writer.close()
     return learner
 

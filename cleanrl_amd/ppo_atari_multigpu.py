@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cleanrl_amd import cli, runner  # noqa: E402
 from cleanrl_amd.agents import AtariAgent as Agent  # noqa: E402
 from cleanrl_amd.args import PPOArgs  # noqa: E402
-from cleanrl_amd.ppo_atari import make_atari_envs  # noqa: E402
+from cleanrl_amd.ppo_atari import make_atari_env_groups  # noqa: E402
 
 
 @dataclass
@@ -61,13 +61,14 @@ def main(argv=None):
     # CRUCIAL (reference :207): a different seed per data-parallel worker, the same torch seed for model init
     runner.seed_everything(args, local_rank, multigpu=True)
     device = runner.select_device(args, local_rank, world_size, multigpu=True)
-    envs = make_atari_envs(args, run_name, args.local_num_envs, args.seed)
-    assert hasattr(envs.single_action_space, "n"), "only discrete action space is supported"
-    agent = Agent(envs).to(device)
+    envs = make_atari_env_groups(args, run_name, args.local_num_envs, args.seed)
+    assert hasattr(envs[0].single_action_space, "n"), "only discrete action space is supported"
+    agent = Agent(envs[0]).to(device)
     torch.manual_seed(args.seed)                      # :231 per-rank action sampling from here on
     learner = runner.train(args, envs, agent, device, writer, local_rank=local_rank, world_size=world_size,
                            local_num_envs=args.local_num_envs, verbose_rank_line=True)
-    envs.close()
+    for e in envs:
+        e.close()
     if local_rank == 0:
         writer.close()
     if world_size > 1:

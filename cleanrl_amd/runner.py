@@ -86,71 +86,106 @@ def open_writer(args, run_name: str, enabled: bool = True):
     return writer
 
 
+def _env_step(envs, act_np, env_api: str, writer, global_step: int, avg_returns: list):
+    """One ``envs.step`` in the reference's API of choice -> (next_obs, reward, next_done); prints / logs episodic returns
+    exactly where the reference does."""
+    if env_api == "gym":
+        next_obs, reward, next_done, info = envs.step(act_np)
+        if writer is not None:                          # ppo_atari_envpool.py:241-247
+            for idx, d in enumerate(next_done):
+                if d and info["lives"][idx] == 0:
+                    print(f"global_step={global_step}, episodic_return={info['r'][idx]}")
+                    avg_returns[:] = (avg_returns + [info["r"][idx]])[-20:]
+                    writer.add_scalar("charts/avg_episodic_return", np.average(avg_returns), global_step)
+                    writer.add_scalar("charts/episodic_return", info["r"][idx], global_step)
+                    writer.add_scalar("charts/episodic_length", info["l"][idx], global_step)
+    elif env_api == "pettingzoo":                       # ppo_pettingzoo_ma_atari.py:203-213: envs alternate players
+        next_obs, reward, next_done, info = envs.step(act_np)
+        if writer is not None:
+            for idx, item in enumerate(info):
+                player_idx = idx % 2
+                if "episode" in item.keys():
+                    print(f"global_step={global_step}, {player_idx}-episodic_return={item['episode']['r']}")
+                    writer.add_scalar(f"charts/episodic_return-player{player_idx}", item["episode"]["r"], global_step)
+                    writer.add_scalar(f"charts/episodic_length-player{player_idx}", item["episode"]["l"], global_step)
+    elif env_api == "procgen":                          # ppo_procgen.py:241-250: 4-tuple, one info dict per env
+        next_obs, reward, next_done, info = envs.step(act_np)
+        if writer is not None:
+            for item in info:
+                if "episode" in item.keys():
+                    print(f"global_step={global_step}, episodic_return={item['episode']['r']}")
+                    writer.add_scalar("charts/episodic_return", item["episode"]["r"], global_step)
+                    writer.add_scalar("charts/episodic_length", item["episode"]["l"], global_step)
+                    break
+    else:
+        next_obs, reward, terminations, truncations, infos = envs.step(act_np)
+        next_done = np.logical_or(terminations, truncations)
+        if writer is not None and "final_info" in infos:            # :277-282
+            for info in infos["final_info"]:
+                if info and "episode" in info:
+                    print(f"global_step={global_step}, episodic_return={info['episode']['r']}")
+                    writer.add_scalar("charts/episodic_return", info["episode"]["r"], global_step)
+                    writer.add_scalar("charts/episodic_length", info["episode"]["l"], global_step)
+    return next_obs, reward, next_done
+
+
 def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: int = 1, env_api: str = "gymnasium",
           local_num_envs=None, verbose_rank_line: bool = False, learner_cls=PPOLearner):
-    """The hot loop of every PPO script (ppo.py:178-309).  Returns the learner (for tests / evaluation)."""
+    """The hot loop of every PPO script (ppo.py:178-309).  Returns the learner (for tests / evaluation).
+
+    ``envs`` may be a LIST of vector envs ("env groups", the scripts' ``--env-groups K``): the rollout then runs as K
+    overlapped lanes (cleanrl_amd/pipeline.py) -- same per-env trajectories as the serial loop, host stepping of one group
+    hidden behind the GPU work and the PCIe copies of the others."""
+    groups = list(envs) if isinstance(envs, (list, tuple)) else None
+    if groups is not None and len(groups) == 1:
+        envs, groups = groups[0], None
+    space_env = groups[0] if groups is not None else envs
     local_num_envs = local_num_envs or args.num_envs
-    learner = learner_cls(agent, args, envs.single_observation_space, envs.single_action_space, local_num_envs, device,
+    learner = learner_cls(agent, args, space_env.single_observation_space, space_env.single_action_space, local_num_envs, device,
                           world_size=world_size, sample_seed=args.seed)
     global_step = 0
     start_time = time.time()
-    if env_api in ("gym", "procgen", "pettingzoo"):             # envpool / procgen / supersuit: reset() returns obs only (:214)
-        next_obs = envs.reset()
-    else:
-        next_obs, _ = envs.reset(seed=args.seed)
-    learner.observe(0, next_obs, np.zeros(local_num_envs, np.float32))
     avg_returns = []
+    grouped = None
+    if groups is not None:
+        from .pipeline import GroupedRollout
+
+        grouped = GroupedRollout(learner, len(groups), frame_delta=bool(getattr(args, "frame_delta", True)))
+        for g, ge in enumerate(groups):
+            o = ge.reset() if env_api in ("gym", "procgen", "pettingzoo") else ge.reset(seed=args.seed + g)[0]
+            grouped.first_observation(g, o)
+    else:
+        if env_api in ("gym", "procgen", "pettingzoo"):             # envpool / procgen / supersuit: reset() returns obs only (:214)
+            next_obs = envs.reset()
+        else:
+            next_obs, _ = envs.reset(seed=args.seed)
+        learner.observe(0, next_obs, np.zeros(local_num_envs, np.float32))
     metrics = {}
+    action = None
     for iteration in range(1, args.num_iterations + 1):
         lrnow = args.learning_rate
         if args.anneal_lr:                                      # :251-254
             frac = 1.0 - (iteration - 1.0) / args.num_iterations
             lrnow = frac * args.learning_rate
-        for step in range(0, args.num_steps):
-            global_step += args.num_envs
-            action = learner.act(step)
-            act_np = action.cpu().numpy()                       # :269  D2H + sync, as the reference
-            if env_api == "gym":
-                next_obs, reward, next_done, info = envs.step(act_np)
-                if writer is not None:                          # ppo_atari_envpool.py:241-247
-                    for idx, d in enumerate(next_done):
-                        if d and info["lives"][idx] == 0:
-                            print(f"global_step={global_step}, episodic_return={info['r'][idx]}")
-                            avg_returns = (avg_returns + [info["r"][idx]])[-20:]
-                            writer.add_scalar("charts/avg_episodic_return", np.average(avg_returns), global_step)
-                            writer.add_scalar("charts/episodic_return", info["r"][idx], global_step)
-                            writer.add_scalar("charts/episodic_length", info["l"][idx], global_step)
-            elif env_api == "pettingzoo":                       # ppo_pettingzoo_ma_atari.py:203-213: envs alternate players
-                next_obs, reward, next_done, info = envs.step(act_np)
-                if writer is not None:
-                    for idx, item in enumerate(info):
-                        player_idx = idx % 2
-                        if "episode" in item.keys():
-                            print(f"global_step={global_step}, {player_idx}-episodic_return={item['episode']['r']}")
-                            writer.add_scalar(f"charts/episodic_return-player{player_idx}", item["episode"]["r"], global_step)
-                            writer.add_scalar(f"charts/episodic_length-player{player_idx}", item["episode"]["l"], global_step)
-            elif env_api == "procgen":                          # ppo_procgen.py:241-250: 4-tuple, one info dict per env
-                next_obs, reward, next_done, info = envs.step(act_np)
-                if writer is not None:
-                    for item in info:
-                        if "episode" in item.keys():
-                            print(f"global_step={global_step}, episodic_return={item['episode']['r']}")
-                            writer.add_scalar("charts/episodic_return", item["episode"]["r"], global_step)
-                            writer.add_scalar("charts/episodic_length", item["episode"]["l"], global_step)
-                            break
-            else:
-                next_obs, reward, terminations, truncations, infos = envs.step(act_np)
-                next_done = np.logical_or(terminations, truncations)
-                if writer is not None and "final_info" in infos:            # :277-282
-                    for info in infos["final_info"]:
-                        if info and "episode" in info:
-                            print(f"global_step={global_step}, episodic_return={info['episode']['r']}")
-                            writer.add_scalar("charts/episodic_return", info["episode"]["r"], global_step)
-                            writer.add_scalar("charts/episodic_length", info["episode"]["l"], global_step)
-            learner.store_reward(step, reward)
-            learner.observe(step + 1, next_obs, next_done)
+        if grouped is not None:
+            base = global_step
+
+            def step_fn(g, act_np, step, _base=base):
+                return _env_step(groups[g], act_np, env_api, writer, _base + (step + 1) * args.num_envs, avg_returns)
+
+            grouped.run(step_fn)
+            global_step += args.num_envs * args.num_steps
+        else:
+            for step in range(0, args.num_steps):
+                global_step += args.num_envs
+                action = learner.act(step)
+                act_np = action.cpu().numpy()                       # :269  D2H + sync, as the reference
+                next_obs, reward, next_done = _env_step(envs, act_np, env_api, writer, global_step, avg_returns)
+                learner.store_reward(step, reward)
+                learner.observe(step + 1, next_obs, next_done)
         if verbose_rank_line:                                   # ppo_atari_multigpu.py:284-286
-            print(f"local_rank: {local_rank}, action.sum(): {action.sum()}, iteration: {iteration}, "
+            asum = action.sum() if action is not None else learner.actions[-1].sum()
+            print(f"local_rank: {local_rank}, action.sum(): {asum}, iteration: {iteration}, "
                   f"agent.actor.weight.sum(): {agent.actor.weight.sum()}")
         learner.finish_rollout()
         metrics = learner.update(lrnow)

@@ -208,6 +208,13 @@ MI355PPO_API int mi355ppo_obs_u8_to_f32(const uint8_t* src_u8, const int64_t* in
 MI355PPO_API int mi355ppo_obs_nchw_to_nhwc_u8(const uint8_t* src, uint8_t* dst, int64_t rows, int C, int HW,
                                               void* stream);
 
+/* FrameStack(4) delta store: dst_rows[r] = prev_rows[r] with channels 1..3 moved to 0..2 and channel 3 taken from
+ * newest_planes[r] (rows, HW) -- the next observation of every env that was not reset, from ONE new plane.  Lets the
+ * host send 1/4 of the frame bytes per step (envs flagged done send their full stack through
+ * mi355ppo_obs_nchw_to_nhwc_u8).  prev_rows may equal dst_rows. */
+MI355PPO_API int mi355ppo_obs_shift_append_u8_c4(const uint8_t* prev_rows, const uint8_t* newest_planes, uint8_t* dst_rows,
+                                                 int64_t rows, int HW, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a8/a9  Flat-buffer optimiser step: (grad * grad_scale) -> global-norm clip -> Adam, fused.
  * Replaces the unpack-and-divide of cleanrl/ppo_atari_multigpu.py:368-374 (grad_scale =

@@ -222,6 +222,36 @@ def test_conv_wgrad(layer, images):
     assert torch.equal(dW, dW2) and torch.equal(db, db2), "weight gradient must be deterministic"
 
 
+@pytest.mark.parametrize("layer", [1, 2, 3])
+def test_conv_wgrad_full_minibatch_against_float64_on_a_strided_slab(layer):
+    """Kernels R (layer 1) and T (layers 2, 3) at the config-C minibatch size, where every workgroup / partial / image-pair
+    combination of the 512-partial workspace is in play: dz is non-zero on a slab of 512 images strided through the whole
+    batch (every 64th image), so the float64 weight gradient of those 512 images IS the exact answer for the 32,768-image
+    launch; the other 32,256 images still stream through the kernel (their products are exact zeros)."""
+    M, step = 32768, 64
+    cin, cout, k, s, hin, hout = SPEC[layer]
+    g = torch.Generator().manual_seed(70 + layer)
+    slab = torch.arange(step // 2 - 1, M, step)                                   # 512 images, odd and even image parities
+    dz_slab = torch.randn(len(slab), cout, hout, hout, generator=g)
+    dz = torch.zeros(M, hout, hout, cout, device=DEV)
+    dz[slab.to(DEV)] = _nhwc(dz_slab).to(DEV)
+    gd = torch.Generator(device=DEV).manual_seed(71)
+    if layer == 1:
+        obs = torch.randint(0, 256, (M + 100, 84, 84, 4), dtype=torch.uint8, device=DEV, generator=gd)
+        inds = torch.randperm(M + 100, device=DEV, generator=gd)[:M]
+        x_slab = obs[inds[slab.to(DEV)]].cpu().permute(0, 3, 1, 2).double() / 255.0
+        dW, db = cnn.conv_wgrad(obs, dz, 1, inds)
+    else:
+        src = torch.relu(torch.randn(M, hin, hin, cin, device=DEV, generator=gd))
+        x_slab = src[slab.to(DEV)].cpu().permute(0, 3, 1, 2).double()
+        dW, db = cnn.conv_wgrad(src, dz, layer)
+    Wd = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    bd = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    refW, refb = torch.autograd.grad(F.conv2d(x_slab, Wd, bd, stride=s), (Wd, bd), dz_slab.double())
+    _close(dW, refW, f"conv{layer} wgrad dW at M=32768 (512-image slab)")
+    _close(db, refb, f"conv{layer} wgrad db at M=32768 (512-image slab)")
+
+
 @pytest.mark.parametrize("images", [48, 4096])
 def test_trunk_matches_reference_network_forward_backward(images):
     """The whole conv stack + Linear(3136,512) against the reference's nn.Sequential in float64 (same weights)."""

@@ -1,0 +1,89 @@
+"""Env-group lanes (cleanrl_amd/pipeline.py) on the host path: K overlapped lanes fill the rollout buffers exactly as the
+serial loop over the same K vector envs does (the lanes only re-order work in time, never data)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from cleanrl_amd import envs as E
+from cleanrl_amd.agents import AtariAgent
+from cleanrl_amd.learner import PPOLearner
+from cleanrl_amd.learner_smoke import default_args
+from cleanrl_amd.pipeline import GroupedRollout, split_env_groups
+
+
+def _groups(N, K, seed):
+    return split_env_groups(lambda g, n: E.SyntheticAtariVecEnv(n, seed=seed + g * n, api="gym", done_p=0.2), N, K)
+
+
+def _learner(N, T):
+    env = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+    torch.manual_seed(3)
+    agent = AtariAgent(env)
+    return PPOLearner(agent, default_args(num_steps=T), env.single_observation_space, env.single_action_space, N, torch.device("cpu"))
+
+
+@pytest.mark.parametrize("K", [1, 2, 4])
+def test_lanes_fill_the_buffers_like_the_serial_loop(K):
+    N, T = 8, 6
+    ref, L = _learner(N, T), _learner(N, T)
+    # serial: one loop over the K vector envs, rows written group by group
+    groups = _groups(N, K, seed=11)
+    per = N // K
+    obs = np.concatenate([g.reset() for g in groups])
+    ref.observe(0, obs, np.zeros(N, np.float32))
+    for step in range(T):
+        a = ref.act(step).numpy()
+        res = [g.step(a[i * per:(i + 1) * per]) for i, g in enumerate(groups)]
+        ref.store_reward(step, np.concatenate([r[1] for r in res]))
+        ref.observe(step + 1, np.concatenate([r[0] for r in res]), np.concatenate([r[2] for r in res]))
+    # lanes: K threads
+    groups2 = _groups(N, K, seed=11)
+    roll = GroupedRollout(L, K)
+    for g, ge in enumerate(groups2):
+        roll.first_observation(g, ge.reset())
+    seen = []
+
+    def step_fn(g, actions, step):
+        assert actions.shape == (per,)
+        seen.append((g, step))
+        o, r, d, _ = groups2[g].step(actions)
+        return o, r, d
+
+    roll.run(step_fn)
+    assert sorted(seen) == [(g, s) for g in range(K) for s in range(T)]
+    for name in ("obs", "boot_obs", "dones", "boot_done", "rewards"):
+        assert torch.equal(getattr(L, name), getattr(ref, name)), name
+    # the policy is a function of the observation rows alone: same values whichever way the rows were batched
+    torch.testing.assert_close(L.values, ref.values, rtol=1e-5, atol=1e-6)
+    assert float(L.dones.sum()) > 0                      # the done path was exercised
+
+
+def test_lane_errors_surface_on_the_callers_thread():
+    N, T, K = 4, 3, 2
+    L = _learner(N, T)
+    roll = GroupedRollout(L, K)
+    groups = _groups(N, K, seed=1)
+    for g, ge in enumerate(groups):
+        roll.first_observation(g, ge.reset())
+
+    def step_fn(g, actions, step):
+        if g == 1 and step == 1:
+            raise RuntimeError("env group 1 broke")
+        o, r, d, _ = groups[g].step(actions)
+        return o, r, d
+
+    with pytest.raises(RuntimeError, match="env group 1 broke"):
+        roll.run(step_fn)
+
+
+def test_env_groups_flag_runs_the_script_end_to_end(capsys):
+    from cleanrl_amd import ppo_atari_envpool
+
+    L = ppo_atari_envpool.main(["--no-cuda", "--synthetic-env", "--num-envs", "4", "--env-groups", "2", "--num-steps", "8",
+                                "--total-timesteps", "64", "--num-minibatches", "2", "--update-epochs", "1"])
+    assert np.isfinite(L.last_metrics["loss"]) and "SPS:" in capsys.readouterr().out
+    with pytest.raises(AssertionError, match="multiple"):
+        ppo_atari_envpool.main(["--no-cuda", "--synthetic-env", "--num-envs", "5", "--env-groups", "2", "--num-steps", "8",
+                                "--total-timesteps", "40", "--num-minibatches", "1"])

@@ -1,9 +1,9 @@
-"""PCIe-inclusive mode: the same learner fed by a HOST vector env (the reference's arrangement: env on the host, one
-D2H of the actions and one H2D of the frames per step).  Frames come from envs.SyntheticAtariVecEnv (numpy, host cores),
-go through PPOLearner.observe(): pinned staging + uint8 H2D on a side stream + relayout kernel.
+"""PCIe-inclusive mode: the same learner fed by HOST vector envs (the reference's arrangement: envs on the host, one D2H of
+the actions and one H2D of the frames per step).  Frames come from envs.SyntheticAtariVecEnv (numpy, host cores) and go
+through the env-group lanes of cleanrl_amd/pipeline.py.
 
-    python tools/host_env_bench.py [--num-envs 1024] [--iters 2]      -> one JSON line
-This number is NOT bench.py's `value` (which starts with inputs resident in HBM); it is recorded in DESIGN.md §5.
+    python tools/host_env_bench.py [--num-envs 1024] [--iters 2] [--groups 1 2 4 8]      -> one JSON line per group count
+This number is NOT bench.py's `value` (which starts with inputs resident in HBM); bench.py reports it as `pcie_inclusive`.
 """
 import argparse
 import json
@@ -21,36 +21,40 @@ from cleanrl_amd.envs import SyntheticAtariVecEnv  # noqa: E402
 from cleanrl_amd.learner import PPOLearner  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--num-envs", type=int, default=1024)
-    ap.add_argument("--num-steps", type=int, default=128)
-    ap.add_argument("--iters", type=int, default=2)
-    a = ap.parse_args()
-    dev = torch.device("cuda:0")
-    N, T = a.num_envs, a.num_steps
-    env = SyntheticAtariVecEnv(N, seed=1)
+def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, device=None):
+    """PCIe-inclusive env-steps/s of the learner fed by HOST vector envs (numpy stand-ins on host threads): ``groups`` = 1 is
+    the reference's serial arrangement (act -> D2H -> envs.step -> H2D of the full stacks), ``groups`` > 1 the overlapped
+    env-group lanes of cleanrl_amd/pipeline.py.  Returns the dict that main() prints."""
+    from cleanrl_amd.pipeline import GroupedRollout, split_env_groups
+
+    dev = device or torch.device("cuda:0")
+    N, T = num_envs, num_steps
+    envs = split_env_groups(lambda g, n: SyntheticAtariVecEnv(n, seed=1 + g * n, api="gym"), N, groups)
     torch.manual_seed(1)
     np.random.seed(1)
-    agent = AtariAgent(env).to(dev)
+    agent = AtariAgent(envs[0]).to(dev)
     args = learner_smoke.default_args(num_steps=T, num_minibatches=4, update_epochs=4, clip_coef=0.1)
-    L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, dev, sample_seed=1)
-    obs, _ = env.reset(seed=1)
-    L.observe(0, obs, np.zeros(N, np.float32))
-    t_env = t_roll = t_upd = 0.0
-    for it in range(a.iters + 1):
+    L = PPOLearner(agent, args, envs[0].single_observation_space, envs[0].single_action_space, N, dev, sample_seed=1)
+    roll = GroupedRollout(L, groups, frame_delta=frame_delta)
+    for g, e in enumerate(envs):
+        roll.first_observation(g, e.reset())
+    t_env = [0.0] * groups
+
+    def step_fn(g, actions, step):
+        e0 = time.perf_counter()
+        o, r, d, _ = envs[g].step(actions)
+        t_env[g] += time.perf_counter() - e0
+        return o, r, d
+
+    t_roll = t_upd = 0.0
+    for it in range(iters + 1):
         if it == 1:                                   # iteration 0 is warm-up
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            t_env = t_roll = t_upd = 0.0
+            t_roll = t_upd = 0.0
+            t_env[:] = [0.0] * groups
         r0 = time.perf_counter()
-        for step in range(T):
-            act = L.act(step).cpu().numpy()           # D2H + sync, as the reference (:269)
-            e0 = time.perf_counter()
-            obs, reward, term, trunc, _ = env.step(act)
-            t_env += time.perf_counter() - e0
-            L.store_reward(step, reward)
-            L.observe(step + 1, obs, np.logical_or(term, trunc))
+        roll.run(step_fn)
         L.finish_rollout()
         torch.cuda.synchronize()
         t_roll += time.perf_counter() - r0
@@ -60,10 +64,24 @@ def main():
         torch.cuda.synchronize()
         t_upd += time.perf_counter() - u0
     el = time.perf_counter() - t0
-    print(json.dumps({"mode": "host env (numpy) -> pinned -> uint8 H2D side stream", "num_envs": N, "num_steps": T,
-                      "iters": a.iters, "sps": N * T * a.iters / el, "ms_per_iter": el / a.iters * 1e3,
-                      "rollout_ms": t_roll / a.iters * 1e3, "of_which_host_env_ms": t_env / a.iters * 1e3,
-                      "update_ms": t_upd / a.iters * 1e3, "h2d_bytes_per_step": N * 28224}))
+    delta = roll.lanes[0].delta
+    return {"mode": f"host envs (numpy stand-ins) in {groups} env group(s): pinned uint8 staging, one stream + host thread per group"
+                    + (", newest-frame-only H2D" if delta else ", full-stack H2D"),
+            "num_envs": N, "num_steps": T, "iters": iters, "env_groups": groups, "sps": N * T * iters / el,
+            "ms_per_iter": el / iters * 1e3, "rollout_ms": t_roll / iters * 1e3,
+            "host_env_ms_per_group": [t / iters * 1e3 for t in t_env], "update_ms": t_upd / iters * 1e3,
+            "h2d_bytes_per_step": N * (7056 if delta else 28224)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-envs", type=int, default=1024)
+    ap.add_argument("--num-steps", type=int, default=128)
+    ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--groups", type=int, nargs="*", default=[1, 2, 4, 8])
+    a = ap.parse_args()
+    for k in a.groups:
+        print(json.dumps(run(a.num_envs, a.num_steps, a.iters, k, frame_delta=k > 1)), flush=True)
 
 
 if __name__ == "__main__":
