@@ -104,7 +104,7 @@ def parse():
     p.add_argument("--cpu-baseline-envs", type=int, default=128)
     p.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets (pure SPS run)")
     p.add_argument("--no-pcie-inclusive", action="store_true", help="skip the host-env (PCIe-inclusive) leg after the timed region")
-    p.add_argument("--pcie-env-groups", type=int, default=4)
+    p.add_argument("--pcie-env-groups", type=int, default=2)
     return p.parse_args()
 
 
