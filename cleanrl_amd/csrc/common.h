@@ -13,6 +13,10 @@ namespace mi355ppo {
 
 void set_error(const char* fmt, ...);
 
+// kernel P (conv1p.hip): layer-1 weight gradient on the bf16 matrix pipe; partial layout of kernel R (conv.hip reduces them)
+int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
+                  hipStream_t s);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }

@@ -1778,17 +1778,22 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     float* part_b = part_w + (size_t)lparts * total_w;
     float* mid = part_b + (size_t)lparts * Cout;
     float* mid_b = mid + (size_t)((lparts + kRedChunk - 1) / kRedChunk) * total_w;
-    // Tuning switches.  Layer 1: 3 = kernel R (rows, default), 2 = kernel D (direct dz), 1 = kernel W.
+    // Tuning switches.  Layer 1: 4 = kernel P (bf16 pipe, exact products, conv1p.hip; default), 3 = kernel R (rows, f32 MFMA),
+    // 2 = kernel D (direct dz), 1 = kernel W.
     // Layers 2, 3: 3 = kernel T (taps) with paired 8-byte loads on layer 2 (default), 1 = kernel T with 4-byte loads on both
     // layers, 2 = likewise with the deeper layer-2 prefetch ring, 0 = kernel W.
-    static const int s_wk = getenv("MI355PPO_WGRAD") ? atoi(getenv("MI355PPO_WGRAD")) : 3;
+    static const int s_wk = getenv("MI355PPO_WGRAD") ? atoi(getenv("MI355PPO_WGRAD")) : 4;
     static const int s_wt = getenv("MI355PPO_WGRAD_TAPS") ? atoi(getenv("MI355PPO_WGRAD_TAPS")) : 3;
     const size_t smem = wgrad_smem(g.src_bytes, Hout * Hout, Cout);
     hipStream_t s = as_stream(stream);
     hipError_t e = hipSuccess;
     int grid = wgrad_grid(images);      // workgroups launched
     int wparts = grid;                  // partials they write (weights and bias alike)
-    if (layer == 1 && s_wk == 3) {      // kernel R: one partial per wave; LDS = 4 waves x 2 slab buffers of 8 KiB
+    if (layer == 1 && s_wk == 4) {      // kernel P (conv1p.hip): bf16 matrix pipe, exact products; one partial per wave
+        wparts = grid * 4;
+        const int rc = conv1p_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images, grid, s);
+        if (rc) return rc;
+    } else if (layer == 1 && s_wk == 3) {      // kernel R: one partial per wave; LDS = 4 waves x 2 slab buffers of 8 KiB
         auto k = conv_wgrad_rows_kernel<GeomConv1>;
         const size_t sm = 4 * 2 * 8192;
         wparts = grid * 4;

@@ -105,3 +105,95 @@ def test_kernel_R_index_maps_give_the_layer1_weight_gradient():
     W = torch.zeros(32, 4, 8, 8, dtype=torch.float64, requires_grad=True)
     (ref,) = torch.autograd.grad(F.conv2d(x, W, None, stride=4), W, torch.from_numpy(dz).permute(0, 3, 1, 2))
     assert np.abs(got - ref.numpy()).max() <= 1e-9 * np.abs(ref.numpy()).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Kernel P (cleanrl_amd/csrc/conv1p.hip): layer-1 weight gradient on the bf16 pipe.  Index maps restated: the transposed
+# LDS staging (4-chunk quads + the q = 20 chunk), the 15 pixel groups -> 8 steps, the dz window / slot mapping of the
+# short group, the shifted read for tap columns 4..7, the three-term bf16 split, and the partial's column order.
+def _p_row(g): return g // 3 if g < 15 else 4
+def _p_ox0(g): return 8 * (g % 3) if g < 15 else 16
+def _p_nv(g): return (8 if g % 3 < 2 else 4) if g < 15 else 0
+
+
+def _bf16_terms(x):
+    """x (f32) -> (hi, mid, lo) as the kernel forms them: truncations to the top 16 bits of x, x - hi, (x - hi) - mid."""
+    x = np.asarray(x, np.float32)
+    trunc = lambda v: (v.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    hi = trunc(x)
+    r = (x - hi).astype(np.float32)
+    mid = trunc(r)
+    lo = (r - mid).astype(np.float32)
+    assert np.array_equal(trunc(lo), lo), "the third term must be a bf16 value"
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x.astype(np.float64))
+    return hi, mid, lo
+
+
+def _emulate_kernel_p(frames, dz):
+    """frames (images, 84, 84, 4) uint8, dz (images, 20, 20, 32) f32 -> partial [32][256] (float64 accumulation of the exact
+    products), one workgroup of four waves."""
+    images = frames.shape[0]
+    part = np.zeros((32, 256))
+    LINE, ROWLDS = 32, 512
+    for wave in range(4):
+        acc = np.zeros((8, 32, 32))                               # [tap row r][channel n][column li = kw*4 + c]
+        for img in range(images):
+            slab = frames[img].reshape(84, 336)[20 * wave:20 * wave + 24]          # 24 source rows of 336 bytes
+            tt = np.full(24 * ROWLDS, 0xEE, np.uint8)                                # never-written bytes must not matter
+            for ident in range(120):                                                 # quads: q = 4Q .. 4Q+3 of source row R
+                R, Q = divmod(ident, 5)
+                st = [slab[R, (4 * Q + k) * 16:(4 * Q + k) * 16 + 16].reshape(4, 4) for k in range(4)]   # [chunk k][pixel t][channel]
+                for t in range(4):
+                    for ch in range(4):
+                        base = R * ROWLDS + (t * 4 + ch) * LINE + 4 * Q
+                        tt[base:base + 4] = [st[k][t, ch] for k in range(4)]
+            for R in range(24):                                                      # the q = 20 chunk: byte 0 of a dword store
+                st20 = slab[R, 320:336].reshape(4, 4)
+                for t in range(4):
+                    for ch in range(4):
+                        base = R * ROWLDS + (t * 4 + ch) * LINE + 20
+                        tt[base:base + 4] = [st20[t, ch], 0, 0, 0]
+            for s in range(8):
+                a_terms = np.zeros((3, 32, 16))                   # [term][channel n][slot]
+                b_vals = np.zeros((8, 32, 16))                    # [tap row][column li][slot]
+                for lh in range(2):
+                    g = 2 * s + lh
+                    row, ox0, nv = _p_row(g), _p_ox0(g), _p_nv(g)
+                    lox = ox0 if nv == 8 else 12
+                    orow = 5 * wave + row
+                    ring = dz[img, orow, lox:lox + 8, :]          # (8 pixels, 32 channels): all inside the row
+                    for j in range(8):
+                        if nv == 8:
+                            x = ring[j]
+                        elif nv == 4 and j < 4:
+                            x = ring[j + 4]
+                        else:
+                            x = np.zeros(32, np.float32)
+                        for term, v in enumerate(_bf16_terms(x)):
+                            a_terms[term, :, 8 * lh + j] = v
+                    for li in range(32):
+                        kw, c = li >> 2, li & 3
+                        line = ((kw & 3) * 4 + c) * LINE
+                        sh = kw >> 2
+                        for r in range(8):
+                            lp = (4 * row + r) * ROWLDS + line + ox0
+                            w = tt[lp:lp + 12]
+                            b_vals[r, li, 8 * lh:8 * lh + 8] = w[sh:sh + 8]
+                for r in range(8):
+                    for term in range(3):
+                        acc[r] += a_terms[term] @ b_vals[r].T
+        for r in range(8):
+            part[:, r * 32:(r + 1) * 32] += acc[r]
+    return part
+
+
+def test_kernel_p_index_maps_give_the_layer1_weight_gradient():
+    rs = np.random.RandomState(5)
+    images = 2
+    frames = rs.randint(0, 256, size=(images, 84, 84, 4)).astype(np.uint8)
+    dz = (rs.standard_normal((images, 20, 20, 32)) * np.exp(rs.uniform(-8, 2, size=(images, 20, 20, 32)))).astype(np.float32)
+    part = _emulate_kernel_p(frames, dz)
+    x = torch.from_numpy(frames).permute(0, 3, 1, 2).double()
+    ref = torch.nn.grad.conv2d_weight(x, (32, 4, 8, 8), torch.from_numpy(dz).permute(0, 3, 1, 2).double(), stride=4)   # (n, c, r, kw)
+    ref = ref.permute(0, 2, 3, 1).reshape(32, 256).numpy()                                                             # [n][(r, kw, c)]
+    assert np.abs(part - ref).max() <= 1e-9 * np.abs(ref).max()
