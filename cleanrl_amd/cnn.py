@@ -18,8 +18,10 @@ from .ops import _chk, _on, _ptr, _stream, _workspace
 
 # layer -> (Cin, Cout, K, stride, Hin, Hout)
 LAYERS = {1: (4, 32, 8, 4, 84, 20), 2: (32, 64, 4, 2, 20, 9), 3: (64, 64, 3, 1, 9, 7)}
-MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2, MODE_DGRAD_S1_CLASSES, MODE_FWD_Q = 0, 1, 2, 3, 4
+MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2, MODE_DGRAD_S1_CLASSES, MODE_FWD_Q, MODE_DGRAD_S2_CLASSES = 0, 1, 2, 3, 4, 5
 BT_CLASSES_NUMEL = 81 * 4096
+BT2_CLASSES_NUMEL = 16 * 128 * 64   # layer-2 data gradient, one matrix per border class of the 10x10 class grid (mode 5)
+VARIANT_DGRAD2_CLASSES = 6
 QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 storage elements (kernel Q's integer-digit pack)
 VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
 
@@ -28,7 +30,8 @@ def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch
     lib = _lib.load()
     cin, cout, k, _, _, _ = LAYERS[layer]
     _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
-    numel = BT_CLASSES_NUMEL if mode == MODE_DGRAD_S1_CLASSES else QPACK_NUMEL if mode == MODE_FWD_Q else W.numel()
+    numel = (BT_CLASSES_NUMEL if mode == MODE_DGRAD_S1_CLASSES else QPACK_NUMEL if mode == MODE_FWD_Q
+             else BT2_CLASSES_NUMEL if mode == MODE_DGRAD_S2_CLASSES else W.numel())
     if out is None:
         out = torch.empty(numel, dtype=torch.float32, device=W.device)
     _chk(out, torch.float32, "Bt", (numel,))
@@ -73,7 +76,8 @@ def conv_dgrad(dz: torch.Tensor, Bt: torch.Tensor, act_in: torch.Tensor, layer: 
     images = dz.shape[0]
     _chk(dz, torch.float32, "dz", (images, hout, hout, cout))
     _chk(act_in, torch.float32, "act_in", (images, hin, hin, cin))
-    _chk(Bt, torch.float32, "Bt", (BT_CLASSES_NUMEL if variant == 5 else cout * cin * k * k,))
+    _chk(Bt, torch.float32, "Bt", (BT_CLASSES_NUMEL if variant == 5 else BT2_CLASSES_NUMEL if variant == VARIANT_DGRAD2_CLASSES
+                                   else cout * cin * k * k,))
     if out is None:
         out = torch.empty_like(act_in)
     _chk(out, torch.float32, "out", (images, hin, hin, cin))
@@ -203,7 +207,10 @@ class NatureTrunkFn(torch.autograd.Function):
         else:
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1), a2, 3, dz2)
         dW2, db2 = conv_wgrad(a1, dz2, 2)
-        conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
+        if a1.numel() * 4 < (1 << 32) - 8192:
+            conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2_CLASSES), a1, 2, dz1, variant=VARIANT_DGRAD2_CLASSES)   # no padding zeros
+        else:
+            conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
         dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds)
         return None, None, dW1, db1, dW2, db2, dW3, db3, None
 

@@ -469,6 +469,7 @@ using GeomDgrad3 = FixedGeom<7, 7, 64, 3, 3, 9, 9, 1, -2, 9, 9, 64, 1>;       //
 using GeomDgrad2 = FixedGeom<9, 9, 64, 2, 2, 10, 10, 1, -1, 20, 20, 32, 2>;   // source = dz2, destination = da1 (4 classes)
 
 constexpr int kC3_total = 81 * 4096;         // floats of the per-class layer-3 data-gradient matrices: (1+2+3+2+1)^2 * 64 * 64
+constexpr int kC2_total = 16 * 128 * 64;     // floats of the per-class layer-2 data-gradient matrices: (1+2+1)^2 taps * (4*32) rows * 64
 constexpr unsigned kOob = 0xFFFFF000u;      // buffer offset that is out of range for every tensor < 4 GiB - 4 KiB
 constexpr int kRsrcWord3 = 0x00020000;      // raw buffer, 32-bit elements (gfx9 / CDNA resource format)
 
@@ -1391,6 +1392,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce2(const float* __restric
 // mode 0 (forward):           Bt[n=cout][(r,c,cin)]          = W[cout][cin][r][c]
 // mode 1 (dgrad, stride 1):   Bt[n=cin][(r,c,cout)]          = W[cout][cin][KH-1-r][KW-1-c]
 // mode 2 (dgrad, stride 2):   Bt[cls][n=cin][(r,c,cout)]     = W[cout][cin][ph+2-2r][pw+2-2c], cls = 2*ph+pw, r,c in {0,1}
+// mode 5 (dgrad, stride 2, per border class): the same, one [4*cin][(r',c',cout)] matrix per class of the class grid
 __global__ __launch_bounds__(256) void conv_repack_kernel(const float* __restrict__ W, float* __restrict__ Bt, int Cout,
                                                           int Cin, int KH, int KW, int mode, float scale) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -1418,6 +1420,25 @@ __global__ __launch_bounds__(256) void conv_repack_kernel(const float* __restric
                     const int rr = k / (nrt[b] * Cout), rem = k - rr * (nrt[b] * Cout), cc = rem / Cout, co = rem - cc * Cout;
                     const int r = r0t[a] + rr, c = r0t[b] + cc;
                     Bt[e] = W[((co * Cin + n) * KH + (KH - 1 - r)) * KW + (KW - 1 - c)];
+                    return;
+                }
+                off += sz;
+            }
+    } else if (mode == 5) {
+        // per-class matrices of the layer-2 data gradient: border class (a,b) of the 10x10 class grid, [4 parity classes x
+        // n=cin][(r',c',cout)], taps as in mode 2 restricted to the class's valid window
+        const int r0t[3] = {1, 0, 0}, nrt[3] = {1, 2, 1};
+        int off = 0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                const int K = nrt[a] * nrt[b] * Cout, sz = 4 * Cin * K;
+                if (e >= off && e < off + sz) {
+                    const int e2 = e - off, row = e2 / K, k = e2 - row * K;
+                    const int cls = row / Cin, n = row - cls * Cin;
+                    const int rr = k / (nrt[b] * Cout), rem = k - rr * (nrt[b] * Cout), cc = rem / Cout, co = rem - cc * Cout;
+                    const int r = r0t[a] + rr, c = r0t[b] + cc;
+                    const int ph = cls >> 1, pw = cls & 1;
+                    Bt[e] = W[((co * Cin + n) * KH + (ph + 2 - 2 * r)) * KW + (pw + 2 - 2 * c)];
                     return;
                 }
                 off += sz;
@@ -1457,9 +1478,9 @@ extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, floa
     MI355_REQUIRE(W && Bt, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
     if (mode == 4 && layer == 1) return mi355ppo_cnn_conv1q_pack(W, Bt, stream);   // integer-digit pack of kernel Q (conv1q.hip)
-    MI355_REQUIRE(mode == 0 || ((mode == 1 || mode == 3) && layer == 3) || (mode == 2 && layer == 2), MI355PPO_EINVAL,
+    MI355_REQUIRE(mode == 0 || ((mode == 1 || mode == 3) && layer == 3) || ((mode == 2 || mode == 5) && layer == 2), MI355PPO_EINVAL,
                   "%s: mode %d is not defined for layer %d", fn, mode, layer);
-    const int total = mode == 3 ? kC3_total : Cout * Cin * KH * KH;
+    const int total = mode == 3 ? kC3_total : mode == 5 ? kC2_total : Cout * Cin * KH * KH;
     hipLaunchKernelGGL(conv_repack_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), W, Bt, Cout, Cin, KH,
                        KH, mode, layer == 1 ? kInv255 : 1.0f);     // layer 1 consumes raw uint8 taps
     return check_launch("conv_repack_kernel");
@@ -1592,6 +1613,49 @@ static int launch_dgrad3_classes(const float* dz, const float* Bt, const float* 
     return launch_dgrad3_group<1, 1, 1, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s);
 }
 
+// ---- layer-2 data gradient without its structural zeros.  da1 (20x20) = four stride-parity classes of 2x2-tap
+// correlations of dz2 (9x9) on a 10x10 class grid; class-grid row gy only has the taps r with 0 <= gy-1+r < 9, so 19 % of
+// the (pixel, tap) products of an image are zeros of the padding.  Grid rows / columns fall into three classes {0},
+// {1..8},{9} with tap windows of 1,2,1 taps; a (row class, column class) pair is a dense, un-padded problem.  The four
+// parity classes stay one 128-channel GEMM inside every border class (CLS4).
+static const int kC2_r0[3] = {1, 0, 0}, kC2_nr[3] = {1, 2, 1}, kC2_p0[3] = {0, 1, 9};
+static int c2_bt_offset(int a, int b) {      // element offset of class (a,b)'s matrix [128][nr*nc*64] in the mode-5 repack
+    int off = 0;
+    for (int aa = 0; aa < 3; ++aa)
+        for (int bb = 0; bb < 3; ++bb) {
+            if (aa == a && bb == b) return off;
+            off += 128 * kC2_nr[aa] * kC2_nr[bb] * 64;
+        }
+    return off;
+}
+template <int NR, int NC, int GY, int GX>
+static int launch_dgrad2_group(const float* dz, const float* Bt, const float* act_in, float* dsrc, long long images,
+                               long long srcb, long long dstb, hipStream_t s) {
+    using G = FixedGeom<9, 9, 64, NR, NC, GY, GX, 1, 0, 20, 20, 32, 2>;
+    ClsParams cp{};
+    int n = 0;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            if (kC2_nr[a] == NR && kC2_nr[b] == NC && (kC2_nr[a] == 2 ? 8 : 1) == GY && (kC2_nr[b] == 2 ? 8 : 1) == GX) {
+                cp.offy[n] = kC2_p0[a] - 1 + kC2_r0[a];
+                cp.offx[n] = kC2_p0[b] - 1 + kC2_r0[b];
+                cp.day[n] = 2 * kC2_p0[a];
+                cp.dax[n] = 2 * kC2_p0[b];
+                cp.bt_off[n] = c2_bt_offset(a, b);
+                ++n;
+            }
+    const long long P = images * GY * GX;
+    return launch_fixed_cfg<G, 4, false, EPI_MASK, false, true, 1>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, P, srcb, dstb, s, &cp, n);
+}
+static int launch_dgrad2_classes(const float* dz, const float* Bt, const float* act_in, float* dsrc, long long images,
+                                 long long srcb, long long dstb, hipStream_t s) {
+    int rc;
+    if ((rc = launch_dgrad2_group<2, 2, 8, 8>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    if ((rc = launch_dgrad2_group<1, 2, 1, 8>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    if ((rc = launch_dgrad2_group<2, 1, 8, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s))) return rc;
+    return launch_dgrad2_group<1, 1, 1, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s);
+}
+
 // MI355PPO_CONV_CFG (tuning): 0 = MT 2 / 8 waves (default), 1 = MT 1 / 16 waves, 2 = MT 1 / 8 waves
 template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4 = false, int MT = 2>
 static int launch_stream(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
@@ -1684,7 +1748,8 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
                   "%s: layer=%d must be 2 or 3 (conv1's input needs no gradient)", fn, layer);
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
-    MI355_REQUIRE(variant >= 0 && variant <= 5 && (variant != 5 || layer == 3), MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
+    MI355_REQUIRE(variant >= 0 && variant <= 6 && (variant != 5 || layer == 3) && (variant != 6 || layer == 2), MI355PPO_EINVAL,
+                  "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(dz, 16) && aligned(Bt, 16) && aligned(act_in, 16) && aligned(dsrc, 16), MI355PPO_EALIGN,
                   "%s: pointers must be 16-byte aligned", fn);
     MI355_REQUIRE((long long)images * Hin * Hin * Cin < (1LL << 31), MI355PPO_EINVAL, "%s: destination exceeds 2^31 elements", fn);
@@ -1711,6 +1776,8 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
         g.KH = g.KW = 2; g.GY = g.GX = Hin / 2; g.SS = 1; g.OFF = -1; g.DM = 2; g.DAY = g.DAX = 0; g.classes = 4;
         g.K = 4 * Cout; g.P = (long long)images * (Hin / 2) * (Hin / 2);
         const long long srcb2 = (long long)images * Hout * Hout * Cout * 4, dstb2 = (long long)images * Hin * Hin * Cin * 4;
+        if (variant == 6)       // Bt must be the mode-5 (per border class) repack
+            return launch_dgrad2_classes(dz, Bt, act_in, dsrc, images, srcb2, dstb2, s);
         if (variant == 2)       // one pass for all four parity classes: they read the SAME dz taps (only weights and
                                 // destination pixel differ), so the 4x32 class channels form one 128-wide GEMM
             return launch_fixed<GeomDgrad2, 4, false, EPI_MASK, true, true, 1>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g.P, srcb2, dstb2, s);

@@ -48,11 +48,19 @@ constexpr int kQRsrcWord3 = 0x00020000;
 // One workgroup: W (32,4,8,8) f32 as torch stores it -> the pack.
 __global__ __launch_bounds__(256) void conv1q_pack_kernel(const float* __restrict__ W, unsigned char* __restrict__ pack) {
     __shared__ int s_E[32];
+    __shared__ float s_max[32][8];
     __shared__ int s_sum[kQDigits][32][8];
     const int tid = threadIdx.x;
+    {   // per-channel largest magnitude: thread (n, r) scans its 32 weights, 8 partial maxima per channel
+        const int n = tid >> 3, r = tid & 7;
+        float m = 0.0f;
+        for (int e32 = 0; e32 < 32; ++e32) m = fmaxf(m, fabsf(W[((n * kQC + (e32 & 3)) * 8 + r) * 8 + (e32 >> 2)]));
+        s_max[n][r] = m;
+    }
+    __syncthreads();
     if (tid < 32) {
         float m = 0.0f;
-        for (int k = 0; k < 256; ++k) m = fmaxf(m, fabsf(W[tid * 256 + k]));
+        for (int r = 0; r < 8; ++r) m = fmaxf(m, s_max[tid][r]);
         int E = 0;
         if (m > 0.0f) {
             (void)frexpf(m, &E);                 // m = f * 2^E, f in [0.5, 1)

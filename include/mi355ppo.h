@@ -246,6 +246,8 @@ MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_
  *   mode 2  layer-2 data gradient            Bt[4][Cin][(r,c,cout)] (one 2x2-tap matrix per parity class)
  *   mode 3  layer-3 data gradient, per border class: 25 matrices [Cin][(r',c',cout)] for the 5x5 (row class,
  *           column class) tap windows (mi355ppo_cnn_conv_dgrad_f32_variant(..., variant 5)); 81*4096 floats
+ *   mode 5  layer-2 data gradient, per border class: 9 matrices [4*Cin][(r',c',cout)] for the 3x3 (row class, column
+ *           class) tap windows of the 10x10 class grid (variant 6); 16*128*64 floats
  *   mode 4  layer 1 only: the integer-digit pack of kernel Q (csrc/conv1q.hip): every weight as a 31-bit
  *           fixed-point number on its output channel's scale, four signed radix-256 digits in the operand
  *           layout of v_mfma_i32_32x32x32_i8, + accumulator start values + per-channel scales;
@@ -273,7 +275,8 @@ MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds,
  * 2 = fixed-geometry streaming kernel (weights resident in LDS, A fragments fetched straight into a register ring,
  *     taps as compile-time immediates, buffer loads/stores; tensors must be < 4 GiB), 4 = its run-time-geometry
  *     predecessor; data gradient only: 3 = one launch per stride-parity class (layer 2), 5 = layer 3 split into
- *     its 25 border classes so that no padding zeros are multiplied (needs the mode-3 repack);
+ *     its 25 border classes so that no padding zeros are multiplied (needs the mode-3 repack), 6 = layer 2 split
+ *     into the 9 border classes of its class grid (needs the mode-5 repack);
  *     forward of layer 1 only: 6 = kernel Q (Bt = the mode-4 pack). */
 MI355PPO_API int mi355ppo_cnn_conv_fwd_f32_variant(const void* src, const int64_t* inds, const float* Bt, const float* bias,
                                                    float* dst, int64_t images, int layer, int variant, void* stream);

@@ -175,13 +175,15 @@ def test_conv_fwd_f32(layer, images, variant):
     _close(got, _nhwc(ref), f"conv{layer} fwd")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 19, 128, 700, 7000])
 def test_conv_dgrad_with_relu_mask(layer, images, variant):
     if variant == 5 and layer != 3:
         pytest.skip("variant 5 (border classes) is the layer-3 data gradient")
-    if images == 7000 and variant not in (2, 5):
+    if variant == 6 and layer != 2:
+        pytest.skip("variant 6 (border classes) is the layer-2 data gradient")
+    if images == 7000 and variant not in (2, 5, 6):
         pytest.skip("the 7000-image case is checked on the default kernels only (CPU reference time)")
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(20 + layer)
@@ -191,7 +193,8 @@ def test_conv_dgrad_with_relu_mask(layer, images, variant):
     dz = torch.randn(images, cout, hout, hout, generator=g)
     out = F.conv2d(act, W.double(), None, stride=s)
     (ref,) = torch.autograd.grad(out, pre, dz.double())                              # conv_transpose * (act > 0)
-    mode = (cnn.MODE_DGRAD_S1_CLASSES if variant == 5 else cnn.MODE_DGRAD_S1) if layer == 3 else cnn.MODE_DGRAD_S2
+    mode = ((cnn.MODE_DGRAD_S1_CLASSES if variant == 5 else cnn.MODE_DGRAD_S1) if layer == 3
+            else (cnn.MODE_DGRAD_S2_CLASSES if variant == 6 else cnn.MODE_DGRAD_S2))
     got = cnn.conv_dgrad(_nhwc(dz).to(DEV), cnn.repack_weights(W.to(DEV), layer, mode),
                          _nhwc(act.detach().float()).to(DEV), layer, variant=variant)
     _close(got, _nhwc(ref), f"conv{layer} dgrad")

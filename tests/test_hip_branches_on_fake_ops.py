@@ -438,8 +438,8 @@ class FakeCnn:
 
         cin, cout, k, _, _, _ = cnn.LAYERS[layer]
         _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
-        assert (layer, mode) in ((1, 0), (1, 4), (2, 0), (3, 0), (3, 1), (2, 2), (3, 3))
-        numel = cnn.BT_CLASSES_NUMEL if mode == 3 else cnn.QPACK_NUMEL if mode == 4 else W.numel()
+        assert (layer, mode) in ((1, 0), (1, 4), (2, 0), (3, 0), (3, 1), (2, 2), (3, 3), (2, 5))
+        numel = cnn.BT_CLASSES_NUMEL if mode == 3 else cnn.QPACK_NUMEL if mode == 4 else cnn.BT2_CLASSES_NUMEL if mode == 5 else W.numel()
         if out is None:
             out = torch.empty(numel)
         _chk(out, torch.float32, "Bt", (numel,))
@@ -474,7 +474,7 @@ class FakeCnn:
         from cleanrl_amd import cnn
 
         cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
-        W = self._w(Bt, layer, (3,) if variant == 5 else ((1,) if layer == 3 else (2,)))
+        W = self._w(Bt, layer, (3,) if variant == 5 else (5,) if variant == 6 else ((1,) if layer == 3 else (2,)))
         _chk(dz, torch.float32, "dz", (dz.shape[0], hout, hout, cout))
         _chk(act_in, torch.float32, "act_in", (dz.shape[0], hin, hin, cin))
         gi = torch.nn.functional.conv_transpose2d(dz.permute(0, 3, 1, 2), W, stride=s).permute(0, 2, 3, 1) * (act_in > 0)

@@ -65,9 +65,11 @@ def main():
                 mode = cnn.MODE_DGRAD_S1 if layer == 3 else cnn.MODE_DGRAD_S2
                 btd = cnn.repack_weights(W, layer, mode)
                 dsrc = torch.empty_like(src)
-                for v in ((2, 5) if layer == 3 else (2,)):
+                for v in ((2, 5) if layer == 3 else (2, 6)):
                     if v == 5:
                         btd = cnn.repack_weights(W, layer, cnn.MODE_DGRAD_S1_CLASSES)
+                    if v == 6:
+                        btd = cnn.repack_weights(W, layer, cnn.MODE_DGRAD_S2_CLASSES)
                     us = bench(lambda: cnn.conv_dgrad(dz, btd, src, layer, dsrc, variant=v))
                     out(k="dgrad", variant=v, layer=layer, M=M, us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / PEAK,
                         note="flops counted as the forward conv's")
