@@ -12,28 +12,24 @@
 // Arithmetic: v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, exact f32 products with one rounding per
 // fma, 157 TFLOP/s chip peak (the same rate as the f32 vector unit).  No reduced precision anywhere.
 //
-// Kernel G (conv_gemm_kernel): C[m][n] = sum_k A[m][k] * Bt[n][k]
+// The GEMM view: C[m][n] = sum_k A[m][k] * Bt[n][k]
 //   m  = a destination pixel (img, gy, gx);  n = output channel;  k = (r, c, ch) tap-major, channel-minor.
 //   A[m][k] = src[img, gy*SS + OFF + r, gx*SS + OFF + c, ch] (0 outside the tensor): with channels-last
-//   storage a (pixel, r) pair is ONE contiguous run of KW*C elements, so the tile loader is a coalesced
-//   16-byte-per-lane stream with no im2col buffer.  The same kernel is the forward conv (SS = stride,
-//   OFF = 0), the stride-1 data gradient (OFF = -(K-1), flipped weights) and the stride-2 data gradient
-//   (four parity classes of destination pixels, each a 2x2-tap stride-1 problem with its own weight matrix).
-//   256 threads own a 128-pixel x BN-channel tile; K is walked in 32-element stages through a double-buffered
-//   LDS ring (row stride 36 floats: the ds_read_b128 fragment reads and ds_write_b128 stage writes are
-//   bank-conflict free); wave w multiplies pixels [32w, 32w+32) by all BN channels.
-//   An MFMA k-pair is {kk*8 + e, kk*8 + 4 + e}: lanes 0-31 / 32-63 each fetch FOUR consecutive k with one
-//   ds_read_b128 (A and B use the same k permutation, so the product is unchanged).
+//   storage a (pixel, r) pair is ONE contiguous run of KW*C elements, so no im2col buffer exists anywhere.
+//   The same GEMM is the forward conv (SS = stride, OFF = 0), the stride-1 data gradient (OFF = -(K-1), flipped
+//   weights) and the stride-2 data gradient (four parity classes of destination pixels, each a 2x2-tap stride-1
+//   problem with its own weight matrix).  The weight gradient is dWt[n][k] = sum_m dz[m][n] * A[m][k], one partial per
+//   workgroup / wave, summed in a fixed order by conv_wgrad_reduce1/2 (deterministic) and scattered into torch's
+//   (Cout, Cin, KH, KW) layout.
 //
-// Kernel W (conv_wgrad_kernel): dWt[n][k] = sum_m dz[m][n] * A[m][k]; a persistent workgroup stages one
-//   image (source + dz) in LDS at a time, keeps the WHOLE dWt tile set in accumulators (Cout x K / 1024
-//   MFMA tiles per wave), reads the patches straight out of the staged image (implicit im2col in LDS) and
-//   writes one partial per workgroup; conv_wgrad_reduce sums the partials in a fixed order (deterministic)
-//   and scatters into torch's (Cout, Cin, KH, KW) layout.  First generation; the defaults are now
-//
+// Kernels in this file (the LDS-tiled first generation G and the staged weight-gradient kernels W / D were removed in
+// round 2; DESIGN.md section 3.2 keeps their measurements as the tuning log):
+// Kernel S (conv_stream_kernel): forward / data gradient with run-time geometry -- the fallback for tensors beyond the
+//   4 GiB that kernel F's 32-bit buffer offsets address;
 // Kernel F (conv_fixed_kernel): forward / data gradient with compile-time geometry, the weight matrix resident in LDS,
 //   A fragments streamed global -> register ring, buffer loads / stores for padding and tails;
-// Kernel R (conv_wgrad_rows_kernel): layer-1 weight gradient, wave-autonomous (private double-buffered LDS slab, no barrier);
+// Kernel R (conv_wgrad_rows_kernel): layer-1 weight gradient on the f32 pipe, wave-autonomous (private double-buffered LDS
+//   slab, no barrier) -- the A/B counterpart of kernel P (conv1p.hip, bf16 pipe), which is the default;
 // Kernel T (conv_wgrad_taps_kernel): layer-2/3 weight gradient, operands straight from global memory in MFMA operand
 //   layout, a sliding register window of source columns, no LDS at all.
 // Each is documented where it is defined; DESIGN.md section 3.2 has the measurements and the tuning log.
@@ -70,165 +66,10 @@ struct ConvGeom {
 __device__ __forceinline__ float u8_tap(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }
 constexpr float kInv255 = 1.0f / 255.0f;
 
-constexpr int kBM = 128;      // pixels per workgroup tile
-constexpr int kBK = 32;       // k elements per stage
-constexpr int kLd = 36;       // LDS row stride in floats (32 + 4 pad)
-
 enum { EPI_BIAS_RELU = 0, EPI_MASK = 1, EPI_RAW = 2 };
 
-template <int BN, bool U8IN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const void* __restrict__ src_v,
-                                                           const int64_t* __restrict__ inds,
-                                                           const float* __restrict__ Bt_all,
-                                                           const float* __restrict__ bias,
-                                                           const float* __restrict__ mask_src,
-                                                           float* __restrict__ dst, ConvGeom g) {
-    constexpr int NJT = BN / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][kBM * kLd];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLd];
-    __shared__ long long s_dstoff[kBM];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int cls = blockIdx.y;
-    const float* __restrict__ Bt = Bt_all + (size_t)cls * BN * g.K;
-    const int day = g.classes == 4 ? (cls >> 1) : g.DAY;
-    const int dax = g.classes == 4 ? (cls & 1) : g.DAX;
-    const long long tile0 = (long long)blockIdx.x * kBM;
-    const int per_img = g.GY * g.GX;
-
-    // destination offsets of the tile's 128 rows (element index of channel 0), -1 = beyond P
-    if (tid < kBM) {
-        const long long p = tile0 + tid;
-        long long off = -1;
-        if (p < g.P) {
-            const long long img = p / per_img;
-            const int rem = (int)(p - img * per_img);
-            const int gy = rem / g.GX, gx = rem - gy * g.GX;
-            off = ((img * g.DH + (gy * g.DM + day)) * g.DW + (gx * g.DM + dax)) * (long long)g.DC;
-        }
-        s_dstoff[tid] = off;
-    }
-
-    // this thread's four A rows: lrow + 32*q
-    const int lrow = tid >> 3, c4 = tid & 7;
-    long long abase[4];
-    int asy[4], asx[4];
-    bool arow_ok[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const long long p = tile0 + lrow + 32 * q;
-        arow_ok[q] = p < g.P;
-        const long long pp = arow_ok[q] ? p : 0;
-        const long long img = pp / per_img;
-        const int rem = (int)(pp - img * per_img);
-        const int gy = rem / g.GX, gx = rem - gy * g.GX;
-        asy[q] = gy * g.SS + g.OFF;
-        asx[q] = gx * g.SS + g.OFF;
-        const long long simg = (U8IN && inds) ? inds[img] : img;
-        abase[q] = ((simg * g.H + asy[q]) * g.W + asx[q]) * (long long)g.C;
-    }
-    const int runlen = g.KW * g.C;
-    const int rowpitch = g.W * g.C;
-    const int nstages = g.K / kBK;
-
-    float4 areg[4];
-    float4 breg[NJT];
-    int st_r = 0, st_rem = 0;    // position of the NEXT stage to load: tap row r, offset within the run
-
-    auto load_stage = [&](int s) {
-        const int k0 = s * kBK;
-        const int cx = U8IN ? 0 : (st_rem >> g.logC);     // tap column of this stage (f32 sources: one pixel per stage)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long long off = abase[q] + (long long)st_r * rowpitch + st_rem + c4 * 4;
-            if (U8IN) {
-                uint32_t w = 0;
-                if (arow_ok[q]) w = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(src_v) + off);
-                areg[q].x = u8_tap(w, 0);
-                areg[q].y = u8_tap(w, 1);
-                areg[q].z = u8_tap(w, 2);
-                areg[q].w = u8_tap(w, 3);
-            } else {
-                const int sy = asy[q] + st_r, sx = asx[q] + cx;
-                const bool ok = arow_ok[q] && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
-                areg[q] = ok ? *reinterpret_cast<const float4*>(static_cast<const float*>(src_v) + off)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt)
-            breg[jt] = *reinterpret_cast<const float4*>(Bt + (size_t)(lrow + 32 * jt) * g.K + k0 + c4 * 4);
-        st_rem += kBK;
-        if (st_rem == runlen) { st_rem = 0; ++st_r; }
-    };
-    auto write_stage = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * q) * kLd + c4 * 4]) = areg[q];
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt)
-            *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * jt) * kLd + c4 * 4]) = breg[jt];
-    };
-
-    f32x16 acc[NJT];
-#pragma unroll
-    for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[jt][e] = 0.0f;
-
-    load_stage(0);
-    write_stage(0);
-    __syncthreads();
-    for (int s = 0; s < nstages; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstages) load_stage(s + 1);
-        const float* __restrict__ Ap = &As[buf][(32 * wave + li) * kLd + 4 * lh];
-        const float* __restrict__ Bp = &Bs[buf][li * kLd + 4 * lh];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const float4 a = *reinterpret_cast<const float4*>(Ap + kk * 8);
-            float4 b[NJT];
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) b[jt] = *reinterpret_cast<const float4*>(Bp + jt * 32 * kLd + kk * 8);
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[jt].x, acc[jt], 0, 0, 0);
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[jt].y, acc[jt], 0, 0, 0);
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[jt].z, acc[jt], 0, 0, 0);
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[jt].w, acc[jt], 0, 0, 0);
-        }
-        if (s + 1 < nstages) write_stage(buf ^ 1);
-        __syncthreads();
-    }
-
-    // epilogue: D[row = (e&3) + 8*(e>>2) + 4*lh][col = li]
-#pragma unroll
-    for (int jt = 0; jt < NJT; ++jt) {
-        const int n = jt * 32 + li;
-        const float bv = (EPI == EPI_BIAS_RELU) ? bias[n] : 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const long long off = s_dstoff[row];
-            if (off >= 0) {
-                float v = acc[jt][e];
-                if (EPI == EPI_BIAS_RELU) {
-                    v = v + bv;
-                    v = v > 0.0f ? v : 0.0f;          // torch.relu / clamp_min(0): NaN propagates either way
-                } else if (EPI == EPI_MASK) {
-                    v = mask_src[off + n] > 0.0f ? v : 0.0f;   // ReLU backward: grad * (out > 0)
-                }
-                dst[off + n] = v;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------ kernel S
-// conv_stream_kernel: the same GEMM as conv_gemm_kernel with the roles of the memories swapped.  The whole
+// conv_stream_kernel: the GEMM of the file header with the weight matrix, not the pixels, resident on chip.  The whole
 // weight matrix Bt (N x K, <= 148 KB) is loaded ONCE per workgroup into LDS and stays there; every wave then
 // streams its own 32-pixel tiles: a lane fetches its A fragments (16 bytes = 4 consecutive k of ITS pixel, or 16
 // uint8 taps) straight from global memory into a register ring that runs D chunks ahead -- across tile
@@ -704,374 +545,10 @@ __global__ __launch_bounds__(64 * NW) void conv_fixed_kernel(const void* __restr
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
-struct WgradGeom {
-    int H, W, C;       // source per image
-    int KH, KW, SS;    // taps, stride (no padding)
-    int GY, GX;        // dz grid per image
-    int N;             // Cout
-    int K;             // KH*KW*C
-    int images;
-    int src_bytes;     // bytes of one source image as stored (u8: H*W*C, f32: 4*H*W*C)
-    int diag;          // tuning only (MI355PPO_CONV_DIAG): bit0 no prefetch, bit1 no LDS commit, bit2 no MFMA loop
-};
-
-// NCI = Cout/32 (1 or 2); TPW = MFMA tiles per wave = (N/32)*(K/32)/4; NS / ND = 16-byte chunks of one source /
-// dz image per thread (ceil(bytes / 16 / 256)).  While image i is multiplied out of LDS, image i+1 is already
-// in flight into registers (NS + ND uint4 per thread), so the only exposed memory time is the first image's.
-// SPLIT: every wave owns ALL tiles (TPW = all of them) and a quarter of the pixel pairs instead of a quarter of the
-// tiles and all pairs -- more MFMAs per fragment fetch for the thin conv1 problem (8 tiles); each wave then writes
-// its own partial.
-// B128 (layer 2: a tap row is 128 floats = 4 tiles): lane l owns patch elements 4l..4l+3 of each of the wave's two tap
-// rows instead of element l of each of its 8 tiles, so two ds_read_b128 replace eight ds_read_b32; tile 4r+c then
-// holds the columns {128r + 4l + c} (a permutation of dW's columns, undone when the partial is written).
-template <int NCI, int TPW, bool U8IN, int NS, int ND, bool SPLIT, int RD, bool B128 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_kernel(const void* __restrict__ src_v,
-                                                            const int64_t* __restrict__ inds,
-                                                            const float* __restrict__ dz,
-                                                            float* __restrict__ part_w,     // [grid][N][K]
-                                                            float* __restrict__ part_b,     // [grid][N]
-                                                            WgradGeom g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int npix = g.GY * g.GX;
-    const int npairs = (npix + 1) >> 1;
-    // layout: [src image][dz image: (2*npairs) x N floats][pixbase: 2*npairs ints]
-    unsigned char* s_src = smem;
-    float* s_dz = reinterpret_cast<float*>(smem + ((g.src_bytes + 15) & ~15));
-    int* s_pixbase = reinterpret_cast<int*>(s_dz + (size_t)2 * npairs * g.N);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int ci = SPLIT ? 0 : wave % NCI, jgroup = SPLIT ? 0 : wave / NCI;
-    const int P0 = SPLIT ? wave : 0, PS = SPLIT ? 4 : 1;
-
-    for (int p = tid; p < 2 * npairs; p += 256) {
-        int v = 0;
-        if (p < npix) {
-            const int gy = p / g.GX, gx = p - gy * g.GX;
-            v = ((gy * g.SS) * g.W + gx * g.SS) * g.C;
-        }
-        s_pixbase[p] = v;
-    }
-    for (int e = npix * g.N + tid; e < 2 * npairs * g.N; e += 256) s_dz[e] = 0.0f;   // pad pixel of odd grids
-
-    const int runlen = g.KW * g.C, rowpitch = g.W * g.C;
-    int patch_off[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int e0 = (jgroup * TPW + t) * 32;
-        patch_off[t] = (e0 / runlen) * rowpitch + (e0 % runlen) + li;
-    }
-
-    f32x16 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const int dz4 = npix * g.N / 4;            // float4 per dz image
-    const int src16 = g.src_bytes / 16;        // 16-byte chunks per source image
-    u32x4 rs[NS];
-    float4 rd[ND];
-    auto prefetch = [&](int img) {
-        const long long simg = (U8IN && inds) ? inds[img] : img;
-        const u32x4* gsrc = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(src_v) + simg * (long long)g.src_bytes);
-        const float4* gdz = reinterpret_cast<const float4*>(dz + (long long)img * npix * g.N);
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const int e = tid + 256 * q;
-            rs[q] = gsrc[e < src16 ? e : 0];
-        }
-#pragma unroll
-        for (int q = 0; q < ND; ++q) {
-            const int e = tid + 256 * q;
-            rd[q] = gdz[e < dz4 ? e : 0];
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const int e = tid + 256 * q;
-            if (e < src16) reinterpret_cast<u32x4*>(s_src)[e] = rs[q];
-        }
-#pragma unroll
-        for (int q = 0; q < ND; ++q) {
-            const int e = tid + 256 * q;
-            if (e < dz4) {
-                reinterpret_cast<float4*>(s_dz)[e] = rd[q];
-                bsum.x += rd[q].x; bsum.y += rd[q].y; bsum.z += rd[q].z; bsum.w += rd[q].w;
-            }
-        }
-    };
-    auto frag_a = [&](int pr) { return s_dz[(2 * pr + lh) * g.N + ci * 32 + li]; };
-    auto frag_b_at = [&](int pb, float (&b)[TPW]) {
-        if constexpr (B128) {
-            static_assert(!B128 || (TPW == 8 && !U8IN && !SPLIT), "B128 is the layer-2 configuration");
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_src) + pb + (2 * jgroup + r) * rowpitch + 4 * li);
-                b[4 * r + 0] = v.x; b[4 * r + 1] = v.y; b[4 * r + 2] = v.z; b[4 * r + 3] = v.w;
-            }
-            return;
-        }
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            if (U8IN) b[t] = __uint_as_float((unsigned)s_src[pb + patch_off[t]]);   // raw byte; converted when consumed (a
-                                                                                    // cvt here would wait for the ds_read at once)
-            else b[t] = reinterpret_cast<const float*>(s_src)[pb + patch_off[t]];
-        }
-    };
-
-    int img = blockIdx.x;
-    if (img < g.images) prefetch(img);
-    for (; img < g.images; img += gridDim.x) {
-        __syncthreads();                       // previous image fully consumed
-        if (!(g.diag & 2)) commit();
-        __syncthreads();
-        const int nxt = img + gridDim.x;
-        if (nxt < g.images && !(g.diag & 1)) prefetch(nxt);      // in flight during the whole multiply phase
-        if (g.diag & 4) continue;
-        // Operand ring of RD pixel pairs (fixed registers per slot), pixbase one pair further ahead, and scheduling
-        // fences so that the LDS reads of pair q+RD are ISSUED right after the MFMAs of pair q -- (RD-1) pairs of MFMA
-        // time before they are needed (hipcc otherwise sinks them behind the MFMAs and every pair pays a dependent
-        // ds_read -> ds_read round trip with the matrix pipe idle).  RD = 4 for the thin layer-1 problem (2 MFMAs per
-        // pair and wave), 2 otherwise.
-        const int last = npairs - 1;
-        float ra[RD];
-        float rb[RD][TPW];
-        int pbn;                                   // pixbase of the next pair to be fetched
-        {
-            int q = P0;
-#pragma unroll
-            for (int sl = 0; sl < RD; ++sl) {
-                const int qq = q < last ? q : last;
-                ra[sl] = q <= last ? frag_a(qq) : 0.0f;
-                frag_b_at(s_pixbase[2 * qq + lh], rb[sl]);
-                q += PS;
-            }
-            pbn = s_pixbase[2 * (q < last ? q : last) + lh];
-        }
-        for (int pr = P0; pr < npairs; pr += RD * PS) {
-#pragma unroll
-            for (int sl = 0; sl < RD; ++sl) {
-                // pairs past the end were fetched from the (clamped) last pair with their dz fragment forced to 0, so the
-                // MFMAs stay unconditional (a branch around them makes hipcc copy all accumulators at the join)
-#pragma unroll
-                for (int t = 0; t < TPW; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[sl], U8IN ? (float)__float_as_uint(rb[sl][t]) : rb[sl][t], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                const int q = pr + (sl + RD) * PS, qq = q < last ? q : last, q1 = q + PS < last ? q + PS : last;
-                if (!(g.diag & 8)) {
-                    ra[sl] = q <= last ? frag_a(qq) : 0.0f;
-                    frag_b_at(pbn, rb[sl]);
-                    pbn = s_pixbase[2 * q1 + lh];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    // partial weights: D[row i = cout within ci][col j = patch element within tile]
-    float* pw = part_w + (size_t)(SPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * g.N * g.K;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int kcol = B128 ? 256 * jgroup + 128 * (t >> 2) + 4 * li + (t & 3) : (jgroup * TPW + t) * 32 + li;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int n = ci * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            pw[(size_t)n * g.K + kcol] = acc[t][e];
-        }
-    }
-    // partial bias gradient: thread t always loaded channels (4t % N) .. +3
-    __syncthreads();
-    float4* s_b = reinterpret_cast<float4*>(s_dz);     // reuse (256 float4 = 4 KiB <= dz image)
-    s_b[tid] = bsum;
-    __syncthreads();
-    if (tid < g.N) {
-        const int grp = tid >> 2, comp = tid & 3, ngrp = g.N >> 2;
-        float s = 0.0f;
-        for (int t = grp; t < 256; t += ngrp) s += reinterpret_cast<const float*>(&s_b[t])[comp];
-        part_b[(size_t)blockIdx.x * g.N + tid] = s;
-    }
-}
-
-// ---- weight gradient, second generation (kernel D).  Kernel W staged the source image AND the dz image of every
-// image through LDS; the dz image (up to 51 KB f32) was most of that traffic, and needs no staging at all: a dz
-// fragment is 32 consecutive channels of one pixel per half-wave -- perfectly coalesced as it lies.  Here only the source
-// image goes through LDS (its patches overlap, so it is read 4-9x), while the dz fragments come straight from global
-// memory into a register ring that runs across image boundaries (the loads are issued in exactly the order they are
-// consumed, RING pixel pairs ahead).  The bias gradient is the running sum of the dz fragments a lane sees.
-//   PSPLIT (layer 1: 8 tiles): every wave owns ALL tiles and a quarter of the pixel pairs -> one partial per wave;
-//   otherwise (layers 2, 3: 32 / 36 tiles): wave w owns channel half w % NCI and tile group w / NCI, all pixel pairs.
-// STEPS = pixel pairs per wave and image, padded to a multiple of RING (padding pairs carry dz = 0).
-// DMA: the source image goes global -> LDS with global_load_lds (no registers, no commit phase) into the buffer that is not
-// being multiplied from; ONE barrier per image, entered after the wave has waited for its own pieces with s_waitcnt
-// vmcnt(RING) -- the counter is in order and exactly the RING dz fragments issued after the DMA may stay outstanding.
-template <class G, int NCI, int TPW, bool U8IN, bool PSPLIT, int STEPS, int RING, int NS, bool DMA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_direct_kernel(
-    const void* __restrict__ src_v, const int64_t* __restrict__ inds, const float* __restrict__ dz,
-    float* __restrict__ part_w,      // [parts][N][K]
-    float* __restrict__ part_b,      // [parts][N]
-    int images) {
-    constexpr int kSrcBytes = G::H * G::W * G::C * (U8IN ? 1 : 4), kN = G::DC, kK = G::K, kNpix = G::GY * G::GX;
-    static_assert(STEPS % RING == 0, "steps per image must be a multiple of the ring depth");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kImgPad = NS * 256 * 16;                       // one LDS image buffer (whole 16-byte chunks per thread)
-    unsigned char* s_src = smem;
-    int* s_pixbase = reinterpret_cast<int*>(smem + (DMA ? 2 * kImgPad : ((kSrcBytes + 15) & ~15)));
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int ci = PSPLIT ? 0 : wave % NCI, jgroup = PSPLIT ? 0 : wave / NCI;
-    const int P0 = PSPLIT ? wave : 0, PS = PSPLIT ? 4 : 1;
-    constexpr int npix = kNpix;
-    const int ntab = 2 * (P0 + PS * STEPS) + 2;                  // pixel indices the steps can touch (clamped table)
-    for (int p = tid; p < ntab; p += 256) {
-        const int pp = p < npix ? p : npix - 1;
-        const int gy = pp / G::GX, gx = pp - gy * G::GX;
-        s_pixbase[p] = ((gy * G::SS) * G::W + gx * G::SS) * G::C;
-    }
-    constexpr int runlen = G::RUN, rowpitch = G::PITCH;
-    int patch_off[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int e0 = (jgroup * TPW + t) * 32;
-        patch_off[t] = (e0 / runlen) * rowpitch + (e0 % runlen) + li;
-    }
-    f32x16 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
-    float bsum = 0.0f;
-
-    // dz ring: element (image, step) = dz[image][pixel 2*(P0 + PS*step) + lh][ci*32 + li], 0 for padding pixels
-    // (the fragment is stored raw and masked when it is consumed: a select here would make the wave wait for the load it
-    // has just issued.  Masking is only needed when the padded step grid reaches past the image's pixels.)
-    constexpr bool MASK = 2 * ((PSPLIT ? 3 : 0) + (PSPLIT ? 4 : 1) * (STEPS - 1)) + 1 >= kNpix;
-    float ring[RING];
-    unsigned rmask = 0u;
-    int l_img = blockIdx.x, l_step = 0;
-    // The load cursor runs exactly RING steps ahead and STEPS % RING == 0, so it can only wrap to the next image after
-    // slot RING-1: the check is compiled into that slot alone (a branch in every slot makes hipcc rotate the ring through
-    // register copies at the loop back-edge, which waits for ALL outstanding loads every RING steps).
-    auto dzload = [&](int slot, bool may_wrap) {
-        const int p = 2 * (P0 + PS * l_step) + lh;
-        const bool ok = l_img < images && p < npix;
-        const long long idx = ok ? ((long long)l_img * npix + p) * kN + ci * 32 + li : (long long)li;
-        ring[slot] = dz[idx];
-        if (MASK) rmask = (rmask & ~(1u << slot)) | ((ok ? 1u : 0u) << slot);
-        ++l_step;
-        if (may_wrap && l_step == STEPS) { l_step = 0; l_img += gridDim.x; }
-    };
-#pragma unroll
-    for (int j = 0; j < RING; ++j) dzload(j, j == RING - 1);
-
-    constexpr int src16 = kSrcBytes / 16;
-    u32x4 rs[NS];
-    auto prefetch = [&](int img) {
-        const long long simg = (U8IN && inds) ? inds[img] : img;
-        const u32x4* gs = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(src_v) + simg * (long long)kSrcBytes);
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const int e = tid + 256 * q;
-            rs[q] = gs[e < src16 ? e : 0];
-        }
-    };
-    // uint8, 8 tiles (layer 1): the 8 x 32 taps of a pixel are 64 dwords; lane l fetches dwords l and l + 32 (tap rows
-    // l/8 and l/8 + 4, columns 4(l%8) .. +3) with two ds_read_b32 instead of eight ds_read_u8.  Tile 4h + c then holds, in
-    // lane l, the tap (row l/8 + 4h, column 4(l%8) + c): a permutation of dW's columns, undone when the partial is written.
-    constexpr bool PACK8 = U8IN && PSPLIT && TPW == 8 && G::RUN == 32;
-    const unsigned char* cur = s_src;                            // LDS image being multiplied from
-    auto frag_b = [&](int pb, float (&b)[TPW]) {
-        if constexpr (PACK8) {
-            const int o = pb + (li >> 3) * rowpitch + 4 * (li & 7);
-            b[0] = __uint_as_float(*reinterpret_cast<const uint32_t*>(cur + o));
-            b[1] = __uint_as_float(*reinterpret_cast<const uint32_t*>(cur + o + 4 * rowpitch));
-            return;
-        }
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            if (U8IN) b[t] = __uint_as_float((unsigned)cur[pb + patch_off[t]]);       // raw byte, converted when consumed
-            else b[t] = reinterpret_cast<const float*>(cur)[pb + patch_off[t]];
-        }
-    };
-    auto pix = [&](int step) { return s_pixbase[2 * (P0 + PS * step) + lh]; };
-
-    auto dma = [&](int img, int buf) {                          // this thread's NS chunks of image `img` -> LDS buffer `buf`
-        const long long simg = (U8IN && inds) ? inds[img] : img;
-        const unsigned char* gs = static_cast<const unsigned char*>(src_v) + simg * (long long)kSrcBytes;
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const int e = tid + 256 * q;
-            __builtin_amdgcn_global_load_lds(gs + (size_t)(e < src16 ? e : src16 - 1) * 16,
-                                             (__attribute__((address_space(3))) void*)(smem + buf * kImgPad + (256 * q + 64 * wave) * 16),
-                                             16, 0, 0);
-        }
-    };
-    int img = blockIdx.x, buf = 0;
-    if (img < images) {
-        if (DMA) dma(img, 0);
-        else prefetch(img);
-    }
-    for (; img < images; img += gridDim.x) {
-        if (DMA) {
-            __builtin_amdgcn_s_waitcnt(0x0F70 | (RING & 0xF) | ((RING >> 4) << 14));   // vmcnt(RING): my DMA pieces have landed
-            __syncthreads();                   // everyone's pieces have landed; the other buffer is no longer read
-            cur = s_src + buf * kImgPad;
-            if (img + (int)gridDim.x < images) dma(img + gridDim.x, buf ^ 1);
-            buf ^= 1;
-        } else {
-            __syncthreads();                       // previous image fully consumed
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                const int e = tid + 256 * q;
-                if (e < src16) reinterpret_cast<u32x4*>(s_src)[e] = rs[q];
-            }
-            __syncthreads();
-            if (img + (int)gridDim.x < images) prefetch(img + gridDim.x);      // in flight during the whole multiply phase
-        }
-        float rb[2][TPW];
-        frag_b(pix(0), rb[0]);
-        frag_b(pix(1), rb[1]);
-        int pbn = pix(2);
-        for (int s0 = 0; s0 < STEPS; s0 += RING) {
-#pragma unroll
-            for (int j = 0; j < RING; ++j) {
-                const float a = (MASK && !((rmask >> j) & 1u)) ? 0.0f : ring[j];
-                bsum += a;
-                const int sl = (RING % 2 == 0) ? (j & 1) : ((s0 + j) & 1);
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    float bv;
-                    if constexpr (PACK8) bv = u8_tap(__float_as_uint(rb[sl][t >> 2]), t & 3);
-                    else bv = U8IN ? (float)__float_as_uint(rb[sl][t]) : rb[sl][t];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                dzload(j, j == RING - 1);                          // (image, step + RING) -- or the next image's first steps
-                frag_b(pbn, rb[sl]);                               // step + 2 (slots refilled past the last step are never consumed)
-                const int s3 = s0 + j + 3;
-                pbn = pix(s3 < STEPS ? s3 : STEPS - 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    float* pw = part_w + (size_t)(PSPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * kN * kK;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int kcol = PACK8 ? ((li >> 3) + 4 * (t >> 2)) * 32 + 4 * (li & 7) + (t & 3) : (jgroup * TPW + t) * 32 + li;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) pw[(size_t)(ci * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * kK + kcol] = acc[t][e];
-    }
-    const float both = bsum + __shfl_xor(bsum, 32, 64);
-    if (lh == 0 && (PSPLIT || jgroup == 0))
-        part_b[(size_t)(PSPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * kN + ci * 32 + li] = both;
-}
-
-// ---- weight gradient of layer 1, third generation (kernel R, "rows").  Kernel D's waves still met at two barriers per
-// image (stage the shared source image, then multiply) and paid a pixel-table read, an address add and a predicated 64-bit
-// index computation beside every 8 MFMAs.  Here a wave is autonomous:
+// ---- weight gradient of layer 1 on the f32 pipe (kernel R, "rows"; the default is kernel P in conv1p.hip, R is its
+// f32-MFMA counterpart for A/B runs: MI355PPO_WGRAD=3).  Its predecessors (kernels W and D, removed in round 2) met at two
+// workgroup barriers per image and paid a pixel-table read, an address add and a predicated 64-bit index computation beside
+// every 8 MFMAs.  Here a wave is autonomous:
 //   * wave w owns output rows 5w .. 5w+4 of every image of its workgroup, i.e. the 24 source rows 20w .. 20w+23 (8,064 bytes;
 //     neighbouring waves overlap by 4 rows).  It stages that slab itself, global -> registers -> its own double-buffered
 //     LDS region, so there is NO workgroup barrier anywhere: LDS instructions of one wave execute in order;
@@ -1082,7 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //     instead of two plus the table read;
 //   * the next image's slab is fetched during round 0 (one 16-byte load per step) and written to the other LDS buffer
 //     during round 3; the dz fragments run one round ahead, straight from global memory, across image boundaries.
-// Lane roles as in kernel D / PACK8: lane (li, lh) supplies, for pixel 2j + lh of the row, the dword of tap row li/8 (+4),
+// Lane roles: lane (li, lh) supplies, for pixel 2j + lh of the row, the dword of tap row li/8 (+4),
 // tap columns 4(li%8) .. +3; tile 4h + c holds tap (row li/8 + 4h, column 4(li%8) + c) -- undone when the partial is written.
 template <class G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_rows_kernel(
@@ -1211,7 +688,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //     all 9 taps of input-channel half w >> 1; layer 2 (4x4, 32 ch) tap rows 2(w >> 1), 2(w >> 1) + 1, all 4 columns;
 //   * the whole image (49 / 81 steps) is unrolled: every load is (per-image pointer + immediate); the image-pair loop is
 //     unrolled by two so that the prefetch of the next pair lands in the other half of the (logical) register arrays.
-// One partial dW per workgroup as in kernel W (same reduce kernels).
+// One partial dW per workgroup (same reduce kernels as every weight-gradient kernel).
 //   PAIR (layer 2, default; measured 1.52 -> 1.41 ms per entry point, bit-identical dW): with 32 input channels
 //   two neighbouring source columns are 256 contiguous bytes, so ONE 8-byte load per lane fetches both -- lanes 0-15 hold
 //   channels (2l, 2l+1) of column x, lanes 16-31 of column x+1 -- and the two tiles it feeds are {tap kw, tap kw+1} x
@@ -1677,7 +1154,7 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
     MI355_REQUIRE(layer == 1 || inds == nullptr, MI355PPO_EINVAL, "%s: inds (row gather) is only defined for layer 1", fn);
-    MI355_REQUIRE((variant >= 0 && variant <= 4) || (variant == 6 && layer == 1), MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
+    MI355_REQUIRE(variant == 0 || variant == 2 || variant == 4 || (variant == 6 && layer == 1), MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(src, 16) && aligned(Bt, 16) && aligned(dst, 16) && aligned(inds, 8), MI355PPO_EALIGN,
                   "%s: src/Bt/dst must be 16-byte aligned", fn);
     if (variant == 6) return mi355ppo_cnn_conv1q_fwd(src, inds, Bt, bias, dst, images, stream);   // Bt = the mode-4 pack
@@ -1707,14 +1184,8 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
         if (layer == 1) return launch_stream<1, true, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g, s);
         return launch_stream<2, false, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g, s);
     }
-    const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 1);
-    if (layer == 1)
-        hipLaunchKernelGGL((conv_gemm_kernel<32, true, EPI_BIAS_RELU>), grid, dim3(256), 0, s, src, inds, Bt, bias,
-                           (const float*)nullptr, dst, g);
-    else
-        hipLaunchKernelGGL((conv_gemm_kernel<64, false, EPI_BIAS_RELU>), grid, dim3(256), 0, s, src, inds, Bt, bias,
-                           (const float*)nullptr, dst, g);
-    return check_launch("conv_gemm_kernel(fwd)");
+    set_error("%s: unknown variant %d", fn, variant);
+    return MI355PPO_EINVAL;
 }
 
 extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds, const float* Bt, const float* bias,
@@ -1748,8 +1219,8 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
                   "%s: layer=%d must be 2 or 3 (conv1's input needs no gradient)", fn, layer);
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
-    MI355_REQUIRE(variant >= 0 && variant <= 6 && (variant != 5 || layer == 3) && (variant != 6 || layer == 2), MI355PPO_EINVAL,
-                  "%s: unknown variant %d", fn, variant);
+    MI355_REQUIRE((variant == 0 || variant == 2 || variant == 4 || (variant == 3 && layer == 2) || (variant == 5 && layer == 3) ||
+                   (variant == 6 && layer == 2)), MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(dz, 16) && aligned(Bt, 16) && aligned(act_in, 16) && aligned(dsrc, 16), MI355PPO_EALIGN,
                   "%s: pointers must be 16-byte aligned", fn);
     MI355_REQUIRE((long long)images * Hin * Hin * Cin < (1LL << 31), MI355PPO_EINVAL, "%s: destination exceeds 2^31 elements", fn);
@@ -1769,9 +1240,8 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
             return launch_fixed<GeomDgrad3, 2, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g.P, srcb3, dstb3, s);
         if (variant == 4)
             return launch_stream<2, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
-        const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 1);
-        hipLaunchKernelGGL((conv_gemm_kernel<64, false, EPI_MASK>), grid, dim3(256), 0, s, (const void*)dz,
-                           (const int64_t*)nullptr, Bt, (const float*)nullptr, act_in, dsrc, g);
+        set_error("%s: unknown variant %d for layer 3", fn, variant);
+        return MI355PPO_EINVAL;
     } else {
         g.KH = g.KW = 2; g.GY = g.GX = Hin / 2; g.SS = 1; g.OFF = -1; g.DM = 2; g.DAY = g.DAX = 0; g.classes = 4;
         g.K = 4 * Cout; g.P = (long long)images * (Hin / 2) * (Hin / 2);
@@ -1787,11 +1257,9 @@ static int conv_dgrad_impl(const float* dz, const float* Bt, const float* act_in
         }
         if (variant == 3)
             return launch_stream<1, false, EPI_MASK, true>((const void*)dz, nullptr, Bt, nullptr, act_in, dsrc, g, s);
-        const dim3 grid((unsigned)((g.P + kBM - 1) / kBM), 4);
-        hipLaunchKernelGGL((conv_gemm_kernel<32, false, EPI_MASK>), grid, dim3(256), 0, s, (const void*)dz,
-                           (const int64_t*)nullptr, Bt, (const float*)nullptr, act_in, dsrc, g);
+        set_error("%s: unknown variant %d for layer 2", fn, variant);
+        return MI355PPO_EINVAL;
     }
-    return check_launch("conv_gemm_kernel(dgrad)");
 }
 
 extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32(const float* dz, const float* Bt, const float* act_in, float* dsrc,
@@ -1804,10 +1272,6 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32_variant(const float* dz,
     return conv_dgrad_impl(dz, Bt, act_in, dsrc, images, layer, variant, stream);
 }
 
-static size_t wgrad_smem(int src_bytes, int npix, int N) {
-    const int npairs = (npix + 1) / 2;
-    return (size_t)((src_bytes + 15) & ~15) + (size_t)2 * npairs * N * 4 + (size_t)2 * npairs * 4;
-}
 static int wgrad_grid(int64_t images) { return images < 512 ? (int)images : 512; }
 
 extern "C" MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t images, int layer) {
@@ -1832,73 +1296,47 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
                   workspace ? workspace_bytes : (size_t)0, need);
     MI355_REQUIRE(aligned(src, 16) && aligned(dz, 16) && aligned(dW, 4) && aligned(db, 4) && aligned(workspace, 16) &&
                       aligned(inds, 8), MI355PPO_EALIGN, "%s: src/dz/workspace must be 16-byte aligned", fn);
-    WgradGeom g;
-    g.H = g.W = Hin; g.C = Cin; g.KH = g.KW = KH; g.SS = SS; g.GY = g.GX = Hout; g.N = Cout; g.K = KH * KH * Cin;
-    g.images = (int)images; g.src_bytes = Hin * Hin * Cin * (layer == 1 ? 1 : 4);
-    static const int s_wdiag = getenv("MI355PPO_CONV_DIAG") ? atoi(getenv("MI355PPO_CONV_DIAG")) : 0;
-    g.diag = s_wdiag;
+    const int K = KH * KH * Cin;
     // Workspace layout (sized by mi355ppo_cnn_conv_wgrad_workspace_bytes for the kernel with the most partials):
     //   part_w [lparts][Cout*K] | part_b [lparts][Cout] | mid [ceil(lparts/32)][Cout*K] | mid_b [ceil(lparts/32)][Cout]
     const int lparts = wgrad_grid(images) * (layer == 1 ? 4 : 1);
-    const int total_w = Cout * g.K;
+    const int total_w = Cout * K;
     float* part_w = static_cast<float*>(workspace);
     float* part_b = part_w + (size_t)lparts * total_w;
     float* mid = part_b + (size_t)lparts * Cout;
     float* mid_b = mid + (size_t)((lparts + kRedChunk - 1) / kRedChunk) * total_w;
-    // Tuning switches.  Layer 1: 4 = kernel P (bf16 pipe, exact products, conv1p.hip; default), 3 = kernel R (rows, f32 MFMA),
-    // 2 = kernel D (direct dz), 1 = kernel W.
-    // Layers 2, 3: 3 = kernel T (taps) with paired 8-byte loads on layer 2 (default), 1 = kernel T with 4-byte loads on both
-    // layers, 2 = likewise with the deeper layer-2 prefetch ring, 0 = kernel W.
+    // Layer 1: kernel P (bf16 pipe, exact products, conv1p.hip); MI355PPO_WGRAD=3 selects kernel R (rows, f32 MFMA) for A/B
+    // runs.  Layers 2, 3: kernel T (taps); MI355PPO_WGRAD_TAPS: 3 = paired 8-byte loads on layer 2 (default), 1 = 4-byte
+    // loads on both layers, 2 = likewise with the deeper layer-2 prefetch ring.
     static const int s_wk = getenv("MI355PPO_WGRAD") ? atoi(getenv("MI355PPO_WGRAD")) : 4;
     static const int s_wt = getenv("MI355PPO_WGRAD_TAPS") ? atoi(getenv("MI355PPO_WGRAD_TAPS")) : 3;
-    const size_t smem = wgrad_smem(g.src_bytes, Hout * Hout, Cout);
     hipStream_t s = as_stream(stream);
-    hipError_t e = hipSuccess;
     int grid = wgrad_grid(images);      // workgroups launched
     int wparts = grid;                  // partials they write (weights and bias alike)
-    if (layer == 1 && s_wk == 4) {      // kernel P (conv1p.hip): bf16 matrix pipe, exact products; one partial per wave
+    if (layer == 1 && s_wk != 3) {      // kernel P: one partial per wave
         wparts = grid * 4;
         const int rc = conv1p_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images, grid, s);
         if (rc) return rc;
-    } else if (layer == 1 && s_wk == 3) {      // kernel R: one partial per wave; LDS = 4 waves x 2 slab buffers of 8 KiB
+    } else if (layer == 1) {            // kernel R: one partial per wave; LDS = 4 waves x 2 slab buffers of 8 KiB
         auto k = conv_wgrad_rows_kernel<GeomConv1>;
         const size_t sm = 4 * 2 * 8192;
         wparts = grid * 4;
-        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), sm);
-        if (e == hipSuccess)
-            hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images);
-    } else if (layer == 1 && s_wk == 2) {      // kernel D: one partial per wave; LDS = source image + pixel table (2*(3 + 4*50) + 2 ints)
-        auto k = conv_wgrad_direct_kernel<GeomConv1, 1, 8, true, true, 50, 10, 7, false>;
-        const size_t sm = ((size_t)(g.src_bytes + 15) & ~(size_t)15) + (2 * (3 + 4 * 50) + 2) * sizeof(int);
-        wparts = grid * 4;
-        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), sm);
-        if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, (int)images);
-    } else if (layer == 1) {
-        auto k = conv_wgrad_kernel<1, 2, true, 7, 13, false, 2>;
-        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
-        if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
-    } else if (s_wt && layer == 2) {    // kernel T: a workgroup walks image PAIRS
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), sm);
+        if (e != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute(%zu bytes of LDS): %s", fn, sm, hipGetErrorString(e));
+            return MI355PPO_EHIP;
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images);
+    } else if (layer == 2) {            // kernel T: a workgroup walks image PAIRS
         wparts = grid = wgrad_grid((images + 1) / 2);
         auto k5 = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 5>;
         auto k8 = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 8>;
         auto kp = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 5, true>;
-        hipLaunchKernelGGL(s_wt == 3 ? kp : s_wt == 2 ? k8 : k5, dim3(grid), dim3(256), 0, s, static_cast<const float*>(src), dz, part_w, part_b, (int)images);
-    } else if (s_wt && layer == 3) {
+        hipLaunchKernelGGL(s_wt == 1 ? k5 : s_wt == 2 ? k8 : kp, dim3(grid), dim3(256), 0, s, static_cast<const float*>(src), dz, part_w, part_b, (int)images);
+    } else {
         wparts = grid = wgrad_grid((images + 1) / 2);
         auto k = conv_wgrad_taps_kernel<GeomConv3, 3, 2, 6>;
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, static_cast<const float*>(src), dz, part_w, part_b, (int)images);
-    } else if (layer == 2) {
-        auto k = conv_wgrad_kernel<2, 8, false, 13, 6, false, 2, true>;
-        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
-        if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
-    } else {
-        auto k = conv_wgrad_kernel<2, 9, false, 6, 4, false, 2>;
-        e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), smem);
-        if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, src, inds, dz, part_w, part_b, g);
-    }
-    if (e != hipSuccess) {
-        set_error("%s: hipFuncSetAttribute(%zu bytes of LDS): %s", fn, smem, hipGetErrorString(e));
-        return MI355PPO_EHIP;
     }
     int rc = check_launch("conv_wgrad_kernel");
     if (rc) return rc;

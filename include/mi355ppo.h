@@ -271,10 +271,10 @@ MI355PPO_API int mi355ppo_cnn_conv1q_fwd(const void* src_u8, const int64_t* inds
  * correctly rounded.  layers 2,3: src is f32, inds must be NULL. */
 MI355PPO_API int mi355ppo_cnn_conv_fwd_f32(const void* src, const int64_t* inds, const float* Bt, const float* bias,
                                            float* dst, int64_t images, int layer, void* stream);
-/* `variant` (tuning/testing): 0 = auto (= 2), 1 = LDS-tiled kernel (A and B staged per 32-k stage),
- * 2 = fixed-geometry streaming kernel (weights resident in LDS, A fragments fetched straight into a register ring,
+/* `variant` (tuning/testing): 0 = auto (= 2; 4 for tensors beyond 4 GiB),
+ * 2 = fixed-geometry streaming kernel F (weights resident in LDS, A fragments fetched straight into a register ring,
  *     taps as compile-time immediates, buffer loads/stores; tensors must be < 4 GiB), 4 = its run-time-geometry
- *     predecessor; data gradient only: 3 = one launch per stride-parity class (layer 2), 5 = layer 3 split into
+ *     predecessor S; data gradient only: 3 = one launch per stride-parity class (layer 2), 5 = layer 3 split into
  *     its 25 border classes so that no padding zeros are multiplied (needs the mode-3 repack), 6 = layer 2 split
  *     into the 9 border classes of its class grid (needs the mode-5 repack);
  *     forward of layer 1 only: 6 = kernel Q (Bt = the mode-4 pack). */

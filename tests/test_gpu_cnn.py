@@ -56,7 +56,7 @@ def test_repack_layouts(layer, mode):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [2, 4])
 @pytest.mark.parametrize("images", [1, 37, 256, 1100])
 def test_conv1_fwd_u8_gather(images, variant):
     frames = torch.from_numpy(synthetic.atari_frames(images + 5, seed=3))            # (R,4,84,84) uint8
@@ -158,7 +158,7 @@ def test_conv1q_extreme_inputs_and_weights():
     assert torch.equal(got[..., 3].cpu(), torch.relu(b[3]).expand(6, 20, 20))              # the zero channel is exactly its bias
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [2, 4])
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 19, 128, 700, 7000])
 def test_conv_fwd_f32(layer, images, variant):
@@ -175,10 +175,12 @@ def test_conv_fwd_f32(layer, images, variant):
     _close(got, _nhwc(ref), f"conv{layer} fwd")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 19, 128, 700, 7000])
 def test_conv_dgrad_with_relu_mask(layer, images, variant):
+    if variant == 3 and layer != 2:
+        pytest.skip("variant 3 (one launch per stride-parity class) is the layer-2 data gradient")
     if variant == 5 and layer != 3:
         pytest.skip("variant 5 (border classes) is the layer-3 data gradient")
     if variant == 6 and layer != 2:
