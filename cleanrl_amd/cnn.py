@@ -128,6 +128,44 @@ def trunk_fwd(obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3, conv1_variant
     return a3
 
 
+def fc_fwd_relu(a: torch.Tensor, Wp: torch.Tensor, bias: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``relu(a @ Wp.T + bias)`` on the bf16 matrix pipe with exact products (csrc/fcx.hip)."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = Wp.shape[0]
+    _chk(a, torch.float32, "a", (M, K))
+    _chk(Wp, torch.float32, "Wp", (N, K))
+    _chk(bias, torch.float32, "bias", (N,))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _chk(out, torch.float32, "out", (M, N))
+    with _on(a.device):
+        st = lib.mi355ppo_fc_fwd_relu_f32(_ptr(a), _ptr(Wp), _ptr(bias), _ptr(out), M, N, K, _stream(a.device))
+    _lib.check(st, "mi355ppo_fc_fwd_relu_f32")
+    return out
+
+
+def fc_dgrad_mask(dz: torch.Tensor, Wt: torch.Tensor, act_in: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``(dz @ Wt.T) * (act_in > 0)`` with ``Wt = Wp.T`` (N_in, N_out): the FC data gradient with the ReLU backward of the
+    layer below fused into its epilogue."""
+    lib = _lib.load()
+    M, K = dz.shape
+    N = Wt.shape[0]
+    _chk(dz, torch.float32, "dz", (M, K))
+    _chk(Wt, torch.float32, "Wt", (N, K))
+    _chk(act_in, torch.float32, "act_in", (M, N))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dz.device)
+    _chk(out, torch.float32, "out", (M, N))
+    with _on(dz.device):
+        st = lib.mi355ppo_fc_dgrad_mask_f32(_ptr(dz), _ptr(Wt), _ptr(act_in), _ptr(out), M, N, K, _stream(dz.device))
+    _lib.check(st, "mi355ppo_fc_dgrad_mask_f32")
+    return out
+
+
+FCX_MIN_ROWS = 4096          # below this (rollout-sized batches) the 128 x 128 workgroup tiles cannot fill the chip: library GEMM
+
+
 class _Buffers:
     """Activation / gradient buffers reused across calls of one batch size (no allocator traffic in the loop), and the
     repacked weight matrices.  The matrices are re-derived from the parameters on every use unless the owner opts in to
@@ -140,6 +178,8 @@ class _Buffers:
         self.cache_weights = False
         self.weights_version = 0
         self._bt = {}
+        self.last_a3_ptr = None            # data pointer of the a3 the trunk produced last (LinearReLUHwcFn checks its input is it)
+        self.a3_grad_is_masked = False     # set by LinearReLUHwcFn.backward when conv3's ReLU backward rode in the FC data gradient
 
     def fc_weight(self, W: torch.Tensor) -> torch.Tensor:
         """Linear(3136,512) weight with (h,w,c)-ordered input features, cached like the conv matrices."""
@@ -150,6 +190,17 @@ class _Buffers:
         if hit is None or hit[0] != tag:
             hit = (tag, fc_weight_hwc(W.detach()).contiguous())
             self._bt["fc"] = hit
+        return hit[1]
+
+    def fc_weight_t(self, W: torch.Tensor) -> torch.Tensor:
+        """``fc_weight(W).T`` as a dense (3136, 512) matrix (the B operand of the FC data gradient), cached likewise."""
+        if not self.cache_weights:
+            return fc_weight_hwc(W.detach()).t().contiguous()
+        tag = (self.weights_version, W._version, W.data_ptr())
+        hit = self._bt.get("fc_t")
+        if hit is None or hit[0] != tag:
+            hit = (tag, self.fc_weight(W).t().contiguous())
+            self._bt["fc_t"] = hit
         return hit[1]
 
     def weights(self, W: torch.Tensor, layer: int, mode: int) -> torch.Tensor:
@@ -191,6 +242,7 @@ class NatureTrunkFn(torch.autograd.Function):
             conv_fwd(a1, bt2, b2.detach(), 2, None, a2)
             conv_fwd(a2, bt3, b3.detach(), 3, None, a3)
         ctx.obs, ctx.inds, ctx.acts, ctx.bufs = obs_u8, inds, (a1, a2, a3), bufs
+        bufs.last_a3_ptr = a3.data_ptr()
         ctx.save_for_backward(W2, W3)
         return a3
 
@@ -200,7 +252,11 @@ class NatureTrunkFn(torch.autograd.Function):
         a1, a2, a3 = ctx.acts
         m = a3.shape[0]
         dz1, dz2, _ = ctx.bufs.get(m, a3.device, True)
-        dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)        # ReLU backward of the last conv
+        if ctx.bufs.a3_grad_is_masked:          # the FC data-gradient kernel already applied (a3 > 0)
+            ctx.bufs.a3_grad_is_masked = False
+            dz3 = da3.contiguous().view(a3.shape)
+        else:
+            dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)    # ReLU backward of the last conv
         dW3, db3 = conv_wgrad(a2, dz3, 3)
         if a2.numel() * 4 < (1 << 32) - 8192:     # the border-class kernels address tensors with 32-bit buffer offsets
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # no padding zeros
@@ -236,24 +292,41 @@ def fc_weight_hwc(weight: torch.Tensor) -> torch.Tensor:
 
 class LinearReLUHwcFn(torch.autograd.Function):
     """``relu(a @ fc_weight_hwc(W).T + b)`` for the trunk's (h, w, c)-ordered features -- Agent.network[7:9]
-    (Linear(3136, 512) + ReLU, cleanrl/ppo_atari_multigpu.py:144-145).  Plain library GEMMs (hipBLASLt), arranged so
-    that the ReLU rides in the forward GEMM's epilogue and the weight gradient -- a (512 x M)(M x 3136) product whose
-    98 output tiles cannot fill 256 CUs -- is split over M into a batched GEMM plus a small sum."""
+    (Linear(3136, 512) + ReLU, cleanrl/ppo_atari_multigpu.py:144-145).  Minibatch-sized batches: forward and data gradient
+    on kernel X (bf16 pipe, exact products; bias + ReLU / the ReLU backward of conv3 in the epilogues).  The weight gradient
+    -- a (512 x M)(M x 3136) product whose 98 output tiles cannot fill 256 CUs -- stays a library GEMM split over M into a
+    batched GEMM plus a small sum, like every rollout-sized call."""
 
     SPLIT = 16
 
     @staticmethod
     def forward(ctx, a, W, b, bufs=None):
         Wp = bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()).contiguous()
-        h = torch._addmm_activation(b.detach(), a, Wp.t())                     # bias + ReLU fused into the GEMM epilogue
-        ctx.save_for_backward(a, h, Wp)
+        # minibatch-sized batches on the GPU: kernel X (csrc/fcx.hip), bf16 matrix pipe with exact products; bias + ReLU in
+        # its epilogue.  Rollout-sized batches and the host path: the library GEMM with the same fused epilogue.
+        ctx.fcx = bool(a.is_cuda and bufs is not None and a.shape[0] >= FCX_MIN_ROWS and a.shape[1] % 16 == 0 and a.is_contiguous())
+        if ctx.fcx:
+            h = fc_fwd_relu(a, Wp, b.detach().contiguous())
+        else:
+            h = torch._addmm_activation(b.detach(), a, Wp.t())                 # bias + ReLU fused into the GEMM epilogue
+        ctx.bufs = bufs
+        ctx.save_for_backward(a, h, Wp, W)
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        a, h, Wp = ctx.saved_tensors
+        a, h, Wp, W = ctx.saved_tensors
         dz = torch.ops.aten.threshold_backward(dh.contiguous(), h, 0.0)
-        da = dz @ Wp if ctx.needs_input_grad[0] else None
+        da = None
+        if ctx.needs_input_grad[0]:
+            bufs = ctx.bufs
+            if ctx.fcx and bufs.last_a3_ptr == a.data_ptr():
+                # `a` is the trunk's ReLU output a3: its ReLU backward rides in this GEMM's epilogue (kernel X, EPI_MASK) and
+                # NatureTrunkFn.backward is told not to mask again -- the separate pass over the 411 MB tensor is gone
+                da = fc_dgrad_mask(dz, bufs.fc_weight_t(W), a)
+                bufs.a3_grad_is_masked = True
+            else:
+                da = dz @ Wp
         m, n = dz.shape
         s = LinearReLUHwcFn.SPLIT
         if m % s == 0 and m >= 4096:

@@ -1,0 +1,191 @@
+// Kernel X -- Linear(3136, 512) of the NatureCNN (cleanrl/ppo_atari_multigpu.py:144-145) on the bf16 matrix pipe with EXACT
+// products: C[m][n] = sum_k A[m][k] * B[n][k], f32 operands, both K-contiguous.
+//
+// An f32 number is the exact sum of three bf16 terms (hi = its top 8 significand bits, mid = the next 8, lo = the last 8),
+// so a[m][k] * b[n][k] = sum over the 3 x 3 term pairs of products that are each exact in f32 (8 x 8 significand bits).
+// Nine `v_mfma_f32_32x32x16_bf16` (f32 accumulation) therefore compute what eight `v_mfma_f32_32x32x2_f32` compute --
+// exact products, f32 accumulation -- in 9 x 32 instead of 8 x 64 matrix-pipe cycles per 16 k.  No reduced precision.
+//
+// No LDS: both operands are already in MFMA operand layout as they lie in memory (a lane = one row, 8 consecutive k = 32
+// contiguous bytes = two 16-byte loads), the scheme of kernel F's A operand.  A wave owns a 64 x 64 block of C (2 x 2
+// tiles), a workgroup 128 x 128 (its waves share rows of A / B through L1); per 16 k a wave loads 4 fragments, splits them
+// in registers (4 VALU + 1.5 v_perm per value) and issues 36 MFMAs, the next 16 k already in flight.
+//
+// Epilogues: EPI_BIAS_RELU (forward: h = relu(a @ Wp^T + b)) and EPI_MASK (data gradient: da = (dz @ Wp) * (a > 0) -- the
+// ReLU backward of the layer BELOW, conv3, applied where the gradient is produced, as the conv data-gradient kernels do;
+// the reference runs it as a separate pass over the 411 MB tensor).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace mi355ppo {
+
+typedef float x_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int x_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 x_bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { X_BIAS_RELU = 0, X_MASK = 1 };
+
+struct XTerms {
+    x_bf16x8 t[3];       // hi, mid, lo of 8 consecutive k
+};
+
+__device__ __forceinline__ unsigned x_pack(float e1, float e0) {
+    return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
+}
+
+// 8 f32 (two 16-byte loads) -> three packed bf16x8 whose element-wise sum is the input, exactly
+__device__ __forceinline__ XTerms x_split(const x_u32x4& lo4, const x_u32x4& hi4) {
+    float x[8] = {__uint_as_float(lo4.x), __uint_as_float(lo4.y), __uint_as_float(lo4.z), __uint_as_float(lo4.w),
+                  __uint_as_float(hi4.x), __uint_as_float(hi4.y), __uint_as_float(hi4.z), __uint_as_float(hi4.w)};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const float x0 = x[j], x1 = x[j + 1];
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        const float l0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), l1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        h[j >> 1] = x_pack(x1, x0);
+        m[j >> 1] = x_pack(r1, r0);
+        l[j >> 1] = x_pack(l1, l0);
+    }
+    XTerms o;
+    o.t[0] = __builtin_bit_cast(x_bf16x8, (x_u32x4){h[0], h[1], h[2], h[3]});
+    o.t[1] = __builtin_bit_cast(x_bf16x8, (x_u32x4){m[0], m[1], m[2], m[3]});
+    o.t[2] = __builtin_bit_cast(x_bf16x8, (x_u32x4){l[0], l[1], l[2], l[3]});
+    return o;
+}
+
+// A (M, K) row-major with leading dimension lda, B (N, K) with ldb, C (M, N) with ldc; K % 16 == 0.
+// bias (N) for X_BIAS_RELU; cmask (M, N) with ldc for X_MASK.
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fcx_gemm_nt_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
+    const float* __restrict__ cmask, float* __restrict__ C, int ldc, int M, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * 128 + (wave >> 1) * 64, n0 = blockIdx.x * 128 + (wave & 1) * 64;
+    if (m0 >= M || n0 >= N) return;                       // (whole wave; no barriers in this kernel)
+    // row pointers of this lane's four fragments (rows past the edge re-read the last row: results dropped at the store)
+    const float* pa[2];
+    const float* pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = m0 + 32 * i + li, rb = n0 + 32 * i + li;
+        pa[i] = A + (size_t)(ra < M ? ra : M - 1) * lda + 8 * lh;
+        pb[i] = B + (size_t)(rb < N ? rb : N - 1) * ldb + 8 * lh;
+    }
+    x_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    x_u32x4 raw[2][4][2];                                 // [stage][fragment: A0 A1 B0 B1][16-byte half]
+    auto fetch = [&](int st, int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            raw[st][i][0] = *reinterpret_cast<const x_u32x4*>(pa[i] + k0);
+            raw[st][i][1] = *reinterpret_cast<const x_u32x4*>(pa[i] + k0 + 4);
+            raw[st][2 + i][0] = *reinterpret_cast<const x_u32x4*>(pb[i] + k0);
+            raw[st][2 + i][1] = *reinterpret_cast<const x_u32x4*>(pb[i] + k0 + 4);
+        }
+    };
+    auto multiply = [&](int st) {
+        XTerms f[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = x_split(raw[st][q][0], raw[st][q][1]);
+        // term pairs outermost, the four independent tiles innermost: no MFMA waits for the one before it
+#pragma unroll
+        for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i].t[ta], f[2 + j].t[tb], acc[i][j], 0, 0, 0);
+    };
+    fetch(0, 0);
+    int k0 = 0;
+    for (; k0 + 32 <= K; k0 += 32) {                      // two stages per trip: the stage index stays a compile-time constant
+        fetch(1, k0 + 16);
+        __builtin_amdgcn_sched_barrier(0);                // the loads stay AHEAD of the 36 MFMAs they overlap with
+        multiply(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, k0 + 32 < K ? k0 + 32 : k0);             // (past the end: re-read, never multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (k0 < K) multiply(0);                              // K / 16 odd: the last stage is already in raw[0]
+
+    // ---- epilogue: accumulator element e of tile (i, j) is C[m0 + 32 i + (e & 3) + 8 (e >> 2) + 4 lh][n0 + 32 j + li]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 32 * j + li;
+        const bool nok = n < N;
+        const float bj = (EPI == X_BIAS_RELU && nok) ? bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (EPI == X_MASK) {
+                float mk[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    mk[e] = (nok && m < M) ? cmask[(size_t)m * ldc + n] : 0.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (nok && m < M) C[(size_t)m * ldc + n] = mk[e] > 0.0f ? acc[i][j][e] : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    float v = acc[i][j][e] + bj;
+                    v = v > 0.0f ? v : 0.0f;
+                    if (nok && m < M) C[(size_t)m * ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mi355ppo
+
+using namespace mi355ppo;
+
+static int fcx_check(const char* fn, const float* A, const float* B, const float* C, int M, int N, int K, int lda, int ldb, int ldc) {
+    MI355_REQUIRE(A && B && C, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, MI355PPO_EINVAL, "%s: M=%d N=%d K=%d (K must be a positive multiple of 16)", fn, M, N, K);
+    MI355_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 4 == 0 && ldb % 4 == 0, MI355PPO_EINVAL,
+                  "%s: leading dimensions lda=%d ldb=%d ldc=%d (lda, ldb: multiples of 4, >= K; ldc >= N)", fn, lda, ldb, ldc);
+    MI355_REQUIRE(aligned(A, 16) && aligned(B, 16) && aligned(C, 4), MI355PPO_EALIGN, "%s: A and B must be 16-byte aligned", fn);
+    MI355_REQUIRE((M + 127) / 128 <= 65535, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
+    return MI355PPO_OK;
+}
+
+extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float* W, const float* bias, float* h, int M, int N, int K,
+                                                     void* stream) {
+    const char* fn = "mi355ppo_fc_fwd_relu_f32";
+    int rc = fcx_check(fn, a, W, h, M, N, K, K, K, N);
+    if (rc) return rc;
+    MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
+    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 0, as_stream(stream), a, K, W, K,
+                       bias, (const float*)nullptr, h, N, M, N, K);
+    return check_launch(fn);
+}
+
+extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, const float* Wt, const float* act_in, float* da, int M, int N,
+                                                       int K, void* stream) {
+    const char* fn = "mi355ppo_fc_dgrad_mask_f32";
+    int rc = fcx_check(fn, dz, Wt, da, M, N, K, K, K, N);
+    if (rc) return rc;
+    MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
+    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 0, as_stream(stream), dz, K, Wt, K,
+                       (const float*)nullptr, act_in, da, N, M, N, K);
+    return check_launch(fn);
+}

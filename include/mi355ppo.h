@@ -230,6 +230,20 @@ MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_
                            float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * FC   Linear(3136, 512) + ReLU of the NatureCNN (cleanrl/ppo_atari_multigpu.py:144-145) on the bf16 matrix pipe with
+ * exact products (csrc/fcx.hip): every f32 operand is split in registers into three bf16 terms that sum to it exactly,
+ * so the 3 x 3 term products are exact in f32 and nine bf16 MFMAs (f32 accumulate) do the work of eight f32 MFMAs in
+ * 56 % of their matrix-pipe time.  Same arithmetic class as an f32-MFMA GEMM (exact products, f32 accumulation).
+ *   fwd  : h (M,N) = relu(a (M,K) @ W (N,K)^T + bias (N))                      K % 16 == 0
+ *   dgrad: da (M,N) = (dz (M,K) @ Wt (N,K)^T) * (act_in (M,N) > 0)   with Wt = W^T: the ReLU backward of the layer that
+ *          produced act_in (conv3) is applied where the gradient is produced.
+ * All matrices row-major and dense; a / dz / W / Wt 16-byte aligned. */
+MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float* W, const float* bias, float* h, int M, int N, int K,
+                                          void* stream);
+MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, const float* Wt, const float* act_in, float* da, int M, int N, int K,
+                                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * CNN  NatureCNN convolution stack (Agent.network convs, cleanrl/ppo_atari_multigpu.py:136-142) as
  * f32-MFMA implicit GEMMs on channels-last tensors: forward with fused uint8 gather + /255 + bias +
  * ReLU, data gradient with the ReLU-backward mask fused, weight + bias gradient.  f32 in, f32
