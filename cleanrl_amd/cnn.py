@@ -145,20 +145,37 @@ def fc_fwd_relu(a: torch.Tensor, Wp: torch.Tensor, bias: torch.Tensor, out: torc
     return out
 
 
+FC_PAD = 4          # extra floats per row of the K = 512 operands of the FC data gradient: a dense 2 KiB pitch puts the 32 rows of
+                    # a fragment load on one cache channel (measured: 1.47 ms against 0.70 ms for the forward of the same size)
+
+
+def _row_major(t: torch.Tensor, name: str):
+    """(rows, cols) f32 device tensor with unit column stride and a row pitch that is a multiple of 4 floats -> its pitch."""
+    if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 4 or t.stride(0) < t.shape[1]:
+        raise ValueError(f"{name}: expected a row-major f32 device matrix with a 16-byte-multiple row pitch, got shape "
+                         f"{tuple(t.shape)} strides {t.stride()} {t.dtype} on {t.device}")
+    return t.stride(0)
+
+
+def padded_rows(rows: int, cols: int, device, pad: int = FC_PAD) -> torch.Tensor:
+    """A (rows, cols) view with row pitch cols + pad."""
+    return torch.empty((rows, cols + pad), dtype=torch.float32, device=device)[:, :cols]
+
+
 def fc_dgrad_mask(dz: torch.Tensor, Wt: torch.Tensor, act_in: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """``(dz @ Wt.T) * (act_in > 0)`` with ``Wt = Wp.T`` (N_in, N_out): the FC data gradient with the ReLU backward of the
-    layer below fused into its epilogue."""
+    layer below fused into its epilogue.  ``dz`` and ``Wt`` may carry a padded row pitch (``padded_rows``)."""
     lib = _lib.load()
     M, K = dz.shape
     N = Wt.shape[0]
-    _chk(dz, torch.float32, "dz", (M, K))
-    _chk(Wt, torch.float32, "Wt", (N, K))
+    assert Wt.shape[1] == K
+    lddz, ldwt = _row_major(dz, "dz"), _row_major(Wt, "Wt")
     _chk(act_in, torch.float32, "act_in", (M, N))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dz.device)
     _chk(out, torch.float32, "out", (M, N))
     with _on(dz.device):
-        st = lib.mi355ppo_fc_dgrad_mask_f32(_ptr(dz), _ptr(Wt), _ptr(act_in), _ptr(out), M, N, K, _stream(dz.device))
+        st = lib.mi355ppo_fc_dgrad_mask_f32(_ptr(dz), lddz, _ptr(Wt), ldwt, _ptr(act_in), _ptr(out), M, N, K, _stream(dz.device))
     _lib.check(st, "mi355ppo_fc_dgrad_mask_f32")
     return out
 
@@ -192,14 +209,27 @@ class _Buffers:
             self._bt["fc"] = hit
         return hit[1]
 
+    def fc_dz(self, m: int, n: int, dev) -> torch.Tensor:
+        """Reusable (m, n) buffer with a padded row pitch for the FC layer's pre-activation gradient."""
+        key = ("fc_dz", m, n, dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+        b = self.by_m.get(key)
+        if b is None:
+            b = padded_rows(m, n, dev)
+            self.by_m[key] = b
+        return b
+
     def fc_weight_t(self, W: torch.Tensor) -> torch.Tensor:
         """``fc_weight(W).T`` as a dense (3136, 512) matrix (the B operand of the FC data gradient), cached likewise."""
         if not self.cache_weights:
-            return fc_weight_hwc(W.detach()).t().contiguous()
+            wt = padded_rows(W.shape[1], W.shape[0], W.device)
+            wt.copy_(fc_weight_hwc(W.detach()).t())
+            return wt
         tag = (self.weights_version, W._version, W.data_ptr())
         hit = self._bt.get("fc_t")
         if hit is None or hit[0] != tag:
-            hit = (tag, self.fc_weight(W).t().contiguous())
+            wt = hit[1] if hit is not None else padded_rows(W.shape[1], W.shape[0], W.device)     # (3136, 512), pitch 516
+            wt.copy_(self.fc_weight(W).t())
+            hit = (tag, wt)
             self._bt["fc_t"] = hit
         return hit[1]
 
@@ -316,11 +346,16 @@ class LinearReLUHwcFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh):
         a, h, Wp, W = ctx.saved_tensors
-        dz = torch.ops.aten.threshold_backward(dh.contiguous(), h, 0.0)
+        bufs = ctx.bufs
+        fused = bool(ctx.fcx and ctx.needs_input_grad[0] and bufs.last_a3_ptr == a.data_ptr())
+        if fused:                                   # dz with a padded row pitch (kernel X's A operand at K = 512, see FC_PAD)
+            dz = bufs.fc_dz(dh.shape[0], dh.shape[1], dh.device)
+            torch.mul(dh, h > 0, out=dz)
+        else:
+            dz = torch.ops.aten.threshold_backward(dh.contiguous(), h, 0.0)
         da = None
         if ctx.needs_input_grad[0]:
-            bufs = ctx.bufs
-            if ctx.fcx and bufs.last_a3_ptr == a.data_ptr():
+            if fused:
                 # `a` is the trunk's ReLU output a3: its ReLU backward rides in this GEMM's epilogue (kernel X, EPI_MASK) and
                 # NatureTrunkFn.backward is told not to mask again -- the separate pass over the 411 MB tensor is gone
                 da = fc_dgrad_mask(dz, bufs.fc_weight_t(W), a)
@@ -330,7 +365,8 @@ class LinearReLUHwcFn(torch.autograd.Function):
         m, n = dz.shape
         s = LinearReLUHwcFn.SPLIT
         if m % s == 0 and m >= 4096:
-            dWp = torch.bmm(dz.view(s, m // s, n).transpose(1, 2), a.view(s, m // s, a.shape[1])).sum(0)
+            dz3 = dz.as_strided((s, m // s, n), (dz.stride(0) * (m // s), dz.stride(0), 1))      # == dz.view(s, m // s, n) for a dense dz
+            dWp = torch.bmm(dz3.transpose(1, 2), a.view(s, m // s, a.shape[1])).sum(0)
         else:
             dWp = dz.t() @ a
         dW = dWp.view(n, 7, 7, 64).permute(0, 3, 1, 2).reshape(n, 64 * 7 * 7)     # back to the (c, h, w) feature order

@@ -7,14 +7,14 @@
 // exact products, f32 accumulation -- in 9 x 32 instead of 8 x 64 matrix-pipe cycles per 16 k.  No reduced precision.
 //
 // No LDS: both operands are already in MFMA operand layout as they lie in memory (a lane = one row, 8 consecutive k = 32
-// contiguous bytes = two 16-byte loads), the scheme of kernel F's A operand.  A wave owns a 64 x 64 block of C (2 x 2
-// tiles), a workgroup 128 x 128 (its waves share rows of A / B through L1); per 16 k a wave loads 4 fragments, splits them
-// in registers (4 VALU + 1.5 v_perm per value) and issues 36 MFMAs, the next 16 k already in flight.
+// contiguous bytes = two 16-byte loads), the scheme of kernel F's A operand; the fragments are split in registers
+// (4 VALU + 1.5 v_perm per value).  Tiling and pipeline: see the kernel.
 //
 // Epilogues: EPI_BIAS_RELU (forward: h = relu(a @ Wp^T + b)) and EPI_MASK (data gradient: da = (dz @ Wp) * (a > 0) -- the
 // ReLU backward of the layer BELOW, conv3, applied where the gradient is produced, as the conv data-gradient kernels do;
 // the reference runs it as a separate pass over the 411 MB tensor).
 #include "common.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -57,100 +57,143 @@ __device__ __forceinline__ XTerms x_split(const x_u32x4& lo4, const x_u32x4& hi4
 
 // A (M, K) row-major with leading dimension lda, B (N, K) with ldb, C (M, N) with ldc; K % 16 == 0.
 // bias (N) for X_BIAS_RELU; cmask (M, N) with ldc for X_MASK.
+// One wave per SIMD (512 registers): a wave owns 64 x 128 of C (2 x 4 tiles, 128 accumulator registers); the four waves of a
+// workgroup sit on top of each other (256 x 128) and share the B rows through L1.  Per 16 k: 6 fragments (12 loads), 264 VALU
+// for the splits, 72 MFMAs.  The loop is software-pipelined by hand -- loads two stages ahead, the split of stage s+1 issued
+// BETWEEN the MFMAs of stage s (one MFMA : four VALU, `sched_group_barrier`), because a wave that first splits and then
+// multiplies leaves the matrix pipe idle during the split (measured: 50 % of the pipe at two such waves per SIMD).
+constexpr int kXMT = 2, kXNT = 4, kXF = kXMT + kXNT;
+
 template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fcx_gemm_nt_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fcx_gemm_nt_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
     const float* __restrict__ cmask, float* __restrict__ C, int ldc, int M, int N, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * 128 + (wave >> 1) * 64, n0 = blockIdx.x * 128 + (wave & 1) * 64;
-    if (m0 >= M || n0 >= N) return;                       // (whole wave; no barriers in this kernel)
-    // row pointers of this lane's four fragments (rows past the edge re-read the last row: results dropped at the store)
-    const float* pa[2];
-    const float* pb[2];
+    const int m0 = blockIdx.y * 256 + wave * 64, n0 = blockIdx.x * 128;
+    if (m0 >= M) return;                                  // (whole wave; no barriers in this kernel)
+    // row pointers of this lane's six fragments (rows past the edge re-read the last row: results dropped at the store)
+    const float* pf[kXF];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = m0 + 32 * i + li, rb = n0 + 32 * i + li;
-        pa[i] = A + (size_t)(ra < M ? ra : M - 1) * lda + 8 * lh;
-        pb[i] = B + (size_t)(rb < N ? rb : N - 1) * ldb + 8 * lh;
+    for (int i = 0; i < kXMT; ++i) {
+        const int r = m0 + 32 * i + li;
+        pf[i] = A + (size_t)(r < M ? r : M - 1) * lda + 8 * lh;
     }
-    x_f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < kXNT; ++j) {
+        const int r = n0 + 32 * j + li;
+        pf[kXMT + j] = B + (size_t)(r < N ? r : N - 1) * ldb + 8 * lh;
+    }
+    x_f32x16 acc[kXMT][kXNT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < kXMT; ++i)
+#pragma unroll
+        for (int j = 0; j < kXNT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    x_u32x4 raw[2][4][2];                                 // [stage][fragment: A0 A1 B0 B1][16-byte half]
+    x_u32x4 raw[2][kXF][2];                               // [stage parity][fragment][16-byte half]
+    XTerms pc[2][kXF];                                    // split fragments of stage s live in pc[s & 1]
     auto fetch = [&](int st, int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            raw[st][i][0] = *reinterpret_cast<const x_u32x4*>(pa[i] + k0);
-            raw[st][i][1] = *reinterpret_cast<const x_u32x4*>(pa[i] + k0 + 4);
-            raw[st][2 + i][0] = *reinterpret_cast<const x_u32x4*>(pb[i] + k0);
-            raw[st][2 + i][1] = *reinterpret_cast<const x_u32x4*>(pb[i] + k0 + 4);
+        for (int q = 0; q < kXF; ++q) {
+            raw[st][q][0] = *reinterpret_cast<const x_u32x4*>(pf[q] + k0);
+            raw[st][q][1] = *reinterpret_cast<const x_u32x4*>(pf[q] + k0 + 4);
         }
     };
-    auto multiply = [&](int st) {
-        XTerms f[4];
+    const int nsteps = K >> 4;
+    auto kof = [&](int s) { return (s < nsteps ? s : nsteps - 1) << 4; };       // past the end: re-read, never multiplied
+    // one pipeline step for a stage of parity q: MFMAs of pc[q] (stage s), split raw[q ^ 1] (stage s+1) into pc[q ^ 1], fetch
+    // stage s+2 into raw[q] (free: its stage was split one step ago).  Fixed parity = compile-time register indices.
+    auto step = [&](auto qc, int s) {
+        constexpr int q = decltype(qc)::value;
+        fetch(q, kof(s + 2));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) f[q] = x_split(raw[st][q][0], raw[st][q][1]);
-        // term pairs outermost, the four independent tiles innermost: no MFMA waits for the one before it
+        for (int f = 0; f < kXF; ++f) pc[q ^ 1][f] = x_split(raw[q ^ 1][f][0], raw[q ^ 1][f][1]);
+        // term pairs outermost, the eight independent tiles innermost: no MFMA waits for the one before it
 #pragma unroll
         for (int ta = 0; ta < 3; ++ta)
 #pragma unroll
             for (int tb = 0; tb < 3; ++tb)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < kXMT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i].t[ta], f[2 + j].t[tb], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < kXNT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pc[q][i].t[ta], pc[q][kXMT + j].t[tb], acc[i][j], 0, 0, 0);
+        // issue order: the 12 loads first, then 72 x (1 MFMA, 4 VALU)
+        __builtin_amdgcn_sched_group_barrier(0x020, 2 * kXF, 0);
+#pragma unroll
+        for (int g = 0; g < 9 * kXMT * kXNT; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
+    // prologue: stage 0 split into pc[0], stage 1 raw in flight in raw[1]
     fetch(0, 0);
-    int k0 = 0;
-    for (; k0 + 32 <= K; k0 += 32) {                      // two stages per trip: the stage index stays a compile-time constant
-        fetch(1, k0 + 16);
-        __builtin_amdgcn_sched_barrier(0);                // the loads stay AHEAD of the 36 MFMAs they overlap with
-        multiply(0);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(0, k0 + 32 < K ? k0 + 32 : k0);             // (past the end: re-read, never multiplied)
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(1);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < kXF; ++f) pc[0][f] = x_split(raw[0][f][0], raw[0][f][1]);
+    fetch(1, kof(1));
+    __builtin_amdgcn_sched_barrier(0);
+    int s = 0;
+    for (; s + 2 <= nsteps; s += 2) {
+        step(std::integral_constant<int, 0>{}, s);
+        step(std::integral_constant<int, 1>{}, s + 1);
     }
-    if (k0 < K) multiply(0);                              // K / 16 odd: the last stage is already in raw[0]
+    if (s < nsteps) step(std::integral_constant<int, 0>{}, s);
 
-    // ---- epilogue: accumulator element e of tile (i, j) is C[m0 + 32 i + (e & 3) + 8 (e >> 2) + 4 lh][n0 + 32 j + li]
+    // ---- epilogue: accumulator element e of tile (i, j) is C[m0 + 32 i + (e & 3) + 8 (e >> 2) + 4 lh][n0 + 32 j + li].
+    // Offsets are row * ldc + n with the row part shared by the four column tiles.  X_MASK: ALL 128 mask values of the
+    // wave's block are requested before the first one is used (one wave per SIMD: nothing else hides a load's latency;
+    // fetched tile by tile the epilogue cost 8 dependent round trips per 35 us of MFMAs).
+    const bool wave_rows_ok = m0 + 64 <= M;
+    if (EPI == X_MASK) {
+        float mk[kXMT][kXNT][16];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + 32 * j + li;
-        const bool nok = n < N;
-        const float bj = (EPI == X_BIAS_RELU && nok) ? bias[n] : 0.0f;
+        for (int i = 0; i < kXMT; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (EPI == X_MASK) {
-                float mk[16];
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float* row = cmask + (size_t)(m < M ? m : M - 1) * ldc;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    mk[e] = (nok && m < M) ? cmask[(size_t)m * ldc + n] : 0.0f;
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (nok && m < M) C[(size_t)m * ldc + n] = mk[e] > 0.0f ? acc[i][j][e] : 0.0f;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    float v = acc[i][j][e] + bj;
-                    v = v > 0.0f ? v : 0.0f;
-                    if (nok && m < M) C[(size_t)m * ldc + n] = v;
+                for (int j = 0; j < kXNT; ++j) {
+                    const int n = n0 + 32 * j + li;
+                    mk[i][j][e] = row[n < N ? n : N - 1];
                 }
             }
+#pragma unroll
+        for (int i = 0; i < kXMT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float* row = C + (size_t)m * ldc;
+#pragma unroll
+                for (int j = 0; j < kXNT; ++j) {
+                    const int n = n0 + 32 * j + li;
+                    if ((wave_rows_ok || m < M) && n < N) row[n] = mk[i][j][e] > 0.0f ? acc[i][j][e] : 0.0f;
+                }
+            }
+    } else {
+        float bj[kXNT];
+#pragma unroll
+        for (int j = 0; j < kXNT; ++j) {
+            const int n = n0 + 32 * j + li;
+            bj[j] = bias[n < N ? n : N - 1];
         }
+#pragma unroll
+        for (int i = 0; i < kXMT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float* row = C + (size_t)m * ldc;
+#pragma unroll
+                for (int j = 0; j < kXNT; ++j) {
+                    const int n = n0 + 32 * j + li;
+                    float v = acc[i][j][e] + bj[j];
+                    v = v > 0.0f ? v : 0.0f;
+                    if ((wave_rows_ok || m < M) && n < N) row[n] = v;
+                }
+            }
     }
 }
 
@@ -164,7 +207,7 @@ static int fcx_check(const char* fn, const float* A, const float* B, const float
     MI355_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 4 == 0 && ldb % 4 == 0, MI355PPO_EINVAL,
                   "%s: leading dimensions lda=%d ldb=%d ldc=%d (lda, ldb: multiples of 4, >= K; ldc >= N)", fn, lda, ldb, ldc);
     MI355_REQUIRE(aligned(A, 16) && aligned(B, 16) && aligned(C, 4), MI355PPO_EALIGN, "%s: A and B must be 16-byte aligned", fn);
-    MI355_REQUIRE((M + 127) / 128 <= 65535, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
+    MI355_REQUIRE((M + 255) / 256 <= 65535, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
     return MI355PPO_OK;
 }
 
@@ -174,18 +217,18 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float
     int rc = fcx_check(fn, a, W, h, M, N, K, K, K, N);
     if (rc) return rc;
     MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
-    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 0, as_stream(stream), a, K, W, K,
+    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), a, K, W, K,
                        bias, (const float*)nullptr, h, N, M, N, K);
     return check_launch(fn);
 }
 
-extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, const float* Wt, const float* act_in, float* da, int M, int N,
-                                                       int K, void* stream) {
+extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, int lddz, const float* Wt, int ldwt, const float* act_in,
+                                                       float* da, int M, int N, int K, void* stream) {
     const char* fn = "mi355ppo_fc_dgrad_mask_f32";
-    int rc = fcx_check(fn, dz, Wt, da, M, N, K, K, K, N);
+    int rc = fcx_check(fn, dz, Wt, da, M, N, K, lddz, ldwt, N);
     if (rc) return rc;
     MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
-    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 0, as_stream(stream), dz, K, Wt, K,
-                       (const float*)nullptr, act_in, da, N, M, N, K);
+    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), dz, lddz, Wt,
+                       ldwt, (const float*)nullptr, act_in, da, N, M, N, K);
     return check_launch(fn);
 }

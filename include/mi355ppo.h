@@ -236,12 +236,14 @@ MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_
  * 56 % of their matrix-pipe time.  Same arithmetic class as an f32-MFMA GEMM (exact products, f32 accumulation).
  *   fwd  : h (M,N) = relu(a (M,K) @ W (N,K)^T + bias (N))                      K % 16 == 0
  *   dgrad: da (M,N) = (dz (M,K) @ Wt (N,K)^T) * (act_in (M,N) > 0)   with Wt = W^T: the ReLU backward of the layer that
- *          produced act_in (conv3) is applied where the gradient is produced.
- * All matrices row-major and dense; a / dz / W / Wt 16-byte aligned. */
+ *          produced act_in (conv3) is applied where the gradient is produced.  dz and Wt take leading dimensions
+ *          (floats, multiples of 4): with K = 512 a dense row pitch is 2 KiB and the 32 rows of a fragment load would all
+ *          fall on one cache channel -- callers pad the pitch (516).
+ * All matrices row-major; a / h / da / act_in dense; a / dz / W / Wt 16-byte aligned. */
 MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float* W, const float* bias, float* h, int M, int N, int K,
                                           void* stream);
-MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, const float* Wt, const float* act_in, float* da, int M, int N, int K,
-                                            void* stream);
+MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, int lddz, const float* Wt, int ldwt, const float* act_in, float* da,
+                                            int M, int N, int K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CNN  NatureCNN convolution stack (Agent.network convs, cleanrl/ppo_atari_multigpu.py:136-142) as
