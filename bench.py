@@ -103,6 +103,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-envs", type=int, default=128)
     p.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets (pure SPS run)")
+    p.add_argument("--no-rollout-graphs", action="store_true", help="issue the rollout kernel by kernel instead of one hipGraph per step")
     p.add_argument("--no-pcie-inclusive", action="store_true", help="skip the host-env (PCIe-inclusive) leg after the timed region")
     p.add_argument("--pcie-env-groups", type=int, default=2)
     return p.parse_args()
@@ -190,6 +191,9 @@ def main():
     torch.manual_seed(seed)
     learner = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, device, world_size=world,
                          sample_seed=seed)
+    learner.observe(0, env.obs_into(learner.stage_obs), learner.dones[0])
+    if learner.fused_cnn and not cli.no_rollout_graphs:
+        learner.capture_rollout(env)        # one hipGraph per rollout step (before the timing hooks: no event records in a capture)
     timer = KernelTimer()
     conv_flops = {}
     unhook = []          # (module, name, original) of everything the kernel timing wraps
@@ -243,7 +247,6 @@ def main():
         ops.obs_u8_to_f32 = obs_hook
         ops.gae = timer.wrap("gae", real_gae)
         ops.ppo_loss_categorical = timer.wrap("loss", real_loss)
-    learner.observe(0, env.obs_into(learner.stage_obs), learner.dones[0])
     total_iters = cli.warmup + cli.steps
 
     phase_events = []
@@ -303,6 +306,8 @@ def main():
                 "local_num_envs": N, "num_steps": T, "global_num_envs": world * N, "minibatch_rows": M,
                 "parallelism": f"dp{world} (one learner per GPU, RCCL all-reduce of the flat f32 gradient)",
                 "env": "device-resident synthetic generator (no PCIe in the timed region)",
+                "rollout": "one hipGraph per env step (policy forward, sampling, env step, observation store)"
+                           if getattr(learner, "_rollout_graphs", None) else "kernel-by-kernel launches",
                 "cnn": "f32-MFMA implicit-GEMM kernels (csrc/conv.hip); layer-1 forward on the int8 MFMA with exact int32 "
                        "accumulation over 31-bit fixed-point weights (csrc/conv1q.hip): error vs float64 <= the f32 kernel's"
                        if learner.fused_cnn else "torch Conv2d (MIOpen)",
@@ -315,7 +320,8 @@ def main():
                             "note": "GPU-timeline split of ms_per_step (events on the learner's stream)"}
         if not cli.no_kernel_timing and learner.fused_cnn:
             # dominant kernel of the path = the conv launch with the largest total time inside the timed region
-            tot = {k: timer.mean_us(k)[0] * timer.mean_us(k)[1] * (16 if k.endswith(f"@{N}") else 1) for k in conv_flops}
+            tot = {k: timer.mean_us(k)[0] * timer.mean_us(k)[1] * (16 if k.endswith(f"@{N}") else 1) for k in conv_flops
+                   if timer.mean_us(k)[1] > 0}          # (rollout-sized launches inside captured graphs carry no event brackets)
             dom = max(tot, key=tot.get)
             us, n = timer.mean_us(dom)
             tf = conv_flops[dom] / us / 1e6
@@ -353,7 +359,7 @@ def main():
                                  "GBps": loss_bytes / lus / 1e3, "launches_timed": ln,
                                  "note": "one launch per minibatch (advantage statistics once per epoch, scalar fold once per update)"},
             }
-            for k in sorted(conv_flops):
+            for k in sorted(tot):
                 kus, kn = timer.mean_us(k)
                 launches = kn * (16 if k.endswith(f"@{N}") else 1)          # rollout-sized launches are sampled 1 in 16
                 out["kernels"][k] = {"avg_us": kus, "launches_timed": kn, "TFLOPs": conv_flops[k] / kus / 1e6,

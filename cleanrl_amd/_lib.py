@@ -21,6 +21,7 @@ SIGNATURES = {
     "mi355ppo_gae_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P]),
     "mi355ppo_gae_f32_variant": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_int, _P]),
     "mi355ppo_categorical_sample_f32": (c_int, [_P, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_int, _P]),
+    "mi355ppo_categorical_sample_ctr_f32": (c_int, [_P, _P, c_uint64, c_uint64, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "mi355ppo_categorical_logprob_entropy_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "mi355ppo_categorical_logprob_entropy_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "mi355ppo_normal_logprob_entropy_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "mi355ppo_fc_fwd_relu_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_fc_dgrad_mask_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_synth_atari_step_u8": (c_int, [_P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, c_int, c_double, c_int, _P]),
+    "mi355ppo_synth_atari_step_ctr_u8": (c_int, [_P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_double, c_int, _P]),
     "mi355ppo_heads_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_heads_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mi355ppo_heads_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),

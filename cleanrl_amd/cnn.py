@@ -199,13 +199,18 @@ class _Buffers:
         self.a3_grad_is_masked = False     # set by LinearReLUHwcFn.backward when conv3's ReLU backward rode in the FC data gradient
 
     def fc_weight(self, W: torch.Tensor) -> torch.Tensor:
-        """Linear(3136,512) weight with (h,w,c)-ordered input features, cached like the conv matrices."""
+        """Linear(3136,512) weight with (h,w,c)-ordered input features, cached like the conv matrices (re-derived INTO the
+        same buffer: captured rollout steps keep reading one address)."""
         if not self.cache_weights:
             return fc_weight_hwc(W.detach()).contiguous()
         tag = (self.weights_version, W._version, W.data_ptr())
         hit = self._bt.get("fc")
         if hit is None or hit[0] != tag:
-            hit = (tag, fc_weight_hwc(W.detach()).contiguous())
+            if hit is None:
+                hit = (tag, fc_weight_hwc(W.detach()).contiguous())
+            else:
+                hit[1].copy_(fc_weight_hwc(W.detach()))
+                hit = (tag, hit[1])
             self._bt["fc"] = hit
         return hit[1]
 

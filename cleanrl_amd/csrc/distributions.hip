@@ -19,7 +19,8 @@ namespace mi355ppo {
 template <int AMAX>
 __global__ __launch_bounds__(256) void categorical_sample_kernel(const float* __restrict__ logits,
                                                                  const float* __restrict__ noise, uint64_t seed,
-                                                                 uint64_t offset, int64_t* __restrict__ action_i64,
+                                                                 uint64_t offset, const uint64_t* __restrict__ offset_base,
+                                                                 int64_t* __restrict__ action_i64,
                                                                  float* __restrict__ action_f32,
                                                                  float* __restrict__ logprob,
                                                                  float* __restrict__ entropy, int B, int A) {
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void categorical_sample_kernel(const float* __
     } else {
         const Philox rng(seed);
         const int nblk = (A + 3) / 4;
+        if (offset_base) offset += *offset_base;       // the stream position lives in device memory: a captured launch can be replayed
 #pragma unroll
         for (int g = 0; g < (AMAX + 3) / 4; ++g) {
             if (g * 4 < A) {
@@ -207,24 +209,31 @@ using namespace mi355ppo;
         else { FN(64, __VA_ARGS__); }                                       \
     } while (0)
 
-extern "C" MI355PPO_API int mi355ppo_categorical_sample_f32(const float* logits, const float* noise_exp1, uint64_t seed,
-                                               uint64_t offset, int64_t* action_i64, float* action_f32, float* logprob,
-                                               float* entropy, int B, int A, void* stream) {
+extern "C" MI355PPO_API int mi355ppo_categorical_sample_ctr_f32(const float* logits, const float* noise_exp1, uint64_t seed,
+                                               uint64_t offset, const uint64_t* offset_base, int64_t* action_i64,
+                                               float* action_f32, float* logprob, float* entropy, int B, int A, void* stream) {
     MI355_REQUIRE(logits && logprob, MI355PPO_EINVAL, "mi355ppo_categorical_sample_f32: null pointer");
     MI355_REQUIRE(action_i64 || action_f32, MI355PPO_EINVAL, "mi355ppo_categorical_sample_f32: no action output");
     MI355_REQUIRE(B > 0 && A > 0 && A <= 64, MI355PPO_EINVAL,
                   "mi355ppo_categorical_sample_f32: B=%d must be >0 and A=%d in 1..64", B, A);
     MI355_REQUIRE(aligned(logits, 4) && aligned(logprob, 4) && aligned(action_i64, 8) && aligned(action_f32, 4) &&
-                      aligned(noise_exp1, 4) && aligned(entropy, 4),
+                      aligned(noise_exp1, 4) && aligned(entropy, 4) && aligned(offset_base, 8),
                   MI355PPO_EALIGN, "mi355ppo_categorical_sample_f32: misaligned pointer");
     const int block = block_for(B);
 #define LAUNCH(AMAX, ...)                                                                                          \
     hipLaunchKernelGGL((categorical_sample_kernel<AMAX>), dim3(grid_for(B, block)), dim3(block), 0,                \
-                       as_stream(stream), logits, noise_exp1, seed, offset, action_i64, action_f32, logprob, entropy, \
-                       B, A)
+                       as_stream(stream), logits, noise_exp1, seed, offset, offset_base, action_i64, action_f32, logprob, \
+                       entropy, B, A)
     MI355_DISPATCH_AMAX(A, LAUNCH, 0);
 #undef LAUNCH
     return check_launch("categorical_sample_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_categorical_sample_f32(const float* logits, const float* noise_exp1, uint64_t seed,
+                                               uint64_t offset, int64_t* action_i64, float* action_f32, float* logprob,
+                                               float* entropy, int B, int A, void* stream) {
+    return mi355ppo_categorical_sample_ctr_f32(logits, noise_exp1, seed, offset, nullptr, action_i64, action_f32, logprob, entropy, B, A,
+                                               stream);
 }
 
 extern "C" MI355PPO_API int mi355ppo_categorical_logprob_entropy_f32(const float* logits, const int64_t* action_i64,

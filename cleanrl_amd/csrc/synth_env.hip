@@ -10,9 +10,10 @@ namespace mi355ppo {
 
 __global__ __launch_bounds__(256) void synth_env_scalars_kernel(long long* __restrict__ cursor, float* __restrict__ reward,
                                                                 float* __restrict__ done, int N, int pool, float done_p,
-                                                                uint64_t seed, uint64_t step) {
+                                                                uint64_t seed, uint64_t step, const uint64_t* __restrict__ step_base) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
+    if (step_base) step += *step_base;               // replayable: the env's step count lives in device memory
     const uint4 r = Philox(seed)((uint64_t)n, step);
     const float u = u32_to_unit_open(r.x), ud = u32_to_unit_open(r.y);
     reward[n] = (u > 0.95f ? 1.0f : 0.0f) - (u < 0.05f ? 1.0f : 0.0f);
@@ -36,21 +37,28 @@ __global__ __launch_bounds__(256) void synth_env_frames_kernel(const uint8_t* __
 
 using namespace mi355ppo;
 
-extern "C" MI355PPO_API int mi355ppo_synth_atari_step_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed,
-                                                         uint64_t step, uint8_t* obs, float* reward, float* done, int N,
-                                                         double done_p, int advance, void* stream) {
+extern "C" MI355PPO_API int mi355ppo_synth_atari_step_ctr_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed,
+                                                             uint64_t step, const uint64_t* step_base, uint8_t* obs, float* reward,
+                                                             float* done, int N, double done_p, int advance, void* stream) {
     const char* fn = "mi355ppo_synth_atari_step_u8";
     MI355_REQUIRE(planes && cursor && obs, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(N > 0 && pool > 0, MI355PPO_EINVAL, "%s: N=%d pool=%d must be positive", fn, N, pool);
     MI355_REQUIRE(!advance || (reward && done), MI355PPO_EINVAL, "%s: reward/done are required when advancing", fn);
-    MI355_REQUIRE(aligned(planes, 16) && aligned(obs, 16) && aligned(cursor, 8), MI355PPO_EALIGN, "%s: planes/obs must be 16-byte aligned", fn);
+    MI355_REQUIRE(aligned(planes, 16) && aligned(obs, 16) && aligned(cursor, 8) && aligned(step_base, 8), MI355PPO_EALIGN,
+                  "%s: planes/obs must be 16-byte aligned", fn);
     hipStream_t s = as_stream(stream);
     if (advance) {
         hipLaunchKernelGGL(synth_env_scalars_kernel, dim3((N + 255) / 256), dim3(256), 0, s, reinterpret_cast<long long*>(cursor),
-                           reward, done, N, pool, (float)done_p, seed, step);
+                           reward, done, N, pool, (float)done_p, seed, step, step_base);
         int rc = check_launch("synth_env_scalars_kernel");
         if (rc) return rc;
     }
     hipLaunchKernelGGL(synth_env_frames_kernel, dim3(N * 4), dim3(256), 0, s, planes, reinterpret_cast<const long long*>(cursor), obs, pool);
     return check_launch("synth_env_frames_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_synth_atari_step_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed,
+                                                         uint64_t step, uint8_t* obs, float* reward, float* done, int N,
+                                                         double done_p, int advance, void* stream) {
+    return mi355ppo_synth_atari_step_ctr_u8(planes, pool, cursor, seed, step, nullptr, obs, reward, done, N, done_p, advance, stream);
 }

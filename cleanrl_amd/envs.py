@@ -248,6 +248,8 @@ class DeviceSyntheticAtariVecEnv:
         self.cursor = torch.randint(0, pool_planes, (num_envs,), device=device, generator=self.gen)
         self.pool = pool_planes
         self._seed, self._step = int(seed) & (2**64 - 1), 0
+        self.step_base = None      # 1-element int64 device tensor once the learner captured its rollout steps (then the step
+        self._step_rel = None      # count of a captured launch is step_base + its position in the rollout)
 
     def _call(self, out, reward, done, advance):
         """Two launches per env step (csrc/synth_env.hip) instead of ~14 torch kernels: the rollout is short enough for
@@ -260,8 +262,10 @@ class DeviceSyntheticAtariVecEnv:
         if advance:
             assert reward.dtype == t.float32 and done.dtype == t.float32 and reward.is_contiguous() and done.is_contiguous()
             self._step += 1
-        st = lib.mi355ppo_synth_atari_step_u8(
-            self.planes.data_ptr(), self.pool, self.cursor.data_ptr(), self._seed, self._step, out.data_ptr(),
+        rel = self._step_rel if (advance and self._step_rel is not None) else None
+        st = lib.mi355ppo_synth_atari_step_ctr_u8(
+            self.planes.data_ptr(), self.pool, self.cursor.data_ptr(), self._seed, self._step if rel is None else rel,
+            self.step_base.data_ptr() if rel is not None else None, out.data_ptr(),
             reward.data_ptr() if advance else None, done.data_ptr() if advance else None, self.num_envs, float(self.done_p),
             int(advance), t.cuda.current_stream(self.device).cuda_stream)
         _lib.check(st, "mi355ppo_synth_atari_step_u8")

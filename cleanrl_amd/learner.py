@@ -200,16 +200,17 @@ class PPOLearner:
         return obs_rows
 
     @torch.no_grad()
-    def act(self, step: int, rows=None, rng_offset=None):
+    def act(self, step: int, rows=None, rng_offset=None, rng_base=None):
         """Action logic (:262-266): network forward on ``obs[step]``, sample, store action / logprob / value.
         ``rows=(lo, hi)`` restricts the call to that slice of the envs (an env-group lane of pipeline.py, on the lane's
-        stream); ``rng_offset`` then is the lane's reserved Philox offset for this step."""
+        stream); ``rng_offset`` then is the lane's reserved Philox offset for this step.  ``rng_base`` (1-element int64 device
+        tensor) is added to the offset on the device: the form a captured step uses (``capture_rollout``)."""
         lo, hi = (0, self.N) if rows is None else rows
         if self.hip:
             p, value = self._heads_rollout(self.obs[step][lo:hi])
             seed, off = self.agent.rng.next() if rng_offset is None else (self.agent.rng.seed, int(rng_offset))
             if self.discrete:
-                a64, _, _, _ = self.ops.categorical_sample(p.contiguous(), seed=seed, offset=off,
+                a64, _, _, _ = self.ops.categorical_sample(p.contiguous(), seed=seed, offset=off, offset_base=rng_base,
                                                             action_f32_out=self.actions[step][lo:hi],
                                                             logprob_out=self.logprobs[step][lo:hi], want_entropy=False)
                 action = a64
@@ -223,6 +224,59 @@ class PPOLearner:
         self.actions[step][lo:hi] = action
         self.logprobs[step][lo:hi] = logprob
         return action
+
+    # ------------------------------------------------------------------ hipGraph of the rollout steps (device-resident envs)
+    def capture_rollout(self, env) -> None:
+        """Capture every rollout step -- policy forward, sampling, the device env's step, the store of the next observation --
+        into one hipGraph per step (the step's rollout-storage rows are baked into its launches; the Philox positions of
+        the sampler and of the env live in device memory and advance by T per rollout).  ``replay_rollout()`` then issues a
+        whole rollout as T graph launches instead of ~30 T kernel launches: bit-identical buffers (tests), no host work
+        beside the replays.  For envs that write straight into device rows (``step_into``)."""
+        assert self.hip and self.discrete and hasattr(env, "step_into"), "capture_rollout needs the HIP path and a device-resident env"
+        dev, T = self.device, self.T
+        self.warm_rollout_caches()
+        self._rng_base = torch.full((1,), int(self.agent.rng.offset), dtype=torch.int64, device=dev)
+        env.step_base = torch.full((1,), int(env._step), dtype=torch.int64, device=dev)
+        self._graph_env = env
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graphs, pool = [], None
+
+        def body(step):
+            self.act(step, rng_offset=step + 1, rng_base=self._rng_base)
+            _, done_dst = self._slot(step + 1)
+            env._step_rel = step + 1
+            frames = env.step_into(self.stage_obs, self.rewards[step], done_dst)
+            env._step_rel = None
+            self.observe(step + 1, frames, done_dst)
+
+        host_rng, host_env = self.agent.rng.offset, env._step
+        cursor0 = env.cursor.clone()
+        with torch.cuda.stream(side):
+            body(0)                                   # warm-up on the capture stream: per-stream workspaces and trunk buffers exist
+        side.synchronize()
+        for step in range(T):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=side):
+                body(step)
+            pool = pool or g.pool()
+            graphs.append(g)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        # capturing executes nothing, but the warm-up step and the host counters moved: restore the pre-capture state
+        env.cursor.copy_(cursor0)
+        self.agent.rng.offset, env._step = host_rng, host_env
+        self._rollout_graphs = graphs
+
+    def replay_rollout(self) -> None:
+        """One rollout of T captured steps (then ``finish_rollout()`` as usual)."""
+        T, env = self.T, self._graph_env
+        self.warm_rollout_caches()               # the repacked matrices the captured launches read: re-derived in place
+        for g in self._rollout_graphs:
+            g.replay()
+        self._rng_base.add_(T)
+        env.step_base.add_(T)
+        self.agent.rng.offset += T               # host mirrors: eager calls and captured steps stay interchangeable
+        env._step += T
 
     def store_reward(self, step: int, reward) -> None:
         """``rewards[step] = torch.tensor(reward).to(device).view(-1)`` (:271)."""

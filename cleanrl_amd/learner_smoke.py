@@ -23,6 +23,10 @@ def default_args(**kw):
 def rollout(learner: PPOLearner, env: DeviceSyntheticAtariVecEnv) -> None:
     """T steps with the device env writing straight into the rollout-storage rows."""
     T = learner.T
+    if getattr(learner, "_rollout_graphs", None) is not None and learner._graph_env is env:
+        learner.replay_rollout()                                                     # T graph launches (PPOLearner.capture_rollout)
+        learner.finish_rollout()
+        return
     for step in range(T):
         learner.act(step)
         _, done_dst = learner._slot(step + 1)

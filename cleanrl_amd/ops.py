@@ -103,11 +103,12 @@ def gae(rewards, dones, values, next_done, next_value, gamma: float, gae_lambda:
 
 # ------------------------------------------------------------------------------------------- K2
 def categorical_sample(logits, noise_exp1=None, seed: int = 0, offset: int = 0, action_f32_out=None,
-                       logprob_out=None, want_entropy: bool = True, want_i64: bool = True):
+                       logprob_out=None, want_entropy: bool = True, want_i64: bool = True, offset_base=None):
     """``Categorical(logits=logits)``: sample, log_prob, entropy (ppo_atari_multigpu.py:156-159).
 
     ``noise_exp1`` (B,A) Exponential(1) draws reproduces torch's multinomial draw for that noise
-    (parity mode); otherwise a Philox stream keyed by ``(seed, offset)`` is used.
+    (parity mode); otherwise a Philox stream keyed by ``(seed, offset)`` is used; ``offset_base`` (1-element int64 device
+    tensor) is added to ``offset`` on the device, so a captured launch can be replayed at a new stream position.
     Returns ``(action_i64 | None, action_f32 | None, logprob, entropy | None)``.
     """
     lib = _lib.load()
@@ -125,10 +126,12 @@ def categorical_sample(logits, noise_exp1=None, seed: int = 0, offset: int = 0, 
     lp = logprob_out if logprob_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
     _chk(lp, torch.float32, "logprob_out", (B,))
     ent = torch.empty(B, dtype=torch.float32, device=dev) if want_entropy else None
+    if offset_base is not None:
+        _chk(offset_base, torch.int64, "offset_base", (1,))
     with _on(dev):
-        st = lib.mi355ppo_categorical_sample_f32(_ptr(logits), _ptr(noise_exp1), int(seed) & (2**64 - 1),
-                                                 int(offset) & (2**64 - 1), _ptr(a64), _ptr(af), _ptr(lp), _ptr(ent),
-                                                 B, A, _stream(dev))
+        st = lib.mi355ppo_categorical_sample_ctr_f32(_ptr(logits), _ptr(noise_exp1), int(seed) & (2**64 - 1),
+                                                     int(offset) & (2**64 - 1), _ptr(offset_base), _ptr(a64), _ptr(af), _ptr(lp),
+                                                     _ptr(ent), B, A, _stream(dev))
     _lib.check(st, "mi355ppo_categorical_sample_f32")
     return a64, af, lp, ent
 

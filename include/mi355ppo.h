@@ -91,6 +91,12 @@ MI355PPO_API int mi355ppo_categorical_sample_f32(const float* logits, const floa
                                     int64_t* action_i64, float* action_f32,
                                     float* logprob, float* entropy,
                                     int B, int A, void* stream);
+/* The same with the Philox stream position in device memory: offset_eff = offset + *offset_base (offset_base may be
+ * NULL).  A launch captured into a hipGraph can then be replayed with a new position (the rollout-step graphs of
+ * PPOLearner.capture_rollout advance the base once per rollout). */
+MI355PPO_API int mi355ppo_categorical_sample_ctr_f32(const float* logits, const float* noise_exp1, uint64_t seed,
+                                        uint64_t offset, const uint64_t* offset_base, int64_t* action_i64,
+                                        float* action_f32, float* logprob, float* entropy, int B, int A, void* stream);
 
 /* log_prob / entropy of GIVEN actions (the `action is not None` branch, :157-159).
  * Exactly one of action_i64 / action_f32 must be non-NULL. */
@@ -345,6 +351,9 @@ MI355PPO_API int mi355ppo_heads_bwd_f32(const float* h, const float* Wa, const f
 MI355PPO_API int mi355ppo_synth_atari_step_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed, uint64_t step,
                                               uint8_t* obs, float* reward, float* done, int N, double done_p, int advance,
                                               void* stream);
+MI355PPO_API int mi355ppo_synth_atari_step_ctr_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed, uint64_t step,
+                                                  const uint64_t* step_base, uint8_t* obs, float* reward, float* done, int N,
+                                                  double done_p, int advance, void* stream);   /* step_eff = step + *step_base */
 
 #ifdef __cplusplus
 }

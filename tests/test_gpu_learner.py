@@ -402,3 +402,38 @@ def test_env_group_lanes_on_the_gpu_match_the_serial_host_env_loop(K, delta):
         runs.append((L.actions.clone(), L.logprobs.clone()))
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])     # timing-independent sampling
     assert float(ref.dones.sum()) > 0
+
+
+def test_captured_rollout_steps_replay_bit_identically_to_the_eager_loop():
+    """PPOLearner.capture_rollout: every rollout step as one hipGraph (Philox positions of the sampler and of the device env in
+    device memory).  Two iterations -- rollout, update, rollout -- replayed against the eager loop from the same seeds: all
+    rollout buffers bit-equal, so the captured launches see the updated (re-packed in place) weights and fresh stream positions."""
+    N, T = 32, 8
+
+    def make():
+        torch.manual_seed(4)
+        np.random.seed(4)
+        env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=6, done_p=0.1)
+        agent = AtariAgent(env).to(DEV)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=1)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
+        L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
+        return L, env
+
+    (Le, enve), (Lg, envg) = make(), make()
+    Lg.capture_rollout(envg)
+    assert len(Lg._rollout_graphs) == T
+    for it in range(2):
+        learner_smoke.rollout(Le, enve)
+        learner_smoke.rollout(Lg, envg)
+        torch.cuda.synchronize()
+        for name in ("obs", "boot_obs", "actions", "logprobs", "values", "rewards", "dones", "boot_done", "advantages", "returns"):
+            assert torch.equal(getattr(Lg, name), getattr(Le, name)), (it, name)
+        np.random.seed(100 + it)
+        me = Le.update(2.5e-4)
+        np.random.seed(100 + it)
+        mg = Lg.update(2.5e-4)
+        Le.start_iteration(); Lg.start_iteration()
+        assert me["loss"] == mg["loss"] and torch.equal(Le.flat.params, Lg.flat.params)
+    assert Lg.agent.rng.offset == Le.agent.rng.offset and envg._step == enve._step
+    assert float(Le.dones.sum()) > 0
