@@ -1,4 +1,4 @@
-"""profiles/traffic.json from the HBM-traffic PMC passes of tools/gpu_traffic.sh (profiles/r01_pmc_traffic_{fetch,write}.csv).
+"""profiles/traffic.json from the HBM-traffic PMC passes of tools/gpu_traffic.sh (profiles/r02_pmc_traffic_{fetch,write}.csv).
 
 HBM bytes per launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB: on gfx950 FETCH_SIZE tallies 128-byte read requests at
 64 bytes (MI355X_MICROARCH.md "HBM"; confirmed here by the calibration copies of the same passes: a 1 GiB read reports
@@ -12,19 +12,23 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 IMAGES = 32768
 KEYS = {   # bench key -> (kernel-name substring, geometry substring); conv3_dgrad sums its 9 border-class launches
-    "conv1_fwd": ("conv_fixed_kernel", "FixedGeom<84, 84, 4, 8, 8, 20, 20, 4, 0,"),
+    "conv1_fwd": ("conv1q_fwd_kernel", ""),
     "conv2_fwd": ("conv_fixed_kernel", "FixedGeom<20, 20, 32, 4, 4, 9, 9, 2, 0,"),
     "conv3_fwd": ("conv_fixed_kernel", "FixedGeom<9, 9, 64, 3, 3, 7, 7, 1, 0,"),
-    "conv2_dgrad": ("conv_fixed_kernel", "FixedGeom<9, 9, 64, 2, 2, 10, 10, 1, -1,"),
+    "conv2_dgrad": ("conv_fixed_kernel", ("FixedGeom<9, 9, 64, 2, 2, 8, 8,", "FixedGeom<9, 9, 64, 1, 2, 1, 8,", "FixedGeom<9, 9, 64, 2, 1, 8, 1,",
+                                          "FixedGeom<9, 9, 64, 1, 1, 1, 1,")),          # the four border-class launches
     "conv3_dgrad": ("conv_fixed_kernel", "FixedGeom<7, 7, 64,"),
-    "conv1_wgrad": ("conv_wgrad_rows_kernel", "FixedGeom<84, 84, 4,"),
+    "conv1_wgrad": ("conv1p_wgrad_kernel", ""),
     "conv2_wgrad": ("conv_wgrad_taps_kernel", "FixedGeom<20, 20, 32,"),
     "conv3_wgrad": ("conv_wgrad_taps_kernel", "FixedGeom<9, 9, 64,"),
+    "fc_fwd": ("fcx_gemm_nt_kernel<0>", ""),
+    "fc_dgrad": ("fcx_gemm_nt_kernel<1>", ""),
 }
 ALGORITHMIC = {   # bytes per image the algorithm must move (inputs read once + outputs written once)
     "conv1_fwd": 28224 + 51200, "conv2_fwd": 51200 + 20736, "conv3_fwd": 20736 + 12544,
     "conv2_dgrad": 20736 + 51200 + 51200, "conv3_dgrad": 12544 + 20736 + 20736,
     "conv1_wgrad": 28224 + 51200, "conv2_wgrad": 51200 + 20736, "conv3_wgrad": 20736 + 12544,
+    "fc_fwd": 12544 + 2048, "fc_dgrad": 2048 + 12544 + 12544,        # per row: a3 + h;  dz + mask + da3 (the 6.4 MB weight not counted)
 }
 
 
@@ -34,15 +38,16 @@ def load(name):
 
 
 def main():
-    fetch, write = load("r01_pmc_traffic_fetch.csv"), load("r01_pmc_traffic_write.csv")
+    fetch, write = load("r02_pmc_traffic_fetch.csv"), load("r02_pmc_traffic_write.csv")
     out = {"source": "tools/gpu_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/conv_traffic 32768 3",
            "correction": "bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950: 128-byte read requests tallied at 64 bytes)",
            "calibration_fetch_KiB_for_1GiB_read": {k[:40]: v for k, v in fetch.items() if "calib" in k},
            "calibration_write_KiB_for_1GiB_write": {k[:40]: v for k, v in write.items() if "calib" in k},
            "hbm_bytes_per_launch": {}, "read_bytes": {}, "write_bytes": {}, "algorithmic_bytes": {}, "traffic_over_algorithmic": {}}
     for key, (kern, geom) in KEYS.items():
-        rd = sum(v for k, v in fetch.items() if kern in k and geom in k) * 1024 * 2
-        wr = sum(v for k, v in write.items() if kern in k and geom in k) * 1024
+        geoms = geom if isinstance(geom, tuple) else (geom,)
+        rd = sum(v for k, v in fetch.items() if kern in k and any(g in k for g in geoms)) * 1024 * 2
+        wr = sum(v for k, v in write.items() if kern in k and any(g in k for g in geoms)) * 1024
         name = f"{key}@{IMAGES}"
         out["read_bytes"][name], out["write_bytes"][name] = rd, wr
         out["hbm_bytes_per_launch"][name] = rd + wr
