@@ -64,14 +64,18 @@ __device__ __forceinline__ XTerms x_split(const x_u32x4& lo4, const x_u32x4& hi4
 // multiplies leaves the matrix pipe idle during the split (measured: 50 % of the pipe at two such waves per SIMD).
 constexpr int kXMT = 2, kXNT = 4, kXF = kXMT + kXNT;
 
-template <int EPI>
+// WAVES_N: the four waves of a workgroup sit side by side (64 x 512: they share the A rows, each A row leaves HBM once --
+// the forward, where A is the 411 MB activation and B the 6.4 MB weight; measured 3.6 x the algorithmic bytes with the
+// waves stacked) instead of on top of each other (256 x 128: they share the B rows).
+template <int EPI, bool WAVES_N>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fcx_gemm_nt_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
     const float* __restrict__ cmask, float* __restrict__ C, int ldc, int M, int N, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * 256 + wave * 64, n0 = blockIdx.x * 128;
-    if (m0 >= M) return;                                  // (whole wave; no barriers in this kernel)
+    const int m0 = WAVES_N ? blockIdx.y * 64 : blockIdx.y * 256 + wave * 64;
+    const int n0 = WAVES_N ? blockIdx.x * 512 + wave * 128 : blockIdx.x * 128;
+    if (m0 >= M || n0 >= N) return;                       // (whole wave; no barriers in this kernel)
     // row pointers of this lane's six fragments (rows past the edge re-read the last row: results dropped at the store)
     const float* pf[kXF];
 #pragma unroll
@@ -207,7 +211,7 @@ static int fcx_check(const char* fn, const float* A, const float* B, const float
     MI355_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 4 == 0 && ldb % 4 == 0, MI355PPO_EINVAL,
                   "%s: leading dimensions lda=%d ldb=%d ldc=%d (lda, ldb: multiples of 4, >= K; ldc >= N)", fn, lda, ldb, ldc);
     MI355_REQUIRE(aligned(A, 16) && aligned(B, 16) && aligned(C, 4), MI355PPO_EALIGN, "%s: A and B must be 16-byte aligned", fn);
-    MI355_REQUIRE((M + 255) / 256 <= 65535, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
+    MI355_REQUIRE((M + 63) / 64 <= 65535 * 64, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
     return MI355PPO_OK;
 }
 
@@ -217,8 +221,9 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float
     int rc = fcx_check(fn, a, W, h, M, N, K, K, K, N);
     if (rc) return rc;
     MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
-    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), a, K, W, K,
-                       bias, (const float*)nullptr, h, N, M, N, K);
+    MI355_REQUIRE((M + 63) / 64 <= 65535, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
+    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU, true>), dim3((N + 511) / 512, (M + 63) / 64), dim3(256), 0, as_stream(stream), a, K,
+                       W, K, bias, (const float*)nullptr, h, N, M, N, K);
     return check_launch(fn);
 }
 
@@ -228,7 +233,7 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, int lddz
     int rc = fcx_check(fn, dz, Wt, da, M, N, K, lddz, ldwt, N);
     if (rc) return rc;
     MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
-    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), dz, lddz, Wt,
-                       ldwt, (const float*)nullptr, act_in, da, N, M, N, K);
+    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK, false>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), dz, lddz,
+                       Wt, ldwt, (const float*)nullptr, act_in, da, N, M, N, K);
     return check_launch(fn);
 }
