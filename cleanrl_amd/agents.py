@@ -111,7 +111,7 @@ class AtariAgent(_DiscreteMixin, nn.Module):
         feats = self._trunk(obs_rows, inds, net[0], net[2], net[4])
         hidden = cnn.LinearReLUHwcFn.apply(feats, net[7].weight, net[7].bias, self._trunk.bufs)
         if cnn.heads_supported(self.actor, self.critic):
-            return cnn.HeadsFn.apply(hidden, self.actor.weight, self.actor.bias, self.critic.weight, self.critic.bias)
+            return cnn.HeadsFn.apply(hidden, self.actor.weight, self.actor.bias, self.critic.weight, self.critic.bias, self._trunk.bufs)
         return self.actor(hidden), self.critic(hidden)      # > 7 actions: library GEMMs
 
     def get_value(self, x):

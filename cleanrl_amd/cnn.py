@@ -180,6 +180,25 @@ def fc_dgrad_mask(dz: torch.Tensor, Wt: torch.Tensor, act_in: torch.Tensor, out:
     return out
 
 
+def fc_wgrad(dz: torch.Tensor, a: torch.Tensor, hwc_channels: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``dz.T @ a`` (N, K) on the f32 matrix pipe (csrc/fcw.hip, kernel Y), the batch slabs added in a fixed order.  With
+    ``hwc_channels = C`` the columns of ``a`` are (h, w, c)-ordered features and the result comes out in the reference's
+    (c, h, w) order -- the gradient of ``Linear.weight`` itself."""
+    lib = _lib.load()
+    M, N = dz.shape
+    K = a.shape[1]
+    lddz = _row_major(dz, "dz")
+    _chk(a, torch.float32, "a", (M, K))
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float32, device=dz.device)
+    _chk(out, torch.float32, "out", (N, K))
+    ws = _workspace(dz.device, lib.mi355ppo_fc_wgrad_workspace_bytes(M, N, K))
+    with _on(dz.device):
+        st = lib.mi355ppo_fc_wgrad_f32(_ptr(dz), lddz, _ptr(a), _ptr(out), M, N, K, int(hwc_channels), _ptr(ws), ws.numel(), _stream(dz.device))
+    _lib.check(st, "mi355ppo_fc_wgrad_f32")
+    return out
+
+
 FCX_MIN_ROWS = 4096          # below this (rollout-sized batches) the 128 x 128 workgroup tiles cannot fill the chip: library GEMM
 
 
@@ -197,6 +216,7 @@ class _Buffers:
         self._bt = {}
         self.last_a3_ptr = None            # data pointer of the a3 the trunk produced last (LinearReLUHwcFn checks its input is it)
         self.a3_grad_is_masked = False     # set by LinearReLUHwcFn.backward when conv3's ReLU backward rode in the FC data gradient
+        self.fc_dz_from_heads = None       # (data pointer of dz, FC bias gradient) when the FC layer's ReLU backward rode in HeadsFn.backward
 
     def fc_weight(self, W: torch.Tensor) -> torch.Tensor:
         """Linear(3136,512) weight with (h,w,c)-ordered input features, cached like the conv matrices (re-derived INTO the
@@ -328,11 +348,9 @@ def fc_weight_hwc(weight: torch.Tensor) -> torch.Tensor:
 class LinearReLUHwcFn(torch.autograd.Function):
     """``relu(a @ fc_weight_hwc(W).T + b)`` for the trunk's (h, w, c)-ordered features -- Agent.network[7:9]
     (Linear(3136, 512) + ReLU, cleanrl/ppo_atari_multigpu.py:144-145).  Minibatch-sized batches: forward and data gradient
-    on kernel X (bf16 pipe, exact products; bias + ReLU / the ReLU backward of conv3 in the epilogues).  The weight gradient
-    -- a (512 x M)(M x 3136) product whose 98 output tiles cannot fill 256 CUs -- stays a library GEMM split over M into a
-    batched GEMM plus a small sum, like every rollout-sized call."""
-
-    SPLIT = 16
+    on kernel X (bf16 pipe, exact products; bias + ReLU / the ReLU backward of conv3 in the epilogues), the weight gradient
+    on kernel Y (f32 pipe, the batch cut into slabs, csrc/fcw.hip); this layer's own ReLU backward and bias gradient ride in
+    ``HeadsFn.backward``.  Rollout-sized calls (no backward) use the library GEMM with the fused epilogue."""
 
     @staticmethod
     def forward(ctx, a, W, b, bufs=None):
@@ -352,12 +370,15 @@ class LinearReLUHwcFn(torch.autograd.Function):
     def backward(ctx, dh):
         a, h, Wp, W = ctx.saved_tensors
         bufs = ctx.bufs
-        fused = bool(ctx.fcx and ctx.needs_input_grad[0] and bufs.last_a3_ptr == a.data_ptr())
-        if fused:                                   # dz with a padded row pitch (kernel X's A operand at K = 512, see FC_PAD)
-            dz = bufs.fc_dz(dh.shape[0], dh.shape[1], dh.device)
-            torch.mul(dh, h > 0, out=dz)
+        pre = bufs.fc_dz_from_heads if bufs is not None else None
+        db = None
+        if pre is not None and pre[0] == dh.data_ptr() and dh.stride(1) == 1 and dh.stride(0) % 4 == 0:
+            dz, db = dh, pre[1]                     # HeadsFn.backward already applied this layer's ReLU mask and summed the bias gradient
         else:
             dz = torch.ops.aten.threshold_backward(dh.contiguous(), h, 0.0)
+        if bufs is not None:
+            bufs.fc_dz_from_heads = None
+        fused = bool(ctx.fcx and ctx.needs_input_grad[0] and bufs.last_a3_ptr == a.data_ptr())
         da = None
         if ctx.needs_input_grad[0]:
             if fused:
@@ -368,14 +389,11 @@ class LinearReLUHwcFn(torch.autograd.Function):
             else:
                 da = dz @ Wp
         m, n = dz.shape
-        s = LinearReLUHwcFn.SPLIT
-        if m % s == 0 and m >= 4096:
-            dz3 = dz.as_strided((s, m // s, n), (dz.stride(0) * (m // s), dz.stride(0), 1))      # == dz.view(s, m // s, n) for a dense dz
-            dWp = torch.bmm(dz3.transpose(1, 2), a.view(s, m // s, a.shape[1])).sum(0)
+        if ctx.fcx and n % 64 == 0 and a.shape[1] % 224 == 0 and a.shape[1] % 64 == 0:
+            dW = fc_wgrad(dz, a, 64)               # kernel Y: f32 matrix pipe, written in the (c, h, w) feature order of W itself
         else:
-            dWp = dz.t() @ a
-        dW = dWp.view(n, 7, 7, 64).permute(0, 3, 1, 2).reshape(n, 64 * 7 * 7)     # back to the (c, h, w) feature order
-        return da, dW, dz.sum(0), None
+            dW = (dz.t() @ a).view(n, 7, 7, 64).permute(0, 3, 1, 2).reshape(n, 64 * 7 * 7)     # back to the (c, h, w) feature order
+        return da, dW, (db if db is not None else dz.sum(0)), None
 
 
 def heads_supported(actor: torch.nn.Linear, critic: torch.nn.Linear) -> bool:
@@ -387,8 +405,12 @@ class HeadsFn(torch.autograd.Function):
     bandwidth-bound pass over ``h`` forward and one backward (``csrc/heads.hip``) instead of six degenerate GEMMs."""
 
     @staticmethod
-    def forward(ctx, h, Wa, ba, Wc, bc):
+    def forward(ctx, h, Wa, ba, Wc, bc, relu_bufs=None):
+        """``relu_bufs``: the trunk's ``_Buffers`` when ``h`` is the output of ``LinearReLUHwcFn`` -- backward then returns the
+        gradient with respect to that layer's PRE-activation (its ReLU mask applied here, where h and dh are in registers) and
+        leaves its bias gradient in ``relu_bufs.fc_dz_from_heads``."""
         lib = _lib.load()
+        ctx.relu_bufs = relu_bufs
         M, H = h.shape
         A = Wa.shape[0]
         h = _chk(h.contiguous(), torch.float32, "h", (M, H))
@@ -412,12 +434,21 @@ class HeadsFn(torch.autograd.Function):
         dev = h.device
         dlogits = dlogits.contiguous() if dlogits is not None else torch.zeros((M, A), device=dev)
         dvalue = dvalue.contiguous() if dvalue is not None else torch.zeros((M, 1), device=dev)
-        dh = torch.empty_like(h)
+        bufs = ctx.relu_bufs
+        # (ReLU variant: dz with a padded row pitch -- kernel X's A operand at K = 512, see FC_PAD)
+        dh = bufs.fc_dz(M, H, dev) if bufs is not None else torch.empty_like(h)
         dWa, dba = torch.empty_like(Wa), torch.empty(A, dtype=torch.float32, device=dev)
         dWc, dbc = torch.empty_like(Wc), torch.empty(1, dtype=torch.float32, device=dev)
         ws = _workspace(dev, lib.mi355ppo_heads_bwd_workspace_bytes(M, A))
         with _on(dev):
-            st = lib.mi355ppo_heads_bwd_f32(_ptr(h), _ptr(Wa), _ptr(Wc), _ptr(dlogits), _ptr(dvalue), _ptr(dh), _ptr(dWa),
-                                            _ptr(dba), _ptr(dWc), _ptr(dbc), M, A, H, _ptr(ws), ws.numel(), _stream(dev))
-        _lib.check(st, "mi355ppo_heads_bwd_f32")
-        return dh, dWa, dba, dWc, dbc
+            if bufs is not None:
+                dbh = torch.empty(H, dtype=torch.float32, device=dev)
+                st = lib.mi355ppo_heads_bwd_relu_f32(_ptr(h), _ptr(Wa), _ptr(Wc), _ptr(dlogits), _ptr(dvalue), _ptr(dh), dh.stride(0),
+                                                     _ptr(dWa), _ptr(dba), _ptr(dWc), _ptr(dbc), _ptr(dbh), M, A, H, _ptr(ws), ws.numel(),
+                                                     _stream(dev))
+                bufs.fc_dz_from_heads = (dh.data_ptr(), dbh)
+            else:
+                st = lib.mi355ppo_heads_bwd_f32(_ptr(h), _ptr(Wa), _ptr(Wc), _ptr(dlogits), _ptr(dvalue), _ptr(dh), _ptr(dWa),
+                                                _ptr(dba), _ptr(dWc), _ptr(dbc), M, A, H, _ptr(ws), ws.numel(), _stream(dev))
+        _lib.check(st, "mi355ppo_heads_bwd_relu_f32" if bufs is not None else "mi355ppo_heads_bwd_f32")
+        return dh, dWa, dba, dWc, dbc, None

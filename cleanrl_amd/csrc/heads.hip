@@ -62,13 +62,18 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
     }
 }
 
-template <int NA>
+// RELU: h is the output of a ReLU (the FC layer's, ppo_atari_multigpu.py:145): the gradient written is the one with
+// respect to that layer's PRE-activation, dz = dh * (h > 0), and its column sums (that layer's bias gradient) are
+// accumulated as one more partial row -- both for free here (h and dh are in registers), a `threshold_backward` pass over
+// 2 x 67 MB and a column reduction over 67 MB when done by the layer itself.
+template <int NA, bool RELU>
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ h, const float* __restrict__ Wa,
                                                         const float* __restrict__ Wc, const float* __restrict__ dlogits,
                                                         const float* __restrict__ dvalue, float* __restrict__ dh,
-                                                        float* __restrict__ part,      // [grid][NA][512 + 1]
-                                                        int M, int A) {
-    __shared__ float red[NA][kHid + 1];
+                                                        float* __restrict__ part,      // [grid][NA + 1][512 + 1]
+                                                        int M, int A, int lddh) {
+    __shared__ float red[NA + 1][kHid + 1];
+    float accz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wv = blockIdx.x * 4 + wave, nwv = gridDim.x * 4;
     float w[NA][8], acc[NA][8], accb[NA];
@@ -97,7 +102,14 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                 acc[a][i] += ga * hv[i];
             }
         }
-        float* dr = dh + (size_t)m * kHid + lane * 8;
+        if (RELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                d[i] = hv[i] > 0.0f ? d[i] : 0.0f;
+                accz[i] += d[i];
+            }
+        }
+        float* dr = dh + (size_t)m * lddh + lane * 8;
         *reinterpret_cast<float4*>(dr) = make_float4(d[0], d[1], d[2], d[3]);
         *reinterpret_cast<float4*>(dr + 4) = make_float4(d[4], d[5], d[6], d[7]);
     }
@@ -113,21 +125,31 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                 }
                 if (lane == 0) red[a][kHid] = wsel == 0 ? accb[a] : red[a][kHid] + accb[a];
             }
+            if (RELU) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float* r = &red[NA][lane * 8 + i];
+                    *r = wsel == 0 ? accz[i] : *r + accz[i];
+                }
+            }
         }
         __syncthreads();
     }
-    float* out = part + (size_t)blockIdx.x * NA * (kHid + 1);
-    for (int e = threadIdx.x; e < NA * (kHid + 1); e += 256) out[e] = red[e / (kHid + 1)][e % (kHid + 1)];
+    constexpr int rows = RELU ? NA + 1 : NA;
+    float* out = part + (size_t)blockIdx.x * rows * (kHid + 1);
+    for (int e = threadIdx.x; e < rows * (kHid + 1); e += 256) out[e] = (e % (kHid + 1) == kHid && e / (kHid + 1) == NA) ? 0.0f : red[e / (kHid + 1)][e % (kHid + 1)];
 }
 
 // dWa (A,512), dba (A), dWc (512), dbc (1) from the workgroup partials, fixed order.
+// (with dbh: one more partial row, the column sums of dz -> dbh (512))
 __global__ __launch_bounds__(256) void heads_bwd_reduce(const float* __restrict__ part, int nparts, int NA, int A,
                                                         float* __restrict__ dWa, float* __restrict__ dba,
-                                                        float* __restrict__ dWc, float* __restrict__ dbc) {
+                                                        float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ dbh) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= NA * (kHid + 1)) return;
+    const int rows = dbh ? NA + 1 : NA;
+    if (e >= rows * (kHid + 1)) return;
     float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const size_t stride = (size_t)NA * (kHid + 1);
+    const size_t stride = (size_t)rows * (kHid + 1);
     int p = 0;
     for (; p + 8 <= nparts; p += 8) {
 #pragma unroll
@@ -136,7 +158,9 @@ __global__ __launch_bounds__(256) void heads_bwd_reduce(const float* __restrict_
     for (; p < nparts; ++p) s8[p & 7] += part[(size_t)p * stride + e];
     const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     const int a = e / (kHid + 1), j = e - a * (kHid + 1);
-    if (a < A) {
+    if (a == NA) {
+        if (j < kHid) dbh[j] = s;
+    } else if (a < A) {
         if (j < kHid) dWa[(size_t)a * kHid + j] = s;
         else dba[a] = s;
     } else {
@@ -180,26 +204,29 @@ extern "C" MI355PPO_API int mi355ppo_heads_fwd_f32(const float* h, const float* 
 
 extern "C" MI355PPO_API size_t mi355ppo_heads_bwd_workspace_bytes(int M, int A) {
     if (M <= 0 || A < 1 || A > 7) return 0;
-    return (size_t)heads_grid(M) * (A + 1) * (kHid + 1) * sizeof(float);
+    return (size_t)heads_grid(M) * (A + 2) * (kHid + 1) * sizeof(float);      // (A + 1 rows; one more for the ReLU variant's bias gradient)
 }
 
-extern "C" MI355PPO_API int mi355ppo_heads_bwd_f32(const float* h, const float* Wa, const float* Wc, const float* dlogits,
-                                                   const float* dvalue, float* dh, float* dWa, float* dba, float* dWc,
-                                                   float* dbc, int M, int A, int H, void* workspace, size_t workspace_bytes,
-                                                   void* stream) {
-    const char* fn = "mi355ppo_heads_bwd_f32";
+static int heads_bwd(const char* fn, const float* h, const float* Wa, const float* Wc, const float* dlogits, const float* dvalue, float* dh,
+                     float* dWa, float* dba, float* dWc, float* dbc, float* dbh, int lddh, int M, int A, int H, void* workspace,
+                     size_t workspace_bytes, void* stream) {
     MI355_REQUIRE(h && Wa && Wc && dlogits && dvalue && dh && dWa && dba && dWc && dbc, MI355PPO_EINVAL, "%s: null pointer", fn);
     int rc = heads_check(fn, M, A, H);
     if (rc) return rc;
+    MI355_REQUIRE(lddh >= H && lddh % 4 == 0, MI355PPO_EINVAL, "%s: row pitch %d of the hidden gradient (a multiple of 4, >= %d)", fn, lddh, H);
     const size_t need = mi355ppo_heads_bwd_workspace_bytes(M, A);
     MI355_REQUIRE(workspace && workspace_bytes >= need, MI355PPO_EWORKSPACE, "%s: workspace %zu bytes < required %zu", fn,
                   workspace ? workspace_bytes : (size_t)0, need);
     MI355_REQUIRE(aligned(h, 16) && aligned(Wa, 16) && aligned(Wc, 16) && aligned(dh, 16) && aligned(workspace, 4) &&
-                      aligned(dlogits, 4) && aligned(dvalue, 4), MI355PPO_EALIGN, "%s: h / Wa / Wc / dh must be 16-byte aligned", fn);
+                      aligned(dlogits, 4) && aligned(dvalue, 4) && aligned(dbh, 4), MI355PPO_EALIGN, "%s: h / Wa / Wc / dh must be 16-byte aligned", fn);
     const int nb = heads_grid(M);
     float* part = static_cast<float*>(workspace);
     hipStream_t s = as_stream(stream);
-#define LAUNCH(NA) hipLaunchKernelGGL((heads_bwd_kernel<NA>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A)
+#define LAUNCH(NA)                                                                                                                   \
+    do {                                                                                                                             \
+        if (dbh) hipLaunchKernelGGL((heads_bwd_kernel<NA, true>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A, lddh);  \
+        else hipLaunchKernelGGL((heads_bwd_kernel<NA, false>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A, lddh);    \
+    } while (0)
     switch (A + 1) {
         case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break;
         case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;
@@ -207,7 +234,24 @@ extern "C" MI355PPO_API int mi355ppo_heads_bwd_f32(const float* h, const float* 
 #undef LAUNCH
     rc = check_launch("heads_bwd_kernel");
     if (rc) return rc;
-    const int total = (A + 1) * (kHid + 1);
-    hipLaunchKernelGGL(heads_bwd_reduce, dim3((total + 255) / 256), dim3(256), 0, s, part, nb, A + 1, A, dWa, dba, dWc, dbc);
+    const int total = (A + 1 + (dbh ? 1 : 0)) * (kHid + 1);
+    hipLaunchKernelGGL(heads_bwd_reduce, dim3((total + 255) / 256), dim3(256), 0, s, part, nb, A + 1, A, dWa, dba, dWc, dbc, dbh);
     return check_launch("heads_bwd_reduce");
+}
+
+extern "C" MI355PPO_API int mi355ppo_heads_bwd_f32(const float* h, const float* Wa, const float* Wc, const float* dlogits,
+                                                   const float* dvalue, float* dh, float* dWa, float* dba, float* dWc,
+                                                   float* dbc, int M, int A, int H, void* workspace, size_t workspace_bytes,
+                                                   void* stream) {
+    return heads_bwd("mi355ppo_heads_bwd_f32", h, Wa, Wc, dlogits, dvalue, dh, dWa, dba, dWc, dbc, nullptr, H, M, A, H, workspace,
+                     workspace_bytes, stream);
+}
+
+extern "C" MI355PPO_API int mi355ppo_heads_bwd_relu_f32(const float* h, const float* Wa, const float* Wc, const float* dlogits,
+                                                        const float* dvalue, float* dz, int lddz, float* dWa, float* dba,
+                                                        float* dWc, float* dbc, float* dbh, int M, int A, int H, void* workspace,
+                                                        size_t workspace_bytes, void* stream) {
+    const char* fn = "mi355ppo_heads_bwd_relu_f32";
+    MI355_REQUIRE(dbh, MI355PPO_EINVAL, "%s: null pointer", fn);
+    return heads_bwd(fn, h, Wa, Wc, dlogits, dvalue, dz, dWa, dba, dWc, dbc, dbh, lddz, M, A, H, workspace, workspace_bytes, stream);
 }

@@ -251,6 +251,15 @@ MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float* W, const 
 MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, int lddz, const float* Wt, int ldwt, const float* act_in, float* da,
                                             int M, int N, int K, void* stream);
 
+/* FC weight gradient (csrc/fcw.hip, f32 matrix pipe): dW (N,K) = dz (M,N)^T @ a (M,K), the batch cut into slabs whose
+ * partials are added in a fixed order (deterministic).  dz takes a leading dimension (even); a is dense.  N % 64 == 0,
+ * K % 224 == 0 (whole 64 x 224 wave tiles: 512 x 3136 = 8 x 14 of them); dz 8-byte, a and the workspace 16-byte aligned.
+ * hwc_channels = C > 0: the columns of a are features in (h, w, c) order with C channels (the trunk's layout) and dW is
+ * written in the reference's (c, h, w) order, i.e. directly as the gradient of Linear(3136,512).weight; 0: as computed. */
+MI355PPO_API size_t mi355ppo_fc_wgrad_workspace_bytes(int M, int N, int K);
+MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
+                                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * CNN  NatureCNN convolution stack (Agent.network convs, cleanrl/ppo_atari_multigpu.py:136-142) as
  * f32-MFMA implicit GEMMs on channels-last tensors: forward with fused uint8 gather + /255 + bias +
@@ -341,6 +350,14 @@ MI355PPO_API size_t mi355ppo_heads_bwd_workspace_bytes(int M, int A);
 MI355PPO_API int mi355ppo_heads_bwd_f32(const float* h, const float* Wa, const float* Wc, const float* dlogits,
                                         const float* dvalue, float* dh, float* dWa, float* dba, float* dWc, float* dbc,
                                         int M, int A, int H, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for an h that is the output of a ReLU (the FC layer's, :145): writes dz = dh * (h > 0), the gradient with respect
+ * to that layer's pre-activation, and dbh (H) = its column sums (that layer's bias gradient) -- autograd's
+ * threshold_backward pass and the bias reduction of the Linear below, done where h and dh are in registers anyway.
+ * dz takes a row pitch lddz (floats, a multiple of 4, >= H). */
+MI355PPO_API int mi355ppo_heads_bwd_relu_f32(const float* h, const float* Wa, const float* Wc, const float* dlogits,
+                                             const float* dvalue, float* dz, int lddz, float* dWa, float* dba, float* dWc,
+                                             float* dbc, float* dbh, int M, int A, int H, void* workspace,
+                                             size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Test / benchmark support -- NOT part of the reference path.  One step of the device-resident synthetic Atari

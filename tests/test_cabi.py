@@ -94,8 +94,15 @@ def test_cnn_and_heads_entry_points_validate_before_any_launch():
     assert b"workspace" in lib.mi355ppo_last_error()
     assert lib.mi355ppo_heads_fwd_f32(p, p, p, p, p, p, p, 8, 8, 512, None) == -1      # A must be 1..7
     assert lib.mi355ppo_heads_fwd_f32(p, p, p, p, p, p, p, 8, 4, 256, None) == -1      # hidden width is 512
-    assert lib.mi355ppo_heads_bwd_workspace_bytes(32768, 4) == 512 * 5 * 513 * 4
+    assert lib.mi355ppo_heads_bwd_workspace_bytes(32768, 4) == 512 * 6 * 513 * 4     # A + 1 rows, + 1 for the ReLU variant's bias gradient
     assert lib.mi355ppo_heads_bwd_f32(p, p, p, p, p, p, p, p, p, p, 8, 4, 512, None, 0, None) == -4
+    assert lib.mi355ppo_heads_bwd_relu_f32(p, p, p, p, p, p, 514, p, p, p, p, p, 8, 4, 512, p, 1 << 30, None) == -1     # pitch: a multiple of 4
+    assert lib.mi355ppo_heads_bwd_relu_f32(p, p, p, p, p, p, 516, p, p, p, p, None, 8, 4, 512, p, 1 << 30, None) == -1  # dbh is required
+    assert lib.mi355ppo_fc_wgrad_workspace_bytes(32768, 512, 3136) == 9 * 512 * 3136 * 4       # nine batch slabs
+    assert lib.mi355ppo_fc_wgrad_workspace_bytes(700, 512, 3136) == 512 * 3136 * 4
+    assert lib.mi355ppo_fc_wgrad_f32(p, 512, p, p, 8, 500, 3136, 64, p, 1 << 30, None) == -1   # N % 32
+    assert lib.mi355ppo_fc_wgrad_f32(p, 512, p, p, 8, 512, 3136, 60, p, 1 << 30, None) == -1   # channels must divide K
+    assert lib.mi355ppo_fc_wgrad_f32(p, 512, p, p, 8, 512, 3136, 64, p, 16, None) == -4
     assert lib.mi355ppo_synth_atari_step_u8(p, 0, p, 1, 1, p, p, p, 4, 0.01, 1, None) == -1
 
 

@@ -323,6 +323,61 @@ def test_heads_forward_backward(M, A):
         assert err <= max(2e-5 * scale, 4.0 * err_t), f"{name}: err {err:.3e}, torch f32 err {err_t:.3e}, scale {scale:.3e}"
 
 
+@pytest.mark.parametrize("M", [1, 700, 4099, 8192])
+def test_fc_weight_gradient_kernel_y_against_float64(M):
+    """Kernel Y (csrc/fcw.hip): dW = dz^T a of Linear(3136, 512) on the f32 pipe, the batch cut into slabs (1 at M <= 1023,
+    8 at 4099 with an odd last slab, 9 from 4608) added in a fixed order, against float64; the library's f32 GEMM on the
+    same inputs calibrates the bound (both accumulate M exact products in f32).  With the channel count given the columns
+    come out in the reference's (c, h, w) order."""
+    g = torch.Generator().manual_seed(170 + M)
+    a = torch.relu(torch.randn(M, 3136, generator=g)) * torch.exp(torch.randn(M, 3136, generator=g))
+    dz = torch.randn(M, 512, generator=g) * (torch.rand(M, 512, generator=g) > 0.4)
+    ref = dz.double().t() @ a.double()
+    cal = (dz.to(DEV).t() @ a.to(DEV)).cpu().double()
+    got = cnn.fc_wgrad(dz.to(DEV), a.to(DEV))
+    scale = ref.abs().max().item()
+    err, err_t = (got.cpu().double() - ref).abs().max().item(), (cal - ref).abs().max().item()
+    assert err <= max(2e-5 * scale, 4.0 * err_t), f"dW: err {err:.3e}, library f32 err {err_t:.3e}, scale {scale:.3e}"
+    dz_p = torch.empty((M, 516), device=DEV)[:, :512]                       # the learner's padded row pitch: same bits
+    dz_p.copy_(dz)
+    assert torch.equal(cnn.fc_wgrad(dz_p, a.to(DEV)), got)
+    chw = cnn.fc_wgrad(dz.to(DEV), a.to(DEV), 64)                          # (hw, c) -> (c, hw) columns
+    assert torch.equal(chw, got.view(512, 49, 64).permute(0, 2, 1).reshape(512, 3136))
+    assert torch.equal(got, cnn.fc_wgrad(dz.to(DEV), a.to(DEV)))            # deterministic
+
+
+@pytest.mark.parametrize("M,A", [(1, 4), (4100, 6), (32768, 4)])
+def test_heads_backward_relu_variant(M, A):
+    """The ReLU variant of the heads' backward: the gradient it writes is the plain one times (h > 0), bit for bit, with a
+    padded row pitch; the extra output is the column sum of that (the FC layer's bias gradient)."""
+    lib = cnn._lib.load()
+    g = torch.Generator().manual_seed(7 * M + A)
+    h = torch.relu(torch.randn(M, 512, generator=g)).to(DEV)
+    Wa, Wc = (torch.randn(A, 512, generator=g) * 0.05).to(DEV), (torch.randn(1, 512, generator=g) * 0.05).to(DEV)
+    gl, gv = torch.randn(M, A, generator=g).to(DEV), torch.randn(M, 1, generator=g).to(DEV)
+    ws = torch.empty(lib.mi355ppo_heads_bwd_workspace_bytes(M, A), dtype=torch.uint8, device=DEV)
+    P = cnn._ptr
+    outs = {}
+    for relu in (False, True):
+        dh = torch.full((M, 516), 7.0, device=DEV)[:, :512] if relu else torch.empty((M, 512), device=DEV)
+        dWa, dba, dWc, dbc, dbh = (torch.empty_like(Wa), torch.empty(A, device=DEV), torch.empty_like(Wc), torch.empty(1, device=DEV),
+                                   torch.empty(512, device=DEV))
+        with torch.cuda.device(DEV):
+            st = (lib.mi355ppo_heads_bwd_relu_f32(P(h), P(Wa), P(Wc), P(gl), P(gv), P(dh), 516, P(dWa), P(dba), P(dWc), P(dbc), P(dbh), M, A,
+                                                  512, P(ws), ws.numel(), None) if relu else
+                  lib.mi355ppo_heads_bwd_f32(P(h), P(Wa), P(Wc), P(gl), P(gv), P(dh), P(dWa), P(dba), P(dWc), P(dbc), M, A, 512, P(ws),
+                                             ws.numel(), None))
+        assert st == 0, lib.mi355ppo_last_error()
+        outs[relu] = (dh, dWa, dba, dWc, dbc, dbh)
+    plain, fused = outs[False], outs[True]
+    assert torch.equal(fused[0], plain[0] * (h > 0))
+    for k in range(1, 5):
+        assert torch.equal(fused[k], plain[k])                               # the head gradients do not change
+    ref = fused[0].double().sum(0)
+    assert (fused[5].double() - ref).abs().max().item() <= 2e-6 * max(ref.abs().max().item(), fused[0].abs().sum(0).max().item())
+    assert torch.all(fused[0].as_strided((M, 4), (516, 1), fused[0].storage_offset() + 512) == 7.0)       # the padding is not written
+
+
 def test_full_minibatch_size_properties():
     """Config-C minibatch (32,768 images, where a float64 CPU convolution is out of reach): size-independent properties.
     The data and weight gradients are LINEAR in dz (the ReLU mask depends on the activation only); the forward of a

@@ -53,10 +53,11 @@ class FakeOps:
 
     @staticmethod
     def categorical_sample(logits, noise_exp1=None, seed=0, offset=0, action_f32_out=None, logprob_out=None,
-                           want_entropy=True, want_i64=True):
+                           want_entropy=True, want_i64=True, offset_base=None):
         B, A = logits.shape
         _chk(logits, torch.float32, "logits", (B, A))
         assert isinstance(seed, int) and isinstance(offset, int) and offset > 0
+        assert offset_base is None or (offset_base.dtype == torch.int64 and offset_base.numel() == 1)
         probs = Categorical(logits=logits)
         a = probs.sample()
         if action_f32_out is not None:

@@ -62,6 +62,8 @@ int main(int argc, char** argv) {
     float *bt1q = dalloc<float>(mi355ppo_cnn_conv1q_pack_bytes() / 4), *bt2c = dalloc<float>(16 * 128 * 64);     // round-2 defaults
     // FC layer (kernel X): a3 flat (M, 3136) -> h (M, 512); data gradient back into dz3 with the (a3 > 0) mask
     float *Wfc = dalloc<float>(512 * 3136), *Wfct = dalloc<float>(3136 * 516), *hfc = dalloc<float>((size_t)M * 512), *dzfc = dalloc<float>((size_t)M * 516);
+    const size_t wsfcb = mi355ppo_fc_wgrad_workspace_bytes((int)M, 512, 3136);
+    float *dWfc = dalloc<float>(512 * 3136); void* wsfc; CHECK(hipMalloc(&wsfc, wsfcb));
     float *bias = dalloc<float>(512), *dW = dalloc<float>(36864), *db = dalloc<float>(64);
     size_t wsb = 0;
     for (int l = 1; l <= 3; l++) { size_t b = mi355ppo_cnn_conv_wgrad_workspace_bytes(M, l); if (b > wsb) wsb = b; }
@@ -89,8 +91,8 @@ int main(int argc, char** argv) {
             calib_copy_b128<<<8192, 256, 0, st>>>(c0, c1, cal_b / 16);
             calib_copy_b32<<<8192, 256, 0, st>>>((const uint32_t*)c0, (uint32_t*)c1, cal_b / 4);
         }
-    hipEvent_t ev[11][2];
-    float tot[10] = {0};
+    hipEvent_t ev[12][2];
+    float tot[11] = {0};
     for (auto& e : ev) { CHECK(hipEventCreate(&e[0])); CHECK(hipEventCreate(&e[1])); }
     float *dW1 = dalloc<float>(8192), *dW2 = dalloc<float>(32768), *dW3 = dalloc<float>(36864), *db1 = dalloc<float>(64), *db2 = dalloc<float>(64), *db3 = dalloc<float>(64);
 #define TIMED(i, call) do { CHECK(hipEventRecord(ev[i][0], st)); ABI(call); CHECK(hipEventRecord(ev[i][1], st)); } while (0)
@@ -100,6 +102,7 @@ int main(int argc, char** argv) {
         TIMED(2, mi355ppo_cnn_conv_fwd_f32(a2, nullptr, bt3, bias, a3, M, 3, st));
         TIMED(8, mi355ppo_fc_fwd_relu_f32(a3, Wfc, bias, hfc, (int)M, 512, 3136, st));               // kernel X forward (bias: first 512 of a larger fill below)
         TIMED(9, mi355ppo_fc_dgrad_mask_f32(dzfc, 516, Wfct, 516, a3, dz3, (int)M, 3136, 512, st)); // kernel X data gradient + (a3 > 0)
+        TIMED(10, mi355ppo_fc_wgrad_f32(dzfc, 516, a3, dWfc, (int)M, 512, 3136, 64, wsfc, wsfcb, st));  // kernel Y + its slab reduction
         TIMED(3, mi355ppo_cnn_conv_wgrad_f32(a2, nullptr, dz3, dW3, db3, M, 3, ws, wsb, st));
         TIMED(4, mi355ppo_cnn_conv_dgrad_f32_variant(dz3, bt3c, a2, dz2, M, 3, 5, st));
         TIMED(5, mi355ppo_cnn_conv_wgrad_f32(a1, nullptr, dz2, dW2, db2, M, 2, ws, wsb, st));
@@ -107,18 +110,18 @@ int main(int argc, char** argv) {
         TIMED(7, mi355ppo_cnn_conv_wgrad_f32(obs, inds, dz1, dW1, db1, M, 1, ws, wsb, st));
         CHECK(hipStreamSynchronize(st));
         if (r > 0 || reps == 1)
-            for (int i = 0; i < 10; i++) { float ms; CHECK(hipEventElapsedTime(&ms, ev[i][0], ev[i][1])); tot[i] += ms; }
+            for (int i = 0; i < 11; i++) { float ms; CHECK(hipEventElapsedTime(&ms, ev[i][0], ev[i][1])); tot[i] += ms; }
         if (r + 1 < reps) {   // the gradients the next repetition starts from stay a bounded signal
             fill_f32<<<4096, 256, 0, st>>>(dz1, a1n, 2u); fill_f32<<<4096, 256, 0, st>>>(dz2, a2n, 3u);
         }
     }
     CHECK(hipStreamSynchronize(st));
     {
-        const char* nm[10] = {"fwd1", "fwd2", "fwd3", "wgrad3", "dgrad3", "wgrad2", "dgrad2", "wgrad1", "fc_fwd", "fc_dgrad"};
+        const char* nm[11] = {"fwd1", "fwd2", "fwd3", "wgrad3", "dgrad3", "wgrad2", "dgrad2", "wgrad1", "fc_fwd", "fc_dgrad", "fc_wgrad"};
         const int nt = reps > 1 ? reps - 1 : 1;
         float sum = 0;
         std::printf("{\"images\": %lld, \"timed_reps\": %d", (long long)M, nt);
-        for (int i = 0; i < 10; i++) { std::printf(", \"%s_us\": %.1f", nm[i], tot[i] / nt * 1e3f); sum += tot[i] / nt; }
+        for (int i = 0; i < 11; i++) { std::printf(", \"%s_us\": %.1f", nm[i], tot[i] / nt * 1e3f); sum += tot[i] / nt; }
         std::printf(", \"sum_ms\": %.3f}\n", sum);
     }
     if (argc > 3) {
