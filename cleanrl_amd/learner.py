@@ -98,6 +98,7 @@ class PPOLearner:
         if self.hip:
             self._h2d = torch.cuda.Stream(device=device)
             self._h2d_evt = torch.cuda.Event()
+            self._stage_free = torch.cuda.Event()    # compute stream: the staging / rollout buffers may be overwritten by the copy stream
             self._pin_obs = torch.zeros((N,) + self.frame_shape, dtype=obs_dtype).pin_memory()
             # device staging for incoming channel-planar frames (H2D target / device-env output)
             self.stage_obs = torch.zeros((N,) + self.frame_shape, dtype=obs_dtype, device=device) if self.relayout else None
@@ -114,11 +115,26 @@ class PPOLearner:
             self._inds_dev = torch.empty((int(args.update_epochs), self.batch_size), dtype=torch.int64, device=device)
             self._inds_pin = torch.empty((int(args.update_epochs), self.batch_size), dtype=torch.int64).pin_memory()
             self._total_norm = torch.zeros(1, device=device)
+            self._stage_free.record(torch.cuda.current_stream(device))       # after every buffer's zero fill
         self._mb_adv_md = None      # the current minibatch's (mean, std + 1e-8) row of ops.adv_stats, or None
         self._mb_slot = None        # (LossSlots, k): K3's scalar fold deferred to one launch per update (categorical family)
         self._loss_slots = None
         if self.hip and self.discrete and type(self).forward_backward_hip is PPOLearner.forward_backward_hip:
             self._loss_slots = self.ops.LossSlots(self._scalars.shape[0], device)
+        # world > 1: the all-reduce of the largest parameter's gradient (NatureCNN: Linear(3136,512).weight, 95 % of the
+        # bytes, complete right after the heads' and the FC layer's backward) is started from a post-accumulate hook and runs
+        # on RCCL's stream while the three conv layers' backward -- two thirds of the backward pass -- still computes; the
+        # small rest follows the backward (`_minibatch_hip`).  The reference all-reduces after the whole backward (:360-367).
+        self._ar_early = None       # (offset, numel) of the early bucket in the flat gradient buffer
+        self._ar_armed = False
+        self._ar_work = None
+        if (self.hip and world_size > 1 and type(self).forward_backward_hip is PPOLearner.forward_backward_hip
+                and os.environ.get("MI355PPO_AR_OVERLAP", "1") != "0"):
+            i = max(range(len(self.flat.segments)), key=lambda j: self.flat.segments[j][1])
+            off, n = self.flat.segments[i]
+            if n >= (1 << 18) and n * 2 > self.flat.numel:       # worth a launch of its own
+                self._ar_early = (off, n)
+                self.flat._params_list[i].register_post_accumulate_grad_hook(self._early_all_reduce)
 
     # ------------------------------------------------------------------ rollout (a2)
     def _slot(self, step: int):
@@ -147,6 +163,9 @@ class PPOLearner:
         np.copyto(self._pin_obs_np, next_obs, casting="unsafe")      # one host memcpy straight into pinned memory
         np.copyto(self._pin_rd_np[0], next_done, casting="unsafe")
         h2d_dst = self.stage_obs if self.relayout else obs_dst
+        # the copy stream must not overtake the compute stream's last use of its target: the zero fill at construction, the
+        # relayout kernel of the previous step
+        self._h2d.wait_event(self._stage_free)
         with torch.cuda.stream(self._h2d):
             h2d_dst.copy_(self._pin_obs, non_blocking=True)
             done_dst.copy_(self._pin_rd[0], non_blocking=True)
@@ -154,6 +173,7 @@ class PPOLearner:
         torch.cuda.current_stream(self.device).wait_event(self._h2d_evt)
         if self.relayout:
             self.ops.obs_nchw_to_nhwc_u8(self.stage_obs, obs_dst)
+        self._stage_free.record(torch.cuda.current_stream(self.device))
 
     def start_iteration(self) -> None:
         """Carry the bootstrap observation of the previous rollout into slot 0 (the reference keeps it in
@@ -370,10 +390,29 @@ class PPOLearner:
         dev.copy_(pin, non_blocking=True)
         return dev
 
+    def _early_all_reduce(self, _param) -> None:
+        """Post-accumulate hook of the largest parameter: its slice of the flat gradient is final for this minibatch."""
+        if self._ar_armed:
+            off, n = self._ar_early
+            self._ar_work = dist.all_reduce(self.flat.grads[off:off + n], op=dist.ReduceOp.SUM, async_op=True)
+            self._ar_armed = False
+
     def _minibatch_hip(self, idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, lr, scalars_out):
+        self._ar_armed = self._ar_early is not None
         self.forward_backward_hip(idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, scalars_out)
         if self.world_size > 1:
-            dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM)        # :367 on the persistent flat buffer (RCCL)
+            g = self.flat.grads
+            if self._ar_work is not None:                                 # :367 in three pieces: the early bucket is in flight
+                off, n = self._ar_early
+                if off > 0:
+                    dist.all_reduce(g[:off], op=dist.ReduceOp.SUM)
+                if off + n < g.numel():
+                    dist.all_reduce(g[off + n:], op=dist.ReduceOp.SUM)
+                self._ar_work.wait()                                      # the compute stream waits for RCCL's
+                self._ar_work = None
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)                  # :367 on the persistent flat buffer (RCCL)
+            self._ar_armed = False
         self.optimizer_step_hip(lr)
 
     def forward_backward_hip(self, idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, scalars_out):

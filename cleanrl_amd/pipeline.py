@@ -124,9 +124,13 @@ class GroupedRollout:
         lane = self.lanes[g]
         done = np.zeros(lane.n, np.float32) if done is None else done
         if lane.hip:
+            main = torch.cuda.current_stream(self.L.device)
+            # the lane's staging buffers and the learner's rollout buffers were allocated AND zero-filled on the main stream:
+            # without this wait that fill can land after the lane's first copy (seen as a rare corrupted slot 0)
+            lane.stream.wait_stream(main)
             with torch.cuda.stream(lane.stream):
                 lane.observe(0, obs, done, first=True)
-            torch.cuda.current_stream(self.L.device).wait_stream(lane.stream)
+            main.wait_stream(lane.stream)
         else:
             lane.observe(0, obs, done, first=True)
 

@@ -397,7 +397,11 @@ def test_env_group_lanes_on_the_gpu_match_the_serial_host_env_loop(K, delta):
         roll.run(step_fn)
         torch.cuda.synchronize()
         for name in ("obs", "boot_obs", "dones", "boot_done", "rewards"):
-            assert torch.equal(getattr(L, name), getattr(ref, name)), name
+            got, want = getattr(L, name), getattr(ref, name)
+            if not torch.equal(got, want):
+                idx = (got != want).nonzero()
+                where = {f"dim{d}": sorted(set(idx[:, d].tolist()))[:8] for d in range(idx.shape[1])}
+                raise AssertionError(f"{name} differs from the serial loop in {idx.shape[0]} elements at {where}; dones={ref.dones.nonzero().tolist()[:12]}")
         torch.testing.assert_close(L.values, ref.values, rtol=1e-5, atol=1e-6)
         runs.append((L.actions.clone(), L.logprobs.clone()))
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])     # timing-independent sampling
