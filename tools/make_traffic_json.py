@@ -21,14 +21,16 @@ KEYS = {   # bench key -> (kernel-name substring, geometry substring); conv3_dgr
     "conv1_wgrad": ("conv1p_wgrad_kernel", ""),
     "conv2_wgrad": ("conv_wgrad_taps_kernel", "FixedGeom<20, 20, 32,"),
     "conv3_wgrad": ("conv_wgrad_taps_kernel", "FixedGeom<9, 9, 64,"),
-    "fc_fwd": ("fcx_gemm_nt_kernel<0>", ""),
-    "fc_dgrad": ("fcx_gemm_nt_kernel<1>", ""),
+    "fc_fwd": ("fcx_gemm_nt_kernel<0,", ""),
+    "fc_dgrad": ("fcx_gemm_nt_kernel<1,", ""),
+    "fc_wgrad": ("fcw_", ""),                         # kernel Y + the sum of its nine slab partials
 }
 ALGORITHMIC = {   # bytes per image the algorithm must move (inputs read once + outputs written once)
     "conv1_fwd": 28224 + 51200, "conv2_fwd": 51200 + 20736, "conv3_fwd": 20736 + 12544,
     "conv2_dgrad": 20736 + 51200 + 51200, "conv3_dgrad": 12544 + 20736 + 20736,
     "conv1_wgrad": 28224 + 51200, "conv2_wgrad": 51200 + 20736, "conv3_wgrad": 20736 + 12544,
     "fc_fwd": 12544 + 2048, "fc_dgrad": 2048 + 12544 + 12544,        # per row: a3 + h;  dz + mask + da3 (the 6.4 MB weight not counted)
+    "fc_wgrad": 2048 + 12544,                                         # per row: dz + a3 (the 6.4 MB result and its partials not counted)
 }
 
 
