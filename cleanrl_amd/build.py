@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libmi355ppo.so")
-SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "optim.hip", "conv.hip", "conv1q.hip", "conv1p.hip", "fcx.hip", "fcw.hip", "heads.hip", "synth_env.hip"]
+SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "optim.hip", "conv.hip", "conv1q.hip", "conv1p.hip", "convx.hip", "fcx.hip", "fcw.hip", "heads.hip", "synth_env.hip"]
 HEADERS = ["common.h", "catrow.h", os.path.join("..", "..", "include", "mi355ppo.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every f32 multiply/add rounds separately, as the reference's un-fused torch ops do.

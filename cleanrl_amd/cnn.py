@@ -11,6 +11,8 @@ flat parameter buffer) and are repacked into the kernels' matrix layouts on use 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -18,12 +20,20 @@ from .ops import _chk, _on, _ptr, _stream, _workspace
 
 # layer -> (Cin, Cout, K, stride, Hin, Hout)
 LAYERS = {1: (4, 32, 8, 4, 84, 20), 2: (32, 64, 4, 2, 20, 9), 3: (64, 64, 3, 1, 9, 7)}
-MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2, MODE_DGRAD_S1_CLASSES, MODE_FWD_Q, MODE_DGRAD_S2_CLASSES = 0, 1, 2, 3, 4, 5
+MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2, MODE_DGRAD_S1_CLASSES, MODE_FWD_Q, MODE_DGRAD_S2_CLASSES, MODE_FWD_X = 0, 1, 2, 3, 4, 5, 6
 BT_CLASSES_NUMEL = 81 * 4096
 BT2_CLASSES_NUMEL = 16 * 128 * 64   # layer-2 data gradient, one matrix per border class of the 10x10 class grid (mode 5)
 VARIANT_DGRAD2_CLASSES = 6
 QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 storage elements (kernel Q's integer-digit pack)
 VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
+VARIANT_X = 7                       # layer-2 / 3 forward on the bf16 matrix pipe with exact products (csrc/convx.hip); Bt = the mode-6 pack
+_FWD23_BF16 = os.environ.get("MI355PPO_FWD23", "f32") == "bf16"      # minibatch-sized forward of layers 2 / 3: kernel F (default) or kernel C
+
+
+def xpack_numel(layer: int) -> int:
+    """f32 storage elements of the mode-6 pack: three bf16 planes = 6 bytes per weight."""
+    cin, cout, k, _, _, _ = LAYERS[layer]
+    return cout * cin * k * k * 6 // 4
 
 
 def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -31,7 +41,7 @@ def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch
     cin, cout, k, _, _, _ = LAYERS[layer]
     _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
     numel = (BT_CLASSES_NUMEL if mode == MODE_DGRAD_S1_CLASSES else QPACK_NUMEL if mode == MODE_FWD_Q
-             else BT2_CLASSES_NUMEL if mode == MODE_DGRAD_S2_CLASSES else W.numel())
+             else BT2_CLASSES_NUMEL if mode == MODE_DGRAD_S2_CLASSES else xpack_numel(layer) if mode == MODE_FWD_X else W.numel())
     if out is None:
         out = torch.empty(numel, dtype=torch.float32, device=W.device)
     _chk(out, torch.float32, "Bt", (numel,))
@@ -56,7 +66,7 @@ def conv_fwd(src: torch.Tensor, Bt: torch.Tensor, bias: torch.Tensor, layer: int
         assert inds is None
         images = src.shape[0]
         _chk(src, torch.float32, "src", (images, hin, hin, cin))
-    _chk(Bt, torch.float32, "Bt", (QPACK_NUMEL if variant == VARIANT_Q else cout * cin * k * k,))
+    _chk(Bt, torch.float32, "Bt", (QPACK_NUMEL if variant == VARIANT_Q else xpack_numel(layer) if variant == VARIANT_X else cout * cin * k * k,))
     _chk(bias, torch.float32, "bias", (cout,))
     if out is None:
         out = torch.empty((images, hout, hout, cout), dtype=torch.float32, device=src.device)
@@ -289,13 +299,17 @@ class NatureTrunkFn(torch.autograd.Function):
         a1, a2, a3 = bufs.get(m, obs_u8.device, False)
         # layer 1 runs on the integer matrix pipe (kernel Q): uint8 taps are exact int8 operands, weights four int8 digits
         bt1 = bufs.weights(W1, 1, MODE_FWD_Q)
-        bt2, bt3 = bufs.weights(W2, 2, MODE_FWD), bufs.weights(W3, 3, MODE_FWD)
         if m <= 4096 and obs_u8.is_contiguous() and tuple(obs_u8.shape[1:]) == (84, 84, 4):     # inference-sized: one call
+            bt2, bt3 = bufs.weights(W2, 2, MODE_FWD), bufs.weights(W3, 3, MODE_FWD)
             trunk_fwd(obs_u8, inds, bt1, b1.detach(), bt2, b2.detach(), bt3, b3.detach(), a1, a2, a3, conv1_variant=VARIANT_Q)
         else:
             conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1, variant=VARIANT_Q)
-            conv_fwd(a1, bt2, b2.detach(), 2, None, a2)
-            conv_fwd(a2, bt3, b3.detach(), 3, None, a3)
+            if _FWD23_BF16:         # layers 2 and 3 at minibatch size on the bf16 matrix pipe with exact products (kernel C)
+                conv_fwd(a1, bufs.weights(W2, 2, MODE_FWD_X), b2.detach(), 2, None, a2, variant=VARIANT_X)
+                conv_fwd(a2, bufs.weights(W3, 3, MODE_FWD_X), b3.detach(), 3, None, a3, variant=VARIANT_X)
+            else:
+                conv_fwd(a1, bufs.weights(W2, 2, MODE_FWD), b2.detach(), 2, None, a2)
+                conv_fwd(a2, bufs.weights(W3, 3, MODE_FWD), b3.detach(), 3, None, a3)
         ctx.obs, ctx.inds, ctx.acts, ctx.bufs = obs_u8, inds, (a1, a2, a3), bufs
         bufs.last_a3_ptr = a3.data_ptr()
         ctx.save_for_backward(W2, W3)

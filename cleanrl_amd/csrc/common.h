@@ -14,6 +14,10 @@ namespace mi355ppo {
 void set_error(const char* fmt, ...);
 
 // kernel P (conv1p.hip): layer-1 weight gradient on the bf16 matrix pipe; partial layout of kernel R (conv.hip reduces them)
+// kernel C (convx.hip): layers 2 / 3 forward on the bf16 pipe with exact products; pack = the pre-split weights (repack mode 6)
+size_t convx_pack_bytes(int layer);
+int convx_pack(const float* W, void* pack, int layer, hipStream_t s);
+int convx_fwd(const float* src, const void* pack, const float* bias, float* dst, long long images, int layer, hipStream_t s);
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
                   hipStream_t s);
 

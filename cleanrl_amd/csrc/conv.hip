@@ -955,6 +955,10 @@ extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, floa
     MI355_REQUIRE(W && Bt, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
     if (mode == 4 && layer == 1) return mi355ppo_cnn_conv1q_pack(W, Bt, stream);   // integer-digit pack of kernel Q (conv1q.hip)
+    if (mode == 6 && layer >= 2) {                                                  // bf16 term planes of kernel C (convx.hip)
+        MI355_REQUIRE(aligned(Bt, 16), MI355PPO_EALIGN, "%s: the pack must be 16-byte aligned", fn);
+        return convx_pack(W, Bt, layer, as_stream(stream));
+    }
     MI355_REQUIRE(mode == 0 || ((mode == 1 || mode == 3) && layer == 3) || ((mode == 2 || mode == 5) && layer == 2), MI355PPO_EINVAL,
                   "%s: mode %d is not defined for layer %d", fn, mode, layer);
     const int total = mode == 3 ? kC3_total : mode == 5 ? kC2_total : Cout * Cin * KH * KH;
@@ -1154,10 +1158,13 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
     MI355_REQUIRE(layer == 1 || inds == nullptr, MI355PPO_EINVAL, "%s: inds (row gather) is only defined for layer 1", fn);
-    MI355_REQUIRE(variant == 0 || variant == 2 || variant == 4 || (variant == 6 && layer == 1), MI355PPO_EINVAL, "%s: unknown variant %d", fn, variant);
+    MI355_REQUIRE(variant == 0 || variant == 2 || variant == 4 || (variant == 6 && layer == 1) || (variant == 7 && layer >= 2), MI355PPO_EINVAL,
+                  "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(src, 16) && aligned(Bt, 16) && aligned(dst, 16) && aligned(inds, 8), MI355PPO_EALIGN,
                   "%s: src/Bt/dst must be 16-byte aligned", fn);
     if (variant == 6) return mi355ppo_cnn_conv1q_fwd(src, inds, Bt, bias, dst, images, stream);   // Bt = the mode-4 pack
+    if (variant == 7)                                                                               // Bt = the mode-6 pack
+        return convx_fwd(static_cast<const float*>(src), Bt, bias, dst, images, layer, as_stream(stream));
     ConvGeom g;
     g.H = g.W = Hin; g.C = Cin; g.KH = g.KW = KH; g.GY = g.GX = Hout; g.SS = SS; g.OFF = 0;
     g.DH = g.DW = Hout; g.DC = Cout; g.DM = 1; g.DAY = g.DAX = 0; g.K = KH * KH * Cin; g.N = Cout; g.classes = 1;

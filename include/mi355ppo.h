@@ -283,6 +283,10 @@ MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a
  *           fixed-point number on its output channel's scale, four signed radix-256 digits in the operand
  *           layout of v_mfma_i32_32x32x32_i8, + accumulator start values + per-channel scales;
  *           mi355ppo_cnn_conv1q_pack_bytes() = 33,408 bytes.  Consumed by forward variant 6.
+ *   mode 6  layers 2 and 3: the weights split into their three bf16 term planes (hi + mid + lo = the f32 weight,
+ *           exactly) in the fragment order of kernel C (csrc/convx.hip): [(kh,kw,cin) / 16][Cout / 32][term][64 lanes]
+ *           [8 bf16]; Cout*Cin*KH*KW*6 bytes = 49,152 / 55,296 floats of storage.  Consumed by forward variant 7
+ *           (layers 2 / 3 on the bf16 matrix pipe with exact products: the minibatch-sized forward).
  * modes 0-2 have Cout*Cin*KH*KW floats.
  */
 MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, float* Bt, int layer, int mode, void* stream);

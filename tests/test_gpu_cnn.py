@@ -175,6 +175,32 @@ def test_conv_fwd_f32(layer, images, variant):
     _close(got, _nhwc(ref), f"conv{layer} fwd")
 
 
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("images", [1, 19, 700, 7000])
+def test_conv_fwd_kernel_c_bf16_pipe_exact_products(layer, images):
+    """Kernel C (csrc/convx.hip): layers 2 / 3 forward on the bf16 matrix pipe, every f32 operand as three bf16 terms with
+    exact 3 x 3 products -- held to the bound of the f32-MFMA kernel (2e-5 of the result's scale vs float64) on activations with
+    a wide dynamic range and every low-order bit set, and compared with kernel F on the same inputs (the two differ by
+    summation order only).  The pack is checked through its layout: the three planes sum back to the weight, exactly."""
+    cin, cout, k, s, hin, hout = SPEC[layer]
+    g = torch.Generator().manual_seed(300 + layer + images)
+    x = torch.relu(torch.randn(images, cin, hin, hin, generator=g)) * torch.exp(torch.randn(images, cin, hin, hin, generator=g))
+    W, b = _params(layer, 4)
+    ref = F.relu(F.conv2d(x.double(), W.double(), b.double(), stride=s))
+    pack = cnn.repack_weights(W.to(DEV), layer, cnn.MODE_FWD_X)
+    planes = pack.view(torch.bfloat16).view(cin * k * k // 16, cout // 32, 3, 2, 32, 8).float().sum(2)      # [s][j][lh][li][e]
+    Wk = planes.permute(1, 3, 0, 2, 4).reshape(cout, k, k, cin).permute(0, 3, 1, 2)                          # co = 32 j + li; k = 16 s + 8 lh + e = (ty, tx, ci)
+    assert torch.equal(Wk.cpu(), W)
+    xd = _nhwc(x).to(DEV)
+    got = cnn.conv_fwd(xd, pack, b.to(DEV), layer, variant=cnn.VARIANT_X)
+    assert got.shape == (images, hout, hout, cout)
+    _close(got, _nhwc(ref), f"conv{layer} fwd (kernel C)")
+    f32 = cnn.conv_fwd(xd, cnn.repack_weights(W.to(DEV), layer), b.to(DEV), layer)
+    _close(got, f32, f"conv{layer} fwd: kernel C vs kernel F", tol=4e-6)
+    assert torch.equal((got == 0), (f32 == 0)) or ((got == 0) != (f32 == 0)).float().mean().item() < 1e-4       # the ReLU cuts at the same places
+    assert torch.equal(got, cnn.conv_fwd(xd, pack, b.to(DEV), layer, variant=cnn.VARIANT_X))                  # deterministic
+
+
 @pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 19, 128, 700, 7000])

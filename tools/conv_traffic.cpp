@@ -82,6 +82,9 @@ int main(int argc, char** argv) {
     ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3, 3, 0, st)); ABI(mi355ppo_cnn_repack_weights_f32(W2, bt2d, 2, 2, st));
     ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3d, 3, 1, st)); ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3c, 3, 3, st));
     ABI(mi355ppo_cnn_repack_weights_f32(W1, bt1q, 1, 4, st)); ABI(mi355ppo_cnn_repack_weights_f32(W2, bt2c, 2, 5, st));
+    float *bt2x = dalloc<float>(49152), *bt3x = dalloc<float>(55296);                                   // kernel C packs (mode 6)
+    ABI(mi355ppo_cnn_repack_weights_f32(W2, bt2x, 2, 6, st)); ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3x, 3, 6, st));
+    const bool fwd_f32 = getenv("CONV_TRAFFIC_FWD_F32") != nullptr;                                    // layers 2 / 3 forward on kernel F
     fill_f32<<<4096, 256, 0, st>>>(Wfc, 512 * 3136, 10u); fill_f32<<<4096, 256, 0, st>>>(Wfct, 3136 * 516, 11u);
     fill_f32<<<4096, 256, 0, st>>>(dzfc, (size_t)M * 516, 12u);
     CHECK(hipStreamSynchronize(st));
@@ -98,8 +101,13 @@ int main(int argc, char** argv) {
 #define TIMED(i, call) do { CHECK(hipEventRecord(ev[i][0], st)); ABI(call); CHECK(hipEventRecord(ev[i][1], st)); } while (0)
     for (int r = 0; r < reps; r++) {                                // one minibatch update's conv launches, in order
         TIMED(0, mi355ppo_cnn_conv_fwd_f32_variant(obs, inds, bt1q, bias, a1, M, 1, 6, st));        // kernel Q
-        TIMED(1, mi355ppo_cnn_conv_fwd_f32(a1, nullptr, bt2, bias, a2, M, 2, st));
-        TIMED(2, mi355ppo_cnn_conv_fwd_f32(a2, nullptr, bt3, bias, a3, M, 3, st));
+        if (fwd_f32) {
+            TIMED(1, mi355ppo_cnn_conv_fwd_f32(a1, nullptr, bt2, bias, a2, M, 2, st));
+            TIMED(2, mi355ppo_cnn_conv_fwd_f32(a2, nullptr, bt3, bias, a3, M, 3, st));
+        } else {
+            TIMED(1, mi355ppo_cnn_conv_fwd_f32_variant(a1, nullptr, bt2x, bias, a2, M, 2, 7, st));    // kernel C
+            TIMED(2, mi355ppo_cnn_conv_fwd_f32_variant(a2, nullptr, bt3x, bias, a3, M, 3, 7, st));
+        }
         TIMED(8, mi355ppo_fc_fwd_relu_f32(a3, Wfc, bias, hfc, (int)M, 512, 3136, st));               // kernel X forward (bias: first 512 of a larger fill below)
         TIMED(9, mi355ppo_fc_dgrad_mask_f32(dzfc, 516, Wfct, 516, a3, dz3, (int)M, 3136, 512, st)); // kernel X data gradient + (a3 > 0)
         TIMED(10, mi355ppo_fc_wgrad_f32(dzfc, 516, a3, dWfc, (int)M, 512, 3136, 64, wsfc, wsfcb, st));  // kernel Y + its slab reduction
