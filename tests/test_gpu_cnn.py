@@ -404,6 +404,43 @@ def test_heads_backward_relu_variant(M, A):
     assert torch.all(fused[0].as_strided((M, 4), (516, 1), fused[0].storage_offset() + 512) == 7.0)       # the padding is not written
 
 
+def test_fc_kernels_at_the_full_minibatch_size_against_float64_on_the_device():
+    """Config-C minibatch (32,768 rows): kernels X (forward, data gradient + mask) and Y (weight gradient, nine slabs) against
+    torch's float64 GEMMs run on the GPU -- the CPU cannot produce a 105-GFLOP float64 reference in test time, the device can.
+    Same bounds as at the small sizes; the library's f32 GEMM calibrates the weight-gradient bound (32,768 f32 accumulations)."""
+    M = 32768
+    g = torch.Generator(device=DEV).manual_seed(77)
+    a = torch.relu(torch.randn(M, 3136, device=DEV, generator=g)) * torch.exp(torch.randn(M, 3136, device=DEV, generator=g))
+    W = torch.randn(512, 3136, device=DEV, generator=g) / 56.0
+    b = torch.randn(512, device=DEV, generator=g) * 0.1
+    dz = torch.randn(M, 512, device=DEV, generator=g) * (torch.rand(M, 512, device=DEV, generator=g) > 0.4)
+    a64, W64, dz64 = a.double(), W.double(), dz.double()
+    _close(cnn.fc_fwd_relu(a, W, b), torch.relu(a64 @ W64.t() + b.double()), "fc fwd (kernel X) at 32768")
+    Wt = torch.empty((3136, 516), device=DEV)[:, :512]
+    Wt.copy_(W.t())
+    _close(cnn.fc_dgrad_mask(dz, Wt, a), (dz64 @ W64) * (a > 0), "fc dgrad + mask (kernel X) at 32768")
+    ref = dz64.t() @ a64
+    got = cnn.fc_wgrad(dz, a)
+    scale = ref.abs().max().item()
+    err, err_t = (got.double() - ref).abs().max().item(), ((dz.t() @ a).double() - ref).abs().max().item()
+    assert err <= max(2e-5 * scale, 4.0 * err_t), f"dW at 32768: err {err:.3e}, library f32 err {err_t:.3e}, scale {scale:.3e}"
+
+
+def test_kernel_c_agrees_with_kernel_f_at_the_full_minibatch_size():
+    """32,768 images: the bf16-pipe forward of layers 2 / 3 (kernel C) against the f32-pipe kernel F on the same activations --
+    both compute exact products with f32 accumulation, in different orders."""
+    M = 32768
+    g = torch.Generator(device=DEV).manual_seed(78)
+    for layer in (2, 3):
+        cin, cout, k, s, hin, hout = SPEC[layer]
+        x = torch.relu(torch.randn(M, hin, hin, cin, device=DEV, generator=g))
+        W, b = (t.to(DEV) for t in _params(layer, 60 + layer))
+        f = cnn.conv_fwd(x, cnn.repack_weights(W, layer), b, layer)
+        c = cnn.conv_fwd(x, cnn.repack_weights(W, layer, cnn.MODE_FWD_X), b, layer, variant=cnn.VARIANT_X)
+        _close(c, f, f"conv{layer} fwd at 32768: kernel C vs kernel F", tol=4e-6)
+        del x, f, c
+
+
 def test_full_minibatch_size_properties():
     """Config-C minibatch (32,768 images, where a float64 CPU convolution is out of reach): size-independent properties.
     The data and weight gradients are LINEAR in dz (the ReLU mask depends on the activation only); the forward of a
