@@ -124,6 +124,33 @@ int main(int argc, char** argv) {
         }
     }
     CHECK(hipStreamSynchronize(st));
+    if (getenv("CONV_TRAFFIC_PAIRS")) {
+        // two-stream experiment: kernels with complementary bottlenecks side by side.  Pairs that are independent in the
+        // backward pass: (layer-1 wgrad = kernel P: VALU-bound) with (layer-2 wgrad: matrix-pipe-bound), both need only dz1 / dz2.
+        hipStream_t st2; CHECK(hipStreamCreate(&st2));
+        void* ws2; CHECK(hipMalloc(&ws2, wsb));
+        hipEvent_t e0, e1, e2, f0;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&e2)); CHECK(hipEventCreate(&f0));
+        float serial = 0, both = 0;
+        for (int r = 0; r < 4; r++) {
+            CHECK(hipEventRecord(e0, st));
+            ABI(mi355ppo_cnn_conv_wgrad_f32(a1, nullptr, dz2, dW2, db2, M, 2, ws, wsb, st));
+            ABI(mi355ppo_cnn_conv_wgrad_f32(obs, inds, dz1, dW1, db1, M, 1, ws, wsb, st));
+            CHECK(hipEventRecord(e1, st));
+            CHECK(hipStreamSynchronize(st));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (r) serial += ms;
+            CHECK(hipEventRecord(e0, st));
+            CHECK(hipStreamWaitEvent(st2, e0, 0));
+            ABI(mi355ppo_cnn_conv_wgrad_f32(a1, nullptr, dz2, dW2, db2, M, 2, ws2, wsb, st2));
+            ABI(mi355ppo_cnn_conv_wgrad_f32(obs, inds, dz1, dW1, db1, M, 1, ws, wsb, st));
+            CHECK(hipEventRecord(f0, st2));
+            CHECK(hipStreamWaitEvent(st, f0, 0));
+            CHECK(hipEventRecord(e2, st));
+            CHECK(hipStreamSynchronize(st));
+            CHECK(hipEventElapsedTime(&ms, e0, e2)); if (r) both += ms;
+        }
+        std::printf("{\"pair\": \"wgrad2 || wgrad1\", \"serial_us\": %.1f, \"two_streams_us\": %.1f}\n", serial / 3 * 1e3f, both / 3 * 1e3f);
+    }
     {
         const char* nm[11] = {"fwd1", "fwd2", "fwd3", "wgrad3", "dgrad3", "wgrad2", "dgrad2", "wgrad1", "fc_fwd", "fc_dgrad", "fc_wgrad"};
         const int nt = reps > 1 ? reps - 1 : 1;
