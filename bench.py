@@ -96,17 +96,50 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--local-num-envs", type=int, default=1024)
-    p.add_argument("--num-steps", type=int, default=128)
+    p.add_argument("--config", choices=sorted(CONFIGS), default="C",
+                   help="BASELINE.json workload: C = configs[2] (default, the configuration the metric is quoted on); "
+                        "B = configs[1] (128 envs); D = configs[3] at its per-GPU size (256 envs); E = configs[4] "
+                        "(ppo_continuous_action, Normal kernels)")
+    p.add_argument("--local-num-envs", type=int, default=None, help="override the config's envs per GPU")
+    p.add_argument("--num-steps", type=int, default=None, help="override the config's rollout length")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                   help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only with --same-device)")
+    p.add_argument("--same-device", action="store_true",
+                   help="PLUMBING SMOKE, not a measurement: run all --gpus ranks on cuda:0 (needs --backend gloo: RCCL refuses "
+                        "two ranks on one device).  Exercises the launcher, barrier, max-over-ranks timing and rank-0 JSON line")
     p.add_argument("--n-actions", type=int, default=4)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-baseline-envs", type=int, default=128)
+    p.add_argument("--cpu-baseline-envs", type=int, default=64)
     p.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets (pure SPS run)")
     p.add_argument("--no-rollout-graphs", action="store_true", help="issue the rollout kernel by kernel instead of one hipGraph per step")
     p.add_argument("--no-pcie-inclusive", action="store_true", help="skip the host-env (PCIe-inclusive) leg after the timed region")
     p.add_argument("--pcie-env-groups", type=int, default=2)
-    return p.parse_args()
+    cli = p.parse_args()
+    cfg = CONFIGS[cli.config]
+    if cli.local_num_envs is None:
+        cli.local_num_envs = cfg["local_num_envs"]
+    if cli.num_steps is None:
+        cli.num_steps = cfg["num_steps"]
+    if cli.same_device and cli.backend != "gloo":
+        p.error("--same-device needs --backend gloo (RCCL refuses two ranks on one device)")
+    return cli
+
+
+# BASELINE.json's configs, as bench workloads (per GPU).  Every image config runs the same code path: NatureCNN A = 4,
+# 4 epochs x 4 minibatches, synthetic 84x84x4 uint8 frames from the device-resident generator.
+CONFIGS = {
+    "B": dict(local_num_envs=128, num_steps=128,
+              workload="configs[1]: ppo_atari_envpool Breakout-v5 num_envs=128 num_steps=128 (minibatch 4,096 rows)"),
+    "C": dict(local_num_envs=1024, num_steps=128,
+              workload="configs[2]: ppo_atari Breakout num_envs=1024/GPU num_steps=128 (minibatch 32,768 rows)"),
+    "D": dict(local_num_envs=256, num_steps=128,
+              workload="configs[3] at its per-GPU size: ppo_atari_multigpu Breakout local_num_envs=256 num_steps=128 "
+                       "(minibatch 8,192 rows)"),
+    "E": dict(local_num_envs=64, num_steps=2048,
+              workload="configs[4]: ppo_continuous_action HalfCheetah-v4-shaped (obs 17, act 6) num_envs=64 num_steps=2048, "
+                       "32 minibatches x 10 epochs, Normal sample + log_prob / fused Normal loss kernels"),
+}
 
 
 class KernelTimer:
@@ -145,6 +178,8 @@ def self_launch(cli) -> int:
     import subprocess
 
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if cli.same_device and have >= 1:
+        have = cli.gpus                              # plumbing smoke: every rank on cuda:0
     if have < cli.gpus:
         print(f"bench.py: --gpus {cli.gpus} requested but this box has {have} GPU(s); refusing to run fewer ranks than asked",
               file=sys.stderr)
@@ -166,12 +201,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == cli.gpus, f"--gpus {cli.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU"
     assert torch.cuda.is_available(), "bench.py measures the MI355X path and needs a GPU"
-    assert torch.cuda.device_count() > local_rank, f"rank {rank}: no GPU {local_rank} on this box ({torch.cuda.device_count()} visible)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device(f"cuda:{local_rank}")
+    dev_index = 0 if cli.same_device else local_rank
+    assert torch.cuda.device_count() > dev_index, f"rank {rank}: no GPU {dev_index} on this box ({torch.cuda.device_count()} visible)"
+    torch.cuda.set_device(dev_index)
+    device = torch.device(f"cuda:{dev_index}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if cli.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)     # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)                       # --same-device smoke only
+    if cli.config == "E":
+        return main_continuous(cli, rank, world, device)
 
     from cleanrl_amd import _lib, learner_smoke, ops
     from cleanrl_amd.agents import AtariAgent
@@ -301,10 +342,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "configs[2]: ppo_atari Breakout num_envs=1024/GPU num_steps=128, synthetic 84x84x4 uint8 "
-                            "observations resident in HBM, NatureCNN A=4, 4 epochs x 4 minibatches",
+                "workload": CONFIGS[cli.config]["workload"] + ", synthetic 84x84x4 uint8 observations resident in HBM, "
+                            "NatureCNN A=4, 4 epochs x 4 minibatches",
+                "baseline_config": cli.config,
                 "local_num_envs": N, "num_steps": T, "global_num_envs": world * N, "minibatch_rows": M,
-                "parallelism": f"dp{world} (one learner per GPU, RCCL all-reduce of the flat f32 gradient)",
+                "parallelism": f"dp{world} (one learner per GPU, RCCL all-reduce of the flat f32 gradient)" if not cli.same_device
+                               else f"dp{world} SAME-DEVICE PLUMBING SMOKE (all ranks on cuda:0, gloo): not a measurement",
                 "env": "device-resident synthetic generator (no PCIe in the timed region)",
                 "rollout": "one hipGraph per env step (policy forward, sampling, env step, observation store)"
                            if getattr(learner, "_rollout_graphs", None) else "kernel-by-kernel launches",
@@ -397,18 +440,18 @@ def main():
         if world == 1 and not cli.no_cpu_baseline:
             from oracle import cpu_ppo_port
 
-            # warm the host first (thread pool, oneDNN primitives, allocator) with a small untimed iteration, then time ONE
-            # full iteration at BASELINE configs[1]'s size (ppo_atari_envpool: 128 envs x 128 steps)
-            cpu_ppo_port.run(num_envs=8, num_steps=16, iterations=1, seed=cli.seed, n_actions=cli.n_actions)
-            cb = cpu_ppo_port.run(num_envs=cli.cpu_baseline_envs, num_steps=T, iterations=1, warmup_iterations=0,
+            # one untimed warm-up iteration AT THE TIMED SHAPE (thread pool, oneDNN primitives and the allocator see the timed
+            # shapes), then two timed iterations of the ppo_atari_envpool loop body; the median iteration is reported
+            cb = cpu_ppo_port.run(num_envs=cli.cpu_baseline_envs, num_steps=128, iterations=2, warmup_iterations=1,
                                   seed=cli.seed, n_actions=cli.n_actions)
             out["cpu_baseline"] = {
-                "value": cb["sps"], "unit": "env-steps/s", "cores": cb["cores"], "kind": "port",
-                "sample": f"{cb['iterations']} full PPO iteration of the reference loop body (ppo_atari_envpool.py:217-341 restated in "
+                "value": cb["sps_median"], "unit": "env-steps/s", "cores": cb["cores"], "kind": "port",
+                "sample": f"{cb['iterations']} full PPO iterations of the reference loop body (ppo_atari_envpool.py:217-341 restated in "
                           f"stock torch CPU ops, f32 observation storage, oracle/cpu_ppo_port.py) at num_envs={cb['num_envs']} x "
-                          f"num_steps={cb['num_steps']} = {cb['env_steps']} env-steps in {cb['seconds']:.1f} s after a small warm-up "
-                          f"iteration; host cpu_count={os.cpu_count()}; the reference script itself cannot run on this box (no "
-                          f"envpool / gym / tyro, and /root/reference does not travel), hence kind=port",
+                          f"num_steps={cb['num_steps']} = {cb['env_steps']} env-steps in {cb['seconds']:.1f} s (median iteration "
+                          f"reported; per-iteration s: {[round(x, 2) for x in cb['iteration_seconds']]}) after one untimed warm-up "
+                          f"iteration of the same shape; host cpu_count={os.cpu_count()}; the reference script itself cannot run "
+                          f"on this box (no envpool / gym / tyro, and /root/reference does not travel), hence kind=port",
             }
         if world == 1 and not cli.no_pcie_inclusive:
             # never `value`: the same learner fed by HOST envs (numpy stand-ins on host threads), actions D2H and frames H2D
@@ -426,6 +469,130 @@ def main():
             out["pcie_inclusive"] = {"overlapped": ov, "serial_reference_arrangement": se,
                                      "note": "whole PPO iterations with the envs on the host; not comparable with `value`, whose "
                                              "inputs are resident in HBM"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_continuous(cli, rank, world, device):
+    """``--config E``: BASELINE configs[4], ppo_continuous_action (HalfCheetah-v4-shaped obs 17 / act 6, 64 envs x 2048 steps,
+    32 minibatches x 10 epochs; ppo_continuous_action.py:54-76 defaults) on the Normal kernels: K2' sample + log_prob per env
+    step, K1 GAE over (2048, 64), K3' fused Normal loss forward + backward per minibatch, K6 clip + Adam.  The 64-64 tanh
+    MLPs are torch Linear layers (library GEMMs: plumbing).  Env = device-resident stand-in (no PCIe in the timed region)."""
+    from cleanrl_amd import _lib, learner_smoke, ops
+    from cleanrl_amd.agents import ContinuousAgent
+    from cleanrl_amd.envs import DeviceSyntheticContinuousVecEnv
+    from cleanrl_amd.learner import PPOLearner
+
+    _lib.load(build_if_missing=True)
+    N, T = cli.local_num_envs, cli.num_steps
+    args = learner_smoke.default_args(num_steps=T, num_minibatches=32, update_epochs=10, learning_rate=3e-4, clip_coef=0.2,
+                                      ent_coef=0.0, vf_coef=0.5)         # ppo_continuous_action.py:54-76
+    seed = cli.seed + rank
+    np.random.seed(seed)
+    torch.manual_seed(cli.seed)
+    env = DeviceSyntheticContinuousVecEnv(N, device, seed=seed)
+    agent = ContinuousAgent(env).to(device)
+    torch.manual_seed(seed)
+    learner = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, device, world_size=world,
+                         sample_seed=seed)
+    learner.observe(0, env.obs(), learner.dones[0])
+    timer = KernelTimer()
+    if not cli.no_kernel_timing:
+        seen = {"n": 0}
+        real_sample = ops.normal_sample
+
+        def sample_hook(*a, **kw):                    # rollout launches: bracket every 16th (the rollout is host-bound)
+            seen["n"] += 1
+            return real_sample(*a, **kw) if seen["n"] % 16 else timer.wrap("normal_sample", real_sample)(*a, **kw)
+
+        ops.normal_sample = sample_hook
+        ops.gae = timer.wrap("gae", ops.gae)
+        ops.ppo_loss_normal = timer.wrap("loss_normal", ops.ppo_loss_normal)
+        ops.clip_adam_ = timer.wrap("clip_adam", ops.clip_adam_)
+    total_iters = cli.warmup + cli.steps
+    phase_events = []
+
+    def one_step(i):
+        lr = (1.0 - i / max(total_iters, 1)) * args.learning_rate
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        for step in range(T):                                                     # ppo_continuous_action.py:205-228
+            action = learner.act(step)
+            next_obs, reward, done = env.step(action)
+            learner.store_reward(step, reward)
+            learner.observe(step + 1, next_obs, done)
+        learner.finish_rollout()
+        ev[1].record()
+        m = learner.update(lr)
+        learner.start_iteration()
+        ev[2].record()
+        phase_events.append(ev)
+        return m
+
+    for i in range(cli.warmup):
+        one_step(i)
+    timer.reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(cli.steps):
+        metrics = one_step(cli.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    learner.flat.check_views()
+    assert np.isfinite(metrics["loss"]), metrics
+    if rank == 0:
+        M, D, O = learner.minibatch_size, env.act_dim, env.obs_dim
+        out = {
+            "metric": "env-steps/sec (SPS) PPO Breakout num_envs=1024 @1/2/4/8 MI355X; GAE HBM GB/s",
+            "value": world * N * T * cli.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": cli.steps,
+            "warmup": cli.warmup, "ms_per_step": elapsed / cli.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": CONFIGS["E"]["workload"] + "; NOT the configuration the metric is quoted on (that is "
+                                   "--config C): a parity / coverage workload of BASELINE.json's configs list",
+                       "baseline_config": "E", "local_num_envs": N, "num_steps": T, "minibatch_rows": M, "obs_dim": O, "act_dim": D,
+                       "parallelism": f"dp{world}",
+                       "env": "device-resident linear-system stand-in (torch ops on the learner's stream; no PCIe in the timed region)",
+                       "network": "two 64-64 tanh MLPs as torch Linear layers (library GEMMs)"},
+            "final_loss": metrics["loss"],
+        }
+        timed = phase_events[-cli.steps:]
+        out["phases_ms"] = {"rollout_incl_gae": float(np.mean([e[0].elapsed_time(e[1]) for e in timed])),
+                            "update": float(np.mean([e[1].elapsed_time(e[2]) for e in timed])),
+                            "note": "GPU-timeline split; with ~25 launches per env step and ~45 per minibatch of <= 10 us each, both "
+                                    "phases are bound by host launch issue, not by any kernel"}
+        if not cli.no_kernel_timing:
+            alg = {"gae": 20 * T * N + 8 * N,                                      # SURVEY 8d
+                   "loss_normal": (12 * D + 28 + 8) * M,                           # mean, action in; dmean out; 5 behaviour scalars, new value; dvalue; indices
+                   "normal_sample": (4 * D + 4 * D + 4 + 4) * N,                   # mean in; action, logprob out (+ entropy)
+                   "clip_adam": 36 * learner.flat.numel}
+            ks = {}
+            for k, b in alg.items():
+                us, n = timer.mean_us(k)
+                if n:
+                    ks[k] = {"algorithmic_bytes": b, "avg_us_event_bracket": us, "GBps": b / us / 1e3, "launches_timed": n,
+                             "frac_of_hbm_peak": b / us / 1e3 / HBM_PEAK_GBPS}
+            out["kernels"] = ks
+            dom = "loss_normal"
+            if dom in ks:
+                out["roofline"] = {
+                    "kernel": "loss_normal_main (K3', csrc/loss.hip): fused Normal log_prob + entropy + clipped surrogate + value loss, "
+                              f"forward + backward, one minibatch of {M} rows x {D} action dims",
+                    "bound": "hbm", "achieved": ks[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ks[dom]["frac_of_hbm_peak"], "traffic": None,
+                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_us": ks[dom]["avg_us_event_bracket"],
+                    "launches_timed": ks[dom]["launches_timed"],
+                    "note": f"{alg[dom]} B per launch is cache-resident: the launch is latency-bound (event brackets include launch overhead)",
+                }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -67,6 +67,8 @@ SIGNATURES = {
     "mi355ppo_fc_wgrad_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
 }
 
+ABI_VERSION = 120       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+
 _lib = None
 
 
@@ -100,8 +102,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     v = lib.mi355ppo_version()
-    if v // 100 != 1:
-        raise RuntimeError(f"libmi355ppo.so reports version {v}; this binding expects 1xx -- rebuild it")
+    if v // 10 != ABI_VERSION // 10:         # major and minor: a signature change bumps the minor (arguments would shift silently)
+        raise RuntimeError(f"libmi355ppo.so reports ABI version {v}; this binding expects {ABI_VERSION // 10}x -- rebuild it "
+                           "(`python -m cleanrl_amd.build`)")
     _lib = lib
     return lib
 

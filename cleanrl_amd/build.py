@@ -69,6 +69,12 @@ def build_tools(verbose: bool = True) -> str:
               "-lmi355ppo", "-Wl,-rpath,$ORIGIN/../cleanrl_amd/csrc"])
         if verbose:
             print(f"[cleanrl_amd.build] built {exe}", file=sys.stderr)
+    # the matrix-pipe floor microbenchmark (tools/mfma_floor.cpp: cycles per MFMA on random operands, with VALU fillers)
+    fsrc, fexe = os.path.join(root, "tools", "mfma_floor.cpp"), os.path.join(root, "tools", "mfma_floor")
+    if os.path.exists(fsrc) and _stale(fexe, [fsrc]):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", fsrc, "-o", fexe])
+        if verbose:
+            print(f"[cleanrl_amd.build] built {fexe}", file=sys.stderr)
     return exe
 
 

@@ -30,6 +30,12 @@ VARIANT_X = 7                       # layer-2 / 3 forward on the bf16 matrix pip
 _FWD23_BF16 = os.environ.get("MI355PPO_FWD23", "f32") == "bf16"      # minibatch-sized forward of layers 2 / 3: kernel F (default) or kernel C
 
 
+def extra_forward_modes():
+    """(layer, mode) pairs NatureTrunkFn.forward requests beyond (1, FWD_Q), (2, FWD), (3, FWD) at some batch size; the
+    learner derives them before the env-group lanes start, so that lanes only ever READ the weight cache."""
+    return [(2, MODE_FWD_X), (3, MODE_FWD_X)] if _FWD23_BF16 else []
+
+
 def xpack_numel(layer: int) -> int:
     """f32 storage elements of the mode-6 pack: three bf16 planes = 6 bytes per weight."""
     cin, cout, k, _, _, _ = LAYERS[layer]

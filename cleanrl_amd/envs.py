@@ -136,10 +136,17 @@ class SyntheticAtariVecEnv:
     Observation n at time t is planes[c_n+t .. c_n+t+3] of a fixed random plane pool (so consecutive
     observations share 3 of 4 channels, like FrameStack); reward in {-1,0,+1} with P=(.05,.9,.05);
     episode ends Bernoulli(1/200) (then the cursor jumps).  Actions are accepted and ignored.
+
+    ``autoreset="same_step"`` (gym < 1.0 vector envs): the step that reports done already returns the next episode's first
+    stack.  ``"next_step"`` (envpool's gym API, gymnasium >= 1.0): that step returns the episode's last stack, and the
+    FOLLOWING call returns the fresh stack with done = False and reward 0.
     """
 
     def __init__(self, num_envs: int, seed: int = 0, n_actions: int = 4, pool_planes: int = 2048, api: str = "gymnasium",
-                 done_p: float = 1.0 / 200.0, frames: int = 4):
+                 done_p: float = 1.0 / 200.0, frames: int = 4, autoreset: str = "same_step"):
+        assert autoreset in ("same_step", "next_step")
+        self.autoreset = autoreset
+        self._pending = np.zeros(num_envs, bool)       # next_step mode: envs whose next call is their reset
         self.num_envs, self.api, self.done_p = num_envs, api, done_p
         self.single_observation_space = Box(0, 255, (frames, 84, 84), np.uint8)      # frames = 1: FrameStack(1) of ppo_atari_lstm.py:105
         self.single_action_space = Discrete(n_actions)
@@ -162,6 +169,7 @@ class SyntheticAtariVecEnv:
             self.rng = np.random.RandomState(seed)
         self.cursor = self.rng.randint(0, len(self.planes), size=self.num_envs).astype(np.int64)
         self.stats = _EpisodeStats(self.num_envs)
+        self._pending[:] = False
         obs = self._obs(out)
         return obs if self.api == "gym" else (obs, {})
 
@@ -171,7 +179,13 @@ class SyntheticAtariVecEnv:
         done = self.rng.random_sample(n) < self.done_p
         self.cursor += 1
         jump = self.rng.randint(0, len(self.planes), size=n)
-        self.cursor = np.where(done, jump, self.cursor)
+        if self.autoreset == "next_step":
+            reward = np.where(self._pending, 0.0, reward)
+            done = done & ~self._pending                                  # the reset call itself reports done = False
+            self.cursor = np.where(self._pending, jump, self.cursor)
+            self._pending = done.copy()
+        else:
+            self.cursor = np.where(done, jump, self.cursor)
         r, l = self.stats.update(reward.astype(np.float32), done)
         obs = self._obs(out)
         if self.api == "gym":       # envpool gym-style 4-tuple (ppo_atari_envpool.py:237-247)
@@ -276,6 +290,51 @@ class DeviceSyntheticAtariVecEnv:
 
     def step_into(self, obs_out, reward_out, done_out):
         return self._call(obs_out, reward_out, done_out, True)
+
+    def close(self):
+        pass
+
+
+class DeviceSyntheticContinuousVecEnv:
+    """``SyntheticContinuousVecEnv`` (HalfCheetah-v4-shaped: obs 17, act 6) stepped in HBM with a handful of torch ops on
+    the learner's stream, for ``bench.py --config E``: observations, rewards and dones are device tensors, so the timed
+    region holds no PCIe traffic.  A stand-in env (plumbing), not part of the hot path."""
+
+    def __init__(self, num_envs: int, device, seed: int = 0, obs_dim: int = 17, act_dim: int = 6, noise_bank: int = 257,
+                 horizon: int = 1000):
+        import torch
+
+        self.torch, self.device = torch, device
+        self.num_envs, self.obs_dim, self.act_dim, self.horizon = num_envs, obs_dim, act_dim, horizon
+        self.single_observation_space = Box(-np.inf, np.inf, (obs_dim,))
+        self.single_action_space = Box(-1.0, 1.0, (act_dim,))
+        rs = np.random.RandomState(seed + 777)
+        a = rs.standard_normal((obs_dim, obs_dim)) / math.sqrt(obs_dim)
+        A = 0.9 * a / max(1.0, np.abs(np.linalg.eigvals(a)).max())
+        f32 = lambda x: torch.as_tensor(np.asarray(x, np.float32), device=device)   # noqa: E731
+        self.At, self.B = f32(A.T.copy()), f32(rs.standard_normal((act_dim, obs_dim)) * 0.3)
+        self.w = f32(rs.standard_normal(obs_dim) / math.sqrt(obs_dim))
+        self.noise = f32(0.01 * rs.standard_normal((noise_bank, num_envs, obs_dim)))
+        self.state = f32(0.1 * rs.standard_normal((num_envs, obs_dim)))
+        self.reset_state = self.state.clone()
+        self.steps = torch.zeros(num_envs, device=device)
+        self._k = 0
+
+    def obs(self):
+        return self.state
+
+    def step(self, action):
+        """-> (next_obs (N,obs) f32, reward (N) f32, done (N) f32), all on the device."""
+        t = self.torch
+        a = action.clamp(-1.0, 1.0)                                              # ClipAction (ppo_continuous_action.py:96)
+        nxt = t.addmm(self.noise[self._k % self.noise.shape[0]], self.state, self.At).addmm_(a, self.B)
+        self._k += 1
+        reward = nxt @ self.w - 0.1 * (a * a).sum(1)
+        self.steps += 1.0
+        done = (self.steps >= self.horizon).float()                              # 1000-step truncation
+        self.steps.mul_(1.0 - done)
+        self.state = t.where(done[:, None] > 0, self.reset_state, nxt)
+        return self.state, reward, done
 
     def close(self):
         pass

@@ -206,6 +206,8 @@ class PPOLearner:
         bufs.weights(net[0].weight, 1, cnn.MODE_FWD_Q)
         bufs.weights(net[2].weight, 2, cnn.MODE_FWD)
         bufs.weights(net[4].weight, 3, cnn.MODE_FWD)
+        for layer, mode in cnn.extra_forward_modes():    # whatever else NatureTrunkFn.forward may ask for at a lane's batch size
+            bufs.weights(net[2 * layer - 2].weight, layer, mode)
         bufs.fc_weight(net[7].weight)
 
     def _features(self, obs_rows):
@@ -402,6 +404,16 @@ class PPOLearner:
         self.forward_backward_hip(idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, scalars_out)
         if self.world_size > 1:
             g = self.flat.grads
+            # Stream-ordering audit for the nccl (RCCL) backend -- every statement below was checked against
+            # ProcessGroupNCCL's semantics, which differ from gloo's (gloo's wait() blocks the HOST; nccl's only orders streams):
+            #  * a collective is enqueued on RCCL's internal stream AFTER an event recorded on the current (compute) stream
+            #    at call time, so it reads gradient values every kernel launched before the call has written -- the early
+            #    piece's hook fires after the FC weight-gradient kernel was launched on the compute stream;
+            #  * a blocking call (async_op=False) and Work.wait() both make the CURRENT stream wait for the collective: the
+            #    fused norm + clip + Adam kernels of optimizer_step_hip() are launched on that same stream afterwards, so
+            #    they read the reduced buffer, never a partially reduced one; nothing else reads flat.grads;
+            #  * the three pieces are disjoint slices of one buffer, so the in-flight early piece and the two late ones
+            #    never touch the same bytes; the buffer is zeroed by the Adam kernel, i.e. after all three completed.
             if self._ar_work is not None:                                 # :367 in three pieces: the early bucket is in flight
                 off, n = self._ar_early
                 if off > 0:

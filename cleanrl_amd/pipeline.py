@@ -9,8 +9,12 @@ GPU runs lane B's policy forward and the copy engine moves lane B's frames -- no
 trajectories as the serial loop (a group's envs only ever see their own actions, the policy is fixed during a rollout).
 
 PCIe bytes: frames travel as uint8 through pinned memory, and for FrameStack(4) envs only the NEWEST 84x84 plane of every
-env that was not reset (``frame_delta``): the device rebuilds the stack from the previous row (``obs_shift_append_u8``);
-envs flagged done send their full stack.  7 KB per env and step instead of the reference's 113 KB of f32.
+env whose stack is the previous one shifted by a frame (``frame_delta``): the device rebuilds the stack from the previous
+row (``obs_shift_append_u8``).  An env sends its full stack when it may have been reset -- its done flag is set at this step
+(same-step autoreset: gym < 1.0 vector envs) OR was set at the previous one (next-step autoreset: envpool's gym API,
+gymnasium >= 1.0, where the call AFTER done returns the fresh stack with done = False) -- and whenever a host-side probe
+(one pixel row of each of the three carried planes, 252 bytes per env) finds that the new stack is not the old one shifted
+(``full_stack_rows``).  7 KB per env and step instead of the reference's 113 KB of f32.
 
 Sampling stays deterministic: the Philox offset of (step, group) is reserved up front (``_SampleCounter.reserve``), so the
 action streams do not depend on thread timing.
@@ -24,6 +28,23 @@ import numpy as np
 import torch
 
 StepFn = Callable[[int, np.ndarray, int], tuple]      # (group, actions, step) -> (next_obs, reward, next_done) as numpy
+
+PROBE_ROW = 41        # the pixel row of every plane the shift probe compares
+
+
+def stack_probe(obs: np.ndarray) -> np.ndarray:
+    """(n, 4, 84, 84) uint8 stacks -> (n, 4, 84) copy of one pixel row per plane."""
+    return np.array(obs[:, :, PROBE_ROW, :])
+
+
+def full_stack_rows(done, prev_done, probe, prev_probe) -> np.ndarray:
+    """Indices of the envs that must send their whole 4-plane stack this step instead of the newest plane only: flagged done
+    now (same-step autoreset), flagged done at the previous step (next-step autoreset: this call returned the fresh stack),
+    or planes 0-2 of the new stack are not planes 1-3 of the previous one on the probe row (any other discontinuity)."""
+    need = np.asarray(done).astype(bool) | np.asarray(prev_done).astype(bool)
+    if prev_probe is not None:
+        need = need | (probe[:, :3] != prev_probe[:, 1:]).any(axis=(1, 2))
+    return np.flatnonzero(need)
 
 
 class _Lane:
@@ -53,6 +74,8 @@ class _Lane:
             self.pin_new = torch.zeros((n, 84, 84), dtype=torch.uint8).pin_memory()
             self.pin_new_np = self.pin_new.numpy()
             self.dev_new = torch.zeros((n, 84, 84), dtype=torch.uint8, device=dev)
+            self.prev_done = np.zeros(n, bool)          # done flags of the previous step (next-step autoreset envs)
+            self.prev_probe = None                      # stack_probe() of the previous observation
 
     def rows(self, t):
         return t[self.lo:self.hi]
@@ -78,11 +101,15 @@ class _Lane:
             done_dst.copy_(torch.as_tensor(np.asarray(done), dtype=torch.float32))
             return
         np.copyto(self.pin_rd_np[0], done, casting="unsafe")
+        if self.delta and first:
+            self.prev_probe, self.prev_done = stack_probe(np.asarray(obs)), np.asarray(done).astype(bool)
         if self.delta and not first:
             prev_rows = self.rows(L._slot(step - 1)[0])
             obs = np.asarray(obs)
             np.copyto(self.pin_new_np, obs[:, 3])                              # the newest plane of every env: 7 KB each
-            reset = np.flatnonzero(np.asarray(done))
+            probe = stack_probe(obs)
+            reset = full_stack_rows(done, self.prev_done, probe, self.prev_probe)
+            self.prev_probe, self.prev_done = probe, np.asarray(done).astype(bool)
             for j, i in enumerate(reset):
                 np.copyto(self.pin_obs_np[j], obs[i])                          # reset envs: their whole (fresh) stack
             self.dev_new.copy_(self.pin_new, non_blocking=True)

@@ -152,7 +152,10 @@ def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: in
 
         grouped = GroupedRollout(learner, len(groups), frame_delta=bool(getattr(args, "frame_delta", True)))
         for g, ge in enumerate(groups):
-            o = ge.reset() if env_api in ("gym", "procgen", "pettingzoo") else ge.reset(seed=args.seed + g)[0]
+            # gymnasium's SyncVectorEnv seeds env i of a group with seed + i: offset every group by its first env's index, so the
+            # union over the groups is seed .. seed + N - 1, the single-vector-env case (no two envs share a seed)
+            o = (ge.reset() if env_api in ("gym", "procgen", "pettingzoo")
+                 else ge.reset(seed=args.seed + g * (local_num_envs // len(groups)))[0])
             grouped.first_observation(g, o)
     else:
         if env_api in ("gym", "procgen", "pettingzoo"):             # envpool / procgen / supersuit: reset() returns obs only (:214)

@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 100 /* 0.1.0 */
+#define MI355PPO_VERSION 120 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+                                  point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2: round 3); a binding
+                                  must check major AND minor (cleanrl_amd/_lib.py does) */
 
 #if defined(__GNUC__)
 #define MI355PPO_API __attribute__((visibility("default")))

@@ -82,9 +82,11 @@ def run(num_envs=32, num_steps=128, iterations=1, warmup_iterations=0, seed=1, n
     next_done = torch.zeros(N)
     batch, mb = T * N, T * N // num_minibatches
     timed_steps, t_start, done_iters = 0, None, 0
+    iter_secs = []
     for it in range(warmup_iterations + iterations):
         if it == warmup_iterations:
             t_start = time.perf_counter()
+        t_it = time.perf_counter()
         for step in range(T):                                                    # :224-247
             obs[step] = next_obs
             dones[step] = next_done
@@ -117,11 +119,13 @@ def run(num_envs=32, num_steps=128, iterations=1, warmup_iterations=0, seed=1, n
         if it >= warmup_iterations:
             timed_steps += batch
             done_iters += 1
+            iter_secs.append(time.perf_counter() - t_it)
             if max_seconds is not None and time.perf_counter() - t_start > max_seconds:
                 break
     secs = time.perf_counter() - t_start
-    return dict(sps=timed_steps / secs, seconds=secs, env_steps=timed_steps, iterations=done_iters,
-                cores=torch.get_num_threads(), num_envs=num_envs, num_steps=num_steps)
+    return dict(sps=timed_steps / secs, sps_median=batch / float(np.median(iter_secs)), iteration_seconds=iter_secs, seconds=secs,
+                env_steps=timed_steps, iterations=done_iters, cores=torch.get_num_threads(), num_envs=num_envs,
+                num_steps=num_steps)
 
 
 if __name__ == "__main__":

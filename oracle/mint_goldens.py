@@ -254,26 +254,30 @@ class _GradSpy:
     ``.grad`` -- i.e. the gradient after ``loss.backward()``, the collective block (multi-GPU script) and
     ``clip_grad_norm_`` -- for the first ``keep`` steps.  Everything else is forwarded untouched."""
 
-    def __init__(self, optimizer, params, keep=1):
+    def __init__(self, optimizer, params, keep=1, keep_steps=None, on_step=None):
         self._opt, self._params, self._keep, self.grads = optimizer, list(params), keep, []
+        self._keep_steps, self._on_step, self.n_steps = keep_steps, on_step, 0      # 1-based step numbers to record instead of the first `keep`
 
     def __getattr__(self, name):
         return getattr(self._opt, name)
 
     def step(self, *a, **kw):
-        if len(self.grads) < self._keep:
+        self.n_steps += 1
+        if (self._keep_steps is None and len(self.grads) < self._keep) or (self._keep_steps is not None and self.n_steps in self._keep_steps):
             self.grads.append(_flat([p.grad for p in self._params]).clone())
+        if self._on_step is not None:
+            self._on_step(self.n_steps)
         return self._opt.step(*a, **kw)
 
 
-def _grad_record(prefix, g, params):
+def _grad_record(prefix, g, params, stride=GRAD_STRIDE):
     """Strided subsample + norms of a flat gradient (the whole vector is 6.7 MB; the subsample estimates the cosine,
     the norms pin the scale globally and per parameter tensor)."""
     sizes = [p.numel() for p in params]
     per = torch.stack([t.double().norm() for t in torch.split(g, sizes)])
-    return {f"{prefix}_sub": g[::GRAD_STRIDE].clone(), f"{prefix}_norm": np.float64(g.double().norm().item()),
+    return {f"{prefix}_sub": g[::stride].clone(), f"{prefix}_norm": np.float64(g.double().norm().item()),
             f"{prefix}_tensor_norms": per, f"{prefix}_absmax": np.float64(g.abs().max().item()),
-            f"{prefix}_stride": np.int64(GRAD_STRIDE)}
+            f"{prefix}_stride": np.int64(stride)}
 
 
 class _FakeDist:
@@ -426,6 +430,81 @@ def mint_atari_iteration():
         # the clipped gradient the FIRST optimizer.step() of the update saw (minibatch 1 of epoch 1)
         **_grad_record("mb1_grad", optimizer.grads[0], agent.parameters()))}
     _save("atari_iteration", cases)
+
+
+# --------------------------------------------------------------- config B at its full size: one whole iteration, 16 updates
+SCALAR_KEYS = ("loss", "pg_loss", "v_loss", "entropy_loss", "old_approx_kl", "approx_kl")
+
+
+def mint_atari_iteration_config_b():
+    """BASELINE configs[1] at full size: one whole iteration of ppo_atari_envpool.py with num_envs = 128, num_steps = 128,
+    4 minibatches x 4 epochs = 16 updates of 4,096 rows.  The reference Agent's action logic (:223-232) fills the rollout, then
+    its GAE lines (:251-263) and its flatten + epoch / minibatch update lines (:265-322) are executed verbatim.  The frames
+    (129 x 128 x 4 x 84 x 84 uint8 = 466 MB) come from ``synthetic.atari_frames`` (numpy legacy RandomState: both sides
+    regenerate them from the seed; a checksum is stored).  Recorded: the seven scalars of ALL 16 minibatches, the clipped
+    flat gradient the optimizer saw at updates 1, 8 and 16 (strided), the parameters after update 16 (strided), the rollout
+    tensors (actions, log-probs, values) and the GAE output."""
+    import textwrap
+
+    import torch.nn as nn
+
+    script = "ppo_atari_envpool.py"
+    lines = R._read(script)
+    T, N, A = 128, 128, 4
+    frame_seed = 77
+    torch.manual_seed(21)
+    Agent, _ = R.load_agent_class(script)
+    envs = R.fake_envs((4, 84, 84), n_actions=A)
+    agent = Agent(envs)
+    args = R.make_args(num_steps=T, num_envs=N, num_minibatches=4, update_epochs=4, batch_size=T * N, minibatch_size=T * N // 4)
+    ns = {}
+    scalars = []
+
+    def on_step(k):          # called inside the reference's own loop, right before optimizer.step() of update k
+        scalars.append([float(ns[key]) for key in SCALAR_KEYS] + [float(ns["clipfracs"][-1])])
+
+    optimizer = _GradSpy(R.make_optimizer(agent, 2.5e-4), agent.parameters(), keep_steps=(1, 8, 16), on_step=on_step)
+    init = _flat(agent.parameters()).clone()
+    frames = torch.from_numpy(synthetic.atari_frames((T + 1) * N, seed=frame_seed)).view(T + 1, N, 4, 84, 84)
+    rs = np.random.RandomState(frame_seed + 1)
+    step_done = torch.from_numpy((rs.random_sample((T + 1, N)) < 1.0 / 50.0).astype(np.float32))
+    step_done[0] = 0.0
+    rewards = torch.from_numpy(rs.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=(T, N), p=[0.05, 0.9, 0.05]).astype(np.float32))
+    obs = torch.zeros((T, N, 4, 84, 84))
+    actions, logprobs, dones, values = (torch.zeros((T, N)) for _ in range(4))
+    torch.manual_seed(23)                                      # the sampler's stream
+    for step in range(T):
+        obs[step], dones[step] = frames[step].float(), step_done[step]
+        with torch.no_grad():
+            action, logprob, _, value = agent.get_action_and_value(obs[step])
+            values[step] = value.flatten()
+        actions[step], logprobs[step] = action, logprob
+    next_obs, next_done = frames[T].float(), step_done[T]
+    device = torch.device("cpu")
+    ns.update(args=args, agent=agent, optimizer=optimizer, envs=envs, obs=obs, actions=actions, logprobs=logprobs,
+              rewards=rewards, dones=dones, values=values, next_obs=next_obs, next_done=next_done, device=device, np=np,
+              torch=torch, nn=nn)
+    g0 = R._find(lines, "# bootstrap value if not done") + 1
+    g1 = R._find(lines, "returns = advantages + values", g0)
+    exec(textwrap.dedent("\n".join(lines[g0:g1 + 1])), ns)
+    u0 = R._find(lines, "# flatten the batch", g1) + 1
+    u1 = R._find(lines, "y_pred, y_true = b_values.cpu().numpy()", u0)
+    np.random.seed(6)
+    exec(textwrap.dedent("\n".join(lines[u0:u1])), ns)
+    assert optimizer.n_steps == 16 and len(optimizer.grads) == 3
+    final = _flat(agent.parameters())
+    sub = slice(0, None, 89)
+    d = dict(
+        frame_seed=np.int64(frame_seed), frames_checksum=np.int64(frames.sum(dtype=torch.int64).item()),
+        frames_first_row=frames[0, 0, 0, 0].clone(), step_done=step_done, rewards=rewards, actions=actions, logprobs=logprobs,
+        values=values, advantages=ns["advantages"], returns=ns["returns"], init_params_sub=init[sub], final_params_sub=final[sub],
+        stride=np.int64(89), init_checksum=np.float64(init.double().sum().item()),
+        final_checksum=np.float64(final.double().sum().item()), scalars=np.array(scalars, np.float32),
+        scalar_names=np.array(list(SCALAR_KEYS) + ["clipfrac"]), init_seed=np.int64(21), sample_seed=np.int64(23),
+        shuffle_seed=np.int64(6), lr=np.float64(2.5e-4), lines=np.array([g0 + 1, g1 + 1, u0 + 1, u1], np.int64))
+    for k, gk in zip((1, 8, 16), optimizer.grads):
+        d.update(_grad_record(f"mb{k}_grad", gk, agent.parameters(), stride=53))
+    _save("atari_iteration_cfgB", {"atari_T128_N128": d})
 
 
 # --------------------------------------------------------------- recurrent script: rollout -> GAE -> env-wise update
@@ -736,6 +815,10 @@ def mint_rnd_iteration():
 def main():
     assert R.available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:                     # python -m oracle.mint_goldens atari_iteration_config_b ...: only these
+        for name in sys.argv[1:]:
+            globals()["mint_" + name]()
+        return
     for script in ["ppo.py", "ppo_atari.py", "ppo_atari_envpool.py", "ppo_atari_multigpu.py", "ppo_continuous_action.py", "ppo_procgen.py"]:
         print(script, R.line_ranges(script))
     mint_gae()
@@ -745,6 +828,7 @@ def main():
     mint_loss_normal()
     mint_update_step()
     mint_atari_iteration()
+    mint_atari_iteration_config_b()
     mint_lstm_iteration()
     mint_procgen_update()
     mint_rnd_iteration()

@@ -52,3 +52,25 @@ def test_bench_gpus_n_never_runs_fewer_ranks_than_asked():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr and "{" not in out.stdout
+
+
+def test_config_flag_selects_the_baseline_workloads(monkeypatch):
+    """``--config`` maps to BASELINE.json's configs (per-GPU sizes); explicit size flags override; ``--same-device`` is only
+    accepted together with ``--backend gloo``."""
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    want = {"B": (128, 128), "C": (1024, 128), "D": (256, 128), "E": (64, 2048)}
+    for c, (n, t) in want.items():
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--config", c])
+        cli = bench.parse()
+        assert (cli.config, cli.local_num_envs, cli.num_steps) == (c, n, t)
+        assert f"configs[{'ABCDE'.index(c)}]" in bench.CONFIGS[c]["workload"]
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "D", "--local-num-envs", "32", "--num-steps", "8"])
+    cli = bench.parse()
+    assert (cli.local_num_envs, cli.num_steps) == (32, 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--same-device"])
+    try:
+        bench.parse()
+        raise AssertionError("--same-device without --backend gloo must be refused")
+    except SystemExit as e:
+        assert e.code == 2

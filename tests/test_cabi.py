@@ -11,6 +11,7 @@ import torch
 from cleanrl_amd import _lib, ops
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mi355ppo.h")
 
 
 def header_symbols():
@@ -28,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.load()
     for name in header_symbols():
         assert getattr(lib, name) is not None
-    assert lib.mi355ppo_version() == 100
+    assert lib.mi355ppo_version() == _lib.ABI_VERSION == int(re.search(r"#define MI355PPO_VERSION (\d+)", open(HEADER).read()).group(1))
 
 
 def test_validation_errors_are_loud_and_precede_any_launch():

@@ -426,6 +426,66 @@ def test_fc_kernels_at_the_full_minibatch_size_against_float64_on_the_device():
     assert err <= max(2e-5 * scale, 4.0 * err_t), f"dW at 32768: err {err:.3e}, library f32 err {err_t:.3e}, scale {scale:.3e}"
 
 
+def _conv64_nhwc(x_nhwc, W, b, stride):
+    """float64 convolution ON THE DEVICE as im2col (F.unfold) + one float64 GEMM: (B,H,W,C) -> (B,Ho,Wo,Cout), no ReLU."""
+    B, H, _, C = x_nhwc.shape
+    cout, cin, k, _ = W.shape
+    ho = (H - k) // stride + 1
+    cols = F.unfold(x_nhwc.permute(0, 3, 1, 2), kernel_size=k, stride=stride)            # (B, C*k*k, Ho*Wo), (c, kh, kw) order
+    y = torch.einsum("nk,bkl->bln", W.reshape(cout, -1), cols)
+    if b is not None:
+        y = y + b
+    return y.reshape(B, ho, ho, cout)
+
+
+def _slab(M, n=2048):
+    """Image indices of a float64 slab strided through a batch of M images, including both ends of the batch."""
+    idx = torch.arange(0, M, max(1, M // n))[:n]
+    return torch.unique(torch.cat([idx, torch.arange(0, min(64, M)), torch.arange(max(0, M - 64), M)])).to(DEV)
+
+
+def test_conv_forward_and_data_gradient_kernels_at_the_full_minibatch_size_against_float64_on_the_device():
+    """Config-C minibatch (32,768 images), every DEFAULT convolution kernel of the forward and data-gradient path at its bench
+    launch size, against a float64 convolution computed on the device (im2col + float64 GEMM; autograd of it for the data
+    gradients) on a slab of ~2,100 images strided through the batch with both ends included:
+      kernel Q (layer-1 forward through the row gather), kernel F (layer-2 / layer-3 forward), the layer-3 data gradient per
+      border class (variant 5, nine launches) and the layer-2 data gradient per border class (variant 6, four launches), each
+      with its fused ReLU-backward mask.  Bound: 2e-5 of the reference's scale (the bound of the small-size float64 tests).
+    Reference layers: ppo_atari_multigpu.py:136-142."""
+    M = 32768
+    g = torch.Generator(device=DEV).manual_seed(11)
+    sl = _slab(M)
+    params = {l: tuple(t.to(DEV) for t in _params(l, 70 + l)) for l in (1, 2, 3)}
+    # ---- layer 1 (kernel Q): uint8 rows through a permutation
+    obs = torch.randint(0, 256, (M, 84, 84, 4), dtype=torch.uint8, device=DEV, generator=g)
+    inds = torch.randperm(M, device=DEV, generator=g)
+    W1, b1 = params[1]
+    a1 = cnn.conv_fwd(obs, cnn.repack_weights(W1, 1, cnn.MODE_FWD_Q), b1, 1, inds, variant=cnn.VARIANT_Q)
+    ref = torch.relu(_conv64_nhwc(obs[inds[sl]].double() / 255.0, W1.double(), b1.double(), 4))
+    _close(a1[sl], ref, "conv1 fwd (kernel Q) at 32768 images")
+    del obs, ref
+    # ---- layers 2 and 3 forward (kernel F) on the activations the previous kernel produced
+    W2, b2 = params[2]
+    a2 = cnn.conv_fwd(a1, cnn.repack_weights(W2, 2), b2, 2)
+    _close(a2[sl], torch.relu(_conv64_nhwc(a1[sl].double(), W2.double(), b2.double(), 2)), "conv2 fwd (kernel F) at 32768 images")
+    W3, b3 = params[3]
+    a3 = cnn.conv_fwd(a2, cnn.repack_weights(W3, 3), b3, 3)
+    _close(a3[sl], torch.relu(_conv64_nhwc(a2[sl].double(), W3.double(), b3.double(), 1)), "conv3 fwd (kernel F) at 32768 images")
+    # ---- data gradients, default variants, masks fused
+    dz3 = torch.randn(a3.shape, device=DEV, generator=g) * (a3 > 0)
+    dz2 = cnn.conv_dgrad(dz3, cnn.repack_weights(W3, 3, cnn.MODE_DGRAD_S1_CLASSES), a2, 3, variant=5)
+    x = a2[sl].double().requires_grad_(True)
+    _conv64_nhwc(x, W3.double(), None, 1).backward(dz3[sl].double())
+    _close(dz2[sl], x.grad * (a2[sl] > 0), "conv3 dgrad (border classes, variant 5) at 32768 images")
+    assert ((a2 > 0) | (dz2 == 0)).all()
+    del x, dz3, a3
+    dz1 = cnn.conv_dgrad(dz2, cnn.repack_weights(W2, 2, cnn.MODE_DGRAD_S2_CLASSES), a1, 2, variant=cnn.VARIANT_DGRAD2_CLASSES)
+    x = a1[sl].double().requires_grad_(True)
+    _conv64_nhwc(x, W2.double(), None, 2).backward(dz2[sl].double())
+    _close(dz1[sl], x.grad * (a1[sl] > 0), "conv2 dgrad (border classes, variant 6) at 32768 images")
+    assert ((a1 > 0) | (dz1 == 0)).all()
+
+
 def test_kernel_c_agrees_with_kernel_f_at_the_full_minibatch_size():
     """32,768 images: the bf16-pipe forward of layers 2 / 3 (kernel C) against the f32-pipe kernel F on the same activations --
     both compute exact products with f32 accumulation, in different orders."""

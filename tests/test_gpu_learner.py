@@ -149,6 +149,100 @@ def test_atari_hip_path_teacher_forced_against_reference_iteration():
     L.flat.check_views()
 
 
+def _spy_steps(L, keep):
+    """Capture the flat gradient buffer as the optimiser steps numbered in ``keep`` (1-based) see it (pre-Adam, pre-clip)."""
+    seen, count = {}, [0]
+    real = L.optimizer_step_hip
+
+    def spy(lr):
+        count[0] += 1
+        if count[0] in keep:
+            seen[count[0]] = L.flat.grads.clone()
+        real(lr)
+
+    L.optimizer_step_hip = spy
+    return seen
+
+
+def test_config_b_whole_iteration_teacher_forced_all_16_updates():
+    """BASELINE configs[1] at its full size -- 128 envs x 128 steps, 4 epochs x 4 minibatches = 16 updates of 4,096 rows --
+    against one whole iteration of ppo_atari_envpool.py's own lines :217-322 (tests/golden/atari_iteration_cfgB.npz: the
+    reference's sampled actions forced; frames regenerated from the seed).  Checked: every rollout value, the GAE output,
+    the seven scalars of ALL 16 minibatches, the pre-Adam gradient at updates 1, 8 and 16, the parameters after update 16.
+    A drift that compounds over updates (a stale repacked weight matrix, a permutation-row slip) fails here.  Strict."""
+    from cleanrl_amd import synthetic
+
+    g = load_golden("atari_iteration_cfgB")["atari_T128_N128"]
+    T, N = g["rewards"].shape
+    assert (T, N) == (128, 128)
+    frames = synthetic.atari_frames((T + 1) * N, seed=int(g["frame_seed"])).reshape(T + 1, N, 4, 84, 84)
+    assert int(frames.sum(dtype=np.int64)) == int(g["frames_checksum"]) and np.array_equal(frames[0, 0, 0, 0], g["frames_first_row"])
+    env = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+    torch.manual_seed(int(g["init_seed"]))
+    agent = AtariAgent(env).to(DEV)
+    args = learner_smoke.default_args(num_steps=T, num_minibatches=4, update_epochs=4)
+    L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=1)
+    assert L.hip and L.fused_cnn and L.minibatch_size == 4096
+    stride = int(g["stride"])
+    np.testing.assert_allclose(L.flat.params[::stride].cpu().numpy(), g["init_params_sub"], rtol=1e-5, atol=1e-6)
+    step_done = g["step_done"]
+    L.observe(0, frames[0], step_done[0])
+    worst_value = 0.0
+    for step in range(T):
+        L.act(step)
+        worst_value = max(worst_value, float(np.abs(L.values[step].cpu().numpy() - g["values"][step]).max()))
+        L.actions[step].copy_(torch.from_numpy(g["actions"][step]))
+        L.logprobs[step].copy_(torch.from_numpy(g["logprobs"][step]))
+        L.values[step].copy_(torch.from_numpy(g["values"][step]))
+        L.store_reward(step, g["rewards"][step])
+        L.observe(step + 1, frames[step + 1], step_done[step + 1])
+    # f32 conv stack with another summation order (and 1/255 folded into the layer-1 weights): 5e-5 of the value scale
+    assert worst_value <= 5e-5 * max(1.0, float(np.abs(g["values"]).max())), worst_value
+    L.finish_rollout()
+    np.testing.assert_allclose(L.advantages.cpu().numpy(), g["advantages"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(L.returns.cpu().numpy(), g["returns"], rtol=1e-4, atol=1e-4)
+    L.advantages.copy_(torch.from_numpy(g["advantages"]))
+    L.returns.copy_(torch.from_numpy(g["returns"]))
+    seen = _spy_steps(L, (1, 8, 16))
+    np.random.seed(int(g["shuffle_seed"]))
+    m = L.update(float(g["lr"]))
+    assert m["num_updates"] == 16
+    # ---- the seven scalars of every minibatch: (loss, pg_loss, v_loss, entropy, old_approx_kl, approx_kl, clipfrac)
+    sc = L._scalars[:16].cpu().numpy().astype(np.float64)
+    ref = g["scalars"].astype(np.float64)
+    assert [str(x) for x in g["scalar_names"]] == ["loss", "pg_loss", "v_loss", "entropy_loss", "old_approx_kl", "approx_kl", "clipfrac"]
+    # rtol 1e-3 of each scalar plus an absolute floor per column: pg_loss and the KL estimates sit near 0 (normalised
+    # advantages, ratio ~ 1), clipfrac is a count over 4,096 rows (one row = 2.4e-4)
+    atol = np.array([2e-4, 2e-4, 2e-4, 1e-4, 2e-5, 2e-5, 2.5e-3])
+    err = np.abs(sc - ref)
+    bar = 1e-3 * np.abs(ref) + atol
+    assert (err <= bar).all(), "minibatch scalars off the reference's lines: worst err/bar per column %s at updates %s\n%s" % (
+        (err / bar).max(0).round(3), (err / bar).argmax(0) + 1, np.c_[sc[:, 0], ref[:, 0]])
+    # ---- pre-Adam gradients at updates 1, 8 and 16, clipped as clip_grad_norm_(0.5) does
+    sizes = [p.numel() for p in agent.parameters()]
+    for k in (1, 8, 16):
+        gh = seen[k].cpu().numpy()
+        n = np.linalg.norm(gh.astype(np.float64))
+        clipped = gh * min(1.0, args.max_grad_norm / (n + 1e-6))
+        s = int(g[f"mb{k}_grad_stride"])
+        want = g[f"mb{k}_grad_sub"]
+        assert np.abs(clipped[::s] - want).max() <= 1e-3 * float(g[f"mb{k}_grad_absmax"]), (k, np.abs(clipped[::s] - want).max())
+        assert _cos(clipped[::s], want) > 0.99999, (k, _cos(clipped[::s], want))
+        np.testing.assert_allclose(np.linalg.norm(clipped.astype(np.float64)), float(g[f"mb{k}_grad_norm"]), rtol=1e-3)
+        per = np.array([np.linalg.norm(c.astype(np.float64)) for c in np.split(clipped, np.cumsum(sizes)[:-1])])
+        np.testing.assert_allclose(per, g[f"mb{k}_grad_tensor_norms"], rtol=2e-3, err_msg=f"update {k}")
+    # ---- parameters after update 16, by decile of |g| (update 16's gradient)
+    delta = L.flat.params[::stride].cpu().numpy() - g["init_params_sub"]
+    want = g["final_params_sub"] - g["init_params_sub"]
+    close, deciles = _decile_report(delta, want, np.abs(seen[16].cpu().numpy()[::stride]), rtol=5e-2, atol=2e-5)
+    assert close.mean() > 0.98, f"only {close.mean():.4f} of sampled parameters match; by |g| decile: {deciles}"
+    assert min(deciles[2:]) > 0.99, f"parameters with non-tiny gradients must follow the reference update: {deciles}"
+    # the update as a whole: direction and length of the 16-step parameter move
+    assert _cos(delta, want) > 0.999, _cos(delta, want)
+    np.testing.assert_allclose(np.linalg.norm(delta), np.linalg.norm(want), rtol=1e-2)
+    L.flat.check_views()
+
+
 def test_dp_step_matches_reference_collective_block_golden():
     """ppo_atari_multigpu.py:320-377 for world_size=2 (golden from the reference's lines): rank-1 gradient is
     summed into the flat buffer exactly where the RCCL all-reduce acts, then the fused /world -> clip -> Adam."""
@@ -355,16 +449,20 @@ def test_device_synthetic_env_streams():
     assert abs(d.mean().item() - 0.1) < 5 * (0.1 * 0.9 / n) ** 0.5
 
 
-@pytest.mark.parametrize("K,delta", [(2, True), (4, True), (2, False)])
-def test_env_group_lanes_on_the_gpu_match_the_serial_host_env_loop(K, delta):
+@pytest.mark.parametrize("K,delta,autoreset", [(2, True, "same_step"), (4, True, "same_step"), (2, False, "same_step"),
+                                               (2, True, "next_step"), (4, True, "next_step")])
+def test_env_group_lanes_on_the_gpu_match_the_serial_host_env_loop(K, delta, autoreset):
     """The overlapped host-env pipeline (cleanrl_amd/pipeline.py: K threads, K streams, pinned uint8 staging, newest-frame-only
     H2D + device-side stack shift) fills the rollout buffers bit for bit like the serial observe() loop that sends every
-    full stack; the sampled actions are a deterministic function of (seed, step, group), not of thread timing."""
+    full stack; the sampled actions are a deterministic function of (seed, step, group), not of thread timing.
+    ``autoreset="next_step"`` is envpool's / gymnasium >= 1.0's behaviour: the call AFTER done returns the fresh stack with
+    done = False (round-2 advisor finding: the newest-frame path then has to send that env's whole stack as well)."""
     from cleanrl_amd.pipeline import GroupedRollout, split_env_groups
 
     N, T = 16, 12
     per = N // K
-    mk = lambda: split_env_groups(lambda g, n: E.SyntheticAtariVecEnv(n, seed=21 + g * n, api="gym", done_p=0.15), N, K)
+    mk = lambda: split_env_groups(lambda g, n: E.SyntheticAtariVecEnv(n, seed=21 + g * n, api="gym", done_p=0.15,
+                                                                      autoreset=autoreset), N, K)
     space = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
 
     def learner():

@@ -80,3 +80,32 @@ def test_ppo_atari_multigpu_script_two_ranks_on_one_gpu():
         assert len(by_rank) == 2 and by_rank["0"] == by_rank["1"], f"replicas diverged at iteration {it}: {by_rank}"
     assert len({sums[i]["0"] for i in sums}) == 3                     # the weights move every iteration
     assert any(acts[i]["0"] != acts[i]["1"] for i in acts)           # different rollouts per rank
+
+
+def test_bench_multi_rank_legs_run_with_two_ranks_on_one_gpu():
+    """``bench.py --gpus 2`` end to end with both ranks on cuda:0 (``--same-device --backend gloo``: a plumbing smoke, not a
+    measurement): the self-launcher, the rendezvous on 127.0.0.1, the barrier + synchronize brackets, the max-over-ranks
+    all-reduce of the elapsed time and the rank-0 JSON line -- everything the driver's 2/4/8-GPU runs go through except RCCL
+    itself (reference launch shape: ppo_atari_multigpu.py:166-177; its all-reduce :360-377)."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--same-device",
+           "--backend", "gloo", "--local-num-envs", "64", "--num-steps", "16", "--no-cpu-baseline", "--no-pcie-inclusive"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line (rank 0 only), got {len(lines)}:\n{out.stdout[-2000:]}"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["parallelism"].startswith("dp2") and "SAME-DEVICE" in j["config"]["parallelism"]
+    assert j["config"]["global_num_envs"] == 128 and j["config"]["local_num_envs"] == 64
+    assert np.isfinite(j["final_loss"]) and j["value"] > 0
+    # value = the units ALL ranks processed / the max-over-ranks time
+    np.testing.assert_allclose(j["value"], 2 * 64 * 16 * 1 / (j["ms_per_step"] * 1e-3), rtol=1e-6)
+    # without --same-device the launcher refuses to run fewer ranks than asked on a one-GPU box
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 2 and "refusing" in r.stderr

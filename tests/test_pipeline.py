@@ -87,3 +87,42 @@ def test_env_groups_flag_runs_the_script_end_to_end(capsys):
     with pytest.raises(AssertionError, match="multiple"):
         ppo_atari_envpool.main(["--no-cuda", "--synthetic-env", "--num-envs", "5", "--env-groups", "2", "--num-steps", "8",
                                 "--total-timesteps", "40", "--num-minibatches", "1"])
+
+
+@pytest.mark.parametrize("autoreset", ["same_step", "next_step"])
+def test_newest_frame_rule_rebuilds_every_stack_under_both_autoreset_conventions(autoreset):
+    """``pipeline.full_stack_rows`` (which envs must send their whole stack) on the host: rebuilding each observation as
+    "previous stack shifted + newest plane" for all other envs reproduces the env's observations exactly -- for gym < 1.0
+    vector envs (reset in the step that reports done) and for envpool / gymnasium >= 1.0 (reset in the FOLLOWING call, which
+    reports done = False: round-2 advisor finding).  Dropping either half of the rule breaks the convention it covers."""
+    from cleanrl_amd.pipeline import full_stack_rows, stack_probe
+
+    env = E.SyntheticAtariVecEnv(12, seed=5, api="gym", done_p=0.2, autoreset=autoreset)
+    prev = env.reset().copy()
+    prev_done, prev_probe = np.zeros(12, bool), stack_probe(prev)
+    stale_without_prev_done = 0
+    n_full = 0
+    for _ in range(40):
+        obs, _, done, _ = env.step(np.zeros(12, np.int64))
+        probe = stack_probe(obs)
+        rows = full_stack_rows(done, prev_done, probe, prev_probe)
+        n_full += len(rows)
+        rebuilt = np.concatenate([prev[:, 1:], obs[:, 3:4]], axis=1)       # what obs_shift_append_u8 computes on the device
+        rebuilt[rows] = obs[rows]
+        assert np.array_equal(rebuilt, obs)
+        only_done = np.concatenate([prev[:, 1:], obs[:, 3:4]], axis=1)     # the round-2 rule: done at this step only
+        only_done[np.flatnonzero(done)] = obs[np.flatnonzero(done)]
+        stale_without_prev_done += int((only_done != obs).any())
+        prev, prev_done, prev_probe = obs.copy(), np.asarray(done).astype(bool), probe
+    assert 0 < n_full < 12 * 40 // 2                                       # resets happened, and most steps still send one plane
+    assert (stale_without_prev_done > 0) == (autoreset == "next_step")
+    # the probe alone (no done flags at all) also finds every discontinuity of these byte streams
+    env2 = E.SyntheticAtariVecEnv(6, seed=9, api="gym", done_p=0.3, autoreset=autoreset)
+    prev = env2.reset().copy()
+    for _ in range(20):
+        obs, _, done, _ = env2.step(np.zeros(6, np.int64))
+        rows = full_stack_rows(np.zeros(6, bool), np.zeros(6, bool), stack_probe(obs), stack_probe(prev))
+        rebuilt = np.concatenate([prev[:, 1:], obs[:, 3:4]], axis=1)
+        rebuilt[rows] = obs[rows]
+        assert np.array_equal(rebuilt, obs)
+        prev = obs.copy()
