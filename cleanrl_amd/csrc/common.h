@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/mi355ppo.h"
 
@@ -22,6 +23,17 @@ int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz
                   hipStream_t s);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Term pairs of the three-term bf16 split multiplied by kernels X (fcx.hip) and C (convx.hip): 9 = all 3 x 3 (every f32
+// product exact), 6 = the pairs (a_i, b_j) with i + j <= 2 -- the three dropped pairs (mid x lo, lo x mid, lo x lo) are
+// together below 2^-21 of the product (typically 2^-24: under the rounding of ONE f32 multiply), see DESIGN.md.  Read once.
+inline int bf16_term_pairs() {
+    static const int n = [] {
+        const char* e = getenv("MI355PPO_BF16_PAIRS");
+        return (e && e[0] == '9') ? 9 : 6;
+    }();
+    return n;
+}
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void convx_pack_kernel(const float* __restrict
     pack[o + 1024] = (unsigned short)(__float_as_uint(l) >> 16);
 }
 
-template <class G>
+// NP = 9: all 3 x 3 term pairs (exact products); NP = 6: the pairs with x + y <= 2 (common.h: bf16_term_pairs).
+template <class G, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convx_fwd_kernel(
     const float* __restrict__ src, const unsigned char* __restrict__ pack, const float* __restrict__ bias, float* __restrict__ dst,
     long long P) {
@@ -150,18 +151,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int x = 0; x < 3; ++x)
 #pragma unroll
-            for (int y = 0; y < 3; ++y)
+            for (int y = 0; y < 3; ++y) {
+                if (NP == 6 && x + y > 2) continue;
 #pragma unroll
                 for (int i = 0; i < kCMT; ++i)
 #pragma unroll
                     for (int j = 0; j < kCNT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[q][i].t[x], tb[q][j].t[y], acc[i][j], 0, 0, 0);
-        // issue order: the 14 loads first, then 72 x (1 MFMA, 3 VALU)
+            }
+        // issue order: the 14 loads first, then NP x 8 x (1 MFMA, 3 or 4 VALU): the 176 VALU of the splits spread over the MFMAs
         __builtin_amdgcn_sched_group_barrier(0x020, 2 * kCMT + 3 * kCNT, 0);
 #pragma unroll
-        for (int g = 0; g < 9 * kCMT * kCNT; ++g) {
+        for (int g = 0; g < NP * kCMT * kCNT; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, NP == 9 ? 3 : 4, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -202,8 +205,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <class G>
 static int convx_launch(const float* src, const void* pack, const float* bias, float* dst, long long images, hipStream_t s) {
     const long long P = images * G::PER_IMG, tiles = (P + 32 * kCMT - 1) / (32 * kCMT);
-    hipLaunchKernelGGL((convx_fwd_kernel<G>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, src, static_cast<const unsigned char*>(pack), bias,
-                       dst, P);
+    if (bf16_term_pairs() == 9)
+        hipLaunchKernelGGL((convx_fwd_kernel<G, 9>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, src, static_cast<const unsigned char*>(pack),
+                           bias, dst, P);
+    else
+        hipLaunchKernelGGL((convx_fwd_kernel<G, 6>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, src, static_cast<const unsigned char*>(pack),
+                           bias, dst, P);
     return check_launch("convx_fwd_kernel");
 }
 

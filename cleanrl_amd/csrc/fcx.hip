@@ -67,7 +67,8 @@ constexpr int kXMT = 2, kXNT = 4, kXF = kXMT + kXNT;
 // WAVES_N: the four waves of a workgroup sit side by side (64 x 512: they share the A rows, each A row leaves HBM once --
 // the forward, where A is the 411 MB activation and B the 6.4 MB weight; measured 3.6 x the algorithmic bytes with the
 // waves stacked) instead of on top of each other (256 x 128: they share the B rows).
-template <int EPI, bool WAVES_N>
+// NP = 9: all 3 x 3 term pairs (exact products); NP = 6: the pairs with ta + tb <= 2 (common.h: bf16_term_pairs).
+template <int EPI, bool WAVES_N, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fcx_gemm_nt_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
     const float* __restrict__ cmask, float* __restrict__ C, int ldc, int M, int N, int K) {
@@ -118,18 +119,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int ta = 0; ta < 3; ++ta)
 #pragma unroll
-            for (int tb = 0; tb < 3; ++tb)
+            for (int tb = 0; tb < 3; ++tb) {
+                if (NP == 6 && ta + tb > 2) continue;
 #pragma unroll
                 for (int i = 0; i < kXMT; ++i)
 #pragma unroll
                     for (int j = 0; j < kXNT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pc[q][i].t[ta], pc[q][kXMT + j].t[tb], acc[i][j], 0, 0, 0);
-        // issue order: the 12 loads first, then 72 x (1 MFMA, 4 VALU)
+            }
+        // issue order: the 12 loads first, then NP x 8 x (1 MFMA, 4 or 6 VALU): the 264 VALU of the splits spread over the MFMAs
         __builtin_amdgcn_sched_group_barrier(0x020, 2 * kXF, 0);
 #pragma unroll
-        for (int g = 0; g < 9 * kXMT * kXNT; ++g) {
+        for (int g = 0; g < NP * kXMT * kXNT; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, NP == 9 ? 4 : 6, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -222,8 +225,12 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float
     if (rc) return rc;
     MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
     MI355_REQUIRE((M + 63) / 64 <= 65535, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
-    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU, true>), dim3((N + 511) / 512, (M + 63) / 64), dim3(256), 0, as_stream(stream), a, K,
-                       W, K, bias, (const float*)nullptr, h, N, M, N, K);
+    if (bf16_term_pairs() == 9)
+        hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU, true, 9>), dim3((N + 511) / 512, (M + 63) / 64), dim3(256), 0, as_stream(stream), a, K,
+                           W, K, bias, (const float*)nullptr, h, N, M, N, K);
+    else
+        hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU, true, 6>), dim3((N + 511) / 512, (M + 63) / 64), dim3(256), 0, as_stream(stream), a, K,
+                           W, K, bias, (const float*)nullptr, h, N, M, N, K);
     return check_launch(fn);
 }
 
@@ -233,7 +240,11 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, int lddz
     int rc = fcx_check(fn, dz, Wt, da, M, N, K, lddz, ldwt, N);
     if (rc) return rc;
     MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
-    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK, false>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), dz, lddz,
-                       Wt, ldwt, (const float*)nullptr, act_in, da, N, M, N, K);
+    if (bf16_term_pairs() == 9)
+        hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK, false, 9>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), dz, lddz,
+                           Wt, ldwt, (const float*)nullptr, act_in, da, N, M, N, K);
+    else
+        hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK, false, 6>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), dz, lddz,
+                           Wt, ldwt, (const float*)nullptr, act_in, da, N, M, N, K);
     return check_launch(fn);
 }
