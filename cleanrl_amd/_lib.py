@@ -34,6 +34,10 @@ SIGNATURES = {
     "mi355ppo_loss_categorical_fwd_bwd_f32": (
         c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int, _P,
                 _P, _P, _P, _P, c_size_t, _P]),
+    "mi355ppo_batch_pack_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P]),
+    "mi355ppo_adv_stats_packed_f32": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_size_t, _P]),
+    "mi355ppo_loss_categorical_packed_fwd_bwd_f32": (
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mi355ppo_loss_normal_fwd_bwd_f32": (
         c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int, _P,
                 _P, _P, _P, _P, _P, c_size_t, _P]),

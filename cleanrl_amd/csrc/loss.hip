@@ -43,6 +43,10 @@ constexpr int kStatsMaxBlocks = 1024;   // partial pairs of the advantage statis
 constexpr int kMaxGrid = 2048;          // workgroups of the persistent row pass
 constexpr int kNumSums = 6;             // pg, v, entropy, -logratio, (ratio-1)-logratio, clip indicator
 constexpr int kMaxD = 64;
+// Packed behaviour rows: one 32-byte row per flat batch index, {action (f32 storage), old log-prob, advantage, return, old
+// value, 0, 0, 0}.  A minibatch row then costs ONE 32-byte gather instead of five 4-byte gathers out of five arrays (five
+// 128-byte lines per row once the flat batch outgrows the caches: DESIGN.md section 3.1).
+constexpr int kPackFloats = 8, kPackAdv = 2;
 
 struct LossSlot {          // 64-byte head of a workspace: what the scalar fold needs to know about the call that filled it
     int M, nblocks, D, pad;
@@ -61,7 +65,9 @@ struct LossParams {
 
 // ---- 1. advantage statistics ---------------------------------------------------------------------
 // UN independent rows per lane and sweep (index loads, then gathers, all in flight together).
-template <int UN>
+// `b_adv` element i lives at b_adv[i * STRIDE]: STRIDE = 1 for the (B) advantage array, kPackFloats for packed behaviour
+// rows (the caller passes pack + kPackAdv).
+template <int UN, int STRIDE = 1>
 __device__ __forceinline__ void adv_sums(const int64_t* __restrict__ inds, const float* __restrict__ b_adv, int64_t M,
                                          int64_t first, int64_t step, double& s, double& ss) {
     for (int64_t m = first; m < M; m += UN * step) {
@@ -74,7 +80,7 @@ __device__ __forceinline__ void adv_sums(const int64_t* __restrict__ inds, const
             i[u] = inds ? inds[mc] : mc;
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) a[u] = b_adv[i[u]];
+        for (int u = 0; u < UN; ++u) a[u] = b_adv[i[u] * STRIDE];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const double d = (m + u * step < M) ? (double)a[u] : 0.0;
@@ -110,14 +116,15 @@ __device__ __forceinline__ void mean_den_from_sums(double s, double ss, double n
 // (mean, std + 1e-8) pairs of `nseg` consecutive minibatches of `M` rows each (the last may be shorter: `total` rows in
 // all) of one permutation: workgroup (x, y) sums rows x*256 + lane + k*gridDim.x*256 of segment y, four in flight per lane;
 // adv_stats_fold folds a segment's gridDim.x partial pairs in index order.
+template <int STRIDE>
 __global__ __launch_bounds__(256) void adv_stats_partials(const int64_t* __restrict__ inds, const float* __restrict__ b_adv,
                                                           int M, int64_t total, double* __restrict__ partials) {
     __shared__ double red[4];
     const int64_t lo = (int64_t)blockIdx.y * M;
     const int64_t n = (total - lo) < (int64_t)M ? (total - lo) : (int64_t)M;
     double s = 0.0, ss = 0.0;
-    adv_sums<4>(inds ? inds + lo : nullptr, inds ? b_adv : b_adv + lo, n, (int64_t)blockIdx.x * 256 + threadIdx.x,
-                (int64_t)gridDim.x * 256, s, ss);
+    adv_sums<4, STRIDE>(inds ? inds + lo : nullptr, inds ? b_adv : b_adv + lo * STRIDE, n, (int64_t)blockIdx.x * 256 + threadIdx.x,
+                        (int64_t)gridDim.x * 256, s, ss);
     const double bs = block_sum<4>(s, red);
     const double bss = block_sum<4>(ss, red);
     if (threadIdx.x == 0) {
@@ -252,7 +259,8 @@ struct CatRows {
     float v[U], old_lp[U], adv[U], ret[U], old_v[U], act[U];
 };
 
-template <int AMAX, int U, bool VEC>
+// PACKED: `b_actions` points at the packed behaviour rows (kPackFloats per flat index) and the other four pointers are unused.
+template <int AMAX, int U, bool VEC, bool PACKED = false>
 __device__ __forceinline__ void cat_load(CatRows<AMAX, U>& r, int64_t mfirst, int64_t S, const float* __restrict__ logits,
                                          const float* __restrict__ value, const int64_t* __restrict__ inds,
                                          const float* __restrict__ b_actions, const float* __restrict__ b_logprobs,
@@ -273,11 +281,18 @@ __device__ __forceinline__ void cat_load(CatRows<AMAX, U>& r, int64_t mfirst, in
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        r.act[u] = b_actions[i[u]];           // b_actions.long()[mb_inds]  (:320), truncated in cat_rows
-        r.old_lp[u] = b_logprobs[i[u]];
-        r.adv[u] = b_adv[i[u]];
-        r.ret[u] = b_ret[i[u]];
-        r.old_v[u] = b_val[i[u]];
+        if (PACKED) {                         // one 32-byte row: a 16-byte and a 4-byte load of the same 32-byte sector
+            const float* prow = b_actions + i[u] * kPackFloats;
+            const float4 q = *reinterpret_cast<const float4*>(prow);
+            r.act[u] = q.x; r.old_lp[u] = q.y; r.adv[u] = q.z; r.ret[u] = q.w;
+            r.old_v[u] = prow[4];
+        } else {
+            r.act[u] = b_actions[i[u]];       // b_actions.long()[mb_inds]  (:320), truncated in cat_rows
+            r.old_lp[u] = b_logprobs[i[u]];
+            r.adv[u] = b_adv[i[u]];
+            r.ret[u] = b_ret[i[u]];
+            r.old_v[u] = b_val[i[u]];
+        }
         r.v[u] = value[mc[u]];
         const float* row = logits + mc[u] * A;
         if (VEC) {                            // A == AMAX == 4, 16-byte aligned base (host-checked)
@@ -333,7 +348,7 @@ __device__ __forceinline__ void cat_rows(const CatRows<AMAX, U>& r, int64_t mfir
 }
 
 // Lane's rows: m = blockIdx*256 + thread + k * (grid*256).
-template <int AMAX, bool VEC>
+template <int AMAX, bool VEC, bool PACKED = false>
 __global__ __launch_bounds__(256) void loss_categorical_main(
     const float* __restrict__ logits, const float* __restrict__ value, const int64_t* __restrict__ inds,
     const float* __restrict__ b_actions, const float* __restrict__ b_logprobs, const float* __restrict__ b_adv,
@@ -350,16 +365,31 @@ __global__ __launch_bounds__(256) void loss_categorical_main(
     for (int k = 0; k < kNumSums; ++k) sums[k] = 0.0;
     CatRows<AMAX, 1> r;
     // the first row's loads are issued before the statistics are folded: the fold's round trip hides behind them
-    cat_load<AMAX, 1, VEC>(r, m0, S, logits, value, inds, b_actions, b_logprobs, b_adv, b_ret, b_val, A, P.M);
+    cat_load<AMAX, 1, VEC, PACKED>(r, m0, S, logits, value, inds, b_actions, b_logprobs, b_adv, b_ret, b_val, A, P.M);
     float mean = 0.0f, den = 1.0f;
     if (P.norm_adv) fold_adv_stats(stats_partials, adv_mean_den, P, lds4, s_pub, mean, den);
     cat_rows<AMAX, 1, VEC>(r, m0, S, A, mean, den, P, dlogits, dvalue, sums);
     for (int64_t m = m0 + S; m < (int64_t)P.M; m += S) {
-        cat_load<AMAX, 1, VEC>(r, m, S, logits, value, inds, b_actions, b_logprobs, b_adv, b_ret, b_val, A, P.M);
+        cat_load<AMAX, 1, VEC, PACKED>(r, m, S, logits, value, inds, b_actions, b_logprobs, b_adv, b_ret, b_val, A, P.M);
         cat_rows<AMAX, 1, VEC>(r, m, S, A, mean, den, P, dlogits, dvalue, sums);
     }
     emit_block_sums(sums, block_partials, kNumSums, 0, red);
     write_slot_head(slot, P, 0);
+}
+
+// ---- 2a'. packed behaviour rows ------------------------------------------------------------------------------------
+// pack[i] = {actions[i], logprobs[i], advantages[i], returns[i], values[i], 0, 0, 0}: five coalesced 4-byte loads and two
+// 16-byte stores per lane; 52 bytes per row.  Once per iteration, after GAE (the five arrays are final then).
+__global__ __launch_bounds__(256) void batch_pack_kernel(const float* __restrict__ b_actions, const float* __restrict__ b_logprobs,
+                                                         const float* __restrict__ b_adv, const float* __restrict__ b_ret,
+                                                         const float* __restrict__ b_val, float* __restrict__ pack, int64_t B) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) {
+        const float4 q = make_float4(b_actions[i], b_logprobs[i], b_adv[i], b_ret[i]);
+        const float v = b_val[i];
+        float4* row = reinterpret_cast<float4*>(pack + i * kPackFloats);
+        row[0] = q;
+        row[1] = make_float4(v, 0.0f, 0.0f, 0.0f);
+    }
 }
 
 // ---- 2b. normal main -----------------------------------------------------------------------------
@@ -544,8 +574,44 @@ extern "C" MI355PPO_API int mi355ppo_adv_stats_f32(const float* b_advantages, co
     MI355_REQUIRE(aligned(workspace, 8), MI355PPO_EALIGN, "%s: workspace must be 8-byte aligned", fn);
     const int per_seg = adv_stats_per_seg(M);
     double* partials = static_cast<double*>(workspace);
-    hipLaunchKernelGGL(adv_stats_partials, dim3(per_seg, (unsigned)nseg), dim3(256), 0, as_stream(stream), inds, b_advantages, M,
+    hipLaunchKernelGGL(adv_stats_partials<1>, dim3(per_seg, (unsigned)nseg), dim3(256), 0, as_stream(stream), inds, b_advantages, M,
                        total, partials);
+    int rc = check_launch("adv_stats_partials");
+    if (rc) return rc;
+    hipLaunchKernelGGL(adv_stats_fold, dim3((unsigned)nseg), dim3(256), 0, as_stream(stream), partials, per_seg, M, total, mean_den);
+    return check_launch(fn);
+}
+
+extern "C" MI355PPO_API int mi355ppo_batch_pack_f32(const float* b_actions_f32, const float* b_logprobs, const float* b_advantages,
+                                                   const float* b_returns, const float* b_values, float* pack, int64_t B,
+                                                   void* stream) {
+    const char* fn = "mi355ppo_batch_pack_f32";
+    MI355_REQUIRE(b_actions_f32 && b_logprobs && b_advantages && b_returns && b_values && pack, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(B > 0, MI355PPO_EINVAL, "%s: B=%lld must be positive", fn, (long long)B);
+    MI355_REQUIRE(aligned(b_actions_f32, 4) && aligned(b_logprobs, 4) && aligned(b_advantages, 4) && aligned(b_returns, 4) &&
+                      aligned(b_values, 4) && aligned(pack, 32), MI355PPO_EALIGN, "%s: misaligned pointer (pack rows are 32-byte aligned)", fn);
+    const int64_t blocks = (B + 255) / 256;
+    hipLaunchKernelGGL(batch_pack_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream), b_actions_f32,
+                       b_logprobs, b_advantages, b_returns, b_values, pack, B);
+    return check_launch(fn);
+}
+
+extern "C" MI355PPO_API int mi355ppo_adv_stats_packed_f32(const float* pack, const int64_t* inds, int64_t total, int M, float* mean_den,
+                                                         void* workspace, size_t workspace_bytes, void* stream) {
+    const char* fn = "mi355ppo_adv_stats_packed_f32";
+    MI355_REQUIRE(pack && mean_den, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(M > 0 && total > 0, MI355PPO_EINVAL, "%s: M=%d, total=%lld must be positive", fn, M, (long long)total);
+    MI355_REQUIRE(aligned(pack, 32) && aligned(inds, 8) && aligned(mean_den, 4), MI355PPO_EALIGN, "%s: misaligned pointer", fn);
+    const int64_t nseg = (total + M - 1) / M;
+    MI355_REQUIRE(nseg <= 65535, MI355PPO_EINVAL, "%s: %lld minibatches exceed one launch", fn, (long long)nseg);
+    const size_t need = mi355ppo_adv_stats_workspace_bytes(total, M);
+    MI355_REQUIRE(workspace && workspace_bytes >= need, MI355PPO_EWORKSPACE, "%s: workspace %zu bytes < required %zu", fn,
+                  workspace ? workspace_bytes : (size_t)0, need);
+    MI355_REQUIRE(aligned(workspace, 8), MI355PPO_EALIGN, "%s: workspace must be 8-byte aligned", fn);
+    const int per_seg = adv_stats_per_seg(M);
+    double* partials = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(adv_stats_partials<kPackFloats>, dim3(per_seg, (unsigned)nseg), dim3(256), 0, as_stream(stream), inds,
+                       pack + kPackAdv, M, total, partials);
     int rc = check_launch("adv_stats_partials");
     if (rc) return rc;
     hipLaunchKernelGGL(adv_stats_fold, dim3((unsigned)nseg), dim3(256), 0, as_stream(stream), partials, per_seg, M, total, mean_den);
@@ -603,6 +669,43 @@ extern "C" MI355PPO_API int mi355ppo_loss_categorical_fwd_bwd_f32(const float* n
     else { LAUNCH(64, false); }
 #undef LAUNCH
     rc = check_launch("loss_categorical_main");
+    if (rc || !scalars7) return rc;                  // scalars7 == NULL: deferred, mi355ppo_loss_scalars_f32 folds the slot later
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, s, static_cast<const unsigned char*>(workspace), (size_t)0, scalars7,
+                       (float*)nullptr);
+    return check_launch("loss_finalize");
+}
+
+extern "C" MI355PPO_API int mi355ppo_loss_categorical_packed_fwd_bwd_f32(const float* new_logits, const float* new_value,
+                                                                        const int64_t* mb_inds, const float* pack, int M, int A,
+                                                                        double clip_coef, double ent_coef, double vf_coef,
+                                                                        int norm_adv, int clip_vloss, const float* adv_mean_den,
+                                                                        float* scalars7, float* dlogits, float* dvalue,
+                                                                        void* workspace, size_t workspace_bytes, void* stream) {
+    const char* fn = "mi355ppo_loss_categorical_packed_fwd_bwd_f32";
+    int rc = check_common(fn, new_logits, new_value, pack, pack, pack, pack, pack, M, scalars7, dlogits, dvalue, workspace,
+                          workspace_bytes, 0);
+    if (rc) return rc;
+    MI355_REQUIRE(A > 0 && A <= 64, MI355PPO_EINVAL, "%s: A=%d must be in 1..64", fn, A);
+    MI355_REQUIRE(aligned(pack, 32) && aligned(mb_inds, 8) && aligned(adv_mean_den, 4), MI355PPO_EALIGN,
+                  "%s: misaligned pointer (pack rows are 32-byte aligned)", fn);
+    MI355_REQUIRE(!norm_adv || adv_mean_den, MI355PPO_EINVAL,
+                  "%s: norm_adv needs adv_mean_den (mi355ppo_adv_stats_packed_f32); the packed path has no statistics launch of its own", fn);
+    hipStream_t s = as_stream(stream);
+    const LossParams P = make_params(M, clip_coef, ent_coef, vf_coef, norm_adv, clip_vloss, true);
+    LossSlot* slot = static_cast<LossSlot*>(workspace);
+    double* stats = reinterpret_cast<double*>(slot + 1);
+    double* partials = stats + 2 * kStatsMaxBlocks;
+    const int blocks = main_blocks_for(M);
+#define LAUNCH(AMAX, VEC)                                                                                                      \
+    hipLaunchKernelGGL((loss_categorical_main<AMAX, VEC, true>), dim3(blocks), dim3(256), 0, s, new_logits, new_value, mb_inds, \
+                       pack, pack, pack, pack, pack, A, P, stats, adv_mean_den, slot, partials, dlogits, dvalue)
+    if (A == 4 && aligned(new_logits, 16) && aligned(dlogits, 16)) { LAUNCH(4, true); }
+    else if (A <= 4) { LAUNCH(4, false); }
+    else if (A <= 8) { LAUNCH(8, false); }
+    else if (A <= 18) { LAUNCH(18, false); }
+    else { LAUNCH(64, false); }
+#undef LAUNCH
+    rc = check_launch("loss_categorical_main (packed)");
     if (rc || !scalars7) return rc;                  // scalars7 == NULL: deferred, mi355ppo_loss_scalars_f32 folds the slot later
     hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, s, static_cast<const unsigned char*>(workspace), (size_t)0, scalars7,
                        (float*)nullptr);

@@ -116,6 +116,8 @@ class PPOLearner:
             self._inds_pin = torch.empty((int(args.update_epochs), self.batch_size), dtype=torch.int64).pin_memory()
             self._total_norm = torch.zeros(1, device=device)
             self._stage_free.record(torch.cuda.current_stream(device))       # after every buffer's zero fill
+        self._pack = None           # (B, 8) packed behaviour rows (ops.batch_pack) of the current update, or None
+        self._pack_buf = None       # their storage, allocated by the first update()
         self._mb_adv_md = None      # the current minibatch's (mean, std + 1e-8) row of ops.adv_stats, or None
         self._mb_slot = None        # (LossSlots, k): K3's scalar fold deferred to one launch per update (categorical family)
         self._loss_slots = None
@@ -337,6 +339,13 @@ class PPOLearner:
         b_actions = self.actions.reshape((-1,) + self.act_shape)
         b_logprobs, b_advantages = self.logprobs.reshape(-1), self.advantages.reshape(-1)
         b_returns, b_values = self.returns.reshape(-1), self.values.reshape(-1)
+        # K3 gathers ONE 32-byte row per minibatch row instead of five 4-byte values out of five arrays: the five behaviour
+        # arrays are final here (GAE done; tests may have overwritten them), packed once per iteration
+        use_pack = self.hip and self.discrete and type(self).forward_backward_hip is PPOLearner.forward_backward_hip
+        if use_pack:
+            if self._pack_buf is None:
+                self._pack_buf = torch.empty((B, self.ops.PACK_FLOATS), dtype=torch.float32, device=self.device)
+            self._pack = self.ops.batch_pack(b_actions, b_logprobs, b_advantages, b_returns, b_values, out=self._pack_buf)
         k = 0
         folded = 0                       # scalar rows already folded out of the loss slots
         stop = False
@@ -348,7 +357,12 @@ class PPOLearner:
                 inds_dev = self.upload_permutation(epoch, b_inds)
                 # :337-338 hoisted: (mean, std + 1e-8) of every minibatch of this epoch depend only on the permutation and
                 # the GAE output -> one launch per epoch, and K3 runs without its statistics launch
-                adv_md = self.ops.adv_stats(b_advantages, inds_dev, M) if a.norm_adv else None
+                if not a.norm_adv:
+                    adv_md = None
+                elif use_pack:
+                    adv_md = self.ops.adv_stats_packed(self._pack, inds_dev, M)
+                else:
+                    adv_md = self.ops.adv_stats(b_advantages, inds_dev, M)
             for start in range(0, B, M):
                 end = start + M
                 if self.hip:
@@ -370,7 +384,7 @@ class PPOLearner:
                     stop = True
             if stop:
                 break
-        self._mb_adv_md = self._mb_slot = None                            # direct forward_backward_hip calls fold at once
+        self._mb_adv_md = self._mb_slot = self._pack = None               # direct forward_backward_hip calls: arrays, fold at once
         y_pred, y_true = b_values.cpu().numpy(), b_returns.cpu().numpy()  # :382-384
         var_y = np.var(y_true)
         explained_var = np.nan if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y
@@ -445,7 +459,13 @@ class PPOLearner:
                 x = b_obs.index_select(0, idx)
             p, value = self.agent.heads(x)                                # :320 network forward
         value = value.view(-1)
-        if self.discrete:
+        if self.discrete and self._pack is not None:                     # inside update(): packed behaviour rows
+            _, dp, dvalue = ops.ppo_loss_categorical_packed(p.detach().contiguous(), value.detach().contiguous(), idx, self._pack,
+                                                            a.clip_coef, a.ent_coef, a.vf_coef, a.norm_adv, a.clip_vloss,
+                                                            scalars_out=scalars_out, adv_mean_den=self._mb_adv_md,
+                                                            slot=self._mb_slot)
+            torch.autograd.backward([p, value], [dp, dvalue])             # :358
+        elif self.discrete:
             _, dp, dvalue = ops.ppo_loss_categorical(p.detach().contiguous(), value.detach().contiguous(), idx, b_actions,
                                                      b_logprobs, b_advantages, b_returns, b_values, a.clip_coef,
                                                      a.ent_coef, a.vf_coef, a.norm_adv, a.clip_vloss,

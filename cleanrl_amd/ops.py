@@ -303,6 +303,82 @@ def adv_stats(b_advantages, inds, minibatch_size: int, out=None):
     return out
 
 
+PACK_FLOATS = 8       # floats per packed behaviour row: {action, old log-prob, advantage, return, old value, 0, 0, 0}
+
+
+def batch_pack(b_actions, b_logprobs, b_advantages, b_returns, b_values, out=None):
+    """The five per-row behaviour arrays of the flat batch -> ``(B, 8)`` packed rows (one 32-byte gather per minibatch row in
+    K3 instead of five 4-byte gathers; ppo_atari_multigpu.py:320-352).  Once per iteration, after GAE."""
+    lib = _lib.load()
+    Bf, b_logprobs, b_advantages, b_returns, b_values = _flat_batch(b_logprobs, b_advantages, b_returns, b_values)
+    b_actions = _chk(b_actions.reshape(-1), torch.float32, "b_actions (f32 storage, as the reference)", (Bf,))
+    dev = b_logprobs.device
+    out = out if out is not None else torch.empty((Bf, PACK_FLOATS), dtype=torch.float32, device=dev)
+    _chk(out, torch.float32, "pack", (Bf, PACK_FLOATS))
+    with _on(dev):
+        st = lib.mi355ppo_batch_pack_f32(_ptr(b_actions), _ptr(b_logprobs), _ptr(b_advantages), _ptr(b_returns), _ptr(b_values),
+                                         _ptr(out), Bf, _stream(dev))
+    _lib.check(st, "mi355ppo_batch_pack_f32")
+    return out
+
+
+def adv_stats_packed(pack, inds, minibatch_size: int, out=None):
+    """:func:`adv_stats` reading the advantages out of the packed rows of :func:`batch_pack`."""
+    lib = _lib.load()
+    _chk(pack, torch.float32, "pack")
+    if pack.dim() != 2 or pack.shape[1] != PACK_FLOATS:
+        raise ValueError(f"pack: expected (B, {PACK_FLOATS}), got {tuple(pack.shape)}")
+    total = pack.shape[0] if inds is None else inds.numel()
+    if inds is not None:
+        _chk(inds, torch.int64, "inds", (total,))
+    nseg = (total + minibatch_size - 1) // minibatch_size
+    out = out if out is not None else torch.empty(nseg, 2, dtype=torch.float32, device=pack.device)
+    _chk(out, torch.float32, "out", (nseg, 2))
+    ws = _workspace(pack.device, lib.mi355ppo_adv_stats_workspace_bytes(total, int(minibatch_size)))
+    with _on(pack.device):
+        st = lib.mi355ppo_adv_stats_packed_f32(_ptr(pack), _ptr(inds), total, int(minibatch_size), _ptr(out), _ptr(ws), ws.numel(),
+                                               _stream(pack.device))
+    _lib.check(st, "mi355ppo_adv_stats_packed_f32")
+    return out
+
+
+def ppo_loss_categorical_packed(new_logits, new_value, mb_inds, pack, clip_coef: float, ent_coef: float, vf_coef: float,
+                                norm_adv: bool = True, clip_vloss: bool = True, scalars_out=None, dlogits_out=None,
+                                dvalue_out=None, adv_mean_den=None, slot=None):
+    """:func:`ppo_loss_categorical` on the packed rows of :func:`batch_pack` (bit-identical results).  ``adv_mean_den`` (a row
+    of :func:`adv_stats_packed`) is required when ``norm_adv`` is set."""
+    lib = _lib.load()
+    M, A = new_logits.shape
+    _chk(new_logits, torch.float32, "new_logits", (M, A))
+    new_value = _chk(new_value.reshape(-1), torch.float32, "new_value", (M,))
+    dev = new_logits.device
+    if mb_inds is not None:
+        _chk(mb_inds, torch.int64, "mb_inds", (M,))
+    _chk(pack, torch.float32, "pack")
+    if pack.dim() != 2 or pack.shape[1] != PACK_FLOATS:
+        raise ValueError(f"pack: expected (B, {PACK_FLOATS}), got {tuple(pack.shape)}")
+    if norm_adv and adv_mean_den is None:
+        adv_mean_den = adv_stats_packed(pack, mb_inds, M)[0] if mb_inds is not None else adv_stats_packed(pack[:M], None, M)[0]
+    if adv_mean_den is not None:
+        _chk(adv_mean_den, torch.float32, "adv_mean_den", (2,))
+    dlogits = dlogits_out if dlogits_out is not None else torch.empty_like(new_logits)
+    dvalue = dvalue_out if dvalue_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    if slot is not None:
+        slots, k = slot
+        ws_ptr, ws_bytes, scalars = slots.ptr(k), slots.stride, None
+    else:
+        scalars = scalars_out if scalars_out is not None else torch.empty(7, dtype=torch.float32, device=dev)
+        ws = _workspace(dev, lib.mi355ppo_loss_workspace_bytes(M, 0))
+        ws_ptr, ws_bytes = _ptr(ws), ws.numel()
+    with _on(dev):
+        st = lib.mi355ppo_loss_categorical_packed_fwd_bwd_f32(
+            _ptr(new_logits), _ptr(new_value), _ptr(mb_inds), _ptr(pack), M, A, float(clip_coef), float(ent_coef), float(vf_coef),
+            int(bool(norm_adv)), int(bool(clip_vloss)), _ptr(adv_mean_den), _ptr(scalars), _ptr(dlogits), _ptr(dvalue), ws_ptr,
+            ws_bytes, _stream(dev))
+    _lib.check(st, "mi355ppo_loss_categorical_packed_fwd_bwd_f32")
+    return scalars, dlogits, dvalue
+
+
 def ppo_loss_categorical(new_logits, new_value, mb_inds, b_actions, b_logprobs, b_advantages, b_returns, b_values,
                          clip_coef: float, ent_coef: float, vf_coef: float, norm_adv: bool = True,
                          clip_vloss: bool = True, scalars_out=None, dlogits_out=None, dvalue_out=None, adv_mean_den=None,

@@ -184,6 +184,26 @@ MI355PPO_API size_t mi355ppo_adv_stats_workspace_bytes(int64_t total, int M);
 MI355PPO_API int mi355ppo_adv_stats_f32(const float* b_advantages, const int64_t* inds, int64_t total, int M,
                                         float* mean_den, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Packed behaviour rows (round 3): the five per-row behaviour scalars the loss gathers through mb_inds --
+ * `b_actions.long()[mb_inds]`, `b_logprobs[mb_inds]`, `b_advantages[mb_inds]`, `b_returns[mb_inds]`, `b_values[mb_inds]`
+ * (cleanrl/ppo_atari_multigpu.py:320-352) -- stored as ONE 32-byte row per flat batch index,
+ *   pack[i] = {action (f32 storage), old log-prob, advantage, return, old value, 0, 0, 0},
+ * so that a minibatch row costs one 32-byte gather instead of five 4-byte gathers from five arrays (five 128-byte lines
+ * per row once the flat batch outgrows the caches).  mi355ppo_batch_pack_f32 builds the rows once per iteration, after
+ * GAE; the *_packed_* entry points are the K3 calls above reading them: same arithmetic, bit-identical results.
+ *   pack (B, 8) f32, 32-byte aligned.  The packed loss call takes its advantage statistics from the caller
+ *   (adv_mean_den from mi355ppo_adv_stats_packed_f32) whenever norm_adv is set: one launch per minibatch. */
+MI355PPO_API int mi355ppo_batch_pack_f32(const float* b_actions_f32, const float* b_logprobs, const float* b_advantages,
+                                         const float* b_returns, const float* b_values, float* pack, int64_t B, void* stream);
+MI355PPO_API int mi355ppo_adv_stats_packed_f32(const float* pack, const int64_t* inds, int64_t total, int M,
+                                               float* mean_den, void* workspace, size_t workspace_bytes, void* stream);
+MI355PPO_API int mi355ppo_loss_categorical_packed_fwd_bwd_f32(const float* new_logits, const float* new_value,
+                                          const int64_t* mb_inds, const float* pack, int M, int A,
+                                          double clip_coef, double ent_coef, double vf_coef,
+                                          int norm_adv, int clip_vloss, const float* adv_mean_den,
+                                          float* scalars7, float* dlogits, float* dvalue,
+                                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Continuous-action variant, cleanrl/ppo_continuous_action.py:265-300:
  *   new_mean (M,D), logstd (D), b_actions (Bflat,D) -> dmean (M,D), dlogstd (D), dvalue (M). */
 MI355PPO_API int mi355ppo_loss_normal_fwd_bwd_f32(const float* new_mean, const float* logstd, const float* new_value,

@@ -240,6 +240,51 @@ def test_loss_categorical_vs_c_oracle_at_config_sizes(M, A, flags):
         assert torch.equal(table[2], sc5) and torch.equal(table[1], sc) and float(table[0].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("M,A,flags", [(32768, 4, (1, 1)), (8192, 4, (1, 0)), (4096, 6, (0, 1)), (1000, 18, (1, 1)), (5, 3, (1, 1)),
+                                       (1, 4, (0, 1)), (300001, 4, (1, 1)), (700003, 18, (1, 1))])
+def test_loss_categorical_on_packed_behaviour_rows_is_bit_identical(M, A, flags):
+    """Round 3: the five behaviour scalars of a row as ONE 32-byte packed row (mi355ppo_batch_pack_f32) -- the packed K3 call
+    and the packed advantage statistics run the same arithmetic on the same values, so every output is bit-identical to the
+    five-array call (which the tests above hold to the reference's lines and to the C oracle); identity indices included."""
+    rs = np.random.RandomState(7 * M + A)
+    Bf = 4 * M
+    logits = G(rs.standard_normal((M, A)).astype(np.float32))
+    value = G(rs.standard_normal(M).astype(np.float32))
+    inds = G(rs.permutation(Bf)[:M].astype(np.int64))
+    b_actions = G(rs.randint(0, A, Bf).astype(np.float32))
+    b_logprobs = G((-np.log(A) + rs.standard_normal(Bf) * 0.3).astype(np.float32))
+    b_adv = G((rs.standard_normal(Bf) * 2 + 0.5).astype(np.float32))
+    b_val = G(rs.standard_normal(Bf).astype(np.float32))
+    b_ret = b_val + b_adv
+    kw = dict(clip_coef=0.1, ent_coef=0.01, vf_coef=0.5, norm_adv=bool(flags[0]), clip_vloss=bool(flags[1]))
+    pack = ops.batch_pack(b_actions, b_logprobs, b_adv, b_ret, b_val)
+    want = torch.zeros(Bf, 8, device=DEV)
+    for j, t in enumerate((b_actions, b_logprobs, b_adv, b_ret, b_val)):
+        want[:, j] = t
+    assert torch.equal(pack, want)                                                  # the row layout of the header
+    md = ops.adv_stats(b_adv, inds, M) if flags[0] else None
+    if flags[0]:
+        assert torch.equal(ops.adv_stats_packed(pack, inds, M), md)
+        assert torch.equal(ops.adv_stats_packed(pack, None, M), ops.adv_stats(b_adv, None, M))       # every minibatch of an unpermuted epoch
+    row = md[0] if md is not None else None
+    sc, dl, dv = ops.ppo_loss_categorical(logits, value, inds, b_actions, b_logprobs, b_adv, b_ret, b_val, adv_mean_den=row, **kw)
+    scp, dlp, dvp = ops.ppo_loss_categorical_packed(logits, value, inds, pack, adv_mean_den=row, **kw)
+    assert torch.equal(scp, sc) and torch.equal(dlp, dl) and torch.equal(dvp, dv)
+    # without a caller-supplied statistics row the wrapper computes it from the packed rows: same bits again
+    scq, dlq, _ = ops.ppo_loss_categorical_packed(logits, value, inds, pack, **kw)
+    assert torch.equal(scq, sc) and torch.equal(dlq, dl)
+    # identity indices; and the deferred scalar fold
+    row_id = ops.adv_stats(b_adv[:M], None, M)[0] if flags[0] else None
+    sc_i, dl_i, dv_i = ops.ppo_loss_categorical(logits, value, None, b_actions, b_logprobs, b_adv, b_ret, b_val, adv_mean_den=row_id, **kw)
+    sc_j, dl_j, dv_j = ops.ppo_loss_categorical_packed(logits, value, None, pack, adv_mean_den=row_id, **kw)
+    assert torch.equal(sc_j, sc_i) and torch.equal(dl_j, dl_i) and torch.equal(dv_j, dv_i)
+    slots = ops.LossSlots(2, DEV)
+    none, dl_s, _ = ops.ppo_loss_categorical_packed(logits, value, inds, pack, adv_mean_den=row, slot=(slots, 1), **kw)
+    table = torch.zeros(2, 7, device=DEV)
+    slots.fold(1, table, first=1)
+    assert none is None and torch.equal(dl_s, dl) and torch.equal(table[1], sc)
+
+
 def test_loss_autograd_function_matches_torch_autograd_on_device():
     """PPOLossCategorical plugged under a tiny network == the reference op chain differentiated by autograd."""
     torch.manual_seed(0)

@@ -129,6 +129,38 @@ class FakeOps:
             _chk(scalars_out, torch.float32, "scalars_out", (7,)).copy_(sc)
         return (scalars_out if scalars_out is not None else sc), logits.grad, value.grad
 
+    PACK_FLOATS = 8
+
+    @staticmethod
+    def batch_pack(b_actions, b_logprobs, b_advantages, b_returns, b_values, out=None):
+        """include/mi355ppo.h: pack[i] = {action, old log-prob, advantage, return, old value, 0, 0, 0}."""
+        Bf = b_logprobs.numel()
+        cols = [_chk(t.reshape(-1), torch.float32, n, (Bf,)) for t, n in ((b_actions, "b_actions"), (b_logprobs, "b_logprobs"),
+                (b_advantages, "b_advantages"), (b_returns, "b_returns"), (b_values, "b_values"))]
+        out = out if out is not None else torch.empty(Bf, 8)
+        _chk(out, torch.float32, "pack", (Bf, 8))
+        out.zero_()
+        for j, c in enumerate(cols):
+            out[:, j] = c
+        return out
+
+    @staticmethod
+    def adv_stats_packed(pack, inds, minibatch_size, out=None):
+        _chk(pack, torch.float32, "pack")
+        assert pack.dim() == 2 and pack.shape[1] == 8
+        return FakeOps.adv_stats(pack[:, 2].contiguous(), inds, minibatch_size, out)
+
+    @staticmethod
+    def ppo_loss_categorical_packed(new_logits, new_value, mb_inds, pack, clip_coef, ent_coef, vf_coef, norm_adv=True,
+                                    clip_vloss=True, scalars_out=None, dlogits_out=None, dvalue_out=None, adv_mean_den=None,
+                                    slot=None):
+        _chk(pack, torch.float32, "pack")
+        assert pack.dim() == 2 and pack.shape[1] == 8 and float(pack[:, 5:].abs().sum()) == 0.0
+        assert not norm_adv or adv_mean_den is not None, "the packed K3 entry point has no statistics launch of its own"
+        c = [pack[:, j].contiguous() for j in range(5)]
+        return FakeOps.ppo_loss_categorical(new_logits, new_value, mb_inds, c[0], c[1], c[2], c[3], c[4], clip_coef, ent_coef, vf_coef,
+                                            norm_adv, clip_vloss, scalars_out, dlogits_out, dvalue_out, adv_mean_den, slot)
+
     @staticmethod
     def normal_sample(mean, logstd, noise=None, seed=0, offset=0, action_out=None, logprob_out=None):
         B, D = mean.shape

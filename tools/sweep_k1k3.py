@@ -70,9 +70,19 @@ def main():
                                                       dlogits_out=dl, dvalue_out=dv, adv_mean_den=md, slot=(slots, 0))
                 us2 = ev_us(f2, REPS)
                 slots.fold(1, sc.view(1, 7))
+                # round 3: the five behaviour scalars as one 32-byte packed row per flat index (one gather instead of five)
+                pack = ops.batch_pack(b_actions, b_lp, b_adv, b_ret, b_val)
+                us_pack = ev_us(lambda: ops.batch_pack(b_actions, b_lp, b_adv, b_ret, b_val, out=pack), REPS)
+                f3 = lambda: ops.ppo_loss_categorical_packed(logits, value, inds, pack, 0.1, 0.01, 0.5, True, True, dlogits_out=dl,
+                                                             dvalue_out=dv, adv_mean_den=md, slot=(slots, 0))
+                us3 = ev_us(f3, REPS)
+                slots.fold(1, sc.view(1, 7))
+                del pack
             nbytes = (8 * A + 28 + (8 if inds is not None else 0)) * M
             print(json.dumps(dict(kernel="loss_categorical", mode=mode, M=M, B=B, algorithmic_bytes=nbytes, event_us_per_call=us,
-                                  GBps=nbytes / us / 1e3, event_us_per_call_learner_mode=us2)), flush=True)
+                                  GBps=nbytes / us / 1e3, event_us_per_call_learner_mode=us2, GBps_learner_mode=nbytes / us2 / 1e3,
+                                  event_us_per_call_packed_rows=us3, GBps_packed_rows=nbytes / us3 / 1e3,
+                                  batch_pack_event_us=us_pack)), flush=True)
 
 
 if __name__ == "__main__":
