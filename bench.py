@@ -239,8 +239,9 @@ def main():
     conv_flops = {}
     unhook = []          # (module, name, original) of everything the kernel timing wraps
     if not cli.no_kernel_timing:
-        real_obs, real_gae, real_loss = ops.obs_u8_to_f32, ops.gae, ops.ppo_loss_categorical
-        unhook += [(ops, "obs_u8_to_f32", real_obs), (ops, "gae", real_gae), (ops, "ppo_loss_categorical", real_loss)]
+        real_obs, real_gae, real_loss, real_loss_p = ops.obs_u8_to_f32, ops.gae, ops.ppo_loss_categorical, ops.ppo_loss_categorical_packed
+        unhook += [(ops, "obs_u8_to_f32", real_obs), (ops, "gae", real_gae), (ops, "ppo_loss_categorical", real_loss),
+                   (ops, "ppo_loss_categorical_packed", real_loss_p)]
         if learner.fused_cnn:
             from cleanrl_amd import cnn
 
@@ -288,6 +289,7 @@ def main():
         ops.obs_u8_to_f32 = obs_hook
         ops.gae = timer.wrap("gae", real_gae)
         ops.ppo_loss_categorical = timer.wrap("loss", real_loss)
+        ops.ppo_loss_categorical_packed = timer.wrap("loss", real_loss_p)      # the learner's call: packed behaviour rows
     total_iters = cli.warmup + cli.steps
 
     phase_events = []
@@ -397,10 +399,11 @@ def main():
             loss_bytes = (8 * cli.n_actions + 28 + 8) * M
             out["kernels"] = {
                 "gae": {"algorithmic_bytes": gae_bytes, "avg_us_event_bracket": gus, "GBps": gae_bytes / gus / 1e3,
-                        "launches_timed": gn, "note": "128x1024 is launch/latency-bound: see profiles/ for the kernel time"},
+                        "launches_timed": gn, "note": f"{T}x{N} is launch/latency-bound: see profiles/ for the kernel time"},
                 "loss_fwd_bwd": {"algorithmic_bytes": loss_bytes, "avg_us_event_bracket": lus,
                                  "GBps": loss_bytes / lus / 1e3, "launches_timed": ln,
-                                 "note": "one launch per minibatch (advantage statistics once per epoch, scalar fold once per update)"},
+                                 "note": "one launch per minibatch on packed behaviour rows (one 32-byte gather per row; advantage "
+                                         "statistics once per epoch, scalar fold once per update)"},
             }
             for k in sorted(tot):
                 kus, kn = timer.mean_us(k)

@@ -27,6 +27,7 @@ VARIANT_DGRAD2_CLASSES = 6
 QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 storage elements (kernel Q's integer-digit pack)
 VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
 VARIANT_X = 7                       # layer-2 / 3 forward on the bf16 matrix pipe with exact products (csrc/convx.hip); Bt = the mode-6 pack
+_FC_Z = os.environ.get("MI355PPO_FC", "z") != "x"      # FC forward / data gradient: kernel Z (pre-split weights, coalesced loads) or kernel X
 _FWD23_BF16 = os.environ.get("MI355PPO_FWD23", "f32") == "bf16"      # minibatch-sized forward of layers 2 / 3: kernel F (default) or kernel C
 
 
@@ -161,6 +162,57 @@ def fc_fwd_relu(a: torch.Tensor, Wp: torch.Tensor, bias: torch.Tensor, out: torc
     return out
 
 
+def fc_pack(B: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """(N, K) f32 matrix (unit column stride, any row pitch >= K) -> kernel Z's pre-split fragment-order pack (csrc/gemmz.hip)."""
+    lib = _lib.load()
+    if B.dtype != torch.float32 or not B.is_cuda or B.dim() != 2 or B.stride(1) != 1 or B.stride(0) < B.shape[1]:
+        raise ValueError(f"fc_pack: expected a row-major f32 device matrix, got {tuple(B.shape)} strides {B.stride()} {B.dtype} on {B.device}")
+    N, K = B.shape
+    nbytes = lib.mi355ppo_fc_pack_bytes(N, K)
+    if nbytes == 0:
+        raise ValueError(f"fc_pack: K={K} must be a positive multiple of 16")
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=B.device)
+    _chk(out, torch.uint8, "pack", (nbytes,))
+    with _on(B.device):
+        st = lib.mi355ppo_fc_pack_f32(_ptr(B), B.stride(0), N, K, _ptr(out), _stream(B.device))
+    _lib.check(st, "mi355ppo_fc_pack_f32")
+    return out
+
+
+def fc_fwd_relu_packed(a: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, N: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``relu(a @ B.T + bias)`` with ``pack = fc_pack(B)``, B (N, K): kernel Z."""
+    lib = _lib.load()
+    M, K = a.shape
+    lda = _row_major(a, "a")
+    _chk(bias, torch.float32, "bias", (N,))
+    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(N, K),))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _chk(out, torch.float32, "out", (M, N))
+    with _on(a.device):
+        st = lib.mi355ppo_fc_fwd_relu_packed_f32(_ptr(a), lda, _ptr(pack), _ptr(bias), _ptr(out), M, N, K, _stream(a.device))
+    _lib.check(st, "mi355ppo_fc_fwd_relu_packed_f32")
+    return out
+
+
+def fc_dgrad_mask_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``(dz @ B.T) * (act_in > 0)`` with ``pack = fc_pack(B)``, B (N, K) = the transposed weight: kernel Z."""
+    lib = _lib.load()
+    M, K = dz.shape
+    N = act_in.shape[1]
+    lddz = _row_major(dz, "dz")
+    _chk(act_in, torch.float32, "act_in", (M, N))
+    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(N, K),))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=dz.device)
+    _chk(out, torch.float32, "out", (M, N))
+    with _on(dz.device):
+        st = lib.mi355ppo_fc_dgrad_mask_packed_f32(_ptr(dz), lddz, _ptr(pack), _ptr(act_in), _ptr(out), M, N, K, _stream(dz.device))
+    _lib.check(st, "mi355ppo_fc_dgrad_mask_packed_f32")
+    return out
+
+
 FC_PAD = 4          # extra floats per row of the K = 512 operands of the FC data gradient: a dense 2 KiB pitch puts the 32 rows of
                     # a fragment load on one cache channel (measured: 1.47 ms against 0.70 ms for the forward of the same size)
 
@@ -248,6 +300,24 @@ class _Buffers:
                 hit[1].copy_(fc_weight_hwc(W.detach()))
                 hit = (tag, hit[1])
             self._bt["fc"] = hit
+        return hit[1]
+
+    def fc_pack_fwd(self, W: torch.Tensor) -> torch.Tensor:
+        """Kernel Z's pack of the (h,w,c)-ordered Linear(3136,512) weight (the forward's B operand), cached like the matrices."""
+        return self._pack_cached("fc_pack_fwd", W, lambda: self.fc_weight(W))
+
+    def fc_pack_dgrad(self, W: torch.Tensor) -> torch.Tensor:
+        """Kernel Z's pack of its transpose (3136, 512): the data gradient's B operand."""
+        return self._pack_cached("fc_pack_dgrad", W, lambda: self.fc_weight_t(W))
+
+    def _pack_cached(self, key, W, source):
+        if not self.cache_weights:
+            return fc_pack(source())
+        tag = (self.weights_version, W._version, W.data_ptr())
+        hit = self._bt.get(key)
+        if hit is None or hit[0] != tag:
+            hit = (tag, fc_pack(source(), hit[1] if hit is not None else None))
+            self._bt[key] = hit
         return hit[1]
 
     def fc_dz(self, m: int, n: int, dev) -> torch.Tensor:
@@ -378,7 +448,9 @@ class LinearReLUHwcFn(torch.autograd.Function):
         # minibatch-sized batches on the GPU: kernel X (csrc/fcx.hip), bf16 matrix pipe with exact products; bias + ReLU in
         # its epilogue.  Rollout-sized batches and the host path: the library GEMM with the same fused epilogue.
         ctx.fcx = bool(a.is_cuda and bufs is not None and a.shape[0] >= FCX_MIN_ROWS and a.shape[1] % 16 == 0 and a.is_contiguous())
-        if ctx.fcx:
+        if ctx.fcx and _FC_Z:
+            h = fc_fwd_relu_packed(a, bufs.fc_pack_fwd(W), b.detach().contiguous(), Wp.shape[0])
+        elif ctx.fcx:
             h = fc_fwd_relu(a, Wp, b.detach().contiguous())
         else:
             h = torch._addmm_activation(b.detach(), a, Wp.t())                 # bias + ReLU fused into the GEMM epilogue
@@ -404,7 +476,7 @@ class LinearReLUHwcFn(torch.autograd.Function):
             if fused:
                 # `a` is the trunk's ReLU output a3: its ReLU backward rides in this GEMM's epilogue (kernel X, EPI_MASK) and
                 # NatureTrunkFn.backward is told not to mask again -- the separate pass over the 411 MB tensor is gone
-                da = fc_dgrad_mask(dz, bufs.fc_weight_t(W), a)
+                da = fc_dgrad_mask_packed(dz, bufs.fc_pack_dgrad(W), a) if _FC_Z else fc_dgrad_mask(dz, bufs.fc_weight_t(W), a)
                 bufs.a3_grad_is_masked = True
             else:
                 da = dz @ Wp

@@ -18,6 +18,7 @@
 // One wave per SIMD (512 registers) owns 128 pixels x 64 channels (4 x 2 tiles = 128 accumulator registers).  Per k-step:
 // 8 + 6 loads, 176 VALU (four A fragments split), 72 MFMAs.
 #include "common.h"
+#include "bf16split.h"
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -40,34 +41,7 @@ using CGeom3 = CGeom<9, 9, 64, 3, 3, 7, 7, 1>;
 constexpr int kCCout = 64, kCMT = 4, kCNT = 2;
 constexpr int kCStepBytes = kCNT * 3 * 64 * 16;                    // 6 KiB of B terms per k-step
 
-struct CTerms {
-    c_bf16x8 t[3];
-};
-
-__device__ __forceinline__ unsigned c_pack(float e1, float e0) {
-    return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
-}
-
-// 8 f32 -> three packed bf16x8 whose element-wise sum is the input, exactly (hi = top 8 significand bits, mid, lo)
-__device__ __forceinline__ CTerms c_split(const c_u32x4& lo4, const c_u32x4& hi4) {
-    const float x[8] = {__uint_as_float(lo4.x), __uint_as_float(lo4.y), __uint_as_float(lo4.z), __uint_as_float(lo4.w),
-                        __uint_as_float(hi4.x), __uint_as_float(hi4.y), __uint_as_float(hi4.z), __uint_as_float(hi4.w)};
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const float x0 = x[j], x1 = x[j + 1];
-        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
-        const float l0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), l1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-        h[j >> 1] = c_pack(x1, x0);
-        m[j >> 1] = c_pack(r1, r0);
-        l[j >> 1] = c_pack(l1, l0);
-    }
-    CTerms o;
-    o.t[0] = __builtin_bit_cast(c_bf16x8, (c_u32x4){h[0], h[1], h[2], h[3]});
-    o.t[1] = __builtin_bit_cast(c_bf16x8, (c_u32x4){m[0], m[1], m[2], m[3]});
-    o.t[2] = __builtin_bit_cast(c_bf16x8, (c_u32x4){l[0], l[1], l[2], l[3]});
-    return o;
-}
+using CTerms = SplitTerms;
 
 // pack[s][j][t][lane][e] (bf16) = term t of W[co = 32 j + (lane & 31)][ci][ty][tx] with k = 16 s + 8 (lane >> 5) + e =
 // (ty * KW + tx) * C + ci; W is the Conv2d weight (Cout, C, KH, KW).
@@ -88,10 +62,10 @@ __global__ __launch_bounds__(256) void convx_pack_kernel(const float* __restrict
 }
 
 // NP = 9: all 3 x 3 term pairs (exact products); NP = 6: the pairs with x + y <= 2 (common.h: bf16_term_pairs).
-template <class G, int NP>
+template <class G, int NP, int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convx_fwd_kernel(
     const float* __restrict__ src, const unsigned char* __restrict__ pack, const float* __restrict__ bias, float* __restrict__ dst,
-    long long P) {
+    long long P, unsigned m8, unsigned m16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const long long p0 = ((long long)blockIdx.x * 4 + wave) * (32 * kCMT);
@@ -146,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_sched_barrier(0);
         fetchA(q, (c2 ? next_off : row_off) + 16 * u2);
 #pragma unroll
-        for (int i = 0; i < kCMT; ++i) ta[q ^ 1][i] = c_split(raw[q ^ 1][i][0], raw[q ^ 1][i][1]);
+        for (int i = 0; i < kCMT; ++i) ta[q ^ 1][i] = split8<SPLIT>(raw[q ^ 1][i][0], raw[q ^ 1][i][1], m8, m16);
         // term pairs outermost, the eight independent tiles innermost: no MFMA waits for the one before it
 #pragma unroll
         for (int x = 0; x < 3; ++x)
@@ -172,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     fetchA(0, 0);
     fetchB(0, 0);
 #pragma unroll
-    for (int i = 0; i < kCMT; ++i) ta[0][i] = c_split(raw[0][i][0], raw[0][i][1]);
+    for (int i = 0; i < kCMT; ++i) ta[0][i] = split8<SPLIT>(raw[0][i][0], raw[0][i][1], m8, m16);
     fetchA(1, 16);
     __builtin_amdgcn_sched_barrier(0);
     for (int row = 0; row < G::KH; ++row) {
@@ -205,12 +179,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <class G>
 static int convx_launch(const float* src, const void* pack, const float* bias, float* dst, long long images, hipStream_t s) {
     const long long P = images * G::PER_IMG, tiles = (P + 32 * kCMT - 1) / (32 * kCMT);
-    if (bf16_term_pairs() == 9)
-        hipLaunchKernelGGL((convx_fwd_kernel<G, 9>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, src, static_cast<const unsigned char*>(pack),
-                           bias, dst, P);
-    else
-        hipLaunchKernelGGL((convx_fwd_kernel<G, 6>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, src, static_cast<const unsigned char*>(pack),
-                           bias, dst, P);
+#define CONVX_FWD(NP, SP)                                                                                                   \
+    hipLaunchKernelGGL((convx_fwd_kernel<G, NP, SP>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, src,                 \
+                       static_cast<const unsigned char*>(pack), bias, dst, P, 0xffff0000u, 0xffffff00u)
+    const int np = bf16_term_pairs(), sp = bf16_split_mode();
+    if (np == 9 && sp == 0) CONVX_FWD(9, 0);
+    else if (np == 9) CONVX_FWD(9, 1);
+    else if (sp == 0) CONVX_FWD(6, 0);
+    else CONVX_FWD(6, 1);
+#undef CONVX_FWD
     return check_launch("convx_fwd_kernel");
 }
 

@@ -14,6 +14,7 @@
 // ReLU backward of the layer BELOW, conv3, applied where the gradient is produced, as the conv data-gradient kernels do;
 // the reference runs it as a separate pass over the 411 MB tensor).
 #include "common.h"
+#include "bf16split.h"
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -26,34 +27,7 @@ typedef __bf16 x_bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { X_BIAS_RELU = 0, X_MASK = 1 };
 
-struct XTerms {
-    x_bf16x8 t[3];       // hi, mid, lo of 8 consecutive k
-};
-
-__device__ __forceinline__ unsigned x_pack(float e1, float e0) {
-    return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
-}
-
-// 8 f32 (two 16-byte loads) -> three packed bf16x8 whose element-wise sum is the input, exactly
-__device__ __forceinline__ XTerms x_split(const x_u32x4& lo4, const x_u32x4& hi4) {
-    float x[8] = {__uint_as_float(lo4.x), __uint_as_float(lo4.y), __uint_as_float(lo4.z), __uint_as_float(lo4.w),
-                  __uint_as_float(hi4.x), __uint_as_float(hi4.y), __uint_as_float(hi4.z), __uint_as_float(hi4.w)};
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const float x0 = x[j], x1 = x[j + 1];
-        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
-        const float l0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), l1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-        h[j >> 1] = x_pack(x1, x0);
-        m[j >> 1] = x_pack(r1, r0);
-        l[j >> 1] = x_pack(l1, l0);
-    }
-    XTerms o;
-    o.t[0] = __builtin_bit_cast(x_bf16x8, (x_u32x4){h[0], h[1], h[2], h[3]});
-    o.t[1] = __builtin_bit_cast(x_bf16x8, (x_u32x4){m[0], m[1], m[2], m[3]});
-    o.t[2] = __builtin_bit_cast(x_bf16x8, (x_u32x4){l[0], l[1], l[2], l[3]});
-    return o;
-}
+using XTerms = SplitTerms;
 
 // A (M, K) row-major with leading dimension lda, B (N, K) with ldb, C (M, N) with ldc; K % 16 == 0.
 // bias (N) for X_BIAS_RELU; cmask (M, N) with ldc for X_MASK.
@@ -68,10 +42,10 @@ constexpr int kXMT = 2, kXNT = 4, kXF = kXMT + kXNT;
 // the forward, where A is the 411 MB activation and B the 6.4 MB weight; measured 3.6 x the algorithmic bytes with the
 // waves stacked) instead of on top of each other (256 x 128: they share the B rows).
 // NP = 9: all 3 x 3 term pairs (exact products); NP = 6: the pairs with ta + tb <= 2 (common.h: bf16_term_pairs).
-template <int EPI, bool WAVES_N, int NP>
+template <int EPI, bool WAVES_N, int NP, int SPLIT, bool COAL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fcx_gemm_nt_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, const float* __restrict__ bias,
-    const float* __restrict__ cmask, float* __restrict__ C, int ldc, int M, int N, int K) {
+    const float* __restrict__ cmask, float* __restrict__ C, int ldc, int M, int N, int K, unsigned m8, unsigned m16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int m0 = WAVES_N ? blockIdx.y * 64 : blockIdx.y * 256 + wave * 64;
@@ -89,6 +63,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int r = n0 + 32 * j + li;
         pf[kXMT + j] = B + (size_t)(r < N ? r : N - 1) * ldb + 8 * lh;
     }
+    if (COAL) {
+        // TIMING EXPERIMENT ONLY (MI355PPO_FCX_COAL=1, results are garbage): the same number of 16-byte loads and the same
+        // bytes per k-step, but four consecutive lanes read one row's 64 contiguous bytes -- what a coalesced load + LDS
+        // transposition would ask of the memory pipeline.  Tests whether the per-lane row gather (every lane its own cache
+        // line) is what bounds the kernel.
+#pragma unroll
+        for (int i = 0; i < kXMT; ++i) {
+            const int r = m0 + 32 * i + (lane >> 2);
+            pf[i] = A + (size_t)(r < M ? r : M - 1) * lda + 4 * (lane & 3);
+        }
+#pragma unroll
+        for (int j = 0; j < kXNT; ++j) {
+            const int r = n0 + 32 * j + (lane >> 2);
+            pf[kXMT + j] = B + (size_t)(r < N ? r : N - 1) * ldb + 4 * (lane & 3);
+        }
+    }
     x_f32x16 acc[kXMT][kXNT];
 #pragma unroll
     for (int i = 0; i < kXMT; ++i)
@@ -103,7 +93,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int q = 0; q < kXF; ++q) {
             raw[st][q][0] = *reinterpret_cast<const x_u32x4*>(pf[q] + k0);
-            raw[st][q][1] = *reinterpret_cast<const x_u32x4*>(pf[q] + k0 + 4);
+            raw[st][q][1] = *reinterpret_cast<const x_u32x4*>(pf[q] + k0 + (COAL ? 16 * (size_t)(q < kXMT ? lda : ldb) : (size_t)4));
         }
     };
     const int nsteps = K >> 4;
@@ -114,7 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int q = decltype(qc)::value;
         fetch(q, kof(s + 2));
 #pragma unroll
-        for (int f = 0; f < kXF; ++f) pc[q ^ 1][f] = x_split(raw[q ^ 1][f][0], raw[q ^ 1][f][1]);
+        for (int f = 0; f < kXF; ++f) pc[q ^ 1][f] = split8<SPLIT>(raw[q ^ 1][f][0], raw[q ^ 1][f][1], m8, m16);
         // term pairs outermost, the eight independent tiles innermost: no MFMA waits for the one before it
 #pragma unroll
         for (int ta = 0; ta < 3; ++ta)
@@ -139,7 +129,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // prologue: stage 0 split into pc[0], stage 1 raw in flight in raw[1]
     fetch(0, 0);
 #pragma unroll
-    for (int f = 0; f < kXF; ++f) pc[0][f] = x_split(raw[0][f][0], raw[0][f][1]);
+    for (int f = 0; f < kXF; ++f) pc[0][f] = split8<SPLIT>(raw[0][f][0], raw[0][f][1], m8, m16);
     fetch(1, kof(1));
     __builtin_amdgcn_sched_barrier(0);
     int s = 0;
@@ -225,12 +215,19 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float
     if (rc) return rc;
     MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
     MI355_REQUIRE((M + 63) / 64 <= 65535, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
-    if (bf16_term_pairs() == 9)
-        hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU, true, 9>), dim3((N + 511) / 512, (M + 63) / 64), dim3(256), 0, as_stream(stream), a, K,
-                           W, K, bias, (const float*)nullptr, h, N, M, N, K);
-    else
-        hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU, true, 6>), dim3((N + 511) / 512, (M + 63) / 64), dim3(256), 0, as_stream(stream), a, K,
-                           W, K, bias, (const float*)nullptr, h, N, M, N, K);
+#define FCX_FWD(NP, SP)                                                                                                       \
+    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU, true, NP, SP>), dim3((N + 511) / 512, (M + 63) / 64), dim3(256), 0,    \
+                       as_stream(stream), a, K, W, K, bias, (const float*)nullptr, h, N, M, N, K, 0xffff0000u, 0xffffff00u)
+    const int np = bf16_term_pairs(), sp = bf16_split_mode();
+    static const bool coal = getenv("MI355PPO_FCX_COAL") != nullptr;      // timing experiment, garbage results
+    if (coal)
+        hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_BIAS_RELU, true, 6, 1, true>), dim3((N + 511) / 512, (M + 63) / 64), dim3(256), 0,
+                           as_stream(stream), a, K, W, K, bias, (const float*)nullptr, h, N, M, N, K, 0xffff0000u, 0xffffff00u);
+    else if (np == 9 && sp == 0) FCX_FWD(9, 0);
+    else if (np == 9) FCX_FWD(9, 1);
+    else if (sp == 0) FCX_FWD(6, 0);
+    else FCX_FWD(6, 1);
+#undef FCX_FWD
     return check_launch(fn);
 }
 
@@ -240,11 +237,14 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, int lddz
     int rc = fcx_check(fn, dz, Wt, da, M, N, K, lddz, ldwt, N);
     if (rc) return rc;
     MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
-    if (bf16_term_pairs() == 9)
-        hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK, false, 9>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), dz, lddz,
-                           Wt, ldwt, (const float*)nullptr, act_in, da, N, M, N, K);
-    else
-        hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK, false, 6>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0, as_stream(stream), dz, lddz,
-                           Wt, ldwt, (const float*)nullptr, act_in, da, N, M, N, K);
+#define FCX_DGRAD(NP, SP)                                                                                                     \
+    hipLaunchKernelGGL((fcx_gemm_nt_kernel<X_MASK, false, NP, SP>), dim3((N + 127) / 128, (M + 255) / 256), dim3(256), 0,      \
+                       as_stream(stream), dz, lddz, Wt, ldwt, (const float*)nullptr, act_in, da, N, M, N, K, 0xffff0000u, 0xffffff00u)
+    const int np = bf16_term_pairs(), sp = bf16_split_mode();
+    if (np == 9 && sp == 0) FCX_DGRAD(9, 0);
+    else if (np == 9) FCX_DGRAD(9, 1);
+    else if (sp == 0) FCX_DGRAD(6, 0);
+    else FCX_DGRAD(6, 1);
+#undef FCX_DGRAD
     return check_launch(fn);
 }

@@ -273,6 +273,22 @@ MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float* W, const 
 MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, int lddz, const float* Wt, int ldwt, const float* act_in, float* da,
                                             int M, int N, int K, void* stream);
 
+/* Round 3 -- kernel Z (csrc/gemmz.hip), the same two GEMMs with the weight matrix split AHEAD (once per optimizer step) into
+ * MFMA fragment order and the activations loaded coalesced through a wave-private LDS transposition: the per-lane row gather
+ * of the entry points above kept the vector-memory front end 83 % busy and the matrix pipe 37 % busy.  The six largest of
+ * the nine term pairs are multiplied (MI355PPO_BF16_PAIRS=9: all nine); the three dropped pairs are below the rounding of one
+ * f32 multiply.
+ *   pack  : B (N,K) f32 with leading dimension ldb -> mi355ppo_fc_pack_bytes(N, K) bytes, 16-byte aligned
+ *   fwd   : h (M,N) = relu(a (M,K; lda) @ B^T + bias)         pack = pack(W  (N = 512,  K = 3136))
+ *   dgrad : da (M,N) = (dz (M,K; lddz) @ B^T) * (act_in > 0)  pack = pack(Wt (N = 3136, K = 512))
+ * K % 16 == 0; a / dz 16-byte aligned with leading dimensions that are multiples of 4 floats, below 4 GiB in all. */
+MI355PPO_API size_t mi355ppo_fc_pack_bytes(int N, int K);
+MI355PPO_API int mi355ppo_fc_pack_f32(const float* B, int ldb, int N, int K, void* pack, void* stream);
+MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
+                                                 int M, int N, int K, void* stream);
+MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, int lddz, const void* pack, const float* act_in, float* da,
+                                                   int M, int N, int K, void* stream);
+
 /* FC weight gradient (csrc/fcw.hip, f32 matrix pipe): dW (N,K) = dz (M,N)^T @ a (M,K), the batch cut into slabs whose
  * partials are added in a fixed order (deterministic).  dz takes a leading dimension (even); a is dense.  N % 64 == 0,
  * K % 224 == 0 (whole 64 x 224 wave tiles: 512 x 3136 = 8 x 14 of them); dz 8-byte, a and the workspace 16-byte aligned.

@@ -416,9 +416,11 @@ def test_fc_kernels_at_the_full_minibatch_size_against_float64_on_the_device():
     dz = torch.randn(M, 512, device=DEV, generator=g) * (torch.rand(M, 512, device=DEV, generator=g) > 0.4)
     a64, W64, dz64 = a.double(), W.double(), dz.double()
     _close(cnn.fc_fwd_relu(a, W, b), torch.relu(a64 @ W64.t() + b.double()), "fc fwd (kernel X) at 32768")
+    _close(cnn.fc_fwd_relu_packed(a, cnn.fc_pack(W), b, 512), torch.relu(a64 @ W64.t() + b.double()), "fc fwd (kernel Z) at 32768")
     Wt = torch.empty((3136, 516), device=DEV)[:, :512]
     Wt.copy_(W.t())
     _close(cnn.fc_dgrad_mask(dz, Wt, a), (dz64 @ W64) * (a > 0), "fc dgrad + mask (kernel X) at 32768")
+    _close(cnn.fc_dgrad_mask_packed(dz, cnn.fc_pack(Wt), a), (dz64 @ W64) * (a > 0), "fc dgrad + mask (kernel Z) at 32768")
     ref = dz64.t() @ a64
     got = cnn.fc_wgrad(dz, a)
     scale = ref.abs().max().item()
@@ -545,6 +547,65 @@ def test_full_minibatch_size_properties():
     W1b, _ = cnn.conv_wgrad(obs, d1b, 1, inds)
     W1ab, _ = cnn.conv_wgrad(obs, d1a + d1b, 1, inds)
     assert (W1ab - (W1a + W1b)).abs().max().item() <= 2e-4 * (W1a.abs().max() + W1b.abs().max()).item()
+
+
+def _unpack_z(pack, N, K):
+    """Decode kernel Z's pack back into three (N, K) float64 planes: the inverse of zpack_kernel (csrc/gemmz.hip)."""
+    ntiles = (N + 31) // 32
+    raw = pack.cpu().numpy().view(np.uint16).reshape(K // 16, ntiles, 3, 64, 8)          # [s][j][t][lane][e]
+    f32 = (raw.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    planes = np.zeros((3, ntiles * 32, K))
+    for lane in range(64):
+        n_in, kb = lane & 31, lane >> 5
+        for t in range(3):
+            # rows 32 j + n_in, columns 16 s + 8 kb + e
+            planes[t, n_in::32, :].reshape(ntiles, K // 16, 16)[:, :, 8 * kb:8 * kb + 8] = f32[:, :, t, lane, :].transpose(1, 0, 2)
+    return planes[:, :N]
+
+
+@pytest.mark.parametrize("N,K", [(512, 3136), (3136, 512), (40, 32)])
+def test_fc_pack_planes_sum_back_to_the_matrix_exactly(N, K):
+    """Kernel Z's pre-split weight pack: the three bf16 planes sum back to every weight bit for bit (the split loses nothing),
+    each plane is bf16-representable by construction, rows past N in the last 32-row tile are zero; padded row pitch allowed."""
+    g = torch.Generator().manual_seed(N + K)
+    W = torch.randn(N, K, generator=g) * torch.exp(2.0 * torch.randn(N, K, generator=g))      # wide dynamic range, all 24 bits used
+    Wp = cnn.padded_rows(N, K, DEV)
+    Wp.copy_(W)
+    for src in (W.to(DEV), Wp):
+        planes = _unpack_z(cnn.fc_pack(src), N, K)
+        assert np.array_equal(planes.sum(0), W.double().numpy())
+        assert np.all(np.abs(planes[1]) <= np.abs(planes[0]) * 2.0 ** -7 + 1e-300) and np.all(np.abs(planes[2]) <= np.abs(planes[0]) * 2.0 ** -15 + 1e-300)
+
+
+@pytest.mark.parametrize("M", [1, 130, 4100])
+def test_fcz_forward_and_masked_data_gradient_against_float64(M):
+    """Kernel Z (csrc/gemmz.hip): the FC layer's forward and data gradient with the weight pre-split into fragment order and the
+    activations loaded coalesced through LDS -- the bounds of kernel X's test (2e-5 of the result's scale against float64; the
+    library's f32 GEMM is held to the same bound for calibration), the error not above 1.25 x the library GEMM's."""
+    g = torch.Generator().manual_seed(190 + M)
+    a = torch.relu(torch.randn(M, 3136, generator=g)) * torch.exp(torch.randn(M, 3136, generator=g))
+    W = torch.randn(512, 3136, generator=g) / 56.0
+    b = torch.randn(512, generator=g) * 0.1
+    ref = torch.relu(a.double() @ W.double().t() + b.double())
+    got = cnn.fc_fwd_relu_packed(a.to(DEV), cnn.fc_pack(W.to(DEV)), b.to(DEV), 512)
+    _close(got, ref, "fc fwd (kernel Z)")
+    lib32 = torch.relu(a.to(DEV) @ W.to(DEV).t() + b.to(DEV))
+    _close(lib32, ref, "fc fwd (library f32 GEMM, calibration)")
+    e_z, e_lib = (got.cpu().double() - ref).abs().mean().item(), (lib32.cpu().double() - ref).abs().mean().item()
+    assert e_z <= 1.25 * e_lib + 1e-12, f"kernel Z mean error {e_z:.3e} vs library f32 GEMM {e_lib:.3e}"
+    dz = torch.randn(M, 512, generator=g) * torch.exp(torch.randn(M, 512, generator=g))
+    Wt = W.t().contiguous()                                    # (3136, 512)
+    ref_da = (dz.double() @ W.double()) * (a > 0).double()
+    pk = cnn.fc_pack(Wt.to(DEV))
+    got_da = cnn.fc_dgrad_mask_packed(dz.to(DEV), pk, a.to(DEV))
+    _close(got_da, ref_da, "fc dgrad + mask (kernel Z)")
+    dz_p = cnn.padded_rows(M, 512, DEV)                        # the learner's padded row pitch: same bits
+    dz_p.copy_(dz)
+    assert torch.equal(cnn.fc_dgrad_mask_packed(dz_p, pk, a.to(DEV)), got_da)
+    assert torch.equal(got_da.cpu() == 0, (ref_da == 0).to(torch.bool) | (got_da.cpu() == 0))       # masked entries are exact zeros
+    assert torch.equal(got, cnn.fc_fwd_relu_packed(a.to(DEV), cnn.fc_pack(W.to(DEV)), b.to(DEV), 512))     # deterministic
+    # against kernel X on the same inputs: both multiply the same term pairs, in other orders
+    _close(got, cnn.fc_fwd_relu(a.to(DEV), W.to(DEV), b.to(DEV)), "kernel Z vs kernel X", tol=4e-6)
 
 
 @pytest.mark.parametrize("M", [1, 130, 4100])

@@ -29,7 +29,7 @@ __device__ __forceinline__ uint32_t rnd_bf16x2(uint32_t h, bool zero) {
     return (h & 0x807f807fu) | 0x3f803f80u;
 }
 
-template <int NACC, int FILL, bool F32, int WAVES>
+template <int NACC, int FILL, bool F32, int WAVES, int CHAINS = 16>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void floor_kernel(
     float* __restrict__ out, int iters, uint32_t seed, int zero) {
     const uint32_t id = (blockIdx.x * blockDim.x + threadIdx.x) * 16u + seed;
@@ -71,11 +71,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         }
 #pragma unroll
         for (int t = 0; t < FILL * NACC; ++t) {
-            const int w = t & 15;
+            const int w = t % CHAINS;      // CHAINS independent dependency chains: a filler reads what the filler CHAINS slots earlier wrote
             u32x4& v = (w & 8) ? bw[q ^ 1][(w >> 2) & 1] : aw[q ^ 1][(w >> 2) & 1];
             // first visit of a word in this body: swap its two mantissa-carrying bytes (sign / exponent bytes stay: finite values,
             // toggling operand bits); later visits: the identity selection (same instruction, same issue cost)
-            v[w & 3] = __builtin_amdgcn_perm(v[w & 3], c1, t < 16 ? 0x07040506u : 0x07060504u);
+            v[w & 3] = __builtin_amdgcn_perm(v[w & 3], c1, t < CHAINS ? 0x07040506u : 0x07060504u);
         }
 #pragma unroll
         for (int j = 0; j < NACC; ++j) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int NACC, int FILL, bool F32, int WAVES>
+template <int NACC, int FILL, bool F32, int WAVES, int CHAINS = 16>
 static void run(const char* what, int iters, int zero, float* out, hipStream_t st) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -108,7 +108,7 @@ static void run(const char* what, int iters, int zero, float* out, hipStream_t s
     const int reps = 4;
     for (int r = 0; r < reps; ++r) {
         CHECK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL((floor_kernel<NACC, FILL, F32, WAVES>), dim3(256), dim3(64 * WAVES), 0, st, out, iters, 1234u + r, zero);
+        hipLaunchKernelGGL((floor_kernel<NACC, FILL, F32, WAVES, CHAINS>), dim3(256), dim3(64 * WAVES), 0, st, out, iters, 1234u + r, zero);
         CHECK(hipEventRecord(e1, st));
         CHECK(hipStreamSynchronize(st));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -117,9 +117,9 @@ static void run(const char* what, int iters, int zero, float* out, hipStream_t s
     const double per_simd = (double)iters * NACC * (WAVES / 4);
     const double mean_ms = sum / (reps - 1);
     const double flop = F32 ? 4096.0 : 32768.0;
-    std::printf("{\"what\": \"%s\", \"mfma\": \"%s\", \"nacc\": %d, \"valu_per_mfma\": %d, \"waves_per_simd\": %d, \"operands\": \"%s\", \"ms\": %.3f, "
+    std::printf("{\"what\": \"%s\", \"mfma\": \"%s\", \"nacc\": %d, \"valu_per_mfma\": %d, \"waves_per_simd\": %d, \"valu_chains\": %d, \"operands\": \"%s\", \"ms\": %.3f, "
                 "\"nominal_cycles_per_mfma\": %.2f, \"TFLOPs\": %.1f}\n",
-                what, F32 ? "f32_32x32x2" : "bf16_32x32x16", NACC, FILL, WAVES / 4, zero ? "zero" : "random", mean_ms,
+                what, F32 ? "f32_32x32x2" : "bf16_32x32x16", NACC, FILL, WAVES / 4, FILL ? CHAINS : 0, zero ? "zero" : "random", mean_ms,
                 mean_ms * 1e-3 * 2.4e9 / per_simd, per_simd * 1024.0 * flop / (mean_ms * 1e-3) / 1e12);
     std::fflush(stdout);
 }
@@ -137,6 +137,16 @@ int main() {
     run<8, 5, false, 4>("fillers", it, 0, out, st);
     run<8, 6, false, 4>("fillers", it, 0, out, st);
     run<8, 8, false, 4>("fillers", it, 0, out, st);
+    // dependent VALU chains: a filler reads the result of the filler CHAINS slots before it (kernels X / C as compiled: 1 - 2)
+    run<8, 4, false, 4, 1>("fillers in ONE dependency chain", it, 0, out, st);
+    run<8, 4, false, 4, 2>("fillers in two chains", it, 0, out, st);
+    run<8, 4, false, 4, 3>("fillers in three chains", it, 0, out, st);
+    run<8, 4, false, 4, 4>("fillers in four chains", it, 0, out, st);
+    run<8, 4, false, 4, 8>("fillers in eight chains", it, 0, out, st);
+    run<8, 3, false, 4, 2>("3 fillers in two chains", it, 0, out, st);
+    run<8, 2, false, 4, 1>("2 fillers in one chain", it, 0, out, st);
+    run<8, 4, false, 8, 1>("two waves per SIMD, fillers in ONE chain", it / 2, 0, out, st);
+    run<8, 4, false, 8, 2>("two waves per SIMD, fillers in two chains", it / 2, 0, out, st);
     run<1, 0, false, 4>("one accumulator (dependent chain)", it * 4, 0, out, st);
     run<2, 0, false, 4>("two accumulators", it * 2, 0, out, st);
     run<4, 0, false, 4>("four accumulators", it * 2, 0, out, st);
