@@ -65,6 +65,8 @@ SIGNATURES = {
     "mi355ppo_fc_pack_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "mi355ppo_fc_fwd_relu_packed_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_fc_dgrad_mask_packed_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "mi355ppo_cnn_conv_fwd_packed_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "mi355ppo_cnn_conv_dgrad_packed_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_synth_atari_step_u8": (c_int, [_P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, c_int, c_double, c_int, _P]),
     "mi355ppo_synth_atari_step_ctr_u8": (c_int, [_P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_double, c_int, _P]),
     "mi355ppo_heads_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -213,6 +213,51 @@ def fc_dgrad_mask_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Ten
     return out
 
 
+ZPACK_SHAPE = {(2, MODE_FWD): (64, 512), (3, MODE_FWD): (64, 576), (3, MODE_DGRAD_S1): (64, 576), (2, MODE_DGRAD_S2): (128, 256)}
+
+
+def conv_zpack(W: torch.Tensor, layer: int, mode: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Kernel Z's pack of a conv layer's (N, K) matrix: ``fc_pack(repack_weights(W, layer, mode))`` -- mode 0 for the forward,
+    MODE_DGRAD_S1 (layer 3) / MODE_DGRAD_S2 (layer 2) for the data gradients."""
+    n, k = ZPACK_SHAPE[(layer, mode)]
+    return fc_pack(repack_weights(W, layer, mode).view(n, k), out)
+
+
+def conv_fwd_packed(src: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, layer: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``relu(conv(src) + bias)`` of layer 2 / 3 on kernel Z (csrc/gemmz.hip); ``pack = conv_zpack(W, layer, MODE_FWD)``."""
+    lib = _lib.load()
+    cin, cout, k, _, hin, hout = LAYERS[layer]
+    images = src.shape[0]
+    _chk(src, torch.float32, "src", (images, hin, hin, cin))
+    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(cout, cin * k * k),))
+    _chk(bias, torch.float32, "bias", (cout,))
+    if out is None:
+        out = torch.empty((images, hout, hout, cout), dtype=torch.float32, device=src.device)
+    _chk(out, torch.float32, "out", (images, hout, hout, cout))
+    with _on(src.device):
+        st = lib.mi355ppo_cnn_conv_fwd_packed_f32(_ptr(src), _ptr(pack), _ptr(bias), _ptr(out), images, layer, _stream(src.device))
+    _lib.check(st, "mi355ppo_cnn_conv_fwd_packed_f32")
+    return out
+
+
+def conv_dgrad_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor, layer: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Data gradient of layer 2 / 3 masked by ``act_in > 0`` on kernel Z; ``pack = conv_zpack(W, layer, MODE_DGRAD_S2 / _S1)``."""
+    lib = _lib.load()
+    cin, cout, k, _, hin, hout = LAYERS[layer]
+    images = dz.shape[0]
+    _chk(dz, torch.float32, "dz", (images, hout, hout, cout))
+    _chk(act_in, torch.float32, "act_in", (images, hin, hin, cin))
+    n, kk = ZPACK_SHAPE[(layer, MODE_DGRAD_S2 if layer == 2 else MODE_DGRAD_S1)]
+    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(n, kk),))
+    if out is None:
+        out = torch.empty_like(act_in)
+    _chk(out, torch.float32, "out", (images, hin, hin, cin))
+    with _on(dz.device):
+        st = lib.mi355ppo_cnn_conv_dgrad_packed_f32(_ptr(dz), _ptr(pack), _ptr(act_in), _ptr(out), images, layer, _stream(dz.device))
+    _lib.check(st, "mi355ppo_cnn_conv_dgrad_packed_f32")
+    return out
+
+
 FC_PAD = 4          # extra floats per row of the K = 512 operands of the FC data gradient: a dense 2 KiB pitch puts the 32 rows of
                     # a fragment load on one cache channel (measured: 1.47 ms against 0.70 ms for the forward of the same size)
 

@@ -1,23 +1,28 @@
-// Kernel Z -- the exact-product bf16 GEMM of round 3 (replaces kernel X for the FC layer of the NatureCNN,
-// cleanrl/ppo_atari_multigpu.py:144-145):  C[m][n] = sum_k A[m][k] * B[n][k],  A (M, K) f32 row-major (the activations or the
-// incoming gradient), B (N, K) the weight matrix.
+// Kernel Z -- the exact-product bf16 GEMM / implicit-GEMM family of round 3:  C[m][n] = sum_k A[m][k] * B[n][k].
+//   * GEMM rows (the FC layer of the NatureCNN, cleanrl/ppo_atari_multigpu.py:144-145): A (M, K) f32 row-major -- the
+//     activations (forward) or the incoming gradient (data gradient), B (N, K) the weight matrix / its transpose;
+//   * convolution rows (:139-142): row m = an output pixel (forward of layers 2 / 3) or a pixel of the data gradient's grid, k =
+//     (tap row, tap column, channel) -- with channels-last storage the KW * C values of one tap row of the pixel's window are
+//     contiguous, so a k-step is 64 contiguous bytes at a fixed offset from the window origin: no im2col buffer.  Zero padding
+//     of the data gradients is the buffer instructions' range check (an invalid tap loads from an out-of-range offset: 0).
 //
-// What bounded kernel X (profiles/r03_pmc_*.csv, profiles/r03_conv_traffic_pairs_ab.jsonl): with "lane = row" fragment loads
-// every lane of a 16-byte load touches its own cache line, and the vector-memory front end (TA) processes about one line per
-// clock -- 48 such loads per k-step and CU kept it 83 % busy and the matrix pipe 37 % busy; the 264 split instructions per
-// k-step did the rest.  Hence:
+// What bounded kernels X / C (profiles/r03_pmc_busy_kernels_x_c.csv, profiles/r03_conv_traffic_pairs_ab.jsonl): with "lane =
+// row" fragment loads every lane of a 16-byte load touches its own cache line, and the vector-memory front end (TA) processes
+// about one line per clock -- it was 80 % busy with the matrix pipe 37 % busy (the same loads issued four lanes per row: FC
+// forward 691 -> 531 us, results aside); the 264 split instructions per k-step of kernel X did the rest.  Hence:
 //   * B is split AHEAD, once per optimizer step, into MFMA fragment order (`zpack_kernel`: [k-step][32-column tile][term]
 //     [lane][8 bf16] = one contiguous KiB per fragment load): no VALU for B in the GEMM, fully coalesced loads;
 //   * A is loaded COALESCED -- four consecutive lanes read the 64 contiguous bytes (16 k) of one row, a wave instruction
 //     covers 16 rows -- written to a wave-private LDS tile (row pitch 80 bytes: conflict-free for the 16-byte writes and for
-//     the 16-byte "lane = row" reads), read back as fragments and split in registers (44 VALU per fragment).  Wave-private:
-//     no workgroup barrier anywhere; LDS operations of one wave execute in order.
+//     the 16-byte "lane = row" reads; tests/test_kernel_maps.py), read back as fragments and split in registers (44 VALU per
+//     fragment).  Wave-private: no workgroup barrier anywhere; the LDS operations of one wave execute in order.
 // Arithmetic: every f32 is the exact sum of three bf16 terms (bf16split.h); the six term pairs (i, j), i + j <= 2, are
 // multiplied on `v_mfma_f32_32x32x16_bf16` with f32 accumulation; the three dropped pairs are below the rounding of one f32
 // multiply.  MI355PPO_BF16_PAIRS=9 multiplies all nine (exact products).
 //
-// One wave per SIMD owns 64 x 128 of C (2 x 4 tiles, 128 accumulator registers).  Per k-step (16 k): 4 + 12 global loads, 4
-// LDS writes, 4 LDS reads, 88 VALU, 48 MFMAs.
+// A wave owns (32 MT) rows x (32 NT) columns of C.  FC and the layer-2 data gradient (N = 128): MT 2 x NT 4 = 128 accumulator
+// registers, one wave per SIMD; the N = 64 convolutions: MT 2 x NT 2 = 64 accumulator registers, two waves per SIMD (the
+// partner's MFMAs run under a wave's prologue / epilogue: these problems have K = 512 .. 576 only).
 #include "common.h"
 #include "bf16split.h"
 #include <type_traits>
@@ -28,12 +33,11 @@ namespace mi355ppo {
 
 typedef float z_f32x16 __attribute__((ext_vector_type(16)));
 
-enum { Z_BIAS_RELU = 0, Z_MASK = 1 };
-constexpr int kZMT = 2, kZNT = 4;                     // 32-row / 32-column tiles per wave
-constexpr int kZRows = 32 * kZMT;                     // A rows per wave
-constexpr int kZLoads = kZRows / 16;                  // coalesced 16-byte loads per lane and k-step (16 rows per wave instruction)
+enum { Z_BIAS_RELU = 0, Z_MASK = 1, Z_MASK_CLS4 = 2 };
 constexpr int kZPitch = 20;                           // floats per LDS row: 16 k + 4 pad (80 bytes)
 constexpr int kZTileBytes = 3 * 64 * 16;              // one 32-column tile of one k-step in the pack: 3 terms x 1 KiB
+constexpr unsigned kZOob = 0xFFFFF000u;               // buffer offset out of range for every tensor < 4 GiB - 4 KiB
+constexpr int kZRsrcWord3 = 0x00020000;               // raw buffer, 32-bit elements (gfx9 / CDNA resource format)
 
 // pack[s][j][t][lane][e] (bf16) = term t of B[n = 32 j + (lane & 31)][k = 16 s + 8 (lane >> 5) + e]; rows n >= N are zero.
 __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ B, int ldb, int N, int K, unsigned short* __restrict__ pack) {
@@ -61,57 +65,130 @@ constexpr int z_item_at(int g, int items, int span) {
     return -1;
 }
 
-// WAVES_N: the four waves of a workgroup sit side by side (64 x 512 of C: they read the same A rows -- the forward, where A is
-// the 411 MB activation) or on top of each other (256 x 128: they stream the same B fragments -- the data gradient).
-template <int EPI, bool WAVES_N, int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void zgemm_kernel(
-    const float* __restrict__ A, int lda, const unsigned char* __restrict__ pack, const float* __restrict__ bias,
-    const float* __restrict__ cmask, float* __restrict__ C, int ldc, int M, int N, int K, unsigned m8, unsigned m16) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * kZRows * kZPitch];      // 4 waves x 64 rows x 80 bytes = 20 KiB
+// ---- row geometries: where row m of A starts, and where k-step s sits relative to that ----------------------------------
+// GEMM rows: row m at m * lda floats, k-step s at 16 s floats.
+struct ZRowsLinear {
+    static constexpr bool CONV = false, PAD = false;
+    static constexpr int K = 0, SPR = 1, PITCHB = 0, PER_IMG = 1, GX = 1, S = 1, OFF = 0, H = 1, W = 1, C = 16, KH = 1, KW = 1, DH = 1, DW = 1,
+                         DC = 1, DM = 1;
+};
+// Convolution rows (FixedGeom's parameters, conv.hip): source (images, H, W, C), window KH x KW, grid GY x GX per image with
+// stride S and origin offset OFF (negative: zero padding); destination (images, DH, DW, DC), grid pixel -> destination pixel
+// (gy * DM, gx * DM) (+ the class offset of Z_MASK_CLS4).
+template <int H_, int W_, int C_, int KH_, int KW_, int GY_, int GX_, int S_, int OFF_, int DH_, int DW_, int DC_, int DM_>
+struct ZRowsConv {
+    static constexpr bool CONV = true, PAD = OFF_ < 0;
+    static constexpr int H = H_, W = W_, C = C_, KH = KH_, KW = KW_, GY = GY_, GX = GX_, S = S_, OFF = OFF_, DH = DH_, DW = DW_,
+                         DC = DC_, DM = DM_;
+    static constexpr int RUN = KW * C, SPR = RUN / 16, K = KH * RUN, PITCHB = W * C * 4, PER_IMG = GY * GX;
+    static_assert(C % 16 == 0 && KH * KW <= 32, "a k-step lies inside one tap; the validity mask is 32 bits");
+};
+using ZConv2 = ZRowsConv<20, 20, 32, 4, 4, 9, 9, 2, 0, 9, 9, 64, 1>;
+using ZConv3 = ZRowsConv<9, 9, 64, 3, 3, 7, 7, 1, 0, 7, 7, 64, 1>;
+using ZDgrad3 = ZRowsConv<7, 7, 64, 3, 3, 9, 9, 1, -2, 9, 9, 64, 1>;        // source = dz3, destination = da2
+using ZDgrad2 = ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1, 20, 20, 32, 2>;    // source = dz2, destination = da1 (4 parity classes = 4 column tiles)
+
+struct ZArgs {
+    const void* A;              // source tensor
+    unsigned a_bytes;           // its size (buffer range check)
+    int lda;                    // GEMM rows: leading dimension of A in floats
+    const unsigned char* pack;  // B, pre-split (zpack_kernel)
+    const float* bias;          // Z_BIAS_RELU
+    const float* mask;          // Z_MASK*: C is zeroed where mask <= 0 (same indexing as C)
+    float* C;
+    int ldc;                    // GEMM rows: leading dimension of C; convolution rows: unused (DC)
+    long long M;                // rows: matrix rows, or images * GY * GX
+    int N, K;
+    unsigned m8, m16;           // 0xffff0000, 0xffffff00: in SGPRs (as literals every v_and would be an 8-byte instruction)
+};
+
+// WAVES_N: the waves of a workgroup sit side by side (they read the same A rows) instead of on top of each other (they stream
+// the same B fragments).
+template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int NP>
+__global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4))) void z_kernel(ZArgs a) {
+    constexpr int ROWS = 32 * MT, LOADS = ROWS / 16;
+    __shared__ __attribute__((aligned(16))) float lds[NWAVES * ROWS * kZPitch];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int m0 = WAVES_N ? blockIdx.y * kZRows : (blockIdx.y * 4 + wave) * kZRows;
-    const int n0 = WAVES_N ? (blockIdx.x * 4 + wave) * (32 * kZNT) : blockIdx.x * (32 * kZNT);
+    const long long M = a.M;
+    const int N = a.N;
+    const long long m0 = WAVES_N ? (long long)blockIdx.y * ROWS : ((long long)blockIdx.y * NWAVES + wave) * ROWS;
+    const int n0 = WAVES_N ? (blockIdx.x * NWAVES + wave) * (32 * NT) : blockIdx.x * (32 * NT);
     if (m0 >= M || n0 >= N) return;                       // (whole wave; no barriers in this kernel)
     const int ntiles = (N + 31) / 32, j0 = n0 / 32;
-    float* const wl = lds + wave * (kZRows * kZPitch);
-    // coalesced A loads: load u of a k-step reads row m0 + 16 u + (lane >> 2), floats 4 (lane & 3) .. + 3 of the step's 16
-    // (rows past M re-read the last row: their results are dropped at the store)
-    unsigned voff[kZLoads];
+    float* const wl = lds + wave * (ROWS * kZPitch);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)a.a_bytes, kZRsrcWord3);
+    // coalesced A loads: load u of a k-step reads row m0 + 16 u + (lane >> 2), floats 4 (lane & 3) .. + 3 of the step's 16.
+    // voff = byte offset of that row's k = 0 (+ the lane's 16-byte chunk); vm = validity bits (tap row * KW + tap column).
+    unsigned voff[LOADS], vm[LOADS];
 #pragma unroll
-    for (int u = 0; u < kZLoads; ++u) {
-        const int r = m0 + 16 * u + (lane >> 2);
-        voff[u] = (unsigned)(r < M ? r : M - 1) * (unsigned)lda * 4u + 16u * (unsigned)(lane & 3);      // bytes; A < 4 GiB (host-checked)
+    for (int u = 0; u < LOADS; ++u) {
+        const long long r = m0 + 16 * u + (lane >> 2);
+        const long long rc = r < M ? r : M - 1;           // rows past M re-read the last row: their results are dropped at the store
+        if constexpr (RG::CONV) {
+            const unsigned img = (unsigned)(rc / RG::PER_IMG), rem = (unsigned)(rc - (long long)img * RG::PER_IMG);
+            const int gy = (int)(rem / RG::GX), gx = (int)(rem - (rem / RG::GX) * RG::GX);
+            const int sy0 = gy * RG::S + RG::OFF, sx0 = gx * RG::S + RG::OFF;
+            voff[u] = (unsigned)((((int)img * RG::H + sy0) * RG::W + sx0) * RG::C * 4) + 16u * (unsigned)(lane & 3);   // may wrap for PAD taps
+            unsigned m = 0u;
+            if constexpr (RG::PAD) {
+#pragma unroll
+                for (int ty = 0; ty < RG::KH; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < RG::KW; ++tx)
+                        if (sy0 + ty >= 0 && sy0 + ty < RG::H && sx0 + tx >= 0 && sx0 + tx < RG::W) m |= 1u << (ty * RG::KW + tx);
+            }
+            vm[u] = m;
+        } else {
+            voff[u] = (unsigned)rc * (unsigned)a.lda * 4u + 16u * (unsigned)(lane & 3);          // A < 4 GiB (host-checked)
+            vm[u] = 0u;
+        }
     }
-    const unsigned char* const Ab = reinterpret_cast<const unsigned char*>(A);
     float* const wr_ptr = wl + (lane >> 2) * kZPitch + 4 * (lane & 3);               // + 16 u rows
     const float* const rd_ptr = wl + li * kZPitch + 8 * lh;                          // + 32 i rows
-    const unsigned char* const pb = pack + (size_t)j0 * kZTileBytes + 16 * lane;
+    const unsigned char* const pb = a.pack + (size_t)j0 * kZTileBytes + 16 * lane;
     const size_t step_bytes = (size_t)ntiles * kZTileBytes;
+    const unsigned m8 = a.m8, m16 = a.m16;
 
-    z_f32x16 acc[kZMT][kZNT];
+    z_f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < kZMT; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < kZNT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    s_u32x4 stage[kZLoads];                               // A of a later k-step, as loaded (coalesced layout), on its way to LDS
-    s_u32x4 raw[kZMT][2];                                 // fragments of the NEXT k-step as read back from LDS (f32, lane = row)
-    unsigned ta[2][kZMT][3][4];                           // split A fragments: [k-step parity][fragment][term][4 x 2 bf16]
-    s_u32x4 tb[2][kZNT][3];                               // B fragments straight from the pack
-    const int nsteps = K >> 4;
+    s_u32x4 stage[LOADS];                                 // A of a later k-step, as loaded (coalesced layout), on its way to LDS
+    s_u32x4 raw[MT][2];                                   // fragments of the NEXT k-step as read back from LDS (f32, lane = row)
+    unsigned ta[2][MT][3][4];                             // split A fragments: [k-step parity][fragment][term][4 x 2 bf16]
+    s_u32x4 tb[2][NT][3];                                 // B fragments straight from the pack
+    const int nsteps = RG::CONV ? RG::K / 16 : a.K >> 4;
     auto kclamp = [&](int s) { return s < nsteps ? s : nsteps - 1; };                // past the end: re-read, never multiplied
     auto load_a = [&](int s) {
-        const unsigned char* base = Ab + (size_t)kclamp(s) * 64;
+        const int sc = kclamp(s);
+        if constexpr (RG::CONV) {
+            const int ty = sc / RG::SPR, us = sc - ty * RG::SPR;                     // (uniform: scalar unit)
+            const int off = ty * RG::PITCHB + us * 64;
+            if constexpr (RG::PAD) {
+                const int tap = ty * RG::KW + (us * 16) / RG::C;
 #pragma unroll
-        for (int u = 0; u < kZLoads; ++u) stage[u] = *reinterpret_cast<const s_u32x4*>(base + voff[u]);
+                for (int u = 0; u < LOADS; ++u) {
+                    const unsigned vo = ((vm[u] >> tap) & 1u) ? voff[u] + (unsigned)off : kZOob;
+                    stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < LOADS; ++u) stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[u], off, 0));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < LOADS; ++u) stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[u], sc * 64, 0));
+        }
     };
     auto load_b = [&](int par, int s) {
         const unsigned char* p = pb + (size_t)kclamp(s) * step_bytes;
 #pragma unroll
-        for (int j = 0; j < kZNT; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const bool ok = j0 + j < ntiles;                                        // (wave-uniform) tiles past N: re-read tile j0
 #pragma unroll
             for (int t = 0; t < 3; ++t) tb[par][j][t] = *reinterpret_cast<const s_u32x4*>(p + (ok ? j : 0) * kZTileBytes + t * 1024);
@@ -119,11 +196,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto to_lds = [&]() {
 #pragma unroll
-        for (int u = 0; u < kZLoads; ++u) *reinterpret_cast<s_u32x4*>(wr_ptr + 16 * u * kZPitch) = stage[u];
+        for (int u = 0; u < LOADS; ++u) *reinterpret_cast<s_u32x4*>(wr_ptr + 16 * u * kZPitch) = stage[u];
     };
     auto read_frags = [&]() {
 #pragma unroll
-        for (int i = 0; i < kZMT; ++i) {
+        for (int i = 0; i < MT; ++i) {
             raw[i][0] = *reinterpret_cast<const s_u32x4*>(rd_ptr + 32 * i * kZPitch);
             raw[i][1] = *reinterpret_cast<const s_u32x4*>(rd_ptr + 32 * i * kZPitch + 4);
         }
@@ -163,11 +240,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //   `stage` = A of step s + 2 (loaded during the previous step) -> LDS;  A of step s + 3 (global) -> `stage`;
     //   fragments of step s + 2: LDS -> `raw`
     // The instruction order is pinned by hand (hipcc's sched_group_barrier solver did not reproduce this pipeline: it left the
-    // split in front of the MFMAs and chained MFMAs on one accumulator): after MFMA g of the step's NM comes item
-    // `item_after(g)` -- one of the 6 * kZMT split pieces, then the LDS writes, the A loads, the LDS reads -- behind a
-    // sched_barrier; the last kTail MFMAs run bare and cover the LDS round trip.  Term pairs outermost, the eight independent
-    // tiles innermost: no MFMA waits for the one before it.
-    constexpr int NM = NP * kZMT * kZNT, kPieces = 6 * kZMT, kItems = kPieces + 3, kTail = 12;
+    // split in front of the MFMAs and chained MFMAs on one accumulator): behind MFMA g of the step's NM comes the item
+    // z_item_at(g) -- one of the 6 MT split pieces, then the LDS writes, the A loads, the LDS reads -- and a sched_barrier; the
+    // last kTail MFMAs run bare and cover the LDS round trip.  Term pairs outermost, the MT x NT independent tiles innermost: no
+    // MFMA waits for the one before it.
+    constexpr int NM = NP * MT * NT, kPieces = 6 * MT, kItems = kPieces + 3, kTail = NM > 2 * kItems ? NM / 4 : NM - kItems;
+    static_assert(NM - kTail >= kItems, "one MFMA per scheduled item");
     constexpr int PX[9] = {0, 0, 1, 0, 2, 1, 1, 2, 2}, PY[9] = {0, 1, 0, 2, 0, 1, 2, 1, 2};     // pairs by weight: the first six have x + y <= 2
     auto step = [&](auto qc, int s) {
         constexpr int q = decltype(qc)::value;
@@ -175,7 +253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... G>(std::integer_sequence<int, G...>) {
             ([&] {
-                constexpr int g = G, pi = g / (kZMT * kZNT), i = (g / kZNT) % kZMT, j = g % kZNT;
+                constexpr int g = G, pi = g / (MT * NT), i = (g / NT) % MT, j = g % NT;
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                     __builtin_bit_cast(s_bf16x8, (s_u32x4){ta[q][i][PX[pi]][0], ta[q][i][PX[pi]][1], ta[q][i][PX[pi]][2], ta[q][i][PX[pi]][3]}),
                     __builtin_bit_cast(s_bf16x8, tb[q][j][PY[pi]]), acc[i][j], 0, 0, 0);
@@ -215,58 +293,90 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (s < nsteps) step(std::integral_constant<int, 0>{}, s);
 
-    // ---- epilogue: accumulator element e of tile (i, j) is C[m0 + 32 i + (e & 3) + 8 (e >> 2) + 4 lh][n0 + 32 j + li]
-    const bool wave_rows_ok = m0 + kZRows <= M;
-    if (EPI == Z_MASK) {
-        // all mask values of the wave's block are requested before the first one is used (one wave per SIMD: nothing else hides
-        // a load's latency)
-        float mk[kZMT][kZNT][16];
+    // ---- epilogue: accumulator element e of tile (i, j) is C[row m0 + 32 i + (e & 3) + 8 (e >> 2) + 4 lh][column n0 + 32 j + li].
+    // Element offset of (row m, column tile j): GEMM rows and the convolutions whose destination pixel IS the row (channels
+    // last, DC = N): m * ldc + n; Z_MASK_CLS4 (layer-2 data gradient): column tile j = stride-parity class (j >> 1, j & 1) of
+    // grid pixel m -> destination pixel (2 gy + (j >> 1), 2 gx + (j & 1)), channel li.
+    const int ldc = RG::CONV ? RG::DC : a.ldc;
+    auto row_off = [&](long long m) -> long long {
+        if constexpr (EPI == Z_MASK_CLS4) {
+            const long long img = m / RG::PER_IMG;
+            const int rem = (int)(m - img * RG::PER_IMG), gy = rem / RG::GX, gx = rem - gy * RG::GX;
+            return ((img * RG::DH + gy * RG::DM) * RG::DW + gx * RG::DM) * (long long)RG::DC;
+        } else {
+            return m * (long long)ldc;
+        }
+    };
+    auto col_off = [&](int j) -> int {
+        if constexpr (EPI == Z_MASK_CLS4) return ((j >> 1) * RG::DW + (j & 1)) * RG::DC + li;
+        else return n0 + 32 * j + li;
+    };
+    const bool wave_rows_ok = m0 + ROWS <= M;
+    if constexpr (EPI != Z_BIAS_RELU) {
+        // all mask values of one 32-row tile are requested before the first one is used (few waves per SIMD: nothing else hides a
+        // load's latency)
 #pragma unroll
-        for (int i = 0; i < kZMT; ++i)
+        for (int i = 0; i < MT; ++i) {
+            float mk[NT][16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float* row = cmask + (size_t)(m < M ? m : M - 1) * ldc;
+                const long long m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float* row = a.mask + row_off(m < M ? m : M - 1);
 #pragma unroll
-                for (int j = 0; j < kZNT; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     const int n = n0 + 32 * j + li;
-                    mk[i][j][e] = row[n < N ? n : N - 1];
+                    mk[j][e] = (EPI == Z_MASK_CLS4 || n < N) ? row[col_off(j)] : 0.0f;
                 }
             }
 #pragma unroll
-        for (int i = 0; i < kZMT; ++i)
-#pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                float* row = C + (size_t)m * ldc;
+                const long long m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float* row = a.C + row_off(m < M ? m : M - 1);
 #pragma unroll
-                for (int j = 0; j < kZNT; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     const int n = n0 + 32 * j + li;
-                    if ((wave_rows_ok || m < M) && n < N) row[n] = mk[i][j][e] > 0.0f ? acc[i][j][e] : 0.0f;
+                    if ((wave_rows_ok || m < M) && (EPI == Z_MASK_CLS4 || n < N)) row[col_off(j)] = mk[j][e] > 0.0f ? acc[i][j][e] : 0.0f;
                 }
             }
+        }
     } else {
-        float bj[kZNT];
+        float bj[NT];
 #pragma unroll
-        for (int j = 0; j < kZNT; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int n = n0 + 32 * j + li;
-            bj[j] = bias[n < N ? n : N - 1];
+            bj[j] = a.bias[n < N ? n : N - 1];
         }
 #pragma unroll
-        for (int i = 0; i < kZMT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                float* row = C + (size_t)m * ldc;
+                const long long m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float* row = a.C + row_off(m < M ? m : M - 1);
 #pragma unroll
-                for (int j = 0; j < kZNT; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     const int n = n0 + 32 * j + li;
                     float v = acc[i][j][e] + bj[j];
                     v = v > 0.0f ? v : 0.0f;
-                    if ((wave_rows_ok || m < M) && n < N) row[n] = v;
+                    if ((wave_rows_ok || m < M) && n < N) row[col_off(j)] = v;
                 }
             }
     }
+}
+
+template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N>
+static int z_launch(const ZArgs& a, hipStream_t s, const char* what) {
+    const long long row_blocks = (a.M + 32 * MT - 1) / (32 * MT), col_blocks = (a.N + 32 * NT - 1) / (32 * NT);
+    const dim3 grid = WAVES_N ? dim3((unsigned)((col_blocks + NWAVES - 1) / NWAVES), (unsigned)row_blocks)
+                              : dim3((unsigned)col_blocks, (unsigned)((row_blocks + NWAVES - 1) / NWAVES));
+    if (grid.y > 65535u) {            // (hardware grid limit) 4.1 M rows at the smallest row block: beyond every caller's sizes
+        set_error("%s: %lld rows exceed one launch", what, a.M);
+        return MI355PPO_EINVAL;
+    }
+    if (bf16_term_pairs() == 9)
+        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 9>), grid, dim3(64 * NWAVES), 0, s, a);
+    else
+        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 6>), grid, dim3(64 * NWAVES), 0, s, a);
+    return check_launch(what);
 }
 
 }  // namespace mi355ppo
@@ -296,8 +406,16 @@ static int zgemm_check(const char* fn, const float* A, const void* pack, const f
     MI355_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, MI355PPO_EINVAL, "%s: M=%d N=%d K=%d (K must be a positive multiple of 16)", fn, M, N, K);
     MI355_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0, MI355PPO_EINVAL, "%s: leading dimensions lda=%d ldc=%d (lda: a multiple of 4, >= K; ldc >= N)", fn, lda, ldc);
     MI355_REQUIRE(aligned(A, 16) && aligned(pack, 16) && aligned(C, 4), MI355PPO_EALIGN, "%s: A and pack must be 16-byte aligned", fn);
-    MI355_REQUIRE((long long)M * lda * 4 < (1LL << 32), MI355PPO_EINVAL, "%s: A (%d x %d floats) must stay below 4 GiB (32-bit row offsets)", fn, M, lda);
+    MI355_REQUIRE((long long)M * lda * 4 < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: A (%d x %d floats) must stay below 4 GiB (32-bit row offsets)", fn, M, lda);
     return MI355PPO_OK;
+}
+
+static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, const float* bias, const float* mask, float* C, int ldc,
+                   long long M, int N, int K) {
+    ZArgs a;
+    a.A = A; a.a_bytes = (unsigned)a_bytes; a.lda = lda; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.mask = mask;
+    a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
+    return a;
 }
 
 extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
@@ -306,15 +424,8 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int 
     int rc = zgemm_check(fn, a, pack, h, M, N, K, lda, N);
     if (rc) return rc;
     MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
-    MI355_REQUIRE((M + kZRows - 1) / kZRows <= 65535, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
-    const dim3 grid((N + 128 * 4 - 1) / (128 * 4), (M + kZRows - 1) / kZRows);
-    if (bf16_term_pairs() == 9)
-        hipLaunchKernelGGL((zgemm_kernel<Z_BIAS_RELU, true, 9>), grid, dim3(256), 0, as_stream(stream), a, lda,
-                           static_cast<const unsigned char*>(pack), bias, (const float*)nullptr, h, N, M, N, K, 0xffff0000u, 0xffffff00u);
-    else
-        hipLaunchKernelGGL((zgemm_kernel<Z_BIAS_RELU, true, 6>), grid, dim3(256), 0, as_stream(stream), a, lda,
-                           static_cast<const unsigned char*>(pack), bias, (const float*)nullptr, h, N, M, N, K, 0xffff0000u, 0xffffff00u);
-    return check_launch(fn);
+    return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, h, N, M, N, K),
+                                                             as_stream(stream), fn);
 }
 
 extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, int lddz, const void* pack, const float* act_in, float* da,
@@ -323,13 +434,45 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, i
     int rc = zgemm_check(fn, dz, pack, da, M, N, K, lddz, N);
     if (rc) return rc;
     MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
-    MI355_REQUIRE((M + 4 * kZRows - 1) / (4 * kZRows) <= 65535, MI355PPO_EINVAL, "%s: M=%d exceeds one launch", fn, M);
-    const dim3 grid((N + 127) / 128, (M + 4 * kZRows - 1) / (4 * kZRows));
-    if (bf16_term_pairs() == 9)
-        hipLaunchKernelGGL((zgemm_kernel<Z_MASK, false, 9>), grid, dim3(256), 0, as_stream(stream), dz, lddz,
-                           static_cast<const unsigned char*>(pack), (const float*)nullptr, act_in, da, N, M, N, K, 0xffff0000u, 0xffffff00u);
-    else
-        hipLaunchKernelGGL((zgemm_kernel<Z_MASK, false, 6>), grid, dim3(256), 0, as_stream(stream), dz, lddz,
-                           static_cast<const unsigned char*>(pack), (const float*)nullptr, act_in, da, N, M, N, K, 0xffff0000u, 0xffffff00u);
-    return check_launch(fn);
+    return z_launch<ZRowsLinear, 2, 4, 4, Z_MASK, false>(zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, N, M, N, K),
+                                                         as_stream(stream), fn);
+}
+
+// ---- convolutions of layers 2 and 3 on kernel Z.  `pack` = mi355ppo_fc_pack_f32 of the layer's (N, K) f32 matrix from
+// mi355ppo_cnn_repack_weights_f32: mode 0 for the forward (N = 64 output channels, K = (tap row, tap column, input channel)),
+// mode 1 for the layer-3 data gradient (N = 64 input channels, K = (r, c, output channel), taps flipped), mode 2 for the
+// layer-2 data gradient (N = 4 stride-parity classes x 32 input channels, K = (r, c, output channel)).
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, const void* pack, const float* bias, float* dst,
+                                                             int64_t images, int layer, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_fwd_packed_f32";
+    MI355_REQUIRE(src && pack && bias && dst, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(layer == 2 || layer == 3, MI355PPO_EINVAL, "%s: layer=%d must be 2 or 3", fn, layer);
+    MI355_REQUIRE(images > 0, MI355PPO_EINVAL, "%s: images=%lld must be positive", fn, (long long)images);
+    MI355_REQUIRE(aligned(src, 16) && aligned(pack, 16) && aligned(dst, 16) && aligned(bias, 4), MI355PPO_EALIGN, "%s: src / pack / dst must be 16-byte aligned", fn);
+    const long long srcb = (long long)images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4;
+    MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: the source (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);
+    if (layer == 2)
+        return z_launch<ZConv2, 2, 2, 8, Z_BIAS_RELU, false>(zargs(src, srcb, 0, pack, bias, nullptr, dst, 64, (long long)images * 81, 64, ZConv2::K),
+                                                             as_stream(stream), fn);
+    return z_launch<ZConv3, 2, 2, 8, Z_BIAS_RELU, false>(zargs(src, srcb, 0, pack, bias, nullptr, dst, 64, (long long)images * 49, 64, ZConv3::K),
+                                                         as_stream(stream), fn);
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, const void* pack, const float* act_in, float* dsrc,
+                                                               int64_t images, int layer, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_dgrad_packed_f32";
+    MI355_REQUIRE(dz && pack && act_in && dsrc, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(layer == 2 || layer == 3, MI355PPO_EINVAL, "%s: layer=%d must be 2 or 3", fn, layer);
+    MI355_REQUIRE(images > 0, MI355PPO_EINVAL, "%s: images=%lld must be positive", fn, (long long)images);
+    MI355_REQUIRE(aligned(dz, 16) && aligned(pack, 16) && aligned(dsrc, 16) && aligned(act_in, 16), MI355PPO_EALIGN,
+                  "%s: dz / pack / act_in / dsrc must be 16-byte aligned", fn);
+    MI355_REQUIRE(act_in != dsrc, MI355PPO_EINVAL, "%s: act_in must not alias dsrc", fn);
+    const long long srcb = (long long)images * (layer == 2 ? 9 * 9 * 64 : 7 * 7 * 64) * 4;
+    MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: dz (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);
+    if (layer == 3)        // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
+        return z_launch<ZDgrad3, 2, 2, 8, Z_MASK, false>(zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, 64, (long long)images * 81, 64, ZDgrad3::K),
+                                                         as_stream(stream), fn);
+    // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
+    return z_launch<ZDgrad2, 2, 4, 4, Z_MASK_CLS4, false>(zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, 0, (long long)images * 100, 128, ZDgrad2::K),
+                                                          as_stream(stream), fn);
 }

@@ -289,6 +289,19 @@ MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int lda, const 
 MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, int lddz, const void* pack, const float* act_in, float* da,
                                                    int M, int N, int K, void* stream);
 
+/* The same kernel family on the convolutions of layers 2 and 3 (cleanrl/ppo_atari_multigpu.py:139-142): a row of the GEMM is an
+ * output pixel (forward) or a pixel of the data gradient's grid, a k-step 64 contiguous bytes of a tap row of its window
+ * (channels-last activations; zero padding through the buffer range check).  `pack` = mi355ppo_fc_pack_f32 of the layer's
+ * (N, K) f32 matrix from mi355ppo_cnn_repack_weights_f32 -- mode 0 (forward: N = 64, K = 512 / 576), mode 1 (layer-3 data
+ * gradient: N = 64, K = 576), mode 2 (layer-2 data gradient: N = 128 = 4 stride-parity classes x 32 channels, K = 256).
+ *   fwd  : dst (images, Hout, Hout, 64) = relu(conv(src (images, Hin, Hin, Cin)) + bias)
+ *   dgrad: dsrc (images, Hin, Hin, Cin) = conv_transpose(dz (images, Hout, Hout, 64)) * (act_in > 0)
+ * Tensors channels-last f32, 16-byte aligned, sources below 4 GiB. */
+MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, const void* pack, const float* bias, float* dst,
+                                                  int64_t images, int layer, void* stream);
+MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, const void* pack, const float* act_in, float* dsrc,
+                                                    int64_t images, int layer, void* stream);
+
 /* FC weight gradient (csrc/fcw.hip, f32 matrix pipe): dW (N,K) = dz (M,N)^T @ a (M,K), the batch cut into slabs whose
  * partials are added in a fixed order (deterministic).  dz takes a leading dimension (even); a is dense.  N % 64 == 0,
  * K % 224 == 0 (whole 64 x 224 wave tiles: 512 x 3136 = 8 x 14 of them); dz 8-byte, a and the workspace 16-byte aligned.

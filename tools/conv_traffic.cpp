@@ -88,9 +88,15 @@ int main(int argc, char** argv) {
     const bool fc_x = getenv("CONV_TRAFFIC_FC_X") != nullptr;                                          // FC forward / data gradient on kernel X
     void *pk_fwd, *pk_dg;
     CHECK(hipMalloc(&pk_fwd, mi355ppo_fc_pack_bytes(512, 3136))); CHECK(hipMalloc(&pk_dg, mi355ppo_fc_pack_bytes(3136, 512)));
+    const bool conv_z = getenv("CONV_TRAFFIC_CONV_Z") != nullptr;                                      // layers 2 / 3 forward + data gradients on kernel Z
+    void *pz2, *pz3, *pzd2, *pzd3;
+    CHECK(hipMalloc(&pz2, mi355ppo_fc_pack_bytes(64, 512))); CHECK(hipMalloc(&pz3, mi355ppo_fc_pack_bytes(64, 576)));
+    CHECK(hipMalloc(&pzd2, mi355ppo_fc_pack_bytes(128, 256))); CHECK(hipMalloc(&pzd3, mi355ppo_fc_pack_bytes(64, 576)));
     const bool fwd_f32 = getenv("CONV_TRAFFIC_FWD_F32") != nullptr;                                    // layers 2 / 3 forward on kernel F
     fill_f32<<<4096, 256, 0, st>>>(Wfc, 512 * 3136, 10u); fill_f32<<<4096, 256, 0, st>>>(Wfct, 3136 * 516, 11u);
     fill_f32<<<4096, 256, 0, st>>>(dzfc, (size_t)M * 516, 12u);
+    ABI(mi355ppo_fc_pack_f32(bt2, 512, 64, 512, pz2, st)); ABI(mi355ppo_fc_pack_f32(bt3, 576, 64, 576, pz3, st));
+    ABI(mi355ppo_fc_pack_f32(bt2d, 256, 128, 256, pzd2, st)); ABI(mi355ppo_fc_pack_f32(bt3d, 576, 64, 576, pzd3, st));
     ABI(mi355ppo_fc_pack_f32(Wfc, 3136, 512, 3136, pk_fwd, st)); ABI(mi355ppo_fc_pack_f32(Wfct, 516, 3136, 512, pk_dg, st));
     CHECK(hipStreamSynchronize(st));
 
@@ -106,7 +112,10 @@ int main(int argc, char** argv) {
 #define TIMED(i, call) do { CHECK(hipEventRecord(ev[i][0], st)); ABI(call); CHECK(hipEventRecord(ev[i][1], st)); } while (0)
     for (int r = 0; r < reps; r++) {                                // one minibatch update's conv launches, in order
         TIMED(0, mi355ppo_cnn_conv_fwd_f32_variant(obs, inds, bt1q, bias, a1, M, 1, 6, st));        // kernel Q
-        if (fwd_f32) {
+        if (conv_z) {
+            TIMED(1, mi355ppo_cnn_conv_fwd_packed_f32(a1, pz2, bias, a2, M, 2, st));                  // kernel Z
+            TIMED(2, mi355ppo_cnn_conv_fwd_packed_f32(a2, pz3, bias, a3, M, 3, st));
+        } else if (fwd_f32) {
             TIMED(1, mi355ppo_cnn_conv_fwd_f32(a1, nullptr, bt2, bias, a2, M, 2, st));
             TIMED(2, mi355ppo_cnn_conv_fwd_f32(a2, nullptr, bt3, bias, a3, M, 3, st));
         } else {
@@ -122,9 +131,11 @@ int main(int argc, char** argv) {
         }
         TIMED(10, mi355ppo_fc_wgrad_f32(dzfc, 516, a3, dWfc, (int)M, 512, 3136, 64, wsfc, wsfcb, st));  // kernel Y + its slab reduction
         TIMED(3, mi355ppo_cnn_conv_wgrad_f32(a2, nullptr, dz3, dW3, db3, M, 3, ws, wsb, st));
-        TIMED(4, mi355ppo_cnn_conv_dgrad_f32_variant(dz3, bt3c, a2, dz2, M, 3, 5, st));
+        if (conv_z) TIMED(4, mi355ppo_cnn_conv_dgrad_packed_f32(dz3, pzd3, a2, dz2, M, 3, st));
+        else TIMED(4, mi355ppo_cnn_conv_dgrad_f32_variant(dz3, bt3c, a2, dz2, M, 3, 5, st));
         TIMED(5, mi355ppo_cnn_conv_wgrad_f32(a1, nullptr, dz2, dW2, db2, M, 2, ws, wsb, st));
-        TIMED(6, mi355ppo_cnn_conv_dgrad_f32_variant(dz2, bt2c, a1, dz1, M, 2, 6, st));               // border classes
+        if (conv_z) TIMED(6, mi355ppo_cnn_conv_dgrad_packed_f32(dz2, pzd2, a1, dz1, M, 2, st));
+        else TIMED(6, mi355ppo_cnn_conv_dgrad_f32_variant(dz2, bt2c, a1, dz1, M, 2, 6, st));           // border classes
         TIMED(7, mi355ppo_cnn_conv_wgrad_f32(obs, inds, dz1, dW1, db1, M, 1, ws, wsb, st));
         CHECK(hipStreamSynchronize(st));
         if (r > 0 || reps == 1)
