@@ -27,6 +27,9 @@ VARIANT_DGRAD2_CLASSES = 6
 QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 storage elements (kernel Q's integer-digit pack)
 VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
 VARIANT_X = 7                       # layer-2 / 3 forward on the bf16 matrix pipe with exact products (csrc/convx.hip); Bt = the mode-6 pack
+_CONV_Z = os.environ.get("MI355PPO_CONV", "z") != "f"    # layers 2 / 3 forward + data gradients: kernel Z, or the f32-pipe kernel F
+DGRAD3_Z_MAX_IMAGES = 4096   # layer-3 data gradient: kernel Z multiplies the padding taps (1.65 x the work) -- faster than kernel F's nine
+                             # border-class launches up to here (profiles/r03_conv_traffic_convz_sizes.jsonl), slower beyond
 _FC_Z = os.environ.get("MI355PPO_FC", "z") != "x"      # FC forward / data gradient: kernel Z (pre-split weights, coalesced loads) or kernel X
 _FWD23_BF16 = os.environ.get("MI355PPO_FWD23", "f32") == "bf16"      # minibatch-sized forward of layers 2 / 3: kernel F (default) or kernel C
 
@@ -35,6 +38,14 @@ def extra_forward_modes():
     """(layer, mode) pairs NatureTrunkFn.forward requests beyond (1, FWD_Q), (2, FWD), (3, FWD) at some batch size; the
     learner derives them before the env-group lanes start, so that lanes only ever READ the weight cache."""
     return [(2, MODE_FWD_X), (3, MODE_FWD_X)] if _FWD23_BF16 else []
+
+
+def warm_forward_packs(bufs, net) -> None:
+    """Kernel Z's forward packs of layers 2 / 3 (re-derived into the same buffers: captured rollout steps keep reading one
+    address)."""
+    if _CONV_Z:
+        bufs.conv_zpack(net[2].weight, 2, MODE_FWD)
+        bufs.conv_zpack(net[4].weight, 3, MODE_FWD)
 
 
 def xpack_numel(layer: int) -> int:
@@ -355,6 +366,10 @@ class _Buffers:
         """Kernel Z's pack of its transpose (3136, 512): the data gradient's B operand."""
         return self._pack_cached("fc_pack_dgrad", W, lambda: self.fc_weight_t(W))
 
+    def conv_zpack(self, W: torch.Tensor, layer: int, mode: int) -> torch.Tensor:
+        """Kernel Z's pack of a conv layer's matrix (forward: MODE_FWD; data gradients: MODE_DGRAD_S1 / _S2), cached likewise."""
+        return self._pack_cached(("zpack", layer, mode), W, lambda: self.weights(W, layer, mode).view(*ZPACK_SHAPE[(layer, mode)]))
+
     def _pack_cached(self, key, W, source):
         if not self.cache_weights:
             return fc_pack(source())
@@ -420,7 +435,11 @@ class NatureTrunkFn(torch.autograd.Function):
         a1, a2, a3 = bufs.get(m, obs_u8.device, False)
         # layer 1 runs on the integer matrix pipe (kernel Q): uint8 taps are exact int8 operands, weights four int8 digits
         bt1 = bufs.weights(W1, 1, MODE_FWD_Q)
-        if m <= 4096 and obs_u8.is_contiguous() and tuple(obs_u8.shape[1:]) == (84, 84, 4):     # inference-sized: one call
+        if _CONV_Z:                 # layers 2 and 3 on kernel Z (bf16 pipe, pre-split weights, coalesced window loads)
+            conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1, variant=VARIANT_Q)
+            conv_fwd_packed(a1, bufs.conv_zpack(W2, 2, MODE_FWD), b2.detach(), 2, a2)
+            conv_fwd_packed(a2, bufs.conv_zpack(W3, 3, MODE_FWD), b3.detach(), 3, a3)
+        elif m <= 4096 and obs_u8.is_contiguous() and tuple(obs_u8.shape[1:]) == (84, 84, 4):     # inference-sized: one call
             bt2, bt3 = bufs.weights(W2, 2, MODE_FWD), bufs.weights(W3, 3, MODE_FWD)
             trunk_fwd(obs_u8, inds, bt1, b1.detach(), bt2, b2.detach(), bt3, b3.detach(), a1, a2, a3, conv1_variant=VARIANT_Q)
         else:
@@ -448,12 +467,16 @@ class NatureTrunkFn(torch.autograd.Function):
         else:
             dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)    # ReLU backward of the last conv
         dW3, db3 = conv_wgrad(a2, dz3, 3)
-        if a2.numel() * 4 < (1 << 32) - 8192:     # the border-class kernels address tensors with 32-bit buffer offsets
+        if _CONV_Z and m <= DGRAD3_Z_MAX_IMAGES:
+            conv_dgrad_packed(dz3, ctx.bufs.conv_zpack(W3, 3, MODE_DGRAD_S1), a2, 3, dz2)
+        elif a2.numel() * 4 < (1 << 32) - 8192:     # the border-class kernels address tensors with 32-bit buffer offsets
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # no padding zeros
         else:
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1), a2, 3, dz2)
         dW2, db2 = conv_wgrad(a1, dz2, 2)
-        if a1.numel() * 4 < (1 << 32) - 8192:
+        if _CONV_Z and dz2.numel() * 4 < (1 << 32) - 8192:
+            conv_dgrad_packed(dz2, ctx.bufs.conv_zpack(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
+        elif a1.numel() * 4 < (1 << 32) - 8192:
             conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2_CLASSES), a1, 2, dz1, variant=VARIANT_DGRAD2_CLASSES)   # no padding zeros
         else:
             conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)

@@ -313,31 +313,38 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     };
     const bool wave_rows_ok = m0 + ROWS <= M;
     if constexpr (EPI != Z_BIAS_RELU) {
-        // all mask values of one 32-row tile are requested before the first one is used (few waves per SIMD: nothing else hides a
-        // load's latency)
+        // The mask values are requested before the first one is used -- of the wave's whole block with one wave per SIMD (nothing
+        // else hides a load's latency there: per-tile batches cost the FC data gradient 2 x, 643 -> 1253 us), of one 32-row tile
+        // at a time with two waves per SIMD (registers).
+        constexpr int IB = NWAVES == 4 ? MT : 1;                                    // 32-row tiles per batch
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            float mk[NT][16];
+        for (int i0 = 0; i0 < MT; i0 += IB) {
+            float mk[IB][NT][16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long long m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float* row = a.mask + row_off(m < M ? m : M - 1);
+            for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = n0 + 32 * j + li;
-                    mk[j][e] = (EPI == Z_MASK_CLS4 || n < N) ? row[col_off(j)] : 0.0f;
+                for (int e = 0; e < 16; ++e) {
+                    const long long m = m0 + 32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float* row = a.mask + row_off(m < M ? m : M - 1);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int n = n0 + 32 * j + li;
+                        mk[ib][j][e] = (EPI == Z_MASK_CLS4 || n < N) ? row[col_off(j)] : 0.0f;
+                    }
                 }
-            }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long long m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                float* row = a.C + row_off(m < M ? m : M - 1);
+            for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = n0 + 32 * j + li;
-                    if ((wave_rows_ok || m < M) && (EPI == Z_MASK_CLS4 || n < N)) row[col_off(j)] = mk[j][e] > 0.0f ? acc[i][j][e] : 0.0f;
+                for (int e = 0; e < 16; ++e) {
+                    const long long m = m0 + 32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    float* row = a.C + row_off(m < M ? m : M - 1);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int n = n0 + 32 * j + li;
+                        if ((wave_rows_ok || m < M) && (EPI == Z_MASK_CLS4 || n < N))
+                            row[col_off(j)] = mk[ib][j][e] > 0.0f ? acc[i0 + ib][j][e] : 0.0f;
+                    }
                 }
-            }
         }
     } else {
         float bj[NT];

@@ -210,6 +210,7 @@ class PPOLearner:
         bufs.weights(net[4].weight, 3, cnn.MODE_FWD)
         for layer, mode in cnn.extra_forward_modes():    # whatever else NatureTrunkFn.forward may ask for at a lane's batch size
             bufs.weights(net[2 * layer - 2].weight, layer, mode)
+        cnn.warm_forward_packs(bufs, net)
         bufs.fc_weight(net[7].weight)
 
     def _features(self, obs_rows):
