@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fP
 # of the file compile to identical code with and without the flag.
 # fcx.hip / convx.hip: no SLP vectorizer -- it packs pairs of the split's f32 subtractions into v_pk_add_f32 (plus dead
 # halves), and packed f32 VALU beside MFMAs is an anti-lever on this chip (MI355X_MICROARCH.md, per-instruction constants).
-EXTRA_FLAGS = {"conv.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "fcx.hip": ["-fno-slp-vectorize"], "gemmz.hip": ["-fno-slp-vectorize"],
+EXTRA_FLAGS = {"conv.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "fcx.hip": ["-fno-slp-vectorize"], "gemmz.hip": ["-fno-slp-vectorize"], "fcw.hip": ["-fno-slp-vectorize"],
                "convx.hip": ["-fno-slp-vectorize"]}
 
 

@@ -19,6 +19,8 @@
 // Workgroup -> XCD: the four n-tiles that read the same (k-tile, slab) block of `a` (the 411 MB operand) get the same XCD
 // (workgroups are dealt to the 8 XCDs round robin), so that block leaves HBM once and is served three times by that L2.
 #include "common.h"
+#include "bf16split.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -152,6 +154,201 @@ __global__ __launch_bounds__(256) void fcw_reduce_kernel(const float* __restrict
     dW[o] = s;
 }
 
+// ------------------------------------------------------------------------------------------------------------ kernel W
+// The same weight gradient on the bf16 matrix pipe (round 3): dWp[n][k] = sum_m dz[m][n] * a[m][k] with the six largest term
+// pairs of the three-term bf16 split (bf16split.h; MI355PPO_BF16_PAIRS=9: all nine), f32 accumulation.
+//
+// The reduction index m is the SLOW index of both operands in memory, and the bf16 MFMA wants 8 consecutive m per lane: both
+// operands are transposed on the way in.  Per k-step (16 batch rows) a wave loads its [16 m][128 n] block of dz and its
+// [16 m][64 k] block of a COALESCED (a row of the block = 512 / 256 contiguous bytes), writes them to a wave-private LDS tile
+// as they are, and reads fragments back TRANSPOSED: lane (li, lh) of fragment i takes column 32 i + li, rows 8 lh .. 8 lh + 7
+// with eight 4-byte LDS reads (consecutive lanes = consecutive banks: conflict-free), then splits them in registers.  Wave-
+// private LDS, double-buffered: no workgroup barrier.  A wave owns 128 (n) x 64 (k) of dWp (4 x 2 tiles, 128 accumulator
+// registers, one wave per SIMD); the four waves of a workgroup cover n = 0 .. 511 of one 64-column block of k and read the same
+// rows of `a` (the 411 MB operand leaves HBM once); the batch is dealt to S = 5 slabs in 16-row blocks (49 x 5 = 245
+// workgroups at K = 3136: one round), partials summed in slab order by fcw_reduce_kernel.
+// Per k-step: 12 global loads, 12 LDS writes, 48 LDS reads, 264 VALU, 48 MFMAs -- about seven issued instructions per MFMA:
+// the wave is issue-bound at ~58 cycles per MFMA (tools/mfma_floor: 8 fillers -> 62), still 1.9 x the f32 pipe's 8 x 65 / 0.77
+// cycles for the same 16 x 32 x 32 block.
+typedef float w_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kWMT = 4, kWNT = 2;                         // 32-row tiles of n (dz) x 32-column tiles of k (a) per wave
+constexpr int kWn = 32 * kWMT, kWk = 32 * kWNT;           // 128 x 64
+constexpr int kWSlabs = 5;
+constexpr int kWLdsFloats = 16 * (kWn + kWk);             // one k-step of a wave: [16][128] + [16][64] floats = 12 KiB
+constexpr unsigned kWOob = 0xFFFFF000u;
+constexpr int kWRsrcWord3 = 0x00020000;
+
+// schedule of a k-step: item t sits behind MFMA t.  kinds: 0 = read fragment `arg` from LDS (8 ds_read_b32), 1 = split piece
+// `arg` = 6 * fragment + piece, 2 = LDS writes (third `arg` of the 12), 3 = global loads (third `arg`), -1 = nothing.
+struct WItem { int kind, arg; };
+constexpr WItem w_item(int t) {
+    // R0 R1 | S0.0 S0.1 S0.2 W0 S0.3 S0.4 S0.5 R2 | S1.* (W1) R3 | S2.* (W2) R4 | S3.* (L0) R5 | S4.* (L1) | S5.* (L2)
+    if (t == 0) return {0, 0};
+    if (t == 1) return {0, 1};
+    int u = t - 2;
+    for (int f = 0; f < 6; ++f) {
+        const int len = 6 + 1 + (f < 4 ? 1 : 0);          // six split pieces, one W / L item, (one fragment read)
+        if (u < len) {
+            if (u < 3) return {1, 6 * f + u};
+            if (u == 3) return f < 3 ? WItem{2, f} : WItem{3, f - 3};
+            if (u < 7) return {1, 6 * f + u - 1};
+            return {0, f + 2};
+        }
+        u -= len;
+    }
+    return {-1, 0};
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fcw_bf16_kernel(
+    const float* __restrict__ dz, int lddz, const float* __restrict__ a, float* __restrict__ part, int M, int N, int K, int nkb,
+    unsigned m8, unsigned m16) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * kWLdsFloats];        // 4 waves x 2 buffers x 12 KiB = 96 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kb = blockIdx.x % nkb, slab = blockIdx.x / nkb;
+    const int n0 = wave * kWn, k0 = kb * kWk;
+    const int nblocks = M / 16;                           // 16-row blocks of the batch; slab s takes blocks s, s + S, s + 2 S, ...
+    const int nsteps = (nblocks - slab + kWSlabs - 1) / kWSlabs;
+    float* const wl = lds + wave * (2 * kWLdsFloats);
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, (int)((unsigned)M * (unsigned)lddz * 4u), kWRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a), 0, (int)((unsigned)M * (unsigned)K * 4u), kWRsrcWord3);
+    // coalesced loads of a 16-row block: dz rows are 128 floats of this wave's n range (32 lanes x 16 bytes: 2 rows per
+    // instruction, 8 instructions), a rows 64 floats (16 lanes: 4 rows per instruction, 4 instructions)
+    const unsigned vo_dz = (unsigned)(lane >> 5) * (unsigned)lddz * 4u + (unsigned)n0 * 4u + 16u * (unsigned)(lane & 31);
+    const unsigned vo_a = (unsigned)(lane >> 4) * (unsigned)K * 4u + (unsigned)k0 * 4u + 16u * (unsigned)(lane & 15);
+    float* const wr_dz = wl + (lane >> 5) * kWn + 4 * (lane & 31);                  // + 2 u rows (u < 8)
+    float* const wr_a = wl + 16 * kWn + (lane >> 4) * kWk + 4 * (lane & 15);        // + 4 u rows (u < 4)
+    const float* const rd_dz = wl + (8 * lh) * kWn + li;                            // + e rows, + 32 i columns
+    const float* const rd_a = wl + 16 * kWn + (8 * lh) * kWk + li;
+
+    w_f32x16 acc[kWMT][kWNT];
+#pragma unroll
+    for (int i = 0; i < kWMT; ++i)
+#pragma unroll
+        for (int j = 0; j < kWNT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    s_u32x4 stage[12];                                    // one block as loaded: 8 x dz, 4 x a
+    unsigned raw[2][8];                                   // two fragments as read back from LDS (f32, lane = column, 8 rows)
+    unsigned tt[2][6][3][4];                              // split fragments: [k-step parity][fragment: 4 x dz, 2 x a][term][4 x 2 bf16]
+    auto sclamp = [&](int s) { return s < nsteps ? s : nsteps - 1; };               // past the end: re-read, never multiplied
+    auto load_third = [&](int s, auto tc) {               // third tc of the 12 global loads of step s's block
+        constexpr int t3 = decltype(tc)::value;
+        const int blk = slab + sclamp(s) * kWSlabs;
+        const unsigned so_dz = (unsigned)blk * 16u * (unsigned)lddz * 4u, so_a = (unsigned)blk * 16u * (unsigned)K * 4u;
+#pragma unroll
+        for (int u = 4 * t3; u < 4 * t3 + 4; ++u) {
+            if (u < 8) stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, vo_dz + (unsigned)(2 * u) * (unsigned)lddz * 4u, so_dz, 0));
+            else stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, vo_a + (unsigned)(4 * (u - 8)) * (unsigned)K * 4u, so_a, 0));
+        }
+    };
+    auto write_third = [&](int buf, auto tc) {            // third tc of the 12 LDS writes of `stage` into buffer `buf`
+        constexpr int t3 = decltype(tc)::value;
+#pragma unroll
+        for (int u = 4 * t3; u < 4 * t3 + 4; ++u) {
+            if (u < 8) *reinterpret_cast<s_u32x4*>(wr_dz + buf * kWLdsFloats + 2 * u * kWn) = stage[u];
+            else *reinterpret_cast<s_u32x4*>(wr_a + buf * kWLdsFloats + 4 * (u - 8) * kWk) = stage[u];
+        }
+    };
+    auto read_frag = [&](int buf, auto fc) {              // fragment f (0..3: dz tile, 4..5: a tile) of buffer `buf` -> raw[f & 1]
+        constexpr int f = decltype(fc)::value;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            raw[f & 1][e] = f < 4 ? __float_as_uint(rd_dz[buf * kWLdsFloats + e * kWn + 32 * f]) : __float_as_uint(rd_a[buf * kWLdsFloats + e * kWk + 32 * (f - 4)]);
+    };
+    unsigned t8[4], t16[4];
+    float smid[4], slo[4];
+    auto split_piece = [&](int par, auto fc, auto pc) {   // piece pc (0..5) of fragment f: halves of 4 elements x {masks, subtractions, packs}
+        constexpr int f = decltype(fc)::value, hf = decltype(pc)::value / 3, piece = decltype(pc)::value % 3;
+        if constexpr (piece == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t8[j] = raw[f & 1][4 * hf + j] & m8;
+                t16[j] = raw[f & 1][4 * hf + j] & m16;
+            }
+        } else if constexpr (piece == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                smid[j] = __uint_as_float(t16[j]) - __uint_as_float(t8[j]);
+                slo[j] = __uint_as_float(raw[f & 1][4 * hf + j]) - __uint_as_float(t16[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                tt[par][f][0][2 * hf + (j >> 1)] = __builtin_amdgcn_perm(raw[f & 1][4 * hf + j + 1], raw[f & 1][4 * hf + j], 0x07060302u);
+                tt[par][f][1][2 * hf + (j >> 1)] = split_pack(smid[j + 1], smid[j]);
+                tt[par][f][2][2 * hf + (j >> 1)] = split_pack(slo[j + 1], slo[j]);
+            }
+        }
+    };
+    auto frag_of = [&](int par, int f, int term) {
+        return __builtin_bit_cast(s_bf16x8, (s_u32x4){tt[par][f][term][0], tt[par][f][term][1], tt[par][f][term][2], tt[par][f][term][3]});
+    };
+    constexpr int NM = NP * kWMT * kWNT;
+    constexpr int PX[9] = {0, 0, 1, 0, 2, 1, 1, 2, 2}, PY[9] = {0, 1, 0, 2, 0, 1, 2, 1, 2};
+    // One pipeline step of parity q (the MFMAs of step s on tt[q]); meanwhile: the fragments of step s + 1 are read from LDS
+    // buffer q ^ 1 and split into tt[q ^ 1]; `stage` (the block of step s + 2, loaded during the previous step) is written to
+    // LDS buffer q (its fragments were all read during the previous step); the block of step s + 3 is loaded into `stage`.
+    // Order pinned by hand: item w_item(g) behind MFMA g, each followed by a sched_barrier.
+    auto step = [&](auto qc, int s) {
+        constexpr int q = decltype(qc)::value;
+        [&]<int... G>(std::integer_sequence<int, G...>) {
+            ([&] {
+                constexpr int g = G, pi = g / (kWMT * kWNT), i = (g / kWNT) % kWMT, j = g % kWNT;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(q, i, PX[pi]), frag_of(q, 4 + j, PY[pi]), acc[i][j], 0, 0, 0);
+                constexpr WItem it = w_item(g);
+                if constexpr (it.kind == 0) read_frag(q ^ 1, std::integral_constant<int, it.arg>{});
+                else if constexpr (it.kind == 1) split_piece(q ^ 1, std::integral_constant<int, it.arg / 6>{}, std::integral_constant<int, it.arg % 6>{});
+                else if constexpr (it.kind == 2) write_third(q, std::integral_constant<int, it.arg>{});
+                else if constexpr (it.kind == 3) load_third(s + 3, std::integral_constant<int, it.arg>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, NM>{});
+    };
+    auto load_all = [&](int s) { load_third(s, std::integral_constant<int, 0>{}); load_third(s, std::integral_constant<int, 1>{}); load_third(s, std::integral_constant<int, 2>{}); };
+    auto write_all = [&](int buf) { write_third(buf, std::integral_constant<int, 0>{}); write_third(buf, std::integral_constant<int, 1>{}); write_third(buf, std::integral_constant<int, 2>{}); };
+    auto split_all = [&](int par, int buf) {              // all six fragments of LDS buffer `buf` -> tt[par] (prologue)
+        // (ONE pack expansion: hipcc / clang mis-substitutes the outer pack element inside a nested pack-expanding lambda --
+        // every inner call saw fragment 0, piece 0; found with a host replica of this bookkeeping)
+        [&]<int... T>(std::integer_sequence<int, T...>) {
+            ([&] {
+                if constexpr (T % 6 == 0) read_frag(buf, std::integral_constant<int, T / 6>{});
+                split_piece(par, std::integral_constant<int, T / 6>{}, std::integral_constant<int, T % 6>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, 36>{});
+    };
+    if (nsteps > 0) {
+        // prologue: step 0 -> LDS buffer 0 -> tt[0]; step 1 -> LDS buffer 1; step 2 in `stage`
+        load_all(0);
+        write_all(0);
+        load_all(1);
+        split_all(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        write_all(1);
+        load_all(2);
+        __builtin_amdgcn_sched_barrier(0);
+        int s = 0;
+        for (; s + 2 <= nsteps; s += 2) {
+            step(std::integral_constant<int, 0>{}, s);
+            step(std::integral_constant<int, 1>{}, s + 1);
+        }
+        if (s < nsteps) step(std::integral_constant<int, 0>{}, s);
+    }
+    // partial [slab][n][k]: accumulator element e of tile (i, j) is row n0 + 32 i + (e & 3) + 8 (e >> 2) + 4 lh, column k0 + 32 j + li
+    float* out = part + (size_t)slab * N * K;
+#pragma unroll
+    for (int i = 0; i < kWMT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = n0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float* row = out + (size_t)n * K + k0 + li;
+#pragma unroll
+            for (int j = 0; j < kWNT; ++j) row[32 * j] = acc[i][j][e];
+        }
+}
+
 static int fcw_slabs(int M) {
     int s = M / 512;                                      // at least 256 row pairs per slab
     return s < 1 ? 1 : (s > kYMaxSlabs ? kYMaxSlabs : s);
@@ -163,7 +360,8 @@ using namespace mi355ppo;
 
 extern "C" MI355PPO_API size_t mi355ppo_fc_wgrad_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return (size_t)fcw_slabs(M) * N * K * sizeof(float);
+    const int slabs = fcw_slabs(M) > kWSlabs ? fcw_slabs(M) : kWSlabs;                     // kernel Y's or kernel W's slabs, whichever is more
+    return (size_t)slabs * N * K * sizeof(float);
 }
 
 extern "C" MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
@@ -180,11 +378,26 @@ extern "C" MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, con
                   workspace ? workspace_bytes : (size_t)0, need);
     MI355_REQUIRE(aligned(dz, 8) && aligned(a, 16) && aligned(dW, 4) && aligned(workspace, 16), MI355PPO_EALIGN,
                   "%s: dz must be 8-byte, a and the workspace 16-byte aligned", fn);
+    hipStream_t s = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    // kernel W (bf16 pipe) for this layer's shape at minibatch sizes; kernel Y (f32 pipe) otherwise (MI355PPO_FC_WGRAD=y: always)
+    static const bool force_y = [] { const char* e = getenv("MI355PPO_FC_WGRAD"); return e && e[0] == 'y'; }();
+    if (!force_y && N == 4 * kWn && K % kWk == 0 && M % 16 == 0 && M >= 1024 && aligned(dz, 16) && lddz % 4 == 0 &&
+        (long long)M * K * 4 < (1LL << 32) - 8192) {
+        const int nkb = K / kWk;
+        if (bf16_term_pairs() == 9)
+            hipLaunchKernelGGL((fcw_bf16_kernel<9>), dim3((unsigned)(nkb * kWSlabs)), dim3(256), 0, s, dz, lddz, a, part, M, N, K, nkb, 0xffff0000u, 0xffffff00u);
+        else
+            hipLaunchKernelGGL((fcw_bf16_kernel<6>), dim3((unsigned)(nkb * kWSlabs)), dim3(256), 0, s, dz, lddz, a, part, M, N, K, nkb, 0xffff0000u, 0xffffff00u);
+        int rcw = check_launch("fcw_bf16_kernel");
+        if (rcw) return rcw;
+        const size_t totalw = (size_t)N * K;
+        hipLaunchKernelGGL(fcw_reduce_kernel, dim3((unsigned)((totalw + 255) / 256)), dim3(256), 0, s, part, kWSlabs, dW, N, K, hwc_channels);
+        return check_launch("fcw_reduce_kernel");
+    }
     const int nslabs = fcw_slabs(M);
     const int ntn = (N + kYWgN - 1) / kYWgN, ntk = (K + kYWgK - 1) / kYWgK;
     const int combos = ntk * nslabs, groups = (combos + 7) / 8;                            // 8 (k-tile, slab) pairs per group, one per XCD
-    hipStream_t s = as_stream(stream);
-    float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(fcw_kernel, dim3((unsigned)(groups * ntn * 8)), dim3(256), 0, s, dz, lddz, a, K, part, M, N, K, ntn, ntk, nslabs);
     int rc = check_launch("fcw_kernel");
     if (rc) return rc;
