@@ -19,6 +19,8 @@ void set_error(const char* fmt, ...);
 size_t convx_pack_bytes(int layer);
 int convx_pack(const float* W, void* pack, int layer, hipStream_t s);
 int convx_fwd(const float* src, const void* pack, const float* bias, float* dst, long long images, int layer, hipStream_t s);
+// kernel V (convw.hip): layers 2 / 3 weight + bias gradient on the bf16 pipe; returns 1 when the batch does not qualify
+int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s);
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
                   hipStream_t s);
 

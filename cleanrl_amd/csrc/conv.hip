@@ -1334,6 +1334,8 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
             return MI355PPO_EHIP;
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images);
+    } else if (int vparts = 0; convw_launch(static_cast<const float*>(src), dz, part_w, part_b, images, layer, &vparts, s) != 1) {
+        wparts = vparts;                // kernel V (bf16 pipe, convw.hip) took it: one partial per slab (an error surfaces in check_launch below)
     } else if (layer == 2) {            // kernel T: a workgroup walks image PAIRS
         wparts = grid = wgrad_grid((images + 1) / 2);
         auto k5 = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 5>;

@@ -273,8 +273,11 @@ def test_conv_dgrad_with_relu_mask(layer, images, variant):
 
 
 @pytest.mark.parametrize("layer", [1, 2, 3])
-@pytest.mark.parametrize("images", [1, 7, 600])
+@pytest.mark.parametrize("images", [1, 7, 600, 608, 2064])
 def test_conv_wgrad(layer, images):
+    # 1 / 7 / 600 images: kernels P (layer 1) and T (layers 2, 3).  608 / 2,064 images (multiples of 16, enough 16-pixel blocks for
+    # every slab): layers 2 / 3 run on kernel V (bf16 pipe, convw.hip) -- slabs with uneven step counts, image boundaries inside
+    # the 16-pixel blocks, all four / six wave groups
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(30 + layer)
     W, b = _params(layer, 4)
