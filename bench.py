@@ -17,10 +17,12 @@ Weak scaling: every rank (one process per GPU, RCCL over xGMI) keeps 1024 envs; 
 env-steps/sec = N * 1024 * 128 * K / max-over-ranks(time).
 
 The JSON line also carries
-  ``roofline``      for the dominant HIP kernel of the path = the convolution launch with the largest total time in
-                    the timed region (f32-MFMA implicit GEMMs, csrc/conv.hip; the uint8 gather + /255 of K5 is fused
-                    into them): algorithmic flops / launch duration, timed live with HIP events on the learner's
-                    stream around each launch; ``traffic`` = HBM bytes per launch from the committed PMC passes
+  ``roofline``      for the dominant HIP kernel of the path = the convolution / FC launch with the largest total time in
+                    the timed region (KERNEL_INFO below names them; the uint8 gather + /255 of K5, bias, ReLU and
+                    ReLU-backward passes are fused into them): ALGORITHMIC flops of the f32 convolution / launch duration,
+                    timed live with HIP events on the learner's stream around each launch, against the dense f32 MFMA peak
+                    (the dtype the path computes in); ``pipe`` prices the bf16 products a split kernel actually executes
+                    against the bf16 peak; ``traffic`` = HBM bytes per launch from the committed PMC passes
                     (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction);
   ``kernels``       the same accounting for every conv launch shape, and GB/s for the GAE and fused-loss kernels
                     (latency-bound at this size);
@@ -75,6 +77,24 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= the f32 vector peak), same guide
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide (the 2:1-sparsity headline figure is never used)
+# The hand-written kernels of the conv stack + FC layer, by the letter DESIGN.md gives them.  `pipe`: the matrix pipe a kernel
+# multiplies on; `products`: MFMA products executed per f32 product of the convolution / GEMM (bf16 pipe: the term pairs of the
+# three-term split -- six by default, MI355PPO_BF16_PAIRS=9 for all nine; kernel P's uint8 taps are exact bf16 operands, so
+# only its f32 operand is split: three).
+BF16_PAIRS = 9 if os.environ.get("MI355PPO_BF16_PAIRS", "6")[:1] == "9" else 6
+KERNEL_INFO = {
+    "Q": ("conv1q_fwd_kernel (csrc/conv1q.hip): int8-digit MFMA, exact int32 accumulation; uint8 gather, /255, bias and ReLU fused", "i8", 4),
+    "P": ("conv1p_wgrad_kernel (csrc/conv1p.hip): bf16 MFMA, uint8 taps exact, dz in three bf16 terms; uint8 gather fused", "bf16", 3),
+    "Z": ("z_kernel (csrc/gemmz.hip): bf16 MFMA on three-term splits, weights pre-split into fragment order, activations loaded "
+          "coalesced through wave-private LDS; bias + ReLU / the ReLU-backward mask in the epilogue", "bf16", BF16_PAIRS),
+    "V": ("convw_bf16_kernel (csrc/convw.hip): bf16 MFMA on three-term splits, both operands transposed through LDS; bias gradient "
+          "fused", "bf16", BF16_PAIRS),
+    "W": ("fcw_bf16_kernel (csrc/fcw.hip): bf16 MFMA on three-term splits, both operands transposed through LDS", "bf16", BF16_PAIRS),
+    "F": ("conv_fixed_kernel (csrc/conv.hip): f32-MFMA implicit GEMM; bias + ReLU / the ReLU-backward mask in the epilogue", "f32", 1),
+    "T": ("conv_wgrad_taps_kernel (csrc/conv.hip): f32-MFMA implicit GEMM", "f32", 1),
+    "Y": ("fcw_kernel (csrc/fcw.hip): f32 MFMA", "f32", 1),
+}
 OBS_ROW_BYTES = 4 * 84 * 84   # 28,224
 
 
@@ -236,7 +256,8 @@ def main():
     if learner.fused_cnn and not cli.no_rollout_graphs:
         learner.capture_rollout(env)        # one hipGraph per rollout step (before the timing hooks: no event records in a capture)
     timer = KernelTimer()
-    conv_flops = {}
+    conv_flops = {}      # key "<op>@<rows>" -> algorithmic flops of one launch (the f32 convolution / GEMM: 2 x M x N x K)
+    kernel_of = {}       # key -> letter in KERNEL_INFO
     unhook = []          # (module, name, original) of everything the kernel timing wraps
     if not cli.no_kernel_timing:
         real_obs, real_gae, real_loss, real_loss_p = ops.obs_u8_to_f32, ops.gae, ops.ppo_loss_categorical, ops.ppo_loss_categorical_packed
@@ -245,41 +266,50 @@ def main():
         if learner.fused_cnn:
             from cleanrl_amd import cnn
 
+            lib = _lib.load()
             seen = {}
 
-            def conv_hook(kind, real, images_of):
+            def timed_op(name, key_of):
+                """Wrap cnn.<name>: key_of(*args) -> (key, flops, kernel letter); rollout-sized launches are bracketed 1 in 16
+                (the rollout is host-bound; two event records per launch would slow it)."""
+                real = getattr(cnn, name)
+                unhook.append((cnn, name, real))
+
                 def hooked(*a, **kw):
-                    layer = a[3] if kind != "wgrad" else a[2]
-                    images = images_of(*a, **kw)
-                    cin, cout, k, _, _, hout = cnn.LAYERS[layer]
-                    key = f"conv{layer}_{kind}@{images}"
-                    conv_flops[key] = 2.0 * images * hout * hout * cout * cin * k * k
+                    key, flops, letter = key_of(*a, **kw)
+                    conv_flops[key], kernel_of[key] = flops, letter
                     seen[key] = seen.get(key, 0) + 1
-                    if images == N and seen[key] % 16:          # rollout-sized launches: bracket every 16th (the rollout is
-                        return real(*a, **kw)                   # host-bound; two event records per launch would slow it)
+                    if key.endswith(f"@{N}") and seen[key] % 16:
+                        return real(*a, **kw)
                     return timer.wrap(key, real)(*a, **kw)
 
-                return hooked
+                setattr(cnn, name, hooked)
 
-            def fwd_images(src, Bt, bias, layer, inds=None, out=None, variant=0):
-                return src.shape[0] if inds is None else inds.numel()
+            def conv_flop(layer, images):
+                cin, cout, k, _, _, hout = cnn.LAYERS[layer]
+                return 2.0 * images * hout * hout * cout * cin * k * k
 
-            real_trunk = cnn.trunk_fwd
-            unhook += [(cnn, n, getattr(cnn, n)) for n in ("trunk_fwd", "conv_fwd", "conv_dgrad", "conv_wgrad")]
+            def k_fwd(src, Bt, bias, layer, inds=None, out=None, variant=0):
+                images = src.shape[0] if inds is None else inds.numel()
+                return f"conv{layer}_fwd@{images}", conv_flop(layer, images), ("Q" if variant == cnn.VARIANT_Q else "F")
 
-            def trunk_hook(*a, **kw):
+            def k_trunk(*a, **kw):
                 images = a[8].shape[0]
-                key = f"trunk_fwd(conv1+2+3)@{images}"
-                conv_flops[key] = sum(2.0 * images * c[5] * c[5] * c[1] * c[0] * c[2] * c[2] for c in cnn.LAYERS.values())
-                seen[key] = seen.get(key, 0) + 1
-                if images == N and seen[key] % 16:
-                    return real_trunk(*a, **kw)
-                return timer.wrap(key, real_trunk)(*a, **kw)
+                return f"trunk_fwd(conv1+2+3)@{images}", sum(conv_flop(l, images) for l in cnn.LAYERS), "F"
 
-            cnn.trunk_fwd = trunk_hook
-            cnn.conv_fwd = conv_hook("fwd", cnn.conv_fwd, fwd_images)
-            cnn.conv_dgrad = conv_hook("dgrad", cnn.conv_dgrad, lambda dz, *a, **kw: dz.shape[0])
-            cnn.conv_wgrad = conv_hook("wgrad", cnn.conv_wgrad, lambda src, dz, *a, **kw: dz.shape[0])
+            def k_wgrad(src, dz, layer, inds=None):
+                return f"conv{layer}_wgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), chr(lib.mi355ppo_cnn_conv_wgrad_kernel(dz.shape[0], layer))
+
+            timed_op("conv_fwd", k_fwd)
+            timed_op("trunk_fwd", k_trunk)
+            timed_op("conv_dgrad", lambda dz, Bt, act_in, layer, out=None, variant=0: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), "F"))
+            timed_op("conv_wgrad", k_wgrad)
+            timed_op("conv_fwd_packed", lambda src, pack, bias, layer, out=None: (f"conv{layer}_fwd@{src.shape[0]}", conv_flop(layer, src.shape[0]), "Z"))
+            timed_op("conv_dgrad_packed", lambda dz, pack, act_in, layer, out=None: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), "Z"))
+            timed_op("fc_fwd_relu_packed", lambda a, pack, bias, n, out=None: (f"fc_fwd@{a.shape[0]}", 2.0 * a.shape[0] * n * a.shape[1], "Z"))
+            timed_op("fc_dgrad_mask_packed", lambda dz, pack, act_in, out=None: (f"fc_dgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * act_in.shape[1], "Z"))
+            timed_op("fc_wgrad", lambda dz, a, hwc_channels=0, out=None: (f"fc_wgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * a.shape[1],
+                                                                         chr(lib.mi355ppo_fc_wgrad_kernel(dz.shape[0], dz.shape[1], a.shape[1]))))
 
         def obs_hook(src, inds=None, out=None, scale_255=True):
             if inds is not None:
@@ -353,8 +383,9 @@ def main():
                 "env": "device-resident synthetic generator (no PCIe in the timed region)",
                 "rollout": "one hipGraph per env step (policy forward, sampling, env step, observation store)"
                            if getattr(learner, "_rollout_graphs", None) else "kernel-by-kernel launches",
-                "cnn": "f32-MFMA implicit-GEMM kernels (csrc/conv.hip); layer-1 forward on the int8 MFMA with exact int32 "
-                       "accumulation over 31-bit fixed-point weights (csrc/conv1q.hip): error vs float64 <= the f32 kernel's"
+                "cnn": "layer-1 forward on the int8 MFMA with exact int32 accumulation over 31-bit fixed-point weights (kernel Q); every "
+                       f"other convolution / FC GEMM on the bf16 MFMA over exact three-term splits of the f32 operands, {BF16_PAIRS} of 9 term "
+                       "pairs (kernels Z, V, W, P): f32 in, f32 accumulate, error vs float64 <= the f32-MFMA kernels' (tests/test_gpu_cnn.py)"
                        if learner.fused_cnn else "torch Conv2d (MIOpen)",
             },
             "final_loss": metrics["loss"],
@@ -370,29 +401,31 @@ def main():
             dom = max(tot, key=tot.get)
             us, n = timer.mean_us(dom)
             tf = conv_flops[dom] / us / 1e6
-            if dom.startswith("conv1_fwd"):
-                # layer-1 forward runs on the integer matrix pipe (kernel Q, csrc/conv1q.hip): 1/8 of the f32 pipe's time,
-                # so the launch is bound by HBM -- uint8 rows in, f32 activations out
+            text, pipe, products = KERNEL_INFO[kernel_of[dom]]
+            common = {"avg_launch_us": us, "launches_timed": n, "share_of_step_time": tot[dom] / (elapsed * 1e6),
+                      "traffic": _traffic_of(dom)}
+            if kernel_of[dom] == "Q":
+                # layer-1 forward runs on the integer matrix pipe (kernel Q): 1/8 of the f32 pipe's time, so the launch is bound
+                # by HBM -- uint8 rows in, f32 activations out
                 alg = _conv1_fwd_bytes(int(dom.split("@")[1]))
-                out["roofline"] = {
-                    "kernel": f"{dom}: conv1q_fwd_kernel (int8-digit MFMA, exact int32 accumulation, csrc/conv1q.hip); uint8 gather, "
-                              "/255, bias and ReLU fused",
-                    "bound": "hbm", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": alg / us / 1e3 / HBM_PEAK_GBPS, "traffic": _traffic_of(dom),
-                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": us, "launches_timed": n,
-                    "share_of_step_time": tot[dom] / (elapsed * 1e6),
-                }
+                out["roofline"] = {"kernel": f"{dom}: kernel Q = {text}", "bound": "hbm", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg, **common}
             else:
-                out["roofline"] = {
-                    "kernel": f"{dom}: " + ("conv_wgrad_rows_kernel" if dom.startswith("conv1_wgrad") else
-                                            "conv_wgrad_taps_kernel" if "_wgrad" in dom else "conv_fixed_kernel") +
-                              " (f32-MFMA implicit GEMM, csrc/conv.hip); the uint8 gather + /255 (K5), bias, ReLU, ReLU-backward and "
-                              "bias-gradient passes are fused into the conv kernels and have none of their own",
-                    "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": _traffic_of(dom),
-                    "algorithmic_flops_per_launch": conv_flops[dom], "avg_launch_us": us, "launches_timed": n,
-                    "share_of_step_time": tot[dom] / (elapsed * 1e6),
-                }
+                # `achieved` = the ALGORITHMIC flops of the f32 convolution / GEMM the launch computes (2 x M x N x K, no padding, no
+                # term pairs) per second, against the dense f32 MFMA peak -- the peak of the dtype the path computes in.  A bf16-pipe
+                # kernel executes `products` MFMA products per algorithmic product (the term pairs of the exact split): `pipe`
+                # prices THAT work against the bf16 dense peak, and against the rate one wave per SIMD sustains on random
+                # operands on this chip (power-limited: tools/mfma_floor.cpp, profiles/r03_mfma_floor.jsonl).
+                out["roofline"] = {"kernel": f"{dom}: kernel {kernel_of[dom]} = {text}", "bound": "mfma", "achieved": tf,
+                                   "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                                   "algorithmic_flops_per_launch": conv_flops[dom], **common}
+                if pipe == "bf16":
+                    out["roofline"]["pipe"] = {
+                        "mfma": "v_mfma_f32_32x32x16_bf16", "products_per_f32_product": products, "executed_TFLOPs": tf * products,
+                        "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "frac": tf * products / MFMA_BF16_PEAK_TFLOPS,
+                        "frac_of_measured_stream_rate": tf * products / (MFMA_BF16_PEAK_TFLOPS * 32.0 / 47.7),
+                        "note": "executed = algorithmic x term pairs (padding taps of the data gradients not counted); measured stream "
+                                "rate = 32 nominal cycles per MFMA / 47.7 measured on random operands (profiles/r03_mfma_floor.jsonl)"}
             gus, gn = timer.mean_us("gae")
             lus, ln = timer.mean_us("loss")
             gae_bytes = 20 * T * N + 8 * N
@@ -408,11 +441,15 @@ def main():
             for k in sorted(tot):
                 kus, kn = timer.mean_us(k)
                 launches = kn * (16 if k.endswith(f"@{N}") else 1)          # rollout-sized launches are sampled 1 in 16
-                out["kernels"][k] = {"avg_us": kus, "launches_timed": kn, "TFLOPs": conv_flops[k] / kus / 1e6,
+                _, pipe, products = KERNEL_INFO[kernel_of[k]]
+                out["kernels"][k] = {"kernel": kernel_of[k], "pipe": pipe, "avg_us": kus, "launches_timed": kn,
+                                     "TFLOPs": conv_flops[k] / kus / 1e6,
                                      "frac_of_f32_mfma_peak": conv_flops[k] / kus / 1e6 / MFMA_F32_PEAK_TFLOPS,
                                      "ms_per_step": kus * launches / cli.steps / 1e3,
                                      "hbm_bytes_per_launch_pmc": _traffic_of(k)}
-                if k.startswith("conv1_fwd"):        # kernel Q: HBM-bound, the f32-pipe fraction is > 1 by construction
+                if pipe == "bf16":
+                    out["kernels"][k]["frac_of_bf16_mfma_peak_executed"] = conv_flops[k] * products / kus / 1e6 / MFMA_BF16_PEAK_TFLOPS
+                if kernel_of[k] == "Q":              # HBM-bound, the f32-pipe fraction is > 1 by construction
                     alg = _conv1_fwd_bytes(int(k.split("@")[1]))
                     out["kernels"][k].update({"bound": "hbm", "algorithmic_bytes": alg, "GBps": alg / kus / 1e3,
                                               "frac_of_hbm_peak": alg / kus / 1e3 / HBM_PEAK_GBPS})

@@ -54,13 +54,12 @@ SIGNATURES = {
     "mi355ppo_cnn_conv_fwd_f32_variant": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "mi355ppo_cnn_conv_dgrad_f32_variant": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "mi355ppo_cnn_conv_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "mi355ppo_cnn_conv_wgrad_kernel": (c_int, [c_int64, c_int]),
     "mi355ppo_cnn_conv_wgrad_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_size_t, _P]),
     "mi355ppo_cnn_trunk_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_cnn_conv1q_pack_bytes": (c_size_t, []),
     "mi355ppo_cnn_conv1q_pack": (c_int, [_P, _P, _P]),
     "mi355ppo_cnn_conv1q_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, _P]),
-    "mi355ppo_fc_fwd_relu_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    "mi355ppo_fc_dgrad_mask_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_fc_pack_bytes": (c_size_t, [c_int, c_int]),
     "mi355ppo_fc_pack_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "mi355ppo_fc_fwd_relu_packed_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
@@ -74,10 +73,11 @@ SIGNATURES = {
     "mi355ppo_heads_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "mi355ppo_heads_bwd_relu_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "mi355ppo_fc_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mi355ppo_fc_wgrad_kernel": (c_int, [c_int, c_int, c_int]),
     "mi355ppo_fc_wgrad_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
 }
 
-ABI_VERSION = 120       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 130       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libmi355ppo.so")
-SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "optim.hip", "conv.hip", "convw.hip", "conv1q.hip", "conv1p.hip", "convx.hip", "fcx.hip", "gemmz.hip", "fcw.hip", "heads.hip", "synth_env.hip"]
+SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "optim.hip", "conv.hip", "convw.hip", "conv1q.hip", "conv1p.hip", "gemmz.hip", "fcw.hip", "heads.hip", "synth_env.hip"]
 HEADERS = ["common.h", "catrow.h", "bf16split.h", os.path.join("..", "..", "include", "mi355ppo.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every f32 multiply/add rounds separately, as the reference's un-fused torch ops do.
@@ -22,10 +22,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fP
 # conv.hip: the streaming weight-gradient kernel unrolls a whole image (81 steps x 8 MFMAs); past LLVM's default
 # `#pragma unroll` size limit the loop is only partly unrolled and its register "arrays" stay in scratch.  The other kernels
 # of the file compile to identical code with and without the flag.
-# fcx.hip / convx.hip: no SLP vectorizer -- it packs pairs of the split's f32 subtractions into v_pk_add_f32 (plus dead
+# gemmz.hip / fcw.hip / convw.hip: no SLP vectorizer -- it packs pairs of the split's f32 subtractions into v_pk_add_f32 (plus dead
 # halves), and packed f32 VALU beside MFMAs is an anti-lever on this chip (MI355X_MICROARCH.md, per-instruction constants).
-EXTRA_FLAGS = {"conv.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "fcx.hip": ["-fno-slp-vectorize"], "gemmz.hip": ["-fno-slp-vectorize"], "fcw.hip": ["-fno-slp-vectorize"], "convw.hip": ["-fno-slp-vectorize"],
-               "convx.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"conv.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "gemmz.hip": ["-fno-slp-vectorize"], "fcw.hip": ["-fno-slp-vectorize"], "convw.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target: str, deps: list[str]) -> bool:

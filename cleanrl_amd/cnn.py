@@ -20,24 +20,14 @@ from .ops import _chk, _on, _ptr, _stream, _workspace
 
 # layer -> (Cin, Cout, K, stride, Hin, Hout)
 LAYERS = {1: (4, 32, 8, 4, 84, 20), 2: (32, 64, 4, 2, 20, 9), 3: (64, 64, 3, 1, 9, 7)}
-MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2, MODE_DGRAD_S1_CLASSES, MODE_FWD_Q, MODE_DGRAD_S2_CLASSES, MODE_FWD_X = 0, 1, 2, 3, 4, 5, 6
+MODE_FWD, MODE_DGRAD_S1, MODE_DGRAD_S2, MODE_DGRAD_S1_CLASSES, MODE_FWD_Q, MODE_DGRAD_S2_CLASSES = 0, 1, 2, 3, 4, 5
 BT_CLASSES_NUMEL = 81 * 4096
 BT2_CLASSES_NUMEL = 16 * 128 * 64   # layer-2 data gradient, one matrix per border class of the 10x10 class grid (mode 5)
 VARIANT_DGRAD2_CLASSES = 6
 QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 storage elements (kernel Q's integer-digit pack)
 VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
-VARIANT_X = 7                       # layer-2 / 3 forward on the bf16 matrix pipe with exact products (csrc/convx.hip); Bt = the mode-6 pack
 _CONV_Z = os.environ.get("MI355PPO_CONV", "z") != "f"    # layers 2 / 3 forward + data gradients: kernel Z, or the f32-pipe kernel F
-DGRAD3_Z_MAX_IMAGES = 1 << 30    # layer-3 data gradient: kernel Z multiplies the padding taps (1.65 x the MFMAs) and still beats kernel F's nine
-                                 # border-class launches at every size measured (32,768 images: 1,022 vs 1,163 us on one box, profiles/r03_conv_traffic_ab_same_box.jsonl)
-_FC_Z = os.environ.get("MI355PPO_FC", "z") != "x"      # FC forward / data gradient: kernel Z (pre-split weights, coalesced loads) or kernel X
-_FWD23_BF16 = os.environ.get("MI355PPO_FWD23", "f32") == "bf16"      # minibatch-sized forward of layers 2 / 3: kernel F (default) or kernel C
-
-
-def extra_forward_modes():
-    """(layer, mode) pairs NatureTrunkFn.forward requests beyond (1, FWD_Q), (2, FWD), (3, FWD) at some batch size; the
-    learner derives them before the env-group lanes start, so that lanes only ever READ the weight cache."""
-    return [(2, MODE_FWD_X), (3, MODE_FWD_X)] if _FWD23_BF16 else []
+BUF_LIMIT = (1 << 32) - 8192     # kernels Z / F address a tensor with 32-bit buffer offsets: larger tensors take kernel S (64-bit pointers)
 
 
 def warm_forward_packs(bufs, net) -> None:
@@ -48,18 +38,12 @@ def warm_forward_packs(bufs, net) -> None:
         bufs.conv_zpack(net[4].weight, 3, MODE_FWD)
 
 
-def xpack_numel(layer: int) -> int:
-    """f32 storage elements of the mode-6 pack: three bf16 planes = 6 bytes per weight."""
-    cin, cout, k, _, _, _ = LAYERS[layer]
-    return cout * cin * k * k * 6 // 4
-
-
 def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch.Tensor | None = None) -> torch.Tensor:
     lib = _lib.load()
     cin, cout, k, _, _, _ = LAYERS[layer]
     _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
     numel = (BT_CLASSES_NUMEL if mode == MODE_DGRAD_S1_CLASSES else QPACK_NUMEL if mode == MODE_FWD_Q
-             else BT2_CLASSES_NUMEL if mode == MODE_DGRAD_S2_CLASSES else xpack_numel(layer) if mode == MODE_FWD_X else W.numel())
+             else BT2_CLASSES_NUMEL if mode == MODE_DGRAD_S2_CLASSES else W.numel())
     if out is None:
         out = torch.empty(numel, dtype=torch.float32, device=W.device)
     _chk(out, torch.float32, "Bt", (numel,))
@@ -84,7 +68,7 @@ def conv_fwd(src: torch.Tensor, Bt: torch.Tensor, bias: torch.Tensor, layer: int
         assert inds is None
         images = src.shape[0]
         _chk(src, torch.float32, "src", (images, hin, hin, cin))
-    _chk(Bt, torch.float32, "Bt", (QPACK_NUMEL if variant == VARIANT_Q else xpack_numel(layer) if variant == VARIANT_X else cout * cin * k * k,))
+    _chk(Bt, torch.float32, "Bt", (QPACK_NUMEL if variant == VARIANT_Q else cout * cin * k * k,))
     _chk(bias, torch.float32, "bias", (cout,))
     if out is None:
         out = torch.empty((images, hout, hout, cout), dtype=torch.float32, device=src.device)
@@ -154,23 +138,6 @@ def trunk_fwd(obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3, conv1_variant
                                             _ptr(a1), _ptr(a2), _ptr(a3), images, int(conv1_variant), _stream(dev))
     _lib.check(st, "mi355ppo_cnn_trunk_fwd_f32")
     return a3
-
-
-def fc_fwd_relu(a: torch.Tensor, Wp: torch.Tensor, bias: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-    """``relu(a @ Wp.T + bias)`` on the bf16 matrix pipe with exact products (csrc/fcx.hip)."""
-    lib = _lib.load()
-    M, K = a.shape
-    N = Wp.shape[0]
-    _chk(a, torch.float32, "a", (M, K))
-    _chk(Wp, torch.float32, "Wp", (N, K))
-    _chk(bias, torch.float32, "bias", (N,))
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    _chk(out, torch.float32, "out", (M, N))
-    with _on(a.device):
-        st = lib.mi355ppo_fc_fwd_relu_f32(_ptr(a), _ptr(Wp), _ptr(bias), _ptr(out), M, N, K, _stream(a.device))
-    _lib.check(st, "mi355ppo_fc_fwd_relu_f32")
-    return out
 
 
 def fc_pack(B: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -286,26 +253,9 @@ def padded_rows(rows: int, cols: int, device, pad: int = FC_PAD) -> torch.Tensor
     return torch.empty((rows, cols + pad), dtype=torch.float32, device=device)[:, :cols]
 
 
-def fc_dgrad_mask(dz: torch.Tensor, Wt: torch.Tensor, act_in: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-    """``(dz @ Wt.T) * (act_in > 0)`` with ``Wt = Wp.T`` (N_in, N_out): the FC data gradient with the ReLU backward of the
-    layer below fused into its epilogue.  ``dz`` and ``Wt`` may carry a padded row pitch (``padded_rows``)."""
-    lib = _lib.load()
-    M, K = dz.shape
-    N = Wt.shape[0]
-    assert Wt.shape[1] == K
-    lddz, ldwt = _row_major(dz, "dz"), _row_major(Wt, "Wt")
-    _chk(act_in, torch.float32, "act_in", (M, N))
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=dz.device)
-    _chk(out, torch.float32, "out", (M, N))
-    with _on(dz.device):
-        st = lib.mi355ppo_fc_dgrad_mask_f32(_ptr(dz), lddz, _ptr(Wt), ldwt, _ptr(act_in), _ptr(out), M, N, K, _stream(dz.device))
-    _lib.check(st, "mi355ppo_fc_dgrad_mask_f32")
-    return out
-
-
 def fc_wgrad(dz: torch.Tensor, a: torch.Tensor, hwc_channels: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
-    """``dz.T @ a`` (N, K) on the f32 matrix pipe (csrc/fcw.hip, kernel Y), the batch slabs added in a fixed order.  With
+    """``dz.T @ a`` (N, K) (csrc/fcw.hip: kernel W on the bf16 pipe at minibatch sizes, kernel Y on the f32 pipe otherwise), the
+    batch slabs added in a fixed order.  With
     ``hwc_channels = C`` the columns of ``a`` are (h, w, c)-ordered features and the result comes out in the reference's
     (c, h, w) order -- the gradient of ``Linear.weight`` itself."""
     lib = _lib.load()
@@ -323,7 +273,7 @@ def fc_wgrad(dz: torch.Tensor, a: torch.Tensor, hwc_channels: int = 0, out: torc
     return out
 
 
-FCX_MIN_ROWS = 4096          # below this (rollout-sized batches) the 128 x 128 workgroup tiles cannot fill the chip: library GEMM
+FCZ_MIN_ROWS = 4096          # below this (rollout-sized batches) kernel Z's 128 x 128 workgroup tiles cannot fill the chip: library GEMM
 
 
 class _Buffers:
@@ -433,6 +383,14 @@ class NatureTrunkFn(torch.autograd.Function):
     def forward(ctx, obs_u8, inds, W1, b1, W2, b2, W3, b3, bufs):
         m = obs_u8.shape[0] if inds is None else inds.numel()
         a1, a2, a3 = bufs.get(m, obs_u8.device, False)
+        if a1.numel() * 4 >= BUF_LIMIT:     # beyond 32-bit buffer offsets: the f32-pipe kernels with 64-bit pointers (kernel S) throughout
+            conv_fwd(obs_u8, bufs.weights(W1, 1, MODE_FWD), b1.detach(), 1, inds, a1)
+            conv_fwd(a1, bufs.weights(W2, 2, MODE_FWD), b2.detach(), 2, None, a2)
+            conv_fwd(a2, bufs.weights(W3, 3, MODE_FWD), b3.detach(), 3, None, a3)
+            ctx.obs, ctx.inds, ctx.acts, ctx.bufs = obs_u8, inds, (a1, a2, a3), bufs
+            bufs.last_a3_ptr = a3.data_ptr()
+            ctx.save_for_backward(W2, W3)
+            return a3
         # layer 1 runs on the integer matrix pipe (kernel Q): uint8 taps are exact int8 operands, weights four int8 digits
         bt1 = bufs.weights(W1, 1, MODE_FWD_Q)
         if _CONV_Z:                 # layers 2 and 3 on kernel Z (bf16 pipe, pre-split weights, coalesced window loads)
@@ -444,12 +402,8 @@ class NatureTrunkFn(torch.autograd.Function):
             trunk_fwd(obs_u8, inds, bt1, b1.detach(), bt2, b2.detach(), bt3, b3.detach(), a1, a2, a3, conv1_variant=VARIANT_Q)
         else:
             conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1, variant=VARIANT_Q)
-            if _FWD23_BF16:         # layers 2 and 3 at minibatch size on the bf16 matrix pipe with exact products (kernel C)
-                conv_fwd(a1, bufs.weights(W2, 2, MODE_FWD_X), b2.detach(), 2, None, a2, variant=VARIANT_X)
-                conv_fwd(a2, bufs.weights(W3, 3, MODE_FWD_X), b3.detach(), 3, None, a3, variant=VARIANT_X)
-            else:
-                conv_fwd(a1, bufs.weights(W2, 2, MODE_FWD), b2.detach(), 2, None, a2)
-                conv_fwd(a2, bufs.weights(W3, 3, MODE_FWD), b3.detach(), 3, None, a3)
+            conv_fwd(a1, bufs.weights(W2, 2, MODE_FWD), b2.detach(), 2, None, a2)
+            conv_fwd(a2, bufs.weights(W3, 3, MODE_FWD), b3.detach(), 3, None, a3)
         ctx.obs, ctx.inds, ctx.acts, ctx.bufs = obs_u8, inds, (a1, a2, a3), bufs
         bufs.last_a3_ptr = a3.data_ptr()
         ctx.save_for_backward(W2, W3)
@@ -467,16 +421,18 @@ class NatureTrunkFn(torch.autograd.Function):
         else:
             dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)    # ReLU backward of the last conv
         dW3, db3 = conv_wgrad(a2, dz3, 3)
-        if _CONV_Z and m <= DGRAD3_Z_MAX_IMAGES:
+        # (layer-3 data gradient: kernel Z multiplies the padding taps, 1.65 x the MFMAs, and still beats kernel F's nine
+        # border-class launches at every size measured: profiles/r03_conv_traffic_ab_same_box.jsonl)
+        if _CONV_Z and a2.numel() * 4 < BUF_LIMIT:
             conv_dgrad_packed(dz3, ctx.bufs.conv_zpack(W3, 3, MODE_DGRAD_S1), a2, 3, dz2)
-        elif a2.numel() * 4 < (1 << 32) - 8192:     # the border-class kernels address tensors with 32-bit buffer offsets
+        elif a2.numel() * 4 < BUF_LIMIT:            # the border-class kernels address tensors with 32-bit buffer offsets
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # no padding zeros
         else:
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1), a2, 3, dz2)
         dW2, db2 = conv_wgrad(a1, dz2, 2)
-        if _CONV_Z and dz2.numel() * 4 < (1 << 32) - 8192:
+        if _CONV_Z and a1.numel() * 4 < BUF_LIMIT:
             conv_dgrad_packed(dz2, ctx.bufs.conv_zpack(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
-        elif a1.numel() * 4 < (1 << 32) - 8192:
+        elif a1.numel() * 4 < BUF_LIMIT:
             conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2_CLASSES), a1, 2, dz1, variant=VARIANT_DGRAD2_CLASSES)   # no padding zeros
         else:
             conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
@@ -506,20 +462,19 @@ def fc_weight_hwc(weight: torch.Tensor) -> torch.Tensor:
 class LinearReLUHwcFn(torch.autograd.Function):
     """``relu(a @ fc_weight_hwc(W).T + b)`` for the trunk's (h, w, c)-ordered features -- Agent.network[7:9]
     (Linear(3136, 512) + ReLU, cleanrl/ppo_atari_multigpu.py:144-145).  Minibatch-sized batches: forward and data gradient
-    on kernel X (bf16 pipe, exact products; bias + ReLU / the ReLU backward of conv3 in the epilogues), the weight gradient
-    on kernel Y (f32 pipe, the batch cut into slabs, csrc/fcw.hip); this layer's own ReLU backward and bias gradient ride in
-    ``HeadsFn.backward``.  Rollout-sized calls (no backward) use the library GEMM with the fused epilogue."""
+    on kernel Z (bf16 pipe, pre-split weights; bias + ReLU / the ReLU backward of conv3 in the epilogues, csrc/gemmz.hip), the
+    weight gradient on kernel W (bf16 pipe, the batch cut into slabs, csrc/fcw.hip); this layer's own ReLU backward and bias
+    gradient ride in ``HeadsFn.backward``.  Rollout-sized calls (no backward) use the library GEMM with the fused epilogue."""
 
     @staticmethod
     def forward(ctx, a, W, b, bufs=None):
         Wp = bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()).contiguous()
-        # minibatch-sized batches on the GPU: kernel X (csrc/fcx.hip), bf16 matrix pipe with exact products; bias + ReLU in
-        # its epilogue.  Rollout-sized batches and the host path: the library GEMM with the same fused epilogue.
-        ctx.fcx = bool(a.is_cuda and bufs is not None and a.shape[0] >= FCX_MIN_ROWS and a.shape[1] % 16 == 0 and a.is_contiguous())
-        if ctx.fcx and _FC_Z:
+        # minibatch-sized batches on the GPU: kernel Z (csrc/gemmz.hip), bf16 matrix pipe, bias + ReLU in its epilogue.
+        # Rollout-sized batches and the host path: the library GEMM with the same fused epilogue.
+        ctx.fcz = bool(a.is_cuda and bufs is not None and a.shape[0] >= FCZ_MIN_ROWS and a.shape[1] % 16 == 0 and a.is_contiguous()
+                       and a.numel() * 4 < BUF_LIMIT)
+        if ctx.fcz:
             h = fc_fwd_relu_packed(a, bufs.fc_pack_fwd(W), b.detach().contiguous(), Wp.shape[0])
-        elif ctx.fcx:
-            h = fc_fwd_relu(a, Wp, b.detach().contiguous())
         else:
             h = torch._addmm_activation(b.detach(), a, Wp.t())                 # bias + ReLU fused into the GEMM epilogue
         ctx.bufs = bufs
@@ -538,19 +493,19 @@ class LinearReLUHwcFn(torch.autograd.Function):
             dz = torch.ops.aten.threshold_backward(dh.contiguous(), h, 0.0)
         if bufs is not None:
             bufs.fc_dz_from_heads = None
-        fused = bool(ctx.fcx and ctx.needs_input_grad[0] and bufs.last_a3_ptr == a.data_ptr())
+        fused = bool(ctx.fcz and ctx.needs_input_grad[0] and bufs.last_a3_ptr == a.data_ptr())
         da = None
         if ctx.needs_input_grad[0]:
             if fused:
-                # `a` is the trunk's ReLU output a3: its ReLU backward rides in this GEMM's epilogue (kernel X, EPI_MASK) and
+                # `a` is the trunk's ReLU output a3: its ReLU backward rides in this GEMM's epilogue (kernel Z, Z_MASK) and
                 # NatureTrunkFn.backward is told not to mask again -- the separate pass over the 411 MB tensor is gone
-                da = fc_dgrad_mask_packed(dz, bufs.fc_pack_dgrad(W), a) if _FC_Z else fc_dgrad_mask(dz, bufs.fc_weight_t(W), a)
+                da = fc_dgrad_mask_packed(dz, bufs.fc_pack_dgrad(W), a)
                 bufs.a3_grad_is_masked = True
             else:
                 da = dz @ Wp
         m, n = dz.shape
-        if ctx.fcx and n % 64 == 0 and a.shape[1] % 224 == 0 and a.shape[1] % 64 == 0:
-            dW = fc_wgrad(dz, a, 64)               # kernel Y: f32 matrix pipe, written in the (c, h, w) feature order of W itself
+        if ctx.fcz and n % 64 == 0 and a.shape[1] % 224 == 0 and a.shape[1] % 64 == 0:
+            dW = fc_wgrad(dz, a, 64)               # kernel W (bf16 pipe), written in the (c, h, w) feature order of W itself
         else:
             dW = (dz.t() @ a).view(n, 7, 7, 64).permute(0, 3, 1, 2).reshape(n, 64 * 7 * 7)     # back to the (c, h, w) feature order
         return da, dW, (db if db is not None else dz.sum(0)), None
@@ -595,7 +550,7 @@ class HeadsFn(torch.autograd.Function):
         dlogits = dlogits.contiguous() if dlogits is not None else torch.zeros((M, A), device=dev)
         dvalue = dvalue.contiguous() if dvalue is not None else torch.zeros((M, 1), device=dev)
         bufs = ctx.relu_bufs
-        # (ReLU variant: dz with a padded row pitch -- kernel X's A operand at K = 512, see FC_PAD)
+        # (ReLU variant: dz with a padded row pitch -- kernel Z's A operand at K = 512, see FC_PAD)
         dh = bufs.fc_dz(M, H, dev) if bufs is not None else torch.empty_like(h)
         dWa, dba = torch.empty_like(Wa), torch.empty(A, dtype=torch.float32, device=dev)
         dWc, dbc = torch.empty_like(Wc), torch.empty(1, dtype=torch.float32, device=dev)

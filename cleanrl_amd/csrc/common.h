@@ -14,19 +14,16 @@ namespace mi355ppo {
 
 void set_error(const char* fmt, ...);
 
-// kernel P (conv1p.hip): layer-1 weight gradient on the bf16 matrix pipe; partial layout of kernel R (conv.hip reduces them)
-// kernel C (convx.hip): layers 2 / 3 forward on the bf16 pipe with exact products; pack = the pre-split weights (repack mode 6)
-size_t convx_pack_bytes(int layer);
-int convx_pack(const float* W, void* pack, int layer, hipStream_t s);
-int convx_fwd(const float* src, const void* pack, const float* bias, float* dst, long long images, int layer, hipStream_t s);
-// kernel V (convw.hip): layers 2 / 3 weight + bias gradient on the bf16 pipe; returns 1 when the batch does not qualify
-int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s);
+// kernel P (conv1p.hip): layer-1 weight gradient on the bf16 matrix pipe; one partial per wave (conv.hip reduces them)
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
                   hipStream_t s);
+// kernel V (convw.hip): layers 2 / 3 weight + bias gradient on the bf16 pipe; returns 1 when the batch does not qualify
+bool convw_applies(int64_t images, int layer);
+int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Term pairs of the three-term bf16 split multiplied by kernels X (fcx.hip) and C (convx.hip): 9 = all 3 x 3 (every f32
+// Term pairs of the three-term bf16 split multiplied by kernels Z (gemmz.hip), W (fcw.hip) and V (convw.hip): 9 = all 3 x 3 (every f32
 // product exact), 6 = the pairs (a_i, b_j) with i + j <= 2 -- the three dropped pairs (mid x lo, lo x mid, lo x lo) are
 // together below 2^-21 of the product (typically 2^-24: under the rounding of ONE f32 multiply), see DESIGN.md.  Read once.
 inline int bf16_term_pairs() {

@@ -55,7 +55,6 @@ struct ConvGeom {
     int classes;          // 1, or 4 = stride-2 data-gradient parity classes (blockIdx.y)
     int logC;             // log2(C) (f32 sources)
     long long P;          // total GEMM rows = images * GY * GX
-    int diag;             // tuning only (MI355PPO_CONV_DIAG): bit0 = no ring refills, bit1 = no B fragment reads, bit2 = no epilogue
 };
 
 // uint8 taps enter the MFMAs as the exact integers 0..255 (one v_cvt_f32_ubyteN each) and the 1/255 of
@@ -198,12 +197,10 @@ __global__ __launch_bounds__(64 * NW) void conv_stream_kernel(const void* __rest
 #pragma unroll
             for (int d = 0; d < kRing; ++d) {
                 Bp += U8IN ? 32 : 8;                  // B fragments of the NEXT chunk are read under this chunk's MFMAs
-                if (!(g.diag & 2)) {
 #pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt)
+                for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-                        for (int q = 0; q < NB; ++q) bnxt[jt][q] = *reinterpret_cast<const float4*>(Bp + jt * 32 * ldb + 4 * q);
-                }
+                    for (int q = 0; q < NB; ++q) bnxt[jt][q] = *reinterpret_cast<const float4*>(Bp + jt * 32 * ldb + 4 * q);
                 u32x4 A[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -225,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stream_kernel(const void* __rest
                         }
                     }
                 }
-                if (!(g.diag & 1)) fetch(d);         // refill the slot just consumed (kRing chunks ahead)
+                fetch(d);                            // refill the slot just consumed (kRing chunks ahead)
                 advance(d == kRing - 1);
                 __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: hipcc otherwise sinks all kRing loads to the
                                                      // loop tail and the first one is awaited one instruction later
@@ -236,10 +233,6 @@ __global__ __launch_bounds__(64 * NW) void conv_stream_kernel(const void* __rest
             }
         }
         // ---- epilogue: destination offset of THIS lane's pixel, fetched per accumulator row by a wave shuffle
-        if (g.diag & 4) {
-            if (acc[0][0][0] == 123.456f) dst[0] = 1.0f;
-            continue;
-        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             int myoff = -1;
@@ -545,137 +538,6 @@ __global__ __launch_bounds__(64 * NW) void conv_fixed_kernel(const void* __restr
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
-// ---- weight gradient of layer 1 on the f32 pipe (kernel R, "rows"; the default is kernel P in conv1p.hip, R is its
-// f32-MFMA counterpart for A/B runs: MI355PPO_WGRAD=3).  Its predecessors (kernels W and D, removed in round 2) met at two
-// workgroup barriers per image and paid a pixel-table read, an address add and a predicated 64-bit index computation beside
-// every 8 MFMAs.  Here a wave is autonomous:
-//   * wave w owns output rows 5w .. 5w+4 of every image of its workgroup, i.e. the 24 source rows 20w .. 20w+23 (8,064 bytes;
-//     neighbouring waves overlap by 4 rows).  It stages that slab itself, global -> registers -> its own double-buffered
-//     LDS region, so there is NO workgroup barrier anywhere: LDS instructions of one wave execute in order;
-//   * one "round" = one output row = 10 pixel pairs, fully unrolled, 5 rounds per image: every LDS and global address of
-//     the loop body is (per-image base register + compile-time immediate);
-//   * the taps of output row r, tap rows 4-7, are the taps of output row r+1, tap rows 0-3 (stride 4 == half the 8-row
-//     window): the dword a lane fetched as "lower half" of row r+1 is kept and re-used -> one ds_read_b32 per pixel pair
-//     instead of two plus the table read;
-//   * the next image's slab is fetched during round 0 (one 16-byte load per step) and written to the other LDS buffer
-//     during round 3; the dz fragments run one round ahead, straight from global memory, across image boundaries.
-// Lane roles: lane (li, lh) supplies, for pixel 2j + lh of the row, the dword of tap row li/8 (+4),
-// tap columns 4(li%8) .. +3; tile 4h + c holds tap (row li/8 + 4h, column 4(li%8) + c) -- undone when the partial is written.
-template <class G>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_rows_kernel(
-    const unsigned char* __restrict__ src, const int64_t* __restrict__ inds, const float* __restrict__ dz,
-    float* __restrict__ part_w,      // [grid * 4][32][256]
-    float* __restrict__ part_b,      // [grid * 4][32]
-    int images) {
-    static_assert(G::C == 4 && G::KH == 8 && G::KW == 8 && G::SS == 4 && G::GX == 20 && G::GY == 20 && G::DC == 32 && G::W == 84,
-                  "kernel R is written for Conv2d(4, 32, 8, stride 4) on 84x84 frames");
-    constexpr int kImg = G::H * G::W * G::C, kPitch = G::PITCH;          // 28,224 / 336 bytes
-    constexpr int kRounds = 5, kPPR = 10;                                // output rows per wave, pixel pairs per output row
-    constexpr int kRowStep = G::SS * kPitch;                             // 1,344 bytes between output rows == 4 tap rows
-    constexpr int kSlab = (G::KH + G::SS * (kRounds - 1)) * kPitch;      // 24 source rows = 8,064 bytes
-    constexpr int kBuf = 8192, kChunks = kSlab / 16, kNS = 8;            // 504 16-byte chunks, 8 per lane (last ones clamped)
-    constexpr int kN = 32, kK = 256, kDzImg = G::PER_IMG * kN;           // floats of one dz image
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-    unsigned char* const wbuf = smem + wave * (2 * kBuf);                // this wave's two slab buffers
-    const int L0 = lh * (G::SS * G::C) + (li >> 3) * kPitch + 4 * (li & 7);
-    const int lane_dz = (wave * (kRounds * 2 * kPPR) + lh) * kN + li;    // float offset of (pixel lh of the wave's first pair, channel li)
-    const int step_img = gridDim.x;
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
-    float bsum = 0.0f;
-
-    auto row_of = [&](int img) { return inds ? inds[img] : (long long)img; };     // rollout row of minibatch image `img` (scalar load)
-    auto slab = [&](long long simg) { return src + simg * (long long)kImg + wave * (G::SS * kRounds * kPitch); };
-    auto chunk_of = [&](int q) { const int e = lane + 64 * q; return e < kChunks ? e : kChunks - 1; };
-
-    int img = blockIdx.x;
-    if (img >= images) return;                                           // (grid <= images: never taken)
-    u32x4 rs[kNS];
-    {   // first image: straight through the registers into buffer 0
-        const unsigned char* g0 = slab(row_of(img));
-#pragma unroll
-        for (int q = 0; q < kNS; ++q) rs[q] = *reinterpret_cast<const u32x4*>(g0 + chunk_of(q) * 16);
-#pragma unroll
-        for (int q = 0; q < kNS; ++q) *reinterpret_cast<u32x4*>(wbuf + (lane + 64 * q) * 16) = rs[q];
-        __builtin_amdgcn_wave_barrier();
-    }
-    float ring[kPPR];
-    uint32_t row[2][kPPR];
-    {
-        const float* gd = dz + (long long)img * kDzImg;
-#pragma unroll
-        for (int j = 0; j < kPPR; ++j) ring[j] = gd[lane_dz + 2 * j * kN];
-#pragma unroll
-        for (int j = 0; j < kPPR; ++j) {
-            row[0][j] = *reinterpret_cast<const uint32_t*>(wbuf + L0 + 2 * j * (G::SS * G::C));
-            row[1][j] = *reinterpret_cast<const uint32_t*>(wbuf + L0 + kRowStep + 2 * j * (G::SS * G::C));
-        }
-    }
-    int buf = 0;
-    int nimg = img + step_img < images ? img + step_img : img;          // clamped: past the end the refills are never consumed
-    long long snext = row_of(nimg);                                       // fetched a whole image before it is needed
-    for (; img < images; img += step_img) {
-        const unsigned char* const lcur = wbuf + buf * kBuf + L0;
-        const unsigned char* const lnxt = wbuf + (buf ^ 1) * kBuf + L0;
-        unsigned char* const wnxt = wbuf + (buf ^ 1) * kBuf + lane * 16;
-        const float* const gd = dz + (long long)img * kDzImg + lane_dz;
-        const float* const gdn = dz + (long long)nimg * kDzImg + lane_dz;
-        const unsigned char* const gsl = slab(snext);
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-#pragma unroll
-            for (int j = 0; j < kPPR; ++j) {
-                const float a = ring[j];
-                bsum += a;
-                const uint32_t w0 = row[r & 1][j], w1 = row[(r + 1) & 1][j];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w0, 0), acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w0, 1), acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w0, 2), acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w0, 3), acc[3], 0, 0, 0);
-                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w1, 0), acc[4], 0, 0, 0);
-                acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w1, 1), acc[5], 0, 0, 0);
-                acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w1, 2), acc[6], 0, 0, 0);
-                acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, u8_tap(w1, 3), acc[7], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                // refills: dz one round ahead; the tap dwords two output rows ahead (the next image's first two at the end)
-                if (r + 1 < kRounds) {
-                    ring[j] = gd[((r + 1) * 2 * kPPR + 2 * j) * kN];
-                    row[r & 1][j] = *reinterpret_cast<const uint32_t*>(lcur + (r + 2) * kRowStep + 2 * j * (G::SS * G::C));
-                } else {
-                    ring[j] = gdn[2 * j * kN];
-                    row[0][j] = *reinterpret_cast<const uint32_t*>(lnxt + 2 * j * (G::SS * G::C));
-                    row[1][j] = *reinterpret_cast<const uint32_t*>(lnxt + kRowStep + 2 * j * (G::SS * G::C));
-                }
-                if (r == 0 && j < kNS) rs[j] = *reinterpret_cast<const u32x4*>(gsl + chunk_of(j) * 16);
-                if (r == 3 && j < kNS) *reinterpret_cast<u32x4*>(wnxt + 64 * j * 16) = rs[j];
-                if (r == 1 && j == 0) {                                  // the row index of the image after next (used next iteration)
-                    nimg = nimg + step_img < images ? nimg + step_img : nimg;       // (gdn above already holds the old nimg's pointer)
-                    snext = row_of(nimg);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        buf ^= 1;
-    }
-
-    float* pw = part_w + (size_t)(blockIdx.x * 4 + wave) * kN * kK;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int kcol = ((li >> 3) + 4 * (t >> 2)) * 32 + 4 * (li & 7) + (t & 3);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) pw[(size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * kK + kcol] = acc[t][e];
-    }
-    const float both = bsum + __shfl_xor(bsum, 32, 64);
-    if (lh == 0) part_b[(size_t)(blockIdx.x * 4 + wave) * kN + li] = both;
-}
-
 // ---- weight gradient of layers 2 and 3, third generation (kernel T, "taps"): no LDS, no barrier, no address table.
 // With 32 or 64 input channels an MFMA tile (32 columns of dW) is ONE tap (kh, kw) x 32 input channels, so the B operand
 // of tile (kh, kw) for an output pixel is the dword `src[y*SS + kh][x*SS + kw][c0 + li]` -- 32 consecutive channels of one
@@ -955,10 +817,6 @@ extern "C" MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, floa
     MI355_REQUIRE(W && Bt, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
     if (mode == 4 && layer == 1) return mi355ppo_cnn_conv1q_pack(W, Bt, stream);   // integer-digit pack of kernel Q (conv1q.hip)
-    if (mode == 6 && layer >= 2) {                                                  // bf16 term planes of kernel C (convx.hip)
-        MI355_REQUIRE(aligned(Bt, 16), MI355PPO_EALIGN, "%s: the pack must be 16-byte aligned", fn);
-        return convx_pack(W, Bt, layer, as_stream(stream));
-    }
     MI355_REQUIRE(mode == 0 || ((mode == 1 || mode == 3) && layer == 3) || ((mode == 2 || mode == 5) && layer == 2), MI355PPO_EINVAL,
                   "%s: mode %d is not defined for layer %d", fn, mode, layer);
     const int total = mode == 3 ? kC3_total : mode == 5 ? kC2_total : Cout * Cin * KH * KH;
@@ -994,15 +852,12 @@ static int launch_stream_cfg(const void* src, const int64_t* inds, const float* 
         return MI355PPO_EHIP;
     }
     const int ntiles = (int)((g.P + 32 * MT - 1) / (32 * MT));
-    static const int s_diag = getenv("MI355PPO_CONV_DIAG") ? atoi(getenv("MI355PPO_CONV_DIAG")) : 0;
-    ConvGeom gd = g;
-    gd.diag = s_diag;
     // persistent workgroups of 8 waves: one per CU when the weights fill the LDS, two when they are small
     // (one 8-wave workgroup per CU: the kernels use 160-240 VGPRs, so two would not be co-resident anyway)
     int wgs = 256 / g.classes;
     const int need = (ntiles + NW - 1) / NW;
     if (wgs > need) wgs = need;
-    hipLaunchKernelGGL(k, dim3((unsigned)wgs, (unsigned)g.classes), dim3(64 * NW), smem, s, src, inds, Bt, bias, mask_src, dst, gd,
+    hipLaunchKernelGGL(k, dim3((unsigned)wgs, (unsigned)g.classes), dim3(64 * NW), smem, s, src, inds, Bt, bias, mask_src, dst, g,
                        ntiles);
     return check_launch("conv_stream_kernel");
 }
@@ -1141,11 +996,9 @@ static int launch_dgrad2_classes(const float* dz, const float* Bt, const float* 
 template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4 = false, int MT = 2>
 static int launch_stream(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
                          float* dst, const ConvGeom& g, hipStream_t s) {
-    static const int cfg = getenv("MI355PPO_CONV_CFG") ? atoi(getenv("MI355PPO_CONV_CFG")) : 0;
     if (NJT == 4 || MT == 1) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
-    if (cfg == 1) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 16>(src, inds, Bt, bias, mask_src, dst, g, s);
     // small problems (rollout batches): 32-pixel tiles give every wave of the chip something to do
-    if (cfg == 2 || g.P < 64LL * 4 * 2048) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
+    if (g.P < 64LL * 4 * 2048) return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 1, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
     return launch_stream_cfg<NJT, U8IN, EPI, PAD, CLS4, 2, 8>(src, inds, Bt, bias, mask_src, dst, g, s);
 }
 
@@ -1158,13 +1011,11 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
     MI355_REQUIRE(layer == 1 || inds == nullptr, MI355PPO_EINVAL, "%s: inds (row gather) is only defined for layer 1", fn);
-    MI355_REQUIRE(variant == 0 || variant == 2 || variant == 4 || (variant == 6 && layer == 1) || (variant == 7 && layer >= 2), MI355PPO_EINVAL,
+    MI355_REQUIRE(variant == 0 || variant == 2 || variant == 4 || (variant == 6 && layer == 1), MI355PPO_EINVAL,
                   "%s: unknown variant %d", fn, variant);
     MI355_REQUIRE(aligned(src, 16) && aligned(Bt, 16) && aligned(dst, 16) && aligned(inds, 8), MI355PPO_EALIGN,
                   "%s: src/Bt/dst must be 16-byte aligned", fn);
     if (variant == 6) return mi355ppo_cnn_conv1q_fwd(src, inds, Bt, bias, dst, images, stream);   // Bt = the mode-4 pack
-    if (variant == 7)                                                                               // Bt = the mode-6 pack
-        return convx_fwd(static_cast<const float*>(src), Bt, bias, dst, images, layer, as_stream(stream));
     ConvGeom g;
     g.H = g.W = Hin; g.C = Cin; g.KH = g.KW = KH; g.GY = g.GX = Hout; g.SS = SS; g.OFF = 0;
     g.DH = g.DW = Hout; g.DC = Cout; g.DM = 1; g.DAY = g.DAX = 0; g.K = KH * KH * Cin; g.N = Cout; g.classes = 1;
@@ -1179,8 +1030,7 @@ static int conv_fwd_impl(const void* src, const int64_t* inds, const float* Bt, 
             // layer 1 has the shortest tiles (8 chunks): on gfx9 loads and stores share one out-of-order vmcnt, so the tile
             // epilogue's stores force a full drain of the prefetch ring at every tile boundary; three 4-wave workgroups per
             // CU (3 waves per SIMD at 152 VGPRs) give the matrix pipe two other waves to run meanwhile.
-            static const int s_c1 = getenv("MI355PPO_CONV1_WG") ? atoi(getenv("MI355PPO_CONV1_WG")) : 3;
-            if (s_c1 == 3 && g.P >= 64LL * 4 * 2048)
+            if (g.P >= 64LL * 4 * 2048)
                 return launch_fixed_cfg<GeomConv1, 1, true, EPI_BIAS_RELU, false, false, 2, 4, 3>(src, inds, Bt, bias, nullptr, dst, g.P, 0, dstb, s);
             return launch_fixed<GeomConv1, 1, true, EPI_BIAS_RELU, false>(src, inds, Bt, bias, nullptr, dst, g.P, 0, dstb, s);
         }
@@ -1289,6 +1139,11 @@ extern "C" MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t i
     return ((wparts + nchunks) * (size_t)Cout * KH * KH * Cin + (wparts + nchunks) * Cout) * sizeof(float);
 }
 
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_kernel(int64_t images, int layer) {
+    if (images <= 0 || layer < 1 || layer > 3) return 0;
+    return layer == 1 ? 'P' : convw_applies(images, layer) ? 'V' : 'T';
+}
+
 extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW,
                                                         float* db, int64_t images, int layer, void* workspace,
                                                         size_t workspace_bytes, void* stream) {
@@ -1312,36 +1167,21 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     float* part_b = part_w + (size_t)lparts * total_w;
     float* mid = part_b + (size_t)lparts * Cout;
     float* mid_b = mid + (size_t)((lparts + kRedChunk - 1) / kRedChunk) * total_w;
-    // Layer 1: kernel P (bf16 pipe, exact products, conv1p.hip); MI355PPO_WGRAD=3 selects kernel R (rows, f32 MFMA) for A/B
-    // runs.  Layers 2, 3: kernel T (taps); MI355PPO_WGRAD_TAPS: 3 = paired 8-byte loads on layer 2 (default), 1 = 4-byte
-    // loads on both layers, 2 = likewise with the deeper layer-2 prefetch ring.
-    static const int s_wk = getenv("MI355PPO_WGRAD") ? atoi(getenv("MI355PPO_WGRAD")) : 4;
-    static const int s_wt = getenv("MI355PPO_WGRAD_TAPS") ? atoi(getenv("MI355PPO_WGRAD_TAPS")) : 3;
+    // Layer 1: kernel P (bf16 pipe, exact products, conv1p.hip).  Layers 2, 3: kernel V (bf16 pipe, convw.hip) for batches it
+    // can cut into slabs, else kernel T (taps, f32 pipe; paired 8-byte loads on layer 2).
     hipStream_t s = as_stream(stream);
     int grid = wgrad_grid(images);      // workgroups launched
     int wparts = grid;                  // partials they write (weights and bias alike)
-    if (layer == 1 && s_wk != 3) {      // kernel P: one partial per wave
+    if (layer == 1) {                   // kernel P: one partial per wave
         wparts = grid * 4;
         const int rc = conv1p_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images, grid, s);
         if (rc) return rc;
-    } else if (layer == 1) {            // kernel R: one partial per wave; LDS = 4 waves x 2 slab buffers of 8 KiB
-        auto k = conv_wgrad_rows_kernel<GeomConv1>;
-        const size_t sm = 4 * 2 * 8192;
-        wparts = grid * 4;
-        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), sm);
-        if (e != hipSuccess) {
-            set_error("%s: hipFuncSetAttribute(%zu bytes of LDS): %s", fn, sm, hipGetErrorString(e));
-            return MI355PPO_EHIP;
-        }
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images);
     } else if (int vparts = 0; convw_launch(static_cast<const float*>(src), dz, part_w, part_b, images, layer, &vparts, s) != 1) {
         wparts = vparts;                // kernel V (bf16 pipe, convw.hip) took it: one partial per slab (an error surfaces in check_launch below)
     } else if (layer == 2) {            // kernel T: a workgroup walks image PAIRS
         wparts = grid = wgrad_grid((images + 1) / 2);
-        auto k5 = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 5>;
-        auto k8 = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 8>;
         auto kp = conv_wgrad_taps_kernel<GeomConv2, 2, 1, 5, true>;
-        hipLaunchKernelGGL(s_wt == 1 ? k5 : s_wt == 2 ? k8 : kp, dim3(grid), dim3(256), 0, s, static_cast<const float*>(src), dz, part_w, part_b, (int)images);
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(256), 0, s, static_cast<const float*>(src), dz, part_w, part_b, (int)images);
     } else {
         wparts = grid = wgrad_grid((images + 1) / 2);
         auto k = conv_wgrad_taps_kernel<GeomConv3, 3, 2, 6>;

@@ -282,15 +282,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 static int convw_slabs(int layer) { return layer == 2 ? 256 : 170; }      // x 4 / x 6 wave groups = 1,024 / 1,020 waves
 
-// Launches kernel V for layer 2 / 3 if the batch qualifies (a multiple of 16 images, large enough for every slab to have work);
-// *nparts = partials written (part_w [nparts][64 * K], part_b [nparts][64]).  Returns 1 if it does not apply.
-int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s) {
+// Kernel V takes a batch of layer 2 / 3 that is a multiple of 16 images, large enough for every slab to have work, with
+// tensors inside the 32-bit buffer range (MI355PPO_CONV_WGRAD=t: never -- kernel T, for A/B runs).
+bool convw_applies(int64_t images, int layer) {
     static const bool force_t = [] { const char* e = getenv("MI355PPO_CONV_WGRAD"); return e && e[0] == 't'; }();
+    if (force_t || (layer != 2 && layer != 3) || images <= 0) return false;
     const long long P = images * (layer == 2 ? 81 : 49);
+    return images % 16 == 0 && P / 16 >= 4LL * convw_slabs(layer) &&
+           images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4 < (1LL << 32) - 8192 && P * 64 * 4 < (1LL << 32) - 8192;
+}
+
+// Launches kernel V if the batch qualifies; *nparts = partials written (part_w [nparts][64 * K], part_b [nparts][64]).
+// Returns 1 if it does not apply.
+int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s) {
+    if (!convw_applies(images, layer)) return 1;
     const int S = convw_slabs(layer);
-    if (force_t || (layer != 2 && layer != 3) || images % 16 != 0 || P / 16 < 4LL * S ||
-        images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4 >= (1LL << 32) - 8192 || P * 64 * 4 >= (1LL << 32) - 8192)
-        return 1;
     *nparts = S;
     const int np = bf16_term_pairs();
     if (layer == 2) {

@@ -358,10 +358,22 @@ static int fcw_slabs(int M) {
 
 using namespace mi355ppo;
 
+// kernel W takes this layer's shape at minibatch sizes (MI355PPO_FC_WGRAD=y: never -- kernel Y, for A/B runs); the operands'
+// alignment is checked at the launch
+static bool fcw_w_shape(int M, int N, int K) {
+    static const bool force_y = [] { const char* e = getenv("MI355PPO_FC_WGRAD"); return e && e[0] == 'y'; }();
+    return !force_y && N == 4 * kWn && K % kWk == 0 && M % 16 == 0 && M >= 1024 && (long long)M * K * 4 < (1LL << 32) - 8192;
+}
+
 extern "C" MI355PPO_API size_t mi355ppo_fc_wgrad_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int slabs = fcw_slabs(M) > kWSlabs ? fcw_slabs(M) : kWSlabs;                     // kernel Y's or kernel W's slabs, whichever is more
+    const int slabs = (fcw_w_shape(M, N, K) && kWSlabs > fcw_slabs(M)) ? kWSlabs : fcw_slabs(M);   // kernel Y's or kernel W's slabs, whichever is more
     return (size_t)slabs * N * K * sizeof(float);
+}
+
+extern "C" MI355PPO_API int mi355ppo_fc_wgrad_kernel(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return fcw_w_shape(M, N, K) ? 'W' : 'Y';
 }
 
 extern "C" MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
@@ -380,10 +392,8 @@ extern "C" MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, con
                   "%s: dz must be 8-byte, a and the workspace 16-byte aligned", fn);
     hipStream_t s = as_stream(stream);
     float* part = static_cast<float*>(workspace);
-    // kernel W (bf16 pipe) for this layer's shape at minibatch sizes; kernel Y (f32 pipe) otherwise (MI355PPO_FC_WGRAD=y: always)
-    static const bool force_y = [] { const char* e = getenv("MI355PPO_FC_WGRAD"); return e && e[0] == 'y'; }();
-    if (!force_y && N == 4 * kWn && K % kWk == 0 && M % 16 == 0 && M >= 1024 && aligned(dz, 16) && lddz % 4 == 0 &&
-        (long long)M * K * 4 < (1LL << 32) - 8192) {
+    // kernel W (bf16 pipe) for this layer's shape at minibatch sizes; kernel Y (f32 pipe) otherwise
+    if (fcw_w_shape(M, N, K) && aligned(dz, 16) && lddz % 4 == 0) {
         const int nkb = K / kWk;
         if (bf16_term_pairs() == 9)
             hipLaunchKernelGGL((fcw_bf16_kernel<9>), dim3((unsigned)(nkb * kWSlabs)), dim3(256), 0, s, dz, lddz, a, part, M, N, K, nkb, 0xffff0000u, 0xffffff00u);

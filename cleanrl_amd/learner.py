@@ -208,9 +208,7 @@ class PPOLearner:
         bufs.weights(net[0].weight, 1, cnn.MODE_FWD_Q)
         bufs.weights(net[2].weight, 2, cnn.MODE_FWD)
         bufs.weights(net[4].weight, 3, cnn.MODE_FWD)
-        for layer, mode in cnn.extra_forward_modes():    # whatever else NatureTrunkFn.forward may ask for at a lane's batch size
-            bufs.weights(net[2 * layer - 2].weight, layer, mode)
-        cnn.warm_forward_packs(bufs, net)
+        cnn.warm_forward_packs(bufs, net)                # kernel Z's packs: what NatureTrunkFn.forward asks for at a lane's batch size
         bufs.fc_weight(net[7].weight)
 
     def _features(self, obs_rows):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 120 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 130 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2: round 3); a binding
                                   must check major AND minor (cleanrl_amd/_lib.py does) */
 
@@ -258,30 +258,20 @@ MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_
                            float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * FC   Linear(3136, 512) + ReLU of the NatureCNN (cleanrl/ppo_atari_multigpu.py:144-145) on the bf16 matrix pipe with
- * exact products (csrc/fcx.hip): every f32 operand is split in registers into three bf16 terms that sum to it exactly,
- * so the 3 x 3 term products are exact in f32 and nine bf16 MFMAs (f32 accumulate) do the work of eight f32 MFMAs in
- * 56 % of their matrix-pipe time.  Same arithmetic class as an f32-MFMA GEMM (exact products, f32 accumulation).
- *   fwd  : h (M,N) = relu(a (M,K) @ W (N,K)^T + bias (N))                      K % 16 == 0
- *   dgrad: da (M,N) = (dz (M,K) @ Wt (N,K)^T) * (act_in (M,N) > 0)   with Wt = W^T: the ReLU backward of the layer that
- *          produced act_in (conv3) is applied where the gradient is produced.  dz and Wt take leading dimensions
- *          (floats, multiples of 4): with K = 512 a dense row pitch is 2 KiB and the 32 rows of a fragment load would all
- *          fall on one cache channel -- callers pad the pitch (516).
- * All matrices row-major; a / h / da / act_in dense; a / dz / W / Wt 16-byte aligned. */
-MI355PPO_API int mi355ppo_fc_fwd_relu_f32(const float* a, const float* W, const float* bias, float* h, int M, int N, int K,
-                                          void* stream);
-MI355PPO_API int mi355ppo_fc_dgrad_mask_f32(const float* dz, int lddz, const float* Wt, int ldwt, const float* act_in, float* da,
-                                            int M, int N, int K, void* stream);
-
-/* Round 3 -- kernel Z (csrc/gemmz.hip), the same two GEMMs with the weight matrix split AHEAD (once per optimizer step) into
- * MFMA fragment order and the activations loaded coalesced through a wave-private LDS transposition: the per-lane row gather
- * of the entry points above kept the vector-memory front end 83 % busy and the matrix pipe 37 % busy.  The six largest of
- * the nine term pairs are multiplied (MI355PPO_BF16_PAIRS=9: all nine); the three dropped pairs are below the rounding of one
- * f32 multiply.
+ * FC   Linear(3136, 512) + ReLU of the NatureCNN (cleanrl/ppo_atari_multigpu.py:144-145) on the bf16 matrix pipe
+ * (kernel Z, csrc/gemmz.hip): every f32 operand is split into three bf16 terms that sum to it exactly, so products of terms
+ * are exact in f32 and bf16 MFMAs with f32 accumulation do the work of f32 MFMAs in a fraction of their matrix-pipe time.
+ * The six largest of the nine term pairs are multiplied (MI355PPO_BF16_PAIRS=9: all nine, every f32 product exact); the
+ * three dropped pairs are together below the rounding of one f32 multiply.  The weight matrix is split AHEAD (once per
+ * optimizer step) into MFMA fragment order (`pack`); the activations are loaded coalesced, transposed through wave-private
+ * LDS and split in registers.  (The first generation -- lane = row gathers of both operands, round 2's kernel X -- kept the
+ * vector-memory front end 83 % busy and the matrix pipe 37 % busy: profiles/r03_pmc_busy_kernels_x_c.csv.)
  *   pack  : B (N,K) f32 with leading dimension ldb -> mi355ppo_fc_pack_bytes(N, K) bytes, 16-byte aligned
  *   fwd   : h (M,N) = relu(a (M,K; lda) @ B^T + bias)         pack = pack(W  (N = 512,  K = 3136))
- *   dgrad : da (M,N) = (dz (M,K; lddz) @ B^T) * (act_in > 0)  pack = pack(Wt (N = 3136, K = 512))
- * K % 16 == 0; a / dz 16-byte aligned with leading dimensions that are multiples of 4 floats, below 4 GiB in all. */
+ *   dgrad : da (M,N) = (dz (M,K; lddz) @ B^T) * (act_in > 0)  pack = pack(Wt (N = 3136, K = 512)): the ReLU backward of the
+ *           layer that produced act_in (conv3) is applied where the gradient is produced
+ * All matrices row-major; h / da / act_in dense.  K % 16 == 0; a / dz 16-byte aligned with leading dimensions that are
+ * multiples of 4 floats, below 4 GiB in all. */
 MI355PPO_API size_t mi355ppo_fc_pack_bytes(int N, int K);
 MI355PPO_API int mi355ppo_fc_pack_f32(const float* B, int ldb, int N, int K, void* pack, void* stream);
 MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
@@ -302,12 +292,14 @@ MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, const void* 
 MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, const void* pack, const float* act_in, float* dsrc,
                                                     int64_t images, int layer, void* stream);
 
-/* FC weight gradient (csrc/fcw.hip, f32 matrix pipe): dW (N,K) = dz (M,N)^T @ a (M,K), the batch cut into slabs whose
- * partials are added in a fixed order (deterministic).  dz takes a leading dimension (even); a is dense.  N % 64 == 0,
+/* FC weight gradient (csrc/fcw.hip): dW (N,K) = dz (M,N)^T @ a (M,K), the batch cut into slabs whose partials are added in a
+ * fixed order (deterministic).  Kernel W (bf16 pipe, both operands transposed through LDS and split in registers) when
+ * N == 512, K % 64 == 0, M % 16 == 0 and M >= 1024; kernel Y (f32 matrix pipe) otherwise.  dz takes a leading dimension (even); a is dense.  N % 64 == 0,
  * K % 224 == 0 (whole 64 x 224 wave tiles: 512 x 3136 = 8 x 14 of them); dz 8-byte, a and the workspace 16-byte aligned.
  * hwc_channels = C > 0: the columns of a are features in (h, w, c) order with C channels (the trunk's layout) and dW is
  * written in the reference's (c, h, w) order, i.e. directly as the gradient of Linear(3136,512).weight; 0: as computed. */
 MI355PPO_API size_t mi355ppo_fc_wgrad_workspace_bytes(int M, int N, int K);
+MI355PPO_API int mi355ppo_fc_wgrad_kernel(int M, int N, int K);      /* 'W' or 'Y': the kernel a call of this shape runs (profiling aid) */
 MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
                                        void* workspace, size_t workspace_bytes, void* stream);
 
@@ -334,10 +326,6 @@ MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a
  *           fixed-point number on its output channel's scale, four signed radix-256 digits in the operand
  *           layout of v_mfma_i32_32x32x32_i8, + accumulator start values + per-channel scales;
  *           mi355ppo_cnn_conv1q_pack_bytes() = 33,408 bytes.  Consumed by forward variant 6.
- *   mode 6  layers 2 and 3: the weights split into their three bf16 term planes (hi + mid + lo = the f32 weight,
- *           exactly) in the fragment order of kernel C (csrc/convx.hip): [(kh,kw,cin) / 16][Cout / 32][term][64 lanes]
- *           [8 bf16]; Cout*Cin*KH*KW*6 bytes = 49,152 / 55,296 floats of storage.  Consumed by forward variant 7
- *           (layers 2 / 3 on the bf16 matrix pipe with exact products: the minibatch-sized forward).
  * modes 0-2 have Cout*Cin*KH*KW floats.
  */
 MI355PPO_API int mi355ppo_cnn_repack_weights_f32(const float* W, float* Bt, int layer, int mode, void* stream);
@@ -385,8 +373,13 @@ MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32_variant(const float* dz, const floa
 
 /* dW (torch layout (Cout,Cin,KH,KW)) and db (Cout) from the layer input `src` (layer 1: uint8 + inds
  * as above) and the pre-activation gradient dz (images, Hout, Wout, Cout).  Overwrites dW / db.
- * Deterministic: per-workgroup partials in `workspace`, summed in a fixed order. */
+ * Deterministic: per-workgroup partials in `workspace`, summed in a fixed order.
+ * Layer 1: kernel P (csrc/conv1p.hip; bf16 pipe: the uint8 taps are exact bf16 operands, dz is split into three bf16 terms).
+ * Layers 2, 3: kernel V (csrc/convw.hip; bf16 pipe, both operands transposed through LDS and split in registers, the batch
+ * cut into slabs) for batches of a multiple of 16 images with every tensor below 4 GiB; kernel T (f32 pipe, csrc/conv.hip)
+ * otherwise.  mi355ppo_cnn_conv_wgrad_kernel: 'P', 'V' or 'T', the kernel a call of this size runs (profiling aid). */
 MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t images, int layer);
+MI355PPO_API int mi355ppo_cnn_conv_wgrad_kernel(int64_t images, int layer);
 MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW, float* db,
                                              int64_t images, int layer, void* workspace, size_t workspace_bytes,
                                              void* stream);

@@ -471,9 +471,9 @@ class FakeCnn:
 
         cin, cout, k, _, _, _ = cnn.LAYERS[layer]
         _chk(W, torch.float32, f"W{layer}", (cout, cin, k, k))
-        assert (layer, mode) in ((1, 0), (1, 4), (2, 0), (3, 0), (3, 1), (2, 2), (3, 3), (2, 5), (2, 6), (3, 6))
+        assert (layer, mode) in ((1, 0), (1, 4), (2, 0), (3, 0), (3, 1), (2, 2), (3, 3), (2, 5))
         numel = (cnn.BT_CLASSES_NUMEL if mode == 3 else cnn.QPACK_NUMEL if mode == 4 else cnn.BT2_CLASSES_NUMEL if mode == 5
-                 else cnn.xpack_numel(layer) if mode == 6 else W.numel())
+                 else W.numel())
         if out is None:
             out = torch.empty(numel)
         _chk(out, torch.float32, "Bt", (numel,))
@@ -490,8 +490,8 @@ class FakeCnn:
         from cleanrl_amd import cnn
 
         cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
-        assert variant in (0, cnn.VARIANT_Q, cnn.VARIANT_X) and (variant == 0 or (layer == 1) == (variant == cnn.VARIANT_Q))
-        W = self._w(Bt, layer, (4,) if variant == cnn.VARIANT_Q else (6,) if variant == cnn.VARIANT_X else (0,))      # the pack and the kernel must belong together
+        assert variant in (0, cnn.VARIANT_Q) and (variant == 0 or layer == 1)
+        W = self._w(Bt, layer, (4,) if variant == cnn.VARIANT_Q else (0,))      # the pack and the kernel must belong together
         x = src if inds is None else src[inds]
         if layer == 1:
             _chk(src, torch.uint8, "src")

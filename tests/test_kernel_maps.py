@@ -75,38 +75,6 @@ def test_kernel_T_index_maps_give_the_weight_gradient(layer, pair_loads, images)
     assert np.abs(got - ref.numpy()).max() <= 1e-9 * np.abs(ref.numpy()).max()
 
 
-def test_kernel_R_index_maps_give_the_layer1_weight_gradient():
-    """``conv_wgrad_rows_kernel`` (kernel R): wave w owns output rows 5w..5w+4; lane (li, lh) supplies, for pixel 2j + lh of a
-    row, the packed dword of tap row li/8 (+4 for the second dword), tap columns-with-channels 4(li%8)..+3; tile 4h + c holds
-    byte c of dword h.  Emulated on uint8 frames; the 1/255 is applied to the reduced sum, as the reduce kernel does."""
-    rs = np.random.RandomState(5)
-    images = 2
-    frames = rs.randint(0, 256, size=(images, 84, 84, 4)).astype(np.float64)          # (H, W, C) rows of the rollout buffer
-    dz = rs.standard_normal((images, 20, 20, 32))
-    li = np.arange(32)
-    dWt = np.zeros((32, 256))                                                          # [cout][(kh, kw, c)]
-    for wave in range(4):
-        acc = np.zeros((8, 32, 32))
-        for img in range(images):
-            flat = frames[img].reshape(84, 84 * 4)                                     # a source row = 336 bytes
-            for r in range(5):
-                gy = 5 * wave + r
-                for j in range(10):
-                    a = np.stack([dz[img, gy, 2 * j + lh, li] for lh in range(2)], axis=1)          # (32, 2)
-                    for h in range(2):                                                 # dword h: tap rows li/8 + 4h
-                        for c in range(4):                                             # byte c of the dword
-                            b = np.stack([flat[4 * gy + (li >> 3) + 4 * h, 16 * (2 * j + lh) + 4 * (li & 7) + c] for lh in range(2)])
-                            acc[4 * h + c] += a @ b
-        for t in range(8):
-            kcol = ((li >> 3) + 4 * (t >> 2)) * 32 + 4 * (li & 7) + (t & 3)
-            dWt[:, kcol] += acc[t]
-    got = (dWt / 255.0).reshape(32, 8, 8, 4).transpose(0, 3, 1, 2)
-    x = torch.from_numpy(frames / 255.0).permute(0, 3, 1, 2)
-    W = torch.zeros(32, 4, 8, 8, dtype=torch.float64, requires_grad=True)
-    (ref,) = torch.autograd.grad(F.conv2d(x, W, None, stride=4), W, torch.from_numpy(dz).permute(0, 3, 1, 2))
-    assert np.abs(got - ref.numpy()).max() <= 1e-9 * np.abs(ref.numpy()).max()
-
-
 # ---------------------------------------------------------------------------------------------------------------------
 # Kernel P (cleanrl_amd/csrc/conv1p.hip): layer-1 weight gradient on the bf16 pipe.  Index maps restated: the transposed
 # LDS staging (4-chunk quads + the q = 20 chunk), the 15 pixel groups -> 8 steps, the dz window / slot mapping of the

@@ -82,17 +82,13 @@ int main(int argc, char** argv) {
     ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3, 3, 0, st)); ABI(mi355ppo_cnn_repack_weights_f32(W2, bt2d, 2, 2, st));
     ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3d, 3, 1, st)); ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3c, 3, 3, st));
     ABI(mi355ppo_cnn_repack_weights_f32(W1, bt1q, 1, 4, st)); ABI(mi355ppo_cnn_repack_weights_f32(W2, bt2c, 2, 5, st));
-    float *bt2x = dalloc<float>(49152), *bt3x = dalloc<float>(55296);                                   // kernel C packs (mode 6)
-    ABI(mi355ppo_cnn_repack_weights_f32(W2, bt2x, 2, 6, st)); ABI(mi355ppo_cnn_repack_weights_f32(W3, bt3x, 3, 6, st));
     // kernel Z (round 3): the FC weight and its transpose pre-split into fragment order
-    const bool fc_x = getenv("CONV_TRAFFIC_FC_X") != nullptr;                                          // FC forward / data gradient on kernel X
     void *pk_fwd, *pk_dg;
     CHECK(hipMalloc(&pk_fwd, mi355ppo_fc_pack_bytes(512, 3136))); CHECK(hipMalloc(&pk_dg, mi355ppo_fc_pack_bytes(3136, 512)));
-    const bool conv_z = getenv("CONV_TRAFFIC_CONV_Z") != nullptr;                                      // layers 2 / 3 forward + data gradients on kernel Z
+    const bool conv_z = getenv("CONV_TRAFFIC_CONV_F") == nullptr;      // layers 2 / 3 forward + data gradients: kernel Z (the learner's default) or, for A/B runs, kernel F
     void *pz2, *pz3, *pzd2, *pzd3;
     CHECK(hipMalloc(&pz2, mi355ppo_fc_pack_bytes(64, 512))); CHECK(hipMalloc(&pz3, mi355ppo_fc_pack_bytes(64, 576)));
     CHECK(hipMalloc(&pzd2, mi355ppo_fc_pack_bytes(128, 256))); CHECK(hipMalloc(&pzd3, mi355ppo_fc_pack_bytes(64, 576)));
-    const bool fwd_f32 = getenv("CONV_TRAFFIC_FWD_F32") != nullptr;                                    // layers 2 / 3 forward on kernel F
     fill_f32<<<4096, 256, 0, st>>>(Wfc, 512 * 3136, 10u); fill_f32<<<4096, 256, 0, st>>>(Wfct, 3136 * 516, 11u);
     fill_f32<<<4096, 256, 0, st>>>(dzfc, (size_t)M * 516, 12u);
     ABI(mi355ppo_fc_pack_f32(bt2, 512, 64, 512, pz2, st)); ABI(mi355ppo_fc_pack_f32(bt3, 576, 64, 576, pz3, st));
@@ -115,21 +111,13 @@ int main(int argc, char** argv) {
         if (conv_z) {
             TIMED(1, mi355ppo_cnn_conv_fwd_packed_f32(a1, pz2, bias, a2, M, 2, st));                  // kernel Z
             TIMED(2, mi355ppo_cnn_conv_fwd_packed_f32(a2, pz3, bias, a3, M, 3, st));
-        } else if (fwd_f32) {
-            TIMED(1, mi355ppo_cnn_conv_fwd_f32(a1, nullptr, bt2, bias, a2, M, 2, st));
+        } else {
+            TIMED(1, mi355ppo_cnn_conv_fwd_f32(a1, nullptr, bt2, bias, a2, M, 2, st));                // kernel F
             TIMED(2, mi355ppo_cnn_conv_fwd_f32(a2, nullptr, bt3, bias, a3, M, 3, st));
-        } else {
-            TIMED(1, mi355ppo_cnn_conv_fwd_f32_variant(a1, nullptr, bt2x, bias, a2, M, 2, 7, st));    // kernel C
-            TIMED(2, mi355ppo_cnn_conv_fwd_f32_variant(a2, nullptr, bt3x, bias, a3, M, 3, 7, st));
         }
-        if (fc_x) {
-            TIMED(8, mi355ppo_fc_fwd_relu_f32(a3, Wfc, bias, hfc, (int)M, 512, 3136, st));               // kernel X forward
-            TIMED(9, mi355ppo_fc_dgrad_mask_f32(dzfc, 516, Wfct, 516, a3, dz3, (int)M, 3136, 512, st)); // kernel X data gradient + (a3 > 0)
-        } else {
-            TIMED(8, mi355ppo_fc_fwd_relu_packed_f32(a3, 3136, pk_fwd, bias, hfc, (int)M, 512, 3136, st));        // kernel Z forward
-            TIMED(9, mi355ppo_fc_dgrad_mask_packed_f32(dzfc, 516, pk_dg, a3, dz3, (int)M, 3136, 512, st));        // kernel Z data gradient + (a3 > 0)
-        }
-        TIMED(10, mi355ppo_fc_wgrad_f32(dzfc, 516, a3, dWfc, (int)M, 512, 3136, 64, wsfc, wsfcb, st));  // kernel Y + its slab reduction
+        TIMED(8, mi355ppo_fc_fwd_relu_packed_f32(a3, 3136, pk_fwd, bias, hfc, (int)M, 512, 3136, st));        // kernel Z forward
+        TIMED(9, mi355ppo_fc_dgrad_mask_packed_f32(dzfc, 516, pk_dg, a3, dz3, (int)M, 3136, 512, st));        // kernel Z data gradient + (a3 > 0)
+        TIMED(10, mi355ppo_fc_wgrad_f32(dzfc, 516, a3, dWfc, (int)M, 512, 3136, 64, wsfc, wsfcb, st));  // kernel W + its slab reduction
         TIMED(3, mi355ppo_cnn_conv_wgrad_f32(a2, nullptr, dz3, dW3, db3, M, 3, ws, wsb, st));
         if (conv_z) TIMED(4, mi355ppo_cnn_conv_dgrad_packed_f32(dz3, pzd3, a2, dz2, M, 3, st));
         else TIMED(4, mi355ppo_cnn_conv_dgrad_f32_variant(dz3, bt3c, a2, dz2, M, 3, 5, st));
