@@ -20,9 +20,11 @@
 // multiplied on `v_mfma_f32_32x32x16_bf16` with f32 accumulation; the three dropped pairs are below the rounding of one f32
 // multiply.  MI355PPO_BF16_PAIRS=9 multiplies all nine (exact products).
 //
-// A wave owns (32 MT) rows x (32 NT) columns of C.  FC and the layer-2 data gradient (N = 128): MT 2 x NT 4 = 128 accumulator
-// registers, one wave per SIMD; the N = 64 convolutions: MT 2 x NT 2 = 64 accumulator registers, two waves per SIMD (the
-// partner's MFMAs run under a wave's prologue / epilogue: these problems have K = 512 .. 576 only).
+// A wave owns (32 MT) rows x (32 NT) columns of C.  FC at minibatch size: MT 2 x NT 4 = 128 accumulator registers, one wave per
+// SIMD; the convolutions (K = 256 .. 576 only) and the FC forward of smaller batches: MT 2 x NT 2 = 64 accumulator registers and
+// about 200 VGPRs, two waves per SIMD from two DIFFERENT 4-wave workgroups per CU -- started at different times, so one wave's
+// prologue / epilogue falls under the other's MFMAs (8-wave workgroups ran their two waves per SIMD in phase: 2 - 5 % slower,
+// profiles/r03_zcfg_ab.jsonl).
 #include "common.h"
 #include "bf16split.h"
 #include <type_traits>
@@ -105,8 +107,9 @@ struct ZArgs {
 
 // WAVES_N: the waves of a workgroup sit side by side (they read the same A rows) instead of on top of each other (they stream
 // the same B fragments).
-template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int NP>
-__global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4))) void z_kernel(ZArgs a) {
+// OCC: waves per SIMD the kernel is compiled for (of one workgroup or of several per CU).
+template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int NP, int OCC>
+__global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void z_kernel(ZArgs a) {
     constexpr int ROWS = 32 * MT, LOADS = ROWS / 16;
     __shared__ __attribute__((aligned(16))) float lds[NWAVES * ROWS * kZPitch];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -317,14 +320,14 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     unsigned coff[NT];                                    // byte offset of this lane's column in tile j (out of range past N)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        if constexpr (EPI == Z_MASK_CLS4) coff[j] = (unsigned)(((j >> 1) * RG::DW + (j & 1)) * RG::DC + li) * 4u;
+        if constexpr (EPI == Z_MASK_CLS4) coff[j] = (unsigned)((((j0 + j) >> 1) * RG::DW + ((j0 + j) & 1)) * RG::DC + li) * 4u;
         else coff[j] = n0 + 32 * j + li < N ? (unsigned)(n0 + 32 * j + li) * 4u : kZOob;
     }
     auto at = [&](unsigned ro, int j) -> unsigned { return (ro == kZOob || coff[j] == kZOob) ? kZOob : ro + coff[j]; };
     if constexpr (EPI != Z_BIAS_RELU) {
         // The mask values are requested before the first one is used -- of the wave's whole block with one wave per SIMD (nothing
         // else hides a load's latency there), of one 32-row tile at a time with two waves per SIMD (registers).
-        constexpr int IB = NWAVES == 4 ? MT : 1;                                    // 32-row tiles per batch
+        constexpr int IB = OCC == 1 ? MT : 1;                                       // 32-row tiles per batch
 #pragma unroll
         for (int i0 = 0; i0 < MT; i0 += IB) {
             unsigned mk[IB][NT][16];
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWA
     }
 }
 
-template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N>
+template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int OCC = NWAVES / 4>
 static int z_launch(const ZArgs& a, hipStream_t s, const char* what) {
     const long long row_blocks = (a.M + 32 * MT - 1) / (32 * MT), col_blocks = (a.N + 32 * NT - 1) / (32 * NT);
     const dim3 grid = WAVES_N ? dim3((unsigned)((col_blocks + NWAVES - 1) / NWAVES), (unsigned)row_blocks)
@@ -380,9 +383,9 @@ static int z_launch(const ZArgs& a, hipStream_t s, const char* what) {
         return MI355PPO_EINVAL;
     }
     if (bf16_term_pairs() == 9)
-        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 9>), grid, dim3(64 * NWAVES), 0, s, a);
+        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 9, OCC>), grid, dim3(64 * NWAVES), 0, s, a);
     else
-        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 6>), grid, dim3(64 * NWAVES), 0, s, a);
+        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 6, OCC>), grid, dim3(64 * NWAVES), 0, s, a);
     return check_launch(what);
 }
 
@@ -432,8 +435,12 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int 
     int rc = zgemm_check(fn, a, pack, h, M, N, K, lda, N);
     if (rc) return rc;
     MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
-    return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, h, (long long)M * N * 4, N, M, N, K),
-                                                             as_stream(stream), fn);
+    const ZArgs za = zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, h, (long long)M * N * 4, N, M, N, K);
+    // 64 x 128 wave tiles, one wave per SIMD, for the large batches; below 16,384 rows those do not fill the chip (M / 64 workgroups):
+    // 64 x 64 wave tiles, two 4-wave workgroups per CU (measured on one box, profiles/r03_zcfg_ab.jsonl: 32,768 rows 471 vs 531 us,
+    // 8,192 rows 205 vs 145 us, 4,096 rows 182 vs 128 us)
+    if (M < 16384) return z_launch<ZRowsLinear, 2, 2, 4, Z_BIAS_RELU, true, 2>(za, as_stream(stream), fn);
+    return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(za, as_stream(stream), fn);
 }
 
 extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, int lddz, const void* pack, const float* act_in, float* da,
@@ -442,8 +449,8 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, i
     int rc = zgemm_check(fn, dz, pack, da, M, N, K, lddz, N);
     if (rc) return rc;
     MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
-    return z_launch<ZRowsLinear, 2, 4, 4, Z_MASK, false>(zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, (long long)M * N * 4, N, M, N, K),
-                                                         as_stream(stream), fn);
+    const ZArgs za = zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, (long long)M * N * 4, N, M, N, K);
+    return z_launch<ZRowsLinear, 2, 4, 4, Z_MASK, false>(za, as_stream(stream), fn);
 }
 
 // ---- convolutions of layers 2 and 3 on kernel Z.  `pack` = mi355ppo_fc_pack_f32 of the layer's (N, K) f32 matrix from
@@ -459,11 +466,12 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, c
     MI355_REQUIRE(aligned(src, 16) && aligned(pack, 16) && aligned(dst, 16) && aligned(bias, 4), MI355PPO_EALIGN, "%s: src / pack / dst must be 16-byte aligned", fn);
     const long long srcb = (long long)images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4;
     MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: the source (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);   // (the destination is smaller)
-    if (layer == 2)
-        return z_launch<ZConv2, 2, 2, 8, Z_BIAS_RELU, false>(zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K),
-                                                             as_stream(stream), fn);
-    return z_launch<ZConv3, 2, 2, 8, Z_BIAS_RELU, false>(zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K),
-                                                         as_stream(stream), fn);
+    if (layer == 2) {
+        const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K);
+        return z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
+    }
+    const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
+    return z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
 }
 
 extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, const void* pack, const float* act_in, float* dsrc,
@@ -479,10 +487,11 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, 
     const long long dstb = (long long)images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4;
     MI355_REQUIRE(srcb < (1LL << 32) - 8192 && dstb < (1LL << 32) - 8192, MI355PPO_EINVAL,
                   "%s: dz (%lld bytes) and dsrc (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb, dstb);
-    if (layer == 3)        // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
-        return z_launch<ZDgrad3, 2, 2, 8, Z_MASK, false>(zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K),
-                                                         as_stream(stream), fn);
+    if (layer == 3) {      // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
+        const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K);
+        return z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, as_stream(stream), fn);
+    }
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
-    return z_launch<ZDgrad2, 2, 4, 4, Z_MASK_CLS4, false>(zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K),
-                                                          as_stream(stream), fn);
+    const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K);
+    return z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2>(za, as_stream(stream), fn);
 }
