@@ -70,16 +70,42 @@ constexpr int z_item_at(int g, int items, int span) {
 // ---- row geometries: where row m of A starts, and where k-step s sits relative to that ----------------------------------
 // GEMM rows: row m at m * lda floats, k-step s at 16 s floats.
 struct ZRowsLinear {
-    static constexpr bool CONV = false, PAD = false;
+    static constexpr bool CONV = false, PAD = false, CLS = false;
     static constexpr int K = 0, SPR = 1, PITCHB = 0, PER_IMG = 1, GX = 1, S = 1, OFF = 0, H = 1, W = 1, C = 16, KH = 1, KW = 1, DH = 1, DW = 1,
                          DC = 1, DM = 1;
 };
 // Convolution rows (FixedGeom's parameters, conv.hip): source (images, H, W, C), window KH x KW, grid GY x GX per image with
 // stride S and origin offset OFF (negative: zero padding); destination (images, DH, DW, DC), grid pixel -> destination pixel
 // (gy * DM, gx * DM) (+ the class offset of Z_MASK_CLS4).
-template <int H_, int W_, int C_, int KH_, int KW_, int GY_, int GX_, int S_, int OFF_, int DH_, int DW_, int DC_, int DM_>
+//
+// Border classes (AX, the data gradients): a grid coordinate g reaches taps t with 0 <= g * S + OFF + t < extent only.  The
+// coordinates with the same valid tap range [T0, T1) form a class (G0 .. G0 + NG - 1); a (row class, column class) pair is a
+// border class of the grid.  With AX the rows of the GEMM are ordered class by class -- row r of class (cy, cx) = image
+// r / (NG[cy] NG[cx]), pixel r % (NG[cy] NG[cx]) of the class's rectangle -- so that a wave's 64 rows share ONE valid tap
+// window and the k-loop runs over the valid taps only: no MFMA multiplies a padding zero (the layer-3 data gradient's padded
+// windows hold 1.65 x its valid taps, the layer-2 one's 1.23 x).
+struct ZAxisDgrad3 {        // 9 positions, 3 taps, origin offset -2, source extent 7
+    static constexpr int NC = 5, G0[5] = {0, 1, 2, 7, 8}, NG[5] = {1, 1, 5, 1, 1}, T0[5] = {2, 1, 0, 0, 0}, T1[5] = {3, 3, 3, 2, 1};
+};
+struct ZAxisDgrad2 {        // 10 positions, 2 taps, origin offset -1, source extent 9
+    static constexpr int NC = 3, G0[3] = {0, 1, 9}, NG[3] = {1, 8, 1}, T0[3] = {1, 0, 0}, T1[3] = {2, 2, 1};
+};
+template <class AX>
+constexpr bool z_axis_ok(int G, int KT, int S, int OFF, int EXT) {      // the tables above against the definition
+    int covered = 0;
+    for (int c = 0; c < AX::NC; ++c)
+        for (int g = AX::G0[c]; g < AX::G0[c] + AX::NG[c]; ++g, ++covered)
+            for (int t = 0; t < KT; ++t)
+                if ((g * S + OFF + t >= 0 && g * S + OFF + t < EXT) != (t >= AX::T0[c] && t < AX::T1[c])) return false;
+    return covered == G;
+}
+struct ZNoAxis {};
+
+template <int H_, int W_, int C_, int KH_, int KW_, int GY_, int GX_, int S_, int OFF_, int DH_, int DW_, int DC_, int DM_, class AX_ = ZNoAxis>
 struct ZRowsConv {
-    static constexpr bool CONV = true, PAD = OFF_ < 0;
+    using AX = AX_;
+    static constexpr bool CLS = !std::is_same_v<AX_, ZNoAxis>;
+    static constexpr bool CONV = true, PAD = OFF_ < 0 && !CLS;
     static constexpr int H = H_, W = W_, C = C_, KH = KH_, KW = KW_, GY = GY_, GX = GX_, S = S_, OFF = OFF_, DH = DH_, DW = DW_,
                          DC = DC_, DM = DM_;
     static constexpr int RUN = KW * C, SPR = RUN / 16, K = KH * RUN, PITCHB = W * C * 4, PER_IMG = GY * GX;
@@ -87,8 +113,32 @@ struct ZRowsConv {
 };
 using ZConv2 = ZRowsConv<20, 20, 32, 4, 4, 9, 9, 2, 0, 9, 9, 64, 1>;
 using ZConv3 = ZRowsConv<9, 9, 64, 3, 3, 7, 7, 1, 0, 7, 7, 64, 1>;
-using ZDgrad3 = ZRowsConv<7, 7, 64, 3, 3, 9, 9, 1, -2, 9, 9, 64, 1>;        // source = dz3, destination = da2
-using ZDgrad2 = ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1, 20, 20, 32, 2>;    // source = dz2, destination = da1 (4 parity classes = 4 column tiles)
+using ZDgrad3 = ZRowsConv<7, 7, 64, 3, 3, 9, 9, 1, -2, 9, 9, 64, 1, ZAxisDgrad3>;        // source = dz3, destination = da2
+using ZDgrad2 = ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1, 20, 20, 32, 2, ZAxisDgrad2>;    // source = dz2, destination = da1 (4 parity classes = 4 column tiles)
+static_assert(z_axis_ok<ZAxisDgrad3>(9, 3, 1, -2, 7) && z_axis_ok<ZAxisDgrad2>(10, 2, 1, -1, 9), "border-class tables");
+
+// Border classes of a grid in the order the kernel walks them: heaviest first (pixels x valid taps), so that the short tiles
+// of the corner classes fill the tail of the launch.
+template <class AX>
+struct ZClassOrder {
+    int c[AX::NC * AX::NC];
+    constexpr ZClassOrder() : c{} {
+        constexpr int n = AX::NC * AX::NC;
+        auto weight = [](int k) { return AX::NG[k / AX::NC] * AX::NG[k % AX::NC] * (AX::T1[k / AX::NC] - AX::T0[k / AX::NC]) * (AX::T1[k % AX::NC] - AX::T0[k % AX::NC]); };
+        for (int i = 0; i < n; ++i) c[i] = i;
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j)
+                if (weight(c[j]) > weight(c[i])) { const int t = c[i]; c[i] = c[j]; c[j] = t; }
+    }
+};
+// 64-row wave tiles of a class-ordered launch
+template <class RG>
+static long long z_class_tiles(long long images, int rows) {
+    long long t = 0;
+    for (int cy = 0; cy < RG::AX::NC; ++cy)
+        for (int cx = 0; cx < RG::AX::NC; ++cx) t += (images * RG::AX::NG[cy] * RG::AX::NG[cx] + rows - 1) / rows;
+    return t;
+}
 
 struct ZArgs {
     const void* A;              // source tensor
@@ -101,6 +151,7 @@ struct ZArgs {
     unsigned c_bytes;           // size of C (and of the mask, which has C's shape): buffer range check
     int ldc;                    // GEMM rows: leading dimension of C; convolution rows: unused (DC)
     long long M;                // rows: matrix rows, or images * GY * GX
+    long long images;           // convolution rows: images
     int N, K;
     unsigned m8, m16;           // 0xffff0000, 0xffffff00: in SGPRs (as literals every v_and would be an 8-byte instruction)
 };
@@ -112,13 +163,48 @@ template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int NP, i
 __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void z_kernel(ZArgs a) {
     constexpr int ROWS = 32 * MT, LOADS = ROWS / 16;
     __shared__ __attribute__((aligned(16))) float lds[NWAVES * ROWS * kZPitch];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // (the wave index in an SGPR)
     const int li = lane & 31, lh = lane >> 5;
-    const long long M = a.M;
     const int N = a.N;
-    const long long m0 = WAVES_N ? (long long)blockIdx.y * ROWS : ((long long)blockIdx.y * NWAVES + wave) * ROWS;
     const int n0 = WAVES_N ? (blockIdx.x * NWAVES + wave) * (32 * NT) : blockIdx.x * (32 * NT);
+    long long wtile = WAVES_N ? (long long)blockIdx.y : (long long)blockIdx.y * NWAVES + wave;        // this wave's row tile
+    // border classes: which class the tile belongs to (wave-uniform), its pixel rectangle and its valid tap window
+    int c_gy0 = 0, c_gx0 = 0, c_nx = 1, c_npix = 1, c_ty0 = 0, c_nty = 1, c_us0 = 0, c_spr = 1;
+    unsigned c_mg_npix = 0, c_mg_nx = 0;                  // reciprocals for r / npix, p / nx (exact for r * d < 2^32)
+    long long Mrows = a.M;
+    if constexpr (RG::CLS) {
+        using AX = typename RG::AX;
+        constexpr ZClassOrder<AX> ord{};
+        const long long images = a.images;
+        int cls = -1;
+        for (int i = 0; i < AX::NC * AX::NC; ++i) {
+            const int c = ord.c[i];
+            const long long t = (images * (AX::NG[c / AX::NC] * AX::NG[c % AX::NC]) + ROWS - 1) / ROWS;
+            if (wtile < t) { cls = c; break; }
+            wtile -= t;
+        }
+        if (cls < 0) return;
+        const int cy = cls / AX::NC, cx = cls % AX::NC;
+        c_gy0 = AX::G0[cy]; c_gx0 = AX::G0[cx]; c_nx = AX::NG[cx]; c_npix = AX::NG[cy] * c_nx;
+        c_ty0 = AX::T0[cy]; c_nty = AX::T1[cy] - c_ty0;
+        c_us0 = AX::T0[cx] * (RG::C / 16); c_spr = (AX::T1[cx] - AX::T0[cx]) * (RG::C / 16);
+        c_mg_npix = c_npix > 1 ? (unsigned)((1ull << 32) / (unsigned)c_npix + 1) : 0u;
+        c_mg_nx = c_nx > 1 ? (unsigned)((1ull << 32) / (unsigned)c_nx + 1) : 0u;
+        Mrows = images * c_npix;
+    }
+    const long long M = Mrows;
+    const long long m0 = wtile * ROWS;
     if (m0 >= M || n0 >= N) return;                       // (whole wave; no barriers in this kernel)
+    // class row r -> (image, grid y, grid x)
+    auto cls_pixel = [&](unsigned r, unsigned& img, int& gy, int& gx) {          // (selects, no branches: d == 1 has no 32-bit reciprocal)
+        const unsigned q = __umulhi(r, c_mg_npix);
+        img = c_npix > 1 ? q : r;
+        const unsigned p = r - img * (unsigned)c_npix;
+        const unsigned q2 = __umulhi(p, c_mg_nx);
+        const unsigned py = c_nx > 1 ? q2 : p;
+        gy = c_gy0 + (int)py;
+        gx = c_gx0 + (int)(p - py * (unsigned)c_nx);
+    };
     const int ntiles = (N + 31) / 32, j0 = n0 / 32;
     float* const wl = lds + wave * (ROWS * kZPitch);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)a.a_bytes, kZRsrcWord3);
@@ -130,8 +216,16 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         const long long r = m0 + 16 * u + (lane >> 2);
         const long long rc = r < M ? r : M - 1;           // rows past M re-read the last row: their results are dropped at the store
         if constexpr (RG::CONV) {
-            const unsigned img = (unsigned)(rc / RG::PER_IMG), rem = (unsigned)(rc - (long long)img * RG::PER_IMG);
-            const int gy = (int)(rem / RG::GX), gx = (int)(rem - (rem / RG::GX) * RG::GX);
+            unsigned img;
+            int gy, gx;
+            if constexpr (RG::CLS) {
+                cls_pixel((unsigned)rc, img, gy, gx);
+            } else {
+                img = (unsigned)(rc / RG::PER_IMG);
+                const unsigned rem = (unsigned)(rc - (long long)img * RG::PER_IMG);
+                gy = (int)(rem / RG::GX);
+                gx = (int)(rem - (rem / RG::GX) * RG::GX);
+            }
             const int sy0 = gy * RG::S + RG::OFF, sx0 = gx * RG::S + RG::OFF;
             voff[u] = (unsigned)((((int)img * RG::H + sy0) * RG::W + sx0) * RG::C * 4) + 16u * (unsigned)(lane & 3);   // may wrap for PAD taps
             unsigned m = 0u;
@@ -166,11 +260,26 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     s_u32x4 raw[MT][2];                                   // fragments of the NEXT k-step as read back from LDS (f32, lane = row)
     unsigned ta[2][MT][3][4];                             // split A fragments: [k-step parity][fragment][term][4 x 2 bf16]
     s_u32x4 tb[2][NT][3];                                 // B fragments straight from the pack
-    const int nsteps = RG::CONV ? RG::K / 16 : a.K >> 4;
+    const int nsteps = RG::CLS ? c_nty * c_spr : RG::CONV ? RG::K / 16 : a.K >> 4;
     auto kclamp = [&](int s) { return s < nsteps ? s : nsteps - 1; };                // past the end: re-read, never multiplied
-    auto load_a = [&](int s) {
+    // border classes: the k-steps of a tile are the chunks us0 .. us0 + spr - 1 of tap rows ty0 .. ty0 + nty - 1; the loads of A
+    // and of B each walk them with their own cursor (the loads are issued in step order; past the end a cursor stays put)
+    struct Cursor { int n, ty, us; };
+    Cursor ca{0, c_ty0, c_us0}, cb{0, c_ty0, c_us0};
+    auto advance = [&](Cursor& c) {
+        if (c.n + 1 < nsteps) {
+            ++c.n;
+            if (++c.us == c_us0 + c_spr) { c.us = c_us0; ++c.ty; }
+        }
+    };
+    auto load_a_into = [&](s_u32x4 (&stage)[LOADS], int s) {
         const int sc = kclamp(s);
-        if constexpr (RG::CONV) {
+        if constexpr (RG::CLS) {
+            const unsigned off = (unsigned)(ca.ty * RG::PITCHB + ca.us * 64);       // every tap of the class window is valid for every row
+#pragma unroll
+            for (int u = 0; u < LOADS; ++u) stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[u] + off, 0, 0));
+            advance(ca);
+        } else if constexpr (RG::CONV) {
             const int ty = sc / RG::SPR, us = sc - ty * RG::SPR;                     // (uniform: scalar unit)
             const int off = ty * RG::PITCHB + us * 64;
             if constexpr (RG::PAD) {
@@ -189,8 +298,10 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             for (int u = 0; u < LOADS; ++u) stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[u], sc * 64, 0));
         }
     };
+    auto load_a = [&](int s) { load_a_into(stage, s); };
     auto load_b = [&](int par, int s) {
-        const unsigned char* p = pb + (size_t)kclamp(s) * step_bytes;
+        const unsigned char* p = pb + (size_t)(RG::CLS ? cb.ty * RG::SPR + cb.us : kclamp(s)) * step_bytes;
+        if constexpr (RG::CLS) advance(cb);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const bool ok = j0 + j < ntiles;                                        // (wave-uniform) tiles past N: re-read tile j0
@@ -198,10 +309,11 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             for (int t = 0; t < 3; ++t) tb[par][j][t] = *reinterpret_cast<const s_u32x4*>(p + (ok ? j : 0) * kZTileBytes + t * 1024);
         }
     };
-    auto to_lds = [&]() {
+    auto to_lds_from = [&](const s_u32x4 (&stage)[LOADS]) {
 #pragma unroll
         for (int u = 0; u < LOADS; ++u) *reinterpret_cast<s_u32x4*>(wr_ptr + 16 * u * kZPitch) = stage[u];
     };
+    auto to_lds = [&]() { to_lds_from(stage); };
     auto read_frags = [&]() {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -278,18 +390,24 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             (split_piece(par, std::integral_constant<int, T / 6>{}, std::integral_constant<int, (T / 3) % 2>{}, std::integral_constant<int, T % 3>{}), ...);
         }(std::make_integer_sequence<int, kPieces>{});
     };
-    // prologue: step 0 split into ta[0] with its B terms in tb[0]; fragments of step 1 in `raw`; A of step 2 in `stage`
-    load_a(0);
-    load_b(0, 0);
-    to_lds();
-    load_a(1);
-    read_frags();
-    split_all(0);
-    __builtin_amdgcn_sched_barrier(0);
-    to_lds();
-    load_a(2);
-    read_frags();
-    __builtin_amdgcn_sched_barrier(0);
+    // prologue: step 0 split into ta[0] with its B terms in tb[0]; fragments of step 1 in `raw`; A of step 2 in `stage`.  The
+    // loads of all three steps go out together (one memory latency per tile instead of three in a row: the accumulators are
+    // not live yet, the two extra staging sets cost nothing)
+    {
+        s_u32x4 st0[LOADS], st1[LOADS];
+        load_a_into(st0, 0);
+        load_b(0, 0);
+        load_a_into(st1, 1);
+        load_a(2);
+        __builtin_amdgcn_sched_barrier(0);
+        to_lds_from(st0);
+        read_frags();
+        split_all(0);
+        __builtin_amdgcn_sched_barrier(0);
+        to_lds_from(st1);
+        read_frags();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     int s = 0;
     for (; s + 2 <= nsteps; s += 2) {
         step(std::integral_constant<int, 0>{}, s);
@@ -308,6 +426,13 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     const __amdgpu_buffer_rsrc_t rsrc_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask), 0, EPI != Z_BIAS_RELU ? (int)c_bytes : 0, kZRsrcWord3);
     const int ldc = RG::CONV ? RG::DC : a.ldc;
     auto row_off = [&](long long m) -> unsigned {
+        if constexpr (RG::CLS) {                          // computed for every row, selected at the end: an early exit would put a
+            unsigned img;                                 // branch (and its own wait) around every load of the epilogue
+            int gy, gx;
+            cls_pixel((unsigned)m, img, gy, gx);
+            const unsigned off = (unsigned)((((int)img * RG::DH + gy * RG::DM) * RG::DW + gx * RG::DM) * RG::DC) * 4u;
+            return m < M ? off : kZOob;
+        }
         if (m >= M) return kZOob;
         if constexpr (EPI == Z_MASK_CLS4) {
             const long long img = m / RG::PER_IMG;
@@ -375,7 +500,9 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
 
 template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int OCC = NWAVES / 4>
 static int z_launch(const ZArgs& a, hipStream_t s, const char* what) {
-    const long long row_blocks = (a.M + 32 * MT - 1) / (32 * MT), col_blocks = (a.N + 32 * NT - 1) / (32 * NT);
+    long long row_blocks = (a.M + 32 * MT - 1) / (32 * MT);
+    const long long col_blocks = (a.N + 32 * NT - 1) / (32 * NT);
+    if constexpr (RG::CLS) row_blocks = z_class_tiles<RG>(a.M / RG::PER_IMG, 32 * MT);
     const dim3 grid = WAVES_N ? dim3((unsigned)((col_blocks + NWAVES - 1) / NWAVES), (unsigned)row_blocks)
                               : dim3((unsigned)col_blocks, (unsigned)((row_blocks + NWAVES - 1) / NWAVES));
     if (grid.y > 65535u) {            // (hardware grid limit) 4.1 M rows at the smallest row block: beyond every caller's sizes
@@ -422,10 +549,10 @@ static int zgemm_check(const char* fn, const float* A, const void* pack, const f
 }
 
 static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, const float* bias, const float* mask, float* C,
-                   long long c_bytes, int ldc, long long M, int N, int K) {
+                   long long c_bytes, int ldc, long long M, int N, int K, long long images = 0) {
     ZArgs a;
     a.A = A; a.a_bytes = (unsigned)a_bytes; a.lda = lda; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.mask = mask;
-    a.C = C; a.c_bytes = (unsigned)c_bytes; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
+    a.C = C; a.c_bytes = (unsigned)c_bytes; a.ldc = ldc; a.M = M; a.images = images; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
     return a;
 }
 
@@ -488,10 +615,10 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, 
     MI355_REQUIRE(srcb < (1LL << 32) - 8192 && dstb < (1LL << 32) - 8192, MI355PPO_EINVAL,
                   "%s: dz (%lld bytes) and dsrc (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb, dstb);
     if (layer == 3) {      // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
-        const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K);
+        const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K, images);
         return z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, as_stream(stream), fn);
     }
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
-    const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K);
+    const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K, images);
     return z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2>(za, as_stream(stream), fn);
 }

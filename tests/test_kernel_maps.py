@@ -196,3 +196,78 @@ def test_kernel_z_coalesced_load_lds_transposition_delivers_the_mfma_fragments()
     for g8 in range(8):
         banks = [((lane >> 2) * PITCH + 4 * (lane & 3) + d) % 64 for lane in range(8 * g8, 8 * g8 + 8) for d in range(4)]
         assert len(set(banks)) == len(banks) == 32
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Kernel Z, border-class rows of the data gradients (csrc/gemmz.hip: ZAxisDgrad3 / ZAxisDgrad2, ZClassOrder, cls_pixel, the tap
+# cursors): emulated row by row -- class order, row -> (image, grid pixel) with the kernel's multiply-high division, the class's
+# valid tap window -- against the float64 transposed convolution.  The tables are read from the source, so the test follows it.
+def _axis_tables(name):
+    import os
+    import re
+
+    src = open(os.path.join(os.path.dirname(__file__), "..", "cleanrl_amd", "csrc", "gemmz.hip")).read()
+    body = re.search(r"struct %s \{[^}]*?static constexpr int NC = (\d+), (.*?);\s*\};" % name, src, re.S)
+    nc = int(body.group(1))
+    arrs = {k: [int(x) for x in v.split(",")] for k, v in re.findall(r"(\w+)\[\d+\] = \{([^}]*)\}", body.group(2))}
+    assert all(len(arrs[k]) == nc for k in ("G0", "NG", "T0", "T1"))
+    return nc, arrs
+
+
+def _umulhi_div(r, d):
+    """The kernel's r / d: multiply-high by floor(2^32 / d) + 1 (d > 1), exact while r * d < 2^32."""
+    if d == 1:
+        return r
+    magic = ((1 << 32) // d + 1) & 0xFFFFFFFF
+    return (r * magic) >> 32
+
+
+@pytest.mark.parametrize("layer,images", [(3, 1), (3, 5), (2, 3)])
+def test_kernel_z_border_class_rows_give_the_data_gradient(layer, images):
+    H, C, KT, G, OFF, DH, DM, name = ((7, 64, 3, 9, -2, 9, 1, "ZAxisDgrad3") if layer == 3 else (9, 64, 2, 10, -1, 20, 2, "ZAxisDgrad2"))
+    NC, ax = _axis_tables(name)
+    N = 64 if layer == 3 else 128                          # layer 2: 4 stride-parity classes x 32 input channels
+    rs = np.random.RandomState(layer)
+    dz = rs.standard_normal((images, H, H, C))             # the GEMM's source: the incoming gradient, channels last
+    Bm = rs.standard_normal((N, KT, KT, C))                # B[n][(r, c, cout)]: the repacked (flipped) weights
+    ROWS = 64
+    weight = lambda k: ax["NG"][k // NC] * ax["NG"][k % NC] * (ax["T1"][k // NC] - ax["T0"][k // NC]) * (ax["T1"][k % NC] - ax["T0"][k % NC])
+    order = list(range(NC * NC))
+    for i in range(len(order)):                            # ZClassOrder's selection sort, verbatim (ties keep table order)
+        for j in range(i + 1, len(order)):
+            if weight(order[j]) > weight(order[i]):
+                order[i], order[j] = order[j], order[i]
+    out = np.full((images, G, G, N), np.nan)
+    tiles = 0
+    for c in order:
+        cy, cx = c // NC, c % NC
+        nx, npix = ax["NG"][cx], ax["NG"][cy] * ax["NG"][cx]
+        rows = images * npix
+        tiles += (rows + ROWS - 1) // ROWS
+        for r in range(rows):
+            img = _umulhi_div(r, npix)
+            p = r - img * npix
+            py = _umulhi_div(p, nx)
+            gy, gx = ax["G0"][cy] + py, ax["G0"][cx] + (p - py * nx)
+            acc = np.zeros(N)
+            for ty in range(ax["T0"][cy], ax["T1"][cy]):   # the cursor's walk: valid tap rows x valid tap columns (x channel chunks)
+                for tx in range(ax["T0"][cx], ax["T1"][cx]):
+                    sy, sx = gy + OFF + ty, gx + OFF + tx
+                    assert 0 <= sy < H and 0 <= sx < H     # every tap of the class window is valid for every row of the class
+                    acc += Bm[:, ty, tx, :] @ dz[img, sy, sx, :]
+            assert np.isnan(out[img, gy, gx, 0])            # every (image, pixel) exactly once
+            out[img, gy, gx] = acc
+    assert not np.isnan(out).any()
+    # the same sum over ALL taps with zero padding (what the un-classed kernel multiplied)
+    ref = np.zeros_like(out)
+    for ty in range(KT):
+        for tx in range(KT):
+            for gy in range(G):
+                for gx in range(G):
+                    sy, sx = gy + OFF + ty, gx + OFF + tx
+                    if 0 <= sy < H and 0 <= sx < H:
+                        ref[:, gy, gx, :] += dz[:, sy, sx, :] @ Bm[:, ty, tx, :].T
+    assert np.abs(out - ref).max() <= 1e-9 * np.abs(ref).max()
+    valid = sum(weight(k) for k in range(NC * NC))
+    assert valid * (1.65 if layer == 3 else 1.23) == pytest.approx(G * G * KT * KT, rel=0.01)      # the padded windows' MFMA overhead
+    assert tiles == sum((images * ax["NG"][k // NC] * ax["NG"][k % NC] + ROWS - 1) // ROWS for k in range(NC * NC))
