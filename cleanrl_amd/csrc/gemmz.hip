@@ -131,14 +131,9 @@ struct ZClassOrder {
                 if (weight(c[j]) > weight(c[i])) { const int t = c[i]; c[i] = c[j]; c[j] = t; }
     }
 };
-// 64-row wave tiles of a class-ordered launch
+// wave tiles of a class-ordered launch: PER_IMG per group of `rows` images
 template <class RG>
-static long long z_class_tiles(long long images, int rows) {
-    long long t = 0;
-    for (int cy = 0; cy < RG::AX::NC; ++cy)
-        for (int cx = 0; cx < RG::AX::NC; ++cx) t += (images * RG::AX::NG[cy] * RG::AX::NG[cx] + rows - 1) / rows;
-    return t;
-}
+static long long z_class_tiles(long long images, int rows) { return (images + rows - 1) / rows * RG::PER_IMG; }
 
 struct ZArgs {
     const void* A;              // source tensor
@@ -166,44 +161,63 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // (the wave index in an SGPR)
     const int li = lane & 31, lh = lane >> 5;
     const int N = a.N;
-    const int n0 = WAVES_N ? (blockIdx.x * NWAVES + wave) * (32 * NT) : blockIdx.x * (32 * NT);
-    long long wtile = WAVES_N ? (long long)blockIdx.y : (long long)blockIdx.y * NWAVES + wave;        // this wave's row tile
-    // border classes: which class the tile belongs to (wave-uniform), its pixel rectangle and its valid tap window
+    // Workgroup -> (column block, row block).  The convolutions re-read their source through the L2 (windows overlap; the
+    // border classes of an image group share its taps), and every XCD has its own L2: workgroups are dealt to the XCDs round
+    // robin in launch order, so XCD x runs the CONTIGUOUS range [start_x, start_x + count_x) of the logical order -- neighbours in
+    // that order (the column blocks of one row block, then the next row block) meet in one L2 at about the same time.
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (RG::CONV) {
+        const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y;
+        const unsigned x = L & 7u, q = total >> 3, rem = total & 7u;
+        const unsigned logical = x * q + (x < rem ? x : rem) + (L >> 3);
+        bx = logical % gridDim.x;
+        by = logical / gridDim.x;
+    }
+    const int n0 = WAVES_N ? (bx * NWAVES + wave) * (32 * NT) : bx * (32 * NT);
+    long long wtile = WAVES_N ? (long long)by : (long long)by * NWAVES + wave;        // this wave's row tile
+    // Border classes: rows run group by group -- a group = ROWS images = PER_IMG tiles: class (cy, cx) owns NG[cy] NG[cx] of them,
+    // heaviest class first -- so that all classes of an image are multiplied while its taps sit in the L2.  Row r of a class's
+    // tiles in a group = image r / npix of the group, pixel r % npix of the class rectangle.
     int c_gy0 = 0, c_gx0 = 0, c_nx = 1, c_npix = 1, c_ty0 = 0, c_nty = 1, c_us0 = 0, c_spr = 1;
     unsigned c_mg_npix = 0, c_mg_nx = 0;                  // reciprocals for r / npix, p / nx (exact for r * d < 2^32)
-    long long Mrows = a.M;
+    long long c_img0 = 0;                                 // first image of the group
     if constexpr (RG::CLS) {
         using AX = typename RG::AX;
         constexpr ZClassOrder<AX> ord{};
-        const long long images = a.images;
-        int cls = -1;
+        const long long grp = wtile / RG::PER_IMG;
+        int t = (int)(wtile - grp * RG::PER_IMG), cls = ord.c[0];
+        c_img0 = grp * ROWS;
+        if (c_img0 >= a.images) return;
         for (int i = 0; i < AX::NC * AX::NC; ++i) {
-            const int c = ord.c[i];
-            const long long t = (images * (AX::NG[c / AX::NC] * AX::NG[c % AX::NC]) + ROWS - 1) / ROWS;
-            if (wtile < t) { cls = c; break; }
-            wtile -= t;
+            cls = ord.c[i];
+            const int np = AX::NG[cls / AX::NC] * AX::NG[cls % AX::NC];
+            if (t < np) break;
+            t -= np;
         }
-        if (cls < 0) return;
+        wtile = t;                                        // the tile's index among the class's tiles of this group
         const int cy = cls / AX::NC, cx = cls % AX::NC;
         c_gy0 = AX::G0[cy]; c_gx0 = AX::G0[cx]; c_nx = AX::NG[cx]; c_npix = AX::NG[cy] * c_nx;
         c_ty0 = AX::T0[cy]; c_nty = AX::T1[cy] - c_ty0;
         c_us0 = AX::T0[cx] * (RG::C / 16); c_spr = (AX::T1[cx] - AX::T0[cx]) * (RG::C / 16);
         c_mg_npix = c_npix > 1 ? (unsigned)((1ull << 32) / (unsigned)c_npix + 1) : 0u;
         c_mg_nx = c_nx > 1 ? (unsigned)((1ull << 32) / (unsigned)c_nx + 1) : 0u;
-        Mrows = images * c_npix;
     }
-    const long long M = Mrows;
+    const long long M = RG::CLS ? (long long)ROWS * c_npix : a.M;       // (border classes: the class's rows in this group, whole tiles)
     const long long m0 = wtile * ROWS;
     if (m0 >= M || n0 >= N) return;                       // (whole wave; no barriers in this kernel)
-    // class row r -> (image, grid y, grid x)
-    auto cls_pixel = [&](unsigned r, unsigned& img, int& gy, int& gx) {          // (selects, no branches: d == 1 has no 32-bit reciprocal)
+    // class row r -> (image, grid y, grid x); images past the batch (last group) report ok = false and are clamped
+    auto cls_pixel = [&](unsigned r, unsigned& img, int& gy, int& gx) -> bool {  // (selects, no branches: d == 1 has no 32-bit reciprocal)
         const unsigned q = __umulhi(r, c_mg_npix);
-        img = c_npix > 1 ? q : r;
-        const unsigned p = r - img * (unsigned)c_npix;
+        const unsigned loc = c_npix > 1 ? q : r;
+        const unsigned p = r - loc * (unsigned)c_npix;
         const unsigned q2 = __umulhi(p, c_mg_nx);
         const unsigned py = c_nx > 1 ? q2 : p;
         gy = c_gy0 + (int)py;
         gx = c_gx0 + (int)(p - py * (unsigned)c_nx);
+        const long long im = c_img0 + loc;
+        const bool ok = im < a.images;
+        img = (unsigned)(ok ? im : a.images - 1);
+        return ok;
     };
     const int ntiles = (N + 31) / 32, j0 = n0 / 32;
     float* const wl = lds + wave * (ROWS * kZPitch);
@@ -429,9 +443,9 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         if constexpr (RG::CLS) {                          // computed for every row, selected at the end: an early exit would put a
             unsigned img;                                 // branch (and its own wait) around every load of the epilogue
             int gy, gx;
-            cls_pixel((unsigned)m, img, gy, gx);
+            const bool ok = cls_pixel((unsigned)m, img, gy, gx);
             const unsigned off = (unsigned)((((int)img * RG::DH + gy * RG::DM) * RG::DW + gx * RG::DM) * RG::DC) * 4u;
-            return m < M ? off : kZOob;
+            return ok ? off : kZOob;
         }
         if (m >= M) return kZOob;
         if constexpr (EPI == Z_MASK_CLS4) {
@@ -520,6 +534,11 @@ static int z_launch(const ZArgs& a, hipStream_t s, const char* what) {
 
 using namespace mi355ppo;
 
+static int z_cfg() {        // tile-shape experiment (removed once measured)
+    static const int c = [] { const char* e = getenv("MI355PPO_Z_CFG"); return e ? atoi(e) : 0; }();
+    return c;
+}
+
 static size_t zpack_bytes(int N, int K) { return (size_t)(K / 16) * (size_t)((N + 31) / 32) * kZTileBytes; }
 
 extern "C" MI355PPO_API size_t mi355ppo_fc_pack_bytes(int N, int K) {
@@ -595,9 +614,11 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, c
     MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: the source (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);   // (the destination is smaller)
     if (layer == 2) {
         const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K);
+        if (z_cfg() & 1) return z_launch<ZConv2, 4, 2, 4, Z_BIAS_RELU, false, 1>(za, as_stream(stream), fn);
         return z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
     }
     const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
+    if (z_cfg() & 1) return z_launch<ZConv3, 4, 2, 4, Z_BIAS_RELU, false, 1>(za, as_stream(stream), fn);
     return z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
 }
 
@@ -616,9 +637,12 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, 
                   "%s: dz (%lld bytes) and dsrc (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb, dstb);
     if (layer == 3) {      // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
         const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K, images);
+        if (z_cfg() & 2) return z_launch<ZDgrad3, 4, 2, 4, Z_MASK, false, 1>(za, as_stream(stream), fn);
         return z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, as_stream(stream), fn);
     }
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
     const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K, images);
+    if (z_cfg() & 4) return z_launch<ZDgrad2, 4, 2, 4, Z_MASK_CLS4, false, 1>(za, as_stream(stream), fn);
+    if (z_cfg() & 8) return z_launch<ZDgrad2, 4, 4, 4, Z_MASK_CLS4, false, 1>(za, as_stream(stream), fn);
     return z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2>(za, as_stream(stream), fn);
 }

@@ -200,7 +200,7 @@ def test_kernel_z_coalesced_load_lds_transposition_delivers_the_mfma_fragments()
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Kernel Z, border-class rows of the data gradients (csrc/gemmz.hip: ZAxisDgrad3 / ZAxisDgrad2, ZClassOrder, cls_pixel, the tap
-# cursors): emulated row by row -- class order, row -> (image, grid pixel) with the kernel's multiply-high division, the class's
+# cursors): emulated row by row -- image groups, class order, row -> (image, grid pixel) with the kernel's multiply-high division, the class's
 # valid tap window -- against the float64 transposed convolution.  The tables are read from the source, so the test follows it.
 def _axis_tables(name):
     import os
@@ -222,7 +222,7 @@ def _umulhi_div(r, d):
     return (r * magic) >> 32
 
 
-@pytest.mark.parametrize("layer,images", [(3, 1), (3, 5), (2, 3)])
+@pytest.mark.parametrize("layer,images", [(3, 1), (3, 70), (2, 3)])
 def test_kernel_z_border_class_rows_give_the_data_gradient(layer, images):
     H, C, KT, G, OFF, DH, DM, name = ((7, 64, 3, 9, -2, 9, 1, "ZAxisDgrad3") if layer == 3 else (9, 64, 2, 10, -1, 20, 2, "ZAxisDgrad2"))
     NC, ax = _axis_tables(name)
@@ -239,24 +239,30 @@ def test_kernel_z_border_class_rows_give_the_data_gradient(layer, images):
                 order[i], order[j] = order[j], order[i]
     out = np.full((images, G, G, N), np.nan)
     tiles = 0
-    for c in order:
-        cy, cx = c // NC, c % NC
-        nx, npix = ax["NG"][cx], ax["NG"][cy] * ax["NG"][cx]
-        rows = images * npix
-        tiles += (rows + ROWS - 1) // ROWS
-        for r in range(rows):
-            img = _umulhi_div(r, npix)
-            p = r - img * npix
-            py = _umulhi_div(p, nx)
-            gy, gx = ax["G0"][cy] + py, ax["G0"][cx] + (p - py * nx)
-            acc = np.zeros(N)
-            for ty in range(ax["T0"][cy], ax["T1"][cy]):   # the cursor's walk: valid tap rows x valid tap columns (x channel chunks)
-                for tx in range(ax["T0"][cx], ax["T1"][cx]):
-                    sy, sx = gy + OFF + ty, gx + OFF + tx
-                    assert 0 <= sy < H and 0 <= sx < H     # every tap of the class window is valid for every row of the class
-                    acc += Bm[:, ty, tx, :] @ dz[img, sy, sx, :]
-            assert np.isnan(out[img, gy, gx, 0])            # every (image, pixel) exactly once
-            out[img, gy, gx] = acc
+    for grp in range((images + ROWS - 1) // ROWS):          # a group = ROWS images = G * G tiles; classes heaviest first inside it
+        group_tiles = 0
+        for c in order:
+            cy, cx = c // NC, c % NC
+            nx, npix = ax["NG"][cx], ax["NG"][cy] * ax["NG"][cx]
+            group_tiles += npix                             # the class owns npix whole tiles of the group
+            for r in range(ROWS * npix):
+                loc = _umulhi_div(r, npix)
+                img = grp * ROWS + loc
+                if img >= images:                           # last group: rows of images past the batch are dropped at the store
+                    continue
+                p = r - loc * npix
+                py = _umulhi_div(p, nx)
+                gy, gx = ax["G0"][cy] + py, ax["G0"][cx] + (p - py * nx)
+                acc = np.zeros(N)
+                for ty in range(ax["T0"][cy], ax["T1"][cy]):   # the cursor's walk: valid tap rows x valid tap columns (x channel chunks)
+                    for tx in range(ax["T0"][cx], ax["T1"][cx]):
+                        sy, sx = gy + OFF + ty, gx + OFF + tx
+                        assert 0 <= sy < H and 0 <= sx < H     # every tap of the class window is valid for every row of the class
+                        acc += Bm[:, ty, tx, :] @ dz[img, sy, sx, :]
+                assert np.isnan(out[img, gy, gx, 0])            # every (image, pixel) exactly once
+                out[img, gy, gx] = acc
+        assert group_tiles == G * G
+        tiles += group_tiles
     assert not np.isnan(out).any()
     # the same sum over ALL taps with zero padding (what the un-classed kernel multiplied)
     ref = np.zeros_like(out)
@@ -270,4 +276,20 @@ def test_kernel_z_border_class_rows_give_the_data_gradient(layer, images):
     assert np.abs(out - ref).max() <= 1e-9 * np.abs(ref).max()
     valid = sum(weight(k) for k in range(NC * NC))
     assert valid * (1.65 if layer == 3 else 1.23) == pytest.approx(G * G * KT * KT, rel=0.01)      # the padded windows' MFMA overhead
-    assert tiles == sum((images * ax["NG"][k // NC] * ax["NG"][k % NC] + ROWS - 1) // ROWS for k in range(NC * NC))
+    assert tiles == (images + ROWS - 1) // ROWS * G * G
+
+
+@pytest.mark.parametrize("total", [1, 7, 8, 9, 10, 63, 64, 65, 1000, 5184])
+def test_kernel_z_xcd_aware_workgroup_order_is_a_bijection_with_contiguous_ranges(total):
+    """gemmz.hip's workgroup remap: launch index L -> XCD L % 8 (round-robin dispatch) runs logical index start[x] + L // 8 -- every
+    logical index exactly once, and XCD x owns one contiguous range."""
+    q, rem = total >> 3, total & 7
+    per_xcd = {}
+    for L in range(total):
+        x = L & 7
+        logical = x * q + min(x, rem) + (L >> 3)
+        per_xcd.setdefault(x, []).append(logical)
+    allv = sorted(v for vs in per_xcd.values() for v in vs)
+    assert allv == list(range(total))
+    for x, vs in per_xcd.items():
+        assert vs == list(range(vs[0], vs[0] + len(vs)))

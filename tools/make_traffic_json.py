@@ -1,8 +1,8 @@
-"""profiles/traffic.json from the HBM-traffic PMC passes of tools/gpu_traffic.sh (profiles/r02_pmc_traffic_{fetch,write}.csv).
+"""profiles/traffic.json from the HBM-traffic PMC passes of tools/gpu_r3_final.sh (profiles/r03_pmc_{fetch,write}.csv).
 
 HBM bytes per launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB: on gfx950 FETCH_SIZE tallies 128-byte read requests at
 64 bytes (MI355X_MICROARCH.md "HBM"; confirmed here by the calibration copies of the same passes: a 1 GiB read reports
-512 MiB at both 16 and 4 bytes per lane, a 1 GiB write reports 1 GiB).  Keys are bench.py's conv launch names.
+512 MiB at both 16 and 4 bytes per lane, a 1 GiB write reports 1 GiB).  Keys are bench.py's launch names.
 """
 import csv
 import json
@@ -11,19 +11,18 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 IMAGES = 32768
-KEYS = {   # bench key -> (kernel-name substring, geometry substring); conv3_dgrad sums its 9 border-class launches
+KEYS = {   # bench key -> (kernel-name substring, geometry substring) in rocpd_pmc.py's (truncated) kernel names
     "conv1_fwd": ("conv1q_fwd_kernel", ""),
-    "conv2_fwd": ("conv_fixed_kernel", "FixedGeom<20, 20, 32, 4, 4, 9, 9, 2, 0,"),
-    "conv3_fwd": ("conv_fixed_kernel", "FixedGeom<9, 9, 64, 3, 3, 7, 7, 1, 0,"),
-    "conv2_dgrad": ("conv_fixed_kernel", ("FixedGeom<9, 9, 64, 2, 2, 8, 8,", "FixedGeom<9, 9, 64, 1, 2, 1, 8,", "FixedGeom<9, 9, 64, 2, 1, 8, 1,",
-                                          "FixedGeom<9, 9, 64, 1, 1, 1, 1,")),          # the four border-class launches
-    "conv3_dgrad": ("conv_fixed_kernel", "FixedGeom<7, 7, 64,"),
+    "conv2_fwd": ("z_kernel", "ZRowsConv<20, 20, 32, 4, 4, 9, 9, 2, 0,"),
+    "conv3_fwd": ("z_kernel", "ZRowsConv<9, 9, 64, 3, 3, 7, 7, 1, 0,"),
+    "conv2_dgrad": ("z_kernel", "ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1,"),
+    "conv3_dgrad": ("z_kernel", "ZRowsConv<7, 7, 64, 3, 3, 9, 9, 1, -2,"),
     "conv1_wgrad": ("conv1p_wgrad_kernel", ""),
-    "conv2_wgrad": ("conv_wgrad_taps_kernel", "FixedGeom<20, 20, 32,"),
-    "conv3_wgrad": ("conv_wgrad_taps_kernel", "FixedGeom<9, 9, 64,"),
-    "fc_fwd": ("fcx_gemm_nt_kernel<0,", ""),
-    "fc_dgrad": ("fcx_gemm_nt_kernel<1,", ""),
-    "fc_wgrad": ("fcw_", ""),                         # kernel Y + the sum of its nine slab partials
+    "conv2_wgrad": ("convw_bf16_kernel", "VGeom<20, 20, 32,"),
+    "conv3_wgrad": ("convw_bf16_kernel", "VGeom<9, 9, 64,"),
+    "fc_fwd": ("z_kernel", "ZRowsLinear, 2, 4, 4, 0, true"),
+    "fc_dgrad": ("z_kernel", "ZRowsLinear, 2, 4, 4, 1, false"),
+    "fc_wgrad": ("fcw_", ""),                         # kernel W + the sum of its slab partials
 }
 ALGORITHMIC = {   # bytes per image the algorithm must move (inputs read once + outputs written once)
     "conv1_fwd": 28224 + 51200, "conv2_fwd": 51200 + 20736, "conv3_fwd": 20736 + 12544,
@@ -40,8 +39,8 @@ def load(name):
 
 
 def main():
-    fetch, write = load("r02_pmc_traffic_fetch.csv"), load("r02_pmc_traffic_write.csv")
-    out = {"source": "tools/gpu_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/conv_traffic 32768 3",
+    fetch, write = load("r03_pmc_fetch.csv"), load("r03_pmc_write.csv")
+    out = {"source": "tools/gpu_r3_final.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/conv_traffic 32768 3",
            "correction": "bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950: 128-byte read requests tallied at 64 bytes)",
            "calibration_fetch_KiB_for_1GiB_read": {k[:40]: v for k, v in fetch.items() if "calib" in k},
            "calibration_write_KiB_for_1GiB_write": {k[:40]: v for k, v in write.items() if "calib" in k},
