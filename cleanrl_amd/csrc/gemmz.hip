@@ -534,11 +534,6 @@ static int z_launch(const ZArgs& a, hipStream_t s, const char* what) {
 
 using namespace mi355ppo;
 
-static int z_cfg() {        // tile-shape experiment (removed once measured)
-    static const int c = [] { const char* e = getenv("MI355PPO_Z_CFG"); return e ? atoi(e) : 0; }();
-    return c;
-}
-
 static size_t zpack_bytes(int N, int K) { return (size_t)(K / 16) * (size_t)((N + 31) / 32) * kZTileBytes; }
 
 extern "C" MI355PPO_API size_t mi355ppo_fc_pack_bytes(int N, int K) {
@@ -614,11 +609,9 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, c
     MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: the source (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);   // (the destination is smaller)
     if (layer == 2) {
         const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K);
-        if (z_cfg() & 1) return z_launch<ZConv2, 4, 2, 4, Z_BIAS_RELU, false, 1>(za, as_stream(stream), fn);
         return z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
     }
     const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
-    if (z_cfg() & 1) return z_launch<ZConv3, 4, 2, 4, Z_BIAS_RELU, false, 1>(za, as_stream(stream), fn);
     return z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
 }
 
@@ -637,12 +630,9 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, 
                   "%s: dz (%lld bytes) and dsrc (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb, dstb);
     if (layer == 3) {      // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
         const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K, images);
-        if (z_cfg() & 2) return z_launch<ZDgrad3, 4, 2, 4, Z_MASK, false, 1>(za, as_stream(stream), fn);
         return z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, as_stream(stream), fn);
     }
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
     const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K, images);
-    if (z_cfg() & 4) return z_launch<ZDgrad2, 4, 2, 4, Z_MASK_CLS4, false, 1>(za, as_stream(stream), fn);
-    if (z_cfg() & 8) return z_launch<ZDgrad2, 4, 4, 4, Z_MASK_CLS4, false, 1>(za, as_stream(stream), fn);
     return z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2>(za, as_stream(stream), fn);
 }
