@@ -1,5 +1,6 @@
-"""Error of the bf16-pipe kernels (X: FC forward; C: layers 2 / 3 forward) against float64, next to the f32-pipe / library result on
-the same inputs.  Run once per setting of MI355PPO_BF16_PAIRS (read once per process): prints one JSON line."""
+"""Error of the bf16-pipe kernel Z (FC forward; layers 2 / 3 forward) against float64, next to the f32-pipe / library result on the
+same inputs.  Run once per setting of MI355PPO_BF16_PAIRS (read once per process): prints one JSON line.  (profiles/r03_err_pairs.jsonl
+was taken with round 2's kernels X / C, which multiplied the same term pairs: keys x_* / c_*.)"""
 import json
 import os
 import sys
@@ -17,7 +18,7 @@ a = torch.relu(torch.randn(M, 3136, device=DEV, generator=g)) * torch.exp(torch.
 W = torch.randn(512, 3136, device=DEV, generator=g) / 56.0
 b = torch.randn(512, device=DEV, generator=g) * 0.1
 ref = torch.relu(a.double() @ W.double().t() + b.double())
-x = cnn.fc_fwd_relu(a, W, b).double()
+x = cnn.fc_fwd_relu_packed(a, cnn.fc_pack(W), b, 512).double()
 lib = torch.relu(a @ W.t() + b).double()
 s = ref.abs().max().item()
 out["fc_fwd"] = {"x_max": (x - ref).abs().max().item() / s, "x_mean": (x - ref).abs().mean().item() / s,
@@ -31,7 +32,7 @@ for layer, (cin, cout, k, st, hin) in spec.items():
     cols = torch.nn.functional.unfold(xin.double().permute(0, 3, 1, 2), kernel_size=k, stride=st)
     ref = torch.relu(torch.einsum("nk,bkl->bln", Wc.double().reshape(cout, -1), cols) + bc.double()).reshape(2048, -1, cout)
     f = cnn.conv_fwd(xin, cnn.repack_weights(Wc, layer), bc, layer).double().reshape(2048, -1, cout)
-    c = cnn.conv_fwd(xin, cnn.repack_weights(Wc, layer, cnn.MODE_FWD_X), bc, layer, variant=cnn.VARIANT_X).double().reshape(2048, -1, cout)
+    c = cnn.conv_fwd_packed(xin, cnn.conv_zpack(Wc, layer, cnn.MODE_FWD), bc, layer).double().reshape(2048, -1, cout)
     s = ref.abs().max().item()
     out[f"conv{layer}_fwd"] = {"c_max": (c - ref).abs().max().item() / s, "c_mean": (c - ref).abs().mean().item() / s,
                                "f_max": (f - ref).abs().max().item() / s, "f_mean": (f - ref).abs().mean().item() / s,
