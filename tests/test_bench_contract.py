@@ -23,7 +23,7 @@ def test_defaults_and_traffic_lookup(monkeypatch):
     for k in keys:
         got = bench._traffic_of(k)
         alg = t["algorithmic_bytes"][k]
-        assert got == t["hbm_bytes_per_launch"][k] and alg <= got < 2.0 * alg, (k, got, alg)    # never below the algorithmic bytes
+        assert got == t["hbm_bytes_per_launch"][k] and alg <= got < 2.5 * alg, (k, got, alg)    # never below the algorithmic bytes; re-reads stay a small factor
     assert bench._traffic_of("trunk_fwd(conv1+2+3)@1024") is None
     assert bench.MFMA_F32_PEAK_TFLOPS == 157.3 and bench.HBM_PEAK_GBPS == 8000.0
 

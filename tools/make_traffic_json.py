@@ -11,6 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 IMAGES = 32768
+# the newest passes over the committed kernel set (the group-major / XCD-range workgroup order of kernel Z)
+FETCH_CSV, WRITE_CSV = "r03_pmc_fetch_group_major_xcd.csv", "r03_pmc_write_group_major_xcd.csv"
 KEYS = {   # bench key -> (kernel-name substring, geometry substring) in rocpd_pmc.py's (truncated) kernel names
     "conv1_fwd": ("conv1q_fwd_kernel", ""),
     "conv2_fwd": ("z_kernel", "ZRowsConv<20, 20, 32, 4, 4, 9, 9, 2, 0,"),
@@ -39,8 +41,8 @@ def load(name):
 
 
 def main():
-    fetch, write = load("r03_pmc_fetch.csv"), load("r03_pmc_write.csv")
-    out = {"source": "tools/gpu_r3_final.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/conv_traffic 32768 3",
+    fetch, write = load(FETCH_CSV), load(WRITE_CSV)
+    out = {"source": f"profiles/{FETCH_CSV}, profiles/{WRITE_CSV} (tools/gpu_quick_traffic.sh): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/conv_traffic 32768 3",
            "correction": "bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950: 128-byte read requests tallied at 64 bytes)",
            "calibration_fetch_KiB_for_1GiB_read": {k[:40]: v for k, v in fetch.items() if "calib" in k},
            "calibration_write_KiB_for_1GiB_write": {k[:40]: v for k, v in write.items() if "calib" in k},
