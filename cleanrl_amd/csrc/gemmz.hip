@@ -154,10 +154,20 @@ struct ZArgs {
 // WAVES_N: the waves of a workgroup sit side by side (they read the same A rows) instead of on top of each other (they stream
 // the same B fragments).
 // OCC: waves per SIMD the kernel is compiled for (of one workgroup or of several per CU).
-template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int NP, int OCC>
+// BLDS: the stacked waves of a workgroup (WAVES_N = false) multiply the SAME B fragments.  Every wave streaming them for itself
+//   kept the vector-memory front end busier than the matrix pipe (6 of the 10 KiB a 64 x 64 wave tile pulls per k-step are B:
+//   TA 0.74 - 0.83 busy, matrix pipe 0.34 - 0.55, profiles/r03_pmc_*.csv; with the B loads compiled out the layer-2 forward ran
+//   1,133 -> 845 us).  With BLDS the workgroup fetches the B of a k-step PAIR once -- every wave 1 / NWAVES of its 2 NT x 3 KiB
+//   pieces, two pairs ahead -- into a two-slot LDS ring, and all waves read their fragments from there (ds_read_b128, lane-
+//   linear: conflict-free): one s_barrier per k-step pair, B's share of the L1 traffic / NWAVES.  The waves of a workgroup must
+//   walk the same k-steps: no wave leaves early (rows past the batch are clamped and their stores dropped), and with border
+//   classes the NWAVES waves take the SAME class tile of NWAVES consecutive image groups.  K / 16 must be even.
+template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int NP, int OCC, bool BLDS>
 __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void z_kernel(ZArgs a) {
     constexpr int ROWS = 32 * MT, LOADS = ROWS / 16;
-    __shared__ __attribute__((aligned(16))) float lds[NWAVES * ROWS * kZPitch];
+    constexpr int kPairPieces = 2 * NT * 3, kPairBytes = kPairPieces * 1024, kShare = kPairPieces / NWAVES;      // B of a k-step pair
+    static_assert(!BLDS || (!WAVES_N && kPairPieces % NWAVES == 0), "B ring: stacked waves, whole KiB pieces per wave");
+    __shared__ __attribute__((aligned(16))) float lds[NWAVES * ROWS * kZPitch + (BLDS ? 2 * kPairBytes / 4 : 0)];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // (the wave index in an SGPR)
     const int li = lane & 31, lh = lane >> 5;
     const int N = a.N;
@@ -184,10 +194,16 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     if constexpr (RG::CLS) {
         using AX = typename RG::AX;
         constexpr ZClassOrder<AX> ord{};
-        const long long grp = wtile / RG::PER_IMG;
+        long long grp = wtile / RG::PER_IMG;
         int t = (int)(wtile - grp * RG::PER_IMG), cls = ord.c[0];
+        if constexpr (BLDS) {                             // the waves of a workgroup: tile t of NWAVES consecutive groups
+            const unsigned quad = by / (unsigned)RG::PER_IMG;
+            t = (int)(by - quad * (unsigned)RG::PER_IMG);
+            grp = (long long)quad * NWAVES + wave;
+        }
         c_img0 = grp * ROWS;
-        if (c_img0 >= a.images) return;
+        if constexpr (!BLDS)
+            if (c_img0 >= a.images) return;               // (BLDS: a group past the batch multiplies the last image, stores dropped)
         for (int i = 0; i < AX::NC * AX::NC; ++i) {
             cls = ord.c[i];
             const int np = AX::NG[cls / AX::NC] * AX::NG[cls % AX::NC];
@@ -204,7 +220,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     }
     const long long M = RG::CLS ? (long long)ROWS * c_npix : a.M;       // (border classes: the class's rows in this group, whole tiles)
     const long long m0 = wtile * ROWS;
-    if (m0 >= M || n0 >= N) return;                       // (whole wave; no barriers in this kernel)
+    if constexpr (!BLDS)
+        if (m0 >= M || n0 >= N) return;                   // (whole wave; no barriers without BLDS)
     // class row r -> (image, grid y, grid x); images past the batch (last group) report ok = false and are clamped
     auto cls_pixel = [&](unsigned r, unsigned& img, int& gy, int& gx) -> bool {  // (selects, no branches: d == 1 has no 32-bit reciprocal)
         const unsigned q = __umulhi(r, c_mg_npix);
@@ -323,6 +340,45 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             for (int t = 0; t < 3; ++t) tb[par][j][t] = *reinterpret_cast<const s_u32x4*>(p + (ok ? j : 0) * kZTileBytes + t * 1024);
         }
     };
+    // ---- BLDS: the workgroup's B ring.  Piece x of a pair = (k-step half h, column tile j, term t), x = (h NT + j) 3 + t, one KiB
+    // each; wave w fetches pieces w kShare .. + kShare - 1.  `bcur` / `bnxt` = byte offsets of the two slots.
+    unsigned char* const ring = reinterpret_cast<unsigned char*>(lds + NWAVES * ROWS * kZPitch);
+    s_u32x4 bst[BLDS ? kShare : 1];
+    size_t bsrc[BLDS ? kShare : 1];                       // where this wave's pieces sit relative to the pair's first k-step
+    unsigned bcur = 0, bnxt = kPairBytes;
+    Cursor cp{0, c_ty0, c_us0};                           // first k-step of the next pair to fetch (stays on the last pair)
+    if constexpr (BLDS) {
+#pragma unroll
+        for (int u = 0; u < kShare; ++u) {
+            const int x = wave * kShare + u, h = x / (NT * 3), jt = x - h * (NT * 3), j = jt / 3;
+            const int jt_ok = j0 + j < ntiles ? jt : jt - 3 * j;                     // column tiles past N: re-read tile j0 (never stored)
+            bsrc[u] = (size_t)h * step_bytes + (size_t)jt_ok * 1024;
+        }
+    }
+    auto load_bpair = [&]() {
+        const unsigned char* p = pb + (size_t)(RG::CLS ? cp.ty * RG::SPR + cp.us : cp.n) * step_bytes;
+#pragma unroll
+        for (int u = 0; u < kShare; ++u) bst[u] = *reinterpret_cast<const s_u32x4*>(p + bsrc[u]);
+        if (cp.n + 2 < nsteps) {
+            cp.n += 2;
+            cp.us += 2;
+            if (cp.us == c_us0 + c_spr) { cp.us = c_us0; ++cp.ty; }
+        }
+    };
+    auto write_bpair = [&](unsigned slot) {
+#pragma unroll
+        for (int u = 0; u < kShare; ++u) *reinterpret_cast<s_u32x4*>(ring + slot + (wave * kShare + u) * 1024 + 16 * lane) = bst[u];
+    };
+    auto read_b = [&](int par, unsigned slot, int h) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) tb[par][j][t] = *reinterpret_cast<const s_u32x4*>(ring + slot + ((h * NT + j) * 3 + t) * 1024 + 16 * lane);
+    };
+    auto ring_barrier = [&]() {                           // this wave's ring writes have landed; then every wave's
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
     auto to_lds_from = [&](const s_u32x4 (&stage)[LOADS]) {
 #pragma unroll
         for (int u = 0; u < LOADS; ++u) *reinterpret_cast<s_u32x4*>(wr_ptr + 16 * u * kZPitch) = stage[u];
@@ -374,12 +430,19 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     // z_item_at(g) -- one of the 6 MT split pieces, then the LDS writes, the A loads, the LDS reads -- and a sched_barrier; the
     // last kTail MFMAs run bare and cover the LDS round trip.  Term pairs outermost, the MT x NT independent tiles innermost: no
     // MFMA waits for the one before it.
-    constexpr int NM = NP * MT * NT, kPieces = 6 * MT, kItems = kPieces + 3, kTail = NM > 2 * kItems ? NM / 4 : NM - kItems;
+    // BLDS: two more items in the even steps -- this wave's pieces of pair p + 1 to the ring (loaded two steps earlier), its pieces
+    // of pair p + 2 from global memory -- and the odd steps open with the ring barrier.
+    constexpr int NM = NP * MT * NT, kPieces = 6 * MT, kItems = kPieces + 3 + (BLDS ? 2 : 0), kTail = NM > 2 * kItems ? NM / 4 : NM - kItems;
     static_assert(NM - kTail >= kItems, "one MFMA per scheduled item");
     constexpr int PX[9] = {0, 0, 1, 0, 2, 1, 1, 2, 2}, PY[9] = {0, 1, 0, 2, 0, 1, 2, 1, 2};     // pairs by weight: the first six have x + y <= 2
     auto step = [&](auto qc, int s) {
         constexpr int q = decltype(qc)::value;
-        load_b(q ^ 1, s + 1);
+        if constexpr (BLDS) {
+            if constexpr (q == 1) ring_barrier();
+            read_b(q ^ 1, q == 0 ? bcur : bnxt, q ^ 1);                            // B of step s + 1: second half of this pair / first of the next
+        } else {
+            load_b(q ^ 1, s + 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... G>(std::integer_sequence<int, G...>) {
             ([&] {
@@ -393,7 +456,9 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
                         split_piece(q ^ 1, std::integral_constant<int, t / 6>{}, std::integral_constant<int, (t / 3) % 2>{}, std::integral_constant<int, t % 3>{});
                     else if constexpr (t == kPieces) to_lds();
                     else if constexpr (t == kPieces + 1) load_a(s + 3);
-                    else read_frags();
+                    else if constexpr (t == kPieces + 2) read_frags();
+                    else if constexpr (t == kPieces + 3) { if constexpr (q == 0) write_bpair(bnxt); }
+                    else { if constexpr (q == 0) load_bpair(); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
@@ -410,10 +475,17 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     {
         s_u32x4 st0[LOADS], st1[LOADS];
         load_a_into(st0, 0);
-        load_b(0, 0);
+        if constexpr (BLDS) load_bpair();                 // pair 0 -> ring slot 0
+        else load_b(0, 0);
         load_a_into(st1, 1);
         load_a(2);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BLDS) {
+            write_bpair(bcur);
+            load_bpair();                                 // pair 1 stays in registers until step 0
+            ring_barrier();
+            read_b(0, bcur, 0);
+        }
         to_lds_from(st0);
         read_frags();
         split_all(0);
@@ -426,8 +498,10 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     for (; s + 2 <= nsteps; s += 2) {
         step(std::integral_constant<int, 0>{}, s);
         step(std::integral_constant<int, 1>{}, s + 1);
+        if constexpr (BLDS) { const unsigned t = bcur; bcur = bnxt; bnxt = t; }
     }
-    if (s < nsteps) step(std::integral_constant<int, 0>{}, s);
+    if constexpr (!BLDS)
+        if (s < nsteps) step(std::integral_constant<int, 0>{}, s);
 
     // ---- epilogue: accumulator element e of tile (i, j) is C[row m0 + 32 i + (e & 3) + 8 (e >> 2) + 4 lh][column n0 + 32 j + li].
     // Byte offset of (row m, column tile j): GEMM rows and the convolutions whose destination pixel IS the row (channels last,
@@ -512,27 +586,42 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     }
 }
 
-template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int OCC = NWAVES / 4>
+template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int OCC = NWAVES / 4, bool BLDS = false>
 static int z_launch(const ZArgs& a, hipStream_t s, const char* what) {
     long long row_blocks = (a.M + 32 * MT - 1) / (32 * MT);
     const long long col_blocks = (a.N + 32 * NT - 1) / (32 * NT);
     if constexpr (RG::CLS) row_blocks = z_class_tiles<RG>(a.M / RG::PER_IMG, 32 * MT);
-    const dim3 grid = WAVES_N ? dim3((unsigned)((col_blocks + NWAVES - 1) / NWAVES), (unsigned)row_blocks)
-                              : dim3((unsigned)col_blocks, (unsigned)((row_blocks + NWAVES - 1) / NWAVES));
+    dim3 grid = WAVES_N ? dim3((unsigned)((col_blocks + NWAVES - 1) / NWAVES), (unsigned)row_blocks)
+                        : dim3((unsigned)col_blocks, (unsigned)((row_blocks + NWAVES - 1) / NWAVES));
+    if constexpr (BLDS && RG::CLS) {      // a workgroup = one class tile of NWAVES consecutive image groups
+        const long long groups = (a.M / RG::PER_IMG + 32 * MT - 1) / (32 * MT);
+        grid.y = (unsigned)((groups + NWAVES - 1) / NWAVES * RG::PER_IMG);
+    }
     if (grid.y > 65535u) {            // (hardware grid limit) 4.1 M rows at the smallest row block: beyond every caller's sizes
         set_error("%s: %lld rows exceed one launch", what, a.M);
         return MI355PPO_EINVAL;
     }
     if (bf16_term_pairs() == 9)
-        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 9, OCC>), grid, dim3(64 * NWAVES), 0, s, a);
+        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 9, OCC, BLDS>), grid, dim3(64 * NWAVES), 0, s, a);
     else
-        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 6, OCC>), grid, dim3(64 * NWAVES), 0, s, a);
+        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 6, OCC, BLDS>), grid, dim3(64 * NWAVES), 0, s, a);
     return check_launch(what);
 }
 
 }  // namespace mi355ppo
 
 using namespace mi355ppo;
+
+// The convolutions share B through the workgroup's LDS ring (BLDS) from 2,048 images on; below, a launch is a single round of
+// workgroups and the ring's barriers cost what its saved L1 traffic buys (1,024 images: layer 3 forward 31.5 -> 33.8 us).
+// MI355PPO_Z_BLDS=0: every wave streams its own B fragments at every size (same-box A/B runs).  Read once.
+static bool z_blds(long long images) {
+    static const bool on = [] {
+        const char* e = getenv("MI355PPO_Z_BLDS");
+        return !(e && e[0] == '0');
+    }();
+    return on && images >= 2048;
+}
 
 static size_t zpack_bytes(int N, int K) { return (size_t)(K / 16) * (size_t)((N + 31) / 32) * kZTileBytes; }
 
@@ -591,6 +680,8 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, i
     if (rc) return rc;
     MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
     const ZArgs za = zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, (long long)M * N * 4, N, M, N, K);
+    // (the B ring -- z_launch<..., 1, true> for even K / 16 -- measured 630 -> 720 us here: one wave per SIMD has nothing to run while
+    // it waits at the ring barrier; profiles/r03_blds_ab.jsonl)
     return z_launch<ZRowsLinear, 2, 4, 4, Z_MASK, false>(za, as_stream(stream), fn);
 }
 
@@ -609,9 +700,11 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, c
     MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: the source (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);   // (the destination is smaller)
     if (layer == 2) {
         const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K);
+        if (z_blds(images)) return z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, as_stream(stream), fn);
         return z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
     }
     const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
+    if (z_blds(images)) return z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, as_stream(stream), fn);
     return z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
 }
 
@@ -630,9 +723,11 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, 
                   "%s: dz (%lld bytes) and dsrc (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb, dstb);
     if (layer == 3) {      // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
         const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K, images);
+        if (z_blds(images)) return z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2, true>(za, as_stream(stream), fn);
         return z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, as_stream(stream), fn);
     }
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
     const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K, images);
+    if (z_blds(images)) return z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2, true>(za, as_stream(stream), fn);
     return z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2>(za, as_stream(stream), fn);
 }

@@ -176,12 +176,13 @@ def test_conv_fwd_f32(layer, images, variant):
 
 
 @pytest.mark.parametrize("layer", [2, 3])
-@pytest.mark.parametrize("images", [1, 19, 700, 7000])
+@pytest.mark.parametrize("images", [1, 19, 700, 2049, 7000])
 def test_conv_fwd_kernel_z(layer, images):
     """Kernel Z (csrc/gemmz.hip) on the forward of layers 2 / 3: output pixels as GEMM rows, coalesced window loads through the
     wave-private LDS transposition, weights pre-split into fragment order -- the float64 bound of every forward kernel (2e-5 of
     the result's scale) on activations with a wide dynamic range, next to kernel F on the same inputs; deterministic; tails
-    (1 and 19 images: partial 64-pixel row blocks)."""
+    (1 and 19 images: partial 64-pixel row blocks).  From 2,048 images on the workgroup shares B through its LDS ring: 2,049
+    images leave the last workgroup with waves past the batch that still take part in the ring."""
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(400 + layer + images)
     x = torch.relu(torch.randn(images, cin, hin, hin, generator=g)) * torch.exp(torch.randn(images, cin, hin, hin, generator=g))
@@ -198,11 +199,13 @@ def test_conv_fwd_kernel_z(layer, images):
 
 
 @pytest.mark.parametrize("layer", [2, 3])
-@pytest.mark.parametrize("images", [1, 19, 128, 700, 7000])
+@pytest.mark.parametrize("images", [1, 19, 128, 700, 2049, 2310, 7000])
 def test_conv_dgrad_kernel_z_with_relu_mask(layer, images):
     """Kernel Z on the data gradients: layer 3 as the zero-padded full correlation of dz3 with the flipped taps (padding = the
     buffer range check), layer 2 as ONE 128-column GEMM over the 10 x 10 grid whose four column tiles are the stride-parity
-    classes; ReLU-backward mask fused.  float64 bound of every data-gradient kernel; exact zeros where the activation is 0."""
+    classes; ReLU-backward mask fused.  float64 bound of every data-gradient kernel; exact zeros where the activation is 0.
+    From 2,048 images on (B ring) a workgroup's four waves take one class tile of four consecutive 64-image groups: 2,049 and
+    2,310 images leave the last workgroups with one and one-and-a-bit live groups."""
     cin, cout, k, s, hin, hout = SPEC[layer]
     g = torch.Generator().manual_seed(420 + layer)
     pre = torch.randn(images, cin, hin, hin, generator=g).double().requires_grad_(True)

@@ -179,6 +179,7 @@ int main(int argc, char** argv) {
         };
         dump(dW1, 8192, 1); dump(db1, 32, 1); dump(dW2, 32768, 1); dump(db2, 64, 1); dump(dW3, 36864, 1); dump(db3, 64, 1);
         dump(a1, a1n, 4099); dump(a2, a2n, 1031); dump(a3, a3n, 1031); dump(dz2, a2n, 1031); dump(dz1, a1n, 4099);
+        dump(hfc, (size_t)M * 512, 1021); dump(dz3, a3n, 1031); dump(dWfc, 512 * 3136, 211);
         std::fclose(f);
     }
     dW = dW1;

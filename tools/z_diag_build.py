@@ -5,7 +5,7 @@ that `LD_PRELOAD=tools/oldlib/zdiag_<n>/libmi355ppo.so tools/conv_traffic 32768 
     bit 1 (2)   no stores
     bit 2 (4)   one k-step per tile
     bit 3 (8)   no global loads of A inside the k-loop (the prologue's three stay)
-    bit 4 (16)  no loads of B inside the k-loop
+    bit 4 (16)  no loads of B inside the k-loop (with the B ring: no ring fills and no fragment reads; the barriers stay)
     bit 5 (32)  no split (the VALU work between the MFMAs)
     bit 6 (64)  no LDS round trip inside the k-loop
 
@@ -29,7 +29,10 @@ PATCHES = [
      "                    v = v > 0.0f ? v : 0.0f;\n                    if (!(Z_DIAG & 2) || v == 123.456f) __builtin_amdgcn_raw_buffer_store_b32("),
     ("    const int nsteps = RG::CLS ?", "    const int nsteps = (Z_DIAG & 4) ? 1 : RG::CLS ?"),
     ("                    else if constexpr (t == kPieces + 1) load_a(s + 3);", "                    else if constexpr (t == kPieces + 1) { if constexpr (!(Z_DIAG & 8)) load_a(s + 3); }"),
-    ("        load_b(q ^ 1, s + 1);\n        __builtin_amdgcn_sched_barrier(0);", "        if constexpr (!(Z_DIAG & 16)) load_b(q ^ 1, s + 1);\n        __builtin_amdgcn_sched_barrier(0);"),
+    ("            read_b(q ^ 1, q == 0 ? bcur : bnxt, q ^ 1);", "            if constexpr (!(Z_DIAG & 16)) read_b(q ^ 1, q == 0 ? bcur : bnxt, q ^ 1);"),
+    ("                    else if constexpr (t == kPieces + 3) { if constexpr (q == 0) write_bpair(bnxt); }", "                    else if constexpr (t == kPieces + 3) { if constexpr (q == 0 && !(Z_DIAG & 16)) write_bpair(bnxt); }"),
+    ("                    else { if constexpr (q == 0) load_bpair(); }", "                    else { if constexpr (q == 0 && !(Z_DIAG & 16)) load_bpair(); }"),
+    ("            load_b(q ^ 1, s + 1);\n        }", "            if constexpr (!(Z_DIAG & 16)) load_b(q ^ 1, s + 1);\n        }"),
     ("                    if constexpr (t < kPieces)\n                        split_piece(", "                    if constexpr (t < kPieces && (Z_DIAG & 32)) {\n                    } else if constexpr (t < kPieces)\n                        split_piece("),
     ("                    else if constexpr (t == kPieces) to_lds();", "                    else if constexpr (t == kPieces) { if constexpr (!(Z_DIAG & 64)) to_lds(); }"),
     ("                    else read_frags();", "                    else { if constexpr (!(Z_DIAG & 64)) read_frags(); }"),
