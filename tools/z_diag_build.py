@@ -35,7 +35,7 @@ PATCHES = [
     ("            load_b(q ^ 1, s + 1);\n        }", "            if constexpr (!(Z_DIAG & 16)) load_b(q ^ 1, s + 1);\n        }"),
     ("                    if constexpr (t < kPieces)\n                        split_piece(", "                    if constexpr (t < kPieces && (Z_DIAG & 32)) {\n                    } else if constexpr (t < kPieces)\n                        split_piece("),
     ("                    else if constexpr (t == kPieces) to_lds();", "                    else if constexpr (t == kPieces) { if constexpr (!(Z_DIAG & 64)) to_lds(); }"),
-    ("                    else read_frags();", "                    else { if constexpr (!(Z_DIAG & 64)) read_frags(); }"),
+    ("                    else if constexpr (t == kPieces + 2) read_frags();", "                    else if constexpr (t == kPieces + 2) { if constexpr (!(Z_DIAG & 64)) read_frags(); }"),
 ]
 
 
