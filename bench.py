@@ -304,10 +304,11 @@ def main():
             timed_op("trunk_fwd", k_trunk)
             timed_op("conv_dgrad", lambda dz, Bt, act_in, layer, out=None, variant=0: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), "F"))
             timed_op("conv_wgrad", k_wgrad)
-            timed_op("conv_fwd_packed", lambda src, pack, bias, layer, out=None: (f"conv{layer}_fwd@{src.shape[0]}", conv_flop(layer, src.shape[0]), "Z"))
-            timed_op("conv_dgrad_packed", lambda dz, pack, act_in, layer, out=None: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), "Z"))
+            timed_op("conv1q_fwd_bits", lambda obs, pack, bias, inds, out, bits: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))
+            timed_op("conv_fwd_packed", lambda src, pack, bias, layer, out=None, bits=None: (f"conv{layer}_fwd@{src.shape[0]}", conv_flop(layer, src.shape[0]), "Z"))
+            timed_op("conv_dgrad_packed", lambda dz, pack, act_in, layer, out=None, bits=None: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), "Z"))
             timed_op("fc_fwd_relu_packed", lambda a, pack, bias, n, out=None: (f"fc_fwd@{a.shape[0]}", 2.0 * a.shape[0] * n * a.shape[1], "Z"))
-            timed_op("fc_dgrad_mask_packed", lambda dz, pack, act_in, out=None: (f"fc_dgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * act_in.shape[1], "Z"))
+            timed_op("fc_dgrad_mask_packed", lambda dz, pack, act_in, out=None, bits=None: (f"fc_dgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * act_in.shape[1], "Z"))
             timed_op("fc_wgrad", lambda dz, a, hwc_channels=0, out=None: (f"fc_wgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * a.shape[1],
                                                                          chr(lib.mi355ppo_fc_wgrad_kernel(dz.shape[0], dz.shape[1], a.shape[1]))))
 

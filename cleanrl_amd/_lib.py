@@ -66,6 +66,10 @@ SIGNATURES = {
     "mi355ppo_fc_dgrad_mask_packed_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_cnn_conv_fwd_packed_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_cnn_conv_dgrad_packed_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "mi355ppo_cnn_conv1q_fwd_bits": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P]),
+    "mi355ppo_cnn_conv_fwd_packed_bits_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
+    "mi355ppo_cnn_conv_dgrad_packed_bits_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "mi355ppo_fc_dgrad_maskbits_packed_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_synth_atari_step_u8": (c_int, [_P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, c_int, c_double, c_int, _P]),
     "mi355ppo_synth_atari_step_ctr_u8": (c_int, [_P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_double, c_int, _P]),
     "mi355ppo_heads_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
@@ -77,7 +81,7 @@ SIGNATURES = {
     "mi355ppo_fc_wgrad_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
 }
 
-ABI_VERSION = 130       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 131       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

@@ -27,6 +27,7 @@ VARIANT_DGRAD2_CLASSES = 6
 QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 storage elements (kernel Q's integer-digit pack)
 VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
 _CONV_Z = os.environ.get("MI355PPO_CONV", "z") != "f"    # layers 2 / 3 forward + data gradients: kernel Z, or the f32-pipe kernel F
+_MASK_BITS = os.environ.get("MI355PPO_MASK_BITS", "1") != "0"   # ReLU masks travel to the data gradients as bits (0: as the f32 activations; A/B runs)
 BUF_LIMIT = (1 << 32) - 8192     # kernels Z / F address a tensor with 32-bit buffer offsets: larger tensors take kernel S (64-bit pointers)
 
 
@@ -174,8 +175,10 @@ def fc_fwd_relu_packed(a: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, 
     return out
 
 
-def fc_dgrad_mask_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-    """``(dz @ B.T) * (act_in > 0)`` with ``pack = fc_pack(B)``, B (N, K) = the transposed weight: kernel Z."""
+def fc_dgrad_mask_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor, out: torch.Tensor | None = None,
+                         bits: torch.Tensor | None = None) -> torch.Tensor:
+    """``(dz @ B.T) * (act_in > 0)`` with ``pack = fc_pack(B)``, B (N, K) = the transposed weight: kernel Z.  ``bits``: the mask
+    ``act_in > 0`` as written by ``conv_fwd_packed(..., bits=)`` (N % 32 == 0); ``act_in`` then only gives the shape."""
     lib = _lib.load()
     M, K = dz.shape
     N = act_in.shape[1]
@@ -186,7 +189,11 @@ def fc_dgrad_mask_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Ten
         out = torch.empty((M, N), dtype=torch.float32, device=dz.device)
     _chk(out, torch.float32, "out", (M, N))
     with _on(dz.device):
-        st = lib.mi355ppo_fc_dgrad_mask_packed_f32(_ptr(dz), lddz, _ptr(pack), _ptr(act_in), _ptr(out), M, N, K, _stream(dz.device))
+        if bits is not None:
+            _chk(bits, torch.int32, "bits", (mask_words(M * N),))
+            st = lib.mi355ppo_fc_dgrad_maskbits_packed_f32(_ptr(dz), lddz, _ptr(pack), _ptr(bits), _ptr(out), M, N, K, _stream(dz.device))
+        else:
+            st = lib.mi355ppo_fc_dgrad_mask_packed_f32(_ptr(dz), lddz, _ptr(pack), _ptr(act_in), _ptr(out), M, N, K, _stream(dz.device))
     _lib.check(st, "mi355ppo_fc_dgrad_mask_packed_f32")
     return out
 
@@ -201,8 +208,40 @@ def conv_zpack(W: torch.Tensor, layer: int, mode: int, out: torch.Tensor | None 
     return fc_pack(repack_weights(W, layer, mode).view(n, k), out)
 
 
-def conv_fwd_packed(src: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, layer: int, out: torch.Tensor | None = None) -> torch.Tensor:
-    """``relu(conv(src) + bias)`` of layer 2 / 3 on kernel Z (csrc/gemmz.hip); ``pack = conv_zpack(W, layer, MODE_FWD)``."""
+def mask_words(numel: int) -> int:
+    """uint32 words of a ReLU bit mask over ``numel`` activation elements (bit b of word w <-> flat element 32 w + b)."""
+    assert numel % 32 == 0
+    return numel // 32
+
+
+def unpack_mask_bits(bits: torch.Tensor, shape) -> torch.Tensor:
+    """The bit mask written by the ``*_bits`` forwards as a bool tensor of the activation's shape (tests, debugging)."""
+    w = bits.view(-1).to(torch.int64) & 0xFFFFFFFF
+    return ((w[:, None] >> torch.arange(32, device=bits.device)) & 1).bool().view(*shape)
+
+
+def conv1q_fwd_bits(obs_u8: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, inds: torch.Tensor | None, out: torch.Tensor,
+                    bits: torch.Tensor) -> torch.Tensor:
+    """Layer-1 forward on kernel Q that also writes ``(out > 0)`` as bits (``bits``: int32, ``out.numel() // 32`` words)."""
+    lib = _lib.load()
+    _chk(obs_u8, torch.uint8, "src")
+    images = obs_u8.shape[0] if inds is None else inds.numel()
+    if inds is not None:
+        _chk(inds, torch.int64, "inds")
+    _chk(pack, torch.float32, "Bt", (QPACK_NUMEL,))
+    _chk(bias, torch.float32, "bias", (32,))
+    _chk(out, torch.float32, "out", (images, 20, 20, 32))
+    _chk(bits, torch.int32, "bits", (mask_words(out.numel()),))
+    with _on(obs_u8.device):
+        st = lib.mi355ppo_cnn_conv1q_fwd_bits(_ptr(obs_u8), _ptr(inds), _ptr(pack), _ptr(bias), _ptr(out), _ptr(bits), images, _stream(obs_u8.device))
+    _lib.check(st, "mi355ppo_cnn_conv1q_fwd_bits")
+    return out
+
+
+def conv_fwd_packed(src: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, layer: int, out: torch.Tensor | None = None,
+                    bits: torch.Tensor | None = None) -> torch.Tensor:
+    """``relu(conv(src) + bias)`` of layer 2 / 3 on kernel Z (csrc/gemmz.hip); ``pack = conv_zpack(W, layer, MODE_FWD)``.
+    ``bits`` (int32, ``out.numel() // 32`` words): also receives ``(out > 0)`` as a bit mask."""
     lib = _lib.load()
     cin, cout, k, _, hin, hout = LAYERS[layer]
     images = src.shape[0]
@@ -213,25 +252,36 @@ def conv_fwd_packed(src: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, l
         out = torch.empty((images, hout, hout, cout), dtype=torch.float32, device=src.device)
     _chk(out, torch.float32, "out", (images, hout, hout, cout))
     with _on(src.device):
-        st = lib.mi355ppo_cnn_conv_fwd_packed_f32(_ptr(src), _ptr(pack), _ptr(bias), _ptr(out), images, layer, _stream(src.device))
+        if bits is not None:
+            _chk(bits, torch.int32, "bits", (mask_words(out.numel()),))
+            st = lib.mi355ppo_cnn_conv_fwd_packed_bits_f32(_ptr(src), _ptr(pack), _ptr(bias), _ptr(out), _ptr(bits), images, layer, _stream(src.device))
+        else:
+            st = lib.mi355ppo_cnn_conv_fwd_packed_f32(_ptr(src), _ptr(pack), _ptr(bias), _ptr(out), images, layer, _stream(src.device))
     _lib.check(st, "mi355ppo_cnn_conv_fwd_packed_f32")
     return out
 
 
-def conv_dgrad_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor, layer: int, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Data gradient of layer 2 / 3 masked by ``act_in > 0`` on kernel Z; ``pack = conv_zpack(W, layer, MODE_DGRAD_S2 / _S1)``."""
+def conv_dgrad_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor | None, layer: int, out: torch.Tensor | None = None,
+                      bits: torch.Tensor | None = None) -> torch.Tensor:
+    """Data gradient of layer 2 / 3 masked by ``act_in > 0`` on kernel Z; ``pack = conv_zpack(W, layer, MODE_DGRAD_S2 / _S1)``.
+    ``bits``: the mask as written by the layer below's ``*_bits`` forward instead of ``act_in`` (which may then be None)."""
     lib = _lib.load()
     cin, cout, k, _, hin, hout = LAYERS[layer]
     images = dz.shape[0]
     _chk(dz, torch.float32, "dz", (images, hout, hout, cout))
-    _chk(act_in, torch.float32, "act_in", (images, hin, hin, cin))
+    if bits is None:
+        _chk(act_in, torch.float32, "act_in", (images, hin, hin, cin))
     n, kk = ZPACK_SHAPE[(layer, MODE_DGRAD_S2 if layer == 2 else MODE_DGRAD_S1)]
     _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(n, kk),))
     if out is None:
-        out = torch.empty_like(act_in)
+        out = torch.empty((images, hin, hin, cin), dtype=torch.float32, device=dz.device)
     _chk(out, torch.float32, "out", (images, hin, hin, cin))
     with _on(dz.device):
-        st = lib.mi355ppo_cnn_conv_dgrad_packed_f32(_ptr(dz), _ptr(pack), _ptr(act_in), _ptr(out), images, layer, _stream(dz.device))
+        if bits is not None:
+            _chk(bits, torch.int32, "bits", (mask_words(out.numel()),))
+            st = lib.mi355ppo_cnn_conv_dgrad_packed_bits_f32(_ptr(dz), _ptr(pack), _ptr(bits), _ptr(out), images, layer, _stream(dz.device))
+        else:
+            st = lib.mi355ppo_cnn_conv_dgrad_packed_f32(_ptr(dz), _ptr(pack), _ptr(act_in), _ptr(out), images, layer, _stream(dz.device))
     _lib.check(st, "mi355ppo_cnn_conv_dgrad_packed_f32")
     return out
 
@@ -289,6 +339,7 @@ class _Buffers:
         self.weights_version = 0
         self._bt = {}
         self.last_a3_ptr = None            # data pointer of the a3 the trunk produced last (LinearReLUHwcFn checks its input is it)
+        self.last_a3_bits = None           # ... and its ReLU mask as bits, when the trunk's forward wrote one (kernel Z, gradients enabled)
         self.a3_grad_is_masked = False     # set by LinearReLUHwcFn.backward when conv3's ReLU backward rode in the FC data gradient
         self.fc_dz_from_heads = None       # (data pointer of dz, FC bias gradient) when the FC layer's ReLU backward rode in HeadsFn.backward
 
@@ -365,6 +416,15 @@ class _Buffers:
             self._bt[key] = hit
         return hit[1]
 
+    def get_bits(self, m: int, dev):
+        """ReLU masks of a1, a2, a3 as bits (int32 words; one set per batch size and stream, like the activations)."""
+        key = ("bits", m, dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+        b = self.by_m.get(key)
+        if b is None:
+            b = [torch.empty(mask_words(m * n), dtype=torch.int32, device=dev) for n in (20 * 20 * 32, 9 * 9 * 64, 7 * 7 * 64)]
+            self.by_m[key] = b
+        return b
+
     def get(self, m: int, dev, grads: bool):
         # one set per (batch size, stream): the env-group lanes of a rollout (pipeline.py) run the same batch size concurrently
         key = (m, dev, grads, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
@@ -380,20 +440,31 @@ class NatureTrunkFn(torch.autograd.Function):
     """a3 = relu(conv3(relu(conv2(relu(conv1(obs[inds] / 255)))))) as one autograd node; a3 is (M, 7, 7, 64)."""
 
     @staticmethod
-    def forward(ctx, obs_u8, inds, W1, b1, W2, b2, W3, b3, bufs):
+    def forward(ctx, obs_u8, inds, W1, b1, W2, b2, W3, b3, bufs, want_bits=False):
         m = obs_u8.shape[0] if inds is None else inds.numel()
         a1, a2, a3 = bufs.get(m, obs_u8.device, False)
         if a1.numel() * 4 >= BUF_LIMIT:     # beyond 32-bit buffer offsets: the f32-pipe kernels with 64-bit pointers (kernel S) throughout
             conv_fwd(obs_u8, bufs.weights(W1, 1, MODE_FWD), b1.detach(), 1, inds, a1)
             conv_fwd(a1, bufs.weights(W2, 2, MODE_FWD), b2.detach(), 2, None, a2)
             conv_fwd(a2, bufs.weights(W3, 3, MODE_FWD), b3.detach(), 3, None, a3)
-            ctx.obs, ctx.inds, ctx.acts, ctx.bufs = obs_u8, inds, (a1, a2, a3), bufs
-            bufs.last_a3_ptr = a3.data_ptr()
+            ctx.obs, ctx.inds, ctx.acts, ctx.bufs, ctx.bits = obs_u8, inds, (a1, a2, a3), bufs, None
+            bufs.last_a3_ptr, bufs.last_a3_bits = a3.data_ptr(), None
             ctx.save_for_backward(W2, W3)
             return a3
         # layer 1 runs on the integer matrix pipe (kernel Q): uint8 taps are exact int8 operands, weights four int8 digits
         bt1 = bufs.weights(W1, 1, MODE_FWD_Q)
-        if _CONV_Z:                 # layers 2 and 3 on kernel Z (bf16 pipe, pre-split weights, coalesced window loads)
+        ctx.bits = None
+        bufs.last_a3_bits = None
+        if _CONV_Z and _MASK_BITS and want_bits and any(ctx.needs_input_grad):
+            # a backward will follow (the caller saw gradients enabled; inside forward() they never are): every forward also writes its ReLU mask as bits -- the data gradients then read 1/32 of the
+            # mask bytes (the f32 activations stay: the weight gradients read them)
+            mb1, mb2, mb3 = bufs.get_bits(m, obs_u8.device)
+            conv1q_fwd_bits(obs_u8, bt1, b1.detach(), inds, a1, mb1)
+            conv_fwd_packed(a1, bufs.conv_zpack(W2, 2, MODE_FWD), b2.detach(), 2, a2, bits=mb2)
+            conv_fwd_packed(a2, bufs.conv_zpack(W3, 3, MODE_FWD), b3.detach(), 3, a3, bits=mb3)
+            ctx.bits = (mb1, mb2, mb3)
+            bufs.last_a3_bits = mb3
+        elif _CONV_Z:               # layers 2 and 3 on kernel Z (bf16 pipe, pre-split weights, coalesced window loads)
             conv_fwd(obs_u8, bt1, b1.detach(), 1, inds, a1, variant=VARIANT_Q)
             conv_fwd_packed(a1, bufs.conv_zpack(W2, 2, MODE_FWD), b2.detach(), 2, a2)
             conv_fwd_packed(a2, bufs.conv_zpack(W3, 3, MODE_FWD), b3.detach(), 3, a3)
@@ -423,21 +494,22 @@ class NatureTrunkFn(torch.autograd.Function):
         dW3, db3 = conv_wgrad(a2, dz3, 3)
         # (layer-3 data gradient: kernel Z multiplies the padding taps, 1.65 x the MFMAs, and still beats kernel F's nine
         # border-class launches at every size measured: profiles/r03_conv_traffic_ab_same_box.jsonl)
+        bits = ctx.bits
         if _CONV_Z and a2.numel() * 4 < BUF_LIMIT:
-            conv_dgrad_packed(dz3, ctx.bufs.conv_zpack(W3, 3, MODE_DGRAD_S1), a2, 3, dz2)
+            conv_dgrad_packed(dz3, ctx.bufs.conv_zpack(W3, 3, MODE_DGRAD_S1), a2, 3, dz2, bits=bits[1] if bits else None)
         elif a2.numel() * 4 < BUF_LIMIT:            # the border-class kernels address tensors with 32-bit buffer offsets
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # no padding zeros
         else:
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1), a2, 3, dz2)
         dW2, db2 = conv_wgrad(a1, dz2, 2)
         if _CONV_Z and a1.numel() * 4 < BUF_LIMIT:
-            conv_dgrad_packed(dz2, ctx.bufs.conv_zpack(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
+            conv_dgrad_packed(dz2, ctx.bufs.conv_zpack(W2, 2, MODE_DGRAD_S2), a1, 2, dz1, bits=bits[0] if bits else None)
         elif a1.numel() * 4 < BUF_LIMIT:
             conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2_CLASSES), a1, 2, dz1, variant=VARIANT_DGRAD2_CLASSES)   # no padding zeros
         else:
             conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
         dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds)
-        return None, None, dW1, db1, dW2, db2, dW3, db3, None
+        return None, None, dW1, db1, dW2, db2, dW3, db3, None, None
 
 
 class NatureTrunk:
@@ -449,7 +521,7 @@ class NatureTrunk:
 
     def __call__(self, obs_u8, inds, conv1, conv2, conv3):
         a3 = NatureTrunkFn.apply(obs_u8, inds, conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight,
-                                 conv3.bias, self.bufs)
+                                 conv3.bias, self.bufs, torch.is_grad_enabled())
         return a3.reshape(a3.shape[0], -1)
 
 
@@ -499,7 +571,7 @@ class LinearReLUHwcFn(torch.autograd.Function):
             if fused:
                 # `a` is the trunk's ReLU output a3: its ReLU backward rides in this GEMM's epilogue (kernel Z, Z_MASK) and
                 # NatureTrunkFn.backward is told not to mask again -- the separate pass over the 411 MB tensor is gone
-                da = fc_dgrad_mask_packed(dz, bufs.fc_pack_dgrad(W), a)
+                da = fc_dgrad_mask_packed(dz, bufs.fc_pack_dgrad(W), a, bits=bufs.last_a3_bits)
                 bufs.a3_grad_is_masked = True
             else:
                 da = dz @ Wp

@@ -99,10 +99,18 @@ __global__ __launch_bounds__(256) void conv1q_pack_kernel(const float* __restric
     if (tid < 32) reinterpret_cast<float*>(pack + kQScaleOff)[tid] = (float)(ldexp(1.0, s_E[tid] - 6) / 255.0);
 }
 
-template <int NW>
+// lane `l` of w := the wave-uniform value x
+__device__ __forceinline__ int q_writelane(int w, unsigned x, int l) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(x), "i"(l));
+    return w;
+}
+
+// BITS: also writes (dst > 0) as one bit per element -- word p = the 32 channels of pixel p -- the ReLU mask the layer-2 data
+// gradient needs (mi355ppo_cnn_conv_dgrad_packed_bits_f32 reads 1,600 bytes per image instead of the 51,200-byte activation).
+template <int NW, bool BITS>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv1q_fwd_kernel(const unsigned char* __restrict__ src, const int64_t* __restrict__ inds,
                                                              const unsigned char* __restrict__ pack, const float* __restrict__ bias,
-                                                             float* __restrict__ dst, unsigned P, int ntiles, unsigned dst_bytes) {
+                                                             float* __restrict__ dst, unsigned* __restrict__ bits, unsigned P, int ntiles, unsigned dst_bytes) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     // digit matrices, in operand layout, -> LDS [row][digit][lane]
@@ -118,6 +126,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const float scale = reinterpret_cast<const float*>(pack + kQScaleOff)[li];
     const float bias_r = bias[li];
     const __amdgpu_buffer_rsrc_t rsrc_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, kQRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsrc_bits = __builtin_amdgcn_make_buffer_rsrc(bits, 0, BITS ? (int)(dst_bytes >> 5) : 0, kQRsrcWord3);
     const int nwv = gridDim.x * NW;
 
     // pointer to byte 16*lh of tap row 0 of the lane's pixel of `tile` (pixels past P read pixel 0: results dropped).
@@ -173,6 +182,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
             const unsigned p = (unsigned)tile * 32u + (unsigned)li;
             if (p < P) myoff = p * 128u;                                  // pixel-major (N,20,20,32) f32: 128 bytes per pixel
         }
+        int wv = 0;                                                       // BITS: lane L (< 32) collects the mask word of pixel L of the tile
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const unsigned off = (unsigned)__shfl((int)myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64) + (unsigned)(li * 4);
@@ -184,7 +194,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
             v = v + bias_r;
             v = v > 0.0f ? v : 0.0f;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_dst, off, 0, 0);   // dropped when out of range
+            if constexpr (BITS) {      // ballot lanes 0..31: the 32 channels of pixel (e & 3) + 8 (e >> 2); lanes 32..63: of that pixel + 4
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.0f);
+                wv = q_writelane(wv, (unsigned)bal, (e & 3) + 8 * (e >> 2));
+                wv = q_writelane(wv, (unsigned)(bal >> 32), (e & 3) + 8 * (e >> 2) + 4);
+            }
         }
+        if constexpr (BITS)            // myoff = 128 p (or out of range): word p sits at byte 4 p
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)wv, rsrc_bits, (lh == 0 && myoff != kQOob) ? myoff >> 5 : kQOob, 0, 0);
         cur = nxt;
         nxt = setup(tile + 2 * nwv);
     }
@@ -206,14 +223,13 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_pack(const float* W, void* pack,
     return check_launch(fn);
 }
 
-extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_fwd(const void* src_u8, const int64_t* inds, const void* pack, const float* bias,
-                                                    float* dst, int64_t images, void* stream) {
-    const char* fn = "mi355ppo_cnn_conv1q_fwd";
+static int conv1q_fwd_impl(const char* fn, const void* src_u8, const int64_t* inds, const void* pack, const float* bias, float* dst,
+                           unsigned* bits, int64_t images, void* stream) {
     MI355_REQUIRE(src_u8 && pack && bias && dst, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
-    MI355_REQUIRE(aligned(src_u8, 16) && aligned(pack, 16) && aligned(dst, 16) && aligned(inds, 8) && aligned(bias, 4),
-                  MI355PPO_EALIGN, "%s: src/pack/dst must be 16-byte aligned", fn);
+    MI355_REQUIRE(aligned(src_u8, 16) && aligned(pack, 16) && aligned(dst, 128) && aligned(inds, 8) && aligned(bias, 4) && aligned(bits, 4),
+                  MI355PPO_EALIGN, "%s: src/pack must be 16-byte aligned, dst 128-byte aligned", fn);
     const long long P = (long long)images * kQPerImg, dstb = P * 128;
     MI355_REQUIRE(dstb <= (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: destination of %lld bytes exceeds the 32-bit buffer range", fn, dstb);
     if (g_q_cus == 0) {
@@ -228,8 +244,25 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_fwd(const void* src_u8, const in
     constexpr int NW = 4;
     long long wgs = (long long)g_q_cus * 3;                   // three 4-wave workgroups per CU = three waves per SIMD
     if (wgs * NW > ntiles) wgs = (ntiles + NW - 1) / NW;
-    hipLaunchKernelGGL((conv1q_fwd_kernel<NW>), dim3((unsigned)wgs), dim3(64 * NW), 0, as_stream(stream),
-                       static_cast<const unsigned char*>(src_u8), inds, static_cast<const unsigned char*>(pack), bias, dst, (unsigned)P,
-                       ntiles, (unsigned)dstb);
+    if (bits)
+        hipLaunchKernelGGL((conv1q_fwd_kernel<NW, true>), dim3((unsigned)wgs), dim3(64 * NW), 0, as_stream(stream),
+                           static_cast<const unsigned char*>(src_u8), inds, static_cast<const unsigned char*>(pack), bias, dst, bits, (unsigned)P,
+                           ntiles, (unsigned)dstb);
+    else
+        hipLaunchKernelGGL((conv1q_fwd_kernel<NW, false>), dim3((unsigned)wgs), dim3(64 * NW), 0, as_stream(stream),
+                           static_cast<const unsigned char*>(src_u8), inds, static_cast<const unsigned char*>(pack), bias, dst, bits, (unsigned)P,
+                           ntiles, (unsigned)dstb);
     return check_launch(fn);
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_fwd(const void* src_u8, const int64_t* inds, const void* pack, const float* bias,
+                                                    float* dst, int64_t images, void* stream) {
+    return conv1q_fwd_impl("mi355ppo_cnn_conv1q_fwd", src_u8, inds, pack, bias, dst, nullptr, images, stream);
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_fwd_bits(const void* src_u8, const int64_t* inds, const void* pack, const float* bias,
+                                                         float* dst, uint32_t* mask_bits, int64_t images, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv1q_fwd_bits";
+    MI355_REQUIRE(mask_bits, MI355PPO_EINVAL, "%s: null pointer", fn);
+    return conv1q_fwd_impl(fn, src_u8, inds, pack, bias, dst, mask_bits, images, stream);
 }

@@ -35,7 +35,27 @@ namespace mi355ppo {
 
 typedef float z_f32x16 __attribute__((ext_vector_type(16)));
 
-enum { Z_BIAS_RELU = 0, Z_MASK = 1, Z_MASK_CLS4 = 2 };
+// Epilogues.  Z_BIAS_RELU: C = relu(acc + bias); Z_MASK / Z_MASK_CLS4: C = acc where mask > 0 (an f32 tensor of C's shape: the forward
+// activation), else 0.  The *_BITS / Z_MASKB* variants carry the ReLU mask as ONE BIT per element instead (word w, bit b <-> element
+// 32 w + b of the flat tensor; set where the activation is > 0): the forward writes the words beside its f32 output (a ballot per
+// accumulator row, one 32-lane store per 32 x 32 tile), the data gradient fetches one word per row and column tile (a wave
+// instruction per 64 x 32 tile instead of thirty-two) and selects by lane mask -- 1/32 of the mask bytes (the three data gradients
+// read 2.8 GB of masks per 32,768-image minibatch otherwise).
+// lane `l` of w := the wave-uniform value x (v_writelane_b32; hipcc 7.2 has no builtin for it)
+__device__ __forceinline__ int z_writelane(int w, unsigned x, int l) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(x), "i"(l));
+    return w;
+}
+
+enum { Z_BIAS_RELU = 0, Z_MASK = 1, Z_MASK_CLS4 = 2, Z_MASKB = 3, Z_MASKB_CLS4 = 4, Z_BIAS_RELU_BITS = 5 };
+
+// x where bit (lane) of the 64-bit lane mask {hi, lo} is set, else 0: one v_cndmask with the mask in an SGPR pair.
+__device__ __forceinline__ float z_keep_where(float x, unsigned lo, unsigned hi) {
+    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    return r;
+}
 constexpr int kZPitch = 20;                           // floats per LDS row: 16 k + 4 pad (80 bytes)
 constexpr int kZTileBytes = 3 * 64 * 16;              // one 32-column tile of one k-step in the pack: 3 terms x 1 KiB
 constexpr unsigned kZOob = 0xFFFFF000u;               // buffer offset out of range for every tensor < 4 GiB - 4 KiB
@@ -142,6 +162,8 @@ struct ZArgs {
     const unsigned char* pack;  // B, pre-split (zpack_kernel)
     const float* bias;          // Z_BIAS_RELU
     const float* mask;          // Z_MASK*: C is zeroed where mask <= 0 (same indexing as C)
+    const unsigned* bits_in;    // Z_MASKB*: the same mask as bits (word w, bit b = element 32 w + b of C's flat tensor)
+    unsigned* bits_out;         // Z_BIAS_RELU_BITS: (C > 0) as bits, written beside C
     float* C;
     unsigned c_bytes;           // size of C (and of the mask, which has C's shape): buffer range check
     int ldc;                    // GEMM rows: leading dimension of C; convolution rows: unused (DC)
@@ -511,7 +533,12 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     // return 0, their stores are dropped -- so the epilogue has no branches and no per-access waits.
     const unsigned c_bytes = a.c_bytes;
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)c_bytes, kZRsrcWord3);
-    const __amdgpu_buffer_rsrc_t rsrc_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask), 0, EPI != Z_BIAS_RELU ? (int)c_bytes : 0, kZRsrcWord3);
+    constexpr bool kCls4 = EPI == Z_MASK_CLS4 || EPI == Z_MASKB_CLS4, kMaskF32 = EPI == Z_MASK || EPI == Z_MASK_CLS4,
+                   kMaskBits = EPI == Z_MASKB || EPI == Z_MASKB_CLS4, kBitsOut = EPI == Z_BIAS_RELU_BITS;
+    static_assert(!(kMaskBits || kBitsOut) || ROWS == 64, "bit masks: one word per lane = one row of the wave's 64");
+    const __amdgpu_buffer_rsrc_t rsrc_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask), 0, kMaskF32 ? (int)c_bytes : 0, kZRsrcWord3);
+    const void* const bits_base = kMaskBits ? (const void*)a.bits_in : (const void*)a.bits_out;
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(bits_base), 0, (kMaskBits || kBitsOut) ? (int)(c_bytes >> 5) : 0, kZRsrcWord3);
     const int ldc = RG::CONV ? RG::DC : a.ldc;
     auto row_off = [&](long long m) -> unsigned {
         if constexpr (RG::CLS) {                          // computed for every row, selected at the end: an early exit would put a
@@ -522,7 +549,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             return ok ? off : kZOob;
         }
         if (m >= M) return kZOob;
-        if constexpr (EPI == Z_MASK_CLS4) {
+        if constexpr (kCls4) {
             const long long img = m / RG::PER_IMG;
             const int rem = (int)(m - img * RG::PER_IMG), gy = rem / RG::GX, gx = rem - gy * RG::GX;
             return (unsigned)((((int)img * RG::DH + gy * RG::DM) * RG::DW + gx * RG::DM) * RG::DC) * 4u;
@@ -533,11 +560,38 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     unsigned coff[NT];                                    // byte offset of this lane's column in tile j (out of range past N)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        if constexpr (EPI == Z_MASK_CLS4) coff[j] = (unsigned)((((j0 + j) >> 1) * RG::DW + ((j0 + j) & 1)) * RG::DC + li) * 4u;
+        if constexpr (kCls4) coff[j] = (unsigned)((((j0 + j) >> 1) * RG::DW + ((j0 + j) & 1)) * RG::DC + li) * 4u;
         else coff[j] = n0 + 32 * j + li < N ? (unsigned)(n0 + 32 * j + li) * 4u : kZOob;
     }
     auto at = [&](unsigned ro, int j) -> unsigned { return (ro == kZOob || coff[j] == kZOob) ? kZOob : ro + coff[j]; };
-    if constexpr (EPI != Z_BIAS_RELU) {
+    if constexpr (kMaskBits) {
+        // lane L holds the mask word of row m0 + L for each of the wave's column tiles: C's element (row, column n) is bit n % 32 of
+        // word (byte offset of the element) / 128 -- every 32-column tile of a row starts on a 128-byte boundary of C
+        unsigned wm[NT];
+        {
+            const unsigned ro = row_off(m0 + lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                unsigned o = kZOob;
+                if constexpr (kCls4) o = ro == kZOob ? kZOob : (ro + (unsigned)((((j0 + j) >> 1) * RG::DW + ((j0 + j) & 1)) * RG::DC) * 4u) >> 5;
+                else o = (ro == kZOob || n0 + 32 * j >= N) ? kZOob : (ro + (unsigned)(n0 + 32 * j) * 4u) >> 5;
+                wm[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_b, o, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned ro = row_off(m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wm[j], 32 * i + (e & 3) + 8 * (e >> 2));
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)wm[j], 32 * i + (e & 3) + 8 * (e >> 2) + 4);
+                    const float v = z_keep_where(acc[i][j][e], lo, hi);       // lanes 0..31 (lh = 0): bit li of `lo`, lanes 32..63: of `hi`
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, at(ro, j), 0, 0);
+                }
+            }
+    } else if constexpr (kMaskF32) {
         // The mask values are requested before the first one is used -- of the wave's whole block with one wave per SIMD (nothing
         // else hides a load's latency there), of one 32-row tile at a time with two waves per SIMD (registers).
         constexpr int IB = OCC == 1 ? MT : 1;                                       // 32-row tiles per batch
@@ -572,7 +626,10 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             bj[j] = a.bias[n < N ? n : N - 1];
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
+            int wv[NT];                                   // kBitsOut: lane L (< 32) collects the mask word of row m0 + 32 i + L
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wv[j] = 0;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const unsigned ro = row_off(m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
@@ -581,8 +638,22 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
                     float v = acc[i][j][e] + bj[j];
                     v = v > 0.0f ? v : 0.0f;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, at(ro, j), 0, 0);
+                    if constexpr (kBitsOut) {             // lanes 0..31 of the ballot: the 32 columns of row (e & 3) + 8 (e >> 2); 32..63: of that row + 4
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.0f);
+                        wv[j] = z_writelane(wv[j], (unsigned)bal, (e & 3) + 8 * (e >> 2));
+                        wv[j] = z_writelane(wv[j], (unsigned)(bal >> 32), (e & 3) + 8 * (e >> 2) + 4);
+                    }
                 }
             }
+            if constexpr (kBitsOut) {
+                const unsigned ro = lh == 0 ? row_off(m0 + 32 * i + li) : kZOob;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const unsigned o = (ro == kZOob || n0 + 32 * j >= N) ? kZOob : (ro + (unsigned)(n0 + 32 * j) * 4u) >> 5;
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)wv[j], rsrc_b, o, 0, 0);
+                }
+            }
+        }
     }
 }
 
@@ -655,6 +726,7 @@ static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, 
                    long long c_bytes, int ldc, long long M, int N, int K, long long images = 0) {
     ZArgs a;
     a.A = A; a.a_bytes = (unsigned)a_bytes; a.lda = lda; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.mask = mask;
+    a.bits_in = nullptr; a.bits_out = nullptr;
     a.C = C; a.c_bytes = (unsigned)c_bytes; a.ldc = ldc; a.M = M; a.images = images; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
     return a;
 }
@@ -673,61 +745,114 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int 
     return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(za, as_stream(stream), fn);
 }
 
-extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, int lddz, const void* pack, const float* act_in, float* da,
-                                                              int M, int N, int K, void* stream) {
-    const char* fn = "mi355ppo_fc_dgrad_mask_packed_f32";
+static int fc_dgrad_impl(const char* fn, const float* dz, int lddz, const void* pack, const float* act_in, const unsigned* bits, float* da,
+                         int M, int N, int K, void* stream) {
     int rc = zgemm_check(fn, dz, pack, da, M, N, K, lddz, N);
     if (rc) return rc;
-    MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
-    const ZArgs za = zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, (long long)M * N * 4, N, M, N, K);
+    ZArgs za = zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, (long long)M * N * 4, N, M, N, K);
     // (the B ring -- z_launch<..., 1, true> for even K / 16 -- measured 630 -> 720 us here: one wave per SIMD has nothing to run while
     // it waits at the ring barrier; profiles/r03_blds_ab.jsonl)
+    if (bits) {
+        MI355_REQUIRE(N % 32 == 0 && aligned(bits, 4) && aligned(da, 128), MI355PPO_EINVAL, "%s: bit masks need N %% 32 == 0 (N=%d) and da on a 128-byte boundary", fn, N);
+        za.bits_in = bits;
+        return z_launch<ZRowsLinear, 2, 4, 4, Z_MASKB, false>(za, as_stream(stream), fn);
+    }
+    MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);
     return z_launch<ZRowsLinear, 2, 4, 4, Z_MASK, false>(za, as_stream(stream), fn);
+}
+
+extern "C" MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, int lddz, const void* pack, const float* act_in, float* da,
+                                                              int M, int N, int K, void* stream) {
+    return fc_dgrad_impl("mi355ppo_fc_dgrad_mask_packed_f32", dz, lddz, pack, act_in, nullptr, da, M, N, K, stream);
+}
+
+// The same with the ReLU mask as bits (word w, bit b <-> element 32 w + b of the flat (M, N) activation; N % 32 == 0), as written by
+// mi355ppo_cnn_conv_fwd_packed_bits_f32 for the layer below.
+extern "C" MI355PPO_API int mi355ppo_fc_dgrad_maskbits_packed_f32(const float* dz, int lddz, const void* pack, const uint32_t* mask_bits,
+                                                                  float* da, int M, int N, int K, void* stream) {
+    const char* fn = "mi355ppo_fc_dgrad_maskbits_packed_f32";
+    MI355_REQUIRE(mask_bits, MI355PPO_EINVAL, "%s: null pointer", fn);
+    return fc_dgrad_impl(fn, dz, lddz, pack, nullptr, mask_bits, da, M, N, K, stream);
 }
 
 // ---- convolutions of layers 2 and 3 on kernel Z.  `pack` = mi355ppo_fc_pack_f32 of the layer's (N, K) f32 matrix from
 // mi355ppo_cnn_repack_weights_f32: mode 0 for the forward (N = 64 output channels, K = (tap row, tap column, input channel)),
 // mode 1 for the layer-3 data gradient (N = 64 input channels, K = (r, c, output channel), taps flipped), mode 2 for the
 // layer-2 data gradient (N = 4 stride-parity classes x 32 input channels, K = (r, c, output channel)).
-extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, const void* pack, const float* bias, float* dst,
-                                                             int64_t images, int layer, void* stream) {
-    const char* fn = "mi355ppo_cnn_conv_fwd_packed_f32";
+static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pack, const float* bias, float* dst, unsigned* bits,
+                                int64_t images, int layer, void* stream) {
     MI355_REQUIRE(src && pack && bias && dst, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer == 2 || layer == 3, MI355PPO_EINVAL, "%s: layer=%d must be 2 or 3", fn, layer);
     MI355_REQUIRE(images > 0, MI355PPO_EINVAL, "%s: images=%lld must be positive", fn, (long long)images);
-    MI355_REQUIRE(aligned(src, 16) && aligned(pack, 16) && aligned(dst, 16) && aligned(bias, 4), MI355PPO_EALIGN, "%s: src / pack / dst must be 16-byte aligned", fn);
+    MI355_REQUIRE(aligned(src, 16) && aligned(pack, 16) && aligned(dst, 128) && aligned(bias, 4) && aligned(bits, 4), MI355PPO_EALIGN,
+                  "%s: src / pack must be 16-byte aligned, dst 128-byte aligned", fn);
     const long long srcb = (long long)images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4;
     MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: the source (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);   // (the destination is smaller)
+    hipStream_t st = as_stream(stream);
     if (layer == 2) {
-        const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K);
-        if (z_blds(images)) return z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, as_stream(stream), fn);
-        return z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
+        ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K);
+        za.bits_out = bits;
+        if (bits) return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2>(za, st, fn);
+        return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
     }
-    const ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
-    if (z_blds(images)) return z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, as_stream(stream), fn);
-    return z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, as_stream(stream), fn);
+    ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
+    za.bits_out = bits;
+    if (bits) return z_blds(images) ? z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2, true>(za, st, fn) : z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2>(za, st, fn);
+    return z_blds(images) ? z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, st, fn) : z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
 }
 
-extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, const void* pack, const float* act_in, float* dsrc,
-                                                               int64_t images, int layer, void* stream) {
-    const char* fn = "mi355ppo_cnn_conv_dgrad_packed_f32";
-    MI355_REQUIRE(dz && pack && act_in && dsrc, MI355PPO_EINVAL, "%s: null pointer", fn);
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, const void* pack, const float* bias, float* dst,
+                                                             int64_t images, int layer, void* stream) {
+    return conv_fwd_packed_impl("mi355ppo_cnn_conv_fwd_packed_f32", src, pack, bias, dst, nullptr, images, layer, stream);
+}
+
+// The same, also writing (dst > 0) as bits (images * 81 * 2 words for layer 2, images * 49 * 2 for layer 3): the mask the data
+// gradient of the layer ABOVE needs (mi355ppo_cnn_conv_dgrad_packed_bits_f32 / mi355ppo_fc_dgrad_maskbits_packed_f32).
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_bits_f32(const float* src, const void* pack, const float* bias, float* dst,
+                                                                  uint32_t* mask_bits, int64_t images, int layer, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_fwd_packed_bits_f32";
+    MI355_REQUIRE(mask_bits, MI355PPO_EINVAL, "%s: null pointer", fn);
+    return conv_fwd_packed_impl(fn, src, pack, bias, dst, mask_bits, images, layer, stream);
+}
+
+static int conv_dgrad_packed_impl(const char* fn, const float* dz, const void* pack, const float* act_in, const unsigned* bits, float* dsrc,
+                                  int64_t images, int layer, void* stream) {
+    MI355_REQUIRE(dz && pack && (act_in || bits) && dsrc, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer == 2 || layer == 3, MI355PPO_EINVAL, "%s: layer=%d must be 2 or 3", fn, layer);
     MI355_REQUIRE(images > 0, MI355PPO_EINVAL, "%s: images=%lld must be positive", fn, (long long)images);
-    MI355_REQUIRE(aligned(dz, 16) && aligned(pack, 16) && aligned(dsrc, 16) && aligned(act_in, 16), MI355PPO_EALIGN,
-                  "%s: dz / pack / act_in / dsrc must be 16-byte aligned", fn);
+    MI355_REQUIRE(aligned(dz, 16) && aligned(pack, 16) && aligned(dsrc, 128) && aligned(act_in, 16) && aligned(bits, 4), MI355PPO_EALIGN,
+                  "%s: dz / pack / act_in must be 16-byte aligned, dsrc 128-byte aligned", fn);
     MI355_REQUIRE(act_in != dsrc, MI355PPO_EINVAL, "%s: act_in must not alias dsrc", fn);
     const long long srcb = (long long)images * (layer == 2 ? 9 * 9 * 64 : 7 * 7 * 64) * 4;
     const long long dstb = (long long)images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4;
     MI355_REQUIRE(srcb < (1LL << 32) - 8192 && dstb < (1LL << 32) - 8192, MI355PPO_EINVAL,
                   "%s: dz (%lld bytes) and dsrc (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb, dstb);
+    hipStream_t st = as_stream(stream);
     if (layer == 3) {      // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
-        const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K, images);
-        if (z_blds(images)) return z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2, true>(za, as_stream(stream), fn);
-        return z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, as_stream(stream), fn);
+        ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K, images);
+        za.bits_in = bits;
+        if (bits) return z_blds(images) ? z_launch<ZDgrad3, 2, 2, 4, Z_MASKB, false, 2, true>(za, st, fn) : z_launch<ZDgrad3, 2, 2, 4, Z_MASKB, false, 2>(za, st, fn);
+        return z_blds(images) ? z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2, true>(za, st, fn) : z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, st, fn);
     }
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
-    const ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K, images);
-    if (z_blds(images)) return z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2, true>(za, as_stream(stream), fn);
-    return z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2>(za, as_stream(stream), fn);
+    ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K, images);
+    za.bits_in = bits;
+    if (bits) return z_blds(images) ? z_launch<ZDgrad2, 2, 2, 4, Z_MASKB_CLS4, false, 2, true>(za, st, fn) : z_launch<ZDgrad2, 2, 2, 4, Z_MASKB_CLS4, false, 2>(za, st, fn);
+    return z_blds(images) ? z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2, true>(za, st, fn) : z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2>(za, st, fn);
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, const void* pack, const float* act_in, float* dsrc,
+                                                               int64_t images, int layer, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_dgrad_packed_f32";
+    MI355_REQUIRE(act_in, MI355PPO_EINVAL, "%s: null pointer", fn);
+    return conv_dgrad_packed_impl(fn, dz, pack, act_in, nullptr, dsrc, images, layer, stream);
+}
+
+// The same with the ReLU mask of the layer's INPUT activation as bits (layer 2: images * 400 words from mi355ppo_cnn_conv1q_fwd_bits;
+// layer 3: images * 81 * 2 words from mi355ppo_cnn_conv_fwd_packed_bits_f32 of layer 2).
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_bits_f32(const float* dz, const void* pack, const uint32_t* mask_bits, float* dsrc,
+                                                                    int64_t images, int layer, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_dgrad_packed_bits_f32";
+    MI355_REQUIRE(mask_bits, MI355PPO_EINVAL, "%s: null pointer", fn);
+    return conv_dgrad_packed_impl(fn, dz, pack, nullptr, mask_bits, dsrc, images, layer, stream);
 }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 130 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 131 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2: round 3); a binding
                                   must check major AND minor (cleanrl_amd/_lib.py does) */
 
@@ -291,6 +291,23 @@ MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f32(const float* src, const void* 
                                                   int64_t images, int layer, void* stream);
 MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f32(const float* dz, const void* pack, const float* act_in, float* dsrc,
                                                     int64_t images, int layer, void* stream);
+
+/* ReLU masks as bits.  The data gradients read the forward activation of the layer below only for its sign -- the reference's
+ * autograd keeps the whole f32 tensor for `threshold_backward` (cleanrl/ppo_atari_multigpu.py:137-145: nn.ReLU after every layer).
+ * The *_bits forwards write, beside the f32 activation, ONE BIT per element: word w, bit b <-> element 32 w + b of the flat
+ * channels-last tensor, set where the activation is > 0 (numel / 32 uint32 words: 400 / 162 / 98 per image for a1 / a2 / a3);
+ * the *_bits / maskbits data gradients take those words instead of `act_in` -- 1/32 of the mask bytes, identical results.
+ *   conv1q_fwd_bits            : kernel Q (layer 1), also a1's mask       -> conv_dgrad_packed_bits(layer 2)
+ *   conv_fwd_packed_bits(2, 3) : kernel Z forward, also a2's / a3's mask  -> conv_dgrad_packed_bits(layer 3) / fc_dgrad_maskbits
+ * dst / dsrc / da must sit on a 128-byte boundary (a 32-element tile of the tensor = one word). */
+MI355PPO_API int mi355ppo_cnn_conv1q_fwd_bits(const void* src_u8, const int64_t* inds, const void* pack, const float* bias,
+                                              float* dst, uint32_t* mask_bits, int64_t images, void* stream);
+MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_bits_f32(const float* src, const void* pack, const float* bias, float* dst,
+                                                       uint32_t* mask_bits, int64_t images, int layer, void* stream);
+MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_bits_f32(const float* dz, const void* pack, const uint32_t* mask_bits, float* dsrc,
+                                                         int64_t images, int layer, void* stream);
+MI355PPO_API int mi355ppo_fc_dgrad_maskbits_packed_f32(const float* dz, int lddz, const void* pack, const uint32_t* mask_bits,
+                                                       float* da, int M, int N, int K, void* stream);
 
 /* FC weight gradient (csrc/fcw.hip): dW (N,K) = dz (M,N)^T @ a (M,K), the batch cut into slabs whose partials are added in a
  * fixed order (deterministic).  Kernel W (bf16 pipe, both operands transposed through LDS and split in registers) when

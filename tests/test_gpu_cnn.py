@@ -630,6 +630,87 @@ def test_fcz_forward_and_masked_data_gradient_against_float64(M):
 
 
 
+# ---- ReLU masks as bits (include/mi355ppo.h "ReLU masks as bits"): the *_bits forwards write (activation > 0) as one bit per
+# element beside the f32 tensor, the *_bits data gradients select by those bits -- everything must equal the f32-mask kernels
+# bit for bit, at sizes with partial tiles and (from 2,048 images) under the B ring.
+@pytest.mark.parametrize("images", [1, 37, 1100])
+def test_conv1q_forward_also_writes_the_relu_mask_as_bits(images):
+    g = torch.Generator().manual_seed(930 + images)
+    rows = images + 5
+    obs = torch.randint(0, 256, (rows, 84, 84, 4), dtype=torch.uint8, generator=g).to(DEV)
+    inds = torch.randperm(rows, generator=g)[:images].to(DEV)
+    W, b = _params(1, 12)
+    b = b - 0.3                                                # a good share of exact zeros after the ReLU
+    pack = cnn.repack_weights(W.to(DEV), 1, cnn.MODE_FWD_Q)
+    ref = cnn.conv_fwd(obs, pack, b.to(DEV), 1, inds, variant=cnn.VARIANT_Q)
+    out = torch.full((images, 20, 20, 32), float("nan"), device=DEV)
+    bits = torch.full((cnn.mask_words(out.numel()),), -1, dtype=torch.int32, device=DEV)
+    cnn.conv1q_fwd_bits(obs, pack, b.to(DEV), inds, out, bits)
+    assert torch.equal(out, ref)
+    assert torch.equal(cnn.unpack_mask_bits(bits, out.shape), out > 0)
+    assert 0.05 < (out > 0).float().mean().item() < 0.95
+
+
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("images", [1, 19, 2049])
+def test_conv_fwd_kernel_z_also_writes_the_relu_mask_as_bits(layer, images):
+    cin, cout, k, s, hin, hout = SPEC[layer]
+    g = torch.Generator().manual_seed(940 + layer + images)
+    x = _nhwc(torch.relu(torch.randn(images, cin, hin, hin, generator=g))).to(DEV)
+    W, b = _params(layer, 4)
+    pack = cnn.conv_zpack(W.to(DEV), layer, cnn.MODE_FWD)
+    ref = cnn.conv_fwd_packed(x, pack, b.to(DEV), layer)
+    bits = torch.full((cnn.mask_words(ref.numel()),), -1, dtype=torch.int32, device=DEV)
+    out = cnn.conv_fwd_packed(x, pack, b.to(DEV), layer, bits=bits)
+    assert torch.equal(out, ref)
+    assert torch.equal(cnn.unpack_mask_bits(bits, out.shape), out > 0)
+    assert 0.05 < (out > 0).float().mean().item() < 0.95
+
+
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("images", [1, 19, 700, 2049, 2310])
+def test_conv_dgrad_kernel_z_with_the_relu_mask_as_bits(layer, images):
+    """The mask words come from the layer below's forward (layer 2's data gradient: kernel Q's a1 mask; layer 3's: kernel Z's a2
+    mask), the result must equal the data gradient masked by the f32 activation itself."""
+    cin, cout, k, s, hin, hout = SPEC[layer]
+    g = torch.Generator().manual_seed(950 + layer + images)
+    W, _ = _params(layer, 3)
+    mode = cnn.MODE_DGRAD_S1 if layer == 3 else cnn.MODE_DGRAD_S2
+    pack = cnn.conv_zpack(W.to(DEV), layer, mode)
+    dz = _nhwc(torch.randn(images, cout, hout, hout, generator=g)).to(DEV)
+    if layer == 2:                                             # a1 and its mask from kernel Q
+        obs = torch.randint(0, 256, (images, 84, 84, 4), dtype=torch.uint8, generator=g).to(DEV)
+        W1, b1 = _params(1, 12)
+        act = torch.empty((images, 20, 20, 32), device=DEV)
+        bits = torch.empty(cnn.mask_words(act.numel()), dtype=torch.int32, device=DEV)
+        cnn.conv1q_fwd_bits(obs, cnn.repack_weights(W1.to(DEV), 1, cnn.MODE_FWD_Q), (b1 - 0.3).to(DEV), None, act, bits)
+    else:                                                      # a2 and its mask from kernel Z's layer-2 forward
+        x = _nhwc(torch.relu(torch.randn(images, 32, 20, 20, generator=g))).to(DEV)
+        W2, b2 = _params(2, 4)
+        bits = torch.empty(cnn.mask_words(images * 81 * 64), dtype=torch.int32, device=DEV)
+        act = cnn.conv_fwd_packed(x, cnn.conv_zpack(W2.to(DEV), 2, cnn.MODE_FWD), b2.to(DEV), 2, bits=bits)
+    ref = cnn.conv_dgrad_packed(dz, pack, act, layer)
+    got = cnn.conv_dgrad_packed(dz, pack, None, layer, bits=bits)
+    assert torch.equal(got, ref)
+    assert ((act > 0) | (got == 0)).all() and (got != 0).any()
+
+
+@pytest.mark.parametrize("M", [1, 130, 4100])
+def test_fcz_masked_data_gradient_with_the_relu_mask_as_bits(M):
+    g = torch.Generator().manual_seed(960 + M)
+    a2 = _nhwc(torch.relu(torch.randn(M, 64, 9, 9, generator=g))).to(DEV)
+    W3, b3 = _params(3, 4)
+    bits = torch.empty(cnn.mask_words(M * 3136), dtype=torch.int32, device=DEV)
+    a3 = cnn.conv_fwd_packed(a2, cnn.conv_zpack(W3.to(DEV), 3, cnn.MODE_FWD), b3.to(DEV), 3, bits=bits).view(M, 3136)
+    Wt = (torch.randn(3136, 512, generator=g) / 56.0).to(DEV)
+    pk = cnn.fc_pack(Wt)
+    dz = torch.randn(M, 512, generator=g).to(DEV)
+    ref = cnn.fc_dgrad_mask_packed(dz, pk, a3)
+    got = cnn.fc_dgrad_mask_packed(dz, pk, a3, bits=bits)
+    assert torch.equal(got, ref)
+    assert ((a3 > 0) | (got == 0)).all() and (got != 0).any()
+
+
 def test_tensors_beyond_4GiB_take_the_64bit_pointer_kernel():
     """Kernels Z, F and V address a tensor with 32-bit buffer offsets.  84,000 images put layer 2's input (and layer 1's output
     and gradient) at 4.30 GB: the entry points and the trunk then route to kernel S (64-bit pointers) and kernel T.  Held to

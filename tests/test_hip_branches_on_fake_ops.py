@@ -546,23 +546,48 @@ class FakeCnn:
         assert tag == "zpack" and l == layer and m in modes, (tag, l, m, layer, modes)
         return W
 
-    def conv_fwd_packed(self, src, pack, bias, layer, out=None):
+    # ReLU masks as bits (include/mi355ppo.h): word w, bit b <-> flat element 32 w + b, set where the activation is > 0
+    @staticmethod
+    def _write_bits(bits, y):
+        w = (y.reshape(-1, 32) > 0).to(torch.int64)
+        words = (w << torch.arange(32)).sum(1)
+        _chk(bits, torch.int32, "bits", (y.numel() // 32,)).copy_(torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32))
+        self_bits = getattr(FakeCnn, "bits_written", 0)
+        FakeCnn.bits_written = self_bits + 1
+
+    def conv1q_fwd_bits(self, obs_u8, pack, bias, inds, out, bits):
+        from cleanrl_amd import cnn
+
+        y = self.conv_fwd(obs_u8, pack, bias, 1, inds, out, variant=cnn.VARIANT_Q)
+        self._write_bits(bits, y)
+        return y
+
+    def conv_fwd_packed(self, src, pack, bias, layer, out=None, bits=None):
         from cleanrl_amd import cnn
 
         cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
         W = self._zw(pack, layer, (0,))
         _chk(src, torch.float32, "src", (src.shape[0], hin, hin, cin))
         y = torch.relu(torch.nn.functional.conv2d(src.permute(0, 3, 1, 2), W, bias, stride=s)).permute(0, 2, 3, 1)
-        return y.contiguous() if out is None else _chk(out, torch.float32, "out", tuple(y.shape)).copy_(y)
+        y = y.contiguous() if out is None else _chk(out, torch.float32, "out", tuple(y.shape)).copy_(y)
+        if bits is not None:
+            self._write_bits(bits, y)
+        return y
 
-    def conv_dgrad_packed(self, dz, pack, act_in, layer, out=None):
+    def conv_dgrad_packed(self, dz, pack, act_in, layer, out=None, bits=None):
         from cleanrl_amd import cnn
 
         cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
         W = self._zw(pack, layer, (1,) if layer == 3 else (2,))
         _chk(dz, torch.float32, "dz", (dz.shape[0], hout, hout, cout))
-        _chk(act_in, torch.float32, "act_in", (dz.shape[0], hin, hin, cin))
-        gi = torch.nn.functional.conv_transpose2d(dz.permute(0, 3, 1, 2), W, stride=s).permute(0, 2, 3, 1) * (act_in > 0)
+        if bits is not None:                              # the kernel reads ONLY the bits: they must be the activation's sign
+            mask = cnn.unpack_mask_bits(_chk(bits, torch.int32, "bits", (dz.shape[0] * hin * hin * cin // 32,)), (dz.shape[0], hin, hin, cin))
+            assert act_in is None or torch.equal(mask, act_in > 0)
+            FakeCnn.bits_read = getattr(FakeCnn, "bits_read", 0) + 1
+        else:
+            _chk(act_in, torch.float32, "act_in", (dz.shape[0], hin, hin, cin))
+            mask = act_in > 0
+        gi = torch.nn.functional.conv_transpose2d(dz.permute(0, 3, 1, 2), W, stride=s).permute(0, 2, 3, 1) * mask
         return gi.contiguous() if out is None else _chk(out, torch.float32, "out", tuple(gi.shape)).copy_(gi)
 
     def trunk_fwd(self, obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3, conv1_variant=0):
@@ -580,8 +605,10 @@ def test_fused_cnn_branch_and_weight_matrix_cache(monkeypatch):
     from cleanrl_amd.agents import AtariAgent
 
     fk = FakeCnn()
-    for name in ("repack_weights", "conv_fwd", "conv_dgrad", "conv_wgrad", "trunk_fwd", "fc_pack", "conv_fwd_packed", "conv_dgrad_packed"):
+    for name in ("repack_weights", "conv_fwd", "conv_dgrad", "conv_wgrad", "trunk_fwd", "fc_pack", "conv_fwd_packed", "conv_dgrad_packed",
+                 "conv1q_fwd_bits"):
         monkeypatch.setattr(cnn, name, getattr(fk, name))
+    FakeCnn.bits_written = FakeCnn.bits_read = 0
     monkeypatch.setattr(cnn, "heads_supported", lambda actor, critic: False)      # HeadsFn binds the library directly
     T, N = 6, 4
     rs = np.random.RandomState(13)
@@ -601,6 +628,9 @@ def test_fused_cnn_branch_and_weight_matrix_cache(monkeypatch):
     # pack, derived exactly as often (2 forward packs per forward-matrix set, 2 data-gradient packs per backward set).
     assert fk.repacks == 3 + 2 + 3 * 5
     assert fk.packs == 2 + 2 + 3 * 4
+    # ReLU masks as bits: written by the three forwards of each of the 4 minibatch updates (never by a rollout forward, which no
+    # backward follows), read by the two conv data gradients of each
+    assert FakeCnn.bits_written == 3 * 4 and FakeCnn.bits_read == 2 * 4
     # a second rollout sees the updated weights (the cache was invalidated by the last step)
     logits_a, _ = fake._heads_rollout(fake.obs[0])
     with torch.no_grad():

@@ -85,6 +85,8 @@ int main(int argc, char** argv) {
     // kernel Z (round 3): the FC weight and its transpose pre-split into fragment order
     void *pk_fwd, *pk_dg;
     CHECK(hipMalloc(&pk_fwd, mi355ppo_fc_pack_bytes(512, 3136))); CHECK(hipMalloc(&pk_dg, mi355ppo_fc_pack_bytes(3136, 512)));
+    const bool bits = getenv("CONV_TRAFFIC_NOBITS") == nullptr;        // ReLU masks as bits (the learner's default) or as the f32 activations
+    uint32_t *mb1 = dalloc<uint32_t>(a1n / 32), *mb2 = dalloc<uint32_t>(a2n / 32), *mb3 = dalloc<uint32_t>(a3n / 32);
     const bool conv_z = getenv("CONV_TRAFFIC_CONV_F") == nullptr;      // layers 2 / 3 forward + data gradients: kernel Z (the learner's default) or, for A/B runs, kernel F
     void *pz2, *pz3, *pzd2, *pzd3;
     CHECK(hipMalloc(&pz2, mi355ppo_fc_pack_bytes(64, 512))); CHECK(hipMalloc(&pz3, mi355ppo_fc_pack_bytes(64, 576)));
@@ -107,8 +109,14 @@ int main(int argc, char** argv) {
     float *dW1 = dalloc<float>(8192), *dW2 = dalloc<float>(32768), *dW3 = dalloc<float>(36864), *db1 = dalloc<float>(64), *db2 = dalloc<float>(64), *db3 = dalloc<float>(64);
 #define TIMED(i, call) do { CHECK(hipEventRecord(ev[i][0], st)); ABI(call); CHECK(hipEventRecord(ev[i][1], st)); } while (0)
     for (int r = 0; r < reps; r++) {                                // one minibatch update's conv launches, in order
+        if (conv_z && bits) {
+            TIMED(0, mi355ppo_cnn_conv1q_fwd_bits(obs, inds, bt1q, bias, a1, mb1, M, st));                          // kernel Q (+ a1's mask bits)
+            TIMED(1, mi355ppo_cnn_conv_fwd_packed_bits_f32(a1, pz2, bias, a2, mb2, M, 2, st));                     // kernel Z (+ mask bits)
+            TIMED(2, mi355ppo_cnn_conv_fwd_packed_bits_f32(a2, pz3, bias, a3, mb3, M, 3, st));
+        } else
         TIMED(0, mi355ppo_cnn_conv_fwd_f32_variant(obs, inds, bt1q, bias, a1, M, 1, 6, st));        // kernel Q
-        if (conv_z) {
+        if (conv_z && bits) {
+        } else if (conv_z) {
             TIMED(1, mi355ppo_cnn_conv_fwd_packed_f32(a1, pz2, bias, a2, M, 2, st));                  // kernel Z
             TIMED(2, mi355ppo_cnn_conv_fwd_packed_f32(a2, pz3, bias, a3, M, 3, st));
         } else {
@@ -116,13 +124,16 @@ int main(int argc, char** argv) {
             TIMED(2, mi355ppo_cnn_conv_fwd_f32(a2, nullptr, bt3, bias, a3, M, 3, st));
         }
         TIMED(8, mi355ppo_fc_fwd_relu_packed_f32(a3, 3136, pk_fwd, bias, hfc, (int)M, 512, 3136, st));        // kernel Z forward
-        TIMED(9, mi355ppo_fc_dgrad_mask_packed_f32(dzfc, 516, pk_dg, a3, dz3, (int)M, 3136, 512, st));        // kernel Z data gradient + (a3 > 0)
+        if (conv_z && bits) TIMED(9, mi355ppo_fc_dgrad_maskbits_packed_f32(dzfc, 516, pk_dg, mb3, dz3, (int)M, 3136, 512, st));
+        else TIMED(9, mi355ppo_fc_dgrad_mask_packed_f32(dzfc, 516, pk_dg, a3, dz3, (int)M, 3136, 512, st));        // kernel Z data gradient + (a3 > 0)
         TIMED(10, mi355ppo_fc_wgrad_f32(dzfc, 516, a3, dWfc, (int)M, 512, 3136, 64, wsfc, wsfcb, st));  // kernel W + its slab reduction
         TIMED(3, mi355ppo_cnn_conv_wgrad_f32(a2, nullptr, dz3, dW3, db3, M, 3, ws, wsb, st));
-        if (conv_z) TIMED(4, mi355ppo_cnn_conv_dgrad_packed_f32(dz3, pzd3, a2, dz2, M, 3, st));
+        if (conv_z && bits) TIMED(4, mi355ppo_cnn_conv_dgrad_packed_bits_f32(dz3, pzd3, mb2, dz2, M, 3, st));
+        else if (conv_z) TIMED(4, mi355ppo_cnn_conv_dgrad_packed_f32(dz3, pzd3, a2, dz2, M, 3, st));
         else TIMED(4, mi355ppo_cnn_conv_dgrad_f32_variant(dz3, bt3c, a2, dz2, M, 3, 5, st));
         TIMED(5, mi355ppo_cnn_conv_wgrad_f32(a1, nullptr, dz2, dW2, db2, M, 2, ws, wsb, st));
-        if (conv_z) TIMED(6, mi355ppo_cnn_conv_dgrad_packed_f32(dz2, pzd2, a1, dz1, M, 2, st));
+        if (conv_z && bits) TIMED(6, mi355ppo_cnn_conv_dgrad_packed_bits_f32(dz2, pzd2, mb1, dz1, M, 2, st));
+        else if (conv_z) TIMED(6, mi355ppo_cnn_conv_dgrad_packed_f32(dz2, pzd2, a1, dz1, M, 2, st));
         else TIMED(6, mi355ppo_cnn_conv_dgrad_f32_variant(dz2, bt2c, a1, dz1, M, 2, 6, st));           // border classes
         TIMED(7, mi355ppo_cnn_conv_wgrad_f32(obs, inds, dz1, dW1, db1, M, 1, ws, wsb, st));
         CHECK(hipStreamSynchronize(st));
