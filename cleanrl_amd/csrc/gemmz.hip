@@ -557,6 +557,15 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             return (unsigned)m * (unsigned)ldc * 4u;
         }
     };
+    // Row offsets of the epilogue.  Border classes: a row's (image, pixel) costs two multiply-high divisions and a dozen selects --
+    // computed ONCE per lane for row m0 + lane and fetched per accumulator row with a lane permute (the 32 evaluations per tile were
+    // ~700 VALU instructions beside a 312-MFMA k-loop in the layer-2 data gradient).
+    unsigned ro_lane = 0u;
+    if constexpr (RG::CLS && ROWS == 64) ro_lane = row_off(m0 + lane);
+    auto ro_of = [&](int r) -> unsigned {                 // r = row of the tile (its lh-dependent part included)
+        if constexpr (RG::CLS && ROWS == 64) return (unsigned)__shfl((int)ro_lane, r, 64);
+        else return row_off(m0 + r);
+    };
     unsigned coff[NT];                                    // byte offset of this lane's column in tile j (out of range past N)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -569,7 +578,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         // word (byte offset of the element) / 128 -- every 32-column tile of a row starts on a 128-byte boundary of C
         unsigned wm[NT];
         {
-            const unsigned ro = row_off(m0 + lane);
+            const unsigned ro = (RG::CLS && ROWS == 64) ? ro_lane : row_off(m0 + lane);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 unsigned o = kZOob;
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const unsigned ro = row_off(m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
+                const unsigned ro = ro_of(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wm[j], 32 * i + (e & 3) + 8 * (e >> 2));
@@ -602,7 +611,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const unsigned ro = row_off(m0 + 32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh);
+                    const unsigned ro = ro_of(32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) mk[ib][j][e] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_m, at(ro, j), 0, 0);
                 }
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const unsigned ro = row_off(m0 + 32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh);
+                    const unsigned ro = ro_of(32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const float v = __uint_as_float(mk[ib][j][e]) > 0.0f ? acc[i0 + ib][j][e] : 0.0f;
@@ -632,7 +641,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             for (int j = 0; j < NT; ++j) wv[j] = 0;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const unsigned ro = row_off(m0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
+                const unsigned ro = ro_of(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     float v = acc[i][j][e] + bj[j];
