@@ -137,6 +137,30 @@ using ZDgrad3 = ZRowsConv<7, 7, 64, 3, 3, 9, 9, 1, -2, 9, 9, 64, 1, ZAxisDgrad3>
 using ZDgrad2 = ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1, 20, 20, 32, 2, ZAxisDgrad2>;    // source = dz2, destination = da1 (4 parity classes = 4 column tiles)
 static_assert(z_axis_ok<ZAxisDgrad3>(9, 3, 1, -2, 7) && z_axis_ok<ZAxisDgrad2>(10, 2, 1, -1, 9), "border-class tables");
 
+// Order in which the forward convolutions walk their k-steps: visited index v -> k-step (tap row * SPR + 16-float chunk of the tap row;
+// also the step's position in the pack).  A source line is wanted by every (output pixel, tap) pair that lands on it -- 4 pairs in
+// layer 2 (4 x 4 taps, stride 2: the taps of equal row and column parity), 9 in layer 3 -- and in plain (tap row, tap column) order
+// those requests lie 4 to 24 k-steps apart while the 256 waves of an XCD stream 1 MB per k-step through its 4 MB L2: the layer-2 /
+// layer-3 forwards fetched their input 2.0 / 2.2 times, the layer-2 one at the fabric's copy rate (profiles/traffic.json).  Hence
+// PHASES: all taps that share source lines are walked back to back -- layer 2: (tap-row parity, tap-column parity) = 4 phases of
+// 2 x 2 taps x 2 chunks; layer 3: the two 128-byte lines of a source pixel = 2 phases of 3 x 3 taps x 2 chunks -- so that a phase
+// re-requests ONE set of lines (10 KB per wave, 2.6 MB per XCD) every other step.  The two chunks of a line stay adjacent: a k-step
+// pair (the B ring's unit) is two consecutive steps of the pack.
+template <class RG>
+__device__ __forceinline__ int z_kstep(int v) {
+    if constexpr (RG::CONV && !RG::CLS && RG::KH == 4 && RG::KW == 4 && RG::S == 2 && RG::C == 32) {
+        const int g = v >> 3, w = v & 7;                                        // phase (row parity, column parity); step in the phase
+        const int ty = (g >> 1) + 2 * (w >> 2), tx = (g & 1) + 2 * ((w >> 1) & 1);
+        return ty * RG::SPR + 2 * tx + (w & 1);
+    } else if constexpr (RG::CONV && !RG::CLS && RG::KH == 3 && RG::KW == 3 && RG::S == 1 && RG::C == 64) {
+        const int lp = v >= 18 ? 1 : 0, w = v - 18 * lp, combo = w >> 1;        // which line of the pixel; (tap row, tap column)
+        const int ty = combo / 3, tx = combo - 3 * ty;
+        return ty * RG::SPR + 4 * tx + 2 * lp + (w & 1);
+    } else {
+        return v;
+    }
+}
+
 // Border classes of a grid in the order the kernel walks them: heaviest first (pixels x valid taps), so that the short tiles
 // of the corner classes fill the tail of the launch.
 template <class AX>
@@ -333,7 +357,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             for (int u = 0; u < LOADS; ++u) stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[u] + off, 0, 0));
             advance(ca);
         } else if constexpr (RG::CONV) {
-            const int ty = sc / RG::SPR, us = sc - ty * RG::SPR;                     // (uniform: scalar unit)
+            const int sm = z_kstep<RG>(sc);
+            const int ty = sm / RG::SPR, us = sm - ty * RG::SPR;                     // (uniform: scalar unit)
             const int off = ty * RG::PITCHB + us * 64;
             if constexpr (RG::PAD) {
                 const int tap = ty * RG::KW + (us * 16) / RG::C;
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     };
     auto load_a = [&](int s) { load_a_into(stage, s); };
     auto load_b = [&](int par, int s) {
-        const unsigned char* p = pb + (size_t)(RG::CLS ? cb.ty * RG::SPR + cb.us : kclamp(s)) * step_bytes;
+        const unsigned char* p = pb + (size_t)(RG::CLS ? cb.ty * RG::SPR + cb.us : z_kstep<RG>(kclamp(s))) * step_bytes;
         if constexpr (RG::CLS) advance(cb);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -378,7 +403,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         }
     }
     auto load_bpair = [&]() {
-        const unsigned char* p = pb + (size_t)(RG::CLS ? cp.ty * RG::SPR + cp.us : cp.n) * step_bytes;
+        const unsigned char* p = pb + (size_t)(RG::CLS ? cp.ty * RG::SPR + cp.us : z_kstep<RG>(cp.n)) * step_bytes;      // (a pair = two consecutive steps of the pack)
 #pragma unroll
         for (int u = 0; u < kShare; ++u) bst[u] = *reinterpret_cast<const s_u32x4*>(p + bsrc[u]);
         if (cp.n + 2 < nsteps) {
