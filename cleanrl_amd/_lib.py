@@ -64,6 +64,8 @@ SIGNATURES = {
     "mi355ppo_fc_pack_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "mi355ppo_fc_fwd_relu_packed_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_fc_dgrad_mask_packed_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "mi355ppo_fc_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mi355ppo_fc_fwd_relu_packed_ws_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "mi355ppo_cnn_conv_fwd_packed_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_cnn_conv_dgrad_packed_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_cnn_conv1q_fwd_bits": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P]),
@@ -81,7 +83,7 @@ SIGNATURES = {
     "mi355ppo_fc_wgrad_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
 }
 
-ABI_VERSION = 131       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 132       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

@@ -32,11 +32,12 @@ BUF_LIMIT = (1 << 32) - 8192     # kernels Z / F address a tensor with 32-bit bu
 
 
 def warm_forward_packs(bufs, net) -> None:
-    """Kernel Z's forward packs of layers 2 / 3 (re-derived into the same buffers: captured rollout steps keep reading one
-    address)."""
+    """Kernel Z's forward packs of layers 2 / 3 and of the FC layer (re-derived into the same buffers: captured rollout steps
+    keep reading one address)."""
     if _CONV_Z:
         bufs.conv_zpack(net[2].weight, 2, MODE_FWD)
         bufs.conv_zpack(net[4].weight, 3, MODE_FWD)
+    bufs.fc_pack_fwd(net[7].weight)        # Linear(3136, 512): kernel Z at every batch size (K split over the grid for a rollout step)
 
 
 def repack_weights(W: torch.Tensor, layer: int, mode: int = MODE_FWD, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -169,8 +170,13 @@ def fc_fwd_relu_packed(a: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, 
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _chk(out, torch.float32, "out", (M, N))
+    nws = lib.mi355ppo_fc_fwd_workspace_bytes(M, N, K)       # rollout-sized batches: K split over the grid, partials in a workspace
     with _on(a.device):
-        st = lib.mi355ppo_fc_fwd_relu_packed_f32(_ptr(a), lda, _ptr(pack), _ptr(bias), _ptr(out), M, N, K, _stream(a.device))
+        if nws:
+            ws = _workspace(a.device, nws)
+            st = lib.mi355ppo_fc_fwd_relu_packed_ws_f32(_ptr(a), lda, _ptr(pack), _ptr(bias), _ptr(out), M, N, K, _ptr(ws), ws.numel(), _stream(a.device))
+        else:
+            st = lib.mi355ppo_fc_fwd_relu_packed_f32(_ptr(a), lda, _ptr(pack), _ptr(bias), _ptr(out), M, N, K, _stream(a.device))
     _lib.check(st, "mi355ppo_fc_fwd_relu_packed_f32")
     return out
 
@@ -323,7 +329,7 @@ def fc_wgrad(dz: torch.Tensor, a: torch.Tensor, hwc_channels: int = 0, out: torc
     return out
 
 
-FCZ_MIN_ROWS = 4096          # below this (rollout-sized batches) kernel Z's 128 x 128 workgroup tiles cannot fill the chip: library GEMM
+FCZ_MIN_ROWS = 1             # kernel Z at every batch size: from 4,096 rows whole-K wave tiles, below (a rollout step) K split over the grid
 
 
 class _Buffers:
@@ -540,22 +546,23 @@ class LinearReLUHwcFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, W, b, bufs=None):
-        Wp = bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()).contiguous()
-        # minibatch-sized batches on the GPU: kernel Z (csrc/gemmz.hip), bf16 matrix pipe, bias + ReLU in its epilogue.
-        # Rollout-sized batches and the host path: the library GEMM with the same fused epilogue.
+        # on the GPU: kernel Z (csrc/gemmz.hip), bf16 matrix pipe, bias + ReLU in its epilogue -- minibatch-sized batches with
+        # whole-K wave tiles, rollout-sized ones with K split over the grid.  The host path (and operands kernel Z cannot take):
+        # the library GEMM with the same fused epilogue.
         ctx.fcz = bool(a.is_cuda and bufs is not None and a.shape[0] >= FCZ_MIN_ROWS and a.shape[1] % 16 == 0 and a.is_contiguous()
                        and a.numel() * 4 < BUF_LIMIT)
         if ctx.fcz:
-            h = fc_fwd_relu_packed(a, bufs.fc_pack_fwd(W), b.detach().contiguous(), Wp.shape[0])
+            h = fc_fwd_relu_packed(a, bufs.fc_pack_fwd(W), b.detach().contiguous(), W.shape[0])
         else:
+            Wp = bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()).contiguous()
             h = torch._addmm_activation(b.detach(), a, Wp.t())                 # bias + ReLU fused into the GEMM epilogue
         ctx.bufs = bufs
-        ctx.save_for_backward(a, h, Wp, W)
+        ctx.save_for_backward(a, h, W)
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        a, h, Wp, W = ctx.saved_tensors
+        a, h, W = ctx.saved_tensors
         bufs = ctx.bufs
         pre = bufs.fc_dz_from_heads if bufs is not None else None
         db = None
@@ -574,7 +581,7 @@ class LinearReLUHwcFn(torch.autograd.Function):
                 da = fc_dgrad_mask_packed(dz, bufs.fc_pack_dgrad(W), a, bits=bufs.last_a3_bits)
                 bufs.a3_grad_is_masked = True
             else:
-                da = dz @ Wp
+                da = dz @ (bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()))
         m, n = dz.shape
         if ctx.fcz and n % 64 == 0 and a.shape[1] % 224 == 0 and a.shape[1] % 64 == 0:
             dW = fc_wgrad(dz, a, 64)               # kernel W (bf16 pipe), written in the (c, h, w) feature order of W itself

@@ -47,7 +47,10 @@ __device__ __forceinline__ int z_writelane(int w, unsigned x, int l) {
     return w;
 }
 
-enum { Z_BIAS_RELU = 0, Z_MASK = 1, Z_MASK_CLS4 = 2, Z_MASKB = 3, Z_MASKB_CLS4 = 4, Z_BIAS_RELU_BITS = 5 };
+// Z_RAW (GEMM rows, split K): blockIdx.z owns `steps_per` k-steps and stores its raw f32 partial of C into slab z of a workspace;
+// zsplit_reduce_kernel adds the slabs in order, then bias + ReLU (rollout-sized batches: M / 64 x N / 64 wave tiles alone cannot fill
+// the chip and each would walk all K / 16 = 196 k-steps in a row).
+enum { Z_BIAS_RELU = 0, Z_MASK = 1, Z_MASK_CLS4 = 2, Z_MASKB = 3, Z_MASKB_CLS4 = 4, Z_BIAS_RELU_BITS = 5, Z_RAW = 6 };
 
 // x where bit (lane) of the 64-bit lane mask {hi, lo} is set, else 0: one v_cndmask with the mask in an SGPR pair.
 __device__ __forceinline__ float z_keep_where(float x, unsigned lo, unsigned hi) {
@@ -195,6 +198,7 @@ struct ZArgs {
     long long images;           // convolution rows: images
     int N, K;
     unsigned m8, m16;           // 0xffff0000, 0xffffff00: in SGPRs (as literals every v_and would be an 8-byte instruction)
+    int steps_per;              // Z_RAW: k-steps per K split (blockIdx.z); 0 otherwise
 };
 
 // WAVES_N: the waves of a workgroup sit side by side (they read the same A rows) instead of on top of each other (they stream
@@ -337,7 +341,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     s_u32x4 raw[MT][2];                                   // fragments of the NEXT k-step as read back from LDS (f32, lane = row)
     unsigned ta[2][MT][3][4];                             // split A fragments: [k-step parity][fragment][term][4 x 2 bf16]
     s_u32x4 tb[2][NT][3];                                 // B fragments straight from the pack
-    const int nsteps = RG::CLS ? c_nty * c_spr : RG::CONV ? RG::K / 16 : a.K >> 4;
+    const int k0 = EPI == Z_RAW ? (int)blockIdx.z * a.steps_per : 0;              // first k-step of this K split
+    const int nsteps = RG::CLS ? c_nty * c_spr : RG::CONV ? RG::K / 16 : EPI == Z_RAW ? ((a.K >> 4) - k0 < a.steps_per ? (a.K >> 4) - k0 : a.steps_per) : a.K >> 4;
     auto kclamp = [&](int s) { return s < nsteps ? s : nsteps - 1; };                // past the end: re-read, never multiplied
     // border classes: the k-steps of a tile are the chunks us0 .. us0 + spr - 1 of tap rows ty0 .. ty0 + nty - 1; the loads of A
     // and of B each walk them with their own cursor (the loads are issued in step order; past the end a cursor stays put)
@@ -373,12 +378,12 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < LOADS; ++u) stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[u], sc * 64, 0));
+            for (int u = 0; u < LOADS; ++u) stage[u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[u], (k0 + sc) * 64, 0));
         }
     };
     auto load_a = [&](int s) { load_a_into(stage, s); };
     auto load_b = [&](int par, int s) {
-        const unsigned char* p = pb + (size_t)(RG::CLS ? cb.ty * RG::SPR + cb.us : z_kstep<RG>(kclamp(s))) * step_bytes;
+        const unsigned char* p = pb + (size_t)(RG::CLS ? cb.ty * RG::SPR + cb.us : k0 + z_kstep<RG>(kclamp(s))) * step_bytes;
         if constexpr (RG::CLS) advance(cb);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -557,7 +562,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     // (C and the mask are below 4 GiB, host-checked): rows past M and columns past N get an out-of-range offset -- their loads
     // return 0, their stores are dropped -- so the epilogue has no branches and no per-access waits.
     const unsigned c_bytes = a.c_bytes;
-    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)c_bytes, kZRsrcWord3);
+    float* const c_base = EPI == Z_RAW ? a.C + (size_t)blockIdx.z * (size_t)(c_bytes >> 2) : a.C;     // Z_RAW: slab z of the workspace
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(c_base, 0, (int)c_bytes, kZRsrcWord3);
     constexpr bool kCls4 = EPI == Z_MASK_CLS4 || EPI == Z_MASKB_CLS4, kMaskF32 = EPI == Z_MASK || EPI == Z_MASK_CLS4,
                    kMaskBits = EPI == Z_MASKB || EPI == Z_MASKB_CLS4, kBitsOut = EPI == Z_BIAS_RELU_BITS;
     static_assert(!(kMaskBits || kBitsOut) || ROWS == 64, "bit masks: one word per lane = one row of the wave's 64");
@@ -652,6 +658,15 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
                     }
                 }
         }
+    } else if constexpr (EPI == Z_RAW) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned ro = ro_of(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e]), rsrc_c, at(ro, j), 0, 0);
+            }
     } else {
         float bj[NT];
 #pragma unroll
@@ -702,6 +717,7 @@ static int z_launch(const ZArgs& a, hipStream_t s, const char* what) {
         const long long groups = (a.M / RG::PER_IMG + 32 * MT - 1) / (32 * MT);
         grid.y = (unsigned)((groups + NWAVES - 1) / NWAVES * RG::PER_IMG);
     }
+    if constexpr (EPI == Z_RAW) grid.z = (unsigned)(((a.K >> 4) + a.steps_per - 1) / a.steps_per);
     if (grid.y > 65535u) {            // (hardware grid limit) 4.1 M rows at the smallest row block: beyond every caller's sizes
         set_error("%s: %lld rows exceed one launch", what, a.M);
         return MI355PPO_EINVAL;
@@ -761,8 +777,45 @@ static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, 
     ZArgs a;
     a.A = A; a.a_bytes = (unsigned)a_bytes; a.lda = lda; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.mask = mask;
     a.bits_in = nullptr; a.bits_out = nullptr;
+    a.steps_per = 0;
     a.C = C; a.c_bytes = (unsigned)c_bytes; a.ldc = ldc; a.M = M; a.images = images; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
     return a;
+}
+
+// h[m][n] = relu(bias[n] + part[0][m][n] + part[1][m][n] + ...): the K splits of Z_RAW added in order (deterministic)
+__global__ __launch_bounds__(256) void zsplit_reduce_kernel(const float4* __restrict__ part, int splits, size_t slab4, const float* __restrict__ bias,
+                                                            int n4, float4* __restrict__ h, size_t total4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 acc = part[i];
+    for (int z = 1; z < splits; ++z) {
+        const float4 p = part[(size_t)z * slab4 + i];
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    const float* const b = bias + 4 * (i % (size_t)n4);
+    acc.x += b[0]; acc.y += b[1]; acc.z += b[2]; acc.w += b[3];
+    h[i] = make_float4(acc.x > 0.0f ? acc.x : 0.0f, acc.y > 0.0f ? acc.y : 0.0f, acc.z > 0.0f ? acc.z : 0.0f, acc.w > 0.0f ? acc.w : 0.0f);
+}
+
+// K splits of the small-batch forward: (row tile, column tile, split) wave tiles for ONE wave per SIMD (1,024: measured 30.8 us at
+// 1,024 rows, 22.6 at 512 -- the library GEMM's 31.3 / 22.6; two waves per SIMD = twice the partials: 38.7 / 29.3 us,
+// tools/gpu_fcsplit2.sh), at least 4 k-steps per split.
+static int zsplit_steps_per(int M, int N, int K) {
+    const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    const int total = K / 16;
+    static const int target = [] { const char* e = getenv("MI355PPO_FC_SPLIT_WAVES"); return e ? atoi(e) : 1024; }();      // (tuning runs)
+    long long want = (target + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    int per = (int)((total + want - 1) / want);
+    if (per < 4) per = 4;
+    if (per > total) per = total;
+    return per;
+}
+
+extern "C" MI355PPO_API size_t mi355ppo_fc_fwd_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 16 || M >= 4096) return 0;          // (from 4,096 rows on the forward needs no workspace)
+    const int per = zsplit_steps_per(M, N, K), splits = (K / 16 + per - 1) / per;
+    return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
 extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
@@ -777,6 +830,29 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int 
     // 8,192 rows 205 vs 145 us, 4,096 rows 182 vs 128 us)
     if (M < 16384) return z_launch<ZRowsLinear, 2, 2, 4, Z_BIAS_RELU, true, 2>(za, as_stream(stream), fn);
     return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(za, as_stream(stream), fn);
+}
+
+// The same with a workspace of mi355ppo_fc_fwd_workspace_bytes(M, N, K) bytes: batches below 4,096 rows (a rollout step's 1,024
+// envs) split K over blockIdx.z -- raw partials into the workspace, then one pass that adds them in order, bias, ReLU.  Without a
+// workspace (or when none is needed) this IS mi355ppo_fc_fwd_relu_packed_f32.
+extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_ws_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
+                                                               int M, int N, int K, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "mi355ppo_fc_fwd_relu_packed_ws_f32";
+    const size_t need = mi355ppo_fc_fwd_workspace_bytes(M, N, K);
+    if (need == 0 || !ws || N % 4) return mi355ppo_fc_fwd_relu_packed_f32(a, lda, pack, bias, h, M, N, K, stream);
+    int rc = zgemm_check(fn, a, pack, h, M, N, K, lda, N);
+    if (rc) return rc;
+    MI355_REQUIRE(bias && aligned(bias, 4) && aligned(h, 16) && aligned(ws, 16), MI355PPO_EINVAL, "%s: bias missing, or h / workspace not 16-byte aligned", fn);
+    MI355_REQUIRE(ws_bytes >= need, MI355PPO_EINVAL, "%s: workspace of %zu bytes, %zu needed (mi355ppo_fc_fwd_workspace_bytes)", fn, ws_bytes, need);
+    ZArgs za = zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, static_cast<float*>(ws), (long long)M * N * 4, N, M, N, K);
+    za.steps_per = zsplit_steps_per(M, N, K);
+    const int splits = (K / 16 + za.steps_per - 1) / za.steps_per;
+    rc = z_launch<ZRowsLinear, 2, 2, 4, Z_RAW, true, 2>(za, as_stream(stream), fn);
+    if (rc) return rc;
+    const size_t total4 = (size_t)M * N / 4;
+    hipLaunchKernelGGL(zsplit_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       static_cast<const float4*>(ws), splits, total4, bias, N / 4, reinterpret_cast<float4*>(h), total4);
+    return check_launch(fn);
 }
 
 static int fc_dgrad_impl(const char* fn, const float* dz, int lddz, const void* pack, const float* act_in, const unsigned* bits, float* da,

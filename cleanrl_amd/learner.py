@@ -208,8 +208,7 @@ class PPOLearner:
         bufs.weights(net[0].weight, 1, cnn.MODE_FWD_Q)
         bufs.weights(net[2].weight, 2, cnn.MODE_FWD)
         bufs.weights(net[4].weight, 3, cnn.MODE_FWD)
-        cnn.warm_forward_packs(bufs, net)                # kernel Z's packs: what NatureTrunkFn.forward asks for at a lane's batch size
-        bufs.fc_weight(net[7].weight)
+        cnn.warm_forward_packs(bufs, net)                # kernel Z's packs: what NatureTrunkFn / LinearReLUHwcFn.forward ask for
 
     def _features(self, obs_rows):
         """uint8 image rows -> normalised f32 (K5, no gather); other observations pass through."""

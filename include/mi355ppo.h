@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 131 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 132 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2: round 3); a binding
                                   must check major AND minor (cleanrl_amd/_lib.py does) */
 
@@ -278,6 +278,13 @@ MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int lda, const 
                                                  int M, int N, int K, void* stream);
 MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, int lddz, const void* pack, const float* act_in, float* da,
                                                    int M, int N, int K, void* stream);
+/* Forward for rollout-sized batches (M < 4096: a rollout step's 1,024 envs).  M / 64 x N / 64 wave tiles alone cannot fill the chip,
+ * so K is split over the grid: raw f32 partials go to `ws` (mi355ppo_fc_fwd_workspace_bytes(M, N, K) bytes, 16-byte aligned; 0 bytes =
+ * no split needed), one more pass adds them in a fixed order, then bias and ReLU -- Agent.network[7:9] of the rollout's policy forward
+ * (cleanrl/ppo_atari_multigpu.py:144-145,262-264) without a library GEMM.  With ws = NULL: mi355ppo_fc_fwd_relu_packed_f32. */
+MI355PPO_API size_t mi355ppo_fc_fwd_workspace_bytes(int M, int N, int K);
+MI355PPO_API int mi355ppo_fc_fwd_relu_packed_ws_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
+                                                    int M, int N, int K, void* ws, size_t ws_bytes, void* stream);
 
 /* The same kernel family on the convolutions of layers 2 and 3 (cleanrl/ppo_atari_multigpu.py:139-142): a row of the GEMM is an
  * output pixel (forward) or a pixel of the data gradient's grid, a k-step 64 contiguous bytes of a tap row of its window

@@ -596,13 +596,14 @@ def test_fc_pack_planes_sum_back_to_the_matrix_exactly(N, K):
         assert np.all(np.abs(planes[1]) <= np.abs(planes[0]) * 2.0 ** -7 + 1e-300) and np.all(np.abs(planes[2]) <= np.abs(planes[0]) * 2.0 ** -15 + 1e-300)
 
 
-@pytest.mark.parametrize("M", [1, 130, 4100])
+@pytest.mark.parametrize("M", [1, 130, 1024, 4095, 4100])
 def test_fcz_forward_and_masked_data_gradient_against_float64(M):
     """Kernel Z (csrc/gemmz.hip): the FC layer's forward and data gradient with the weight pre-split into fragment order and the
     activations loaded coalesced through LDS, against float64 on operands with low-order bits set everywhere and a wide dynamic
     range (the three-term split must lose nothing): 2e-5 of the result's scale; the library's f32 GEMM is held to the same bound
     for calibration, and kernel Z's mean error to 2.5 x the library's (both accumulate 3,136 products in f32 -- the library as a
-    tree, kernel Z in order; the six term pairs kernel Z multiplies leave out less than the rounding of one f32 product)."""
+    tree, kernel Z in order; the six term pairs kernel Z multiplies leave out less than the rounding of one f32 product).
+    Below 4,096 rows the forward splits K over the grid (raw partials in a workspace, added in order, then bias + ReLU)."""
     g = torch.Generator().manual_seed(190 + M)
     a = torch.relu(torch.randn(M, 3136, generator=g)) * torch.exp(torch.randn(M, 3136, generator=g))
     W = torch.randn(512, 3136, generator=g) / 56.0

@@ -64,6 +64,8 @@ int main(int argc, char** argv) {
     float *Wfc = dalloc<float>(512 * 3136), *Wfct = dalloc<float>(3136 * 516), *hfc = dalloc<float>((size_t)M * 512), *dzfc = dalloc<float>((size_t)M * 516);
     const size_t wsfcb = mi355ppo_fc_wgrad_workspace_bytes((int)M, 512, 3136);
     float *dWfc = dalloc<float>(512 * 3136); void* wsfc; CHECK(hipMalloc(&wsfc, wsfcb));
+    const size_t wsfwdb = mi355ppo_fc_fwd_workspace_bytes((int)M, 512, 3136);
+    void* wsfwd = nullptr; if (wsfwdb) CHECK(hipMalloc(&wsfwd, wsfwdb));
     float *bias = dalloc<float>(512), *dW = dalloc<float>(36864), *db = dalloc<float>(64);
     size_t wsb = 0;
     for (int l = 1; l <= 3; l++) { size_t b = mi355ppo_cnn_conv_wgrad_workspace_bytes(M, l); if (b > wsb) wsb = b; }
@@ -123,7 +125,7 @@ int main(int argc, char** argv) {
             TIMED(1, mi355ppo_cnn_conv_fwd_f32(a1, nullptr, bt2, bias, a2, M, 2, st));                // kernel F
             TIMED(2, mi355ppo_cnn_conv_fwd_f32(a2, nullptr, bt3, bias, a3, M, 3, st));
         }
-        TIMED(8, mi355ppo_fc_fwd_relu_packed_f32(a3, 3136, pk_fwd, bias, hfc, (int)M, 512, 3136, st));        // kernel Z forward
+        TIMED(8, mi355ppo_fc_fwd_relu_packed_ws_f32(a3, 3136, pk_fwd, bias, hfc, (int)M, 512, 3136, wsfwd, wsfwdb, st));   // kernel Z forward (K split below 4,096 rows)
         if (conv_z && bits) TIMED(9, mi355ppo_fc_dgrad_maskbits_packed_f32(dzfc, 516, pk_dg, mb3, dz3, (int)M, 3136, 512, st));
         else TIMED(9, mi355ppo_fc_dgrad_mask_packed_f32(dzfc, 516, pk_dg, a3, dz3, (int)M, 3136, 512, st));        // kernel Z data gradient + (a3 > 0)
         TIMED(10, mi355ppo_fc_wgrad_f32(dzfc, 516, a3, dWfc, (int)M, 512, 3136, 64, wsfc, wsfcb, st));  // kernel W + its slab reduction
