@@ -134,7 +134,7 @@ def parse():
     p.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets (pure SPS run)")
     p.add_argument("--no-rollout-graphs", action="store_true", help="issue the rollout kernel by kernel instead of one hipGraph per step")
     p.add_argument("--no-pcie-inclusive", action="store_true", help="skip the host-env (PCIe-inclusive) leg after the timed region")
-    p.add_argument("--pcie-env-groups", type=int, default=2)
+    p.add_argument("--pcie-env-groups", type=int, default=4)
     cli = p.parse_args()
     cfg = CONFIGS[cli.config]
     if cli.local_num_envs is None:

@@ -160,7 +160,7 @@ class SyntheticAtariVecEnv:
     def _obs(self, out=None):
         idx = (self.cursor[:, None] + self._win) % len(self.planes)
         if out is not None:
-            np.take(self.planes, idx, axis=0, out=out)
+            np.take(self.planes, idx, axis=0, out=out, mode="clip")     # (idx is in range; mode="raise" would buffer `out`)
             return out
         return self.planes[idx]
 

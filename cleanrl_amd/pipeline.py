@@ -18,6 +18,12 @@ gymnasium >= 1.0, where the call AFTER done returns the fresh stack with done = 
 
 Sampling stays deterministic: the Philox offset of (step, group) is reserved up front (``_SampleCounter.reserve``), so the
 action streams do not depend on thread timing.
+
+Beyond two lanes the host threads used to fight over the GIL: a lane step's policy forward alone is three autograd nodes and a
+dozen library / torch calls (4 lanes ran SLOWER than 2, profiles/r02_host_env_bench_groups.jsonl).  ``GroupedRollout.capture()``
+records the policy forward + sampling + D2H of the actions of every (lane, step) as one hipGraph on the lane's stream (the
+step's rollout rows are baked in; the Philox position lives in device memory), so that a lane step is one graph launch --
+the same kernels on the same data in the same order, hence the same actions.
 """
 from __future__ import annotations
 
@@ -91,8 +97,17 @@ class _Lane:
         self.evt.synchronize()                    # waits for THIS lane's work only; the other lanes keep the GPU busy
         return self.pin_act_np
 
-    def observe(self, step: int, obs, done, first: bool = False) -> None:
-        """rows [lo, hi) of slot ``step`` <- this group's next observation / done flags."""
+    def act_captured(self, step: int) -> np.ndarray:
+        """``act`` as one graph launch on the lane's stream (``GroupedRollout.capture``)."""
+        self.graphs[step].replay()
+        self.evt.record(self.stream)
+        self.evt.synchronize()
+        return self.pin_act_np
+
+    def observe(self, step: int, obs, done, first: bool = False, pinned_env=None) -> None:
+        """rows [lo, hi) of slot ``step`` <- this group's next observation / done flags.  ``pinned_env``: a ``ProcessVecEnv`` whose
+        shared segments are registered as pinned host memory (``pin()``): frames then go to the GPU straight from what the worker
+        wrote (``newest_t`` / ``obs_t``) instead of through this lane's staging buffers."""
         L = self.L
         obs_dst, done_dst = L._slot(step)
         obs_dst, done_dst = self.rows(obs_dst), self.rows(done_dst)
@@ -106,17 +121,24 @@ class _Lane:
         if self.delta and not first:
             prev_rows = self.rows(L._slot(step - 1)[0])
             obs = np.asarray(obs)
-            np.copyto(self.pin_new_np, obs[:, 3])                              # the newest plane of every env: 7 KB each
             probe = stack_probe(obs)
             reset = full_stack_rows(done, self.prev_done, probe, self.prev_probe)
             self.prev_probe, self.prev_done = probe, np.asarray(done).astype(bool)
-            for j, i in enumerate(reset):
-                np.copyto(self.pin_obs_np[j], obs[i])                          # reset envs: their whole (fresh) stack
-            self.dev_new.copy_(self.pin_new, non_blocking=True)
+            if pinned_env is not None:
+                self.dev_new.copy_(pinned_env.newest_t, non_blocking=True)      # DMA from the worker's own (registered) buffer
+            else:
+                np.copyto(self.pin_new_np, obs[:, 3])                          # the newest plane of every env: 7 KB each
+                for j, i in enumerate(reset):
+                    np.copyto(self.pin_obs_np[j], obs[i])                      # reset envs: their whole (fresh) stack
+                self.dev_new.copy_(self.pin_new, non_blocking=True)
             L.ops.obs_shift_append_u8(prev_rows, self.dev_new, obs_dst)
             if len(reset):
                 k = len(reset)
-                self.dev_obs[:k].copy_(self.pin_obs[:k], non_blocking=True)
+                if pinned_env is not None:
+                    for j, i in enumerate(reset):
+                        self.dev_obs[j].copy_(pinned_env.obs_t[int(i)], non_blocking=True)
+                else:
+                    self.dev_obs[:k].copy_(self.pin_obs[:k], non_blocking=True)
                 for j, i in enumerate(reset):
                     L.ops.obs_nchw_to_nhwc_u8(self.dev_obs[j:j + 1], obs_dst[int(i):int(i) + 1])
         else:
@@ -146,6 +168,39 @@ class GroupedRollout:
         per = N // groups
         self.L, self.K, self.threads = learner, groups, threads and groups > 1
         self.lanes: List[_Lane] = [_Lane(learner, g, g * per, (g + 1) * per, frame_delta) for g in range(groups)]
+        self._rng_base = None           # capture(): 1-element int64 device tensor, the first Philox offset of the current rollout
+
+    def capture(self) -> None:
+        """One hipGraph per (lane, step): the policy forward on the lane's rows of slot ``step``, sampling (Philox offset =
+        ``step * K + g`` + the rollout's first offset, which lives in device memory), the stores of action / log-prob / value
+        and the D2H of the actions into the lane's pinned buffer.  Call once, after ``first_observation`` of every group."""
+        L, K, T = self.L, self.K, self.L.T
+        assert L.hip and L.discrete, "capture() needs the HIP path and a Discrete action space"
+        dev = L.device
+        main = torch.cuda.current_stream(dev)
+        L.warm_rollout_caches()
+        self._rng_base = torch.zeros(1, dtype=torch.int64, device=dev)
+        host_rng = L.agent.rng.offset
+        pool = None
+        for lane in self.lanes:
+            lane.stream.wait_stream(main)
+
+            def body(step, lane=lane):
+                a = L.act(step, rows=(lane.lo, lane.hi), rng_offset=step * K + lane.g, rng_base=self._rng_base)
+                lane.pin_act.copy_(a.view(lane.pin_act.shape), non_blocking=True)
+
+            with torch.cuda.stream(lane.stream):
+                body(0)                               # warm-up on the lane's stream: its trunk buffers and workspaces exist
+            lane.stream.synchronize()
+            lane.graphs = []
+            for step in range(T):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=lane.stream):
+                    body(step)
+                pool = pool or g.pool()
+                lane.graphs.append(g)
+            main.wait_stream(lane.stream)
+        L.agent.rng.offset = host_rng               # (the warm-up steps drew nothing from the host counter, but stay explicit)
 
     def first_observation(self, g: int, obs, done=None) -> None:
         lane = self.lanes[g]
@@ -168,14 +223,76 @@ class GroupedRollout:
                 torch.cuda.set_device(L.device)
             ctx = torch.cuda.stream(lane.stream) if lane.hip else _null()
             with ctx:
+                captured = lane.hip and getattr(lane, "graphs", None) is not None
                 for step in range(T):
                     off = None if rng_first is None else rng_first + step * K + lane.g
-                    actions = lane.act(step, off)
+                    actions = lane.act_captured(step) if captured else lane.act(step, off)
                     next_obs, reward, next_done = step_fn(lane.g, actions, step)
                     lane.store_reward(step, reward)
                     lane.observe(step + 1, next_obs, next_done)
         except BaseException as e:          # noqa: BLE001 -- re-raised on the caller's thread
             errors.append(e)
+
+    def run_async(self, envs) -> None:
+        """One rollout driven from ONE host thread: ``envs[g]`` are ``ProcessVecEnv``s (``step_async`` / ``poll`` / ``step_wait``:
+        the envs step in their own processes) and the lanes' policy steps are captured (``capture()``).  The loop polls every
+        lane -- actions ready on the GPU -> hand them to the lane's worker; worker done -> store its reward, DMA its frames, launch
+        the lane's next captured step -- so no lane waits for another and no two host threads fight over the GIL.  Same
+        trajectories as ``run`` (a group's envs only see their own actions; the Philox position of (step, group) is fixed)."""
+        import time
+
+        L, K, T = self.L, self.K, self.L.T
+        assert L.hip and self._rng_base is not None, "run_async needs the HIP path and capture()"
+        rng_first = L.agent.rng.reserve(T * K)
+        L.warm_rollout_caches()
+        main = torch.cuda.current_stream(L.device)
+        self._rng_base.fill_(int(rng_first))
+        pinned = [e if getattr(e, "newest_t", None) is not None else None for e in envs]
+        step, waiting_env = [0] * K, [False] * K
+        stats = self.async_stats = {"gpu_wait_s": 0.0, "env_wait_s": 0.0, "host_s": 0.0, "lane_steps": 0}   # per-phase latencies, summed over lane steps
+        mark = [time.perf_counter()] * K
+        for lane in self.lanes:
+            lane.stream.wait_stream(main)
+            with torch.cuda.stream(lane.stream):
+                lane.graphs[0].replay()
+                lane.evt.record(lane.stream)
+        left = K
+        while left:
+            progressed = False
+            for g, lane in enumerate(self.lanes):
+                t = step[g]
+                if t >= T:
+                    continue
+                if not waiting_env[g]:
+                    if lane.evt.query():                  # this lane's actions are in its pinned buffer
+                        now = time.perf_counter()
+                        stats["gpu_wait_s"] += now - mark[g]
+                        envs[g].step_async(lane.pin_act_np)
+                        mark[g] = time.perf_counter()
+                        stats["host_s"] += mark[g] - now
+                        waiting_env[g] = progressed = True
+                elif envs[g].poll():
+                    now = time.perf_counter()
+                    stats["env_wait_s"] += now - mark[g]
+                    res = envs[g].step_wait()
+                    with torch.cuda.stream(lane.stream):
+                        lane.store_reward(t, res[1])
+                        lane.observe(t + 1, res[0], res[2], pinned_env=pinned[g] if lane.delta else None)
+                        step[g] = t + 1
+                        if t + 1 < T:
+                            lane.graphs[t + 1].replay()
+                        lane.evt.record(lane.stream)
+                    waiting_env[g] = False
+                    progressed = True
+                    mark[g] = time.perf_counter()
+                    stats["host_s"] += mark[g] - now
+                    stats["lane_steps"] += 1
+                    if t + 1 >= T:
+                        left -= 1
+            if not progressed:
+                time.sleep(0)                             # yield: nothing is ready yet
+        for lane in self.lanes:
+            main.wait_stream(lane.stream)
 
     def run(self, step_fn: StepFn) -> None:
         """One rollout of T steps for every group (the learner's ``finish_rollout`` is left to the caller)."""
@@ -184,6 +301,8 @@ class GroupedRollout:
         if L.hip:
             L.warm_rollout_caches()
             main = torch.cuda.current_stream(L.device)
+            if self._rng_base is not None:
+                self._rng_base.fill_(int(rng_first))  # the captured sampler launches add (step * K + g) to this
             for lane in self.lanes:
                 lane.stream.wait_stream(main)      # the lanes read the parameters / slot 0 the main stream wrote
         errors: list = []

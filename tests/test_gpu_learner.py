@@ -521,6 +521,106 @@ def test_env_group_lanes_on_the_gpu_match_the_serial_host_env_loop(K, delta, aut
     assert float(ref.dones.sum()) > 0
 
 
+@pytest.mark.parametrize("K", [2, 4])
+def test_captured_lane_steps_match_the_eager_lanes(K):
+    """``GroupedRollout.capture()``: the policy forward + sampling + D2H of every (lane, step) as one hipGraph.  Two rollouts with
+    an update in between (the captured launches must read the re-derived weight packs and the advanced Philox position) fill
+    every rollout buffer bit for bit like the eager lanes."""
+    from cleanrl_amd.pipeline import GroupedRollout, split_env_groups
+
+    N, T = 16, 8
+    mk = lambda: split_env_groups(lambda g, n: E.SyntheticAtariVecEnv(n, seed=31 + g * n, api="gym", done_p=0.1), N, K)
+    space = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+    out = []
+    for captured in (False, True):
+        torch.manual_seed(6)
+        np.random.seed(6)
+        agent = AtariAgent(space).to(DEV)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=1)
+        L = PPOLearner(agent, args, space.single_observation_space, space.single_action_space, N, DEV, sample_seed=4)
+        groups = mk()
+        roll = GroupedRollout(L, K, frame_delta=True)
+        for g, ge in enumerate(groups):
+            roll.first_observation(g, ge.reset())
+        if captured:
+            roll.capture()
+            assert all(len(lane.graphs) == T for lane in roll.lanes)
+
+        def step_fn(g, actions, step, groups=groups):
+            o, r, d, _ = groups[g].step(actions)
+            return o, r, d
+
+        snaps = []
+        for it in range(2):
+            roll.run(step_fn)
+            L.finish_rollout()
+            torch.cuda.synchronize()
+            snaps.append({k: getattr(L, k).clone() for k in ("obs", "actions", "logprobs", "values", "rewards", "dones", "advantages")})
+            L.update(args.learning_rate)
+            L.start_iteration()
+        out.append(snaps)
+    for it in range(2):
+        for k, v in out[0][it].items():
+            assert torch.equal(v, out[1][it][k]), f"rollout {it}: {k} differs between eager and captured lane steps"
+    assert not torch.equal(out[0][0]["logprobs"], out[0][1]["logprobs"])          # the update changed the policy between the rollouts
+
+
+@pytest.mark.parametrize("K,pin", [(2, True), (4, True), (2, False)])
+def test_one_thread_driver_over_worker_process_envs_matches_the_threaded_lanes(K, pin):
+    """``GroupedRollout.run_async``: envs stepped in worker processes (cleanrl_amd/env_workers.py), captured lane steps, ONE host
+    thread polling every lane, frames DMA'd straight from the workers' registered shared memory (``pin``) -- against the threaded
+    eager lanes over in-process envs: every rollout buffer bit for bit, over two rollouts with an update in between."""
+    from cleanrl_amd.env_workers import ProcessVecEnv
+    from cleanrl_amd.pipeline import GroupedRollout, split_env_groups
+
+    N, T = 16, 8
+    space = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+    kw = lambda g, n: dict(num_envs=n, seed=41 + g * n, api="gym", done_p=0.1)
+    out = []
+    for one_thread in (False, True):
+        torch.manual_seed(6)
+        np.random.seed(6)
+        agent = AtariAgent(space).to(DEV)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=1)
+        L = PPOLearner(agent, args, space.single_observation_space, space.single_action_space, N, DEV, sample_seed=4)
+        if one_thread:
+            groups = split_env_groups(lambda g, n: ProcessVecEnv(("cleanrl_amd.envs", "SyntheticAtariVecEnv", kw(g, n))), N, K)
+        else:
+            groups = split_env_groups(lambda g, n: E.SyntheticAtariVecEnv(**kw(g, n)), N, K)
+        try:
+            roll = GroupedRollout(L, K, frame_delta=True)
+            for g, ge in enumerate(groups):
+                roll.first_observation(g, ge.reset())
+            if one_thread:
+                roll.capture()
+                if pin:
+                    assert all([ge.pin() for ge in groups]), "hipHostRegister of the shared segments failed"
+
+            def step_fn(g, actions, step, groups=groups):
+                o, r, d, _ = groups[g].step(actions)
+                return o, r, d
+
+            snaps = []
+            for it in range(2):
+                if one_thread:
+                    roll.run_async(groups)
+                else:
+                    roll.run(step_fn)
+                L.finish_rollout()
+                torch.cuda.synchronize()
+                snaps.append({k: getattr(L, k).clone() for k in ("obs", "boot_obs", "actions", "logprobs", "values", "rewards", "dones", "advantages")})
+                L.update(args.learning_rate)
+                L.start_iteration()
+            out.append(snaps)
+        finally:
+            for ge in groups:
+                ge.close()
+    for it in range(2):
+        for k, v in out[0][it].items():
+            assert torch.equal(v, out[1][it][k]), f"rollout {it}: {k} differs between the threaded lanes and the one-thread driver"
+    assert float(out[0][0]["dones"].sum()) > 0
+
+
 def test_captured_rollout_steps_replay_bit_identically_to_the_eager_loop():
     """PPOLearner.capture_rollout: every rollout step as one hipGraph (Philox positions of the sampler and of the device env in
     device memory).  Two iterations -- rollout, update, rollout -- replayed against the eager loop from the same seeds: all

@@ -21,7 +21,7 @@ from cleanrl_amd.envs import SyntheticAtariVecEnv  # noqa: E402
 from cleanrl_amd.learner import PPOLearner  # noqa: E402
 
 
-def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, device=None):
+def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, device=None, graphs=None, workers=None, pin=True):
     """PCIe-inclusive env-steps/s of the learner fed by HOST vector envs (numpy stand-ins on host threads): ``groups`` = 1 is
     the reference's serial arrangement (act -> D2H -> envs.step -> H2D of the full stacks), ``groups`` > 1 the overlapped
     env-group lanes of cleanrl_amd/pipeline.py.  Returns the dict that main() prints."""
@@ -29,7 +29,14 @@ def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, devic
 
     dev = device or torch.device("cuda:0")
     N, T = num_envs, num_steps
-    envs = split_env_groups(lambda g, n: SyntheticAtariVecEnv(n, seed=1 + g * n, api="gym"), N, groups)
+    workers = groups > 1 if workers is None else workers
+    if workers:          # every group's vector env in its own process, frames through shared memory (cleanrl_amd/env_workers.py)
+        from cleanrl_amd.env_workers import ProcessVecEnv
+
+        envs = split_env_groups(lambda g, n: ProcessVecEnv(("cleanrl_amd.envs", "SyntheticAtariVecEnv", dict(num_envs=n, seed=1 + g * n, api="gym"))),
+                                N, groups)
+    else:
+        envs = split_env_groups(lambda g, n: SyntheticAtariVecEnv(n, seed=1 + g * n, api="gym"), N, groups)
     torch.manual_seed(1)
     np.random.seed(1)
     agent = AtariAgent(envs[0]).to(dev)
@@ -38,6 +45,11 @@ def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, devic
     roll = GroupedRollout(L, groups, frame_delta=frame_delta)
     for g, e in enumerate(envs):
         roll.first_observation(g, e.reset())
+    graphs = groups > 1 if graphs is None else graphs
+    if graphs:
+        roll.capture()                                # one hipGraph per (lane, step) for the policy forward + sampling + D2H
+    one_thread = bool(graphs and workers)             # envs in processes + captured lane steps: one host thread drives every lane
+    pinned = one_thread and pin and all([e.pin() for e in envs])      # frames DMA'd straight from the workers' (registered) shared memory
     t_env = [0.0] * groups
 
     def step_fn(g, actions, step):
@@ -54,7 +66,10 @@ def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, devic
             t_roll = t_upd = 0.0
             t_env[:] = [0.0] * groups
         r0 = time.perf_counter()
-        roll.run(step_fn)
+        if one_thread:
+            roll.run_async(envs)
+        else:
+            roll.run(step_fn)
         L.finish_rollout()
         torch.cuda.synchronize()
         t_roll += time.perf_counter() - r0
@@ -64,13 +79,18 @@ def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, devic
         torch.cuda.synchronize()
         t_upd += time.perf_counter() - u0
     el = time.perf_counter() - t0
+    for e in envs:
+        e.close()
     delta = roll.lanes[0].delta
-    return {"mode": f"host envs (numpy stand-ins) in {groups} env group(s): pinned uint8 staging, one stream + host thread per group"
-                    + (", newest-frame-only H2D" if delta else ", full-stack H2D"),
+    return {"mode": f"host envs (numpy stand-ins{', one worker process per group' if workers else ''}) in {groups} env group(s): pinned uint8 staging, one stream + host thread per group"
+                    + (", newest-frame-only H2D" if delta else ", full-stack H2D") + (", captured lane steps" if graphs else "")
+                    + (", one driver thread" + (", frames DMA'd from the workers' pinned shared memory" if pinned else "") if one_thread else ""),
             "num_envs": N, "num_steps": T, "iters": iters, "env_groups": groups, "sps": N * T * iters / el,
             "ms_per_iter": el / iters * 1e3, "rollout_ms": t_roll / iters * 1e3,
             "host_env_ms_per_group": [t / iters * 1e3 for t in t_env], "update_ms": t_upd / iters * 1e3,
-            "h2d_bytes_per_step": N * (7056 if delta else 28224)}
+            "h2d_bytes_per_step": N * (7056 if delta else 28224),
+            **({"lane_step_us": {k: (v / max(roll.async_stats["lane_steps"], 1) * 1e6 if k != "lane_steps" else v) for k, v in roll.async_stats.items()}}
+               if one_thread else {})}
 
 
 def main():
@@ -79,9 +99,13 @@ def main():
     ap.add_argument("--num-steps", type=int, default=128)
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--groups", type=int, nargs="*", default=[1, 2, 4, 8])
+    ap.add_argument("--no-graphs", action="store_true", help="eager lane steps (the arrangement before GroupedRollout.capture)")
+    ap.add_argument("--no-pin", action="store_true", help="do not register the workers' shared memory as pinned host memory (stage through the lanes' buffers)")
+    ap.add_argument("--no-workers", action="store_true", help="step every group's envs in the training process (threads only)")
     a = ap.parse_args()
     for k in a.groups:
-        print(json.dumps(run(a.num_envs, a.num_steps, a.iters, k, frame_delta=k > 1)), flush=True)
+        print(json.dumps(run(a.num_envs, a.num_steps, a.iters, k, frame_delta=k > 1, graphs=False if a.no_graphs else None,
+                             workers=False if a.no_workers else None, pin=not a.no_pin)), flush=True)
 
 
 if __name__ == "__main__":
