@@ -64,6 +64,39 @@ class _Env:
         return self.obs(), reward, done
 
 
+def update_from_rollout(agent, optimizer, obs, actions, logprobs, rewards, dones, values, next_obs, next_done, *,
+                        num_minibatches=4, update_epochs=4, gamma=0.99, gae_lambda=0.95, clip_coef=0.1, ent_coef=0.01,
+                        vf_coef=0.5, max_grad_norm=0.5):
+    """GAE + flatten + epochs x minibatches of one iteration (ppo_atari_envpool.py:250-322) on a filled rollout.  The host
+    shuffle draws from numpy's global stream as the reference does (seed it before the call).  Returns what the last
+    minibatch left behind (advantages, returns, the last loss dict).  ``tests/test_oracle_golden.py`` holds this function to
+    the whole-iteration golden minted from the reference's own lines (``atari_iteration.npz``), so the loop ``run`` times
+    is pinned as a whole, not only piece by piece."""
+    T, N = rewards.shape
+    batch = T * N
+    mb = batch // num_minibatches
+    with torch.no_grad():                                                        # :250-263
+        next_value = agent.get_value(next_obs).reshape(-1)
+        advantages, returns = TO.gae(rewards, dones, values, next_done, next_value, gamma, gae_lambda)
+    b_obs = obs.reshape((-1,) + tuple(obs.shape[2:]))                            # :266-271
+    b_logprobs, b_actions = logprobs.reshape(-1), actions.reshape(-1)
+    b_advantages, b_returns, b_values = advantages.reshape(-1), returns.reshape(-1), values.reshape(-1)
+    b_inds = np.arange(batch)
+    out = None
+    for epoch in range(update_epochs):                                          # :276-322
+        np.random.shuffle(b_inds)
+        for start in range(0, batch, mb):
+            mb_inds = b_inds[start:start + mb]
+            _, newlogprob, entropy, newvalue = agent.get_action_and_value(b_obs[mb_inds], b_actions.long()[mb_inds])
+            out = TO.ppo_loss(newlogprob, entropy, newvalue, b_logprobs[mb_inds], b_advantages[mb_inds],
+                              b_returns[mb_inds], b_values[mb_inds], clip_coef, ent_coef, vf_coef, True, True)
+            optimizer.zero_grad()
+            out["loss"].backward()
+            nn.utils.clip_grad_norm_(agent.parameters(), max_grad_norm)
+            optimizer.step()
+    return dict(advantages=advantages, returns=returns, last=out)
+
+
 def run(num_envs=32, num_steps=128, iterations=1, warmup_iterations=0, seed=1, num_minibatches=4, update_epochs=4,
         gamma=0.99, gae_lambda=0.95, clip_coef=0.1, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, lr=2.5e-4,
         n_actions=4, max_seconds=None):
@@ -80,7 +113,7 @@ def run(num_envs=32, num_steps=128, iterations=1, warmup_iterations=0, seed=1, n
     dones, values = torch.zeros((T, N)), torch.zeros((T, N))
     next_obs = torch.Tensor(envs.obs()).to(dev)
     next_done = torch.zeros(N)
-    batch, mb = T * N, T * N // num_minibatches
+    batch = T * N
     timed_steps, t_start, done_iters = 0, None, 0
     iter_secs = []
     for it in range(warmup_iterations + iterations):
@@ -98,24 +131,9 @@ def run(num_envs=32, num_steps=128, iterations=1, warmup_iterations=0, seed=1, n
             o, reward, d = envs.step(action.cpu().numpy())
             rewards[step] = torch.tensor(reward, dtype=torch.float32).view(-1)
             next_obs, next_done = torch.Tensor(o).to(dev), torch.Tensor(d).to(dev)
-        with torch.no_grad():                                                    # :250-263
-            next_value = agent.get_value(next_obs).reshape(-1)
-            advantages, returns = TO.gae(rewards, dones, values, next_done, next_value, gamma, gae_lambda)
-        b_obs = obs.reshape((-1, 4, 84, 84))                                     # :266-271
-        b_logprobs, b_actions = logprobs.reshape(-1), actions.reshape(-1)
-        b_advantages, b_returns, b_values = advantages.reshape(-1), returns.reshape(-1), values.reshape(-1)
-        b_inds = np.arange(batch)
-        for epoch in range(update_epochs):                                      # :276-322
-            np.random.shuffle(b_inds)
-            for start in range(0, batch, mb):
-                mb_inds = b_inds[start:start + mb]
-                _, newlogprob, entropy, newvalue = agent.get_action_and_value(b_obs[mb_inds], b_actions.long()[mb_inds])
-                out = TO.ppo_loss(newlogprob, entropy, newvalue, b_logprobs[mb_inds], b_advantages[mb_inds],
-                                  b_returns[mb_inds], b_values[mb_inds], clip_coef, ent_coef, vf_coef, True, True)
-                optimizer.zero_grad()
-                out["loss"].backward()
-                nn.utils.clip_grad_norm_(agent.parameters(), max_grad_norm)
-                optimizer.step()
+        update_from_rollout(agent, optimizer, obs, actions, logprobs, rewards, dones, values, next_obs, next_done,
+                            num_minibatches=num_minibatches, update_epochs=update_epochs, gamma=gamma, gae_lambda=gae_lambda,
+                            clip_coef=clip_coef, ent_coef=ent_coef, vf_coef=vf_coef, max_grad_norm=max_grad_norm)
         if it >= warmup_iterations:
             timed_steps += batch
             done_iters += 1

@@ -169,3 +169,41 @@ def test_numpy_float64_closed_form_loss_gradients_agree_with_reference_autograd(
     np.testing.assert_allclose(sc, ref, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(dl, g["dlogits"], rtol=1e-4, atol=1e-5 * np.abs(g["dlogits"]).max())
     np.testing.assert_allclose(dv, g["dvalue"].reshape(-1), rtol=1e-4, atol=1e-5 * np.abs(g["dvalue"]).max())
+
+
+def test_cpu_baseline_port_whole_iteration_matches_the_reference_lines():
+    """bench.py's ``cpu_baseline`` (kind = "port", oracle/cpu_ppo_port.py) times ``update_from_rollout`` inside its loop.
+    Teacher-forced on the rollout of the whole-iteration golden (ppo_atari_envpool.py:250-322 exec'd verbatim by
+    oracle/mint_goldens.py::mint_atari_iteration: T = 8, N = 4, 2 epochs x 2 minibatches, four Adam steps), the port must
+    leave the reference's advantages, returns, last-minibatch scalars and parameters.  Same stock torch CPU ops in the same
+    order; the only difference is the orthogonal initialisation's LAPACK QR, which moves with the host CPU by a few ulp
+    (measured here: 7.5e-8), so the bars are absolute and three orders below what the update moves a parameter (2.4e-4 on
+    average over the four Adam steps) -- not a statistical tolerance."""
+    import torch.optim as optim
+
+    from oracle import cpu_ppo_port as P
+
+    g = load_golden("atari_iteration")["atari_T8_N4"]
+    Tn, N = g["rewards"].shape
+    torch.manual_seed(int(g["init_seed"]))
+    agent = P.RefAgent(4)
+    flat = lambda: torch.cat([p.detach().reshape(-1) for p in agent.parameters()])          # noqa: E731
+    stride = int(g["stride"])
+    np.testing.assert_allclose(flat()[::stride].numpy(), g["init_params_sub"], rtol=0, atol=3e-7)   # the reference Agent's init stream
+    assert abs(flat().double().sum().item() - float(g["init_checksum"])) < 1e-3
+    optimizer = optim.Adam(agent.parameters(), lr=float(g["lr"]), eps=1e-5)
+    frames = T(g["frames_u8"]).float()
+    done = T(g["step_done"])
+    np.random.seed(int(g["shuffle_seed"]))
+    out = P.update_from_rollout(agent, optimizer, frames[:Tn], T(g["actions"]), T(g["logprobs"]), T(g["rewards"]), done[:Tn],
+                                T(g["values"]), frames[Tn], done[Tn], num_minibatches=2, update_epochs=2)
+    np.testing.assert_allclose(out["advantages"].numpy(), g["advantages"], rtol=0, atol=5e-6)   # next_value comes from the agent
+    np.testing.assert_allclose(out["returns"].numpy(), g["returns"], rtol=0, atol=5e-6)
+    last = out["last"]
+    for key, ref in (("loss", "last_loss"), ("pg_loss", "last_pg_loss"), ("v_loss", "last_v_loss"), ("entropy", "last_entropy"),
+                     ("approx_kl", "last_approx_kl")):
+        np.testing.assert_allclose(float(last[key].detach()), float(g[ref]), rtol=5e-5, atol=2e-7, err_msg=key)
+    moved = np.abs(g["final_params_sub"] - g["init_params_sub"]).mean()
+    assert moved > 1e-4                                                                      # the update did something
+    np.testing.assert_allclose(flat()[::stride].numpy(), g["final_params_sub"], rtol=0, atol=1e-6)
+    assert abs(flat().double().sum().item() - float(g["final_checksum"])) < 1e-3
