@@ -1,4 +1,4 @@
-"""profiles/traffic.json from the HBM-traffic PMC passes of tools/gpu_r3_final.sh (profiles/r03_pmc_{fetch,write}.csv).
+"""profiles/traffic.json from the HBM-traffic PMC passes of tools/gpu_r3_final2.sh (profiles/r03_pmc_{fetch,write}.csv).
 
 HBM bytes per launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB: on gfx950 FETCH_SIZE tallies 128-byte read requests at
 64 bytes (MI355X_MICROARCH.md "HBM"; confirmed here by the calibration copies of the same passes: a 1 GiB read reports
@@ -11,8 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 IMAGES = 32768
-# the newest passes over the committed kernel set (the group-major / XCD-range workgroup order of kernel Z)
-FETCH_CSV, WRITE_CSV = "r03_pmc_fetch_group_major_xcd.csv", "r03_pmc_write_group_major_xcd.csv"
+# the newest passes over the committed kernel set (tools/gpu_r3_final2.sh: B ring, mask bits, phased k-order)
+FETCH_CSV, WRITE_CSV = "r03_pmc_fetch.csv", "r03_pmc_write.csv"
 KEYS = {   # bench key -> (kernel-name substring, geometry substring) in rocpd_pmc.py's (truncated) kernel names
     "conv1_fwd": ("conv1q_fwd_kernel", ""),
     "conv2_fwd": ("z_kernel", "ZRowsConv<20, 20, 32, 4, 4, 9, 9, 2, 0,"),
@@ -23,14 +23,15 @@ KEYS = {   # bench key -> (kernel-name substring, geometry substring) in rocpd_p
     "conv2_wgrad": ("convw_bf16_kernel", "VGeom<20, 20, 32,"),
     "conv3_wgrad": ("convw_bf16_kernel", "VGeom<9, 9, 64,"),
     "fc_fwd": ("z_kernel", "ZRowsLinear, 2, 4, 4, 0, true"),
-    "fc_dgrad": ("z_kernel", "ZRowsLinear, 2, 4, 4, 1, false"),
+    "fc_dgrad": ("z_kernel", "ZRowsLinear, 2, 4, 4, 3, false"),     # epilogue 3 = ReLU-backward from mask bits
     "fc_wgrad": ("fcw_", ""),                         # kernel W + the sum of its slab partials
 }
-ALGORITHMIC = {   # bytes per image the algorithm must move (inputs read once + outputs written once)
-    "conv1_fwd": 28224 + 51200, "conv2_fwd": 51200 + 20736, "conv3_fwd": 20736 + 12544,
-    "conv2_dgrad": 20736 + 51200 + 51200, "conv3_dgrad": 12544 + 20736 + 20736,
+ALGORITHMIC = {   # bytes per image the algorithm must move (inputs read once + outputs written once); the ReLU masks travel as bits
+    # (1/32 of the activation's bytes): written by the forward that produces the activation, read by the data gradient above it
+    "conv1_fwd": 28224 + 51200 + 1600, "conv2_fwd": 51200 + 20736 + 648, "conv3_fwd": 20736 + 12544 + 392,
+    "conv2_dgrad": 20736 + 1600 + 51200, "conv3_dgrad": 12544 + 648 + 20736,
     "conv1_wgrad": 28224 + 51200, "conv2_wgrad": 51200 + 20736, "conv3_wgrad": 20736 + 12544,
-    "fc_fwd": 12544 + 2048, "fc_dgrad": 2048 + 12544 + 12544,        # per row: a3 + h;  dz + mask + da3 (the 6.4 MB weight not counted)
+    "fc_fwd": 12544 + 2048, "fc_dgrad": 2048 + 392 + 12544,          # per row: a3 + h;  dz + mask bits + da3 (the 6.4 MB weight not counted)
     "fc_wgrad": 2048 + 12544,                                         # per row: dz + a3 (the 6.4 MB result and its partials not counted)
 }
 
@@ -42,7 +43,7 @@ def load(name):
 
 def main():
     fetch, write = load(FETCH_CSV), load(WRITE_CSV)
-    out = {"source": f"profiles/{FETCH_CSV}, profiles/{WRITE_CSV} (tools/gpu_quick_traffic.sh): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/conv_traffic 32768 3",
+    out = {"source": f"profiles/{FETCH_CSV}, profiles/{WRITE_CSV} (tools/gpu_r3_final2.sh): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/conv_traffic 32768 3",
            "correction": "bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950: 128-byte read requests tallied at 64 bytes)",
            "calibration_fetch_KiB_for_1GiB_read": {k[:40]: v for k, v in fetch.items() if "calib" in k},
            "calibration_write_KiB_for_1GiB_write": {k[:40]: v for k, v in write.items() if "calib" in k},
