@@ -81,9 +81,24 @@ SIGNATURES = {
     "mi355ppo_fc_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mi355ppo_fc_wgrad_kernel": (c_int, [c_int, c_int, c_int]),
     "mi355ppo_fc_wgrad_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    # host-pointer twins (csrc/host_twins.hip): the device signatures minus stream / workspace
+    "mi355ppo_gae_f32_cpu": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double]),
+    "mi355ppo_categorical_sample_f32_cpu": (c_int, [_P, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_int]),
+    "mi355ppo_categorical_logprob_entropy_f32_cpu": (c_int, [_P, _P, _P, _P, _P, c_int, c_int]),
+    "mi355ppo_categorical_logprob_entropy_bwd_f32_cpu": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int]),
+    "mi355ppo_normal_sample_f32_cpu": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, _P, c_int, c_int]),
+    "mi355ppo_normal_logprob_entropy_f32_cpu": (c_int, [_P, _P, _P, _P, _P, c_int, c_int]),
+    "mi355ppo_normal_logprob_entropy_bwd_f32_cpu": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int]),
+    "mi355ppo_loss_categorical_fwd_bwd_f32_cpu": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int, _P, _P, _P, _P]),
+    "mi355ppo_loss_normal_fwd_bwd_f32_cpu": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_double, c_int, c_int, _P, _P, _P, _P, _P]),
+    "mi355ppo_clip_adam_f32_cpu": (
+        c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, c_double, c_int64, _P]),
+    "mi355ppo_obs_u8_to_f32_cpu": (c_int, [_P, _P, _P, c_int64, c_int64, c_int]),
 }
 
-ABI_VERSION = 132       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 140       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

@@ -30,7 +30,7 @@ __device__ __forceinline__ void load_row(float (&x)[AMAX], const float* __restri
 }
 
 template <int AMAX>
-__device__ __forceinline__ void categorical_row(const float (&x)[AMAX], int A, CatRow<AMAX>& out) {
+MI355_HD void categorical_row(const float (&x)[AMAX], int A, CatRow<AMAX>& out) {
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < AMAX; ++j) if (j < A) m = fmaxf(m, x[j]);

@@ -9,6 +9,9 @@
 #include "../../include/mi355ppo.h"
 
 #define MI355_WAVE 64
+// Row / element math shared by the device kernels and their host-pointer twins (host_twins.hip): one definition, compiled for
+// both sides, so "same math" is a property of the source and not of two restatements.
+#define MI355_HD __host__ __device__ __forceinline__
 
 namespace mi355ppo {
 
@@ -54,8 +57,45 @@ inline int check_launch(const char* what) {
         }                                       \
     } while (0)
 
-// ------------------------------------------------------------------------------------ device
+// ------------------------------------------------------------------------------------ host + device
 #ifdef __HIPCC__
+
+MI355_HD uint32_t mulhi_u32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+// Philox4x32-10 (Salmon et al., SC'11).  Counter-based: the caller chooses the counter so that the
+// stream does not depend on the launch geometry (nor on host vs device: the twins draw the same words).
+struct Philox {
+    uint32_t k0, k1;
+    MI355_HD Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    MI355_HD uint4 operator()(uint64_t ctr_lo, uint64_t ctr_hi) const {
+        uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint32_t hi0 = mulhi_u32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            const uint32_t hi1 = mulhi_u32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            const uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+
+// uint32 -> uniform in (0,1): the top 23 bits k give (k + 0.5) * 2^-23.  k + 0.5 = (2k+1)/2 needs 24 significand
+// bits, so every value is exact in f32 and lies in [2^-24, 1 - 2^-24]: neither 0 nor 1 can be produced (with 24 bits
+// of x, (2^24-1) + 0.5 would round to 2^24 and return exactly 1).
+MI355_HD float u32_to_unit_open(uint32_t x) {
+    return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
+}
+
+// ------------------------------------------------------------------------------------ device
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -84,33 +124,6 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
     }
     __syncthreads();
     return r;
-}
-
-// Philox4x32-10 (Salmon et al., SC'11).  Counter-based: the caller chooses the counter so that the
-// stream does not depend on the launch geometry.
-struct Philox {
-    uint32_t k0, k1;
-    __device__ __forceinline__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
-    __device__ __forceinline__ uint4 operator()(uint64_t ctr_lo, uint64_t ctr_hi) const {
-        uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
-        uint32_t a = k0, b = k1;
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-            const uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-            a += 0x9E3779B9u; b += 0xBB67AE85u;
-        }
-        return make_uint4(c0, c1, c2, c3);
-    }
-};
-
-// uint32 -> uniform in (0,1): the top 23 bits k give (k + 0.5) * 2^-23.  k + 0.5 = (2k+1)/2 needs 24 significand
-// bits, so every value is exact in f32 and lies in [2^-24, 1 - 2^-24]: neither 0 nor 1 can be produced (with 24 bits
-// of x, (2^24-1) + 0.5 would round to 2^24 and return exactly 1).
-__device__ __forceinline__ float u32_to_unit_open(uint32_t x) {
-    return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
 #endif  // __HIPCC__

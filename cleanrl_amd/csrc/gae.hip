@@ -19,24 +19,11 @@
 // reference's order ((g*nv)*nnt), ((r+.)-v), (((g*l)*nnt)*last); g*l is formed in double on the
 // host and rounded to f32 once, as Python/torch do for `args.gamma * args.gae_lambda * tensor`.
 #include "common.h"
+#include "ppo_rows.h"
 
 #pragma clang fp contract(off)
 
 namespace mi355ppo {
-
-__device__ __forceinline__ float gae_step(float r, float v, float nextv, float nextd, float last,
-                                          float gamma, float gl, float* ret_out) {
-    const float nnt = 1.0f - nextd;
-    float x = gamma * nextv;
-    x = x * nnt;
-    x = r + x;
-    const float delta = x - v;
-    float c = gl * nnt;
-    c = c * last;
-    const float adv = delta + c;
-    *ret_out = adv + v;
-    return adv;
-}
 
 template <int V> struct Vec;
 template <> struct Vec<1> { using type = float; };

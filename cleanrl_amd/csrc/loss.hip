@@ -34,6 +34,7 @@
 // torch.clamp passes gradient on the closed interval; both are reproduced.
 #include "common.h"
 #include "catrow.h"
+#include "ppo_rows.h"
 
 #pragma clang fp contract(off)
 
@@ -41,7 +42,6 @@ namespace mi355ppo {
 
 constexpr int kStatsMaxBlocks = 1024;   // partial pairs of the advantage statistics (256 lanes x 4 rows per sweep each)
 constexpr int kMaxGrid = 2048;          // workgroups of the persistent row pass
-constexpr int kNumSums = 6;             // pg, v, entropy, -logratio, (ratio-1)-logratio, clip indicator
 constexpr int kMaxD = 64;
 // Packed behaviour rows: one 32-byte row per flat batch index, {action (f32 storage), old log-prob, advantage, return, old
 // value, 0, 0, 0}.  A minibatch row then costs ONE 32-byte gather instead of five 4-byte gathers out of five arrays (five
@@ -52,15 +52,6 @@ struct LossSlot {          // 64-byte head of a workspace: what the scalar fold 
     int M, nblocks, D, pad;
     float ent_coef, vf_coef;
     int pad2[10];
-};
-
-struct LossParams {
-    float lo, hi;        // (float)(1 - clip), (float)(1 + clip): torch.clamp(ratio, 1 - c, 1 + c) scalar args
-    float clip;          // (float)clip
-    float ent_coef, vf_coef;
-    int norm_adv, clip_vloss;
-    int M;
-    int stats_blocks;    // partial pairs written by loss_adv_stats; 0 = the caller supplied (mean, std + 1e-8)
 };
 
 // ---- 1. advantage statistics ---------------------------------------------------------------------
@@ -102,15 +93,6 @@ __global__ __launch_bounds__(256) void loss_adv_stats(const int64_t* __restrict_
         partials[2 * blockIdx.x] = bs;
         partials[2 * blockIdx.x + 1] = bss;
     }
-}
-
-// torch: (adv - adv.mean()) / (adv.std() + 1e-8), std unbiased.
-__device__ __forceinline__ void mean_den_from_sums(double s, double ss, double n, float* mean, float* den) {
-    const double mu = s / n;
-    double var = (ss - s * mu) / (n - 1.0);
-    if (var < 0.0) var = 0.0;
-    *mean = (float)mu;
-    *den = (float)sqrt(var) + 1e-8f;
 }
 
 // (mean, std + 1e-8) pairs of `nseg` consecutive minibatches of `M` rows each (the last may be shorter: `total` rows in
@@ -169,60 +151,6 @@ __device__ __forceinline__ void fold_adv_stats(const double* __restrict__ partia
     __syncthreads();
     mean = s_pub[0];
     den = s_pub[1];
-}
-
-struct RowTerms {
-    float g_lp;      // d loss / d newlogprob for this row (already / M)
-    float dvalue;    // d loss / d newvalue
-    float sums[kNumSums];
-};
-
-// Everything that does not depend on the distribution family.
-__device__ __forceinline__ RowTerms ppo_row_terms(float newlp, float H, float v, float old_lp, float adv, float ret,
-                                                  float old_v, float mean, float den, const LossParams& P) {
-    RowTerms o;
-    const float inv_m = 1.0f / (float)P.M;
-    const float logratio = newlp - old_lp;
-    const float ratio = expf(logratio);
-    float A = adv;
-    if (P.norm_adv) A = (adv - mean) / den;
-    const float nA = -A;
-    const float pg1 = nA * ratio;
-    const float clamped = fminf(fmaxf(ratio, P.lo), P.hi);
-    const float pg2 = nA * clamped;
-    const float inr = (ratio >= P.lo && ratio <= P.hi) ? 1.0f : 0.0f;
-    float w;   // d max(pg1,pg2) / d ratio, in units of nA
-    if (pg1 > pg2) w = 1.0f;
-    else if (pg2 > pg1) w = inr;
-    else w = 0.5f + 0.5f * inr;
-    o.g_lp = (inv_m * (nA * w)) * ratio;
-
-    const float du = v - ret;
-    const float u = du * du;
-    float vterm, gv;
-    if (P.clip_vloss) {
-        const float dv = v - old_v;
-        const float cl = fminf(fmaxf(dv, -P.clip), P.clip);
-        const float vc = old_v + cl;
-        const float dc = vc - ret;
-        const float c = dc * dc;
-        const float inv = (dv >= -P.clip && dv <= P.clip) ? 1.0f : 0.0f;
-        vterm = fmaxf(u, c);
-        if (u > c) gv = 2.0f * du;
-        else if (c > u) gv = (2.0f * dc) * inv;
-        else gv = 0.5f * (2.0f * du) + 0.5f * ((2.0f * dc) * inv);
-    } else {
-        vterm = u;
-        gv = 2.0f * du;
-    }
-    o.dvalue = ((P.vf_coef * 0.5f) * inv_m) * gv;
-    o.sums[0] = fmaxf(pg1, pg2);
-    o.sums[1] = vterm;
-    o.sums[2] = H;
-    o.sums[3] = -logratio;
-    o.sums[4] = (ratio - 1.0f) - logratio;
-    o.sums[5] = (fabsf(ratio - 1.0f) > P.clip) ? 1.0f : 0.0f;
-    return o;
 }
 
 // Block-reduce the lane sums into this workgroup's partial (fixed order).  `extra` = D more per-wave f64 sums already in

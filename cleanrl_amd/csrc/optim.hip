@@ -11,6 +11,7 @@
 //                zeroes the gradient for the next backward           (reads 16, writes 16 B/param)
 // Algorithmic bytes = 36 B/param (1.69 M params -> 60.7 MB per step, HBM/L2-streaming, float4).
 #include "common.h"
+#include "ppo_rows.h"
 
 #pragma clang fp contract(off)
 
@@ -35,30 +36,6 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict
     }
     const double r = block_sum<4>(s, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = r;
-}
-
-struct AdamParams {
-    float scale, max_norm;
-    float w1;         // (float)(1 - beta1)              lerp weight
-    float beta2;      // (float)beta2
-    float w2;         // (float)(1 - beta2)
-    float bc2_sqrt;   // (float)sqrt(1 - beta2^step)
-    float eps;
-    float neg_step;   // (float)(-(lr / (1 - beta1^step)))
-    int nblocks;
-    int zero_grads;
-};
-
-__device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, float coef, const AdamParams& A) {
-    float gg = g * A.scale;
-    gg = gg * coef;
-    m = m + A.w1 * (gg - m);                 // exp_avg.lerp_(grad, 1 - beta1), small-weight form
-    v = v * A.beta2;                         // exp_avg_sq.mul_(beta2)
-    v = v + (A.w2 * gg) * gg;                //            .addcmul_(grad, grad, value=1 - beta2)
-    float denom = sqrtf(v) / A.bc2_sqrt;     // (exp_avg_sq.sqrt() / bias_correction2_sqrt)
-    denom = denom + A.eps;                   //            .add_(eps)
-    p = p + A.neg_step * (m / denom);        // param.addcdiv_(exp_avg, denom, value=-step_size)
-    g = A.zero_grads ? 0.0f : gg;
 }
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g,

@@ -505,17 +505,17 @@ class PPOLearner:
             if self.hwc_frames:
                 x = x.permute((0, 3, 1, 2))                       # "bhwc" -> "bchw" (ppo_procgen.py:150)
         p, newvalue = self.agent.heads(x)
-        acts = b_actions.long()[mb_inds] if self.discrete else b_actions[mb_inds]
+        # K3 through the C ABI's host-pointer twins: the distribution, the three loss terms and their gradients down to the
+        # network outputs in one call on the FLAT batch arrays + mb_inds -- the seam the GPU path crosses (forward_backward_hip)
+        inds = torch.as_tensor(mb_inds, dtype=torch.int64)
         if self.discrete:
-            probs = torch.distributions.Categorical(logits=p)
-            newlogprob, entropy = probs.log_prob(acts), probs.entropy()
+            loss, scalars = host_ops.ppo_loss_categorical(p, newvalue, inds, b_actions, b_logprobs, b_advantages, b_returns,
+                                                          b_values, a.clip_coef, a.ent_coef, a.vf_coef, a.norm_adv, a.clip_vloss)
         else:
             p = self.agent.perturb_mean(p) if getattr(self.agent, "rpo_alpha", None) is not None else p
-            probs = torch.distributions.Normal(p, torch.exp(self.agent.actor_logstd.expand_as(p)))
-            newlogprob, entropy = probs.log_prob(acts).sum(1), probs.entropy().sum(1)
-        loss, scalars = host_ops.ppo_loss(newlogprob, entropy, newvalue, b_logprobs[mb_inds], b_advantages[mb_inds],
-                                          b_returns[mb_inds], b_values[mb_inds], a.clip_coef, a.ent_coef, a.vf_coef,
-                                          a.norm_adv, a.clip_vloss)
+            loss, scalars = host_ops.ppo_loss_normal(p, self.agent.actor_logstd, newvalue, inds, b_actions, b_logprobs,
+                                                     b_advantages, b_returns, b_values, a.clip_coef, a.ent_coef, a.vf_coef,
+                                                     a.norm_adv, a.clip_vloss)
         self.optimizer.zero_grad()
         loss.backward()
         self._host_allreduce_grads()

@@ -32,9 +32,9 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 132 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
-                                  point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2: round 3); a binding
-                                  must check major AND minor (cleanrl_amd/_lib.py does) */
+#define MI355PPO_VERSION 140 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+                                  point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2, 1.3: round 3;
+                                  1.4: the *_cpu host-pointer twins); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
 
 #if defined(__GNUC__)
 #define MI355PPO_API __attribute__((visibility("default")))
@@ -256,6 +256,55 @@ MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_
                            double grad_scale, double max_grad_norm, double lr,
                            double beta1, double beta2, double eps, int64_t step,
                            float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-pointer twins (csrc/host_twins.hip) of the PPO-path entry points above: the same arguments minus `stream` and
+ * `workspace`, every pointer a HOST pointer, the call returns when the result is written.  Same math by construction: the
+ * row / element functions (GAE step, Categorical row, loss row terms, advantage statistics fold, Adam element, Philox stream)
+ * are the device kernels' own, compiled for the host from the same headers (csrc/ppo_rows.h, catrow.h, common.h) without FMA
+ * contraction; results differ from the device's only by libm vs the device math library (expf / logf: a few ulp) and by the
+ * order of the f64 reductions (row order here).  Serial.  They serve BASELINE config A -- cleanrl/ppo.py on CPU (`--no-cuda`:
+ * CartPole, num_envs = 4) -- and the world_size-2 gloo tests through cleanrl_amd/host_ops.py.  They are NOT a fallback: nothing
+ * routes a device pointer here, and a CUDA device without the HIP kernels raises (cleanrl_amd/_lib.py).
+ * Reference lines: as for the device entry point of the same name.
+ */
+MI355PPO_API int mi355ppo_gae_f32_cpu(const float* rewards, const float* dones, const float* values, const float* next_done,
+                                      const float* next_value, float* advantages, float* returns, int T, int N, double gamma,
+                                      double gae_lambda);
+MI355PPO_API int mi355ppo_categorical_sample_f32_cpu(const float* logits, const float* noise_exp1, uint64_t seed, uint64_t offset,
+                                                     int64_t* action_i64, float* action_f32, float* logprob, float* entropy,
+                                                     int B, int A);
+MI355PPO_API int mi355ppo_categorical_logprob_entropy_f32_cpu(const float* logits, const int64_t* action_i64,
+                                                              const float* action_f32, float* logprob, float* entropy, int B,
+                                                              int A);
+MI355PPO_API int mi355ppo_categorical_logprob_entropy_bwd_f32_cpu(const float* logits, const int64_t* action_i64,
+                                                                  const float* action_f32, const float* g_logprob,
+                                                                  const float* g_entropy, float* dlogits, int B, int A);
+MI355PPO_API int mi355ppo_normal_sample_f32_cpu(const float* mean, const float* logstd, const float* noise_std_normal, uint64_t seed,
+                                                uint64_t offset, float* action, float* logprob_sum, float* entropy_sum, int B,
+                                                int D);
+MI355PPO_API int mi355ppo_normal_logprob_entropy_f32_cpu(const float* mean, const float* logstd, const float* action,
+                                                         float* logprob_sum, float* entropy_sum, int B, int D);
+MI355PPO_API int mi355ppo_normal_logprob_entropy_bwd_f32_cpu(const float* mean, const float* logstd, const float* action,
+                                                             const float* g_logprob, const float* g_entropy, float* dmean,
+                                                             float* dlogstd_rows, int B, int D);
+MI355PPO_API int mi355ppo_loss_categorical_fwd_bwd_f32_cpu(const float* new_logits, const float* new_value, const int64_t* mb_inds,
+                                                           const float* b_actions_f32, const float* b_logprobs,
+                                                           const float* b_advantages, const float* b_returns, const float* b_values,
+                                                           int M, int A, double clip_coef, double ent_coef, double vf_coef,
+                                                           int norm_adv, int clip_vloss, const float* adv_mean_den, float* scalars7,
+                                                           float* dlogits, float* dvalue);
+MI355PPO_API int mi355ppo_loss_normal_fwd_bwd_f32_cpu(const float* new_mean, const float* logstd, const float* new_value,
+                                                      const int64_t* mb_inds, const float* b_actions, const float* b_logprobs,
+                                                      const float* b_advantages, const float* b_returns, const float* b_values,
+                                                      int M, int D, double clip_coef, double ent_coef, double vf_coef, int norm_adv,
+                                                      int clip_vloss, const float* adv_mean_den, float* scalars7, float* dmean,
+                                                      float* dlogstd, float* dvalue);
+MI355PPO_API int mi355ppo_clip_adam_f32_cpu(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                            double grad_scale, double max_grad_norm, double lr, double beta1, double beta2,
+                                            double eps, int64_t step, float* total_norm_out);
+MI355PPO_API int mi355ppo_obs_u8_to_f32_cpu(const uint8_t* src_u8, const int64_t* inds, float* dst_f32, int64_t rows,
+                                            int64_t row_bytes, int scale_255);
 
 /* ---------------------------------------------------------------------------------------------
  * FC   Linear(3136, 512) + ReLU of the NatureCNN (cleanrl/ppo_atari_multigpu.py:144-145) on the bf16 matrix pipe

@@ -59,12 +59,15 @@ def test_ppg_phase_matches_the_reference_lines(one_thread, capsys):
     np.random.seed(int(g["shuffle_seed"]))
     m = L.update(float(g["lr"]))                                      # policy phase
     assert torch.equal(L.advantages.reshape(-1), torch.from_numpy(g["b_advantages"]))     # full-batch normalisation
-    assert (_flat(agent)[::stride] - torch.from_numpy(g["policy_params_sub"])).abs().max().item() <= 1e-7
+    # (the policy phase's loss runs through the fused host twin of K3, mi355ppo_loss_categorical_fwd_bwd_f32_cpu: libm expf / logf
+    # and f64 row-order sums instead of torch's kernels -- a few ulp per gradient, which Adam's normalisation turns into at most
+    # 1.2e-6 here; one Adam step moves a parameter by lr = 5e-4)
+    assert (_flat(agent)[::stride] - torch.from_numpy(g["policy_params_sub"])).abs().max().item() <= 4e-6
     assert abs(m["loss"] - float(g["policy_loss"])) <= 1e-6 * max(1.0, abs(float(g["policy_loss"])))
     assert torch.equal(L.aux_obs[:, :N], torch.from_numpy(g["frames_u8"][:T])) and torch.equal(L.aux_returns[:, :N], L.returns)
     aux = L.aux_phase()                                               # auxiliary phase (continues the numpy shuffle stream)
     assert "aux epoch 2" in capsys.readouterr().out
-    assert (_flat(agent)[::stride] - torch.from_numpy(g["final_params_sub"])).abs().max().item() <= 2e-7
+    assert (_flat(agent)[::stride] - torch.from_numpy(g["final_params_sub"])).abs().max().item() <= 4e-6
     assert abs(_flat(agent).double().sum().item() - float(g["final_checksum"])) <= 1e-4
     for key in ("kl_loss", "aux_value_loss", "real_value_loss"):
         ref = float(g[key])
