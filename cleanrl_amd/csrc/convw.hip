@@ -64,14 +64,23 @@ constexpr VItem v_item(int t, int nf) {
 template <class G, int NT, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convw_bf16_kernel(
     const float* __restrict__ src, const float* __restrict__ dz, float* __restrict__ part_w, float* __restrict__ part_b, int images,
-    int nslabs, unsigned m8, unsigned m16) {
+    int nslabs, unsigned m8, unsigned m16, int xcd_order) {
     constexpr int MT = 2, NF = MT + NT, NGROUPS = G::TILES / NT, NL = 4 + 2 * NT;       // fragments; wave groups; loads per block
     constexpr int LDSF = 16 * (kVCout + 32 * NT);                                       // floats of one block in LDS
     static_assert(G::TILES % NT == 0, "whole groups of NT tiles");
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * LDSF];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int unit = blockIdx.x * 4 + wave;
+    // Workgroups are dealt to the eight XCDs round robin in launch order; neighbours in the UNIT order share data -- the six wave
+    // groups of a layer-3 slab sit in two consecutive workgroups and read the same dz and source pixels, consecutive slabs take
+    // adjacent 16-pixel blocks whose windows overlap -- so XCD x takes a contiguous range of the unit order (kernel Z's scheme):
+    // what neighbours share is fetched into ONE L2 (layer 3 fetched 1.9 x its algorithmic bytes in launch order, profiles/traffic.json).
+    unsigned wg = blockIdx.x;
+    if (xcd_order) {
+        const unsigned total = gridDim.x, x = wg & 7u, q = total >> 3, rem = total & 7u;
+        wg = x * q + (x < rem ? x : rem) + (wg >> 3);
+    }
+    const int unit = (int)wg * 4 + wave;
     if (unit >= nslabs * NGROUPS) return;                 // (whole wave; no barriers in this kernel)
     const int slab = unit / NGROUPS, grp = unit - slab * NGROUPS;
     const long long P = (long long)images * G::PER_IMG;
@@ -299,14 +308,15 @@ int convw_launch(const float* src, const float* dz, float* part_w, float* part_b
     const int S = convw_slabs(layer);
     *nparts = S;
     const int np = bf16_term_pairs();
+    static const int xcd = [] { const char* e = getenv("MI355PPO_V_XCD"); return e ? atoi(e) : 1; }();      // (A/B runs)
     if (layer == 2) {
         const int grid = (S * (VGeom2::TILES / 4) + 3) / 4;
-        if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 9>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u);
-        else hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 6>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u);
+        if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 9>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd);
+        else hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 6>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd);
     } else {
         const int grid = (S * (VGeom3::TILES / 3) + 3) / 4;
-        if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 9>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u);
-        else hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 6>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u);
+        if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 9>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd);
+        else hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 6>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd);
     }
     return check_launch("convw_bf16_kernel");
 }

@@ -199,6 +199,7 @@ struct ZArgs {
     int N, K;
     unsigned m8, m16;           // 0xffff0000, 0xffffff00: in SGPRs (as literals every v_and would be an 8-byte instruction)
     int steps_per;              // Z_RAW: k-steps per K split (blockIdx.z); 0 otherwise
+    int super_rows;             // GEMM rows, stacked waves: row blocks per supertile of the workgroup order (0: launch order)
 };
 
 // WAVES_N: the waves of a workgroup sit side by side (they read the same A rows) instead of on top of each other (they stream
@@ -232,6 +233,24 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         const unsigned logical = x * q + (x < rem ? x : rem) + (L >> 3);
         bx = logical % gridDim.x;
         by = logical / gridDim.x;
+    } else if constexpr (!WAVES_N && EPI != Z_RAW) {
+        // GEMM rows with stacked waves (the FC data gradient: 25 column blocks x M / 256 row blocks, K = 512): in launch order the
+        // column blocks of a row block land on all eight XCDs, so every L2 streams the whole 9.6 MB of B (and all the A rows in
+        // flight) once per ~10 row blocks -- 1.8 GB of L2 misses per launch for 0.49 GB of algorithmic bytes
+        // (profiles/traffic.json).  Instead: XCD x takes a CONTIGUOUS range of the logical order, and the logical order walks
+        // supertiles of `super_rows` row blocks x all column blocks, row block fastest: the supertile's A rows (super_rows x
+        // 512 KB) stay in the L2 while B streams through once per supertile.
+        if (a.super_rows > 0) {
+            const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y;
+            const unsigned x = L & 7u, q = total >> 3, rem = total & 7u;
+            const unsigned logical = x * q + (x < rem ? x : rem) + (L >> 3);
+            const unsigned per = (unsigned)a.super_rows * gridDim.x;
+            const unsigned sup = logical / per, r = logical - sup * per;
+            const unsigned left = gridDim.y - sup * (unsigned)a.super_rows;
+            const unsigned rows = left < (unsigned)a.super_rows ? left : (unsigned)a.super_rows;      // (the last supertile may be short)
+            bx = r / rows;
+            by = sup * (unsigned)a.super_rows + (r - bx * rows);
+        }
     }
     const int n0 = WAVES_N ? (bx * NWAVES + wave) * (32 * NT) : bx * (32 * NT);
     long long wtile = WAVES_N ? (long long)by : (long long)by * NWAVES + wave;        // this wave's row tile
@@ -778,6 +797,7 @@ static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, 
     a.A = A; a.a_bytes = (unsigned)a_bytes; a.lda = lda; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.mask = mask;
     a.bits_in = nullptr; a.bits_out = nullptr;
     a.steps_per = 0;
+    a.super_rows = 0;
     a.C = C; a.c_bytes = (unsigned)c_bytes; a.ldc = ldc; a.M = M; a.images = images; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
     return a;
 }
@@ -862,6 +882,8 @@ static int fc_dgrad_impl(const char* fn, const float* dz, int lddz, const void* 
     ZArgs za = zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, (long long)M * N * 4, N, M, N, K);
     // (the B ring -- z_launch<..., 1, true> for even K / 16 -- measured 630 -> 720 us here: one wave per SIMD has nothing to run while
     // it waits at the ring barrier; profiles/r03_blds_ab.jsonl)
+    static const int super_rows = [] { const char* e = getenv("MI355PPO_Z_SUPER"); return e ? atoi(e) : 4; }();      // (A/B runs)
+    za.super_rows = super_rows;
     if (bits) {
         MI355_REQUIRE(N % 32 == 0 && aligned(bits, 4) && aligned(da, 128), MI355PPO_EINVAL, "%s: bit masks need N %% 32 == 0 (N=%d) and da on a 128-byte boundary", fn, N);
         za.bits_in = bits;

@@ -293,3 +293,37 @@ def test_kernel_z_xcd_aware_workgroup_order_is_a_bijection_with_contiguous_range
     assert allv == list(range(total))
     for x, vs in per_xcd.items():
         assert vs == list(range(vs[0], vs[0] + len(vs)))
+
+
+def _z_supertile_order(gx, gy, super_rows):
+    """The workgroup -> (column block, row block) map of kernel Z for GEMM rows with stacked waves (gemmz.hip, the FC data
+    gradient), restated: launch index L runs on XCD L % 8; XCD x takes a contiguous range of the logical order; the logical
+    order walks supertiles of `super_rows` row blocks x all column blocks, row block fastest."""
+    out = []
+    total = gx * gy
+    for L in range(total):
+        x, q, rem = L & 7, total >> 3, total & 7
+        logical = x * q + min(x, rem) + (L >> 3)
+        per = super_rows * gx
+        sup, r = divmod(logical, per)
+        rows = min(gy - sup * super_rows, super_rows)
+        bx = r // rows
+        by = sup * super_rows + (r - bx * rows)
+        out.append((L & 7, logical, bx, by))
+    return out
+
+
+@pytest.mark.parametrize("gx,gy", [(25, 128), (25, 16), (25, 32), (25, 1), (25, 3), (7, 5), (1, 9), (25, 129)])
+def test_kernel_z_supertile_order_is_a_bijection_and_keeps_a_supertile_on_one_xcd(gx, gy):
+    order = _z_supertile_order(gx, gy, 4)
+    tiles = {(bx, by) for _, _, bx, by in order}
+    assert tiles == {(bx, by) for bx in range(gx) for by in range(gy)}          # every tile exactly once
+    assert len(order) == gx * gy
+    if (gx * gy) % 8 == 0 and (gx * gy // 8) % (4 * gx) == 0:                    # (config C: 3,200 workgroups = 8 x 4 supertiles)
+        for xcd in range(8):
+            sups = {by // 4 for x, _, _, by in order if x == xcd}
+            assert len(sups) == gy // 4 // 8                                    # whole supertiles, none shared between XCDs
+        # consecutive workgroups of an XCD (its launch order) walk a supertile row block fastest: 32 in flight = 8 column blocks
+        mine = sorted((logical, bx, by) for x, logical, bx, by in order if x == 0)
+        first32 = mine[:32]
+        assert {by for _, _, by in first32} == {0, 1, 2, 3} and {bx for _, bx, _ in first32} == set(range(8))
