@@ -308,7 +308,8 @@ int convw_launch(const float* src, const float* dz, float* part_w, float* part_b
     const int S = convw_slabs(layer);
     *nparts = S;
     const int np = bf16_term_pairs();
-    static const int xcd = [] { const char* e = getenv("MI355PPO_V_XCD"); return e ? atoi(e) : 1; }();      // (A/B runs)
+    const int xcd = 1;      // XCD-contiguous unit order: L2-miss reads 3.20 -> 2.38 GB (layer 2), 2.07 -> 1.12 GB (layer 3), times -0 .. 1.5 %
+                            // (same-box A/B with a run-time switch, profiles/r03_raster_ab.jsonl, r03_pmc_fetch_raster_{before,after}.csv)
     if (layer == 2) {
         const int grid = (S * (VGeom2::TILES / 4) + 3) / 4;
         if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 9>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd);

@@ -882,8 +882,9 @@ static int fc_dgrad_impl(const char* fn, const float* dz, int lddz, const void* 
     ZArgs za = zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, (long long)M * N * 4, N, M, N, K);
     // (the B ring -- z_launch<..., 1, true> for even K / 16 -- measured 630 -> 720 us here: one wave per SIMD has nothing to run while
     // it waits at the ring barrier; profiles/r03_blds_ab.jsonl)
-    static const int super_rows = [] { const char* e = getenv("MI355PPO_Z_SUPER"); return e ? atoi(e) : 4; }();      // (A/B runs)
-    za.super_rows = super_rows;
+    // supertiles of 4 row blocks: L2-miss reads 1.75 -> 0.62 GB per launch at 32,768 rows, 612 -> 605 us (2 / 8 row blocks: 598 / 602 us;
+    // same-box A/B with a run-time switch, profiles/r03_raster_ab.jsonl, r03_pmc_fetch_raster_{before,after}.csv)
+    za.super_rows = 4;
     if (bits) {
         MI355_REQUIRE(N % 32 == 0 && aligned(bits, 4) && aligned(da, 128), MI355PPO_EINVAL, "%s: bit masks need N %% 32 == 0 (N=%d) and da on a 128-byte boundary", fn, N);
         za.bits_in = bits;
