@@ -206,7 +206,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * kWLdsFloats];        // 4 waves x 2 buffers x 12 KiB = 96 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int kb = blockIdx.x % nkb, slab = blockIdx.x / nkb;
+    // Every workgroup reads ALL of its slab's dz (512 columns): in launch order the 49 workgroups of a slab land on all eight XCDs
+    // and each L2 fetches the whole dz (8 x 67 MB of the launch's 0.95 GB of L2 misses, profiles/traffic.json).  XCD x takes a
+    // contiguous range of the (slab, k block) order instead (kernel Z's scheme): an L2 then sees at most two slabs.
+    unsigned wg = blockIdx.x;
+    {
+        const unsigned total = gridDim.x, x = wg & 7u, q = total >> 3, rem = total & 7u;
+        wg = x * q + (x < rem ? x : rem) + (wg >> 3);
+    }
+    const int kb = (int)wg % nkb, slab = (int)wg / nkb;
     const int n0 = wave * kWn, k0 = kb * kWk;
     const int nblocks = M / 16;                           // 16-row blocks of the batch; slab s takes blocks s, s + S, s + 2 S, ...
     const int nsteps = (nblocks - slab + kWSlabs - 1) / kWSlabs;

@@ -3,7 +3,7 @@
 # (MI355PPO_Z_SUPER = row blocks per supertile, 0 = launch order) and kernel V's XCD-contiguous unit order (MI355PPO_V_XCD).
 # Bit-identity of the dumped results first, then timings, then the L2-miss read traffic (FETCH_SIZE pass).
 # Ran on the commit that introduced the two orders, where both were behind these run-time switches; the switches were removed
-# with the result (supertiles of 4 row blocks, XCD-contiguous units): check that commit out to repeat the A/B.
+# with the result (supertiles of 4 row blocks, XCD-contiguous units): check that commit (f3bbcca) out to repeat the A/B.
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/raster; mkdir -p $O

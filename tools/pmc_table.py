@@ -1,4 +1,4 @@
-"""Markdown rows from the PMC passes of tools/gpu_r3_final.sh (profiles/r03_pmc_{busy,mem,lds,fetch,write}.csv): per kernel of one
+"""Markdown rows from the PMC passes of tools/gpu_r3_final2.sh (profiles/r03_pmc_{busy,mem,lds,fetch,write}.csv): per kernel of one
 minibatch update at 32,768 images -- matrix-pipe busy, effective clock, wave cycles waiting, VALU / LDS / TA busy, L2-miss traffic.
 
     matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = [("conv1q_fwd_kernel", "", "Q conv1 fwd"), ("z_kernel", "ZRowsConv<20, 20, 32, 4, 4, 9, 9, 2, 0,", "Z conv2 fwd"),
          ("z_kernel", "ZRowsConv<9, 9, 64, 3, 3, 7, 7, 1, 0,", "Z conv3 fwd"), ("z_kernel", "ZRowsLinear, 2, 4, 4, 0, true", "Z FC fwd"),
-         ("z_kernel", "ZRowsLinear, 2, 4, 4, 1, false", "Z FC dgrad"), ("fcw_bf16_kernel", "", "W FC wgrad"),
+         ("z_kernel", "ZRowsLinear, 2, 4, 4, 3, false", "Z FC dgrad"), ("fcw_bf16_kernel", "", "W FC wgrad"),
          ("convw_bf16_kernel", "VGeom<9, 9, 64,", "V conv3 wgrad"), ("z_kernel", "ZRowsConv<7, 7, 64, 3, 3, 9, 9, 1, -2,", "Z conv3 dgrad"),
          ("convw_bf16_kernel", "VGeom<20, 20, 32,", "V conv2 wgrad"), ("z_kernel", "ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1,", "Z conv2 dgrad"),
          ("conv1p_wgrad_kernel", "", "P conv1 wgrad")]
