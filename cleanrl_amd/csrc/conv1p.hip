@@ -45,8 +45,8 @@ constexpr int kPLine = 32;                                // bytes per (R, t, c)
 constexpr int kPRowLds = 16 * kPLine;                     // 512 bytes of LDS per source row
 constexpr int kPSlabLds = kPSlabRows * kPRowLds;          // 12,288 bytes per wave
 constexpr int kPSteps = 8, kPGroups = 15;
-constexpr int kPQuads = kPSlabRows * 5;                   // 120 four-chunk pieces (q = 0..19 of every source row): two per lane
-constexpr int kPQuadsPerLane = 2;                         // (+ the 24 chunks q = 20, one each for lanes 0..23)
+constexpr int kPPieceQuads = 8 * 5;                       // staging piece = 8 source rows: 40 four-chunk quads (q = 0..19), one per lane
+                                                          // (+ the 8 chunks q = 20, one each for lanes 0..7)
 
 // group g of a wave's 5 output rows -> (output row, first pixel, valid pixels); g = 15 is the empty 16th slot
 __host__ __device__ constexpr int p_row(int g) { return g < kPGroups ? g / 3 : kPRowsPerWave - 1; }
@@ -58,7 +58,8 @@ __device__ __forceinline__ unsigned p_perm(unsigned hi, unsigned lo, unsigned se
 // two f32 whose low 16 bits are irrelevant/zero -> packed bf16 pair (element 0 in the low half)
 __device__ __forceinline__ unsigned p_pack_hi16(float e1, float e0) { return p_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u); }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1p_wgrad_kernel(
+template <int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv1p_wgrad_kernel(
     const unsigned char* __restrict__ src, const int64_t* __restrict__ inds, const float* __restrict__ dz,
     float* __restrict__ part_w,      // [grid * 4][32][256]
     float* __restrict__ part_b,      // [grid * 4][32]
@@ -85,39 +86,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto slab = [&](long long simg) { return src + simg * (long long)kPImg + wave * (4 * kPRowsPerWave * kPPitch); };
 
     // ---- staging: global (16-byte chunks = 4 pixels) -> registers -> 4x4 byte transposes -> LDS lines ----
-    p_u32x4 st[kPQuadsPerLane][4], st20;
-    auto stage_load = [&](const unsigned char* g0) {
+    // In three PIECES of 8 source rows (40 four-chunk quads + the 8 chunks q = 20: one quad and at most one chunk per lane,
+    // 20 registers in flight instead of the whole slab's 36 -- the kernel spilled 32 VGPRs at its two-waves-per-SIMD budget).
+    // Piece P of the NEXT image replaces rows 8P .. 8P+7 as soon as the current image's last reader of those rows has issued
+    // (output row r reads source rows 4r .. 4r+7; LDS instructions of one wave execute in order): piece 0 after step 2
+    // (groups 0-5 = output rows 0, 1), piece 1 after step 5 (rows 2, 3), piece 2 after step 7.
+    p_u32x4 st[4], st20;
+    auto stage_load = [&](auto pc, const unsigned char* g0) {
+        constexpr int P = decltype(pc)::value;
+        const int id = lane < kPPieceQuads ? lane : kPPieceQuads - 1;
+        const int R = 8 * P + id / 5, Q = id - 5 * (id / 5);
 #pragma unroll
-        for (int m = 0; m < kPQuadsPerLane; ++m) {
-            const int id0 = lane + 64 * m;
-            const int id = id0 < kPQuads ? id0 : kPQuads - 1;
-            const int R = id / 5, Q = id - 5 * R;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) st[m][k] = *reinterpret_cast<const p_u32x4*>(g0 + R * kPPitch + (4 * Q + k) * 16);
-        }
-        st20 = *reinterpret_cast<const p_u32x4*>(g0 + (lane < kPSlabRows ? lane : kPSlabRows - 1) * kPPitch + 20 * 16);
+        for (int k = 0; k < 4; ++k) st[k] = *reinterpret_cast<const p_u32x4*>(g0 + R * kPPitch + (4 * Q + k) * 16);
+        st20 = *reinterpret_cast<const p_u32x4*>(g0 + (8 * P + (lane < 8 ? lane : 7)) * kPPitch + 20 * 16);
     };
-    auto stage_store = [&]() {
+    auto stage_store = [&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        if (lane < kPPieceQuads) {
+            const int R = 8 * P + lane / 5, Q = lane - 5 * (lane / 5);
+            unsigned char* const base = tt + R * kPRowLds + 4 * Q;
 #pragma unroll
-        for (int m = 0; m < kPQuadsPerLane; ++m) {
-            const int id = lane + 64 * m;
-            if (id < kPQuads) {
-                const int R = id / 5, Q = id - 5 * R;
-                unsigned char* const base = tt + R * kPRowLds + 4 * Q;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {                              // pixel 4q + t of chunks q = 4Q .. 4Q+3
-                    const unsigned d0 = st[m][0][t], d1 = st[m][1][t], d2 = st[m][2][t], d3 = st[m][3][t];
-                    const unsigned lo01 = p_perm(d1, d0, 0x05010400u), hi01 = p_perm(d1, d0, 0x07030602u);
-                    const unsigned lo23 = p_perm(d3, d2, 0x05010400u), hi23 = p_perm(d3, d2, 0x07030602u);
-                    *reinterpret_cast<unsigned*>(base + (t * 4 + 0) * kPLine) = p_perm(lo23, lo01, 0x05040100u);
-                    *reinterpret_cast<unsigned*>(base + (t * 4 + 1) * kPLine) = p_perm(lo23, lo01, 0x07060302u);
-                    *reinterpret_cast<unsigned*>(base + (t * 4 + 2) * kPLine) = p_perm(hi23, hi01, 0x05040100u);
-                    *reinterpret_cast<unsigned*>(base + (t * 4 + 3) * kPLine) = p_perm(hi23, hi01, 0x07060302u);
-                }
+            for (int t = 0; t < 4; ++t) {                                  // pixel 4q + t of chunks q = 4Q .. 4Q+3
+                const unsigned d0 = st[0][t], d1 = st[1][t], d2 = st[2][t], d3 = st[3][t];
+                const unsigned lo01 = p_perm(d1, d0, 0x05010400u), hi01 = p_perm(d1, d0, 0x07030602u);
+                const unsigned lo23 = p_perm(d3, d2, 0x05010400u), hi23 = p_perm(d3, d2, 0x07030602u);
+                *reinterpret_cast<unsigned*>(base + (t * 4 + 0) * kPLine) = p_perm(lo23, lo01, 0x05040100u);
+                *reinterpret_cast<unsigned*>(base + (t * 4 + 1) * kPLine) = p_perm(lo23, lo01, 0x07060302u);
+                *reinterpret_cast<unsigned*>(base + (t * 4 + 2) * kPLine) = p_perm(hi23, hi01, 0x05040100u);
+                *reinterpret_cast<unsigned*>(base + (t * 4 + 3) * kPLine) = p_perm(hi23, hi01, 0x07060302u);
             }
         }
-        if (lane < kPSlabRows) {                                           // q = 20 (x = 80..83): bytes 21..23 of the dword are padding
-            unsigned char* const base = tt + lane * kPRowLds + 20;
+        if (lane < 8) {                                                    // q = 20 (x = 80..83): bytes 21..23 of the dword are padding
+            unsigned char* const base = tt + (8 * P + lane) * kPRowLds + 20;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -152,8 +152,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int img = blockIdx.x;
     if (img >= images) return;                                           // (grid <= images: never taken)
-    stage_load(slab(row_of(img)));
-    stage_store();
+    {
+        const unsigned char* const g0 = slab(row_of(img));
+        stage_load(std::integral_constant<int, 0>{}, g0); stage_store(std::integral_constant<int, 0>{});
+        stage_load(std::integral_constant<int, 1>{}, g0); stage_store(std::integral_constant<int, 1>{});
+        stage_load(std::integral_constant<int, 2>{}, g0); stage_store(std::integral_constant<int, 2>{});
+    }
     dz_fetch(dz + (long long)img * (400 * 32) + dz_lane, std::integral_constant<int, 0>{});
     int nimg = img + step_img < images ? img + step_img : img;           // clamped: past the end the prefetches are never consumed
     long long snext = row_of(nimg);
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float* const gd = dz + (long long)img * (400 * 32) + dz_lane;
         const float* const gdn = dz + (long long)nimg * (400 * 32) + dz_lane;
         asm volatile("" : "+v"(lhx));
-        stage_load(slab(snext));                                         // the next image's slab: in flight during the 8 steps
+        const unsigned char* const gnext = slab(snext);                  // the next image's slab, staged piece by piece during the 8 steps
+        stage_load(std::integral_constant<int, 0>{}, gnext);
         nimg = nimg + step_img < images ? nimg + step_img : nimg;
         snext = row_of(nimg);
 
@@ -229,8 +234,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);                        // one pair's conversions at a time (register pressure)
             }
         };
-        [&]<int... S>(std::integer_sequence<int, S...>) { (step(std::integral_constant<int, S>{}), ...); }(std::make_integer_sequence<int, kPSteps>{});
-        stage_store();                                                   // after the last step's reads (in-order LDS): next slab in place
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        stage_store(std::integral_constant<int, 0>{});                   // rows 0-7: output rows 0, 1 have issued their reads
+        stage_load(std::integral_constant<int, 1>{}, gnext);
+        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+        stage_store(std::integral_constant<int, 1>{});                   // rows 8-15: output rows 2, 3 done
+        stage_load(std::integral_constant<int, 2>{}, gnext);
+        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+        stage_store(std::integral_constant<int, 2>{});                   // rows 16-23: after the last step's reads
     }
 
     float* pw = part_w + (size_t)(blockIdx.x * 4 + wave) * 32 * 256;
@@ -244,7 +255,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
                   hipStream_t s) {
-    auto k = conv1p_wgrad_kernel;
+    static const int occ = [] { const char* e = getenv("MI355PPO_P_OCC"); return e ? atoi(e) : 2; }();      // (A/B runs)
+    auto k = occ == 1 ? conv1p_wgrad_kernel<1> : conv1p_wgrad_kernel<2>;
     const size_t sm = 4 * (size_t)kPSlabLds;
     static bool attr_done = false;           // 48 KiB: within the default dynamic-LDS limit, but set it explicitly once
     if (!attr_done) {

@@ -105,22 +105,29 @@ def _emulate_kernel_p(frames, dz):
     LINE, ROWLDS = 32, 512
     for wave in range(4):
         acc = np.zeros((8, 32, 32))                               # [tap row r][channel n][column li = kw*4 + c]
-        for img in range(images):
-            slab = frames[img].reshape(84, 336)[20 * wave:20 * wave + 24]          # 24 source rows of 336 bytes
-            tt = np.full(24 * ROWLDS, 0xEE, np.uint8)                                # never-written bytes must not matter
-            for ident in range(120):                                                 # quads: q = 4Q .. 4Q+3 of source row R
-                R, Q = divmod(ident, 5)
+        tt = np.full(24 * ROWLDS, 0xEE, np.uint8)                                    # never-written bytes must not matter
+
+        def stage_piece(img, P):
+            """Piece P of image `img`'s slab = source rows 8P .. 8P+7 -> the wave's LDS lines (40 quads + the 8 chunks q = 20)."""
+            slab = frames[img].reshape(84, 336)[20 * wave:20 * wave + 24]            # 24 source rows of 336 bytes
+            for ident in range(40):                                                  # quads: q = 4Q .. 4Q+3 of source row R
+                R, Q = 8 * P + ident // 5, ident % 5
                 st = [slab[R, (4 * Q + k) * 16:(4 * Q + k) * 16 + 16].reshape(4, 4) for k in range(4)]   # [chunk k][pixel t][channel]
                 for t in range(4):
                     for ch in range(4):
                         base = R * ROWLDS + (t * 4 + ch) * LINE + 4 * Q
                         tt[base:base + 4] = [st[k][t, ch] for k in range(4)]
-            for R in range(24):                                                      # the q = 20 chunk: byte 0 of a dword store
+            for R in range(8 * P, 8 * P + 8):                                        # the q = 20 chunk: byte 0 of a dword store
                 st20 = slab[R, 320:336].reshape(4, 4)
                 for t in range(4):
                     for ch in range(4):
                         base = R * ROWLDS + (t * 4 + ch) * LINE + 20
                         tt[base:base + 4] = [st20[t, ch], 0, 0, 0]
+
+        for P in range(3):
+            stage_piece(0, P)
+        for img in range(images):
+            nxt = min(img + 1, images - 1)
             for s in range(8):
                 a_terms = np.zeros((3, 32, 16))                   # [term][channel n][slot]
                 b_vals = np.zeros((8, 32, 16))                    # [tap row][column li][slot]
@@ -150,6 +157,10 @@ def _emulate_kernel_p(frames, dz):
                 for r in range(8):
                     for term in range(3):
                         acc[r] += a_terms[term] @ b_vals[r].T
+                # the NEXT image's slab replaces the LDS rows piece by piece, as soon as their last reader of this image has issued
+                # (conv1p.hip: after steps 2, 5 and 7; LDS instructions of one wave execute in order)
+                if s in (2, 5, 7):
+                    stage_piece(nxt, (2, 5, 7).index(s))
         for r in range(8):
             part[:, r * 32:(r + 1) * 32] += acc[r]
     return part
@@ -157,7 +168,7 @@ def _emulate_kernel_p(frames, dz):
 
 def test_kernel_p_index_maps_give_the_layer1_weight_gradient():
     rs = np.random.RandomState(5)
-    images = 2
+    images = 3                                                    # first image, a middle one, the last (whose prefetch re-reads itself)
     frames = rs.randint(0, 256, size=(images, 84, 84, 4)).astype(np.uint8)
     dz = (rs.standard_normal((images, 20, 20, 32)) * np.exp(rs.uniform(-8, 2, size=(images, 20, 20, 32)))).astype(np.float32)
     part = _emulate_kernel_p(frames, dz)
