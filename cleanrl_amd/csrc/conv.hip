@@ -1173,8 +1173,6 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     int grid = wgrad_grid(images);      // workgroups launched
     int wparts = grid;                  // partials they write (weights and bias alike)
     if (layer == 1) {                   // kernel P: one partial per wave
-        static const int pgrid = [] { const char* e = getenv("MI355PPO_P_GRID"); return e ? atoi(e) : 512; }();      // (A/B runs)
-        if (grid > pgrid) grid = pgrid;
         wparts = grid * 4;
         const int rc = conv1p_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images, grid, s);
         if (rc) return rc;

@@ -58,8 +58,7 @@ __device__ __forceinline__ unsigned p_perm(unsigned hi, unsigned lo, unsigned se
 // two f32 whose low 16 bits are irrelevant/zero -> packed bf16 pair (element 0 in the low half)
 __device__ __forceinline__ unsigned p_pack_hi16(float e1, float e0) { return p_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u); }
 
-template <int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv1p_wgrad_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1p_wgrad_kernel(
     const unsigned char* __restrict__ src, const int64_t* __restrict__ inds, const float* __restrict__ dz,
     float* __restrict__ part_w,      // [grid * 4][32][256]
     float* __restrict__ part_b,      // [grid * 4][32]
@@ -255,8 +254,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
                   hipStream_t s) {
-    static const int occ = [] { const char* e = getenv("MI355PPO_P_OCC"); return e ? atoi(e) : 2; }();      // (A/B runs)
-    auto k = occ == 1 ? conv1p_wgrad_kernel<1> : conv1p_wgrad_kernel<2>;
+    // (one wave per SIMD -- 372 registers, no spill at all -- measured 1,135 us against 868 at 32,768 images: profiles/r03_kernel_p_pieces_ab.jsonl)
+    auto k = conv1p_wgrad_kernel;
     const size_t sm = 4 * (size_t)kPSlabLds;
     static bool attr_done = false;           // 48 KiB: within the default dynamic-LDS limit, but set it explicitly once
     if (!attr_done) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of kernel P (conv1 weight gradient): the previous commit's library (tools/oldlib/base: whole-slab staging, 32 spilled
 # VGPRs) against the in-tree one (slab staged in three pieces: 2 spilled), at two waves per SIMD and -- MI355PPO_P_OCC=1 -- at one
-# wave per SIMD with 372 registers (no spill), grid 512 / 256.  Bit-identity of the dumped results first, then timings, then traffic.
+# wave per SIMD with 372 registers (no spill), grid 512 / 256 (the two switches exist only in the commit that introduced the pieces).  Bit-identity of the dumped results first, then timings, then traffic.
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pab; mkdir -p $O; L=$R/cleanrl_amd/csrc/libmi355ppo.so
