@@ -135,6 +135,13 @@ def parse():
     p.add_argument("--no-rollout-graphs", action="store_true", help="issue the rollout kernel by kernel instead of one hipGraph per step")
     p.add_argument("--no-pcie-inclusive", action="store_true", help="skip the host-env (PCIe-inclusive) leg after the timed region")
     p.add_argument("--pcie-env-groups", type=int, default=4)
+    p.add_argument("--sync-metrics", action="store_true",
+                   help="read every iteration's diagnostics before the next one starts (the reference's arrangement: one device "
+                        "synchronisation per iteration); default: resolve them one iteration late, so that the host runs ahead "
+                        "of the GPU and a host stall does not drain the GPU's queue")
+    p.add_argument("--inject-host-stall-ms", type=float, default=0.0,
+                   help="DIAGNOSTIC: sleep this long on the host before the 6th minibatch of every update (what a descheduled "
+                        "thread / page-in / garbage collection does on a busy box); compare with and without --sync-metrics")
     cli = p.parse_args()
     cfg = CONFIGS[cli.config]
     if cli.local_num_envs is None:
@@ -331,11 +338,29 @@ def main():
         ev[0].record()
         learner_smoke.rollout(learner, env)
         ev[1].record()
-        m = learner.update(lr)
+        if cli.sync_metrics:
+            m = learner.update(lr)
+        else:
+            # diagnostics resolved one iteration late (PPOLearner.update_async): the host enqueues iteration i + 1 while the GPU
+            # still runs iteration i; everything enqueued is still executed inside the timed region (synchronize at its end)
+            pending.append(learner.update_async(lr))
+            m = pending.pop(0).result() if len(pending) > 1 else None
         learner.start_iteration()
         ev[2].record()
         phase_events.append(ev)
         return m
+
+    pending = []
+    if cli.inject_host_stall_ms > 0:
+        real_mb, count = learner._minibatch_hip, [0]
+
+        def stalled_minibatch(*a, **kw):
+            count[0] += 1
+            if count[0] % 16 == 6:
+                time.sleep(cli.inject_host_stall_ms / 1e3)
+            return real_mb(*a, **kw)
+
+        learner._minibatch_hip = stalled_minibatch
 
     for i in range(cli.warmup):
         one_step(i)
@@ -351,6 +376,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    while pending:
+        metrics = pending.pop(0).result()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -570,7 +597,7 @@ def main_continuous(cli, rank, world, device):
             learner.observe(step + 1, next_obs, done)
         learner.finish_rollout()
         ev[1].record()
-        m = learner.update(lr)
+        m = learner.update(lr)       # (host-bound configuration: the GPU waits for the host, there is nothing to run ahead of)
         learner.start_iteration()
         ev[2].record()
         phase_events.append(ev)

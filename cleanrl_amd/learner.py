@@ -36,6 +36,34 @@ import torch.optim as optim
 from . import host_ops
 
 
+class PendingMetrics:
+    """Diagnostics of one ``PPOLearner.update_async`` call: ``result()`` waits for the copies (HIP path) and computes what the
+    reference logs per iteration (ppo_atari_multigpu.py:382-397)."""
+
+    def __init__(self, event, values, returns, scalars, host_last, num_updates):
+        self._event, self._values, self._returns, self._scalars = event, values, returns, scalars
+        self._host_last, self._k, self._out = host_last, num_updates, None
+
+    def result(self) -> dict:
+        if self._out is None:
+            if self._event is not None:
+                self._event.synchronize()
+            y_pred, y_true = self._values.numpy(), self._returns.numpy()      # :382-384
+            var_y = np.var(y_true)
+            explained_var = np.nan if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y
+            if self._scalars is not None:
+                sc = self._scalars.numpy()
+                last_np, clipfrac = sc[-1], float(np.mean(sc[:, 6]))
+            else:
+                last, clipfracs = self._host_last
+                last_np, clipfrac = last.numpy(), float(np.mean(clipfracs))
+            self._out = dict(loss=float(last_np[0]), policy_loss=float(last_np[1]), value_loss=float(last_np[2]),
+                             entropy=float(last_np[3]), old_approx_kl=float(last_np[4]), approx_kl=float(last_np[5]),
+                             clipfrac=clipfrac, explained_variance=float(explained_var), num_updates=self._k)
+            self._values = self._returns = self._scalars = self._host_last = None
+        return self._out
+
+
 class PPOLearner:
     def __init__(self, agent: nn.Module, args, obs_space, act_space, num_envs: int, device: torch.device,
                  world_size: int = 1, sample_seed: int = 0):
@@ -114,6 +142,7 @@ class PPOLearner:
             # update() call, which starts after this call's closing D2H of the scalars (a stream sync).
             self._inds_dev = torch.empty((int(args.update_epochs), self.batch_size), dtype=torch.int64, device=device)
             self._inds_pin = torch.empty((int(args.update_epochs), self.batch_size), dtype=torch.int64).pin_memory()
+            self._inds_ev = {}          # epoch -> event behind the last H2D copy out of that pinned row
             self._total_norm = torch.zeros(1, device=device)
             self._stage_free.record(torch.cuda.current_stream(device))       # after every buffer's zero fill
         self._pack = None           # (B, 8) packed behaviour rows (ops.batch_pack) of the current update, or None
@@ -330,6 +359,17 @@ class PPOLearner:
     def update(self, lr: float) -> dict:
         """Epochs x minibatches of the clipped-surrogate update (:311-380) + explained variance (:382-384).
         Returns the scalars the reference logs (values of the LAST minibatch, clipfrac averaged)."""
+        return self.update_async(lr).result()
+
+    def update_async(self, lr: float) -> "PendingMetrics":
+        """``update`` without its device synchronisation: everything is enqueued, the diagnostics (:382-397 -- two (T, N) arrays
+        for the explained variance and the (updates, 7) loss scalars) are copied to pinned host memory behind an event, and
+        ``.result()`` of the returned handle waits for that event only.  A caller that resolves the handle one iteration late
+        lets the host run a whole iteration ahead of the GPU: a host stall of tens of milliseconds (a descheduled thread, a
+        page-in, a garbage collection) then no longer drains the GPU's queue -- measured on a fresh box, where the first
+        process loses 18-32 ms of GPU time per iteration to such stalls (profiles/r03_cold_first_process_gaps.txt).  The
+        training arithmetic and its order are the same; only the moment the host READS the diagnostics moves.  (CPU path and
+        ``--target-kl``: resolved at once -- the early stop needs the value.)"""
         a = self.args
         B, M = self.batch_size, self.minibatch_size
         b_inds = np.arange(B)                                             # :312
@@ -383,25 +423,37 @@ class PPOLearner:
             if stop:
                 break
         self._mb_adv_md = self._mb_slot = self._pack = None               # direct forward_backward_hip calls: arrays, fold at once
-        y_pred, y_true = b_values.cpu().numpy(), b_returns.cpu().numpy()  # :382-384
-        var_y = np.var(y_true)
-        explained_var = np.nan if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y
         if self.hip:
             if self._loss_slots is not None and k > folded:
                 self._loss_slots.fold(k - folded, self._scalars, first=folded)   # one launch for every minibatch of the update
-            sc = self._scalars[:k].cpu().numpy()
-            last_np, clipfrac = sc[-1], float(np.mean(sc[:, 6]))
-        else:
-            last_np, clipfrac = last.numpy(), float(np.mean(clipfracs))
-        return dict(loss=float(last_np[0]), policy_loss=float(last_np[1]), value_loss=float(last_np[2]),
-                    entropy=float(last_np[3]), old_approx_kl=float(last_np[4]), approx_kl=float(last_np[5]),
-                    clipfrac=clipfrac, explained_variance=float(explained_var), num_updates=k)
+            # :382-384 and the logged scalars: async D2H into pinned memory (the caching host allocator keeps a block out of
+            # reuse until the copy that used it has executed), one event behind them
+            on_gpu = b_values.is_cuda              # (the HIP branches also run on CPU tensors under the tests' stand-in ops)
+            host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=on_gpu) for t in (b_values, b_returns, self._scalars[:k])]
+            for h, t in zip(host, (b_values, b_returns, self._scalars[:k])):
+                h.copy_(t, non_blocking=True)
+            ev = None
+            if on_gpu:
+                ev = torch.cuda.Event()
+                ev.record()
+            return PendingMetrics(ev, host[0], host[1], host[2], None, k)
+        return PendingMetrics(None, b_values, b_returns, None, (last, clipfracs), k)
 
     def upload_permutation(self, epoch: int, b_inds: np.ndarray) -> torch.Tensor:
-        """Host permutation of this epoch (:315) -> its own pinned row -> its own device row (async H2D)."""
+        """Host permutation of this epoch (:315) -> its own pinned row -> its own device row (async H2D).  The pinned row is
+        rewritten only after the copy that last read it has executed (an event per row: the host may be an iteration ahead)."""
         pin, dev = self._inds_pin[epoch], self._inds_dev[epoch]
+        on_gpu = dev.is_cuda                       # (the HIP branches also run on CPU tensors under the tests' stand-in ops)
+        evs = self.__dict__.setdefault("_inds_ev", {})
+        ev = evs.get(epoch)
+        if ev is not None:
+            ev.synchronize()
         pin.copy_(torch.from_numpy(b_inds))
         dev.copy_(pin, non_blocking=True)
+        if on_gpu:
+            if ev is None:
+                ev = evs[epoch] = torch.cuda.Event()
+            ev.record()
         return dev
 
     def _early_all_reduce(self, _param) -> None:

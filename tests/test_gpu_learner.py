@@ -654,3 +654,42 @@ def test_captured_rollout_steps_replay_bit_identically_to_the_eager_loop():
         assert me["loss"] == mg["loss"] and torch.equal(Le.flat.params, Lg.flat.params)
     assert Lg.agent.rng.offset == Le.agent.rng.offset and envg._step == enve._step
     assert float(Le.dones.sum()) > 0
+
+
+def test_update_async_with_the_host_an_iteration_ahead_is_bit_identical_to_the_synchronous_loop():
+    """PPOLearner.update_async: diagnostics resolved one iteration late (bench.py's default), the host enqueuing iteration
+    i + 1 -- captured rollout steps, the next permutations through the event-guarded pinned rows, the next update -- while the
+    GPU still runs iteration i.  Four iterations against the synchronous loop from the same seeds: parameters, Adam state
+    and every iteration's logged scalars bit-equal; the metrics handles resolve in any order, late."""
+    N, T = 32, 8
+
+    def make():
+        torch.manual_seed(4)
+        env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=6, done_p=0.1)
+        agent = AtariAgent(env).to(DEV)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=3)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
+        L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
+        L.capture_rollout(env)
+        return L, env
+
+    (Ls, envs_), (La, enva) = make(), make()
+    sync_metrics, handles = [], []
+    np.random.seed(11)
+    for it in range(4):
+        learner_smoke.rollout(Ls, envs_)
+        sync_metrics.append(Ls.update(2.5e-4 * (1 - it / 4)))
+        Ls.start_iteration()
+    np.random.seed(11)
+    for it in range(4):                              # nothing here waits for the GPU
+        learner_smoke.rollout(La, enva)
+        handles.append(La.update_async(2.5e-4 * (1 - it / 4)))
+        La.start_iteration()
+    late = [h.result() for h in reversed(handles)][::-1]
+    torch.cuda.synchronize()
+    assert torch.equal(La.flat.params, Ls.flat.params)
+    assert torch.equal(La.flat.exp_avg, Ls.flat.exp_avg) and torch.equal(La.flat.exp_avg_sq, Ls.flat.exp_avg_sq)
+    for it in range(4):
+        assert late[it] == sync_metrics[it] or all(
+            (late[it][k] == sync_metrics[it][k]) or (np.isnan(late[it][k]) and np.isnan(sync_metrics[it][k])) for k in late[it]), it
+    assert handles[0].result() is late[0]            # resolved once, cached
