@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void zsplit_reduce_kernel(const float4* __rest
 
 // K splits of the small-batch forward: (row tile, column tile, split) wave tiles for ONE wave per SIMD (1,024: measured 30.8 us at
 // 1,024 rows, 22.6 at 512 -- the library GEMM's 31.3 / 22.6; two waves per SIMD = twice the partials: 38.7 / 29.3 us,
-// tools/gpu_fcsplit2.sh), at least 4 k-steps per split.
+// tools/gpu/fcsplit2.sh), at least 4 k-steps per split.
 static int zsplit_steps_per(int M, int N, int K) {
     const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
     const int total = K / 16;

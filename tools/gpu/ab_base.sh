@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of two builds of the library on the torch-free driver: tools/oldlib/base/libmi355ppo.so (the previous commit's) against the
-# in-tree one; bit-identity of the dumped results, then timings.   usage: gpu_ab_base.sh [keys...]
+# in-tree one; bit-identity of the dumped results, then timings.   usage: tools/gpu/ab_base.sh [keys...]
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; L=$R/cleanrl_amd/csrc/libmi355ppo.so

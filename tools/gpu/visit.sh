@@ -1,5 +1,5 @@
 #!/bin/bash
-# Generic GPU-box visit: full GPU test suite, bench.py, rocprofv3 kernel stats of bench.py.  usage: gpu_visit.sh <tag> [pytest-args...]
+# Generic GPU-box visit: full GPU test suite, bench.py, rocprofv3 kernel stats of bench.py.  usage: tools/gpu/visit.sh <tag> [pytest-args...]
 set -u
 tag=${1:-visit}; shift || true
 mkdir -p gpurun_out

@@ -1,4 +1,4 @@
-"""Markdown rows from the PMC passes of tools/gpu_r3_final2.sh (profiles/r03_pmc_{busy,mem,lds,fetch,write}.csv): per kernel of one
+"""Markdown rows from the PMC passes of tools/gpu/r3_final2.sh (profiles/r03_pmc_{busy,mem,lds,fetch,write}.csv): per kernel of one
 minibatch update at 32,768 images -- matrix-pipe busy, effective clock, wave cycles waiting, VALU / LDS / TA busy, L2-miss traffic.
 
     matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
