@@ -18,6 +18,7 @@ _P = c_void_p  # every tensor argument is a raw device pointer
 SIGNATURES = {
     "mi355ppo_version": (c_int, []),
     "mi355ppo_last_error": (c_char_p, []),
+    "mi355ppo_init": (c_int, [c_int]),
     "mi355ppo_gae_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, _P]),
     "mi355ppo_gae_f32_variant": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double, c_int, _P]),
     "mi355ppo_categorical_sample_f32": (c_int, [_P, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_int, _P]),
@@ -138,6 +139,20 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
                            "(`python -m cleanrl_amd.build`)")
     _lib = lib
     return lib
+
+
+_inited: set = set()
+
+
+def require_device(index: int) -> None:
+    """Raise unless HIP device ``index`` can run the library's kernels (``mi355ppo_init``: gfx950 only).  Once per device."""
+    if index in _inited:
+        return
+    lib = load()
+    if lib.mi355ppo_init(int(index)) != 0:
+        msg = lib.mi355ppo_last_error()
+        raise RuntimeError(f"libmi355ppo cannot run on cuda:{index}: {msg.decode() if msg else 'mi355ppo_init failed'}")
+    _inited.add(index)
 
 
 def check(status: int, fn: str) -> None:

@@ -82,6 +82,7 @@ class PPOLearner:
             from .flat import FlatParams
 
             _lib.load()
+            _lib.require_device(device.index if device.index is not None else torch.cuda.current_device())   # gfx950 or a sentence why not
             self.ops = ops
             self.flat = FlatParams(agent)
             self.optimizer = None

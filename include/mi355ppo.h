@@ -50,6 +50,11 @@ extern "C" {
 
 MI355PPO_API int mi355ppo_version(void);
 MI355PPO_API const char* mi355ppo_last_error(void);
+/* Capability check: 0 if `device` (a HIP device ordinal) can run this library's kernels (gfx950), MI355PPO_EHIP / EINVAL with a
+ * message otherwise (no device, ordinal out of range, another architecture).  Optional -- the library keeps no per-device state
+ * and every entry point works without it --; cleanrl_amd/_lib.py calls it once per device, so that a wrong GPU fails at load
+ * time with a sentence instead of at the first launch with "invalid device function". */
+MI355PPO_API int mi355ppo_init(int device);
 
 /* ---------------------------------------------------------------------------------------------
  * K1  Generalised Advantage Estimation, fused reverse scan.

@@ -59,6 +59,18 @@ def test_validation_errors_are_loud_and_precede_any_launch():
     assert lib.mi355ppo_obs_u8_to_f32(p, None, p, 4, 6, 1, None) == -1   # row_bytes % 4 != 0
 
 
+def test_init_reports_a_box_without_a_device_loudly():
+    """mi355ppo_init on this CPU-only box: no HIP device -> EHIP and a message; on the GPU box the same call is part of
+    tests/test_gpu_kernels.py (0 for the MI355X, EINVAL for an ordinal out of range)."""
+    lib = _lib.load()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the gpu-marked test")
+    assert lib.mi355ppo_init(0) == -3
+    assert b"no HIP device" in lib.mi355ppo_last_error()
+    with pytest.raises(RuntimeError, match="cannot run on cuda:0"):
+        _lib.require_device(0)
+
+
 def test_ops_refuse_cpu_tensors_there_is_no_fallback():
     x = torch.zeros(4, 4)
     with pytest.raises(TypeError, match="CUDA/HIP"):

@@ -416,3 +416,12 @@ def test_obs_relayout_nchw_to_nhwc_u8():
     # (CPU torch divides; torch's GPU kernel multiplies by 1/255 and is 1 ulp off for 126 byte values -- the CPU
     # quotient is the oracle's and the kernel's definition, see obs.hip)
     assert x.is_contiguous(memory_format=torch.channels_last) and torch.equal(x.cpu(), frames.cpu().float() / 255.0)
+
+
+def test_init_accepts_the_mi355x_and_rejects_a_missing_ordinal():
+    from cleanrl_amd import _lib
+
+    lib = _lib.load()
+    assert lib.mi355ppo_init(0) == 0, lib.mi355ppo_last_error()
+    assert lib.mi355ppo_init(torch.cuda.device_count()) == -1 and b"out of range" in lib.mi355ppo_last_error()
+    _lib.require_device(0)
