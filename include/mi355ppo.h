@@ -32,9 +32,9 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 140 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 150 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2, 1.3: round 3;
-                                  1.4: the *_cpu host-pointer twins); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
+                                  1.4: the *_cpu host-pointer twins; 1.5: mi355ppo_init); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
 
 #if defined(__GNUC__)
 #define MI355PPO_API __attribute__((visibility("default")))
