@@ -17,6 +17,7 @@
 #include "ppo_rows.h"
 
 #include <math.h>
+#include <stddef.h>
 #include <string.h>
 
 #pragma clang fp contract(off)
@@ -356,7 +357,7 @@ extern "C" MI355PPO_API int mi355ppo_loss_normal_fwd_bwd_f32_cpu(
     for (int m = 0; m < M; ++m) {
         const int64_t i = mb_inds ? mb_inds[m] : m;
         float lp, ent;
-        normal_row<false>(new_mean, logstd, nullptr, unused, 0, m, nullptr, b_actions + ((size_t)i - (size_t)m) * D, &lp, &ent, D);
+        normal_row<false>(new_mean, logstd, nullptr, unused, 0, m, nullptr, b_actions + ((ptrdiff_t)i - (ptrdiff_t)m) * D, &lp, &ent, D);   // (row m of new_mean, row i of b_actions)
         const RowTerms t = ppo_row_terms(lp, ent, new_value[m], b_logprobs[i], b_advantages[i], b_returns[i], b_values[i], amean,
                                          den, P);
         for (int k = 0; k < kNumSums; ++k) tot[k] += (double)t.sums[k];
