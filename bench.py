@@ -133,6 +133,9 @@ def parse():
     p.add_argument("--cpu-baseline-envs", type=int, default=64)
     p.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets (pure SPS run)")
     p.add_argument("--no-rollout-graphs", action="store_true", help="issue the rollout kernel by kernel instead of one hipGraph per step")
+    p.add_argument("--rollout-steps-per-graph", type=int, default=0,
+                   help="consecutive env steps captured into one hipGraph (0 = the whole rollout in one graph, the default: a replay "
+                        "boundary costs ~8 us of GPU idle; 1 = a graph per step)")
     p.add_argument("--no-pcie-inclusive", action="store_true", help="skip the host-env (PCIe-inclusive) leg after the timed region")
     p.add_argument("--pcie-env-groups", type=int, default=4)
     p.add_argument("--sync-metrics", action="store_true",
@@ -261,7 +264,7 @@ def main():
                          sample_seed=seed)
     learner.observe(0, env.obs_into(learner.stage_obs), learner.dones[0])
     if learner.fused_cnn and not cli.no_rollout_graphs:
-        learner.capture_rollout(env)        # one hipGraph per rollout step (before the timing hooks: no event records in a capture)
+        learner.capture_rollout(env, steps_per_graph=cli.rollout_steps_per_graph or T)      # (before the timing hooks: no event records in a capture)
     timer = KernelTimer()
     conv_flops = {}      # key "<op>@<rows>" -> algorithmic flops of one launch (the f32 convolution / GEMM: 2 x M x N x K)
     kernel_of = {}       # key -> letter in KERNEL_INFO
@@ -409,8 +412,11 @@ def main():
                 "parallelism": f"dp{world} (one learner per GPU, RCCL all-reduce of the flat f32 gradient)" if not cli.same_device
                                else f"dp{world} SAME-DEVICE PLUMBING SMOKE (all ranks on cuda:0, gloo): not a measurement",
                 "env": "device-resident synthetic generator (no PCIe in the timed region)",
-                "rollout": "one hipGraph per env step (policy forward, sampling, env step, observation store)"
+                "rollout": (f"{len(learner._rollout_graphs)} hipGraph(s) of {-(-T // len(learner._rollout_graphs))} env step(s) each (policy "
+                            "forward, sampling, env step, observation store)")
                            if getattr(learner, "_rollout_graphs", None) else "kernel-by-kernel launches",
+                "diagnostics": "synchronous (one device synchronisation per iteration)" if cli.sync_metrics
+                               else "read one iteration late (PPOLearner.update_async): the host runs an iteration ahead of the GPU",
                 "cnn": "layer-1 forward on the int8 MFMA with exact int32 accumulation over 31-bit fixed-point weights (kernel Q); every "
                        f"other convolution / FC GEMM on the bf16 MFMA over exact three-term splits of the f32 operands, {BF16_PAIRS} of 9 term "
                        "pairs (kernels Z, V, W, P): f32 in, f32 accumulate, error vs float64 <= the f32-MFMA kernels' (tests/test_gpu_cnn.py)"

@@ -278,7 +278,7 @@ class PPOLearner:
         return action
 
     # ------------------------------------------------------------------ hipGraph of the rollout steps (device-resident envs)
-    def capture_rollout(self, env) -> None:
+    def capture_rollout(self, env, steps_per_graph: int = 1) -> None:
         """Capture every rollout step -- policy forward, sampling, the device env's step, the store of the next observation --
         into one hipGraph per step (the step's rollout-storage rows are baked into its launches; the Philox positions of
         the sampler and of the env live in device memory and advance by T per rollout).  ``replay_rollout()`` then issues a
@@ -307,10 +307,14 @@ class PPOLearner:
         with torch.cuda.stream(side):
             body(0)                                   # warm-up on the capture stream: per-stream workspaces and trunk buffers exist
         side.synchronize()
-        for step in range(T):
+        # `steps_per_graph` consecutive steps per graph (1: T graphs; T: the whole rollout is one graph -- a replay boundary costs
+        # ~8 us of GPU idle against 1-2 us between the kernels inside a graph, profiles/r03_cold_second_process_gaps.txt)
+        per = max(1, min(int(steps_per_graph), T))
+        for first in range(0, T, per):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, stream=side):
-                body(step)
+                for step in range(first, min(first + per, T)):
+                    body(step)
             pool = pool or g.pool()
             graphs.append(g)
         torch.cuda.current_stream(dev).wait_stream(side)

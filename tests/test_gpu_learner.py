@@ -621,7 +621,8 @@ def test_one_thread_driver_over_worker_process_envs_matches_the_threaded_lanes(K
     assert float(out[0][0]["dones"].sum()) > 0
 
 
-def test_captured_rollout_steps_replay_bit_identically_to_the_eager_loop():
+@pytest.mark.parametrize("per", [1, 3, 8])
+def test_captured_rollout_steps_replay_bit_identically_to_the_eager_loop(per):
     """PPOLearner.capture_rollout: every rollout step as one hipGraph (Philox positions of the sampler and of the device env in
     device memory).  Two iterations -- rollout, update, rollout -- replayed against the eager loop from the same seeds: all
     rollout buffers bit-equal, so the captured launches see the updated (re-packed in place) weights and fresh stream positions."""
@@ -638,8 +639,8 @@ def test_captured_rollout_steps_replay_bit_identically_to_the_eager_loop():
         return L, env
 
     (Le, enve), (Lg, envg) = make(), make()
-    Lg.capture_rollout(envg)
-    assert len(Lg._rollout_graphs) == T
+    Lg.capture_rollout(envg, steps_per_graph=per)            # 1: a graph per step; 3: ragged groups; 8: the whole rollout in one
+    assert len(Lg._rollout_graphs) == -(-T // per)
     for it in range(2):
         learner_smoke.rollout(Le, enve)
         learner_smoke.rollout(Lg, envg)
