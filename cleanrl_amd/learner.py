@@ -310,9 +310,12 @@ class PPOLearner:
         # `steps_per_graph` consecutive steps per graph (1: T graphs; T: the whole rollout is one graph -- a replay boundary costs
         # ~8 us of GPU idle against 1-2 us between the kernels inside a graph, profiles/r03_cold_second_process_gaps.txt)
         per = max(1, min(int(steps_per_graph), T))
+        # world > 1: the process group's watchdog thread may query events while this thread captures; only actions of THIS thread
+        # may invalidate the capture then (torch's default mode is "global")
+        capture_kw = {"capture_error_mode": "thread_local"} if self.world_size > 1 else {}
         for first in range(0, T, per):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=side):
+            with torch.cuda.graph(g, pool=pool, stream=side, **capture_kw):
                 for step in range(first, min(first + per, T)):
                     body(step)
             pool = pool or g.pool()
