@@ -814,6 +814,82 @@ def mint_rnd_iteration():
     _save("rnd_iteration", cases)
 
 
+def mint_continuous_iteration():
+    """BASELINE configs[4]'s script, one whole iteration on synthetic inputs (T = 16, N = 4, obs 17 / act 6 = HalfCheetah's
+    shapes): the reference Agent of ppo_continuous_action.py fills the rollout through its own ``get_action_and_value``
+    (:134-141, torch's Normal sampler seeded), then the script's GAE lines (:232-246) and its flatten + epoch / minibatch
+    update lines (:248-309; 2 minibatches x 3 epochs = six Adam steps; clip 0.2, ent 0.0, the script's defaults) are exec'd
+    verbatim.  Recorded: the rollout, GAE outputs, every minibatch's loss scalars, the clipped gradient of the first step,
+    ``actor_logstd`` after every step (the shared parameter the Normal loss twin / kernel sums its gradient for) and the
+    parameters at the end."""
+    import textwrap
+
+    import torch.nn as nn
+
+    script = "ppo_continuous_action.py"
+    lines = R._read(script)
+    T, N, OBS, ACT = 16, 4, 17, 6
+    torch.manual_seed(31)
+    Agent, _ = R.load_agent_class(script)
+    envs = R.fake_envs((OBS,), action_shape=(ACT,))
+    agent = Agent(envs)
+    args = R.make_args(num_steps=T, num_envs=N, num_minibatches=2, update_epochs=3, batch_size=T * N, minibatch_size=T * N // 2,
+                       clip_coef=0.2, ent_coef=0.0, learning_rate=3e-4)
+    logstd_trace, scalars = [], []
+    keys = ("loss", "pg_loss", "v_loss", "entropy_loss", "old_approx_kl", "approx_kl")
+
+    optimizer = _GradSpy(R.make_optimizer(agent, 3e-4), agent.parameters())
+    init = _flat(agent.parameters()).clone()
+    g = torch.Generator().manual_seed(57)
+    obs_seq = torch.randn(T + 1, N, OBS, generator=g)
+    step_done = (torch.rand(T + 1, N, generator=g) < 0.15).float()
+    step_done[0] = 0.0
+    rewards = torch.randn(T, N, generator=g)
+    obs = torch.zeros((T, N, OBS))
+    actions = torch.zeros((T, N, ACT))
+    logprobs, dones, values = (torch.zeros((T, N)) for _ in range(3))
+    torch.manual_seed(37)                                      # the sampler's stream
+    for step in range(T):
+        obs[step], dones[step] = obs_seq[step], step_done[step]
+        with torch.no_grad():
+            action, logprob, _, value = agent.get_action_and_value(obs[step])
+            values[step] = value.flatten()
+        actions[step], logprobs[step] = action, logprob
+    next_obs, next_done = obs_seq[T], step_done[T]
+    device = torch.device("cpu")
+    ns = dict(args=args, agent=agent, optimizer=optimizer, envs=envs, obs=obs, actions=actions, logprobs=logprobs,
+              rewards=rewards, dones=dones, values=values, next_obs=next_obs, next_done=next_done, device=device, np=np,
+              torch=torch, nn=nn)
+    g0 = R._find(lines, "# bootstrap value if not done") + 1
+    g1 = R._find(lines, "returns = advantages + values", g0)
+    exec(textwrap.dedent("\n".join(lines[g0:g1 + 1])), ns)
+    u0 = R._find(lines, "# flatten the batch", g1) + 1
+    u1 = R._find(lines, "y_pred, y_true = b_values.cpu().numpy()", u0)
+    body = lines[u0:u1]
+    # record every minibatch's scalars: one statement appended after `optimizer.step()` at its own indentation
+    k = max(i for i, ln in enumerate(body) if "optimizer.step()" in ln)
+    indent = body[k][:len(body[k]) - len(body[k].lstrip())]
+    body.insert(k + 1, indent + "_record(loss, pg_loss, v_loss, entropy_loss, old_approx_kl, approx_kl)")
+
+    def _record(*v):                                           # runs right after `optimizer.step()` of every minibatch
+        scalars.append(torch.stack([x.detach().reshape(()) for x in v]))
+        logstd_trace.append(agent.actor_logstd.detach().clone().reshape(-1))
+
+    ns["_record"] = _record
+    np.random.seed(9)
+    exec(textwrap.dedent("\n".join(body)), ns)
+    final = _flat(agent.parameters())
+    assert len(scalars) == 6 and len(logstd_trace) == 6
+    cases = {"mujoco_T16_N4": dict(
+        obs_seq=obs_seq, step_done=step_done, rewards=rewards, actions=actions, logprobs=logprobs, values=values,
+        advantages=ns["advantages"], returns=ns["returns"], init_params=init, final_params=final,
+        scalars=torch.stack(scalars), scalar_names=np.array(keys), logstd_after_step=torch.stack(logstd_trace),
+        clipfracs=np.array(ns["clipfracs"], np.float32), init_seed=np.int64(31), sample_seed=np.int64(37), shuffle_seed=np.int64(9),
+        lr=np.float64(3e-4), lines=np.array([g0 + 1, g1 + 1, u0 + 1, u1], np.int64),
+        **_grad_record("mb1_grad", optimizer.grads[0], agent.parameters(), stride=1))}
+    _save("continuous_iteration", cases)
+
+
 def main():
     assert R.available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -836,6 +912,7 @@ def main():
     mint_rnd_iteration()
     mint_ppg_phase()
     mint_ma_atari_update()
+    mint_continuous_iteration()
 
 
 if __name__ == "__main__":

@@ -213,3 +213,78 @@ def test_whole_atari_iteration_matches_the_reference_lines():
         assert abs(m["value_loss"] - float(g["last_v_loss"])) <= 1e-6 and abs(m["entropy"] - float(g["last_entropy"])) <= 1e-6
     finally:
         torch.set_num_threads(n)
+
+
+def test_whole_continuous_iteration_matches_the_reference_lines():
+    """ppo_continuous_action.py (BASELINE configs[4]'s script), one whole iteration through the learner's API on CPU against
+    tests/golden/continuous_iteration.npz (the script's own lines :134-141, :232-246, :248-309 exec'd on HalfCheetah-shaped
+    synthetic inputs; 2 minibatches x 3 epochs = six Adam steps).  Sampled actions, log-probs and values come out of the same
+    torch ops as the reference's (bit-equal); GAE runs through ``mi355ppo_gae_f32_cpu`` (bit-equal); the update runs through the
+    fused Normal loss twin ``mi355ppo_loss_normal_fwd_bwd_f32_cpu`` -- a few ulp per gradient (libm vs torch's expf / logf, f64
+    row-order sums): parameters after the six steps within 5e-7 (measured 3e-8) where the update moves them by 1e-3 on average,
+    every minibatch's loss scalars, the first step's clipped gradient and the shared ``actor_logstd`` after every step held too."""
+    g = load_golden("continuous_iteration")["mujoco_T16_N4"]
+    T, N = g["rewards"].shape
+    OBS, ACT = g["obs_seq"].shape[-1], g["actions"].shape[-1]
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)                       # as when minted
+    try:
+        env = SimpleNamespace(single_observation_space=E.Box(-np.inf, np.inf, (OBS,)), single_action_space=E.Box(-1.0, 1.0, (ACT,)))
+        torch.manual_seed(int(g["init_seed"]))
+        agent = ContinuousAgent(env)
+        flat = lambda: torch.cat([p.detach().reshape(-1) for p in agent.parameters()])      # noqa: E731
+        np.testing.assert_allclose(flat().numpy(), g["init_params"], rtol=0, atol=3e-7)     # (orthogonal_: LAPACK QR moves by ulps with the host CPU)
+        args = default_args(num_steps=T, num_minibatches=2, update_epochs=3, clip_coef=0.2, ent_coef=0.0, learning_rate=3e-4)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, torch.device("cpu"))
+        obs_seq, step_done = g["obs_seq"], g["step_done"]
+        L.observe(0, obs_seq[0], step_done[0])
+        torch.manual_seed(int(g["sample_seed"]))
+        for step in range(T):
+            L.act(step)
+            L.store_reward(step, g["rewards"][step])
+            L.observe(step + 1, obs_seq[step + 1], step_done[step + 1])
+        for mine, gold in ((L.actions, "actions"), (L.logprobs, "logprobs"), (L.values, "values")):
+            np.testing.assert_allclose(mine.numpy(), g[gold], rtol=0, atol=2e-6, err_msg=gold)
+            getattr(L, gold).copy_(torch.from_numpy(g[gold]))             # teacher-forced from here: the update sees the golden rollout
+        L.finish_rollout()
+        np.testing.assert_allclose(L.advantages.numpy(), g["advantages"], rtol=0, atol=5e-6)   # bootstrap value from the agent
+        np.testing.assert_allclose(L.returns.numpy(), g["returns"], rtol=0, atol=5e-6)
+        L.advantages.copy_(torch.from_numpy(g["advantages"]))
+        L.returns.copy_(torch.from_numpy(g["returns"]))
+        # record what the reference recorded: scalars of every minibatch, actor_logstd after every optimizer step
+        scal, logstd, grads = [], [], []
+        real_mb, real_step = L._minibatch_host, L.optimizer.step
+
+        def mb(*a, **kw):
+            out = real_mb(*a, **kw)
+            scal.append(out.clone())
+            logstd.append(agent.actor_logstd.detach().clone().reshape(-1))
+            return out
+
+        def step(*a, **kw):
+            if not grads:
+                grads.append(torch.cat([p.grad.reshape(-1) for p in agent.parameters()]).clone())      # after clip_grad_norm_
+            return real_step(*a, **kw)
+
+        L._minibatch_host, L.optimizer.step = mb, step
+        np.random.seed(int(g["shuffle_seed"]))
+        m = L.update(float(g["lr"]))
+        assert m["num_updates"] == 6 and len(scal) == 6
+        names = list(g["scalar_names"])
+        mine = torch.stack(scal).numpy()              # loss, pg, v, entropy, old_kl, kl, clipfrac  (ops.LOSS_SCALAR_NAMES order)
+        col = {"loss": 0, "pg_loss": 1, "v_loss": 2, "entropy_loss": 3, "old_approx_kl": 4, "approx_kl": 5}
+        for j, name in enumerate(names):
+            np.testing.assert_allclose(mine[:, col[name]], g["scalars"][:, j], rtol=2e-5, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(mine[:, 6], g["clipfracs"], atol=1e-6)
+        # the clipped gradient of the first optimizer step: direction and scale
+        g1, ref1 = grads[0].double().numpy(), g["mb1_grad_sub"].astype(np.float64)
+        cos = float(g1 @ ref1 / (np.linalg.norm(g1) * np.linalg.norm(ref1)))
+        assert cos > 1 - 1e-9 and abs(np.linalg.norm(g1) - float(g["mb1_grad_norm"])) <= 1e-5 * float(g["mb1_grad_norm"])
+        np.testing.assert_allclose(g1, ref1, rtol=0, atol=5e-6 * float(g["mb1_grad_absmax"]))
+        # six Adam steps of ~lr = 3e-4 each
+        np.testing.assert_allclose(torch.stack(logstd).numpy(), g["logstd_after_step"], rtol=0, atol=2e-8)       # measured 9e-10
+        moved = np.abs(g["final_params"] - g["init_params"])
+        assert moved.mean() > 2e-4
+        np.testing.assert_allclose(flat().numpy(), g["final_params"], rtol=0, atol=5e-7)       # measured 3e-8; the update moves 1e-3
+    finally:
+        torch.set_num_threads(n)
