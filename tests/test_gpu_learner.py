@@ -694,3 +694,65 @@ def test_update_async_with_the_host_an_iteration_ahead_is_bit_identical_to_the_s
         assert late[it] == sync_metrics[it] or all(
             (late[it][k] == sync_metrics[it][k]) or (np.isnan(late[it][k]) and np.isnan(sync_metrics[it][k])) for k in late[it]), it
     assert handles[0].result() is late[0]            # resolved once, cached
+
+
+def test_continuous_hip_path_teacher_forced_against_reference_iteration():
+    """BASELINE configs[4]'s script on the HIP path -- K2' (Normal log-prob), K1, the fused Normal loss K3', K6 -- against a whole
+    iteration of ppo_continuous_action.py's own lines (tests/golden/continuous_iteration.npz: 3 epochs x 2 minibatches), the
+    reference's sampled actions forced.  The MLP itself runs on hipBLASLt (a different f32 summation order than CPU torch), so the
+    bars are relative to what an Adam step moves (lr = 3e-4): every minibatch's loss scalars, ``actor_logstd`` after every step
+    (its gradient is the column sum the K3' kernel forms), the parameters after six steps."""
+    g = load_golden("continuous_iteration")["mujoco_T16_N4"]
+    T, N = g["rewards"].shape
+    OBS, ACT = g["obs_seq"].shape[-1], g["actions"].shape[-1]
+    env = SimpleNamespace(single_observation_space=E.Box(-np.inf, np.inf, (OBS,)), single_action_space=E.Box(-1.0, 1.0, (ACT,)))
+    torch.manual_seed(int(g["init_seed"]))
+    agent = ContinuousAgent(env).to(DEV)
+    args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=3, clip_coef=0.2, ent_coef=0.0, learning_rate=3e-4)
+    L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=1)
+    assert L.hip and not L.discrete
+    np.testing.assert_allclose(L.flat.params.cpu().numpy(), g["init_params"], rtol=0, atol=3e-6)
+    obs_seq, step_done = g["obs_seq"], g["step_done"]
+    L.observe(0, obs_seq[0], step_done[0])
+    for step in range(T):
+        L.act(step)
+        np.testing.assert_allclose(L.values[step].cpu().numpy(), g["values"][step], rtol=1e-4, atol=2e-5)
+        L.actions[step].copy_(torch.from_numpy(g["actions"][step]))
+        L.logprobs[step].copy_(torch.from_numpy(g["logprobs"][step]))
+        L.values[step].copy_(torch.from_numpy(g["values"][step]))
+        L.store_reward(step, g["rewards"][step])
+        L.observe(step + 1, obs_seq[step + 1], step_done[step + 1])
+    # K2' on the forced actions reproduces the reference's log-probs
+    with torch.no_grad():
+        mean, _ = agent.heads(torch.from_numpy(obs_seq[:T]).to(DEV).reshape(T * N, OBS))
+    lp, _ = L.ops.normal_logprob_entropy(mean.contiguous(), agent.actor_logstd.detach(), L.actions.reshape(T * N, ACT).contiguous())
+    np.testing.assert_allclose(lp.cpu().numpy(), g["logprobs"].reshape(-1), rtol=1e-4, atol=2e-5)
+    L.finish_rollout()
+    np.testing.assert_allclose(L.advantages.cpu().numpy(), g["advantages"], rtol=1e-4, atol=1e-4)
+    L.advantages.copy_(torch.from_numpy(g["advantages"]))
+    L.returns.copy_(torch.from_numpy(g["returns"]))
+    logstd = []
+    real = L.optimizer_step_hip
+
+    def spy(lr):
+        real(lr)
+        logstd.append(agent.actor_logstd.detach().reshape(-1).clone())
+
+    L.optimizer_step_hip = spy
+    np.random.seed(int(g["shuffle_seed"]))
+    m = L.update(float(g["lr"]))
+    assert m["num_updates"] == 6
+    sc = L._scalars[:6].cpu().numpy()                  # loss, pg, v, entropy, old_kl, kl, clipfrac
+    ref = g["scalars"]                                 # loss, pg_loss, v_loss, entropy_loss, old_approx_kl, approx_kl
+    np.testing.assert_allclose(sc[:, :4], ref[:, :4], rtol=2e-3, atol=5e-5)
+    np.testing.assert_allclose(sc[:, 4:6], ref[:, 4:6], rtol=5e-2, atol=5e-5)      # KL estimates: differences of nearly equal numbers
+    np.testing.assert_allclose(sc[:, 6], g["clipfracs"], atol=1e-6)
+    got_ls = torch.stack(logstd).cpu().numpy()
+    step_move = np.abs(np.diff(np.vstack([np.zeros(ACT, np.float32), g["logstd_after_step"]]), axis=0)).mean()
+    assert np.abs(got_ls - g["logstd_after_step"]).max() <= 0.1 * step_move + 1e-6, (np.abs(got_ls - g["logstd_after_step"]).max(), step_move)
+    delta = L.flat.params.cpu().numpy() - g["init_params"]
+    want = g["final_params"] - g["init_params"]
+    close = np.isclose(delta, want, rtol=5e-2, atol=2e-5)
+    assert close.mean() > 0.98, f"only {close.mean():.4f} of the parameters follow the reference update"
+    assert np.abs(delta - want).mean() <= 0.02 * np.abs(want).mean(), (np.abs(delta - want).mean(), np.abs(want).mean())
+    L.flat.check_views()
