@@ -814,6 +814,71 @@ def mint_rnd_iteration():
     _save("rnd_iteration", cases)
 
 
+def mint_ppo_iteration():
+    """BASELINE configs[0]'s script (cleanrl/ppo.py, CartPole-shaped: obs 4, 2 actions, the MLP Agent), one whole iteration on
+    synthetic inputs (T = 16, N = 4): the reference Agent fills the rollout (:122-126 through torch's Categorical, seeded), then
+    the script's GAE lines and its flatten + epoch / minibatch update lines (4 minibatches x 4 epochs = sixteen Adam steps,
+    the script's defaults: clip 0.2, ent 0.01) are exec'd verbatim.  Recorded as in ``mint_continuous_iteration``."""
+    import textwrap
+
+    import torch.nn as nn
+
+    script = "ppo.py"
+    lines = R._read(script)
+    T, N, OBS, A = 16, 4, 4, 2
+    torch.manual_seed(41)
+    Agent, _ = R.load_agent_class(script)
+    envs = R.fake_envs((OBS,), n_actions=A)
+    agent = Agent(envs)
+    args = R.make_args(num_steps=T, num_envs=N, num_minibatches=4, update_epochs=4, batch_size=T * N, minibatch_size=T * N // 4,
+                       clip_coef=0.2, ent_coef=0.01, learning_rate=2.5e-4)
+    scalars = []
+    keys = ("loss", "pg_loss", "v_loss", "entropy_loss", "old_approx_kl", "approx_kl")
+    optimizer = _GradSpy(R.make_optimizer(agent, 2.5e-4), agent.parameters())
+    init = _flat(agent.parameters()).clone()
+    g = torch.Generator().manual_seed(59)
+    obs_seq = torch.randn(T + 1, N, OBS, generator=g) * 0.5
+    step_done = (torch.rand(T + 1, N, generator=g) < 0.15).float()
+    step_done[0] = 0.0
+    rewards = torch.ones(T, N)                                 # CartPole pays 1 per step
+    obs = torch.zeros((T, N, OBS))
+    actions, logprobs, dones, values = (torch.zeros((T, N)) for _ in range(4))
+    torch.manual_seed(43)                                      # the sampler's stream
+    for step in range(T):
+        obs[step], dones[step] = obs_seq[step], step_done[step]
+        with torch.no_grad():
+            action, logprob, _, value = agent.get_action_and_value(obs[step])
+            values[step] = value.flatten()
+        actions[step], logprobs[step] = action, logprob
+    next_obs, next_done = obs_seq[T], step_done[T]
+    device = torch.device("cpu")
+    ns = dict(args=args, agent=agent, optimizer=optimizer, envs=envs, obs=obs, actions=actions, logprobs=logprobs,
+              rewards=rewards, dones=dones, values=values, next_obs=next_obs, next_done=next_done, device=device, np=np,
+              torch=torch, nn=nn)
+    g0 = R._find(lines, "# bootstrap value if not done") + 1
+    g1 = R._find(lines, "returns = advantages + values", g0)
+    exec(textwrap.dedent("\n".join(lines[g0:g1 + 1])), ns)
+    u0 = R._find(lines, "# flatten the batch", g1) + 1
+    u1 = R._find(lines, "y_pred, y_true = b_values.cpu().numpy()", u0)
+    body = lines[u0:u1]
+    k = max(i for i, ln in enumerate(body) if "optimizer.step()" in ln)
+    indent = body[k][:len(body[k]) - len(body[k].lstrip())]
+    body.insert(k + 1, indent + "_record(loss, pg_loss, v_loss, entropy_loss, old_approx_kl, approx_kl)")
+    ns["_record"] = lambda *v: scalars.append(torch.stack([x.detach().reshape(()) for x in v]))
+    np.random.seed(10)
+    exec(textwrap.dedent("\n".join(body)), ns)
+    final = _flat(agent.parameters())
+    assert len(scalars) == 16
+    cases = {"cartpole_T16_N4": dict(
+        obs_seq=obs_seq, step_done=step_done, rewards=rewards, actions=actions, logprobs=logprobs, values=values,
+        advantages=ns["advantages"], returns=ns["returns"], init_params=init, final_params=final,
+        scalars=torch.stack(scalars), scalar_names=np.array(keys), clipfracs=np.array(ns["clipfracs"], np.float32),
+        init_seed=np.int64(41), sample_seed=np.int64(43), shuffle_seed=np.int64(10), lr=np.float64(2.5e-4),
+        lines=np.array([g0 + 1, g1 + 1, u0 + 1, u1], np.int64),
+        **_grad_record("mb1_grad", optimizer.grads[0], agent.parameters(), stride=1))}
+    _save("ppo_iteration", cases)
+
+
 def mint_continuous_iteration():
     """BASELINE configs[4]'s script, one whole iteration on synthetic inputs (T = 16, N = 4, obs 17 / act 6 = HalfCheetah's
     shapes): the reference Agent of ppo_continuous_action.py fills the rollout through its own ``get_action_and_value``
@@ -913,6 +978,7 @@ def main():
     mint_ppg_phase()
     mint_ma_atari_update()
     mint_continuous_iteration()
+    mint_ppo_iteration()
 
 
 if __name__ == "__main__":

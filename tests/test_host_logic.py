@@ -288,3 +288,52 @@ def test_whole_continuous_iteration_matches_the_reference_lines():
         np.testing.assert_allclose(flat().numpy(), g["final_params"], rtol=0, atol=5e-7)       # measured 3e-8; the update moves 1e-3
     finally:
         torch.set_num_threads(n)
+
+
+def test_whole_ppo_iteration_matches_the_reference_lines():
+    """cleanrl/ppo.py (BASELINE configs[0]: the CPU configuration), one whole iteration through the learner's API on CPU against
+    tests/golden/ppo_iteration.npz (the script's own lines exec'd on CartPole-shaped synthetic inputs; 4 minibatches x 4 epochs
+    = sixteen Adam steps).  This is the path config A runs: torch's Categorical for the rollout (bit-equal), ``mi355ppo_gae_f32_cpu``
+    (bit-equal) and the fused Categorical loss twin ``mi355ppo_loss_categorical_fwd_bwd_f32_cpu`` for the update."""
+    g = load_golden("ppo_iteration")["cartpole_T16_N4"]
+    T, N = g["rewards"].shape
+    OBS = g["obs_seq"].shape[-1]
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)                       # as when minted
+    try:
+        env = SimpleNamespace(single_observation_space=E.Box(-np.inf, np.inf, (OBS,)), single_action_space=E.Discrete(2))
+        torch.manual_seed(int(g["init_seed"]))
+        agent = MlpAgent(env)
+        flat = lambda: torch.cat([p.detach().reshape(-1) for p in agent.parameters()])      # noqa: E731
+        np.testing.assert_allclose(flat().numpy(), g["init_params"], rtol=0, atol=3e-7)
+        args = default_args(num_steps=T, num_minibatches=4, update_epochs=4, clip_coef=0.2, ent_coef=0.01, learning_rate=2.5e-4)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, torch.device("cpu"))
+        obs_seq, step_done = g["obs_seq"], g["step_done"]
+        L.observe(0, obs_seq[0], step_done[0])
+        torch.manual_seed(int(g["sample_seed"]))
+        for step in range(T):
+            L.act(step)
+            L.store_reward(step, g["rewards"][step])
+            L.observe(step + 1, obs_seq[step + 1], step_done[step + 1])
+        assert torch.equal(L.actions, torch.from_numpy(g["actions"]))                        # same sampler stream, same draws
+        for gold in ("logprobs", "values"):
+            np.testing.assert_allclose(getattr(L, gold).numpy(), g[gold], rtol=0, atol=2e-6, err_msg=gold)
+            getattr(L, gold).copy_(torch.from_numpy(g[gold]))
+        L.finish_rollout()
+        np.testing.assert_allclose(L.advantages.numpy(), g["advantages"], rtol=0, atol=5e-6)
+        L.advantages.copy_(torch.from_numpy(g["advantages"]))
+        L.returns.copy_(torch.from_numpy(g["returns"]))
+        scal = []
+        real_mb = L._minibatch_host
+        L._minibatch_host = lambda *a, **kw: (scal.append(real_mb(*a, **kw).clone()), scal[-1])[1]
+        np.random.seed(int(g["shuffle_seed"]))
+        m = L.update(float(g["lr"]))
+        assert m["num_updates"] == 16 and len(scal) == 16
+        mine = torch.stack(scal).numpy()
+        np.testing.assert_allclose(mine[:, :6], g["scalars"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(mine[:, 6], g["clipfracs"], atol=1e-6)
+        moved = np.abs(g["final_params"] - g["init_params"]).mean()
+        assert moved > 5e-4
+        np.testing.assert_allclose(flat().numpy(), g["final_params"], rtol=0, atol=5e-7)       # measured 3e-8; sixteen Adam steps move 1e-3
+    finally:
+        torch.set_num_threads(n)
