@@ -138,6 +138,9 @@ def parse():
                         "boundary costs ~8 us of GPU idle; 1 = a graph per step)")
     p.add_argument("--no-pcie-inclusive", action="store_true", help="skip the host-env (PCIe-inclusive) leg after the timed region")
     p.add_argument("--pcie-env-groups", type=int, default=4)
+    p.add_argument("--update-graphs", action="store_true",
+                   help="one hipGraph per (epoch, minibatch) slot of the update (PPOLearner.capture_update; bit-identical to the eager "
+                        "update in the GPU tests, not yet measured at the BASELINE configurations: opt-in); single GPU only")
     p.add_argument("--sync-metrics", action="store_true",
                    help="read every iteration's diagnostics before the next one starts (the reference's arrangement: one device "
                         "synchronisation per iteration); default: resolve them one iteration late, so that the host runs ahead "
@@ -265,6 +268,9 @@ def main():
     learner.observe(0, env.obs_into(learner.stage_obs), learner.dones[0])
     if learner.fused_cnn and not cli.no_rollout_graphs:
         learner.capture_rollout(env, steps_per_graph=cli.rollout_steps_per_graph or T)      # (before the timing hooks: no event records in a capture)
+    if cli.update_graphs and learner.fused_cnn and world == 1:
+        learner.capture_update()            # (before the timing hooks: no event records in a capture)
+        cli.no_kernel_timing = True         # replays run no Python: the per-launch event brackets would stay empty (pure SPS line)
     timer = KernelTimer()
     conv_flops = {}      # key "<op>@<rows>" -> algorithmic flops of one launch (the f32 convolution / GEMM: 2 x M x N x K)
     kernel_of = {}       # key -> letter in KERNEL_INFO

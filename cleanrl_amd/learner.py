@@ -150,6 +150,8 @@ class PPOLearner:
         self._pack_buf = None       # their storage, allocated by the first update()
         self._mb_adv_md = None      # the current minibatch's (mean, std + 1e-8) row of ops.adv_stats, or None
         self._mb_slot = None        # (LossSlots, k): K3's scalar fold deferred to one launch per update (categorical family)
+        self._update_graphs = None  # capture_update(): [epoch][minibatch] -> hipGraph of one minibatch's forward + loss + backward
+        self._adv_md_buf = None
         self._loss_slots = None
         if self.hip and self.discrete and type(self).forward_backward_hip is PPOLearner.forward_backward_hip:
             self._loss_slots = self.ops.LossSlots(self._scalars.shape[0], device)
@@ -406,12 +408,16 @@ class PPOLearner:
                 if not a.norm_adv:
                     adv_md = None
                 elif use_pack:
-                    adv_md = self.ops.adv_stats_packed(self._pack, inds_dev, M)
+                    adv_md = self.ops.adv_stats_packed(self._pack, inds_dev, M,
+                                                       out=self._adv_md_buf[epoch] if self._update_graphs is not None else None)
                 else:
                     adv_md = self.ops.adv_stats(b_advantages, inds_dev, M)
             for start in range(0, B, M):
                 end = start + M
-                if self.hip:
+                if self.hip and self._update_graphs is not None:
+                    self._update_graphs[epoch][start // M].replay()       # forward + fused loss + backward of this slot (capture_update)
+                    self.optimizer_step_hip(lr)                           # lr and Adam's step count are launch arguments: eager
+                elif self.hip:
                     self._mb_adv_md = adv_md[start // M] if adv_md is not None else None
                     self._mb_slot = (self._loss_slots, k) if self._loss_slots is not None else None
                     self._minibatch_hip(inds_dev[start:end], b_obs, b_actions, b_logprobs, b_advantages, b_returns,
@@ -446,6 +452,69 @@ class PPOLearner:
                 ev.record()
             return PendingMetrics(ev, host[0], host[1], host[2], None, k)
         return PendingMetrics(None, b_values, b_returns, None, (last, clipfracs), k)
+
+    def capture_update(self) -> None:
+        """Opt-in (``bench.py --update-graphs``).  State at the end of round 3: bit-identical to the eager update over three
+        iterations at a small shape on the MI355X (tests/test_gpu_learner.py::test_captured_update_slots_...); NOT yet run at the
+        BASELINE configurations and NOT yet measured (the round's GPU minutes were spent) -- hence not the default.
+
+        One hipGraph per (epoch, minibatch) slot of the update: K5 gather + network forward + fused loss + backward through the
+        custom autograd nodes of that slot (:320-358), ~50 launches, replayed by ``update`` / ``update_async`` with the
+        optimizer step (two launches whose learning rate and step count are launch arguments) issued eagerly after it.
+        Everything a slot reads sits at a fixed address: its rows of the epoch's device permutation (``_inds_dev[epoch]``),
+        the packed behaviour rows, the epoch's advantage statistics (``_adv_md_buf``), its loss slot and scalar row, the
+        flat parameter / gradient buffers, the weight packs (re-derived in place by launches inside the graph: the capture
+        bumps the weights' version before every slot, so the repack launches are part of every graph).  Why: the update then
+        costs the host ~3 launches per minibatch instead of ~55, so a busy host no longer drains the GPU's queue in a training
+        loop that synchronises every env step (host envs), where ``update_async`` cannot help."""
+        assert self.hip and self.discrete and self.world_size == 1 and self._loss_slots is not None, \
+            "capture_update: the single-GPU categorical HIP path"
+        a, dev = self.args, self.device
+        B, M = self.batch_size, self.minibatch_size
+        assert B % M == 0, "capture_update needs whole minibatches"
+        E_, nmb = int(a.update_epochs), B // M
+        b_obs = self.obs.reshape((-1,) + self.obs_shape)
+        b_actions = self.actions.reshape((-1,) + self.act_shape)
+        b_logprobs, b_advantages = self.logprobs.reshape(-1), self.advantages.reshape(-1)
+        b_returns, b_values = self.returns.reshape(-1), self.values.reshape(-1)
+        if self._pack_buf is None:
+            self._pack_buf = torch.empty((B, self.ops.PACK_FLOATS), dtype=torch.float32, device=dev)
+        # the warm-up EXECUTES a slot: give it valid operands (indices inside the batch, a non-zero denominator)
+        self._inds_dev.copy_(torch.arange(B, dtype=torch.int64, device=dev).expand(E_, B))
+        self._adv_md_buf = torch.zeros((E_, nmb, 2), dtype=torch.float32, device=dev)
+        self._adv_md_buf[..., 1] = 1.0
+        self._pack = self.ops.batch_pack(b_actions, b_logprobs, b_advantages, b_returns, b_values, out=self._pack_buf)
+        trunk = getattr(self.agent, "_trunk", None)
+
+        def slot(e, j):
+            k = e * nmb + j
+            if trunk is not None:
+                trunk.bufs.weights_version += 1                       # every graph re-derives the packs it reads
+            self._mb_adv_md = self._adv_md_buf[e][j] if a.norm_adv else None
+            self._mb_slot = (self._loss_slots, k)
+            self.forward_backward_hip(self._inds_dev[e][j * M:(j + 1) * M], b_obs, b_actions, b_logprobs, b_advantages,
+                                      b_returns, b_values, self._scalars[k])
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            slot(0, 0)                                                    # warm-up on the capture stream (workspaces, trunk buffers)
+            self.flat.grads.zero_()                                       # it accumulated a gradient nobody applies
+        side.synchronize()
+        graphs, pool = [], None
+        for e in range(E_):
+            row = []
+            for j in range(nmb):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=side):
+                    slot(e, j)
+                pool = pool or g.pool()
+                row.append(g)
+            graphs.append(row)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.flat.grads.zero_()
+        self._mb_adv_md = self._mb_slot = self._pack = None
+        self._update_graphs = graphs
 
     def upload_permutation(self, epoch: int, b_inds: np.ndarray) -> torch.Tensor:
         """Host permutation of this epoch (:315) -> its own pinned row -> its own device row (async H2D).  The pinned row is

@@ -756,3 +756,34 @@ def test_continuous_hip_path_teacher_forced_against_reference_iteration():
     assert close.mean() > 0.98, f"only {close.mean():.4f} of the parameters follow the reference update"
     assert np.abs(delta - want).mean() <= 0.02 * np.abs(want).mean(), (np.abs(delta - want).mean(), np.abs(want).mean())
     L.flat.check_views()
+
+
+def test_captured_update_slots_are_bit_identical_to_the_eager_update():
+    """capture_update: one hipGraph per (epoch, minibatch) slot (forward + fused loss + backward), optimizer step eager.  Three
+    iterations against the eager learner from the same seeds: parameters, Adam state and logged scalars bit-equal."""
+    N, T = 32, 8
+
+    def make(graphs):
+        torch.manual_seed(4)
+        env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=6, done_p=0.1)
+        agent = AtariAgent(env).to(DEV)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=2)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
+        L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
+        if graphs:
+            L.capture_update()
+        return L, env
+
+    (Le, enve), (Lg, envg) = make(False), make(True)
+    assert torch.equal(Le.flat.params, Lg.flat.params) and not Lg.flat.grads.any()       # the capture's warm-up changed nothing
+    for it in range(3):
+        learner_smoke.rollout(Le, enve)
+        learner_smoke.rollout(Lg, envg)
+        np.random.seed(100 + it)
+        me = Le.update(2.5e-4 * (1 - it / 3))
+        np.random.seed(100 + it)
+        mg = Lg.update(2.5e-4 * (1 - it / 3))
+        Le.start_iteration(); Lg.start_iteration()
+        assert torch.equal(Le.flat.params, Lg.flat.params), it
+        assert torch.equal(Le.flat.exp_avg, Lg.flat.exp_avg) and torch.equal(Le.flat.exp_avg_sq, Lg.flat.exp_avg_sq), it
+        assert me == mg or all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
