@@ -582,6 +582,8 @@ def main_continuous(cli, rank, world, device):
     learner = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, device, world_size=world,
                          sample_seed=seed)
     learner.observe(0, env.obs(), learner.dones[0])
+    if cli.update_graphs and world == 1:      # (opt-in; the Normal path of capture_update has not run on a GPU yet)
+        learner.capture_update()
     timer = KernelTimer()
     if not cli.no_kernel_timing:
         seen = {"n": 0}

@@ -411,7 +411,8 @@ class PPOLearner:
                     adv_md = self.ops.adv_stats_packed(self._pack, inds_dev, M,
                                                        out=self._adv_md_buf[epoch] if self._update_graphs is not None else None)
                 else:
-                    adv_md = self.ops.adv_stats(b_advantages, inds_dev, M)
+                    adv_md = self.ops.adv_stats(b_advantages, inds_dev, M,
+                                                out=self._adv_md_buf[epoch] if self._update_graphs is not None else None)
             for start in range(0, B, M):
                 end = start + M
                 if self.hip and self._update_graphs is not None:
@@ -467,8 +468,11 @@ class PPOLearner:
         bumps the weights' version before every slot, so the repack launches are part of every graph).  Why: the update then
         costs the host ~3 launches per minibatch instead of ~55, so a busy host no longer drains the GPU's queue in a training
         loop that synchronises every env step (host envs), where ``update_async`` cannot help."""
-        assert self.hip and self.discrete and self.world_size == 1 and self._loss_slots is not None, \
-            "capture_update: the single-GPU categorical HIP path"
+        assert self.hip and self.world_size == 1 and type(self).forward_backward_hip is PPOLearner.forward_backward_hip, \
+            "capture_update: the single-GPU HIP path of the plain PPO learner"
+        assert getattr(self.agent, "rpo_alpha", None) is None, "capture_update: RPO draws noise inside the update (not covered)"
+        # (the Normal / continuous-action path is covered by the same code but has NOT run on a GPU yet: its test is opt-in,
+        #  tests/test_gpu_learner.py::test_captured_update_slots_continuous_path, MI355PPO_TEST_UPDATE_GRAPHS_CONTINUOUS=1)
         a, dev = self.args, self.device
         B, M = self.batch_size, self.minibatch_size
         assert B % M == 0, "capture_update needs whole minibatches"
@@ -477,13 +481,15 @@ class PPOLearner:
         b_actions = self.actions.reshape((-1,) + self.act_shape)
         b_logprobs, b_advantages = self.logprobs.reshape(-1), self.advantages.reshape(-1)
         b_returns, b_values = self.returns.reshape(-1), self.values.reshape(-1)
-        if self._pack_buf is None:
+        if self._pack_buf is None and self.discrete:
             self._pack_buf = torch.empty((B, self.ops.PACK_FLOATS), dtype=torch.float32, device=dev)
         # the warm-up EXECUTES a slot: give it valid operands (indices inside the batch, a non-zero denominator)
         self._inds_dev.copy_(torch.arange(B, dtype=torch.int64, device=dev).expand(E_, B))
         self._adv_md_buf = torch.zeros((E_, nmb, 2), dtype=torch.float32, device=dev)
         self._adv_md_buf[..., 1] = 1.0
-        self._pack = self.ops.batch_pack(b_actions, b_logprobs, b_advantages, b_returns, b_values, out=self._pack_buf)
+        use_pack = self.discrete and self._loss_slots is not None
+        self._pack = (self.ops.batch_pack(b_actions, b_logprobs, b_advantages, b_returns, b_values, out=self._pack_buf)
+                      if use_pack else None)
         trunk = getattr(self.agent, "_trunk", None)
 
         def slot(e, j):
@@ -491,7 +497,7 @@ class PPOLearner:
             if trunk is not None:
                 trunk.bufs.weights_version += 1                       # every graph re-derives the packs it reads
             self._mb_adv_md = self._adv_md_buf[e][j] if a.norm_adv else None
-            self._mb_slot = (self._loss_slots, k)
+            self._mb_slot = (self._loss_slots, k) if self._loss_slots is not None else None
             self.forward_backward_hip(self._inds_dev[e][j * M:(j + 1) * M], b_obs, b_actions, b_logprobs, b_advantages,
                                       b_returns, b_values, self._scalars[k])
 

@@ -787,3 +787,47 @@ def test_captured_update_slots_are_bit_identical_to_the_eager_update():
         assert torch.equal(Le.flat.params, Lg.flat.params), it
         assert torch.equal(Le.flat.exp_avg, Lg.flat.exp_avg) and torch.equal(Le.flat.exp_avg_sq, Lg.flat.exp_avg_sq), it
         assert me == mg or all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
+
+
+@pytest.mark.skipif(os.environ.get("MI355PPO_TEST_UPDATE_GRAPHS_CONTINUOUS") != "1",
+                    reason="capture_update on the Normal path was written after the round's GPU minutes were spent: not run on a GPU yet "
+                           "(set MI355PPO_TEST_UPDATE_GRAPHS_CONTINUOUS=1)")
+def test_captured_update_slots_continuous_path():
+    """capture_update on the continuous-action path (torch MLP + fused Normal loss + the shared actor_logstd's column sum) against
+    the eager update: parameters, Adam state and scalars bit-equal over three iterations."""
+    N, T = 16, 32
+
+    def make(graphs):
+        torch.manual_seed(4)
+        env = E.DeviceSyntheticContinuousVecEnv(N, DEV, seed=6)
+        agent = ContinuousAgent(env).to(DEV)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=4, update_epochs=3, clip_coef=0.2, ent_coef=0.0, learning_rate=3e-4)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
+        L.observe(0, env.obs(), L.dones[0])
+        if graphs:
+            L.capture_update()
+        return L, env
+
+    def rollout(L, env):
+        for step in range(T):
+            action = L.act(step)
+            next_obs, reward, done = env.step(action)
+            L.store_reward(step, reward)
+            L.observe(step + 1, next_obs, done)
+        L.finish_rollout()
+
+    (Le, enve), (Lg, envg) = make(False), make(True)
+    assert torch.equal(Le.flat.params, Lg.flat.params) and not Lg.flat.grads.any()
+    for it in range(3):
+        rollout(Le, enve)
+        rollout(Lg, envg)
+        for name in ("obs", "actions", "logprobs", "values", "advantages", "returns"):
+            assert torch.equal(getattr(Le, name), getattr(Lg, name)), (it, name)
+        np.random.seed(100 + it)
+        me = Le.update(3e-4 * (1 - it / 3))
+        np.random.seed(100 + it)
+        mg = Lg.update(3e-4 * (1 - it / 3))
+        Le.start_iteration(); Lg.start_iteration()
+        assert torch.equal(Le.flat.params, Lg.flat.params), it
+        assert torch.equal(Le.flat.exp_avg, Lg.flat.exp_avg) and torch.equal(Le.flat.exp_avg_sq, Lg.flat.exp_avg_sq), it
+        assert all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
