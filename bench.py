@@ -19,11 +19,15 @@ env-steps/sec = N * 1024 * 128 * K / max-over-ranks(time).
 The JSON line also carries
   ``roofline``      for the dominant HIP kernel of the path = the convolution / FC launch with the largest total time in
                     the timed region (KERNEL_INFO below names them; the uint8 gather + /255 of K5, bias, ReLU and
-                    ReLU-backward passes are fused into them): ALGORITHMIC flops of the f32 convolution / launch duration,
-                    timed live with HIP events on the learner's stream around each launch, against the dense f32 MFMA peak
-                    (the dtype the path computes in); ``pipe`` prices the bf16 products a split kernel actually executes
-                    against the bf16 peak; ``traffic`` = HBM bytes per launch from the committed PMC passes
+                    ReLU-backward passes are fused into them), timed live with HIP events on the learner's stream around each
+                    launch and priced on the pipe it EXECUTES on (``roofline_entry``): a bf16-pipe kernel's ``achieved`` is the
+                    algorithmic f32 flops x the MFMA term pairs it issues per f32 product, against the dense bf16 MFMA peak --
+                    a bound, ``frac`` <= 1; the f32-equivalent rate (which the split kernels push past the f32 MFMA peak) is the
+                    secondary ``frac_of_f32_mfma_peak``; ``traffic`` = HBM bytes per launch from the committed PMC passes
                     (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction);
+  ``hbm_frac``      kernel Q (layer-1 forward, the HBM-bound launch that reads the observation bytes): algorithmic bytes /
+                    launch time / 8 TB/s -- north_star's HBM-roofline figure;
+  ``iteration_f32_equiv_TFLOPs``  algorithmic f32 flops of the whole iteration / ms_per_step;
   ``kernels``       the same accounting for every conv launch shape, and GB/s for the GAE and fused-loss kernels
                     (latency-bound at this size);
   ``cpu_baseline``  the oracle's CPU port of the reference loop (oracle/cpu_ppo_port.py), rank 0, N=1 only,
@@ -175,6 +179,49 @@ CONFIGS = {
 }
 
 
+def roofline_entry(key, us, launches_timed, flops, letter, share, traffic):
+    """The ``roofline`` object of the JSON line for the dominant conv / FC launch ``key`` ("conv2_dgrad@32768"): a BOUND, i.e.
+    ``frac`` <= 1 by construction.  A kernel is priced on the pipe it executes on:
+
+    * kernel Q (int8 pipe at 1/8 of the f32 pipe's time): HBM-bound -- algorithmic bytes / launch time against 8 TB/s;
+    * bf16-pipe kernels (Z, V, W, P): ``achieved`` = EXECUTED bf16 MFMA flops per second = the algorithmic f32 flops of the
+      convolution / GEMM x the MFMA products issued per f32 product (the term pairs of the exact three-term split: 6 by
+      default, 9 with MI355PPO_BF16_PAIRS=9; kernel P: 3 -- its uint8 operand is exact in bf16), ``peak`` = the dense bf16
+      MFMA peak (2,500 TFLOP/s; never the 2:1-sparsity figure);
+    * f32-pipe kernels (F, T, Y): algorithmic flops against the dense f32 MFMA peak.
+
+    The f32-equivalent view (algorithmic flops / the f32 peak, which the split kernels legitimately exceed) is kept as the
+    secondary fields ``algorithmic_TFLOPs`` / ``frac_of_f32_mfma_peak``."""
+    text, pipe, products = KERNEL_INFO[letter]
+    tf = flops / us / 1e6
+    common = {"avg_launch_us": us, "launches_timed": launches_timed, "share_of_step_time": share, "traffic": traffic}
+    if letter == "Q":
+        alg = _conv1_fwd_bytes(int(key.split("@")[1]))
+        return {"kernel": f"{key}: kernel Q = {text}", "bound": "hbm", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg, **common}
+    peak = MFMA_BF16_PEAK_TFLOPS if pipe == "bf16" else MFMA_F32_PEAK_TFLOPS
+    r = {"kernel": f"{key}: kernel {letter} = {text}", "bound": "mfma", "achieved": tf * products, "peak": peak, "unit": "TFLOP/s",
+         "frac": tf * products / peak, "pipe": pipe, "mfma_products_per_f32_product": products,
+         "algorithmic_flops_per_launch": flops, "algorithmic_TFLOPs": tf, "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS, **common}
+    if pipe == "bf16":
+        r["mfma"] = "v_mfma_f32_32x32x16_bf16"
+        r["frac_of_measured_stream_rate"] = tf * products / (MFMA_BF16_PEAK_TFLOPS * 32.0 / 47.7)
+        r["note"] = ("achieved = algorithmic f32 flops x term pairs executed (padding taps of the data gradients are not multiplied and "
+                     "not counted); frac_of_measured_stream_rate: against 32 nominal cycles per MFMA / 47.7 measured for a bare MFMA "
+                     "stream on random operands on this power-limited chip (profiles/r03_mfma_floor.jsonl)")
+    return r
+
+
+def iteration_flops(N, T, M, n_actions, epochs):
+    """Algorithmic f32 flops of one PPO iteration of the NatureCNN path: (T + 1) x N rollout / bootstrap forwards, and per update
+    pass over the batch forward + weight gradients of every layer + data gradients of every layer but the first."""
+    conv = [2.0 * hout * hout * cout * cin * k * k for (cin, cout, k, _, _, hout) in
+            ((4, 32, 8, 4, 84, 20), (32, 64, 4, 2, 20, 9), (64, 64, 3, 1, 9, 7))]
+    fc, heads = 2.0 * 3136 * 512, 2.0 * 512 * (n_actions + 1)
+    fwd = sum(conv) + fc + heads
+    return (T + 1) * N * fwd + epochs * T * N * (2 * fwd + (fwd - conv[0]))
+
+
 class KernelTimer:
     """HIP-event brackets around chosen kernel launches on the learner's stream (torch.cuda.Event records on
     the current stream, which is the stream every libmi355ppo launch is enqueued on)."""
@@ -268,9 +315,13 @@ def main():
     learner.observe(0, env.obs_into(learner.stage_obs), learner.dones[0])
     if learner.fused_cnn and not cli.no_rollout_graphs:
         learner.capture_rollout(env, steps_per_graph=cli.rollout_steps_per_graph or T)      # (before the timing hooks: no event records in a capture)
+    update_mode = "eager launches"
     if cli.update_graphs and learner.fused_cnn and world == 1:
         learner.capture_update()            # (before the timing hooks: no event records in a capture)
         cli.no_kernel_timing = True         # replays run no Python: the per-launch event brackets would stay empty (pure SPS line)
+        update_mode = "one hipGraph per (epoch, minibatch) slot: forward + fused loss + backward (PPOLearner.capture_update)"
+    elif cli.update_graphs:
+        update_mode = "eager launches (--update-graphs IGNORED: world > 1 or the CNN is not on the fused kernels)"
     timer = KernelTimer()
     conv_flops = {}      # key "<op>@<rows>" -> algorithmic flops of one launch (the f32 convolution / GEMM: 2 x M x N x K)
     kernel_of = {}       # key -> letter in KERNEL_INFO
@@ -421,6 +472,7 @@ def main():
                 "rollout": (f"{len(learner._rollout_graphs)} hipGraph(s) of {-(-T // len(learner._rollout_graphs))} env step(s) each (policy "
                             "forward, sampling, env step, observation store)")
                            if getattr(learner, "_rollout_graphs", None) else "kernel-by-kernel launches",
+                "update": update_mode,
                 "diagnostics": "synchronous (one device synchronisation per iteration)" if cli.sync_metrics
                                else "read one iteration late (PPOLearner.update_async): the host runs an iteration ahead of the GPU",
                 "cnn": "layer-1 forward on the int8 MFMA with exact int32 accumulation over 31-bit fixed-point weights (kernel Q); every "
@@ -440,32 +492,19 @@ def main():
                    if timer.mean_us(k)[1] > 0}          # (rollout-sized launches inside captured graphs carry no event brackets)
             dom = max(tot, key=tot.get)
             us, n = timer.mean_us(dom)
-            tf = conv_flops[dom] / us / 1e6
-            text, pipe, products = KERNEL_INFO[kernel_of[dom]]
-            common = {"avg_launch_us": us, "launches_timed": n, "share_of_step_time": tot[dom] / (elapsed * 1e6),
-                      "traffic": _traffic_of(dom)}
-            if kernel_of[dom] == "Q":
-                # layer-1 forward runs on the integer matrix pipe (kernel Q): 1/8 of the f32 pipe's time, so the launch is bound
-                # by HBM -- uint8 rows in, f32 activations out
-                alg = _conv1_fwd_bytes(int(dom.split("@")[1]))
-                out["roofline"] = {"kernel": f"{dom}: kernel Q = {text}", "bound": "hbm", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBPS,
-                                   "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg, **common}
-            else:
-                # `achieved` = the ALGORITHMIC flops of the f32 convolution / GEMM the launch computes (2 x M x N x K, no padding, no
-                # term pairs) per second, against the dense f32 MFMA peak -- the peak of the dtype the path computes in.  A bf16-pipe
-                # kernel executes `products` MFMA products per algorithmic product (the term pairs of the exact split): `pipe`
-                # prices THAT work against the bf16 dense peak, and against the rate one wave per SIMD sustains on random
-                # operands on this chip (power-limited: tools/mfma_floor.cpp, profiles/r03_mfma_floor.jsonl).
-                out["roofline"] = {"kernel": f"{dom}: kernel {kernel_of[dom]} = {text}", "bound": "mfma", "achieved": tf,
-                                   "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                                   "algorithmic_flops_per_launch": conv_flops[dom], **common}
-                if pipe == "bf16":
-                    out["roofline"]["pipe"] = {
-                        "mfma": "v_mfma_f32_32x32x16_bf16", "products_per_f32_product": products, "executed_TFLOPs": tf * products,
-                        "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "frac": tf * products / MFMA_BF16_PEAK_TFLOPS,
-                        "frac_of_measured_stream_rate": tf * products / (MFMA_BF16_PEAK_TFLOPS * 32.0 / 47.7),
-                        "note": "executed = algorithmic x term pairs (padding taps of the data gradients not counted); measured stream "
-                                "rate = 32 nominal cycles per MFMA / 47.7 measured on random operands (profiles/r03_mfma_floor.jsonl)"}
+            out["roofline"] = roofline_entry(dom, us, n, conv_flops[dom], kernel_of[dom], tot[dom] / (elapsed * 1e6), _traffic_of(dom))
+            # north_star's HBM figure: the one HBM-bound launch of the conv stack (kernel Q: uint8 rows in, f32 activations out)
+            qk = f"conv1_fwd@{M}"
+            if kernel_of.get(qk) == "Q" and timer.mean_us(qk)[1]:
+                qus = timer.mean_us(qk)[0]
+                out["hbm_frac"] = _conv1_fwd_bytes(M) / qus / 1e3 / HBM_PEAK_GBPS
+                out["hbm_frac_note"] = (f"kernel Q ({qk}): {_conv1_fwd_bytes(M)} algorithmic bytes in {qus:.0f} us = "
+                                        f"{_conv1_fwd_bytes(M) / qus / 1e3:.0f} GB/s of {HBM_PEAK_GBPS:.0f} GB/s")
+            it_flops = iteration_flops(N, T, M, cli.n_actions, int(args.update_epochs))
+            out["iteration_f32_equiv_TFLOPs"] = it_flops / (elapsed / cli.steps) / 1e12
+            out["iteration_f32_equiv_note"] = (f"{it_flops / 1e12:.2f} algorithmic TFLOP per iteration (f32 convolution / GEMM flops of the rollout "
+                                               "forwards and the update's forward, data- and weight-gradient passes; no term pairs, no padding) / "
+                                               f"ms_per_step; the dense f32 MFMA peak is {MFMA_F32_PEAK_TFLOPS} TFLOP/s")
             gus, gn = timer.mean_us("gae")
             lus, ln = timer.mean_us("loss")
             gae_bytes = 20 * T * N + 8 * N
@@ -582,8 +621,12 @@ def main_continuous(cli, rank, world, device):
     learner = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, device, world_size=world,
                          sample_seed=seed)
     learner.observe(0, env.obs(), learner.dones[0])
-    if cli.update_graphs and world == 1:      # (opt-in; the Normal path of capture_update has not run on a GPU yet)
+    update_mode = "eager launches"
+    if cli.update_graphs and world == 1:
         learner.capture_update()
+        update_mode = "one hipGraph per (epoch, minibatch) slot (PPOLearner.capture_update)"
+    elif cli.update_graphs:
+        update_mode = "eager launches (--update-graphs IGNORED: world > 1)"
     timer = KernelTimer()
     if not cli.no_kernel_timing:
         seen = {"n": 0}
@@ -647,7 +690,7 @@ def main_continuous(cli, rank, world, device):
             "config": {"workload": CONFIGS["E"]["workload"] + "; NOT the configuration the metric is quoted on (that is "
                                    "--config C): a parity / coverage workload of BASELINE.json's configs list",
                        "baseline_config": "E", "local_num_envs": N, "num_steps": T, "minibatch_rows": M, "obs_dim": O, "act_dim": D,
-                       "parallelism": f"dp{world}",
+                       "parallelism": f"dp{world}", "update": update_mode,
                        "env": "device-resident linear-system stand-in (torch ops on the learner's stream; no PCIe in the timed region)",
                        "network": "two 64-64 tanh MLPs as torch Linear layers (library GEMMs)"},
             "final_loss": metrics["loss"],

@@ -58,7 +58,16 @@ def _worker(spec, names, n, obs_shape, obs_dtype, act_shape, act_dtype, conn):
     env = getattr(importlib.import_module(mod), attr)(**kwargs)
     segs = _attach(names)
     v = _views(segs, n, obs_shape, obs_dtype, act_shape, act_dtype)
-    takes_out = True
+    import inspect
+
+    def _accepts_out(fn):           # decided once from the signature: a TypeError raised INSIDE a step must surface, not re-step
+        try:
+            ps = inspect.signature(fn).parameters
+        except (TypeError, ValueError):
+            return False
+        return "out" in ps or any(q.kind is inspect.Parameter.VAR_KEYWORD for q in ps.values())
+
+    step_takes_out, reset_takes_out = _accepts_out(env.step), _accepts_out(env.reset)
 
     def publish(obs):
         if obs is not v["obs"]:
@@ -72,22 +81,12 @@ def _worker(spec, names, n, obs_shape, obs_dtype, act_shape, act_dtype, conn):
             if cmd == b"q":
                 break
             if cmd == b"r":
-                try:
-                    res = env.reset(out=v["obs"])
-                except TypeError:
-                    res = env.reset()
+                res = env.reset(out=v["obs"]) if reset_takes_out else env.reset()
                 publish(res[0] if isinstance(res, tuple) else res)
                 conn.send_bytes(b"g" if not isinstance(res, tuple) else b"G")
                 continue
             act = v["act"]
-            if takes_out:
-                try:
-                    res = env.step(act, out=v["obs"])
-                except TypeError:
-                    takes_out = False
-                    res = env.step(act)
-            else:
-                res = env.step(act)
+            res = env.step(act, out=v["obs"]) if step_takes_out else env.step(act)
             publish(res[0])
             v["reward"][:] = res[1]
             v["done"][0] = res[2]

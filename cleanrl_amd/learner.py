@@ -452,7 +452,9 @@ class PPOLearner:
                 ev = torch.cuda.Event()
                 ev.record()
             return PendingMetrics(ev, host[0], host[1], host[2], None, k)
-        return PendingMetrics(None, b_values, b_returns, None, (last, clipfracs), k)
+        pm = PendingMetrics(None, b_values, b_returns, None, (last, clipfracs), k)
+        pm.result()                     # CPU path: resolved at once (the handle holds views of buffers the next rollout overwrites)
+        return pm
 
     def capture_update(self) -> None:
         """Opt-in (``bench.py --update-graphs``).  State at the end of round 3: bit-identical to the eager update over three
@@ -490,6 +492,8 @@ class PPOLearner:
         use_pack = self.discrete and self._loss_slots is not None
         self._pack = (self.ops.batch_pack(b_actions, b_logprobs, b_advantages, b_returns, b_values, out=self._pack_buf)
                       if use_pack else None)
+        if self.image and self.fused_cnn:
+            self.warm_rollout_caches()                                    # the trunk exists and caches its packs behind weights_version
         trunk = getattr(self.agent, "_trunk", None)
 
         def slot(e, j):

@@ -277,7 +277,8 @@ class GroupedRollout:
                     res = envs[g].step_wait()
                     with torch.cuda.stream(lane.stream):
                         lane.store_reward(t, res[1])
-                        lane.observe(t + 1, res[0], res[2], pinned_env=pinned[g] if lane.delta else None)
+                        done = res[2] if len(res) == 4 else np.logical_or(res[2], res[3])      # gymnasium API: terminated | truncated
+                        lane.observe(t + 1, res[0], done, pinned_env=pinned[g] if lane.delta else None)
                         step[g] = t + 1
                         if t + 1 < T:
                             lane.graphs[t + 1].replay()

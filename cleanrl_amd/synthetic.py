@@ -45,3 +45,18 @@ def atari_frames(n: int, seed: int = 1, frame_stacked: bool = False) -> np.ndarr
     planes = rs.randint(0, 256, size=(n + 3, 84, 84), dtype=np.uint8)
     idx = np.arange(n)[:, None] + np.arange(4)[None, :]
     return planes[idx]
+
+
+def continuous_inputs(T: int, N: int, obs_dim: int, seed: int, done_p: float = 1.0 / 1000.0, unit_rewards: bool = False):
+    """Vector-observation stand-in streams for the whole-iteration goldens of configs A / E: ``obs_seq`` (T+1, N, obs_dim)
+    N(0, 1) f32 (0.5 N(0,1) for the CartPole-shaped case), ``step_done`` (T+1, N) Bernoulli(done_p) as f32 with row 0
+    cleared, ``rewards`` (T, N) N(0,1) -- or all ones (CartPole pays 1 per step).  numpy legacy ``RandomState``: the same
+    arrays on any box."""
+    rs = np.random.RandomState(seed)
+    obs_seq = rs.standard_normal((T + 1, N, obs_dim)).astype(np.float32)
+    if unit_rewards:
+        obs_seq *= np.float32(0.5)
+    step_done = (rs.random_sample((T + 1, N)) < done_p).astype(np.float32)
+    step_done[0] = 0.0
+    rewards = np.ones((T, N), np.float32) if unit_rewards else rs.standard_normal((T, N)).astype(np.float32)
+    return obs_seq, step_done, rewards

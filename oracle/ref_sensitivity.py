@@ -1,7 +1,8 @@
 """How far do two runs of the REFERENCE's own lines drift apart over the 16 updates of the config-B iteration when only the f32
 summation order changes?  TEST INFRASTRUCTURE (build container only; needs /root/reference).
 
-    python -m oracle.ref_sensitivity [threads]
+    python -m oracle.ref_sensitivity [threads]            # config B (golden minted with 1 thread)
+    python -m oracle.ref_sensitivity C [threads]          # config C at its full size (golden minted with 8 threads; default here: 4)
 
 Re-executes oracle/mint_goldens.py::mint_atari_iteration_config_b (ppo_atari_envpool.py:217-322, verbatim) with `threads` torch
 CPU threads (default 8; the committed golden was minted with 1: oneDNN / ATen then reduce in another order) and prints, for the
@@ -19,15 +20,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
-    threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     from oracle import mint_goldens as MG
 
-    g = dict(np.load(os.path.join(MG.OUT, "atari_iteration_cfgB.npz")))
-    g = {k.split("/", 1)[1]: v for k, v in g.items()}
-    torch.use_deterministic_algorithms(False)
-    torch.set_num_threads(threads)
-    d = MG.mint_atari_iteration_config_b(save=False)
-    out = {"threads": threads}
+    if len(sys.argv) > 1 and sys.argv[1].upper() == "C":
+        from oracle import mint_full_size as MF
+
+        threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+        g = dict(np.load(os.path.join(MG.OUT, "atari_iteration_cfgC.npz")))
+        g = {k.split("/", 1)[1]: v for k, v in g.items()}
+        torch.use_deterministic_algorithms(False)
+        d = MF.mint_config_c(threads=threads, save=False)
+        out = {"config": "C", "threads": threads, "golden_threads": int(g["torch_threads"])}
+    else:
+        threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+        g = dict(np.load(os.path.join(MG.OUT, "atari_iteration_cfgB.npz")))
+        g = {k.split("/", 1)[1]: v for k, v in g.items()}
+        torch.use_deterministic_algorithms(False)
+        torch.set_num_threads(threads)
+        d = MG.mint_atari_iteration_config_b(save=False)
+        out = {"threads": threads}
     cos = lambda a, b: float(np.dot(a.astype(np.float64), b.astype(np.float64)) / (np.linalg.norm(a.astype(np.float64)) * np.linalg.norm(b.astype(np.float64))))
     out["values_max_abs"] = float(np.abs(d["values"] - g["values"]).max())
     sc_err = np.abs(d["scalars"].astype(np.float64) - g["scalars"].astype(np.float64))

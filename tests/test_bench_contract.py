@@ -74,3 +74,25 @@ def test_config_flag_selects_the_baseline_workloads(monkeypatch):
         raise AssertionError("--same-device without --backend gloo must be refused")
     except SystemExit as e:
         assert e.code == 2
+
+
+def test_roofline_entry_is_a_bound_on_the_executing_pipe():
+    """``roofline.frac`` prices a kernel on the pipe it executes on (round-3 review: the f32-peak pricing read 1.014 for
+    kernel P at config B -- not a bound).  Numbers: the round-3 bench launches (profiles/r03_bench_cfg{B,C}.json)."""
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    conv = lambda cin, cout, k, hout, images: 2.0 * images * hout * hout * cout * cin * k * k          # noqa: E731
+    # config C: layer-2 data gradient on kernel Z, 1,140 us at 32,768 images -> 0.97 of the f32 peak = 0.366 of the bf16 pipe
+    r = bench.roofline_entry("conv2_dgrad@32768", 1140.0, 48, conv(32, 64, 4, 9, 32768), "Z", 0.117, 2.81e9)
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - 0.366) < 0.003 and abs(r["frac_of_f32_mfma_peak"] - 0.970) < 0.005 and r["frac"] == r["achieved"] / r["peak"]
+    # config B: layer-1 weight gradient on kernel P (three products per f32 product), 168 us at 4,096 images: 1.014 of the f32 peak
+    r = bench.roofline_entry("conv1_wgrad@4096", 168.0, 48, conv(4, 32, 8, 20, 4096), "P", 0.07, None)
+    assert r["frac_of_f32_mfma_peak"] > 1.0 and r["frac"] < 0.25 and r["mfma_products_per_f32_product"] == 3
+    # an f32-pipe kernel is priced against the f32 peak, kernel Q against HBM
+    r = bench.roofline_entry("conv2_fwd@32768", 1290.0, 48, conv(32, 64, 4, 9, 32768), "F", 0.1, None)
+    assert r["peak"] == 157.3 and 0.8 < r["frac"] < 0.9
+    r = bench.roofline_entry("conv1_fwd@32768", 616.0, 48, conv(4, 32, 8, 20, 32768), "Q", 0.06, None)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.5 < r["frac"] < 0.56
+    # whole-iteration flops at config C: ~28.4 TFLOP (round-3 review's figure)
+    assert abs(bench.iteration_flops(1024, 128, 32768, 4, 4) / 1e12 - 28.4) < 0.4

@@ -258,6 +258,24 @@ def test_config_b_whole_iteration_teacher_forced_all_16_updates():
     L.flat.check_views()
 
 
+def test_config_c_whole_iteration_teacher_forced_all_16_updates():
+    """BASELINE configs[2] -- the configuration the metric is quoted on -- at its full size: 1024 envs x 128 steps, 4 epochs x 4
+    minibatches = 16 updates of 32,768 rows, against one whole iteration of cleanrl/ppo_atari.py's own lines :234-311
+    (tests/golden/atari_iteration_cfgC.npz from oracle/mint_full_size.py; the reference's sampled actions forced, the 3.7 GB
+    of frames regenerated from the seed on both sides).  Every rollout value, the GAE output, the seven scalars of ALL 16
+    minibatches, the pre-Adam gradient at updates 1 / 8 / 16, the parameters after update 16.  Bars: config B's (update 1: same
+    parameters on both sides; updates 8 / 16: multiples of the reference's own distance from itself under another summation
+    order, tests/golden/atari_iteration_cfgC_ref_sensitivity.json).  Strict."""
+    from whole_iteration import check_atari_iteration, run_atari_iteration
+
+    g = load_golden("atari_iteration_cfgC")["atari_T128_N1024"]
+    assert g["rewards"].shape == (128, 1024)
+    out = run_atari_iteration(g, DEV)
+    bars = {1: (1e-3, 1e-5, 1e-3, 2e-3), 8: (1e-3, 1e-5, 1e-3, 5e-3), 16: (2e-3, 5e-5, 1e-3, 1.2e-2)}
+    problems = check_atari_iteration(out, g, bars)
+    assert not problems, "\n".join(problems)
+
+
 def test_dp_step_matches_reference_collective_block_golden():
     """ppo_atari_multigpu.py:320-377 for world_size=2 (golden from the reference's lines): rank-1 gradient is
     summed into the flat buffer exactly where the RCCL all-reduce acts, then the fused /world -> clip -> Adam."""
@@ -758,16 +776,17 @@ def test_continuous_hip_path_teacher_forced_against_reference_iteration():
     L.flat.check_views()
 
 
-def test_captured_update_slots_are_bit_identical_to_the_eager_update():
-    """capture_update: one hipGraph per (epoch, minibatch) slot (forward + fused loss + backward), optimizer step eager.  Three
-    iterations against the eager learner from the same seeds: parameters, Adam state and logged scalars bit-equal."""
-    N, T = 32, 8
+@pytest.mark.parametrize("N,T,nmb,epochs", [(32, 8, 2, 2), (128, 128, 4, 4)])
+def test_captured_update_slots_are_bit_identical_to_the_eager_update(N, T, nmb, epochs):
+    """capture_update: one hipGraph per (epoch, minibatch) slot (forward + fused loss + backward + the optimizer step).  Three
+    iterations against the eager learner from the same seeds: parameters, Adam state and logged scalars bit-equal -- at a small
+    shape and at BASELINE config B's (128 envs x 128 steps, 16 slots of 4,096 rows)."""
 
     def make(graphs):
         torch.manual_seed(4)
         env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=6, done_p=0.1)
         agent = AtariAgent(env).to(DEV)
-        args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=2)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=nmb, update_epochs=epochs)
         L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
         L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
         if graphs:
@@ -789,9 +808,6 @@ def test_captured_update_slots_are_bit_identical_to_the_eager_update():
         assert me == mg or all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
 
 
-@pytest.mark.skipif(os.environ.get("MI355PPO_TEST_UPDATE_GRAPHS_CONTINUOUS") != "1",
-                    reason="capture_update on the Normal path was written after the round's GPU minutes were spent: not run on a GPU yet "
-                           "(set MI355PPO_TEST_UPDATE_GRAPHS_CONTINUOUS=1)")
 def test_captured_update_slots_continuous_path():
     """capture_update on the continuous-action path (torch MLP + fused Normal loss + the shared actor_logstd's column sum) against
     the eager update: parameters, Adam state and scalars bit-equal over three iterations."""

@@ -65,6 +65,31 @@ def test_two_ranks_execute_the_collective_block_against_the_reference_golden(tmp
     assert close.mean() > 0.99, f"only {close.mean():.4f} of sampled parameters match the reference update"
 
 
+def test_config_d_whole_iteration_two_ranks_against_the_reference_lines(tmp_path):
+    """BASELINE configs[3] at its per-GPU size with world = 2: each rank's 256 envs x 128 steps, 16 updates of 8,192 local rows
+    with the flat gradient SUM-all-reduced across the two processes and divided by the world size in the fused clip + Adam
+    kernel, against one whole iteration of ppo_atari_multigpu.py's own lines :287-377 executed by two reference ranks
+    (tests/golden/atari_iteration_cfgD.npz, oracle/mint_full_size.py).  Checked per rank: rollout values, GAE, the scalars of
+    all 16 local minibatches, the averaged + clipped gradient at updates 1 / 8 / 16, the parameters after update 16; and the
+    replicas stay bit-identical.  Bars as config B's test (the later updates' bars are multiples of the reference's distance
+    from itself under another summation order)."""
+    from whole_iteration import check_atari_iteration
+
+    _torchrun([os.path.join("tests", "dp_cfgd_worker.py"), str(tmp_path)], timeout=1500)
+    g = load_golden("atari_iteration_cfgD")["atari_T128_N256_world2"]
+    outs = [dict(np.load(tmp_path / f"rank{r}.npz")) for r in (0, 1)]
+    assert outs[0]["params_checksum"] == outs[1]["params_checksum"] and np.array_equal(outs[0]["final_params_sub"], outs[1]["final_params_sub"]), \
+        "the replicas diverged"
+    for k in (1, 8, 16):
+        assert np.array_equal(outs[0][f"grad{k}_sub"], outs[1][f"grad{k}_sub"]), f"all-reduced gradients differ between the ranks at update {k}"
+    bars = {1: (1e-3, 1e-5, 1e-3, 2e-3), 8: (1e-3, 1e-5, 1e-3, 5e-3), 16: (2e-3, 5e-5, 1e-3, 1.2e-2)}
+    problems = []
+    for r in (0, 1):
+        o = {k: (v.item() if v.ndim == 0 else v) for k, v in outs[r].items()}
+        problems += [f"rank {r}: {p}" for p in check_atari_iteration(o, g, bars, sfx=f"_rank{r}")]
+    assert not problems, "\n".join(problems)
+
+
 def test_ppo_atari_multigpu_script_two_ranks_on_one_gpu():
     """The drop-in script itself, ``--cuda`` on, both ranks on device 0 (``--device-ids 0 0``), backend gloo: replicas print
     the same actor weight sum after every update while sampling different actions (per-rank seeds)."""
