@@ -142,9 +142,12 @@ def parse():
                         "boundary costs ~8 us of GPU idle; 1 = a graph per step)")
     p.add_argument("--no-pcie-inclusive", action="store_true", help="skip the host-env (PCIe-inclusive) leg after the timed region")
     p.add_argument("--pcie-env-groups", type=int, default=4)
-    p.add_argument("--update-graphs", action="store_true",
-                   help="one hipGraph per (epoch, minibatch) slot of the update (PPOLearner.capture_update; bit-identical to the eager "
-                        "update in the GPU tests, not yet measured at the BASELINE configurations: opt-in); single GPU only")
+    p.add_argument("--update-graphs", action="store_true", help="(the default on one GPU; kept for old command lines)")
+    p.add_argument("--no-update-graphs", action="store_true",
+                   help="issue the update launch by launch instead of replaying one hipGraph per (epoch, minibatch) slot (forward + fused "
+                        "loss + backward + clip + Adam; PPOLearner.capture_update, bit-identical to the eager update in the GPU tests; "
+                        "profiles/r04_update_graphs_ab.jsonl).  With graphs the per-launch event brackets of `roofline` / `kernels` come "
+                        "from ONE extra eager iteration right after the timed region (a replay runs no Python to put events around)")
     p.add_argument("--sync-metrics", action="store_true",
                    help="read every iteration's diagnostics before the next one starts (the reference's arrangement: one device "
                         "synchronisation per iteration); default: resolve them one iteration late, so that the host runs ahead "
@@ -316,20 +319,22 @@ def main():
     if learner.fused_cnn and not cli.no_rollout_graphs:
         learner.capture_rollout(env, steps_per_graph=cli.rollout_steps_per_graph or T)      # (before the timing hooks: no event records in a capture)
     update_mode = "eager launches"
-    if cli.update_graphs and learner.fused_cnn and world == 1:
+    use_update_graphs = not cli.no_update_graphs and learner.fused_cnn and world == 1
+    if use_update_graphs:
         learner.capture_update()            # (before the timing hooks: no event records in a capture)
-        cli.no_kernel_timing = True         # replays run no Python: the per-launch event brackets would stay empty (pure SPS line)
-        update_mode = "one hipGraph per (epoch, minibatch) slot: forward + fused loss + backward (PPOLearner.capture_update)"
-    elif cli.update_graphs:
-        update_mode = "eager launches (--update-graphs IGNORED: world > 1 or the CNN is not on the fused kernels)"
+        update_mode = ("one hipGraph per (epoch, minibatch) slot: forward + fused loss + backward + clip + Adam (PPOLearner.capture_update); "
+                       "per-launch event brackets from one extra eager iteration after the timed region")
+    elif not cli.no_update_graphs:
+        update_mode = "eager launches (update graphs need one GPU and the fused CNN kernels: world > 1 or MI355PPO_CNN=miopen)"
     timer = KernelTimer()
     conv_flops = {}      # key "<op>@<rows>" -> algorithmic flops of one launch (the f32 convolution / GEMM: 2 x M x N x K)
     kernel_of = {}       # key -> letter in KERNEL_INFO
     unhook = []          # (module, name, original) of everything the kernel timing wraps
-    if not cli.no_kernel_timing:
+
+    def install_timing_hooks():
         real_obs, real_gae, real_loss, real_loss_p = ops.obs_u8_to_f32, ops.gae, ops.ppo_loss_categorical, ops.ppo_loss_categorical_packed
-        unhook += [(ops, "obs_u8_to_f32", real_obs), (ops, "gae", real_gae), (ops, "ppo_loss_categorical", real_loss),
-                   (ops, "ppo_loss_categorical_packed", real_loss_p)]
+        unhook.extend([(ops, "obs_u8_to_f32", real_obs), (ops, "gae", real_gae), (ops, "ppo_loss_categorical", real_loss),
+                       (ops, "ppo_loss_categorical_packed", real_loss_p)])
         if learner.fused_cnn:
             from cleanrl_amd import cnn
 
@@ -388,6 +393,9 @@ def main():
         ops.gae = timer.wrap("gae", real_gae)
         ops.ppo_loss_categorical = timer.wrap("loss", real_loss)
         ops.ppo_loss_categorical_packed = timer.wrap("loss", real_loss_p)      # the learner's call: packed behaviour rows
+
+    if not cli.no_kernel_timing and not use_update_graphs:
+        install_timing_hooks()
     total_iters = cli.warmup + cli.steps
 
     phase_events = []
@@ -442,6 +450,17 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    timing_iters = cli.steps
+    if not cli.no_kernel_timing and use_update_graphs:
+        # the per-launch durations: one more iteration issued launch by launch with event brackets (outside the timed region; the
+        # same kernels on the same buffers as the replayed slots)
+        graphs, learner._update_graphs = learner._update_graphs, None
+        install_timing_hooks()
+        timer.reset()
+        cli.sync_metrics, saved_sync = True, cli.sync_metrics
+        one_step(total_iters - 1)
+        torch.cuda.synchronize()
+        cli.sync_metrics, learner._update_graphs, timing_iters = saved_sync, graphs, 1
     learner.flat.check_views()
     assert np.isfinite(metrics["loss"]), metrics
 
@@ -482,7 +501,7 @@ def main():
             },
             "final_loss": metrics["loss"],
         }
-        timed = phase_events[-cli.steps:]
+        timed = phase_events[cli.warmup:cli.warmup + cli.steps]
         out["phases_ms"] = {"rollout_incl_gae": float(np.mean([e[0].elapsed_time(e[1]) for e in timed])),
                             "update": float(np.mean([e[1].elapsed_time(e[2]) for e in timed])),
                             "note": "GPU-timeline split of ms_per_step (events on the learner's stream)"}
@@ -492,7 +511,8 @@ def main():
                    if timer.mean_us(k)[1] > 0}          # (rollout-sized launches inside captured graphs carry no event brackets)
             dom = max(tot, key=tot.get)
             us, n = timer.mean_us(dom)
-            out["roofline"] = roofline_entry(dom, us, n, conv_flops[dom], kernel_of[dom], tot[dom] / (elapsed * 1e6), _traffic_of(dom))
+            out["roofline"] = roofline_entry(dom, us, n, conv_flops[dom], kernel_of[dom], tot[dom] / timing_iters / (elapsed / cli.steps * 1e6),
+                                             _traffic_of(dom))
             # north_star's HBM figure: the one HBM-bound launch of the conv stack (kernel Q: uint8 rows in, f32 activations out)
             qk = f"conv1_fwd@{M}"
             if kernel_of.get(qk) == "Q" and timer.mean_us(qk)[1]:
@@ -524,7 +544,7 @@ def main():
                 out["kernels"][k] = {"kernel": kernel_of[k], "pipe": pipe, "avg_us": kus, "launches_timed": kn,
                                      "TFLOPs": conv_flops[k] / kus / 1e6,
                                      "frac_of_f32_mfma_peak": conv_flops[k] / kus / 1e6 / MFMA_F32_PEAK_TFLOPS,
-                                     "ms_per_step": kus * launches / cli.steps / 1e3,
+                                     "ms_per_step": kus * launches / timing_iters / 1e3,
                                      "hbm_bytes_per_launch_pmc": _traffic_of(k)}
                 if pipe == "bf16":
                     out["kernels"][k]["frac_of_bf16_mfma_peak_executed"] = conv_flops[k] * products / kus / 1e6 / MFMA_BF16_PEAK_TFLOPS
@@ -598,11 +618,22 @@ def main():
         dist.destroy_process_group()
 
 
+def mlp_flops_per_row(O, D):
+    """Algorithmic f32 flops of the two 64-64 tanh MLPs (actor with D outputs, critic) for one minibatch row of the update: forward,
+    weight gradients of every layer, data gradients of layers 2 and 3."""
+    fwd = lambda n: 2.0 * (O * 64 + 64 * 64 + 64 * n)          # noqa: E731
+    dgrad = lambda n: 2.0 * (64 * 64 + 64 * n)                 # noqa: E731
+    return sum(2 * fwd(n) + dgrad(n) for n in (D, 1))
+
+
 def main_continuous(cli, rank, world, device):
     """``--config E``: BASELINE configs[4], ppo_continuous_action (HalfCheetah-v4-shaped obs 17 / act 6, 64 envs x 2048 steps,
-    32 minibatches x 10 epochs; ppo_continuous_action.py:54-76 defaults) on the Normal kernels: K2' sample + log_prob per env
-    step, K1 GAE over (2048, 64), K3' fused Normal loss forward + backward per minibatch, K6 clip + Adam.  The 64-64 tanh
-    MLPs are torch Linear layers (library GEMMs: plumbing).  Env = device-resident stand-in (no PCIe in the timed region)."""
+    32 minibatches x 10 epochs; ppo_continuous_action.py:54-76 defaults) on the fused MLP kernel family K7 (csrc/mlp.hip): one
+    launch per env step for both networks' forward + the Normal sample / log-prob, K1 GAE over (2048, 64), two launches per
+    minibatch for gather + forwards + fused Normal loss + both backward passes + weight gradients, K6 clip + Adam.  The rollout
+    replays as captured hipGraphs, the update as one hipGraph per (epoch, minibatch) slot (one GPU).  Env = device-resident
+    stand-in stepped by its own kernel (no PCIe in the timed region).  MI355PPO_MLP=torch: the round-3 arrangement (library GEMMs
+    behind K2' / K3') for A/B."""
     from cleanrl_amd import _lib, learner_smoke, ops
     from cleanrl_amd.agents import ContinuousAgent
     from cleanrl_amd.envs import DeviceSyntheticContinuousVecEnv
@@ -621,25 +652,28 @@ def main_continuous(cli, rank, world, device):
     learner = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, device, world_size=world,
                          sample_seed=seed)
     learner.observe(0, env.obs(), learner.dones[0])
+    fused = learner.mlp is not None
+    rollout_mode = "kernel-by-kernel launches"
+    if fused and not cli.no_rollout_graphs:
+        per = cli.rollout_steps_per_graph or 256          # 2048 steps x 2 launches: eight graphs of 512 kernel nodes
+        learner.capture_rollout(env, steps_per_graph=per)
+        rollout_mode = f"{len(learner._rollout_graphs)} hipGraph(s) of {min(per, T)} env steps each (fused act kernel + env step kernel)"
     update_mode = "eager launches"
-    if cli.update_graphs and world == 1:
+    use_update_graphs = not cli.no_update_graphs and world == 1
+    if use_update_graphs:
         learner.capture_update()
-        update_mode = "one hipGraph per (epoch, minibatch) slot (PPOLearner.capture_update)"
-    elif cli.update_graphs:
-        update_mode = "eager launches (--update-graphs IGNORED: world > 1)"
+        update_mode = ("one hipGraph per (epoch, minibatch) slot: fused MLP forward + loss + backward, fold, clip + Adam "
+                       "(PPOLearner.capture_update); per-launch event brackets from one extra eager iteration after the timed region")
     timer = KernelTimer()
-    if not cli.no_kernel_timing:
-        seen = {"n": 0}
-        real_sample = ops.normal_sample
 
-        def sample_hook(*a, **kw):                    # rollout launches: bracket every 16th (the rollout is host-bound)
-            seen["n"] += 1
-            return real_sample(*a, **kw) if seen["n"] % 16 else timer.wrap("normal_sample", real_sample)(*a, **kw)
-
-        ops.normal_sample = sample_hook
+    def install_timing_hooks():
         ops.gae = timer.wrap("gae", ops.gae)
         ops.ppo_loss_normal = timer.wrap("loss_normal", ops.ppo_loss_normal)
+        ops.mlp_ppo_fwd_bwd = timer.wrap("mlp_ppo", ops.mlp_ppo_fwd_bwd)
         ops.clip_adam_ = timer.wrap("clip_adam", ops.clip_adam_)
+
+    if not cli.no_kernel_timing and not use_update_graphs:
+        install_timing_hooks()
     total_iters = cli.warmup + cli.steps
     phase_events = []
 
@@ -647,14 +681,16 @@ def main_continuous(cli, rank, world, device):
         lr = (1.0 - i / max(total_iters, 1)) * args.learning_rate
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
-        for step in range(T):                                                     # ppo_continuous_action.py:205-228
-            action = learner.act(step)
-            next_obs, reward, done = env.step(action)
-            learner.store_reward(step, reward)
-            learner.observe(step + 1, next_obs, done)
+        if getattr(learner, "_rollout_graphs", None):
+            learner.replay_rollout()
+        else:
+            for step in range(T):                                                 # ppo_continuous_action.py:205-228
+                action = learner.act(step)
+                obs_dst, done_dst = learner._slot(step + 1)
+                env.step_into(action, obs_dst, learner.rewards[step], done_dst)  # next_obs / reward / done straight into their rows
         learner.finish_rollout()
         ev[1].record()
-        m = learner.update(lr)       # (host-bound configuration: the GPU waits for the host, there is nothing to run ahead of)
+        m = learner.update(lr)
         learner.start_iteration()
         ev[2].record()
         phase_events.append(ev)
@@ -678,6 +714,13 @@ def main_continuous(cli, rank, world, device):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    if not cli.no_kernel_timing and use_update_graphs:
+        graphs, learner._update_graphs = learner._update_graphs, None
+        install_timing_hooks()
+        timer.reset()
+        one_step(total_iters - 1)
+        torch.cuda.synchronize()
+        learner._update_graphs = graphs
     learner.flat.check_views()
     assert np.isfinite(metrics["loss"]), metrics
     if rank == 0:
@@ -690,20 +733,21 @@ def main_continuous(cli, rank, world, device):
             "config": {"workload": CONFIGS["E"]["workload"] + "; NOT the configuration the metric is quoted on (that is "
                                    "--config C): a parity / coverage workload of BASELINE.json's configs list",
                        "baseline_config": "E", "local_num_envs": N, "num_steps": T, "minibatch_rows": M, "obs_dim": O, "act_dim": D,
-                       "parallelism": f"dp{world}", "update": update_mode,
-                       "env": "device-resident linear-system stand-in (torch ops on the learner's stream; no PCIe in the timed region)",
-                       "network": "two 64-64 tanh MLPs as torch Linear layers (library GEMMs)"},
+                       "parallelism": f"dp{world}", "rollout": rollout_mode, "update": update_mode,
+                       "env": "device-resident linear-system stand-in, one kernel per step (no PCIe in the timed region)",
+                       "network": "two 64-64 tanh MLPs on the fused MLP kernel family K7 (csrc/mlp.hip: f32 v_fma, lane = hidden unit, "
+                                  "activations broadcast through wave-private LDS)" if fused
+                                  else "two 64-64 tanh MLPs as torch Linear layers (library GEMMs; MI355PPO_MLP=torch)"},
             "final_loss": metrics["loss"],
         }
-        timed = phase_events[-cli.steps:]
+        timed = phase_events[cli.warmup:cli.warmup + cli.steps]
         out["phases_ms"] = {"rollout_incl_gae": float(np.mean([e[0].elapsed_time(e[1]) for e in timed])),
                             "update": float(np.mean([e[1].elapsed_time(e[2]) for e in timed])),
-                            "note": "GPU-timeline split; with ~25 launches per env step and ~45 per minibatch of <= 10 us each, both "
-                                    "phases are bound by host launch issue, not by any kernel"}
+                            "note": "GPU-timeline split of ms_per_step (events on the learner's stream)"}
         if not cli.no_kernel_timing:
             alg = {"gae": 20 * T * N + 8 * N,
                    "loss_normal": (12 * D + 28 + 8) * M,                           # mean, action in; dmean out; 5 behaviour scalars, new value; dvalue; indices
-                   "normal_sample": (4 * D + 4 * D + 4 + 4) * N,                   # mean in; action, logprob out (+ entropy)
+                   "mlp_ppo": (4 * O + 4 * D + 16 + 8) * M + 2 * 4 * learner.flat.numel,   # obs row, action row, 4 behaviour scalars, index; parameters in, gradients out
                    "clip_adam": 36 * learner.flat.numel}
             ks = {}
             for k, b in alg.items():
@@ -712,8 +756,21 @@ def main_continuous(cli, rank, world, device):
                     ks[k] = {"algorithmic_bytes": b, "avg_us_event_bracket": us, "GBps": b / us / 1e3, "launches_timed": n,
                              "frac_of_hbm_peak": b / us / 1e3 / HBM_PEAK_GBPS}
             out["kernels"] = ks
-            dom = "loss_normal"
-            if dom in ks:
+            if "mlp_ppo" in ks:
+                fl = mlp_flops_per_row(O, D) * M
+                us = ks["mlp_ppo"]["avg_us_event_bracket"]
+                ks["mlp_ppo"].update({"algorithmic_flops": fl, "TFLOPs": fl / us / 1e6})
+                out["roofline"] = {
+                    "kernel": f"mlp_ppo_kernel + mlp_fold_kernel (K7, csrc/mlp.hip): one minibatch of {M} rows -- gather, both MLPs' forward, Normal "
+                              "log-prob, PPO loss row terms, both backward passes, weight gradients (two launches, bracketed together)",
+                    "bound": "mfma", "achieved": fl / us / 1e6, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / us / 1e6 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "pipe": "f32 VALU (v_fma_f32; the f32 vector peak equals the "
+                    "dense f32 MFMA peak, 157.3 TFLOP/s)", "algorithmic_flops_per_launch": fl, "avg_launch_us": us,
+                    "launches_timed": ks["mlp_ppo"]["launches_timed"],
+                    "note": f"{fl / 1e6:.0f} MFLOP and {alg['mlp_ppo']} algorithmic bytes per minibatch: 1.6 us at the f32 peak -- the launch pair is "
+                            "bound by latency (event brackets include the launch gaps), not by a pipe or by HBM"}
+            elif "loss_normal" in ks:
+                dom = "loss_normal"
                 out["roofline"] = {
                     "kernel": "loss_normal_main (K3', csrc/loss.hip): fused Normal log_prob + entropy + clipped surrogate + value loss, "
                               f"forward + backward, one minibatch of {M} rows x {D} action dims",

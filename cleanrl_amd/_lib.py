@@ -82,6 +82,22 @@ SIGNATURES = {
     "mi355ppo_fc_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mi355ppo_fc_wgrad_kernel": (c_int, [c_int, c_int, c_int]),
     "mi355ppo_fc_wgrad_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "mi355ppo_adam_schedule_f32": (c_int, [c_double, c_double, c_double, c_int64, _P]),
+    "mi355ppo_clip_adam_sched_f32": (
+        c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, _P, _P, _P, c_size_t, _P]),
+    # K7: the fused MLP family (csrc/mlp.hip); a network = host array of six device pointers
+    "mi355ppo_mlp_fwd_f32": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
+    "mi355ppo_mlp_act_categorical_f32": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mi355ppo_mlp_act_normal_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P]),
+    "mi355ppo_mlp_ppo_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mi355ppo_mlp_ppo_categorical_fwd_bwd_f32": (
+        c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, c_double, c_double, c_double, c_int, c_int, _P, _P, _P, _P, c_int,
+                _P, c_size_t, _P]),
+    "mi355ppo_mlp_ppo_normal_fwd_bwd_f32": (
+        c_int, [_P, _P, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_double, c_double, c_double, c_int, c_int, _P, _P, _P, _P,
+                _P, c_int, _P, c_size_t, _P]),
+    "mi355ppo_synth_continuous_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_uint64, _P, _P, c_double, _P, _P, _P, _P, c_int, c_int,
+                                                   c_int, _P]),
     # host-pointer twins (csrc/host_twins.hip): the device signatures minus stream / workspace
     "mi355ppo_gae_f32_cpu": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double]),
     "mi355ppo_categorical_sample_f32_cpu": (c_int, [_P, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_int]),
@@ -99,7 +115,7 @@ SIGNATURES = {
     "mi355ppo_obs_u8_to_f32_cpu": (c_int, [_P, _P, _P, c_int64, c_int64, c_int]),
 }
 
-ABI_VERSION = 150       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 160       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

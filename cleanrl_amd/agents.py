@@ -46,6 +46,38 @@ class _SampleCounter:
         return first
 
 
+def fused_mlp_ptrs(agent):
+    """``(actor MlpNetPtrs, critic MlpNetPtrs)`` of an agent whose two networks the fused MLP kernels cover (64-64 tanh,
+    obs_dim <= 32, n_out <= 8, f32 on a HIP device), else None.  Rebuilt when the parameters moved (``.to()``, flat buffers)."""
+    import os
+
+    if os.environ.get("MI355PPO_MLP", "fused") == "torch":       # A/B: keep the networks on library GEMMs
+        return None
+    actor, critic = agent.mlp_nets()
+    w = actor[0].weight
+    if not w.is_cuda or w.dtype != torch.float32:
+        return None
+    key = tuple(p.data_ptr() for p in list(actor.parameters()) + list(critic.parameters()))
+    if agent._fused is None or agent._fused[0] != key:
+        try:
+            a, c = ops.MlpNetPtrs(actor), ops.MlpNetPtrs(critic)
+        except AssertionError:
+            agent._fused = (key, None)
+            return None
+        ok = ops.mlp_supported(a.obs_dim, a.n_out) and c.n_out == 1 and c.obs_dim == a.obs_dim
+        agent._fused = (key, (a, c) if ok else None)
+    return agent._fused[1]
+
+
+def _fused_mlp(agent, x):
+    """The fused forward applies when no autograd graph is being recorded (rollout, bootstrap value) on a HIP device."""
+    if not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32:
+        return None
+    if torch.is_grad_enabled() and any(p.requires_grad for p in agent.parameters()):
+        return None
+    return fused_mlp_ptrs(agent)
+
+
 class _DiscreteMixin:
     discrete = True
 
@@ -145,14 +177,31 @@ class MlpAgent(_DiscreteMixin, nn.Module):
         )
         self.n_actions = envs.single_action_space.n
         self.rng = _SampleCounter()
+        self._fused = None
+
+    def mlp_nets(self):
+        """(actor, critic) ``nn.Sequential`` pair: the seam of the fused MLP kernels (csrc/mlp.hip)."""
+        return self.actor, self.critic
 
     def heads(self, x):
+        f = _fused_mlp(self, x)
+        if f is not None:                      # no autograd graph wanted: both networks in one launch
+            logits, value = ops.mlp_forward(x.contiguous(), *f)
+            return logits, value.unsqueeze(1)
         return self.actor(x), self.critic(x)
 
     def get_value(self, x):
+        f = _fused_mlp(self, x)
+        if f is not None:
+            return ops.mlp_forward(x.contiguous(), *f)[1].unsqueeze(1)
         return self.critic(x)
 
     def get_action_and_value(self, x, action=None):
+        f = _fused_mlp(self, x) if action is None else None
+        if f is not None:                      # rollout step: forwards + sample + log_prob + entropy in one launch
+            seed, off = self.rng.next()
+            a64, _, lp, ent, value, _ = ops.mlp_act_categorical(x.contiguous(), *f, seed=seed, offset=off, want_entropy=True)
+            return a64, lp, ent, value.unsqueeze(1)
         logits, value = self.heads(x)
         action, lp, ent = self._dist(logits, action)
         return action, lp, ent, value
@@ -184,11 +233,23 @@ class ContinuousAgent(nn.Module):
         self.actor_logstd = nn.Parameter(torch.zeros(1, act_dim))
         self.act_dim = act_dim
         self.rng = _SampleCounter()
+        self._fused = None
+
+    def mlp_nets(self):
+        """(actor_mean, critic) ``nn.Sequential`` pair: the seam of the fused MLP kernels (csrc/mlp.hip)."""
+        return self.actor_mean, self.critic
 
     def heads(self, x):
+        f = _fused_mlp(self, x)
+        if f is not None:
+            mean, value = ops.mlp_forward(x.contiguous(), *f)
+            return mean, value.unsqueeze(1)
         return self.actor_mean(x), self.critic(x)
 
     def get_value(self, x):
+        f = _fused_mlp(self, x)
+        if f is not None:
+            return ops.mlp_forward(x.contiguous(), *f)[1].unsqueeze(1)
         return self.critic(x)
 
     def perturb_mean(self, mean):
@@ -198,6 +259,12 @@ class ContinuousAgent(nn.Module):
         return mean + torch.empty_like(mean).uniform_(-self.rpo_alpha, self.rpo_alpha)
 
     def get_action_and_value(self, x, action=None):
+        f = _fused_mlp(self, x) if action is None else None
+        if f is not None:                      # rollout step: forwards + sample + log_prob + entropy in one launch
+            seed, off = self.rng.next()
+            act, lp, ent, value, _ = ops.mlp_act_normal(x.contiguous(), *f, self.actor_logstd.detach(), seed=seed, offset=off,
+                                                        want_entropy=True)
+            return act, lp, ent, value.unsqueeze(1)
         mean, value = self.heads(x)
         if action is not None:
             mean = self.perturb_mean(mean)

@@ -41,8 +41,12 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                         AdamParams A, const double* __restrict__ partials,
-                                                        float* __restrict__ total_norm_out) {
+                                                        float* __restrict__ total_norm_out, const float* __restrict__ sched2) {
     __shared__ float s_coef;
+    if (sched2) {                  // the step's two schedule-dependent constants live in device memory (captured launches)
+        A.neg_step = sched2[0];
+        A.bc2_sqrt = sched2[1];
+    }
     if (threadIdx.x < 64) {
         double s = 0.0;
         for (int b = threadIdx.x; b < A.nblocks; b += 64) s += partials[b];
@@ -85,11 +89,20 @@ extern "C" MI355PPO_API size_t mi355ppo_clip_adam_workspace_bytes(int64_t n) {
     return (size_t)kNormMaxBlocks * sizeof(double);
 }
 
-extern "C" MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                      double grad_scale, double max_grad_norm, double lr, double beta1, double beta2,
-                                      double eps, int64_t step, float* total_norm_out, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
-    const char* fn = "mi355ppo_clip_adam_f32";
+// The two constants of an Adam step that depend on the schedule (learning rate, step count), as the kernel consumes them:
+// out2 = {(float)(-(lr / (1 - beta1^step))), (float)sqrt(1 - beta2^step)} (torch adam.py: step_size, bias_correction2_sqrt).
+extern "C" MI355PPO_API int mi355ppo_adam_schedule_f32(double lr, double beta1, double beta2, int64_t step, float* out2_host) {
+    MI355_REQUIRE(out2_host && step >= 1, MI355PPO_EINVAL, "mi355ppo_adam_schedule_f32: null pointer or step=%lld < 1", (long long)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    out2_host[0] = (float)(-(lr / bc1));
+    out2_host[1] = (float)sqrt(bc2);
+    return MI355PPO_OK;
+}
+
+static int clip_adam_impl(const char* fn, float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double grad_scale,
+                          double max_grad_norm, double lr, double beta1, double beta2, double eps, int64_t step, const float* sched2,
+                          float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream) {
     MI355_REQUIRE(params && grads && exp_avg && exp_avg_sq, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(n > 0 && step >= 1, MI355PPO_EINVAL, "%s: n=%lld must be >0 and step=%lld >= 1", fn, (long long)n,
                   (long long)step);
@@ -97,7 +110,7 @@ extern "C" MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, 
                   "%s: workspace %zu bytes < required %zu", fn, workspace ? workspace_bytes : (size_t)0,
                   (size_t)kNormMaxBlocks * sizeof(double));
     MI355_REQUIRE(aligned(params, 16) && aligned(grads, 16) && aligned(exp_avg, 16) && aligned(exp_avg_sq, 16) &&
-                      aligned(workspace, 8) && aligned(total_norm_out, 4),
+                      aligned(workspace, 8) && aligned(total_norm_out, 4) && aligned(sched2, 4),
                   MI355PPO_EALIGN, "%s: flat buffers must be 16-byte aligned", fn);
     hipStream_t s = as_stream(stream);
     const int64_t n4 = (n + 3) / 4;
@@ -113,16 +126,36 @@ extern "C" MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, 
     A.w1 = (float)(1.0 - beta1);
     A.beta2 = (float)beta2;
     A.w2 = (float)(1.0 - beta2);
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    A.bc2_sqrt = (float)sqrt(bc2);
+    float sc[2];
+    mi355ppo_adam_schedule_f32(lr, beta1, beta2, step, sc);
+    A.neg_step = sc[0];
+    A.bc2_sqrt = sc[1];
     A.eps = (float)eps;
-    A.neg_step = (float)(-(lr / bc1));
     A.nblocks = (int)blocks;
     A.zero_grads = 1;
     int64_t ublocks = (n4 + 255) / 256;
     if (ublocks > 2048) ublocks = 2048;
     hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)ublocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n,
-                       A, partials, total_norm_out);
+                       A, partials, total_norm_out, sched2);
     return check_launch("clip_adam_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                      double grad_scale, double max_grad_norm, double lr, double beta1, double beta2,
+                                      double eps, int64_t step, float* total_norm_out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    return clip_adam_impl("mi355ppo_clip_adam_f32", params, grads, exp_avg, exp_avg_sq, n, grad_scale, max_grad_norm, lr, beta1, beta2, eps,
+                          step, nullptr, total_norm_out, workspace, workspace_bytes, stream);
+}
+
+// The same step with its two schedule-dependent constants read from DEVICE memory (`sched2` = what mi355ppo_adam_schedule_f32
+// writes, copied to the device by the caller): a launch captured into a hipGraph is replayed with the next step's learning
+// rate and bias corrections without re-capturing.  Bit-identical to mi355ppo_clip_adam_f32 for the same (lr, step).
+extern "C" MI355PPO_API int mi355ppo_clip_adam_sched_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                                        double grad_scale, double max_grad_norm, double beta1, double beta2, double eps,
+                                                        const float* sched2, float* total_norm_out, void* workspace,
+                                                        size_t workspace_bytes, void* stream) {
+    MI355_REQUIRE(sched2, MI355PPO_EINVAL, "mi355ppo_clip_adam_sched_f32: null pointer");
+    return clip_adam_impl("mi355ppo_clip_adam_sched_f32", params, grads, exp_avg, exp_avg_sq, n, grad_scale, max_grad_norm, 0.0, beta1, beta2,
+                          eps, 1, sched2, total_norm_out, workspace, workspace_bytes, stream);
 }

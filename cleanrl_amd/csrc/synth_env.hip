@@ -33,9 +33,70 @@ __global__ __launch_bounds__(256) void synth_env_frames_kernel(const uint8_t* __
     for (int e = threadIdx.x; e < 441; e += 256) d[e] = s[e];
 }
 
+// ---- the continuous-control stand-in (cleanrl_amd/envs.py::DeviceSyntheticContinuousVecEnv, bench.py --config E) --------------------
+// a = clip(action, -1, 1); next = noise[k % bank][n] + state[n] @ At + a @ Bm; reward = next . w - 0.1 |a|^2; 1000-step truncation;
+// the state row is the observation.  As torch ops this was ~12 launches per env step.  Thread (env, j) of a half-wave computes
+// element j of its env's next state (O <= 32 lanes of the half-wave active); the reward is a half-wave reduction.
+__global__ __launch_bounds__(256) void synth_continuous_step_kernel(float* __restrict__ state, const float* __restrict__ reset_state,
+                                                                    const float* __restrict__ At, const float* __restrict__ Bm,
+                                                                    const float* __restrict__ w, const float* __restrict__ noise, int bank,
+                                                                    uint64_t k, const uint64_t* __restrict__ k_base, float* __restrict__ steps,
+                                                                    float horizon, const float* __restrict__ action, float* __restrict__ obs_out,
+                                                                    float* __restrict__ reward, float* __restrict__ done, int N, int O, int D) {
+    const int j = threadIdx.x & 31;
+    const int n = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (n >= N) return;                                   // (whole half-waves leave together)
+    if (k_base) k += *k_base;
+    const bool act = j < O;
+    const int jc = act ? j : 0;
+    float v = noise[((size_t)(k % (uint64_t)bank) * N + n) * O + jc];
+    for (int i = 0; i < O; ++i) v = fmaf(state[(size_t)n * O + i], At[i * O + jc], v);
+    float a2 = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float a = fminf(fmaxf(action[(size_t)n * D + d], -1.0f), 1.0f);
+        v = fmaf(a, Bm[d * O + jc], v);
+        a2 = fmaf(a, a, a2);
+    }
+    float r = act ? v * w[jc] : 0.0f;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) r += __shfl_xor(r, off, 32);
+    const float t = steps[n] + 1.0f;
+    const bool dn = t >= horizon;
+    const float nx = dn ? reset_state[(size_t)n * O + jc] : v;
+    // every lane of the half-wave has read its inputs (the state row above all) before any lane overwrites the row
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+        state[(size_t)n * O + j] = nx;
+        if (obs_out != state) obs_out[(size_t)n * O + j] = nx;
+    }
+    if (j == 0) {
+        reward[n] = r - 0.1f * a2;
+        done[n] = dn ? 1.0f : 0.0f;
+        steps[n] = dn ? 0.0f : t;
+    }
+}
+
 }  // namespace mi355ppo
 
 using namespace mi355ppo;
+
+extern "C" MI355PPO_API int mi355ppo_synth_continuous_step_f32(float* state, const float* reset_state, const float* At, const float* Bm,
+                                                              const float* w, const float* noise, int bank, uint64_t k,
+                                                              const uint64_t* k_base, float* steps, double horizon, const float* action,
+                                                              float* obs_out, float* reward, float* done, int N, int O, int D,
+                                                              void* stream) {
+    const char* fn = "mi355ppo_synth_continuous_step_f32";
+    MI355_REQUIRE(state && reset_state && At && Bm && w && noise && steps && action && obs_out && reward && done, MI355PPO_EINVAL,
+                  "%s: null pointer", fn);
+    MI355_REQUIRE(N > 0 && bank > 0 && O > 0 && O <= 32 && D > 0 && D <= 8, MI355PPO_EINVAL, "%s: N=%d bank=%d O=%d (1..32) D=%d (1..8)", fn, N,
+                  bank, O, D);
+    MI355_REQUIRE(aligned(state, 4) && aligned(reset_state, 4) && aligned(At, 4) && aligned(Bm, 4) && aligned(w, 4) && aligned(noise, 4) &&
+                      aligned(k_base, 8) && aligned(steps, 4) && aligned(action, 4) && aligned(obs_out, 4) && aligned(reward, 4) && aligned(done, 4),
+                  MI355PPO_EALIGN, "%s: misaligned pointer", fn);
+    hipLaunchKernelGGL(synth_continuous_step_kernel, dim3((N + 7) / 8), dim3(256), 0, as_stream(stream), state, reset_state, At, Bm, w,
+                       noise, bank, k, k_base, steps, (float)horizon, action, obs_out, reward, done, N, O, D);
+    return check_launch(fn);
+}
 
 extern "C" MI355PPO_API int mi355ppo_synth_atari_step_ctr_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed,
                                                              uint64_t step, const uint64_t* step_base, uint8_t* obs, float* reward,

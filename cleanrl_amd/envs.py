@@ -296,45 +296,57 @@ class DeviceSyntheticAtariVecEnv:
 
 
 class DeviceSyntheticContinuousVecEnv:
-    """``SyntheticContinuousVecEnv`` (HalfCheetah-v4-shaped: obs 17, act 6) stepped in HBM with a handful of torch ops on
-    the learner's stream, for ``bench.py --config E``: observations, rewards and dones are device tensors, so the timed
-    region holds no PCIe traffic.  A stand-in env (plumbing), not part of the hot path."""
+    """``SyntheticContinuousVecEnv`` (HalfCheetah-v4-shaped: obs 17, act 6) stepped in HBM by one kernel launch per step
+    (``mi355ppo_synth_continuous_step_f32``) on the learner's stream, for ``bench.py --config E``: observations, rewards and dones
+    are device tensors, so the timed region holds no PCIe traffic.  ``step_into`` writes the next observation, the reward and the
+    done flag straight into the rollout-storage rows; the position in the noise bank lives in device memory as well
+    (``step_base``), so a captured step can be replayed (``PPOLearner.capture_rollout``).  A stand-in env (plumbing), not part of
+    the hot path."""
 
     def __init__(self, num_envs: int, device, seed: int = 0, obs_dim: int = 17, act_dim: int = 6, noise_bank: int = 257,
                  horizon: int = 1000):
         import torch
 
-        self.torch, self.device = torch, device
+        from . import ops
+
+        self.torch, self.device, self.ops = torch, device, ops
         self.num_envs, self.obs_dim, self.act_dim, self.horizon = num_envs, obs_dim, act_dim, horizon
         self.single_observation_space = Box(-np.inf, np.inf, (obs_dim,))
         self.single_action_space = Box(-1.0, 1.0, (act_dim,))
         rs = np.random.RandomState(seed + 777)
         a = rs.standard_normal((obs_dim, obs_dim)) / math.sqrt(obs_dim)
         A = 0.9 * a / max(1.0, np.abs(np.linalg.eigvals(a)).max())
-        f32 = lambda x: torch.as_tensor(np.asarray(x, np.float32), device=device)   # noqa: E731
+        f32 = lambda x: torch.as_tensor(np.asarray(x, np.float32), device=device).contiguous()   # noqa: E731
         self.At, self.B = f32(A.T.copy()), f32(rs.standard_normal((act_dim, obs_dim)) * 0.3)
         self.w = f32(rs.standard_normal(obs_dim) / math.sqrt(obs_dim))
         self.noise = f32(0.01 * rs.standard_normal((noise_bank, num_envs, obs_dim)))
         self.state = f32(0.1 * rs.standard_normal((num_envs, obs_dim)))
         self.reset_state = self.state.clone()
         self.steps = torch.zeros(num_envs, device=device)
-        self._k = 0
+        self._reward = torch.zeros(num_envs, device=device)
+        self._done = torch.zeros(num_envs, device=device)
+        self._step = 0                  # host mirror of the env's step count (position in the noise bank)
+        self.step_base = None           # device-resident count: set by PPOLearner.capture_rollout
+        self._step_rel = None
 
     def obs(self):
         return self.state
 
+    def step_into(self, action, obs_out, reward_out, done_out):
+        """One step with the results written into caller-provided rows (``obs_out`` may be the env's own ``state``)."""
+        if self._step_rel is None:
+            k, base = self._step, None
+            self._step += 1
+        else:                           # inside a capture: position = *step_base + the step's index in the rollout
+            k, base = self._step_rel, self.step_base
+        self.ops.synth_continuous_step(self.state, self.reset_state, self.At, self.B, self.w, self.noise, k, self.steps, float(self.horizon),
+                                       action, obs_out, reward_out, done_out, k_base=base)
+        return obs_out
+
     def step(self, action):
-        """-> (next_obs (N,obs) f32, reward (N) f32, done (N) f32), all on the device."""
-        t = self.torch
-        a = action.clamp(-1.0, 1.0)                                              # ClipAction (ppo_continuous_action.py:96)
-        nxt = t.addmm(self.noise[self._k % self.noise.shape[0]], self.state, self.At).addmm_(a, self.B)
-        self._k += 1
-        reward = nxt @ self.w - 0.1 * (a * a).sum(1)
-        self.steps += 1.0
-        done = (self.steps >= self.horizon).float()                              # 1000-step truncation
-        self.steps.mul_(1.0 - done)
-        self.state = t.where(done[:, None] > 0, self.reset_state, nxt)
-        return self.state, reward, done
+        """-> (next_obs (N,obs) f32, reward (N) f32, done (N) f32), all on the device (views of the env's own buffers)."""
+        self.step_into(action.contiguous(), self.state, self._reward, self._done)
+        return self.state, self._reward, self._done
 
     def close(self):
         pass

@@ -146,6 +146,14 @@ class PPOLearner:
             self._inds_ev = {}          # epoch -> event behind the last H2D copy out of that pinned row
             self._total_norm = torch.zeros(1, device=device)
             self._stage_free.record(torch.cuda.current_stream(device))       # after every buffer's zero fill
+        # the reference's 64-64 tanh MLP agents (ppo.py, ppo_continuous_action.py, rpo_continuous_action.py) on the fused MLP kernels
+        # (csrc/mlp.hip): rollout step = one launch, minibatch forward + loss + backward = two launches (MI355PPO_MLP=torch keeps
+        # the networks on library GEMMs behind K2 / K3 for A/B timing)
+        self.mlp = None
+        if self.hip and not self.image and hasattr(agent, "mlp_nets") and type(self).forward_backward_hip is PPOLearner.forward_backward_hip:
+            from .agents import fused_mlp_ptrs
+
+            self.mlp = fused_mlp_ptrs(agent)            # after FlatParams: the parameters sit at their final addresses
         self._pack = None           # (B, 8) packed behaviour rows (ops.batch_pack) of the current update, or None
         self._pack_buf = None       # their storage, allocated by the first update()
         self._mb_adv_md = None      # the current minibatch's (mean, std + 1e-8) row of ops.adv_stats, or None
@@ -153,7 +161,7 @@ class PPOLearner:
         self._update_graphs = None  # capture_update(): [epoch][minibatch] -> hipGraph of one minibatch's forward + loss + backward
         self._adv_md_buf = None
         self._loss_slots = None
-        if self.hip and self.discrete and type(self).forward_backward_hip is PPOLearner.forward_backward_hip:
+        if self.hip and self.discrete and self.mlp is None and type(self).forward_backward_hip is PPOLearner.forward_backward_hip:
             self._loss_slots = self.ops.LossSlots(self._scalars.shape[0], device)
         # world > 1: the all-reduce of the largest parameter's gradient (NatureCNN: Linear(3136,512).weight, 95 % of the
         # bytes, complete right after the heads' and the FC layer's backward) is started from a post-accumulate hook and runs
@@ -260,6 +268,18 @@ class PPOLearner:
         stream); ``rng_offset`` then is the lane's reserved Philox offset for this step.  ``rng_base`` (1-element int64 device
         tensor) is added to the offset on the device: the form a captured step uses (``capture_rollout``)."""
         lo, hi = (0, self.N) if rows is None else rows
+        if self.hip and self.mlp is not None:
+            # both networks' forward + sampling + log_prob in ONE launch, written straight into the rollout storage
+            seed, off = self.agent.rng.next() if rng_offset is None else (self.agent.rng.seed, int(rng_offset))
+            obs_rows = self.obs[step][lo:hi]
+            if self.discrete:
+                a64 = self.ops.mlp_act_categorical(obs_rows, *self.mlp, seed=seed, offset=off, offset_base=rng_base,
+                                                   action_f32_out=self.actions[step][lo:hi], logprob_out=self.logprobs[step][lo:hi],
+                                                   value_out=self.values[step][lo:hi], want_i64=rng_base is None)[0]
+                return a64 if a64 is not None else self.actions[step][lo:hi]
+            return self.ops.mlp_act_normal(obs_rows, *self.mlp, self.agent.actor_logstd.detach(), seed=seed, offset=off,
+                                           offset_base=rng_base, action_out=self.actions[step][lo:hi],
+                                           logprob_out=self.logprobs[step][lo:hi], value_out=self.values[step][lo:hi])[0]
         if self.hip:
             p, value = self._heads_rollout(self.obs[step][lo:hi])
             seed, off = self.agent.rng.next() if rng_offset is None else (self.agent.rng.seed, int(rng_offset))
@@ -286,7 +306,9 @@ class PPOLearner:
         the sampler and of the env live in device memory and advance by T per rollout).  ``replay_rollout()`` then issues a
         whole rollout as T graph launches instead of ~30 T kernel launches: bit-identical buffers (tests), no host work
         beside the replays.  For envs that write straight into device rows (``step_into``)."""
-        assert self.hip and self.discrete and hasattr(env, "step_into"), "capture_rollout needs the HIP path and a device-resident env"
+        vector = self.mlp is not None                     # the MLP agents: vector observations, the env takes the action
+        assert self.hip and hasattr(env, "step_into") and (vector or self.discrete), \
+            "capture_rollout needs the HIP path and a device-resident env (NatureCNN agent, or an MLP agent on the fused kernels)"
         dev, T = self.device, self.T
         self.warm_rollout_caches()
         self._rng_base = torch.full((1,), int(self.agent.rng.offset), dtype=torch.int64, device=dev)
@@ -297,15 +319,20 @@ class PPOLearner:
         graphs, pool = [], None
 
         def body(step):
-            self.act(step, rng_offset=step + 1, rng_base=self._rng_base)
-            _, done_dst = self._slot(step + 1)
+            action = self.act(step, rng_offset=step + 1, rng_base=self._rng_base)
+            obs_dst, done_dst = self._slot(step + 1)
+            if vector:                                    # the env writes the next observation straight into its rollout row
+                env._step_rel = step
+                env.step_into(action, obs_dst, self.rewards[step], done_dst)
+                env._step_rel = None
+                return
             env._step_rel = step + 1
             frames = env.step_into(self.stage_obs, self.rewards[step], done_dst)
             env._step_rel = None
             self.observe(step + 1, frames, done_dst)
 
         host_rng, host_env = self.agent.rng.offset, env._step
-        cursor0 = env.cursor.clone()
+        cursor0 = (torch.cat([env.state.reshape(-1), env.steps]) if vector else env.cursor).clone()
         with torch.cuda.stream(side):
             body(0)                                   # warm-up on the capture stream: per-stream workspaces and trunk buffers exist
         side.synchronize()
@@ -324,7 +351,11 @@ class PPOLearner:
             graphs.append(g)
         torch.cuda.current_stream(dev).wait_stream(side)
         # capturing executes nothing, but the warm-up step and the host counters moved: restore the pre-capture state
-        env.cursor.copy_(cursor0)
+        if vector:
+            env.state.copy_(cursor0[:env.state.numel()].view_as(env.state))
+            env.steps.copy_(cursor0[env.state.numel():])
+        else:
+            env.cursor.copy_(cursor0)
         self.agent.rng.offset, env._step = host_rng, host_env
         self._rollout_graphs = graphs
 
@@ -354,7 +385,10 @@ class PPOLearner:
         """Bootstrap value of the observation in the bootstrap slot, then GAE (:288-301)."""
         a = self.args
         if self.hip:
-            _, next_value = self._heads_rollout(self.boot_obs)
+            if self.mlp is not None:
+                next_value = self.ops.mlp_forward(self.boot_obs, *self.mlp)[1]
+            else:
+                _, next_value = self._heads_rollout(self.boot_obs)
             self.ops.gae(self.rewards, self.dones, self.values, self.boot_done, next_value.reshape(-1).contiguous(),
                          a.gamma, a.gae_lambda, self.advantages, self.returns)
         else:
@@ -389,7 +423,8 @@ class PPOLearner:
         b_returns, b_values = self.returns.reshape(-1), self.values.reshape(-1)
         # K3 gathers ONE 32-byte row per minibatch row instead of five 4-byte values out of five arrays: the five behaviour
         # arrays are final here (GAE done; tests may have overwritten them), packed once per iteration
-        use_pack = self.hip and self.discrete and type(self).forward_backward_hip is PPOLearner.forward_backward_hip
+        use_pack = (self.hip and self.discrete and self.mlp is None
+                    and type(self).forward_backward_hip is PPOLearner.forward_backward_hip)
         if use_pack:
             if self._pack_buf is None:
                 self._pack_buf = torch.empty((B, self.ops.PACK_FLOATS), dtype=torch.float32, device=self.device)
@@ -416,8 +451,11 @@ class PPOLearner:
             for start in range(0, B, M):
                 end = start + M
                 if self.hip and self._update_graphs is not None:
-                    self._update_graphs[epoch][start // M].replay()       # forward + fused loss + backward of this slot (capture_update)
-                    self.optimizer_step_hip(lr)                           # lr and Adam's step count are launch arguments: eager
+                    if k == 0:
+                        self._upload_adam_schedule(lr)                    # every slot's (step size, bias correction) -> device memory
+                    # forward + fused loss + backward + clip + Adam of this slot (capture_update)
+                    self._update_graphs[epoch][start // M].replay()
+                    self.flat.step += 1
                 elif self.hip:
                     self._mb_adv_md = adv_md[start // M] if adv_md is not None else None
                     self._mb_slot = (self._loss_slots, k) if self._loss_slots is not None else None
@@ -438,6 +476,10 @@ class PPOLearner:
             if stop:
                 break
         self._mb_adv_md = self._mb_slot = self._pack = None               # direct forward_backward_hip calls: arrays, fold at once
+        if self.hip and self._update_graphs is not None:
+            trunk = getattr(self.agent, "_trunk", None)
+            if trunk is not None:                   # the replayed Adam kernels rewrote the parameters: the rollout's packs are stale
+                trunk.bufs.weights_version += 1
         if self.hip:
             if self._loss_slots is not None and k > folded:
                 self._loss_slots.fold(k - folded, self._scalars, first=folded)   # one launch for every minibatch of the update
@@ -457,13 +499,13 @@ class PPOLearner:
         return pm
 
     def capture_update(self) -> None:
-        """Opt-in (``bench.py --update-graphs``).  State at the end of round 3: bit-identical to the eager update over three
-        iterations at a small shape on the MI355X (tests/test_gpu_learner.py::test_captured_update_slots_...); NOT yet run at the
-        BASELINE configurations and NOT yet measured (the round's GPU minutes were spent) -- hence not the default.
+        """``bench.py``'s default on one GPU (``--no-update-graphs``: eager).  Bit-identical to the eager update over three
+        iterations on the MI355X at a small shape, at config B's and on the continuous-action path
+        (tests/test_gpu_learner.py::test_captured_update_slots_...); measured in profiles/r04_update_graphs_ab.jsonl.
 
         One hipGraph per (epoch, minibatch) slot of the update: K5 gather + network forward + fused loss + backward through the
-        custom autograd nodes of that slot (:320-358), ~50 launches, replayed by ``update`` / ``update_async`` with the
-        optimizer step (two launches whose learning rate and step count are launch arguments) issued eagerly after it.
+        custom autograd nodes of that slot (:320-358) + the fused clip / Adam step (:376-377), ~55 launches, replayed by
+        ``update`` / ``update_async``.  The optimizer's schedule-dependent constants come from a device table (see below).
         Everything a slot reads sits at a fixed address: its rows of the epoch's device permutation (``_inds_dev[epoch]``),
         the packed behaviour rows, the epoch's advantage statistics (``_adv_md_buf``), its loss slot and scalar row, the
         flat parameter / gradient buffers, the weight packs (re-derived in place by launches inside the graph: the capture
@@ -489,7 +531,7 @@ class PPOLearner:
         self._inds_dev.copy_(torch.arange(B, dtype=torch.int64, device=dev).expand(E_, B))
         self._adv_md_buf = torch.zeros((E_, nmb, 2), dtype=torch.float32, device=dev)
         self._adv_md_buf[..., 1] = 1.0
-        use_pack = self.discrete and self._loss_slots is not None
+        use_pack = self.discrete and self._loss_slots is not None and self.mlp is None
         self._pack = (self.ops.batch_pack(b_actions, b_logprobs, b_advantages, b_returns, b_values, out=self._pack_buf)
                       if use_pack else None)
         if self.image and self.fused_cnn:
@@ -505,11 +547,30 @@ class PPOLearner:
             self.forward_backward_hip(self._inds_dev[e][j * M:(j + 1) * M], b_obs, b_actions, b_logprobs, b_advantages,
                                       b_returns, b_values, self._scalars[k])
 
+        # the optimizer step joins the graph: its two schedule-dependent constants (step size with the annealed learning rate and
+        # bias correction 1, sqrt of bias correction 2) are read from row k of a device table that update() refills before the
+        # first replay of an iteration (mi355ppo_clip_adam_sched_f32); everything else of the step is fixed at capture time
+        n_slots = E_ * nmb
+        self._adam_sched = torch.zeros((n_slots, 2), dtype=torch.float32, device=dev)
+        self._adam_sched[:, 1] = 1.0                                      # (the warm-up slot executes: step size 0, a finite denominator)
+        self._adam_sched_pin = torch.zeros((n_slots, 2), dtype=torch.float32).pin_memory()
+        self._adam_sched_ev = None
+        slot_fb = slot
+
+        def slot(e, j):                                                   # noqa: F811 -- forward/backward, then the optimizer step
+            slot_fb(e, j)
+            self.ops.clip_adam_sched_(self.flat.params, self.flat.grads, self.flat.exp_avg, self.flat.exp_avg_sq,
+                                      self._adam_sched[e * nmb + j], a.max_grad_norm, grad_scale=1.0 / self.world_size, eps=self.adam_eps,
+                                      total_norm_out=self._total_norm)
+
+        state0 = [t.clone() for t in (self.flat.params, self.flat.exp_avg, self.flat.exp_avg_sq)]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             slot(0, 0)                                                    # warm-up on the capture stream (workspaces, trunk buffers)
-            self.flat.grads.zero_()                                       # it accumulated a gradient nobody applies
+            for t, t0 in zip((self.flat.params, self.flat.exp_avg, self.flat.exp_avg_sq), state0):
+                t.copy_(t0)                                               # the warm-up's optimizer step (zero step size) is undone exactly
+            self.flat.grads.zero_()
         side.synchronize()
         graphs, pool = [], None
         for e in range(E_):
@@ -525,6 +586,22 @@ class PPOLearner:
         self.flat.grads.zero_()
         self._mb_adv_md = self._mb_slot = self._pack = None
         self._update_graphs = graphs
+
+    def _upload_adam_schedule(self, lr: float) -> None:
+        """Rows k = 0 .. slots-1 of the device table the captured optimizer steps read: Adam step ``flat.step + k + 1`` at this
+        iteration's learning rate (``ops.adam_schedule``: the library's own arithmetic, so eager and captured steps agree bit for
+        bit).  One small pinned H2D copy per iteration; the pinned rows are rewritten only after the previous copy executed."""
+        if self._adam_sched_ev is not None:
+            self._adam_sched_ev.synchronize()
+        pin = self._adam_sched_pin
+        for k in range(pin.shape[0]):
+            ns, bc = self.ops.adam_schedule(lr, self.flat.step + k + 1)
+            pin[k, 0], pin[k, 1] = ns, bc
+        self._adam_sched.copy_(pin, non_blocking=True)
+        if self._adam_sched.is_cuda:
+            if self._adam_sched_ev is None:
+                self._adam_sched_ev = torch.cuda.Event()
+            self._adam_sched_ev.record()
 
     def upload_permutation(self, epoch: int, b_inds: np.ndarray) -> torch.Tensor:
         """Host permutation of this epoch (:315) -> its own pinned row -> its own device row (async H2D).  The pinned row is
@@ -582,6 +659,18 @@ class PPOLearner:
         """K5 gather -> network forward -> K3 fused loss fwd+bwd -> autograd through the network only (:320-358).
         Gradients land in the persistent flat buffer (``.grad`` of every parameter is a view of it)."""
         a, ops = self.args, self.ops
+        if self.mlp is not None:
+            # K7: b_obs[mb_inds] gather, both networks' forward, the distribution, K3's loss row terms, both backward passes and
+            # the weight gradients in two launches; gradients are added into the flat buffer's views
+            shift = None
+            if getattr(self.agent, "rpo_alpha", None) is not None:        # RPO: loss on mean + U(-alpha, alpha), d/dmean unchanged
+                shift = self.agent.perturb_mean(torch.zeros((idx.numel(),) + self.act_shape, device=self.device))
+            ls = None if self.discrete else self.agent.actor_logstd
+            ops.mlp_ppo_fwd_bwd(b_obs, idx, self.mlp[0], self.mlp[1], b_actions, b_logprobs, b_advantages, b_returns, b_values,
+                                a.clip_coef, a.ent_coef, a.vf_coef, a.norm_adv, a.clip_vloss, adv_mean_den=self._mb_adv_md,
+                                scalars_out=scalars_out, logstd=None if ls is None else ls.detach(),
+                                logstd_grad=None if ls is None else ls.grad, mean_shift=shift)
+            return
         if self.image and self.fused_cnn:
             p, value = self.agent.heads_u8(b_obs, idx)                    # :320 gather + /255 fused into conv1
         else:

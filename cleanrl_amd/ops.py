@@ -566,3 +566,213 @@ def clip_adam_(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, max_gra
                                         int(step), _ptr(total_norm_out), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(st, "mi355ppo_clip_adam_f32")
     return total_norm_out
+
+
+def adam_schedule(lr: float, step: int, beta1: float = 0.9, beta2: float = 0.999):
+    """The two schedule-dependent constants of Adam step ``step`` (1-based) as the kernels consume them (host floats):
+    ``(-(lr / (1 - beta1^step)), sqrt(1 - beta2^step))`` -- computed by the library, so that eager and captured steps agree bit
+    for bit."""
+    out = (ctypes.c_float * 2)()
+    _lib.check(_lib.load().mi355ppo_adam_schedule_f32(float(lr), float(beta1), float(beta2), int(step), out), "mi355ppo_adam_schedule_f32")
+    return float(out[0]), float(out[1])
+
+
+def clip_adam_sched_(params, grads, exp_avg, exp_avg_sq, sched2, max_grad_norm: float, grad_scale: float = 1.0, beta1: float = 0.9,
+                     beta2: float = 0.999, eps: float = 1e-5, total_norm_out=None):
+    """``clip_adam_`` with the step's (step_size, bias_correction2_sqrt) read from the 2-float DEVICE tensor ``sched2``
+    (``adam_schedule`` values copied there by the caller): capturable, replayable with the next step's schedule."""
+    lib = _lib.load()
+    n = params.numel()
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, torch.float32, nm, (n,))
+    _chk(sched2, torch.float32, "sched2", (2,))
+    dev = params.device
+    if total_norm_out is None:
+        total_norm_out = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.mi355ppo_clip_adam_workspace_bytes(n))
+    with _on(dev):
+        st = lib.mi355ppo_clip_adam_sched_f32(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), n, float(grad_scale),
+                                              float(max_grad_norm), float(beta1), float(beta2), float(eps), _ptr(sched2),
+                                              _ptr(total_norm_out), _ptr(ws), ws.numel(), _stream(dev))
+    _lib.check(st, "mi355ppo_clip_adam_sched_f32")
+    return total_norm_out
+
+
+# ------------------------------------------------------------------------------------------- K7: the fused MLP agents
+MLP_MAX_OBS, MLP_MAX_OUT, MLP_HIDDEN = 32, 8, 64
+
+
+class MlpNetPtrs:
+    """The six parameter tensors of one 64-64 tanh MLP (``nn.Sequential(Linear, Tanh, Linear, Tanh, Linear)``, ppo.py:100-117)
+    as the C ABI wants them: a host array of six device pointers (weights in torch's (out, in) layout), and the same for their
+    ``.grad`` views.  Built once per network: parameters and gradients of a flat-buffer agent never move."""
+
+    def __init__(self, seq):
+        lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+        assert len(lin) == 3 and lin[0].out_features == MLP_HIDDEN and lin[1].in_features == MLP_HIDDEN and \
+            lin[1].out_features == MLP_HIDDEN and lin[2].in_features == MLP_HIDDEN, "the fused MLP kernels are the reference's 64-64 networks"
+        self.obs_dim, self.n_out = lin[0].in_features, lin[2].out_features
+        self.tensors = [t for m in lin for t in (m.weight, m.bias)]
+        for t in self.tensors:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self.params = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in self.tensors])
+        self._grad_ptrs = None
+
+    def grads(self):
+        g = [t.grad for t in self.tensors]
+        assert all(x is not None and x.is_contiguous() for x in g), "fused MLP backward needs allocated .grad tensors (flat buffers)"
+        key = tuple(x.data_ptr() for x in g)
+        if self._grad_ptrs is None or self._grad_ptrs[0] != key:
+            self._grad_ptrs = (key, (ctypes.c_void_p * 6)(*key))
+        return self._grad_ptrs[1]
+
+    def refresh(self):
+        """Re-read the parameter pointers (after ``module.to(...)`` / a flat-buffer rebind)."""
+        self.params = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in self.tensors])
+
+
+def mlp_supported(obs_dim: int, n_out: int) -> bool:
+    return 0 < obs_dim <= MLP_MAX_OBS and 0 < n_out <= MLP_MAX_OUT
+
+
+def mlp_forward(obs, actor: MlpNetPtrs, critic: MlpNetPtrs, actor_out=None, value_out=None):
+    """Both networks' forward in one launch -> ``(actor_out (B, n_out), value (B))``."""
+    lib = _lib.load()
+    B, O = obs.shape
+    _chk(obs, torch.float32, "obs", (B, actor.obs_dim))
+    dev = obs.device
+    out = actor_out if actor_out is not None else torch.empty((B, actor.n_out), dtype=torch.float32, device=dev)
+    val = value_out if value_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    _chk(out, torch.float32, "actor_out", (B, actor.n_out))
+    _chk(val, torch.float32, "value_out", (B,))
+    with _on(dev):
+        st = lib.mi355ppo_mlp_fwd_f32(_ptr(obs), B, O, actor.params, critic.params, actor.n_out, _ptr(out), _ptr(val), _stream(dev))
+    _lib.check(st, "mi355ppo_mlp_fwd_f32")
+    return out, val
+
+
+def mlp_act_categorical(obs, actor: MlpNetPtrs, critic: MlpNetPtrs, noise_exp1=None, seed: int = 0, offset: int = 0, offset_base=None,
+                        action_f32_out=None, logprob_out=None, value_out=None, want_i64: bool = True, want_entropy: bool = False,
+                        want_logits: bool = False):
+    """One rollout step of the Categorical MLP agent (ppo.py:205-210): both forwards + sample + log_prob (+ entropy) in one launch.
+    -> ``(action_i64 | None, action_f32 | None, logprob, entropy | None, value, logits | None)``."""
+    lib = _lib.load()
+    B, O = obs.shape
+    _chk(obs, torch.float32, "obs", (B, actor.obs_dim))
+    dev, A = obs.device, actor.n_out
+    if noise_exp1 is not None:
+        _chk(noise_exp1, torch.float32, "noise_exp1", (B, A))
+    a64 = torch.empty(B, dtype=torch.int64, device=dev) if want_i64 else None
+    af = action_f32_out if action_f32_out is not None else (None if want_i64 else torch.empty(B, dtype=torch.float32, device=dev))
+    lp = logprob_out if logprob_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    val = value_out if value_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    for t, nm in ((af, "action_f32_out"), (lp, "logprob_out"), (val, "value_out")):
+        if t is not None:
+            _chk(t, torch.float32, nm, (B,))
+    ent = torch.empty(B, dtype=torch.float32, device=dev) if want_entropy else None
+    logits = torch.empty((B, A), dtype=torch.float32, device=dev) if want_logits else None
+    if offset_base is not None:
+        _chk(offset_base, torch.int64, "offset_base", (1,))
+    with _on(dev):
+        st = lib.mi355ppo_mlp_act_categorical_f32(_ptr(obs), B, O, actor.params, critic.params, A, _ptr(noise_exp1), int(seed) & (2**64 - 1),
+                                                  int(offset) & (2**64 - 1), _ptr(offset_base), _ptr(a64), _ptr(af), _ptr(lp), _ptr(ent),
+                                                  _ptr(val), _ptr(logits), _stream(dev))
+    _lib.check(st, "mi355ppo_mlp_act_categorical_f32")
+    return a64, af, lp, ent, val, logits
+
+
+def mlp_act_normal(obs, actor: MlpNetPtrs, critic: MlpNetPtrs, logstd, noise=None, seed: int = 0, offset: int = 0, offset_base=None,
+                   action_out=None, logprob_out=None, value_out=None, want_entropy: bool = False, want_mean: bool = False):
+    """One rollout step of the continuous-action agent (ppo_continuous_action.py:221-226) in one launch.
+    -> ``(action (B, D), logprob, entropy | None, value, mean | None)``."""
+    lib = _lib.load()
+    B, O = obs.shape
+    _chk(obs, torch.float32, "obs", (B, actor.obs_dim))
+    dev, D = obs.device, actor.n_out
+    logstd = _chk(logstd.reshape(-1), torch.float32, "logstd", (D,))
+    if noise is not None:
+        _chk(noise, torch.float32, "noise", (B, D))
+    act = action_out if action_out is not None else torch.empty((B, D), dtype=torch.float32, device=dev)
+    _chk(act, torch.float32, "action_out", (B, D))
+    lp = logprob_out if logprob_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    val = value_out if value_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    _chk(lp, torch.float32, "logprob_out", (B,))
+    _chk(val, torch.float32, "value_out", (B,))
+    ent = torch.empty(B, dtype=torch.float32, device=dev) if want_entropy else None
+    mean = torch.empty((B, D), dtype=torch.float32, device=dev) if want_mean else None
+    if offset_base is not None:
+        _chk(offset_base, torch.int64, "offset_base", (1,))
+    with _on(dev):
+        st = lib.mi355ppo_mlp_act_normal_f32(_ptr(obs), B, O, actor.params, critic.params, _ptr(logstd), D, _ptr(noise),
+                                             int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), _ptr(offset_base), _ptr(act), _ptr(lp),
+                                             _ptr(ent), _ptr(val), _ptr(mean), _stream(dev))
+    _lib.check(st, "mi355ppo_mlp_act_normal_f32")
+    return act, lp, ent, val, mean
+
+
+def mlp_ppo_fwd_bwd(b_obs, mb_inds, actor: MlpNetPtrs, critic: MlpNetPtrs, b_actions, b_logprobs, b_advantages, b_returns, b_values,
+                    clip_coef, ent_coef, vf_coef, norm_adv=True, clip_vloss=True, adv_mean_den=None, scalars_out=None, logstd=None,
+                    logstd_grad=None, mean_shift=None, rows_per_block: int = 0):
+    """One minibatch of the update of an MLP agent in two launches (ppo.py:250-287 / ppo_continuous_action.py:265-302 up to and
+    including ``loss.backward()``): gather, both forwards, distribution, PPO loss, both backward passes.  Gradients are ADDED to
+    the networks' ``.grad`` tensors (and ``logstd_grad``); -> the seven scalars of K3.  ``logstd`` given = Normal head."""
+    lib = _lib.load()
+    Bf, O = b_obs.shape
+    _chk(b_obs, torch.float32, "b_obs", (Bf, actor.obs_dim))
+    dev, nout = b_obs.device, actor.n_out
+    if mb_inds is not None:
+        _chk(mb_inds, torch.int64, "mb_inds")
+        M = mb_inds.numel()
+    else:
+        M = Bf
+    _, lpv, advv, retv, valv = _flat_batch(b_logprobs, b_advantages, b_returns, b_values)
+    normal = logstd is not None
+    _chk(b_actions, torch.float32, "b_actions", (Bf, nout) if normal else (Bf,))
+    if norm_adv:
+        if adv_mean_den is None:
+            adv_mean_den = adv_stats(advv, mb_inds, M)[0]
+        _chk(adv_mean_den, torch.float32, "adv_mean_den", (2,))
+    sc = scalars_out if scalars_out is not None else torch.empty(7, dtype=torch.float32, device=dev)
+    _chk(sc, torch.float32, "scalars_out", (7,))
+    nbytes = lib.mi355ppo_mlp_ppo_workspace_bytes(M, O, nout, int(rows_per_block))
+    if nbytes == 0:
+        raise ValueError(f"mlp_ppo_fwd_bwd: unsupported shape (obs_dim={O} <= {MLP_MAX_OBS}, n_out={nout} <= {MLP_MAX_OUT})")
+    ws = _workspace(dev, nbytes)
+    with _on(dev):
+        if normal:
+            ls = _chk(logstd.reshape(-1), torch.float32, "logstd", (nout,))
+            lg = _chk(logstd_grad.reshape(-1), torch.float32, "logstd_grad", (nout,))
+            if mean_shift is not None:
+                _chk(mean_shift, torch.float32, "mean_shift", (M, nout))
+            st = lib.mi355ppo_mlp_ppo_normal_fwd_bwd_f32(
+                _ptr(b_obs), _ptr(mb_inds), M, O, actor.params, critic.params, _ptr(ls), nout, _ptr(mean_shift), _ptr(b_actions), _ptr(lpv),
+                _ptr(advv), _ptr(retv), _ptr(valv), float(clip_coef), float(ent_coef), float(vf_coef), int(bool(norm_adv)),
+                int(bool(clip_vloss)), _ptr(adv_mean_den), actor.grads(), critic.grads(), _ptr(lg), _ptr(sc), int(rows_per_block), _ptr(ws),
+                ws.numel(), _stream(dev))
+        else:
+            st = lib.mi355ppo_mlp_ppo_categorical_fwd_bwd_f32(
+                _ptr(b_obs), _ptr(mb_inds), M, O, actor.params, critic.params, nout, _ptr(b_actions), _ptr(lpv), _ptr(advv), _ptr(retv),
+                _ptr(valv), float(clip_coef), float(ent_coef), float(vf_coef), int(bool(norm_adv)), int(bool(clip_vloss)),
+                _ptr(adv_mean_den), actor.grads(), critic.grads(), _ptr(sc), int(rows_per_block), _ptr(ws), ws.numel(), _stream(dev))
+    _lib.check(st, "mi355ppo_mlp_ppo_fwd_bwd_f32")
+    return sc
+
+
+def synth_continuous_step(state, reset_state, At, Bm, w, noise, k: int, steps, horizon: float, action, obs_out, reward, done, k_base=None):
+    """One step of the device-resident continuous-control stand-in env (test / bench support, not the reference path)."""
+    lib = _lib.load()
+    N, O = state.shape
+    D = action.shape[1]
+    bank = noise.shape[0]
+    for t, nm, shp in ((state, "state", (N, O)), (reset_state, "reset_state", (N, O)), (At, "At", (O, O)), (Bm, "Bm", (D, O)), (w, "w", (O,)),
+                       (noise, "noise", (bank, N, O)), (steps, "steps", (N,)), (action, "action", (N, D)), (obs_out, "obs_out", (N, O)),
+                       (reward, "reward", (N,)), (done, "done", (N,))):
+        _chk(t, torch.float32, nm, shp)
+    if k_base is not None:
+        _chk(k_base, torch.int64, "k_base", (1,))
+    dev = state.device
+    with _on(dev):
+        st = lib.mi355ppo_synth_continuous_step_f32(_ptr(state), _ptr(reset_state), _ptr(At), _ptr(Bm), _ptr(w), _ptr(noise), bank,
+                                                    int(k) & (2**64 - 1), _ptr(k_base), _ptr(steps), float(horizon), _ptr(action),
+                                                    _ptr(obs_out), _ptr(reward), _ptr(done), N, O, D, _stream(dev))
+    _lib.check(st, "mi355ppo_synth_continuous_step_f32")

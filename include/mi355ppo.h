@@ -32,9 +32,10 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 150 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 160 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2, 1.3: round 3;
-                                  1.4: the *_cpu host-pointer twins; 1.5: mi355ppo_init); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
+                                  1.4: the *_cpu host-pointer twins; 1.5: mi355ppo_init; 1.6: round 4 -- the fused MLP family K7,
+                                  mi355ppo_clip_adam_sched_f32); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
 
 #if defined(__GNUC__)
 #define MI355PPO_API __attribute__((visibility("default")))
@@ -261,6 +262,61 @@ MI355PPO_API int mi355ppo_clip_adam_f32(float* params, float* grads, float* exp_
                            double grad_scale, double max_grad_norm, double lr,
                            double beta1, double beta2, double eps, int64_t step,
                            float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The two schedule-dependent constants of an Adam step, as the kernels consume them (HOST function, host pointer):
+ * out2_host = {(float)(-(lr / (1 - beta1^step))), (float)sqrt(1 - beta2^step)}  (torch adam.py: step_size, bias_correction2_sqrt). */
+MI355PPO_API int mi355ppo_adam_schedule_f32(double lr, double beta1, double beta2, int64_t step, float* out2_host);
+/* mi355ppo_clip_adam_f32 with those two constants read from DEVICE memory (`sched2`, 2 floats the caller copied there): a launch
+ * captured into a hipGraph is replayed with the next step's learning rate / bias corrections without re-capturing
+ * (PPOLearner.capture_update).  Bit-identical to mi355ppo_clip_adam_f32 for the same (lr, step). */
+MI355PPO_API int mi355ppo_clip_adam_sched_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                              double grad_scale, double max_grad_norm, double beta1, double beta2, double eps,
+                                              const float* sched2, float* total_norm_out, void* workspace, size_t workspace_bytes,
+                                              void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7  The reference's MLP agents (two independent 64-64 tanh networks: actor and critic) as one kernel family (csrc/mlp.hip).
+ * Agents: cleanrl/ppo.py:100-126 (Categorical head), cleanrl/ppo_continuous_action.py:112-141 (Normal head with the
+ * state-independent actor_logstd).  A network is passed as a HOST array of six DEVICE pointers in torch's own layouts:
+ *   {W1 (64, O), b1 (64), W2 (64, 64), b2 (64), W3 (n_out, 64), b3 (n_out)}   (nn.Linear.weight is (out, in))
+ * obs_dim O <= 32 and n_out <= 8 (CartPole 4 / 2, HalfCheetah 17 / 6, Ant 27 / 8 ...): beyond that the entry points return
+ * MI355PPO_EINVAL and the caller keeps the networks on library GEMMs.
+ *
+ * mi355ppo_mlp_fwd_f32: both forwards -- actor_out (B, n_out) = logits or mean, value (B) -- e.g. the bootstrap value of
+ *   ppo.py:218-219.
+ * mi355ppo_mlp_act_*: the rollout step of Agent.get_action_and_value(next_obs) (ppo.py:205-210,
+ *   ppo_continuous_action.py:221-226): both forwards + K2 / K2' (same Philox streams as mi355ppo_categorical_sample_ctr_f32 /
+ *   mi355ppo_normal_sample_f32: counter = row * ceil(n_out / 4) + column / 4; offset_eff = offset + *offset_base) in ONE launch.
+ *   logits_out / mean_out / entropy may be NULL.
+ * mi355ppo_mlp_ppo_*_fwd_bwd_f32: one minibatch of the update (ppo.py:250-287 / ppo_continuous_action.py:265-302 up to and
+ *   including loss.backward()): gather b_obs[mb_inds], both forwards, the distribution, the PPO loss terms of K3 (same row
+ *   function), both backward passes; the parameter gradients are ADDED to `actor_grads` / `critic_grads` (host arrays of six
+ *   device pointers, layouts as the parameters; `dlogstd` (D) likewise), the seven scalars of K3 written to scalars7.
+ *   norm_adv needs adv_mean_den (mi355ppo_adv_stats_f32).  mean_shift (M, D) or NULL is added to the mean before the loss
+ *   (rpo_continuous_action.py:138-142).  rows_per_block: 0 = auto.  Two launches; deterministic (fixed-order f64 folds).
+ */
+MI355PPO_API int mi355ppo_mlp_fwd_f32(const float* obs, int B, int O, const void* const* actor, const void* const* critic, int n_out,
+                                      float* actor_out, float* value, void* stream);
+MI355PPO_API int mi355ppo_mlp_act_categorical_f32(const float* obs, int B, int O, const void* const* actor, const void* const* critic,
+                                                  int A, const float* noise_exp1, uint64_t seed, uint64_t offset,
+                                                  const uint64_t* offset_base, int64_t* action_i64, float* action_f32, float* logprob,
+                                                  float* entropy, float* value, float* logits_out, void* stream);
+MI355PPO_API int mi355ppo_mlp_act_normal_f32(const float* obs, int B, int O, const void* const* actor_mean, const void* const* critic,
+                                             const float* logstd, int D, const float* noise_std_normal, uint64_t seed, uint64_t offset,
+                                             const uint64_t* offset_base, float* action, float* logprob_sum, float* entropy_sum,
+                                             float* value, float* mean_out, void* stream);
+MI355PPO_API size_t mi355ppo_mlp_ppo_workspace_bytes(int M, int O, int n_out, int rows_per_block);
+MI355PPO_API int mi355ppo_mlp_ppo_categorical_fwd_bwd_f32(
+    const float* b_obs, const int64_t* mb_inds, int M, int O, const void* const* actor, const void* const* critic, int A,
+    const float* b_actions_f32, const float* b_logprobs, const float* b_advantages, const float* b_returns, const float* b_values,
+    double clip_coef, double ent_coef, double vf_coef, int norm_adv, int clip_vloss, const float* adv_mean_den, void* const* actor_grads,
+    void* const* critic_grads, float* scalars7, int rows_per_block, void* workspace, size_t workspace_bytes, void* stream);
+MI355PPO_API int mi355ppo_mlp_ppo_normal_fwd_bwd_f32(
+    const float* b_obs, const int64_t* mb_inds, int M, int O, const void* const* actor_mean, const void* const* critic, const float* logstd,
+    int D, const float* mean_shift, const float* b_actions, const float* b_logprobs, const float* b_advantages, const float* b_returns,
+    const float* b_values, double clip_coef, double ent_coef, double vf_coef, int norm_adv, int clip_vloss, const float* adv_mean_den,
+    void* const* actor_grads, void* const* critic_grads, float* dlogstd, float* scalars7, int rows_per_block, void* workspace,
+    size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-pointer twins (csrc/host_twins.hip) of the PPO-path entry points above: the same arguments minus `stream` and
@@ -497,6 +553,14 @@ MI355PPO_API int mi355ppo_synth_atari_step_u8(const uint8_t* planes, int pool, i
 MI355PPO_API int mi355ppo_synth_atari_step_ctr_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed, uint64_t step,
                                                   const uint64_t* step_base, uint8_t* obs, float* reward, float* done, int N,
                                                   double done_p, int advance, void* stream);   /* step_eff = step + *step_base */
+
+/* The continuous-control stand-in (cleanrl_amd/envs.py::DeviceSyntheticContinuousVecEnv; bench.py --config E), one launch per env
+ * step: a = clip(action, -1, 1); next = noise[(k + *k_base) % bank][n] + state[n] @ At + a @ Bm; reward = next . w - 0.1 |a|^2;
+ * truncation after `horizon` steps (state := reset_state).  state (N, O) is updated in place and copied to obs_out. */
+MI355PPO_API int mi355ppo_synth_continuous_step_f32(float* state, const float* reset_state, const float* At, const float* Bm, const float* w,
+                                                    const float* noise, int bank, uint64_t k, const uint64_t* k_base, float* steps,
+                                                    double horizon, const float* action, float* obs_out, float* reward, float* done, int N,
+                                                    int O, int D, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@ summation order changes?  TEST INFRASTRUCTURE (build container only; needs /root
 
     python -m oracle.ref_sensitivity [threads]            # config B (golden minted with 1 thread)
     python -m oracle.ref_sensitivity C [threads]          # config C at its full size (golden minted with 8 threads; default here: 4)
+    python -m oracle.ref_sensitivity D [threads]          # config D, two ranks (golden: 4 threads per rank; default here: 2)
 
 Re-executes oracle/mint_goldens.py::mint_atari_iteration_config_b (ppo_atari_envpool.py:217-322, verbatim) with `threads` torch
 CPU threads (default 8; the committed golden was minted with 1: oneDNN / ATen then reduce in another order) and prints, for the
@@ -31,6 +32,17 @@ def main():
         torch.use_deterministic_algorithms(False)
         d = MF.mint_config_c(threads=threads, save=False)
         out = {"config": "C", "threads": threads, "golden_threads": int(g["torch_threads"])}
+    elif len(sys.argv) > 1 and sys.argv[1].upper() == "D":
+        from oracle import mint_full_size as MF
+
+        threads = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+        g = dict(np.load(os.path.join(MG.OUT, "atari_iteration_cfgD.npz")))
+        g = {k.split("/", 1)[1]: v for k, v in g.items()}
+        g["values"] = g["values_rank0"]
+        torch.use_deterministic_algorithms(False)
+        d = MF.mint_config_d(threads=threads, save=False)
+        d["values"] = d["values_rank0"]
+        out = {"config": "D", "threads": threads, "golden_threads": int(g["torch_threads"])}
     else:
         threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
         g = dict(np.load(os.path.join(MG.OUT, "atari_iteration_cfgB.npz")))

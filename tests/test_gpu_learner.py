@@ -272,8 +272,10 @@ def test_config_c_whole_iteration_teacher_forced_all_16_updates():
     assert g["rewards"].shape == (128, 1024)
     out = run_atari_iteration(g, DEV)
     bars = {1: (1e-3, 1e-5, 1e-3, 2e-3), 8: (1e-3, 1e-5, 1e-3, 5e-3), 16: (2e-3, 5e-5, 1e-3, 1.2e-2)}
-    problems = check_atari_iteration(out, g, bars)
-    assert not problems, "\n".join(problems)
+    report = []
+    problems = check_atari_iteration(out, g, bars, report=report)
+    print("\n".join(["config C whole iteration vs the reference's lines:"] + report))
+    assert not problems, "\n".join(problems + report)
 
 
 def test_dp_step_matches_reference_collective_block_golden():

@@ -83,11 +83,14 @@ def test_config_d_whole_iteration_two_ranks_against_the_reference_lines(tmp_path
     for k in (1, 8, 16):
         assert np.array_equal(outs[0][f"grad{k}_sub"], outs[1][f"grad{k}_sub"]), f"all-reduced gradients differ between the ranks at update {k}"
     bars = {1: (1e-3, 1e-5, 1e-3, 2e-3), 8: (1e-3, 1e-5, 1e-3, 5e-3), 16: (2e-3, 5e-5, 1e-3, 1.2e-2)}
-    problems = []
+    problems, report = [], []
     for r in (0, 1):
         o = {k: (v.item() if v.ndim == 0 else v) for k, v in outs[r].items()}
-        problems += [f"rank {r}: {p}" for p in check_atari_iteration(o, g, bars, sfx=f"_rank{r}")]
-    assert not problems, "\n".join(problems)
+        rep = []
+        problems += [f"rank {r}: {p}" for p in check_atari_iteration(o, g, bars, sfx=f"_rank{r}", report=rep)]
+        report += [f"rank {r}: {x}" for x in rep]
+    print("\n".join(["config D whole iteration vs the reference's lines:"] + report))
+    assert not problems, "\n".join(problems + report)
 
 
 def test_ppo_atari_multigpu_script_two_ranks_on_one_gpu():

@@ -84,9 +84,11 @@ def run_atari_iteration(g, dev, rank=0, world=1, T=128, N=None):
     return out
 
 
-def check_atari_iteration(out, g, bars, sfx="", clip_rows=None):
-    """``bars[k]`` = (max element / absmax, 1 - cosine, whole norm, per-tensor norms) for the gradient at update k."""
+def check_atari_iteration(out, g, bars, sfx="", clip_rows=None, report=None):
+    """``bars[k]`` = (max element / absmax, 1 - cosine, whole norm, per-tensor norms) for the gradient at update k.
+    ``report`` (a list) receives one line per measured quantity, pass or fail."""
     problems = []
+    report = report if report is not None else []
     if out["init_err"] > 2e-6:
         problems.append(f"initial parameters differ from the reference Agent's: {out['init_err']:.2e}")
     if out["worst_value"] > 5e-5 * out["value_scale"]:
@@ -110,6 +112,8 @@ def check_atari_iteration(out, g, bars, sfx="", clip_rows=None):
         nrm = out[f"grad{k}_norm"] / float(g[f"mb{k}_grad_norm"]) - 1.0
         per_rel = np.abs(out[f"grad{k}_tensor_norms"] / g[f"mb{k}_grad_tensor_norms"] - 1.0)
         b = bars[k]
+        report.append(f"update {k}: max|dg|/absmax {worst:.2e}, 1-cosine {1 - c:.2e}, norm {nrm:+.2e}, per-tensor norms max {per_rel.max():.2e} "
+                      f"(reference's clipped norm {float(g[f'mb{k}_grad_norm']):.4f})")
         if worst > b[0] or 1.0 - c > b[1] or abs(nrm) > b[2] or per_rel.max() > b[3]:
             problems.append(f"update {k}: max|dg|/absmax {worst:.2e}, 1-cosine {1 - c:.2e}, norm {nrm:+.2e}, per-tensor norms {per_rel.round(5)}")
     delta = out["final_params_sub"] - g["init_params_sub"]
@@ -117,6 +121,9 @@ def check_atari_iteration(out, g, bars, sfx="", clip_rows=None):
     close = np.isclose(delta, want, rtol=5e-2, atol=2e-5)
     order = np.argsort(out["grad16_mag_sub"])
     deciles = [float(close[p].mean()) for p in np.array_split(order, 10)]
+    report.append(f"values {out['worst_value']:.2e}, GAE {out['adv_err']:.2e}; scalars worst err/bar per column {(err / bar).max(0).round(3)}; "
+                  f"16-step move: cosine {cos(delta, want):.7f}, length ratio {np.linalg.norm(delta) / np.linalg.norm(want):.5f}, "
+                  f"within 5 % {close.mean():.4f}; params checksum {out['params_checksum']!r}")
     if close.mean() <= 0.98 or min(deciles[2:]) <= 0.99:
         problems.append(f"only {close.mean():.4f} of sampled parameters match after 16 updates; by |g| decile: {deciles}")
     if cos(delta, want) <= 0.9999 or abs(np.linalg.norm(delta) / np.linalg.norm(want) - 1.0) > 2e-3:

@@ -44,6 +44,15 @@ __global__ void fill_inds(int64_t* p, int64_t n, int64_t rows) {    // a slice o
     if (i < n) p[i] = (i * 40503 + 17) % rows;
 }
 
+// order-independent 64-bit hash of a tensor's bit patterns: sum_i bits_i * (2 i + 1) mod 2^64 (integer adds commute: the value does
+// not depend on how the grid is scheduled) -- two runs print equal hashes iff (up to collisions) every element is bit-identical
+__global__ void hash_u32(const uint32_t* __restrict__ p, size_t n, unsigned long long* out) {
+    unsigned long long h = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        h += (unsigned long long)p[i] * (2ull * i + 1ull);
+    atomicAdd(out, h);
+}
+
 template <class T> static T* dalloc(size_t n) { void* p; CHECK(hipMalloc(&p, n * sizeof(T))); return (T*)p; }
 
 int main(int argc, char** argv) {
@@ -194,6 +203,20 @@ int main(int argc, char** argv) {
         dump(a1, a1n, 4099); dump(a2, a2n, 1031); dump(a3, a3n, 1031); dump(dz2, a2n, 1031); dump(dz1, a1n, 4099);
         dump(hfc, (size_t)M * 512, 1021); dump(dz3, a3n, 1031); dump(dWfc, 512 * 3136, 211);
         std::fclose(f);
+    }
+    if (std::getenv("CONV_TRAFFIC_HASH")) {
+        unsigned long long* dh = dalloc<unsigned long long>(1);
+        auto hash = [&](const char* name, const float* d, size_t n) {
+            CHECK(hipMemsetAsync(dh, 0, 8, st));
+            hipLaunchKernelGGL(hash_u32, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(d), n, dh);
+            unsigned long long hv = 0;
+            CHECK(hipMemcpyAsync(&hv, dh, 8, hipMemcpyDeviceToHost, st)); CHECK(hipStreamSynchronize(st));
+            std::printf("hash %s %016llx\n", name, hv);
+        };
+        hash("a1", a1, a1n); hash("a2", a2, a2n); hash("a3", a3, a3n); hash("hfc", hfc, (size_t)M * 512);
+        hash("dz3", dz3, a3n); hash("dz2", dz2, a2n); hash("dz1", dz1, a1n);
+        hash("dW1", dW1, 8192); hash("db1", db1, 32); hash("dW2", dW2, 32768); hash("db2", db2, 64); hash("dW3", dW3, 36864); hash("db3", db3, 64);
+        hash("dWfc", dWfc, (size_t)512 * 3136);
     }
     dW = dW1;
     float h[4]; CHECK(hipMemcpy(h, dW, sizeof h, hipMemcpyDeviceToHost));
