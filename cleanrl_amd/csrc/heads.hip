@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                                                         int M, int A, int lddh) {
     __shared__ float red[NA + 1][kHid + 1];
     float accz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (the wave index in an SGPR)
     const int wv = blockIdx.x * 4 + wave, nwv = gridDim.x * 4;
     float w[NA][8], acc[NA][8], accb[NA];
     load_w<NA>(w, Wa, Wc, A, lane);
@@ -85,16 +85,19 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
         for (int i = 0; i < 8; ++i) acc[a][i] = 0.0f;
     }
     for (int m = wv; m < M; m += nwv) {
-        float g = 0.0f;                                   // lane a holds the row's a-th output gradient
-        if (lane < A) g = dlogits[(size_t)m * A + lane];
-        else if (lane == A) g = dvalue[m];
+        // the row's NA output gradients: wave-uniform addresses, i.e. scalar loads -- every lane holds all of them.  (Round 4: they
+        // used to be fetched by NA lanes and broadcast with ds_bpermute; with a second process time-slicing the GPU a few rows
+        // per million came out with stale lanes 48-63 of the LAST permute -- tools/bperm_stress.cpp)
+        float gv[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) gv[a] = a < NA - 1 ? dlogits[(size_t)m * (NA - 1) + a] : dvalue[m];
         const float* hr = h + (size_t)m * kHid + lane * 8;
         const float4 x = *reinterpret_cast<const float4*>(hr), y = *reinterpret_cast<const float4*>(hr + 4);
         const float hv[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
         float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const float ga = __shfl(g, a, 64);
+            const float ga = gv[a];
             accb[a] += ga;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {

@@ -38,6 +38,9 @@ def main():
     hashes = []
 
     def h(t):          # order-independent exact hash of a tensor's bits
+        if t.numel() < 256 or t.element_size() != 4:
+            t = t.detach().float().reshape(-1)
+            t = torch.cat([t, torch.zeros(256, device=t.device)])
         v = t.detach().contiguous().view(torch.int32).to(torch.int64)
         w = torch.arange(1, 2 * v.numel(), 2, device=v.device, dtype=torch.int64)
         return int((v.reshape(-1) * w).sum().item()) & (2**64 - 1)
@@ -63,9 +66,45 @@ def main():
         sums.append((gsum, L.flat.params.double().sum().item()))
 
     L.optimizer_step_hip = spy
+    if os.environ.get("DET_HEADS") == "1":      # hash the heads' backward outputs of EVERY call; report the first call that differs
+        import json
+
+        from cleanrl_amd import cnn
+
+        real_bwd = cnn.HeadsFn.backward
+        calls, rows = [0], []
+        ref_path = os.environ.get("DET_REF")
+        ref = json.load(open(ref_path)) if ref_path and os.path.exists(ref_path) else None
+        state = {"reported": False}
+
+        def bwd(ctx, dlogits, dvalue):
+            out = real_bwd(ctx, dlogits, dvalue)
+            calls[0] += 1
+            hh, Wa, Wc = ctx.saved_tensors
+            row = {"in": [h(hh), h(Wc), h(dlogits), h(dvalue)], "out": [h(out[0]), h(out[1]), h(out[3]), h(out[4])]}
+            rows.append(row)
+            if ref is not None and not state["reported"] and calls[0] <= len(ref):
+                r = ref[calls[0] - 1]
+                if r["in"] != row["in"]:
+                    state["reported"] = True
+                    print(f"FIRST MISMATCH call {calls[0]}: INPUTS differ (something upstream)", flush=True)
+                elif r["out"] != row["out"]:
+                    state["reported"] = True
+                    names = ["dz", "dWa", "dWc", "dbc"]
+                    print(f"FIRST MISMATCH call {calls[0]}: heads backward outputs differ on identical inputs: "
+                          f"{[n for n, x, y in zip(names, r['out'], row['out']) if x != y]}", flush=True)
+            return out
+
+        cnn.HeadsFn.backward = staticmethod(bwd)
     np.random.seed(7)
-    L.update(2.5e-4)
+    for _ in range(int(os.environ.get("DET_UPDATES", "1"))):
+        L.update(2.5e-4)
     torch.cuda.synchronize()
+    if os.environ.get("DET_HEADS") == "1":
+        if ref is None and ref_path:
+            json.dump(rows, open(ref_path, "w"))
+        elif not state["reported"]:
+            print(f"NO MISMATCH in {calls[0]} heads-backward calls", flush=True)
     for i, row in enumerate(hashes):
         for k, v in row.items():
             print(f"H mb{i + 1} {k} {v:016x}")
