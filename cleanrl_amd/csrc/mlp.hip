@@ -622,9 +622,9 @@ __global__ __launch_bounds__(256) void mlp_fold_kernel(const MlpFoldArgs a) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------
-static inline int pick_rows(int64_t rows, int want, int target_blocks) {
+static inline int pick_rows(int64_t rows, int want, int target_blocks, int min_rows = 4) {
     int R = want > 0 ? want : (int)((rows + target_blocks - 1) / target_blocks);
-    if (R < 4) R = 4;
+    if (R < min_rows) R = min_rows;
     if (R > 64) R = 64;
     return R;
 }
@@ -679,7 +679,7 @@ extern "C" MI355PPO_API int mi355ppo_mlp_fwd_f32(const float* obs, int B, int O,
     MI355_REQUIRE(aligned(obs, 4) && aligned(actor_out, 4) && aligned(value, 4), MI355PPO_EALIGN, "%s: misaligned pointer", fn);
     MlpActArgs a = {};
     if ((rc = fill_net(fn, critic, a.net[0])) || (rc = fill_net(fn, actor, a.net[1]))) return rc;
-    a.obs = obs; a.B = B; a.O = O; a.nout = n_out; a.R = pick_rows(B, 0, 256);
+    a.obs = obs; a.B = B; a.O = O; a.nout = n_out; a.R = pick_rows(B, 0, 256, 1);     // rollout: the launch is a latency chain -- one row per wave when the batch allows
     a.value = value; a.actor_out = actor_out;
     return act_launch<false, 0>(fn, a, as_stream(stream));
 }
@@ -700,7 +700,7 @@ extern "C" MI355PPO_API int mi355ppo_mlp_act_categorical_f32(const float* obs, i
                   MI355PPO_EALIGN, "%s: misaligned pointer", fn);
     MlpActArgs a = {};
     if ((rc = fill_net(fn, critic, a.net[0])) || (rc = fill_net(fn, actor, a.net[1]))) return rc;
-    a.obs = obs; a.B = B; a.O = O; a.nout = A; a.R = pick_rows(B, 0, 256);
+    a.obs = obs; a.B = B; a.O = O; a.nout = A; a.R = pick_rows(B, 0, 256, 1);     // rollout: the launch is a latency chain -- one row per wave when the batch allows
     a.noise = noise_exp1; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
     a.action_i64 = action_i64; a.action_f32 = action_f32; a.logprob = logprob; a.entropy = entropy; a.value = value;
     a.actor_out = logits_out;
@@ -722,7 +722,7 @@ extern "C" MI355PPO_API int mi355ppo_mlp_act_normal_f32(const float* obs, int B,
                   MI355PPO_EALIGN, "%s: misaligned pointer", fn);
     MlpActArgs a = {};
     if ((rc = fill_net(fn, critic, a.net[0])) || (rc = fill_net(fn, actor_mean, a.net[1]))) return rc;
-    a.obs = obs; a.B = B; a.O = O; a.nout = D; a.R = pick_rows(B, 0, 256);
+    a.obs = obs; a.B = B; a.O = O; a.nout = D; a.R = pick_rows(B, 0, 256, 1);     // rollout: the launch is a latency chain -- one row per wave when the batch allows
     a.logstd = logstd; a.noise = noise_std_normal; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
     a.action_f32 = action; a.logprob = logprob_sum; a.entropy = entropy_sum; a.value = value; a.actor_out = mean_out;
     return act_launch<true, 1>(fn, a, as_stream(stream));

@@ -434,7 +434,10 @@ class PPOLearner:
         stop = False
         clipfracs = []
         last = None
-        for epoch in range(int(a.update_epochs)):
+        replayed = self.hip and self._update_graphs is not None and a.target_kl is None
+        if replayed:
+            k = self._replay_update(lr, b_inds, b_advantages, use_pack)
+        for epoch in range(0 if replayed else int(a.update_epochs)):
             np.random.shuffle(b_inds)                                     # :315 host MT19937, per-rank seed
             if self.hip:
                 inds_dev = self.upload_permutation(epoch, b_inds)
@@ -587,6 +590,41 @@ class PPOLearner:
         self._mb_adv_md = self._mb_slot = self._pack = None
         self._update_graphs = graphs
 
+    def _replay_update(self, lr: float, b_inds: np.ndarray, b_advantages, use_pack: bool) -> int:
+        """The whole update as graph replays (``capture_update``; no early stop): every epoch's host permutation is drawn first --
+        the same ``np.random.shuffle`` calls in the same order as the epoch loop (:315) --, all of them travel in ONE pinned H2D
+        copy, the advantage statistics of every (epoch, minibatch) come from ONE launch (the flattened permutations are
+        epochs x minibatches consecutive segments), then the slots replay back to back.  Why not per epoch: a host-to-device
+        copy call returns only once the stream has drained (measured: 0.56 ms on an idle stream, +1 ms behind 32 small graphs;
+        tools/gpu/copy_probe.py), which serialised host and GPU at every epoch boundary of the small configurations."""
+        a = self.args
+        E_, B, M = int(a.update_epochs), self.batch_size, self.minibatch_size
+        evs = self.__dict__.setdefault("_inds_ev", {})
+        if evs.get("all") is not None:
+            evs["all"].synchronize()                                      # the previous iteration's copy has read the pinned rows
+        pin_np = self.__dict__.setdefault("_inds_pin_np", self._inds_pin.numpy())
+        for e in range(E_):
+            np.random.shuffle(b_inds)                                     # :315 host MT19937, per-rank seed
+            pin_np[e] = b_inds
+        self._inds_dev.copy_(self._inds_pin, non_blocking=True)
+        if self._inds_dev.is_cuda:
+            if evs.get("all") is None:
+                evs["all"] = torch.cuda.Event()
+            evs["all"].record()
+        if a.norm_adv:                                                    # :337-338 for every slot at once
+            flat = self._inds_dev.view(-1)
+            if use_pack:
+                self.ops.adv_stats_packed(self._pack, flat, M, out=self._adv_md_buf.view(-1, 2))
+            else:
+                self.ops.adv_stats(b_advantages, flat, M, out=self._adv_md_buf.view(-1, 2))
+        self._upload_adam_schedule(lr)                                    # every slot's (step size, bias correction) -> device memory
+        for row in self._update_graphs:
+            for g in row:
+                g.replay()                                                # forward + fused loss + backward + clip + Adam of the slot
+        n = sum(len(row) for row in self._update_graphs)
+        self.flat.step += n
+        return n
+
     def _upload_adam_schedule(self, lr: float) -> None:
         """Rows k = 0 .. slots-1 of the device table the captured optimizer steps read: Adam step ``flat.step + k + 1`` at this
         iteration's learning rate (``ops.adam_schedule``: the library's own arithmetic, so eager and captured steps agree bit for
@@ -594,9 +632,9 @@ class PPOLearner:
         if self._adam_sched_ev is not None:
             self._adam_sched_ev.synchronize()
         pin = self._adam_sched_pin
+        pin_np = self.__dict__.setdefault("_adam_sched_pin_np", pin.numpy())
         for k in range(pin.shape[0]):
-            ns, bc = self.ops.adam_schedule(lr, self.flat.step + k + 1)
-            pin[k, 0], pin[k, 1] = ns, bc
+            pin_np[k] = self.ops.adam_schedule(lr, self.flat.step + k + 1)
         self._adam_sched.copy_(pin, non_blocking=True)
         if self._adam_sched.is_cuda:
             if self._adam_sched_ev is None:

@@ -275,7 +275,8 @@ def test_config_e_whole_iteration_320_updates_on_the_fused_mlp_kernels():
         (err / bar).max(0).round(3), (err / bar).argmax(0) + 1)
     np.testing.assert_allclose(sc[:32], ref[:32], rtol=2e-4, atol=3e-5)          # first epoch: tight
     problems = []
-    for k, (b_el, b_cos) in zip(keep, ((2e-4, 1e-7), (2e-2, 2e-4), (4e-2, 1e-3))):
+    for k, (b_el, b_cos) in zip(keep, ((1e-5, 1e-10), (1e-5, 1e-10), (2e-3, 1e-6))):      # measured 8e-7 / 7e-7 / 1.6e-4; the reference's own
+                                                                                             # distance from itself at 4 CPU threads: 8e-7 / 6e-7 / 1.5e-4
         gh = seen[k].cpu().numpy().astype(np.float64)
         n = np.linalg.norm(gh)
         clipped = gh * min(1.0, args.max_grad_norm / (n + 1e-6))
@@ -287,13 +288,13 @@ def test_config_e_whole_iteration_320_updates_on_the_fused_mlp_kernels():
     got_ls = torch.stack(logstd).cpu().numpy()
     ls_err = np.abs(got_ls - g["logstd_before_step"])
     move = np.abs(g["logstd_before_step"][-1] - g["logstd_before_step"][0]).max()
-    if ls_err.max() > 0.02 * move:
+    if ls_err.max() > 1e-4 * move:
         problems.append(f"actor_logstd trajectory: worst {ls_err.max():.2e} against a total movement of {move:.2e}")
     delta = L.flat.params.cpu().numpy() - g["init_params"]
     want = g["final_params"] - g["init_params"]
     c = float(delta.astype(np.float64) @ want.astype(np.float64) / (np.linalg.norm(delta) * np.linalg.norm(want)))
     close = np.isclose(delta, want, rtol=5e-2, atol=5e-5)
-    if c < 0.999 or close.mean() < 0.97 or abs(np.linalg.norm(delta) / np.linalg.norm(want) - 1) > 1e-2:
+    if c < 0.999999 or close.mean() < 0.999 or abs(np.linalg.norm(delta) / np.linalg.norm(want) - 1) > 1e-4:
         problems.append(f"320-step parameter move: cosine {c:.6f}, length ratio {np.linalg.norm(delta) / np.linalg.norm(want):.5f}, "
                         f"{close.mean():.4f} of the parameters within 5 %")
     print("config E whole iteration vs the reference's lines: values %.2e; scalars worst err/bar per column %s (first epoch worst abs %s); "
