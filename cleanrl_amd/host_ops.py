@@ -6,8 +6,8 @@ CUDA device always runs the HIP kernels and raises if ``libmi355ppo.so`` is miss
 refuse CUDA tensors.  The twins (csrc/host_twins.hip, declared in include/mi355ppo.h) are the device
 kernels' own row / element functions compiled for the host, so the CPU loop crosses the SAME C ABI seams
 as the GPU loop: GAE (ppo.py:218-231), the fused loss forward + backward (ppo.py:250-285 and its autograd)
-and, for tests, sampling and clip + Adam.  ``ppo_loss`` -- the reference's lines in torch ops -- stays for
-the learners whose loss has extra terms (LSTM state, RND's second value head) on the host path.
+and, for tests, sampling and clip + Adam.  The learners whose loss has extra terms (LSTM state, RND's second value
+head and distillation loss) cross the same twin on their logits / value and add their terms outside.
 """
 from __future__ import annotations
 
@@ -208,33 +208,3 @@ def obs_u8_to_f32(src_u8, inds=None, scale_255=True):
     _lib.check(lib.mi355ppo_obs_u8_to_f32_cpu(_p(src), _p(idx), _p(out), rows, row_bytes, int(bool(scale_255))),
                "mi355ppo_obs_u8_to_f32_cpu")
     return out
-
-
-def ppo_loss(newlogprob, entropy, newvalue, mb_logprobs, mb_advantages, mb_returns, mb_values, clip_coef, ent_coef,
-             vf_coef, norm_adv, clip_vloss):
-    """ppo.py:251-285 in torch ops -> (loss, scalars7 in ops.LOSS_SCALAR_NAMES order).  For the host paths of the learners
-    whose loss carries extra terms (learner_lstm / learner_rnd); the plain PPO learner uses the fused twins above."""
-    logratio = newlogprob - mb_logprobs
-    ratio = logratio.exp()
-    with torch.no_grad():
-        old_approx_kl = (-logratio).mean()
-        approx_kl = ((ratio - 1) - logratio).mean()
-        clipfrac = ((ratio - 1.0).abs() > clip_coef).float().mean()
-    if norm_adv:
-        mb_advantages = (mb_advantages - mb_advantages.mean()) / (mb_advantages.std() + 1e-8)
-    pg_loss1 = -mb_advantages * ratio
-    pg_loss2 = -mb_advantages * torch.clamp(ratio, 1 - clip_coef, 1 + clip_coef)
-    pg_loss = torch.max(pg_loss1, pg_loss2).mean()
-    newvalue = newvalue.view(-1)
-    if clip_vloss:
-        v_loss_unclipped = (newvalue - mb_returns) ** 2
-        v_clipped = mb_values + torch.clamp(newvalue - mb_values, -clip_coef, clip_coef)
-        v_loss_clipped = (v_clipped - mb_returns) ** 2
-        v_loss = 0.5 * torch.max(v_loss_unclipped, v_loss_clipped).mean()
-    else:
-        v_loss = 0.5 * ((newvalue - mb_returns) ** 2).mean()
-    entropy_loss = entropy.mean()
-    loss = pg_loss - ent_coef * entropy_loss + v_loss * vf_coef
-    scalars = torch.stack([loss.detach(), pg_loss.detach(), v_loss.detach(), entropy_loss.detach(), old_approx_kl,
-                           approx_kl, clipfrac])
-    return loss, scalars

@@ -149,15 +149,16 @@ class LSTMPPOLearner(PPOLearner):
         """The reference's minibatch body on CPU tensors (:304-352)."""
         a = self.args
         self.optimizer.param_groups[0]["lr"] = lr
-        _, newlogprob, entropy, newvalue, _ = self.agent.get_action_and_value(
-            b_obs[mb_inds],
+        # the network up to its outputs (:304-309: get_action_and_value's forward), then K3 through the C ABI's host-pointer twin:
+        # distribution, loss terms and their gradients down to (logits, value) on the FLAT batch arrays + mb_inds -- the seam the
+        # HIP branch crosses (forward_backward_hip)
+        logits, newvalue, _ = self.agent.heads_seq(
+            self.agent._normalise(b_obs[mb_inds]),
             (self.initial_lstm_state[0][:, mbenvinds], self.initial_lstm_state[1][:, mbenvinds]),
-            b_dones[mb_inds],
-            b_actions.long()[mb_inds],
-        )
-        loss, scalars = host_ops.ppo_loss(newlogprob, entropy, newvalue, b_logprobs[mb_inds], b_advantages[mb_inds],
-                                          b_returns[mb_inds], b_values[mb_inds], a.clip_coef, a.ent_coef, a.vf_coef,
-                                          a.norm_adv, a.clip_vloss)
+            b_dones[mb_inds])
+        loss, scalars = host_ops.ppo_loss_categorical(logits, newvalue, torch.as_tensor(mb_inds, dtype=torch.int64), b_actions,
+                                                      b_logprobs, b_advantages, b_returns, b_values, a.clip_coef, a.ent_coef,
+                                                      a.vf_coef, a.norm_adv, a.clip_vloss)
         self.optimizer.zero_grad()
         loss.backward()
         self._host_allreduce_grads()

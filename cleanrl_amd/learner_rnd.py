@@ -262,16 +262,18 @@ class RNDPPOLearner(PPOLearner):
 
     def _minibatch_rnd_host(self, mb_inds, b_obs, rnd_next_obs, b_actions, b_logprobs, b_advantages, b_ext_returns,
                             b_int_returns, b_ext_values, lr):
-        """The reference's minibatch body on CPU tensors (:461-524).  Returns the 7 scalars of ``host_ops.ppo_loss`` with
+        """The reference's minibatch body on CPU tensors (:461-524).  Returns the 7 scalars of K3's host-pointer twin with
         ``v_loss = ext + int`` and ``loss`` including the distillation term, followed by the distillation loss."""
         a = self.args
         self.optimizer.param_groups[0]["lr"] = lr
         forward_loss = self._forward_loss(rnd_next_obs[mb_inds])
-        _, newlogprob, entropy, new_ext_values, new_int_values = self.agent.get_action_and_value(
-            b_obs[mb_inds], b_actions.long()[mb_inds])
-        ext_loss, sc = host_ops.ppo_loss(newlogprob, entropy, new_ext_values, b_logprobs[mb_inds], b_advantages[mb_inds],
-                                         b_ext_returns[mb_inds], b_ext_values[mb_inds], a.clip_coef, a.ent_coef, a.vf_coef,
-                                         a.norm_adv, a.clip_vloss)
+        # the network's three outputs (get_action_and_value's forward, :478-480), then K3 through the C ABI's host-pointer twin on
+        # the combined advantage and the (clipped) extrinsic value -- the seam the HIP branch crosses (_minibatch_rnd_hip); the
+        # intrinsic value loss and the distillation term are added outside
+        logits, new_ext_values, new_int_values = self.agent.heads3(self.agent._normalise(b_obs[mb_inds]))
+        ext_loss, sc = host_ops.ppo_loss_categorical(logits, new_ext_values, torch.as_tensor(mb_inds, dtype=torch.int64), b_actions,
+                                                     b_logprobs, b_advantages, b_ext_returns, b_ext_values, a.clip_coef, a.ent_coef,
+                                                     a.vf_coef, a.norm_adv, a.clip_vloss)
         int_v_loss = 0.5 * ((new_int_values.view(-1) - b_int_returns[mb_inds]) ** 2).mean()
         loss = ext_loss + int_v_loss * a.vf_coef + forward_loss.view(())
         self.optimizer.zero_grad()

@@ -25,6 +25,14 @@ from cleanrl_amd.learner_rnd import RNDPPOLearner, _Combined
 from cleanrl_amd.learner_smoke import default_args
 
 
+def _host_ppo_loss(*a):
+    """(loss, scalars7) by the oracle's restatement of the reference's loss lines (oracle/torch_oracle.ppo_loss)."""
+    from oracle import torch_oracle as TO
+
+    o = TO.ppo_loss(*a)
+    return o["loss"], torch.stack([o[k].detach() for k in ("loss", "pg_loss", "v_loss", "entropy", "old_approx_kl", "approx_kl", "clipfrac")])
+
+
 def _chk(t, dtype, name, shape=None):
     assert isinstance(t, torch.Tensor), name
     assert t.dtype == dtype, f"{name}: dtype {t.dtype}"
@@ -116,7 +124,7 @@ class FakeOps:
         value = new_value.reshape(-1).clone().requires_grad_(True)
         probs = Categorical(logits=logits)
         acts = b_actions.reshape(-1).long()[mb_inds]
-        loss, sc = host_ops.ppo_loss(probs.log_prob(acts), probs.entropy(), value, b_logprobs.reshape(-1)[mb_inds],
+        loss, sc = _host_ppo_loss(probs.log_prob(acts), probs.entropy(), value, b_logprobs.reshape(-1)[mb_inds],
                                      b_advantages.reshape(-1)[mb_inds], b_returns.reshape(-1)[mb_inds],
                                      b_values.reshape(-1)[mb_inds], clip_coef, ent_coef, vf_coef, norm_adv, clip_vloss)
         loss.backward()
@@ -192,7 +200,7 @@ class FakeOps:
         value = new_value.reshape(-1).clone().requires_grad_(True)
         probs = torch.distributions.Normal(mean, torch.exp(ls.expand_as(mean)))
         acts = b_actions.reshape(Bf, D)[mb_inds]
-        loss, sc = host_ops.ppo_loss(probs.log_prob(acts).sum(1), probs.entropy().sum(1), value, b_logprobs.reshape(-1)[mb_inds],
+        loss, sc = _host_ppo_loss(probs.log_prob(acts).sum(1), probs.entropy().sum(1), value, b_logprobs.reshape(-1)[mb_inds],
                                      b_advantages.reshape(-1)[mb_inds], b_returns.reshape(-1)[mb_inds],
                                      b_values.reshape(-1)[mb_inds], clip_coef, ent_coef, vf_coef, norm_adv, clip_vloss)
         loss.backward()
