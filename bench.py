@@ -369,7 +369,7 @@ def main():
                 images = a[8].shape[0]
                 return f"trunk_fwd(conv1+2+3)@{images}", sum(conv_flop(l, images) for l in cnn.LAYERS), "F"
 
-            def k_wgrad(src, dz, layer, inds=None):
+            def k_wgrad(src, dz, layer, inds=None, out=None):
                 return f"conv{layer}_wgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), chr(lib.mi355ppo_cnn_conv_wgrad_kernel(dz.shape[0], layer))
 
             timed_op("conv_fwd", k_fwd)
@@ -590,8 +590,18 @@ def main():
                           f"num_steps={cb['num_steps']} = {cb['env_steps']} env-steps in {cb['seconds']:.1f} s (median iteration "
                           f"reported; per-iteration s: {[round(x, 2) for x in cb['iteration_seconds']]}) after one untimed warm-up "
                           f"iteration of the same shape; host cpu_count={os.cpu_count()}; the reference script itself cannot run "
-                          f"on this box (no envpool / gym / tyro, and /root/reference does not travel), hence kind=port",
+                          f"on this box (no envpool / gym / tyro, and /root/reference does not travel), hence kind=port; num_envs="
+                          f"{cb['num_envs']}, not the metric's 1024: one iteration at 1024 envs is ~4 minutes of CPU work on these cores "
+                          f"(outside the 10-30 s sample budget); no extrapolation attempted",
             }
+            # the reference's VERBATIM lines at the metric's full size were timed where /root/reference exists (the build container,
+            # 8 cores, while minting tests/golden/atari_iteration_cfgC.npz): reported beside the port, never as `value`
+            rpath = os.path.join(ROOT, "profiles", "r04_reference_lines_cpu_timing.json")
+            if os.path.exists(rpath):
+                r = json.load(open(rpath))
+                out["cpu_baseline"]["reference_lines_at_metric_config"] = {
+                    "value": r["env_steps_per_s"], "unit": "env-steps/s", "cores": r["cores"], "kind": "reference",
+                    "sample": r["what"] + "; " + r["host"] + f"; {r['env_steps']} env-steps in {r['iteration_s']} s; " + r["note"]}
         if world == 1 and not cli.no_pcie_inclusive:
             # never `value`: the same learner fed by HOST envs (numpy stand-ins on host threads), actions D2H and frames H2D
             # every step as in the reference's loop (:269-272), through the overlapped env-group lanes (cleanrl_amd/pipeline.py)

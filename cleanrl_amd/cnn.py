@@ -102,8 +102,9 @@ def conv_dgrad(dz: torch.Tensor, Bt: torch.Tensor, act_in: torch.Tensor, layer: 
     return out
 
 
-def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tensor | None = None):
-    """``(dW (Cout,Cin,K,K), db (Cout))`` from the layer input and the pre-activation gradient."""
+def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tensor | None = None, out=None):
+    """``(dW (Cout,Cin,K,K), db (Cout))`` from the layer input and the pre-activation gradient; ``out=(dW, db)`` writes into the
+    caller's tensors (e.g. the parameters' ``.grad`` views of a flat gradient buffer)."""
     lib = _lib.load()
     cin, cout, k, _, hin, hout = LAYERS[layer]
     images = dz.shape[0]
@@ -118,8 +119,11 @@ def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tens
         assert inds is None
         _chk(src, torch.float32, "src", (images, hin, hin, cin))
     dev = dz.device
-    dW = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
-    db = torch.empty(cout, dtype=torch.float32, device=dev)
+    if out is not None:
+        dW, db = _chk(out[0], torch.float32, "dW", (cout, cin, k, k)), _chk(out[1], torch.float32, "db", (cout,))
+    else:
+        dW = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
+        db = torch.empty(cout, dtype=torch.float32, device=dev)
     ws = _workspace(dev, lib.mi355ppo_cnn_conv_wgrad_workspace_bytes(images, layer))
     with _on(dev):
         st = lib.mi355ppo_cnn_conv_wgrad_f32(_ptr(src), _ptr(inds), _ptr(dz), _ptr(dW), _ptr(db), images, layer, _ptr(ws),
@@ -348,6 +352,11 @@ class _Buffers:
         self.last_a3_bits = None           # ... and its ReLU mask as bits, when the trunk's forward wrote one (kernel Z, gradients enabled)
         self.a3_grad_is_masked = False     # set by LinearReLUHwcFn.backward when conv3's ReLU backward rode in the FC data gradient
         self.fc_dz_from_heads = None       # (data pointer of dz, FC bias gradient) when the FC layer's ReLU backward rode in HeadsFn.backward
+        # direct_grads: the backward nodes WRITE their parameter gradients into the parameters' .grad tensors (views of a flat gradient
+        # buffer that the optimizer kernel leaves zeroed) and hand autograd None -- no temporary, no AccumulateGrad add per parameter
+        # (12 small launches per minibatch).  Only an owner that guarantees zeroed .grad before every backward sets it (PPOLearner).
+        self.direct_grads = False
+        self.after_fc_wgrad = None         # callback(param) once Linear(3136,512).weight's gradient is final (world > 1: early all-reduce)
 
     def fc_weight(self, W: torch.Tensor) -> torch.Tensor:
         """Linear(3136,512) weight with (h,w,c)-ordered input features, cached like the conv matrices (re-derived INTO the
@@ -454,6 +463,7 @@ class NatureTrunkFn(torch.autograd.Function):
             conv_fwd(a1, bufs.weights(W2, 2, MODE_FWD), b2.detach(), 2, None, a2)
             conv_fwd(a2, bufs.weights(W3, 3, MODE_FWD), b3.detach(), 3, None, a3)
             ctx.obs, ctx.inds, ctx.acts, ctx.bufs, ctx.bits = obs_u8, inds, (a1, a2, a3), bufs, None
+            ctx.params = (W1, b1, W2, b2, W3, b3)
             bufs.last_a3_ptr, bufs.last_a3_bits = a3.data_ptr(), None
             ctx.save_for_backward(W2, W3)
             return a3
@@ -482,6 +492,7 @@ class NatureTrunkFn(torch.autograd.Function):
             conv_fwd(a1, bufs.weights(W2, 2, MODE_FWD), b2.detach(), 2, None, a2)
             conv_fwd(a2, bufs.weights(W3, 3, MODE_FWD), b3.detach(), 3, None, a3)
         ctx.obs, ctx.inds, ctx.acts, ctx.bufs = obs_u8, inds, (a1, a2, a3), bufs
+        ctx.params = (W1, b1, W2, b2, W3, b3)
         bufs.last_a3_ptr = a3.data_ptr()
         ctx.save_for_backward(W2, W3)
         return a3
@@ -497,7 +508,9 @@ class NatureTrunkFn(torch.autograd.Function):
             dz3 = da3.contiguous().view(a3.shape)
         else:
             dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)    # ReLU backward of the last conv
-        dW3, db3 = conv_wgrad(a2, dz3, 3)
+        direct = ctx.bufs.direct_grads and all(p.grad is not None for p in ctx.params)
+        gout = (lambda l: (ctx.params[2 * l - 2].grad, ctx.params[2 * l - 1].grad)) if direct else (lambda l: None)
+        dW3, db3 = conv_wgrad(a2, dz3, 3, out=gout(3))
         # (layer-3 data gradient: kernel Z multiplies the padding taps, 1.65 x the MFMAs, and still beats kernel F's nine
         # border-class launches at every size measured: profiles/r03_conv_traffic_ab_same_box.jsonl)
         bits = ctx.bits
@@ -507,14 +520,16 @@ class NatureTrunkFn(torch.autograd.Function):
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # no padding zeros
         else:
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1), a2, 3, dz2)
-        dW2, db2 = conv_wgrad(a1, dz2, 2)
+        dW2, db2 = conv_wgrad(a1, dz2, 2, out=gout(2))
         if _CONV_Z and a1.numel() * 4 < BUF_LIMIT:
             conv_dgrad_packed(dz2, ctx.bufs.conv_zpack(W2, 2, MODE_DGRAD_S2), a1, 2, dz1, bits=bits[0] if bits else None)
         elif a1.numel() * 4 < BUF_LIMIT:
             conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2_CLASSES), a1, 2, dz1, variant=VARIANT_DGRAD2_CLASSES)   # no padding zeros
         else:
             conv_dgrad(dz2, ctx.bufs.weights(W2, 2, MODE_DGRAD_S2), a1, 2, dz1)
-        dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds)
+        dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds, out=gout(1))
+        if direct:
+            return (None,) * 10
         return None, None, dW1, db1, dW2, db2, dW3, db3, None, None
 
 
@@ -557,6 +572,7 @@ class LinearReLUHwcFn(torch.autograd.Function):
             Wp = bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()).contiguous()
             h = torch._addmm_activation(b.detach(), a, Wp.t())                 # bias + ReLU fused into the GEMM epilogue
         ctx.bufs = bufs
+        ctx.bias = b
         ctx.save_for_backward(a, h, W)
         return h
 
@@ -583,10 +599,18 @@ class LinearReLUHwcFn(torch.autograd.Function):
             else:
                 da = dz @ (bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()))
         m, n = dz.shape
-        if ctx.fcz and n % 64 == 0 and a.shape[1] % 224 == 0 and a.shape[1] % 64 == 0:
-            dW = fc_wgrad(dz, a, 64)               # kernel W (bf16 pipe), written in the (c, h, w) feature order of W itself
+        wk = ctx.fcz and n % 64 == 0 and a.shape[1] % 224 == 0 and a.shape[1] % 64 == 0
+        direct = bool(wk and bufs is not None and bufs.direct_grads and W.grad is not None and ctx.bias.grad is not None
+                      and W.grad.is_contiguous())
+        if wk:
+            dW = fc_wgrad(dz, a, 64, out=W.grad if direct else None)   # kernel W (bf16 pipe), written in the (c, h, w) feature order of W itself
         else:
             dW = (dz.t() @ a).view(n, 7, 7, 64).permute(0, 3, 1, 2).reshape(n, 64 * 7 * 7)     # back to the (c, h, w) feature order
+        if direct:
+            ctx.bias.grad.copy_(db if db is not None else dz.sum(0))      # (512 floats)
+            if bufs.after_fc_wgrad is not None:
+                bufs.after_fc_wgrad(W)
+            return da, None, None, None
         return da, dW, (db if db is not None else dz.sum(0)), None
 
 
@@ -617,6 +641,7 @@ class HeadsFn(torch.autograd.Function):
                                             _stream(h.device))
         _lib.check(st, "mi355ppo_heads_fwd_f32")
         ctx.save_for_backward(h, Wa, Wc)
+        ctx.biases = (ba, bc)
         return logits, value
 
     @staticmethod
@@ -631,8 +656,13 @@ class HeadsFn(torch.autograd.Function):
         bufs = ctx.relu_bufs
         # (ReLU variant: dz with a padded row pitch -- kernel Z's A operand at K = 512, see FC_PAD)
         dh = bufs.fc_dz(M, H, dev) if bufs is not None else torch.empty_like(h)
-        dWa, dba = torch.empty_like(Wa), torch.empty(A, dtype=torch.float32, device=dev)
-        dWc, dbc = torch.empty_like(Wc), torch.empty(1, dtype=torch.float32, device=dev)
+        ba, bc = ctx.biases
+        direct = bool(bufs is not None and bufs.direct_grads and all(p.grad is not None and p.grad.is_contiguous() for p in (Wa, ba, Wc, bc)))
+        if direct:                                        # the kernel's reduction writes the gradients where the optimizer reads them
+            dWa, dba, dWc, dbc = Wa.grad, ba.grad, Wc.grad, bc.grad
+        else:
+            dWa, dba = torch.empty_like(Wa), torch.empty(A, dtype=torch.float32, device=dev)
+            dWc, dbc = torch.empty_like(Wc), torch.empty(1, dtype=torch.float32, device=dev)
         ws = _workspace(dev, lib.mi355ppo_heads_bwd_workspace_bytes(M, A))
         with _on(dev):
             if bufs is not None:
@@ -645,4 +675,6 @@ class HeadsFn(torch.autograd.Function):
                 st = lib.mi355ppo_heads_bwd_f32(_ptr(h), _ptr(Wa), _ptr(Wc), _ptr(dlogits), _ptr(dvalue), _ptr(dh), _ptr(dWa),
                                                 _ptr(dba), _ptr(dWc), _ptr(dbc), M, A, H, _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(st, "mi355ppo_heads_bwd_relu_f32" if bufs is not None else "mi355ppo_heads_bwd_f32")
+        if direct:
+            return dh, None, None, None, None, None
         return dh, dWa, dba, dWc, dbc, None

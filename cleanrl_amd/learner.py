@@ -230,9 +230,21 @@ class PPOLearner:
                 from . import cnn
 
                 self.agent._trunk = cnn.NatureTrunk()
-            self.agent._trunk.bufs.cache_weights = True      # this learner bumps weights_version after every optimiser step
+            self._own_trunk_buffers()
             return self.agent.heads_u8(obs_rows)
         return self.agent.heads(self._features(obs_rows))
+
+    def _own_trunk_buffers(self) -> None:
+        """This learner owns the trunk's buffers: it bumps ``weights_version`` after every optimiser step (cached packs), and its
+        flat gradient buffer is zeroed by the optimizer kernel before every backward, so the backward nodes may write parameter
+        gradients straight into the ``.grad`` views (``direct_grads``; MI355PPO_DIRECT_GRADS=0: through autograd's accumulation)."""
+        bufs = self.agent._trunk.bufs
+        bufs.cache_weights = True
+        if not getattr(bufs, "_owned", False):
+            bufs._owned = True
+            bufs.direct_grads = os.environ.get("MI355PPO_DIRECT_GRADS", "1") != "0"
+            if self._ar_early is not None:              # world > 1: the early bucket's all-reduce starts when its gradient is final
+                bufs.after_fc_wgrad = self._early_all_reduce
 
     def warm_rollout_caches(self) -> None:
         """Re-derive the cached forward matrices on the current stream, so that the env-group lanes of a rollout
@@ -244,7 +256,7 @@ class PPOLearner:
         if self.agent._trunk is None:
             self.agent._trunk = cnn.NatureTrunk()
         bufs, net = self.agent._trunk.bufs, self.agent.network
-        bufs.cache_weights = True
+        self._own_trunk_buffers()
         bufs.weights(net[0].weight, 1, cnn.MODE_FWD_Q)
         bufs.weights(net[2].weight, 2, cnn.MODE_FWD)
         bufs.weights(net[4].weight, 3, cnn.MODE_FWD)
@@ -416,6 +428,12 @@ class PPOLearner:
         ``--target-kl``: resolved at once -- the early stop needs the value.)"""
         a = self.args
         B, M = self.batch_size, self.minibatch_size
+        if self.hip and self.image and self.fused_cnn:
+            if self.agent._trunk is None:
+                from . import cnn
+
+                self.agent._trunk = cnn.NatureTrunk()
+            self._own_trunk_buffers()
         b_inds = np.arange(B)                                             # :312
         b_obs = self.obs.reshape((-1,) + self.obs_shape)                  # :304-309, views
         b_actions = self.actions.reshape((-1,) + self.act_shape)

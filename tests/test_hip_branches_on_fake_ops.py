@@ -524,7 +524,7 @@ class FakeCnn:
             return gi.contiguous()
         return _chk(out, torch.float32, "out", tuple(gi.shape)).copy_(gi)
 
-    def conv_wgrad(self, src, dz, layer, inds=None):
+    def conv_wgrad(self, src, dz, layer, inds=None, out=None):
         from cleanrl_amd import cnn
 
         cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
@@ -534,6 +534,10 @@ class FakeCnn:
             _chk(src, torch.uint8, "src")
             x = x.float() / 255.0
         dW = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (cout, cin, k, k), dz.permute(0, 3, 1, 2), stride=s)
+        if out is not None:                        # direct_grads: the kernel writes where the optimizer reads
+            _chk(out[0], torch.float32, "dW", (cout, cin, k, k)).copy_(dW)
+            _chk(out[1], torch.float32, "db", (cout,)).copy_(dz.sum((0, 1, 2)))
+            return out
         return dW, dz.sum((0, 1, 2))
 
     # ---- kernel Z (round 3): a pack is derived from a repacked (N, K) matrix and remembers which (weights, layer, mode) that was
