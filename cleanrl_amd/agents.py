@@ -146,6 +146,24 @@ class AtariAgent(_DiscreteMixin, nn.Module):
             return cnn.HeadsFn.apply(hidden, self.actor.weight, self.actor.bias, self.critic.weight, self.critic.bias, self._trunk.bufs)
         return self.actor(hidden), self.critic(hidden)      # > 7 actions: library GEMMs
 
+    def act_u8(self, obs_rows, seed, offset, offset_base=None, action_f32_out=None, logprob_out=None, value_out=None, want_i64=True):
+        """The learner's rollout step on uint8 rows (no autograd graph): trunk, then Linear(3136,512) + heads + Categorical draw in two
+        launches (``cnn.fc_heads_act_categorical``).  None when the fused step does not apply (wide action spaces, huge batches)."""
+        from . import cnn
+
+        if self._trunk is None:
+            self._trunk = cnn.NatureTrunk()
+        net = self.network
+        if torch.is_grad_enabled() or not cnn.heads_supported(self.actor, self.critic):
+            return None
+        feats = self._trunk(obs_rows, None, net[0], net[2], net[4])
+        if not cnn.fc_heads_act_supported(feats):
+            return None
+        return cnn.fc_heads_act_categorical(feats, self._trunk.bufs.fc_pack_fwd(net[7].weight), net[7].bias.detach().contiguous(),
+                                            self.actor.weight.detach(), self.actor.bias.detach(), self.critic.weight.detach(),
+                                            self.critic.bias.detach(), seed, offset, offset_base, action_f32_out, logprob_out, value_out,
+                                            want_i64=want_i64)
+
     def get_value(self, x):
         return self.critic(self.network(self._normalise(x)))
 

@@ -185,6 +185,42 @@ def fc_fwd_relu_packed(a: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, 
     return out
 
 
+def fc_heads_act_supported(a: torch.Tensor, N: int = 512) -> bool:
+    """The fused rollout step behind the trunk applies to rollout-sized batches (the FC forward splits K below 4,096 rows)."""
+    return bool(a.is_cuda and a.dim() == 2 and a.shape[1] % 16 == 0 and a.stride(1) == 1 and
+                _lib.load().mi355ppo_fc_fwd_workspace_bytes(a.shape[0], N, a.shape[1]) > 0)
+
+
+def fc_heads_act_categorical(a: torch.Tensor, pack: torch.Tensor, fc_bias: torch.Tensor, Wa, ba, Wc, bc, seed: int, offset: int,
+                             offset_base=None, action_f32_out=None, logprob_out=None, value_out=None, noise_exp1=None, want_i64: bool = True):
+    """``a`` = the trunk's (M, 3136) features -> Linear(3136,512) + ReLU (K split over the grid), actor / critic heads, Categorical
+    sample + log-prob: two launches (``mi355ppo_fc_heads_act_categorical_f32``).  -> ``(action_i64 | None, action_f32, logprob, value)``."""
+    lib = _lib.load()
+    M, K = a.shape
+    lda = _row_major(a, "a")
+    A, H = Wa.shape
+    dev = a.device
+    _chk(fc_bias, torch.float32, "fc_bias", (H,))
+    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(H, K),))
+    a64 = torch.empty(M, dtype=torch.int64, device=dev) if want_i64 else None
+    af = action_f32_out if action_f32_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    lp = logprob_out if logprob_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    val = value_out if value_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    for t, nm in ((af, "action_f32_out"), (lp, "logprob_out"), (val, "value_out")):
+        _chk(t, torch.float32, nm, (M,))
+    if offset_base is not None:
+        _chk(offset_base, torch.int64, "offset_base", (1,))
+    if noise_exp1 is not None:
+        _chk(noise_exp1, torch.float32, "noise_exp1", (M, A))
+    ws = _workspace(dev, lib.mi355ppo_fc_fwd_workspace_bytes(M, H, K))
+    with _on(dev):
+        st = lib.mi355ppo_fc_heads_act_categorical_f32(_ptr(a), lda, _ptr(pack), _ptr(fc_bias), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), M, A, H, K,
+                                                       _ptr(noise_exp1), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), _ptr(offset_base),
+                                                       _ptr(a64), _ptr(af), _ptr(lp), _ptr(val), None, _ptr(ws), ws.numel(), _stream(dev))
+    _lib.check(st, "mi355ppo_fc_heads_act_categorical_f32")
+    return a64, af, lp, val
+
+
 def fc_dgrad_mask_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor, out: torch.Tensor | None = None,
                          bits: torch.Tensor | None = None) -> torch.Tensor:
     """``(dz @ B.T) * (act_in > 0)`` with ``pack = fc_pack(B)``, B (N, K) = the transposed weight: kernel Z.  ``bits``: the mask

@@ -59,5 +59,42 @@ MI355_HD void categorical_row(const float (&x)[AMAX], int A, CatRow<AMAX>& out) 
     out.H = -h;
 }
 
+// One draw of torch.multinomial(probs, 1) for a row whose CatRow is `c`: argmax_j probs_j / q_j with q ~ Exp(1) (ATen's
+// multinomial; first maximum wins).  The draws are the caller's (`noise_row`, parity mode) or come from the Philox stream keyed by
+// (seed; counter = row * ceil(A / 4) + j / 4, offset): the ONE definition behind K2 (distributions.hip), K7's rollout step (mlp.hip)
+// and the fused FC + heads + sampling kernel of the NatureCNN rollout (heads.hip) -- same row, same words, same action.
+template <int AMAX>
+__device__ __forceinline__ int categorical_sample_row(const CatRow<AMAX>& c, int A, const float* __restrict__ noise_row, uint64_t seed,
+                                                      uint64_t offset, uint64_t row, float* best_lp_out) {
+    float q[AMAX];
+    if (noise_row) {
+#pragma unroll
+        for (int j = 0; j < AMAX; ++j) q[j] = j < A ? noise_row[j] : 1.0f;
+    } else {
+        const Philox rng(seed);
+        const int nblk = (A + 3) / 4;
+#pragma unroll
+        for (int g = 0; g < (AMAX + 3) / 4; ++g) {
+            if (g * 4 < A) {
+                const uint4 r = rng(row * nblk + g, offset);
+                const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (g * 4 + k < AMAX) q[g * 4 + k] = -logf(u32_to_unit_open(rr[k]));
+            }
+        }
+    }
+    int best = 0;
+    float bestv = -INFINITY, best_lp = 0.0f;
+#pragma unroll
+    for (int j = 0; j < AMAX; ++j) {
+        if (j < A) {
+            const float v = c.p[j] / q[j];
+            if (v > bestv) { bestv = v; best = j; best_lp = c.lp[j]; }
+        }
+    }
+    *best_lp_out = best_lp;
+    return best;
+}
 
 }  // namespace mi355ppo

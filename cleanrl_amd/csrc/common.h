@@ -24,6 +24,10 @@ int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz
 bool convw_applies(int64_t images, int layer);
 int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s);
 
+// kernel Z (gemmz.hip): the K-split raw partials of the rollout-sized FC forward, (splits, M, N) f32 into `ws`
+int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
+                    hipStream_t stream);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Term pairs of the three-term bf16 split multiplied by kernels Z (gemmz.hip), W (fcw.hip) and V (convw.hip): 9 = all 3 x 3 (every f32

@@ -31,35 +31,9 @@ __global__ __launch_bounds__(256) void categorical_sample_kernel(const float* __
     CatRow<AMAX> c;
     categorical_row<AMAX>(x, A, c);
 
-    float q[AMAX];
-    if (noise) {
-        load_row<AMAX>(q, noise + (int64_t)row * A, A);
-    } else {
-        const Philox rng(seed);
-        const int nblk = (A + 3) / 4;
-        if (offset_base) offset += *offset_base;       // the stream position lives in device memory: a captured launch can be replayed
-#pragma unroll
-        for (int g = 0; g < (AMAX + 3) / 4; ++g) {
-            if (g * 4 < A) {
-                const uint4 r = rng((uint64_t)row * nblk + g, offset);
-                const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (g * 4 + k < AMAX) q[g * 4 + k] = -logf(u32_to_unit_open(rr[k]));
-            }
-        }
-    }
-    // multinomial(probs, 1) == argmax_j probs_j / q_j (first maximum wins)
-    int best = 0;
-    float bestv = -INFINITY;
-    float best_lp = 0.0f;
-#pragma unroll
-    for (int j = 0; j < AMAX; ++j) {
-        if (j < A) {
-            const float v = c.p[j] / q[j];
-            if (v > bestv) { bestv = v; best = j; best_lp = c.lp[j]; }
-        }
-    }
+    if (offset_base) offset += *offset_base;           // the stream position lives in device memory: a captured launch can be replayed
+    float best_lp;
+    const int best = categorical_sample_row<AMAX>(c, A, noise ? noise + (int64_t)row * A : nullptr, seed, offset, (uint64_t)row, &best_lp);
     if (action_i64) action_i64[row] = best;
     if (action_f32) action_f32[row] = (float)best;
     logprob[row] = best_lp;

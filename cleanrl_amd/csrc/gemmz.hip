@@ -875,6 +875,24 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_ws_f32(const float* a, i
     return check_launch(fn);
 }
 
+// The K-split half of mi355ppo_fc_fwd_relu_packed_ws_f32 alone: raw partials of a (M, K) x pack -> (splits, M, N) in `ws`; the caller
+// folds them (heads.hip's fused FC-fold + heads + sampling kernel of the rollout).  Returns the number of splits in *splits (>= 2).
+namespace mi355ppo {
+int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
+                    hipStream_t stream) {
+    const size_t need = mi355ppo_fc_fwd_workspace_bytes(M, N, K);
+    MI355_REQUIRE(need > 0 && N % 4 == 0, MI355PPO_EINVAL, "%s: M=%d rows need no K split (use the unfused entry points from 4,096 rows on)", fn, M);
+    int rc = zgemm_check(fn, a, pack, static_cast<const float*>(ws), M, N, K, lda, N);
+    if (rc) return rc;
+    MI355_REQUIRE(ws && aligned(ws, 16) && ws_bytes >= need, MI355PPO_EWORKSPACE, "%s: workspace of %zu bytes, %zu needed (mi355ppo_fc_fwd_workspace_bytes)",
+                  fn, ws ? ws_bytes : (size_t)0, need);
+    ZArgs za = zargs(a, (long long)M * lda * 4, lda, pack, nullptr, nullptr, static_cast<float*>(ws), (long long)M * N * 4, N, M, N, K);
+    za.steps_per = zsplit_steps_per(M, N, K);
+    *splits = (K / 16 + za.steps_per - 1) / za.steps_per;
+    return z_launch<ZRowsLinear, 2, 2, 4, Z_RAW, true, 2>(za, stream, fn);
+}
+}  // namespace mi355ppo
+
 static int fc_dgrad_impl(const char* fn, const float* dz, int lddz, const void* pack, const float* act_in, const unsigned* bits, float* da,
                          int M, int N, int K, void* stream) {
     int rc = zgemm_check(fn, dz, pack, da, M, N, K, lddz, N);

@@ -12,6 +12,7 @@
 // stay in registers over all rows a wave visits; waves -> workgroup (LDS, wave order) -> grid partials are folded in a
 // fixed order (deterministic).  Algorithmic bytes: forward 2048*M + 4*NA*M, backward 4096*M + 4*NA*M (+ partials).
 #include "common.h"
+#include "catrow.h"
 
 #pragma clang fp contract(off)
 
@@ -62,6 +63,69 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
     }
 }
 
+// Rollout step, fused (round 4): the K-split fold of the FC layer (h = relu(bias + part[0] + part[1] + ...), the order of
+// gemmz.hip's zsplit_reduce_kernel), the two heads (heads_fwd_kernel's arithmetic: 8 products per lane, wave butterfly, + bias) and
+// the Categorical draw (catrow.h's row functions: K2's) of one row per wave iteration -- action, log-prob and value go straight
+// into their rollout-storage rows.  Four launches of a captured env step (fold, heads, sample, the value copy) become one; the
+// results are bit-identical to the four (tests/test_gpu_kernels.py).
+template <int NA>
+__global__ __launch_bounds__(256) void heads_act_kernel(const float* __restrict__ part, int splits, size_t slab, const float* __restrict__ fc_bias,
+                                                        const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                        const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                        const float* __restrict__ noise, uint64_t seed, uint64_t offset,
+                                                        const uint64_t* __restrict__ offset_base, int64_t* __restrict__ action_i64,
+                                                        float* __restrict__ action_f32, float* __restrict__ logprob,
+                                                        float* __restrict__ value, float* __restrict__ hidden, int M) {
+    constexpr int A = NA - 1;
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
+    float w[NA][8];
+    load_w<NA>(w, Wa, Wc, A, lane);
+    float fb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fb[i] = fc_bias[lane * 8 + i];
+    if (offset_base) offset += *offset_base;
+    for (int m = wv; m < M; m += nwv) {
+        const float* pr = part + (size_t)m * kHid + lane * 8;
+        float4 x = *reinterpret_cast<const float4*>(pr), y = *reinterpret_cast<const float4*>(pr + 4);
+        for (int z = 1; z < splits; ++z) {
+            const float4 p = *reinterpret_cast<const float4*>(pr + (size_t)z * slab), q = *reinterpret_cast<const float4*>(pr + (size_t)z * slab + 4);
+            x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+            y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
+        }
+        float hv[8] = {x.x + fb[0], x.y + fb[1], x.z + fb[2], x.w + fb[3], y.x + fb[4], y.y + fb[5], y.z + fb[6], y.w + fb[7]};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hv[i] = hv[i] > 0.0f ? hv[i] : 0.0f;
+        if (hidden) {
+            float* hr = hidden + (size_t)m * kHid + lane * 8;
+            *reinterpret_cast<float4*>(hr) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+            *reinterpret_cast<float4*>(hr + 4) = make_float4(hv[4], hv[5], hv[6], hv[7]);
+        }
+        float out[NA];                                  // every lane ends up with all NA sums (the butterfly is an all-reduce)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += hv[i] * w[a][i];
+            out[a] = wave_sum(s) + (a < A ? ba[a] : bc[0]);
+        }
+        if (lane == 0) {
+            constexpr int AMAX = A <= 4 ? 4 : 8;
+            float xl[AMAX];
+#pragma unroll
+            for (int j = 0; j < AMAX; ++j) xl[j] = j < A ? out[j < A ? j : 0] : -INFINITY;
+            CatRow<AMAX> c;
+            categorical_row<AMAX>(xl, A, c);
+            float best_lp;
+            const int best = categorical_sample_row<AMAX>(c, A, noise ? noise + (size_t)m * A : nullptr, seed, offset, (uint64_t)m, &best_lp);
+            if (action_i64) action_i64[m] = best;
+            if (action_f32) action_f32[m] = (float)best;
+            logprob[m] = best_lp;
+            value[m] = out[A];
+        }
+    }
+}
+
 // RELU: h is the output of a ReLU (the FC layer's, ppo_atari_multigpu.py:145): the gradient written is the one with
 // respect to that layer's PRE-activation, dz = dh * (h > 0), and its column sums (that layer's bias gradient) are
 // accumulated as one more partial row -- both for free here (h and dh are in registers), a `threshold_backward` pass over
@@ -87,7 +151,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
     for (int m = wv; m < M; m += nwv) {
         // the row's NA output gradients: wave-uniform addresses, i.e. scalar loads -- every lane holds all of them.  (Round 4: they
         // used to be fetched by NA lanes and broadcast with ds_bpermute; with a second process time-slicing the GPU a few rows
-        // per million came out with stale lanes 48-63 of the LAST permute -- tools/bperm_stress.cpp)
+        // per million came out with stale lanes 48-63 of the LAST permute -- tools/gpu/heads_stress.py)
         float gv[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) gv[a] = a < NA - 1 ? dlogits[(size_t)m * (NA - 1) + a] : dvalue[m];
@@ -203,6 +267,36 @@ extern "C" MI355PPO_API int mi355ppo_heads_fwd_f32(const float* h, const float* 
     }
 #undef LAUNCH
     return check_launch("heads_fwd_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_fc_heads_act_categorical_f32(const float* a3, int lda, const void* fc_pack, const float* fc_bias,
+                                                                  const float* Wa, const float* ba, const float* Wc, const float* bc, int M,
+                                                                  int A, int H, int K, const float* noise_exp1, uint64_t seed,
+                                                                  uint64_t offset, const uint64_t* offset_base, int64_t* action_i64,
+                                                                  float* action_f32, float* logprob, float* value, float* hidden_out,
+                                                                  void* workspace, size_t workspace_bytes, void* stream) {
+    const char* fn = "mi355ppo_fc_heads_act_categorical_f32";
+    MI355_REQUIRE(a3 && fc_pack && fc_bias && Wa && ba && Wc && bc && logprob && value, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(action_i64 || action_f32, MI355PPO_EINVAL, "%s: no action output", fn);
+    int rc = heads_check(fn, M, A, H);
+    if (rc) return rc;
+    MI355_REQUIRE(aligned(Wa, 16) && aligned(Wc, 16) && aligned(fc_bias, 4) && aligned(ba, 4) && aligned(bc, 4) && aligned(noise_exp1, 4) &&
+                      aligned(offset_base, 8) && aligned(action_i64, 8) && aligned(action_f32, 4) && aligned(logprob, 4) && aligned(value, 4) &&
+                      aligned(hidden_out, 16), MI355PPO_EALIGN, "%s: Wa / Wc / hidden_out must be 16-byte aligned", fn);
+    int splits = 0;
+    rc = z_fc_raw_launch(fn, a3, lda, fc_pack, M, H, K, workspace, workspace_bytes, &splits, as_stream(stream));
+    if (rc) return rc;
+    const dim3 grid(heads_grid(M));
+    const float* part = static_cast<const float*>(workspace);
+    const size_t slab = (size_t)M * kHid;
+#define LAUNCH(NA) hipLaunchKernelGGL((heads_act_kernel<NA>), grid, dim3(256), 0, as_stream(stream), part, splits, slab, fc_bias, Wa, ba, Wc, bc, \
+                                      noise_exp1, seed, offset, offset_base, action_i64, action_f32, logprob, value, hidden_out, M)
+    switch (A + 1) {
+        case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break;
+        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;
+    }
+#undef LAUNCH
+    return check_launch("heads_act_kernel");
 }
 
 extern "C" MI355PPO_API size_t mi355ppo_heads_bwd_workspace_bytes(int M, int A) {

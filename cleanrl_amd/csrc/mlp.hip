@@ -231,33 +231,8 @@ __global__ __launch_bounds__(64) void mlp_act_kernel(const MlpActArgs a) {
         for (int j = 0; j < AMAX; ++j) x[j] = j < A ? out[j] : -INFINITY;
         CatRow<AMAX> c;
         categorical_row<AMAX>(x, A, c);
-        float q[AMAX];
-        if (a.noise) {
-#pragma unroll
-            for (int j = 0; j < AMAX; ++j) q[j] = j < A ? a.noise[row * A + j] : 1.0f;
-        } else {                                   // the stream of categorical_sample_kernel: counter = row * nblk + g
-            const Philox rng(a.seed);
-            const int nblk = (A + 3) / 4;
-#pragma unroll
-            for (int g = 0; g < (AMAX + 3) / 4; ++g) {
-                if (g * 4 < A) {
-                    const uint4 r = rng((uint64_t)row * nblk + g, offset);
-                    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (g * 4 + k < AMAX) q[g * 4 + k] = -logf(u32_to_unit_open(rr[k]));
-                }
-            }
-        }
-        int best = 0;
-        float bestv = -INFINITY, best_lp = 0.0f;
-#pragma unroll
-        for (int j = 0; j < AMAX; ++j) {
-            if (j < A) {
-                const float v = c.p[j] / q[j];
-                if (v > bestv) { bestv = v; best = j; best_lp = c.lp[j]; }
-            }
-        }
+        float best_lp;
+        const int best = categorical_sample_row<AMAX>(c, A, a.noise ? a.noise + row * A : nullptr, a.seed, offset, (uint64_t)row, &best_lp);
         if (a.action_i64) a.action_i64[row] = best;
         if (a.action_f32) a.action_f32[row] = (float)best;
         a.logprob[row] = best_lp;

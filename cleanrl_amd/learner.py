@@ -36,6 +36,9 @@ import torch.optim as optim
 from . import host_ops
 
 
+_FUSED_ACT = os.environ.get("MI355PPO_FUSED_ACT", "1") != "0"      # A/B: the rollout step's FC fold + heads + sampling as one kernel
+
+
 class PendingMetrics:
     """Diagnostics of one ``PPOLearner.update_async`` call: ``result()`` waits for the copies (HIP path) and computes what the
     reference logs per iteration (ppo_atari_multigpu.py:382-397)."""
@@ -292,6 +295,20 @@ class PPOLearner:
             return self.ops.mlp_act_normal(obs_rows, *self.mlp, self.agent.actor_logstd.detach(), seed=seed, offset=off,
                                            offset_base=rng_base, action_out=self.actions[step][lo:hi],
                                            logprob_out=self.logprobs[step][lo:hi], value_out=self.values[step][lo:hi])[0]
+        if self.hip and self.discrete and self.image and self.fused_cnn and hasattr(self.agent, "act_u8") and _FUSED_ACT:
+            # trunk, then Linear(3136,512) + heads + Categorical draw in two launches; action / log-prob / value written in place
+            if self.agent._trunk is None:
+                from . import cnn
+
+                self.agent._trunk = cnn.NatureTrunk()
+            self._own_trunk_buffers()
+            seed, off = (self.agent.rng.seed, self.agent.rng.offset + 1) if rng_offset is None else (self.agent.rng.seed, int(rng_offset))
+            r = self.agent.act_u8(self.obs[step][lo:hi], seed, off, rng_base, self.actions[step][lo:hi], self.logprobs[step][lo:hi],
+                                  self.values[step][lo:hi], want_i64=rng_base is None)
+            if r is not None:
+                if rng_offset is None:
+                    self.agent.rng.next()
+                return r[0] if r[0] is not None else r[1]
         if self.hip:
             p, value = self._heads_rollout(self.obs[step][lo:hi])
             seed, off = self.agent.rng.next() if rng_offset is None else (self.agent.rng.seed, int(rng_offset))

@@ -541,6 +541,18 @@ MI355PPO_API int mi355ppo_heads_bwd_relu_f32(const float* h, const float* Wa, co
                                              float* dbc, float* dbh, int M, int A, int H, void* workspace,
                                              size_t workspace_bytes, void* stream);
 
+/* Rollout step of the NatureCNN agent, fused behind the trunk (round 4): Linear(3136,512) with K split over the grid (raw partials in
+ * `workspace`, mi355ppo_fc_fwd_workspace_bytes(M, 512, 3136) bytes; M < 4096), then ONE kernel for the partial fold + bias + ReLU,
+ * the two heads and the Categorical draw -- Agent.get_action_and_value(next_obs) from conv3's output on
+ * (cleanrl/ppo_atari_multigpu.py:144-149,155-159) -- writing action / log-prob / value (and optionally the hidden activations) in
+ * place.  Bit-identical to mi355ppo_fc_fwd_relu_packed_ws_f32 -> mi355ppo_heads_fwd_f32 -> mi355ppo_categorical_sample_ctr_f32. */
+MI355PPO_API int mi355ppo_fc_heads_act_categorical_f32(const float* a3, int lda, const void* fc_pack, const float* fc_bias,
+                                                       const float* Wa, const float* ba, const float* Wc, const float* bc, int M, int A,
+                                                       int H, int K, const float* noise_exp1, uint64_t seed, uint64_t offset,
+                                                       const uint64_t* offset_base, int64_t* action_i64, float* action_f32,
+                                                       float* logprob, float* value, float* hidden_out, void* workspace,
+                                                       size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Test / benchmark support -- NOT part of the reference path.  One step of the device-resident synthetic Atari
  * vector env (cleanrl_amd/envs.py::DeviceSyntheticAtariVecEnv) that stands in for envpool / ALE, which this image

@@ -373,6 +373,36 @@ def test_heads_forward_backward(M, A):
         assert err <= max(2e-5 * scale, 4.0 * err_t), f"{name}: err {err:.3e}, torch f32 err {err_t:.3e}, scale {scale:.3e}"
 
 
+@pytest.mark.parametrize("M,A,philox", [(1024, 4, True), (1024, 4, False), (256, 6, True), (100, 7, True), (8, 1, True), (3000, 4, True)])
+def test_fused_rollout_step_behind_the_trunk_is_bit_identical_to_its_four_launches(M, A, philox):
+    """``fc_heads_act_categorical`` (K-split FC partials, then ONE kernel for fold + bias + ReLU + heads + Categorical draw) against
+    the launches it replaces: ``fc_fwd_relu_packed`` -> ``HeadsFn`` -> ``ops.categorical_sample`` (+ the value copy)."""
+    from cleanrl_amd import ops
+
+    g = torch.Generator().manual_seed(7 * M + A)
+    a = torch.relu(torch.randn(M, 3136, generator=g)).to(DEV)
+    fc, actor, critic = torch.nn.Linear(3136, 512).to(DEV), torch.nn.Linear(512, A).to(DEV), torch.nn.Linear(512, 1).to(DEV)
+    with torch.no_grad():
+        actor.weight.mul_(30.0)                                     # spread the logits so that the draw is not near-uniform
+    pack = cnn.fc_pack(fc.weight.detach())
+    assert cnn.fc_heads_act_supported(a)
+    noise = None if philox else torch.empty(M, A, device=DEV).exponential_(1.0, generator=torch.Generator(DEV).manual_seed(3))
+    base = torch.full((1,), 1000, dtype=torch.int64, device=DEV) if philox else None
+    with torch.no_grad():
+        h = cnn.fc_fwd_relu_packed(a, pack, fc.bias.detach(), 512)
+        logits, value = cnn.HeadsFn.apply(h, actor.weight, actor.bias, critic.weight, critic.bias)
+        a64, af, lp, _ = ops.categorical_sample(logits.contiguous(), noise_exp1=noise, seed=11, offset=5, offset_base=base, want_entropy=False)
+        out_a, out_lp, out_v = (torch.full((M,), -7.0, device=DEV) for _ in range(3))
+        b64, bf, blp, bv = cnn.fc_heads_act_categorical(a, pack, fc.bias.detach(), actor.weight.detach(), actor.bias.detach(), critic.weight.detach(),
+                                                        critic.bias.detach(), 11, 5, base, out_a, out_lp, out_v, noise_exp1=noise)
+    assert bf is out_a and blp is out_lp and bv is out_v
+    assert torch.equal(b64, a64) and torch.equal(bf, a64.float())
+    assert torch.equal(blp, lp), f"log-probs differ: {(blp - lp).abs().max().item():.3e}"
+    assert torch.equal(bv, value.view(-1)), f"values differ: {(bv - value.view(-1)).abs().max().item():.3e}"
+    if A > 1:
+        assert len(torch.unique(a64)) > 1
+
+
 @pytest.mark.parametrize("M", [1, 700, 4099, 8192])
 def test_fc_weight_gradient_kernel_y_against_float64(M):
     """Kernel Y (csrc/fcw.hip): dW = dz^T a of Linear(3136, 512) on the f32 pipe, the batch cut into slabs (1 at M <= 1023,
