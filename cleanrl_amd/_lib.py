@@ -75,6 +75,7 @@ SIGNATURES = {
     "mi355ppo_fc_dgrad_maskbits_packed_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_synth_atari_step_u8": (c_int, [_P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, c_int, c_double, c_int, _P]),
     "mi355ppo_synth_atari_step_ctr_u8": (c_int, [_P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_double, c_int, _P]),
+    "mi355ppo_synth_atari_step_hwc_ctr_u8": (c_int, [_P, c_int, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_double, c_int, _P]),
     "mi355ppo_heads_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "mi355ppo_heads_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mi355ppo_heads_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),

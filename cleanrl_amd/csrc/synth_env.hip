@@ -33,6 +33,26 @@ __global__ __launch_bounds__(256) void synth_env_frames_kernel(const uint8_t* __
     for (int e = threadIdx.x; e < 441; e += 256) d[e] = s[e];
 }
 
+// The same gather written pixel-interleaved -- obs[n][y][x][c] = planes[(cursor[n] + c) % pool][y][x], the learner's rollout-row
+// layout: a lane reads one dword (4 pixels) of each of the env's 4 planes, transposes the 4 x 4 byte block in registers
+// (obs.hip's relayout) and stores 16 contiguous bytes.  One launch where the channel-planar gather + the relayout kernel were two.
+__global__ __launch_bounds__(256) void synth_env_frames_hwc_kernel(const uint8_t* __restrict__ planes, const long long* __restrict__ cursor,
+                                                                   uint8_t* __restrict__ obs, int pool) {
+    const int n = blockIdx.x;
+    const int q = blockIdx.y * 256 + threadIdx.x;                // pixel quad, 1,764 per plane
+    if (q >= 1764) return;
+    const long long c0 = cursor[n];
+    uint32_t w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = reinterpret_cast<const uint32_t*>(planes + ((c0 + c) % pool) * 7056LL)[q];
+    uint4 o;
+    o.x = (w[0] & 0xffu) | ((w[1] & 0xffu) << 8) | ((w[2] & 0xffu) << 16) | (w[3] << 24);
+    o.y = ((w[0] >> 8) & 0xffu) | (w[1] & 0xff00u) | ((w[2] & 0xff00u) << 8) | ((w[3] & 0xff00u) << 16);
+    o.z = ((w[0] >> 16) & 0xffu) | ((w[1] >> 8) & 0xff00u) | (w[2] & 0xff0000u) | ((w[3] & 0xff0000u) << 8);
+    o.w = (w[0] >> 24) | ((w[1] >> 16) & 0xff00u) | ((w[2] >> 8) & 0xff0000u) | (w[3] & 0xff000000u);
+    reinterpret_cast<uint4*>(obs + (long long)n * 28224LL)[q] = o;
+}
+
 // ---- the continuous-control stand-in (cleanrl_amd/envs.py::DeviceSyntheticContinuousVecEnv, bench.py --config E) --------------------
 // a = clip(action, -1, 1); next = noise[k % bank][n] + state[n] @ At + a @ Bm; reward = next . w - 0.1 |a|^2; 1000-step truncation;
 // the state row is the observation.  As torch ops this was ~12 launches per env step.  Thread (env, j) of a half-wave computes
@@ -98,10 +118,9 @@ extern "C" MI355PPO_API int mi355ppo_synth_continuous_step_f32(float* state, con
     return check_launch(fn);
 }
 
-extern "C" MI355PPO_API int mi355ppo_synth_atari_step_ctr_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed,
-                                                             uint64_t step, const uint64_t* step_base, uint8_t* obs, float* reward,
-                                                             float* done, int N, double done_p, int advance, void* stream) {
-    const char* fn = "mi355ppo_synth_atari_step_u8";
+static int synth_atari_step(const char* fn, bool hwc, const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed, uint64_t step,
+                            const uint64_t* step_base, uint8_t* obs, float* reward, float* done, int N, double done_p, int advance,
+                            void* stream) {
     MI355_REQUIRE(planes && cursor && obs, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(N > 0 && pool > 0, MI355PPO_EINVAL, "%s: N=%d pool=%d must be positive", fn, N, pool);
     MI355_REQUIRE(!advance || (reward && done), MI355PPO_EINVAL, "%s: reward/done are required when advancing", fn);
@@ -114,8 +133,27 @@ extern "C" MI355PPO_API int mi355ppo_synth_atari_step_ctr_u8(const uint8_t* plan
         int rc = check_launch("synth_env_scalars_kernel");
         if (rc) return rc;
     }
+    if (hwc) {
+        hipLaunchKernelGGL(synth_env_frames_hwc_kernel, dim3(N, 7), dim3(256), 0, s, planes, reinterpret_cast<const long long*>(cursor), obs, pool);
+        return check_launch("synth_env_frames_hwc_kernel");
+    }
     hipLaunchKernelGGL(synth_env_frames_kernel, dim3(N * 4), dim3(256), 0, s, planes, reinterpret_cast<const long long*>(cursor), obs, pool);
     return check_launch("synth_env_frames_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_synth_atari_step_ctr_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed,
+                                                             uint64_t step, const uint64_t* step_base, uint8_t* obs, float* reward,
+                                                             float* done, int N, double done_p, int advance, void* stream) {
+    return synth_atari_step("mi355ppo_synth_atari_step_u8", false, planes, pool, cursor, seed, step, step_base, obs, reward, done, N, done_p,
+                            advance, stream);
+}
+
+// The same step with the observation written pixel-interleaved, (N, 84, 84, 4): the layout of the learner's rollout rows.
+extern "C" MI355PPO_API int mi355ppo_synth_atari_step_hwc_ctr_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed,
+                                                                 uint64_t step, const uint64_t* step_base, uint8_t* obs, float* reward,
+                                                                 float* done, int N, double done_p, int advance, void* stream) {
+    return synth_atari_step("mi355ppo_synth_atari_step_hwc_ctr_u8", true, planes, pool, cursor, seed, step, step_base, obs, reward, done, N,
+                            done_p, advance, stream);
 }
 
 extern "C" MI355PPO_API int mi355ppo_synth_atari_step_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed,

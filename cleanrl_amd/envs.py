@@ -265,19 +265,20 @@ class DeviceSyntheticAtariVecEnv:
         self.step_base = None      # 1-element int64 device tensor once the learner captured its rollout steps (then the step
         self._step_rel = None      # count of a captured launch is step_base + its position in the rollout)
 
-    def _call(self, out, reward, done, advance):
+    def _call(self, out, reward, done, advance, hwc=False):
         """Two launches per env step (csrc/synth_env.hip) instead of ~14 torch kernels: the rollout is short enough for
         the stand-in env's own launches to show up in env-steps/sec."""
         from . import _lib
 
         lib = _lib.load()
         t = self.torch
-        assert out.dtype == t.uint8 and out.is_contiguous() and tuple(out.shape) == (self.num_envs, 4, 84, 84)
+        assert out.dtype == t.uint8 and out.is_contiguous() and tuple(out.shape) == (self.num_envs,) + ((84, 84, 4) if hwc else (4, 84, 84))
         if advance:
             assert reward.dtype == t.float32 and done.dtype == t.float32 and reward.is_contiguous() and done.is_contiguous()
             self._step += 1
         rel = self._step_rel if (advance and self._step_rel is not None) else None
-        st = lib.mi355ppo_synth_atari_step_ctr_u8(
+        fn = lib.mi355ppo_synth_atari_step_hwc_ctr_u8 if hwc else lib.mi355ppo_synth_atari_step_ctr_u8
+        st = fn(
             self.planes.data_ptr(), self.pool, self.cursor.data_ptr(), self._seed, self._step if rel is None else rel,
             self.step_base.data_ptr() if rel is not None else None, out.data_ptr(),
             reward.data_ptr() if advance else None, done.data_ptr() if advance else None, self.num_envs, float(self.done_p),
@@ -290,6 +291,11 @@ class DeviceSyntheticAtariVecEnv:
 
     def step_into(self, obs_out, reward_out, done_out):
         return self._call(obs_out, reward_out, done_out, True)
+
+    def step_into_rows(self, rows_out, reward_out, done_out):
+        """``step_into`` with the observation written pixel-interleaved, (N, 84, 84, 4) -- a rollout-storage row of the HIP
+        learner, no relayout launch behind it."""
+        return self._call(rows_out, reward_out, done_out, True, hwc=True)
 
     def close(self):
         pass

@@ -356,6 +356,10 @@ class PPOLearner:
                 env._step_rel = None
                 return
             env._step_rel = step + 1
+            if self.relayout and hasattr(env, "step_into_rows"):      # the env writes the rollout row's own layout
+                env.step_into_rows(obs_dst, self.rewards[step], done_dst)
+                env._step_rel = None
+                return
             frames = env.step_into(self.stage_obs, self.rewards[step], done_dst)
             env._step_rel = None
             self.observe(step + 1, frames, done_dst)

@@ -29,7 +29,10 @@ def rollout(learner: PPOLearner, env: DeviceSyntheticAtariVecEnv) -> None:
         return
     for step in range(T):
         learner.act(step)
-        _, done_dst = learner._slot(step + 1)
+        obs_dst, done_dst = learner._slot(step + 1)
+        if learner.relayout and hasattr(env, "step_into_rows"):
+            env.step_into_rows(obs_dst, learner.rewards[step], done_dst)                 # the rollout row's own layout: no relayout launch
+            continue
         frames = env.step_into(learner.stage_obs, learner.rewards[step], done_dst)   # channel-planar uint8 in HBM
         learner.observe(step + 1, frames, done_dst)                                  # relayout into the rollout row
     learner.finish_rollout()

@@ -565,6 +565,10 @@ MI355PPO_API int mi355ppo_synth_atari_step_u8(const uint8_t* planes, int pool, i
 MI355PPO_API int mi355ppo_synth_atari_step_ctr_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed, uint64_t step,
                                                   const uint64_t* step_base, uint8_t* obs, float* reward, float* done, int N,
                                                   double done_p, int advance, void* stream);   /* step_eff = step + *step_base */
+/* The same step with obs written pixel-interleaved, (N,84,84,4): the rollout rows' layout (gather + relayout in one launch). */
+MI355PPO_API int mi355ppo_synth_atari_step_hwc_ctr_u8(const uint8_t* planes, int pool, int64_t* cursor, uint64_t seed, uint64_t step,
+                                                      const uint64_t* step_base, uint8_t* obs, float* reward, float* done, int N,
+                                                      double done_p, int advance, void* stream);
 
 /* The continuous-control stand-in (cleanrl_amd/envs.py::DeviceSyntheticContinuousVecEnv; bench.py --config E), one launch per env
  * step: a = clip(action, -1, 1); next = noise[(k + *k_base) % bank][n] + state[n] @ At + a @ Bm; reward = next . w - 0.1 |a|^2;

@@ -476,6 +476,14 @@ def test_device_synthetic_env_streams():
         idx = ((env.cursor[:, None] + torch.arange(4, device=DEV)[None, :]) % env.pool)
         assert torch.equal(obs, env.planes[idx])
         rs.append(rew.clone()); ds.append(done.clone())
+    # the pixel-interleaved variant (gather + relayout in one launch): the same stream, the rollout rows' layout
+    twin = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=11, done_p=0.1)
+    twin.cursor.copy_(env.cursor); twin._step = env._step
+    rows, rew2, done2 = torch.empty((N, 84, 84, 4), dtype=torch.uint8, device=DEV), torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    for _ in range(3):
+        env.step_into(obs, rew, done)
+        twin.step_into_rows(rows, rew2, done2)
+        assert torch.equal(rows, obs.permute(0, 2, 3, 1)) and torch.equal(rew, rew2) and torch.equal(done, done2) and torch.equal(env.cursor, twin.cursor)
     r, d = torch.cat(rs), torch.cat(ds)
     assert set(r.unique().tolist()) <= {-1.0, 0.0, 1.0}
     n = r.numel()
