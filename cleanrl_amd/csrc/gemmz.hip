@@ -940,14 +940,23 @@ static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pa
     const long long srcb = (long long)images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4;
     MI355_REQUIRE(srcb < (1LL << 32) - 8192, MI355PPO_EINVAL, "%s: the source (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb);   // (the destination is smaller)
     hipStream_t st = as_stream(stream);
+    // Rollout-sized launches are a single, partly filled round of wave tiles, each walking all K / 16 k-steps: below 768 images 32-row
+    // tiles (twice the waves, half the MFMAs per k-step) -- layer 2 / layer 3 at 256 images 23.4 -> 17.2 / 26.0 -> 18.5 us, at 128
+    // images 22.3 -> 17.6 / 25.2 -> 17.8 us, bit-identical; at 1,024 images the 64-row tiles win (44.7 vs 50.9 us;
+    // profiles/r04_small_tiles_ab.txt).  MI355PPO_Z_SMALL_MT=2: 64-row tiles at every size (A/B runs).
+    static const int small_mt = [] { const char* e = getenv("MI355PPO_Z_SMALL_MT"); return e ? atoi(e) : 1; }();
+    static const long long small_below = [] { const char* e = getenv("MI355PPO_Z_SMALL_BELOW"); return e ? atoll(e) : 768LL; }();
+    const bool small = !bits && small_mt == 1 && images < small_below;
     if (layer == 2) {
         ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K);
         za.bits_out = bits;
+        if (small) return z_launch<ZConv2, 1, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
         if (bits) return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2>(za, st, fn);
         return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
     }
     ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
     za.bits_out = bits;
+    if (small) return z_launch<ZConv3, 1, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
     if (bits) return z_blds(images) ? z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2, true>(za, st, fn) : z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2>(za, st, fn);
     return z_blds(images) ? z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, st, fn) : z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
 }
