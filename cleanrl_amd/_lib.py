@@ -80,6 +80,7 @@ SIGNATURES = {
     "mi355ppo_heads_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mi355ppo_heads_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "mi355ppo_heads_bwd_relu_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "mi355ppo_nature_packs_f32": (c_int, [_P] * 12),
     "mi355ppo_fc_heads_act_categorical_f32": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_uint64, c_uint64, _P,
                                                       _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mi355ppo_fc_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

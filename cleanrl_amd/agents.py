@@ -140,6 +140,7 @@ class AtariAgent(_DiscreteMixin, nn.Module):
         if self._trunk is None:
             self._trunk = cnn.NatureTrunk()
         net = self.network
+        self._trunk.bufs.pack_params = (net[0].weight, net[2].weight, net[4].weight, net[7].weight)
         feats = self._trunk(obs_rows, inds, net[0], net[2], net[4])
         hidden = cnn.LinearReLUHwcFn.apply(feats, net[7].weight, net[7].bias, self._trunk.bufs)
         if cnn.heads_supported(self.actor, self.critic):
@@ -156,6 +157,7 @@ class AtariAgent(_DiscreteMixin, nn.Module):
         net = self.network
         if torch.is_grad_enabled() or not cnn.heads_supported(self.actor, self.critic):
             return None
+        self._trunk.bufs.pack_params = (net[0].weight, net[2].weight, net[4].weight, net[7].weight)
         feats = self._trunk(obs_rows, None, net[0], net[2], net[4])
         if not cnn.fc_heads_act_supported(feats):
             return None

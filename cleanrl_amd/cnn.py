@@ -28,6 +28,7 @@ QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 st
 VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
 _CONV_Z = os.environ.get("MI355PPO_CONV", "z") != "f"    # layers 2 / 3 forward + data gradients: kernel Z, or the f32-pipe kernel F
 _MASK_BITS = os.environ.get("MI355PPO_MASK_BITS", "1") != "0"   # ReLU masks travel to the data gradients as bits (0: as the f32 activations; A/B runs)
+_FUSED_PACKS = os.environ.get("MI355PPO_FUSED_PACKS", "1") != "0"   # all weight packs of the NatureCNN agent in one launch (0: the 13 launches; A/B runs)
 BUF_LIMIT = (1 << 32) - 8192     # kernels Z / F address a tensor with 32-bit buffer offsets: larger tensors take kernel S (64-bit pointers)
 
 
@@ -393,6 +394,41 @@ class _Buffers:
         # (12 small launches per minibatch).  Only an owner that guarantees zeroed .grad before every backward sets it (PPOLearner).
         self.direct_grads = False
         self.after_fc_wgrad = None         # callback(param) once Linear(3136,512).weight's gradient is final (world > 1: early all-reduce)
+        # (W1, W2, W3, Wfc) of the owning NatureCNN agent: with cached weights, a stale pack then means ALL of kernel Q's / kernel Z's
+        # packs are rebuilt together from the parameters in one launch (mi355ppo_nature_packs_f32) instead of 13 small ones
+        self.pack_params = None
+
+    def _pack_keys(self):
+        W1, W2, W3, Wfc = self.pack_params
+        return [((1, MODE_FWD_Q), W1, None), (("zpack", 2, MODE_FWD), W2, (64, 512)), (("zpack", 3, MODE_FWD), W3, (64, 576)),
+                (("zpack", 3, MODE_DGRAD_S1), W3, (64, 576)), (("zpack", 2, MODE_DGRAD_S2), W2, (128, 256)),
+                ("fc_pack_fwd", Wfc, (512, 3136)), ("fc_pack_dgrad", Wfc, (3136, 512))]
+
+    def _repack_all(self, key, W) -> bool:
+        """Rebuild every cached pack in one launch when ``key`` (stale) is one of them and ``W`` its parameter.  -> done?"""
+        if self.pack_params is None or not self.cache_weights or not _FUSED_PACKS:
+            return False
+        keys = self._pack_keys()
+        if not any(k == key and w.data_ptr() == W.data_ptr() for k, w, _ in keys) or not all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for _, w, _ in keys):
+            return False
+        lib = _lib.load()
+        dev = W.device
+        outs = []
+        for k, w, shape in keys:
+            hit = self._bt.get(k)
+            if hit is None:
+                buf = (torch.empty(QPACK_NUMEL, dtype=torch.float32, device=dev) if shape is None
+                       else torch.empty(lib.mi355ppo_fc_pack_bytes(*shape), dtype=torch.uint8, device=dev))
+            else:
+                buf = hit[1]
+            outs.append(buf)
+        W1, W2, W3, Wfc = (w.detach() for w in self.pack_params)
+        with _on(dev):
+            st = lib.mi355ppo_nature_packs_f32(_ptr(W1), _ptr(W2), _ptr(W3), _ptr(Wfc), *[_ptr(o) for o in outs], _stream(dev))
+        _lib.check(st, "mi355ppo_nature_packs_f32")
+        for (k, w, _), buf in zip(keys, outs):
+            self._bt[k] = ((self.weights_version, w._version, w.data_ptr()), buf)
+        return True
 
     def fc_weight(self, W: torch.Tensor) -> torch.Tensor:
         """Linear(3136,512) weight with (h,w,c)-ordered input features, cached like the conv matrices (re-derived INTO the
@@ -428,6 +464,8 @@ class _Buffers:
         tag = (self.weights_version, W._version, W.data_ptr())
         hit = self._bt.get(key)
         if hit is None or hit[0] != tag:
+            if self._repack_all(key, W):
+                return self._bt[key][1]
             hit = (tag, fc_pack(source(), hit[1] if hit is not None else None))
             self._bt[key] = hit
         return hit[1]
@@ -463,6 +501,8 @@ class _Buffers:
         tag = (self.weights_version, W._version, W.data_ptr())
         hit = self._bt.get(key)
         if hit is None or hit[0] != tag:
+            if mode == MODE_FWD_Q and self._repack_all(key, W):
+                return self._bt[key][1]
             hit = (tag, repack_weights(W.detach(), layer, mode, hit[1] if hit is not None else None))
             self._bt[key] = hit
         return hit[1]

@@ -26,6 +26,7 @@
 // prologue / epilogue falls under the other's MFMAs (8-wave workgroups ran their two waves per SIMD in phase: 2 - 5 % slower,
 // profiles/r03_zcfg_ab.jsonl).
 #include "common.h"
+#include "conv1q_pack.h"
 #include "bf16split.h"
 #include <type_traits>
 
@@ -65,6 +66,16 @@ constexpr unsigned kZOob = 0xFFFFF000u;               // buffer offset out of ra
 constexpr int kZRsrcWord3 = 0x00020000;               // raw buffer, 32-bit elements (gfx9 / CDNA resource format)
 
 // pack[s][j][t][lane][e] (bf16) = term t of B[n = 32 j + (lane & 31)][k = 16 s + 8 (lane >> 5) + e]; rows n >= N are zero.
+__device__ __forceinline__ void zpack_store(unsigned short* __restrict__ pack, long long sj, int lane, int e, float x) {
+    const unsigned xb = __float_as_uint(x);
+    const unsigned t8 = xb & 0xffff0000u, t16 = xb & 0xffffff00u;
+    const float mid = __uint_as_float(t16) - __uint_as_float(t8), lo = x - __uint_as_float(t16);
+    const size_t o = ((size_t)sj * 3 * 64 + lane) * 8 + e;                           // term 0; terms 1, 2 follow at + 512, + 1024
+    pack[o] = (unsigned short)(xb >> 16);
+    pack[o + 512] = (unsigned short)(__float_as_uint(mid) >> 16);
+    pack[o + 1024] = (unsigned short)(__float_as_uint(lo) >> 16);
+}
+
 __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ B, int ldb, int N, int K, unsigned short* __restrict__ pack) {
     const int ntiles = (N + 31) / 32;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;                 // (s, j, lane, e)
@@ -73,14 +84,60 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ B,
     const long long sj = idx >> 9;
     const int j = (int)(sj % ntiles), s = (int)(sj / ntiles);
     const int n = 32 * j + (lane & 31), k = 16 * s + 8 * (lane >> 5) + e;
-    const float x = n < N ? B[(size_t)n * ldb + k] : 0.0f;
-    const unsigned xb = __float_as_uint(x);
-    const unsigned t8 = xb & 0xffff0000u, t16 = xb & 0xffffff00u;
-    const float mid = __uint_as_float(t16) - __uint_as_float(t8), lo = x - __uint_as_float(t16);
-    const size_t o = ((size_t)sj * 3 * 64 + lane) * 8 + e;                           // term 0; terms 1, 2 follow at + 512, + 1024
-    pack[o] = (unsigned short)(xb >> 16);
-    pack[o + 512] = (unsigned short)(__float_as_uint(mid) >> 16);
-    pack[o + 1024] = (unsigned short)(__float_as_uint(lo) >> 16);
+    zpack_store(pack, sj, lane, e, n < N ? B[(size_t)n * ldb + k] : 0.0f);
+}
+
+// Every weight pack of the NatureCNN agent in ONE launch, straight from the parameters as torch stores them (round 4).  After an
+// optimizer step the learner used to issue, per minibatch: conv_repack_kernel x 4 and two torch copies (the (h, w, c) reorder of
+// Linear(3136,512).weight and its transpose) to build the f32 matrices, zpack_kernel x 6 over them, and kernel Q's digit pack -- 13
+// launches of 3 - 12 us each, 1 % of a 32,768-image minibatch and 5 % of a 4,096-image one.  Piece p of the grid = the blocks
+// [first[p], first[p + 1]): 0 layer-2 forward (64 x 512), 1 layer-3 forward (64 x 576), 2 layer-3 data gradient (64 x 576, taps
+// flipped), 3 layer-2 data gradient (4 parity classes x 32 channels, 256), 4 FC forward (512 x 3,136, (h, w, c) order), 5 FC data
+// gradient (3,136 x 512), 6 kernel Q's pack (one block).  The element maps are conv.hip's conv_repack_kernel modes 0 / 1 / 2 and
+// cnn.py's fc_weight_hwc; the packs are bit-identical to the 13-launch route (tests/test_gpu_cnn.py).
+struct ZNaturePacks {
+    const float *W1, *W2, *W3, *Wfc;
+    unsigned short* out[6];
+    unsigned char* qpack;
+    unsigned first[8];
+};
+
+__global__ __launch_bounds__(256) void znature_pack_kernel(ZNaturePacks a) {
+    int piece = 0;
+#pragma unroll
+    for (int p = 1; p < 7; ++p)
+        if (blockIdx.x >= a.first[p]) piece = p;
+    if (piece == 6) {
+        conv1q_pack_body(a.W1, a.qpack);
+        return;
+    }
+    constexpr int kN[6] = {64, 64, 64, 128, 512, 3136}, kK[6] = {512, 576, 576, 256, 3136, 512};
+    const int N = kN[piece], K = kK[piece], ntiles = N / 32;
+    const long long idx = (long long)(blockIdx.x - a.first[piece]) * 256 + threadIdx.x;      // (s, j, lane, e)
+    if (idx >= (long long)(K / 16) * ntiles * 512) return;
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const long long sj = idx >> 9;
+    const int j = (int)(sj % ntiles), s = (int)(sj / ntiles);
+    const int n = 32 * j + (lane & 31), k = 16 * s + 8 * (lane >> 5) + e;
+    float x;
+    if (piece == 0) {                      // Bt[cout][(r, c, cin)] = W2[cout][cin][r][c]
+        const int r = k >> 7, c = (k >> 5) & 3, ch = k & 31;
+        x = a.W2[((n * 32 + ch) * 4 + r) * 4 + c];
+    } else if (piece == 1) {               // ... = W3[cout][cin][r][c]
+        const int r = k / 192, rem = k - r * 192, c = rem >> 6, ch = rem & 63;
+        x = a.W3[((n * 64 + ch) * 3 + r) * 3 + c];
+    } else if (piece == 2) {               // Bt[cin][(r, c, cout)] = W3[cout][cin][2 - r][2 - c]
+        const int r = k / 192, rem = k - r * 192, c = rem >> 6, co = rem & 63;
+        x = a.W3[((co * 64 + n) * 3 + (2 - r)) * 3 + (2 - c)];
+    } else if (piece == 3) {               // Bt[cls = 2 ph + pw][cin][(r, c, cout)] = W2[cout][cin][ph + 2 - 2 r][pw + 2 - 2 c]
+        const int cls = n >> 5, ci = n & 31, r = k >> 7, c = (k >> 6) & 1, co = k & 63;
+        x = a.W2[((co * 32 + ci) * 4 + ((cls >> 1) + 2 - 2 * r)) * 4 + ((cls & 1) + 2 - 2 * c)];
+    } else if (piece == 4) {               // B[n][(h, w, c)] = Wfc[n][(c, h, w)]
+        x = a.Wfc[(size_t)n * 3136 + (k & 63) * 49 + (k >> 6)];
+    } else {                               // B[(h, w, c)][n] = the same matrix transposed
+        x = a.Wfc[(size_t)k * 3136 + (n & 63) * 49 + (n >> 6)];
+    }
+    zpack_store(a.out[piece], sj, lane, e, x);
 }
 
 // Item t of `items` sits behind MFMA number ((t + 1) * span) / items - 1 of a k-step (distinct slots for span >= items).
@@ -800,6 +857,37 @@ static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, 
     a.super_rows = 0;
     a.C = C; a.c_bytes = (unsigned)c_bytes; a.ldc = ldc; a.M = M; a.images = images; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
     return a;
+}
+
+// All six kernel-Z packs and kernel Q's pack of the NatureCNN agent from its parameters in torch's layouts, one launch
+// (znature_pack_kernel).  Buffers: mi355ppo_fc_pack_bytes(64, 512), (64, 576), (64, 576), (128, 256), (512, 3136), (3136, 512) and
+// mi355ppo_cnn_conv1q_pack_bytes() bytes; a null output skips its piece (W1 / qpack, W2 / its two packs, ... may be absent together).
+extern "C" MI355PPO_API int mi355ppo_nature_packs_f32(const float* W1, const float* W2, const float* W3, const float* Wfc, void* qpack,
+                                                      void* conv2_fwd, void* conv3_fwd, void* conv3_dgrad, void* conv2_dgrad, void* fc_fwd,
+                                                      void* fc_dgrad, void* stream) {
+    const char* fn = "mi355ppo_nature_packs_f32";
+    void* outs[6] = {conv2_fwd, conv3_fwd, conv3_dgrad, conv2_dgrad, fc_fwd, fc_dgrad};
+    const float* srcs[6] = {W2, W3, W3, W2, Wfc, Wfc};
+    static const int kN[6] = {64, 64, 64, 128, 512, 3136}, kK[6] = {512, 576, 576, 256, 3136, 512};
+    ZNaturePacks a;
+    a.W1 = W1; a.W2 = W2; a.W3 = W3; a.Wfc = Wfc;
+    a.qpack = static_cast<unsigned char*>(qpack);
+    unsigned at = 0;
+    for (int p = 0; p < 6; ++p) {
+        MI355_REQUIRE(!outs[p] || srcs[p], MI355PPO_EINVAL, "%s: pack %d requested without its weight", fn, p);
+        MI355_REQUIRE(aligned(outs[p], 16) && aligned(srcs[p], 4), MI355PPO_EALIGN, "%s: packs must be 16-byte aligned", fn);
+        a.out[p] = static_cast<unsigned short*>(outs[p]);
+        a.first[p] = at;
+        if (outs[p]) at += (unsigned)((long long)kK[p] * kN[p] / 256);       // K x N elements (N is a multiple of 32), 256 per block
+    }
+    MI355_REQUIRE(!qpack || W1, MI355PPO_EINVAL, "%s: kernel Q's pack requested without the layer-1 weight", fn);
+    MI355_REQUIRE(aligned(qpack, 16) && aligned(W1, 4), MI355PPO_EALIGN, "%s: packs must be 16-byte aligned", fn);
+    a.first[6] = at;
+    if (qpack) at += 1;
+    a.first[7] = at;
+    MI355_REQUIRE(at > 0, MI355PPO_EINVAL, "%s: nothing to pack", fn);
+    hipLaunchKernelGGL(znature_pack_kernel, dim3(at), dim3(256), 0, as_stream(stream), a);
+    return check_launch(fn);
 }
 
 // h[m][n] = relu(bias[n] + part[0][m][n] + part[1][m][n] + ...): the K splits of Z_RAW added in order (deterministic)

@@ -541,6 +541,16 @@ MI355PPO_API int mi355ppo_heads_bwd_relu_f32(const float* h, const float* Wa, co
                                              float* dbc, float* dbh, int M, int A, int H, void* workspace,
                                              size_t workspace_bytes, void* stream);
 
+/* Every weight pack of the NatureCNN agent in one launch, from the parameters in torch's layouts (round 4): W1 (32,4,8,8) -> kernel
+ * Q's pack (mi355ppo_cnn_conv1q_pack_bytes()); W2 (64,32,4,4) -> kernel Z's layer-2 forward pack [mi355ppo_fc_pack_bytes(64, 512)] and
+ * data-gradient pack [(128, 256)]; W3 (64,64,3,3) -> layer-3 forward and data-gradient packs [(64, 576) each]; Wfc (512, 3136) in the
+ * reference's (c, h, w) feature order -> the FC forward pack [(512, 3136), features re-ordered (h, w, c)] and data-gradient pack
+ * [(3136, 512)].  Bit-identical to mi355ppo_cnn_repack_weights_f32 (modes 4 / 0 / 1 / 2) + mi355ppo_fc_pack_f32 per matrix -- what the
+ * learner re-derives after each optimizer step (cleanrl/ppo_atari_multigpu.py:377).  A null output skips its piece. */
+MI355PPO_API int mi355ppo_nature_packs_f32(const float* W1, const float* W2, const float* W3, const float* Wfc, void* qpack,
+                                           void* conv2_fwd, void* conv3_fwd, void* conv3_dgrad, void* conv2_dgrad, void* fc_fwd,
+                                           void* fc_dgrad, void* stream);
+
 /* Rollout step of the NatureCNN agent, fused behind the trunk (round 4): Linear(3136,512) with K split over the grid (raw partials in
  * `workspace`, mi355ppo_fc_fwd_workspace_bytes(M, 512, 3136) bytes; M < 4096), then ONE kernel for the partial fold + bias + ReLU,
  * the two heads and the Categorical draw -- Agent.get_action_and_value(next_obs) from conv3's output on

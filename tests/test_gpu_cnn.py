@@ -373,6 +373,40 @@ def test_heads_forward_backward(M, A):
         assert err <= max(2e-5 * scale, 4.0 * err_t), f"{name}: err {err:.3e}, torch f32 err {err_t:.3e}, scale {scale:.3e}"
 
 
+def test_all_weight_packs_in_one_launch_are_bit_identical_to_the_per_matrix_route():
+    """``mi355ppo_nature_packs_f32`` (through ``_Buffers._repack_all``) against repack_weights + fc_pack per matrix, the route it replaces;
+    then the cache follows ``weights_version`` and rebuilds into the SAME buffers (captured launches keep their addresses)."""
+    g = torch.Generator().manual_seed(5)
+    W1, W2, W3 = (torch.randn(*s, generator=g).to(DEV) * 0.05 for s in ((32, 4, 8, 8), (64, 32, 4, 4), (64, 64, 3, 3)))
+    Wfc = (torch.randn(512, 3136, generator=g) * 0.02).to(DEV)
+    W1[3] = 0.0                                                   # a dead channel (kernel Q's per-channel exponent)
+    ref = {(1, cnn.MODE_FWD_Q): cnn.repack_weights(W1, 1, cnn.MODE_FWD_Q),
+           ("zpack", 2, cnn.MODE_FWD): cnn.conv_zpack(W2, 2, cnn.MODE_FWD), ("zpack", 3, cnn.MODE_FWD): cnn.conv_zpack(W3, 3, cnn.MODE_FWD),
+           ("zpack", 3, cnn.MODE_DGRAD_S1): cnn.conv_zpack(W3, 3, cnn.MODE_DGRAD_S1),
+           ("zpack", 2, cnn.MODE_DGRAD_S2): cnn.conv_zpack(W2, 2, cnn.MODE_DGRAD_S2),
+           "fc_pack_fwd": cnn.fc_pack(cnn.fc_weight_hwc(Wfc).contiguous()), "fc_pack_dgrad": cnn.fc_pack(cnn.fc_weight_hwc(Wfc).t().contiguous())}
+    bufs = cnn._Buffers()
+    bufs.cache_weights = True
+    bufs.pack_params = (W1, W2, W3, Wfc)
+    got = bufs.conv_zpack(W2, 2, cnn.MODE_FWD)                    # one stale pack -> all of them
+    assert set(bufs._bt) >= set(ref)
+    for k, want in ref.items():
+        assert torch.equal(bufs._bt[k][1].view(torch.uint8), want.view(torch.uint8)), f"pack {k} differs from the per-matrix route"
+    assert got.data_ptr() == bufs._bt[("zpack", 2, cnn.MODE_FWD)][1].data_ptr()
+    ptrs = {k: bufs._bt[k][1].data_ptr() for k in ref}
+    assert bufs.fc_pack_dgrad(Wfc).data_ptr() == ptrs["fc_pack_dgrad"] and bufs.weights(W1, 1, cnn.MODE_FWD_Q).data_ptr() == ptrs[(1, cnn.MODE_FWD_Q)]
+    with torch.no_grad():                                         # the optimizer kernel writes through raw pointers, then bumps the version
+        for w in (W1, W2, W3, Wfc):
+            w.view(-1)[::7] *= 1.5
+    torch.cuda.synchronize()
+    bufs.weights_version += 1
+    q2 = bufs.weights(W1, 1, cnn.MODE_FWD_Q)
+    assert {k: bufs._bt[k][1].data_ptr() for k in ref} == ptrs
+    assert torch.equal(q2.view(torch.uint8), cnn.repack_weights(W1, 1, cnn.MODE_FWD_Q).view(torch.uint8))
+    assert torch.equal(bufs._bt["fc_pack_fwd"][1], cnn.fc_pack(cnn.fc_weight_hwc(Wfc).contiguous()))
+    assert torch.equal(bufs._bt[("zpack", 2, cnn.MODE_DGRAD_S2)][1], cnn.conv_zpack(W2, 2, cnn.MODE_DGRAD_S2))
+
+
 @pytest.mark.parametrize("M,A,philox", [(1024, 4, True), (1024, 4, False), (256, 6, True), (100, 7, True), (8, 1, True), (3000, 4, True)])
 def test_fused_rollout_step_behind_the_trunk_is_bit_identical_to_its_four_launches(M, A, philox):
     """``fc_heads_act_categorical`` (K-split FC partials, then ONE kernel for fold + bias + ReLU + heads + Categorical draw) against
