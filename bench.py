@@ -317,7 +317,18 @@ def main():
                          sample_seed=seed)
     learner.observe(0, env.obs_into(learner.stage_obs), learner.dones[0])
     if learner.fused_cnn and not cli.no_rollout_graphs:
-        learner.capture_rollout(env, steps_per_graph=cli.rollout_steps_per_graph or T)      # (before the timing hooks: no event records in a capture)
+        try:
+            learner.capture_rollout(env, steps_per_graph=cli.rollout_steps_per_graph or T)      # (before the timing hooks: no event records in a capture)
+        except Exception as e:      # noqa: BLE001
+            # world > 1: a capture beside RCCL's watchdog thread has only ever run over gloo (one-GPU build boxes).  The rollout holds
+            # no collective, so a rank whose capture fails issues its rollout launch by launch instead of ending the whole job.
+            if world == 1:
+                raise
+            print(f"[bench] rank {rank}: rollout-graph capture failed beside the process group ({e!r}); this rank's rollout runs eagerly",
+                  file=sys.stderr, flush=True)
+            learner._rollout_graphs = None
+            env._step_rel = None
+            torch.cuda.synchronize()
     update_mode = "eager launches"
     use_update_graphs = not cli.no_update_graphs and learner.fused_cnn and world == 1
     if use_update_graphs:
