@@ -907,11 +907,20 @@ __global__ __launch_bounds__(256) void zsplit_reduce_kernel(const float4* __rest
 
 // K splits of the small-batch forward: (row tile, column tile, split) wave tiles for ONE wave per SIMD (1,024: measured 30.8 us at
 // 1,024 rows, 22.6 at 512 -- the library GEMM's 31.3 / 22.6; two waves per SIMD = twice the partials: 38.7 / 29.3 us,
-// tools/gpu/fcsplit2.sh), at least 4 k-steps per split.
+// tools/gpu/fcsplit2.sh), at least 4 k-steps per split.  Below 512 rows fewer, longer splits win (a split of 4 k-steps is all
+// prologue and epilogue, and every split is one more partial to fold): 2 M wave tiles, at least 256 -- 128 rows 24.1 -> 18.3 us,
+// 256 rows 22.5 -> 20.0 us (profiles/r04_fcsplit_sweep.txt).  The result depends on the split (f32 summation order), so the choice is a
+// function of the shape alone: the same M always splits the same way.
 static int zsplit_steps_per(int M, int N, int K) {
     const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
     const int total = K / 16;
-    static const int target = [] { const char* e = getenv("MI355PPO_FC_SPLIT_WAVES"); return e ? atoi(e) : 1024; }();      // (tuning runs)
+    static const int forced = [] { const char* e = getenv("MI355PPO_FC_SPLIT_WAVES"); return e ? atoi(e) : 0; }();      // (tuning runs)
+    int target = forced;
+    if (target <= 0) {
+        target = 2 * M;
+        if (target < 256) target = 256;
+        if (target > 1024) target = 1024;
+    }
     long long want = (target + tiles - 1) / tiles;
     if (want < 1) want = 1;
     int per = (int)((total + want - 1) / want);
