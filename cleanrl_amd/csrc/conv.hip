@@ -1195,6 +1195,6 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     rc = check_launch("conv_wgrad_reduce1");
     if (rc) return rc;
     hipLaunchKernelGGL(conv_wgrad_reduce2, dim3((total_w + 255) / 256), dim3(256), 0, s, mid, nchunks, mid_b, nchunks, Cout, Cin,
-                       KH, KH, layer == 1 ? kInv255 : 1.0f, dW, db);
+                       KH, KH, layer == 1 ? kInv255 * conv1p_partial_scale() : 1.0f, dW, db);
     return check_launch("conv_wgrad_reduce2");
 }

@@ -27,6 +27,17 @@
 //     registers (4x4 byte transposes, 8 v_perm per four dwords) between the 16-byte global loads of the NEXT image's slab
 //     (issued at the start of an image) and the ds_write_b32s (after the last step's reads: LDS instructions of one wave
 //     execute in order, so one buffer suffices and there is no workgroup barrier anywhere).
+// Round 4 (ZEXT): the frame operand enters the pipe by ZERO-EXTENSION.  The 16-bit pattern 0x00vv read as a bf16 is v * 2^-133 for every
+// byte v (subnormal below 128, exponent field 1 from 128 on -- the subnormals continue the normal range), and gfx950's bf16 MFMA multiplies
+// subnormal inputs exactly (tools/mfma_denorm.cpp, profiles/r04_mfma_denorm.json; MI200's flushed them).  One v_perm with a per-lane selector
+// builds two operand elements straight from the LDS words -- 4 VALU per tap row instead of 2 v_alignbyte + 8 v_cvt_f32_ubyte + 4 v_perm, 26 %
+// fewer VALU instructions in the kernel -- and dz is multiplied by 2^96 before its split (exact: |dz| < 2^32), so the accumulators hold
+// 2^-37 x the sums and stay in the normal range (sums of magnitude above 2^-89); the reduction multiplies by 2^37 / 255 instead of 1 / 255.
+// Every product is still exact and every sum an f32 accumulation; what changes is the pipe's internal alignment of an instruction's 16
+// products (all frame values now carry ONE exponent), so 6 % of dW1's elements differ from the converted-operand route in the last bit or
+// two (<= 8.8e-8 of the scale), with the same error against float64 (max 4.47e-7 both, mean 6.37e-8 vs 6.34e-8 of the scale; torch's own
+// f32 weight gradient: 1.9e-7; profiles/r04_kernel_p_zext_error.jsonl); db1 is bit-identical.  923 -> 833 us at 32,768 images, 310 -> 284 at
+// 8,192, 201 -> 188 at 4,096 (profiles/r04_kernel_p_zext_ab.txt).  MI355PPO_P_ZEXT=0: the conversion route (A/B runs).
 // Partials: one (32 x 256) matrix + 32 bias sums per wave, layout and fixed-order two-stage reduction of kernel R
 // (conv_wgrad_reduce1/2 in conv.hip) -- deterministic.
 #include "common.h"
@@ -58,6 +69,9 @@ __device__ __forceinline__ unsigned p_perm(unsigned hi, unsigned lo, unsigned se
 // two f32 whose low 16 bits are irrelevant/zero -> packed bf16 pair (element 0 in the low half)
 __device__ __forceinline__ unsigned p_pack_hi16(float e1, float e0) { return p_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u); }
 
+constexpr float kPZextDzScale = 0x1p96f, kPZextOutScale = 0x1p37f;      // 2^96 * 2^-133 = 2^-37
+
+template <bool ZEXT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1p_wgrad_kernel(
     const unsigned char* __restrict__ src, const int64_t* __restrict__ inds, const float* __restrict__ dz,
     float* __restrict__ part_w,      // [grid * 4][32][256]
@@ -70,6 +84,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned char* const tt = p_smem + wave * kPSlabLds;
     const int kw = li >> 2, c = li & 3;
     const unsigned sh = (unsigned)(kw >> 2);                              // tap columns 4..7 read one q further
+    // ZEXT: v_perm selectors (0x0c = the constant byte 0): elements (sh, sh + 1) and (sh + 2, sh + 3) of an 8-byte window, zero-extended
+    const unsigned sel0 = 0x0c000c00u | ((sh + 1u) << 16) | sh, sel1 = 0x0c000c00u | ((sh + 3u) << 16) | (sh + 2u);
     const int lds_lane = ((kw & 3) * 4 + c) * kPLine;                     // this lane's line within a source row
     const int dz_lane = (wave * (kPRowsPerWave * 20)) * 32 + li;          // float offset of (wave's first pixel, channel li)
     const int step_img = gridDim.x;
@@ -178,9 +194,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             [&]<int... J>(std::integer_sequence<int, J...>) {
                 ([&] {
                     constexpr int j = 2 * J;
-                    const float x0 = dz_slot(sc, std::integral_constant<int, j>{}), x1 = dz_slot(sc, std::integral_constant<int, j + 1>{});
+                    float x0 = dz_slot(sc, std::integral_constant<int, j>{}), x1 = dz_slot(sc, std::integral_constant<int, j + 1>{});
                     bsum += x0;
                     bsum += x1;
+                    if constexpr (ZEXT) {                                         // exact (a power of two; |dz| < 2^32)
+                        x0 *= kPZextDzScale;
+                        x1 *= kPZextDzScale;
+                    }
                     const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffff0000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
                     const float r0 = x0 - h0, r1 = x1 - h1;                       // exact
                     const float m0 = __uint_as_float(__float_as_uint(r0) & 0xffff0000u), m1 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
@@ -207,6 +227,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 w[2] = *reinterpret_cast<const unsigned*>(lp + r * kPRowLds + 8);
             };
             auto operand = [&](const unsigned (&w)[3]) -> p_bf16x8 {
+                if constexpr (ZEXT) {
+                    const p_u32x4 bz = {p_perm(w[1], w[0], sel0), p_perm(w[1], w[0], sel1), p_perm(w[2], w[1], sel0), p_perm(w[2], w[1], sel1)};
+                    return __builtin_bit_cast(p_bf16x8, bz);
+                }
                 const unsigned lo = __builtin_amdgcn_alignbyte(w[1], w[0], sh), hi = __builtin_amdgcn_alignbyte(w[2], w[1], sh);
                 const float f0 = (float)(lo & 0xffu), f1 = (float)((lo >> 8) & 0xffu), f2 = (float)((lo >> 16) & 0xffu), f3 = (float)(lo >> 24);
                 const float f4 = (float)(hi & 0xffu), f5 = (float)((hi >> 8) & 0xffu), f6 = (float)((hi >> 16) & 0xffu), f7 = (float)(hi >> 24);
@@ -252,21 +276,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (lh == 0) part_b[(size_t)(blockIdx.x * 4 + wave) * 32 + li] = both;
 }
 
+static bool conv1p_zext() {
+    static const bool on = [] { const char* e = getenv("MI355PPO_P_ZEXT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// factor the reduction applies to kernel P's partial sums (beside 1 / 255): 2^37 with the zero-extended frame operand
+float conv1p_partial_scale() { return conv1p_zext() ? kPZextOutScale : 1.0f; }
+
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
                   hipStream_t s) {
     // (one wave per SIMD -- 372 registers, no spill at all -- measured 1,135 us against 868 at 32,768 images: profiles/r03_kernel_p_pieces_ab.jsonl)
-    auto k = conv1p_wgrad_kernel;
+    const bool zext = conv1p_zext();
+    const void* k = zext ? reinterpret_cast<const void*>(conv1p_wgrad_kernel<true>) : reinterpret_cast<const void*>(conv1p_wgrad_kernel<false>);
     const size_t sm = 4 * (size_t)kPSlabLds;
     static bool attr_done = false;           // 48 KiB: within the default dynamic-LDS limit, but set it explicitly once
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
             (void)hipGetLastError();
             set_error("conv1p_launch: hipFuncSetAttribute(%zu bytes of LDS) failed", sm);
             return MI355PPO_EHIP;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, images);
+    if (zext) hipLaunchKernelGGL(conv1p_wgrad_kernel<true>, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, images);
+    else hipLaunchKernelGGL(conv1p_wgrad_kernel<false>, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, images);
     return check_launch("conv1p_wgrad_kernel");
 }
 
