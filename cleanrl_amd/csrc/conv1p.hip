@@ -31,8 +31,9 @@
 // byte v (subnormal below 128, exponent field 1 from 128 on -- the subnormals continue the normal range), and gfx950's bf16 MFMA multiplies
 // subnormal inputs exactly (tools/mfma_denorm.cpp, profiles/r04_mfma_denorm.json; MI200's flushed them).  One v_perm with a per-lane selector
 // builds two operand elements straight from the LDS words -- 4 VALU per tap row instead of 2 v_alignbyte + 8 v_cvt_f32_ubyte + 4 v_perm, 26 %
-// fewer VALU instructions in the kernel -- and dz is multiplied by 2^96 before its split (exact: |dz| < 2^32), so the accumulators hold
-// 2^-37 x the sums and stay in the normal range (sums of magnitude above 2^-89); the reduction multiplies by 2^37 / 255 instead of 1 / 255.
+// fewer VALU instructions in the kernel -- and dz is multiplied by 2^80 before its split (exact for |dz| < 2^48), so the accumulators hold
+// 2^-53 x the sums and stay in the normal range (sums of magnitude above 2^-73 = 1e-22; tests/test_gpu_cnn.py runs gradients of scale 1e-15
+// and 1e+10); the reduction multiplies by 2^53 / 255 instead of 1 / 255.
 // Every product is still exact and every sum an f32 accumulation; what changes is the pipe's internal alignment of an instruction's 16
 // products (all frame values now carry ONE exponent), so 6 % of dW1's elements differ from the converted-operand route in the last bit or
 // two (<= 8.8e-8 of the scale), with the same error against float64 (max 4.47e-7 both, mean 6.37e-8 vs 6.34e-8 of the scale; torch's own
@@ -69,7 +70,7 @@ __device__ __forceinline__ unsigned p_perm(unsigned hi, unsigned lo, unsigned se
 // two f32 whose low 16 bits are irrelevant/zero -> packed bf16 pair (element 0 in the low half)
 __device__ __forceinline__ unsigned p_pack_hi16(float e1, float e0) { return p_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u); }
 
-constexpr float kPZextDzScale = 0x1p96f, kPZextOutScale = 0x1p37f;      // 2^96 * 2^-133 = 2^-37
+constexpr float kPZextDzScale = 0x1p80f, kPZextOutScale = 0x1p53f;      // 2^80 * 2^-133 = 2^-53
 
 template <bool ZEXT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1p_wgrad_kernel(
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     float x0 = dz_slot(sc, std::integral_constant<int, j>{}), x1 = dz_slot(sc, std::integral_constant<int, j + 1>{});
                     bsum += x0;
                     bsum += x1;
-                    if constexpr (ZEXT) {                                         // exact (a power of two; |dz| < 2^32)
+                    if constexpr (ZEXT) {                                         // exact (a power of two; |dz| < 2^48)
                         x0 *= kPZextDzScale;
                         x1 *= kPZextDzScale;
                     }
@@ -281,7 +282,7 @@ static bool conv1p_zext() {
     return on;
 }
 
-// factor the reduction applies to kernel P's partial sums (beside 1 / 255): 2^37 with the zero-extended frame operand
+// factor the reduction applies to kernel P's partial sums (beside 1 / 255): 2^53 with the zero-extended frame operand
 float conv1p_partial_scale() { return conv1p_zext() ? kPZextOutScale : 1.0f; }
 
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,

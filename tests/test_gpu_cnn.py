@@ -307,6 +307,28 @@ def test_conv_wgrad_full_minibatch_against_float64_on_a_strided_slab(layer):
     _close(db, refb, f"conv{layer} wgrad db at M=32768 (512-image slab)")
 
 
+@pytest.mark.parametrize("scale", [1e-15, 1.0, 1e10])
+def test_conv1_wgrad_zero_extended_frame_operand_over_the_gradient_range(scale):
+    """Kernel P feeds the uint8 frames to the bf16 pipe as SUBNORMAL bf16 (0x00vv = v * 2^-133) and pre-scales dz by 2^80 (csrc/conv1p.hip):
+    a dense gradient of magnitude 1e-15 / 1 / 1e+10 against float64 -- the accumulators (2^-53 x the sums) must neither underflow nor
+    overflow; same bar as every f32 kernel (2e-5 of the result's scale; measured 4.5e-7)."""
+    M = 512
+    g = torch.Generator(device=DEV).manual_seed(9)
+    obs = torch.randint(0, 256, (M, 84, 84, 4), dtype=torch.uint8, device=DEV, generator=g)
+    obs[:4] = 255
+    obs[4:8] = 0
+    obs[8:12] = 127                                                # the largest subnormal pattern ...
+    obs[12:16] = 128                                               # ... and the smallest normal one
+    dz = torch.randn(M, 20, 20, 32, device=DEV, generator=g) * scale
+    dW, db = cnn.conv_wgrad(obs, dz, 1, None)
+    Wd = torch.zeros(32, 4, 8, 8, dtype=torch.float64, device=DEV, requires_grad=True)
+    bd = torch.zeros(32, dtype=torch.float64, device=DEV, requires_grad=True)
+    refW, refb = torch.autograd.grad(F.conv2d(obs.permute(0, 3, 1, 2).double() / 255.0, Wd, bd, stride=4), (Wd, bd), dz.permute(0, 3, 1, 2).double())
+    assert torch.isfinite(dW).all()
+    _close(dW, refW, f"conv1 wgrad dW at gradient scale {scale:g}")
+    _close(db, refb, f"conv1 wgrad db at gradient scale {scale:g}")
+
+
 @pytest.mark.parametrize("images", [48, 4096])
 def test_trunk_matches_reference_network_forward_backward(images):
     """The whole conv stack + Linear(3136,512) against the reference's nn.Sequential in float64 (same weights)."""
