@@ -187,7 +187,7 @@ def fc_fwd_relu_packed(a: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, 
 
 
 def fc_heads_act_supported(a: torch.Tensor, N: int = 512) -> bool:
-    """The fused rollout step behind the trunk applies to rollout-sized batches (the FC forward splits K below 4,096 rows)."""
+    """The fused rollout step behind the trunk applies wherever the FC forward splits K (below 8,192 rows)."""
     return bool(a.is_cuda and a.dim() == 2 and a.shape[1] % 16 == 0 and a.stride(1) == 1 and
                 _lib.load().mi355ppo_fc_fwd_workspace_bytes(a.shape[0], N, a.shape[1]) > 0)
 
@@ -370,7 +370,7 @@ def fc_wgrad(dz: torch.Tensor, a: torch.Tensor, hwc_channels: int = 0, out: torc
     return out
 
 
-FCZ_MIN_ROWS = 1             # kernel Z at every batch size: from 4,096 rows whole-K wave tiles, below (a rollout step) K split over the grid
+FCZ_MIN_ROWS = 1             # kernel Z at every batch size: from 8,192 rows whole-K wave tiles, below (a rollout step, config B's minibatch) K split over the grid
 
 
 class _Buffers:

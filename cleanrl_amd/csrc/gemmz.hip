@@ -930,7 +930,10 @@ static int zsplit_steps_per(int M, int N, int K) {
 }
 
 extern "C" MI355PPO_API size_t mi355ppo_fc_fwd_workspace_bytes(int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0 || K % 16 || M >= 4096) return 0;          // (from 4,096 rows on the forward needs no workspace)
+    // Below 8,192 rows (round 3: 4,096) -- config B's minibatch of 4,096 rows is 512 whole-K wave tiles on 2,048 wave slots: two K splits
+    // 118 -> 79 us; at 8,192 rows a split buys nothing (134 vs 135 us; profiles/r04_fc_split_minibatch_ab.txt).  MI355PPO_FC_SPLIT_BELOW: A/B runs.
+    static const int below = [] { const char* e = getenv("MI355PPO_FC_SPLIT_BELOW"); return e ? atoi(e) : 8192; }();
+    if (M <= 0 || N <= 0 || K <= 0 || K % 16 || M >= below) return 0;          // (from there on whole-K wave tiles: no workspace)
     const int per = zsplit_steps_per(M, N, K), splits = (K / 16 + per - 1) / per;
     return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -949,7 +952,7 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int 
     return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(za, as_stream(stream), fn);
 }
 
-// The same with a workspace of mi355ppo_fc_fwd_workspace_bytes(M, N, K) bytes: batches below 4,096 rows (a rollout step's 1,024
+// The same with a workspace of mi355ppo_fc_fwd_workspace_bytes(M, N, K) bytes: batches below 8,192 rows (a rollout step's 1,024
 // envs) split K over blockIdx.z -- raw partials into the workspace, then one pass that adds them in order, bias, ReLU.  Without a
 // workspace (or when none is needed) this IS mi355ppo_fc_fwd_relu_packed_f32.
 extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_ws_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
@@ -978,7 +981,7 @@ namespace mi355ppo {
 int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
                     hipStream_t stream) {
     const size_t need = mi355ppo_fc_fwd_workspace_bytes(M, N, K);
-    MI355_REQUIRE(need > 0 && N % 4 == 0, MI355PPO_EINVAL, "%s: M=%d rows need no K split (use the unfused entry points from 4,096 rows on)", fn, M);
+    MI355_REQUIRE(need > 0 && N % 4 == 0, MI355PPO_EINVAL, "%s: M=%d rows need no K split (use the unfused entry points from 8,192 rows on)", fn, M);
     int rc = zgemm_check(fn, a, pack, static_cast<const float*>(ws), M, N, K, lda, N);
     if (rc) return rc;
     MI355_REQUIRE(ws && aligned(ws, 16) && ws_bytes >= need, MI355PPO_EWORKSPACE, "%s: workspace of %zu bytes, %zu needed (mi355ppo_fc_fwd_workspace_bytes)",

@@ -388,7 +388,7 @@ MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int lda, const 
                                                  int M, int N, int K, void* stream);
 MI355PPO_API int mi355ppo_fc_dgrad_mask_packed_f32(const float* dz, int lddz, const void* pack, const float* act_in, float* da,
                                                    int M, int N, int K, void* stream);
-/* Forward for rollout-sized batches (M < 4096: a rollout step's 1,024 envs).  M / 64 x N / 64 wave tiles alone cannot fill the chip,
+/* Forward for rollout-sized and small minibatches (M < 8192: a rollout step's 1,024 envs, config B's 4,096-row minibatch).  M / 64 x N / 64 wave tiles alone cannot fill the chip,
  * so K is split over the grid: raw f32 partials go to `ws` (mi355ppo_fc_fwd_workspace_bytes(M, N, K) bytes, 16-byte aligned; 0 bytes =
  * no split needed), one more pass adds them in a fixed order, then bias and ReLU -- Agent.network[7:9] of the rollout's policy forward
  * (cleanrl/ppo_atari_multigpu.py:144-145,262-264) without a library GEMM.  With ws = NULL: mi355ppo_fc_fwd_relu_packed_f32. */
@@ -552,7 +552,7 @@ MI355PPO_API int mi355ppo_nature_packs_f32(const float* W1, const float* W2, con
                                            void* fc_dgrad, void* stream);
 
 /* Rollout step of the NatureCNN agent, fused behind the trunk (round 4): Linear(3136,512) with K split over the grid (raw partials in
- * `workspace`, mi355ppo_fc_fwd_workspace_bytes(M, 512, 3136) bytes; M < 4096), then ONE kernel for the partial fold + bias + ReLU,
+ * `workspace`, mi355ppo_fc_fwd_workspace_bytes(M, 512, 3136) bytes; M < 8192), then ONE kernel for the partial fold + bias + ReLU,
  * the two heads and the Categorical draw -- Agent.get_action_and_value(next_obs) from conv3's output on
  * (cleanrl/ppo_atari_multigpu.py:144-149,155-159) -- writing action / log-prob / value (and optionally the hidden activations) in
  * place.  Bit-identical to mi355ppo_fc_fwd_relu_packed_ws_f32 -> mi355ppo_heads_fwd_f32 -> mi355ppo_categorical_sample_ctr_f32. */
