@@ -699,6 +699,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce1(const float* __restric
     const int p1 = p0 + kRedChunk < nparts ? p0 + kRedChunk : nparts;
     float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int p = p0;
+    if (p1 - p0 == kRedChunk) {                       // a whole chunk: its 32 loads in flight together, added in the order of the loops below
+        float v[kRedChunk];
+#pragma unroll
+        for (int u = 0; u < kRedChunk; ++u) v[u] = part_w[(size_t)(p0 + u) * NK + e];
+#pragma unroll
+        for (int u = 0; u < kRedChunk; ++u) s8[u & 7] += v[u];
+        p = p1;
+    }
     for (; p + 8 <= p1; p += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) s8[u] += part_w[(size_t)(p + u) * NK + e];
@@ -715,7 +723,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce2(const float* __restric
     const int e = blockIdx.x * 256 + threadIdx.x;     // index into [N][K] (tap-major, channel-minor)
     if (e < N * K) {
         float s = 0.0f;
-        for (int c = 0; c < nchunks; ++c) s += mid[(size_t)c * N * K + e];
+        int q = 0;
+        for (; q + 16 <= nchunks; q += 16) {          // 16 loads in flight, the same order of additions
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = mid[(size_t)(q + u) * N * K + e];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; q < nchunks; ++q) s += mid[(size_t)q * N * K + e];
         const int n = e / K, k = e - n * K;
         const int r = k / (KW * C), rem = k - r * (KW * C), c = rem / C, ch = rem - c * C;
         dW[((n * C + ch) * KH + r) * KW + c] = s * scale;

@@ -140,11 +140,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // dW[n][f(k)] = sum over slabs (in slab order) of part[slab][n][k]; with C > 0 the columns are re-ordered from the trunk's
 // (h, w, c) feature order to the reference's (c, h, w): k = hw * C + c  ->  c * (K / C) + hw.
+constexpr int kWSlabs = 5;
 __global__ __launch_bounds__(256) void fcw_reduce_kernel(const float* __restrict__ part, int nslabs, float* __restrict__ dW, int N, int K, int C) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)N * K;
     if (e >= total) return;
-    float s = part[e];
-    for (int p = 1; p < nslabs; ++p) s += part[(size_t)p * total + e];
+    float s;
+    if (nslabs == kWSlabs) {                          // kernel W's slab count: all loads in flight, the same order of additions
+        float v[kWSlabs];
+#pragma unroll
+        for (int p = 0; p < kWSlabs; ++p) v[p] = part[(size_t)p * total + e];
+        s = v[0];
+#pragma unroll
+        for (int p = 1; p < kWSlabs; ++p) s += v[p];
+    } else {
+        s = part[e];
+        for (int p = 1; p < nslabs; ++p) s += part[(size_t)p * total + e];
+    }
     size_t o = e;
     if (C > 0) {
         const int n = (int)(e / K), k = (int)(e - (size_t)n * K);
@@ -173,7 +184,6 @@ __global__ __launch_bounds__(256) void fcw_reduce_kernel(const float* __restrict
 typedef float w_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWMT = 4, kWNT = 2;                         // 32-row tiles of n (dz) x 32-column tiles of k (a) per wave
 constexpr int kWn = 32 * kWMT, kWk = 32 * kWNT;           // 128 x 64
-constexpr int kWSlabs = 5;
 constexpr int kWLdsFloats = 16 * (kWn + kWk);             // one k-step of a wave: [16][128] + [16][64] floats = 12 KiB
 constexpr unsigned kWOob = 0xFFFFF000u;
 constexpr int kWRsrcWord3 = 0x00020000;

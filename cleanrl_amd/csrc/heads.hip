@@ -218,6 +218,13 @@ __global__ __launch_bounds__(256) void heads_bwd_reduce(const float* __restrict_
     float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const size_t stride = (size_t)rows * (kHid + 1);
     int p = 0;
+    for (; p + 32 <= nparts; p += 32) {              // 32 loads in flight (the fold is a latency chain: 13 workgroups), added in the order below
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = part[(size_t)(p + u) * stride + e];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s8[u & 7] += v[u];
+    }
     for (; p + 8 <= nparts; p += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) s8[u] += part[(size_t)(p + u) * stride + e];
