@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // loads pixels 12-19 and uses the upper four (slot j <- loaded[j + 4], slots 4-7 <- 0: see dz_slot); the empty 16th
     // slot loads the same window and uses nothing.  Nothing is read outside the image.
     float ring[8];           // (a second ring -- dz two steps ahead -- round 3: 877 -> 901 us, 7 spilled VGPRs, profiles/r03_kernel_p_ring2_ab.jsonl;
-                             //  round 4, zero-extended operand: 812 -> 857 us, 13 spilled, profiles/r04_kernel_p_ahead_ab.txt)
+                             //  round 4, zero-extended operand: 812 -> 857 us, 13 spilled, profiles/r04_kernel_p_ahead_ab.txt;
+                             //  dz global -> LDS directly (global_load_lds in inline asm, hand-counted vmcnt, 2 / 3 steps ahead in a ring): 800 -> 840 us
+                             //  and the hand-counted waits were not sufficient (results differed from run to run): profiles/r04_kernel_p_dz_lds_direct_ab.txt)
     int lhx = lh;            // re-materialised per image (see the loop): keeps the per-step selects from being hoisted into 30 live VGPRs
     auto dz_fetch = [&](const float* gd, auto sc) {
         constexpr int s = decltype(sc)::value;
