@@ -44,9 +44,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
     float bias = 0.0f;
     if (lane < A) bias = ba[lane];
     else if (lane == A) bias = bc[0];
-    for (int m = wv; m < M; m += nwv) {
-        const float* hr = h + (size_t)m * kHid + lane * 8;
-        const float4 x = *reinterpret_cast<const float4*>(hr), y = *reinterpret_cast<const float4*>(hr + 4);
+    auto row = [&](int m, const float4& x, const float4& y) {
         const float hv[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
         float out = 0.0f;
 #pragma unroll
@@ -60,6 +58,19 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
         out = out + bias;
         if (lane < A) logits[(size_t)m * A + lane] = out;
         else if (lane == A) value[m] = out;
+    };
+    int m = wv;
+    for (; m + nwv < M; m += 2 * nwv) {              // two rows per iteration: their four 16-byte loads in flight together (a row's arithmetic is unchanged)
+        const float* h0 = h + (size_t)m * kHid + lane * 8;
+        const float* h1 = h + (size_t)(m + nwv) * kHid + lane * 8;
+        const float4 x0 = *reinterpret_cast<const float4*>(h0), y0 = *reinterpret_cast<const float4*>(h0 + 4);
+        const float4 x1 = *reinterpret_cast<const float4*>(h1), y1 = *reinterpret_cast<const float4*>(h1 + 4);
+        row(m, x0, y0);
+        row(m + nwv, x1, y1);
+    }
+    if (m < M) {
+        const float* hr = h + (size_t)m * kHid + lane * 8;
+        row(m, *reinterpret_cast<const float4*>(hr), *reinterpret_cast<const float4*>(hr + 4));
     }
 }
 
