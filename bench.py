@@ -147,7 +147,8 @@ def parse():
                    help="issue the update launch by launch instead of replaying one hipGraph per (epoch, minibatch) slot (forward + fused "
                         "loss + backward + clip + Adam; PPOLearner.capture_update, bit-identical to the eager update in the GPU tests; "
                         "profiles/r04_update_graphs_ab.jsonl).  With graphs the per-launch event brackets of `roofline` / `kernels` come "
-                        "from ONE extra eager iteration right after the timed region (a replay runs no Python to put events around)")
+                        "from an extra eager iteration right after the timed region (the second of two: the first one allocates the eager path's buffers inside "
+                        "the brackets; a replay runs no Python to put events around)")
     p.add_argument("--sync-metrics", action="store_true",
                    help="read every iteration's diagnostics before the next one starts (the reference's arrangement: one device "
                         "synchronisation per iteration); default: resolve them one iteration late, so that the host runs ahead "
@@ -334,7 +335,7 @@ def main():
     if use_update_graphs:
         learner.capture_update()            # (before the timing hooks: no event records in a capture)
         update_mode = ("one hipGraph per (epoch, minibatch) slot: forward + fused loss + backward + clip + Adam (PPOLearner.capture_update); "
-                       "per-launch event brackets from one extra eager iteration after the timed region")
+                       "per-launch event brackets from an extra eager iteration after the timed region")
     elif not cli.no_update_graphs:
         update_mode = "eager launches (update graphs need one GPU and the fused CNN kernels: world > 1 or MI355PPO_CNN=miopen)"
     timer = KernelTimer()
@@ -467,8 +468,10 @@ def main():
         # same kernels on the same buffers as the replayed slots)
         graphs, learner._update_graphs = learner._update_graphs, None
         install_timing_hooks()
-        timer.reset()
         cli.sync_metrics, saved_sync = True, cli.sync_metrics
+        one_step(total_iters - 1)          # the eager path's own first iteration: its buffers come out of the allocator inside the brackets
+        torch.cuda.synchronize()           # (config D's FC forward once read 194 us instead of 130) -- not the one that is reported
+        timer.reset()
         one_step(total_iters - 1)
         torch.cuda.synchronize()
         cli.sync_metrics, learner._update_graphs, timing_iters = saved_sync, graphs, 1
@@ -684,7 +687,7 @@ def main_continuous(cli, rank, world, device):
     if use_update_graphs:
         learner.capture_update()
         update_mode = ("one hipGraph per (epoch, minibatch) slot: fused MLP forward + loss + backward, fold, clip + Adam "
-                       "(PPOLearner.capture_update); per-launch event brackets from one extra eager iteration after the timed region")
+                       "(PPOLearner.capture_update); per-launch event brackets from an extra eager iteration after the timed region")
     timer = KernelTimer()
 
     def install_timing_hooks():
@@ -738,6 +741,8 @@ def main_continuous(cli, rank, world, device):
     if not cli.no_kernel_timing and use_update_graphs:
         graphs, learner._update_graphs = learner._update_graphs, None
         install_timing_hooks()
+        one_step(total_iters - 1)          # (the eager path's first iteration allocates inside the brackets: not the one reported)
+        torch.cuda.synchronize()
         timer.reset()
         one_step(total_iters - 1)
         torch.cuda.synchronize()
