@@ -76,6 +76,25 @@ __device__ __forceinline__ void zpack_store(unsigned short* __restrict__ pack, l
     pack[o + 1024] = (unsigned short)(__float_as_uint(lo) >> 16);
 }
 
+// the same for two consecutive elements e0, e0 + 1 (e0 even) of one lane: three 4-byte stores
+__device__ __forceinline__ void zpack_store2(unsigned short* __restrict__ pack, long long sj, int lane, int e0, float x0, float x1) {
+    unsigned w[3];
+    const float xs[2] = {x0, x1};
+    unsigned h[2], m[2], l[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned xb = __float_as_uint(xs[i]);
+        const unsigned t8 = xb & 0xffff0000u, t16 = xb & 0xffffff00u;
+        const float mid = __uint_as_float(t16) - __uint_as_float(t8), lo = xs[i] - __uint_as_float(t16);
+        h[i] = xb >> 16; m[i] = __float_as_uint(mid) >> 16; l[i] = __float_as_uint(lo) >> 16;
+    }
+    w[0] = h[0] | (h[1] << 16); w[1] = m[0] | (m[1] << 16); w[2] = l[0] | (l[1] << 16);
+    const size_t o = ((size_t)sj * 3 * 64 + lane) * 8 + e0;
+    *reinterpret_cast<unsigned*>(pack + o) = w[0];
+    *reinterpret_cast<unsigned*>(pack + o + 512) = w[1];
+    *reinterpret_cast<unsigned*>(pack + o + 1024) = w[2];
+}
+
 __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ B, int ldb, int N, int K, unsigned short* __restrict__ pack) {
     const int ntiles = (N + 31) / 32;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;                 // (s, j, lane, e)
@@ -91,7 +110,7 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ B,
 // optimizer step the learner used to issue, per minibatch: conv_repack_kernel x 4 and two torch copies (the (h, w, c) reorder of
 // Linear(3136,512).weight and its transpose) to build the f32 matrices, zpack_kernel x 6 over them, and kernel Q's digit pack -- 13
 // launches of 3 - 12 us each, 1 % of a 32,768-image minibatch and 5 % of a 4,096-image one.  Piece p of the grid = the blocks
-// [first[p], first[p + 1]): 0 layer-2 forward (64 x 512), 1 layer-3 forward (64 x 576), 2 layer-3 data gradient (64 x 576, taps
+// [first[p], first[p] + count[p]): 0 layer-2 forward (64 x 512), 1 layer-3 forward (64 x 576), 2 layer-3 data gradient (64 x 576, taps
 // flipped), 3 layer-2 data gradient (4 parity classes x 32 channels, 256), 4 FC forward (512 x 3,136, (h, w, c) order), 5 FC data
 // gradient (3,136 x 512), 6 kernel Q's pack (one block).  The element maps are conv.hip's conv_repack_kernel modes 0 / 1 / 2 and
 // cnn.py's fc_weight_hwc; the packs are bit-identical to the 13-launch route (tests/test_gpu_cnn.py).
@@ -99,19 +118,74 @@ struct ZNaturePacks {
     const float *W1, *W2, *W3, *Wfc;
     unsigned short* out[6];
     unsigned char* qpack;
-    unsigned first[8];
+    unsigned first[7], count[7];      // block range of piece p (6 = kernel Q's pack); the long blocks come first in the grid: Q's pack, the FC slices
 };
 
 __global__ __launch_bounds__(256) void znature_pack_kernel(ZNaturePacks a) {
     int piece = 0;
 #pragma unroll
     for (int p = 1; p < 7; ++p)
-        if (blockIdx.x >= a.first[p]) piece = p;
+        if (blockIdx.x >= a.first[p] && blockIdx.x < a.first[p] + a.count[p]) piece = p;
     if (piece == 6) {
         conv1q_pack_body(a.W1, a.qpack);
         return;
     }
-    constexpr int kN[6] = {64, 64, 64, 128, 512, 3136}, kK[6] = {512, 576, 576, 256, 3136, 512};
+    if (piece >= 4) {
+        // The FC weight (512 x 3,136 in (c, h, w) feature order) enters both packs in (h, w, c) order: element by element that is a 4-byte
+        // read at stride 49 (or 3,136) floats per pack element -- 26 of the launch's 28 us.  Instead a block stages a slice whose rows are
+        // CONTIGUOUS in the parameter through LDS (coalesced 16-byte loads) and walks the 49 (h, w) positions over it:
+        //   piece 4, block (j, cb):  rows n = 32 j .. + 31, channels 16 cb .. + 15 = 784 contiguous floats per row -> units (s = 4 hw + cb, j)
+        //   piece 5, block (s, ch):  rows n = 16 s .. + 15, channels 32 ch .. + 31 = 1,568 contiguous floats per row -> units (s, j' = 2 hw + ch)
+        // (row pitch + 1 float: the walk's reads -- lanes along the rows / the channels, 49 floats apart -- touch 32 distinct banks)
+        extern __shared__ __align__(16) float zn_lds[];
+        const int b = (int)(blockIdx.x - a.first[piece]);
+        const int rows = piece == 4 ? 32 : 16, run = piece == 4 ? 784 : 1568, pitch = run + 1;
+        const int r0 = piece == 4 ? 32 * (b >> 2) : 16 * (b >> 1), c0 = piece == 4 ? 784 * (b & 3) : 1568 * (b & 1);
+        const bool al16 = (reinterpret_cast<uintptr_t>(a.Wfc) & 15) == 0;      // (every slice row then starts on a 16-byte boundary: 3,136 and 784 are multiples of 4)
+        const int total4 = rows * (run / 4);                                  // 6,272 16-byte chunks: 24.5 per thread, eight in flight at a time
+        for (int base = 0; base < total4; base += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + threadIdx.x;
+                if (i < total4) {
+                    const int r = i / (run / 4), q = i - r * (run / 4);
+                    const float* g = a.Wfc + (size_t)(r0 + r) * 3136 + c0 + 4 * q;
+                    if (al16) v[u] = *reinterpret_cast<const float4*>(g);
+                    else v[u] = make_float4(g[0], g[1], g[2], g[3]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + threadIdx.x;
+                if (i < total4) {
+                    const int r = i / (run / 4), q = i - r * (run / 4);
+                    float* d = zn_lds + r * pitch + 4 * q;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
+        }
+        __syncthreads();
+        const int lane = threadIdx.x >> 2, e0 = (threadIdx.x & 3) * 2;          // the thread's lane of the unit and its element pair
+        const int li = lane & 31, lh = lane >> 5;
+#pragma unroll 7
+        for (int hw = 0; hw < 49; ++hw) {
+            float x0, x1;
+            long long sj;
+            if (piece == 4) {              // B[n][(hw, c)]: row li of the slice, channels 8 lh + e of the block's 16
+                const float* t = zn_lds + li * pitch + (8 * lh + e0) * 49 + hw;
+                x0 = t[0]; x1 = t[49];
+                sj = (long long)(4 * hw + (b & 3)) * 16 + (b >> 2);
+            } else {                       // B[(hw, c)][n]: channel li of the block's 32, rows 8 lh + e of the slice
+                const float* t = zn_lds + (8 * lh + e0) * pitch + li * 49 + hw;
+                x0 = t[0]; x1 = t[pitch];
+                sj = (long long)(b >> 1) * 98 + 2 * hw + (b & 1);
+            }
+            zpack_store2(a.out[piece], sj, lane, e0, x0, x1);
+        }
+        return;
+    }
+    constexpr int kN[4] = {64, 64, 64, 128}, kK[4] = {512, 576, 576, 256};
     const int N = kN[piece], K = kK[piece], ntiles = N / 32;
     const long long idx = (long long)(blockIdx.x - a.first[piece]) * 256 + threadIdx.x;      // (s, j, lane, e)
     if (idx >= (long long)(K / 16) * ntiles * 512) return;
@@ -129,13 +203,9 @@ __global__ __launch_bounds__(256) void znature_pack_kernel(ZNaturePacks a) {
     } else if (piece == 2) {               // Bt[cin][(r, c, cout)] = W3[cout][cin][2 - r][2 - c]
         const int r = k / 192, rem = k - r * 192, c = rem >> 6, co = rem & 63;
         x = a.W3[((co * 64 + n) * 3 + (2 - r)) * 3 + (2 - c)];
-    } else if (piece == 3) {               // Bt[cls = 2 ph + pw][cin][(r, c, cout)] = W2[cout][cin][ph + 2 - 2 r][pw + 2 - 2 c]
+    } else {                               // Bt[cls = 2 ph + pw][cin][(r, c, cout)] = W2[cout][cin][ph + 2 - 2 r][pw + 2 - 2 c]
         const int cls = n >> 5, ci = n & 31, r = k >> 7, c = (k >> 6) & 1, co = k & 63;
         x = a.W2[((co * 32 + ci) * 4 + ((cls >> 1) + 2 - 2 * r)) * 4 + ((cls & 1) + 2 - 2 * c)];
-    } else if (piece == 4) {               // B[n][(h, w, c)] = Wfc[n][(c, h, w)]
-        x = a.Wfc[(size_t)n * 3136 + (k & 63) * 49 + (k >> 6)];
-    } else {                               // B[(h, w, c)][n] = the same matrix transposed
-        x = a.Wfc[(size_t)k * 3136 + (n & 63) * 49 + (n >> 6)];
     }
     zpack_store(a.out[piece], sj, lane, e, x);
 }
@@ -872,21 +942,34 @@ extern "C" MI355PPO_API int mi355ppo_nature_packs_f32(const float* W1, const flo
     ZNaturePacks a;
     a.W1 = W1; a.W2 = W2; a.W3 = W3; a.Wfc = Wfc;
     a.qpack = static_cast<unsigned char*>(qpack);
-    unsigned at = 0;
     for (int p = 0; p < 6; ++p) {
         MI355_REQUIRE(!outs[p] || srcs[p], MI355PPO_EINVAL, "%s: pack %d requested without its weight", fn, p);
         MI355_REQUIRE(aligned(outs[p], 16) && aligned(srcs[p], 4), MI355PPO_EALIGN, "%s: packs must be 16-byte aligned", fn);
         a.out[p] = static_cast<unsigned short*>(outs[p]);
-        a.first[p] = at;
-        if (outs[p]) at += (unsigned)((long long)kK[p] * kN[p] / 256);       // K x N elements (N is a multiple of 32), 256 per block
+        a.count[p] = !outs[p] ? 0u : p >= 4 ? 64u : (unsigned)((long long)kK[p] * kN[p] / 256);   // the FC packs: 64 LDS-staged slices each; else K x N elements, 256 per block
     }
     MI355_REQUIRE(!qpack || W1, MI355PPO_EINVAL, "%s: kernel Q's pack requested without the layer-1 weight", fn);
     MI355_REQUIRE(aligned(qpack, 16) && aligned(W1, 4), MI355PPO_EALIGN, "%s: packs must be 16-byte aligned", fn);
-    a.first[6] = at;
-    if (qpack) at += 1;
-    a.first[7] = at;
+    a.count[6] = qpack ? 1u : 0u;
+    unsigned at = 0;
+    static const int order[7] = {6, 4, 5, 0, 1, 2, 3};      // grid order: the one-block digit pack (a 12-us latency chain) and the FC slices start first
+    for (int i = 0; i < 7; ++i) {
+        a.first[order[i]] = at;
+        at += a.count[order[i]];
+    }
     MI355_REQUIRE(at > 0, MI355PPO_EINVAL, "%s: nothing to pack", fn);
-    hipLaunchKernelGGL(znature_pack_kernel, dim3(at), dim3(256), 0, as_stream(stream), a);
+    constexpr size_t kLds = (size_t)32 * 785 * sizeof(float);      // the larger of the two FC slices (16 x 1,569 floats is 64 bytes less)
+    static thread_local int lds_set_dev = -1;                       // hipFuncSetAttribute once per (thread, device): legal inside a capture afterwards
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev != lds_set_dev) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(znature_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("%s: hipFuncSetAttribute(%zu bytes of LDS) failed", fn, kLds);
+            return MI355PPO_EHIP;
+        }
+        lds_set_dev = dev;
+    }
+    hipLaunchKernelGGL(znature_pack_kernel, dim3(at), dim3(256), (fc_fwd || fc_dgrad) ? kLds : 0, as_stream(stream), a);
     return check_launch(fn);
 }
 
