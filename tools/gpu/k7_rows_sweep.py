@@ -26,7 +26,7 @@ lp, adv, ret, val = (torch.randn(B, device=dev, generator=g) for _ in range(4))
 inds = torch.randperm(B, device=dev, generator=g)[:M]
 md = torch.tensor([0.0, 1.0], device=dev)
 sc = torch.zeros(7, device=dev)
-for rpb in (0, 4, 8, 16, 32, 64):
+for rpb in [int(x) for x in os.environ.get("K7_RPB", "0,4,8,16,32,64").split(",")]:
     def call():
         ops.mlp_ppo_fwd_bwd(obs, inds, pa, pc, act, lp, adv, ret, val, 0.2, 0.0, 0.5, True, True, adv_mean_den=md, scalars_out=sc,
                             logstd=agent.actor_logstd.detach(), logstd_grad=agent.actor_logstd.grad, rows_per_block=rpb)
