@@ -32,10 +32,11 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 160 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 170 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2, 1.3: round 3;
                                   1.4: the *_cpu host-pointer twins; 1.5: mi355ppo_init; 1.6: round 4 -- the fused MLP family K7,
-                                  mi355ppo_clip_adam_sched_f32); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
+                                  mi355ppo_clip_adam_sched_f32; 1.7: mi355ppo_fc_heads_act_categorical_f32, mi355ppo_nature_packs_f32,
+                                  mi355ppo_synth_atari_step_hwc_ctr_u8); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
 
 #if defined(__GNUC__)
 #define MI355PPO_API __attribute__((visibility("default")))
