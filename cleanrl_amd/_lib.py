@@ -102,6 +102,21 @@ SIGNATURES = {
                 _P, c_int, _P, c_size_t, _P]),
     "mi355ppo_synth_continuous_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_uint64, _P, _P, c_double, _P, _P, _P, _P, c_int, c_int,
                                                    c_int, _P]),
+    # round 5: the NatureCNN GEMMs on the two-term f16 split (csrc/f16split.h): amax records in, amax records out
+    "mi355ppo_absmax_f32": (c_int, [_P, c_int64, _P, _P]),
+    "mi355ppo_fc_pack_f16x2_bytes": (c_size_t, [c_int, c_int]),
+    "mi355ppo_fc_pack_f16x2_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "mi355ppo_nature_packs_f16x2_f32": (c_int, [_P] * 13),
+    "mi355ppo_cnn_conv1q_fwd_amax": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P]),
+    "mi355ppo_cnn_conv_fwd_packed_f16x2_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
+    "mi355ppo_cnn_conv_dgrad_packed_f16x2_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
+    "mi355ppo_cnn_conv_wgrad_f16x2_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_size_t, _P, _P, _P]),
+    "mi355ppo_fc_fwd_relu_packed_f16x2_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
+    "mi355ppo_fc_dgrad_packed_f16x2_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "mi355ppo_fc_wgrad_f16x2_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
+    "mi355ppo_heads_bwd_relu_amax_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "mi355ppo_fc_heads_act_categorical_f16x2_f32": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_uint64, c_uint64, _P,
+                                                            _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     # host-pointer twins (csrc/host_twins.hip): the device signatures minus stream / workspace
     "mi355ppo_gae_f32_cpu": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_double, c_double]),
     "mi355ppo_categorical_sample_f32_cpu": (c_int, [_P, _P, c_uint64, c_uint64, _P, _P, _P, _P, c_int, c_int]),
@@ -119,7 +134,7 @@ SIGNATURES = {
     "mi355ppo_obs_u8_to_f32_cpu": (c_int, [_P, _P, _P, c_int64, c_int64, c_int]),
 }
 
-ABI_VERSION = 170       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 180       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

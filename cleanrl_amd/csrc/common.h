@@ -23,11 +23,12 @@ int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz
                   hipStream_t s);
 // kernel V (convw.hip): layers 2 / 3 weight + bias gradient on the bf16 pipe; returns 1 when the batch does not qualify
 bool convw_applies(int64_t images, int layer);
-int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s);
+int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
+                 const unsigned* dz_amax = nullptr, const unsigned* src_amax = nullptr);      // amax records: the two-term f16 split (f16split.h)
 
 // kernel Z (gemmz.hip): the K-split raw partials of the rollout-sized FC forward, (splits, M, N) f32 into `ws`
 int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
-                    hipStream_t stream);
+                    hipStream_t stream, const unsigned* a_amax = nullptr);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -1160,10 +1160,8 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_kernel(int64_t images, int l
     return layer == 1 ? 'P' : convw_applies(images, layer) ? 'V' : 'T';
 }
 
-extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW,
-                                                        float* db, int64_t images, int layer, void* workspace,
-                                                        size_t workspace_bytes, void* stream) {
-    const char* fn = "mi355ppo_cnn_conv_wgrad_f32";
+static int conv_wgrad_impl(const char* fn, const void* src, const int64_t* inds, const float* dz, float* dW, float* db, int64_t images, int layer,
+                           void* workspace, size_t workspace_bytes, const unsigned* src_amax, const unsigned* dz_amax, void* stream) {
     int Cin, Cout, KH, SS, Hin, Hout;
     MI355_REQUIRE(src && dz && dW && db, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout), MI355PPO_EINVAL, "%s: layer=%d must be 1..3", fn, layer);
@@ -1192,7 +1190,7 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
         wparts = grid * 4;
         const int rc = conv1p_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images, grid, s);
         if (rc) return rc;
-    } else if (int vparts = 0; convw_launch(static_cast<const float*>(src), dz, part_w, part_b, images, layer, &vparts, s) != 1) {
+    } else if (int vparts = 0; convw_launch(static_cast<const float*>(src), dz, part_w, part_b, images, layer, &vparts, s, dz_amax, src_amax) != 1) {
         wparts = vparts;                // kernel V (bf16 pipe, convw.hip) took it: one partial per slab (an error surfaces in check_launch below)
     } else if (layer == 2) {            // kernel T: a workgroup walks image PAIRS
         wparts = grid = wgrad_grid((images + 1) / 2);
@@ -1213,4 +1211,21 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const i
     hipLaunchKernelGGL(conv_wgrad_reduce2, dim3((total_w + 255) / 256), dim3(256), 0, s, mid, nchunks, mid_b, nchunks, Cout, Cin,
                        KH, KH, layer == 1 ? kInv255 * conv1p_partial_scale() : 1.0f, dW, db);
     return check_launch("conv_wgrad_reduce2");
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* inds, const float* dz, float* dW,
+                                                        float* db, int64_t images, int layer, void* workspace,
+                                                        size_t workspace_bytes, void* stream) {
+    return conv_wgrad_impl("mi355ppo_cnn_conv_wgrad_f32", src, inds, dz, dW, db, images, layer, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+// Layers 2 / 3 with kernel V on the two-term f16 split (f16split.h): src_amax / dz_amax = the operands' amax records.  Batches kernel V
+// does not take (mi355ppo_cnn_conv_wgrad_kernel(images, layer) != 'V') run the f32-pipe kernel T as before; the records are then not read.
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f16x2_f32(const float* src, const float* dz, float* dW, float* db, int64_t images, int layer,
+                                                              void* workspace, size_t workspace_bytes, const uint32_t* src_amax,
+                                                              const uint32_t* dz_amax, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_wgrad_f16x2_f32";
+    MI355_REQUIRE(layer == 2 || layer == 3, MI355PPO_EINVAL, "%s: layer=%d must be 2 or 3 (layer 1: kernel P, mi355ppo_cnn_conv_wgrad_f32)", fn, layer);
+    MI355_REQUIRE(src_amax && dz_amax && aligned(src_amax, 64) && aligned(dz_amax, 64), MI355PPO_EINVAL, "%s: amax records missing or not 64-byte aligned", fn);
+    return conv_wgrad_impl(fn, src, nullptr, dz, dW, db, images, layer, workspace, workspace_bytes, src_amax, dz_amax, stream);
 }

@@ -28,6 +28,7 @@
 // written per image), not by the pipe.
 #include "common.h"
 #include "conv1q_pack.h"
+#include "f16split.h"
 
 #pragma clang fp contract(off)
 
@@ -52,7 +53,8 @@ __device__ __forceinline__ int q_writelane(int w, unsigned x, int l) {
 template <int NW, bool BITS>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv1q_fwd_kernel(const unsigned char* __restrict__ src, const int64_t* __restrict__ inds,
                                                              const unsigned char* __restrict__ pack, const float* __restrict__ bias,
-                                                             float* __restrict__ dst, unsigned* __restrict__ bits, unsigned P, int ntiles, unsigned dst_bytes) {
+                                                             float* __restrict__ dst, unsigned* __restrict__ bits, unsigned P, int ntiles, unsigned dst_bytes,
+                                                             unsigned* __restrict__ amax) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     // digit matrices, in operand layout, -> LDS [row][digit][lane]
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
         const long long simg = img == img0 ? s0 : s1;
         return src + ((simg * kQH + gy * 4) * kQW + gx * 4) * (long long)kQC + 16 * lh;
     };
+    unsigned vmax = 0u;                    // bits of the largest value this lane stored (>= 0 after the ReLU): dst's amax record (f16split.h)
     u32x4q ring[kQRows];
     // workgroups are dealt to the 8 XCDs round robin: give each XCD a contiguous range of tile groups, so that the waves
     // that share source rows (vertical window overlap, neighbouring tiles of one image) also share an L2
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
             float v = t * scale;
             v = v + bias_r;
             v = v > 0.0f ? v : 0.0f;
+            vmax = __float_as_uint(v) > vmax ? __float_as_uint(v) : vmax;     // (pixels past P re-read pixel 0: real values)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_dst, off, 0, 0);   // dropped when out of range
             if constexpr (BITS) {      // ballot lanes 0..31: the 32 channels of pixel (e & 3) + 8 (e >> 2); lanes 32..63: of that pixel + 4
                 const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.0f);
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
         cur = nxt;
         nxt = setup(tile + 2 * nwv);
     }
+    if (amax) amax_commit(amax, vmax, blockIdx.x * NW + wave, lane);      // (uniform; one atomic per wave of the persistent grid)
 }
 
 static int g_q_cus = 0;
@@ -166,7 +171,7 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_pack(const float* W, void* pack,
 }
 
 static int conv1q_fwd_impl(const char* fn, const void* src_u8, const int64_t* inds, const void* pack, const float* bias, float* dst,
-                           unsigned* bits, int64_t images, void* stream) {
+                           unsigned* bits, int64_t images, void* stream, unsigned* amax = nullptr) {
     MI355_REQUIRE(src_u8 && pack && bias && dst, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(images > 0 && images <= (1 << 22), MI355PPO_EINVAL, "%s: images=%lld out of range (1..4194304)", fn,
                   (long long)images);
@@ -189,11 +194,11 @@ static int conv1q_fwd_impl(const char* fn, const void* src_u8, const int64_t* in
     if (bits)
         hipLaunchKernelGGL((conv1q_fwd_kernel<NW, true>), dim3((unsigned)wgs), dim3(64 * NW), 0, as_stream(stream),
                            static_cast<const unsigned char*>(src_u8), inds, static_cast<const unsigned char*>(pack), bias, dst, bits, (unsigned)P,
-                           ntiles, (unsigned)dstb);
+                           ntiles, (unsigned)dstb, amax);
     else
         hipLaunchKernelGGL((conv1q_fwd_kernel<NW, false>), dim3((unsigned)wgs), dim3(64 * NW), 0, as_stream(stream),
                            static_cast<const unsigned char*>(src_u8), inds, static_cast<const unsigned char*>(pack), bias, dst, bits, (unsigned)P,
-                           ntiles, (unsigned)dstb);
+                           ntiles, (unsigned)dstb, amax);
     return check_launch(fn);
 }
 
@@ -207,4 +212,13 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_fwd_bits(const void* src_u8, con
     const char* fn = "mi355ppo_cnn_conv1q_fwd_bits";
     MI355_REQUIRE(mask_bits, MI355PPO_EINVAL, "%s: null pointer", fn);
     return conv1q_fwd_impl(fn, src_u8, inds, pack, bias, dst, mask_bits, images, stream);
+}
+
+// The same (mask_bits may be null) that also folds the stored activations into `dst_amax`, dst's amax record (MI355PPO_AMAX_WORDS uint32,
+// zeroed by the caller): what the f16x2 forward of layer 2 scales its A operand by.
+extern "C" MI355PPO_API int mi355ppo_cnn_conv1q_fwd_amax(const void* src_u8, const int64_t* inds, const void* pack, const float* bias,
+                                                         float* dst, uint32_t* mask_bits, int64_t images, uint32_t* dst_amax, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv1q_fwd_amax";
+    MI355_REQUIRE(dst_amax && aligned(dst_amax, 64), MI355PPO_EINVAL, "%s: amax record missing or not 64-byte aligned", fn);
+    return conv1q_fwd_impl(fn, src_u8, inds, pack, bias, dst, mask_bits, images, stream, dst_amax);
 }

@@ -20,6 +20,7 @@
 // carried from step to step by an add-with-carry, the divisions by the row length are multiplies.
 #include "common.h"
 #include "bf16split.h"
+#include "f16split.h"
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -42,18 +43,19 @@ constexpr int kVCout = 64;
 // piece `arg` = 6 * fragment + piece, 2 = LDS writes (third `arg`), 3 = global loads (third `arg`), 4 = source addresses of
 // the block three steps ahead.  Order: R0 R1 | per fragment f: S_f.0-2, X_f, S_f.3-5, R_{f+2} | the X items left over, with
 // X = W0 W1 W2 ADDR L0 L1 L2.
+// ppf = split pieces per fragment: 6 (bf16) or 2 (f16, one per half fragment: f16split.h) -- S_f.0 .. S_f.(ppf/2 - 1), X_f, the rest, R_{f+2}
 struct VItem { int kind, arg; };
 constexpr VItem v_xitem(int x) { return x < 3 ? VItem{2, x} : x == 3 ? VItem{4, 0} : VItem{3, x - 4}; }
-constexpr int v_nitems(int nf) { return 7 * nf + 7; }
-constexpr VItem v_item(int t, int nf) {
+constexpr int v_nitems(int nf, int ppf) { return (ppf + 1) * nf + 7; }
+constexpr VItem v_item(int t, int nf, int ppf) {
     if (t < 2) return {0, t};
     int u = t - 2;
     for (int f = 0; f < nf; ++f) {
-        const int len = 7 + (f + 2 < nf ? 1 : 0);
+        const int len = ppf + 1 + (f + 2 < nf ? 1 : 0);
         if (u < len) {
-            if (u < 3) return {1, 6 * f + u};
-            if (u == 3) return v_xitem(f);
-            if (u < 7) return {1, 6 * f + u - 1};
+            if (u < ppf / 2) return {1, ppf * f + u};
+            if (u == ppf / 2) return v_xitem(f);
+            if (u < ppf + 1) return {1, ppf * f + u - 1};
             return {0, f + 2};
         }
         u -= len;
@@ -61,16 +63,26 @@ constexpr VItem v_item(int t, int nf) {
     return u < 7 - nf ? v_xitem(nf + u) : VItem{-1, 0};
 }
 
-template <class G, int NT, int NP>
+// SPLIT: 0 = three bf16 terms, NP = 6 / 9 pairs; 1 = two f16 terms under the operands' power-of-two scales (amax records of dz and
+// src), NP = 3 pairs, the partial dW un-scaled on its way out (f16split.h).  The bias gradient sums the dz fragments as read (f32).
+template <class G, int NT, int NP, int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convw_bf16_kernel(
     const float* __restrict__ src, const float* __restrict__ dz, float* __restrict__ part_w, float* __restrict__ part_b, int images,
-    int nslabs, unsigned m8, unsigned m16, int xcd_order) {
+    int nslabs, unsigned m8, unsigned m16, int xcd_order, const unsigned* __restrict__ dz_amax, const unsigned* __restrict__ src_amax) {
     constexpr int MT = 2, NF = MT + NT, NGROUPS = G::TILES / NT, NL = 4 + 2 * NT;       // fragments; wave groups; loads per block
+    constexpr int TERMS = SPLIT ? 2 : 3, PPF = SPLIT ? 2 : 6;
     constexpr int LDSF = 16 * (kVCout + 32 * NT);                                       // floats of one block in LDS
     static_assert(G::TILES % NT == 0, "whole groups of NT tiles");
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * LDSF];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    float sz = 1.0f, ss = 1.0f, un = 1.0f;                // SPLIT: the operands' scales and the factor that removes both from the partial
+    if constexpr (SPLIT) {                                // (before the early exit below: the wave reduction wants every lane)
+        const int ez = f16_scale_exp(amax_load(dz_amax, lane)), es = f16_scale_exp(amax_load(src_amax, lane));
+        sz = f16_pow2(ez);
+        ss = f16_pow2(es);
+        un = f16_unscale(ez, es);
+    }
     // Workgroups are dealt to the eight XCDs round robin in launch order; neighbours in the UNIT order share data -- the six wave
     // groups of a layer-3 slab sit in two consecutive workgroups and read the same dz and source pixels, consecutive slabs take
     // adjacent 16-pixel blocks whose windows overlap -- so XCD x takes a contiguous range of the unit order (kernel Z's scheme):
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     s_u32x4 stage[NL];                                    // one block as loaded: 4 x dz, 2 per source tile
     unsigned raw[2][8];                                   // two fragments as read back from LDS (f32, lane = column, 8 rows)
-    unsigned tt[2][NF][3][4];                             // split fragments: [k-step parity][fragment: MT x dz, NT x source][term][4 x 2 bf16]
+    unsigned tt[2][NF][TERMS][4];                         // split fragments: [k-step parity][fragment: MT x dz, NT x source][term][4 x 2 bf16 / f16]
     auto sclamp = [&](int s) { return s < nsteps ? s : nsteps - 1; };               // past the end: re-read, never multiplied
     constexpr int TH = (NL + 2) / 3;                      // loads / LDS writes per third
     auto load_third = [&](int s, auto tc) {               // third tc of the loads of step s's block (source origins in `po`)
@@ -195,23 +207,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     };
-    auto frag_of = [&](int par, int f, int term) {
-        return __builtin_bit_cast(s_bf16x8, (s_u32x4){tt[par][f][term][0], tt[par][f][term][1], tt[par][f][term][2], tt[par][f][term][3]});
+    auto split_piece_h = [&](int par, auto fc, auto hc) { // SPLIT = 1: half hf (4 elements) of fragment f, 10 VALU (+ the bias gradient's 3 adds)
+        constexpr int f = decltype(fc)::value, hf = decltype(hc)::value;
+        if constexpr (f < MT) {
+            const float h4 = (__uint_as_float(raw[f & 1][4 * hf]) + __uint_as_float(raw[f & 1][4 * hf + 1])) +
+                             (__uint_as_float(raw[f & 1][4 * hf + 2]) + __uint_as_float(raw[f & 1][4 * hf + 3]));
+            pend[f] = hf == 0 ? h4 : pend[f] + h4;
+        }
+        unsigned hi[2], lo[2];
+        f16_split4((s_u32x4){raw[f & 1][4 * hf], raw[f & 1][4 * hf + 1], raw[f & 1][4 * hf + 2], raw[f & 1][4 * hf + 3]}, f < MT ? sz : ss, hi, lo);
+        tt[par][f][0][2 * hf] = hi[0]; tt[par][f][0][2 * hf + 1] = hi[1];
+        tt[par][f][TERMS - 1][2 * hf] = lo[0]; tt[par][f][TERMS - 1][2 * hf + 1] = lo[1];
     };
+    auto frag_bits = [&](int par, int f, int term) { return (s_u32x4){tt[par][f][term][0], tt[par][f][term][1], tt[par][f][term][2], tt[par][f][term][3]}; };
     auto next_origins = [&]() {                           // `po` <- window origins of the NEXT block of this slab (then advance)
         po[0] = pix_off(0);
         po[1] = pix_off(1);
         advance();
     };
-    constexpr int NM = NP * MT * NT, NI = v_nitems(NF);
-    constexpr int PX[9] = {0, 0, 1, 0, 2, 1, 1, 2, 2}, PY[9] = {0, 1, 0, 2, 0, 1, 2, 1, 2};
+    constexpr int NM = NP * MT * NT, NI = v_nitems(NF, PPF);
+    static_assert(SPLIT ? (NP == 3 || NP == 4) : (NP == 6 || NP == 9), "term pairs of the split");
+    constexpr int PX[9] = {0, 0, 1, SPLIT ? 1 : 0, 2, 1, 1, 2, 2}, PY[9] = {0, 1, 0, SPLIT ? 1 : 2, 0, 1, 2, 1, 2};
     // One pipeline step of parity q (kernel W's): the MFMAs of step s on tt[q]; meanwhile the fragments of step s + 1 are read
     // from LDS buffer q ^ 1 and split into tt[q ^ 1]; `stage` (the block of step s + 2) goes to LDS buffer q; the block of step
     // s + 3 is loaded into `stage`.  Items t with t * NM / NI == g sit behind MFMA g, each followed by a sched_barrier.
     auto run_item = [&](auto qc, int s, auto tc) {
         constexpr int q = decltype(qc)::value;
-        constexpr VItem it = v_item(decltype(tc)::value, NF);
+        constexpr VItem it = v_item(decltype(tc)::value, NF, PPF);
         if constexpr (it.kind == 0) read_frag(q ^ 1, std::integral_constant<int, it.arg>{});
+        else if constexpr (it.kind == 1 && SPLIT) split_piece_h(q ^ 1, std::integral_constant<int, it.arg / 2>{}, std::integral_constant<int, it.arg % 2>{});
         else if constexpr (it.kind == 1) split_piece(q ^ 1, std::integral_constant<int, it.arg / 6>{}, std::integral_constant<int, it.arg % 6>{});
         else if constexpr (it.kind == 2) write_third(q, std::integral_constant<int, it.arg>{});
         else if constexpr (it.kind == 3) load_third(s + 3, std::integral_constant<int, it.arg>{});
@@ -225,7 +249,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         [&]<int... GI>(std::integer_sequence<int, GI...>) {
             ([&] {
                 constexpr int g = GI, pi = g / (MT * NT), i = (g / NT) % MT, j = g % NT;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(q, i, PX[pi]), frag_of(q, MT + j, PY[pi]), acc[i][j], 0, 0, 0);
+                if constexpr (SPLIT)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, frag_bits(q, i, PX[pi])),
+                                                                       __builtin_bit_cast(s_f16x8, frag_bits(q, MT + j, PY[pi])), acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, frag_bits(q, i, PX[pi])),
+                                                                        __builtin_bit_cast(s_bf16x8, frag_bits(q, MT + j, PY[pi])), acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 constexpr int lo = (g * NI + NM - 1) / NM, hi = ((g + 1) * NI + NM - 1) / NM;      // items t with t * NM / NI == g
                 static_assert(hi - lo <= 2, "at most two items behind one MFMA");
@@ -245,10 +274,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto split_all = [&](int par, int buf) {              // all fragments of LDS buffer `buf` -> tt[par] (prologue; ONE pack expansion, see fcw.hip)
         [&]<int... T>(std::integer_sequence<int, T...>) {
             ([&] {
-                if constexpr (T % 6 == 0) read_frag(buf, std::integral_constant<int, T / 6>{});
-                split_piece(par, std::integral_constant<int, T / 6>{}, std::integral_constant<int, T % 6>{});
+                if constexpr (T % PPF == 0) read_frag(buf, std::integral_constant<int, T / PPF>{});
+                if constexpr (SPLIT) split_piece_h(par, std::integral_constant<int, T / 2>{}, std::integral_constant<int, T % 2>{});
+                else split_piece(par, std::integral_constant<int, T / 6>{}, std::integral_constant<int, T % 6>{});
             }(), ...);
-        }(std::make_integer_sequence<int, 6 * NF>{});
+        }(std::make_integer_sequence<int, PPF * NF>{});
     };
     if (nsteps > 0) {
         // prologue: step 0 -> LDS buffer 0 -> tt[0]; step 1 -> LDS buffer 1; step 2 in `stage`; origins of step 3 follow in step 0
@@ -278,7 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) out[(size_t)(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh) * G::K + kcol] = acc[i][j][e];
+            for (int e = 0; e < 16; ++e) out[(size_t)(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh) * G::K + kcol] = SPLIT ? acc[i][j][e] * un : acc[i][j][e];
     }
     if (grp == 0) {
 #pragma unroll
@@ -303,7 +333,8 @@ bool convw_applies(int64_t images, int layer) {
 
 // Launches kernel V if the batch qualifies; *nparts = partials written (part_w [nparts][64 * K], part_b [nparts][64]).
 // Returns 1 if it does not apply.
-int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s) {
+int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
+                 const unsigned* dz_amax, const unsigned* src_amax) {
     if (!convw_applies(images, layer)) return 1;
     const int S = convw_slabs(layer);
     *nparts = S;
@@ -312,12 +343,14 @@ int convw_launch(const float* src, const float* dz, float* part_w, float* part_b
                             // (same-box A/B with a run-time switch, profiles/r03_raster_ab.jsonl, r03_pmc_fetch_raster_{before,after}.csv)
     if (layer == 2) {
         const int grid = (S * (VGeom2::TILES / 4) + 3) / 4;
-        if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 9>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd);
-        else hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 6>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd);
+        if (dz_amax) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 3, 1>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
+        else if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 9, 0>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
+        else hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 6, 0>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
     } else {
         const int grid = (S * (VGeom3::TILES / 3) + 3) / 4;
-        if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 9>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd);
-        else hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 6>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd);
+        if (dz_amax) hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 3, 1>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
+        else if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 9, 0>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
+        else hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 6, 0>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
     }
     return check_launch("convw_bf16_kernel");
 }

@@ -20,6 +20,7 @@
 // (workgroups are dealt to the 8 XCDs round robin), so that block leaves HBM once and is served three times by that L2.
 #include "common.h"
 #include "bf16split.h"
+#include "f16split.h"
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -191,17 +192,19 @@ constexpr int kWRsrcWord3 = 0x00020000;
 // schedule of a k-step: item t sits behind MFMA t.  kinds: 0 = read fragment `arg` from LDS (8 ds_read_b32), 1 = split piece
 // `arg` = 6 * fragment + piece, 2 = LDS writes (third `arg` of the 12), 3 = global loads (third `arg`), -1 = nothing.
 struct WItem { int kind, arg; };
-constexpr WItem w_item(int t) {
-    // R0 R1 | S0.0 S0.1 S0.2 W0 S0.3 S0.4 S0.5 R2 | S1.* (W1) R3 | S2.* (W2) R4 | S3.* (L0) R5 | S4.* (L1) | S5.* (L2)
+// ppf = split pieces per fragment: 6 (bf16: two halves x {masks, subtractions, packs}) or 2 (f16: one piece per half, f16split.h)
+constexpr WItem w_item(int t, int ppf) {
+    // bf16: R0 R1 | S0.0 S0.1 S0.2 W0 S0.3 S0.4 S0.5 R2 | S1.* (W1) R3 | S2.* (W2) R4 | S3.* (L0) R5 | S4.* (L1) | S5.* (L2)
+    // f16:  R0 R1 | S0.0 W0 S0.1 R2 | S1.0 W1 S1.1 R3 | S2.0 W2 S2.1 R4 | S3.0 L0 S3.1 R5 | S4.0 L1 S4.1 | S5.0 L2 S5.1
     if (t == 0) return {0, 0};
     if (t == 1) return {0, 1};
     int u = t - 2;
     for (int f = 0; f < 6; ++f) {
-        const int len = 6 + 1 + (f < 4 ? 1 : 0);          // six split pieces, one W / L item, (one fragment read)
+        const int len = ppf + 1 + (f < 4 ? 1 : 0);        // the split pieces, one W / L item, (one fragment read)
         if (u < len) {
-            if (u < 3) return {1, 6 * f + u};
-            if (u == 3) return f < 3 ? WItem{2, f} : WItem{3, f - 3};
-            if (u < 7) return {1, 6 * f + u - 1};
+            if (u < ppf / 2) return {1, ppf * f + u};
+            if (u == ppf / 2) return f < 3 ? WItem{2, f} : WItem{3, f - 3};
+            if (u < ppf + 1) return {1, ppf * f + u - 1};
             return {0, f + 2};
         }
         u -= len;
@@ -209,13 +212,23 @@ constexpr WItem w_item(int t) {
     return {-1, 0};
 }
 
-template <int NP>
+// SPLIT: 0 = three bf16 terms, NP = 6 / 9 pairs; 1 = two f16 terms under the operands' power-of-two scales (amax records of dz and a),
+// NP = 3 pairs, the partial un-scaled on its way out (f16split.h)
+template <int NP, int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fcw_bf16_kernel(
     const float* __restrict__ dz, int lddz, const float* __restrict__ a, float* __restrict__ part, int M, int N, int K, int nkb,
-    unsigned m8, unsigned m16) {
+    unsigned m8, unsigned m16, const unsigned* __restrict__ dz_amax, const unsigned* __restrict__ a_amax) {
+    constexpr int TERMS = SPLIT ? 2 : 3, PPF = SPLIT ? 2 : 6;
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * kWLdsFloats];        // 4 waves x 2 buffers x 12 KiB = 96 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    float sz = 1.0f, sa = 1.0f, un = 1.0f;                // SPLIT: the operands' scales and the factor that removes both from the partial
+    if constexpr (SPLIT) {
+        const int ez = f16_scale_exp(amax_load(dz_amax, lane)), ea = f16_scale_exp(amax_load(a_amax, lane));
+        sz = f16_pow2(ez);
+        sa = f16_pow2(ea);
+        un = f16_unscale(ez, ea);
+    }
     // Every workgroup reads ALL of its slab's dz (512 columns): in launch order the 49 workgroups of a slab land on all eight XCDs
     // and each L2 fetches the whole dz (8 x 67 MB of the launch's 0.95 GB of L2 misses, profiles/traffic.json).  XCD x takes a
     // contiguous range of the (slab, k block) order instead (kernel Z's scheme): an L2 then sees at most two slabs.
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     s_u32x4 stage[12];                                    // one block as loaded: 8 x dz, 4 x a
     unsigned raw[2][8];                                   // two fragments as read back from LDS (f32, lane = column, 8 rows)
-    unsigned tt[2][6][3][4];                              // split fragments: [k-step parity][fragment: 4 x dz, 2 x a][term][4 x 2 bf16]
+    unsigned tt[2][6][TERMS][4];                          // split fragments: [k-step parity][fragment: 4 x dz, 2 x a][term][4 x 2 bf16 / f16]
     auto sclamp = [&](int s) { return s < nsteps ? s : nsteps - 1; };               // past the end: re-read, never multiplied
     auto load_third = [&](int s, auto tc) {               // third tc of the 12 global loads of step s's block
         constexpr int t3 = decltype(tc)::value;
@@ -301,11 +314,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     };
-    auto frag_of = [&](int par, int f, int term) {
-        return __builtin_bit_cast(s_bf16x8, (s_u32x4){tt[par][f][term][0], tt[par][f][term][1], tt[par][f][term][2], tt[par][f][term][3]});
+    auto split_piece_h = [&](int par, auto fc, auto hc) { // SPLIT = 1: half hf (4 elements) of fragment f, 10 VALU
+        constexpr int f = decltype(fc)::value, hf = decltype(hc)::value;
+        unsigned hi[2], lo[2];
+        f16_split4((s_u32x4){raw[f & 1][4 * hf], raw[f & 1][4 * hf + 1], raw[f & 1][4 * hf + 2], raw[f & 1][4 * hf + 3]}, f < 4 ? sz : sa, hi, lo);
+        tt[par][f][0][2 * hf] = hi[0]; tt[par][f][0][2 * hf + 1] = hi[1];
+        tt[par][f][TERMS - 1][2 * hf] = lo[0]; tt[par][f][TERMS - 1][2 * hf + 1] = lo[1];
     };
+    auto frag_bits = [&](int par, int f, int term) { return (s_u32x4){tt[par][f][term][0], tt[par][f][term][1], tt[par][f][term][2], tt[par][f][term][3]}; };
     constexpr int NM = NP * kWMT * kWNT;
-    constexpr int PX[9] = {0, 0, 1, 0, 2, 1, 1, 2, 2}, PY[9] = {0, 1, 0, 2, 0, 1, 2, 1, 2};
+    static_assert(SPLIT ? (NP == 3 || NP == 4) : (NP == 6 || NP == 9), "term pairs of the split");
+    static_assert(NM >= 12 + 6 * PPF, "one MFMA per scheduled item");
+    constexpr int PX[9] = {0, 0, 1, SPLIT ? 1 : 0, 2, 1, 1, 2, 2}, PY[9] = {0, 1, 0, SPLIT ? 1 : 2, 0, 1, 2, 1, 2};
     // One pipeline step of parity q (the MFMAs of step s on tt[q]); meanwhile: the fragments of step s + 1 are read from LDS
     // buffer q ^ 1 and split into tt[q ^ 1]; `stage` (the block of step s + 2, loaded during the previous step) is written to
     // LDS buffer q (its fragments were all read during the previous step); the block of step s + 3 is loaded into `stage`.
@@ -315,9 +335,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         [&]<int... G>(std::integer_sequence<int, G...>) {
             ([&] {
                 constexpr int g = G, pi = g / (kWMT * kWNT), i = (g / kWNT) % kWMT, j = g % kWNT;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(q, i, PX[pi]), frag_of(q, 4 + j, PY[pi]), acc[i][j], 0, 0, 0);
-                constexpr WItem it = w_item(g);
+                if constexpr (SPLIT)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, frag_bits(q, i, PX[pi])),
+                                                                       __builtin_bit_cast(s_f16x8, frag_bits(q, 4 + j, PY[pi])), acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s_bf16x8, frag_bits(q, i, PX[pi])),
+                                                                        __builtin_bit_cast(s_bf16x8, frag_bits(q, 4 + j, PY[pi])), acc[i][j], 0, 0, 0);
+                constexpr WItem it = w_item(g, PPF);
                 if constexpr (it.kind == 0) read_frag(q ^ 1, std::integral_constant<int, it.arg>{});
+                else if constexpr (it.kind == 1 && SPLIT) split_piece_h(q ^ 1, std::integral_constant<int, it.arg / 2>{}, std::integral_constant<int, it.arg % 2>{});
                 else if constexpr (it.kind == 1) split_piece(q ^ 1, std::integral_constant<int, it.arg / 6>{}, std::integral_constant<int, it.arg % 6>{});
                 else if constexpr (it.kind == 2) write_third(q, std::integral_constant<int, it.arg>{});
                 else if constexpr (it.kind == 3) load_third(s + 3, std::integral_constant<int, it.arg>{});
@@ -332,10 +358,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // every inner call saw fragment 0, piece 0; found with a host replica of this bookkeeping)
         [&]<int... T>(std::integer_sequence<int, T...>) {
             ([&] {
-                if constexpr (T % 6 == 0) read_frag(buf, std::integral_constant<int, T / 6>{});
-                split_piece(par, std::integral_constant<int, T / 6>{}, std::integral_constant<int, T % 6>{});
+                if constexpr (T % PPF == 0) read_frag(buf, std::integral_constant<int, T / PPF>{});
+                if constexpr (SPLIT) split_piece_h(par, std::integral_constant<int, T / 2>{}, std::integral_constant<int, T % 2>{});
+                else split_piece(par, std::integral_constant<int, T / 6>{}, std::integral_constant<int, T % 6>{});
             }(), ...);
-        }(std::make_integer_sequence<int, 36>{});
+        }(std::make_integer_sequence<int, 6 * PPF>{});
     };
     if (nsteps > 0) {
         // prologue: step 0 -> LDS buffer 0 -> tt[0]; step 1 -> LDS buffer 1; step 2 in `stage`
@@ -363,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int n = n0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
             float* row = out + (size_t)n * K + k0 + li;
 #pragma unroll
-            for (int j = 0; j < kWNT; ++j) row[32 * j] = acc[i][j][e];
+            for (int j = 0; j < kWNT; ++j) row[32 * j] = SPLIT ? acc[i][j][e] * un : acc[i][j][e];
         }
 }
 
@@ -394,9 +421,8 @@ extern "C" MI355PPO_API int mi355ppo_fc_wgrad_kernel(int M, int N, int K) {
     return fcw_w_shape(M, N, K) ? 'W' : 'Y';
 }
 
-extern "C" MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
-                                                  void* workspace, size_t workspace_bytes, void* stream) {
-    const char* fn = "mi355ppo_fc_wgrad_f32";
+static int fc_wgrad_impl(const char* fn, const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
+                         void* workspace, size_t workspace_bytes, const unsigned* dz_amax, const unsigned* a_amax, void* stream) {
     MI355_REQUIRE(dz && a && dW, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 224 == 0, MI355PPO_EINVAL,
                   "%s: M=%d N=%d K=%d (N must be a positive multiple of 64, K of 224: whole 64 x 224 wave tiles)", fn, M, N, K);
@@ -413,10 +439,12 @@ extern "C" MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, con
     // kernel W (bf16 pipe) for this layer's shape at minibatch sizes; kernel Y (f32 pipe) otherwise
     if (fcw_w_shape(M, N, K) && aligned(dz, 16) && lddz % 4 == 0) {
         const int nkb = K / kWk;
-        if (bf16_term_pairs() == 9)
-            hipLaunchKernelGGL((fcw_bf16_kernel<9>), dim3((unsigned)(nkb * kWSlabs)), dim3(256), 0, s, dz, lddz, a, part, M, N, K, nkb, 0xffff0000u, 0xffffff00u);
+        if (dz_amax)
+            hipLaunchKernelGGL((fcw_bf16_kernel<3, 1>), dim3((unsigned)(nkb * kWSlabs)), dim3(256), 0, s, dz, lddz, a, part, M, N, K, nkb, 0xffff0000u, 0xffffff00u, dz_amax, a_amax);
+        else if (bf16_term_pairs() == 9)
+            hipLaunchKernelGGL((fcw_bf16_kernel<9, 0>), dim3((unsigned)(nkb * kWSlabs)), dim3(256), 0, s, dz, lddz, a, part, M, N, K, nkb, 0xffff0000u, 0xffffff00u, dz_amax, a_amax);
         else
-            hipLaunchKernelGGL((fcw_bf16_kernel<6>), dim3((unsigned)(nkb * kWSlabs)), dim3(256), 0, s, dz, lddz, a, part, M, N, K, nkb, 0xffff0000u, 0xffffff00u);
+            hipLaunchKernelGGL((fcw_bf16_kernel<6, 0>), dim3((unsigned)(nkb * kWSlabs)), dim3(256), 0, s, dz, lddz, a, part, M, N, K, nkb, 0xffff0000u, 0xffffff00u, dz_amax, a_amax);
         int rcw = check_launch("fcw_bf16_kernel");
         if (rcw) return rcw;
         const size_t totalw = (size_t)N * K;
@@ -432,4 +460,19 @@ extern "C" MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, con
     const size_t total = (size_t)N * K;
     hipLaunchKernelGGL(fcw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, nslabs, dW, N, K, hwc_channels);
     return check_launch("fcw_reduce_kernel");
+}
+
+extern "C" MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
+                                                  void* workspace, size_t workspace_bytes, void* stream) {
+    return fc_wgrad_impl("mi355ppo_fc_wgrad_f32", dz, lddz, a, dW, M, N, K, hwc_channels, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+// The same with kernel W on the two-term f16 split (f16split.h): dz_amax / a_amax = the operands' amax records.  Shapes kernel W does
+// not take (mi355ppo_fc_wgrad_kernel(M, N, K) == 'Y') run the f32-pipe kernel Y as before; the records are then not read.
+extern "C" MI355PPO_API int mi355ppo_fc_wgrad_f16x2_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
+                                                        void* workspace, size_t workspace_bytes, const uint32_t* dz_amax, const uint32_t* a_amax,
+                                                        void* stream) {
+    const char* fn = "mi355ppo_fc_wgrad_f16x2_f32";
+    MI355_REQUIRE(dz_amax && a_amax && aligned(dz_amax, 64) && aligned(a_amax, 64), MI355PPO_EINVAL, "%s: amax records missing or not 64-byte aligned", fn);
+    return fc_wgrad_impl(fn, dz, lddz, a, dW, M, N, K, hwc_channels, workspace, workspace_bytes, dz_amax, a_amax, stream);
 }

@@ -28,6 +28,7 @@
 #include "common.h"
 #include "conv1q_pack.h"
 #include "bf16split.h"
+#include "f16split.h"
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -106,6 +107,67 @@ __global__ __launch_bounds__(256) void zpack_kernel(const float* __restrict__ B,
     zpack_store(pack, sj, lane, e, n < N ? B[(size_t)n * ldb + k] : 0.0f);
 }
 
+// ---- the f16x2 pack (SPLIT = 1 of kernel Z, f16split.h): [64-byte header: word 0 = bits of max |B|, the rest 0][k-step][32-column tile]
+// [hi, lo][64 lanes][8 f16], the terms of s B with s = 2^f16_scale_exp(max |B|) -- the kernel derives the same s from the header.
+// `pack` below = the first byte behind the header.
+__device__ __forceinline__ void zpack_store_h(unsigned short* __restrict__ pack, long long sj, int lane, int e, float x, float s) {
+    unsigned short h, l;
+    f16_split1(x, s, h, l);
+    const size_t o = ((size_t)sj * 2 * 64 + lane) * 8 + e;                           // term 0; term 1 follows at + 512
+    pack[o] = h;
+    pack[o + 512] = l;
+}
+__device__ __forceinline__ void zpack_store2_h(unsigned short* __restrict__ pack, long long sj, int lane, int e0, float x0, float x1, float s) {
+    unsigned short h0, l0, h1, l1;
+    f16_split1(x0, s, h0, l0);
+    f16_split1(x1, s, h1, l1);
+    const size_t o = ((size_t)sj * 2 * 64 + lane) * 8 + e0;
+    *reinterpret_cast<unsigned*>(pack + o) = (unsigned)h0 | ((unsigned)h1 << 16);
+    *reinterpret_cast<unsigned*>(pack + o + 512) = (unsigned)l0 | ((unsigned)l1 << 16);
+}
+__device__ __forceinline__ void zpack_header(unsigned char* __restrict__ pack, unsigned amax_bits, int t) {      // threads t = 0 .. 15 of one block
+    if (t < kF16PackHeader / 4) reinterpret_cast<unsigned*>(pack)[t] = t == 0 ? amax_bits : 0u;
+}
+
+__global__ __launch_bounds__(256) void zpack_h_kernel(const float* __restrict__ B, int ldb, int N, int K, const unsigned* __restrict__ b_amax,
+                                                      unsigned char* __restrict__ pack) {
+    const unsigned am = amax_load(b_amax, threadIdx.x & 63);                        // (before any exit: the wave reduction wants all lanes)
+    const float sc = f16_pow2(f16_scale_exp(am));
+    if (blockIdx.x == 0) zpack_header(pack, am, threadIdx.x);
+    const int ntiles = (N + 31) / 32;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;                 // (s, j, lane, e)
+    if (idx >= (long long)(K / 16) * ntiles * 512) return;
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const long long sj = idx >> 9;
+    const int j = (int)(sj % ntiles), st = (int)(sj / ntiles);
+    const int n = 32 * j + (lane & 31), k = 16 * st + 8 * (lane >> 5) + e;
+    zpack_store_h(reinterpret_cast<unsigned short*>(pack + kF16PackHeader), sj, lane, e, n < N ? B[(size_t)n * ldb + k] : 0.0f, sc);
+}
+
+// max |x| of up to three tensors into their amax records (rec + MI355PPO_AMAX_WORDS * t), `per` blocks per tensor; the records were zeroed
+struct ZAbsmax3 {
+    const float* x[3];
+    long long n[3];
+};
+__global__ __launch_bounds__(256) void zabsmax_kernel(ZAbsmax3 a, unsigned* __restrict__ rec, int per) {
+    const int t = blockIdx.x / per, b = blockIdx.x - t * per;
+    const float* __restrict__ x = a.x[t];
+    const long long n = a.n[t];
+    unsigned m = 0u;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const long long n4 = n >> 2;
+        for (long long i = (long long)b * 256 + threadIdx.x; i < n4; i += (long long)per * 256) {
+            const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+            const unsigned p = max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu));
+            m = max(m, p);
+        }
+        for (long long i = (n4 << 2) + (long long)b * 256 + threadIdx.x; i < n; i += (long long)per * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    } else {
+        for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += (long long)per * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    }
+    amax_commit(rec + (size_t)MI355PPO_AMAX_WORDS * t, m, (unsigned)blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
 // Every weight pack of the NatureCNN agent in ONE launch, straight from the parameters as torch stores them (round 4).  After an
 // optimizer step the learner used to issue, per minibatch: conv_repack_kernel x 4 and two torch copies (the (h, w, c) reorder of
 // Linear(3136,512).weight and its transpose) to build the f32 matrices, zpack_kernel x 6 over them, and kernel Q's digit pack -- 13
@@ -119,8 +181,11 @@ struct ZNaturePacks {
     unsigned short* out[6];
     unsigned char* qpack;
     unsigned first[7], count[7];      // block range of piece p (6 = kernel Q's pack); the long blocks come first in the grid: Q's pack, the FC slices
+    const unsigned* wrec;             // SPLIT = 1: the amax records of W2, W3, Wfc (MI355PPO_AMAX_WORDS apart), filled by zabsmax_kernel
 };
 
+// SPLIT = 1: the six kernel-Z packs in the f16x2 format (header + two f16 planes under the weight tensor's scale); kernel Q's pack as before
+template <int SPLIT>
 __global__ __launch_bounds__(256) void znature_pack_kernel(ZNaturePacks a) {
     int piece = 0;
 #pragma unroll
@@ -129,6 +194,14 @@ __global__ __launch_bounds__(256) void znature_pack_kernel(ZNaturePacks a) {
     if (piece == 6) {
         conv1q_pack_body(a.W1, a.qpack);
         return;
+    }
+    float sc = 1.0f;
+    unsigned short* const outp = a.out[piece] + (SPLIT ? kF16PackHeader / 2 : 0);       // the planes (behind the header)
+    if constexpr (SPLIT) {                 // (block-uniform code so far: all lanes are active for the wave reduction)
+        const int wt = piece >= 4 ? 2 : (piece == 1 || piece == 2) ? 1 : 0;             // pieces 0, 3: W2; 1, 2: W3; 4, 5: Wfc
+        const unsigned am = amax_load(a.wrec + (size_t)MI355PPO_AMAX_WORDS * wt, threadIdx.x & 63);
+        sc = f16_pow2(f16_scale_exp(am));
+        if (blockIdx.x == a.first[piece]) zpack_header(reinterpret_cast<unsigned char*>(a.out[piece]), am, threadIdx.x);
     }
     if (piece >= 4) {
         // The FC weight (512 x 3,136 in (c, h, w) feature order) enters both packs in (h, w, c) order: element by element that is a 4-byte
@@ -181,7 +254,8 @@ __global__ __launch_bounds__(256) void znature_pack_kernel(ZNaturePacks a) {
                 x0 = t[0]; x1 = t[pitch];
                 sj = (long long)(b >> 1) * 98 + 2 * hw + (b & 1);
             }
-            zpack_store2(a.out[piece], sj, lane, e0, x0, x1);
+            if constexpr (SPLIT) zpack_store2_h(outp, sj, lane, e0, x0, x1, sc);
+            else zpack_store2(outp, sj, lane, e0, x0, x1);
         }
         return;
     }
@@ -207,7 +281,8 @@ __global__ __launch_bounds__(256) void znature_pack_kernel(ZNaturePacks a) {
         const int cls = n >> 5, ci = n & 31, r = k >> 7, c = (k >> 6) & 1, co = k & 63;
         x = a.W2[((co * 32 + ci) * 4 + ((cls >> 1) + 2 - 2 * r)) * 4 + ((cls & 1) + 2 - 2 * c)];
     }
-    zpack_store(a.out[piece], sj, lane, e, x);
+    if constexpr (SPLIT) zpack_store_h(outp, sj, lane, e, x, sc);
+    else zpack_store(outp, sj, lane, e, x);
 }
 
 // Item t of `items` sits behind MFMA number ((t + 1) * span) / items - 1 of a k-step (distinct slots for span >= items).
@@ -327,6 +402,8 @@ struct ZArgs {
     unsigned m8, m16;           // 0xffff0000, 0xffffff00: in SGPRs (as literals every v_and would be an 8-byte instruction)
     int steps_per;              // Z_RAW: k-steps per K split (blockIdx.z); 0 otherwise
     int super_rows;             // GEMM rows, stacked waves: row blocks per supertile of the workgroup order (0: launch order)
+    const unsigned* a_amax;     // SPLIT = 1 (two-term f16 split, f16split.h): amax record of A; B's maximum sits in the pack's header
+    unsigned* c_amax;           // SPLIT = 1: amax record of C to fold the epilogue's values into, or null
 };
 
 // WAVES_N: the waves of a workgroup sit side by side (they read the same A rows) instead of on top of each other (they stream
@@ -340,15 +417,28 @@ struct ZArgs {
 //   linear: conflict-free): one s_barrier per k-step pair, B's share of the L1 traffic / NWAVES.  The waves of a workgroup must
 //   walk the same k-steps: no wave leaves early (rows past the batch are clamped and their stores dropped), and with border
 //   classes the NWAVES waves take the SAME class tile of NWAVES consecutive image groups.  K / 16 must be even.
-template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int NP, int OCC, bool BLDS>
+// SPLIT: 0 = three bf16 terms per operand, NP = 6 (or 9) term pairs on v_mfma_f32_32x32x16_bf16 (bf16split.h);
+//        1 = two f16 terms per operand under per-tensor power-of-two scales, NP = 3 (or 4) pairs on v_mfma_f32_32x32x16_f16
+//            (f16split.h): half the matrix instructions, 10 instead of 22 split instructions per four elements.  The pack is then
+//            [64-byte header][k-step][tile][hi, lo][64 lanes][8 f16], the accumulators are un-scaled in the epilogue.
+template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int NP, int OCC, bool BLDS, int SPLIT>
 __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void z_kernel(ZArgs a) {
     constexpr int ROWS = 32 * MT, LOADS = ROWS / 16;
-    constexpr int kPairPieces = 2 * NT * 3, kPairBytes = kPairPieces * 1024, kShare = kPairPieces / NWAVES;      // B of a k-step pair
+    constexpr int TERMS = SPLIT ? 2 : 3, kTile = TERMS * 1024;                        // one 32-column tile of one k-step in the pack
+    constexpr int kPairPieces = 2 * NT * TERMS, kPairBytes = kPairPieces * 1024, kShare = kPairPieces / NWAVES;      // B of a k-step pair
     static_assert(!BLDS || (!WAVES_N && kPairPieces % NWAVES == 0), "B ring: stacked waves, whole KiB pieces per wave");
     __shared__ __attribute__((aligned(16))) float lds[NWAVES * ROWS * kZPitch + (BLDS ? 2 * kPairBytes / 4 : 0)];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // (the wave index in an SGPR)
     const int li = lane & 31, lh = lane >> 5;
     const int N = a.N;
+    // SPLIT: the operands' scales -- A's from its amax record, B's from the pack header (the load's latency hides under the prologue's)
+    float sa = 1.0f, un = 1.0f;
+    if constexpr (SPLIT) {
+        const int ea = f16_scale_exp(amax_load(a.a_amax, lane));
+        const int eb = f16_scale_exp(*reinterpret_cast<const unsigned*>(a.pack));
+        sa = f16_pow2(ea);
+        un = f16_unscale(ea, eb);
+    }
     // Workgroup -> (column block, row block).  The convolutions re-read their source through the L2 (windows overlap; the
     // border classes of an image group share its taps), and every XCD has its own L2: workgroups are dealt to the XCDs round
     // robin in launch order, so XCD x runs the CONTIGUOUS range [start_x, start_x + count_x) of the logical order -- neighbours in
@@ -471,8 +561,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     }
     float* const wr_ptr = wl + (lane >> 2) * kZPitch + 4 * (lane & 3);               // + 16 u rows
     const float* const rd_ptr = wl + li * kZPitch + 8 * lh;                          // + 32 i rows
-    const unsigned char* const pb = a.pack + (size_t)j0 * kZTileBytes + 16 * lane;
-    const size_t step_bytes = (size_t)ntiles * kZTileBytes;
+    const unsigned char* const pb = a.pack + (SPLIT ? kF16PackHeader : 0) + (size_t)j0 * kTile + 16 * lane;
+    const size_t step_bytes = (size_t)ntiles * kTile;
     const unsigned m8 = a.m8, m16 = a.m16;
 
     z_f32x16 acc[MT][NT];
@@ -485,8 +575,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
 
     s_u32x4 stage[LOADS];                                 // A of a later k-step, as loaded (coalesced layout), on its way to LDS
     s_u32x4 raw[MT][2];                                   // fragments of the NEXT k-step as read back from LDS (f32, lane = row)
-    unsigned ta[2][MT][3][4];                             // split A fragments: [k-step parity][fragment][term][4 x 2 bf16]
-    s_u32x4 tb[2][NT][3];                                 // B fragments straight from the pack
+    unsigned ta[2][MT][TERMS][4];                         // split A fragments: [k-step parity][fragment][term][4 x 2 bf16 / f16]
+    s_u32x4 tb[2][NT][TERMS];                             // B fragments straight from the pack
     const int k0 = EPI == Z_RAW ? (int)blockIdx.z * a.steps_per : 0;              // first k-step of this K split
     const int nsteps = RG::CLS ? c_nty * c_spr : RG::CONV ? RG::K / 16 : EPI == Z_RAW ? ((a.K >> 4) - k0 < a.steps_per ? (a.K >> 4) - k0 : a.steps_per) : a.K >> 4;
     auto kclamp = [&](int s) { return s < nsteps ? s : nsteps - 1; };                // past the end: re-read, never multiplied
@@ -535,10 +625,10 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         for (int j = 0; j < NT; ++j) {
             const bool ok = j0 + j < ntiles;                                        // (wave-uniform) tiles past N: re-read tile j0
 #pragma unroll
-            for (int t = 0; t < 3; ++t) tb[par][j][t] = *reinterpret_cast<const s_u32x4*>(p + (ok ? j : 0) * kZTileBytes + t * 1024);
+            for (int t = 0; t < TERMS; ++t) tb[par][j][t] = *reinterpret_cast<const s_u32x4*>(p + (ok ? j : 0) * kTile + t * 1024);
         }
     };
-    // ---- BLDS: the workgroup's B ring.  Piece x of a pair = (k-step half h, column tile j, term t), x = (h NT + j) 3 + t, one KiB
+    // ---- BLDS: the workgroup's B ring.  Piece x of a pair = (k-step half h, column tile j, term t), x = (h NT + j) TERMS + t, one KiB
     // each; wave w fetches pieces w kShare .. + kShare - 1.  `bcur` / `bnxt` = byte offsets of the two slots.
     unsigned char* const ring = reinterpret_cast<unsigned char*>(lds + NWAVES * ROWS * kZPitch);
     s_u32x4 bst[BLDS ? kShare : 1];
@@ -548,8 +638,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     if constexpr (BLDS) {
 #pragma unroll
         for (int u = 0; u < kShare; ++u) {
-            const int x = wave * kShare + u, h = x / (NT * 3), jt = x - h * (NT * 3), j = jt / 3;
-            const int jt_ok = j0 + j < ntiles ? jt : jt - 3 * j;                     // column tiles past N: re-read tile j0 (never stored)
+            const int x = wave * kShare + u, h = x / (NT * TERMS), jt = x - h * (NT * TERMS), j = jt / TERMS;
+            const int jt_ok = j0 + j < ntiles ? jt : jt - TERMS * j;                 // column tiles past N: re-read tile j0 (never stored)
             bsrc[u] = (size_t)h * step_bytes + (size_t)jt_ok * 1024;
         }
     }
@@ -571,7 +661,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) tb[par][j][t] = *reinterpret_cast<const s_u32x4*>(ring + slot + ((h * NT + j) * 3 + t) * 1024 + 16 * lane);
+            for (int t = 0; t < TERMS; ++t) tb[par][j][t] = *reinterpret_cast<const s_u32x4*>(ring + slot + ((h * NT + j) * TERMS + t) * 1024 + 16 * lane);
     };
     auto ring_barrier = [&]() {                           // this wave's ring writes have landed; then every wave's
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -617,6 +707,14 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             }
         }
     };
+    // SPLIT = 1: the f16 split of one half fragment is ONE piece of 10 VALU instructions (f16split.h)
+    auto split_piece_h = [&](int par, auto ic, auto hc) {
+        constexpr int i = decltype(ic)::value, hf = decltype(hc)::value;
+        unsigned hi[2], lo[2];
+        f16_split4(raw[i][hf], sa, hi, lo);
+        ta[par][i][0][2 * hf] = hi[0]; ta[par][i][0][2 * hf + 1] = hi[1];
+        ta[par][i][TERMS - 1][2 * hf] = lo[0]; ta[par][i][TERMS - 1][2 * hf + 1] = lo[1];
+    };
     // One pipeline step of parity q.  Nothing a step computes depends on a load or LDS access of the SAME step:
     //   B of step s + 1 (global)                      -> tb[q ^ 1]
     //   `raw` = fragments of step s + 1 (read from LDS at the end of the previous step) -> split -> ta[q ^ 1]
@@ -630,9 +728,10 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     // MFMA waits for the one before it.
     // BLDS: two more items in the even steps -- this wave's pieces of pair p + 1 to the ring (loaded two steps earlier), its pieces
     // of pair p + 2 from global memory -- and the odd steps open with the ring barrier.
-    constexpr int NM = NP * MT * NT, kPieces = 6 * MT, kItems = kPieces + 3 + (BLDS ? 2 : 0), kTail = NM > 2 * kItems ? NM / 4 : NM - kItems;
+    constexpr int NM = NP * MT * NT, kPieces = (SPLIT ? 2 : 6) * MT, kItems = kPieces + 3 + (BLDS ? 2 : 0), kTail = NM > 2 * kItems ? NM / 4 : NM - kItems;
     static_assert(NM - kTail >= kItems, "one MFMA per scheduled item");
-    constexpr int PX[9] = {0, 0, 1, 0, 2, 1, 1, 2, 2}, PY[9] = {0, 1, 0, 2, 0, 1, 2, 1, 2};     // pairs by weight: the first six have x + y <= 2
+    static_assert(SPLIT ? (NP == 3 || NP == 4) : (NP == 6 || NP == 9), "term pairs of the split");
+    constexpr int PX[9] = {0, 0, 1, SPLIT ? 1 : 0, 2, 1, 1, 2, 2}, PY[9] = {0, 1, 0, SPLIT ? 1 : 2, 0, 1, 2, 1, 2};     // pairs by weight: bf16 -- the first six have x + y <= 2; f16 -- hi hi, hi lo, lo hi (, lo lo)
     auto step = [&](auto qc, int s) {
         constexpr int q = decltype(qc)::value;
         if constexpr (BLDS) {
@@ -645,12 +744,19 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         [&]<int... G>(std::integer_sequence<int, G...>) {
             ([&] {
                 constexpr int g = G, pi = g / (MT * NT), i = (g / NT) % MT, j = g % NT;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(s_bf16x8, (s_u32x4){ta[q][i][PX[pi]][0], ta[q][i][PX[pi]][1], ta[q][i][PX[pi]][2], ta[q][i][PX[pi]][3]}),
-                    __builtin_bit_cast(s_bf16x8, tb[q][j][PY[pi]]), acc[i][j], 0, 0, 0);
+                if constexpr (SPLIT)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(s_f16x8, (s_u32x4){ta[q][i][PX[pi]][0], ta[q][i][PX[pi]][1], ta[q][i][PX[pi]][2], ta[q][i][PX[pi]][3]}),
+                        __builtin_bit_cast(s_f16x8, tb[q][j][PY[pi]]), acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(s_bf16x8, (s_u32x4){ta[q][i][PX[pi]][0], ta[q][i][PX[pi]][1], ta[q][i][PX[pi]][2], ta[q][i][PX[pi]][3]}),
+                        __builtin_bit_cast(s_bf16x8, tb[q][j][PY[pi]]), acc[i][j], 0, 0, 0);
                 constexpr int t = z_item_at(g, kItems, NM - kTail);                 // the item behind MFMA g, or -1
                 if constexpr (t >= 0) {
-                    if constexpr (t < kPieces)
+                    if constexpr (t < kPieces && SPLIT)
+                        split_piece_h(q ^ 1, std::integral_constant<int, t / 2>{}, std::integral_constant<int, t % 2>{});
+                    else if constexpr (t < kPieces)
                         split_piece(q ^ 1, std::integral_constant<int, t / 6>{}, std::integral_constant<int, (t / 3) % 2>{}, std::integral_constant<int, t % 3>{});
                     else if constexpr (t == kPieces) to_lds();
                     else if constexpr (t == kPieces + 1) load_a(s + 3);
@@ -664,7 +770,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     };
     auto split_all = [&](int par) {
         [&]<int... T>(std::integer_sequence<int, T...>) {
-            (split_piece(par, std::integral_constant<int, T / 6>{}, std::integral_constant<int, (T / 3) % 2>{}, std::integral_constant<int, T % 3>{}), ...);
+            if constexpr (SPLIT) (split_piece_h(par, std::integral_constant<int, T / 2>{}, std::integral_constant<int, T % 2>{}), ...);
+            else (split_piece(par, std::integral_constant<int, T / 6>{}, std::integral_constant<int, (T / 3) % 2>{}, std::integral_constant<int, T % 3>{}), ...);
         }(std::make_integer_sequence<int, kPieces>{});
     };
     // prologue: step 0 split into ta[0] with its B terms in tb[0]; fragments of step 1 in `raw`; A of step 2 in `stage`.  The
@@ -750,6 +857,12 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         else coff[j] = n0 + 32 * j + li < N ? (unsigned)(n0 + 32 * j + li) * 4u : kZOob;
     }
     auto at = [&](unsigned ro, int j) -> unsigned { return (ro == kZOob || coff[j] == kZOob) ? kZOob : ro + coff[j]; };
+    // SPLIT: the accumulators carry both operands' scales; `fin` removes them (a power of two: exact).  `cmax` collects the bit
+    // patterns of |C| for C's amax record -- of every value the wave computed: rows / columns past the edge are re-reads of real rows
+    // and columns (their stores are dropped), so they cannot exceed the tensor's maximum.
+    auto fin = [&](float x) -> float { if constexpr (SPLIT) return x * un; else return x; };
+    unsigned cmax = 0u;
+    auto seen = [&](float v) { if constexpr (SPLIT && EPI != Z_RAW) { const unsigned b = __float_as_uint(v) & 0x7fffffffu; cmax = b > cmax ? b : cmax; } };
     if constexpr (kMaskBits) {
         // lane L holds the mask word of row m0 + L for each of the wave's column tiles: C's element (row, column n) is bit n % 32 of
         // word (byte offset of the element) / 128 -- every 32-column tile of a row starts on a 128-byte boundary of C
@@ -773,7 +886,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
                 for (int j = 0; j < NT; ++j) {
                     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wm[j], 32 * i + (e & 3) + 8 * (e >> 2));
                     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)wm[j], 32 * i + (e & 3) + 8 * (e >> 2) + 4);
-                    const float v = z_keep_where(acc[i][j][e], lo, hi);       // lanes 0..31 (lh = 0): bit li of `lo`, lanes 32..63: of `hi`
+                    const float v = z_keep_where(fin(acc[i][j][e]), lo, hi);  // lanes 0..31 (lh = 0): bit li of `lo`, lanes 32..63: of `hi`
+                    seen(v);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, at(ro, j), 0, 0);
                 }
             }
@@ -799,7 +913,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
                     const unsigned ro = ro_of(32 * (i0 + ib) + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const float v = __uint_as_float(mk[ib][j][e]) > 0.0f ? acc[i0 + ib][j][e] : 0.0f;
+                        const float v = __uint_as_float(mk[ib][j][e]) > 0.0f ? fin(acc[i0 + ib][j][e]) : 0.0f;
+                        seen(v);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, at(ro, j), 0, 0);
                     }
                 }
@@ -811,7 +926,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             for (int e = 0; e < 16; ++e) {
                 const unsigned ro = ro_of(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e]), rsrc_c, at(ro, j), 0, 0);
+                for (int j = 0; j < NT; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fin(acc[i][j][e])), rsrc_c, at(ro, j), 0, 0);
             }
     } else {
         float bj[NT];
@@ -830,8 +945,9 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
                 const unsigned ro = ro_of(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    float v = acc[i][j][e] + bj[j];
+                    float v = fin(acc[i][j][e]) + bj[j];
                     v = v > 0.0f ? v : 0.0f;
+                    seen(v);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, at(ro, j), 0, 0);
                     if constexpr (kBitsOut) {             // lanes 0..31 of the ballot: the 32 columns of row (e & 3) + 8 (e >> 2); 32..63: of that row + 4
                         const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.0f);
@@ -850,6 +966,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
             }
         }
     }
+    if constexpr (SPLIT && EPI != Z_RAW)
+        if (a.c_amax) amax_commit(a.c_amax, cmax, blockIdx.x + 3u * blockIdx.y + (unsigned)wave, lane);      // (wave-uniform condition)
 }
 
 template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int OCC = NWAVES / 4, bool BLDS = false>
@@ -868,10 +986,12 @@ static int z_launch(const ZArgs& a, hipStream_t s, const char* what) {
         set_error("%s: %lld rows exceed one launch", what, a.M);
         return MI355PPO_EINVAL;
     }
-    if (bf16_term_pairs() == 9)
-        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 9, OCC, BLDS>), grid, dim3(64 * NWAVES), 0, s, a);
+    if (a.a_amax)         // the two-term f16 split (the *_f16x2 entry points): `pack` is an f16x2 pack
+        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 3, OCC, BLDS, 1>), grid, dim3(64 * NWAVES), 0, s, a);
+    else if (bf16_term_pairs() == 9)
+        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 9, OCC, BLDS, 0>), grid, dim3(64 * NWAVES), 0, s, a);
     else
-        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 6, OCC, BLDS>), grid, dim3(64 * NWAVES), 0, s, a);
+        hipLaunchKernelGGL((z_kernel<RG, MT, NT, NWAVES, EPI, WAVES_N, 6, OCC, BLDS, 0>), grid, dim3(64 * NWAVES), 0, s, a);
     return check_launch(what);
 }
 
@@ -923,6 +1043,7 @@ static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, 
     ZArgs a;
     a.A = A; a.a_bytes = (unsigned)a_bytes; a.lda = lda; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.mask = mask;
     a.bits_in = nullptr; a.bits_out = nullptr;
+    a.a_amax = nullptr; a.c_amax = nullptr;
     a.steps_per = 0;
     a.super_rows = 0;
     a.C = C; a.c_bytes = (unsigned)c_bytes; a.ldc = ldc; a.M = M; a.images = images; a.N = N; a.K = K; a.m8 = 0xffff0000u; a.m16 = 0xffffff00u;
@@ -932,16 +1053,15 @@ static ZArgs zargs(const void* A, long long a_bytes, int lda, const void* pack, 
 // All six kernel-Z packs and kernel Q's pack of the NatureCNN agent from its parameters in torch's layouts, one launch
 // (znature_pack_kernel).  Buffers: mi355ppo_fc_pack_bytes(64, 512), (64, 576), (64, 576), (128, 256), (512, 3136), (3136, 512) and
 // mi355ppo_cnn_conv1q_pack_bytes() bytes; a null output skips its piece (W1 / qpack, W2 / its two packs, ... may be absent together).
-extern "C" MI355PPO_API int mi355ppo_nature_packs_f32(const float* W1, const float* W2, const float* W3, const float* Wfc, void* qpack,
-                                                      void* conv2_fwd, void* conv3_fwd, void* conv3_dgrad, void* conv2_dgrad, void* fc_fwd,
-                                                      void* fc_dgrad, void* stream) {
-    const char* fn = "mi355ppo_nature_packs_f32";
+static int nature_packs_impl(const char* fn, const float* W1, const float* W2, const float* W3, const float* Wfc, void* qpack, void* conv2_fwd,
+                             void* conv3_fwd, void* conv3_dgrad, void* conv2_dgrad, void* fc_fwd, void* fc_dgrad, unsigned* w_amax, void* stream) {
     void* outs[6] = {conv2_fwd, conv3_fwd, conv3_dgrad, conv2_dgrad, fc_fwd, fc_dgrad};
     const float* srcs[6] = {W2, W3, W3, W2, Wfc, Wfc};
     static const int kN[6] = {64, 64, 64, 128, 512, 3136}, kK[6] = {512, 576, 576, 256, 3136, 512};
     ZNaturePacks a;
     a.W1 = W1; a.W2 = W2; a.W3 = W3; a.Wfc = Wfc;
     a.qpack = static_cast<unsigned char*>(qpack);
+    a.wrec = w_amax;
     for (int p = 0; p < 6; ++p) {
         MI355_REQUIRE(!outs[p] || srcs[p], MI355PPO_EINVAL, "%s: pack %d requested without its weight", fn, p);
         MI355_REQUIRE(aligned(outs[p], 16) && aligned(srcs[p], 4), MI355PPO_EALIGN, "%s: packs must be 16-byte aligned", fn);
@@ -962,15 +1082,51 @@ extern "C" MI355PPO_API int mi355ppo_nature_packs_f32(const float* W1, const flo
     static thread_local int lds_set_dev = -1;                       // hipFuncSetAttribute once per (thread, device): legal inside a capture afterwards
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && dev != lds_set_dev) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(znature_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(znature_pack_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(znature_pack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) != hipSuccess) {
             (void)hipGetLastError();
             set_error("%s: hipFuncSetAttribute(%zu bytes of LDS) failed", fn, kLds);
             return MI355PPO_EHIP;
         }
         lds_set_dev = dev;
     }
-    hipLaunchKernelGGL(znature_pack_kernel, dim3(at), dim3(256), (fc_fwd || fc_dgrad) ? kLds : 0, as_stream(stream), a);
+    if (w_amax) {
+        // the weights' maxima first: zero the three records, one pass over W2 / W3 / Wfc (6.7 MB), then the packs under those scales
+        MI355_REQUIRE(W2 && W3 && Wfc, MI355PPO_EINVAL, "%s: the f16x2 packs need W2, W3 and Wfc", fn);
+        MI355_REQUIRE(aligned(w_amax, 64), MI355PPO_EALIGN, "%s: the amax records must be 64-byte aligned", fn);
+        if (hipMemsetAsync(w_amax, 0, 3 * MI355PPO_AMAX_WORDS * sizeof(unsigned), as_stream(stream)) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("%s: hipMemsetAsync of the amax records failed", fn);
+            return MI355PPO_EHIP;
+        }
+        ZAbsmax3 m;
+        m.x[0] = W2; m.n[0] = 64 * 32 * 4 * 4; m.x[1] = W3; m.n[1] = 64 * 64 * 3 * 3; m.x[2] = Wfc; m.n[2] = 512 * 3136;
+        hipLaunchKernelGGL(zabsmax_kernel, dim3(3 * 64), dim3(256), 0, as_stream(stream), m, w_amax, 64);
+        int rc = check_launch("zabsmax_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(znature_pack_kernel<1>, dim3(at), dim3(256), (fc_fwd || fc_dgrad) ? kLds : 0, as_stream(stream), a);
+    } else {
+        hipLaunchKernelGGL(znature_pack_kernel<0>, dim3(at), dim3(256), (fc_fwd || fc_dgrad) ? kLds : 0, as_stream(stream), a);
+    }
     return check_launch(fn);
+}
+
+extern "C" MI355PPO_API int mi355ppo_nature_packs_f32(const float* W1, const float* W2, const float* W3, const float* Wfc, void* qpack,
+                                                      void* conv2_fwd, void* conv3_fwd, void* conv3_dgrad, void* conv2_dgrad, void* fc_fwd,
+                                                      void* fc_dgrad, void* stream) {
+    return nature_packs_impl("mi355ppo_nature_packs_f32", W1, W2, W3, Wfc, qpack, conv2_fwd, conv3_fwd, conv3_dgrad, conv2_dgrad, fc_fwd, fc_dgrad,
+                             nullptr, stream);
+}
+
+// The same with the six kernel-Z packs in the f16x2 format (mi355ppo_fc_pack_f16x2_bytes of the same shapes) -- what the *_f16x2 entry
+// points take.  `w_amax`: 3 amax records (3 * MI355PPO_AMAX_WORDS uint32, 64-byte aligned) that receive max |W2|, |W3|, |Wfc| (zeroed and
+// filled here: a memset, one pass over the three tensors, the pack launch).
+extern "C" MI355PPO_API int mi355ppo_nature_packs_f16x2_f32(const float* W1, const float* W2, const float* W3, const float* Wfc, void* qpack,
+                                                            void* conv2_fwd, void* conv3_fwd, void* conv3_dgrad, void* conv2_dgrad, void* fc_fwd,
+                                                            void* fc_dgrad, uint32_t* w_amax, void* stream) {
+    const char* fn = "mi355ppo_nature_packs_f16x2_f32";
+    MI355_REQUIRE(w_amax, MI355PPO_EINVAL, "%s: null pointer", fn);
+    return nature_packs_impl(fn, W1, W2, W3, Wfc, qpack, conv2_fwd, conv3_fwd, conv3_dgrad, conv2_dgrad, fc_fwd, fc_dgrad, w_amax, stream);
 }
 
 // h[m][n] = relu(bias[n] + part[0][m][n] + part[1][m][n] + ...): the K splits of Z_RAW added in order (deterministic)
@@ -1021,13 +1177,13 @@ extern "C" MI355PPO_API size_t mi355ppo_fc_fwd_workspace_bytes(int M, int N, int
     return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
-extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
-                                                            int M, int N, int K, void* stream) {
-    const char* fn = "mi355ppo_fc_fwd_relu_packed_f32";
+static int fc_fwd_impl(const char* fn, const float* a, int lda, const void* pack, const float* bias, float* h, int M, int N, int K,
+                       const unsigned* a_amax, unsigned* h_amax, void* stream) {
     int rc = zgemm_check(fn, a, pack, h, M, N, K, lda, N);
     if (rc) return rc;
     MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
-    const ZArgs za = zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, h, (long long)M * N * 4, N, M, N, K);
+    ZArgs za = zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, h, (long long)M * N * 4, N, M, N, K);
+    za.a_amax = a_amax; za.c_amax = h_amax;
     // 64 x 128 wave tiles, one wave per SIMD, for the large batches; below 16,384 rows those do not fill the chip (M / 64 workgroups):
     // 64 x 64 wave tiles, two 4-wave workgroups per CU (measured on one box, profiles/r03_zcfg_ab.jsonl: 32,768 rows 471 vs 531 us,
     // 8,192 rows 205 vs 145 us, 4,096 rows 182 vs 128 us)
@@ -1035,19 +1191,25 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int 
     return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(za, as_stream(stream), fn);
 }
 
+extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
+                                                            int M, int N, int K, void* stream) {
+    return fc_fwd_impl("mi355ppo_fc_fwd_relu_packed_f32", a, lda, pack, bias, h, M, N, K, nullptr, nullptr, stream);
+}
+
 // The same with a workspace of mi355ppo_fc_fwd_workspace_bytes(M, N, K) bytes: batches below 8,192 rows (a rollout step's 1,024
 // envs) split K over blockIdx.z -- raw partials into the workspace, then one pass that adds them in order, bias, ReLU.  Without a
 // workspace (or when none is needed) this IS mi355ppo_fc_fwd_relu_packed_f32.
-extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_ws_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
-                                                               int M, int N, int K, void* ws, size_t ws_bytes, void* stream) {
-    const char* fn = "mi355ppo_fc_fwd_relu_packed_ws_f32";
+static int fc_fwd_ws_impl(const char* fn, const float* a, int lda, const void* pack, const float* bias, float* h, int M, int N, int K, void* ws,
+                          size_t ws_bytes, const unsigned* a_amax, unsigned* h_amax, void* stream) {
     const size_t need = mi355ppo_fc_fwd_workspace_bytes(M, N, K);
-    if (need == 0 || !ws || N % 4) return mi355ppo_fc_fwd_relu_packed_f32(a, lda, pack, bias, h, M, N, K, stream);
+    if (need == 0 || !ws || N % 4) return fc_fwd_impl(fn, a, lda, pack, bias, h, M, N, K, a_amax, h_amax, stream);
+    MI355_REQUIRE(!h_amax, MI355PPO_EINVAL, "%s: the K-split forward (M=%d) does not record h's maximum (no consumer splits h: pass null)", fn, M);
     int rc = zgemm_check(fn, a, pack, h, M, N, K, lda, N);
     if (rc) return rc;
     MI355_REQUIRE(bias && aligned(bias, 4) && aligned(h, 16) && aligned(ws, 16), MI355PPO_EINVAL, "%s: bias missing, or h / workspace not 16-byte aligned", fn);
     MI355_REQUIRE(ws_bytes >= need, MI355PPO_EINVAL, "%s: workspace of %zu bytes, %zu needed (mi355ppo_fc_fwd_workspace_bytes)", fn, ws_bytes, need);
     ZArgs za = zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, static_cast<float*>(ws), (long long)M * N * 4, N, M, N, K);
+    za.a_amax = a_amax;
     za.steps_per = zsplit_steps_per(M, N, K);
     const int splits = (K / 16 + za.steps_per - 1) / za.steps_per;
     rc = z_launch<ZRowsLinear, 2, 2, 4, Z_RAW, true, 2>(za, as_stream(stream), fn);
@@ -1058,11 +1220,16 @@ extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_ws_f32(const float* a, i
     return check_launch(fn);
 }
 
+extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_ws_f32(const float* a, int lda, const void* pack, const float* bias, float* h,
+                                                               int M, int N, int K, void* ws, size_t ws_bytes, void* stream) {
+    return fc_fwd_ws_impl("mi355ppo_fc_fwd_relu_packed_ws_f32", a, lda, pack, bias, h, M, N, K, ws, ws_bytes, nullptr, nullptr, stream);
+}
+
 // The K-split half of mi355ppo_fc_fwd_relu_packed_ws_f32 alone: raw partials of a (M, K) x pack -> (splits, M, N) in `ws`; the caller
 // folds them (heads.hip's fused FC-fold + heads + sampling kernel of the rollout).  Returns the number of splits in *splits (>= 2).
 namespace mi355ppo {
 int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
-                    hipStream_t stream) {
+                    hipStream_t stream, const unsigned* a_amax) {
     const size_t need = mi355ppo_fc_fwd_workspace_bytes(M, N, K);
     MI355_REQUIRE(need > 0 && N % 4 == 0, MI355PPO_EINVAL, "%s: M=%d rows need no K split (use the unfused entry points from 8,192 rows on)", fn, M);
     int rc = zgemm_check(fn, a, pack, static_cast<const float*>(ws), M, N, K, lda, N);
@@ -1070,6 +1237,7 @@ int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, i
     MI355_REQUIRE(ws && aligned(ws, 16) && ws_bytes >= need, MI355PPO_EWORKSPACE, "%s: workspace of %zu bytes, %zu needed (mi355ppo_fc_fwd_workspace_bytes)",
                   fn, ws ? ws_bytes : (size_t)0, need);
     ZArgs za = zargs(a, (long long)M * lda * 4, lda, pack, nullptr, nullptr, static_cast<float*>(ws), (long long)M * N * 4, N, M, N, K);
+    za.a_amax = a_amax;                                                   // non-null: `pack` is an f16x2 pack (the *_f16x2 entry points)
     za.steps_per = zsplit_steps_per(M, N, K);
     *splits = (K / 16 + za.steps_per - 1) / za.steps_per;
     return z_launch<ZRowsLinear, 2, 2, 4, Z_RAW, true, 2>(za, stream, fn);
@@ -1077,10 +1245,11 @@ int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, i
 }  // namespace mi355ppo
 
 static int fc_dgrad_impl(const char* fn, const float* dz, int lddz, const void* pack, const float* act_in, const unsigned* bits, float* da,
-                         int M, int N, int K, void* stream) {
+                         int M, int N, int K, void* stream, const unsigned* dz_amax = nullptr, unsigned* da_amax = nullptr) {
     int rc = zgemm_check(fn, dz, pack, da, M, N, K, lddz, N);
     if (rc) return rc;
     ZArgs za = zargs(dz, (long long)M * lddz * 4, lddz, pack, nullptr, act_in, da, (long long)M * N * 4, N, M, N, K);
+    za.a_amax = dz_amax; za.c_amax = da_amax;
     // (the B ring -- z_launch<..., 1, true> for even K / 16 -- measured 630 -> 720 us here: one wave per SIMD has nothing to run while
     // it waits at the ring barrier; profiles/r03_blds_ab.jsonl)
     // supertiles of 4 row blocks: L2-miss reads 1.75 -> 0.62 GB per launch at 32,768 rows, 612 -> 605 us (2 / 8 row blocks: 598 / 602 us;
@@ -1114,7 +1283,7 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_maskbits_packed_f32(const float* d
 // mode 1 for the layer-3 data gradient (N = 64 input channels, K = (r, c, output channel), taps flipped), mode 2 for the
 // layer-2 data gradient (N = 4 stride-parity classes x 32 input channels, K = (r, c, output channel)).
 static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pack, const float* bias, float* dst, unsigned* bits,
-                                int64_t images, int layer, void* stream) {
+                                int64_t images, int layer, void* stream, const unsigned* src_amax = nullptr, unsigned* dst_amax = nullptr) {
     MI355_REQUIRE(src && pack && bias && dst, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer == 2 || layer == 3, MI355PPO_EINVAL, "%s: layer=%d must be 2 or 3", fn, layer);
     MI355_REQUIRE(images > 0, MI355PPO_EINVAL, "%s: images=%lld must be positive", fn, (long long)images);
@@ -1133,12 +1302,14 @@ static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pa
     if (layer == 2) {
         ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K);
         za.bits_out = bits;
+        za.a_amax = src_amax; za.c_amax = dst_amax;
         if (small) return z_launch<ZConv2, 1, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
         if (bits) return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2>(za, st, fn);
         return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
     }
     ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
     za.bits_out = bits;
+    za.a_amax = src_amax; za.c_amax = dst_amax;
     if (small) return z_launch<ZConv3, 1, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
     if (bits) return z_blds(images) ? z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2, true>(za, st, fn) : z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2>(za, st, fn);
     return z_blds(images) ? z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, st, fn) : z_launch<ZConv3, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
@@ -1159,7 +1330,7 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_bits_f32(const float* s
 }
 
 static int conv_dgrad_packed_impl(const char* fn, const float* dz, const void* pack, const float* act_in, const unsigned* bits, float* dsrc,
-                                  int64_t images, int layer, void* stream) {
+                                  int64_t images, int layer, void* stream, const unsigned* dz_amax = nullptr, unsigned* dsrc_amax = nullptr) {
     MI355_REQUIRE(dz && pack && (act_in || bits) && dsrc, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(layer == 2 || layer == 3, MI355PPO_EINVAL, "%s: layer=%d must be 2 or 3", fn, layer);
     MI355_REQUIRE(images > 0, MI355PPO_EINVAL, "%s: images=%lld must be positive", fn, (long long)images);
@@ -1174,12 +1345,14 @@ static int conv_dgrad_packed_impl(const char* fn, const float* dz, const void* p
     if (layer == 3) {      // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
         ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K, images);
         za.bits_in = bits;
+        za.a_amax = dz_amax; za.c_amax = dsrc_amax;
         if (bits) return z_blds(images) ? z_launch<ZDgrad3, 2, 2, 4, Z_MASKB, false, 2, true>(za, st, fn) : z_launch<ZDgrad3, 2, 2, 4, Z_MASKB, false, 2>(za, st, fn);
         return z_blds(images) ? z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2, true>(za, st, fn) : z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, st, fn);
     }
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
     ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K, images);
     za.bits_in = bits;
+    za.a_amax = dz_amax; za.c_amax = dsrc_amax;
     if (bits) return z_blds(images) ? z_launch<ZDgrad2, 2, 2, 4, Z_MASKB_CLS4, false, 2, true>(za, st, fn) : z_launch<ZDgrad2, 2, 2, 4, Z_MASKB_CLS4, false, 2>(za, st, fn);
     return z_blds(images) ? z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2, true>(za, st, fn) : z_launch<ZDgrad2, 2, 2, 4, Z_MASK_CLS4, false, 2>(za, st, fn);
 }
@@ -1198,4 +1371,75 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_bits_f32(const float*
     const char* fn = "mi355ppo_cnn_conv_dgrad_packed_bits_f32";
     MI355_REQUIRE(mask_bits, MI355PPO_EINVAL, "%s: null pointer", fn);
     return conv_dgrad_packed_impl(fn, dz, pack, nullptr, mask_bits, dsrc, images, layer, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- f16x2 entry points
+// The same kernels on the two-term f16 split (f16split.h; SPLIT = 1 of z_kernel): `pack` is an f16x2 pack (its header carries the
+// weight tensor's maximum), every split operand comes with its amax record, every result a consumer will split again gets its record
+// filled.  Same shapes, alignments and epilogues as the entry points above.
+extern "C" MI355PPO_API size_t mi355ppo_fc_pack_f16x2_bytes(int N, int K) {
+    if (N <= 0 || K <= 0 || K % 16) return 0;
+    return (size_t)kF16PackHeader + (size_t)(K / 16) * (size_t)((N + 31) / 32) * 2048;
+}
+
+// amax |= max |x| over n floats (the record must have been zeroed, or hold the maximum of another part of the same tensor)
+extern "C" MI355PPO_API int mi355ppo_absmax_f32(const float* x, int64_t n, uint32_t* amax, void* stream) {
+    const char* fn = "mi355ppo_absmax_f32";
+    MI355_REQUIRE(x && amax, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(n > 0, MI355PPO_EINVAL, "%s: n=%lld must be positive", fn, (long long)n);
+    MI355_REQUIRE(aligned(x, 4) && aligned(amax, 64), MI355PPO_EALIGN, "%s: the amax record must be 64-byte aligned", fn);
+    ZAbsmax3 m;
+    m.x[0] = x; m.n[0] = n; m.x[1] = m.x[2] = x; m.n[1] = m.n[2] = 0;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zabsmax_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), m, amax, (int)blocks);
+    return check_launch(fn);
+}
+
+// B (N, K) f32 -> its f16x2 pack; `b_amax` = B's amax record (mi355ppo_absmax_f32 of B, or anything >= max |B|)
+extern "C" MI355PPO_API int mi355ppo_fc_pack_f16x2_f32(const float* B, int ldb, int N, int K, const uint32_t* b_amax, void* pack, void* stream) {
+    const char* fn = "mi355ppo_fc_pack_f16x2_f32";
+    MI355_REQUIRE(B && pack && b_amax, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(N > 0 && K > 0 && K % 16 == 0 && ldb >= K, MI355PPO_EINVAL, "%s: N=%d K=%d ldb=%d (K a positive multiple of 16, ldb >= K)", fn, N, K, ldb);
+    MI355_REQUIRE(aligned(B, 4) && aligned(pack, 16) && aligned(b_amax, 64), MI355PPO_EALIGN, "%s: misaligned pointer (pack: 16 bytes, record: 64)", fn);
+    const long long total = (long long)(K / 16) * ((N + 31) / 32) * 512;
+    hipLaunchKernelGGL(zpack_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), B, ldb, N, K, b_amax,
+                       static_cast<unsigned char*>(pack));
+    return check_launch(fn);
+}
+
+// relu(a @ B^T + bias); rows below 8,192 with a workspace: K split over the grid (then h_amax must be null).  h_amax: optional.
+extern "C" MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f16x2_f32(const float* a, int lda, const void* pack, const float* bias, float* h, int M,
+                                                                  int N, int K, void* ws, size_t ws_bytes, const uint32_t* a_amax,
+                                                                  uint32_t* h_amax, void* stream) {
+    const char* fn = "mi355ppo_fc_fwd_relu_packed_f16x2_f32";
+    MI355_REQUIRE(a_amax && aligned(a_amax, 64) && aligned(h_amax, 64), MI355PPO_EINVAL, "%s: a's amax record missing, or a record not 64-byte aligned", fn);
+    return fc_fwd_ws_impl(fn, a, lda, pack, bias, h, M, N, K, ws, ws_bytes, a_amax, h_amax, stream);
+}
+
+// (dz @ B^T) masked by the ReLU of the layer below: `mask_bits` if given, else `act_in` > 0
+extern "C" MI355PPO_API int mi355ppo_fc_dgrad_packed_f16x2_f32(const float* dz, int lddz, const void* pack, const float* act_in,
+                                                               const uint32_t* mask_bits, float* da, int M, int N, int K, const uint32_t* dz_amax,
+                                                               uint32_t* da_amax, void* stream) {
+    const char* fn = "mi355ppo_fc_dgrad_packed_f16x2_f32";
+    MI355_REQUIRE(dz_amax && aligned(dz_amax, 64) && aligned(da_amax, 64), MI355PPO_EINVAL, "%s: dz's amax record missing, or a record not 64-byte aligned", fn);
+    MI355_REQUIRE(act_in || mask_bits, MI355PPO_EINVAL, "%s: neither act_in nor mask_bits", fn);
+    return fc_dgrad_impl(fn, dz, lddz, pack, mask_bits ? nullptr : act_in, mask_bits, da, M, N, K, stream, dz_amax, da_amax);
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f16x2_f32(const float* src, const void* pack, const float* bias, float* dst,
+                                                                   uint32_t* mask_bits, int64_t images, int layer, const uint32_t* src_amax,
+                                                                   uint32_t* dst_amax, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_fwd_packed_f16x2_f32";
+    MI355_REQUIRE(src_amax && aligned(src_amax, 64) && aligned(dst_amax, 64), MI355PPO_EINVAL, "%s: src's amax record missing, or a record not 64-byte aligned", fn);
+    return conv_fwd_packed_impl(fn, src, pack, bias, dst, mask_bits, images, layer, stream, src_amax, dst_amax);
+}
+
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(const float* dz, const void* pack, const float* act_in,
+                                                                     const uint32_t* mask_bits, float* dsrc, int64_t images, int layer,
+                                                                     const uint32_t* dz_amax, uint32_t* dsrc_amax, void* stream) {
+    const char* fn = "mi355ppo_cnn_conv_dgrad_packed_f16x2_f32";
+    MI355_REQUIRE(dz_amax && aligned(dz_amax, 64) && aligned(dsrc_amax, 64), MI355PPO_EINVAL, "%s: dz's amax record missing, or a record not 64-byte aligned", fn);
+    return conv_dgrad_packed_impl(fn, dz, pack, mask_bits ? nullptr : act_in, mask_bits, dsrc, images, layer, stream, dz_amax, dsrc_amax);
 }

@@ -12,6 +12,7 @@
 // stay in registers over all rows a wave visits; waves -> workgroup (LDS, wave order) -> grid partials are folded in a
 // fixed order (deterministic).  Algorithmic bytes: forward 2048*M + 4*NA*M, backward 4096*M + 4*NA*M (+ partials).
 #include "common.h"
+#include "f16split.h"
 #include "catrow.h"
 
 #pragma clang fp contract(off)
@@ -146,12 +147,13 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ Wc, const float* __restrict__ dlogits,
                                                         const float* __restrict__ dvalue, float* __restrict__ dh,
                                                         float* __restrict__ part,      // [grid][NA + 1][512 + 1]
-                                                        int M, int A, int lddh) {
+                                                        int M, int A, int lddh, unsigned* __restrict__ dh_amax) {
     __shared__ float red[NA + 1][kHid + 1];
     float accz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (the wave index in an SGPR)
     const int wv = blockIdx.x * 4 + wave, nwv = gridDim.x * 4;
     float w[NA][8], acc[NA][8], accb[NA];
+    unsigned dmax = 0u;                    // bits of the largest |dh| this lane stored: dh's amax record (f16split.h), when asked for
     load_w<NA>(w, Wa, Wc, A, lane);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
@@ -187,10 +189,16 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                 accz[i] += d[i];
             }
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned b = __float_as_uint(d[i]) & 0x7fffffffu;
+            dmax = b > dmax ? b : dmax;
+        }
         float* dr = dh + (size_t)m * lddh + lane * 8;
         *reinterpret_cast<float4*>(dr) = make_float4(d[0], d[1], d[2], d[3]);
         *reinterpret_cast<float4*>(dr + 4) = make_float4(d[4], d[5], d[6], d[7]);
     }
+    if (dh_amax) amax_commit(dh_amax, dmax, (unsigned)wv, lane);        // (uniform; every lane is back from the row loop)
     // waves fold into one LDS accumulator in wave order (fixed), then one partial per workgroup
     for (int wsel = 0; wsel < 4; ++wsel) {
         if (wave == wsel) {
@@ -287,13 +295,10 @@ extern "C" MI355PPO_API int mi355ppo_heads_fwd_f32(const float* h, const float* 
     return check_launch("heads_fwd_kernel");
 }
 
-extern "C" MI355PPO_API int mi355ppo_fc_heads_act_categorical_f32(const float* a3, int lda, const void* fc_pack, const float* fc_bias,
-                                                                  const float* Wa, const float* ba, const float* Wc, const float* bc, int M,
-                                                                  int A, int H, int K, const float* noise_exp1, uint64_t seed,
-                                                                  uint64_t offset, const uint64_t* offset_base, int64_t* action_i64,
-                                                                  float* action_f32, float* logprob, float* value, float* hidden_out,
-                                                                  void* workspace, size_t workspace_bytes, void* stream) {
-    const char* fn = "mi355ppo_fc_heads_act_categorical_f32";
+static int fc_heads_act_impl(const char* fn, const float* a3, int lda, const void* fc_pack, const float* fc_bias, const float* Wa, const float* ba,
+                             const float* Wc, const float* bc, int M, int A, int H, int K, const float* noise_exp1, uint64_t seed, uint64_t offset,
+                             const uint64_t* offset_base, int64_t* action_i64, float* action_f32, float* logprob, float* value, float* hidden_out,
+                             void* workspace, size_t workspace_bytes, const unsigned* a3_amax, void* stream) {
     MI355_REQUIRE(a3 && fc_pack && fc_bias && Wa && ba && Wc && bc && logprob && value, MI355PPO_EINVAL, "%s: null pointer", fn);
     MI355_REQUIRE(action_i64 || action_f32, MI355PPO_EINVAL, "%s: no action output", fn);
     int rc = heads_check(fn, M, A, H);
@@ -302,7 +307,7 @@ extern "C" MI355PPO_API int mi355ppo_fc_heads_act_categorical_f32(const float* a
                       aligned(offset_base, 8) && aligned(action_i64, 8) && aligned(action_f32, 4) && aligned(logprob, 4) && aligned(value, 4) &&
                       aligned(hidden_out, 16), MI355PPO_EALIGN, "%s: Wa / Wc / hidden_out must be 16-byte aligned", fn);
     int splits = 0;
-    rc = z_fc_raw_launch(fn, a3, lda, fc_pack, M, H, K, workspace, workspace_bytes, &splits, as_stream(stream));
+    rc = z_fc_raw_launch(fn, a3, lda, fc_pack, M, H, K, workspace, workspace_bytes, &splits, as_stream(stream), a3_amax);
     if (rc) return rc;
     const dim3 grid(heads_grid(M));
     const float* part = static_cast<const float*>(workspace);
@@ -317,6 +322,16 @@ extern "C" MI355PPO_API int mi355ppo_fc_heads_act_categorical_f32(const float* a
     return check_launch("heads_act_kernel");
 }
 
+extern "C" MI355PPO_API int mi355ppo_fc_heads_act_categorical_f32(const float* a3, int lda, const void* fc_pack, const float* fc_bias,
+                                                                  const float* Wa, const float* ba, const float* Wc, const float* bc, int M,
+                                                                  int A, int H, int K, const float* noise_exp1, uint64_t seed,
+                                                                  uint64_t offset, const uint64_t* offset_base, int64_t* action_i64,
+                                                                  float* action_f32, float* logprob, float* value, float* hidden_out,
+                                                                  void* workspace, size_t workspace_bytes, void* stream) {
+    return fc_heads_act_impl("mi355ppo_fc_heads_act_categorical_f32", a3, lda, fc_pack, fc_bias, Wa, ba, Wc, bc, M, A, H, K, noise_exp1, seed,
+                             offset, offset_base, action_i64, action_f32, logprob, value, hidden_out, workspace, workspace_bytes, nullptr, stream);
+}
+
 extern "C" MI355PPO_API size_t mi355ppo_heads_bwd_workspace_bytes(int M, int A) {
     if (M <= 0 || A < 1 || A > 7) return 0;
     return (size_t)heads_grid(M) * (A + 2) * (kHid + 1) * sizeof(float);      // (A + 1 rows; one more for the ReLU variant's bias gradient)
@@ -324,7 +339,7 @@ extern "C" MI355PPO_API size_t mi355ppo_heads_bwd_workspace_bytes(int M, int A) 
 
 static int heads_bwd(const char* fn, const float* h, const float* Wa, const float* Wc, const float* dlogits, const float* dvalue, float* dh,
                      float* dWa, float* dba, float* dWc, float* dbc, float* dbh, int lddh, int M, int A, int H, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+                     size_t workspace_bytes, void* stream, unsigned* dh_amax = nullptr) {
     MI355_REQUIRE(h && Wa && Wc && dlogits && dvalue && dh && dWa && dba && dWc && dbc, MI355PPO_EINVAL, "%s: null pointer", fn);
     int rc = heads_check(fn, M, A, H);
     if (rc) return rc;
@@ -339,8 +354,8 @@ static int heads_bwd(const char* fn, const float* h, const float* Wa, const floa
     hipStream_t s = as_stream(stream);
 #define LAUNCH(NA)                                                                                                                   \
     do {                                                                                                                             \
-        if (dbh) hipLaunchKernelGGL((heads_bwd_kernel<NA, true>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A, lddh);  \
-        else hipLaunchKernelGGL((heads_bwd_kernel<NA, false>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A, lddh);    \
+        if (dbh) hipLaunchKernelGGL((heads_bwd_kernel<NA, true>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A, lddh, dh_amax);  \
+        else hipLaunchKernelGGL((heads_bwd_kernel<NA, false>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A, lddh, dh_amax);    \
     } while (0)
     switch (A + 1) {
         case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break;
@@ -369,4 +384,30 @@ extern "C" MI355PPO_API int mi355ppo_heads_bwd_relu_f32(const float* h, const fl
     const char* fn = "mi355ppo_heads_bwd_relu_f32";
     MI355_REQUIRE(dbh, MI355PPO_EINVAL, "%s: null pointer", fn);
     return heads_bwd(fn, h, Wa, Wc, dlogits, dvalue, dz, dWa, dba, dWc, dbc, dbh, lddz, M, A, H, workspace, workspace_bytes, stream);
+}
+
+// The same, also folding |dz| into `dz_amax` (dz's amax record, zeroed by the caller): the FC layer's data and weight gradients on the
+// f16 split (mi355ppo_fc_dgrad_packed_f16x2_f32, mi355ppo_fc_wgrad_f16x2_f32) scale dz by it.
+extern "C" MI355PPO_API int mi355ppo_heads_bwd_relu_amax_f32(const float* h, const float* Wa, const float* Wc, const float* dlogits,
+                                                             const float* dvalue, float* dz, int lddz, float* dWa, float* dba, float* dWc,
+                                                             float* dbc, float* dbh, int M, int A, int H, void* workspace,
+                                                             size_t workspace_bytes, uint32_t* dz_amax, void* stream) {
+    const char* fn = "mi355ppo_heads_bwd_relu_amax_f32";
+    MI355_REQUIRE(dbh && dz_amax, MI355PPO_EINVAL, "%s: null pointer", fn);
+    MI355_REQUIRE(aligned(dz_amax, 64), MI355PPO_EALIGN, "%s: the amax record must be 64-byte aligned", fn);
+    return heads_bwd(fn, h, Wa, Wc, dlogits, dvalue, dz, dWa, dba, dWc, dbc, dbh, lddz, M, A, H, workspace, workspace_bytes, stream, dz_amax);
+}
+
+// mi355ppo_fc_heads_act_categorical_f32 with the FC layer on the f16 split: `fc_pack` is an f16x2 pack, `a3_amax` a3's amax record
+extern "C" MI355PPO_API int mi355ppo_fc_heads_act_categorical_f16x2_f32(const float* a3, int lda, const void* fc_pack, const float* fc_bias,
+                                                                        const float* Wa, const float* ba, const float* Wc, const float* bc,
+                                                                        int M, int A, int H, int K, const float* noise_exp1, uint64_t seed,
+                                                                        uint64_t offset, const uint64_t* offset_base, int64_t* action_i64,
+                                                                        float* action_f32, float* logprob, float* value, float* hidden_out,
+                                                                        void* workspace, size_t workspace_bytes, const uint32_t* a3_amax,
+                                                                        void* stream) {
+    const char* fn = "mi355ppo_fc_heads_act_categorical_f16x2_f32";
+    MI355_REQUIRE(a3_amax && aligned(a3_amax, 64), MI355PPO_EINVAL, "%s: a3's amax record missing or not 64-byte aligned", fn);
+    return fc_heads_act_impl(fn, a3, lda, fc_pack, fc_bias, Wa, ba, Wc, bc, M, A, H, K, noise_exp1, seed, offset, offset_base, action_i64,
+                             action_f32, logprob, value, hidden_out, workspace, workspace_bytes, a3_amax, stream);
 }

@@ -32,17 +32,23 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 170 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 180 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2, 1.3: round 3;
                                   1.4: the *_cpu host-pointer twins; 1.5: mi355ppo_init; 1.6: round 4 -- the fused MLP family K7,
                                   mi355ppo_clip_adam_sched_f32; 1.7: mi355ppo_fc_heads_act_categorical_f32, mi355ppo_nature_packs_f32,
-                                  mi355ppo_synth_atari_step_hwc_ctr_u8); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
+                                  mi355ppo_synth_atari_step_hwc_ctr_u8; 1.8: round 5 -- the *_f16x2 / *_amax entry points and mi355ppo_absmax_f32); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
 
 #if defined(__GNUC__)
 #define MI355PPO_API __attribute__((visibility("default")))
 #else
 #define MI355PPO_API
 #endif
+
+/* An "amax record": the bit pattern of max |x| of an f32 tensor, kept as 16 uint32 slots 64 bytes apart (1 KiB; the record's value is
+ * the maximum over the slots).  The *_f16x2 entry points read the record of every tensor they split into two f16 terms (the tensor's
+ * power-of-two scale derives from it) and fold the values they store into the record of the tensor they produce; the caller zeroes
+ * records before their producers run (one memset for all records of a pass) -- see mi355ppo_absmax_f32 and csrc/f16split.h. */
+#define MI355PPO_AMAX_WORDS 256
 
 #define MI355PPO_OK 0
 #define MI355PPO_EINVAL (-1)     /* null pointer, non-positive or unsupported shape            */
@@ -563,6 +569,60 @@ MI355PPO_API int mi355ppo_fc_heads_act_categorical_f32(const float* a3, int lda,
                                                        const uint64_t* offset_base, int64_t* action_i64, float* action_f32,
                                                        float* logprob, float* value, float* hidden_out, void* workspace,
                                                        size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Round 5 -- the NatureCNN GEMMs on a TWO-TERM f16 split (csrc/f16split.h): three v_mfma_f32_32x32x16_f16 per f32 product where the
+ * three-term bf16 split of the entry points above needs six, f32 accumulation, products of terms exact.  Every split tensor is scaled
+ * by a power of two derived from its amax record (MI355PPO_AMAX_WORDS uint32, 64-byte aligned, see above): an entry point READS the
+ * record of each f32 operand it splits (`*_amax` inputs; required) and FOLDS the values it stores into the record of its result
+ * (`*_amax` outputs; null = nobody will split the result); the caller zeroes the output records of a pass before its first launch.
+ * Weights travel as "f16x2 packs": [64-byte header: max |B|][k-step][32-column tile][hi, lo][64 lanes][8 f16] of s B.
+ * The reference arithmetic is the same as for the bf16 entry points they mirror (cleanrl/ppo_atari_multigpu.py:136-148 forward, :358
+ * backward: f32 Conv2d / Linear); error against float64 at or below theirs (tools/err_f16x2.py, tests/test_gpu_f16x2.py).
+ */
+MI355PPO_API int mi355ppo_absmax_f32(const float* x, int64_t n, uint32_t* amax, void* stream);   /* amax = max(amax, max |x|) */
+MI355PPO_API size_t mi355ppo_fc_pack_f16x2_bytes(int N, int K);
+MI355PPO_API int mi355ppo_fc_pack_f16x2_f32(const float* B, int ldb, int N, int K, const uint32_t* b_amax, void* pack, void* stream);
+/* mi355ppo_nature_packs_f32 with the six kernel-Z packs as f16x2 packs [mi355ppo_fc_pack_f16x2_bytes of the same shapes]; `w_amax` =
+ * three records (3 * MI355PPO_AMAX_WORDS) that receive max |W2|, |W3|, |Wfc| -- zeroed and filled by this call. */
+MI355PPO_API int mi355ppo_nature_packs_f16x2_f32(const float* W1, const float* W2, const float* W3, const float* Wfc, void* qpack,
+                                                 void* conv2_fwd, void* conv3_fwd, void* conv3_dgrad, void* conv2_dgrad, void* fc_fwd,
+                                                 void* fc_dgrad, uint32_t* w_amax, void* stream);
+/* mi355ppo_cnn_conv1q_fwd / _bits (mask_bits may be null) that also records max(dst) -- the layer-2 forward's A-operand scale. */
+MI355PPO_API int mi355ppo_cnn_conv1q_fwd_amax(const void* src_u8, const int64_t* inds, const void* pack, const float* bias, float* dst,
+                                              uint32_t* mask_bits, int64_t images, uint32_t* dst_amax, void* stream);
+/* mi355ppo_cnn_conv_fwd_packed_f32 / _bits_f32 (mask_bits may be null) */
+MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f16x2_f32(const float* src, const void* pack, const float* bias, float* dst, uint32_t* mask_bits,
+                                                        int64_t images, int layer, const uint32_t* src_amax, uint32_t* dst_amax, void* stream);
+/* mi355ppo_cnn_conv_dgrad_packed_f32 / _bits_f32: the ReLU mask from mask_bits if given, else from act_in */
+MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(const float* dz, const void* pack, const float* act_in, const uint32_t* mask_bits,
+                                                          float* dsrc, int64_t images, int layer, const uint32_t* dz_amax, uint32_t* dsrc_amax,
+                                                          void* stream);
+/* mi355ppo_cnn_conv_wgrad_f32 for layers 2 / 3 (kernel V); other batches fall to the f32-pipe kernel and ignore the records */
+MI355PPO_API int mi355ppo_cnn_conv_wgrad_f16x2_f32(const float* src, const float* dz, float* dW, float* db, int64_t images, int layer,
+                                                   void* workspace, size_t workspace_bytes, const uint32_t* src_amax, const uint32_t* dz_amax,
+                                                   void* stream);
+/* mi355ppo_fc_fwd_relu_packed_ws_f32 (ws may be null / 0: whole-K wave tiles); the K-split route records no h_amax (pass null) */
+MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f16x2_f32(const float* a, int lda, const void* pack, const float* bias, float* h, int M, int N,
+                                                       int K, void* ws, size_t ws_bytes, const uint32_t* a_amax, uint32_t* h_amax, void* stream);
+/* mi355ppo_fc_dgrad_mask_packed_f32 / _maskbits_ */
+MI355PPO_API int mi355ppo_fc_dgrad_packed_f16x2_f32(const float* dz, int lddz, const void* pack, const float* act_in, const uint32_t* mask_bits,
+                                                    float* da, int M, int N, int K, const uint32_t* dz_amax, uint32_t* da_amax, void* stream);
+/* mi355ppo_fc_wgrad_f32 (kernel W; other shapes fall to the f32-pipe kernel Y and ignore the records) */
+MI355PPO_API int mi355ppo_fc_wgrad_f16x2_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
+                                             void* workspace, size_t workspace_bytes, const uint32_t* dz_amax, const uint32_t* a_amax,
+                                             void* stream);
+/* mi355ppo_heads_bwd_relu_f32 that also records max |dz| (the FC layer's data / weight gradients scale dz by it) */
+MI355PPO_API int mi355ppo_heads_bwd_relu_amax_f32(const float* h, const float* Wa, const float* Wc, const float* dlogits, const float* dvalue,
+                                                  float* dz, int lddz, float* dWa, float* dba, float* dWc, float* dbc, float* dbh, int M, int A,
+                                                  int H, void* workspace, size_t workspace_bytes, uint32_t* dz_amax, void* stream);
+/* mi355ppo_fc_heads_act_categorical_f32 with an f16x2 `fc_pack` and a3's record */
+MI355PPO_API int mi355ppo_fc_heads_act_categorical_f16x2_f32(const float* a3, int lda, const void* fc_pack, const float* fc_bias,
+                                                             const float* Wa, const float* ba, const float* Wc, const float* bc, int M, int A,
+                                                             int H, int K, const float* noise_exp1, uint64_t seed, uint64_t offset,
+                                                             const uint64_t* offset_base, int64_t* action_i64, float* action_f32,
+                                                             float* logprob, float* value, float* hidden_out, void* workspace,
+                                                             size_t workspace_bytes, const uint32_t* a3_amax, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Test / benchmark support -- NOT part of the reference path.  One step of the device-resident synthetic Atari
