@@ -95,6 +95,13 @@ KERNEL_INFO = {
     "V": ("convw_bf16_kernel (csrc/convw.hip): bf16 MFMA on three-term splits, both operands transposed through LDS; bias gradient "
           "fused", "bf16", BF16_PAIRS),
     "W": ("fcw_bf16_kernel (csrc/fcw.hip): bf16 MFMA on three-term splits, both operands transposed through LDS", "bf16", BF16_PAIRS),
+    # round 5: the same three kernels on the two-term f16 split (csrc/f16split.h): three v_mfma_f32_32x32x16_f16 per f32 product
+    "Zh": ("z_kernel<..., SPLIT = 1> (csrc/gemmz.hip): f16 MFMA on two-term splits under per-tensor power-of-two scales (amax records), "
+           "weights pre-split into fragment order, activations loaded coalesced through wave-private LDS; un-scale + bias + ReLU / the "
+           "ReLU-backward mask + the result's amax in the epilogue", "f16", 3),
+    "Vh": ("convw_bf16_kernel<..., SPLIT = 1> (csrc/convw.hip): f16 MFMA on two-term splits, both operands transposed through LDS; bias "
+           "gradient fused", "f16", 3),
+    "Wh": ("fcw_bf16_kernel<3, 1> (csrc/fcw.hip): f16 MFMA on two-term splits, both operands transposed through LDS", "f16", 3),
     "F": ("conv_fixed_kernel (csrc/conv.hip): f32-MFMA implicit GEMM; bias + ReLU / the ReLU-backward mask in the epilogue", "f32", 1),
     "T": ("conv_wgrad_taps_kernel (csrc/conv.hip): f32-MFMA implicit GEMM", "f32", 1),
     "Y": ("fcw_kernel (csrc/fcw.hip): f32 MFMA", "f32", 1),
@@ -188,10 +195,11 @@ def roofline_entry(key, us, launches_timed, flops, letter, share, traffic):
     ``frac`` <= 1 by construction.  A kernel is priced on the pipe it executes on:
 
     * kernel Q (int8 pipe at 1/8 of the f32 pipe's time): HBM-bound -- algorithmic bytes / launch time against 8 TB/s;
-    * bf16-pipe kernels (Z, V, W, P): ``achieved`` = EXECUTED bf16 MFMA flops per second = the algorithmic f32 flops of the
-      convolution / GEMM x the MFMA products issued per f32 product (the term pairs of the exact three-term split: 6 by
-      default, 9 with MI355PPO_BF16_PAIRS=9; kernel P: 3 -- its uint8 operand is exact in bf16), ``peak`` = the dense bf16
-      MFMA peak (2,500 TFLOP/s; never the 2:1-sparsity figure);
+    * bf16- / f16-pipe kernels (Z, V, W, P; Zh, Vh, Wh): ``achieved`` = EXECUTED 16-bit MFMA flops per second = the algorithmic f32
+      flops of the convolution / GEMM x the MFMA products issued per f32 product (three-term bf16 split: 6 term pairs by default, 9
+      with MI355PPO_BF16_PAIRS=9; two-term f16 split, the default since round 5: 3; kernel P: 3 -- its uint8 operand is exact in
+      bf16), ``peak`` = the dense bf16 / f16 MFMA peak (2,500 TFLOP/s; never the 2:1-sparsity figure).  NOTE: halving the products
+      per f32 product halves ``achieved`` at equal speed -- compare ``avg_launch_us`` / ``algorithmic_TFLOPs`` across splits, not ``frac``;
     * f32-pipe kernels (F, T, Y): algorithmic flops against the dense f32 MFMA peak.
 
     The f32-equivalent view (algorithmic flops / the f32 peak, which the split kernels legitimately exceed) is kept as the
@@ -203,12 +211,12 @@ def roofline_entry(key, us, launches_timed, flops, letter, share, traffic):
         alg = _conv1_fwd_bytes(int(key.split("@")[1]))
         return {"kernel": f"{key}: kernel Q = {text}", "bound": "hbm", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg, **common}
-    peak = MFMA_BF16_PEAK_TFLOPS if pipe == "bf16" else MFMA_F32_PEAK_TFLOPS
+    peak = MFMA_BF16_PEAK_TFLOPS if pipe in ("bf16", "f16") else MFMA_F32_PEAK_TFLOPS      # (the dense f16 and bf16 MFMA peaks are equal)
     r = {"kernel": f"{key}: kernel {letter} = {text}", "bound": "mfma", "achieved": tf * products, "peak": peak, "unit": "TFLOP/s",
          "frac": tf * products / peak, "pipe": pipe, "mfma_products_per_f32_product": products,
          "algorithmic_flops_per_launch": flops, "algorithmic_TFLOPs": tf, "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS, **common}
-    if pipe == "bf16":
-        r["mfma"] = "v_mfma_f32_32x32x16_bf16"
+    if pipe in ("bf16", "f16"):
+        r["mfma"] = "v_mfma_f32_32x32x16_" + pipe
         r["frac_of_measured_stream_rate"] = tf * products / (MFMA_BF16_PEAK_TFLOPS * 32.0 / 47.7)
         r["note"] = ("achieved = algorithmic f32 flops x term pairs executed (padding taps of the data gradients are not multiplied and "
                      "not counted); frac_of_measured_stream_rate: against 32 nominal cycles per MFMA / 47.7 measured for a bare MFMA "
@@ -381,20 +389,24 @@ def main():
                 images = a[8].shape[0]
                 return f"trunk_fwd(conv1+2+3)@{images}", sum(conv_flop(l, images) for l in cnn.LAYERS), "F"
 
-            def k_wgrad(src, dz, layer, inds=None, out=None):
-                return f"conv{layer}_wgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), chr(lib.mi355ppo_cnn_conv_wgrad_kernel(dz.shape[0], layer))
+            def k_wgrad(src, dz, layer, inds=None, out=None, amax=None):
+                letter = chr(lib.mi355ppo_cnn_conv_wgrad_kernel(dz.shape[0], layer))
+                return f"conv{layer}_wgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), letter + "h" if amax is not None and letter == "V" else letter
 
             timed_op("conv_fwd", k_fwd)
             timed_op("trunk_fwd", k_trunk)
             timed_op("conv_dgrad", lambda dz, Bt, act_in, layer, out=None, variant=0: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), "F"))
             timed_op("conv_wgrad", k_wgrad)
+            # (amax: the two-term f16 split of round 5 -- the same kernels, letter + "h")
+            h = lambda letter, amax: letter + "h" if amax is not None else letter
             timed_op("conv1q_fwd_bits", lambda obs, pack, bias, inds, out, bits: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))
-            timed_op("conv_fwd_packed", lambda src, pack, bias, layer, out=None, bits=None: (f"conv{layer}_fwd@{src.shape[0]}", conv_flop(layer, src.shape[0]), "Z"))
-            timed_op("conv_dgrad_packed", lambda dz, pack, act_in, layer, out=None, bits=None: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), "Z"))
-            timed_op("fc_fwd_relu_packed", lambda a, pack, bias, n, out=None: (f"fc_fwd@{a.shape[0]}", 2.0 * a.shape[0] * n * a.shape[1], "Z"))
-            timed_op("fc_dgrad_mask_packed", lambda dz, pack, act_in, out=None, bits=None: (f"fc_dgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * act_in.shape[1], "Z"))
-            timed_op("fc_wgrad", lambda dz, a, hwc_channels=0, out=None: (f"fc_wgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * a.shape[1],
-                                                                         chr(lib.mi355ppo_fc_wgrad_kernel(dz.shape[0], dz.shape[1], a.shape[1]))))
+            timed_op("conv1q_fwd_amax", lambda obs, pack, bias, inds, out, bits, dst_amax: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))
+            timed_op("conv_fwd_packed", lambda src, pack, bias, layer, out=None, bits=None, amax=None: (f"conv{layer}_fwd@{src.shape[0]}", conv_flop(layer, src.shape[0]), h("Z", amax)))
+            timed_op("conv_dgrad_packed", lambda dz, pack, act_in, layer, out=None, bits=None, amax=None: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), h("Z", amax)))
+            timed_op("fc_fwd_relu_packed", lambda a, pack, bias, n, out=None, amax=None: (f"fc_fwd@{a.shape[0]}", 2.0 * a.shape[0] * n * a.shape[1], h("Z", amax)))
+            timed_op("fc_dgrad_mask_packed", lambda dz, pack, act_in, out=None, bits=None, amax=None: (f"fc_dgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * act_in.shape[1], h("Z", amax)))
+            timed_op("fc_wgrad", lambda dz, a, hwc_channels=0, out=None, amax=None: (f"fc_wgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * a.shape[1],
+                                                                                    h(chr(lib.mi355ppo_fc_wgrad_kernel(dz.shape[0], dz.shape[1], a.shape[1])), amax)))
 
         def obs_hook(src, inds=None, out=None, scale_255=True):
             if inds is not None:
@@ -560,7 +572,7 @@ def main():
                                      "frac_of_f32_mfma_peak": conv_flops[k] / kus / 1e6 / MFMA_F32_PEAK_TFLOPS,
                                      "ms_per_step": kus * launches / timing_iters / 1e3,
                                      "hbm_bytes_per_launch_pmc": _traffic_of(k)}
-                if pipe == "bf16":
+                if pipe in ("bf16", "f16"):
                     out["kernels"][k]["frac_of_bf16_mfma_peak_executed"] = conv_flops[k] * products / kus / 1e6 / MFMA_BF16_PEAK_TFLOPS
                 if kernel_of[k] == "Q":              # HBM-bound, the f32-pipe fraction is > 1 by construction
                     alg = _conv1_fwd_bytes(int(k.split("@")[1]))

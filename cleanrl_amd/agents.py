@@ -161,10 +161,11 @@ class AtariAgent(_DiscreteMixin, nn.Module):
         feats = self._trunk(obs_rows, None, net[0], net[2], net[4])
         if not cnn.fc_heads_act_supported(feats):
             return None
-        return cnn.fc_heads_act_categorical(feats, self._trunk.bufs.fc_pack_fwd(net[7].weight), net[7].bias.detach().contiguous(),
+        bufs = self._trunk.bufs
+        return cnn.fc_heads_act_categorical(feats, bufs.fc_pack_fwd(net[7].weight), net[7].bias.detach().contiguous(),
                                             self.actor.weight.detach(), self.actor.bias.detach(), self.critic.weight.detach(),
                                             self.critic.bias.detach(), seed, offset, offset_base, action_f32_out, logprob_out, value_out,
-                                            want_i64=want_i64)
+                                            want_i64=want_i64, amax=bufs.rec_of(cnn.REC_A3, feats) if bufs.f16(feats) else None)
 
     def get_value(self, x):
         return self.critic(self.network(self._normalise(x)))

@@ -30,6 +30,40 @@ _CONV_Z = os.environ.get("MI355PPO_CONV", "z") != "f"    # layers 2 / 3 forward 
 _MASK_BITS = os.environ.get("MI355PPO_MASK_BITS", "1") != "0"   # ReLU masks travel to the data gradients as bits (0: as the f32 activations; A/B runs)
 _FUSED_PACKS = os.environ.get("MI355PPO_FUSED_PACKS", "1") != "0"   # all weight packs of the NatureCNN agent in one launch (0: the 13 launches; A/B runs)
 BUF_LIMIT = (1 << 32) - 8192     # kernels Z / F address a tensor with 32-bit buffer offsets: larger tensors take kernel S (64-bit pointers)
+# Operand split of kernels Z / V / W (round 5): "f16x2" = two f16 terms per f32 under per-tensor power-of-two scales, three matrix
+# instructions per product (csrc/f16split.h); "bf16x3" = round 3's three bf16 terms, six instructions.  Read once per process.
+_SPLIT = os.environ.get("MI355PPO_SPLIT", "f16x2")
+if _SPLIT not in ("f16x2", "bf16x3"):
+    raise ValueError(f"MI355PPO_SPLIT={_SPLIT!r}: expected f16x2 or bf16x3")
+AMAX_WORDS = 256                 # MI355PPO_AMAX_WORDS: uint32 words of an amax record (16 slots, 64 bytes apart)
+REC_A1, REC_A2, REC_A3, REC_DH, REC_DZ3, REC_DZ2, N_REC = 0, 1, 2, 3, 4, 5, 8     # the records of one forward / backward pass of the trunk
+
+
+def new_amax(n: int, device) -> torch.Tensor:
+    """``n`` zeroed amax records (csrc/f16split.h): row r = the record of one tensor."""
+    return torch.zeros((n, AMAX_WORDS), dtype=torch.int32, device=device)
+
+
+def absmax(x: torch.Tensor, rec: torch.Tensor) -> torch.Tensor:
+    """Fold ``max |x|`` into the amax record ``rec`` (one row of ``new_amax``; zero it first unless it already holds part of x)."""
+    lib = _lib.load()
+    _chk(rec, torch.int32, "amax record", (AMAX_WORDS,))
+    if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
+        raise ValueError(f"absmax: expected a contiguous f32 device tensor, got {tuple(x.shape)} {x.dtype} on {x.device}")
+    with _on(x.device):
+        st = lib.mi355ppo_absmax_f32(_ptr(x), x.numel(), _ptr(rec), _stream(x.device))
+    _lib.check(st, "mi355ppo_absmax_f32")
+    return rec
+
+
+def amax_value(rec: torch.Tensor) -> float:
+    """The record's value as a float (tests, debugging): the slots hold bit patterns of non-negative f32."""
+    return float(rec.view(-1)[::16].contiguous().view(torch.float32).max().item())
+
+
+def _rec(t, name):
+    return None if t is None else _ptr(_chk(t, torch.int32, name, (AMAX_WORDS,)))
+
 
 
 def warm_forward_packs(bufs, net) -> None:
@@ -103,9 +137,10 @@ def conv_dgrad(dz: torch.Tensor, Bt: torch.Tensor, act_in: torch.Tensor, layer: 
     return out
 
 
-def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tensor | None = None, out=None):
+def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tensor | None = None, out=None, amax=None):
     """``(dW (Cout,Cin,K,K), db (Cout))`` from the layer input and the pre-activation gradient; ``out=(dW, db)`` writes into the
-    caller's tensors (e.g. the parameters' ``.grad`` views of a flat gradient buffer)."""
+    caller's tensors (e.g. the parameters' ``.grad`` views of a flat gradient buffer).  ``amax = (src_rec, dz_rec)`` (layers 2 / 3):
+    kernel V on the f16 split."""
     lib = _lib.load()
     cin, cout, k, _, hin, hout = LAYERS[layer]
     images = dz.shape[0]
@@ -126,6 +161,13 @@ def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tens
         dW = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
         db = torch.empty(cout, dtype=torch.float32, device=dev)
     ws = _workspace(dev, lib.mi355ppo_cnn_conv_wgrad_workspace_bytes(images, layer))
+    if amax is not None:
+        assert layer in (2, 3)
+        with _on(dev):
+            st = lib.mi355ppo_cnn_conv_wgrad_f16x2_f32(_ptr(src), _ptr(dz), _ptr(dW), _ptr(db), images, layer, _ptr(ws), ws.numel(),
+                                                       _rec(amax[0], "src_amax"), _rec(amax[1], "dz_amax"), _stream(dev))
+        _lib.check(st, "mi355ppo_cnn_conv_wgrad_f16x2_f32")
+        return dW, db
     with _on(dev):
         st = lib.mi355ppo_cnn_conv_wgrad_f32(_ptr(src), _ptr(inds), _ptr(dz), _ptr(dW), _ptr(db), images, layer, _ptr(ws),
                                              ws.numel(), _stream(dev))
@@ -165,17 +207,51 @@ def fc_pack(B: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     return out
 
 
-def fc_fwd_relu_packed(a: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, N: int, out: torch.Tensor | None = None) -> torch.Tensor:
-    """``relu(a @ B.T + bias)`` with ``pack = fc_pack(B)``, B (N, K): kernel Z."""
+def fc_pack_f16x2(B: torch.Tensor, b_amax: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``fc_pack`` in the f16x2 format (header + two f16 planes of s B; csrc/f16split.h).  ``b_amax``: B's amax record (computed here
+    when absent)."""
+    lib = _lib.load()
+    if B.dtype != torch.float32 or not B.is_cuda or B.dim() != 2 or B.stride(1) != 1 or B.stride(0) < B.shape[1]:
+        raise ValueError(f"fc_pack_f16x2: expected a row-major f32 device matrix, got {tuple(B.shape)} strides {B.stride()} {B.dtype} on {B.device}")
+    N, K = B.shape
+    nbytes = lib.mi355ppo_fc_pack_f16x2_bytes(N, K)
+    if nbytes == 0:
+        raise ValueError(f"fc_pack_f16x2: K={K} must be a positive multiple of 16")
+    if b_amax is None:
+        b_amax = new_amax(1, B.device)[0]
+        if B.is_contiguous():
+            absmax(B, b_amax)
+        else:                                   # (a padded row pitch: the pad columns are not B's)
+            absmax(B.contiguous(), b_amax)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=B.device)
+    _chk(out, torch.uint8, "pack", (nbytes,))
+    with _on(B.device):
+        st = lib.mi355ppo_fc_pack_f16x2_f32(_ptr(B), B.stride(0), N, K, _rec(b_amax, "b_amax"), _ptr(out), _stream(B.device))
+    _lib.check(st, "mi355ppo_fc_pack_f16x2_f32")
+    return out
+
+
+def fc_fwd_relu_packed(a: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, N: int, out: torch.Tensor | None = None,
+                       amax=None) -> torch.Tensor:
+    """``relu(a @ B.T + bias)`` with ``pack = fc_pack(B)``, B (N, K): kernel Z.  ``amax = (a_rec, h_rec | None)``: the f16 split --
+    ``pack = fc_pack_f16x2(B)``, ``a_rec`` = a's amax record, ``h_rec`` receives the result's (whole-K route only)."""
     lib = _lib.load()
     M, K = a.shape
     lda = _row_major(a, "a")
     _chk(bias, torch.float32, "bias", (N,))
-    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(N, K),))
+    _chk(pack, torch.uint8, "pack", ((lib.mi355ppo_fc_pack_f16x2_bytes if amax is not None else lib.mi355ppo_fc_pack_bytes)(N, K),))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _chk(out, torch.float32, "out", (M, N))
     nws = lib.mi355ppo_fc_fwd_workspace_bytes(M, N, K)       # rollout-sized batches: K split over the grid, partials in a workspace
+    if amax is not None:
+        ws = _workspace(a.device, nws) if nws else None
+        with _on(a.device):
+            st = lib.mi355ppo_fc_fwd_relu_packed_f16x2_f32(_ptr(a), lda, _ptr(pack), _ptr(bias), _ptr(out), M, N, K, _ptr(ws), ws.numel() if nws else 0,
+                                                           _rec(amax[0], "a_amax"), None if nws else _rec(amax[1], "h_amax"), _stream(a.device))
+        _lib.check(st, "mi355ppo_fc_fwd_relu_packed_f16x2_f32")
+        return out
     with _on(a.device):
         if nws:
             ws = _workspace(a.device, nws)
@@ -193,7 +269,8 @@ def fc_heads_act_supported(a: torch.Tensor, N: int = 512) -> bool:
 
 
 def fc_heads_act_categorical(a: torch.Tensor, pack: torch.Tensor, fc_bias: torch.Tensor, Wa, ba, Wc, bc, seed: int, offset: int,
-                             offset_base=None, action_f32_out=None, logprob_out=None, value_out=None, noise_exp1=None, want_i64: bool = True):
+                             offset_base=None, action_f32_out=None, logprob_out=None, value_out=None, noise_exp1=None, want_i64: bool = True,
+                             amax=None):
     """``a`` = the trunk's (M, 3136) features -> Linear(3136,512) + ReLU (K split over the grid), actor / critic heads, Categorical
     sample + log-prob: two launches (``mi355ppo_fc_heads_act_categorical_f32``).  -> ``(action_i64 | None, action_f32, logprob, value)``."""
     lib = _lib.load()
@@ -202,7 +279,7 @@ def fc_heads_act_categorical(a: torch.Tensor, pack: torch.Tensor, fc_bias: torch
     A, H = Wa.shape
     dev = a.device
     _chk(fc_bias, torch.float32, "fc_bias", (H,))
-    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(H, K),))
+    _chk(pack, torch.uint8, "pack", ((lib.mi355ppo_fc_pack_f16x2_bytes if amax is not None else lib.mi355ppo_fc_pack_bytes)(H, K),))
     a64 = torch.empty(M, dtype=torch.int64, device=dev) if want_i64 else None
     af = action_f32_out if action_f32_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
     lp = logprob_out if logprob_out is not None else torch.empty(M, dtype=torch.float32, device=dev)
@@ -215,15 +292,21 @@ def fc_heads_act_categorical(a: torch.Tensor, pack: torch.Tensor, fc_bias: torch
         _chk(noise_exp1, torch.float32, "noise_exp1", (M, A))
     ws = _workspace(dev, lib.mi355ppo_fc_fwd_workspace_bytes(M, H, K))
     with _on(dev):
-        st = lib.mi355ppo_fc_heads_act_categorical_f32(_ptr(a), lda, _ptr(pack), _ptr(fc_bias), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), M, A, H, K,
-                                                       _ptr(noise_exp1), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), _ptr(offset_base),
-                                                       _ptr(a64), _ptr(af), _ptr(lp), _ptr(val), None, _ptr(ws), ws.numel(), _stream(dev))
+        if amax is not None:        # ``amax`` = a's amax record, ``pack`` an f16x2 pack
+            st = lib.mi355ppo_fc_heads_act_categorical_f16x2_f32(_ptr(a), lda, _ptr(pack), _ptr(fc_bias), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), M, A,
+                                                                 H, K, _ptr(noise_exp1), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
+                                                                 _ptr(offset_base), _ptr(a64), _ptr(af), _ptr(lp), _ptr(val), None, _ptr(ws),
+                                                                 ws.numel(), _rec(amax, "a_amax"), _stream(dev))
+        else:
+            st = lib.mi355ppo_fc_heads_act_categorical_f32(_ptr(a), lda, _ptr(pack), _ptr(fc_bias), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), M, A, H, K,
+                                                           _ptr(noise_exp1), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), _ptr(offset_base),
+                                                           _ptr(a64), _ptr(af), _ptr(lp), _ptr(val), None, _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(st, "mi355ppo_fc_heads_act_categorical_f32")
     return a64, af, lp, val
 
 
 def fc_dgrad_mask_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor, out: torch.Tensor | None = None,
-                         bits: torch.Tensor | None = None) -> torch.Tensor:
+                         bits: torch.Tensor | None = None, amax=None) -> torch.Tensor:
     """``(dz @ B.T) * (act_in > 0)`` with ``pack = fc_pack(B)``, B (N, K) = the transposed weight: kernel Z.  ``bits``: the mask
     ``act_in > 0`` as written by ``conv_fwd_packed(..., bits=)`` (N % 32 == 0); ``act_in`` then only gives the shape."""
     lib = _lib.load()
@@ -231,10 +314,18 @@ def fc_dgrad_mask_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Ten
     N = act_in.shape[1]
     lddz = _row_major(dz, "dz")
     _chk(act_in, torch.float32, "act_in", (M, N))
-    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(N, K),))
+    _chk(pack, torch.uint8, "pack", ((lib.mi355ppo_fc_pack_f16x2_bytes if amax is not None else lib.mi355ppo_fc_pack_bytes)(N, K),))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=dz.device)
     _chk(out, torch.float32, "out", (M, N))
+    if amax is not None:            # the f16 split: ``amax = (dz_rec, out_rec | None)``, ``pack = fc_pack_f16x2(B)``
+        if bits is not None:
+            _chk(bits, torch.int32, "bits", (mask_words(M * N),))
+        with _on(dz.device):
+            st = lib.mi355ppo_fc_dgrad_packed_f16x2_f32(_ptr(dz), lddz, _ptr(pack), _ptr(act_in), _ptr(bits), _ptr(out), M, N, K,
+                                                        _rec(amax[0], "dz_amax"), _rec(amax[1], "da_amax"), _stream(dz.device))
+        _lib.check(st, "mi355ppo_fc_dgrad_packed_f16x2_f32")
+        return out
     with _on(dz.device):
         if bits is not None:
             _chk(bits, torch.int32, "bits", (mask_words(M * N),))
@@ -255,6 +346,12 @@ def conv_zpack(W: torch.Tensor, layer: int, mode: int, out: torch.Tensor | None 
     return fc_pack(repack_weights(W, layer, mode).view(n, k), out)
 
 
+def conv_zpack_f16x2(W: torch.Tensor, layer: int, mode: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``conv_zpack`` in the f16x2 format (the scale from max |W|)."""
+    n, k = ZPACK_SHAPE[(layer, mode)]
+    return fc_pack_f16x2(repack_weights(W, layer, mode).view(n, k), None, out)
+
+
 def mask_words(numel: int) -> int:
     """uint32 words of a ReLU bit mask over ``numel`` activation elements (bit b of word w <-> flat element 32 w + b)."""
     assert numel % 32 == 0
@@ -265,6 +362,26 @@ def unpack_mask_bits(bits: torch.Tensor, shape) -> torch.Tensor:
     """The bit mask written by the ``*_bits`` forwards as a bool tensor of the activation's shape (tests, debugging)."""
     w = bits.view(-1).to(torch.int64) & 0xFFFFFFFF
     return ((w[:, None] >> torch.arange(32, device=bits.device)) & 1).bool().view(*shape)
+
+
+def conv1q_fwd_amax(obs_u8: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, inds: torch.Tensor | None, out: torch.Tensor,
+                    bits: torch.Tensor | None, dst_amax: torch.Tensor) -> torch.Tensor:
+    """Layer-1 forward on kernel Q that also folds ``max(out)`` into the amax record ``dst_amax`` (and writes the mask bits when given)."""
+    lib = _lib.load()
+    _chk(obs_u8, torch.uint8, "src")
+    images = obs_u8.shape[0] if inds is None else inds.numel()
+    if inds is not None:
+        _chk(inds, torch.int64, "inds")
+    _chk(pack, torch.float32, "Bt", (QPACK_NUMEL,))
+    _chk(bias, torch.float32, "bias", (32,))
+    _chk(out, torch.float32, "out", (images, 20, 20, 32))
+    if bits is not None:
+        _chk(bits, torch.int32, "bits", (mask_words(out.numel()),))
+    with _on(obs_u8.device):
+        st = lib.mi355ppo_cnn_conv1q_fwd_amax(_ptr(obs_u8), _ptr(inds), _ptr(pack), _ptr(bias), _ptr(out), _ptr(bits), images,
+                                              _rec(dst_amax, "dst_amax"), _stream(obs_u8.device))
+    _lib.check(st, "mi355ppo_cnn_conv1q_fwd_amax")
+    return out
 
 
 def conv1q_fwd_bits(obs_u8: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, inds: torch.Tensor | None, out: torch.Tensor,
@@ -286,18 +403,26 @@ def conv1q_fwd_bits(obs_u8: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor
 
 
 def conv_fwd_packed(src: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, layer: int, out: torch.Tensor | None = None,
-                    bits: torch.Tensor | None = None) -> torch.Tensor:
+                    bits: torch.Tensor | None = None, amax=None) -> torch.Tensor:
     """``relu(conv(src) + bias)`` of layer 2 / 3 on kernel Z (csrc/gemmz.hip); ``pack = conv_zpack(W, layer, MODE_FWD)``.
     ``bits`` (int32, ``out.numel() // 32`` words): also receives ``(out > 0)`` as a bit mask."""
     lib = _lib.load()
     cin, cout, k, _, hin, hout = LAYERS[layer]
     images = src.shape[0]
     _chk(src, torch.float32, "src", (images, hin, hin, cin))
-    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(cout, cin * k * k),))
+    _chk(pack, torch.uint8, "pack", ((lib.mi355ppo_fc_pack_f16x2_bytes if amax is not None else lib.mi355ppo_fc_pack_bytes)(cout, cin * k * k),))
     _chk(bias, torch.float32, "bias", (cout,))
     if out is None:
         out = torch.empty((images, hout, hout, cout), dtype=torch.float32, device=src.device)
     _chk(out, torch.float32, "out", (images, hout, hout, cout))
+    if amax is not None:            # the f16 split: ``amax = (src_rec, out_rec | None)``, ``pack = conv_zpack_f16x2(W, layer, MODE_FWD)``
+        if bits is not None:
+            _chk(bits, torch.int32, "bits", (mask_words(out.numel()),))
+        with _on(src.device):
+            st = lib.mi355ppo_cnn_conv_fwd_packed_f16x2_f32(_ptr(src), _ptr(pack), _ptr(bias), _ptr(out), _ptr(bits), images, layer,
+                                                            _rec(amax[0], "src_amax"), _rec(amax[1], "dst_amax"), _stream(src.device))
+        _lib.check(st, "mi355ppo_cnn_conv_fwd_packed_f16x2_f32")
+        return out
     with _on(src.device):
         if bits is not None:
             _chk(bits, torch.int32, "bits", (mask_words(out.numel()),))
@@ -309,7 +434,7 @@ def conv_fwd_packed(src: torch.Tensor, pack: torch.Tensor, bias: torch.Tensor, l
 
 
 def conv_dgrad_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor | None, layer: int, out: torch.Tensor | None = None,
-                      bits: torch.Tensor | None = None) -> torch.Tensor:
+                      bits: torch.Tensor | None = None, amax=None) -> torch.Tensor:
     """Data gradient of layer 2 / 3 masked by ``act_in > 0`` on kernel Z; ``pack = conv_zpack(W, layer, MODE_DGRAD_S2 / _S1)``.
     ``bits``: the mask as written by the layer below's ``*_bits`` forward instead of ``act_in`` (which may then be None)."""
     lib = _lib.load()
@@ -319,10 +444,18 @@ def conv_dgrad_packed(dz: torch.Tensor, pack: torch.Tensor, act_in: torch.Tensor
     if bits is None:
         _chk(act_in, torch.float32, "act_in", (images, hin, hin, cin))
     n, kk = ZPACK_SHAPE[(layer, MODE_DGRAD_S2 if layer == 2 else MODE_DGRAD_S1)]
-    _chk(pack, torch.uint8, "pack", (lib.mi355ppo_fc_pack_bytes(n, kk),))
+    _chk(pack, torch.uint8, "pack", ((lib.mi355ppo_fc_pack_f16x2_bytes if amax is not None else lib.mi355ppo_fc_pack_bytes)(n, kk),))
     if out is None:
         out = torch.empty((images, hin, hin, cin), dtype=torch.float32, device=dz.device)
     _chk(out, torch.float32, "out", (images, hin, hin, cin))
+    if amax is not None:            # the f16 split: ``amax = (dz_rec, out_rec | None)``
+        if bits is not None:
+            _chk(bits, torch.int32, "bits", (mask_words(out.numel()),))
+        with _on(dz.device):
+            st = lib.mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(_ptr(dz), _ptr(pack), _ptr(act_in), _ptr(bits), _ptr(out), images, layer,
+                                                              _rec(amax[0], "dz_amax"), _rec(amax[1], "dsrc_amax"), _stream(dz.device))
+        _lib.check(st, "mi355ppo_cnn_conv_dgrad_packed_f16x2_f32")
+        return out
     with _on(dz.device):
         if bits is not None:
             _chk(bits, torch.int32, "bits", (mask_words(out.numel()),))
@@ -350,7 +483,7 @@ def padded_rows(rows: int, cols: int, device, pad: int = FC_PAD) -> torch.Tensor
     return torch.empty((rows, cols + pad), dtype=torch.float32, device=device)[:, :cols]
 
 
-def fc_wgrad(dz: torch.Tensor, a: torch.Tensor, hwc_channels: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
+def fc_wgrad(dz: torch.Tensor, a: torch.Tensor, hwc_channels: int = 0, out: torch.Tensor | None = None, amax=None) -> torch.Tensor:
     """``dz.T @ a`` (N, K) (csrc/fcw.hip: kernel W on the bf16 pipe at minibatch sizes, kernel Y on the f32 pipe otherwise), the
     batch slabs added in a fixed order.  With
     ``hwc_channels = C`` the columns of ``a`` are (h, w, c)-ordered features and the result comes out in the reference's
@@ -364,6 +497,12 @@ def fc_wgrad(dz: torch.Tensor, a: torch.Tensor, hwc_channels: int = 0, out: torc
         out = torch.empty((N, K), dtype=torch.float32, device=dz.device)
     _chk(out, torch.float32, "out", (N, K))
     ws = _workspace(dz.device, lib.mi355ppo_fc_wgrad_workspace_bytes(M, N, K))
+    if amax is not None:            # kernel W on the f16 split: ``amax = (dz_rec, a_rec)``
+        with _on(dz.device):
+            st = lib.mi355ppo_fc_wgrad_f16x2_f32(_ptr(dz), lddz, _ptr(a), _ptr(out), M, N, K, int(hwc_channels), _ptr(ws), ws.numel(),
+                                                 _rec(amax[0], "dz_amax"), _rec(amax[1], "a_amax"), _stream(dz.device))
+        _lib.check(st, "mi355ppo_fc_wgrad_f16x2_f32")
+        return out
     with _on(dz.device):
         st = lib.mi355ppo_fc_wgrad_f32(_ptr(dz), lddz, _ptr(a), _ptr(out), M, N, K, int(hwc_channels), _ptr(ws), ws.numel(), _stream(dz.device))
     _lib.check(st, "mi355ppo_fc_wgrad_f32")
@@ -397,6 +536,55 @@ class _Buffers:
         # (W1, W2, W3, Wfc) of the owning NatureCNN agent: with cached weights, a stale pack then means ALL of kernel Q's / kernel Z's
         # packs are rebuilt together from the parameters in one launch (mi355ppo_nature_packs_f32) instead of 13 small ones
         self.pack_params = None
+        # round 5, the two-term f16 split (csrc/f16split.h): the amax records of the pass in flight (one set per batch size and stream,
+        # like the activations they describe), which tensor each record currently belongs to, and the weights' records (f16x2 packs)
+        self.split = _SPLIT
+        self._owners = {}
+        self.w_amax = None
+
+    def f16(self, t: torch.Tensor) -> bool:
+        """Kernels Z / V / W take the f16 split for this tensor's pass (device tensors; the CPU stand-ins of the tests keep the bf16 names)."""
+        return self.split == "f16x2" and _CONV_Z and t.is_cuda
+
+    @staticmethod
+    def _amax_key(m: int, dev):
+        return ("amax", m, dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+
+    def has_pass(self, m: int, dev) -> bool:
+        return self._amax_key(m, dev) in self.by_m
+
+    def begin_pass(self, m: int, dev) -> torch.Tensor:
+        """The amax records of a forward (+ backward) pass over ``m`` images on the current stream (one set per batch size and stream,
+        like the activations they describe -- the env-group lanes of a rollout run side by side), zeroed: ONE fill for all of them."""
+        key = self._amax_key(m, dev)
+        rec = self.by_m.get(key)
+        if rec is None:
+            rec = new_amax(N_REC, dev)
+            self.by_m[key] = rec
+        else:
+            rec.zero_()
+        self._owners[key] = {}
+        return rec
+
+    def owns(self, idx: int, t: torch.Tensor) -> torch.Tensor:
+        """Record ``idx`` of t's pass, for a producer about to write ``t`` (its epilogue fills the record)."""
+        key = self._amax_key(t.shape[0], t.device)
+        self._owners[key][idx] = t.data_ptr()
+        return self.by_m[key][idx]
+
+    def rec_of(self, idx: int, t: torch.Tensor) -> torch.Tensor:
+        """Record ``idx`` holding ``max |t|``: as filled by t's producer, or -- a tensor that came from somewhere else (torch's
+        threshold_backward, a head wider than the fused kernel takes) -- computed here with one pass over it."""
+        key = self._amax_key(t.shape[0], t.device)
+        rec = self.by_m.get(key)
+        if rec is None:
+            rec = self.begin_pass(t.shape[0], t.device)
+        owners = self._owners[key]
+        if owners.get(idx) != t.data_ptr():
+            rec[idx].zero_()
+            absmax(t if t.is_contiguous() else t.contiguous(), rec[idx])
+            owners[idx] = t.data_ptr()
+        return rec[idx]
 
     def _pack_keys(self):
         W1, W2, W3, Wfc = self.pack_params
@@ -413,19 +601,26 @@ class _Buffers:
             return False
         lib = _lib.load()
         dev = W.device
+        f16 = self.f16(W)
+        nbytes = lib.mi355ppo_fc_pack_f16x2_bytes if f16 else lib.mi355ppo_fc_pack_bytes
         outs = []
         for k, w, shape in keys:
             hit = self._bt.get(k)
             if hit is None:
                 buf = (torch.empty(QPACK_NUMEL, dtype=torch.float32, device=dev) if shape is None
-                       else torch.empty(lib.mi355ppo_fc_pack_bytes(*shape), dtype=torch.uint8, device=dev))
+                       else torch.empty(nbytes(*shape), dtype=torch.uint8, device=dev))
             else:
                 buf = hit[1]
             outs.append(buf)
         W1, W2, W3, Wfc = (w.detach() for w in self.pack_params)
         with _on(dev):
-            st = lib.mi355ppo_nature_packs_f32(_ptr(W1), _ptr(W2), _ptr(W3), _ptr(Wfc), *[_ptr(o) for o in outs], _stream(dev))
-        _lib.check(st, "mi355ppo_nature_packs_f32")
+            if f16:
+                if self.w_amax is None:
+                    self.w_amax = new_amax(3, dev)
+                st = lib.mi355ppo_nature_packs_f16x2_f32(_ptr(W1), _ptr(W2), _ptr(W3), _ptr(Wfc), *[_ptr(o) for o in outs], _ptr(self.w_amax), _stream(dev))
+            else:
+                st = lib.mi355ppo_nature_packs_f32(_ptr(W1), _ptr(W2), _ptr(W3), _ptr(Wfc), *[_ptr(o) for o in outs], _stream(dev))
+        _lib.check(st, "mi355ppo_nature_packs_f16x2_f32" if f16 else "mi355ppo_nature_packs_f32")
         for (k, w, _), buf in zip(keys, outs):
             self._bt[k] = ((self.weights_version, w._version, w.data_ptr()), buf)
         return True
@@ -459,14 +654,15 @@ class _Buffers:
         return self._pack_cached(("zpack", layer, mode), W, lambda: self.weights(W, layer, mode).view(*ZPACK_SHAPE[(layer, mode)]))
 
     def _pack_cached(self, key, W, source):
+        pack = (lambda B, out=None: fc_pack_f16x2(B, None, out)) if self.f16(W) else fc_pack      # (looked up per call: the tests patch cnn.fc_pack)
         if not self.cache_weights:
-            return fc_pack(source())
+            return pack(source())
         tag = (self.weights_version, W._version, W.data_ptr())
         hit = self._bt.get(key)
         if hit is None or hit[0] != tag:
             if self._repack_all(key, W):
                 return self._bt[key][1]
-            hit = (tag, fc_pack(source(), hit[1] if hit is not None else None))
+            hit = (tag, pack(source(), hit[1] if hit is not None else None))
             self._bt[key] = hit
         return hit[1]
 
@@ -547,7 +743,19 @@ class NatureTrunkFn(torch.autograd.Function):
         bt1 = bufs.weights(W1, 1, MODE_FWD_Q)
         ctx.bits = None
         bufs.last_a3_bits = None
-        if _CONV_Z and _MASK_BITS and want_bits and any(ctx.needs_input_grad):
+        ctx.f16 = f16 = bufs.f16(obs_u8)
+        if f16:
+            # the two-term f16 split (csrc/f16split.h): every forward folds its output's maximum into the tensor's amax record, the
+            # next layer scales its A operand by it; one fill zeroes the records of this forward and of the backward that may follow
+            rec = bufs.begin_pass(m, obs_u8.device)
+            mb1 = mb2 = mb3 = None
+            if _MASK_BITS and want_bits and any(ctx.needs_input_grad):
+                mb1, mb2, mb3 = ctx.bits = bufs.get_bits(m, obs_u8.device)
+                bufs.last_a3_bits = mb3
+            conv1q_fwd_amax(obs_u8, bt1, b1.detach(), inds, a1, mb1, bufs.owns(REC_A1, a1))
+            conv_fwd_packed(a1, bufs.conv_zpack(W2, 2, MODE_FWD), b2.detach(), 2, a2, bits=mb2, amax=(rec[REC_A1], bufs.owns(REC_A2, a2)))
+            conv_fwd_packed(a2, bufs.conv_zpack(W3, 3, MODE_FWD), b3.detach(), 3, a3, bits=mb3, amax=(rec[REC_A2], bufs.owns(REC_A3, a3)))
+        elif _CONV_Z and _MASK_BITS and want_bits and any(ctx.needs_input_grad):
             # a backward will follow (the caller saw gradients enabled; inside forward() they never are): every forward also writes its ReLU mask as bits -- the data gradients then read 1/32 of the
             # mask bytes (the f32 activations stay: the weight gradients read them)
             mb1, mb2, mb3 = bufs.get_bits(m, obs_u8.device)
@@ -586,6 +794,19 @@ class NatureTrunkFn(torch.autograd.Function):
             dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)    # ReLU backward of the last conv
         direct = ctx.bufs.direct_grads and all(p.grad is not None for p in ctx.params)
         gout = (lambda l: (ctx.params[2 * l - 2].grad, ctx.params[2 * l - 1].grad)) if direct else (lambda l: None)
+        if getattr(ctx, "f16", False):      # (a1 / a2 below 4 GiB: the forward took this route)
+            bufs, bits = ctx.bufs, ctx.bits
+            r3 = bufs.rec_of(REC_DZ3, dz3)          # filled by the FC data gradient's epilogue when it produced dz3
+            dW3, db3 = conv_wgrad(a2, dz3, 3, out=gout(3), amax=(bufs.rec_of(REC_A2, a2), r3))
+            conv_dgrad_packed(dz3, bufs.conv_zpack(W3, 3, MODE_DGRAD_S1), a2, 3, dz2, bits=bits[1] if bits else None,
+                              amax=(r3, bufs.owns(REC_DZ2, dz2)))
+            r2 = bufs.rec_of(REC_DZ2, dz2)
+            dW2, db2 = conv_wgrad(a1, dz2, 2, out=gout(2), amax=(bufs.rec_of(REC_A1, a1), r2))
+            conv_dgrad_packed(dz2, bufs.conv_zpack(W2, 2, MODE_DGRAD_S2), a1, 2, dz1, bits=bits[0] if bits else None, amax=(r2, None))
+            dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds, out=gout(1))          # kernel P (bf16 pipe, exact products): unchanged
+            if direct:
+                return (None,) * 10
+            return None, None, dW1, db1, dW2, db2, dW3, db3, None, None
         dW3, db3 = conv_wgrad(a2, dz3, 3, out=gout(3))
         # (layer-3 data gradient: kernel Z multiplies the padding taps, 1.65 x the MFMAs, and still beats kernel F's nine
         # border-class launches at every size measured: profiles/r03_conv_traffic_ab_same_box.jsonl)
@@ -642,7 +863,10 @@ class LinearReLUHwcFn(torch.autograd.Function):
         # the library GEMM with the same fused epilogue.
         ctx.fcz = bool(a.is_cuda and bufs is not None and a.shape[0] >= FCZ_MIN_ROWS and a.shape[1] % 16 == 0 and a.is_contiguous()
                        and a.numel() * 4 < BUF_LIMIT)
-        if ctx.fcz:
+        ctx.f16 = bool(ctx.fcz and bufs.f16(a))
+        if ctx.f16:
+            h = fc_fwd_relu_packed(a, bufs.fc_pack_fwd(W), b.detach().contiguous(), W.shape[0], amax=(bufs.rec_of(REC_A3, a), None))
+        elif ctx.fcz:
             h = fc_fwd_relu_packed(a, bufs.fc_pack_fwd(W), b.detach().contiguous(), W.shape[0])
         else:
             Wp = bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()).contiguous()
@@ -670,7 +894,12 @@ class LinearReLUHwcFn(torch.autograd.Function):
             if fused:
                 # `a` is the trunk's ReLU output a3: its ReLU backward rides in this GEMM's epilogue (kernel Z, Z_MASK) and
                 # NatureTrunkFn.backward is told not to mask again -- the separate pass over the 411 MB tensor is gone
-                da = fc_dgrad_mask_packed(dz, bufs.fc_pack_dgrad(W), a, bits=bufs.last_a3_bits)
+                if ctx.f16:
+                    da = torch.empty((dz.shape[0], a.shape[1]), dtype=torch.float32, device=dz.device)
+                    fc_dgrad_mask_packed(dz, bufs.fc_pack_dgrad(W), a, out=da, bits=bufs.last_a3_bits,
+                                         amax=(bufs.rec_of(REC_DH, dz), bufs.owns(REC_DZ3, da)))
+                else:
+                    da = fc_dgrad_mask_packed(dz, bufs.fc_pack_dgrad(W), a, bits=bufs.last_a3_bits)
                 bufs.a3_grad_is_masked = True
             else:
                 da = dz @ (bufs.fc_weight(W) if bufs is not None else fc_weight_hwc(W.detach()))
@@ -678,7 +907,9 @@ class LinearReLUHwcFn(torch.autograd.Function):
         wk = ctx.fcz and n % 64 == 0 and a.shape[1] % 224 == 0 and a.shape[1] % 64 == 0
         direct = bool(wk and bufs is not None and bufs.direct_grads and W.grad is not None and ctx.bias.grad is not None
                       and W.grad.is_contiguous())
-        if wk:
+        if wk and ctx.f16:
+            dW = fc_wgrad(dz, a, 64, out=W.grad if direct else None, amax=(bufs.rec_of(REC_DH, dz), bufs.rec_of(REC_A3, a)))
+        elif wk:
             dW = fc_wgrad(dz, a, 64, out=W.grad if direct else None)   # kernel W (bf16 pipe), written in the (c, h, w) feature order of W itself
         else:
             dW = (dz.t() @ a).view(n, 7, 7, 64).permute(0, 3, 1, 2).reshape(n, 64 * 7 * 7)     # back to the (c, h, w) feature order
@@ -741,7 +972,13 @@ class HeadsFn(torch.autograd.Function):
             dWc, dbc = torch.empty_like(Wc), torch.empty(1, dtype=torch.float32, device=dev)
         ws = _workspace(dev, lib.mi355ppo_heads_bwd_workspace_bytes(M, A))
         with _on(dev):
-            if bufs is not None:
+            if bufs is not None and bufs.f16(h) and bufs.has_pass(M, dev):      # the FC layer's gradients will split dz: record max |dz| here
+                dbh = torch.empty(H, dtype=torch.float32, device=dev)
+                st = lib.mi355ppo_heads_bwd_relu_amax_f32(_ptr(h), _ptr(Wa), _ptr(Wc), _ptr(dlogits), _ptr(dvalue), _ptr(dh), dh.stride(0),
+                                                          _ptr(dWa), _ptr(dba), _ptr(dWc), _ptr(dbc), _ptr(dbh), M, A, H, _ptr(ws), ws.numel(),
+                                                          _ptr(bufs.owns(REC_DH, dh)), _stream(dev))
+                bufs.fc_dz_from_heads = (dh.data_ptr(), dbh)
+            elif bufs is not None:
                 dbh = torch.empty(H, dtype=torch.float32, device=dev)
                 st = lib.mi355ppo_heads_bwd_relu_f32(_ptr(h), _ptr(Wa), _ptr(Wc), _ptr(dlogits), _ptr(dvalue), _ptr(dh), dh.stride(0),
                                                      _ptr(dWa), _ptr(dba), _ptr(dWc), _ptr(dbc), _ptr(dbh), M, A, H, _ptr(ws), ws.numel(),

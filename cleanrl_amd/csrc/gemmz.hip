@@ -946,7 +946,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     float v = fin(acc[i][j][e]) + bj[j];
-                    v = v > 0.0f ? v : 0.0f;
+                    if constexpr (SPLIT) v = v < 0.0f ? 0.0f : v;      // (a NaN from an overflowed f16 operand -- an understated amax record -- stays a NaN)
+                    else v = v > 0.0f ? v : 0.0f;
                     seen(v);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, at(ro, j), 0, 0);
                     if constexpr (kBitsOut) {             // lanes 0..31 of the ballot: the 32 columns of row (e & 3) + 8 (e >> 2); 32..63: of that row + 4

@@ -49,13 +49,19 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 }
 
 // ---- staging: rows [row0, row0 + nrows) of the (gathered) observation matrix -> LDS, pitch OMAX, zero padded ----------------
-// Lane r first fetches the flat-batch index of row r (ONE round trip for the whole block); the element loop then gets a row's index
-// with a lane permute, so all its loads are independent and in flight together.
+// Lane r first fetches the flat-batch index of row r (ONE round trip for the whole block) and parks it in `scratch` (LDS the caller
+// does not need yet: >= 64 int64); the element loop then reads a row's index from there, so all its loads are independent and in
+// flight together.  (Round 4 fetched it with a lane permute, ds_bpermute -- the primitive whose broadcast returned stale lanes in the
+// heads' backward kernel when a second process time-sliced the GPU; plain LDS writes and reads of one wave
+// execute in order.)  Without `inds` the index is arithmetic.
 template <int OMAX>
 __device__ __forceinline__ void stage_rows(float* xs, const float* __restrict__ obs, const int64_t* __restrict__ inds, int64_t row0,
-                                           int nrows, int O, int lane) {
-    const int64_t mine = lane < nrows ? (inds ? inds[row0 + lane] : row0 + lane) : 0;
-    const int lo = (int)mine, hi = (int)(mine >> 32);
+                                           int nrows, int O, int lane, float* scratch) {
+    int64_t* const ids = reinterpret_cast<int64_t*>(scratch);
+    if (inds) {                                            // (uniform)
+        ids[lane] = lane < nrows ? inds[row0 + lane] : 0;
+        __builtin_amdgcn_wave_barrier();
+    }
     constexpr int kIter = 64 * OMAX / 64;                  // R <= 64 rows x OMAX columns, 64 lanes
     float v[kIter];
 #pragma unroll
@@ -63,9 +69,10 @@ __device__ __forceinline__ void stage_rows(float* xs, const float* __restrict__ 
         const int e = lane + 64 * it;
         const int r = e / OMAX, k = e - r * OMAX;
         const int rr = r < nrows ? r : 0;
-        const int64_t i = ((int64_t)__shfl(hi, rr, 64) << 32) | (uint32_t)__shfl(lo, rr, 64);
+        const int64_t i = inds ? ids[rr] : row0 + rr;
         v[it] = (r < nrows && k < O) ? obs[i * O + k] : 0.0f;
     }
+    __builtin_amdgcn_wave_barrier();                       // (the index reads are done before `scratch` is written again)
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         const int e = lane + 64 * it;
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(64) void mlp_act_kernel(const MlpActArgs a) {
     float* H2 = H1 + a.R * kH;
     HiddenW<OMAX> hw;
     hidden_load<OMAX>(hw, n, a.O, lane);
-    stage_rows<OMAX>(xs, a.obs, nullptr, row0, nrows, a.O, lane);
+    stage_rows<OMAX>(xs, a.obs, nullptr, row0, nrows, a.O, lane, nullptr);
     __builtin_amdgcn_wave_barrier();
     hidden_fwd<OMAX>(hw, xs, H1, H2, nrows, lane);
     if (lane >= nrows) return;
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(64) void mlp_ppo_kernel(const MlpPpoArgs a) {
     float* H2 = H1 + a.R * kH;
     HiddenW<OMAX> hw;
     hidden_load<OMAX>(hw, n, O, lane);
-    stage_rows<OMAX>(xs, a.obs, a.inds, row0, nrows, O, lane);
+    stage_rows<OMAX>(xs, a.obs, a.inds, row0, nrows, O, lane, H1);
     // this lane's row (lane = row phase): behaviour data, requested before the hidden layers run
     const bool valid = lane < nrows;
     const int64_t m = row0 + (valid ? lane : 0);

@@ -557,8 +557,7 @@ class PPOLearner:
         assert self.hip and self.world_size == 1 and type(self).forward_backward_hip is PPOLearner.forward_backward_hip, \
             "capture_update: the single-GPU HIP path of the plain PPO learner"
         assert getattr(self.agent, "rpo_alpha", None) is None, "capture_update: RPO draws noise inside the update (not covered)"
-        # (the Normal / continuous-action path is covered by the same code but has NOT run on a GPU yet: its test is opt-in,
-        #  tests/test_gpu_learner.py::test_captured_update_slots_continuous_path, MI355PPO_TEST_UPDATE_GRAPHS_CONTINUOUS=1)
+        # (the Normal / continuous-action path runs the same code: tests/test_gpu_learner.py::test_captured_update_slots_continuous_path)
         a, dev = self.args, self.device
         B, M = self.batch_size, self.minibatch_size
         assert B % M == 0, "capture_update needs whole minibatches"
@@ -608,22 +607,36 @@ class PPOLearner:
         state0 = [t.clone() for t in (self.flat.params, self.flat.exp_avg, self.flat.exp_avg_sq)]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            slot(0, 0)                                                    # warm-up on the capture stream (workspaces, trunk buffers)
-            for t, t0 in zip((self.flat.params, self.flat.exp_avg, self.flat.exp_avg_sq), state0):
-                t.copy_(t0)                                               # the warm-up's optimizer step (zero step size) is undone exactly
-            self.flat.grads.zero_()
-        side.synchronize()
         graphs, pool = [], None
-        for e in range(E_):
-            row = []
-            for j in range(nmb):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=side):
-                    slot(e, j)
-                pool = pool or g.pool()
-                row.append(g)
-            graphs.append(row)
+        try:
+            with torch.cuda.stream(side):
+                slot(0, 0)                                                # warm-up on the capture stream (workspaces, trunk buffers)
+                for t, t0 in zip((self.flat.params, self.flat.exp_avg, self.flat.exp_avg_sq), state0):
+                    t.copy_(t0)                                           # the warm-up's optimizer step (zero step size) is undone exactly
+                self.flat.grads.zero_()
+            side.synchronize()
+            for e in range(E_):
+                row = []
+                for j in range(nmb):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool, stream=side):
+                        slot(e, j)
+                    pool = pool or g.pool()
+                    row.append(g)
+                graphs.append(row)
+        except Exception:
+            # a capture that failed (an op the stream capture does not allow, e.g. inside a library GEMM of a head wider than the fused
+            # kernel takes) must leave a learner that trains eagerly: nothing the warm-up or a partial capture touched may survive
+            graphs = None
+            torch.cuda.synchronize(dev)
+            for t, t0 in zip((self.flat.params, self.flat.exp_avg, self.flat.exp_avg_sq), state0):
+                t.copy_(t0)
+            self.flat.grads.zero_()
+            self._mb_adv_md = self._mb_slot = self._pack = None
+            self._update_graphs = self._adam_sched = None
+            if trunk is not None:
+                trunk.bufs.weights_version += 1
+            raise
         torch.cuda.current_stream(dev).wait_stream(side)
         self.flat.grads.zero_()
         self._mb_adv_md = self._mb_slot = self._pack = None

@@ -64,6 +64,7 @@ def _chk(t: torch.Tensor, dtype, name: str, shape=None) -> torch.Tensor:
 
 
 _workspaces: dict = {}
+_retired: list = []
 
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
@@ -71,6 +72,8 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _retired.append(ws)      # a captured hipGraph may have baked this pointer in: an outgrown workspace is kept, never freed
         ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
         _workspaces[key] = ws
     return ws

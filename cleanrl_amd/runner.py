@@ -170,7 +170,10 @@ def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: in
     if (learner.hip and world_size == 1 and type(learner) is PPOLearner and args.target_kl is None
             and getattr(agent, "rpo_alpha", None) is None and learner.batch_size % max(learner.minibatch_size, 1) == 0
             and (learner.fused_cnn or learner.mlp is not None) and os.environ.get("MI355PPO_UPDATE_GRAPHS", "1") != "0"):
-        learner.capture_update()
+        try:
+            learner.capture_update()
+        except Exception as exc:      # (capture_update restored the parameters, the Adam state and the zeroed gradients)
+            print(f"update graphs: capture failed ({type(exc).__name__}: {str(exc).splitlines()[0][:200]}); the update runs as eager launches", flush=True)
     metrics = {}
     action = None
     for iteration in range(1, args.num_iterations + 1):

@@ -278,6 +278,21 @@ def test_config_c_whole_iteration_teacher_forced_all_16_updates():
     assert not problems, "\n".join(problems + report)
 
 
+def test_config_c_whole_iteration_under_update_graphs():
+    """The same golden on the path ``bench.py`` times at config C: the 16 update slots replayed as captured hipGraphs
+    (``capture_update``, optimizer step inside).  The seven scalars of all 16 minibatches and the parameters after update 16 against
+    the reference's lines with the eager test's bars (the pre-Adam gradients are not observable inside a graph: the eager test
+    above holds them)."""
+    from whole_iteration import check_atari_iteration, run_atari_iteration
+
+    g = load_golden("atari_iteration_cfgC")["atari_T128_N1024"]
+    out = run_atari_iteration(g, DEV, graphs=True)
+    report = []
+    problems = check_atari_iteration(out, g, {}, report=report)
+    print("\n".join(["config C whole iteration under update graphs vs the reference's lines:"] + report))
+    assert not problems, "\n".join(problems + report)
+
+
 def test_dp_step_matches_reference_collective_block_golden():
     """ppo_atari_multigpu.py:320-377 for world_size=2 (golden from the reference's lines): rank-1 gradient is
     summed into the flat buffer exactly where the RCCL all-reduce acts, then the fused /world -> clip -> Adam."""
@@ -816,6 +831,41 @@ def test_captured_update_slots_are_bit_identical_to_the_eager_update(N, T, nmb, 
         assert torch.equal(Le.flat.params, Lg.flat.params), it
         assert torch.equal(Le.flat.exp_avg, Lg.flat.exp_avg) and torch.equal(Le.flat.exp_avg_sq, Lg.flat.exp_avg_sq), it
         assert me == mg or all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
+
+
+def test_captured_update_with_wide_heads_is_bit_identical_or_falls_back_cleanly():
+    """18 actions (most ALE games): the heads are ``nn.Linear`` (library GEMMs + autograd's AccumulateGrad inside the capture).  Either
+    the capture succeeds and replays bit-identically to the eager update, or it raises and leaves a learner that trains eagerly with
+    untouched parameters, Adam state and gradients (``runner.train`` then continues eagerly)."""
+    N, T = 32, 8
+
+    def make():
+        torch.manual_seed(4)
+        env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=6, n_actions=18, done_p=0.1)
+        agent = AtariAgent(env).to(DEV)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=2)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
+        L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
+        return L, env
+
+    (Le, enve), (Lg, envg) = make(), make()
+    try:
+        Lg.capture_update()
+    except Exception as exc:
+        print("capture with 18-action heads failed, eager fallback:", type(exc).__name__, str(exc).splitlines()[0][:160])
+        assert Lg._update_graphs is None
+    assert torch.equal(Le.flat.params, Lg.flat.params) and not Lg.flat.grads.any() and not Lg.flat.exp_avg.any()
+    for it in range(2):
+        learner_smoke.rollout(Le, enve)
+        learner_smoke.rollout(Lg, envg)
+        np.random.seed(100 + it)
+        me = Le.update(2.5e-4)
+        np.random.seed(100 + it)
+        mg = Lg.update(2.5e-4)
+        Le.start_iteration(); Lg.start_iteration()
+        assert torch.equal(Le.flat.params, Lg.flat.params), it
+        assert torch.equal(Le.flat.exp_avg, Lg.flat.exp_avg) and torch.equal(Le.flat.exp_avg_sq, Lg.flat.exp_avg_sq), it
+        assert all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
 
 
 def test_captured_update_slots_continuous_path():

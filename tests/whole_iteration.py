@@ -18,9 +18,11 @@ def cos(a, b):
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
 
 
-def run_atari_iteration(g, dev, rank=0, world=1, T=128, N=None):
+def run_atari_iteration(g, dev, rank=0, world=1, T=128, N=None, graphs=False):
     """-> dict of what the HIP path produced.  ``g`` is the golden case; with world > 1 its per-rank arrays carry the suffix
-    ``_rank<r>`` and torch.distributed must be initialised (the learner all-reduces the flat gradient)."""
+    ``_rank<r>`` and torch.distributed must be initialised (the learner all-reduces the flat gradient).  ``graphs``: the update
+    replays captured hipGraphs (``capture_update``: bench.py's and runner.train's default on one GPU) -- the optimizer step then
+    lives inside the graphs, so the pre-Adam gradients are not observable and only scalars and parameters are returned."""
     sfx = f"_rank{rank}" if world > 1 else ""
     G = lambda k: g[k + sfx]                                                  # noqa: E731
     T, N = G("rewards").shape
@@ -63,13 +65,17 @@ def run_atari_iteration(g, dev, rank=0, world=1, T=128, N=None):
             seen[count[0]] = L.flat.grads.clone()          # after the all-reduce (SUM over the ranks), before /world, clip, Adam
         real(lr)
 
-    L.optimizer_step_hip = spy
+    if graphs:
+        L.capture_update()
+        assert L._update_graphs is not None
+    else:
+        L.optimizer_step_hip = spy
     np.random.seed(int(G("shuffle_seed")))
     m = L.update(float(g["lr"]))
     out["num_updates"] = m["num_updates"]
     out["scalars"] = L._scalars[:m["num_updates"]].cpu().numpy().astype(np.float64)
     sizes = [p.numel() for p in agent.parameters()]
-    for k in keep:
+    for k in (keep if not graphs else ()):
         gh = seen[k].cpu().numpy().astype(np.float64) / world
         n = np.linalg.norm(gh)
         clipped = gh * min(1.0, args.max_grad_norm / (n + 1e-6))             # clip_grad_norm_(0.5) as the reference's step saw it
@@ -106,6 +112,8 @@ def check_atari_iteration(out, g, bars, sfx="", clip_rows=None, report=None):
         problems.append("minibatch scalars off the reference's lines: worst err/bar per column %s at updates %s" % (
             (err / bar).max(0).round(3), (err / bar).argmax(0) + 1))
     for k in (int(x) for x in g["grad_updates"]):
+        if f"grad{k}_sub" not in out:              # (update graphs: the optimizer step sits inside the replayed graph)
+            continue
         want = g[f"mb{k}_grad_sub"]
         worst = np.abs(out[f"grad{k}_sub"] - want).max() / float(g[f"mb{k}_grad_absmax"])
         c = cos(out[f"grad{k}_sub"], want)
@@ -119,7 +127,7 @@ def check_atari_iteration(out, g, bars, sfx="", clip_rows=None, report=None):
     delta = out["final_params_sub"] - g["init_params_sub"]
     want = g["final_params_sub"] - g["init_params_sub"]
     close = np.isclose(delta, want, rtol=5e-2, atol=2e-5)
-    order = np.argsort(out["grad16_mag_sub"])
+    order = np.argsort(out["grad16_mag_sub"] if "grad16_mag_sub" in out else np.abs(want))
     deciles = [float(close[p].mean()) for p in np.array_split(order, 10)]
     report.append(f"values {out['worst_value']:.2e}, GAE {out['adv_err']:.2e}; scalars worst err/bar per column {(err / bar).max(0).round(3)}; "
                   f"16-step move: cosine {cos(delta, want):.7f}, length ratio {np.linalg.norm(delta) / np.linalg.norm(want):.5f}, "

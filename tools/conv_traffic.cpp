@@ -107,6 +107,26 @@ int main(int argc, char** argv) {
     ABI(mi355ppo_fc_pack_f32(bt2, 512, 64, 512, pz2, st)); ABI(mi355ppo_fc_pack_f32(bt3, 576, 64, 576, pz3, st));
     ABI(mi355ppo_fc_pack_f32(bt2d, 256, 128, 256, pzd2, st)); ABI(mi355ppo_fc_pack_f32(bt3d, 576, 64, 576, pzd3, st));
     ABI(mi355ppo_fc_pack_f32(Wfc, 3136, 512, 3136, pk_fwd, st)); ABI(mi355ppo_fc_pack_f32(Wfct, 516, 3136, 512, pk_dg, st));
+    // CONV_TRAFFIC_F16=1: the same launches on the two-term f16 split (round 5; csrc/f16split.h): f16x2 packs, amax records.  Records:
+    // 0 a1, 1 a2, 2 a3, 3 dz3, 4 dz2 (zeroed at the top of every repetition, filled by the producers' epilogues), 8 dzfc (an input
+    // here: mi355ppo_absmax_f32 once), 9 .. 14 the six weight matrices
+    const bool f16 = getenv("CONV_TRAFFIC_F16") != nullptr;
+    uint32_t* rec = dalloc<uint32_t>(16 * MI355PPO_AMAX_WORDS);
+    auto R = [&](int i) { return rec + (size_t)i * MI355PPO_AMAX_WORDS; };
+    void *hz2 = nullptr, *hz3 = nullptr, *hzd2 = nullptr, *hzd3 = nullptr, *hk_fwd = nullptr, *hk_dg = nullptr;
+    if (f16) {
+        CHECK(hipMemsetAsync(rec, 0, 16 * MI355PPO_AMAX_WORDS * 4, st));
+        CHECK(hipMalloc(&hz2, mi355ppo_fc_pack_f16x2_bytes(64, 512))); CHECK(hipMalloc(&hz3, mi355ppo_fc_pack_f16x2_bytes(64, 576)));
+        CHECK(hipMalloc(&hzd2, mi355ppo_fc_pack_f16x2_bytes(128, 256))); CHECK(hipMalloc(&hzd3, mi355ppo_fc_pack_f16x2_bytes(64, 576)));
+        CHECK(hipMalloc(&hk_fwd, mi355ppo_fc_pack_f16x2_bytes(512, 3136))); CHECK(hipMalloc(&hk_dg, mi355ppo_fc_pack_f16x2_bytes(3136, 512)));
+        ABI(mi355ppo_absmax_f32(dzfc, (int64_t)M * 516, R(8), st));
+        ABI(mi355ppo_absmax_f32(bt2, 32768, R(9), st)); ABI(mi355ppo_absmax_f32(bt3, 36864, R(10), st));
+        ABI(mi355ppo_absmax_f32(bt2d, 32768, R(11), st)); ABI(mi355ppo_absmax_f32(bt3d, 36864, R(12), st));
+        ABI(mi355ppo_absmax_f32(Wfc, 512 * 3136, R(13), st)); ABI(mi355ppo_absmax_f32(Wfct, 3136 * 516, R(14), st));
+        ABI(mi355ppo_fc_pack_f16x2_f32(bt2, 512, 64, 512, R(9), hz2, st)); ABI(mi355ppo_fc_pack_f16x2_f32(bt3, 576, 64, 576, R(10), hz3, st));
+        ABI(mi355ppo_fc_pack_f16x2_f32(bt2d, 256, 128, 256, R(11), hzd2, st)); ABI(mi355ppo_fc_pack_f16x2_f32(bt3d, 576, 64, 576, R(12), hzd3, st));
+        ABI(mi355ppo_fc_pack_f16x2_f32(Wfc, 3136, 512, 3136, R(13), hk_fwd, st)); ABI(mi355ppo_fc_pack_f16x2_f32(Wfct, 516, 3136, 512, R(14), hk_dg, st));
+    }
     CHECK(hipStreamSynchronize(st));
 
     if (getenv("CONV_TRAFFIC_CALIB"))
@@ -120,6 +140,20 @@ int main(int argc, char** argv) {
     float *dW1 = dalloc<float>(8192), *dW2 = dalloc<float>(32768), *dW3 = dalloc<float>(36864), *db1 = dalloc<float>(64), *db2 = dalloc<float>(64), *db3 = dalloc<float>(64);
 #define TIMED(i, call) do { CHECK(hipEventRecord(ev[i][0], st)); ABI(call); CHECK(hipEventRecord(ev[i][1], st)); } while (0)
     for (int r = 0; r < reps; r++) {                                // one minibatch update's conv launches, in order
+        if (f16) {
+            CHECK(hipMemsetAsync(rec, 0, 8 * MI355PPO_AMAX_WORDS * 4, st));      // the records the producers fill (what the learner's one fill per pass does)
+            TIMED(0, mi355ppo_cnn_conv1q_fwd_amax(obs, inds, bt1q, bias, a1, mb1, M, R(0), st));
+            TIMED(1, mi355ppo_cnn_conv_fwd_packed_f16x2_f32(a1, hz2, bias, a2, mb2, M, 2, R(0), R(1), st));
+            TIMED(2, mi355ppo_cnn_conv_fwd_packed_f16x2_f32(a2, hz3, bias, a3, mb3, M, 3, R(1), R(2), st));
+            TIMED(8, mi355ppo_fc_fwd_relu_packed_f16x2_f32(a3, 3136, hk_fwd, bias, hfc, (int)M, 512, 3136, wsfwd, wsfwdb, R(2), nullptr, st));
+            TIMED(9, mi355ppo_fc_dgrad_packed_f16x2_f32(dzfc, 516, hk_dg, nullptr, mb3, dz3, (int)M, 3136, 512, R(8), R(3), st));
+            TIMED(10, mi355ppo_fc_wgrad_f16x2_f32(dzfc, 516, a3, dWfc, (int)M, 512, 3136, 64, wsfc, wsfcb, R(8), R(2), st));
+            TIMED(3, mi355ppo_cnn_conv_wgrad_f16x2_f32(a2, dz3, dW3, db3, M, 3, ws, wsb, R(1), R(3), st));
+            TIMED(4, mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(dz3, hzd3, nullptr, mb2, dz2, M, 3, R(3), R(4), st));
+            TIMED(5, mi355ppo_cnn_conv_wgrad_f16x2_f32(a1, dz2, dW2, db2, M, 2, ws, wsb, R(0), R(4), st));
+            TIMED(6, mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(dz2, hzd2, nullptr, mb1, dz1, M, 2, R(4), nullptr, st));
+            TIMED(7, mi355ppo_cnn_conv_wgrad_f32(obs, inds, dz1, dW1, db1, M, 1, ws, wsb, st));
+        } else {
         if (conv_z && bits) {
             TIMED(0, mi355ppo_cnn_conv1q_fwd_bits(obs, inds, bt1q, bias, a1, mb1, M, st));                          // kernel Q (+ a1's mask bits)
             TIMED(1, mi355ppo_cnn_conv_fwd_packed_bits_f32(a1, pz2, bias, a2, mb2, M, 2, st));                     // kernel Z (+ mask bits)
@@ -147,6 +181,7 @@ int main(int argc, char** argv) {
         else if (conv_z) TIMED(6, mi355ppo_cnn_conv_dgrad_packed_f32(dz2, pzd2, a1, dz1, M, 2, st));
         else TIMED(6, mi355ppo_cnn_conv_dgrad_f32_variant(dz2, bt2c, a1, dz1, M, 2, 6, st));           // border classes
         TIMED(7, mi355ppo_cnn_conv_wgrad_f32(obs, inds, dz1, dW1, db1, M, 1, ws, wsb, st));
+        }
         CHECK(hipStreamSynchronize(st));
         if (r > 0 || reps == 1)
             for (int i = 0; i < 11; i++) { float ms; CHECK(hipEventElapsedTime(&ms, ev[i][0], ev[i][1])); tot[i] += ms; }

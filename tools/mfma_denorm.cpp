@@ -23,6 +23,18 @@ __global__ void k(const unsigned short* __restrict__ A, const unsigned short* __
     for (int e = 0; e < 16; ++e) D[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + i] = acc[e];      // row, column i
 }
 
+// Round 5: the same question for v_mfma_f32_32x32x16_f16 (the two-term f16 split of kernels Z / V / W, csrc/f16split.h: the `lo` terms of
+// small elements are f16 SUBNORMALS, pattern 0x0vvv = v * 2^-24).  A[i][k] = an 8-bit integer (f16-exact), B[k][j] = pattern 0x0vvv, v < 1024.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ void kh(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, float* __restrict__ D) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    u16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = A[i * 16 + 8 * h + e]; b[e] = B[(8 * h + e) * 32 + i]; }
+    f32x16 acc = {0};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    for (int e = 0; e < 16; ++e) D[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + i] = acc[e];
+}
+
 static unsigned short bf16_of(float x) { uint32_t u; memcpy(&u, &x, 4); return (unsigned short)(u >> 16); }
 
 int main() {
@@ -58,5 +70,37 @@ int main() {
         }
     printf("{\"test\": \"v_mfma_f32_32x32x16_bf16 with subnormal bf16 inputs (pattern 0x00vv = v * 2^-133)\", \"mismatches\": %d, \"of\": 1024, \"worst_abs_err\": %g, "
            "\"verdict\": \"%s\"}\n", bad, worst, bad == 0 ? "subnormal inputs are multiplied exactly" : "subnormal inputs are NOT exact (flushed?)");
+    {
+        // f16: A = integers m in [-127, 127] as f16 (exact), B = subnormal patterns 0x0vvv (v * 2^-24, v < 1024) and a few normals
+        unsigned short gA[32 * 16], gB[16 * 32];
+        double ja[32 * 16], jb[16 * 32];
+        for (int n = 0; n < 32 * 16; ++n) {
+            s = s * 1664525u + 1013904223u;
+            const int m = (int)((s >> 20) % 255) - 127;
+            ja[n] = m;
+            const _Float16 hm = (_Float16)(float)m;
+            memcpy(&gA[n], &hm, 2);
+        }
+        for (int n = 0; n < 16 * 32; ++n) {
+            s = s * 1664525u + 1013904223u;
+            int v = (int)((s >> 16) & 1023);
+            if (n < 6) v = n == 0 ? 0 : n == 1 ? 1 : n == 2 ? 1023 : n == 3 ? 512 : n == 4 ? 3 : v;
+            gB[n] = (unsigned short)v;                               // exponent field 0: subnormal f16, value v * 2^-24
+            jb[n] = v;
+        }
+        (void)hipMemcpy(dA, gA, sizeof gA, hipMemcpyHostToDevice); (void)hipMemcpy(dB, gB, sizeof gB, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(kh, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+        if (hipMemcpy(hD, dD, sizeof hD, hipMemcpyDeviceToHost) != hipSuccess) { printf("{\"error\": \"hip\"}\n"); return 2; }
+        int badh = 0; double worsth = 0;
+        for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 32; ++j) {
+                double ref = 0;
+                for (int kk = 0; kk < 16; ++kk) ref += ja[i * 16 + kk] * jb[kk * 32 + j];
+                const double got = ldexp((double)hD[i * 32 + j], 24);
+                if (got != ref) { ++badh; if (fabs(got - ref) > worsth) worsth = fabs(got - ref); }
+            }
+        printf("{\"test\": \"v_mfma_f32_32x32x16_f16 with subnormal f16 inputs (pattern 0x0vvv = v * 2^-24)\", \"mismatches\": %d, \"of\": 1024, \"worst_abs_err\": %g, "
+               "\"verdict\": \"%s\"}\n", badh, worsth, badh == 0 ? "subnormal inputs are multiplied exactly" : "subnormal inputs are NOT exact (flushed?)");
+    }
     return 0;
 }
