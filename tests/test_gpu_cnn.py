@@ -408,6 +408,7 @@ def test_all_weight_packs_in_one_launch_are_bit_identical_to_the_per_matrix_rout
            ("zpack", 2, cnn.MODE_DGRAD_S2): cnn.conv_zpack(W2, 2, cnn.MODE_DGRAD_S2),
            "fc_pack_fwd": cnn.fc_pack(cnn.fc_weight_hwc(Wfc).contiguous()), "fc_pack_dgrad": cnn.fc_pack(cnn.fc_weight_hwc(Wfc).t().contiguous())}
     bufs = cnn._Buffers()
+    bufs.split = "bf16x3"                                         # (the f16x2 twin of this test: tests/test_gpu_f16x2.py)
     bufs.cache_weights = True
     bufs.pack_params = (W1, W2, W3, Wfc)
     got = bufs.conv_zpack(W2, 2, cnn.MODE_FWD)                    # one stale pack -> all of them
