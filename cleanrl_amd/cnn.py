@@ -794,7 +794,7 @@ class NatureTrunkFn(torch.autograd.Function):
             dz3 = torch.ops.aten.threshold_backward(da3.contiguous(), a3, 0.0)    # ReLU backward of the last conv
         direct = ctx.bufs.direct_grads and all(p.grad is not None for p in ctx.params)
         gout = (lambda l: (ctx.params[2 * l - 2].grad, ctx.params[2 * l - 1].grad)) if direct else (lambda l: None)
-        if getattr(ctx, "f16", False):      # (a1 / a2 below 4 GiB: the forward took this route)
+        if ctx.bufs.f16(dz3) and a1.numel() * 4 < BUF_LIMIT:      # the two-term f16 split (records: from the producers, else computed here)
             bufs, bits = ctx.bufs, ctx.bits
             r3 = bufs.rec_of(REC_DZ3, dz3)          # filled by the FC data gradient's epilogue when it produced dz3
             dW3, db3 = conv_wgrad(a2, dz3, 3, out=gout(3), amax=(bufs.rec_of(REC_A2, a2), r3))
@@ -811,7 +811,9 @@ class NatureTrunkFn(torch.autograd.Function):
         # (layer-3 data gradient: kernel Z multiplies the padding taps, 1.65 x the MFMAs, and still beats kernel F's nine
         # border-class launches at every size measured: profiles/r03_conv_traffic_ab_same_box.jsonl)
         bits = ctx.bits
-        if _CONV_Z and a2.numel() * 4 < BUF_LIMIT:
+        if _CONV_Z and a2.numel() * 4 < BUF_LIMIT and ctx.bufs.f16(dz3):      # (a1 beyond 4 GiB, a2 within: kernel Z for layer 3, on its f16 pack)
+            conv_dgrad_packed(dz3, ctx.bufs.conv_zpack(W3, 3, MODE_DGRAD_S1), a2, 3, dz2, amax=(ctx.bufs.rec_of(REC_DZ3, dz3), None))
+        elif _CONV_Z and a2.numel() * 4 < BUF_LIMIT:
             conv_dgrad_packed(dz3, ctx.bufs.conv_zpack(W3, 3, MODE_DGRAD_S1), a2, 3, dz2, bits=bits[1] if bits else None)
         elif a2.numel() * 4 < BUF_LIMIT:            # the border-class kernels address tensors with 32-bit buffer offsets
             conv_dgrad(dz3, ctx.bufs.weights(W3, 3, MODE_DGRAD_S1_CLASSES), a2, 3, dz2, variant=5)   # no padding zeros

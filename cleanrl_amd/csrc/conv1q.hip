@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void conv1q_pack_kernel(const float* __restric
 
 // lane `l` of w := the wave-uniform value x
 __device__ __forceinline__ int q_writelane(int w, unsigned x, int l) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(x), "i"(l));
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(x), "i"(l));      // (s_nop: two wait states behind the v_cmp that wrote x -- see gemmz.hip's z_writelane)
     return w;
 }
 

@@ -43,9 +43,12 @@ typedef float z_f32x16 __attribute__((ext_vector_type(16)));
 // accumulator row, one 32-lane store per 32 x 32 tile), the data gradient fetches one word per row and column tile (a wave
 // instruction per 64 x 32 tile instead of thirty-two) and selects by lane mask -- 1/32 of the mask bytes (the three data gradients
 // read 2.8 GB of masks per 32,768-image minibatch otherwise).
-// lane `l` of w := the wave-uniform value x (v_writelane_b32; hipcc 7.2 has no builtin for it)
+// lane `l` of w := the wave-uniform value x (v_writelane_b32; hipcc 7.2 has no builtin for it).  s_nop 1: on gfx940 / gfx950 a VALU
+// instruction that reads an SGPR needs two wait states behind the VALU instruction that wrote it (here: the v_cmp of the ballot), and
+// the compiler's hazard recognizer does not look inside inline asm -- round 5's f16 instantiations scheduled the compare directly in
+// front of the writelane and the mask words came out with bits of the PREVIOUS compare (tests/test_gpu_f16x2.py found it).
 __device__ __forceinline__ int z_writelane(int w, unsigned x, int l) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(x), "i"(l));
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(x), "i"(l));
     return w;
 }
 
@@ -58,7 +61,7 @@ enum { Z_BIAS_RELU = 0, Z_MASK = 1, Z_MASK_CLS4 = 2, Z_MASKB = 3, Z_MASKB_CLS4 =
 __device__ __forceinline__ float z_keep_where(float x, unsigned lo, unsigned hi) {
     const unsigned long long m = ((unsigned long long)hi << 32) | lo;
     float r;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));      // (s_nop: the mask comes from v_readlane -- see z_writelane)
     return r;
 }
 constexpr int kZPitch = 20;                           // floats per LDS row: 16 k + 4 pad (80 bytes)

@@ -73,7 +73,7 @@ def test_absmax_record_is_the_exact_maximum(n):
     r = _rec_of(x[:n])
     y = torch.full((7,), 1e30, device=DEV)
     cnn.absmax(y, r)
-    assert cnn.amax_value(r) == max(x[:n].abs().max().item(), 1e30)
+    assert cnn.amax_value(r) == max(x[:n].abs().max().item(), float(np.float32(1e30)))
     z = cnn.new_amax(1, DEV)[0]
     cnn.absmax(torch.zeros(9, device=DEV), z)
     assert cnn.amax_value(z) == 0.0
@@ -370,7 +370,7 @@ def test_nature_packs_f16x2_equal_the_per_matrix_route():
     for k in ref:
         assert torch.equal(got[k], ref[k]), k
     assert [cnn.amax_value(bufs.w_amax[i]) for i in range(3)] == [W2.abs().max().item(), W3.abs().max().item(), Wfc.abs().max().item()]
-    assert torch.equal(bufs.weights(W1, 1, cnn.MODE_FWD_Q), cnn.repack_weights(W1, 1, cnn.MODE_FWD_Q))
+    assert torch.equal(bufs.weights(W1, 1, cnn.MODE_FWD_Q).view(torch.uint8), cnn.repack_weights(W1, 1, cnn.MODE_FWD_Q).view(torch.uint8))
 
 
 def test_trunk_autograd_under_f16x2_against_float64():
@@ -399,5 +399,10 @@ def test_trunk_autograd_under_f16x2_against_float64():
     _close(logits, l64, "logits under f16x2")
     _close(value, v64, "value under f16x2")
     torch.autograd.backward([l64, v64], [gl.double(), gv.double()])
+    bad = []
     for n, p in ref_agent.named_parameters():
-        _close(got[n], p.grad, f"grad of {n} under f16x2", tol=5e-5)
+        scale = p.grad.abs().max().item()
+        err = (got[n].double() - p.grad).abs().max().item()
+        if not (np.isfinite(err) and err <= 5e-5 * scale):
+            bad.append(f"grad of {n}: err {err:.3e}, scale {scale:.3e}")
+    assert not bad, "; ".join(bad)
