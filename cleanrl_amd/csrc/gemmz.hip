@@ -171,6 +171,31 @@ __global__ __launch_bounds__(256) void zabsmax_kernel(ZAbsmax3 a, unsigned* __re
     amax_commit(rec + (size_t)MI355PPO_AMAX_WORDS * t, m, (unsigned)blockIdx.x * 4u + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
+// The same for the weight tensors of the NatureCNN packs WITHOUT atomics or a zeroed record: kAmaxSlots blocks per tensor, block b
+// STORES the maximum of its share into slot b (every slot is written: the record needs no memset in front -- a memset node inside a
+// captured update graph was the one launch of the pack sequence that a replay did not keep in order, tools/gpu/r5_graph_debug.py).
+__global__ __launch_bounds__(256) void zabsmax_store_kernel(ZAbsmax3 a, unsigned* __restrict__ rec) {
+    __shared__ unsigned wmax[4];
+    const int t = blockIdx.x / kAmaxSlots, b = blockIdx.x - t * kAmaxSlots;
+    const float* __restrict__ x = a.x[t];
+    const long long n = a.n[t];
+    unsigned m = 0u;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const long long n4 = n >> 2;
+        for (long long i = (long long)b * 256 + threadIdx.x; i < n4; i += (long long)kAmaxSlots * 256) {
+            const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+            m = max(m, max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+        }
+        for (long long i = (n4 << 2) + (long long)b * 256 + threadIdx.x; i < n; i += (long long)kAmaxSlots * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    } else {
+        for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += (long long)kAmaxSlots * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    }
+    const unsigned w = wave_umax(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) rec[(size_t)MI355PPO_AMAX_WORDS * t + b * kAmaxStride] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+}
+
 // Every weight pack of the NatureCNN agent in ONE launch, straight from the parameters as torch stores them (round 4).  After an
 // optimizer step the learner used to issue, per minibatch: conv_repack_kernel x 4 and two torch copies (the (h, w, c) reorder of
 // Linear(3136,512).weight and its transpose) to build the f32 matrices, zpack_kernel x 6 over them, and kernel Q's digit pack -- 13
@@ -1095,18 +1120,13 @@ static int nature_packs_impl(const char* fn, const float* W1, const float* W2, c
         lds_set_dev = dev;
     }
     if (w_amax) {
-        // the weights' maxima first: zero the three records, one pass over W2 / W3 / Wfc (6.7 MB), then the packs under those scales
+        // the weights' maxima first -- one pass over W2 / W3 / Wfc (6.7 MB), every slot of the three records stored --, then the packs
         MI355_REQUIRE(W2 && W3 && Wfc, MI355PPO_EINVAL, "%s: the f16x2 packs need W2, W3 and Wfc", fn);
         MI355_REQUIRE(aligned(w_amax, 64), MI355PPO_EALIGN, "%s: the amax records must be 64-byte aligned", fn);
-        if (hipMemsetAsync(w_amax, 0, 3 * MI355PPO_AMAX_WORDS * sizeof(unsigned), as_stream(stream)) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("%s: hipMemsetAsync of the amax records failed", fn);
-            return MI355PPO_EHIP;
-        }
         ZAbsmax3 m;
         m.x[0] = W2; m.n[0] = 64 * 32 * 4 * 4; m.x[1] = W3; m.n[1] = 64 * 64 * 3 * 3; m.x[2] = Wfc; m.n[2] = 512 * 3136;
-        hipLaunchKernelGGL(zabsmax_kernel, dim3(3 * 64), dim3(256), 0, as_stream(stream), m, w_amax, 64);
-        int rc = check_launch("zabsmax_kernel");
+        hipLaunchKernelGGL(zabsmax_store_kernel, dim3(3 * kAmaxSlots), dim3(256), 0, as_stream(stream), m, w_amax);
+        int rc = check_launch("zabsmax_store_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL(znature_pack_kernel<1>, dim3(at), dim3(256), (fc_fwd || fc_dgrad) ? kLds : 0, as_stream(stream), a);
     } else {
@@ -1123,8 +1143,8 @@ extern "C" MI355PPO_API int mi355ppo_nature_packs_f32(const float* W1, const flo
 }
 
 // The same with the six kernel-Z packs in the f16x2 format (mi355ppo_fc_pack_f16x2_bytes of the same shapes) -- what the *_f16x2 entry
-// points take.  `w_amax`: 3 amax records (3 * MI355PPO_AMAX_WORDS uint32, 64-byte aligned) that receive max |W2|, |W3|, |Wfc| (zeroed and
-// filled here: a memset, one pass over the three tensors, the pack launch).
+// points take.  `w_amax`: 3 amax records (3 * MI355PPO_AMAX_WORDS uint32, 64-byte aligned) that receive max |W2|, |W3|, |Wfc| (every slot
+// stored here: one pass over the three tensors, then the pack launch).
 extern "C" MI355PPO_API int mi355ppo_nature_packs_f16x2_f32(const float* W1, const float* W2, const float* W3, const float* Wfc, void* qpack,
                                                             void* conv2_fwd, void* conv3_fwd, void* conv3_dgrad, void* conv2_dgrad, void* fc_fwd,
                                                             void* fc_dgrad, uint32_t* w_amax, void* stream) {

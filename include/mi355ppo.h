@@ -584,7 +584,7 @@ MI355PPO_API int mi355ppo_absmax_f32(const float* x, int64_t n, uint32_t* amax, 
 MI355PPO_API size_t mi355ppo_fc_pack_f16x2_bytes(int N, int K);
 MI355PPO_API int mi355ppo_fc_pack_f16x2_f32(const float* B, int ldb, int N, int K, const uint32_t* b_amax, void* pack, void* stream);
 /* mi355ppo_nature_packs_f32 with the six kernel-Z packs as f16x2 packs [mi355ppo_fc_pack_f16x2_bytes of the same shapes]; `w_amax` =
- * three records (3 * MI355PPO_AMAX_WORDS) that receive max |W2|, |W3|, |Wfc| -- zeroed and filled by this call. */
+ * three records (3 * MI355PPO_AMAX_WORDS) that receive max |W2|, |W3|, |Wfc| -- every slot written by this call (no zeroing needed). */
 MI355PPO_API int mi355ppo_nature_packs_f16x2_f32(const float* W1, const float* W2, const float* W3, const float* Wfc, void* qpack,
                                                  void* conv2_fwd, void* conv3_fwd, void* conv3_dgrad, void* conv2_dgrad, void* fc_fwd,
                                                  void* fc_dgrad, uint32_t* w_amax, void* stream);
