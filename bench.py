@@ -398,7 +398,7 @@ def main():
             timed_op("conv_dgrad", lambda dz, Bt, act_in, layer, out=None, variant=0: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), "F"))
             timed_op("conv_wgrad", k_wgrad)
             # (amax: the two-term f16 split of round 5 -- the same kernels, letter + "h")
-            h = lambda letter, amax: letter + "h" if amax is not None else letter
+            h = lambda letter, amax: letter + "h" if amax is not None and letter in ("Z", "W", "V") else letter      # (kernels Y / T ignore the records)
             timed_op("conv1q_fwd_bits", lambda obs, pack, bias, inds, out, bits: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))
             timed_op("conv1q_fwd_amax", lambda obs, pack, bias, inds, out, bits, dst_amax: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))
             timed_op("conv_fwd_packed", lambda src, pack, bias, layer, out=None, bits=None, amax=None: (f"conv{layer}_fwd@{src.shape[0]}", conv_flop(layer, src.shape[0]), h("Z", amax)))
