@@ -65,8 +65,12 @@ constexpr VItem v_item(int t, int nf, int ppf) {
 
 // SPLIT: 0 = three bf16 terms, NP = 6 / 9 pairs; 1 = two f16 terms under the operands' power-of-two scales (amax records of dz and
 // src), NP = 3 pairs, the partial dW un-scaled on its way out (f16split.h).  The bias gradient sums the dz fragments as read (f32).
-template <class G, int NT, int NP, int SPLIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convw_bf16_kernel(
+// OCCV: waves per SIMD the kernel is compiled for.  1: NT = 4 / 3 tiles per wave (128 / 96 accumulator registers, round 3).  2 (SPLIT = 1
+// only): NT = 2 -- 64 accumulators, two waves per SIMD from two workgroups per CU: with half the matrix instructions per k-step the single
+// wave per SIMD was bound by its own instruction issue (profiles/r05_pmc_busy.csv: instruction-active 0.51 of the wave's time, matrix pipe
+// 0.28 busy), and a second wave's VALU / LDS work fills the first one's matrix-pipe time.
+template <class G, int NT, int NP, int SPLIT, int OCCV = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCCV, OCCV))) void convw_bf16_kernel(
     const float* __restrict__ src, const float* __restrict__ dz, float* __restrict__ part_w, float* __restrict__ part_b, int images,
     int nslabs, unsigned m8, unsigned m16, int xcd_order, const unsigned* __restrict__ dz_amax, const unsigned* __restrict__ src_amax) {
     constexpr int MT = 2, NF = MT + NT, NGROUPS = G::TILES / NT, NL = 4 + 2 * NT;       // fragments; wave groups; loads per block
@@ -319,7 +323,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-static int convw_slabs(int layer) { return layer == 2 ? 256 : 170; }      // x 4 / x 6 wave groups = 1,024 / 1,020 waves
+// f16 split: two tiles per wave, two waves per SIMD -- 8 / 9 wave groups: layer 3 740 -> 606 us, layer 2 872 -> 850 us at 32,768 images, layer 2
+// bit-identical (same slabs), profiles/r05_tile_shape_experiments.txt.  MI355PPO_V_NT2=0: round 3's one-wave shapes (A/B runs).
+static bool convw_nt2() {
+    static const bool on = [] { const char* e = getenv("MI355PPO_V_NT2"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static int convw_slabs(int layer, bool nt2 = false) {      // x 4 / x 6 wave groups = 1,024 / 1,020 waves (nt2: x 8 / x 9 = 2,048 / 2,043)
+    if (nt2) return layer == 2 ? 256 : 227;
+    return layer == 2 ? 256 : 170;
+}
 
 // Kernel V takes a batch of layer 2 / 3 that is a multiple of 16 images, large enough for every slab to have work, with
 // tensors inside the 32-bit buffer range (MI355PPO_CONV_WGRAD=t: never -- kernel T, for A/B runs).
@@ -327,7 +340,7 @@ bool convw_applies(int64_t images, int layer) {
     static const bool force_t = [] { const char* e = getenv("MI355PPO_CONV_WGRAD"); return e && e[0] == 't'; }();
     if (force_t || (layer != 2 && layer != 3) || images <= 0) return false;
     const long long P = images * (layer == 2 ? 81 : 49);
-    return images % 16 == 0 && P / 16 >= 4LL * convw_slabs(layer) &&
+    return images % 16 == 0 && P / 16 >= 4LL * convw_slabs(layer, convw_nt2()) &&
            images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4 < (1LL << 32) - 8192 && P * 64 * 4 < (1LL << 32) - 8192;
 }
 
@@ -336,19 +349,22 @@ bool convw_applies(int64_t images, int layer) {
 int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
                  const unsigned* dz_amax, const unsigned* src_amax) {
     if (!convw_applies(images, layer)) return 1;
-    const int S = convw_slabs(layer);
+    const bool nt2 = dz_amax && convw_nt2();
+    const int S = convw_slabs(layer, nt2);
     *nparts = S;
     const int np = bf16_term_pairs();
     const int xcd = 1;      // XCD-contiguous unit order: L2-miss reads 3.20 -> 2.38 GB (layer 2), 2.07 -> 1.12 GB (layer 3), times -0 .. 1.5 %
                             // (same-box A/B with a run-time switch, profiles/r03_raster_ab.jsonl, r03_pmc_fetch_raster_{before,after}.csv)
     if (layer == 2) {
         const int grid = (S * (VGeom2::TILES / 4) + 3) / 4;
-        if (dz_amax) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 3, 1>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
+        if (nt2) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 2, 3, 1, 2>), dim3((S * (VGeom2::TILES / 2) + 3) / 4), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
+        else if (dz_amax) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 3, 1>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
         else if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 9, 0>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
         else hipLaunchKernelGGL((convw_bf16_kernel<VGeom2, 4, 6, 0>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
     } else {
         const int grid = (S * (VGeom3::TILES / 3) + 3) / 4;
-        if (dz_amax) hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 3, 1>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
+        if (nt2) hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 2, 3, 1, 2>), dim3((S * (VGeom3::TILES / 2) + 3) / 4), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
+        else if (dz_amax) hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 3, 1>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
         else if (np == 9) hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 9, 0>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
         else hipLaunchKernelGGL((convw_bf16_kernel<VGeom3, 3, 6, 0>), dim3(grid), dim3(256), 0, s, src, dz, part_w, part_b, (int)images, S, 0xffff0000u, 0xffffff00u, xcd, dz_amax, src_amax);
     }

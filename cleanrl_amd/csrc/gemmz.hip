@@ -174,26 +174,29 @@ __global__ __launch_bounds__(256) void zabsmax_kernel(ZAbsmax3 a, unsigned* __re
 // The same for the weight tensors of the NatureCNN packs WITHOUT atomics or a zeroed record: kAmaxSlots blocks per tensor, block b
 // STORES the maximum of its share into slot b (every slot is written: the record needs no memset in front -- a memset node inside a
 // captured update graph was the one launch of the pack sequence that a replay did not keep in order, tools/gpu/r5_graph_debug.py).
-__global__ __launch_bounds__(256) void zabsmax_store_kernel(ZAbsmax3 a, unsigned* __restrict__ rec) {
-    __shared__ unsigned wmax[4];
+__global__ __launch_bounds__(1024) void zabsmax_store_kernel(ZAbsmax3 a, unsigned* __restrict__ rec) {
+    __shared__ unsigned wmax[16];
     const int t = blockIdx.x / kAmaxSlots, b = blockIdx.x - t * kAmaxSlots;
     const float* __restrict__ x = a.x[t];
     const long long n = a.n[t];
     unsigned m = 0u;
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const long long n4 = n >> 2;
-        for (long long i = (long long)b * 256 + threadIdx.x; i < n4; i += (long long)kAmaxSlots * 256) {
+        for (long long i = (long long)b * 1024 + threadIdx.x; i < n4; i += (long long)kAmaxSlots * 1024) {
             const uint4 v = reinterpret_cast<const uint4*>(x)[i];
             m = max(m, max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
         }
-        for (long long i = (n4 << 2) + (long long)b * 256 + threadIdx.x; i < n; i += (long long)kAmaxSlots * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+        for (long long i = (n4 << 2) + (long long)b * 1024 + threadIdx.x; i < n; i += (long long)kAmaxSlots * 1024) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
     } else {
-        for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += (long long)kAmaxSlots * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+        for (long long i = (long long)b * 1024 + threadIdx.x; i < n; i += (long long)kAmaxSlots * 1024) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
     }
     const unsigned w = wave_umax(m);
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) rec[(size_t)MI355PPO_AMAX_WORDS * t + b * kAmaxStride] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (threadIdx.x < 64) {
+        const unsigned v = wave_umax(threadIdx.x < 16 ? wmax[threadIdx.x] : 0u);
+        if (threadIdx.x == 0) rec[(size_t)MI355PPO_AMAX_WORDS * t + b * kAmaxStride] = v;
+    }
 }
 
 // Every weight pack of the NatureCNN agent in ONE launch, straight from the parameters as torch stores them (round 4).  After an
@@ -449,6 +452,9 @@ struct ZArgs {
 //        1 = two f16 terms per operand under per-tensor power-of-two scales, NP = 3 (or 4) pairs on v_mfma_f32_32x32x16_f16
 //            (f16split.h): half the matrix instructions, 10 instead of 22 split instructions per four elements.  The pack is then
 //            [64-byte header][k-step][tile][hi, lo][64 lanes][8 f16], the accumulators are un-scaled in the epilogue.
+// (Measured and rejected for SPLIT = 1, each bit-identical: A's global loads issued TWO k-steps ahead of their LDS write -- layer-2 forward
+//  -25 us, the data gradients +15 us, bench +-0: profiles/r05_kernel_z_prefetch_two_steps_ab.jsonl; three waves per SIMD for the ring
+//  kernels (168 VGPRs, 17 - 26 spilled): 1.7 x slower, profiles/r05_tile_shape_experiments.txt.)
 template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int NP, int OCC, bool BLDS, int SPLIT>
 __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void z_kernel(ZArgs a) {
     constexpr int ROWS = 32 * MT, LOADS = ROWS / 16;
@@ -1125,7 +1131,7 @@ static int nature_packs_impl(const char* fn, const float* W1, const float* W2, c
         MI355_REQUIRE(aligned(w_amax, 64), MI355PPO_EALIGN, "%s: the amax records must be 64-byte aligned", fn);
         ZAbsmax3 m;
         m.x[0] = W2; m.n[0] = 64 * 32 * 4 * 4; m.x[1] = W3; m.n[1] = 64 * 64 * 3 * 3; m.x[2] = Wfc; m.n[2] = 512 * 3136;
-        hipLaunchKernelGGL(zabsmax_store_kernel, dim3(3 * kAmaxSlots), dim3(256), 0, as_stream(stream), m, w_amax);
+        hipLaunchKernelGGL(zabsmax_store_kernel, dim3(3 * kAmaxSlots), dim3(1024), 0, as_stream(stream), m, w_amax);
         int rc = check_launch("zabsmax_store_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL(znature_pack_kernel<1>, dim3(at), dim3(256), (fc_fwd || fc_dgrad) ? kLds : 0, as_stream(stream), a);
@@ -1211,6 +1217,8 @@ static int fc_fwd_impl(const char* fn, const float* a, int lda, const void* pack
     // 64 x 128 wave tiles, one wave per SIMD, for the large batches; below 16,384 rows those do not fill the chip (M / 64 workgroups):
     // 64 x 64 wave tiles, two 4-wave workgroups per CU (measured on one box, profiles/r03_zcfg_ab.jsonl: 32,768 rows 471 vs 531 us,
     // 8,192 rows 205 vs 145 us, 4,096 rows 182 vs 128 us)
+    // (round 5, f16 split: the two-wave shape at 32,768 rows again 428 vs 317 us, the data gradient 583 vs 477 us -- 535 with the B ring --,
+    //  bit-identical: profiles/r05_tile_shape_experiments.txt)
     if (M < 16384) return z_launch<ZRowsLinear, 2, 2, 4, Z_BIAS_RELU, true, 2>(za, as_stream(stream), fn);
     return z_launch<ZRowsLinear, 2, 4, 4, Z_BIAS_RELU, true>(za, as_stream(stream), fn);
 }
