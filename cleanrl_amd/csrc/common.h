@@ -23,6 +23,7 @@ int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz
                   hipStream_t s);
 // kernel V (convw.hip): layers 2 / 3 weight + bias gradient on the bf16 pipe; returns 1 when the batch does not qualify
 bool convw_applies(int64_t images, int layer);
+int convw_parts(int64_t images, int layer);
 int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
                  const unsigned* dz_amax = nullptr, const unsigned* src_amax = nullptr);      // amax records: the two-term f16 split (f16split.h)
 

@@ -1146,11 +1146,17 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_f32_variant(const float* dz,
 }
 
 static int wgrad_grid(int64_t images) { return images < 512 ? (int)images : 512; }
+// partial sums the workspace holds: the workgroups of kernels P / T, or kernel V's slabs where those are more (batches of 208 .. 240 images
+// at layer 2: 256 slabs -- round 5: sized for `images` partials before, kernel V's last slabs landed in the bias partials)
+static int wgrad_parts(int64_t images, int layer) {
+    const int g = wgrad_grid(images) * (layer == 1 ? 4 : 1), v = layer == 1 ? 0 : convw_parts(images, layer);
+    return g > v ? g : v;
+}
 
 extern "C" MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t images, int layer) {
     int Cin, Cout, KH, SS, Hin, Hout;
     if (images <= 0 || !layer_dims(layer, &Cin, &Cout, &KH, &SS, &Hin, &Hout)) return 0;
-    const size_t wparts = (size_t)wgrad_grid(images) * (layer == 1 ? 4 : 1);      // layer 1: one partial per wave
+    const size_t wparts = (size_t)wgrad_parts(images, layer);                       // layer 1: one partial per wave
     const size_t nchunks = (wparts + kRedChunk - 1) / kRedChunk;
     return ((wparts + nchunks) * (size_t)Cout * KH * KH * Cin + (wparts + nchunks) * Cout) * sizeof(float);
 }
@@ -1175,7 +1181,7 @@ static int conv_wgrad_impl(const char* fn, const void* src, const int64_t* inds,
     const int K = KH * KH * Cin;
     // Workspace layout (sized by mi355ppo_cnn_conv_wgrad_workspace_bytes for the kernel with the most partials):
     //   part_w [lparts][Cout*K] | part_b [lparts][Cout] | mid [ceil(lparts/32)][Cout*K] | mid_b [ceil(lparts/32)][Cout]
-    const int lparts = wgrad_grid(images) * (layer == 1 ? 4 : 1);
+    const int lparts = wgrad_parts(images, layer);
     const int total_w = Cout * K;
     float* part_w = static_cast<float*>(workspace);
     float* part_b = part_w + (size_t)lparts * total_w;

@@ -344,6 +344,9 @@ bool convw_applies(int64_t images, int layer) {
            images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4 < (1LL << 32) - 8192 && P * 64 * 4 < (1LL << 32) - 8192;
 }
 
+// partials kernel V writes for this batch (0: it does not take it) -- the workspace of mi355ppo_cnn_conv_wgrad_* must hold that many
+int convw_parts(int64_t images, int layer) { return convw_applies(images, layer) ? convw_slabs(layer, convw_nt2()) : 0; }
+
 // Launches kernel V if the batch qualifies; *nparts = partials written (part_w [nparts][64 * K], part_b [nparts][64]).
 // Returns 1 if it does not apply.
 int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,

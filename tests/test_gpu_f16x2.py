@@ -192,7 +192,7 @@ def test_conv_data_gradient_f16x2_against_float64(layer, images):
     assert torch.equal(got2, got) and cnn.amax_value(rd2) == cnn.amax_value(rd)
 
 
-@pytest.mark.parametrize("layer,images", [(2, 256), (2, 2048), (3, 1024), (3, 2064)])
+@pytest.mark.parametrize("layer,images", [(2, 208), (2, 256), (2, 2048), (3, 304), (3, 1024), (3, 2064)])      # (208: fewer images than kernel V's 256 slabs)
 def test_conv_weight_gradient_f16x2_against_float64(layer, images):
     cin, cout, k, st, hin, hout = SPEC[layer]
     lib = cnn._lib.load()
@@ -203,6 +203,7 @@ def test_conv_weight_gradient_f16x2_against_float64(layer, images):
     ref = torch.nn.grad.conv2d_weight(src.double().permute(0, 3, 1, 2), (cout, cin, k, k), dz.double().permute(0, 3, 1, 2), stride=st)
     dW, db = cnn.conv_wgrad(src, dz, layer, amax=(_rec_of(src), _rec_of(dz)))
     dWb, dbb = cnn.conv_wgrad(src, dz, layer)                   # the three-term bf16 kernel on the same operands
+    _close(db, dz.double().sum((0, 1, 2)), f"conv{layer} bias gradient f16x2, {images} images", tol=2e-5)
     e_h = _close(dW, ref, f"conv{layer} wgrad f16x2, {images} images")
     e_b = _close(dWb, ref, f"conv{layer} wgrad bf16x3, {images} images")
     assert e_h <= max(4.0 * e_b, 2e-6), f"f16x2 {e_h:.2e} vs bf16x3 {e_b:.2e}"
