@@ -111,6 +111,7 @@ SIGNATURES = {
     "mi355ppo_cnn_conv_fwd_packed_f16x2_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
     "mi355ppo_cnn_conv_dgrad_packed_f16x2_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P]),
     "mi355ppo_cnn_conv_wgrad_f16x2_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_size_t, _P, _P, _P]),
+    "mi355ppo_cnn_conv1_wgrad_f16x2": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, c_size_t, _P, _P]),
     "mi355ppo_fc_fwd_relu_packed_f16x2_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
     "mi355ppo_fc_dgrad_packed_f16x2_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "mi355ppo_fc_wgrad_f16x2_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),

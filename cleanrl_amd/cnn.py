@@ -36,7 +36,7 @@ _SPLIT = os.environ.get("MI355PPO_SPLIT", "f16x2")
 if _SPLIT not in ("f16x2", "bf16x3"):
     raise ValueError(f"MI355PPO_SPLIT={_SPLIT!r}: expected f16x2 or bf16x3")
 AMAX_WORDS = 256                 # MI355PPO_AMAX_WORDS: uint32 words of an amax record (16 slots, 64 bytes apart)
-REC_A1, REC_A2, REC_A3, REC_DH, REC_DZ3, REC_DZ2, N_REC = 0, 1, 2, 3, 4, 5, 8     # the records of one forward / backward pass of the trunk
+REC_A1, REC_A2, REC_A3, REC_DH, REC_DZ3, REC_DZ2, REC_DZ1, N_REC = 0, 1, 2, 3, 4, 5, 6, 8     # the records of one forward / backward pass of the trunk
 
 
 def new_amax(n: int, device) -> torch.Tensor:
@@ -161,8 +161,13 @@ def conv_wgrad(src: torch.Tensor, dz: torch.Tensor, layer: int, inds: torch.Tens
         dW = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
         db = torch.empty(cout, dtype=torch.float32, device=dev)
     ws = _workspace(dev, lib.mi355ppo_cnn_conv_wgrad_workspace_bytes(images, layer))
+    if amax is not None and layer == 1:          # kernel P with dz in two f16 terms: ``amax = (None, dz_rec)`` (the uint8 frames are exact)
+        with _on(dev):
+            st = lib.mi355ppo_cnn_conv1_wgrad_f16x2(_ptr(src), _ptr(inds), _ptr(dz), _ptr(dW), _ptr(db), images, _ptr(ws), ws.numel(),
+                                                    _rec(amax[1], "dz_amax"), _stream(dev))
+        _lib.check(st, "mi355ppo_cnn_conv1_wgrad_f16x2")
+        return dW, db
     if amax is not None:
-        assert layer in (2, 3)
         with _on(dev):
             st = lib.mi355ppo_cnn_conv_wgrad_f16x2_f32(_ptr(src), _ptr(dz), _ptr(dW), _ptr(db), images, layer, _ptr(ws), ws.numel(),
                                                        _rec(amax[0], "src_amax"), _rec(amax[1], "dz_amax"), _stream(dev))
@@ -802,8 +807,9 @@ class NatureTrunkFn(torch.autograd.Function):
                               amax=(r3, bufs.owns(REC_DZ2, dz2)))
             r2 = bufs.rec_of(REC_DZ2, dz2)
             dW2, db2 = conv_wgrad(a1, dz2, 2, out=gout(2), amax=(bufs.rec_of(REC_A1, a1), r2))
-            conv_dgrad_packed(dz2, bufs.conv_zpack(W2, 2, MODE_DGRAD_S2), a1, 2, dz1, bits=bits[0] if bits else None, amax=(r2, None))
-            dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds, out=gout(1))          # kernel P (bf16 pipe, exact products): unchanged
+            conv_dgrad_packed(dz2, bufs.conv_zpack(W2, 2, MODE_DGRAD_S2), a1, 2, dz1, bits=bits[0] if bits else None,
+                              amax=(r2, bufs.owns(REC_DZ1, dz1)))
+            dW1, db1 = conv_wgrad(ctx.obs, dz1, 1, ctx.inds, out=gout(1), amax=(None, bufs.rec_of(REC_DZ1, dz1)))      # kernel P, dz in two f16 terms
             if direct:
                 return (None,) * 10
             return None, None, dW1, db1, dW2, db2, dW3, db3, None, None

@@ -18,9 +18,8 @@ namespace mi355ppo {
 void set_error(const char* fmt, ...);
 
 // kernel P (conv1p.hip): layer-1 weight gradient on the bf16 matrix pipe; one partial per wave (conv.hip reduces them)
-float conv1p_partial_scale();
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
-                  hipStream_t s);
+                  hipStream_t s, const unsigned* dz_amax, float* partial_scale);
 // kernel V (convw.hip): layers 2 / 3 weight + bias gradient on the bf16 pipe; returns 1 when the batch does not qualify
 bool convw_applies(int64_t images, int layer);
 int convw_parts(int64_t images, int layer);

@@ -1190,11 +1190,12 @@ static int conv_wgrad_impl(const char* fn, const void* src, const int64_t* inds,
     // Layer 1: kernel P (bf16 pipe, exact products, conv1p.hip).  Layers 2, 3: kernel V (bf16 pipe, convw.hip) for batches it
     // can cut into slabs, else kernel T (taps, f32 pipe; paired 8-byte loads on layer 2).
     hipStream_t s = as_stream(stream);
+    float pscale = 1.0f;                // kernel P: the factor its partial sums still carry
     int grid = wgrad_grid(images);      // workgroups launched
     int wparts = grid;                  // partials they write (weights and bias alike)
     if (layer == 1) {                   // kernel P: one partial per wave
         wparts = grid * 4;
-        const int rc = conv1p_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images, grid, s);
+        const int rc = conv1p_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images, grid, s, dz_amax, &pscale);
         if (rc) return rc;
     } else if (int vparts = 0; convw_launch(static_cast<const float*>(src), dz, part_w, part_b, images, layer, &vparts, s, dz_amax, src_amax) != 1) {
         wparts = vparts;                // kernel V (bf16 pipe, convw.hip) took it: one partial per slab (an error surfaces in check_launch below)
@@ -1215,7 +1216,7 @@ static int conv_wgrad_impl(const char* fn, const void* src, const int64_t* inds,
     rc = check_launch("conv_wgrad_reduce1");
     if (rc) return rc;
     hipLaunchKernelGGL(conv_wgrad_reduce2, dim3((total_w + 255) / 256), dim3(256), 0, s, mid, nchunks, mid_b, nchunks, Cout, Cin,
-                       KH, KH, layer == 1 ? kInv255 * conv1p_partial_scale() : 1.0f, dW, db);
+                       KH, KH, layer == 1 ? kInv255 * pscale : 1.0f, dW, db);
     return check_launch("conv_wgrad_reduce2");
 }
 
@@ -1231,7 +1232,17 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_f16x2_f32(const float* src, 
                                                               void* workspace, size_t workspace_bytes, const uint32_t* src_amax,
                                                               const uint32_t* dz_amax, void* stream) {
     const char* fn = "mi355ppo_cnn_conv_wgrad_f16x2_f32";
-    MI355_REQUIRE(layer == 2 || layer == 3, MI355PPO_EINVAL, "%s: layer=%d must be 2 or 3 (layer 1: kernel P, mi355ppo_cnn_conv_wgrad_f32)", fn, layer);
+    MI355_REQUIRE(layer == 2 || layer == 3, MI355PPO_EINVAL, "%s: layer=%d must be 2 or 3 (layer 1: mi355ppo_cnn_conv1_wgrad_f16x2)", fn, layer);
     MI355_REQUIRE(src_amax && dz_amax && aligned(src_amax, 64) && aligned(dz_amax, 64), MI355PPO_EINVAL, "%s: amax records missing or not 64-byte aligned", fn);
     return conv_wgrad_impl(fn, src, nullptr, dz, dW, db, images, layer, workspace, workspace_bytes, src_amax, dz_amax, stream);
+}
+
+// Layer 1 (kernel P) with dz in two f16 terms under its tensor's scale: the uint8 frames are exact f16 operands, only dz needs its amax record
+// (filled by mi355ppo_cnn_conv_dgrad_packed_f16x2_f32 of layer 2).  Same arguments as mi355ppo_cnn_conv_wgrad_f32 with layer = 1.
+extern "C" MI355PPO_API int mi355ppo_cnn_conv1_wgrad_f16x2(const void* src_u8, const int64_t* inds, const float* dz, float* dW, float* db,
+                                                           int64_t images, void* workspace, size_t workspace_bytes, const uint32_t* dz_amax,
+                                                           void* stream) {
+    const char* fn = "mi355ppo_cnn_conv1_wgrad_f16x2";
+    MI355_REQUIRE(dz_amax && aligned(dz_amax, 64), MI355PPO_EINVAL, "%s: dz's amax record missing or not 64-byte aligned", fn);
+    return conv_wgrad_impl(fn, src_u8, inds, dz, dW, db, images, 1, workspace, workspace_bytes, nullptr, dz_amax, stream);
 }

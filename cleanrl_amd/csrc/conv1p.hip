@@ -39,9 +39,15 @@
 // two (<= 8.8e-8 of the scale), with the same error against float64 (max 4.47e-7 both, mean 6.37e-8 vs 6.34e-8 of the scale; torch's own
 // f32 weight gradient: 1.9e-7; profiles/r04_kernel_p_zext_error.jsonl); db1 is bit-identical.  923 -> 833 us at 32,768 images, 310 -> 284 at
 // 8,192, 201 -> 188 at 4,096 (profiles/r04_kernel_p_zext_ab.txt).  MI355PPO_P_ZEXT=0: the conversion route (A/B runs).
+// Round 5 (F16): on the f16 pipe with dz in TWO f16 terms under its tensor's power-of-two scale (the amax record conv2's data gradient
+// fills; csrc/f16split.h) -- 16 instead of 24 matrix instructions per step, 24 instead of 44 split instructions per 8 values.  The frame
+// operand is the same zero-extended pattern: 0x00vv read as an f16 is v * 2^-24 (a subnormal for every byte; the f16 MFMA multiplies
+// subnormals exactly: tools/mfma_denorm.cpp, profiles/r05_mfma_denorm.json).  The accumulators hold s * 2^-24 x the sums; the wave removes
+// the factor (a power of two) when it stores its partial, so the reduction's factor is 1 / 255 alone.
 // Partials: one (32 x 256) matrix + 32 bias sums per wave, layout and fixed-order two-stage reduction of kernel R
 // (conv_wgrad_reduce1/2 in conv.hip) -- deterministic.
 #include "common.h"
+#include "f16split.h"
 
 #pragma clang fp contract(off)
 
@@ -72,16 +78,24 @@ __device__ __forceinline__ unsigned p_pack_hi16(float e1, float e0) { return p_p
 
 constexpr float kPZextDzScale = 0x1p80f, kPZextOutScale = 0x1p53f;      // 2^80 * 2^-133 = 2^-53
 
-template <bool ZEXT>
+// MODE 0: bf16, converted frame operand; 1: bf16, zero-extended (ZEXT); 2: f16 split of dz, zero-extended frame operand (F16)
+template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1p_wgrad_kernel(
     const unsigned char* __restrict__ src, const int64_t* __restrict__ inds, const float* __restrict__ dz,
     float* __restrict__ part_w,      // [grid * 4][32][256]
     float* __restrict__ part_b,      // [grid * 4][32]
-    int images) {
+    int images, const unsigned* __restrict__ dz_amax) {
+    constexpr bool ZEXT = MODE >= 1, F16 = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lh = lane >> 5;
+    float sdz = 1.0f, un = 1.0f;           // F16: dz's scale; the factor that takes s * 2^-24 off the partial
+    if constexpr (F16) {
+        const int ez = f16_scale_exp(amax_load(dz_amax, lane));
+        sdz = f16_pow2(ez);
+        un = f16_pow2(24 - ez);            // ez in [-100, 60]: 2^-36 .. 2^124
+    }
     unsigned char* const tt = p_smem + wave * kPSlabLds;
     const int kw = li >> 2, c = li & 3;
     const unsigned sh = (unsigned)(kw >> 2);                              // tap columns 4..7 read one q further
@@ -201,6 +215,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     float x0 = dz_slot(sc, std::integral_constant<int, j>{}), x1 = dz_slot(sc, std::integral_constant<int, j + 1>{});
                     bsum += x0;
                     bsum += x1;
+                    if constexpr (F16) {                                          // two f16 terms of s dz (f16split.h's steps for one pair)
+                        const s_f32x2 v = s_f32x2{x0, x1} * sdz;
+                        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, s_f16x2));
+                        const s_f32x2 r = {f16_resid_lo(v[0], h), f16_resid_hi(v[1], h)};
+                        a_hi[J] = h;
+                        a_lo[J] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, s_f16x2));
+                        a_mid[J] = 0u;
+                        return;
+                    }
                     if constexpr (ZEXT) {                                         // exact (a power of two; |dz| < 2^48)
                         x0 *= kPZextDzScale;
                         x1 *= kPZextDzScale;
@@ -252,12 +275,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     lds_row(2 * rp + 3, raw[(rp + 1) & 1][1]);
                 }
                 const p_bf16x8 b0 = operand(raw[rp & 1][0]), b1 = operand(raw[rp & 1][1]);
+                if constexpr (F16) {
+                    const s_f16x8 h0 = __builtin_bit_cast(s_f16x8, b0), h1 = __builtin_bit_cast(s_f16x8, b1);
+                    acc[2 * rp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, ah), h0, acc[2 * rp], 0, 0, 0);
+                    acc[2 * rp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, ah), h1, acc[2 * rp + 1], 0, 0, 0);
+                    acc[2 * rp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, al), h0, acc[2 * rp], 0, 0, 0);
+                    acc[2 * rp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, al), h1, acc[2 * rp + 1], 0, 0, 0);
+                } else {
                 acc[2 * rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, b0, acc[2 * rp], 0, 0, 0);
                 acc[2 * rp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, b1, acc[2 * rp + 1], 0, 0, 0);
                 acc[2 * rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, b0, acc[2 * rp], 0, 0, 0);
                 acc[2 * rp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, b1, acc[2 * rp + 1], 0, 0, 0);
                 acc[2 * rp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, b0, acc[2 * rp], 0, 0, 0);
                 acc[2 * rp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, b1, acc[2 * rp + 1], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);                        // one pair's conversions at a time (register pressure)
             }
         };
@@ -275,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) pw[(size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * 256 + r * 32 + li] = acc[r][e];
+        for (int e = 0; e < 16; ++e) pw[(size_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * 256 + r * 32 + li] = F16 ? acc[r][e] * un : acc[r][e];
     const float both = bsum + __shfl_xor(bsum, 32, 64);
     if (lh == 0) part_b[(size_t)(blockIdx.x * 4 + wave) * 32 + li] = both;
 }
@@ -285,26 +316,28 @@ static bool conv1p_zext() {
     return on;
 }
 
-// factor the reduction applies to kernel P's partial sums (beside 1 / 255): 2^53 with the zero-extended frame operand
-float conv1p_partial_scale() { return conv1p_zext() ? kPZextOutScale : 1.0f; }
-
+// Launches kernel P; *partial_scale = the factor (beside 1 / 255) the reduction applies to its partial sums: 2^53 with the zero-extended
+// bf16 frame operand, 1 otherwise.  dz_amax (dz's amax record): the f16 variant.
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
-                  hipStream_t s) {
+                  hipStream_t s, const unsigned* dz_amax, float* partial_scale) {
     // (one wave per SIMD -- 372 registers, no spill at all -- measured 1,135 us against 868 at 32,768 images: profiles/r03_kernel_p_pieces_ab.jsonl)
-    const bool zext = conv1p_zext();
-    const void* k = zext ? reinterpret_cast<const void*>(conv1p_wgrad_kernel<true>) : reinterpret_cast<const void*>(conv1p_wgrad_kernel<false>);
+    const int mode = dz_amax ? 2 : conv1p_zext() ? 1 : 0;
+    *partial_scale = mode == 1 ? kPZextOutScale : 1.0f;
     const size_t sm = 4 * (size_t)kPSlabLds;
     static bool attr_done = false;           // 48 KiB: within the default dynamic-LDS limit, but set it explicitly once
     if (!attr_done) {
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1p_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv1p_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv1p_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
             (void)hipGetLastError();
             set_error("conv1p_launch: hipFuncSetAttribute(%zu bytes of LDS) failed", sm);
             return MI355PPO_EHIP;
         }
         attr_done = true;
     }
-    if (zext) hipLaunchKernelGGL(conv1p_wgrad_kernel<true>, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, images);
-    else hipLaunchKernelGGL(conv1p_wgrad_kernel<false>, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, images);
+    if (mode == 2) hipLaunchKernelGGL(conv1p_wgrad_kernel<2>, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, images, dz_amax);
+    else if (mode == 1) hipLaunchKernelGGL(conv1p_wgrad_kernel<1>, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, images, dz_amax);
+    else hipLaunchKernelGGL(conv1p_wgrad_kernel<0>, dim3(grid), dim3(256), sm, s, src, inds, dz, part_w, part_b, images, dz_amax);
     return check_launch("conv1p_wgrad_kernel");
 }
 

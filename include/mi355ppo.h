@@ -602,6 +602,9 @@ MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(const float* dz, const
 MI355PPO_API int mi355ppo_cnn_conv_wgrad_f16x2_f32(const float* src, const float* dz, float* dW, float* db, int64_t images, int layer,
                                                    void* workspace, size_t workspace_bytes, const uint32_t* src_amax, const uint32_t* dz_amax,
                                                    void* stream);
+/* mi355ppo_cnn_conv_wgrad_f32 for layer 1 (kernel P) with dz in two f16 terms; the uint8 frames are exact f16 operands: only dz's record */
+MI355PPO_API int mi355ppo_cnn_conv1_wgrad_f16x2(const void* src_u8, const int64_t* inds, const float* dz, float* dW, float* db, int64_t images,
+                                                void* workspace, size_t workspace_bytes, const uint32_t* dz_amax, void* stream);
 /* mi355ppo_fc_fwd_relu_packed_ws_f32 (ws may be null / 0: whole-K wave tiles); the K-split route records no h_amax (pass null) */
 MI355PPO_API int mi355ppo_fc_fwd_relu_packed_f16x2_f32(const float* a, int lda, const void* pack, const float* bias, float* h, int M, int N,
                                                        int K, void* ws, size_t ws_bytes, const uint32_t* a_amax, uint32_t* h_amax, void* stream);

@@ -212,6 +212,25 @@ def test_conv_weight_gradient_f16x2_against_float64(layer, images):
     assert torch.equal(dW, cnn.conv_wgrad(src, dz, layer, amax=(_rec_of(src), _rec_of(dz)))[0])
 
 
+@pytest.mark.parametrize("images,scale", [(8, 1.0), (300, 1e-6), (4096, 3e-4)])
+def test_conv1_weight_gradient_f16x2_against_float64(images, scale):
+    """Kernel P with dz in two f16 terms (the uint8 frames enter the f16 pipe by zero-extension: exact) against float64 and against the
+    three-term bf16 variant, through a row gather; the bias gradient is bit-equal (it sums the f32 values as loaded)."""
+    g = torch.Generator(device=DEV).manual_seed(images)
+    obs = torch.randint(0, 256, (images + 5, 84, 84, 4), dtype=torch.uint8, device=DEV, generator=g)
+    inds = torch.randperm(images + 5, device=DEV, generator=g)[:images]
+    dz = (torch.randn(images, 20, 20, 32, device=DEV, generator=g) * torch.exp2(-10 * torch.rand(images, 1, 1, 1, device=DEV, generator=g)) * scale
+          * (torch.rand(images, 20, 20, 32, device=DEV, generator=g) > 0.5))
+    x = obs[inds].double().permute(0, 3, 1, 2) / 255.0
+    ref = torch.nn.grad.conv2d_weight(x, (32, 4, 8, 8), dz.double().permute(0, 3, 1, 2), stride=4)
+    dW, db = cnn.conv_wgrad(obs, dz, 1, inds, amax=(None, _rec_of(dz)))
+    dWb, dbb = cnn.conv_wgrad(obs, dz, 1, inds)
+    e_h, e_b = _close(dW, ref, f"conv1 wgrad f16x2, {images} images"), _close(dWb, ref, f"conv1 wgrad bf16x3, {images} images")
+    assert e_h <= max(4.0 * e_b, 2e-6), f"f16x2 {e_h:.2e} vs bf16x3 {e_b:.2e}"
+    assert torch.equal(db, dbb)
+    assert torch.equal(dW, cnn.conv_wgrad(obs, dz, 1, inds, amax=(None, _rec_of(dz)))[0])
+
+
 @pytest.mark.parametrize("M", [1024, 4096])
 def test_fc_weight_gradient_f16x2_against_float64(M):
     lib = cnn._lib.load()
@@ -339,7 +358,8 @@ def test_f16x2_at_the_full_minibatch_size_against_float64_on_the_device():
     del x, ref
     # conv2 gradients
     dz1 = torch.empty((M, 20, 20, 32), device=DEV)
-    cnn.conv_dgrad_packed(dz2, cnn.conv_zpack_f16x2(W2, 2, cnn.MODE_DGRAD_S2), None, 2, dz1, bits=mb1, amax=(rec[cnn.REC_DZ2], None))
+    cnn.conv_dgrad_packed(dz2, cnn.conv_zpack_f16x2(W2, 2, cnn.MODE_DGRAD_S2), None, 2, dz1, bits=mb1, amax=(rec[cnn.REC_DZ2], rec[cnn.REC_DZ1]))
+    assert cnn.amax_value(rec[cnn.REC_DZ1]) == dz1.abs().max().item()
     x = a1[sl].double().requires_grad_(True)
     _conv64(x, W2.double(), None, 2).backward(dz2[sl].double())
     _close(dz1[sl], x.grad * (a1[sl] > 0), "conv2 dgrad f16x2 at 32768")

@@ -108,7 +108,7 @@ int main(int argc, char** argv) {
     ABI(mi355ppo_fc_pack_f32(bt2d, 256, 128, 256, pzd2, st)); ABI(mi355ppo_fc_pack_f32(bt3d, 576, 64, 576, pzd3, st));
     ABI(mi355ppo_fc_pack_f32(Wfc, 3136, 512, 3136, pk_fwd, st)); ABI(mi355ppo_fc_pack_f32(Wfct, 516, 3136, 512, pk_dg, st));
     // CONV_TRAFFIC_F16=1: the same launches on the two-term f16 split (round 5; csrc/f16split.h): f16x2 packs, amax records.  Records:
-    // 0 a1, 1 a2, 2 a3, 3 dz3, 4 dz2 (zeroed at the top of every repetition, filled by the producers' epilogues), 8 dzfc (an input
+    // 0 a1, 1 a2, 2 a3, 3 dz3, 4 dz2, 5 dz1 (zeroed at the top of every repetition, filled by the producers' epilogues), 8 dzfc (an input
     // here: mi355ppo_absmax_f32 once), 9 .. 14 the six weight matrices
     const bool f16 = getenv("CONV_TRAFFIC_F16") != nullptr;
     uint32_t* rec = dalloc<uint32_t>(16 * MI355PPO_AMAX_WORDS);
@@ -151,8 +151,8 @@ int main(int argc, char** argv) {
             TIMED(3, mi355ppo_cnn_conv_wgrad_f16x2_f32(a2, dz3, dW3, db3, M, 3, ws, wsb, R(1), R(3), st));
             TIMED(4, mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(dz3, hzd3, nullptr, mb2, dz2, M, 3, R(3), R(4), st));
             TIMED(5, mi355ppo_cnn_conv_wgrad_f16x2_f32(a1, dz2, dW2, db2, M, 2, ws, wsb, R(0), R(4), st));
-            TIMED(6, mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(dz2, hzd2, nullptr, mb1, dz1, M, 2, R(4), nullptr, st));
-            TIMED(7, mi355ppo_cnn_conv_wgrad_f32(obs, inds, dz1, dW1, db1, M, 1, ws, wsb, st));
+            TIMED(6, mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(dz2, hzd2, nullptr, mb1, dz1, M, 2, R(4), R(5), st));
+            TIMED(7, mi355ppo_cnn_conv1_wgrad_f16x2(obs, inds, dz1, dW1, db1, M, ws, wsb, R(5), st));
         } else {
         if (conv_z && bits) {
             TIMED(0, mi355ppo_cnn_conv1q_fwd_bits(obs, inds, bt1q, bias, a1, mb1, M, st));                          // kernel Q (+ a1's mask bits)
