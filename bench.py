@@ -628,6 +628,17 @@ def main():
                 out["cpu_baseline"]["reference_lines_at_metric_config"] = {
                     "value": r["env_steps_per_s"], "unit": "env-steps/s", "cores": r["cores"], "kind": "reference",
                     "sample": r["what"] + "; " + r["host"] + f"; {r['env_steps']} env-steps in {r['iteration_s']} s; " + r["note"]}
+            # flat fields (a parser that keeps one level): both baselines at the METRIC's configuration (num_envs = 1024), timed on one
+            # host -- the build container, where /root/reference exists -- so that they are comparable with each other
+            # (profiles/r05_cpu_port_vs_reference_lines.json); `value` above stays the live measurement on this box's cores
+            cpath = os.path.join(ROOT, "profiles", "r05_cpu_port_vs_reference_lines.json")
+            if os.path.exists(cpath):
+                c = json.load(open(cpath))
+                out["cpu_baseline"].update({
+                    "at_metric_config_reference_value": c["reference_lines"]["env_steps_per_s"], "at_metric_config_reference_kind": "reference",
+                    "at_metric_config_port_value": c["port"]["env_steps_per_s"], "at_metric_config_port_kind": "port",
+                    "at_metric_config_cores": c["port"]["cores"], "at_metric_config_unit": "env-steps/s",
+                    "at_metric_config_sample": c["what"] + "; " + c["host"] + "; committed measurement, not taken on this box"})
         if world == 1 and not cli.no_pcie_inclusive:
             # never `value`: the same learner fed by HOST envs (numpy stand-ins on host threads), actions D2H and frames H2D
             # every step as in the reference's loop (:269-272), through the overlapped env-group lanes (cleanrl_amd/pipeline.py)

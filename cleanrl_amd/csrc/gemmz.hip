@@ -895,8 +895,8 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
     // patterns of |C| for C's amax record -- of every value the wave computed: rows / columns past the edge are re-reads of real rows
     // and columns (their stores are dropped), so they cannot exceed the tensor's maximum.
     auto fin = [&](float x) -> float { if constexpr (SPLIT) return x * un; else return x; };
-    unsigned cmax = 0u;
-    auto seen = [&](float v) { if constexpr (SPLIT && EPI != Z_RAW) { const unsigned b = __float_as_uint(v) & 0x7fffffffu; cmax = b > cmax ? b : cmax; } };
+    float cmax = 0.0f;                                    // (one v_max_f32 with the |x| source modifier per value; a NaN is not recorded)
+    auto seen = [&](float v) { if constexpr (SPLIT && EPI != Z_RAW) cmax = __builtin_fmaxf(cmax, __builtin_fabsf(v)); };
     if constexpr (kMaskBits) {
         // lane L holds the mask word of row m0 + L for each of the wave's column tiles: C's element (row, column n) is bit n % 32 of
         // word (byte offset of the element) / 128 -- every 32-column tile of a row starts on a 128-byte boundary of C
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(OCC
         }
     }
     if constexpr (SPLIT && EPI != Z_RAW)
-        if (a.c_amax) amax_commit(a.c_amax, cmax, blockIdx.x + 3u * blockIdx.y + (unsigned)wave, lane);      // (wave-uniform condition)
+        if (a.c_amax) amax_commit(a.c_amax, __float_as_uint(cmax), blockIdx.x + 3u * blockIdx.y + (unsigned)wave, lane);      // (wave-uniform condition)
 }
 
 template <class RG, int MT, int NT, int NWAVES, int EPI, bool WAVES_N, int OCC = NWAVES / 4, bool BLDS = false>
