@@ -548,8 +548,9 @@ class _Buffers:
         self.w_amax = None
 
     def f16(self, t: torch.Tensor) -> bool:
-        """Kernels Z / V / W take the f16 split for this tensor's pass (device tensors; the CPU stand-ins of the tests keep the bf16 names)."""
-        return self.split == "f16x2" and _CONV_Z and t.is_cuda
+        """Kernels Z / V / W take the f16 split for this tensor's pass (device tensors; the CPU stand-ins of the tests keep the bf16 names
+        unless they set ``f16_on_cpu`` and stand in for the amax-aware entry points too)."""
+        return self.split == "f16x2" and _CONV_Z and (t.is_cuda or getattr(self, "f16_on_cpu", False))
 
     @staticmethod
     def _amax_key(m: int, dev):
@@ -587,7 +588,7 @@ class _Buffers:
         owners = self._owners[key]
         if owners.get(idx) != t.data_ptr():
             rec[idx].zero_()
-            absmax(t if t.is_contiguous() else t.contiguous(), rec[idx])
+            absmax(t if t.is_contiguous() else t.contiguous(), rec[idx])      # (module attribute at call time: the tests' stand-in)
             owners[idx] = t.data_ptr()
         return rec[idx]
 

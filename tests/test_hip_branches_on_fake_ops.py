@@ -524,8 +524,13 @@ class FakeCnn:
             return gi.contiguous()
         return _chk(out, torch.float32, "out", tuple(gi.shape)).copy_(gi)
 
-    def conv_wgrad(self, src, dz, layer, inds=None, out=None):
+    def conv_wgrad(self, src, dz, layer, inds=None, out=None, amax=None):
         from cleanrl_amd import cnn
+
+        if amax is not None:                       # (src record, dz record); layer 1: (None, dz record) -- the uint8 frames are exact
+            if amax[0] is not None:
+                self._holds(amax[0], src, f"conv{layer} weight gradient's input")
+            self._holds(amax[1], dz, f"conv{layer} weight gradient's dz")
 
         cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
         _chk(dz, torch.float32, "dz", (dz.shape[0], hout, hout, cout))
@@ -574,8 +579,11 @@ class FakeCnn:
         self._write_bits(bits, y)
         return y
 
-    def conv_fwd_packed(self, src, pack, bias, layer, out=None, bits=None):
+    def conv_fwd_packed(self, src, pack, bias, layer, out=None, bits=None, amax=None):
         from cleanrl_amd import cnn
+
+        if amax is not None:
+            return self.conv_fwd_packed_h(src, pack, bias, layer, out, bits, amax)
 
         cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
         W = self._zw(pack, layer, (0,))
@@ -586,8 +594,11 @@ class FakeCnn:
             self._write_bits(bits, y)
         return y
 
-    def conv_dgrad_packed(self, dz, pack, act_in, layer, out=None, bits=None):
+    def conv_dgrad_packed(self, dz, pack, act_in, layer, out=None, bits=None, amax=None):
         from cleanrl_amd import cnn
+
+        if amax is not None:
+            return self.conv_dgrad_packed_h(dz, pack, act_in, layer, out, bits, amax)
 
         cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
         W = self._zw(pack, layer, (1,) if layer == 3 else (2,))
@@ -601,6 +612,84 @@ class FakeCnn:
             mask = act_in > 0
         gi = torch.nn.functional.conv_transpose2d(dz.permute(0, 3, 1, 2), W, stride=s).permute(0, 2, 3, 1) * mask
         return gi.contiguous() if out is None else _chk(out, torch.float32, "out", tuple(gi.shape)).copy_(gi)
+
+    # ---- round 5: the amax-aware entry points of the two-term f16 split.  A stand-in PRODUCER writes the exact maximum of what it stored
+    # into the record it was handed; a stand-in CONSUMER asserts that the record it was handed holds the exact maximum of the tensor it is
+    # about to split -- so a stale, missing or mis-assigned record (cnn._Buffers.begin_pass / owns / rec_of) fails here, on the CPU.
+    @staticmethod
+    def _put(rec, t):
+        from cleanrl_amd import cnn
+
+        _chk(rec, torch.int32, "amax record", (cnn.AMAX_WORDS,))
+        rec.zero_()
+        rec[0] = torch.tensor(float(t.abs().max()), dtype=torch.float32).view(torch.int32)
+        FakeCnn.recs_written = getattr(FakeCnn, "recs_written", 0) + 1
+
+    @staticmethod
+    def _holds(rec, t, what):
+        from cleanrl_amd import cnn
+
+        got, want = cnn.amax_value(rec), float(t.abs().max())
+        assert got == want, f"{what}: the record says {got!r}, the tensor's maximum is {want!r}"
+        FakeCnn.recs_checked = getattr(FakeCnn, "recs_checked", 0) + 1
+
+    def absmax(self, x, rec):
+        cur = torch.tensor(float(x.abs().max()), dtype=torch.float32)
+        old = rec[:1].view(torch.float32)
+        rec[0] = torch.maximum(cur, old[0]).view(torch.int32)
+        FakeCnn.absmax_calls = getattr(FakeCnn, "absmax_calls", 0) + 1
+        return rec
+
+    def fc_pack_f16x2(self, B, b_amax=None, out=None):
+        out = self.fc_pack(B, out)
+        tag = self.reg[out.data_ptr()]
+        self.reg[out.data_ptr()] = ("zpack_h",) + tuple(tag[1:])
+        return out
+
+    def _zwh(self, pack, layer, modes):
+        tag, W, l, m = self.reg[pack.data_ptr()]
+        assert tag == "zpack_h" and l == layer and m in modes, (tag, l, m, layer, modes)      # an f16x2 entry point needs an f16x2 pack
+        return W
+
+    def conv1q_fwd_amax(self, obs_u8, pack, bias, inds, out, bits, dst_amax):
+        from cleanrl_amd import cnn
+
+        y = self.conv_fwd(obs_u8, pack, bias, 1, inds, out, variant=cnn.VARIANT_Q)
+        if bits is not None:
+            self._write_bits(bits, y)
+        self._put(dst_amax, y)
+        return y
+
+    def conv_fwd_packed_h(self, src, pack, bias, layer, out, bits, amax):
+        from cleanrl_amd import cnn
+
+        cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
+        W = self._zwh(pack, layer, (0,))
+        self._holds(amax[0], src, f"conv{layer} forward's input")
+        y = torch.relu(torch.nn.functional.conv2d(src.permute(0, 3, 1, 2), W, bias, stride=s)).permute(0, 2, 3, 1)
+        y = y.contiguous() if out is None else _chk(out, torch.float32, "out", tuple(y.shape)).copy_(y)
+        if bits is not None:
+            self._write_bits(bits, y)
+        if amax[1] is not None:
+            self._put(amax[1], y)
+        return y
+
+    def conv_dgrad_packed_h(self, dz, pack, act_in, layer, out, bits, amax):
+        from cleanrl_amd import cnn
+
+        cin, cout, k, s, hin, hout = cnn.LAYERS[layer]
+        W = self._zwh(pack, layer, (1,) if layer == 3 else (2,))
+        self._holds(amax[0], dz, f"conv{layer} data gradient's dz")
+        if bits is not None:
+            mask = cnn.unpack_mask_bits(bits, (dz.shape[0], hin, hin, cin))
+            FakeCnn.bits_read = getattr(FakeCnn, "bits_read", 0) + 1
+        else:
+            mask = act_in > 0
+        gi = torch.nn.functional.conv_transpose2d(dz.permute(0, 3, 1, 2), W, stride=s).permute(0, 2, 3, 1) * mask
+        gi = gi.contiguous() if out is None else _chk(out, torch.float32, "out", tuple(gi.shape)).copy_(gi)
+        if amax[1] is not None:
+            self._put(amax[1], gi)
+        return gi
 
     def trunk_fwd(self, obs_u8, inds, bt1, b1, bt2, b2, bt3, b3, a1, a2, a3, conv1_variant=0):
         self.conv_fwd(obs_u8, bt1, b1, 1, inds, a1, variant=conv1_variant)
@@ -648,6 +737,41 @@ def test_fused_cnn_branch_and_weight_matrix_cache(monkeypatch):
     with torch.no_grad():
         logits_b, _ = fake.agent.heads(fake.obs[0].float().permute(0, 3, 1, 2) / 255.0)
     assert torch.allclose(logits_a, logits_b, atol=1e-5)
+
+
+def test_fused_cnn_branch_on_the_f16_split_record_protocol(monkeypatch):
+    """Round 5: the same rollout + 2 x 2 minibatch updates with the trunk on the two-term f16 split (``cnn._Buffers.f16``): every amax record a
+    consumer is handed must hold the exact maximum of the tensor it describes (the stand-ins assert it), whichever kernel -- or the
+    ``rec_of`` fallback, here for dz3, which comes from torch's threshold_backward -- produced it; results equal the host path's."""
+    from cleanrl_amd import cnn
+    from cleanrl_amd.agents import AtariAgent
+
+    fk = FakeCnn()
+    for name in ("repack_weights", "conv_fwd", "conv_dgrad", "conv_wgrad", "trunk_fwd", "fc_pack", "fc_pack_f16x2", "conv_fwd_packed", "conv_dgrad_packed",
+                 "conv1q_fwd_bits", "conv1q_fwd_amax", "absmax"):
+        monkeypatch.setattr(cnn, name, getattr(fk, name))
+    FakeCnn.bits_written = FakeCnn.bits_read = FakeCnn.recs_written = FakeCnn.recs_checked = FakeCnn.absmax_calls = 0
+    monkeypatch.setattr(cnn, "heads_supported", lambda actor, critic: False)
+    T, N = 4, 4
+    rs = np.random.RandomState(17)
+    dones, rewards = _episode_streams(rs, T, N)
+    envs = SimpleNamespace(single_observation_space=E.Box(0, 255, (4, 84, 84), np.uint8), single_action_space=E.Discrete(4))
+    args = lambda: default_args(num_steps=T, num_minibatches=2, update_epochs=2)
+    host, fake = _pair(lambda: AtariAgent(envs),
+                       lambda ag: PPOLearner(ag, args(), envs.single_observation_space, envs.single_action_space, N, torch.device("cpu")))
+    fake.fused_cnn = True
+    fake._x_roll = None
+    fake.agent._trunk = cnn.NatureTrunk()
+    fake.agent._trunk.bufs.split = "f16x2"
+    fake.agent._trunk.bufs.f16_on_cpu = True
+    _compare_rollout_and_update(host, fake, _frames(rs, T, N, (4, 84, 84)), dones, rewards, [host.agent], [fake.agent])
+    # per forward 3 records written; per update pass the two data gradients write 2 more; consumers: 2 per forward (conv2, conv3), and per
+    # backward: wgrad3 (2), dgrad3 (1), wgrad2 (2), dgrad2 (1), wgrad1 (1) = 7
+    n_fwd, n_upd = (T + 1) + 4, 4
+    assert FakeCnn.recs_written == 3 * n_fwd + 2 * n_upd, FakeCnn.recs_written
+    assert FakeCnn.recs_checked == 2 * n_fwd + 7 * n_upd, FakeCnn.recs_checked
+    assert FakeCnn.absmax_calls == n_upd                # dz3 of every update: the one tensor no kernel of this path produced
+    assert FakeCnn.bits_written == 3 * 4 and FakeCnn.bits_read == 2 * 4
 
 
 def test_ragged_tail_minibatch_on_the_hip_branch():
