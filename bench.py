@@ -45,35 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")   # conv stack runs channels-last (see learner.py)
 
-
-def _seed_miopen_find_db():
-    """MIOpen (the conv library behind torch's Conv2d -- plumbing, not the product) benchmarks every solver
-    for every new conv shape on a fresh box: ~3 minutes for this workload.  We ship the find-db entries that
-    search produced on an MI355X (cleanrl_amd/miopen_db/*.ufdb.txt, plain text) and point MIOpen at a writable
-    copy, so it goes straight to the tuned kernels.  A miss (other shapes / MIOpen version) falls back to the
-    normal search."""
-    if "MIOPEN_USER_DB_PATH" in os.environ:
-        return
-    import glob
-    import shutil
-    import tempfile
-
-    src = os.path.join(ROOT, "cleanrl_amd", "miopen_db")
-    files = glob.glob(os.path.join(src, "*.ufdb.txt"))
-    if not files:
-        return
-    dst = os.path.join(tempfile.gettempdir(), f"mi355ppo_miopen_db_{os.getuid()}_{os.environ.get('LOCAL_RANK', '0')}")
-    os.makedirs(dst, exist_ok=True)
-    for f in files:
-        t = os.path.join(dst, os.path.basename(f))
-        if not os.path.exists(t):
-            shutil.copy(f, t)
-    os.environ["MIOPEN_USER_DB_PATH"] = dst
-
-
-_seed_miopen_find_db()
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
