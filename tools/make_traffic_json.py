@@ -1,4 +1,5 @@
-"""profiles/traffic.json from the HBM-traffic PMC passes of tools/gpu/r4_final.sh (profiles/r04_pmc_{fetch,write}.csv; round 3: r03_pmc_*, tools/gpu/r3_final2.sh).
+"""profiles/traffic.json from the HBM-traffic PMC passes of tools/gpu/r5_final.sh (profiles/r05_pmc_{fetch,write}.csv: the f16x2 kernel set; round 4:
+r04_pmc_*, tools/gpu/r4_final.sh; round 3: r03_pmc_*).
 
 HBM bytes per launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB: on gfx950 FETCH_SIZE tallies 128-byte read requests at
 64 bytes (MI355X_MICROARCH.md "HBM"; confirmed here by the calibration copies of the same passes: a 1 GiB read reports
@@ -11,8 +12,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 IMAGES = 32768
-# the newest passes over the committed kernel set (tools/gpu/r4_final.sh)
-FETCH_CSV, WRITE_CSV = "r04_pmc_fetch.csv", "r04_pmc_write.csv"
+# the newest passes over the committed kernel set (tools/gpu/r5_final.sh; CONV_TRAFFIC_F16=1: the default split)
+FETCH_CSV, WRITE_CSV = "r05_pmc_fetch.csv", "r05_pmc_write.csv"
 KEYS = {   # bench key -> (kernel-name substring, geometry substring) in rocpd_pmc.py's (truncated) kernel names
     "conv1_fwd": ("conv1q_fwd_kernel", ""),
     "conv2_fwd": ("z_kernel", "ZRowsConv<20, 20, 32, 4, 4, 9, 9, 2, 0,"),
@@ -43,7 +44,7 @@ def load(name):
 
 def main():
     fetch, write = load(FETCH_CSV), load(WRITE_CSV)
-    out = {"source": f"profiles/{FETCH_CSV}, profiles/{WRITE_CSV} (tools/gpu/r4_final.sh): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/conv_traffic 32768 3",
+    out = {"source": f"profiles/{FETCH_CSV}, profiles/{WRITE_CSV} (tools/gpu/r5_final.sh): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over CONV_TRAFFIC_F16=1 tools/conv_traffic 32768 3",
            "correction": "bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950: 128-byte read requests tallied at 64 bytes)",
            "calibration_fetch_KiB_for_1GiB_read": {k[:40]: v for k, v in fetch.items() if "calib" in k},
            "calibration_write_KiB_for_1GiB_write": {k[:40]: v for k, v in write.items() if "calib" in k},
