@@ -162,37 +162,56 @@ CONFIGS = {
 }
 
 
+# ALGORITHMIC bytes per image of the eleven conv / FC launches of a minibatch update: every input read once + every output written once (the
+# ReLU masks as bits: 1/32 of an activation's bytes); the FC layer's 6.4 MB weight pack / result are not counted.  (tools/make_traffic_json.py
+# holds the same table for profiles/traffic.json)
+ALG_BYTES_PER_IMAGE = {
+    "conv1_fwd": 28224 + 51200 + 1600, "conv2_fwd": 51200 + 20736 + 648, "conv3_fwd": 20736 + 12544 + 392,
+    "conv2_dgrad": 20736 + 1600 + 51200, "conv3_dgrad": 12544 + 648 + 20736,
+    "conv1_wgrad": 28224 + 51200, "conv2_wgrad": 51200 + 20736, "conv3_wgrad": 20736 + 12544,
+    "fc_fwd": 12544 + 2048, "fc_dgrad": 2048 + 392 + 12544, "fc_wgrad": 2048 + 12544,
+}
+
+
 def roofline_entry(key, us, launches_timed, flops, letter, share, traffic):
-    """The ``roofline`` object of the JSON line for the dominant conv / FC launch ``key`` ("conv2_dgrad@32768"): a BOUND, i.e.
-    ``frac`` <= 1 by construction.  A kernel is priced on the pipe it executes on:
+    """The ``roofline`` object of the JSON line for the dominant conv / FC launch ``key`` ("conv2_dgrad@32768"): the BINDING roof of the
+    two-roof model, so ``frac`` <= 1 by construction.  For the launch's algorithmic work
 
-    * kernel Q (int8 pipe at 1/8 of the f32 pipe's time): HBM-bound -- algorithmic bytes / launch time against 8 TB/s;
-    * bf16- / f16-pipe kernels (Z, V, W, P; Zh, Vh, Wh): ``achieved`` = EXECUTED 16-bit MFMA flops per second = the algorithmic f32
-      flops of the convolution / GEMM x the MFMA products issued per f32 product (three-term bf16 split: 6 term pairs by default, 9
-      with MI355PPO_BF16_PAIRS=9; two-term f16 split, the default since round 5: 3; kernel P: 3 -- its uint8 operand is exact in
-      bf16), ``peak`` = the dense bf16 / f16 MFMA peak (2,500 TFLOP/s; never the 2:1-sparsity figure).  NOTE: halving the products
-      per f32 product halves ``achieved`` at equal speed -- compare ``avg_launch_us`` / ``algorithmic_TFLOPs`` across splits, not ``frac``;
-    * f32-pipe kernels (F, T, Y): algorithmic flops against the dense f32 MFMA peak.
+        t_hbm  = algorithmic bytes / 8 TB/s                                   (ALG_BYTES_PER_IMAGE x images)
+        t_mfma = algorithmic f32 flops x MFMA products issued per f32 product / the dense peak of the pipe the kernel multiplies on
+                 (two-term f16 split, the default since round 5: 3 products, 2,500 TFLOP/s; three-term bf16 split: 6 -- or 9 with
+                 MI355PPO_BF16_PAIRS=9; kernel P: 2 / 3, its uint8 operand is exact; f32-pipe kernels F / T / Y: 1, 157.3 TFLOP/s; kernel Q:
+                 int8 pipe, always HBM-bound)
 
-    The f32-equivalent view (algorithmic flops / the f32 peak, which the split kernels legitimately exceed) is kept as the
-    secondary fields ``algorithmic_TFLOPs`` / ``frac_of_f32_mfma_peak``."""
+    the larger one is the roof the launch cannot beat: ``bound`` names it, ``achieved`` / ``peak`` / ``unit`` are in its terms and
+    ``frac`` = t_roof / measured launch time.  Under the f16 split the layer-1 / layer-2 launches (2.4 - 2.9 GB per launch for 0.17 - 0.22
+    TFLOP) are HBM-bound by this model; under the bf16 split (twice the matrix instructions) they were matrix-pipe-bound, which is what
+    round 4's line priced.  Both views travel in the object (``hbm_*`` / ``mfma_*`` fields), so that lines of different splits compare."""
     text, pipe, products = KERNEL_INFO[letter]
+    if letter == "P" and os.environ.get("MI355PPO_SPLIT", "f16x2") == "f16x2":
+        text, pipe, products = text.replace("bf16 MFMA", "f16 MFMA (round 5: dz in two f16 terms)"), "f16", 2
     tf = flops / us / 1e6
-    common = {"avg_launch_us": us, "launches_timed": launches_timed, "share_of_step_time": share, "traffic": traffic}
-    if letter == "Q":
-        alg = _conv1_fwd_bytes(int(key.split("@")[1]))
-        return {"kernel": f"{key}: kernel Q = {text}", "bound": "hbm", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg, **common}
-    peak = MFMA_BF16_PEAK_TFLOPS if pipe in ("bf16", "f16") else MFMA_F32_PEAK_TFLOPS      # (the dense f16 and bf16 MFMA peaks are equal)
-    r = {"kernel": f"{key}: kernel {letter} = {text}", "bound": "mfma", "achieved": tf * products, "peak": peak, "unit": "TFLOP/s",
-         "frac": tf * products / peak, "pipe": pipe, "mfma_products_per_f32_product": products,
-         "algorithmic_flops_per_launch": flops, "algorithmic_TFLOPs": tf, "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS, **common}
+    name, images = key.split("@")[0], int(key.split("@")[1])
+    alg = ALG_BYTES_PER_IMAGE[name] * images
+    peak_tf = MFMA_BF16_PEAK_TFLOPS if pipe in ("bf16", "f16") else MFMA_F32_PEAK_TFLOPS      # (the dense f16 and bf16 MFMA peaks are equal)
+    t_hbm_us = alg / (HBM_PEAK_GBPS * 1e3)
+    t_mfma_us = 0.0 if letter == "Q" else flops * products / (peak_tf * 1e6)
+    r = {"kernel": f"{key}: kernel {letter} = {text}", "avg_launch_us": us, "launches_timed": launches_timed, "share_of_step_time": share, "traffic": traffic,
+         "algorithmic_bytes_per_launch": alg, "algorithmic_flops_per_launch": flops,
+         "hbm_roof_us": t_hbm_us, "hbm_GBps": alg / us / 1e3, "hbm_frac": t_hbm_us / us,
+         "mfma_roof_us": t_mfma_us, "mfma_pipe": pipe, "mfma_products_per_f32_product": products, "mfma_executed_TFLOPs": tf * products,
+         "mfma_frac": t_mfma_us / us, "algorithmic_TFLOPs": tf, "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS}
+    if t_hbm_us >= t_mfma_us:
+        r.update({"bound": "hbm", "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": t_hbm_us / us,
+                  "frac_of_measured_achievable_6290": alg / us / 1e3 / 6290.0})
+    else:
+        r.update({"bound": "mfma", "achieved": tf * products, "peak": peak_tf, "unit": "TFLOP/s", "frac": t_mfma_us / us})
     if pipe in ("bf16", "f16"):
         r["mfma"] = "v_mfma_f32_32x32x16_" + pipe
-        r["frac_of_measured_stream_rate"] = tf * products / (MFMA_BF16_PEAK_TFLOPS * 32.0 / 47.7)
-        r["note"] = ("achieved = algorithmic f32 flops x term pairs executed (padding taps of the data gradients are not multiplied and "
-                     "not counted); frac_of_measured_stream_rate: against 32 nominal cycles per MFMA / 47.7 measured for a bare MFMA "
-                     "stream on random operands on this power-limited chip (profiles/r03_mfma_floor.jsonl)")
+    r["note"] = ("two-roof model: t_hbm = algorithmic bytes / 8 TB/s, t_mfma = algorithmic f32 flops x products issued / the dense peak of the executing "
+                 "pipe; `bound` = the larger, frac = t_roof / avg_launch_us.  Padding taps of the data gradients are neither multiplied nor counted "
+                 "(t_mfma of a data gradient is therefore an upper estimate of its executed work by 19 - 40 %).  `traffic` = L2-miss bytes of the launch "
+                 "from the committed PMC passes (profiles/traffic.json)")
     return r
 
 
@@ -538,18 +557,15 @@ def main():
             for k in sorted(tot):
                 kus, kn = timer.mean_us(k)
                 launches = kn * (16 if k.endswith(f"@{N}") else 1)          # rollout-sized launches are sampled 1 in 16
-                _, pipe, products = KERNEL_INFO[kernel_of[k]]
-                out["kernels"][k] = {"kernel": kernel_of[k], "pipe": pipe, "avg_us": kus, "launches_timed": kn,
-                                     "TFLOPs": conv_flops[k] / kus / 1e6,
-                                     "frac_of_f32_mfma_peak": conv_flops[k] / kus / 1e6 / MFMA_F32_PEAK_TFLOPS,
-                                     "ms_per_step": kus * launches / timing_iters / 1e3,
-                                     "hbm_bytes_per_launch_pmc": _traffic_of(k)}
-                if pipe in ("bf16", "f16"):
-                    out["kernels"][k]["frac_of_bf16_mfma_peak_executed"] = conv_flops[k] * products / kus / 1e6 / MFMA_BF16_PEAK_TFLOPS
-                if kernel_of[k] == "Q":              # HBM-bound, the f32-pipe fraction is > 1 by construction
-                    alg = _conv1_fwd_bytes(int(k.split("@")[1]))
-                    out["kernels"][k].update({"bound": "hbm", "algorithmic_bytes": alg, "GBps": alg / kus / 1e3,
-                                              "frac_of_hbm_peak": alg / kus / 1e3 / HBM_PEAK_GBPS})
+                if k.split("@")[0] not in ALG_BYTES_PER_IMAGE:             # (trunk_fwd: the three forwards in one call of the f32-pipe route)
+                    out["kernels"][k] = {"kernel": kernel_of[k], "avg_us": kus, "launches_timed": kn, "TFLOPs": conv_flops[k] / kus / 1e6,
+                                         "ms_per_step": kus * launches / timing_iters / 1e3}
+                    continue
+                e = roofline_entry(k, kus, kn, conv_flops[k], kernel_of[k], 0.0, _traffic_of(k))      # the same two-roof pricing for every launch
+                out["kernels"][k] = {"kernel": kernel_of[k], "pipe": e["mfma_pipe"], "avg_us": kus, "launches_timed": kn,
+                                     "bound": e["bound"], "frac": e["frac"], "hbm_frac": e["hbm_frac"], "mfma_frac": e["mfma_frac"],
+                                     "GBps": e["hbm_GBps"], "TFLOPs": e["algorithmic_TFLOPs"], "frac_of_f32_mfma_peak": e["frac_of_f32_mfma_peak"],
+                                     "ms_per_step": kus * launches / timing_iters / 1e3, "hbm_bytes_per_launch_pmc": _traffic_of(k)}
         elif not cli.no_kernel_timing:
             us, n = timer.mean_us("obs_gather")
             alg = OBS_ROW_BYTES * 5 * M
