@@ -143,8 +143,8 @@ int main(int argc, char** argv) {
         if (f16) {
             CHECK(hipMemsetAsync(rec, 0, 8 * MI355PPO_AMAX_WORDS * 4, st));      // the records the producers fill (what the learner's one fill per pass does)
             TIMED(0, mi355ppo_cnn_conv1q_fwd_amax(obs, inds, bt1q, bias, a1, mb1, M, R(0), st));
-            TIMED(1, mi355ppo_cnn_conv_fwd_packed_f16x2_f32(a1, hz2, bias, a2, mb2, M, 2, R(0), R(1), st));
-            TIMED(2, mi355ppo_cnn_conv_fwd_packed_f16x2_f32(a2, hz3, bias, a3, mb3, M, 3, R(1), R(2), st));
+            TIMED(1, mi355ppo_cnn_conv_fwd_packed_f16x2_f32(a1, hz2, bias, a2, bits ? mb2 : nullptr, M, 2, R(0), R(1), st));      // (CONV_TRAFFIC_NOBITS: the forwards without their mask words)
+            TIMED(2, mi355ppo_cnn_conv_fwd_packed_f16x2_f32(a2, hz3, bias, a3, bits ? mb3 : nullptr, M, 3, R(1), R(2), st));
             TIMED(8, mi355ppo_fc_fwd_relu_packed_f16x2_f32(a3, 3136, hk_fwd, bias, hfc, (int)M, 512, 3136, wsfwd, wsfwdb, R(2), nullptr, st));
             TIMED(9, mi355ppo_fc_dgrad_packed_f16x2_f32(dzfc, 516, hk_dg, nullptr, mb3, dz3, (int)M, 3136, 512, R(8), R(3), st));
             TIMED(10, mi355ppo_fc_wgrad_f16x2_f32(dzfc, 516, a3, dWfc, (int)M, 512, 3136, 64, wsfc, wsfcb, R(8), R(2), st));
