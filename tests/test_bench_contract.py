@@ -76,22 +76,35 @@ def test_config_flag_selects_the_baseline_workloads(monkeypatch):
         assert e.code == 2
 
 
-def test_roofline_entry_is_a_bound_on_the_executing_pipe():
-    """``roofline.frac`` prices a kernel on the pipe it executes on (round-3 review: the f32-peak pricing read 1.014 for
-    kernel P at config B -- not a bound).  Numbers: the round-3 bench launches (profiles/r03_bench_cfg{B,C}.json)."""
+def test_roofline_entry_is_the_binding_roof_of_the_two_roof_model(monkeypatch):
+    """``roofline`` = the larger of t_hbm (algorithmic bytes / 8 TB/s) and t_mfma (algorithmic f32 flops x matrix instructions per f32 product /
+    the dense peak of the executing pipe) over the measured launch time: a bound (frac <= 1) whichever split runs.  Numbers: round 4's bf16 launches
+    (matrix-pipe-bound, the figures the round-3 / 4 reviews recomputed) and round 5's f16 launches (HBM-bound), profiles/r0{4,5}_bench_cfgC.json."""
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
     conv = lambda cin, cout, k, hout, images: 2.0 * images * hout * hout * cout * cin * k * k          # noqa: E731
-    # config C: layer-2 data gradient on kernel Z, 1,140 us at 32,768 images -> 0.97 of the f32 peak = 0.366 of the bf16 pipe
+    # bf16 split (6 products): layer-2 data gradient on kernel Z, 1,140 us at 32,768 images -> t_mfma 417 us > t_hbm 301 us: 0.366 of the bf16 pipe
     r = bench.roofline_entry("conv2_dgrad@32768", 1140.0, 48, conv(32, 64, 4, 9, 32768), "Z", 0.117, 2.81e9)
     assert r["bound"] == "mfma" and r["peak"] == 2500.0 and r["unit"] == "TFLOP/s"
-    assert abs(r["frac"] - 0.366) < 0.003 and abs(r["frac_of_f32_mfma_peak"] - 0.970) < 0.005 and r["frac"] == r["achieved"] / r["peak"]
-    # config B: layer-1 weight gradient on kernel P (three products per f32 product), 168 us at 4,096 images: 1.014 of the f32 peak
+    assert abs(r["frac"] - 0.366) < 0.003 and abs(r["frac_of_f32_mfma_peak"] - 0.970) < 0.005 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["hbm_frac"] - 0.264) < 0.003 and r["mfma_frac"] == r["frac"]
+    # f16 split (3 products), the same launch at 946 us: t_hbm 301 us > t_mfma 209 us -> HBM-bound, 2.55 TB/s of 8
+    r = bench.roofline_entry("conv2_dgrad@32768", 946.0, 16, conv(32, 64, 4, 9, 32768), "Zh", 0.12, 2.77e9)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - 0.318) < 0.003 and abs(r["achieved"] - 2548) < 10
+    assert abs(r["mfma_frac"] - 0.221) < 0.003 and r["mfma_products_per_f32_product"] == 3 and r["mfma_pipe"] == "f16" and r["frac"] <= 1.0
+    # the FC forward (0.48 GB, 0.105 TFLOP) stays matrix-pipe-bound under either split
+    r = bench.roofline_entry("fc_fwd@32768", 311.0, 16, 2.0 * 32768 * 512 * 3136, "Zh", 0.04, None)
+    assert r["bound"] == "mfma" and abs(r["frac"] - 0.406) < 0.004
+    # config B: layer-1 weight gradient on kernel P: three products per f32 product on the bf16 split (1.014 of the f32 peak: not a bound), two on f16
+    monkeypatch.setenv("MI355PPO_SPLIT", "bf16x3")
     r = bench.roofline_entry("conv1_wgrad@4096", 168.0, 48, conv(4, 32, 8, 20, 4096), "P", 0.07, None)
-    assert r["frac_of_f32_mfma_peak"] > 1.0 and r["frac"] < 0.25 and r["mfma_products_per_f32_product"] == 3
+    assert r["frac_of_f32_mfma_peak"] > 1.0 and r["mfma_frac"] < 0.25 and r["mfma_products_per_f32_product"] == 3 and r["frac"] <= 1.0
+    monkeypatch.setenv("MI355PPO_SPLIT", "f16x2")
+    r = bench.roofline_entry("conv1_wgrad@32768", 644.0, 16, conv(4, 32, 8, 20, 32768), "P", 0.08, None)
+    assert r["bound"] == "hbm" and r["mfma_products_per_f32_product"] == 2 and abs(r["frac"] - 0.505) < 0.005
     # an f32-pipe kernel is priced against the f32 peak, kernel Q against HBM
     r = bench.roofline_entry("conv2_fwd@32768", 1290.0, 48, conv(32, 64, 4, 9, 32768), "F", 0.1, None)
-    assert r["peak"] == 157.3 and 0.8 < r["frac"] < 0.9
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0.8 < r["frac"] < 0.9
     r = bench.roofline_entry("conv1_fwd@32768", 616.0, 48, conv(4, 32, 8, 20, 32768), "Q", 0.06, None)
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.5 < r["frac"] < 0.56
     # whole-iteration flops at config C: ~28.4 TFLOP (round-3 review's figure)
