@@ -253,6 +253,19 @@ class KernelTimer:
         return float(np.mean([a.elapsed_time(b) for a, b in ps])) * 1e3, len(ps)
 
 
+def _all_ranks_agree(captured: bool, learner, device) -> bool:
+    """World > 1: the update runs from graphs only if EVERY rank captured them -- the legs after the timed region (the extra eager iteration
+    of the per-launch brackets) must issue the same collectives on every rank."""
+    import torch.distributed as dist
+
+    flag = torch.tensor([1 if captured else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok = bool(flag.item())
+    if not ok:
+        learner._update_graphs = None
+    return ok
+
+
 def self_launch(cli) -> int:
     """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU,
     the launch line of the module docstring) and hand their output through.  Refuses -- loudly, non-zero -- when the box
@@ -330,13 +343,27 @@ def main():
             env._step_rel = None
             torch.cuda.synchronize()
     update_mode = "eager launches"
-    use_update_graphs = not cli.no_update_graphs and learner.fused_cnn and world == 1
-    if use_update_graphs:
+    use_update_graphs = not cli.no_update_graphs and learner.fused_cnn
+    if use_update_graphs and world > 1:
+        # world > 1: each slot is the graphs between its collectives (learner._SlotGraphs).  A rank whose capture fails keeps the eager update:
+        # both issue the same collectives on the same slices in the same order, so ranks on different routes stay compatible.
+        try:
+            learner.capture_update()
+            update_mode = ("per (epoch, minibatch) slot three hipGraphs with the gradient exchange between them: [forward + fused loss + backward to the "
+                           "FC weight's gradient] | all-reduce of that bucket, asynchronous | [conv backward] | all-reduce of the rest | [clip + Adam] "
+                           "(PPOLearner.capture_update); per-launch event brackets from an extra eager iteration after the timed region")
+        except Exception as e:
+            print(f"[bench] rank {rank}: update-graph capture failed beside the process group ({e!r}); this rank's update runs eagerly", file=sys.stderr, flush=True)
+            use_update_graphs = False
+        use_update_graphs = _all_ranks_agree(use_update_graphs, learner, device)
+        if not use_update_graphs:
+            update_mode = "eager launches (update-graph capture failed on a rank; see stderr)"
+    elif use_update_graphs:
         learner.capture_update()            # (before the timing hooks: no event records in a capture)
         update_mode = ("one hipGraph per (epoch, minibatch) slot: forward + fused loss + backward + clip + Adam (PPOLearner.capture_update); "
                        "per-launch event brackets from an extra eager iteration after the timed region")
     elif not cli.no_update_graphs:
-        update_mode = "eager launches (update graphs need one GPU and the fused CNN kernels: world > 1 or MI355PPO_CNN=miopen)"
+        update_mode = "eager launches (update graphs need the fused CNN kernels: MI355PPO_CNN=miopen)"
     timer = KernelTimer()
     conv_flops = {}      # key "<op>@<rows>" -> algorithmic flops of one launch (the f32 convolution / GEMM: 2 x M x N x K)
     kernel_of = {}       # key -> letter in KERNEL_INFO
@@ -694,11 +721,23 @@ def main_continuous(cli, rank, world, device):
         learner.capture_rollout(env, steps_per_graph=per)
         rollout_mode = f"{len(learner._rollout_graphs)} hipGraph(s) of {min(per, T)} env steps each (fused act kernel + env step kernel)"
     update_mode = "eager launches"
-    use_update_graphs = not cli.no_update_graphs and world == 1
+    use_update_graphs = not cli.no_update_graphs
     if use_update_graphs:
-        learner.capture_update()
-        update_mode = ("one hipGraph per (epoch, minibatch) slot: fused MLP forward + loss + backward, fold, clip + Adam "
-                       "(PPOLearner.capture_update); per-launch event brackets from an extra eager iteration after the timed region")
+        try:
+            learner.capture_update()
+            update_mode = ("one hipGraph per (epoch, minibatch) slot: fused MLP forward + loss + backward, fold, clip + Adam "
+                           "(PPOLearner.capture_update); per-launch event brackets from an extra eager iteration after the timed region" if world == 1 else
+                           "two hipGraphs per (epoch, minibatch) slot with the all-reduce of the flat gradient between them: [fused MLP forward + loss + "
+                           "backward, fold] | all-reduce | [clip + Adam] (PPOLearner.capture_update)")
+        except Exception as e:
+            if world == 1:
+                raise
+            print(f"[bench] rank {rank}: update-graph capture failed beside the process group ({e!r}); this rank's update runs eagerly", file=sys.stderr, flush=True)
+            use_update_graphs = False
+        if world > 1:
+            use_update_graphs = _all_ranks_agree(use_update_graphs, learner, device)
+        if not use_update_graphs:
+            update_mode = "eager launches (update-graph capture failed on a rank; see stderr)"
     timer = KernelTimer()
 
     def install_timing_hooks():

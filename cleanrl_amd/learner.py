@@ -67,6 +67,38 @@ class PendingMetrics:
         return self._out
 
 
+class _SlotGraphs:
+    """One (epoch, minibatch) slot of a captured update (``PPOLearner.capture_update``).  World = 1: one hipGraph.  World > 1: the graphs
+    between the slot's collectives, replayed with the gradient exchange of ``_minibatch_hip`` issued eagerly between them -- the early
+    bucket (Linear(3136,512).weight, 95 % of the bytes) goes out behind the first graph and rides under the second (the conv layers'
+    backward), the small rest follows, the last graph (clip + Adam) is enqueued behind the collectives' completion."""
+    __slots__ = ("segs", "early")
+
+    def __init__(self, segs, early):
+        self.segs, self.early = segs, early
+
+    def replay(self, learner) -> None:
+        segs = self.segs
+        if len(segs) == 1:
+            segs[0].replay()
+            return
+        g, multi = learner.flat.grads, learner.world_size > 1
+        segs[0].replay()
+        if self.early is not None:
+            off, n = self.early
+            work = dist.all_reduce(g[off:off + n], op=dist.ReduceOp.SUM, async_op=True) if multi else None
+            segs[1].replay()
+            if multi:                                                     # the same three disjoint pieces as the eager path, in the same order
+                if off > 0:
+                    dist.all_reduce(g[:off], op=dist.ReduceOp.SUM)
+                if off + n < g.numel():
+                    dist.all_reduce(g[off + n:], op=dist.ReduceOp.SUM)
+                work.wait()
+        elif multi:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        segs[-1].replay()
+
+
 class PPOLearner:
     def __init__(self, agent: nn.Module, args, obs_space, act_space, num_envs: int, device: torch.device,
                  world_size: int = 1, sample_seed: int = 0):
@@ -173,7 +205,11 @@ class PPOLearner:
         self._ar_early = None       # (offset, numel) of the early bucket in the flat gradient buffer
         self._ar_armed = False
         self._ar_work = None
-        if (self.hip and world_size > 1 and type(self).forward_backward_hip is PPOLearner.forward_backward_hip
+        self._capture_cut = None    # capture_update() with world > 1: ends a slot's first graph / begins its second (see _SlotGraphs)
+        # (MI355PPO_UPDATE_GRAPH_CUT=1: the bucket boundary -- and with it the cut of a captured slot -- also with world = 1, where the
+        # collectives are skipped: the one-GPU test of the segmented capture against the single-graph slots)
+        self._force_cut = os.environ.get("MI355PPO_UPDATE_GRAPH_CUT", "0") == "1"
+        if (self.hip and (world_size > 1 or self._force_cut) and type(self).forward_backward_hip is PPOLearner.forward_backward_hip
                 and os.environ.get("MI355PPO_AR_OVERLAP", "1") != "0"):
             i = max(range(len(self.flat.segments)), key=lambda j: self.flat.segments[j][1])
             off, n = self.flat.segments[i]
@@ -496,7 +532,7 @@ class PPOLearner:
                     if k == 0:
                         self._upload_adam_schedule(lr)                    # every slot's (step size, bias correction) -> device memory
                     # forward + fused loss + backward + clip + Adam of this slot (capture_update)
-                    self._update_graphs[epoch][start // M].replay()
+                    self._update_graphs[epoch][start // M].replay(self)
                     self.flat.step += 1
                 elif self.hip:
                     self._mb_adv_md = adv_md[start // M] if adv_md is not None else None
@@ -541,7 +577,10 @@ class PPOLearner:
         return pm
 
     def capture_update(self) -> None:
-        """``bench.py``'s default on one GPU (``--no-update-graphs``: eager).  Bit-identical to the eager update over three
+        """``bench.py``'s and ``runner.train``'s default (``--no-update-graphs`` / MI355PPO_UPDATE_GRAPHS=0: eager).  World > 1 (round 5): a
+        slot is the two or three graphs BETWEEN its collectives, replayed with the eager path's all-reduces issued between them
+        (``_SlotGraphs``, ``_capture_slot_segments``; two ranks on one GPU over gloo bit-identical to the eager two-rank update and at the
+        reference's distance on config D's golden: tests/test_gpu_multirank.py).  Bit-identical to the eager update over three
         iterations on the MI355X at a small shape, at config B's and on the continuous-action path
         (tests/test_gpu_learner.py::test_captured_update_slots_...); measured in profiles/r04_update_graphs_ab.jsonl.
 
@@ -554,8 +593,7 @@ class PPOLearner:
         bumps the weights' version before every slot, so the repack launches are part of every graph).  Why: the update then
         costs the host ~3 launches per minibatch instead of ~55, so a busy host no longer drains the GPU's queue in a training
         loop that synchronises every env step (host envs), where ``update_async`` cannot help."""
-        assert self.hip and self.world_size == 1 and type(self).forward_backward_hip is PPOLearner.forward_backward_hip, \
-            "capture_update: the single-GPU HIP path of the plain PPO learner"
+        assert self.hip and type(self).forward_backward_hip is PPOLearner.forward_backward_hip, "capture_update: the HIP path of the plain PPO learner"
         assert getattr(self.agent, "rpo_alpha", None) is None, "capture_update: RPO draws noise inside the update (not covered)"
         # (the Normal / continuous-action path runs the same code: tests/test_gpu_learner.py::test_captured_update_slots_continuous_path)
         a, dev = self.args, self.device
@@ -598,11 +636,17 @@ class PPOLearner:
         self._adam_sched_ev = None
         slot_fb = slot
 
-        def slot(e, j):                                                   # noqa: F811 -- forward/backward, then the optimizer step
-            slot_fb(e, j)
+        def slot_opt(e, j):
             self.ops.clip_adam_sched_(self.flat.params, self.flat.grads, self.flat.exp_avg, self.flat.exp_avg_sq,
                                       self._adam_sched[e * nmb + j], a.max_grad_norm, grad_scale=1.0 / self.world_size, eps=self.adam_eps,
                                       total_norm_out=self._total_norm)
+
+        def slot(e, j):                                                   # noqa: F811 -- forward/backward, then the optimizer step
+            slot_fb(e, j)
+            slot_opt(e, j)
+
+        # world > 1: a slot is two or three graphs with the gradient exchange between them (_SlotGraphs)
+        segmented = self.world_size > 1 or self._force_cut
 
         state0 = [t.clone() for t in (self.flat.params, self.flat.exp_avg, self.flat.exp_avg_sq)]
         side = torch.cuda.Stream(device=dev)
@@ -618,11 +662,15 @@ class PPOLearner:
             for e in range(E_):
                 row = []
                 for j in range(nmb):
+                    if segmented:
+                        sg, pool = self._capture_slot_segments(side, pool, lambda e=e, j=j: slot_fb(e, j), lambda e=e, j=j: slot_opt(e, j))
+                        row.append(sg)
+                        continue
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, pool=pool, stream=side):
                         slot(e, j)
                     pool = pool or g.pool()
-                    row.append(g)
+                    row.append(_SlotGraphs([g], None))
                 graphs.append(row)
         except Exception:
             # a capture that failed (an op the stream capture does not allow, e.g. inside a library GEMM of a head wider than the fused
@@ -634,6 +682,7 @@ class PPOLearner:
             self.flat.grads.zero_()
             self._mb_adv_md = self._mb_slot = self._pack = None
             self._update_graphs = self._adam_sched = None
+            self._capture_cut = None
             if trunk is not None:
                 trunk.bufs.weights_version += 1
             raise
@@ -641,6 +690,54 @@ class PPOLearner:
         self.flat.grads.zero_()
         self._mb_adv_md = self._mb_slot = self._pack = None
         self._update_graphs = graphs
+
+    def _capture_slot_segments(self, side, pool, forward_backward, optimizer_step):
+        """One (epoch, minibatch) slot for world > 1 as the graphs BETWEEN its collectives (ppo_atari_multigpu.py:358-377: backward, all-reduce,
+        clip, step): [forward ... the FC weight's gradient] | early bucket | [the conv layers' backward] | rest | [clip + Adam].  The first
+        cut falls in the MIDDLE of the autograd backward -- at the callback the eager path starts the early bucket's all-reduce from
+        (``_early_all_reduce``) --, i.e. on the autograd engine's device thread: the capture of the first graph ends and the second begins
+        there, and ends on the calling thread after the backward returned.  Hence capture mode "relaxed": the other modes tie a capture to the
+        thread that began it (and "global" would let the process group's watchdog thread invalidate it, as in ``capture_rollout``).  An agent
+        without an early bucket gets two graphs (backward | whole buffer | step).  Returns (_SlotGraphs, pool)."""
+        graphs = []
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(**({"pool": pool} if pool is not None else {}), capture_error_mode="relaxed")
+            graphs.append(g)
+
+        def end():
+            nonlocal pool
+            graphs[-1].capture_end()
+            pool = pool or graphs[-1].pool()
+
+        def cut():
+            self._capture_cut = None          # once per slot (the eager path's `_ar_armed`: the callback and the parameter's hook may both fire)
+            end()
+            begin()
+
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.stream(side):
+            capturing = False
+            try:
+                begin()
+                capturing = True
+                self._capture_cut = cut if self._ar_early is not None else None
+                forward_backward()
+                self._capture_cut = None
+                early = self._ar_early if len(graphs) == 2 else None      # (the cut fires only on the fused trunk's direct-gradient path)
+                cut()
+                optimizer_step()
+                end()
+                capturing = False
+            finally:
+                self._capture_cut = None
+                if capturing:                                             # leave the stream out of capture mode whatever happened
+                    try:
+                        graphs[-1].capture_end()
+                    except Exception:
+                        pass
+        return _SlotGraphs(graphs, early), pool
 
     def _replay_update(self, lr: float, b_inds: np.ndarray, b_advantages, use_pack: bool) -> int:
         """The whole update as graph replays (``capture_update``; no early stop): every epoch's host permutation is drawn first --
@@ -672,7 +769,7 @@ class PPOLearner:
         self._upload_adam_schedule(lr)                                    # every slot's (step size, bias correction) -> device memory
         for row in self._update_graphs:
             for g in row:
-                g.replay()                                                # forward + fused loss + backward + clip + Adam of the slot
+                g.replay(self)                                            # forward + fused loss + backward (+ all-reduce) + clip + Adam of the slot
         n = sum(len(row) for row in self._update_graphs)
         self.flat.step += n
         return n
@@ -711,14 +808,18 @@ class PPOLearner:
         return dev
 
     def _early_all_reduce(self, _param) -> None:
-        """Post-accumulate hook of the largest parameter: its slice of the flat gradient is final for this minibatch."""
+        """Post-accumulate hook of the largest parameter: its slice of the flat gradient is final for this minibatch.  While
+        ``capture_update`` records a slot for world > 1 the same moment is where the slot's first graph ends and its second begins."""
+        if self._capture_cut is not None:
+            self._capture_cut()
+            return
         if self._ar_armed:
             off, n = self._ar_early
             self._ar_work = dist.all_reduce(self.flat.grads[off:off + n], op=dist.ReduceOp.SUM, async_op=True)
             self._ar_armed = False
 
     def _minibatch_hip(self, idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, lr, scalars_out):
-        self._ar_armed = self._ar_early is not None
+        self._ar_armed = self._ar_early is not None and self.world_size > 1
         self.forward_backward_hip(idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, scalars_out)
         if self.world_size > 1:
             g = self.flat.grads

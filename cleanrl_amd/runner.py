@@ -164,10 +164,10 @@ def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: in
             next_obs, _ = envs.reset(seed=args.seed)
         learner.observe(0, next_obs, np.zeros(local_num_envs, np.float32))
     # The update as captured hipGraphs -- one per (epoch, minibatch) slot: gather, forward, fused loss, backward, clip + Adam -- when
-    # nothing in it needs the host: one GPU, the plain PPO learner on the fused kernels, no KL early stop, no noise drawn inside
-    # the update (RPO).  With host envs every env step synchronises on the actions, so the update starts with an empty GPU queue
+    # nothing in it needs the host: the plain PPO learner on the fused kernels, no KL early stop, no noise drawn inside the update (RPO);
+    # with world > 1 a slot is the graphs between its collectives (learner._SlotGraphs).  With host envs every env step synchronises on the actions, so the update starts with an empty GPU queue
     # and the host only microseconds ahead: ~55 launches per minibatch become one replay (MI355PPO_UPDATE_GRAPHS=0: eager).
-    if (learner.hip and world_size == 1 and type(learner) is PPOLearner and args.target_kl is None
+    if (learner.hip and type(learner) is PPOLearner and args.target_kl is None
             and getattr(agent, "rpo_alpha", None) is None and learner.batch_size % max(learner.minibatch_size, 1) == 0
             and (learner.fused_cnn or learner.mlp is not None) and os.environ.get("MI355PPO_UPDATE_GRAPHS", "1") != "0"):
         try:

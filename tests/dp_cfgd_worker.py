@@ -17,13 +17,13 @@ from conftest import load_golden  # noqa: E402
 from whole_iteration import run_atari_iteration  # noqa: E402
 
 
-def main(out_dir):
+def main(out_dir, graphs=False):
     rank, world = int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = load_golden("atari_iteration_cfgD")["atari_T128_N256_world2"]
     assert int(g["world_size"]) == world
-    out = run_atari_iteration(g, dev, rank=rank, world=world)
+    out = run_atari_iteration(g, dev, rank=rank, world=world, graphs=graphs)     # graphs: three hipGraphs per slot, collectives between them
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: np.asarray(v) for k, v in out.items()})
     dist.barrier()
@@ -31,4 +31,4 @@ def main(out_dir):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], graphs=len(sys.argv) > 2 and sys.argv[2] == "graphs")

@@ -1,0 +1,62 @@
+"""Worker of ``test_gpu_multirank.py::test_update_graphs_with_two_ranks...``: ONE rank of a data-parallel run with the update
+replayed from captured graphs -- per (epoch, minibatch) slot three hipGraphs with the gradient exchange between them
+(``learner._SlotGraphs``) -- beside an eager twin from the same seeds, both ranks on ``cuda:0`` over gloo.  The two learners of
+a rank issue the same collectives in the same order, so the twins interleave safely.  Reference: ppo_atari_multigpu.py:314-377.
+Not a test module."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from cleanrl_amd import envs as E, learner_smoke  # noqa: E402
+from cleanrl_amd.agents import AtariAgent  # noqa: E402
+from cleanrl_amd.learner import PPOLearner  # noqa: E402
+
+
+def main(out_dir, N, T, nmb, epochs, iters):
+    rank, world = int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def make(graphs):
+        torch.manual_seed(4)                                    # same init on every rank (ppo_atari_multigpu.py:211)
+        env = E.DeviceSyntheticAtariVecEnv(N, dev, seed=6 + rank, done_p=0.1)      # per-rank data (:206-212)
+        agent = AtariAgent(env).to(dev)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=nmb, update_epochs=epochs)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, dev, world_size=world, sample_seed=8 + rank)
+        L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
+        if graphs:
+            L.capture_update()
+        return L, env
+
+    (Le, enve), (Lg, envg) = make(False), make(True)
+    segs = sorted({len(s.segs) for row in Lg._update_graphs for s in row})
+    early = all(s.early == Lg._ar_early and s.early is not None for row in Lg._update_graphs for s in row)
+    same = [bool(torch.equal(Le.flat.params, Lg.flat.params) and not Lg.flat.grads.any())]
+    scal = []
+    for it in range(iters):
+        learner_smoke.rollout(Le, enve)
+        learner_smoke.rollout(Lg, envg)
+        np.random.seed(100 + it + 10 * rank)
+        me = Le.update(2.5e-4 * (1 - it / iters))
+        np.random.seed(100 + it + 10 * rank)
+        mg = Lg.update(2.5e-4 * (1 - it / iters))
+        Le.start_iteration(); Lg.start_iteration()
+        same.append(bool(torch.equal(Le.flat.params, Lg.flat.params) and torch.equal(Le.flat.exp_avg, Lg.flat.exp_avg)
+                         and torch.equal(Le.flat.exp_avg_sq, Lg.flat.exp_avg_sq)))
+        scal.append(all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me))
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), params=Lg.flat.params.cpu().numpy(), params_eager=Le.flat.params.cpu().numpy(),
+             same=np.array(same), scalars_same=np.array(scal), segs=np.array(segs), early=early, moved=float((Lg.flat.params != 0).float().mean()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], *(int(x) for x in sys.argv[2:7]))

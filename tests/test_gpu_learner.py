@@ -833,6 +833,43 @@ def test_captured_update_slots_are_bit_identical_to_the_eager_update(N, T, nmb, 
         assert me == mg or all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
 
 
+@pytest.mark.parametrize("N,T,nmb,epochs", [(32, 8, 2, 2), (128, 128, 4, 4)])
+def test_captured_update_slots_cut_at_the_bucket_boundaries_are_bit_identical_to_the_eager_update(monkeypatch, N, T, nmb, epochs):
+    """The world > 1 form of a captured slot on ONE rank (MI355PPO_UPDATE_GRAPH_CUT=1: collectives skipped): three hipGraphs per slot,
+    the first ending -- and the second beginning -- on the autograd engine's thread in the middle of the backward, where the eager
+    data-parallel path starts the early bucket's all-reduce.  Bit-equal to the eager update over three iterations."""
+
+    def make(graphs):
+        torch.manual_seed(4)
+        env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=6, done_p=0.1)
+        agent = AtariAgent(env).to(DEV)
+        args = learner_smoke.default_args(num_steps=T, num_minibatches=nmb, update_epochs=epochs)
+        if graphs:
+            monkeypatch.setenv("MI355PPO_UPDATE_GRAPH_CUT", "1")
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
+        monkeypatch.delenv("MI355PPO_UPDATE_GRAPH_CUT", raising=False)
+        L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
+        if graphs:
+            L.capture_update()
+        return L, env
+
+    (Le, enve), (Lg, envg) = make(False), make(True)
+    assert all(len(s.segs) == 3 and s.early == Lg._ar_early for row in Lg._update_graphs for s in row)
+    assert all(len(s.segs) == 1 for row in (Le._update_graphs or []) for s in row)
+    assert torch.equal(Le.flat.params, Lg.flat.params) and not Lg.flat.grads.any()
+    for it in range(3):
+        learner_smoke.rollout(Le, enve)
+        learner_smoke.rollout(Lg, envg)
+        np.random.seed(100 + it)
+        me = Le.update(2.5e-4 * (1 - it / 3))
+        np.random.seed(100 + it)
+        mg = Lg.update(2.5e-4 * (1 - it / 3))
+        Le.start_iteration(); Lg.start_iteration()
+        assert torch.equal(Le.flat.params, Lg.flat.params), it
+        assert torch.equal(Le.flat.exp_avg, Lg.flat.exp_avg) and torch.equal(Le.flat.exp_avg_sq, Lg.flat.exp_avg_sq), it
+        assert me == mg or all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
+
+
 def test_captured_update_with_wide_heads_is_bit_identical_or_falls_back_cleanly():
     """18 actions (most ALE games): the heads are ``nn.Linear`` (library GEMMs + autograd's AccumulateGrad inside the capture).  Either
     the capture succeeds and replays bit-identically to the eager update, or it raises and leaves a learner that trains eagerly with

@@ -93,6 +93,44 @@ def test_config_d_whole_iteration_two_ranks_against_the_reference_lines(tmp_path
     assert not problems, "\n".join(problems + report)
 
 
+def test_config_d_whole_iteration_two_ranks_under_update_graphs(tmp_path):
+    """The same golden with the update replayed from captured graphs (world > 1: three hipGraphs per slot with the all-reduces between
+    them; bench.py's and runner.train's default route): the scalars of all 16 local minibatches and the parameters after update 16 at the
+    eager test's bars (the pre-Adam gradients are inside the graphs), replicas bit-identical."""
+    from whole_iteration import check_atari_iteration
+
+    _torchrun([os.path.join("tests", "dp_cfgd_worker.py"), str(tmp_path), "graphs"], timeout=1500)
+    g = load_golden("atari_iteration_cfgD")["atari_T128_N256_world2"]
+    outs = [dict(np.load(tmp_path / f"rank{r}.npz")) for r in (0, 1)]
+    assert outs[0]["params_checksum"] == outs[1]["params_checksum"] and np.array_equal(outs[0]["final_params_sub"], outs[1]["final_params_sub"]), \
+        "the replicas diverged"
+    problems, report = [], []
+    for r in (0, 1):
+        o = {k: (v.item() if v.ndim == 0 else v) for k, v in outs[r].items()}
+        rep = []
+        problems += [f"rank {r}: {p}" for p in check_atari_iteration(o, g, {}, sfx=f"_rank{r}", report=rep)]
+        report += [f"rank {r}: {x}" for x in rep]
+    print("\n".join(["config D whole iteration under update graphs vs the reference's lines:"] + report))
+    assert not problems, "\n".join(problems + report)
+
+
+@pytest.mark.parametrize("N,T,nmb,epochs", [(32, 8, 2, 2), (256, 128, 4, 4)])
+def test_update_graphs_with_two_ranks_are_bit_identical_to_the_eager_two_rank_update(tmp_path, N, T, nmb, epochs):
+    """``capture_update`` with world = 2: every (epoch, minibatch) slot is THREE hipGraphs -- [forward + loss + backward down to the FC
+    weight's gradient] | early bucket | [conv backward] | the rest | [clip + Adam] -- with the three all-reduces of the eager path issued
+    between the replays (ppo_atari_multigpu.py:358-377).  Two ranks on one GPU over gloo, each with an eager twin from the same seeds:
+    parameters, Adam state and logged scalars bit-equal after every one of three iterations, replicas bit-equal across the ranks -- at a
+    small shape and at BASELINE config D's per-GPU size (256 envs x 128 steps, 16 slots of 8,192 rows)."""
+    _torchrun([os.path.join("tests", "dp_graphs_worker.py"), str(tmp_path), str(N), str(T), str(nmb), str(epochs), "3"], timeout=1200)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in (0, 1))
+    for r in (r0, r1):
+        assert list(r["segs"]) == [3] and bool(r["early"]), "a slot was not cut at both bucket boundaries"
+        assert r["same"].all(), f"captured and eager learners diverged: {r['same']}"
+        assert r["scalars_same"].all()
+        assert np.array_equal(r["params"], r["params_eager"])
+    assert np.array_equal(r0["params"], r1["params"]), "the replicas diverged"
+
+
 def test_ppo_atari_multigpu_script_two_ranks_on_one_gpu():
     """The drop-in script itself, ``--cuda`` on, both ranks on device 0 (``--device-ids 0 0``), backend gloo: replicas print
     the same actor weight sum after every update while sampling different actions (per-rank seeds)."""
