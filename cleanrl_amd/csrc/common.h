@@ -27,6 +27,14 @@ int convw_launch(const float* src, const float* dz, float* part_w, float* part_b
                  const unsigned* dz_amax = nullptr, const unsigned* src_amax = nullptr);      // amax records: the two-term f16 split (f16split.h)
 
 // kernel Z (gemmz.hip): the K-split raw partials of the rollout-sized FC forward, (splits, M, N) f32 into `ws`
+// convr.hip: kernel R, the input-resident layer-3 forward and layer-2 / layer-3 data gradients on the f16 split (bit-identical to kernel Z's)
+bool convr_on(long long images);
+int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void* pack, const float* bias, float* dst, unsigned dst_bytes, unsigned* bits,
+               long long images, const unsigned* src_amax, unsigned* dst_amax, hipStream_t st);
+int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
+                 long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
+int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
+                 long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
 int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
                     hipStream_t stream, const unsigned* a_amax = nullptr);
 

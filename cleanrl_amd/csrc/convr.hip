@@ -1,0 +1,493 @@
+// Kernel R -- the INPUT-RESIDENT convolution of round 5 (two-term f16 split only): the layer-3 forward and the layer-3 / layer-2 data
+// gradients of the NatureCNN (cleanrl/ppo_atari_multigpu.py:141-142 and their backward, :358) with the source tensor of a GROUP of images
+// held in LDS, already split into f16 hi / lo planes.
+//
+// What bounded kernel Z on these launches (profiles/r05_pmc_*.csv: matrix pipe 0.24 busy, ten VALU instructions per MFMA, TA 0.7 busy,
+// waves waiting on memory 0.36): its rows are im2col rows, so every source element is fetched from the L1 / L2, written to LDS, read back
+// and SPLIT once per tap that touches it -- 9 times in the 3 x 3 layers, 4 times in the layer-2 data gradient -- inside the k-loop, on the
+// matrix instructions' critical path.  Here a workgroup
+//   * loads the f32 source of G consecutive images ONCE (contiguous, 16 bytes per lane), splits every element ONCE (f16split.h, the
+//     tensor's scale from its amax record) and stores the hi / lo halves into a padded pixel grid in LDS: record of a pixel = 64 hi
+//     halves (128 B) | 64 lo halves (128 B) | 16 B pad.  The pad makes the record pitch 17 sixteen-byte slots: "lane = pixel" fragment
+//     reads of 16 lanes with distinct pixel numbers mod 16 hit 16 distinct slots (ds_read_b128: conflict-free).  Zero padding of the data
+//     gradients = a border of zero records written once per launch;
+//   * walks the k-steps with NO address arithmetic and NO VALU in the loop: every fragment is one ds_read_b128 at (lane's window origin +
+//     compile-time offset of the tap / channel chunk), the weights come from the f16x2 pack through the workgroup's two-slot LDS ring
+//     (as kernel Z's BLDS: a k-step pair per slot, one barrier per pair), and the loop is 2 + 2 NT reads per 3 NT matrix instructions;
+//   * prefetches the NEXT group's source into registers during the last k-steps and the epilogue of the current one (one workgroup per CU
+//     holds the LDS).
+// Accumulator layout and epilogue are kernel Z's (lane = channel, accumulator e = row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the tile):
+// a 4-byte store instruction writes two whole 128-byte lines.  (The transposed layout -- lane = pixel, sixteen channels per lane in four
+// 16-byte runs -- needs a quarter of the store instructions, but each touches 32 lines a quarter at a time: measured 300 - 480 cycles per
+// store instruction, the epilogue a third of the layer-2 data gradient's group time.)
+// Arithmetic: the same products in the same order as kernel Z's SPLIT = 1 instances (k-steps in the order of z_kstep / the border classes'
+// ascending taps; per step hi hi, hi lo, lo hi; padded taps add exact zeros): the results are bit-identical to kernel Z's
+// (tools/conv_traffic hashes, tests/test_gpu_f16x2.py).
+#include "common.h"
+#include "f16split.h"
+
+#pragma clang fp contract(off)
+
+namespace mi355ppo {
+
+typedef float r_f32x16 __attribute__((ext_vector_type(16)));
+typedef float r_f32x4 __attribute__((ext_vector_type(4)));
+
+enum { R_BIAS_RELU = 0, R_BIAS_RELU_BITS = 1, R_MASKB = 2, R_MASKB_CLS4 = 3 };
+
+constexpr unsigned kROob = 0xFFFFF000u;               // buffer offset out of range for every tensor < 4 GiB - 4 KiB
+constexpr int kRRsrcWord3 = 0x00020000;               // raw buffer, 32-bit elements
+constexpr int kRPix = 272;                            // bytes per pixel record in LDS: 128 hi | 128 lo | 16 pad
+
+// Source (images, IH, IW, 64) f32 channels-last, zero border of HL pixels, window KH x KW at stride 1 over the padded grid, output grid
+// OH x OW per image; NT 32-column tiles of the pack; G images per group on NW waves of MT 32-row tiles each; destination pixel of grid
+// pixel (gy, gx) and column tile j: R_MASKB_CLS4 -> (2 gy + (j >> 1), 2 gx + (j & 1)) of a (2 OH, 2 OW, 32) image, else pixel (gy, gx) of
+// an (OH, OW, 32 NT) image.  ORDER 1: the layer-3 forward's phase order of kernel Z (z_kstep), 0: ascending.
+template <int IH_, int IW_, int HL_, int KH_, int KW_, int OH_, int OW_, int NT_, int G_, int NW_, int MT_, int ORDER_, int SS_, int WGS_>
+struct RGeom {
+    static constexpr int IH = IH_, IW = IW_, HL = HL_, KH = KH_, KW = KW_, OH = OH_, OW = OW_, NT = NT_, G = G_, NW = NW_, MT = MT_, ORDER = ORDER_;
+    static constexpr int SS = SS_;                                                  // k-steps per ring slot (one barrier per slot)
+    static constexpr int WGS = WGS_;                                                // workgroups per CU the kernel is sized for (LDS, registers)
+    static constexpr int IHP = IH + 2 * HL, IWP = IW + 2 * HL, IPIX = IHP * IWP, OP = OH * OW, ROWS = G * OP, SLOTS = 32 * MT * NW;
+    static constexpr int KSTEPS = KH * KW * 4, SPR = KW * 4;
+    static constexpr int IMGB = IPIX * kRPix, ABYTES = G * IMGB;
+    static constexpr int STEPB = NT * 2048, SLOTB = SS * STEPB;                     // one k-step of the pack; ring slot
+    static constexpr int UNITS = G * IH * IW * 16;                                  // 16-byte units of a group's source
+    static constexpr int THREADS = 64 * NW, NI = (UNITS + THREADS - 1) / THREADS;
+    static_assert(ROWS <= SLOTS && KSTEPS % SS == 0, "a group's rows fit the waves' tiles; whole ring slots");
+    static_assert((ABYTES + 2 * SLOTB) * WGS <= 160 * 1024, "LDS");
+};
+// One workgroup of four waves per CU (one wave per SIMD, 64 rows per wave), against two workgroups per CU with half the images each:
+// profiles/r05_kernel_r_configs.txt.
+using RConv3 = RGeom<9, 9, 0, 3, 3, 7, 7, 2, 5, 4, 2, 1, 6, 1>;          // a2 (9, 9, 64) -> a3 (7, 7, 64): 245 rows of 256
+using RDgrad3 = RGeom<7, 7, 2, 3, 3, 9, 9, 2, 3, 4, 2, 0, 6, 1>;         // dz3 (7, 7, 64) -> da2 (9, 9, 64): 243 rows of 256
+using RDgrad2 = RGeom<9, 9, 1, 2, 2, 10, 10, 4, 2, 4, 2, 0, 4, 1>;       // dz2 (9, 9, 64) -> da1 (20, 20, 32), four stride-parity classes = four column tiles: 200 rows of 256
+
+// Which row of the group sits in which lane.  A fragment read (ds_read_b128, lane = row) is served in groups of 16 lanes -- {0-3, 12-15,
+// 20-27} and {4-11, 16-19, 28-31} of each wave half -- and is conflict-free when the 16 records start in 16 different sixteen-byte slots of
+// the 256-byte bank row, i.e. (record pitch = 17 slots) when the 16 window origins differ mod 16.  Raster order does not give that (a
+// line of 7 or 9 outputs, then a jump); any order of the rows is as good as any other for everything else, so the table deals the rows
+// to the 16-lane sets by the residue of their window origin: set s never gets a residue twice while another set can still take it.
+// Slot = (wave MT + tile) 32 + lane % 32; slots without a row re-read row 0 (never stored).
+template <class RG>
+struct RRowTable {
+    short row[RG::SLOTS];
+    constexpr RRowTable() : row{} {
+        constexpr int NSET = RG::SLOTS / 16;
+        int fill[NSET] = {};
+        bool has[NSET][16] = {};
+        int slot_of[NSET][16] = {};                        // k-th lane (0..15) of set s -> slot
+        for (int s = 0; s < NSET; ++s) {
+            int k = 0;
+            for (int l = 0; l < 32; ++l) {
+                const bool first = l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28);
+                if (first == ((s & 1) == 0)) slot_of[s][k++] = (s >> 1) * 32 + l;
+            }
+        }
+        for (int i = 0; i < RG::SLOTS; ++i) row[i] = -1;
+        int next = 0;
+        for (int pass = 0; pass < 2; ++pass)               // pass 0: conflict-free placements only; pass 1: whatever is left, anywhere
+            for (int r = 0; r < RG::ROWS; ++r) {
+                const int gi = r / RG::OP, p = r - gi * RG::OP, gy = p / RG::OW, gx = p - gy * RG::OW;
+                const int c = (gi * RG::IPIX + gy * RG::IWP + gx) & 15;
+                bool placed = false;
+                for (int i = 0; i < RG::SLOTS && !placed; ++i) placed = row[i] == r;
+                for (int t = 0; t < NSET && !placed; ++t) {
+                    const int s = (next + t) % NSET;
+                    if (fill[s] < 16 && (pass == 1 || !has[s][c])) {
+                        row[slot_of[s][fill[s]++]] = (short)r;
+                        has[s][c] = true;
+                        placed = true;
+                        next = s + 1;
+                    }
+                }
+            }
+    }
+};
+
+// visited index v -> (k-step of the pack, byte offset of the step's hi fragment from the lane's window origin)
+template <class RG>
+__device__ __forceinline__ constexpr int r_kstep(int v) {
+    if constexpr (RG::ORDER == 1) {
+        const int lp = v >= 18 ? 1 : 0, w = v - 18 * lp, combo = w >> 1;
+        const int ty = combo / 3, tx = combo - 3 * ty;
+        return ty * RG::SPR + 4 * tx + 2 * lp + (w & 1);
+    } else {
+        return v;
+    }
+}
+template <class RG>
+__device__ __forceinline__ constexpr int r_tapoff(int ks) {
+    const int ty = ks / RG::SPR, us = ks - ty * RG::SPR, tx = us >> 2, chunk = us & 3;
+    return (ty * RG::IWP + tx) * kRPix + chunk * 32;
+}
+
+// lane `l` of w := the wave-uniform value x; x where bit (lane) of {hi, lo} is set, else 0 (gemmz.hip's z_writelane / z_keep_where: the
+// s_nop covers the two wait states a VALU read of an SGPR needs behind the VALU write the compiler cannot see inside the asm)
+__device__ __forceinline__ int r_writelane(int w, unsigned x, int l) {
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(x), "i"(l));
+    return w;
+}
+__device__ __forceinline__ float r_keep_where(float x, unsigned lo, unsigned hi) {
+    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+    float r;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    return r;
+}
+
+struct RArgs {
+    const float* A;             // source tensor (images, IH, IW, 64)
+    unsigned a_bytes;
+    const unsigned char* pack;  // f16x2 pack of the weights (header + [k-step][tile][hi, lo][lane][8 f16])
+    const float* bias;          // R_BIAS_RELU*
+    const unsigned* bits_in;    // R_MASKB*: the ReLU mask of the destination's activation, one bit per element
+    unsigned* bits_out;         // R_BIAS_RELU_BITS
+    float* C;
+    unsigned c_bytes;
+    long long images;
+    int groups;
+    const unsigned* a_amax;     // amax record of A
+    unsigned* c_amax;           // amax record of C to fold into, or null
+    unsigned long long* trace;  // MI355PPO_R_TRACE=1 (diagnosis): s_memtime stamps of workgroup 0's phases, [group visit < 4][phase < 8][wave]
+};
+
+template <class RG, int EPI>
+__global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG::NW + 3) / 4 * RG::WGS, (RG::NW + 3) / 4 * RG::WGS))) void r_kernel(RArgs a) {
+    constexpr int NT = RG::NT, MT = RG::MT, NW = RG::NW, NI = RG::NI, THREADS = RG::THREADS;
+    constexpr int SS = RG::SS, NSLOT = RG::KSTEPS / SS;
+    constexpr int kPieces = SS * NT * 2;                  // KiB pieces of a ring slot: (step h of the slot, tile j, term t), x = (h NT + j) 2 + t
+    constexpr int kShare = kPieces / NW;
+    static_assert(kPieces % NW == 0, "whole pieces per wave");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RG::ABYTES + 2 * RG::SLOTB];
+    unsigned char* const ring = lds + RG::ABYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int ea = f16_scale_exp(amax_load(a.a_amax, lane));
+    const int eb = f16_scale_exp(*reinterpret_cast<const unsigned*>(a.pack));
+    const float sa = f16_pow2(ea), un = f16_unscale(ea, eb);
+
+    // ---- rows of a group.  Slot (wave MT + i) 32 + x holds row table.row[...] of the group (empty slots repeat row 0: the same values
+    // stored twice).  A-fragment reads: lane -> slot x = lane % 32 of tile i.  Epilogue: accumulator e of tile i -> slot x = (e & 3) +
+    // 8 (e >> 2) + 4 lh; `roff[i][e]` = byte offset of that row's first channel in C for image 0 of the group (+ the lane's channel).
+    constexpr RRowTable<RG> table{};
+    auto row_pixel = [&](int slot, int& gi, int& pp, int& gy, int& gx) {
+        const int r0 = table.row[slot], rc = r0 < 0 ? 0 : r0;
+        gi = rc / RG::OP; pp = rc - gi * RG::OP; gy = pp / RG::OW; gx = pp - gy * RG::OW;
+    };
+    auto row_coff = [&](int gi, int pp, int gy, int gx) -> unsigned {      // C offset of the row (tile j = 0) within the group
+        if constexpr (EPI == R_MASKB_CLS4) return (unsigned)(((gi * (2 * RG::OH) + 2 * gy) * (2 * RG::OW) + 2 * gx) * 32) * 4u;
+        else return (unsigned)((gi * RG::OP + pp) * (32 * NT)) * 4u;
+    };
+    const unsigned char* win[MT];                         // window origin of the lane's fragment row (+ the lane half's 8 channels)
+    unsigned roff[MT][16], rlane = 0u, rword[MT];         // rlane: C offset of slot row `lane` of the wave's 32 MT rows (mask words in); rword[i]: of slot row li of tile i (mask words out)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int gi, pp, gy, gx;
+        row_pixel((wave * MT + i) * 32 + li, gi, pp, gy, gx);
+        win[i] = lds + gi * RG::IMGB + (gy * RG::IWP + gx) * kRPix + 16 * lh;
+        rword[i] = row_coff(gi, pp, gy, gx);
+        if (MT == 1 || lh == i) rlane = rword[i];                         // (MT = 2: lanes 0..31 tile 0, lanes 32..63 tile 1; MT = 1: both halves tile 0)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            row_pixel((wave * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, gi, pp, gy, gx);
+            roff[i][e] = row_coff(gi, pp, gy, gx) + 4u * (unsigned)li;
+        }
+    }
+    static_assert(MT <= 2, "mask words: one lane per row of the wave");
+    unsigned char* const ring_l = ring + 16 * lane;
+
+    // ---- the group's source: unit u = 16 bytes = 4 channels of a pixel; thread tid takes units it * THREADS + tid
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)a.a_bytes, kRRsrcWord3);
+    unsigned udst[NI];                                    // LDS byte address of the unit's hi half (lo: + 128); ~0u: no such unit
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int u = it * THREADS + tid;
+        const int pix = u >> 4, c4 = u & 15, img = pix / (RG::IH * RG::IW), q = pix - img * (RG::IH * RG::IW), qy = q / RG::IW, qx = q - qy * RG::IW;
+        udst[it] = u < RG::UNITS ? (unsigned)(img * RG::IMGB + ((qy + RG::HL) * RG::IWP + qx + RG::HL) * kRPix + c4 * 8) : ~0u;
+    }
+    constexpr int kPrePer = 2;                            // loads of the next group's source issued per k-step
+    static_assert((RG::KSTEPS - 1) * kPrePer >= NI, "the next group's source is requested inside one k-loop");
+    s_u32x4 pre[NI];
+    // (issued unconditionally -- past the last group with out-of-range offsets, which load zeros without touching memory: loads behind a
+    //  branch leave the compiler without a count of the outstanding ones, and every later wait for a weight piece became "all of them")
+    auto prefetch = [&](int grp, int it0, int n) {        // units past the tensor (last group) load zeros: their rows are never stored
+        const bool any = grp < a.groups;
+        const unsigned base = (unsigned)grp * (unsigned)(RG::UNITS * 16);
+#pragma unroll
+        for (int it = it0; it < it0 + n && it < NI; ++it) {
+            const int u = it * THREADS + tid;
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (any && u < RG::UNITS) ? base + (unsigned)u * 16u : kROob, 0, 0));
+        }
+    };
+    auto fill = [&]() {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            unsigned hi[2], lo[2];
+            f16_split4(pre[it], sa, hi, lo);
+            if (udst[it] != ~0u) {
+                *reinterpret_cast<uint2*>(lds + udst[it]) = make_uint2(hi[0], hi[1]);
+                *reinterpret_cast<uint2*>(lds + udst[it] + 128) = make_uint2(lo[0], lo[1]);
+            }
+        }
+    };
+    if constexpr (RG::HL > 0) {                           // the zero border (and everything else, once)
+        for (int o = tid * 16; o < RG::ABYTES; o += THREADS * 16) *reinterpret_cast<s_u32x4*>(lds + o) = (s_u32x4){0u, 0u, 0u, 0u};
+    }
+
+    // ---- epilogue constants
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)a.c_bytes, kRRsrcWord3);
+    const void* const bits_base = EPI == R_BIAS_RELU_BITS ? (const void*)a.bits_out : (const void*)a.bits_in;
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(bits_base), 0, EPI == R_BIAS_RELU ? 0 : (int)(a.c_bytes >> 5), kRRsrcWord3);
+    float bj[NT];                                         // R_BIAS_RELU*: the lane's bias element per column tile
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bj[j] = (EPI == R_BIAS_RELU || EPI == R_BIAS_RELU_BITS) ? a.bias[32 * j + li] : 0.0f;
+    constexpr unsigned kGroupC = (EPI == R_MASKB_CLS4 ? RG::G * 4 * RG::OP * 32 : RG::G * RG::OP * 32 * NT) * 4;      // bytes of C per group
+    auto joff = [](int j) -> int {                        // byte offset of column tile j from the row's first channel
+        return EPI == R_MASKB_CLS4 ? ((j >> 1) * (2 * RG::OW) + (j & 1)) * 32 * 4 : 32 * j * 4;
+    };
+    float cmax = 0.0f;
+
+    // the pack through a buffer resource: per-lane offset 16 lane in ONE register, the piece's offset in an SGPR (64-bit per-piece addresses
+    // of the unrolled loop cost 70 registers)
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.pack), 0, kF16PackHeader + RG::KSTEPS * RG::STEPB, kRRsrcWord3);
+    const unsigned lane16 = 16u * (unsigned)lane;
+    // The weights' ring: slot s = the visited k-steps SS s .. SS s + SS - 1, 2 buffers.  Wave w moves pieces w kShare .. + kShare - 1 of a slot: global ->
+    // registers TWO slots ahead of the write (vector loads return in order and the next group's source -- a trip to HBM -- travels in the
+    // same queue: one slot of distance left the ring waiting), registers -> buffer (s + 1) & 1 at the first step of slot s -- every wave
+    // read that buffer (slot s - 1) for the last time before the barrier of slot s - 1 --, and the barrier of slot s (at its LAST step)
+    // stands between these writes and the first reads of slot s + 1 (issued during that last step, for the step after it).  The weights
+    // are the same for every group: with an even number of slots (the sets' parity carries over) the first two slots of the NEXT group are fetched during the last two
+    // slots of this one (the sets are free by then), so a group starts with its weights in registers.
+    s_u32x4 bst[2][kShare];                               // slot s travels in set s & 1
+    auto load_slot = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < kShare; ++u) {
+            const int x = wave * kShare + u, h = x / (NT * 2), jt = x - h * (NT * 2);       // (wave-uniform: scalar arithmetic)
+            bst[slot & 1][u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, lane16, kF16PackHeader + r_kstep<RG>(SS * slot + h) * RG::STEPB + jt * 1024, 0));
+        }
+    };
+    auto write_slot = [&](int slot) {                     // -> buffer slot & 1
+#pragma unroll
+        for (int u = 0; u < kShare; ++u) *reinterpret_cast<s_u32x4*>(ring_l + (slot & 1) * RG::SLOTB + (wave * kShare + u) * 1024) = bst[slot & 1][u];
+    };
+    auto ring_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    int grp = blockIdx.x, visit = 0;
+    auto stamp = [&](int phase) {
+        if (a.trace && blockIdx.x == 0 && visit < 4 && lane == 0) a.trace[(visit * 8 + phase) * NW + wave] = __builtin_amdgcn_s_memtime();
+    };
+    constexpr bool kCarry = NSLOT % 2 == 0 && NSLOT >= 4;  // slots 0 and 1 of the next group travel in the sets across the group boundary
+    if (grp < a.groups) {
+        prefetch(grp, 0, NI);
+        if constexpr (kCarry) { load_slot(0); load_slot(1); }
+    }
+    for (; grp < a.groups; grp += gridDim.x, ++visit) {
+        stamp(0);
+        // every wave is done with the previous group's records and ring slots
+        __syncthreads();
+        stamp(1);
+        fill();
+        stamp(2);
+        if constexpr (!kCarry) { load_slot(0); load_slot(1); }
+        __builtin_amdgcn_sched_barrier(0);
+        write_slot(0);
+        load_slot(2);
+        ring_barrier();
+        stamp(3);
+
+        r_f32x16 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        s_u32x4 pa[2][MT][2], wb[2][NT][2];               // [k-step parity]: pixel fragments [tile][hi, lo]; weight fragments [tile][hi, lo]
+        auto read_a = [&](int par, int v) {
+            const int off = r_tapoff<RG>(r_kstep<RG>(v));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                pa[par][i][0] = *reinterpret_cast<const s_u32x4*>(win[i] + off);
+                pa[par][i][1] = *reinterpret_cast<const s_u32x4*>(win[i] + off + 128);
+            }
+        };
+        auto read_b = [&](int par, int v) {               // step v = step v % SS of slot v / SS
+            const int buf = (v / SS) & 1, h = v % SS;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wb[par][j][t] = *reinterpret_cast<const s_u32x4*>(ring_l + buf * RG::SLOTB + ((h * NT + j) * 2 + t) * 1024);
+        };
+        read_a(0, 0);
+        read_b(0, 0);
+#pragma unroll
+        for (int v = 0; v < RG::KSTEPS; ++v) {
+            const int q = v & 1, slot = v / SS, h = v % SS;
+            // the operands of step v + 1 are requested before the matrix instructions of step v go out (a wave cannot run ahead of the matrix
+            // pipe: whatever is issued behind a step's MFMAs starts when they end)
+            if (v + 1 < RG::KSTEPS) {
+                if (h == SS - 1) ring_barrier();          // slot + 1 has landed in its buffer (written at the first step of this slot)
+                read_b(q ^ 1, v + 1);
+                read_a(q ^ 1, v + 1);
+            }
+            if (h == 0) {
+                if (slot + 1 < NSLOT) write_slot(slot + 1);
+                if (slot + 3 < NSLOT) load_slot(slot + 3);
+                else if (kCarry && slot + 3 - NSLOT < 2) load_slot(slot + 3 - NSLOT);     // (the last group fetches them for nobody)
+            }
+            // the next group's source, a few loads per step from the second step on: the whole group at once (104 KB per CU in the layer-3
+            // forward) exceeds what a CU keeps in flight and held the issuing waves -- and the matrix pipe behind them -- for 7,000 cycles
+            if (v >= 1 && (v - 1) * kPrePer < NI) prefetch(grp + gridDim.x, (v - 1) * kPrePer, kPrePer);
+            if (a.trace && blockIdx.x == 0 && visit == 1 && lane == 0 && wave == 0) a.trace[4 * 8 * NW + v] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            // hi hi, hi lo (weights), lo hi (pixels): kernel Z's order of the three term pairs, tiles innermost
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, pa[q][i][pi == 2 ? 1 : 0]),
+                                                                           __builtin_bit_cast(s_f16x8, wb[q][j][pi == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        stamp(4);
+        // ---- epilogue (kernel Z's): accumulator e of tile (i, j) = row slot (e & 3) + 8 (e >> 2) + 4 lh of tile i, channel 32 j + li.
+        // Every offset carries the group's base, so rows of images past the batch fall out of the buffer's range: stores dropped, mask
+        // words read as zero.
+        const unsigned gbase = (unsigned)grp * kGroupC;
+        float gmax = 0.0f;
+        if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
+            unsigned wm[NT];                              // lane L: the mask word of slot row L of the wave's rows, per column tile
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wm[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_b, (gbase + rlane + (unsigned)joff(j)) >> 5, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned ro = gbase + roff[i][e];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wm[j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2));
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)wm[j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2) + 4);
+                        const float v = r_keep_where(acc[i][j][e] * un, lo, hi);  // lanes 0..31 (lh = 0): bit li of `lo`, lanes 32..63: of `hi`
+                        gmax = __builtin_fmaxf(gmax, __builtin_fabsf(v));
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, ro + (unsigned)joff(j), 0, 0);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                int wv[NT];                               // R_BIAS_RELU_BITS: lane L (< 32) collects the mask word of slot row L of tile i
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wv[j] = 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned ro = gbase + roff[i][e];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        float v = acc[i][j][e] * un + bj[j];
+                        v = v < 0.0f ? 0.0f : v;                              // (a NaN stays a NaN, as kernel Z's SPLIT epilogue)
+                        gmax = __builtin_fmaxf(gmax, __builtin_fabsf(v));
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, ro + (unsigned)joff(j), 0, 0);
+                        if constexpr (EPI == R_BIAS_RELU_BITS) {              // lanes 0..31 of the ballot: the 32 channels of slot row (e & 3) + 8 (e >> 2); 32..63: of that row + 4
+                            const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.0f);
+                            wv[j] = r_writelane(wv[j], (unsigned)bal, (e & 3) + 8 * (e >> 2));
+                            wv[j] = r_writelane(wv[j], (unsigned)(bal >> 32), (e & 3) + 8 * (e >> 2) + 4);
+                        }
+                    }
+                }
+                if constexpr (EPI == R_BIAS_RELU_BITS) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b32((unsigned)wv[j], rsrc_b, lh == 0 ? (gbase + rword[i] + (unsigned)joff(j)) >> 5 : kROob, 0, 0);
+                }
+            }
+        }
+        cmax = __builtin_fmaxf(cmax, gmax);               // (rows past the batch multiply zeros: 0, or relu(bias) of a real channel -- see below)
+        stamp(5);
+    }
+    if (a.c_amax) amax_commit(a.c_amax, __float_as_uint(cmax), blockIdx.x * NW + (unsigned)wave, lane);
+}
+
+template <class RG, int EPI>
+static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
+    RArgs a = a0;
+    a.groups = (int)((a.images + RG::G - 1) / RG::G);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;
+        }
+        cus = n;
+    }
+    const int grid = a.groups < cus * RG::WGS ? a.groups : cus * RG::WGS;
+    static const bool tracing = getenv("MI355PPO_R_TRACE") != nullptr;
+    static unsigned long long* tbuf = nullptr;
+    if (tracing) {
+        if (!tbuf && hipMalloc(&tbuf, (4 * 8 * RG::NW + 64) * 8) != hipSuccess) tbuf = nullptr;
+        if (tbuf) (void)hipMemsetAsync(tbuf, 0, (4 * 8 * RG::NW + 64) * 8, s);
+        a.trace = tbuf;
+    }
+    hipLaunchKernelGGL((r_kernel<RG, EPI>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
+    if (tracing && tbuf) {
+        unsigned long long h[4 * 8 * RG::NW + 64];
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, tbuf, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            const unsigned long long t0 = h[0];
+            fprintf(stderr, "[r_trace] %s groups=%d grid=%d (ticks since the first stamp; phases: 0 top, 1 past the barrier, 2 filled, 3 ring ready, 4 k-loop done, 5 stored)\n", what, a.groups, grid);
+            for (int v = 0; v < 4; ++v)
+                for (int w = 0; w < RG::NW; w += RG::NW - 1) {
+                    fprintf(stderr, "[r_trace]  visit %d wave %d:", v, w);
+                    for (int ph = 0; ph < 6; ++ph) fprintf(stderr, " %8lld", (long long)(h[(v * 8 + ph) * RG::NW + w] - t0));
+                    fprintf(stderr, "\n");
+                }
+            fprintf(stderr, "[r_trace]  visit 1 wave 0, ticks between the k-steps:");
+            for (int v = 1; v < RG::KSTEPS; ++v) fprintf(stderr, " %lld", (long long)(h[4 * 8 * RG::NW + v] - h[4 * 8 * RG::NW + v - 1]));
+            fprintf(stderr, "\n");
+        }
+    }
+    return check_launch(what);
+}
+
+// Kernel R takes a launch from `MI355PPO_CONV_R_MIN` images on (default 16,384: one persistent workgroup per CU pays its start -- the
+// table, the border fill, an unhidden first load -- once, and below ~8,192 images that is not recovered: profiles/r05_kernel_r_ab.jsonl);
+// MI355PPO_CONV_R=0: never (same-box A/B runs; the results are bit-identical either way).  Read at every call: tests switch them.
+bool convr_on(long long images) {
+    const char* e = getenv("MI355PPO_CONV_R");
+    if (e && e[0] == '0') return false;
+    const char* m = getenv("MI355PPO_CONV_R_MIN");
+    return images >= (m ? atoll(m) : 16384LL);
+}
+
+int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void* pack, const float* bias, float* dst, unsigned dst_bytes, unsigned* bits,
+               long long images, const unsigned* src_amax, unsigned* dst_amax, hipStream_t st) {
+    RArgs a{};
+    a.A = src; a.a_bytes = src_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.bits_out = bits; a.C = dst; a.c_bytes = dst_bytes;
+    a.images = images; a.a_amax = src_amax; a.c_amax = dst_amax;
+    return bits ? r_launch<RConv3, R_BIAS_RELU_BITS>(a, st, fn) : r_launch<RConv3, R_BIAS_RELU>(a, st, fn);
+}
+
+int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
+                 long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st) {
+    RArgs a{};
+    a.A = dz; a.a_bytes = dz_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bits_in = bits; a.C = dsrc; a.c_bytes = dsrc_bytes;
+    a.images = images; a.a_amax = dz_amax; a.c_amax = dsrc_amax;
+    return r_launch<RDgrad3, R_MASKB>(a, st, fn);
+}
+
+int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
+                 long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st) {
+    RArgs a{};
+    a.A = dz; a.a_bytes = dz_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bits_in = bits; a.C = dsrc; a.c_bytes = dsrc_bytes;
+    a.images = images; a.a_amax = dz_amax; a.c_amax = dsrc_amax;
+    return r_launch<RDgrad2, R_MASKB_CLS4>(a, st, fn);
+}
+
+}  // namespace mi355ppo

@@ -1339,6 +1339,8 @@ static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pa
         if (bits) return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2>(za, st, fn);
         return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
     }
+    if (src_amax && convr_on(images))          // f16 split: kernel R (convr.hip), the source of an image group resident in LDS
+        return convr_fwd3(fn, src, (unsigned)srcb, pack, bias, dst, (unsigned)((long long)images * 49 * 64 * 4), bits, images, src_amax, dst_amax, st);
     ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
     za.bits_out = bits;
     za.a_amax = src_amax; za.c_amax = dst_amax;
@@ -1375,6 +1377,11 @@ static int conv_dgrad_packed_impl(const char* fn, const float* dz, const void* p
                   "%s: dz (%lld bytes) and dsrc (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb, dstb);
     hipStream_t st = as_stream(stream);
     if (layer == 3) {      // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
+        // (kernel R's layer-3 data gradient multiplies the zero border -- 1.65 x the valid taps -- and runs 1.09 x kernel Z's time: off unless
+        //  MI355PPO_CONV_R3=1; profiles/r05_kernel_r_ab.jsonl)
+        const char* e3 = getenv("MI355PPO_CONV_R3");
+        const bool r3 = e3 && e3[0] == '1';
+        if (dz_amax && bits && r3 && convr_on(images)) return convr_dgrad3(fn, dz, (unsigned)srcb, pack, bits, dsrc, (unsigned)dstb, images, dz_amax, dsrc_amax, st);
         ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K, images);
         za.bits_in = bits;
         za.a_amax = dz_amax; za.c_amax = dsrc_amax;
@@ -1382,6 +1389,9 @@ static int conv_dgrad_packed_impl(const char* fn, const float* dz, const void* p
         return z_blds(images) ? z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2, true>(za, st, fn) : z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, st, fn);
     }
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
+    const char* e2 = getenv("MI355PPO_CONV_R2");
+    const bool r2 = !(e2 && e2[0] == '0');
+    if (dz_amax && bits && r2 && convr_on(images)) return convr_dgrad2(fn, dz, (unsigned)srcb, pack, bits, dsrc, (unsigned)dstb, images, dz_amax, dsrc_amax, st);
     ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K, images);
     za.bits_in = bits;
     za.a_amax = dz_amax; za.c_amax = dsrc_amax;

@@ -164,6 +164,64 @@ def test_conv_forward_f16x2_against_float64(layer, images):
     assert torch.equal(cnn.unpack_mask_bits(bits, y2.shape), y2 > 0) and cnn.amax_value(ry2) == y2.max().item()
 
 
+@pytest.mark.parametrize("images", [1, 4, 5, 61, 1027])
+def test_kernel_r_forward_layer3_is_kernel_z_bit_for_bit(monkeypatch, images):
+    """Kernel R (csrc/convr.hip: the source of an image group resident in LDS, split once) against kernel Z on the layer-3 forward, with and
+    without the mask bits, at sizes with partial last groups (5 images per group): output, mask words and the output's amax record equal
+    bit for bit -- the same products in the same order --, and the output within the float64 bar."""
+    cin, cout, k, st, hin, hout = SPEC[3]
+    W, b = _params(3, 77 + images)
+    g = torch.Generator(device=DEV).manual_seed(images)
+    x = torch.relu(torch.randn(images, hin, hin, cin, device=DEV, generator=g)) * torch.exp(torch.randn(images, hin, hin, cin, device=DEV, generator=g))
+    pack = cnn.conv_zpack_f16x2(W, 3, cnn.MODE_FWD)
+    rx = _rec_of(x)
+    out = {}
+    for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("R", {"MI355PPO_CONV_R": "1", "MI355PPO_CONV_R_MIN": "1"})):
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        ry, ry2 = cnn.new_amax(2, DEV)
+        y = cnn.conv_fwd_packed(x, pack, b, 3, amax=(rx, ry))
+        bits = torch.zeros(cnn.mask_words(y.numel()), dtype=torch.int32, device=DEV)
+        y2 = cnn.conv_fwd_packed(x, pack, b, 3, bits=bits, amax=(rx, ry2))
+        out[route] = (y, y2, bits, cnn.amax_value(ry), cnn.amax_value(ry2))
+    (yz, yz2, bz, az, az2), (yr, yr2, br, ar, ar2) = out["Z"], out["R"]
+    assert torch.equal(yr.view(torch.int32), yr2.view(torch.int32)) and torch.equal(br, bz) and ar == az == ar2 == yr.max().item()
+    if images >= 768:                                    # (below, kernel Z runs its 32-row tiles without the bits and 64-row tiles with them)
+        assert torch.equal(yr.view(torch.int32), yz.view(torch.int32))
+    assert torch.equal(yr2.view(torch.int32), yz2.view(torch.int32))
+    _close(yr, torch.relu(_conv64(x.double(), W.double(), b.double(), st)), f"kernel R conv3 fwd, {images} images")
+
+
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("images", [1, 2, 3, 61, 1027])
+def test_kernel_r_data_gradients_are_kernel_z_bit_for_bit(monkeypatch, layer, images):
+    """The layer-2 (default from 16,384 images) and layer-3 (MI355PPO_CONV_R3=1) data gradients on kernel R against kernel Z: gradient and its
+    amax record bit-equal (the zero border adds exact zeros where kernel Z's border classes skip the taps), within the float64 bar."""
+    cin, cout, k, st, hin, hout = SPEC[layer]
+    W, _ = _params(layer, 20 * layer + images)
+    g = torch.Generator(device=DEV).manual_seed(3 * images + layer)
+    act = torch.randn(images, hin, hin, cin, device=DEV, generator=g)
+    dz = (torch.randn(images, hout, hout, cout, device=DEV, generator=g) * torch.exp2(-14 * torch.rand(images, 1, 1, 1, device=DEV, generator=g)) * 1e-3
+          * (torch.rand(images, hout, hout, cout, device=DEV, generator=g) > 0.5))
+    m = (act > 0).reshape(-1, 32).to(torch.int64)                     # word w, bit b <-> element 32 w + b of the flat activation
+    w = (m << torch.arange(32, device=DEV)).sum(1)
+    bits = ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32)
+    assert torch.equal(cnn.unpack_mask_bits(bits, act.shape), act > 0)
+    pack = cnn.conv_zpack_f16x2(W, layer, cnn.MODE_DGRAD_S2 if layer == 2 else cnn.MODE_DGRAD_S1)
+    rz = _rec_of(dz)
+    out = {}
+    for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("R", {"MI355PPO_CONV_R": "1", "MI355PPO_CONV_R_MIN": "1", "MI355PPO_CONV_R3": "1"})):
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        rd = cnn.new_amax(1, DEV)[0]
+        got = cnn.conv_dgrad_packed(dz, pack, None, layer, bits=bits, amax=(rz, rd))
+        out[route] = (got, cnn.amax_value(rd))
+    assert torch.equal(out["R"][0].view(torch.int32), out["Z"][0].view(torch.int32)) and out["R"][1] == out["Z"][1] == out["R"][0].abs().max().item()
+    x = act.double().requires_grad_(True)
+    _conv64(x, W.double(), None, st).backward(dz.double())
+    _close(out["R"][0], x.grad * (act > 0), f"kernel R conv{layer} dgrad, {images} images")
+
+
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 37, 64, 700, 2100])
 def test_conv_data_gradient_f16x2_against_float64(layer, images):
