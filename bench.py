@@ -71,6 +71,9 @@ KERNEL_INFO = {
     "Zh": ("z_kernel<..., SPLIT = 1> (csrc/gemmz.hip): f16 MFMA on two-term splits under per-tensor power-of-two scales (amax records), "
            "weights pre-split into fragment order, activations loaded coalesced through wave-private LDS; un-scale + bias + ReLU / the "
            "ReLU-backward mask + the result's amax in the epilogue", "f16", 3),
+    "Rh": ("r_kernel (csrc/convr.hip): f16 MFMA on two-term splits with the SOURCE of a group of images resident in LDS, split once (kernel Z "
+           "splits every element once per tap that reads it); weights from the f16x2 pack through an LDS ring; kernel Z's epilogue; results "
+           "bit-identical to kernel Z's", "f16", 3),
     "Vh": ("convw_bf16_kernel<..., SPLIT = 1> (csrc/convw.hip): f16 MFMA on two-term splits, both operands transposed through LDS; bias "
            "gradient fused", "f16", 3),
     "Wh": ("fcw_bf16_kernel<3, 1> (csrc/fcw.hip): f16 MFMA on two-term splits, both operands transposed through LDS", "f16", 3),
@@ -417,10 +420,16 @@ def main():
             timed_op("conv_wgrad", k_wgrad)
             # (amax: the two-term f16 split of round 5 -- the same kernels, letter + "h")
             h = lambda letter, amax: letter + "h" if amax is not None and letter in ("Z", "W", "V") else letter      # (kernels Y / T ignore the records)
+
+            def zr(images, layer, dgrad, bits, amax):       # kernel R takes some of kernel Z's f16x2 launches (csrc/convr.hip): ask the library
+                if amax is None or (dgrad and bits is None):
+                    return h("Z", amax)
+                return "Rh" if chr(lib.mi355ppo_cnn_conv_packed_kernel_f16x2(images, layer, dgrad)) == "R" else "Zh"
+
             timed_op("conv1q_fwd_bits", lambda obs, pack, bias, inds, out, bits: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))
             timed_op("conv1q_fwd_amax", lambda obs, pack, bias, inds, out, bits, dst_amax: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))
-            timed_op("conv_fwd_packed", lambda src, pack, bias, layer, out=None, bits=None, amax=None: (f"conv{layer}_fwd@{src.shape[0]}", conv_flop(layer, src.shape[0]), h("Z", amax)))
-            timed_op("conv_dgrad_packed", lambda dz, pack, act_in, layer, out=None, bits=None, amax=None: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), h("Z", amax)))
+            timed_op("conv_fwd_packed", lambda src, pack, bias, layer, out=None, bits=None, amax=None: (f"conv{layer}_fwd@{src.shape[0]}", conv_flop(layer, src.shape[0]), zr(src.shape[0], layer, 0, bits, amax)))
+            timed_op("conv_dgrad_packed", lambda dz, pack, act_in, layer, out=None, bits=None, amax=None: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), zr(dz.shape[0], layer, 1, bits, amax)))
             timed_op("fc_fwd_relu_packed", lambda a, pack, bias, n, out=None, amax=None: (f"fc_fwd@{a.shape[0]}", 2.0 * a.shape[0] * n * a.shape[1], h("Z", amax)))
             timed_op("fc_dgrad_mask_packed", lambda dz, pack, act_in, out=None, bits=None, amax=None: (f"fc_dgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * act_in.shape[1], h("Z", amax)))
             timed_op("fc_wgrad", lambda dz, a, hwc_channels=0, out=None, amax=None: (f"fc_wgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * a.shape[1],

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mi355ppo_cnn_conv_dgrad_f32_variant": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "mi355ppo_cnn_conv_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mi355ppo_cnn_conv_wgrad_kernel": (c_int, [c_int64, c_int]),
+    "mi355ppo_cnn_conv_packed_kernel_f16x2": (c_int, [c_int64, c_int, c_int]),
     "mi355ppo_cnn_conv_wgrad_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_size_t, _P]),
     "mi355ppo_cnn_trunk_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_cnn_conv1q_pack_bytes": (c_size_t, []),
@@ -135,7 +136,7 @@ SIGNATURES = {
     "mi355ppo_obs_u8_to_f32_cpu": (c_int, [_P, _P, _P, c_int64, c_int64, c_int]),
 }
 
-ABI_VERSION = 180       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 181       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

@@ -1,5 +1,5 @@
-// Kernel R -- the INPUT-RESIDENT convolution of round 5 (two-term f16 split only): the layer-3 forward and the layer-3 / layer-2 data
-// gradients of the NatureCNN (cleanrl/ppo_atari_multigpu.py:141-142 and their backward, :358) with the source tensor of a GROUP of images
+// Kernel R -- the INPUT-RESIDENT convolution of round 5 (two-term f16 split only): the layer-3 forward and the layer-2 (layer-3: opt-in)
+// data gradients of the NatureCNN (cleanrl/ppo_atari_multigpu.py:141-142 and their backward, :358) with the source tensor of a GROUP of images
 // held in LDS, already split into f16 hi / lo planes.
 //
 // What bounded kernel Z on these launches (profiles/r05_pmc_*.csv: matrix pipe 0.24 busy, ten VALU instructions per MFMA, TA 0.7 busy,
@@ -12,10 +12,14 @@
 //     reads of 16 lanes with distinct pixel numbers mod 16 hit 16 distinct slots (ds_read_b128: conflict-free).  Zero padding of the data
 //     gradients = a border of zero records written once per launch;
 //   * walks the k-steps with NO address arithmetic and NO VALU in the loop: every fragment is one ds_read_b128 at (lane's window origin +
-//     compile-time offset of the tap / channel chunk), the weights come from the f16x2 pack through the workgroup's two-slot LDS ring
-//     (as kernel Z's BLDS: a k-step pair per slot, one barrier per pair), and the loop is 2 + 2 NT reads per 3 NT matrix instructions;
-//   * prefetches the NEXT group's source into registers during the last k-steps and the epilogue of the current one (one workgroup per CU
-//     holds the LDS).
+//     compile-time offset of the tap / channel chunk), the weights come from the f16x2 pack through the workgroup's two-buffer LDS ring
+//     (kernel Z's BLDS with slots of 4 - 6 k-steps: one barrier per slot), the operands of step v + 1 are requested before the matrix
+//     instructions of step v, and the loop is 2 MT + 2 NT reads per 3 MT NT matrix instructions;
+//   * requests the NEXT group's source two 16-byte loads per k-step into registers (one workgroup per CU holds the LDS), splits and stores
+//     it at the top of the next group.
+// Four waves of 64 rows per CU, one per SIMD; which row sits in which lane is a compile-time table that keeps the 16-lane groups of a
+// fragment read on 16 different bank slots (RRowTable).  What was measured on the way (each step bit-identical): profiles/
+// r05_tile_shape_experiments.txt; `MI355PPO_R_TRACE=1` prints workgroup 0's s_memtime stamps per phase and k-step.
 // Accumulator layout and epilogue are kernel Z's (lane = channel, accumulator e = row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the tile):
 // a 4-byte store instruction writes two whole 128-byte lines.  (The transposed layout -- lane = pixel, sixteen channels per lane in four
 // 16-byte runs -- needs a quarter of the store instructions, but each touches 32 lines a quarter at a time: measured 300 - 480 cycles per
@@ -25,6 +29,7 @@
 // (tools/conv_traffic hashes, tests/test_gpu_f16x2.py).
 #include "common.h"
 #include "f16split.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 

@@ -1314,6 +1314,15 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_maskbits_packed_f32(const float* d
 // mi355ppo_cnn_repack_weights_f32: mode 0 for the forward (N = 64 output channels, K = (tap row, tap column, input channel)),
 // mode 1 for the layer-3 data gradient (N = 64 input channels, K = (r, c, output channel), taps flipped), mode 2 for the
 // layer-2 data gradient (N = 4 stride-parity classes x 32 input channels, K = (r, c, output channel)).
+static bool conv_r_takes(long long images, int layer, bool dgrad) {      // which f16x2 launches kernel R (convr.hip) takes -- the one place that decides
+    if (!convr_on(images)) return false;
+    if (!dgrad) return layer == 3;
+    const char* e = getenv(layer == 3 ? "MI355PPO_CONV_R3" : "MI355PPO_CONV_R2");
+    // (kernel R's layer-3 data gradient multiplies the zero border -- 1.65 x the valid taps -- and runs 1.09 x kernel Z's time: opt-in;
+    //  profiles/r05_tile_shape_experiments.txt)
+    return layer == 3 ? (e && e[0] == '1') : !(e && e[0] == '0');
+}
+
 static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pack, const float* bias, float* dst, unsigned* bits,
                                 int64_t images, int layer, void* stream, const unsigned* src_amax = nullptr, unsigned* dst_amax = nullptr) {
     MI355_REQUIRE(src && pack && bias && dst, MI355PPO_EINVAL, "%s: null pointer", fn);
@@ -1339,7 +1348,7 @@ static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pa
         if (bits) return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU_BITS, false, 2>(za, st, fn);
         return z_blds(images) ? z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2, true>(za, st, fn) : z_launch<ZConv2, 2, 2, 4, Z_BIAS_RELU, false, 2>(za, st, fn);
     }
-    if (src_amax && convr_on(images))          // f16 split: kernel R (convr.hip), the source of an image group resident in LDS
+    if (src_amax && conv_r_takes(images, 3, false))      // f16 split: kernel R (convr.hip), the source of an image group resident in LDS
         return convr_fwd3(fn, src, (unsigned)srcb, pack, bias, dst, (unsigned)((long long)images * 49 * 64 * 4), bits, images, src_amax, dst_amax, st);
     ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 49 * 64 * 4, 64, (long long)images * 49, 64, ZConv3::K);
     za.bits_out = bits;
@@ -1377,11 +1386,7 @@ static int conv_dgrad_packed_impl(const char* fn, const float* dz, const void* p
                   "%s: dz (%lld bytes) and dsrc (%lld bytes) must stay below 4 GiB (32-bit buffer offsets)", fn, srcb, dstb);
     hipStream_t st = as_stream(stream);
     if (layer == 3) {      // da2 (images, 9, 9, 64) = full correlation of dz3 with the flipped taps, masked by a2 > 0
-        // (kernel R's layer-3 data gradient multiplies the zero border -- 1.65 x the valid taps -- and runs 1.09 x kernel Z's time: off unless
-        //  MI355PPO_CONV_R3=1; profiles/r05_kernel_r_ab.jsonl)
-        const char* e3 = getenv("MI355PPO_CONV_R3");
-        const bool r3 = e3 && e3[0] == '1';
-        if (dz_amax && bits && r3 && convr_on(images)) return convr_dgrad3(fn, dz, (unsigned)srcb, pack, bits, dsrc, (unsigned)dstb, images, dz_amax, dsrc_amax, st);
+        if (dz_amax && bits && conv_r_takes(images, 3, true)) return convr_dgrad3(fn, dz, (unsigned)srcb, pack, bits, dsrc, (unsigned)dstb, images, dz_amax, dsrc_amax, st);
         ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZDgrad3::K, images);
         za.bits_in = bits;
         za.a_amax = dz_amax; za.c_amax = dsrc_amax;
@@ -1389,9 +1394,7 @@ static int conv_dgrad_packed_impl(const char* fn, const float* dz, const void* p
         return z_blds(images) ? z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2, true>(za, st, fn) : z_launch<ZDgrad3, 2, 2, 4, Z_MASK, false, 2>(za, st, fn);
     }
     // da1 (images, 20, 20, 32): the four stride-parity classes are the four column tiles of one 128-column GEMM over the 10 x 10 grid
-    const char* e2 = getenv("MI355PPO_CONV_R2");
-    const bool r2 = !(e2 && e2[0] == '0');
-    if (dz_amax && bits && r2 && convr_on(images)) return convr_dgrad2(fn, dz, (unsigned)srcb, pack, bits, dsrc, (unsigned)dstb, images, dz_amax, dsrc_amax, st);
+    if (dz_amax && bits && conv_r_takes(images, 2, true)) return convr_dgrad2(fn, dz, (unsigned)srcb, pack, bits, dsrc, (unsigned)dstb, images, dz_amax, dsrc_amax, st);
     ZArgs za = zargs(dz, srcb, 0, pack, nullptr, act_in, dsrc, (long long)images * 400 * 32 * 4, 0, (long long)images * 100, 128, ZDgrad2::K, images);
     za.bits_in = bits;
     za.a_amax = dz_amax; za.c_amax = dsrc_amax;
@@ -1419,6 +1422,10 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_bits_f32(const float*
 // The same kernels on the two-term f16 split (f16split.h; SPLIT = 1 of z_kernel): `pack` is an f16x2 pack (its header carries the
 // weight tensor's maximum), every split operand comes with its amax record, every result a consumer will split again gets its record
 // filled.  Same shapes, alignments and epilogues as the entry points above.
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_packed_kernel_f16x2(int64_t images, int layer, int dgrad) {
+    return (images > 0 && (layer == 2 || layer == 3) && conv_r_takes(images, layer, dgrad != 0)) ? 'R' : 'Z';
+}
+
 extern "C" MI355PPO_API size_t mi355ppo_fc_pack_f16x2_bytes(int N, int K) {
     if (N <= 0 || K <= 0 || K % 16) return 0;
     return (size_t)kF16PackHeader + (size_t)(K / 16) * (size_t)((N + 31) / 32) * 2048;

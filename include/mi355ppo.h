@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 180 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 181 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2, 1.3: round 3;
                                   1.4: the *_cpu host-pointer twins; 1.5: mi355ppo_init; 1.6: round 4 -- the fused MLP family K7,
                                   mi355ppo_clip_adam_sched_f32; 1.7: mi355ppo_fc_heads_act_categorical_f32, mi355ppo_nature_packs_f32,
@@ -598,6 +598,10 @@ MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f16x2_f32(const float* src, const 
 MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(const float* dz, const void* pack, const float* act_in, const uint32_t* mask_bits,
                                                           float* dsrc, int64_t images, int layer, const uint32_t* dz_amax, uint32_t* dsrc_amax,
                                                           void* stream);
+/* 'R' or 'Z': the kernel a forward (dgrad = 0) / bit-masked data-gradient (dgrad = 1) call of this size and layer runs (profiling aid).
+ * Kernel R (csrc/convr.hip) holds the source of a group of images in LDS, split once, and takes the layer-3 forward and the layer-2
+ * data gradient from 16,384 images on; its results are kernel Z's bit for bit (same products, same order). */
+MI355PPO_API int mi355ppo_cnn_conv_packed_kernel_f16x2(int64_t images, int layer, int dgrad);
 /* mi355ppo_cnn_conv_wgrad_f32 for layers 2 / 3 (kernel V); other batches fall to the f32-pipe kernel and ignore the records */
 MI355PPO_API int mi355ppo_cnn_conv_wgrad_f16x2_f32(const float* src, const float* dz, float* dW, float* db, int64_t images, int layer,
                                                    void* workspace, size_t workspace_bytes, const uint32_t* src_amax, const uint32_t* dz_amax,
