@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fP
 # of the file compile to identical code with and without the flag.
 # gemmz.hip / fcw.hip / convw.hip: no SLP vectorizer -- it packs pairs of the split's f32 subtractions into v_pk_add_f32 (plus dead
 # halves), and packed f32 VALU beside MFMAs is an anti-lever on this chip (MI355X_MICROARCH.md, per-instruction constants).
-EXTRA_FLAGS = {"conv.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "gemmz.hip": ["-fno-slp-vectorize"], "convr.hip": ["-fno-slp-vectorize"], "fcw.hip": ["-fno-slp-vectorize"], "convw.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"conv.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "gemmz.hip": ["-fno-slp-vectorize"], "convr.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"], "fcw.hip": ["-fno-slp-vectorize"], "convw.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target: str, deps: list[str]) -> bool:

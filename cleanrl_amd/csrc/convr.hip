@@ -156,7 +156,10 @@ struct RArgs {
     unsigned long long* trace;  // MI355PPO_R_TRACE=1 (diagnosis): s_memtime stamps of workgroup 0's phases, [group visit < 4][phase < 8][wave]
 };
 
-template <class RG, int EPI>
+// OVL: two accumulator banks -- the epilogue of group g runs between the matrix instructions of group g + 1's k-loop (two values per lane
+// and k-step) instead of standing between the two k-loops with the matrix pipe idle (one wave per SIMD: 15 % of a group's time in the
+// layer-3 forward).  Needs 64 more registers: not for the layer-2 data gradient (128 accumulators per bank).
+template <class RG, int EPI, bool OVL>
 __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG::NW + 3) / 4 * RG::WGS, (RG::NW + 3) / 4 * RG::WGS))) void r_kernel(RArgs a) {
     constexpr int NT = RG::NT, MT = RG::MT, NW = RG::NW, NI = RG::NI, THREADS = RG::THREADS;
     constexpr int SS = RG::SS, NSLOT = RG::KSTEPS / SS;
@@ -176,16 +179,19 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     // stored twice).  A-fragment reads: lane -> slot x = lane % 32 of tile i.  Epilogue: accumulator e of tile i -> slot x = (e & 3) +
     // 8 (e >> 2) + 4 lh; `roff[i][e]` = byte offset of that row's first channel in C for image 0 of the group (+ the lane's channel).
     constexpr RRowTable<RG> table{};
-    auto row_pixel = [&](int slot, int& gi, int& pp, int& gy, int& gx) {
+    auto row_pixel = [&](int slot, int& gi, int& pp, int& gy, int& gx) __attribute__((always_inline)) {
         const int r0 = table.row[slot], rc = r0 < 0 ? 0 : r0;
         gi = rc / RG::OP; pp = rc - gi * RG::OP; gy = pp / RG::OW; gx = pp - gy * RG::OW;
     };
-    auto row_coff = [&](int gi, int pp, int gy, int gx) -> unsigned {      // C offset of the row (tile j = 0) within the group
+    auto row_coff = [&](int gi, int pp, int gy, int gx) __attribute__((always_inline)) -> unsigned {      // C offset of the row (tile j = 0) within the group
         if constexpr (EPI == R_MASKB_CLS4) return (unsigned)(((gi * (2 * RG::OH) + 2 * gy) * (2 * RG::OW) + 2 * gx) * 32) * 4u;
         else return (unsigned)((gi * RG::OP + pp) * (32 * NT)) * 4u;
     };
     const unsigned char* win[MT];                         // window origin of the lane's fragment row (+ the lane half's 8 channels)
-    unsigned roff[MT][16], rlane = 0u, rword[MT];         // rlane: C offset of slot row `lane` of the wave's 32 MT rows (mask words in); rword[i]: of slot row li of tile i (mask words out)
+    // (two 16-bit offsets per register where a group's C stays below 64 KiB -- the single-class layers: 16 registers instead of 32 beside
+    //  the second accumulator bank)
+    constexpr bool kPackRoff = (EPI == R_MASKB_CLS4 ? RG::G * 4 * RG::OP * 32 : RG::G * RG::OP * 32 * NT) * 4 < 65536;
+    unsigned roff[MT][kPackRoff ? 8 : 16], rlane = 0u, rword[MT];         // rlane: C offset of slot row `lane` of the wave's 32 MT rows (mask words in); rword[i]: of slot row li of tile i (mask words out)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int gi, pp, gy, gx;
@@ -196,7 +202,9 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             row_pixel((wave * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, gi, pp, gy, gx);
-            roff[i][e] = row_coff(gi, pp, gy, gx) + 4u * (unsigned)li;
+            const unsigned o = row_coff(gi, pp, gy, gx) + 4u * (unsigned)li;
+            if constexpr (kPackRoff) roff[i][e >> 1] = (e & 1) ? (roff[i][e >> 1] | (o << 16)) : o;
+            else roff[i][e] = o;
         }
     }
     static_assert(MT <= 2, "mask words: one lane per row of the wave");
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     s_u32x4 pre[NI];
     // (issued unconditionally -- past the last group with out-of-range offsets, which load zeros without touching memory: loads behind a
     //  branch leave the compiler without a count of the outstanding ones, and every later wait for a weight piece became "all of them")
-    auto prefetch = [&](int grp, int it0, int n) {        // units past the tensor (last group) load zeros: their rows are never stored
+    auto prefetch = [&](int grp, int it0, int n) __attribute__((always_inline)) {        // units past the tensor (last group) load zeros: their rows are never stored
         const bool any = grp < a.groups;
         const unsigned base = (unsigned)grp * (unsigned)(RG::UNITS * 16);
 #pragma unroll
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
             pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (any && u < RG::UNITS) ? base + (unsigned)u * 16u : kROob, 0, 0));
         }
     };
-    auto fill = [&]() {
+    auto fill = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             unsigned hi[2], lo[2];
@@ -241,14 +249,16 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     }
 
     // ---- epilogue constants
-    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)a.c_bytes, kRRsrcWord3);
     const void* const bits_base = EPI == R_BIAS_RELU_BITS ? (const void*)a.bits_out : (const void*)a.bits_in;
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(bits_base), 0, EPI == R_BIAS_RELU ? 0 : (int)(a.c_bytes >> 5), kRRsrcWord3);
+    // C and the mask words of a group that does not exist (OVL: the "previous group" of the first one, the second of an odd pair): zero
+    // records -- stores dropped, loads zero
+    auto rsrc_c_of = [&](int g) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (g >= 0 && g < a.groups) ? (int)a.c_bytes : 0, kRRsrcWord3); };
+    auto rsrc_b_of = [&](int g) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(bits_base), 0, (EPI != R_BIAS_RELU && g >= 0 && g < a.groups) ? (int)(a.c_bytes >> 5) : 0, kRRsrcWord3); };
     float bj[NT];                                         // R_BIAS_RELU*: the lane's bias element per column tile
 #pragma unroll
     for (int j = 0; j < NT; ++j) bj[j] = (EPI == R_BIAS_RELU || EPI == R_BIAS_RELU_BITS) ? a.bias[32 * j + li] : 0.0f;
     constexpr unsigned kGroupC = (EPI == R_MASKB_CLS4 ? RG::G * 4 * RG::OP * 32 : RG::G * RG::OP * 32 * NT) * 4;      // bytes of C per group
-    auto joff = [](int j) -> int {                        // byte offset of column tile j from the row's first channel
+    auto joff = [](int j) __attribute__((always_inline)) -> int {                        // byte offset of column tile j from the row's first channel
         return EPI == R_MASKB_CLS4 ? ((j >> 1) * (2 * RG::OW) + (j & 1)) * 32 * 4 : 32 * j * 4;
     };
     float cmax = 0.0f;
@@ -265,32 +275,87 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     // are the same for every group: with an even number of slots (the sets' parity carries over) the first two slots of the NEXT group are fetched during the last two
     // slots of this one (the sets are free by then), so a group starts with its weights in registers.
     s_u32x4 bst[2][kShare];                               // slot s travels in set s & 1
-    auto load_slot = [&](int slot) {
+    auto load_slot = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kShare; ++u) {
             const int x = wave * kShare + u, h = x / (NT * 2), jt = x - h * (NT * 2);       // (wave-uniform: scalar arithmetic)
             bst[slot & 1][u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, lane16, kF16PackHeader + r_kstep<RG>(SS * slot + h) * RG::STEPB + jt * 1024, 0));
         }
     };
-    auto write_slot = [&](int slot) {                     // -> buffer slot & 1
+    auto write_slot = [&](int slot) __attribute__((always_inline)) {                     // -> buffer slot & 1
 #pragma unroll
         for (int u = 0; u < kShare; ++u) *reinterpret_cast<s_u32x4*>(ring_l + (slot & 1) * RG::SLOTB + (wave * kShare + u) * 1024) = bst[slot & 1][u];
     };
-    auto ring_barrier = [&]() {
+    auto ring_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
 
-    int grp = blockIdx.x, visit = 0;
-    auto stamp = [&](int phase) {
+    int visit = 0;
+    auto stamp = [&](int phase) __attribute__((always_inline)) {
         if (a.trace && blockIdx.x == 0 && visit < 4 && lane == 0) a.trace[(visit * 8 + phase) * NW + wave] = __builtin_amdgcn_s_memtime();
     };
     constexpr bool kCarry = NSLOT % 2 == 0 && NSLOT >= 4;  // slots 0 and 1 of the next group travel in the sets across the group boundary
-    if (grp < a.groups) {
-        prefetch(grp, 0, NI);
-        if constexpr (kCarry) { load_slot(0); load_slot(1); }
-    }
-    for (; grp < a.groups; grp += gridDim.x, ++visit) {
+    constexpr int NB = OVL ? 2 : 1;
+    r_f32x16 acc[NB][MT][NT];
+    unsigned wm[NB][NT];                                  // R_MASKB*: lane L holds the mask word of slot row L of the wave's rows, per column tile
+    int wv = 0;                                           // R_BIAS_RELU_BITS: lane L (< 32) collects the mask word of slot row L of the tile in flight
+    s_u32x4 pa[2][MT][2], wb[2][NT][2];                   // [k-step parity]: pixel fragments [tile][hi, lo]; weight fragments [tile][hi, lo]
+    auto read_a = [&](int par, int v) __attribute__((always_inline)) {
+        const int off = r_tapoff<RG>(r_kstep<RG>(v));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            pa[par][i][0] = *reinterpret_cast<const s_u32x4*>(win[i] + off);
+            pa[par][i][1] = *reinterpret_cast<const s_u32x4*>(win[i] + off + 128);
+        }
+    };
+    auto read_b = [&](int par, int v) __attribute__((always_inline)) {                   // step v = step v % SS of slot v / SS
+        const int buf = (v / SS) & 1, h = v % SS;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) wb[par][j][t] = *reinterpret_cast<const s_u32x4*>(ring_l + buf * RG::SLOTB + ((h * NT + j) * 2 + t) * 1024);
+    };
+    // ---- epilogue (kernel Z's), one value: accumulator e of tile (i, j) = row slot (e & 3) + 8 (e >> 2) + 4 lh of tile i, channel 32 j + li.
+    // Every offset carries the group's base, so rows of images past the batch fall out of the buffer's range: stores dropped, mask words
+    // read as zero.  Values of one (i, j) come in the order e = 0 .. 15 (the mask word out is assembled across them).
+    auto load_masks = [&](auto bankc, unsigned gbase, const __amdgpu_buffer_rsrc_t rb) __attribute__((always_inline)) {
+        constexpr int bank = decltype(bankc)::value;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wm[bank][j] = __builtin_amdgcn_raw_buffer_load_b32(rb, (gbase + rlane + (unsigned)joff(j)) >> 5, 0, 0);
+    };
+    auto epi_elem = [&](auto bankc, int i, int j, int e, unsigned gbase, const __amdgpu_buffer_rsrc_t rc, const __amdgpu_buffer_rsrc_t rb) __attribute__((always_inline)) {
+        constexpr int bank = decltype(bankc)::value;
+        const unsigned rpk = roff[i][kPackRoff ? e >> 1 : e];
+        const unsigned ro = gbase + (kPackRoff ? ((e & 1) ? rpk >> 16 : rpk & 0xffffu) : rpk) + (unsigned)joff(j);
+        float v;
+        if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wm[bank][j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2));
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)wm[bank][j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2) + 4);
+            v = r_keep_where(acc[bank][i][j][e] * un, lo, hi);                // lanes 0..31 (lh = 0): bit li of `lo`, lanes 32..63: of `hi`
+        } else {
+            v = acc[bank][i][j][e] * un + bj[j];
+            v = v < 0.0f ? 0.0f : v;                                          // (a NaN stays a NaN, as kernel Z's SPLIT epilogue)
+        }
+        cmax = __builtin_fmaxf(cmax, __builtin_fabsf(v));                     // (rows past the batch: zeros, or relu(bias) of a real channel -- see below)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, ro, 0, 0);
+        if constexpr (EPI == R_BIAS_RELU_BITS) {          // lanes 0..31 of the ballot: the 32 channels of slot row (e & 3) + 8 (e >> 2); 32..63: of that row + 4
+            if (e == 0) wv = 0;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.0f);
+            wv = r_writelane(wv, (unsigned)bal, (e & 3) + 8 * (e >> 2));
+            wv = r_writelane(wv, (unsigned)(bal >> 32), (e & 3) + 8 * (e >> 2) + 4);
+            if (e == 15) __builtin_amdgcn_raw_buffer_store_b32((unsigned)wv, rb, lh == 0 ? (gbase + rword[i] + (unsigned)joff(j)) >> 5 : kROob, 0, 0);
+        }
+    };
+    constexpr int kElems = MT * NT * 16;                  // values per lane and group; value x = ((i NT + j) 16 + e)
+    constexpr int kEpiPer = (kElems + RG::KSTEPS - 3) / (RG::KSTEPS - 2);     // OVL: values per k-step, steps 1 .. KSTEPS - 2
+    static_assert(!OVL || kEpiPer <= 4, "at most one value behind every third MFMA");
+
+    // One group into bank PAR.  OVL: the values of group `prev` (bank PAR ^ 1) leave between this group's matrix instructions.
+    auto group = [&](auto parc, int grp, int prev) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(parc)::value;
+        const unsigned gprev = (unsigned)prev * kGroupC, gbase = (unsigned)grp * kGroupC;
+        const __amdgpu_buffer_rsrc_t rc_prev = rsrc_c_of(prev), rb_prev = rsrc_b_of(prev), rb_cur = rsrc_b_of(grp);
         stamp(0);
         // every wave is done with the previous group's records and ring slots
         __syncthreads();
@@ -303,30 +368,6 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         load_slot(2);
         ring_barrier();
         stamp(3);
-
-        r_f32x16 acc[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-        s_u32x4 pa[2][MT][2], wb[2][NT][2];               // [k-step parity]: pixel fragments [tile][hi, lo]; weight fragments [tile][hi, lo]
-        auto read_a = [&](int par, int v) {
-            const int off = r_tapoff<RG>(r_kstep<RG>(v));
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                pa[par][i][0] = *reinterpret_cast<const s_u32x4*>(win[i] + off);
-                pa[par][i][1] = *reinterpret_cast<const s_u32x4*>(win[i] + off + 128);
-            }
-        };
-        auto read_b = [&](int par, int v) {               // step v = step v % SS of slot v / SS
-            const int buf = (v / SS) & 1, h = v % SS;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) wb[par][j][t] = *reinterpret_cast<const s_u32x4*>(ring_l + buf * RG::SLOTB + ((h * NT + j) * 2 + t) * 1024);
-        };
         read_a(0, 0);
         read_b(0, 0);
 #pragma unroll
@@ -347,6 +388,8 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
             // the next group's source, a few loads per step from the second step on: the whole group at once (104 KB per CU in the layer-3
             // forward) exceeds what a CU keeps in flight and held the issuing waves -- and the matrix pipe behind them -- for 7,000 cycles
             if (v >= 1 && (v - 1) * kPrePer < NI) prefetch(grp + gridDim.x, (v - 1) * kPrePer, kPrePer);
+            if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4)
+                if (v == RG::KSTEPS - 4) load_masks(std::integral_constant<int, PAR>{}, gbase, rb_cur);      // this group's mask words, for its epilogue
             if (a.trace && blockIdx.x == 0 && visit == 1 && lane == 0 && wave == 0) a.trace[4 * 8 * NW + v] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
             // hi hi, hi lo (weights), lo hi (pixels): kernel Z's order of the three term pairs, tiles innermost
@@ -355,72 +398,82 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, pa[q][i][pi == 2 ? 1 : 0]),
-                                                                           __builtin_bit_cast(s_f16x8, wb[q][j][pi == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        stamp(4);
-        // ---- epilogue (kernel Z's): accumulator e of tile (i, j) = row slot (e & 3) + 8 (e >> 2) + 4 lh of tile i, channel 32 j + li.
-        // Every offset carries the group's base, so rows of images past the batch fall out of the buffer's range: stores dropped, mask
-        // words read as zero.
-        const unsigned gbase = (unsigned)grp * kGroupC;
-        float gmax = 0.0f;
-        if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
-            unsigned wm[NT];                              // lane L: the mask word of slot row L of the wave's rows, per column tile
-#pragma unroll
-            for (int j = 0; j < NT; ++j) wm[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_b, (gbase + rlane + (unsigned)joff(j)) >> 5, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const unsigned ro = gbase + roff[i][e];
-#pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wm[j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2));
-                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)wm[j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2) + 4);
-                        const float v = r_keep_where(acc[i][j][e] * un, lo, hi);  // lanes 0..31 (lh = 0): bit li of `lo`, lanes 32..63: of `hi`
-                        gmax = __builtin_fmaxf(gmax, __builtin_fabsf(v));
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, ro + (unsigned)joff(j), 0, 0);
-                    }
-                }
-        } else {
+                        if (v == 0 && pi == 0) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                int wv[NT];                               // R_BIAS_RELU_BITS: lane L (< 32) collects the mask word of slot row L of tile i
-#pragma unroll
-                for (int j = 0; j < NT; ++j) wv[j] = 0;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const unsigned ro = gbase + roff[i][e];
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        float v = acc[i][j][e] * un + bj[j];
-                        v = v < 0.0f ? 0.0f : v;                              // (a NaN stays a NaN, as kernel Z's SPLIT epilogue)
-                        gmax = __builtin_fmaxf(gmax, __builtin_fabsf(v));
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, ro + (unsigned)joff(j), 0, 0);
-                        if constexpr (EPI == R_BIAS_RELU_BITS) {              // lanes 0..31 of the ballot: the 32 channels of slot row (e & 3) + 8 (e >> 2); 32..63: of that row + 4
-                            const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.0f);
-                            wv[j] = r_writelane(wv[j], (unsigned)bal, (e & 3) + 8 * (e >> 2));
-                            wv[j] = r_writelane(wv[j], (unsigned)(bal >> 32), (e & 3) + 8 * (e >> 2) + 4);
+                            for (int e = 0; e < 16; ++e) acc[PAR][i][j][e] = 0.0f;      // (the MFMA's inline zero)
+                        }
+                        acc[PAR][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, pa[q][i][pi == 2 ? 1 : 0]),
+                                                                                __builtin_bit_cast(s_f16x8, wb[q][j][pi == 1 ? 1 : 0]), acc[PAR][i][j], 0, 0, 0);
+                        if constexpr (OVL) {
+                            const int m = (pi * MT + i) * NT + j;             // behind MFMAs 1, 4, 7, 10 of the step: value (v - 1) kEpiPer + m / 3
+                            if (v >= 1 && v <= RG::KSTEPS - 2 && m % 3 == 1 && m / 3 < kEpiPer) {
+                                const int x = (v - 1) * kEpiPer + m / 3;
+                                if (x < kElems) epi_elem(std::integral_constant<int, PAR ^ 1>{}, x / (16 * NT), (x / 16) % NT, x % 16, gprev, rc_prev, rb_prev);
+                            }
                         }
                     }
-                }
-                if constexpr (EPI == R_BIAS_RELU_BITS) {
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp(4);
+        if constexpr (!OVL) {
+            const __amdgpu_buffer_rsrc_t rc = rsrc_c_of(grp);
+            if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) epi_elem(std::integral_constant<int, 0>{}, i, j, e, gbase, rc, rb_cur);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        __builtin_amdgcn_raw_buffer_store_b32((unsigned)wv[j], rsrc_b, lh == 0 ? (gbase + rword[i] + (unsigned)joff(j)) >> 5 : kROob, 0, 0);
-                }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) epi_elem(std::integral_constant<int, 0>{}, i, j, e, gbase, rc, rb_cur);
             }
         }
-        cmax = __builtin_fmaxf(cmax, gmax);               // (rows past the batch multiply zeros: 0, or relu(bias) of a real channel -- see below)
         stamp(5);
+        ++visit;
+    };
+
+    int grp = blockIdx.x;
+    if (grp < a.groups) {
+        prefetch(grp, 0, NI);
+        if constexpr (kCarry) { load_slot(0); load_slot(1); }
+    }
+    if constexpr (!OVL) {
+        for (; grp < a.groups; grp += gridDim.x) group(std::integral_constant<int, 0>{}, grp, -1);
+    } else {
+        // groups in pairs (bank 0, bank 1), straight-line -- two variants picked by a branch inside the loop doubled the live registers at the
+        // merge points.  A second group past the end multiplies zeros into dropped stores; the "previous group" of the first one stores the
+        // zeroed bank 1 nowhere.
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[NB - 1][i][j][e] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wm[NB - 1][j] = 0u;
+        const int first = grp;
+        for (; grp < a.groups; grp += 2 * (int)gridDim.x) {
+            group(std::integral_constant<int, 0>{}, grp, grp - (int)gridDim.x);
+            group(std::integral_constant<int, NB - 1>{}, grp + (int)gridDim.x, grp);
+        }
+        if (grp > first) {                                // the last group's values (bank 1; possibly a group past the end)
+            const int last = grp - (int)gridDim.x;
+            const unsigned gl = (unsigned)last * kGroupC;
+            const __amdgpu_buffer_rsrc_t rc = rsrc_c_of(last), rb = rsrc_b_of(last);
+#pragma unroll
+            for (int x = 0; x < kElems; ++x) epi_elem(std::integral_constant<int, NB - 1>{}, x / (16 * NT), (x / 16) % NT, x % 16, gl, rc, rb);
+        }
     }
     if (a.c_amax) amax_commit(a.c_amax, __float_as_uint(cmax), blockIdx.x * NW + (unsigned)wave, lane);
 }
 
-template <class RG, int EPI>
+template <class RG, int EPI, bool OVL = false>
 static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
     RArgs a = a0;
     a.groups = (int)((a.images + RG::G - 1) / RG::G);
@@ -441,7 +494,7 @@ static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
         if (tbuf) (void)hipMemsetAsync(tbuf, 0, (4 * 8 * RG::NW + 64) * 8, s);
         a.trace = tbuf;
     }
-    hipLaunchKernelGGL((r_kernel<RG, EPI>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
+    hipLaunchKernelGGL((r_kernel<RG, EPI, OVL>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
     if (tracing && tbuf) {
         unsigned long long h[4 * 8 * RG::NW + 64];
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, tbuf, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -476,6 +529,8 @@ int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void*
     RArgs a{};
     a.A = src; a.a_bytes = src_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.bits_out = bits; a.C = dst; a.c_bytes = dst_bytes;
     a.images = images; a.a_amax = src_amax; a.c_amax = dst_amax;
+    // (OVL does not fit here: with 26 prefetch units of 4 registers beside two accumulator banks the compiler needs ~600 registers --
+    //  400 bytes of spills, 800 us instead of 445; profiles/r05_tile_shape_experiments.txt)
     return bits ? r_launch<RConv3, R_BIAS_RELU_BITS>(a, st, fn) : r_launch<RConv3, R_BIAS_RELU>(a, st, fn);
 }
 
@@ -484,7 +539,9 @@ int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void*
     RArgs a{};
     a.A = dz; a.a_bytes = dz_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bits_in = bits; a.C = dsrc; a.c_bytes = dsrc_bytes;
     a.images = images; a.a_amax = dz_amax; a.c_amax = dsrc_amax;
-    return r_launch<RDgrad3, R_MASKB>(a, st, fn);
+    const char* e = getenv("MI355PPO_CONV_R_OVL");         // 0: the epilogue between the k-loops (A/B runs; bit-identical)
+    if (e && e[0] == '0') return r_launch<RDgrad3, R_MASKB>(a, st, fn);
+    return r_launch<RDgrad3, R_MASKB, true>(a, st, fn);
 }
 
 int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
