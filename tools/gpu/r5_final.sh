@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 closing visit (the f16x2 default): the whole GPU suite, the default bench line (config C, all legs) and its rocprofv3 kernel statistics,
-# per-launch A/B of the two splits, the five PMC passes over one minibatch update's launches, configs B / D / E (+ kernel statistics of E),
+# per-launch A/B of the two splits, kernel R against kernel Z (hashes, times, bench lines), the five PMC passes over one minibatch update's launches, configs B / D / E (+ kernel statistics of E),
 # the determinism check (trained-parameter checksums, alone and two processes at a time), smoke().
 set -u
 export TMPDIR=/tmp
@@ -28,6 +28,14 @@ for i in 1 2; do
   CONV_TRAFFIC_F16=1 timeout 120 tools/conv_traffic 32768 4 2>&1 | grep '^{' | sed 's/^{/{"split": "f16x2", /' >> $O/conv_traffic_ab.jsonl
 done
 cut -c1-400 $O/conv_traffic_ab.jsonl
+# kernel R against kernel Z: hashes (bit-identical) and times at three sizes, then alternating timing runs (-> gpurun_out/r5convr/)
+MI355PPO_CONV_R_MIN=1 SIZES="32768 1027 61" bash tools/gpu/r5_convr.sh 2>&1 | cut -c1-260 | tail -14; echo "kernel R A/B t=$((SECONDS-T0))"
+cp $R/gpurun_out/r5convr/ab.jsonl $O/kernel_r_ab.jsonl 2>/dev/null; cat $R/gpurun_out/r5convr/hashdiff_*.txt > $O/kernel_r_hashdiff.txt 2>/dev/null
+for i in 1 2; do for mode in 1 0; do
+  MI355PPO_CONV_R=$mode timeout 300 python bench.py --no-cpu-baseline --no-pcie-inclusive --no-kernel-timing 2>/dev/null | grep '^{' | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print(json.dumps({'conv_r': $mode, 'value': j['value'], 'ms_per_step': j['ms_per_step'], 'phases_ms': j['phases_ms']}))" | tee -a $O/bench_kernel_r_ab.jsonl | cut -c1-200
+done; done
 pmc_pass() {   # name, counters...
     name=$1; shift
     rm -rf /tmp/pmc_$name
