@@ -28,7 +28,7 @@ int convw_launch(const float* src, const float* dz, float* part_w, float* part_b
 
 // kernel Z (gemmz.hip): the K-split raw partials of the rollout-sized FC forward, (splits, M, N) f32 into `ws`
 // convr.hip: kernel R, the input-resident layer-3 forward and layer-2 / layer-3 data gradients on the f16 split (bit-identical to kernel Z's)
-bool convr_on(long long images);
+bool convr_on(long long images, long long min_images);
 int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void* pack, const float* bias, float* dst, unsigned dst_bytes, unsigned* bits,
                long long images, const unsigned* src_amax, unsigned* dst_amax, hipStream_t st);
 int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,

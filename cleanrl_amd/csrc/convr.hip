@@ -48,25 +48,28 @@ constexpr int kRPix = 272;                            // bytes per pixel record 
 // OH x OW per image; NT 32-column tiles of the pack; G images per group on NW waves of MT 32-row tiles each; destination pixel of grid
 // pixel (gy, gx) and column tile j: R_MASKB_CLS4 -> (2 gy + (j >> 1), 2 gx + (j & 1)) of a (2 OH, 2 OW, 32) image, else pixel (gy, gx) of
 // an (OH, OW, 32 NT) image.  ORDER 1: the layer-3 forward's phase order of kernel Z (z_kstep), 0: ascending.
-template <int IH_, int IW_, int HL_, int KH_, int KW_, int OH_, int OW_, int NT_, int G_, int NW_, int MT_, int ORDER_, int SS_, int WGS_>
+template <int IH_, int IW_, int HL_, int KH_, int KW_, int OH_, int OW_, int NT_, int G_, int NW_, int MT_, int ORDER_, int SS_, int WGS_, int NS_ = 1>
 struct RGeom {
     static constexpr int IH = IH_, IW = IW_, HL = HL_, KH = KH_, KW = KW_, OH = OH_, OW = OW_, NT = NT_, G = G_, NW = NW_, MT = MT_, ORDER = ORDER_;
     static constexpr int SS = SS_;                                                  // k-steps per ring slot (one barrier per slot)
     static constexpr int WGS = WGS_;                                                // workgroups per CU the kernel is sized for (LDS, registers)
-    static constexpr int IHP = IH + 2 * HL, IWP = IW + 2 * HL, IPIX = IHP * IWP, OP = OH * OW, ROWS = G * OP, SLOTS = 32 * MT * NW;
+    // NS: the waves split the column tiles -- wave w multiplies row tiles of row-wave w % (NW / NS) against column tiles (w / (NW / NS)) NT / NS ..
+    static constexpr int NS = NS_, NTW = NT / NS, RW = NW / NS;
+    static constexpr int IHP = IH + 2 * HL, IWP = IW + 2 * HL, IPIX = IHP * IWP, OP = OH * OW, ROWS = G * OP, SLOTS = 32 * MT * (NW / NS_);
     static constexpr int KSTEPS = KH * KW * 4, SPR = KW * 4;
     static constexpr int IMGB = IPIX * kRPix, ABYTES = G * IMGB;
     static constexpr int STEPB = NT * 2048, SLOTB = SS * STEPB;                     // one k-step of the pack; ring slot
     static constexpr int UNITS = G * IH * IW * 16;                                  // 16-byte units of a group's source
     static constexpr int THREADS = 64 * NW, NI = (UNITS + THREADS - 1) / THREADS;
-    static_assert(ROWS <= SLOTS && KSTEPS % SS == 0, "a group's rows fit the waves' tiles; whole ring slots");
+    static_assert(ROWS <= SLOTS && KSTEPS % SS == 0 && NT % NS == 0 && NW % NS == 0, "a group's rows fit the waves' tiles; whole ring slots");
     static_assert((ABYTES + 2 * SLOTB) * WGS <= 160 * 1024, "LDS");
 };
-// One workgroup of four waves per CU (one wave per SIMD, 64 rows per wave), against two workgroups per CU with half the images each:
-// profiles/r05_kernel_r_configs.txt.
-using RConv3 = RGeom<9, 9, 0, 3, 3, 7, 7, 2, 5, 4, 2, 1, 6, 1>;          // a2 (9, 9, 64) -> a3 (7, 7, 64): 245 rows of 256
-using RDgrad3 = RGeom<7, 7, 2, 3, 3, 9, 9, 2, 3, 4, 2, 0, 6, 1>;         // dz3 (7, 7, 64) -> da2 (9, 9, 64): 243 rows of 256
-using RDgrad2 = RGeom<9, 9, 1, 2, 2, 10, 10, 4, 2, 4, 2, 0, 4, 1>;       // dz2 (9, 9, 64) -> da1 (20, 20, 32), four stride-parity classes = four column tiles: 200 rows of 256
+// One persistent workgroup per CU.  64-channel outputs (NT = 2): eight waves of 32 rows, two per SIMD -- 384 / 527 us where four waves of 64 rows
+// (one per SIMD, half the weight-fragment reads per MFMA) took 440 / 585; the layer-2 data gradient (NT = 4: 64 accumulators per 32-row tile)
+// the other way round, 850 against 915 us.  All measured shapes: profiles/r05_tile_shape_experiments.txt.
+using RConv3 = RGeom<9, 9, 0, 3, 3, 7, 7, 2, 5, 8, 1, 1, 6, 1>;          // a2 (9, 9, 64) -> a3 (7, 7, 64): 245 rows of 256
+using RDgrad3 = RGeom<7, 7, 2, 3, 3, 9, 9, 2, 3, 8, 1, 0, 6, 1>;         // dz3 (7, 7, 64) -> da2 (9, 9, 64): 243 rows of 256
+using RDgrad2 = RGeom<9, 9, 1, 2, 2, 10, 10, 4, 2, 8, 2, 0, 4, 1, 2>;       // dz2 (9, 9, 64) -> da1 (20, 20, 32), four stride-parity classes = four column tiles: 200 rows of 256
 
 // Which row of the group sits in which lane.  A fragment read (ds_read_b128, lane = row) is served in groups of 16 lanes -- {0-3, 12-15,
 // 20-27} and {4-11, 16-19, 28-31} of each wave half -- and is conflict-free when the 16 records start in 16 different sixteen-byte slots of
@@ -156,12 +159,9 @@ struct RArgs {
     unsigned long long* trace;  // MI355PPO_R_TRACE=1 (diagnosis): s_memtime stamps of workgroup 0's phases, [group visit < 4][phase < 8][wave]
 };
 
-// OVL: two accumulator banks -- the epilogue of group g runs between the matrix instructions of group g + 1's k-loop (two values per lane
-// and k-step) instead of standing between the two k-loops with the matrix pipe idle (one wave per SIMD: 15 % of a group's time in the
-// layer-3 forward).  Needs 64 more registers: not for the layer-2 data gradient (128 accumulators per bank).
-template <class RG, int EPI, bool OVL>
+template <class RG, int EPI>
 __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG::NW + 3) / 4 * RG::WGS, (RG::NW + 3) / 4 * RG::WGS))) void r_kernel(RArgs a) {
-    constexpr int NT = RG::NT, MT = RG::MT, NW = RG::NW, NI = RG::NI, THREADS = RG::THREADS;
+    constexpr int NT = RG::NT, NTW = RG::NTW, MT = RG::MT, NW = RG::NW, NI = RG::NI, THREADS = RG::THREADS;
     constexpr int SS = RG::SS, NSLOT = RG::KSTEPS / SS;
     constexpr int kPieces = SS * NT * 2;                  // KiB pieces of a ring slot: (step h of the slot, tile j, term t), x = (h NT + j) 2 + t
     constexpr int kShare = kPieces / NW;
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     unsigned char* const ring = lds + RG::ABYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+    const int rw = RG::NS == 1 ? wave : wave % RG::RW, jg = RG::NS == 1 ? 0 : wave / RG::RW;      // row-wave; first column tile / NTW (wave-uniform)
 
     const int ea = f16_scale_exp(amax_load(a.a_amax, lane));
     const int eb = f16_scale_exp(*reinterpret_cast<const unsigned*>(a.pack));
@@ -195,13 +196,13 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int gi, pp, gy, gx;
-        row_pixel((wave * MT + i) * 32 + li, gi, pp, gy, gx);
+        row_pixel((rw * MT + i) * 32 + li, gi, pp, gy, gx);
         win[i] = lds + gi * RG::IMGB + (gy * RG::IWP + gx) * kRPix + 16 * lh;
         rword[i] = row_coff(gi, pp, gy, gx);
         if (MT == 1 || lh == i) rlane = rword[i];                         // (MT = 2: lanes 0..31 tile 0, lanes 32..63 tile 1; MT = 1: both halves tile 0)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            row_pixel((wave * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, gi, pp, gy, gx);
+            row_pixel((rw * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, gi, pp, gy, gx);
             const unsigned o = row_coff(gi, pp, gy, gx) + 4u * (unsigned)li;
             if constexpr (kPackRoff) roff[i][e >> 1] = (e & 1) ? (roff[i][e >> 1] | (o << 16)) : o;
             else roff[i][e] = o;
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     }
     static_assert(MT <= 2, "mask words: one lane per row of the wave");
     unsigned char* const ring_l = ring + 16 * lane;
+    const unsigned char* const ring_r = ring_l + jg * (NTW * 2048);        // this wave's column tiles of a k-step
 
     // ---- the group's source: unit u = 16 bytes = 4 channels of a pixel; thread tid takes units it * THREADS + tid
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)a.a_bytes, kRRsrcWord3);
@@ -250,13 +252,11 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 
     // ---- epilogue constants
     const void* const bits_base = EPI == R_BIAS_RELU_BITS ? (const void*)a.bits_out : (const void*)a.bits_in;
-    // C and the mask words of a group that does not exist (OVL: the "previous group" of the first one, the second of an odd pair): zero
-    // records -- stores dropped, loads zero
     auto rsrc_c_of = [&](int g) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (g >= 0 && g < a.groups) ? (int)a.c_bytes : 0, kRRsrcWord3); };
     auto rsrc_b_of = [&](int g) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(bits_base), 0, (EPI != R_BIAS_RELU && g >= 0 && g < a.groups) ? (int)(a.c_bytes >> 5) : 0, kRRsrcWord3); };
-    float bj[NT];                                         // R_BIAS_RELU*: the lane's bias element per column tile
+    float bj[NTW];                                        // R_BIAS_RELU*: the lane's bias element per column tile
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bj[j] = (EPI == R_BIAS_RELU || EPI == R_BIAS_RELU_BITS) ? a.bias[32 * j + li] : 0.0f;
+    for (int j = 0; j < NTW; ++j) bj[j] = (EPI == R_BIAS_RELU || EPI == R_BIAS_RELU_BITS) ? a.bias[32 * (jg * NTW + j) + li] : 0.0f;
     constexpr unsigned kGroupC = (EPI == R_MASKB_CLS4 ? RG::G * 4 * RG::OP * 32 : RG::G * RG::OP * 32 * NT) * 4;      // bytes of C per group
     auto joff = [](int j) __attribute__((always_inline)) -> int {                        // byte offset of column tile j from the row's first channel
         return EPI == R_MASKB_CLS4 ? ((j >> 1) * (2 * RG::OW) + (j & 1)) * 32 * 4 : 32 * j * 4;
@@ -296,11 +296,10 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         if (a.trace && blockIdx.x == 0 && visit < 4 && lane == 0) a.trace[(visit * 8 + phase) * NW + wave] = __builtin_amdgcn_s_memtime();
     };
     constexpr bool kCarry = NSLOT % 2 == 0 && NSLOT >= 4;  // slots 0 and 1 of the next group travel in the sets across the group boundary
-    constexpr int NB = OVL ? 2 : 1;
-    r_f32x16 acc[NB][MT][NT];
-    unsigned wm[NB][NT];                                  // R_MASKB*: lane L holds the mask word of slot row L of the wave's rows, per column tile
+    r_f32x16 acc[MT][NTW];
+    unsigned wm[NTW];                                  // R_MASKB*: lane L holds the mask word of slot row L of the wave's rows, per column tile
     int wv = 0;                                           // R_BIAS_RELU_BITS: lane L (< 32) collects the mask word of slot row L of the tile in flight
-    s_u32x4 pa[2][MT][2], wb[2][NT][2];                   // [k-step parity]: pixel fragments [tile][hi, lo]; weight fragments [tile][hi, lo]
+    s_u32x4 pa[2][MT][2], wb[2][NTW][2];                   // [k-step parity]: pixel fragments [tile][hi, lo]; weight fragments [tile][hi, lo]
     auto read_a = [&](int par, int v) __attribute__((always_inline)) {
         const int off = r_tapoff<RG>(r_kstep<RG>(v));
 #pragma unroll
@@ -312,29 +311,27 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     auto read_b = [&](int par, int v) __attribute__((always_inline)) {                   // step v = step v % SS of slot v / SS
         const int buf = (v / SS) & 1, h = v % SS;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) wb[par][j][t] = *reinterpret_cast<const s_u32x4*>(ring_l + buf * RG::SLOTB + ((h * NT + j) * 2 + t) * 1024);
+            for (int t = 0; t < 2; ++t) wb[par][j][t] = *reinterpret_cast<const s_u32x4*>(ring_r + buf * RG::SLOTB + ((h * NT + j) * 2 + t) * 1024);
     };
     // ---- epilogue (kernel Z's), one value: accumulator e of tile (i, j) = row slot (e & 3) + 8 (e >> 2) + 4 lh of tile i, channel 32 j + li.
     // Every offset carries the group's base, so rows of images past the batch fall out of the buffer's range: stores dropped, mask words
     // read as zero.  Values of one (i, j) come in the order e = 0 .. 15 (the mask word out is assembled across them).
-    auto load_masks = [&](auto bankc, unsigned gbase, const __amdgpu_buffer_rsrc_t rb) __attribute__((always_inline)) {
-        constexpr int bank = decltype(bankc)::value;
+    auto load_masks = [&](unsigned gbase, const __amdgpu_buffer_rsrc_t rb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wm[bank][j] = __builtin_amdgcn_raw_buffer_load_b32(rb, (gbase + rlane + (unsigned)joff(j)) >> 5, 0, 0);
+        for (int j = 0; j < NTW; ++j) wm[j] = __builtin_amdgcn_raw_buffer_load_b32(rb, (gbase + rlane + (unsigned)joff(j)) >> 5, 0, 0);
     };
-    auto epi_elem = [&](auto bankc, int i, int j, int e, unsigned gbase, const __amdgpu_buffer_rsrc_t rc, const __amdgpu_buffer_rsrc_t rb) __attribute__((always_inline)) {
-        constexpr int bank = decltype(bankc)::value;
+    auto epi_elem = [&](int i, int j, int e, unsigned gbase, const __amdgpu_buffer_rsrc_t rc, const __amdgpu_buffer_rsrc_t rb) __attribute__((always_inline)) {
         const unsigned rpk = roff[i][kPackRoff ? e >> 1 : e];
         const unsigned ro = gbase + (kPackRoff ? ((e & 1) ? rpk >> 16 : rpk & 0xffffu) : rpk) + (unsigned)joff(j);
         float v;
         if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wm[bank][j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2));
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)wm[bank][j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2) + 4);
-            v = r_keep_where(acc[bank][i][j][e] * un, lo, hi);                // lanes 0..31 (lh = 0): bit li of `lo`, lanes 32..63: of `hi`
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wm[j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2));
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)wm[j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2) + 4);
+            v = r_keep_where(acc[i][j][e] * un, lo, hi);                // lanes 0..31 (lh = 0): bit li of `lo`, lanes 32..63: of `hi`
         } else {
-            v = acc[bank][i][j][e] * un + bj[j];
+            v = acc[i][j][e] * un + bj[j];
             v = v < 0.0f ? 0.0f : v;                                          // (a NaN stays a NaN, as kernel Z's SPLIT epilogue)
         }
         cmax = __builtin_fmaxf(cmax, __builtin_fabsf(v));                     // (rows past the batch: zeros, or relu(bias) of a real channel -- see below)
@@ -347,15 +344,10 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
             if (e == 15) __builtin_amdgcn_raw_buffer_store_b32((unsigned)wv, rb, lh == 0 ? (gbase + rword[i] + (unsigned)joff(j)) >> 5 : kROob, 0, 0);
         }
     };
-    constexpr int kElems = MT * NT * 16;                  // values per lane and group; value x = ((i NT + j) 16 + e)
-    constexpr int kEpiPer = (kElems + RG::KSTEPS - 3) / (RG::KSTEPS - 2);     // OVL: values per k-step, steps 1 .. KSTEPS - 2
-    static_assert(!OVL || kEpiPer <= 4, "at most one value behind every third MFMA");
-
-    // One group into bank PAR.  OVL: the values of group `prev` (bank PAR ^ 1) leave between this group's matrix instructions.
-    auto group = [&](auto parc, int grp, int prev) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(parc)::value;
-        const unsigned gprev = (unsigned)prev * kGroupC, gbase = (unsigned)grp * kGroupC;
-        const __amdgpu_buffer_rsrc_t rc_prev = rsrc_c_of(prev), rb_prev = rsrc_b_of(prev), rb_cur = rsrc_b_of(grp);
+    static_assert(RG::NS == 1 || EPI != R_MASKB_CLS4 || NTW == 2, "stride-parity classes: a wave's column tiles are one class row (joff additive)");
+    auto group = [&](int grp) __attribute__((always_inline)) {
+        const unsigned gbase = (unsigned)grp * kGroupC + (unsigned)joff(jg * NTW);      // (joff is additive over the waves' column-tile groups: static_assert below)
+        const __amdgpu_buffer_rsrc_t rb_cur = rsrc_b_of(grp);
         stamp(0);
         // every wave is done with the previous group's records and ring slots
         __syncthreads();
@@ -389,7 +381,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
             // forward) exceeds what a CU keeps in flight and held the issuing waves -- and the matrix pipe behind them -- for 7,000 cycles
             if (v >= 1 && (v - 1) * kPrePer < NI) prefetch(grp + gridDim.x, (v - 1) * kPrePer, kPrePer);
             if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4)
-                if (v == RG::KSTEPS - 4) load_masks(std::integral_constant<int, PAR>{}, gbase, rb_cur);      // this group's mask words, for its epilogue
+                if (v == RG::KSTEPS - 4) load_masks(gbase, rb_cur);      // this group's mask words, for its epilogue
             if (a.trace && blockIdx.x == 0 && visit == 1 && lane == 0 && wave == 0) a.trace[4 * 8 * NW + v] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
             // hi hi, hi lo (weights), lo hi (pixels): kernel Z's order of the three term pairs, tiles innermost
@@ -398,41 +390,33 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
+                    for (int j = 0; j < NTW; ++j) {
                         if (v == 0 && pi == 0) {
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) acc[PAR][i][j][e] = 0.0f;      // (the MFMA's inline zero)
+                            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;      // (the MFMA's inline zero)
                         }
-                        acc[PAR][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, pa[q][i][pi == 2 ? 1 : 0]),
-                                                                                __builtin_bit_cast(s_f16x8, wb[q][j][pi == 1 ? 1 : 0]), acc[PAR][i][j], 0, 0, 0);
-                        if constexpr (OVL) {
-                            const int m = (pi * MT + i) * NT + j;             // behind MFMAs 1, 4, 7, 10 of the step: value (v - 1) kEpiPer + m / 3
-                            if (v >= 1 && v <= RG::KSTEPS - 2 && m % 3 == 1 && m / 3 < kEpiPer) {
-                                const int x = (v - 1) * kEpiPer + m / 3;
-                                if (x < kElems) epi_elem(std::integral_constant<int, PAR ^ 1>{}, x / (16 * NT), (x / 16) % NT, x % 16, gprev, rc_prev, rb_prev);
-                            }
-                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, pa[q][i][pi == 2 ? 1 : 0]),
+                                                                           __builtin_bit_cast(s_f16x8, wb[q][j][pi == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
                     }
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(4);
-        if constexpr (!OVL) {
-            const __amdgpu_buffer_rsrc_t rc = rsrc_c_of(grp);
-            if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
+        // the group's values (kernel Z's epilogue orders: rows outermost for the masked gradients, tiles outermost for the forward's mask words)
+        const __amdgpu_buffer_rsrc_t rc = rsrc_c_of(grp);
+        if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
+                for (int e = 0; e < 16; ++e)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) epi_elem(std::integral_constant<int, 0>{}, i, j, e, gbase, rc, rb_cur);
-            } else {
+                    for (int j = 0; j < NTW; ++j) epi_elem(i, j, e, gbase, rc, rb_cur);
+        } else {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
+                for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) epi_elem(std::integral_constant<int, 0>{}, i, j, e, gbase, rc, rb_cur);
-            }
+                    for (int e = 0; e < 16; ++e) epi_elem(i, j, e, gbase, rc, rb_cur);
         }
         stamp(5);
         ++visit;
@@ -443,37 +427,11 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         prefetch(grp, 0, NI);
         if constexpr (kCarry) { load_slot(0); load_slot(1); }
     }
-    if constexpr (!OVL) {
-        for (; grp < a.groups; grp += gridDim.x) group(std::integral_constant<int, 0>{}, grp, -1);
-    } else {
-        // groups in pairs (bank 0, bank 1), straight-line -- two variants picked by a branch inside the loop doubled the live registers at the
-        // merge points.  A second group past the end multiplies zeros into dropped stores; the "previous group" of the first one stores the
-        // zeroed bank 1 nowhere.
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[NB - 1][i][j][e] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) wm[NB - 1][j] = 0u;
-        const int first = grp;
-        for (; grp < a.groups; grp += 2 * (int)gridDim.x) {
-            group(std::integral_constant<int, 0>{}, grp, grp - (int)gridDim.x);
-            group(std::integral_constant<int, NB - 1>{}, grp + (int)gridDim.x, grp);
-        }
-        if (grp > first) {                                // the last group's values (bank 1; possibly a group past the end)
-            const int last = grp - (int)gridDim.x;
-            const unsigned gl = (unsigned)last * kGroupC;
-            const __amdgpu_buffer_rsrc_t rc = rsrc_c_of(last), rb = rsrc_b_of(last);
-#pragma unroll
-            for (int x = 0; x < kElems; ++x) epi_elem(std::integral_constant<int, NB - 1>{}, x / (16 * NT), (x / 16) % NT, x % 16, gl, rc, rb);
-        }
-    }
+    for (; grp < a.groups; grp += gridDim.x) group(grp);
     if (a.c_amax) amax_commit(a.c_amax, __float_as_uint(cmax), blockIdx.x * NW + (unsigned)wave, lane);
 }
 
-template <class RG, int EPI, bool OVL = false>
+template <class RG, int EPI>
 static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
     RArgs a = a0;
     a.groups = (int)((a.images + RG::G - 1) / RG::G);
@@ -494,7 +452,7 @@ static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
         if (tbuf) (void)hipMemsetAsync(tbuf, 0, (4 * 8 * RG::NW + 64) * 8, s);
         a.trace = tbuf;
     }
-    hipLaunchKernelGGL((r_kernel<RG, EPI, OVL>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
+    hipLaunchKernelGGL((r_kernel<RG, EPI>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
     if (tracing && tbuf) {
         unsigned long long h[4 * 8 * RG::NW + 64];
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, tbuf, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -514,14 +472,16 @@ static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
     return check_launch(what);
 }
 
-// Kernel R takes a launch from `MI355PPO_CONV_R_MIN` images on (default 16,384: one persistent workgroup per CU pays its start -- the
-// table, the border fill, an unhidden first load -- once, and below ~8,192 images that is not recovered: profiles/r05_kernel_r_ab.jsonl);
-// MI355PPO_CONV_R=0: never (same-box A/B runs; the results are bit-identical either way).  Read at every call: tests switch them.
-bool convr_on(long long images) {
+// Which launches kernel R takes (profiles/r05_kernel_r_sizes.txt: same-box A/B at 256 .. 32,768 images): the layer-3 forward and data
+// gradient at every size (at or below kernel Z's time everywhere; 0.72 x at 32,768 and 0.78 x at 1,024 images for the forward), the layer-2
+// data gradient from `min_images` = 512 on (0.76 x at 32,768; 1.13 x at 256: one persistent workgroup per CU with two images each leaves
+// half the chip idle there).  MI355PPO_CONV_R=0: never (A/B runs; the results are bit-identical either way); MI355PPO_CONV_R_MIN overrides
+// the threshold of every layer.  Read at every call: tests switch them.
+bool convr_on(long long images, long long min_images) {
     const char* e = getenv("MI355PPO_CONV_R");
     if (e && e[0] == '0') return false;
     const char* m = getenv("MI355PPO_CONV_R_MIN");
-    return images >= (m ? atoll(m) : 16384LL);
+    return images >= (m ? atoll(m) : min_images);
 }
 
 int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void* pack, const float* bias, float* dst, unsigned dst_bytes, unsigned* bits,
@@ -529,8 +489,6 @@ int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void*
     RArgs a{};
     a.A = src; a.a_bytes = src_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.bits_out = bits; a.C = dst; a.c_bytes = dst_bytes;
     a.images = images; a.a_amax = src_amax; a.c_amax = dst_amax;
-    // (OVL does not fit here: with 26 prefetch units of 4 registers beside two accumulator banks the compiler needs ~600 registers --
-    //  400 bytes of spills, 800 us instead of 445; profiles/r05_tile_shape_experiments.txt)
     return bits ? r_launch<RConv3, R_BIAS_RELU_BITS>(a, st, fn) : r_launch<RConv3, R_BIAS_RELU>(a, st, fn);
 }
 
@@ -539,9 +497,7 @@ int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void*
     RArgs a{};
     a.A = dz; a.a_bytes = dz_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bits_in = bits; a.C = dsrc; a.c_bytes = dsrc_bytes;
     a.images = images; a.a_amax = dz_amax; a.c_amax = dsrc_amax;
-    const char* e = getenv("MI355PPO_CONV_R_OVL");         // 0: the epilogue between the k-loops (A/B runs; bit-identical)
-    if (e && e[0] == '0') return r_launch<RDgrad3, R_MASKB>(a, st, fn);
-    return r_launch<RDgrad3, R_MASKB, true>(a, st, fn);
+    return r_launch<RDgrad3, R_MASKB>(a, st, fn);
 }
 
 int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,

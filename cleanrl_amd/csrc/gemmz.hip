@@ -1315,12 +1315,9 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_maskbits_packed_f32(const float* d
 // mode 1 for the layer-3 data gradient (N = 64 input channels, K = (r, c, output channel), taps flipped), mode 2 for the
 // layer-2 data gradient (N = 4 stride-parity classes x 32 input channels, K = (r, c, output channel)).
 static bool conv_r_takes(long long images, int layer, bool dgrad) {      // which f16x2 launches kernel R (convr.hip) takes -- the one place that decides
-    if (!convr_on(images)) return false;
-    if (!dgrad) return layer == 3;
-    const char* e = getenv(layer == 3 ? "MI355PPO_CONV_R3" : "MI355PPO_CONV_R2");
-    // (kernel R's layer-3 data gradient multiplies the zero border -- 1.65 x the valid taps -- and runs 1.09 x kernel Z's time: opt-in;
-    //  profiles/r05_tile_shape_experiments.txt)
-    return layer == 3 ? (e && e[0] == '1') : !(e && e[0] == '0');
+    if (!dgrad) return layer == 3 && convr_on(images, 1);
+    const char* e = getenv(layer == 3 ? "MI355PPO_CONV_R3" : "MI355PPO_CONV_R2");      // =0: this data gradient on kernel Z
+    return !(e && e[0] == '0') && convr_on(images, layer == 3 ? 1 : 512);
 }
 
 static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pack, const float* bias, float* dst, unsigned* bits,

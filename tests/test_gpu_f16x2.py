@@ -195,7 +195,7 @@ def test_kernel_r_forward_layer3_is_kernel_z_bit_for_bit(monkeypatch, images):
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 2, 3, 61, 1027])
 def test_kernel_r_data_gradients_are_kernel_z_bit_for_bit(monkeypatch, layer, images):
-    """The layer-2 (default from 16,384 images) and layer-3 (MI355PPO_CONV_R3=1) data gradients on kernel R against kernel Z: gradient and its
+    """The layer-2 (default from 512 images) and layer-3 data gradients on kernel R against kernel Z: gradient and its
     amax record bit-equal (the zero border adds exact zeros where kernel Z's border classes skip the taps), within the float64 bar."""
     cin, cout, k, st, hin, hout = SPEC[layer]
     W, _ = _params(layer, 20 * layer + images)
