@@ -31,6 +31,8 @@ int convw_launch(const float* src, const float* dz, float* part_w, float* part_b
 bool convr_on(long long images, long long min_images);
 int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void* pack, const float* bias, float* dst, unsigned dst_bytes, unsigned* bits,
                long long images, const unsigned* src_amax, unsigned* dst_amax, hipStream_t st);
+int convr_fwd2(const char* fn, const float* src, unsigned src_bytes, const void* pack, const float* bias, float* dst, unsigned dst_bytes, unsigned* bits,
+               long long images, const unsigned* src_amax, unsigned* dst_amax, hipStream_t st);
 int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
 int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,

@@ -1,5 +1,5 @@
-// Kernel R -- the INPUT-RESIDENT convolution of round 5 (two-term f16 split only): the layer-3 forward and the layer-2 (layer-3: opt-in)
-// data gradients of the NatureCNN (cleanrl/ppo_atari_multigpu.py:141-142 and their backward, :358) with the source tensor of a GROUP of images
+// Kernel R -- the INPUT-RESIDENT convolution of round 5 (two-term f16 split only): the layer-2 / layer-3 forwards and data gradients of the
+// NatureCNN (cleanrl/ppo_atari_multigpu.py:141-142 and their backward, :358) with the source tensor of a GROUP of images
 // held in LDS, already split into f16 hi / lo planes.
 //
 // What bounded kernel Z on these launches (profiles/r05_pmc_*.csv: matrix pipe 0.24 busy, ten VALU instructions per MFMA, TA 0.7 busy,
@@ -7,8 +7,8 @@
 // and SPLIT once per tap that touches it -- 9 times in the 3 x 3 layers, 4 times in the layer-2 data gradient -- inside the k-loop, on the
 // matrix instructions' critical path.  Here a workgroup
 //   * loads the f32 source of G consecutive images ONCE (contiguous, 16 bytes per lane), splits every element ONCE (f16split.h, the
-//     tensor's scale from its amax record) and stores the hi / lo halves into a padded pixel grid in LDS: record of a pixel = 64 hi
-//     halves (128 B) | 64 lo halves (128 B) | 16 B pad.  The pad makes the record pitch 17 sixteen-byte slots: "lane = pixel" fragment
+//     tensor's scale from its amax record) and stores the hi / lo halves into a padded pixel grid in LDS: record of a pixel = its C hi
+//     halves (2 C bytes) | its C lo halves | 16 B pad.  The pad makes the record pitch an odd number of sixteen-byte slots (17 / 9): "lane = pixel" fragment
 //     reads of 16 lanes with distinct pixel numbers mod 16 hit 16 distinct slots (ds_read_b128: conflict-free).  Zero padding of the data
 //     gradients = a border of zero records written once per launch;
 //   * walks the k-steps with NO address arithmetic and NO VALU in the loop: every fragment is one ds_read_b128 at (lane's window origin +
@@ -42,31 +42,39 @@ enum { R_BIAS_RELU = 0, R_BIAS_RELU_BITS = 1, R_MASKB = 2, R_MASKB_CLS4 = 3 };
 
 constexpr unsigned kROob = 0xFFFFF000u;               // buffer offset out of range for every tensor < 4 GiB - 4 KiB
 constexpr int kRRsrcWord3 = 0x00020000;               // raw buffer, 32-bit elements
-constexpr int kRPix = 272;                            // bytes per pixel record in LDS: 128 hi | 128 lo | 16 pad
 
 // Source (images, IH, IW, 64) f32 channels-last, zero border of HL pixels, window KH x KW at stride 1 over the padded grid, output grid
 // OH x OW per image; NT 32-column tiles of the pack; G images per group on NW waves of MT 32-row tiles each; destination pixel of grid
 // pixel (gy, gx) and column tile j: R_MASKB_CLS4 -> (2 gy + (j >> 1), 2 gx + (j & 1)) of a (2 OH, 2 OW, 32) image, else pixel (gy, gx) of
 // an (OH, OW, 32 NT) image.  ORDER 1: the layer-3 forward's phase order of kernel Z (z_kstep), 0: ascending.
-template <int IH_, int IW_, int HL_, int KH_, int KW_, int OH_, int OW_, int NT_, int G_, int NW_, int MT_, int ORDER_, int SS_, int WGS_, int NS_ = 1>
+template <int IH_, int IW_, int HL_, int KH_, int KW_, int OH_, int OW_, int NT_, int G_, int NW_, int MT_, int ORDER_, int SS_, int WGS_, int NS_ = 1, int IC_ = 64, int S_ = 1>
 struct RGeom {
     static constexpr int IH = IH_, IW = IW_, HL = HL_, KH = KH_, KW = KW_, OH = OH_, OW = OW_, NT = NT_, G = G_, NW = NW_, MT = MT_, ORDER = ORDER_;
+    static constexpr int IC = IC_, S = S_;                                          // source channels; stride of the window over the padded grid
+    static constexpr int PIX = 4 * IC + 16, LO = 2 * IC, C16 = IC / 16, UPP = IC / 4;      // bytes per pixel record: 2 IC hi | 2 IC lo | 16 pad; chunks / 16-byte units per pixel
     static constexpr int SS = SS_;                                                  // k-steps per ring slot (one barrier per slot)
     static constexpr int WGS = WGS_;                                                // workgroups per CU the kernel is sized for (LDS, registers)
     // NS: the waves split the column tiles -- wave w multiplies row tiles of row-wave w % (NW / NS) against column tiles (w / (NW / NS)) NT / NS ..
     static constexpr int NS = NS_, NTW = NT / NS, RW = NW / NS;
     static constexpr int IHP = IH + 2 * HL, IWP = IW + 2 * HL, IPIX = IHP * IWP, OP = OH * OW, ROWS = G * OP, SLOTS = 32 * MT * (NW / NS_);
-    static constexpr int KSTEPS = KH * KW * 4, SPR = KW * 4;
-    static constexpr int IMGB = IPIX * kRPix, ABYTES = G * IMGB;
+    static constexpr int KSTEPS = KH * KW * C16, SPR = KW * C16;
+    static constexpr int IMGB = IPIX * PIX, ABYTES = G * IMGB;
     static constexpr int STEPB = NT * 2048, SLOTB = SS * STEPB;                     // one k-step of the pack; ring slot
-    static constexpr int UNITS = G * IH * IW * 16;                                  // 16-byte units of a group's source
+    static constexpr int UNITS = G * IH * IW * UPP;                                 // 16-byte units of a group's source
+    // Record index of padded pixel (y, x).  Stride 2: the columns are stored even ones first, then the odd ones, so that the windows of
+    // consecutive outputs start at consecutive records (tap column tx picks the half); additive in (window origin) + (tap).
+    static constexpr int pidx(int y, int x) { return S == 2 ? y * IWP + (x & 1) * (IWP / 2) + (x >> 1) : y * IWP + x; }
+    static_assert((S == 1 || (S == 2 && IWP % 2 == 0)) && IC % 16 == 0 && (PIX / 16) % 2 == 1, "strides; whole chunks; an odd record pitch in 16-byte slots");
     static constexpr int THREADS = 64 * NW, NI = (UNITS + THREADS - 1) / THREADS;
     static_assert(ROWS <= SLOTS && KSTEPS % SS == 0 && NT % NS == 0 && NW % NS == 0, "a group's rows fit the waves' tiles; whole ring slots");
     static_assert((ABYTES + 2 * SLOTB) * WGS <= 160 * 1024, "LDS");
 };
-// One persistent workgroup per CU.  64-channel outputs (NT = 2): eight waves of 32 rows, two per SIMD -- 384 / 527 us where four waves of 64 rows
-// (one per SIMD, half the weight-fragment reads per MFMA) took 440 / 585; the layer-2 data gradient (NT = 4: 64 accumulators per 32-row tile)
-// the other way round, 850 against 915 us.  All measured shapes: profiles/r05_tile_shape_experiments.txt.
+// One persistent workgroup per CU.  Layer 3 (NT = 2): eight waves of 32 rows, two per SIMD -- 384 / 527 us where four waves of 64 rows (one per
+// SIMD, half the weight-fragment reads per MFMA) took 440 / 585; the layer-2 data gradient (NT = 4: 64 accumulators per 32-row tile): eight
+// waves of 64 rows, splitting the class tiles two and two (NS = 2), 750 us against 850 (four waves, all tiles) and 915 (eight waves of 32 rows);
+// the layer-2 forward: twelve waves of 32 rows (three per SIMD), splitting the two column tiles -- 6 x 32 row slots for its 162 rows: 775 us
+// against 860 with eight waves and 256 slots.  All measured shapes: profiles/r05_tile_shape_experiments.txt.
+using RConv2 = RGeom<20, 20, 0, 4, 4, 9, 9, 2, 2, 12, 1, 2, 4, 1, 2, 32, 2>;  // a1 (20, 20, 32) -> a2 (9, 9, 64), stride 2: 162 rows of 256 (a1 is 51 KB per image: two images per 160 KB)
 using RConv3 = RGeom<9, 9, 0, 3, 3, 7, 7, 2, 5, 8, 1, 1, 6, 1>;          // a2 (9, 9, 64) -> a3 (7, 7, 64): 245 rows of 256
 using RDgrad3 = RGeom<7, 7, 2, 3, 3, 9, 9, 2, 3, 8, 1, 0, 6, 1>;         // dz3 (7, 7, 64) -> da2 (9, 9, 64): 243 rows of 256
 using RDgrad2 = RGeom<9, 9, 1, 2, 2, 10, 10, 4, 2, 8, 2, 0, 4, 1, 2>;       // dz2 (9, 9, 64) -> da1 (20, 20, 32), four stride-parity classes = four column tiles: 200 rows of 256
@@ -97,7 +105,7 @@ struct RRowTable {
         for (int pass = 0; pass < 2; ++pass)               // pass 0: conflict-free placements only; pass 1: whatever is left, anywhere
             for (int r = 0; r < RG::ROWS; ++r) {
                 const int gi = r / RG::OP, p = r - gi * RG::OP, gy = p / RG::OW, gx = p - gy * RG::OW;
-                const int c = (gi * RG::IPIX + gy * RG::IWP + gx) & 15;
+                const int c = (gi * RG::IPIX + RG::pidx(RG::S * gy, RG::S * gx)) & 15;
                 bool placed = false;
                 for (int i = 0; i < RG::SLOTS && !placed; ++i) placed = row[i] == r;
                 for (int t = 0; t < NSET && !placed; ++t) {
@@ -116,18 +124,22 @@ struct RRowTable {
 // visited index v -> (k-step of the pack, byte offset of the step's hi fragment from the lane's window origin)
 template <class RG>
 __device__ __forceinline__ constexpr int r_kstep(int v) {
-    if constexpr (RG::ORDER == 1) {
+    if constexpr (RG::ORDER == 1) {                       // kernel Z's phase order of the 3 x 3 / 64-channel forward (z_kstep)
         const int lp = v >= 18 ? 1 : 0, w = v - 18 * lp, combo = w >> 1;
         const int ty = combo / 3, tx = combo - 3 * ty;
         return ty * RG::SPR + 4 * tx + 2 * lp + (w & 1);
+    } else if constexpr (RG::ORDER == 2) {                // ... of the 4 x 4 stride-2 / 32-channel forward: (row parity, column parity) phases
+        const int g = v >> 3, w = v & 7;
+        const int ty = (g >> 1) + 2 * (w >> 2), tx = (g & 1) + 2 * ((w >> 1) & 1);
+        return ty * RG::SPR + 2 * tx + (w & 1);
     } else {
         return v;
     }
 }
 template <class RG>
 __device__ __forceinline__ constexpr int r_tapoff(int ks) {
-    const int ty = ks / RG::SPR, us = ks - ty * RG::SPR, tx = us >> 2, chunk = us & 3;
-    return (ty * RG::IWP + tx) * kRPix + chunk * 32;
+    const int ty = ks / RG::SPR, us = ks - ty * RG::SPR, tx = us / RG::C16, chunk = us - tx * RG::C16;
+    return RG::pidx(ty, tx) * RG::PIX + chunk * 32;
 }
 
 // lane `l` of w := the wave-uniform value x; x where bit (lane) of {hi, lo} is set, else 0 (gemmz.hip's z_writelane / z_keep_where: the
@@ -164,8 +176,9 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     constexpr int NT = RG::NT, NTW = RG::NTW, MT = RG::MT, NW = RG::NW, NI = RG::NI, THREADS = RG::THREADS;
     constexpr int SS = RG::SS, NSLOT = RG::KSTEPS / SS;
     constexpr int kPieces = SS * NT * 2;                  // KiB pieces of a ring slot: (step h of the slot, tile j, term t), x = (h NT + j) 2 + t
-    constexpr int kShare = kPieces / NW;
-    static_assert(kPieces % NW == 0, "whole pieces per wave");
+    constexpr int kFetchers = kPieces % NW == 0 ? NW : (kPieces % (NW / 2) == 0 ? NW / 2 : (kPieces % 8 == 0 && NW >= 8 ? 8 : 4));      // waves that move ring pieces
+    constexpr int kShare = kPieces / kFetchers;
+    static_assert(kPieces % kFetchers == 0 && kFetchers <= NW, "whole pieces per fetching wave");
     __shared__ __attribute__((aligned(16))) unsigned char lds[RG::ABYTES + 2 * RG::SLOTB];
     unsigned char* const ring = lds + RG::ABYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     for (int i = 0; i < MT; ++i) {
         int gi, pp, gy, gx;
         row_pixel((rw * MT + i) * 32 + li, gi, pp, gy, gx);
-        win[i] = lds + gi * RG::IMGB + (gy * RG::IWP + gx) * kRPix + 16 * lh;
+        win[i] = lds + gi * RG::IMGB + RG::pidx(RG::S * gy, RG::S * gx) * RG::PIX + 16 * lh;
         rword[i] = row_coff(gi, pp, gy, gx);
         if (MT == 1 || lh == i) rlane = rword[i];                         // (MT = 2: lanes 0..31 tile 0, lanes 32..63 tile 1; MT = 1: both halves tile 0)
 #pragma unroll
@@ -214,12 +227,12 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 
     // ---- the group's source: unit u = 16 bytes = 4 channels of a pixel; thread tid takes units it * THREADS + tid
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)a.a_bytes, kRRsrcWord3);
-    unsigned udst[NI];                                    // LDS byte address of the unit's hi half (lo: + 128); ~0u: no such unit
+    unsigned udst[NI];                                    // LDS byte address of the unit's hi half (lo: + RG::LO); ~0u: no such unit
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
         const int u = it * THREADS + tid;
-        const int pix = u >> 4, c4 = u & 15, img = pix / (RG::IH * RG::IW), q = pix - img * (RG::IH * RG::IW), qy = q / RG::IW, qx = q - qy * RG::IW;
-        udst[it] = u < RG::UNITS ? (unsigned)(img * RG::IMGB + ((qy + RG::HL) * RG::IWP + qx + RG::HL) * kRPix + c4 * 8) : ~0u;
+        const int pix = u / RG::UPP, c4 = u - pix * RG::UPP, img = pix / (RG::IH * RG::IW), q = pix - img * (RG::IH * RG::IW), qy = q / RG::IW, qx = q - qy * RG::IW;
+        udst[it] = u < RG::UNITS ? (unsigned)(img * RG::IMGB + RG::pidx(qy + RG::HL, qx + RG::HL) * RG::PIX + c4 * 8) : ~0u;
     }
     constexpr int kPrePer = 2;                            // loads of the next group's source issued per k-step
     static_assert((RG::KSTEPS - 1) * kPrePer >= NI, "the next group's source is requested inside one k-loop");
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
             f16_split4(pre[it], sa, hi, lo);
             if (udst[it] != ~0u) {
                 *reinterpret_cast<uint2*>(lds + udst[it]) = make_uint2(hi[0], hi[1]);
-                *reinterpret_cast<uint2*>(lds + udst[it] + 128) = make_uint2(lo[0], lo[1]);
+                *reinterpret_cast<uint2*>(lds + udst[it] + RG::LO) = make_uint2(lo[0], lo[1]);
             }
         }
     };
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     // the pack through a buffer resource: per-lane offset 16 lane in ONE register, the piece's offset in an SGPR (64-bit per-piece addresses
     // of the unrolled loop cost 70 registers)
     const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.pack), 0, kF16PackHeader + RG::KSTEPS * RG::STEPB, kRRsrcWord3);
-    const unsigned lane16 = 16u * (unsigned)lane;
+    const unsigned lane16f = (kFetchers == NW || wave < kFetchers) ? 16u * (unsigned)lane : kROob;      // (waves that move no ring pieces load zeros from nowhere: no branch around a load)
     // The weights' ring: slot s = the visited k-steps SS s .. SS s + SS - 1, 2 buffers.  Wave w moves pieces w kShare .. + kShare - 1 of a slot: global ->
     // registers TWO slots ahead of the write (vector loads return in order and the next group's source -- a trip to HBM -- travels in the
     // same queue: one slot of distance left the ring waiting), registers -> buffer (s + 1) & 1 at the first step of slot s -- every wave
@@ -279,12 +292,13 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 #pragma unroll
         for (int u = 0; u < kShare; ++u) {
             const int x = wave * kShare + u, h = x / (NT * 2), jt = x - h * (NT * 2);       // (wave-uniform: scalar arithmetic)
-            bst[slot & 1][u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, lane16, kF16PackHeader + r_kstep<RG>(SS * slot + h) * RG::STEPB + jt * 1024, 0));
+            bst[slot & 1][u] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, lane16f, kF16PackHeader + r_kstep<RG>(SS * slot + h) * RG::STEPB + jt * 1024, 0));
         }
     };
     auto write_slot = [&](int slot) __attribute__((always_inline)) {                     // -> buffer slot & 1
+        if (kFetchers == NW || wave < kFetchers)
 #pragma unroll
-        for (int u = 0; u < kShare; ++u) *reinterpret_cast<s_u32x4*>(ring_l + (slot & 1) * RG::SLOTB + (wave * kShare + u) * 1024) = bst[slot & 1][u];
+            for (int u = 0; u < kShare; ++u) *reinterpret_cast<s_u32x4*>(ring_l + (slot & 1) * RG::SLOTB + (wave * kShare + u) * 1024) = bst[slot & 1][u];
     };
     auto ring_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             pa[par][i][0] = *reinterpret_cast<const s_u32x4*>(win[i] + off);
-            pa[par][i][1] = *reinterpret_cast<const s_u32x4*>(win[i] + off + 128);
+            pa[par][i][1] = *reinterpret_cast<const s_u32x4*>(win[i] + off + RG::LO);
         }
     };
     auto read_b = [&](int par, int v) __attribute__((always_inline)) {                   // step v = step v % SS of slot v / SS
@@ -472,11 +486,12 @@ static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
     return check_launch(what);
 }
 
-// Which launches kernel R takes (profiles/r05_kernel_r_sizes.txt: same-box A/B at 256 .. 32,768 images): the layer-3 forward and data
-// gradient at every size (at or below kernel Z's time everywhere; 0.72 x at 32,768 and 0.78 x at 1,024 images for the forward), the layer-2
-// data gradient from `min_images` = 512 on (0.76 x at 32,768; 1.13 x at 256: one persistent workgroup per CU with two images each leaves
-// half the chip idle there).  MI355PPO_CONV_R=0: never (A/B runs; the results are bit-identical either way); MI355PPO_CONV_R_MIN overrides
-// the threshold of every layer.  Read at every call: tests switch them.
+// Which launches kernel R takes (profiles/r05_kernel_r_sizes.txt: same-box A/B at 256 .. 32,768 images): both forwards and the layer-3 data
+// gradient at every size (at or below kernel Z's time everywhere; at 32,768 images 0.72 x for the layer-3 forward, 0.90 x for the layer-2
+// forward -- its 51-KB source allows two images = 162 of 192 row slots per workgroup), the layer-2 data gradient from `min_images` = 512 on
+// (0.76 x at 32,768; 1.13 x at 256: one persistent workgroup per CU with two images each leaves half the chip idle there).
+// MI355PPO_CONV_R=0: never (A/B runs; the results are bit-identical either way); MI355PPO_CONV_R_MIN overrides the threshold of every layer.
+// Read at every call: tests switch them.
 bool convr_on(long long images, long long min_images) {
     const char* e = getenv("MI355PPO_CONV_R");
     if (e && e[0] == '0') return false;
@@ -490,6 +505,14 @@ int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void*
     a.A = src; a.a_bytes = src_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.bits_out = bits; a.C = dst; a.c_bytes = dst_bytes;
     a.images = images; a.a_amax = src_amax; a.c_amax = dst_amax;
     return bits ? r_launch<RConv3, R_BIAS_RELU_BITS>(a, st, fn) : r_launch<RConv3, R_BIAS_RELU>(a, st, fn);
+}
+
+int convr_fwd2(const char* fn, const float* src, unsigned src_bytes, const void* pack, const float* bias, float* dst, unsigned dst_bytes, unsigned* bits,
+               long long images, const unsigned* src_amax, unsigned* dst_amax, hipStream_t st) {
+    RArgs a{};
+    a.A = src; a.a_bytes = src_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.bits_out = bits; a.C = dst; a.c_bytes = dst_bytes;
+    a.images = images; a.a_amax = src_amax; a.c_amax = dst_amax;
+    return bits ? r_launch<RConv2, R_BIAS_RELU_BITS>(a, st, fn) : r_launch<RConv2, R_BIAS_RELU>(a, st, fn);
 }
 
 int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,

@@ -1315,9 +1315,9 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_maskbits_packed_f32(const float* d
 // mode 1 for the layer-3 data gradient (N = 64 input channels, K = (r, c, output channel), taps flipped), mode 2 for the
 // layer-2 data gradient (N = 4 stride-parity classes x 32 input channels, K = (r, c, output channel)).
 static bool conv_r_takes(long long images, int layer, bool dgrad) {      // which f16x2 launches kernel R (convr.hip) takes -- the one place that decides
-    if (!dgrad) return layer == 3 && convr_on(images, 1);
-    const char* e = getenv(layer == 3 ? "MI355PPO_CONV_R3" : "MI355PPO_CONV_R2");      // =0: this data gradient on kernel Z
-    return !(e && e[0] == '0') && convr_on(images, layer == 3 ? 1 : 512);
+    static const char* const kOff[2][2] = {{"MI355PPO_CONV_R2F", "MI355PPO_CONV_R3F"}, {"MI355PPO_CONV_R2", "MI355PPO_CONV_R3"}};      // =0: this launch on kernel Z
+    const char* e = getenv(kOff[dgrad ? 1 : 0][layer - 2]);
+    return !(e && e[0] == '0') && convr_on(images, dgrad && layer == 2 ? 512 : 1);
 }
 
 static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pack, const float* bias, float* dst, unsigned* bits,
@@ -1338,6 +1338,8 @@ static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pa
     static const long long small_below = [] { const char* e = getenv("MI355PPO_Z_SMALL_BELOW"); return e ? atoll(e) : 768LL; }();
     const bool small = !bits && small_mt == 1 && images < small_below;
     if (layer == 2) {
+        if (src_amax && conv_r_takes(images, 2, false))
+            return convr_fwd2(fn, src, (unsigned)srcb, pack, bias, dst, (unsigned)((long long)images * 81 * 64 * 4), bits, images, src_amax, dst_amax, st);
         ZArgs za = zargs(src, srcb, 0, pack, bias, nullptr, dst, (long long)images * 81 * 64 * 4, 64, (long long)images * 81, 64, ZConv2::K);
         za.bits_out = bits;
         za.a_amax = src_amax; za.c_amax = dst_amax;

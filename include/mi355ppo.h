@@ -599,8 +599,8 @@ MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(const float* dz, const
                                                           float* dsrc, int64_t images, int layer, const uint32_t* dz_amax, uint32_t* dsrc_amax,
                                                           void* stream);
 /* 'R' or 'Z': the kernel a forward (dgrad = 0) / bit-masked data-gradient (dgrad = 1) call of this size and layer runs (profiling aid).
- * Kernel R (csrc/convr.hip) holds the source of a group of images in LDS, split once, and takes the layer-3 forward and data gradient
- * at every size and the layer-2 data gradient from 512 images on; its results are kernel Z's bit for bit (same products, same order). */
+ * Kernel R (csrc/convr.hip) holds the source of a group of images in LDS, split once, and takes both forwards and the layer-3 data
+ * gradient at every size and the layer-2 data gradient from 512 images on; its results are kernel Z's bit for bit (same products, same order). */
 MI355PPO_API int mi355ppo_cnn_conv_packed_kernel_f16x2(int64_t images, int layer, int dgrad);
 /* mi355ppo_cnn_conv_wgrad_f32 for layers 2 / 3 (kernel V); other batches fall to the f32-pipe kernel and ignore the records */
 MI355PPO_API int mi355ppo_cnn_conv_wgrad_f16x2_f32(const float* src, const float* dz, float* dW, float* db, int64_t images, int layer,

@@ -164,32 +164,34 @@ def test_conv_forward_f16x2_against_float64(layer, images):
     assert torch.equal(cnn.unpack_mask_bits(bits, y2.shape), y2 > 0) and cnn.amax_value(ry2) == y2.max().item()
 
 
+@pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 4, 5, 61, 1027])
-def test_kernel_r_forward_layer3_is_kernel_z_bit_for_bit(monkeypatch, images):
-    """Kernel R (csrc/convr.hip: the source of an image group resident in LDS, split once) against kernel Z on the layer-3 forward, with and
-    without the mask bits, at sizes with partial last groups (5 images per group): output, mask words and the output's amax record equal
-    bit for bit -- the same products in the same order --, and the output within the float64 bar."""
-    cin, cout, k, st, hin, hout = SPEC[3]
-    W, b = _params(3, 77 + images)
+def test_kernel_r_forwards_are_kernel_z_bit_for_bit(monkeypatch, layer, images):
+    """Kernel R (csrc/convr.hip: the source of an image group resident in LDS, split once) against kernel Z on the layer-2 (stride 2, 32
+    source channels, 2 images per group) and layer-3 (5 images per group) forwards, with and without the mask bits, at sizes with partial
+    last groups: output, mask words and the output's amax record equal bit for bit -- the same products in the same order --, and the
+    output within the float64 bar."""
+    cin, cout, k, st, hin, hout = SPEC[layer]
+    W, b = _params(layer, 77 + images)
     g = torch.Generator(device=DEV).manual_seed(images)
     x = torch.relu(torch.randn(images, hin, hin, cin, device=DEV, generator=g)) * torch.exp(torch.randn(images, hin, hin, cin, device=DEV, generator=g))
-    pack = cnn.conv_zpack_f16x2(W, 3, cnn.MODE_FWD)
+    pack = cnn.conv_zpack_f16x2(W, layer, cnn.MODE_FWD)
     rx = _rec_of(x)
     out = {}
     for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("R", {"MI355PPO_CONV_R": "1", "MI355PPO_CONV_R_MIN": "1"})):
         for key, val in env.items():
             monkeypatch.setenv(key, val)
         ry, ry2 = cnn.new_amax(2, DEV)
-        y = cnn.conv_fwd_packed(x, pack, b, 3, amax=(rx, ry))
+        y = cnn.conv_fwd_packed(x, pack, b, layer, amax=(rx, ry))
         bits = torch.zeros(cnn.mask_words(y.numel()), dtype=torch.int32, device=DEV)
-        y2 = cnn.conv_fwd_packed(x, pack, b, 3, bits=bits, amax=(rx, ry2))
+        y2 = cnn.conv_fwd_packed(x, pack, b, layer, bits=bits, amax=(rx, ry2))
         out[route] = (y, y2, bits, cnn.amax_value(ry), cnn.amax_value(ry2))
     (yz, yz2, bz, az, az2), (yr, yr2, br, ar, ar2) = out["Z"], out["R"]
     assert torch.equal(yr.view(torch.int32), yr2.view(torch.int32)) and torch.equal(br, bz) and ar == az == ar2 == yr.max().item()
     if images >= 768:                                    # (below, kernel Z runs its 32-row tiles without the bits and 64-row tiles with them)
         assert torch.equal(yr.view(torch.int32), yz.view(torch.int32))
     assert torch.equal(yr2.view(torch.int32), yz2.view(torch.int32))
-    _close(yr, torch.relu(_conv64(x.double(), W.double(), b.double(), st)), f"kernel R conv3 fwd, {images} images")
+    _close(yr, torch.relu(_conv64(x.double(), W.double(), b.double(), st)), f"kernel R conv{layer} fwd, {images} images")
 
 
 @pytest.mark.parametrize("layer", [2, 3])
