@@ -37,6 +37,10 @@ int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void*
                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
 int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
+// convu.hip: kernel U, the layer-3 weight gradient on the f16 split with both operands of an image group resident in LDS (-> 0 launched, 1 not applicable)
+int convu_max_parts();
+int convu_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
+                 const unsigned* dz_amax, const unsigned* src_amax);
 int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
                     hipStream_t stream, const unsigned* a_amax = nullptr);
 

@@ -1149,8 +1149,8 @@ static int wgrad_grid(int64_t images) { return images < 512 ? (int)images : 512;
 // partial sums the workspace holds: the workgroups of kernels P / T, or kernel V's slabs where those are more (batches of 208 .. 240 images
 // at layer 2: 256 slabs -- round 5: sized for `images` partials before, kernel V's last slabs landed in the bias partials)
 static int wgrad_parts(int64_t images, int layer) {
-    const int g = wgrad_grid(images) * (layer == 1 ? 4 : 1), v = layer == 1 ? 0 : convw_parts(images, layer);
-    return g > v ? g : v;
+    const int g = wgrad_grid(images) * (layer == 1 ? 4 : 1), v = layer == 1 ? 0 : convw_parts(images, layer), u = layer == 3 ? convu_max_parts() : 0;
+    return g > v ? (g > u ? g : u) : (v > u ? v : u);
 }
 
 extern "C" MI355PPO_API size_t mi355ppo_cnn_conv_wgrad_workspace_bytes(int64_t images, int layer) {
@@ -1197,6 +1197,8 @@ static int conv_wgrad_impl(const char* fn, const void* src, const int64_t* inds,
         wparts = grid * 4;
         const int rc = conv1p_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images, grid, s, dz_amax, &pscale);
         if (rc) return rc;
+    } else if (int uparts = 0; convu_launch(static_cast<const float*>(src), dz, part_w, part_b, images, layer, &uparts, s, dz_amax, src_amax) == 0) {
+        wparts = uparts;                // kernel U (f16 split, layer 3: both operands resident in LDS, convu.hip): one partial per workgroup
     } else if (int vparts = 0; convw_launch(static_cast<const float*>(src), dz, part_w, part_b, images, layer, &vparts, s, dz_amax, src_amax) != 1) {
         wparts = vparts;                // kernel V (bf16 pipe, convw.hip) took it: one partial per slab (an error surfaces in check_launch below)
     } else if (layer == 2) {            // kernel T: a workgroup walks image PAIRS

@@ -1,0 +1,218 @@
+// Kernel U -- the layer-3 weight (+ bias) gradient of the NatureCNN on the two-term f16 split with BOTH operands of a group of images
+// resident in LDS, split once (kernel R's idea applied to kernel V's problem; cleanrl/ppo_atari_multigpu.py:141 and its backward, :358):
+//     dW[co][(ty, tx, ci)] = sum over output pixels p of dz[p][co] * src[pixel of p shifted by tap (ty, tx)][ci]
+// The reduction index is the PIXEL, the slow index of both tensors in memory.  Kernel V (convw.hip) transposes both operands through
+// wave-private LDS with 4-byte reads and splits every fragment in registers -- 32 LDS reads and ~100 VALU instructions per 12 MFMAs, every
+// source pixel fetched and split once per tap (profiles/r05_pmc_*.csv: VALU 0.54 busy, matrix pipe 0.31).  Here a workgroup
+//   * loads the f32 source (9 x 9 x 64) and dz (7 x 7 x 64) of G = 4 images once, splits every element once (each tensor's scale from its amax
+//     record) and stores hi / lo halves as pixel records (128 B hi | 128 B lo | 16 B pad, as kernel R);
+//   * reads MFMA fragments with `ds_read_b64_tr_b16` -- the LDS transpose read of gfx950: a 16-lane group reads a [4 pixels][16 channels]
+//     block, four contiguous halves per lane, and every lane receives one channel's four pixels (tools/tr_probe.cpp) -- so "8 consecutive k of
+//     one channel" is two such reads, no VALU, no address arithmetic (compile-time offsets; one select per k-step for the image the step's
+//     two pixel lines lie in);
+//   * keeps the whole dW (64 x 576 = 36 tiles of 32 x 32) in the accumulators of its 12 waves (3 tiles each, 3 waves per SIMD) across ALL its
+//     groups and writes one partial per workgroup at the end; conv.hip's two-stage reduce adds the partials in a fixed order (deterministic).
+// k order: the reduction runs over pixel LINES padded to 8 (7 outputs + one zero dz record), so that a block of four k is four consecutive
+// pixels of one line (consecutive records for both operands: dz's line, and the source line shifted by the tap); the padded position
+// multiplies a zero dz by a finite source value.  16 k = two lines per k-step, 14 k-steps per group of 4 images.
+// The bias gradient: every thread adds the raw f32 dz values of the 16-byte units it loads (its four channels are the same for every unit:
+// 768 threads, 16 units per pixel), folded per channel in a fixed order at the end.
+// Arithmetic: exact products of the f16 terms (hi hi, hi lo, lo hi), f32 accumulation in another order than kernel V's (per-workgroup sums
+// over whole images instead of pixel slabs): held to float64 with kernel V's bars, not bit-compared (tests/test_gpu_f16x2.py).
+#include "common.h"
+#include "f16split.h"
+
+#pragma clang fp contract(off)
+
+namespace mi355ppo {
+
+typedef float u_f32x16 __attribute__((ext_vector_type(16)));
+typedef short u_s16x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kUOob = 0xFFFFF000u;
+constexpr int kURsrcWord3 = 0x00020000;
+
+struct UGeom3 {
+    static constexpr int SH = 9, SW = 9, C = 64, KH = 3, KW = 3, OH = 7, OW = 7, CO = 64;
+    static constexpr int LW = 8;                                   // records per dz line in LDS / k per line: OW padded to a multiple of 4
+    static constexpr int G = 4, NW = 12, THREADS = 64 * NW;
+    static constexpr int PIX = 4 * C + 16, LO = 2 * C;             // pixel record: 128 B hi | 128 B lo | 16 B pad
+    static constexpr int SRC_REC = SH * SW, DZ_REC = OH * LW;      // records per image
+    static constexpr int SRC_SLACK = 3;                            // the padded position of the last line reads up to (SH - 1) * SW + LW - 1 + KW - 1 = 81 + 0 .. 1: zeroed slack
+    static constexpr int SRCB = (G * SRC_REC + SRC_SLACK) * PIX, DZB = G * DZ_REC * PIX;
+    static constexpr int KSTEPS = G * OH * LW / 16;                // 14
+    static constexpr int SRC_UNITS = G * SH * SW * (C / 4), DZ_UNITS = G * OH * OW * (CO / 4), UNITS = SRC_UNITS + DZ_UNITS;
+    static constexpr int NIS = (SRC_UNITS + THREADS - 1) / THREADS, NID = (DZ_UNITS + THREADS - 1) / THREADS, NI = NIS + NID;      // 7 + 5 rounds of loads per thread: a round is all source or all dz
+    static constexpr int NTILES = KH * KW * (C / 32), TPW = 2 * NTILES / NW;      // 18 column tiles; 3 tiles per wave (one of the two co tiles each)
+    static_assert(G * OH * LW % 16 == 0 && 2 * NTILES % NW == 0 && THREADS % 16 == 0 && SRCB + DZB <= 160 * 1024 && NI <= KSTEPS - 1, "shape");
+};
+
+template <class UG>
+__global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void convu_kernel(
+    const float* __restrict__ src, const float* __restrict__ dz, float* __restrict__ part_w, float* __restrict__ part_b, long long images,
+    int groups, unsigned src_bytes, unsigned dz_bytes, const unsigned* __restrict__ dz_amax, const unsigned* __restrict__ src_amax) {
+    constexpr int NI = UG::NI, TPW = UG::TPW, PIX = UG::PIX;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[UG::SRCB + UG::DZB];
+    unsigned char* const lsrc = lds;
+    unsigned char* const ldz = lds + UG::SRCB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15, r = i >> 2, c4 = i & 3;             // 16-lane group; its lane's block row / column chunk
+    const int ct = wave & 1, ng = wave >> 1;                                    // co tile; first column tile / TPW
+
+    const int es = f16_scale_exp(amax_load(src_amax, lane)), ed = f16_scale_exp(amax_load(dz_amax, lane));
+    const float ss = f16_pow2(es), sd = f16_pow2(ed), un = f16_unscale(es, ed);
+
+    // zero everything once: dz's padded records and the source slack stay zero (the fill writes real pixels only)
+    for (int o = tid * 16; o < UG::SRCB + UG::DZB; o += UG::THREADS * 16) *reinterpret_cast<s_u32x4*>(lds + o) = (s_u32x4){0u, 0u, 0u, 0u};
+
+    // ---- fragment addresses.  Lane (g, r, c4) passes the address of 4 contiguous halves: row r of its group's block, channels 16 (g & 1) +
+    // 4 c4 .. + 3 of the tile.  Which four pixels form a block is free (any bijection of the step's 16 k, the same for both operands): block
+    // b = 2 (g >> 1) + t (t: first / second read of a fragment) takes pixels b, b + 4, b + 8, b + 12 of the step -- rows FOUR records apart:
+    // 4 x 272 B = 8 eight-byte chunks (mod 32), so the 32 lanes of a pass (4 rows x 2 groups x 4 chunks) cover all 64 banks once.  (Four
+    // CONSECUTIVE pixels per block put the rows 2 chunks apart: ~3-way conflicts, the B reads were 43 % of the kernel's time.)
+    // Pixel 4 r + b of the step = line 2 s + (r >> 1), x = 4 (r & 1) + b.
+    const int half = g >> 1, rline = r >> 1;
+    const unsigned char* const dz_lane = ldz + (4 * r + 2 * half) * PIX + (32 * ct + 16 * (g & 1) + 4 * c4) * 2;       // + 16 s records, + t records (+ LO)
+    const unsigned char* const src_lane = lsrc + (4 * (r & 1) + 2 * half) * PIX + (16 * (g & 1) + 4 * c4) * 2;          // + record of (line, tap), + t records, + 64 cih (+ LO)
+
+    // ---- the group's source and dz: unit = 16 bytes = 4 channels of a pixel; in round `it` thread tid takes unit it * THREADS + tid of the source
+    // (rounds 0 .. NIS - 1) or of dz (the rest); its channel quad tid % 16 is the same for every unit
+    const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)src_bytes, kURsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, (int)dz_bytes, kURsrcWord3);
+    s_u32x4 pre[NI];
+    float db4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto unit_dst = [&](int it) __attribute__((always_inline)) -> unsigned {      // LDS byte offset of the unit's hi half (lo: + LO); ~0u: no such unit
+        if (it < UG::NIS) {
+            const int u = it * UG::THREADS + tid;
+            return u < UG::SRC_UNITS ? (unsigned)((u >> 4) * PIX + (u & 15) * 8) : ~0u;
+        }
+        const int v = (it - UG::NIS) * UG::THREADS + tid, q = v >> 4, gi = q / (UG::OH * UG::OW), p = q - gi * (UG::OH * UG::OW), y = p / UG::OW, x = p - y * UG::OW;
+        return v < UG::DZ_UNITS ? (unsigned)(UG::SRCB + ((gi * UG::OH + y) * UG::LW + x) * PIX + (v & 15) * 8) : ~0u;
+    };
+    auto prefetch = [&](int grp, int it) __attribute__((always_inline)) {        // units past the tensors (last group, groups past the end) load zeros
+        const bool any = grp < groups;
+        if (it < UG::NIS) {
+            const int u = it * UG::THREADS + tid;
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, (any && u < UG::SRC_UNITS) ? (unsigned)grp * (unsigned)(UG::SRC_UNITS * 16) + (unsigned)u * 16u : kUOob, 0, 0));
+        } else {
+            const int v = (it - UG::NIS) * UG::THREADS + tid;
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_d, (any && v < UG::DZ_UNITS) ? (unsigned)grp * (unsigned)(UG::DZ_UNITS * 16) + (unsigned)v * 16u : kUOob, 0, 0));
+        }
+    };
+    auto fill = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const bool is_dz = it >= UG::NIS;
+            unsigned hi[2], lo[2];
+            f16_split4(pre[it], is_dz ? sd : ss, hi, lo);
+            const unsigned d = unit_dst(it);
+            if (d != ~0u) {
+                *reinterpret_cast<uint2*>(lds + d) = make_uint2(hi[0], hi[1]);
+                *reinterpret_cast<uint2*>(lds + d + UG::LO) = make_uint2(lo[0], lo[1]);
+            }
+            if (is_dz) {                                  // (units past the end loaded zeros)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) db4[c] += __uint_as_float(pre[it][c]);
+            }
+        }
+    };
+
+    u_f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    typedef u_s16x4 __attribute__((address_space(3))) * lds_v4;
+    auto tr8 = [&](const unsigned char* p) __attribute__((always_inline)) -> s_u32x4 {          // 8 k of this lane's channel: two transpose reads (blocks b and b + 1: one record apart)
+        const u_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p));
+        const u_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + PIX));
+        const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+        return (s_u32x4){ua.x, ua.y, ub.x, ub.y};
+    };
+
+    int grp = blockIdx.x;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) prefetch(grp, it);
+    for (; grp < groups; grp += gridDim.x) {
+        __syncthreads();                                  // every wave is done with the previous group's records (first pass: the zero fill)
+        fill();
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < UG::KSTEPS; ++s) {
+            if (s >= 1 && s <= NI) prefetch(grp + gridDim.x, s - 1);          // the next group's source and dz, one load per k-step
+            // the two pixel lines of the step: global line L = 2 s + (0 | 1) -> image L / OH, row L % OH; this lane's block row lies in line r >> 1
+            constexpr int OH = UG::OH;
+            const int L0 = 2 * s, L1 = 2 * s + 1;
+            const int rec0 = (L0 / OH) * UG::SRC_REC + (L0 % OH) * UG::SW, rec1 = (L1 / OH) * UG::SRC_REC + (L1 % OH) * UG::SW;
+            const unsigned char* const sline = src_lane + (rline ? rec1 : rec0) * PIX;
+            const unsigned char* const dline = dz_lane + 16 * s * PIX;
+            const s_u32x4 a_hi = tr8(dline), a_lo = tr8(dline + UG::LO);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tile = ng * TPW + t, tap = tile >> 1, cih = tile & 1;      // (wave-uniform)
+                const int ty = tap / UG::KW, tx = tap - ty * UG::KW;
+                const unsigned char* const p = sline + (ty * UG::SW + tx) * PIX + 64 * cih;
+                const s_u32x4 b_hi = tr8(p), b_lo = tr8(p + UG::LO);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_hi), __builtin_bit_cast(s_f16x8, b_hi), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_hi), __builtin_bit_cast(s_f16x8, b_lo), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_lo), __builtin_bit_cast(s_f16x8, b_hi), acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- this workgroup's partial dW: accumulator e of tile t = row co = 32 ct + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column (tap, ci = 32 cih + lane % 32)
+    float* const pw = part_w + (size_t)blockIdx.x * (UG::CO * UG::KH * UG::KW * UG::C);
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = ng * TPW + t, tap = tile >> 1, cih = tile & 1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = 32 * ct + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            pw[co * (UG::KH * UG::KW * UG::C) + tap * UG::C + 32 * cih + li] = acc[t][e] * un;
+        }
+    }
+    // ---- and partial db: the threads' sums, channel quad tid % 16, folded in the order of the thread index
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(lds);     // [THREADS / 16][64]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[(tid >> 4) * 64 + 4 * (tid & 15) + c] = db4[c];
+    __syncthreads();
+    if (tid < UG::CO) {
+        float sum = 0.0f;
+        for (int k = 0; k < UG::THREADS / 16; ++k) sum += red[k * 64 + tid];
+        part_b[(size_t)blockIdx.x * UG::CO + tid] = sum;
+    }
+}
+
+// MI355PPO_CONV_U=0: the layer-3 weight gradient stays on kernel V (A/B runs).  Read at every call.
+bool convu_on() {
+    const char* e = getenv("MI355PPO_CONV_U");
+    return !(e && e[0] == '0');
+}
+
+int convu_max_parts() { return 256; }
+
+// -> 0 launched (nparts partials written), 1 not applicable
+int convu_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
+                 const unsigned* dz_amax, const unsigned* src_amax) {
+    if (layer != 3 || !dz_amax || !src_amax || !convu_on()) return 1;
+    const long long srcb = (long long)images * 9 * 9 * 64 * 4, dzb = (long long)images * 7 * 7 * 64 * 4;
+    if (srcb >= (1LL << 32) - 8192) return 1;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;
+        }
+        cus = n < convu_max_parts() ? n : convu_max_parts();
+    }
+    const int groups = (int)((images + UGeom3::G - 1) / UGeom3::G);
+    const int grid = groups < cus ? groups : cus;
+    hipLaunchKernelGGL((convu_kernel<UGeom3>), dim3((unsigned)grid), dim3(UGeom3::THREADS), 0, s, src, dz, part_w, part_b, (long long)images, groups,
+                       (unsigned)srcb, (unsigned)dzb, dz_amax, src_amax);
+    *nparts = grid;
+    return 0;
+}
+
+}  // namespace mi355ppo
