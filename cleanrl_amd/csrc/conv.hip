@@ -1149,7 +1149,7 @@ static int wgrad_grid(int64_t images) { return images < 512 ? (int)images : 512;
 // partial sums the workspace holds: the workgroups of kernels P / T, or kernel V's slabs where those are more (batches of 208 .. 240 images
 // at layer 2: 256 slabs -- round 5: sized for `images` partials before, kernel V's last slabs landed in the bias partials)
 static int wgrad_parts(int64_t images, int layer) {
-    const int g = wgrad_grid(images) * (layer == 1 ? 4 : 1), v = layer == 1 ? 0 : convw_parts(images, layer), u = layer == 3 ? convu_max_parts() : 0;
+    const int g = wgrad_grid(images) * (layer == 1 ? 4 : 1), v = layer == 1 ? 0 : convw_parts(images, layer), u = layer == 1 ? 0 : convu_max_parts();
     return g > v ? (g > u ? g : u) : (v > u ? v : u);
 }
 

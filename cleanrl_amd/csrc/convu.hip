@@ -31,26 +31,37 @@ typedef short u_s16x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kUOob = 0xFFFFF000u;
 constexpr int kURsrcWord3 = 0x00020000;
 
-struct UGeom3 {
-    static constexpr int SH = 9, SW = 9, C = 64, KH = 3, KW = 3, OH = 7, OW = 7, CO = 64;
-    static constexpr int LW = 8;                                   // records per dz line in LDS / k per line: OW padded to a multiple of 4
-    static constexpr int G = 4, NW = 12, THREADS = 64 * NW;
-    static constexpr int PIX = 4 * C + 16, LO = 2 * C;             // pixel record: 128 B hi | 128 B lo | 16 B pad
-    static constexpr int SRC_REC = SH * SW, DZ_REC = OH * LW;      // records per image
-    static constexpr int SRC_SLACK = 3;                            // the padded position of the last line reads up to (SH - 1) * SW + LW - 1 + KW - 1 = 81 + 0 .. 1: zeroed slack
-    static constexpr int SRCB = (G * SRC_REC + SRC_SLACK) * PIX, DZB = G * DZ_REC * PIX;
-    static constexpr int KSTEPS = G * OH * LW / 16;                // 14
-    static constexpr int SRC_UNITS = G * SH * SW * (C / 4), DZ_UNITS = G * OH * OW * (CO / 4), UNITS = SRC_UNITS + DZ_UNITS;
-    static constexpr int NIS = (SRC_UNITS + THREADS - 1) / THREADS, NID = (DZ_UNITS + THREADS - 1) / THREADS, NI = NIS + NID;      // 7 + 5 rounds of loads per thread: a round is all source or all dz
-    static constexpr int NTILES = KH * KW * (C / 32), TPW = 2 * NTILES / NW;      // 18 column tiles; 3 tiles per wave (one of the two co tiles each)
-    static_assert(G * OH * LW % 16 == 0 && 2 * NTILES % NW == 0 && THREADS % 16 == 0 && SRCB + DZB <= 160 * 1024 && NI <= KSTEPS - 1, "shape");
+// Source (images, SH, SW, C), window KH x KW at stride S; dz (images, OH, OW, 64); G images per group on NW waves.
+// LW > 0 (layer 3): the reduction runs over dz LINES padded to LW records, a k-step = 16 / LW lines -- the source record of a block row is
+//   (compile-time record of its line) + x + tap.
+// LW = 0 (layer 2): the reduction runs over the group's pixels in raster order, padded at the END of the group to whole k-steps (9-pixel
+//   lines would pad to 12); the window origin of every pixel a lane ever touches sits in a per-lane table of 16-bit record numbers
+//   (2 KSTEPS entries, filled once per launch: the same for every group).
+template <int SH_, int SW_, int C_, int KH_, int KW_, int S_, int OH_, int OW_, int LW_, int G_, int NW_, int OCC_>
+struct UGeom {
+    static constexpr int SH = SH_, SW = SW_, C = C_, KH = KH_, KW = KW_, S = S_, OH = OH_, OW = OW_, LW = LW_, G = G_, NW = NW_, OCC = OCC_, CO = 64;
+    static constexpr int THREADS = 64 * NW, OP = OH * OW;
+    static constexpr int PIXS = 4 * C + 16, LOS = 2 * C, PIXD = 4 * CO + 16, LOD = 2 * CO;       // pixel records: 2 C bytes hi | 2 C bytes lo | 16 B pad (an odd number of 16-byte slots)
+    static constexpr int SRC_REC = SH * SW;                                                     // source records per image
+    static constexpr int KPIX = LW > 0 ? G * OH * LW : (G * OP + 15) / 16 * 16, KSTEPS = KPIX / 16;      // dz records per group = k per group
+    static constexpr int SRC_SLACK = LW > 0 ? 3 : 0;               // LW > 0: the padded position of the last line reads up to 2 records past the group: zeroed slack
+    static constexpr int SRCB = (G * SRC_REC + SRC_SLACK) * PIXS, DZB = KPIX * PIXD;
+    static constexpr int UPS = C / 4, UPD = CO / 4;                // 16-byte units per source / dz pixel
+    static constexpr int SRC_UNITS = G * SRC_REC * UPS, DZ_UNITS = G * OP * UPD;
+    static constexpr int NIS = (SRC_UNITS + THREADS - 1) / THREADS, NID = (DZ_UNITS + THREADS - 1) / THREADS, NI = NIS + NID;      // rounds of loads per thread: a round is all source or all dz
+    static constexpr int PRE_PER = (NI + KSTEPS - 2) / (KSTEPS - 1);                            // loads of the next group per k-step
+    static constexpr int CT = C / 32, NTILES = KH * KW * CT, TPW = 2 * NTILES / NW;              // column tiles (tap, 32-channel part); tiles per wave (one of the two co tiles each)
+    static constexpr int pidx(int y, int x) { return S == 2 ? y * SW + (x & 1) * (SW / 2) + (x >> 1) : y * SW + x; }      // (stride 2: even columns first, as kernel R)
+    static_assert(KPIX % 16 == 0 && 2 * NTILES % NW == 0 && THREADS % 16 == 0 && THREADS % UPS == 0 && SRCB + DZB <= 160 * 1024 && (S == 1 || SW % 2 == 0) && (LW == 0 || 16 % LW == 0), "shape");
 };
+using UGeom3 = UGeom<9, 9, 64, 3, 3, 1, 7, 7, 8, 4, 12, 3>;         // a2 / dz3: 4 images, 14 k-steps, 12 waves x 3 tiles, 149 KB
+using UGeom2 = UGeom<20, 20, 32, 4, 4, 2, 9, 9, 0, 2, 8, 2>;        // a1 / dz2: 2 images = 162 pixels in 11 k-steps, 8 waves x 4 tiles, 159 KB
 
 template <class UG>
-__global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void convu_kernel(
+__global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG::OCC, UG::OCC))) void convu_kernel(
     const float* __restrict__ src, const float* __restrict__ dz, float* __restrict__ part_w, float* __restrict__ part_b, long long images,
     int groups, unsigned src_bytes, unsigned dz_bytes, const unsigned* __restrict__ dz_amax, const unsigned* __restrict__ src_amax) {
-    constexpr int NI = UG::NI, TPW = UG::TPW, PIX = UG::PIX;
+    constexpr int NI = UG::NI, TPW = UG::TPW, PIXS = UG::PIXS, PIXD = UG::PIXD;
     __shared__ __attribute__((aligned(16))) unsigned char lds[UG::SRCB + UG::DZB];
     unsigned char* const lsrc = lds;
     unsigned char* const ldz = lds + UG::SRCB;
@@ -69,24 +80,42 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     // b = 2 (g >> 1) + t (t: first / second read of a fragment) takes pixels b, b + 4, b + 8, b + 12 of the step -- rows FOUR records apart:
     // 4 x 272 B = 8 eight-byte chunks (mod 32), so the 32 lanes of a pass (4 rows x 2 groups x 4 chunks) cover all 64 banks once.  (Four
     // CONSECUTIVE pixels per block put the rows 2 chunks apart: ~3-way conflicts, the B reads were 43 % of the kernel's time.)
-    // Pixel 4 r + b of the step = line 2 s + (r >> 1), x = 4 (r & 1) + b.
-    const int half = g >> 1, rline = r >> 1;
-    const unsigned char* const dz_lane = ldz + (4 * r + 2 * half) * PIX + (32 * ct + 16 * (g & 1) + 4 * c4) * 2;       // + 16 s records, + t records (+ LO)
-    const unsigned char* const src_lane = lsrc + (4 * (r & 1) + 2 * half) * PIX + (16 * (g & 1) + 4 * c4) * 2;          // + record of (line, tap), + t records, + 64 cih (+ LO)
+    const int half = g >> 1;
+    const unsigned char* const dz_lane = ldz + (4 * r + 2 * half) * PIXD + (32 * ct + 16 * (g & 1) + 4 * c4) * 2;       // + 16 s records, + t records (+ LOD)
+    // LW > 0: pixel 4 r + b of the step = line (16 / LW) s + (4 r + b) / LW, x = (4 r + b) % LW; with LW = 8: line 2 s + (r >> 1), x = 4 (r & 1) + b
+    const int rline = r >> 1;
+    const unsigned char* const src_lane = lsrc + (UG::LW > 0 ? (4 * (r & 1) + 2 * half) * PIXS : 0) + (16 * (g & 1) + 4 * c4) * 2;      // + record of (pixel | line, tap), + t records, + 64 cpart (+ LOS)
+    // LW = 0: the window origins of pixels 16 s + 4 r + 2 half + t, s < KSTEPS, t < 2, two 16-bit record numbers per register (pixels past the
+    // group: record 0 -- their dz is zero)
+    unsigned origin[UG::LW > 0 ? 1 : UG::KSTEPS];
+    if constexpr (UG::LW == 0) {
+#pragma unroll
+        for (int s = 0; s < UG::KSTEPS; ++s) {
+            unsigned pk = 0u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int pix = 16 * s + 4 * r + 2 * half + t, gi = pix / UG::OP, p = pix - gi * UG::OP, y = p / UG::OW, x = p - y * UG::OW;
+                const unsigned rec = pix < UG::G * UG::OP ? (unsigned)(gi * UG::SRC_REC + UG::pidx(UG::S * y, UG::S * x)) : 0u;
+                pk |= rec << (16 * t);
+            }
+            origin[s] = pk;
+        }
+    }
 
     // ---- the group's source and dz: unit = 16 bytes = 4 channels of a pixel; in round `it` thread tid takes unit it * THREADS + tid of the source
-    // (rounds 0 .. NIS - 1) or of dz (the rest); its channel quad tid % 16 is the same for every unit
+    // (rounds 0 .. NIS - 1) or of dz (the rest); a thread's dz units all carry the channel quad tid % 16
     const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)src_bytes, kURsrcWord3);
     const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, (int)dz_bytes, kURsrcWord3);
     s_u32x4 pre[NI];
     float db4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    auto unit_dst = [&](int it) __attribute__((always_inline)) -> unsigned {      // LDS byte offset of the unit's hi half (lo: + LO); ~0u: no such unit
+    auto unit_dst = [&](int it) __attribute__((always_inline)) -> unsigned {      // LDS byte offset of the unit's hi half; ~0u: no such unit
         if (it < UG::NIS) {
-            const int u = it * UG::THREADS + tid;
-            return u < UG::SRC_UNITS ? (unsigned)((u >> 4) * PIX + (u & 15) * 8) : ~0u;
+            const int u = it * UG::THREADS + tid, pix = u / UG::UPS, q4 = u - pix * UG::UPS, gi = pix / UG::SRC_REC, q = pix - gi * UG::SRC_REC, qy = q / UG::SW, qx = q - qy * UG::SW;
+            return u < UG::SRC_UNITS ? (unsigned)((gi * UG::SRC_REC + UG::pidx(qy, qx)) * PIXS + q4 * 8) : ~0u;
         }
-        const int v = (it - UG::NIS) * UG::THREADS + tid, q = v >> 4, gi = q / (UG::OH * UG::OW), p = q - gi * (UG::OH * UG::OW), y = p / UG::OW, x = p - y * UG::OW;
-        return v < UG::DZ_UNITS ? (unsigned)(UG::SRCB + ((gi * UG::OH + y) * UG::LW + x) * PIX + (v & 15) * 8) : ~0u;
+        const int v = (it - UG::NIS) * UG::THREADS + tid, q = v >> 4, gi = q / UG::OP, p = q - gi * UG::OP, y = p / UG::OW, x = p - y * UG::OW;
+        const int rec = UG::LW > 0 ? (gi * UG::OH + y) * UG::LW + x : q;
+        return v < UG::DZ_UNITS ? (unsigned)(UG::SRCB + rec * PIXD + (v & 15) * 8) : ~0u;
     };
     auto prefetch = [&](int grp, int it) __attribute__((always_inline)) {        // units past the tensors (last group, groups past the end) load zeros
         const bool any = grp < groups;
@@ -107,7 +136,7 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             const unsigned d = unit_dst(it);
             if (d != ~0u) {
                 *reinterpret_cast<uint2*>(lds + d) = make_uint2(hi[0], hi[1]);
-                *reinterpret_cast<uint2*>(lds + d + UG::LO) = make_uint2(lo[0], lo[1]);
+                *reinterpret_cast<uint2*>(lds + d + (is_dz ? UG::LOD : UG::LOS)) = make_uint2(lo[0], lo[1]);
             }
             if (is_dz) {                                  // (units past the end loaded zeros)
 #pragma unroll
@@ -122,9 +151,9 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
     typedef u_s16x4 __attribute__((address_space(3))) * lds_v4;
-    auto tr8 = [&](const unsigned char* p) __attribute__((always_inline)) -> s_u32x4 {          // 8 k of this lane's channel: two transpose reads (blocks b and b + 1: one record apart)
-        const u_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p));
-        const u_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + PIX));
+    auto tr2 = [&](const unsigned char* p0, const unsigned char* p1) __attribute__((always_inline)) -> s_u32x4 {      // 8 k of this lane's channel: two transpose reads (blocks b, b + 1)
+        const u_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p0));
+        const u_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p1));
         const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
         return (s_u32x4){ua.x, ua.y, ub.x, ub.y};
     };
@@ -138,20 +167,31 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < UG::KSTEPS; ++s) {
-            if (s >= 1 && s <= NI) prefetch(grp + gridDim.x, s - 1);          // the next group's source and dz, one load per k-step
-            // the two pixel lines of the step: global line L = 2 s + (0 | 1) -> image L / OH, row L % OH; this lane's block row lies in line r >> 1
-            constexpr int OH = UG::OH;
-            const int L0 = 2 * s, L1 = 2 * s + 1;
-            const int rec0 = (L0 / OH) * UG::SRC_REC + (L0 % OH) * UG::SW, rec1 = (L1 / OH) * UG::SRC_REC + (L1 % OH) * UG::SW;
-            const unsigned char* const sline = src_lane + (rline ? rec1 : rec0) * PIX;
-            const unsigned char* const dline = dz_lane + 16 * s * PIX;
-            const s_u32x4 a_hi = tr8(dline), a_lo = tr8(dline + UG::LO);
+            if (s >= 1) {                                 // the next group's source and dz, PRE_PER loads per k-step
+#pragma unroll
+                for (int u = 0; u < UG::PRE_PER; ++u)
+                    if ((s - 1) * UG::PRE_PER + u < NI) prefetch(grp + gridDim.x, (s - 1) * UG::PRE_PER + u);
+            }
+            // this lane's two source block rows of the step (t = 0, 1): window origins without the tap
+            const unsigned char *s0, *s1;
+            if constexpr (UG::LW > 0) {                   // the step's pixel lines L = (16 / LW) s + (0 | 1) -> image L / OH, row L % OH; the block row lies in line r >> 1
+                constexpr int OH = UG::OH;
+                const int L0 = 2 * s, L1 = 2 * s + 1;
+                const int rec0 = (L0 / OH) * UG::SRC_REC + (L0 % OH) * UG::SW, rec1 = (L1 / OH) * UG::SRC_REC + (L1 % OH) * UG::SW;
+                s0 = src_lane + (rline ? rec1 : rec0) * PIXS;
+                s1 = s0 + PIXS;
+            } else {
+                s0 = src_lane + (origin[s] & 0xffffu) * PIXS;
+                s1 = src_lane + (origin[s] >> 16) * PIXS;
+            }
+            const unsigned char* const dline = dz_lane + 16 * s * PIXD;
+            const s_u32x4 a_hi = tr2(dline, dline + PIXD), a_lo = tr2(dline + UG::LOD, dline + PIXD + UG::LOD);
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                const int tile = ng * TPW + t, tap = tile >> 1, cih = tile & 1;      // (wave-uniform)
+                const int tile = ng * TPW + t, tap = tile / UG::CT, cpart = tile - tap * UG::CT;      // (wave-uniform)
                 const int ty = tap / UG::KW, tx = tap - ty * UG::KW;
-                const unsigned char* const p = sline + (ty * UG::SW + tx) * PIX + 64 * cih;
-                const s_u32x4 b_hi = tr8(p), b_lo = tr8(p + UG::LO);
+                const int off = UG::pidx(ty, tx) * PIXS + 64 * cpart;
+                const s_u32x4 b_hi = tr2(s0 + off, s1 + off), b_lo = tr2(s0 + off + UG::LOS, s1 + off + UG::LOS);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_hi), __builtin_bit_cast(s_f16x8, b_hi), acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_hi), __builtin_bit_cast(s_f16x8, b_lo), acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_lo), __builtin_bit_cast(s_f16x8, b_hi), acc[t], 0, 0, 0);
@@ -159,16 +199,17 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         }
     }
 
-    // ---- this workgroup's partial dW: accumulator e of tile t = row co = 32 ct + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column (tap, ci = 32 cih + lane % 32)
-    float* const pw = part_w + (size_t)blockIdx.x * (UG::CO * UG::KH * UG::KW * UG::C);
+    // ---- this workgroup's partial dW: accumulator e of tile t = row co = 32 ct + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column (tap, ci = 32 cpart + lane % 32)
+    constexpr int K = UG::KH * UG::KW * UG::C;
+    float* const pw = part_w + (size_t)blockIdx.x * (UG::CO * K);
     const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int tile = ng * TPW + t, tap = tile >> 1, cih = tile & 1;
+        const int tile = ng * TPW + t, tap = tile / UG::CT, cpart = tile - tap * UG::CT;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int co = 32 * ct + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            pw[co * (UG::KH * UG::KW * UG::C) + tap * UG::C + 32 * cih + li] = acc[t][e] * un;
+            pw[co * K + tap * UG::C + 32 * cpart + li] = acc[t][e] * un;
         }
     }
     // ---- and partial db: the threads' sums, channel quad tid % 16, folded in the order of the thread index
@@ -184,19 +225,20 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     }
 }
 
-// MI355PPO_CONV_U=0: the layer-3 weight gradient stays on kernel V (A/B runs).  Read at every call.
-bool convu_on() {
+// MI355PPO_CONV_U=0 / MI355PPO_CONV_U2=0: the layer-3 and layer-2 / the layer-2 weight gradient stay on kernel V (A/B runs).  Read at every call.
+bool convu_on(int layer) {
     const char* e = getenv("MI355PPO_CONV_U");
-    return !(e && e[0] == '0');
+    if (e && e[0] == '0') return false;
+    const char* e2 = getenv("MI355PPO_CONV_U2");
+    return layer == 3 || !(e2 && e2[0] == '0');
 }
 
 int convu_max_parts() { return 256; }
 
-// -> 0 launched (nparts partials written), 1 not applicable
-int convu_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
-                 const unsigned* dz_amax, const unsigned* src_amax) {
-    if (layer != 3 || !dz_amax || !src_amax || !convu_on()) return 1;
-    const long long srcb = (long long)images * 9 * 9 * 64 * 4, dzb = (long long)images * 7 * 7 * 64 * 4;
+template <class UG>
+static int convu_launch_t(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int* nparts, hipStream_t s,
+                          const unsigned* dz_amax, const unsigned* src_amax) {
+    const long long srcb = (long long)images * UG::SRC_REC * UG::C * 4, dzb = (long long)images * UG::OP * UG::CO * 4;
     if (srcb >= (1LL << 32) - 8192) return 1;
     static int cus = 0;
     if (cus == 0) {
@@ -207,12 +249,20 @@ int convu_launch(const float* src, const float* dz, float* part_w, float* part_b
         }
         cus = n < convu_max_parts() ? n : convu_max_parts();
     }
-    const int groups = (int)((images + UGeom3::G - 1) / UGeom3::G);
+    const int groups = (int)((images + UG::G - 1) / UG::G);
     const int grid = groups < cus ? groups : cus;
-    hipLaunchKernelGGL((convu_kernel<UGeom3>), dim3((unsigned)grid), dim3(UGeom3::THREADS), 0, s, src, dz, part_w, part_b, (long long)images, groups,
+    hipLaunchKernelGGL((convu_kernel<UG>), dim3((unsigned)grid), dim3(UG::THREADS), 0, s, src, dz, part_w, part_b, (long long)images, groups,
                        (unsigned)srcb, (unsigned)dzb, dz_amax, src_amax);
     *nparts = grid;
     return 0;
+}
+
+// -> 0 launched (nparts partials written), 1 not applicable
+int convu_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
+                 const unsigned* dz_amax, const unsigned* src_amax) {
+    if ((layer != 2 && layer != 3) || !dz_amax || !src_amax || !convu_on(layer)) return 1;
+    return layer == 3 ? convu_launch_t<UGeom3>(src, dz, part_w, part_b, images, nparts, s, dz_amax, src_amax)
+                      : convu_launch_t<UGeom2>(src, dz, part_w, part_b, images, nparts, s, dz_amax, src_amax);
 }
 
 }  // namespace mi355ppo

@@ -252,7 +252,7 @@ def test_conv_data_gradient_f16x2_against_float64(layer, images):
     assert torch.equal(got2, got) and cnn.amax_value(rd2) == cnn.amax_value(rd)
 
 
-@pytest.mark.parametrize("layer,images", [(2, 208), (2, 256), (2, 2048), (3, 304), (3, 1024), (3, 2064), (3, 1), (3, 5), (3, 1027)])      # (208: fewer images than kernel V's 256 slabs)
+@pytest.mark.parametrize("layer,images", [(2, 208), (2, 256), (2, 2048), (3, 304), (3, 1024), (3, 2064), (3, 1), (3, 5), (3, 1027), (2, 1), (2, 3), (2, 1027)])      # (208: fewer images than kernel V's 256 slabs)
 def test_conv_weight_gradient_f16x2_against_float64(layer, images):
     """Layer 2: kernel V; layer 3: kernel U (csrc/convu.hip: both operands of an image group resident in LDS, fragments by LDS transpose
     reads) at every size, partial last groups included -- against float64, against the three-term bf16 kernel and run to run."""
