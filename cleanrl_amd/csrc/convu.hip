@@ -165,16 +165,18 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
         __syncthreads();                                  // every wave is done with the previous group's records (first pass: the zero fill)
         fill();
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < UG::KSTEPS; ++s) {
-            if (s >= 1) {                                 // the next group's source and dz, PRE_PER loads per k-step
-#pragma unroll
-                for (int u = 0; u < UG::PRE_PER; ++u)
-                    if ((s - 1) * UG::PRE_PER + u < NI) prefetch(grp + gridDim.x, (s - 1) * UG::PRE_PER + u);
-            }
-            // this lane's two source block rows of the step (t = 0, 1): window origins without the tap
+        // (step, tile) pairs in one software pipeline: the transpose reads of pair q + 1 go out before the matrix instructions of pair q (a wave
+        // cannot run ahead of the matrix pipe; the compiler's own order was "all reads of a step, wait, its MFMAs")
+        s_u32x4 afr[2][2], bfr[2][2];                     // [parity][hi, lo]: dz fragment of a step; source fragment of a pair
+        auto load_a = [&](int par, int s) __attribute__((always_inline)) {
+            const unsigned char* const dline = dz_lane + 16 * s * PIXD;
+            afr[par][0] = tr2(dline, dline + PIXD);
+            afr[par][1] = tr2(dline + UG::LOD, dline + PIXD + UG::LOD);
+        };
+        auto load_b = [&](int par, int s, int t) __attribute__((always_inline)) {
+            // this lane's two source block rows of the step (first / second read): window origins without the tap
             const unsigned char *s0, *s1;
-            if constexpr (UG::LW > 0) {                   // the step's pixel lines L = (16 / LW) s + (0 | 1) -> image L / OH, row L % OH; the block row lies in line r >> 1
+            if constexpr (UG::LW > 0) {                   // the step's pixel lines L = 2 s + (0 | 1) -> image L / OH, row L % OH; the block row lies in line r >> 1
                 constexpr int OH = UG::OH;
                 const int L0 = 2 * s, L1 = 2 * s + 1;
                 const int rec0 = (L0 / OH) * UG::SRC_REC + (L0 % OH) * UG::SW, rec1 = (L1 / OH) * UG::SRC_REC + (L1 % OH) * UG::SW;
@@ -184,18 +186,33 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
                 s0 = src_lane + (origin[s] & 0xffffu) * PIXS;
                 s1 = src_lane + (origin[s] >> 16) * PIXS;
             }
-            const unsigned char* const dline = dz_lane + 16 * s * PIXD;
-            const s_u32x4 a_hi = tr2(dline, dline + PIXD), a_lo = tr2(dline + UG::LOD, dline + PIXD + UG::LOD);
+            const int tile = ng * TPW + t, tap = tile / UG::CT, cpart = tile - tap * UG::CT;      // (wave-uniform)
+            const int ty = tap / UG::KW, tx = tap - ty * UG::KW;
+            const int off = UG::pidx(ty, tx) * PIXS + 64 * cpart;
+            bfr[par][0] = tr2(s0 + off, s1 + off);
+            bfr[par][1] = tr2(s0 + off + UG::LOS, s1 + off + UG::LOS);
+        };
+        load_a(0, 0);
+        load_b(0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int tile = ng * TPW + t, tap = tile / UG::CT, cpart = tile - tap * UG::CT;      // (wave-uniform)
-                const int ty = tap / UG::KW, tx = tap - ty * UG::KW;
-                const int off = UG::pidx(ty, tx) * PIXS + 64 * cpart;
-                const s_u32x4 b_hi = tr2(s0 + off, s1 + off), b_lo = tr2(s0 + off + UG::LOS, s1 + off + UG::LOS);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_hi), __builtin_bit_cast(s_f16x8, b_hi), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_hi), __builtin_bit_cast(s_f16x8, b_lo), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_lo), __builtin_bit_cast(s_f16x8, b_hi), acc[t], 0, 0, 0);
+        for (int q = 0; q < UG::KSTEPS * TPW; ++q) {
+            const int s = q / TPW, t = q - s * TPW;
+            if (t == 0 && s >= 1) {                       // the next group's source and dz, PRE_PER loads per k-step
+#pragma unroll
+                for (int u = 0; u < UG::PRE_PER; ++u)
+                    if ((s - 1) * UG::PRE_PER + u < NI) prefetch(grp + gridDim.x, (s - 1) * UG::PRE_PER + u);
             }
+            if (q + 1 < UG::KSTEPS * TPW) {
+                const int s1 = (q + 1) / TPW, t1 = (q + 1) - s1 * TPW;
+                if (t1 == 0) load_a(s1 & 1, s1);
+                load_b((q + 1) & 1, s1, t1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const s_u32x4 a_hi = afr[s & 1][0], a_lo = afr[s & 1][1], b_hi = bfr[q & 1][0], b_lo = bfr[q & 1][1];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_hi), __builtin_bit_cast(s_f16x8, b_hi), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_hi), __builtin_bit_cast(s_f16x8, b_lo), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, a_lo), __builtin_bit_cast(s_f16x8, b_hi), acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
