@@ -41,6 +41,8 @@ int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void*
 int convu_max_parts();
 int convu_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
                  const unsigned* dz_amax, const unsigned* src_amax);
+int convu1_launch(const unsigned char* frames, const int64_t* inds, const float* dz, float* part_w, float* part_b, int64_t images, int* nparts,
+                  hipStream_t s, const unsigned* dz_amax);
 int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
                     hipStream_t stream, const unsigned* a_amax = nullptr);
 

@@ -1149,7 +1149,7 @@ static int wgrad_grid(int64_t images) { return images < 512 ? (int)images : 512;
 // partial sums the workspace holds: the workgroups of kernels P / T, or kernel V's slabs where those are more (batches of 208 .. 240 images
 // at layer 2: 256 slabs -- round 5: sized for `images` partials before, kernel V's last slabs landed in the bias partials)
 static int wgrad_parts(int64_t images, int layer) {
-    const int g = wgrad_grid(images) * (layer == 1 ? 4 : 1), v = layer == 1 ? 0 : convw_parts(images, layer), u = layer == 1 ? 0 : convu_max_parts();
+    const int g = wgrad_grid(images) * (layer == 1 ? 4 : 1), v = layer == 1 ? 0 : convw_parts(images, layer), u = convu_max_parts();
     return g > v ? (g > u ? g : u) : (v > u ? v : u);
 }
 
@@ -1193,7 +1193,9 @@ static int conv_wgrad_impl(const char* fn, const void* src, const int64_t* inds,
     float pscale = 1.0f;                // kernel P: the factor its partial sums still carry
     int grid = wgrad_grid(images);      // workgroups launched
     int wparts = grid;                  // partials they write (weights and bias alike)
-    if (layer == 1) {                   // kernel P: one partial per wave
+    if (int u1parts = 0; layer == 1 && convu1_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, images, &u1parts, s, dz_amax) == 0) {
+        wparts = u1parts;               // kernel U's layer-1 variant (f16 split, one image per pass resident in LDS): one partial per workgroup, 1 / 255 left
+    } else if (layer == 1) {            // kernel P: one partial per wave
         wparts = grid * 4;
         const int rc = conv1p_launch(static_cast<const unsigned char*>(src), inds, dz, part_w, part_b, (int)images, grid, s, dz_amax, &pscale);
         if (rc) return rc;

@@ -242,6 +242,162 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- layer 1
+// The layer-1 weight gradient the same way (kernel P's problem, conv1p.hip: dW1[co][(ty, tx, ci)] = sum over the 20 x 20 output pixels of
+// dz1[p][co] * frame[4 y + ty][4 x + tx][ci] / 255, the uint8 frames gathered through `inds`).  One IMAGE per pass:
+//   * the frame sits in LDS as 16-bit integers, 84 rows of 90 four-channel slots (8 bytes; 6 slots of padding per row): 0x00vv IS the f16
+//     subnormal v * 2^-24, which the f16 MFMA multiplies exactly (tools/mfma_denorm.cpp) -- one plane, no split, no conversion;
+//   * dz1 as hi / lo records of 144 bytes (32 channels), 400 of them in pixel order;
+//   * a k-step is a 4 x 4 PATCH of output pixels (25 patches): block b = column x0 + b, its four rows = the patch's four lines.  Both operands'
+//     block rows are then one output line apart -- 20 dz records = 360 eight-byte chunks, and 4 frame rows = 4 * 90 slots = 360 chunks: 8 (mod
+//     32) each, the transpose reads are conflict-free -- and every address is (lane part) + (compile-time part of the step, tap row, read);
+//   * a column tile = one tap row ty: its 32 columns (tx, ci) are 32 contiguous halves of frame row 4 y + ty starting at slot 4 x.
+// Four waves, two tap rows each, one per SIMD (eight waves with one tile each read dz's fragments twice as often per MFMA: 585 us against 398);
+// dW1 (32 x 256) stays in the accumulators across all images of the workgroup; 2 matrix instructions (dz hi, dz lo) per tile and k-step.  Partial sums carry 2^(e_dz - 24): removed on the way out; conv.hip's reduce applies 1 / 255.
+struct UGeom1 {
+    static constexpr int FH = 84, FW = 84, FC = 4, FWP = 90, OH = 20, OW = 20, CO = 32, NW = 4, THREADS = 64 * NW, TPW = 8 / NW;
+    static constexpr int SLOT = 8, FROW = FWP * SLOT, FB = FH * FROW;           // frame: 8-byte slots, 720-byte rows, 60,480 bytes
+    static constexpr int PIXD = 4 * CO + 16, LOD = 2 * CO, DZB = OH * OW * PIXD; // dz records: 64 B hi | 64 B lo | 16 B pad
+    static constexpr int F_UNITS = FH * FW * FC / 16, D_UNITS = OH * OW * CO / 4; // 16-byte units: 1,764 of the frame (4 pixels each), 3,200 of dz
+    static constexpr int NIF = (F_UNITS + THREADS - 1) / THREADS, NID = (D_UNITS + THREADS - 1) / THREADS, NI = NIF + NID;
+    static constexpr int KSTEPS = (OH / 4) * (OW / 4);                          // 25 patches
+    static_assert(OH % 4 == 0 && OW % 4 == 0 && THREADS % 8 == 0 && FW % 4 == 0 && NI <= KSTEPS - 1 && FB + DZB <= 160 * 1024, "shape");
+};
+
+__global__ __launch_bounds__(UGeom1::THREADS) __attribute__((amdgpu_waves_per_eu(UGeom1::NW / 4, UGeom1::NW / 4))) void convu1_kernel(
+    const unsigned char* __restrict__ frames, const long long* __restrict__ inds, const float* __restrict__ dz, float* __restrict__ part_w,
+    float* __restrict__ part_b, int images, unsigned dz_bytes, const unsigned* __restrict__ dz_amax) {
+    using UG = UGeom1;
+    constexpr int NI = UG::NI, PIXD = UG::PIXD;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[UG::FB + UG::DZB];
+    unsigned char* const lfr = lds;
+    unsigned char* const ldz = lds + UG::FB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave = tap row ty of its column tile
+    const int g = lane >> 4, i = lane & 15, r = i >> 2, c4 = i & 3, half = g >> 1;
+
+    const int ed = f16_scale_exp(amax_load(dz_amax, lane));
+    const float sd = f16_pow2(ed), un = f16_pow2(24 - ed);                      // (ed in [-100, 60]: 2^(24 - ed) is a normal f32)
+
+    for (int o = tid * 16; o < UG::FB + UG::DZB; o += UG::THREADS * 16) *reinterpret_cast<s_u32x4*>(lds + o) = (s_u32x4){0u, 0u, 0u, 0u};
+
+    // block b = 2 half + t = patch column, block row r = patch line: dz record (y0 + r) * 20 + x0 + b; frame slot (4 (y0 + r) + ty, 4 (x0 + b))
+    const unsigned char* const dz_lane = ldz + (r * UG::OW + 2 * half) * PIXD + (16 * (g & 1) + 4 * c4) * 2;
+    const unsigned char* const fr_lane = lfr + (4 * r + wave * UG::TPW) * UG::FROW + 4 * (2 * half) * UG::SLOT + (16 * (g & 1) + 4 * c4) * 2;      // + tile's tap row
+
+    const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, (int)dz_bytes, kURsrcWord3);
+    s_u32x4 pre[NI];
+    float db4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto prefetch = [&](int img, int it) __attribute__((always_inline)) {        // images past the batch: zeros (the frame through a null range, dz out of range)
+        const bool any = img < images;
+        if (it < UG::NIF) {
+            const int u = it * UG::THREADS + tid;
+            const long long row = any ? (inds ? inds[img] : (long long)img) : 0;
+            const __amdgpu_buffer_rsrc_t rsrc_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(frames) + row * (UG::FH * UG::FW * UG::FC), 0,
+                                                                                 any ? UG::FH * UG::FW * UG::FC : 0, kURsrcWord3);
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, u < UG::F_UNITS ? (unsigned)u * 16u : kUOob, 0, 0));
+        } else {
+            const int v = (it - UG::NIF) * UG::THREADS + tid;
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_d, (any && v < UG::D_UNITS) ? (unsigned)img * (unsigned)(UG::D_UNITS * 16) + (unsigned)v * 16u : kUOob, 0, 0));
+        }
+    };
+    auto fill = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            if (it < UG::NIF) {                           // 4 pixels x 4 bytes -> 4 slots of 4 x 16 bits (zero-extended)
+                const int u = it * UG::THREADS + tid, row = u / (UG::FW / 4), x4 = u - row * (UG::FW / 4);
+                if (u < UG::F_UNITS) {
+                    s_u32x4 lo4, hi4;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const unsigned w0 = pre[it][2 * p], w1 = pre[it][2 * p + 1];
+                        const s_u32x4 e = {(w0 & 0xffu) | ((w0 & 0xff00u) << 8), ((w0 >> 16) & 0xffu) | ((w0 >> 24) << 16),
+                                           (w1 & 0xffu) | ((w1 & 0xff00u) << 8), ((w1 >> 16) & 0xffu) | ((w1 >> 24) << 16)};
+                        if (p == 0) lo4 = e; else hi4 = e;
+                    }
+                    unsigned char* const d = lfr + row * UG::FROW + 4 * x4 * UG::SLOT;
+                    *reinterpret_cast<s_u32x4*>(d) = lo4;
+                    *reinterpret_cast<s_u32x4*>(d + 16) = hi4;
+                }
+            } else {
+                const int v = (it - UG::NIF) * UG::THREADS + tid;
+                unsigned hi[2], lo[2];
+                f16_split4(pre[it], sd, hi, lo);
+                if (v < UG::D_UNITS) {
+                    unsigned char* const d = ldz + (v >> 3) * PIXD + (v & 7) * 8;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(hi[0], hi[1]);
+                    *reinterpret_cast<uint2*>(d + UG::LOD) = make_uint2(lo[0], lo[1]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) db4[c] += __uint_as_float(pre[it][c]);      // (units past the end loaded zeros)
+            }
+        }
+    };
+
+    u_f32x16 acc[UG::TPW];
+#pragma unroll
+    for (int t = 0; t < UG::TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    typedef u_s16x4 __attribute__((address_space(3))) * lds_v4;
+    auto tr2 = [&](const unsigned char* p0, const unsigned char* p1) __attribute__((always_inline)) -> s_u32x4 {
+        const u_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p0));
+        const u_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p1));
+        const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+        return (s_u32x4){ua.x, ua.y, ub.x, ub.y};
+    };
+
+    int img = blockIdx.x;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) prefetch(img, it);
+    for (; img < images; img += gridDim.x) {
+        __syncthreads();
+        fill();
+        __syncthreads();
+        s_u32x4 fr[2][2 + UG::TPW];                       // [parity]: dz hi, dz lo, the frame fragment of each of the wave's tap rows
+        auto load_step = [&](int par, int s) __attribute__((always_inline)) {
+            const int y0 = 4 * (s / (UG::OW / 4)), x0 = 4 * (s % (UG::OW / 4));
+            const unsigned char* const d = dz_lane + (y0 * UG::OW + x0) * PIXD;
+            const unsigned char* const f = fr_lane + 4 * y0 * UG::FROW + 4 * x0 * UG::SLOT;
+            fr[par][0] = tr2(d, d + PIXD);
+            fr[par][1] = tr2(d + UG::LOD, d + PIXD + UG::LOD);
+#pragma unroll
+            for (int t = 0; t < UG::TPW; ++t) fr[par][2 + t] = tr2(f + t * UG::FROW, f + t * UG::FROW + 4 * UG::SLOT);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < UG::KSTEPS; ++s) {
+            if (s >= 1 && s <= NI) prefetch(img + gridDim.x, s - 1);          // the next image, one load per k-step
+            if (s + 1 < UG::KSTEPS) load_step((s + 1) & 1, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < UG::TPW; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, fr[s & 1][0]), __builtin_bit_cast(s_f16x8, fr[s & 1][2 + t]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_f16x8, fr[s & 1][1]), __builtin_bit_cast(s_f16x8, fr[s & 1][2 + t]), acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- partial dW1: accumulator e = row co = (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column ty * 32 + lane % 32 = (ty, tx, ci)
+    float* const pw = part_w + (size_t)blockIdx.x * (UG::CO * 256);
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < UG::TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pw[((e & 3) + 8 * (e >> 2) + 4 * lh) * 256 + (wave * UG::TPW + t) * 32 + li] = acc[t][e] * un;
+    // ---- partial db1: the threads' sums, channel quad tid % 8, folded in the order of the thread index
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(lds);     // [THREADS / 8][32]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[(tid >> 3) * 32 + 4 * (tid & 7) + c] = db4[c];
+    __syncthreads();
+    if (tid < UG::CO) {
+        float sum = 0.0f;
+        for (int k = 0; k < UG::THREADS / 8; ++k) sum += red[k * 32 + tid];
+        part_b[(size_t)blockIdx.x * UG::CO + tid] = sum;
+    }
+}
+
 // MI355PPO_CONV_U=0 / MI355PPO_CONV_U2=0: the layer-3 and layer-2 / the layer-2 weight gradient stay on kernel V (A/B runs).  Read at every call.
 bool convu_on(int layer) {
     const char* e = getenv("MI355PPO_CONV_U");
@@ -280,6 +436,29 @@ int convu_launch(const float* src, const float* dz, float* part_w, float* part_b
     if ((layer != 2 && layer != 3) || !dz_amax || !src_amax || !convu_on(layer)) return 1;
     return layer == 3 ? convu_launch_t<UGeom3>(src, dz, part_w, part_b, images, nparts, s, dz_amax, src_amax)
                       : convu_launch_t<UGeom2>(src, dz, part_w, part_b, images, nparts, s, dz_amax, src_amax);
+}
+
+// Layer 1 (MI355PPO_CONV_U1=0: kernel P).  -> 0 launched (nparts partials; the reduce applies 1 / 255 only), 1 not applicable
+int convu1_launch(const unsigned char* frames, const int64_t* inds, const float* dz, float* part_w, float* part_b, int64_t images, int* nparts,
+                  hipStream_t s, const unsigned* dz_amax) {
+    const char* e = getenv("MI355PPO_CONV_U1");
+    if (!dz_amax || !convu_on(3) || (e && e[0] == '0')) return 1;
+    const long long dzb = (long long)images * 20 * 20 * 32 * 4;
+    if (dzb >= (1LL << 32) - 8192) return 1;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;
+        }
+        cus = n < convu_max_parts() ? n : convu_max_parts();
+    }
+    const int grid = images < cus ? (int)images : cus;
+    hipLaunchKernelGGL(convu1_kernel, dim3((unsigned)grid), dim3(UGeom1::THREADS), 0, s, frames, reinterpret_cast<const long long*>(inds), dz, part_w, part_b,
+                       (int)images, (unsigned)dzb, dz_amax);
+    *nparts = grid;
+    return 0;
 }
 
 }  // namespace mi355ppo

