@@ -74,6 +74,9 @@ KERNEL_INFO = {
     "Rh": ("r_kernel (csrc/convr.hip): f16 MFMA on two-term splits with the SOURCE of a group of images resident in LDS, split once (kernel Z "
            "splits every element once per tap that reads it); weights from the f16x2 pack through an LDS ring; kernel Z's epilogue; results "
            "bit-identical to kernel Z's", "f16", 3),
+    "Uh": ("convu_kernel / convu1_kernel (csrc/convu.hip): f16 MFMA on two-term splits with BOTH operands of a group of images resident in LDS, split once; "
+           "MFMA fragments by LDS transpose reads (ds_read_b64_tr_b16), the whole weight gradient in the workgroup's accumulators; layer 1: the uint8 "
+           "frame as zero-extended 16-bit = exact f16 subnormals, one plane", "f16", 3),
     "Vh": ("convw_bf16_kernel<..., SPLIT = 1> (csrc/convw.hip): f16 MFMA on two-term splits, both operands transposed through LDS; bias "
            "gradient fused", "f16", 3),
     "Wh": ("fcw_bf16_kernel<3, 1> (csrc/fcw.hip): f16 MFMA on two-term splits, both operands transposed through LDS", "f16", 3),
@@ -191,6 +194,8 @@ def roofline_entry(key, us, launches_timed, flops, letter, share, traffic):
     TFLOP) are HBM-bound by this model; under the bf16 split (twice the matrix instructions) they were matrix-pipe-bound, which is what
     round 4's line priced.  Both views travel in the object (``hbm_*`` / ``mfma_*`` fields), so that lines of different splits compare."""
     text, pipe, products = KERNEL_INFO[letter]
+    if letter == "Uh" and key.startswith("conv1_wgrad"):
+        products = 2                                   # (the uint8 frame is one exact f16 term: dz hi, dz lo)
     if letter == "P" and os.environ.get("MI355PPO_SPLIT", "f16x2") == "f16x2":
         text, pipe, products = text.replace("bf16 MFMA", "f16 MFMA (round 5: dz in two f16 terms)"), "f16", 2
     tf = flops / us / 1e6
@@ -412,7 +417,9 @@ def main():
 
             def k_wgrad(src, dz, layer, inds=None, out=None, amax=None):
                 letter = chr(lib.mi355ppo_cnn_conv_wgrad_kernel(dz.shape[0], layer))
-                return f"conv{layer}_wgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), letter + "h" if amax is not None and letter == "V" else letter
+                if amax is not None and os.environ.get("MI355PPO_CONV_U", "1") != "0" and os.environ.get({1: "MI355PPO_CONV_U1", 2: "MI355PPO_CONV_U2"}.get(layer, "MI355PPO_CONV_U"), "1") != "0":
+                    letter = "U"                             # the f16 split's weight gradients: kernel U (csrc/convu.hip), every size
+                return f"conv{layer}_wgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), letter + "h" if amax is not None and letter in ("V", "U") else letter
 
             timed_op("conv_fwd", k_fwd)
             timed_op("trunk_fwd", k_trunk)

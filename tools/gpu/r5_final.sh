@@ -31,10 +31,12 @@ cut -c1-400 $O/conv_traffic_ab.jsonl
 # kernel R against kernel Z: hashes (bit-identical) and times at three sizes, then alternating timing runs (-> gpurun_out/r5convr/)
 MI355PPO_CONV_R_MIN=1 SIZES="32768 1027 61" bash tools/gpu/r5_convr.sh 2>&1 | cut -c1-260 | tail -14; echo "kernel R A/B t=$((SECONDS-T0))"
 cp $R/gpurun_out/r5convr/ab.jsonl $O/kernel_r_ab.jsonl 2>/dev/null; cat $R/gpurun_out/r5convr/hashdiff_*.txt > $O/kernel_r_hashdiff.txt 2>/dev/null
-for i in 1 2; do for mode in 1 0; do
-  MI355PPO_CONV_R=$mode timeout 300 python bench.py --no-cpu-baseline --no-pcie-inclusive --no-kernel-timing 2>/dev/null | grep '^{' | python -c "
+# bench lines with the round's kernel families switched off one at a time (R: input-resident forwards / data gradients; U: weight gradients), alternating
+for i in 1 2; do for mode in all noU noR noRU; do
+  case $mode in all) e=;; noU) e="MI355PPO_CONV_U=0";; noR) e="MI355PPO_CONV_R=0";; noRU) e="MI355PPO_CONV_R=0 MI355PPO_CONV_U=0";; esac
+  env $e timeout 300 python bench.py --no-cpu-baseline --no-pcie-inclusive --no-kernel-timing 2>/dev/null | grep '^{' | python -c "
 import json,sys
-j=json.loads(sys.stdin.read()); print(json.dumps({'conv_r': $mode, 'value': j['value'], 'ms_per_step': j['ms_per_step'], 'phases_ms': j['phases_ms']}))" | tee -a $O/bench_kernel_r_ab.jsonl | cut -c1-200
+j=json.loads(sys.stdin.read()); print(json.dumps({'kernels': '$mode', 'value': j['value'], 'ms_per_step': j['ms_per_step'], 'phases_ms': j['phases_ms']}))" | tee -a $O/bench_kernel_families_ab.jsonl | cut -c1-200
 done; done
 pmc_pass() {   # name, counters...
     name=$1; shift
