@@ -252,10 +252,11 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
 //     block rows are then one output line apart -- 20 dz records = 360 eight-byte chunks, and 4 frame rows = 4 * 90 slots = 360 chunks: 8 (mod
 //     32) each, the transpose reads are conflict-free -- and every address is (lane part) + (compile-time part of the step, tap row, read);
 //   * a column tile = one tap row ty: its 32 columns (tx, ci) are 32 contiguous halves of frame row 4 y + ty starting at slot 4 x.
-// Four waves, two tap rows each, one per SIMD (eight waves with one tile each read dz's fragments twice as often per MFMA: 585 us against 398);
+// Eight waves, one tap row each, two per SIMD (four waves with two tap rows each, one per SIMD: 682 us against 601; MI355PPO_U1_NW=4);
 // dW1 (32 x 256) stays in the accumulators across all images of the workgroup; 2 matrix instructions (dz hi, dz lo) per tile and k-step.  Partial sums carry 2^(e_dz - 24): removed on the way out; conv.hip's reduce applies 1 / 255.
+template <int NW_>
 struct UGeom1 {
-    static constexpr int FH = 84, FW = 84, FC = 4, FWP = 90, OH = 20, OW = 20, CO = 32, NW = 4, THREADS = 64 * NW, TPW = 8 / NW;
+    static constexpr int FH = 84, FW = 84, FC = 4, FWP = 90, OH = 20, OW = 20, CO = 32, NW = NW_, THREADS = 64 * NW, TPW = 8 / NW;
     static constexpr int SLOT = 8, FROW = FWP * SLOT, FB = FH * FROW;           // frame: 8-byte slots, 720-byte rows, 60,480 bytes
     static constexpr int PIXD = 4 * CO + 16, LOD = 2 * CO, DZB = OH * OW * PIXD; // dz records: 64 B hi | 64 B lo | 16 B pad
     static constexpr int F_UNITS = FH * FW * FC / 16, D_UNITS = OH * OW * CO / 4; // 16-byte units: 1,764 of the frame (4 pixels each), 3,200 of dz
@@ -264,10 +265,10 @@ struct UGeom1 {
     static_assert(OH % 4 == 0 && OW % 4 == 0 && THREADS % 8 == 0 && FW % 4 == 0 && NI <= KSTEPS - 1 && FB + DZB <= 160 * 1024, "shape");
 };
 
-__global__ __launch_bounds__(UGeom1::THREADS) __attribute__((amdgpu_waves_per_eu(UGeom1::NW / 4, UGeom1::NW / 4))) void convu1_kernel(
+template <class UG>
+__global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG::NW / 4, UG::NW / 4))) void convu1_kernel(
     const unsigned char* __restrict__ frames, const long long* __restrict__ inds, const float* __restrict__ dz, float* __restrict__ part_w,
     float* __restrict__ part_b, int images, unsigned dz_bytes, const unsigned* __restrict__ dz_amax) {
-    using UG = UGeom1;
     constexpr int NI = UG::NI, PIXD = UG::PIXD;
     __shared__ __attribute__((aligned(16))) unsigned char lds[UG::FB + UG::DZB];
     unsigned char* const lfr = lds;
@@ -455,8 +456,13 @@ int convu1_launch(const unsigned char* frames, const int64_t* inds, const float*
         cus = n < convu_max_parts() ? n : convu_max_parts();
     }
     const int grid = images < cus ? (int)images : cus;
-    hipLaunchKernelGGL(convu1_kernel, dim3((unsigned)grid), dim3(UGeom1::THREADS), 0, s, frames, reinterpret_cast<const long long*>(inds), dz, part_w, part_b,
-                       (int)images, (unsigned)dzb, dz_amax);
+    const char* w = getenv("MI355PPO_U1_NW");
+    if (w && w[0] == '4')
+        hipLaunchKernelGGL((convu1_kernel<UGeom1<4>>), dim3((unsigned)grid), dim3(256), 0, s, frames, reinterpret_cast<const long long*>(inds), dz, part_w, part_b,
+                           (int)images, (unsigned)dzb, dz_amax);
+    else
+        hipLaunchKernelGGL((convu1_kernel<UGeom1<8>>), dim3((unsigned)grid), dim3(512), 0, s, frames, reinterpret_cast<const long long*>(inds), dz, part_w, part_b,
+                           (int)images, (unsigned)dzb, dz_amax);
     *nparts = grid;
     return 0;
 }
