@@ -1,4 +1,6 @@
 #!/bin/bash
+# WARNING: do not use for kernels whose names exist in both builds -- two code objects with the same kernel name in one process: which one a
+# launch gets is undefined (profiles/r05_kernel_u_ab.txt).  Use template instances + an environment switch inside ONE library instead.
 # A/B of two builds of the library over the torch-free conv driver: gpurun_tmp_ab/libold.so (LD_PRELOAD) against the in-tree build, f16x2,
 # three alternating runs each with output hashes (the two builds must agree bit for bit).
 set -u
