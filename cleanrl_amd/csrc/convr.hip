@@ -17,7 +17,7 @@
 //     instructions of step v, and the loop is 2 MT + 2 NT reads per 3 MT NT matrix instructions;
 //   * requests the NEXT group's source two 16-byte loads per k-step into registers (one workgroup per CU holds the LDS), splits and stores
 //     it at the top of the next group.
-// Four waves of 64 rows per CU, one per SIMD; which row sits in which lane is a compile-time table that keeps the 16-lane groups of a
+// Eight or twelve waves per CU (the instances below RGeom); which row sits in which lane is a compile-time table that keeps the 16-lane groups of a
 // fragment read on 16 different bank slots (RRowTable).  What was measured on the way (each step bit-identical): profiles/
 // r05_tile_shape_experiments.txt; `MI355PPO_R_TRACE=1` prints workgroup 0's s_memtime stamps per phase and k-step.
 // Accumulator layout and epilogue are kernel Z's (lane = channel, accumulator e = row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the tile):
@@ -74,7 +74,7 @@ struct RGeom {
 // waves of 64 rows, splitting the class tiles two and two (NS = 2), 750 us against 850 (four waves, all tiles) and 915 (eight waves of 32 rows);
 // the layer-2 forward: twelve waves of 32 rows (three per SIMD), splitting the two column tiles -- 6 x 32 row slots for its 162 rows: 775 us
 // against 860 with eight waves and 256 slots.  All measured shapes: profiles/r05_tile_shape_experiments.txt.
-using RConv2 = RGeom<20, 20, 0, 4, 4, 9, 9, 2, 2, 12, 1, 2, 4, 1, 2, 32, 2>;  // a1 (20, 20, 32) -> a2 (9, 9, 64), stride 2: 162 rows of 256 (a1 is 51 KB per image: two images per 160 KB)
+using RConv2 = RGeom<20, 20, 0, 4, 4, 9, 9, 2, 2, 12, 1, 2, 4, 1, 2, 32, 2>;  // a1 (20, 20, 32) -> a2 (9, 9, 64), stride 2: 162 rows of 192 (a1 is 51 KB per image: two images per 160 KB)
 using RConv3 = RGeom<9, 9, 0, 3, 3, 7, 7, 2, 5, 8, 1, 1, 6, 1>;          // a2 (9, 9, 64) -> a3 (7, 7, 64): 245 rows of 256
 using RDgrad3 = RGeom<7, 7, 2, 3, 3, 9, 9, 2, 3, 8, 1, 0, 6, 1>;         // dz3 (7, 7, 64) -> da2 (9, 9, 64): 243 rows of 256
 using RDgrad2 = RGeom<9, 9, 1, 2, 2, 10, 10, 4, 2, 8, 2, 0, 4, 1, 2>;       // dz2 (9, 9, 64) -> da1 (20, 20, 32), four stride-parity classes = four column tiles: 200 rows of 256
@@ -202,8 +202,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         else return (unsigned)((gi * RG::OP + pp) * (32 * NT)) * 4u;
     };
     const unsigned char* win[MT];                         // window origin of the lane's fragment row (+ the lane half's 8 channels)
-    // (two 16-bit offsets per register where a group's C stays below 64 KiB -- the single-class layers: 16 registers instead of 32 beside
-    //  the second accumulator bank)
+    // (two 16-bit offsets per register where a group's C stays below 64 KiB -- the single-class layers: 16 registers instead of 32)
     constexpr bool kPackRoff = (EPI == R_MASKB_CLS4 ? RG::G * 4 * RG::OP * 32 : RG::G * RG::OP * 32 * NT) * 4 < 65536;
     unsigned roff[MT][kPackRoff ? 8 : 16], rlane = 0u, rword[MT];         // rlane: C offset of slot row `lane` of the wave's 32 MT rows (mask words in); rword[i]: of slot row li of tile i (mask words out)
 #pragma unroll

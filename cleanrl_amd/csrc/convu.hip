@@ -1,5 +1,5 @@
-// Kernel U -- the layer-3 weight (+ bias) gradient of the NatureCNN on the two-term f16 split with BOTH operands of a group of images
-// resident in LDS, split once (kernel R's idea applied to kernel V's problem; cleanrl/ppo_atari_multigpu.py:141 and its backward, :358):
+// Kernel U -- the weight (+ bias) gradients of the NatureCNN's convolutions on the two-term f16 split with BOTH operands of a group of images
+// resident in LDS, split once.  Described for layer 3; layer 2 = the LW = 0 form of UGeom, layer 1 = convu1_kernel further down (kernel R's idea applied to kernel V's problem; cleanrl/ppo_atari_multigpu.py:141 and its backward, :358):
 //     dW[co][(ty, tx, ci)] = sum over output pixels p of dz[p][co] * src[pixel of p shifted by tap (ty, tx)][ci]
 // The reduction index is the PIXEL, the slow index of both tensors in memory.  Kernel V (convw.hip) transposes both operands through
 // wave-private LDS with 4-byte reads and splits every fragment in registers -- 32 LDS reads and ~100 VALU instructions per 12 MFMAs, every
