@@ -171,7 +171,7 @@ struct RArgs {
     unsigned long long* trace;  // MI355PPO_R_TRACE=1 (diagnosis): s_memtime stamps of workgroup 0's phases, [group visit < 4][phase < 8][wave]
 };
 
-template <class RG, int EPI>
+template <class RG, int EPI, bool SPREAD>
 __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG::NW + 3) / 4 * RG::WGS, (RG::NW + 3) / 4 * RG::WGS))) void r_kernel(RArgs a) {
     constexpr int NT = RG::NT, NTW = RG::NTW, MT = RG::MT, NW = RG::NW, NI = RG::NI, THREADS = RG::THREADS;
     constexpr int SS = RG::SS, NSLOT = RG::KSTEPS / SS;
@@ -233,8 +233,18 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         const int pix = u / RG::UPP, c4 = u - pix * RG::UPP, img = pix / (RG::IH * RG::IW), q = pix - img * (RG::IH * RG::IW), qy = q / RG::IW, qx = q - qy * RG::IW;
         udst[it] = u < RG::UNITS ? (unsigned)(img * RG::IMGB + RG::pidx(qy + RG::HL, qx + RG::HL) * RG::PIX + c4 * 8) : ~0u;
     }
-    constexpr int kPrePer = 2;                            // loads of the next group's source issued per k-step
-    static_assert((RG::KSTEPS - 1) * kPrePer >= NI, "the next group's source is requested inside one k-loop");
+    // Loads of the next group's source issued before k-step v: rounds [pre_lo(v), pre_lo(v + 1)) go out in step v.  Two per step from the second
+    // step on (the small sources of the data gradients: 38 - 42 KB are in flight at once without holding anybody), or -- SPREAD, the forwards'
+    // 104 KB -- evenly over the k-loop: a CU takes in ~11 bytes per cycle from HBM when every CU asks, so 24 KB per step (12 waves x 2 loads) is
+    // five times what arrives, the queue fills within two steps and every wave then waits AT ITS NEXT LOAD until the 104 KB have drained --
+    // s_memtime: k-steps 2 .. 7 of the layer-2 forward took 11,200 ticks instead of 2,000 (profiles/r05_kernel_r_trace.txt).  One round
+    // every ~3 steps asks for what arrives.
+    constexpr int kPreSpan = RG::KSTEPS - 3;              // SPREAD: steps 1 .. kPreSpan carry the NI rounds
+    auto pre_lo = [](int v) constexpr -> int {
+        const int n = SPREAD ? ((v - 1) * NI + kPreSpan - 1) / kPreSpan : (v - 1) * 2;
+        return v < 1 ? 0 : (n > NI ? NI : n);
+    };
+    static_assert(pre_lo(RG::KSTEPS) == NI, "the next group's source is requested inside one k-loop");
     s_u32x4 pre[NI];
     // (issued unconditionally -- past the last group with out-of-range offsets, which load zeros without touching memory: loads behind a
     //  branch leave the compiler without a count of the outstanding ones, and every later wait for a weight piece became "all of them")
@@ -390,9 +400,9 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
                 if (slot + 3 < NSLOT) load_slot(slot + 3);
                 else if (kCarry && slot + 3 - NSLOT < 2) load_slot(slot + 3 - NSLOT);     // (the last group fetches them for nobody)
             }
-            // the next group's source, a few loads per step from the second step on: the whole group at once (104 KB per CU in the layer-3
+            // the next group's source, a few loads at a time (pre_lo above): the whole group at once (104 KB per CU in the layer-3
             // forward) exceeds what a CU keeps in flight and held the issuing waves -- and the matrix pipe behind them -- for 7,000 cycles
-            if (v >= 1 && (v - 1) * kPrePer < NI) prefetch(grp + gridDim.x, (v - 1) * kPrePer, kPrePer);
+            if (pre_lo(v + 1) > pre_lo(v)) prefetch(grp + gridDim.x, pre_lo(v), pre_lo(v + 1) - pre_lo(v));
             if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4)
                 if (v == RG::KSTEPS - 4) load_masks(gbase, rb_cur);      // this group's mask words, for its epilogue
             if (a.trace && blockIdx.x == 0 && visit == 1 && lane == 0 && wave == 0) a.trace[4 * 8 * NW + v] = __builtin_amdgcn_s_memtime();
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     if (a.c_amax) amax_commit(a.c_amax, __float_as_uint(cmax), blockIdx.x * NW + (unsigned)wave, lane);
 }
 
-template <class RG, int EPI>
+template <class RG, int EPI, bool SPREAD_BOTH = false>
 static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
     RArgs a = a0;
     a.groups = (int)((a.images + RG::G - 1) / RG::G);
@@ -465,7 +475,14 @@ static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
         if (tbuf) (void)hipMemsetAsync(tbuf, 0, (4 * 8 * RG::NW + 64) * 8, s);
         a.trace = tbuf;
     }
-    hipLaunchKernelGGL((r_kernel<RG, EPI>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
+    // (MI355PPO_R_SPREAD=0: the forwards' prefetch two loads per step again -- same-box A/B runs; the results are bit-identical)
+    static const bool spread = [] { const char* e = getenv("MI355PPO_R_SPREAD"); return !(e && e[0] == '0'); }();
+    if constexpr (SPREAD_BOTH) {
+        if (spread) hipLaunchKernelGGL((r_kernel<RG, EPI, true>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
+        else hipLaunchKernelGGL((r_kernel<RG, EPI, false>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((r_kernel<RG, EPI, false>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
+    }
     if (tracing && tbuf) {
         unsigned long long h[4 * 8 * RG::NW + 64];
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, tbuf, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -503,7 +520,7 @@ int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void*
     RArgs a{};
     a.A = src; a.a_bytes = src_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.bits_out = bits; a.C = dst; a.c_bytes = dst_bytes;
     a.images = images; a.a_amax = src_amax; a.c_amax = dst_amax;
-    return bits ? r_launch<RConv3, R_BIAS_RELU_BITS>(a, st, fn) : r_launch<RConv3, R_BIAS_RELU>(a, st, fn);
+    return bits ? r_launch<RConv3, R_BIAS_RELU_BITS, true>(a, st, fn) : r_launch<RConv3, R_BIAS_RELU, true>(a, st, fn);
 }
 
 int convr_fwd2(const char* fn, const float* src, unsigned src_bytes, const void* pack, const float* bias, float* dst, unsigned dst_bytes, unsigned* bits,
@@ -511,7 +528,7 @@ int convr_fwd2(const char* fn, const float* src, unsigned src_bytes, const void*
     RArgs a{};
     a.A = src; a.a_bytes = src_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bias = bias; a.bits_out = bits; a.C = dst; a.c_bytes = dst_bytes;
     a.images = images; a.a_amax = src_amax; a.c_amax = dst_amax;
-    return bits ? r_launch<RConv2, R_BIAS_RELU_BITS>(a, st, fn) : r_launch<RConv2, R_BIAS_RELU>(a, st, fn);
+    return bits ? r_launch<RConv2, R_BIAS_RELU_BITS, true>(a, st, fn) : r_launch<RConv2, R_BIAS_RELU, true>(a, st, fn);
 }
 
 int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
