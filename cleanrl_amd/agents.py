@@ -155,8 +155,8 @@ class AtariAgent(_DiscreteMixin, nn.Module):
         if self._trunk is None:
             self._trunk = cnn.NatureTrunk()
         net = self.network
-        if torch.is_grad_enabled() or not cnn.heads_supported(self.actor, self.critic):
-            return None
+        if torch.is_grad_enabled() or not cnn.heads_supported(self.actor, self.critic) or not cnn.fc_heads_act_supported_rows(obs_rows.shape[0]):
+            return None                                   # (decided before the trunk runs: the caller's fallback computes it)
         self._trunk.bufs.pack_params = (net[0].weight, net[2].weight, net[4].weight, net[7].weight)
         feats = self._trunk(obs_rows, None, net[0], net[2], net[4])
         if not cnn.fc_heads_act_supported(feats):

@@ -273,6 +273,12 @@ def fc_heads_act_supported(a: torch.Tensor, N: int = 512) -> bool:
                 _lib.load().mi355ppo_fc_fwd_workspace_bytes(a.shape[0], N, a.shape[1]) > 0)
 
 
+def fc_heads_act_supported_rows(rows: int, K: int = 3136, N: int = 512) -> bool:
+    """The same question from the row count alone -- asked BEFORE the trunk runs, so that a batch the fused step does not take
+    (8,192 rows and more) is not pushed through the trunk twice (once here, once by the fallback)."""
+    return rows > 0 and _lib.load().mi355ppo_fc_fwd_workspace_bytes(int(rows), N, K) > 0
+
+
 def fc_heads_act_categorical(a: torch.Tensor, pack: torch.Tensor, fc_bias: torch.Tensor, Wa, ba, Wc, bc, seed: int, offset: int,
                              offset_base=None, action_f32_out=None, logprob_out=None, value_out=None, noise_exp1=None, want_i64: bool = True,
                              amax=None):

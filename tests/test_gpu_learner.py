@@ -664,6 +664,37 @@ def test_one_thread_driver_over_worker_process_envs_matches_the_threaded_lanes(K
     assert float(out[0][0]["dones"].sum()) > 0
 
 
+def test_a_rollout_step_of_8192_envs_runs_the_trunk_once(monkeypatch):
+    """From 8,192 rows on the FC forward does not split K and the fused [FC + heads + draw] step does not apply: `act_u8` must say so
+    BEFORE it runs the trunk (the fallback computes it), and below that size the fused step must still be the one that runs."""
+    from cleanrl_amd import cnn
+
+    calls = []
+    orig = cnn.NatureTrunk.__call__
+
+    def counting(self, *a, **k):
+        calls.append(a[0].shape[0])
+        return orig(self, *a, **k)
+
+    monkeypatch.setattr(cnn.NatureTrunk, "__call__", counting)
+    for N, fused in ((8192, False), (64, True)):
+        torch.manual_seed(4)
+        env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=6, done_p=0.1)
+        agent = AtariAgent(env).to(DEV)
+        args = learner_smoke.default_args(num_steps=2, num_minibatches=2, update_epochs=1)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
+        L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
+        assert cnn.fc_heads_act_supported_rows(N) == fused
+        del calls[:]
+        action = L.act(0)
+        torch.cuda.synchronize()
+        assert calls == [N], calls
+        assert action.shape[0] == N and int(action.min()) >= 0 and int(action.max()) < env.single_action_space.n
+        assert torch.isfinite(L.values[0]).all() and torch.isfinite(L.logprobs[0]).all() and float(L.logprobs[0].max()) <= 0.0
+        del L, agent, env
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("per", [1, 3, 8])
 def test_captured_rollout_steps_replay_bit_identically_to_the_eager_loop(per):
     """PPOLearner.capture_rollout: every rollout step as one hipGraph (Philox positions of the sampler and of the device env in
