@@ -6,6 +6,8 @@ minibatch update at 32,768 images -- matrix-pipe busy, effective clock, wave cyc
     waiting          = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES  (share of resident wave time spent in s_waitcnt)
     VALU / LDS busy  = 4 x SQ_ACTIVE_INST_{VALU,LDS} / (1024 x GRBM_GUI_ACTIVE / 8)   (the SQ counts in units of 4 cycles)
     TA busy          = TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8)
+    LDS array        = SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8): share of the launch the LDS arrays work; of which conflicts =
+                       SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (the column that shows a bad lane -> bank mapping at a glance)
     traffic          = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md)
 """
 import csv
@@ -37,8 +39,8 @@ def main():
                 return v
         return None
 
-    print("| kernel @ 32,768 images | us | clock GHz | matrix pipe busy | waves waiting | VALU busy | LDS busy | TA busy | L2-miss traffic GB (read + write) |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print("| kernel @ 32,768 images | us | clock GHz | matrix pipe busy | waves waiting | VALU busy | LDS busy | LDS array busy (conflict share) | TA busy | L2-miss traffic GB (read + write) |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     for kern, geom, label in NAMES:
         b, m, l, f, w = (pick(t, kern, geom) for t in (busy, mem, lds, fetch, write))
         if b is None:                                # (a launch runs on kernel Z or on kernel R: one of the two names is in the passes)
@@ -47,7 +49,7 @@ def main():
         cyc_m, cyc_l = m["GRBM_GUI_ACTIVE"] / 8, l["GRBM_GUI_ACTIVE"] / 8
         print(f"| {label} | {b['avg_us']:.0f} | {cyc / b['avg_us'] / 1e3:.2f} | {b['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.2f} | "
               f"{b['SQ_WAIT_INST_ANY'] / b['SQ_WAVE_CYCLES']:.2f} | {4 * m['SQ_ACTIVE_INST_VALU'] / (1024 * cyc_m):.2f} | "
-              f"{4 * l['SQ_ACTIVE_INST_LDS'] / (1024 * cyc_l):.2f} | {m['TA_BUSY_avr'] / cyc_m:.2f} | "
+              f"{4 * l['SQ_ACTIVE_INST_LDS'] / (1024 * cyc_l):.2f} | {l['SQ_LDS_IDX_ACTIVE'] / (256 * cyc_l):.2f} ({l['SQ_LDS_BANK_CONFLICT'] / max(l['SQ_LDS_IDX_ACTIVE'], 1.0):.2f}) | {m['TA_BUSY_avr'] / cyc_m:.2f} | "
               f"{f['FETCH_SIZE'] * 2048 / 1e9:.2f} + {w['WRITE_SIZE'] * 1024 / 1e9:.2f} |")
 
 
