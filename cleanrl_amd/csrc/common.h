@@ -43,6 +43,11 @@ int convu_launch(const float* src, const float* dz, float* part_w, float* part_b
                  const unsigned* dz_amax, const unsigned* src_amax);
 int convu1_launch(const unsigned char* frames, const int64_t* inds, const float* dz, float* part_w, float* part_b, int64_t images, int* nparts,
                   hipStream_t s, const unsigned* dz_amax);
+// gemmg.hip: kernel G, the FC forward / data gradient on the f16 split with both operands through workgroup-wide LDS rings (bit-identical to
+// kernel Z's; epi 0: relu(A B^T + bias), 1: (A B^T) under the ReLU mask bits; -> 0 launched, 1 not applicable, < 0 error)
+bool gemmg_on(long long rows, long long min_rows);
+int gemmg_launch(const char* fn, int epi, const float* A, int lda, const void* pack, const float* bias, const unsigned* bits, float* C, int M, int N,
+                 int K, const unsigned* a_amax, unsigned* c_amax, hipStream_t s);
 int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
                     hipStream_t stream, const unsigned* a_amax = nullptr);
 

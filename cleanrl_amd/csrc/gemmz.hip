@@ -1214,6 +1214,11 @@ static int fc_fwd_impl(const char* fn, const float* a, int lda, const void* pack
     MI355_REQUIRE(bias && aligned(bias, 4), MI355PPO_EINVAL, "%s: bias missing or misaligned", fn);
     ZArgs za = zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, h, (long long)M * N * 4, N, M, N, K);
     za.a_amax = a_amax; za.c_amax = h_amax;
+    // round 6, f16 split: kernel G (gemmg.hip) from 16,384 rows on -- both operands through workgroup-wide LDS rings, bit-identical results
+    if (a_amax && gemmg_on(M, 16384)) {
+        rc = gemmg_launch(fn, 0, a, lda, pack, bias, nullptr, h, M, N, K, a_amax, h_amax, as_stream(stream));
+        if (rc <= 0) return rc;
+    }
     // 64 x 128 wave tiles, one wave per SIMD, for the large batches; below 16,384 rows those do not fill the chip (M / 64 workgroups):
     // 64 x 64 wave tiles, two 4-wave workgroups per CU (measured on one box, profiles/r03_zcfg_ab.jsonl: 32,768 rows 471 vs 531 us,
     // 8,192 rows 205 vs 145 us, 4,096 rows 182 vs 128 us)
@@ -1290,6 +1295,10 @@ static int fc_dgrad_impl(const char* fn, const float* dz, int lddz, const void* 
     if (bits) {
         MI355_REQUIRE(N % 32 == 0 && aligned(bits, 4) && aligned(da, 128), MI355PPO_EINVAL, "%s: bit masks need N %% 32 == 0 (N=%d) and da on a 128-byte boundary", fn, N);
         za.bits_in = bits;
+        if (dz_amax && gemmg_on(M, 8192)) {                 // round 6, f16 split: kernel G (gemmg.hip), bit-identical results
+            rc = gemmg_launch(fn, 1, dz, lddz, pack, nullptr, bits, da, M, N, K, dz_amax, da_amax, as_stream(stream));
+            if (rc <= 0) return rc;
+        }
         return z_launch<ZRowsLinear, 2, 4, 4, Z_MASKB, false>(za, as_stream(stream), fn);
     }
     MI355_REQUIRE(act_in && aligned(act_in, 4) && act_in != da, MI355PPO_EINVAL, "%s: act_in missing, misaligned or aliased with da", fn);

@@ -139,6 +139,52 @@ def test_fc_forward_and_data_gradient_f16x2_against_float64(M):
     assert cnn.amax_value(rd) == da.abs().max().item()
 
 
+def _bits_of(mask):
+    """bool tensor -> the int32 words of its bit mask (word w, bit b <-> flat element 32 w + b)."""
+    m = mask.reshape(-1, 32).to(torch.int64)
+    w = (m << torch.arange(32, device=mask.device)).sum(1)
+    return ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32)
+
+
+@pytest.mark.parametrize("M", [1, 77, 128, 300, 1027, 8192, 9000])
+def test_kernel_g_fc_forward_and_data_gradient_are_kernel_z_bit_for_bit(monkeypatch, M):
+    """Kernel G (csrc/gemmg.hip, round 6: both operands of the FC layer through workgroup-wide LDS rings, A split once per workgroup; the
+    default from 16,384 / 8,192 rows on) against kernel Z's whole-K route on Linear(3136, 512) forward (cleanrl/ppo_atari_multigpu.py:144)
+    and its data gradient under conv3's ReLU mask bits, at sizes with partial row blocks and with the data gradient's partial last column
+    block (3,136 = 12 x 256 + 64 columns): outputs and amax records equal bit for bit -- the same products in the same order --, each within
+    the float64 bar."""
+    g = torch.Generator(device=DEV).manual_seed(1000 + M)
+    a = torch.relu(torch.randn(M, 3136, device=DEV, generator=g)) * torch.exp(torch.randn(M, 3136, device=DEV, generator=g))
+    W = torch.randn(512, 3136, device=DEV, generator=g) / 56.0
+    b = torch.randn(512, device=DEV, generator=g) * 0.1
+    dz = (torch.randn(M, 516, device=DEV, generator=g)[:, :512] * torch.exp2(-16 * torch.rand(M, 1, device=DEV, generator=g)) * 1e-4
+          * (torch.rand(M, 512, device=DEV, generator=g) > 0.4))
+    Wt = torch.empty((3136, 516), device=DEV)[:, :512]
+    Wt.copy_(W.t())
+    pack, packt = cnn.fc_pack_f16x2(W), cnn.fc_pack_f16x2(Wt)
+    bits = _bits_of(a > 0)
+    ra, rz = _rec_of(a), _rec_of(dz)
+    lib = cnn._lib.load()
+    out = {}
+    for route, env in (("Z", {"MI355PPO_FC_G": "0"}), ("G", {"MI355PPO_FC_G": "1", "MI355PPO_FC_G_MIN": "1"})):
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        rh, rd = cnn.new_amax(2, DEV)
+        h = torch.full((M, 512), float("nan"), device=DEV)
+        # (no workspace: the whole-K route at every size -- below 8,192 rows the wrapper would split K over the grid on both routes)
+        st = lib.mi355ppo_fc_fwd_relu_packed_f16x2_f32(cnn._ptr(a), 3136, cnn._ptr(pack), cnn._ptr(b), cnn._ptr(h), M, 512, 3136, None, 0,
+                                                       cnn._ptr(ra), cnn._ptr(rh), None)
+        assert st == 0, lib.mi355ppo_last_error()
+        da = cnn.fc_dgrad_mask_packed(dz, packt, a, out=torch.full((M, 3136), float("nan"), device=DEV), bits=bits, amax=(rz, rd))
+        torch.cuda.synchronize()
+        out[route] = (h, da, cnn.amax_value(rh), cnn.amax_value(rd))
+    (hz, dz_, ahz, adz), (hg, dg, ahg, adg) = out["Z"], out["G"]
+    assert torch.equal(hg.view(torch.int32), hz.view(torch.int32)) and ahg == ahz == hg.max().item()
+    assert torch.equal(dg.view(torch.int32), dz_.view(torch.int32)) and adg == adz == dg.abs().max().item()
+    _close(hg, torch.relu(a.double() @ W.double().t() + b.double()), f"kernel G fc fwd M={M}")
+    _close(dg, (dz.double() @ W.double()) * (a > 0), f"kernel G fc dgrad M={M}")
+
+
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 3, 37, 256, 700, 2100])
 def test_conv_forward_f16x2_against_float64(layer, images):
