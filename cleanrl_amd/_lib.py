@@ -86,6 +86,8 @@ SIGNATURES = {
                                                       _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mi355ppo_fc_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mi355ppo_fc_wgrad_kernel": (c_int, [c_int, c_int, c_int]),
+    "mi355ppo_fc_wgrad_kernel_f16x2": (c_int, [c_int, c_int, c_int]),
+    "mi355ppo_fc_packed_kernel_f16x2": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355ppo_fc_wgrad_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "mi355ppo_adam_schedule_f32": (c_int, [c_double, c_double, c_double, c_int64, _P]),
     "mi355ppo_clip_adam_sched_f32": (
@@ -136,7 +138,7 @@ SIGNATURES = {
     "mi355ppo_obs_u8_to_f32_cpu": (c_int, [_P, _P, _P, c_int64, c_int64, c_int]),
 }
 
-ABI_VERSION = 181       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 182       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

@@ -48,6 +48,11 @@ int convu1_launch(const unsigned char* frames, const int64_t* inds, const float*
 bool gemmg_on(long long rows, long long min_rows);
 int gemmg_launch(const char* fn, int epi, const float* A, int lda, const void* pack, const float* bias, const unsigned* bits, float* C, int M, int N,
                  int K, const unsigned* a_amax, unsigned* c_amax, hipStream_t s);
+// gemmh.hip: kernel H, the FC weight gradient on the f16 split with both operands through a workgroup-wide LDS ring (gemmh_slabs() partials
+// [slab][N][K] into `part`; fcw_reduce_kernel adds them)
+bool gemmh_takes(int M, int N, int K, int lddz);
+int gemmh_slabs();
+int gemmh_launch(const float* dz, int lddz, const float* a, float* part, int M, int N, int K, const unsigned* dz_amax, const unsigned* a_amax, hipStream_t s);
 int z_fc_raw_launch(const char* fn, const float* a, int lda, const void* pack, int M, int N, int K, void* ws, size_t ws_bytes, int* splits,
                     hipStream_t stream, const unsigned* a_amax = nullptr);
 

@@ -153,6 +153,13 @@ __global__ __launch_bounds__(256) void fcw_reduce_kernel(const float* __restrict
         s = v[0];
 #pragma unroll
         for (int p = 1; p < kWSlabs; ++p) s += v[p];
+    } else if (nslabs == 8) {                         // kernel H's slab count (gemmh.hip)
+        float v[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v[p] = part[(size_t)p * total + e];
+        s = v[0];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) s += v[p];
     } else {
         s = part[e];
         for (int p = 1; p < nslabs; ++p) s += part[(size_t)p * total + e];
@@ -412,13 +419,20 @@ static bool fcw_w_shape(int M, int N, int K) {
 
 extern "C" MI355PPO_API size_t mi355ppo_fc_wgrad_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int slabs = (fcw_w_shape(M, N, K) && kWSlabs > fcw_slabs(M)) ? kWSlabs : fcw_slabs(M);   // kernel Y's or kernel W's slabs, whichever is more
+    int slabs = (fcw_w_shape(M, N, K) && kWSlabs > fcw_slabs(M)) ? kWSlabs : fcw_slabs(M);   // kernel Y's or kernel W's slabs, whichever is more
+    if (gemmh_takes(M, N, K, N) && gemmh_slabs() > slabs) slabs = gemmh_slabs();                   // (kernel H, f16 split: 8)
     return (size_t)slabs * N * K * sizeof(float);
 }
 
 extern "C" MI355PPO_API int mi355ppo_fc_wgrad_kernel(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     return fcw_w_shape(M, N, K) ? 'W' : 'Y';
+}
+
+// the kernel mi355ppo_fc_wgrad_f16x2_f32 runs for this shape (dense dz, lddz = N): 'H' (gemmh.hip, round 6), 'W' or 'Y'
+extern "C" MI355PPO_API int mi355ppo_fc_wgrad_kernel_f16x2(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return gemmh_takes(M, N, K, N) ? 'H' : mi355ppo_fc_wgrad_kernel(M, N, K);
 }
 
 static int fc_wgrad_impl(const char* fn, const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
@@ -436,6 +450,14 @@ static int fc_wgrad_impl(const char* fn, const float* dz, int lddz, const float*
                   "%s: dz must be 8-byte, a and the workspace 16-byte aligned", fn);
     hipStream_t s = as_stream(stream);
     float* part = static_cast<float*>(workspace);
+    // round 6, f16 split: kernel H (gemmh.hip) from 8,192 rows on -- both operands through a workgroup-wide LDS ring, split once
+    if (dz_amax && a_amax && aligned(dz, 16) && gemmh_takes(M, N, K, lddz)) {
+        int rch = gemmh_launch(dz, lddz, a, part, M, N, K, dz_amax, a_amax, s);
+        if (rch) return rch;
+        const size_t totalh = (size_t)N * K;
+        hipLaunchKernelGGL(fcw_reduce_kernel, dim3((unsigned)((totalh + 255) / 256)), dim3(256), 0, s, part, gemmh_slabs(), dW, N, K, hwc_channels);
+        return check_launch("fcw_reduce_kernel");
+    }
     // kernel W (bf16 pipe) for this layer's shape at minibatch sizes; kernel Y (f32 pipe) otherwise
     if (fcw_w_shape(M, N, K) && aligned(dz, 16) && lddz % 4 == 0) {
         const int nkb = K / kWk;

@@ -1207,6 +1207,13 @@ extern "C" MI355PPO_API size_t mi355ppo_fc_fwd_workspace_bytes(int M, int N, int
     return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
+// which f16x2 FC launches kernel G (gemmg.hip) takes -- the one place that decides: the forward from 16,384 rows on (below, its 128-row x
+// 256-column blocks do not fill the chip), the bit-masked data gradient from 1,024 (profiles/r06_kernel_g_sizes.txt)
+static bool fc_g_takes(int M, int N, int K, bool dgrad) {
+    return M > 0 && N > 0 && N % 32 == 0 && K >= 128 && K % 64 == 0 && gemmg_on(M, dgrad ? 1024 : 16384);
+}
+extern "C" MI355PPO_API int mi355ppo_fc_packed_kernel_f16x2(int M, int N, int K, int dgrad) { return fc_g_takes(M, N, K, dgrad != 0) ? 'G' : 'Z'; }
+
 static int fc_fwd_impl(const char* fn, const float* a, int lda, const void* pack, const float* bias, float* h, int M, int N, int K,
                        const unsigned* a_amax, unsigned* h_amax, void* stream) {
     int rc = zgemm_check(fn, a, pack, h, M, N, K, lda, N);
@@ -1215,7 +1222,7 @@ static int fc_fwd_impl(const char* fn, const float* a, int lda, const void* pack
     ZArgs za = zargs(a, (long long)M * lda * 4, lda, pack, bias, nullptr, h, (long long)M * N * 4, N, M, N, K);
     za.a_amax = a_amax; za.c_amax = h_amax;
     // round 6, f16 split: kernel G (gemmg.hip) from 16,384 rows on -- both operands through workgroup-wide LDS rings, bit-identical results
-    if (a_amax && gemmg_on(M, 16384)) {
+    if (a_amax && fc_g_takes(M, N, K, false)) {
         rc = gemmg_launch(fn, 0, a, lda, pack, bias, nullptr, h, M, N, K, a_amax, h_amax, as_stream(stream));
         if (rc <= 0) return rc;
     }
@@ -1295,7 +1302,7 @@ static int fc_dgrad_impl(const char* fn, const float* dz, int lddz, const void* 
     if (bits) {
         MI355_REQUIRE(N % 32 == 0 && aligned(bits, 4) && aligned(da, 128), MI355PPO_EINVAL, "%s: bit masks need N %% 32 == 0 (N=%d) and da on a 128-byte boundary", fn, N);
         za.bits_in = bits;
-        if (dz_amax && gemmg_on(M, 8192)) {                 // round 6, f16 split: kernel G (gemmg.hip), bit-identical results
+        if (dz_amax && fc_g_takes(M, N, K, true)) {         // round 6, f16 split: kernel G (gemmg.hip), bit-identical results
             rc = gemmg_launch(fn, 1, dz, lddz, pack, nullptr, bits, da, M, N, K, dz_amax, da_amax, as_stream(stream));
             if (rc <= 0) return rc;
         }

@@ -358,6 +358,35 @@ def test_fc_weight_gradient_f16x2_against_float64(M):
     assert torch.equal(chw, got.view(512, 49, 64).permute(0, 2, 1).reshape(512, 3136))
 
 
+@pytest.mark.parametrize("M", [1000, 1024, 4096, 8192, 9008])
+def test_kernel_h_fc_weight_gradient_against_float64_and_kernel_w(monkeypatch, M):
+    """Kernel H (csrc/gemmh.hip, round 6: both operands of Linear(3136, 512)'s weight gradient through a workgroup-wide LDS ring, split once,
+    fragments by LDS transpose reads; 8 slabs of contiguous rows; the default from 8,192 rows on) against float64 with kernel W's bar, against
+    kernel W itself (another order of the same exact products), with a padded dz pitch, a batch that is not a multiple of the slot size, the
+    (h, w, c) -> (c, h, w) column order, and run twice (deterministic)."""
+    lib = cnn._lib.load()
+    g = torch.Generator(device=DEV).manual_seed(M + 7)
+    a = torch.relu(torch.randn(M, 3136, device=DEV, generator=g)) * torch.exp(torch.randn(M, 3136, device=DEV, generator=g))
+    dz = torch.randn(M, 516, device=DEV, generator=g)[:, :512] * torch.exp2(-12 * torch.rand(M, 1, device=DEV, generator=g)) * 1e-4
+    ref = dz.double().t() @ a.double()
+    rz, ra = _rec_of(dz), _rec_of(a)
+    monkeypatch.setenv("MI355PPO_FC_H", "0")
+    assert chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(M, 512, 3136)) in "WY"
+    w = cnn.fc_wgrad(dz, a, amax=(rz, ra))
+    e_w = _close(w, ref, f"fc wgrad kernel W/Y M={M}")
+    monkeypatch.setenv("MI355PPO_FC_H", "1")
+    monkeypatch.setenv("MI355PPO_FC_H_MIN", "1")
+    assert chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(M, 512, 3136)) == "H"
+    got = cnn.fc_wgrad(dz, a, amax=(rz, ra), out=torch.full((512, 3136), float("nan"), device=DEV))
+    e_h = _close(got, ref, f"fc wgrad kernel H M={M}")
+    assert e_h <= max(4.0 * e_w, 2e-6), f"kernel H {e_h:.2e} vs kernel W {e_w:.2e}"
+    assert torch.equal(got, cnn.fc_wgrad(dz, a, amax=(rz, ra)))
+    chw = cnn.fc_wgrad(dz, a, 64, amax=(rz, ra))
+    assert torch.equal(chw, got.view(512, 49, 64).permute(0, 2, 1).reshape(512, 3136))
+    monkeypatch.delenv("MI355PPO_FC_H_MIN")
+    assert chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(M, 512, 3136)) == ("H" if M >= 8192 else ("W" if M % 16 == 0 and M >= 1024 else "Y"))
+
+
 @pytest.mark.parametrize("images", [5, 1024])
 def test_conv1q_amax_and_heads_backward_amax(images):
     """The two producers outside kernel Z: kernel Q's layer-1 forward and the heads' backward -- same results as their plain entry points,
