@@ -80,6 +80,12 @@ KERNEL_INFO = {
     "Vh": ("convw_bf16_kernel<..., SPLIT = 1> (csrc/convw.hip): f16 MFMA on two-term splits, both operands transposed through LDS; bias "
            "gradient fused", "f16", 3),
     "Wh": ("fcw_bf16_kernel<3, 1> (csrc/fcw.hip): f16 MFMA on two-term splits, both operands transposed through LDS", "f16", 3),
+    # round 6: the FC layer on streaming forms of kernels R / U
+    "Gh": ("g_kernel (csrc/gemmg.hip): f16 MFMA on two-term splits with BOTH operands streamed through workgroup-wide LDS rings, A split once per "
+           "workgroup (kernel Z: once per wave, inside the k-loop); persistent 128 x 256 blocks in XCD-contiguous supertiles; kernel Z's epilogue; results "
+           "bit-identical to kernel Z's", "f16", 3),
+    "Hh": ("h_kernel (csrc/gemmh.hip): f16 MFMA on two-term splits, both operands of the batch reduction streamed through a workgroup-wide LDS ring, split "
+           "once, MFMA fragments by LDS transpose reads (ds_read_b64_tr_b16); 8 batch slabs = 8 XCDs, partials added in slab order", "f16", 3),
     "F": ("conv_fixed_kernel (csrc/conv.hip): f32-MFMA implicit GEMM; bias + ReLU / the ReLU-backward mask in the epilogue", "f32", 1),
     "T": ("conv_wgrad_taps_kernel (csrc/conv.hip): f32-MFMA implicit GEMM", "f32", 1),
     "Y": ("fcw_kernel (csrc/fcw.hip): f32 MFMA", "f32", 1),
@@ -437,10 +443,17 @@ def main():
             timed_op("conv1q_fwd_amax", lambda obs, pack, bias, inds, out, bits, dst_amax: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))
             timed_op("conv_fwd_packed", lambda src, pack, bias, layer, out=None, bits=None, amax=None: (f"conv{layer}_fwd@{src.shape[0]}", conv_flop(layer, src.shape[0]), zr(src.shape[0], layer, 0, bits, amax)))
             timed_op("conv_dgrad_packed", lambda dz, pack, act_in, layer, out=None, bits=None, amax=None: (f"conv{layer}_dgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), zr(dz.shape[0], layer, 1, bits, amax)))
-            timed_op("fc_fwd_relu_packed", lambda a, pack, bias, n, out=None, amax=None: (f"fc_fwd@{a.shape[0]}", 2.0 * a.shape[0] * n * a.shape[1], h("Z", amax)))
-            timed_op("fc_dgrad_mask_packed", lambda dz, pack, act_in, out=None, bits=None, amax=None: (f"fc_dgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * act_in.shape[1], h("Z", amax)))
+            def zg(M, N, K, dgrad, bits, amax):              # kernel G takes the large f16x2 FC launches (csrc/gemmg.hip): ask the library
+                if amax is None or (dgrad and bits is None) or (not dgrad and lib.mi355ppo_fc_fwd_workspace_bytes(M, N, K) > 0):
+                    return h("Z", amax)
+                return "Gh" if chr(lib.mi355ppo_fc_packed_kernel_f16x2(M, N, K, dgrad)) == "G" else "Zh"
+
+            timed_op("fc_fwd_relu_packed", lambda a, pack, bias, n, out=None, amax=None: (f"fc_fwd@{a.shape[0]}", 2.0 * a.shape[0] * n * a.shape[1], zg(a.shape[0], n, a.shape[1], 0, None, amax)))
+            timed_op("fc_dgrad_mask_packed", lambda dz, pack, act_in, out=None, bits=None, amax=None: (f"fc_dgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * act_in.shape[1],
+                                                                                                       zg(dz.shape[0], act_in.shape[1], dz.shape[1], 1, bits, amax)))
             timed_op("fc_wgrad", lambda dz, a, hwc_channels=0, out=None, amax=None: (f"fc_wgrad@{dz.shape[0]}", 2.0 * dz.shape[0] * dz.shape[1] * a.shape[1],
-                                                                                    h(chr(lib.mi355ppo_fc_wgrad_kernel(dz.shape[0], dz.shape[1], a.shape[1])), amax)))
+                                                                                    (lambda k: k + "h" if k in ("H", "W") else k)(chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(dz.shape[0], dz.shape[1], a.shape[1])))
+                                                                                    if amax is not None else chr(lib.mi355ppo_fc_wgrad_kernel(dz.shape[0], dz.shape[1], a.shape[1]))))
 
         def obs_hook(src, inds=None, out=None, scale_255=True):
             if inds is not None:
