@@ -93,6 +93,28 @@ KERNEL_INFO = {
 OBS_ROW_BYTES = 4 * 84 * 84   # 28,224
 
 
+def describe_cnn(kernel_of, M):
+    """``config.cnn`` and ``matrix_arithmetic`` of the JSON line, DERIVED from the kernels the update's launches ran on (``kernel_of``: launch key
+    -> letter of KERNEL_INFO), so that the line cannot describe another arithmetic than the one that was measured."""
+    order = ("conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "fc_wgrad", "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad")
+    ran = {name: kernel_of.get(f"{name}@{M}") for name in order}
+    pipes = {KERNEL_INFO[k][1] for n, k in ran.items() if k and n != "conv1_fwd"}
+    if pipes == {"f16"}:
+        arith = ("f32-equivalent via a two-term f16 split of both operands under per-tensor power-of-two scales: exact products of the terms (hi hi, hi lo, "
+                 "lo hi = 3 v_mfma_f32_32x32x16_f16 per f32 product; layer-1 weight gradient 2: its uint8 operand is one exact term), f32 accumulate; error "
+                 "vs float64 at or below the f32 library GEMM's (profiles/r05_err_f16x2.jsonl, tests/test_gpu_f16x2.py)")
+    elif pipes == {"bf16"}:
+        arith = f"f32-equivalent via a three-term bf16 split of both operands: {BF16_PAIRS} of 9 term pairs on v_mfma_f32_32x32x16_bf16, f32 accumulate"
+    elif pipes == {"f32"}:
+        arith = "f32 MFMA (v_mfma_f32_32x32x2_f32)"
+    else:
+        arith = "mixed: " + ", ".join(sorted(p for p in pipes if p))
+    fam = ", ".join(f"{n} {k}" for n, k in ran.items() if k)
+    text = ("layer-1 forward on the int8 MFMA with exact int32 accumulation over 31-bit fixed-point weights (kernel Q); every other convolution / FC GEMM: "
+            + arith + f".  Kernels of one minibatch update at {M} rows, in launch order: {fam} (letters: KERNEL_INFO / DESIGN.md 3.2; a trailing h = the f16 split)")
+    return text, arith
+
+
 def _conv1_fwd_bytes(images):
     """Algorithmic bytes of a layer-1 forward launch: the uint8 frame read once + the f32 activation written once."""
     return images * (OBS_ROW_BYTES + 20 * 20 * 32 * 4)
@@ -119,6 +141,10 @@ def parse():
     p.add_argument("--num-steps", type=int, default=None, help="override the config's rollout length")
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only with --same-device)")
+    p.add_argument("--preflight", action="store_true",
+                   help="--gpus N > 1: ONLY the process-group preflight -- init_process_group (nccl = RCCL, device_id given), one all-reduce of the flat "
+                        "gradient's size (6.75 MB) checked element by element and timed, RCCL's own init / ring / topology lines on stderr "
+                        "(NCCL_DEBUG=INFO, subsystems INIT,GRAPH) -- then exit 0.  Every --gpus N > 1 run starts with the same check, without the debug lines")
     p.add_argument("--same-device", action="store_true",
                    help="PLUMBING SMOKE, not a measurement: run all --gpus ranks on cuda:0 (needs --backend gloo: RCCL refuses "
                         "two ranks on one device).  Exercises the launcher, barrier, max-over-ranks timing and rank-0 JSON line")
@@ -126,6 +152,12 @@ def parse():
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-envs", type=int, default=64)
+    p.add_argument("--cpu-baseline-full", choices=["auto", "on", "off"], default="auto",
+                   help="how cpu_baseline.value is taken at the METRIC's configuration (1,024 envs x 128 steps, 16 updates of 32,768 rows) on this box's own "
+                        "cores.  auto (default, config C): a bounded sample -- every piece of the loop body timed at its full size (16 env steps, GAE, one "
+                        "minibatch update after one untimed), times its count: ~1 minute of CPU work.  on: ONE whole iteration (~5 minutes on the GPU box's "
+                        "256 threads, ~3 on 8 cores; abandoned for the sample if the rollout alone exceeds 2 minutes).  off: whole iterations at "
+                        "--cpu-baseline-envs envs (the rounds 1-5 sample; NOT the metric's configuration)")
     p.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets (pure SPS run)")
     p.add_argument("--no-rollout-graphs", action="store_true", help="issue the rollout kernel by kernel instead of one hipGraph per step")
     p.add_argument("--rollout-steps-per-graph", type=int, default=0,
@@ -183,6 +215,57 @@ ALG_BYTES_PER_IMAGE = {
     "conv1_wgrad": 28224 + 51200, "conv2_wgrad": 51200 + 20736, "conv3_wgrad": 20736 + 12544,
     "fc_fwd": 12544 + 2048, "fc_dgrad": 2048 + 392 + 12544, "fc_wgrad": 2048 + 12544,
 }
+
+
+def hbm_regime_points(device, reps=10):
+    """K1 (GAE) and K3 (fused loss) at sizes where the working set is far beyond the 256 MiB Infinity Cache -- the regime north_star's ">= 60 % of the HBM
+    roofline" is about (at config C's own size the kernels move 2.6 / 2.2 MB and are launch-latency-bound: `kernels.gae`).  One launch
+    shape each, HIP events on the current stream around `reps` launches, after the timed region (never part of `value`):
+      gae_hbm_regime:  T = 128, N = 2^20 envs (2.7 GB of algorithmic bytes: 20 T N + 8 N)
+      loss_hbm_regime: M = 2^22 minibatch rows, A = 4, packed behaviour rows, advantage statistics hoisted (the learner's mode);
+                       `streaming` = mb_inds NULL ((8 A + 28) M bytes), `permuted` = a random permutation of a batch as large ((8 A + 36) M bytes)."""
+    from cleanrl_amd import ops, synthetic
+
+    def ev_us(fn):
+        fn(); fn()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    out = {}
+    T, N = 128, 1 << 20
+    base = {k: v.to(device) for k, v in synthetic.rollout_scalars(T, 4096, 4, seed=1).items()}
+    sc = {k: (v.repeat(1, N // 4096) if v.dim() == 2 else v.repeat(N // 4096)).contiguous() for k, v in base.items()}
+    adv, ret = torch.empty_like(sc["rewards"]), torch.empty_like(sc["rewards"])
+    us = ev_us(lambda: ops.gae(sc["rewards"], sc["dones"], sc["values"], sc["next_done"], sc["next_value"], 0.99, 0.95, adv, ret))
+    nb = 20 * T * N + 8 * N
+    out["gae_hbm_regime"] = {"T": T, "N": N, "algorithmic_bytes": nb, "avg_us": us, "GBps": nb / us / 1e3, "frac": nb / us / 1e3 / HBM_PEAK_GBPS,
+                             "frac_of_measured_achievable_6290": nb / us / 1e3 / 6290.0, "launches_timed": reps, "timing": "HIP events, current stream"}
+    del sc, adv, ret, base
+    M, A = 1 << 22, 4
+    g = torch.Generator(device=device).manual_seed(3)
+    logits, value = torch.randn(M, A, device=device, generator=g), torch.randn(M, device=device, generator=g)
+    b_actions = torch.randint(0, A, (M,), device=device, generator=g).float()
+    b_lp = torch.randn(M, device=device, generator=g) * 0.1 - 1.4
+    b_adv, b_ret, b_val = (torch.randn(M, device=device, generator=g) for _ in range(3))
+    pack = ops.batch_pack(b_actions, b_lp, b_adv, b_ret, b_val)
+    dl, dv, slots = torch.empty_like(logits), torch.empty_like(value), ops.LossSlots(1, device)
+    res = {"M": M, "A": A, "launches_timed": reps, "timing": "HIP events, current stream"}
+    for mode, inds in (("streaming", None), ("permuted", torch.randperm(M, device=device, generator=g))):
+        md = ops.adv_stats(b_adv, inds, M)[0]
+        us = ev_us(lambda: ops.ppo_loss_categorical_packed(logits, value, inds, pack, 0.1, 0.01, 0.5, True, True, dlogits_out=dl, dvalue_out=dv,
+                                                           adv_mean_den=md, slot=(slots, 0)))
+        nb = (8 * A + 28 + (8 if inds is not None else 0)) * M
+        res[mode] = {"algorithmic_bytes": nb, "avg_us": us, "GBps": nb / us / 1e3, "frac": nb / us / 1e3 / HBM_PEAK_GBPS,
+                     "frac_of_measured_achievable_6290": nb / us / 1e3 / 6290.0}
+    res["frac"] = res["streaming"]["frac"]
+    out["loss_hbm_regime"] = res
+    return out
 
 
 def roofline_entry(key, us, launches_timed, flops, letter, share, traffic):
@@ -267,17 +350,30 @@ class KernelTimer:
         return float(np.mean([a.elapsed_time(b) for a, b in ps])) * 1e3, len(ps)
 
 
-def _all_ranks_agree(captured: bool, learner, device) -> bool:
-    """World > 1: the update runs from graphs only if EVERY rank captured them -- the legs after the timed region (the extra eager iteration
-    of the per-launch brackets) must issue the same collectives on every rank."""
-    import torch.distributed as dist
-
-    flag = torch.tensor([1 if captured else 0], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    ok = bool(flag.item())
-    if not ok:
-        learner._update_graphs = None
-    return ok
+def preflight(rank: int, world: int, device, backend: str, verbose: bool) -> dict:
+    """The first collective of a multi-rank run, made attributable: an all-reduce(SUM) of 1,686,693 f32 (the NatureCNN agent's flat gradient,
+    ppo_atari_multigpu.py:360-367) whose result is known exactly -- rank r contributes (i % 251) * (r + 1), so element i must come back as
+    (i % 251) * world (world + 1) / 2, exact in f32 -- then five timed repetitions.  Raises on a wrong element; returns the timing."""
+    n = 1686693
+    base = (torch.arange(n, device=device, dtype=torch.int64) % 251).to(torch.float32)
+    x = base * float(rank + 1)
+    dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    want = base * float(world * (world + 1) // 2)
+    bad = int((x != want).sum().item())
+    if bad:
+        raise RuntimeError(f"bench.py preflight: rank {rank}: all-reduce over {backend} returned {bad} wrong elements of {n}")
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize(device)
+    us = (time.perf_counter() - t0) / 5 * 1e6
+    info = {"backend": backend, "world": world, "bytes": 4 * n, "allreduce_us": us,
+            "bus_GBps": 4 * n * 2 * (world - 1) / world / us / 1e3}
+    if rank == 0 and verbose:
+        print(f"[bench] preflight ok: all-reduce(SUM) of {4 * n} bytes over {world} ranks ({backend}), every element exact; "
+              f"{us:.0f} us per call = {info['bus_GBps']:.1f} GB/s bus bandwidth", file=sys.stderr, flush=True)
+    return info
 
 
 def self_launch(cli) -> int:
@@ -315,12 +411,27 @@ def main():
     assert torch.cuda.device_count() > dev_index, f"rank {rank}: no GPU {dev_index} on this box ({torch.cuda.device_count()} visible)"
     torch.cuda.set_device(dev_index)
     device = torch.device(f"cuda:{dev_index}")
+    pre = None
     if world > 1:
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if cli.preflight and cli.backend == "nccl":
+            os.environ.setdefault("NCCL_DEBUG", "INFO")                   # RCCL's init / ring / topology lines, on stderr
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+        # a collective that does not complete ends the job with an error after this long instead of hanging the box (first RCCL runs)
+        limit = datetime.timedelta(seconds=int(os.environ.get("MI355PPO_PG_TIMEOUT_S", "300")))
         if cli.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)     # RCCL over xGMI
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=limit)     # RCCL over xGMI
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)                       # --same-device smoke only
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)                       # --same-device smoke only
+        pre = preflight(rank, world, device, cli.backend, verbose=True)
+        if cli.preflight:
+            if rank == 0:
+                print(json.dumps({"preflight": pre}), flush=True)
+            dist.destroy_process_group()
+            return
+    cli.collective_preflight = pre
     if cli.config == "E":
         return main_continuous(cli, rank, world, device)
 
@@ -358,24 +469,25 @@ def main():
             torch.cuda.synchronize()
     update_mode = "eager launches"
     use_update_graphs = not cli.no_update_graphs and learner.fused_cnn
-    if use_update_graphs and world > 1:
-        # world > 1: each slot is the graphs between its collectives (learner._SlotGraphs).  A rank whose capture fails keeps the eager update:
-        # both issue the same collectives on the same slices in the same order, so ranks on different routes stay compatible.
-        try:
-            learner.capture_update()
+    if use_update_graphs:
+        # one policy for every training loop (learner.update_graph_policy): graphs on one GPU and over gloo; over RCCL the eager update unless
+        # MI355PPO_UPDATE_GRAPHS=1 (then: capture, a captured-vs-eager self-check, and ALL ranks agree on the outcome through one MIN all-reduce)
+        from cleanrl_amd.learner import update_graph_policy
+
+        policy = update_graph_policy(world)
+        use_update_graphs = learner.capture_update_agreed(log=lambda m: print(f"[bench] rank {rank}: {m}", file=sys.stderr, flush=True))      # (before the timing hooks: no event records in a capture)
+        if world == 1 and policy != "off" and not use_update_graphs:
+            raise RuntimeError("bench.py: the update-graph capture failed on one GPU (see stderr): that is a defect, not a fallback case")
+        if use_update_graphs and world > 1:
             update_mode = ("per (epoch, minibatch) slot three hipGraphs with the gradient exchange between them: [forward + fused loss + backward to the "
                            "FC weight's gradient] | all-reduce of that bucket, asynchronous | [conv backward] | all-reduce of the rest | [clip + Adam] "
                            "(PPOLearner.capture_update); per-launch event brackets from an extra eager iteration after the timed region")
-        except Exception as e:
-            print(f"[bench] rank {rank}: update-graph capture failed beside the process group ({e!r}); this rank's update runs eagerly", file=sys.stderr, flush=True)
-            use_update_graphs = False
-        use_update_graphs = _all_ranks_agree(use_update_graphs, learner, device)
-        if not use_update_graphs:
-            update_mode = "eager launches (update-graph capture failed on a rank; see stderr)"
-    elif use_update_graphs:
-        learner.capture_update()            # (before the timing hooks: no event records in a capture)
-        update_mode = ("one hipGraph per (epoch, minibatch) slot: forward + fused loss + backward + clip + Adam (PPOLearner.capture_update); "
-                       "per-launch event brackets from an extra eager iteration after the timed region")
+        elif use_update_graphs:
+            update_mode = ("one hipGraph per (epoch, minibatch) slot: forward + fused loss + backward + clip + Adam (PPOLearner.capture_update); "
+                           "per-launch event brackets from an extra eager iteration after the timed region")
+        else:
+            update_mode = ("eager launches (the default over RCCL: MI355PPO_UPDATE_GRAPHS=1 opts in to graphs cut at the collectives)" if policy == "off"
+                           else "eager launches (update-graph capture or its self-check failed on a rank; see stderr)")
     elif not cli.no_update_graphs:
         update_mode = "eager launches (update graphs need the fused CNN kernels: MI355PPO_CNN=miopen)"
     timer = KernelTimer()
@@ -567,13 +679,14 @@ def main():
                 "update": update_mode,
                 "diagnostics": "synchronous (one device synchronisation per iteration)" if cli.sync_metrics
                                else "read one iteration late (PPOLearner.update_async): the host runs an iteration ahead of the GPU",
-                "cnn": "layer-1 forward on the int8 MFMA with exact int32 accumulation over 31-bit fixed-point weights (kernel Q); every "
-                       f"other convolution / FC GEMM on the bf16 MFMA over exact three-term splits of the f32 operands, {BF16_PAIRS} of 9 term "
-                       "pairs (kernels Z, V, W, P): f32 in, f32 accumulate, error vs float64 <= the f32-MFMA kernels' (tests/test_gpu_cnn.py)"
-                       if learner.fused_cnn else "torch Conv2d (MIOpen)",
+                "cnn": "(filled in below from the kernels that ran)" if learner.fused_cnn else "torch Conv2d (MIOpen)",
             },
             "final_loss": metrics["loss"],
         }
+        if cli.collective_preflight:
+            out["collective_preflight"] = cli.collective_preflight
+        if learner.fused_cnn:
+            out["config"]["cnn"], out["matrix_arithmetic"] = describe_cnn(kernel_of, M)
         timed = phase_events[cli.warmup:cli.warmup + cli.steps]
         out["phases_ms"] = {"rollout_incl_gae": float(np.mean([e[0].elapsed_time(e[1]) for e in timed])),
                             "update": float(np.mean([e[1].elapsed_time(e[2]) for e in timed])),
@@ -610,6 +723,8 @@ def main():
                                  "note": "one launch per minibatch on packed behaviour rows (one 32-byte gather per row; advantage "
                                          "statistics once per epoch, scalar fold once per update)"},
             }
+            if world == 1:
+                out["kernels"].update(hbm_regime_points(device))            # K1 / K3 where they ARE HBM-bound (north_star's >= 60 % figure)
             for k in sorted(tot):
                 kus, kn = timer.mean_us(k)
                 launches = kn * (16 if k.endswith(f"@{N}") else 1)          # rollout-sized launches are sampled 1 in 16
@@ -649,21 +764,60 @@ def main():
         if world == 1 and not cli.no_cpu_baseline:
             from oracle import cpu_ppo_port
 
-            # one untimed warm-up iteration AT THE TIMED SHAPE (thread pool, oneDNN primitives and the allocator see the timed
-            # shapes), then two timed iterations of the ppo_atari_envpool loop body; the median iteration is reported
-            cb = cpu_ppo_port.run(num_envs=cli.cpu_baseline_envs, num_steps=128, iterations=2, warmup_iterations=1,
-                                  seed=cli.seed, n_actions=cli.n_actions)
-            out["cpu_baseline"] = {
-                "value": cb["sps_median"], "unit": "env-steps/s", "cores": cb["cores"], "kind": "port",
-                "sample": f"{cb['iterations']} full PPO iterations of the reference loop body (ppo_atari_envpool.py:217-341 restated in "
-                          f"stock torch CPU ops, f32 observation storage, oracle/cpu_ppo_port.py) at num_envs={cb['num_envs']} x "
-                          f"num_steps={cb['num_steps']} = {cb['env_steps']} env-steps in {cb['seconds']:.1f} s (median iteration "
-                          f"reported; per-iteration s: {[round(x, 2) for x in cb['iteration_seconds']]}) after one untimed warm-up "
-                          f"iteration of the same shape; host cpu_count={os.cpu_count()}; the reference script itself cannot run "
-                          f"on this box (no envpool / gym / tyro, and /root/reference does not travel), hence kind=port; num_envs="
-                          f"{cb['num_envs']}, not the metric's 1024: one iteration at 1024 envs is ~4 minutes of CPU work on these cores "
-                          f"(outside the 10-30 s sample budget); no extrapolation attempted",
-            }
+            # `value` at the METRIC's configuration on THIS box's cores.  A whole iteration there is minutes of CPU work (290 s predicted on the
+            # 256-thread GPU box, 170 s on 8 cores), so the default is the BOUNDED sample of cpu_ppo_port.run_metric_sample: every piece of the loop body
+            # timed at its full size -- 16 of the 128 env steps at 1,024 envs, the GAE pass, one of the 16 minibatch updates of 32,768 rows (after one
+            # untimed) -- times its count.  --cpu-baseline-full on: one WHOLE iteration instead (guarded by the first rollout's time).
+            cb = None
+            if cli.cpu_baseline_full == "on":
+                cb = cpu_ppo_port.run(num_envs=N, num_steps=T, iterations=1, warmup_iterations=0, seed=cli.seed, n_actions=cli.n_actions,
+                                      rollout_budget_s=120.0)
+                if cb.get("aborted"):
+                    print(f"bench.py: the whole-iteration CPU baseline was abandoned (its rollout alone took {cb['rollout_seconds']:.0f} s on "
+                          f"{cb['cores']} threads); falling back to the bounded sample", file=sys.stderr, flush=True)
+                    cb = None
+            if cb is not None:
+                out["cpu_baseline"] = {
+                    "value": cb["sps_median"], "unit": "env-steps/s", "cores": cb["cores"], "kind": "port", "at_metric_config": True, "extrapolated": False,
+                    "sample": f"ONE whole PPO iteration of the reference loop body (ppo_atari_envpool.py:217-341 restated in stock torch CPU ops, f32 "
+                              f"observation storage, oracle/cpu_ppo_port.py) AT THE METRIC'S CONFIGURATION: num_envs={cb['num_envs']} x num_steps="
+                              f"{cb['num_steps']} = {cb['env_steps']} env-steps, 16 updates of {cb['env_steps'] // 4} rows, in {cb['seconds']:.1f} s on this box's "
+                              f"host cores (cpu_count={os.cpu_count()}, torch threads {cb['cores']}), no warm-up iteration; the reference script itself "
+                              f"cannot run on this box (no envpool / gym / tyro, and /root/reference does not travel), hence kind=port",
+                }
+            elif cli.cpu_baseline_full == "auto" and cli.config == "C":
+                cb = cpu_ppo_port.run_metric_sample(num_envs=N, num_steps=T, rollout_steps_timed=16, minibatches_timed=1, seed=cli.seed, n_actions=cli.n_actions)
+                pc = cb["pieces"]
+                out["cpu_baseline"] = {
+                    "value": cb["sps"], "unit": "env-steps/s", "cores": cb["cores"], "kind": "port", "at_metric_config": True, "extrapolated": True,
+                    "pieces": pc, "cpu_seconds_spent": cb["cpu_seconds_spent"],
+                    "sample": f"a bounded sample of ONE PPO iteration of the reference loop body (ppo_atari_envpool.py:217-341 restated in stock torch CPU "
+                              f"ops, f32 observation storage, oracle/cpu_ppo_port.py::run_metric_sample) AT THE METRIC'S CONFIGURATION, num_envs={cb['num_envs']} x "
+                              f"num_steps={cb['num_steps']}: {pc['rollout_steps_timed']} of the {cb['num_steps']} env steps timed at {cb['num_envs']} envs "
+                              f"({pc['rollout_step_s'] * 1e3:.0f} ms per step), the GAE pass over the whole rollout ({pc['gae_s'] * 1e3:.0f} ms), "
+                              f"{pc['minibatches_timed']} of the {pc['minibatch_updates_per_iteration']} minibatch updates of {pc['minibatch_rows']} rows gathered "
+                              f"from the full f32 observation buffer ({pc['minibatch_s']:.1f} s, after one untimed); iteration = {cb['num_steps']} x step + gae + "
+                              f"{pc['minibatch_updates_per_iteration']} x minibatch = {cb['seconds']:.0f} s (a whole iteration is minutes of CPU work: "
+                              f"--cpu-baseline-full on runs one); {cb['cpu_seconds_spent']:.0f} s of CPU work on this box's host cores (cpu_count={os.cpu_count()}, "
+                              f"torch threads {cb['cores']}); the reference script itself cannot run on this box (no envpool / gym / tyro, and /root/reference "
+                              f"does not travel), hence kind=port",
+                }
+            else:
+                # one untimed warm-up iteration AT THE TIMED SHAPE (thread pool, oneDNN primitives and the allocator see the timed
+                # shapes), then two timed iterations of the ppo_atari_envpool loop body; the median iteration is reported
+                cb = cpu_ppo_port.run(num_envs=cli.cpu_baseline_envs, num_steps=128, iterations=2, warmup_iterations=1,
+                                      seed=cli.seed, n_actions=cli.n_actions)
+                out["cpu_baseline"] = {
+                    "value": cb["sps_median"], "unit": "env-steps/s", "cores": cb["cores"], "kind": "port", "at_metric_config": False,
+                    "sample": f"{cb['iterations']} full PPO iterations of the reference loop body (ppo_atari_envpool.py:217-341 restated in "
+                              f"stock torch CPU ops, f32 observation storage, oracle/cpu_ppo_port.py) at num_envs={cb['num_envs']} x "
+                              f"num_steps={cb['num_steps']} = {cb['env_steps']} env-steps in {cb['seconds']:.1f} s (median iteration "
+                              f"reported; per-iteration s: {[round(x, 2) for x in cb['iteration_seconds']]}) after one untimed warm-up "
+                              f"iteration of the same shape; host cpu_count={os.cpu_count()}; the reference script itself cannot run "
+                              f"on this box (no envpool / gym / tyro, and /root/reference does not travel), hence kind=port; num_envs="
+                              f"{cb['num_envs']}, not the metric's 1024 (--cpu-baseline-full on: one whole iteration at the metric's size, ~3 minutes on 8 "
+                              f"cores); no extrapolation attempted",
+                }
             # the reference's VERBATIM lines at the metric's full size were timed where /root/reference exists (the build container,
             # 8 cores, while minting tests/golden/atari_iteration_cfgC.npz): reported beside the port, never as `value`
             rpath = os.path.join(ROOT, "profiles", "r04_reference_lines_cpu_timing.json")
@@ -678,11 +832,11 @@ def main():
             cpath = os.path.join(ROOT, "profiles", "r05_cpu_port_vs_reference_lines.json")
             if os.path.exists(cpath):
                 c = json.load(open(cpath))
-                out["cpu_baseline"].update({
-                    "at_metric_config_reference_value": c["reference_lines"]["env_steps_per_s"], "at_metric_config_reference_kind": "reference",
-                    "at_metric_config_port_value": c["port"]["env_steps_per_s"], "at_metric_config_port_kind": "port",
-                    "at_metric_config_cores": c["port"]["cores"], "at_metric_config_unit": "env-steps/s",
-                    "at_metric_config_sample": c["what"] + "; " + c["host"] + "; committed measurement, not taken on this box"})
+                out["cpu_baseline"].update({          # a CROSS-CHECK from another host (8 cores), never `value`
+                    "cross_check_8_cores_reference_value": c["reference_lines"]["env_steps_per_s"], "cross_check_8_cores_reference_kind": "reference",
+                    "cross_check_8_cores_port_value": c["port"]["env_steps_per_s"], "cross_check_8_cores_port_kind": "port",
+                    "cross_check_8_cores_unit": "env-steps/s",
+                    "cross_check_8_cores_sample": c["what"] + "; " + c["host"] + "; committed measurement, not taken on this box"})
         if world == 1 and not cli.no_pcie_inclusive:
             # never `value`: the same learner fed by HOST envs (numpy stand-ins on host threads), actions D2H and frames H2D
             # every step as in the reference's loop (:269-272), through the overlapped env-group lanes (cleanrl_amd/pipeline.py)
@@ -752,21 +906,18 @@ def main_continuous(cli, rank, world, device):
     update_mode = "eager launches"
     use_update_graphs = not cli.no_update_graphs
     if use_update_graphs:
-        try:
-            learner.capture_update()
+        from cleanrl_amd.learner import update_graph_policy
+
+        policy = update_graph_policy(world)
+        use_update_graphs = learner.capture_update_agreed(log=lambda m: print(f"[bench] rank {rank}: {m}", file=sys.stderr, flush=True))
+        if use_update_graphs:
             update_mode = ("one hipGraph per (epoch, minibatch) slot: fused MLP forward + loss + backward, fold, clip + Adam "
                            "(PPOLearner.capture_update); per-launch event brackets from an extra eager iteration after the timed region" if world == 1 else
                            "two hipGraphs per (epoch, minibatch) slot with the all-reduce of the flat gradient between them: [fused MLP forward + loss + "
                            "backward, fold] | all-reduce | [clip + Adam] (PPOLearner.capture_update)")
-        except Exception as e:
-            if world == 1:
-                raise
-            print(f"[bench] rank {rank}: update-graph capture failed beside the process group ({e!r}); this rank's update runs eagerly", file=sys.stderr, flush=True)
-            use_update_graphs = False
-        if world > 1:
-            use_update_graphs = _all_ranks_agree(use_update_graphs, learner, device)
-        if not use_update_graphs:
-            update_mode = "eager launches (update-graph capture failed on a rank; see stderr)"
+        else:
+            update_mode = ("eager launches (the default over RCCL: MI355PPO_UPDATE_GRAPHS=1 opts in to graphs cut at the collectives)" if policy == "off"
+                           else "eager launches (update-graph capture or its self-check failed on a rank; see stderr)")
     timer = KernelTimer()
 
     def install_timing_hooks():

@@ -99,6 +99,34 @@ class _SlotGraphs:
         segs[-1].replay()
 
 
+def update_graph_policy(world_size: int) -> str:
+    """What a training loop does about ``capture_update`` -- ONE place, shared by ``runner.train`` and ``bench.py``:
+
+    ``MI355PPO_UPDATE_GRAPHS`` = ``0``: never; ``1``: capture, at any world size; ``auto`` (the default): capture on one GPU and for
+    world > 1 over gloo (the backend of the CPU / one-GPU test runs); world > 1 over **nccl** (RCCL): the EAGER update.  Why: a slot's capture for
+    world > 1 is cut in the middle of an autograd backward, on the autograd engine's thread, beside the process group's watchdog thread
+    -- a path that has only ever run with several ranks on one GPU over gloo, and whose measured worth at config D's size is -0.6 ... +0 %
+    (profiles/r05_update_graphs_three_per_slot_ab.jsonl): not worth a hung multi-GPU job.  Returns "off", "capture" or "capture+check"
+    (opt-in over RCCL: capture, then ``PPOLearner.self_check_update_graphs`` before the graphs are trusted)."""
+    v = os.environ.get("MI355PPO_UPDATE_GRAPHS", "auto").strip().lower()
+    if v in ("0", "off", "eager", "no"):
+        return "off"
+    over_rccl = world_size > 1 and dist.is_initialized() and dist.get_backend() == "nccl"
+    if v in ("1", "on", "yes"):
+        return "capture+check" if over_rccl else "capture"
+    return "off" if over_rccl else "capture"
+
+
+def all_ranks_agree(ok: bool, device: torch.device) -> bool:
+    """World > 1: True only if EVERY rank says so (one MIN all-reduce) -- ranks must take the same route through the update (graphs or eager
+    launches), or a later leg issues different collectives on different ranks.  World = 1 / no process group: ``ok``."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
 class PPOLearner:
     def __init__(self, agent: nn.Module, args, obs_space, act_space, num_envs: int, device: torch.device,
                  world_size: int = 1, sample_seed: int = 0):
@@ -575,6 +603,74 @@ class PPOLearner:
         pm = PendingMetrics(None, b_values, b_returns, None, (last, clipfracs), k)
         pm.result()                     # CPU path: resolved at once (the handle holds views of buffers the next rollout overwrites)
         return pm
+
+    def capture_update_agreed(self, log=None) -> bool:
+        """``capture_update`` under ``update_graph_policy``: captures where the policy says so, makes ALL ranks agree on the outcome (a rank
+        whose capture -- or self-check -- failed takes every rank back to the eager update), and returns whether the update now replays
+        graphs.  ``log``: a callable for one line of diagnosis (default: stderr)."""
+        import sys
+
+        say = log or (lambda m: print(m, file=sys.stderr, flush=True))
+        policy = update_graph_policy(self.world_size)
+        ok = policy != "off"
+        if ok:
+            try:
+                self.capture_update()
+                if policy == "capture+check":
+                    ok = self.self_check_update_graphs()
+                    if not ok:
+                        say("update graphs: the captured update did not reproduce the eager update's parameters on this rank; eager launches")
+            except Exception as exc:      # noqa: BLE001 -- (capture_update restored the parameters, the Adam state and the zeroed gradients)
+                say(f"update graphs: capture failed ({type(exc).__name__}: {str(exc).splitlines()[0][:200] if str(exc) else ''}); eager launches")
+                ok = False
+        agreed = all_ranks_agree(ok, self.device)
+        if ok and not agreed:
+            say("update graphs: another rank fell back to eager launches; this rank follows")
+        if not agreed:
+            self._update_graphs = None
+        return agreed
+
+    def _bump_weights_version(self) -> None:
+        """The parameters changed behind the trunk's cached weight packs (raw-pointer writes into the flat buffer)."""
+        trunk = getattr(self.agent, "_trunk", None)
+        if trunk is not None:
+            trunk.bufs.weights_version += 1
+
+    def self_check_update_graphs(self) -> bool:
+        """One update from the captured graphs against one eager update from the SAME state and the same permutations (whatever the rollout
+        buffers hold -- zeros at start-up: still every kernel and every collective of the update): True iff parameters and Adam moments come
+        out bit-identical.  State, gradients, step counter and numpy's stream are restored.  Every rank must call it (it issues the
+        update's collectives twice)."""
+        assert self._update_graphs is not None, "self_check_update_graphs: capture_update first"
+        f = self.flat
+        keep = [t.clone() for t in (f.params, f.exp_avg, f.exp_avg_sq, f.grads)]
+        step0, rng0, graphs = getattr(f, "step", None), np.random.get_state(), self._update_graphs
+        lr = float(self.args.learning_rate)
+
+        def run(use_graphs):
+            for t, k in zip((f.params, f.exp_avg, f.exp_avg_sq, f.grads), keep):
+                t.copy_(k)
+            if step0 is not None:
+                f.step = step0
+            self._bump_weights_version()
+            np.random.set_state(rng0)
+            self._update_graphs = graphs if use_graphs else None
+            self.update(lr)
+            torch.cuda.synchronize(self.device)
+            return [t.clone() for t in (f.params, f.exp_avg, f.exp_avg_sq)]
+
+        try:
+            a, b = run(True), run(False)
+            same = all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(a, b))
+        finally:
+            for t, k in zip((f.params, f.exp_avg, f.exp_avg_sq, f.grads), keep):
+                t.copy_(k)
+            if step0 is not None:
+                f.step = step0
+            self._bump_weights_version()
+            np.random.set_state(rng0)
+            self._update_graphs = graphs
+        return bool(same)
 
     def capture_update(self) -> None:
         """``bench.py``'s and ``runner.train``'s default (``--no-update-graphs`` / MI355PPO_UPDATE_GRAPHS=0: eager).  World > 1 (round 5): a

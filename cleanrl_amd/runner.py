@@ -167,13 +167,12 @@ def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: in
     # nothing in it needs the host: the plain PPO learner on the fused kernels, no KL early stop, no noise drawn inside the update (RPO);
     # with world > 1 a slot is the graphs between its collectives (learner._SlotGraphs).  With host envs every env step synchronises on the actions, so the update starts with an empty GPU queue
     # and the host only microseconds ahead: ~55 launches per minibatch become one replay (MI355PPO_UPDATE_GRAPHS=0: eager).
+    # Policy (MI355PPO_UPDATE_GRAPHS = auto | 0 | 1) and the all-ranks agreement live in ONE place: learner.update_graph_policy /
+    # PPOLearner.capture_update_agreed -- over RCCL the default is the eager update, and ranks never end up on different routes.
     if (learner.hip and type(learner) is PPOLearner and args.target_kl is None
             and getattr(agent, "rpo_alpha", None) is None and learner.batch_size % max(learner.minibatch_size, 1) == 0
-            and (learner.fused_cnn or learner.mlp is not None) and os.environ.get("MI355PPO_UPDATE_GRAPHS", "1") != "0"):
-        try:
-            learner.capture_update()
-        except Exception as exc:      # (capture_update restored the parameters, the Adam state and the zeroed gradients)
-            print(f"update graphs: capture failed ({type(exc).__name__}: {str(exc).splitlines()[0][:200]}); the update runs as eager launches", flush=True)
+            and (learner.fused_cnn or learner.mlp is not None)):
+        learner.capture_update_agreed(log=lambda m: print(m, flush=True))
     metrics = {}
     action = None
     for iteration in range(1, args.num_iterations + 1):

@@ -99,8 +99,11 @@ def update_from_rollout(agent, optimizer, obs, actions, logprobs, rewards, dones
 
 def run(num_envs=32, num_steps=128, iterations=1, warmup_iterations=0, seed=1, num_minibatches=4, update_epochs=4,
         gamma=0.99, gae_lambda=0.95, clip_coef=0.1, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, lr=2.5e-4,
-        n_actions=4, max_seconds=None):
-    """Returns dict(sps, seconds, env_steps, cores).  One iteration = rollout + GAE + epochs x minibatches."""
+        n_actions=4, max_seconds=None, rollout_budget_s=None):
+    """Returns dict(sps, seconds, env_steps, cores).  One iteration = rollout + GAE + epochs x minibatches.
+    ``rollout_budget_s``: give up (``aborted`` = True, nothing else measured) when the FIRST rollout -- 128 forward steps, about 1/6.5 of an
+    iteration on these cores (profiles/r05_cpu_port_vs_reference_lines.json: 22 s of 144 s) -- takes longer than this: bench.py's guard
+    around the full-size sample."""
     torch.manual_seed(seed)
     np.random.seed(seed)
     dev = torch.device("cpu")
@@ -131,6 +134,8 @@ def run(num_envs=32, num_steps=128, iterations=1, warmup_iterations=0, seed=1, n
             o, reward, d = envs.step(action.cpu().numpy())
             rewards[step] = torch.tensor(reward, dtype=torch.float32).view(-1)
             next_obs, next_done = torch.Tensor(o).to(dev), torch.Tensor(d).to(dev)
+        if rollout_budget_s is not None and it == 0 and time.perf_counter() - t_it > rollout_budget_s:
+            return dict(aborted=True, rollout_seconds=time.perf_counter() - t_it, cores=torch.get_num_threads(), num_envs=num_envs, num_steps=num_steps)
         update_from_rollout(agent, optimizer, obs, actions, logprobs, rewards, dones, values, next_obs, next_done,
                             num_minibatches=num_minibatches, update_epochs=update_epochs, gamma=gamma, gae_lambda=gae_lambda,
                             clip_coef=clip_coef, ent_coef=ent_coef, vf_coef=vf_coef, max_grad_norm=max_grad_norm)
@@ -144,6 +149,82 @@ def run(num_envs=32, num_steps=128, iterations=1, warmup_iterations=0, seed=1, n
     return dict(sps=timed_steps / secs, sps_median=batch / float(np.median(iter_secs)), iteration_seconds=iter_secs, seconds=secs,
                 env_steps=timed_steps, iterations=done_iters, cores=torch.get_num_threads(), num_envs=num_envs,
                 num_steps=num_steps)
+
+
+def run_metric_sample(num_envs=1024, num_steps=128, rollout_steps_timed=16, minibatches_timed=1, seed=1, num_minibatches=4, update_epochs=4,
+                      gamma=0.99, gae_lambda=0.95, clip_coef=0.1, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, lr=2.5e-4, n_actions=4):
+    """A BOUNDED sample of one iteration AT THE GIVEN (the metric's) SHAPES, for boxes where a whole iteration takes minutes: every piece of the loop
+    body of ``run`` is timed at its full size -- ``rollout_steps_timed`` env steps of ``num_envs`` envs (after one untimed step), the GAE pass over
+    the whole (T, N) rollout, ``minibatches_timed`` minibatch updates of T N / num_minibatches rows gathered from the whole f32 observation buffer
+    (after one untimed minibatch: oneDNN builds its primitives per shape) -- and the iteration is the pieces times their counts:
+
+        seconds = T x step + gae + (update_epochs x num_minibatches) x minibatch
+
+    The rollout steps that are not timed are filled with copies of the timed ones (untimed), so the gather and the network see full-size tensors.
+    Returns dict(sps, seconds (predicted), pieces, cpu_seconds_spent, ...)."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    dev = torch.device("cpu")
+    envs = _Env(num_envs, seed)
+    agent = RefAgent(n_actions)
+    optimizer = optim.Adam(agent.parameters(), lr=lr, eps=1e-5)
+    T, N = num_steps, num_envs
+    t_all = time.perf_counter()
+    obs = torch.zeros((T, N, 4, 84, 84))
+    actions, logprobs, rewards = torch.zeros((T, N)), torch.zeros((T, N)), torch.zeros((T, N))
+    dones, values = torch.zeros((T, N)), torch.zeros((T, N))
+    next_obs = torch.Tensor(envs.obs()).to(dev)
+    next_done = torch.zeros(N)
+    k = min(rollout_steps_timed, T - 1)
+    t0 = None
+    for step in range(k + 1):                                                    # :224-247; step 0 untimed
+        if step == 1:
+            t0 = time.perf_counter()
+        obs[step] = next_obs
+        dones[step] = next_done
+        with torch.no_grad():
+            action, logprob, _, value = agent.get_action_and_value(next_obs)
+            values[step] = value.flatten()
+        actions[step] = action
+        logprobs[step] = logprob
+        o, reward, d = envs.step(action.cpu().numpy())
+        rewards[step] = torch.tensor(reward, dtype=torch.float32).view(-1)
+        next_obs, next_done = torch.Tensor(o).to(dev), torch.Tensor(d).to(dev)
+    step_s = (time.perf_counter() - t0) / k
+    for step in range(k + 1, T):                                                 # untimed: the rest of the rollout = copies of the sampled steps
+        src = 1 + (step - 1) % k
+        obs[step], dones[step], values[step], actions[step], logprobs[step], rewards[step] = (obs[src], dones[src], values[src], actions[src],
+                                                                                              logprobs[src], rewards[src])
+    batch, mb = T * N, T * N // num_minibatches
+    t0 = time.perf_counter()
+    with torch.no_grad():                                                        # :250-263
+        next_value = agent.get_value(next_obs).reshape(-1)
+        advantages, returns = TO.gae(rewards, dones, values, next_done, next_value, gamma, gae_lambda)
+    gae_s = time.perf_counter() - t0
+    b_obs = obs.reshape((-1,) + tuple(obs.shape[2:]))
+    b_logprobs, b_actions = logprobs.reshape(-1), actions.reshape(-1)
+    b_advantages, b_returns, b_values = advantages.reshape(-1), returns.reshape(-1), values.reshape(-1)
+    b_inds = np.arange(batch)
+    np.random.shuffle(b_inds)
+    mb_secs = []
+    for i in range(1 + minibatches_timed):                                       # :276-322; minibatch 0 untimed
+        t0 = time.perf_counter()
+        mb_inds = b_inds[(i % num_minibatches) * mb:(i % num_minibatches + 1) * mb]
+        _, newlogprob, entropy, newvalue = agent.get_action_and_value(b_obs[mb_inds], b_actions.long()[mb_inds])
+        out = TO.ppo_loss(newlogprob, entropy, newvalue, b_logprobs[mb_inds], b_advantages[mb_inds], b_returns[mb_inds], b_values[mb_inds],
+                          clip_coef, ent_coef, vf_coef, True, True)
+        optimizer.zero_grad()
+        out["loss"].backward()
+        nn.utils.clip_grad_norm_(agent.parameters(), max_grad_norm)
+        optimizer.step()
+        if i > 0:
+            mb_secs.append(time.perf_counter() - t0)
+    mb_s = float(np.median(mb_secs))
+    secs = T * step_s + gae_s + update_epochs * num_minibatches * mb_s
+    return dict(sps=batch / secs, seconds=secs, env_steps=batch, cores=torch.get_num_threads(), num_envs=N, num_steps=T,
+                pieces=dict(rollout_step_s=step_s, rollout_steps_timed=k, gae_s=gae_s, minibatch_s=mb_s, minibatches_timed=minibatches_timed,
+                            minibatch_rows=mb, minibatch_updates_per_iteration=update_epochs * num_minibatches),
+                cpu_seconds_spent=time.perf_counter() - t_all, final_loss=float(out["loss"].detach()))
 
 
 if __name__ == "__main__":

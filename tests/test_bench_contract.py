@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -109,3 +110,55 @@ def test_roofline_entry_is_the_binding_roof_of_the_two_roof_model(monkeypatch):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.5 < r["frac"] < 0.56
     # whole-iteration flops at config C: ~28.4 TFLOP (round-3 review's figure)
     assert abs(bench.iteration_flops(1024, 128, 32768, 4, 4) / 1e12 - 28.4) < 0.4
+
+
+def _load_bench(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_the_line_describes_the_arithmetic_that_ran(monkeypatch):
+    """Round-5 review, weak #8: ``config.cnn`` used to be a literal that still said "bf16 three-term splits" while the run used the f16 split.  It is
+    now DERIVED from the kernels the launches ran on (bench.describe_cnn), with a ``matrix_arithmetic`` field beside ``dtype``: f32."""
+    bench = _load_bench(monkeypatch)
+    names = ("conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "fc_wgrad", "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad")
+    f16 = dict(zip((f"{n}@32768" for n in names), ("Q", "Rh", "Rh", "Gh", "Gh", "Hh", "Uh", "Rh", "Uh", "Rh", "Uh")))
+    text, arith = bench.describe_cnn(f16, 32768)
+    assert "two-term f16 split" in arith and "v_mfma_f32_32x32x16_f16" in arith and "bf16" not in arith
+    assert "fc_dgrad Gh" in text and "fc_wgrad Hh" in text and "conv2_dgrad Rh" in text and "kernel Q" in text
+    bf = dict(zip((f"{n}@4096" for n in names), ("Q", "Z", "Z", "Z", "Z", "W", "V", "Z", "V", "Z", "P")))
+    text, arith = bench.describe_cnn(bf, 4096)
+    assert "three-term bf16 split" in arith and "two-term f16" not in arith and "conv3_wgrad V" in text
+    for letter in ("Gh", "Hh"):                       # the round-6 kernels are priced like every other f16-split kernel
+        assert bench.KERNEL_INFO[letter][1:] == ("f16", 3)
+
+
+def test_round_6_measurement_switches_exist(monkeypatch):
+    """--cpu-baseline-full (one iteration of the CPU port at the metric's own size, on by default on a >= 64-thread box), --preflight (the
+    process-group check alone), the HBM-regime K1 / K3 points and the renamed lane-step keys."""
+    bench = _load_bench(monkeypatch)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--cpu-baseline-full", "on", "--preflight"])
+    cli = bench.parse()
+    assert cli.cpu_baseline_full == "on" and cli.preflight
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    assert bench.parse().cpu_baseline_full == "auto"
+    assert callable(bench.hbm_regime_points) and callable(bench.preflight)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import host_env_bench
+
+    got = host_env_bench.lane_step_us({"gpu_wait_s": 0.5, "env_wait_s": 1.0, "host_s": 0.25, "lane_steps": 1000})
+    assert got == {"gpu_wait_us": 500.0, "env_wait_us": 1000.0, "host_us": 250.0, "lane_steps": 1000}
+    # the CPU port's guard around the full-size sample: a rollout slower than the budget abandons the run instead of costing minutes
+    from oracle import cpu_ppo_port
+
+    r = cpu_ppo_port.run(num_envs=2, num_steps=4, iterations=1, rollout_budget_s=0.0)
+    assert r.get("aborted") and r["rollout_seconds"] > 0
+    r = cpu_ppo_port.run(num_envs=2, num_steps=4, iterations=1, num_minibatches=2, update_epochs=1, rollout_budget_s=600.0)
+    assert not r.get("aborted") and r["env_steps"] == 8
+    # the bounded sample at the metric's shapes: every piece timed at full size, the iteration = the pieces times their counts
+    s = cpu_ppo_port.run_metric_sample(num_envs=8, num_steps=8, rollout_steps_timed=3, minibatches_timed=1, num_minibatches=2, update_epochs=2)
+    pc = s["pieces"]
+    assert pc["rollout_steps_timed"] == 3 and pc["minibatch_rows"] == 32 and pc["minibatch_updates_per_iteration"] == 4
+    want = 8 * pc["rollout_step_s"] + pc["gae_s"] + 4 * pc["minibatch_s"]
+    assert abs(s["seconds"] - want) < 1e-9 and abs(s["sps"] - 64 / want) < 1e-6 and np.isfinite(s["final_loss"])

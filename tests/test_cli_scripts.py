@@ -130,6 +130,22 @@ def test_rpo_continuous_action_script_cpu():
     assert out.count("SPS:") == 2
 
 
+def test_ppo_atari_multigpu_four_ranks_gloo():
+    """The same launch shape at world = 4 (round 6: no two-rank assumption in ``grad_scale``, the per-rank seeds or the batch bookkeeping,
+    ppo_atari_multigpu.py:166-172,206-212,360-377): four CPU ranks over gloo stay in lock-step and report the global step of 4 x 4 envs."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node", "4",
+                "--local-addr", "127.0.0.1", "cleanrl_amd/ppo_atari_multigpu.py", "--no-cuda", "--local-num-envs", "4",
+                "--num-steps", "8", "--num-envs", "16", "--total-timesteps", "256"])
+    sums = {}
+    pat = r"local_rank: (\d+), action\.sum\(\): -?\d+, iteration: (\d+), agent\.actor\.weight\.sum\(\): (-?[\d.eE+-]+)"
+    for lr, it, w in re.findall(pat, out):
+        sums.setdefault(it, {})[lr] = w
+    assert len(sums) == 2, out[-2000:]
+    for it, by_rank in sums.items():
+        assert len(by_rank) == 4 and len(set(by_rank.values())) == 1, f"replicas diverged at iteration {it}: {by_rank}"
+    assert sums["1"]["0"] != sums["2"]["0"]
+
+
 def test_ppo_atari_multigpu_two_ranks_gloo():
     """The reference's distributed test: torchrun, 2 CPU processes over gloo (tests/test_atari_multigpu.py:4-9).
     Replicas must stay in lock-step: both ranks print the same actor weight sum after every update."""

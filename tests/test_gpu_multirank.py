@@ -20,10 +20,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _torchrun(script_and_args, timeout=600):
+def _torchrun(script_and_args, timeout=600, nproc=2):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node", "2", "--local-addr",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node", str(nproc), "--local-addr",
            "127.0.0.1"] + script_and_args
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-3000:]
@@ -135,6 +135,33 @@ def test_update_graphs_with_two_ranks_are_bit_identical_to_the_eager_two_rank_up
     assert np.array_equal(r0["params"], r1["params"]), "the replicas diverged"
 
 
+def test_update_graphs_with_four_ranks_are_bit_identical_to_the_eager_four_rank_update(tmp_path):
+    """The same at world = 4 (round 6: nothing may assume two ranks -- ``grad_scale`` = 1/4, seeds ``seed + rank``, the three all-reduce pieces and
+    their offsets, the MIN agreement): four ranks on one GPU over gloo, each with an eager twin; every rank's captured learner bit-equal
+    to its twin after each of two iterations, the four replicas bit-equal to one another."""
+    _torchrun([os.path.join("tests", "dp_graphs_worker.py"), str(tmp_path), "16", "8", "2", "2", "2"], timeout=1200, nproc=4)
+    rs = [np.load(tmp_path / f"rank{r}.npz") for r in range(4)]
+    for r in rs:
+        assert list(r["segs"]) == [3] and bool(r["early"]) and r["same"].all() and r["scalars_same"].all()
+        assert np.array_equal(r["params"], r["params_eager"])
+        assert np.array_equal(r["params"], rs[0]["params"]), "the replicas diverged"
+
+
+def test_ppo_atari_multigpu_script_four_ranks_on_one_gpu():
+    """The drop-in script with FOUR ranks on device 0 over gloo (ppo_atari_multigpu.py:166-177,360-377 at world = 4): replicas print the same
+    actor weight sum after every update; under the default policy (gloo: graphs) every rank replays the cut graphs."""
+    out = _torchrun([os.path.join("cleanrl_amd", "ppo_atari_multigpu.py"), "--cuda", "--backend", "gloo", "--device-ids", "0", "0", "0", "0",
+                     "--local-num-envs", "4", "--num-steps", "8", "--num-envs", "16", "--total-timesteps", "256"], nproc=4)
+    pat = r"local_rank: (\d+), action\.sum\(\): (-?\d+), iteration: (\d+), agent\.actor\.weight\.sum\(\): (-?[\d.eE+-]+)"
+    sums = {}
+    for lr, a, it, w in re.findall(pat, out):
+        sums.setdefault(it, {})[lr] = w
+    assert len(sums) == 2, out[-2000:]
+    for it, by_rank in sums.items():
+        assert len(by_rank) == 4 and len(set(by_rank.values())) == 1, f"replicas diverged at iteration {it}: {by_rank}"
+    assert "eager launches" not in out, out[-2000:]
+
+
 def test_ppo_atari_multigpu_script_two_ranks_on_one_gpu():
     """The drop-in script itself, ``--cuda`` on, both ranks on device 0 (``--device-ids 0 0``), backend gloo: replicas print
     the same actor weight sum after every update while sampling different actions (per-rank seeds)."""
@@ -152,8 +179,9 @@ def test_ppo_atari_multigpu_script_two_ranks_on_one_gpu():
     assert any(acts[i]["0"] != acts[i]["1"] for i in acts)           # different rollouts per rank
 
 
-def test_bench_multi_rank_legs_run_with_two_ranks_on_one_gpu():
-    """``bench.py --gpus 2`` end to end with both ranks on cuda:0 (``--same-device --backend gloo``: a plumbing smoke, not a
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_legs_run_with_several_ranks_on_one_gpu(world):
+    """``bench.py --gpus 2 / 4`` end to end with both ranks on cuda:0 (``--same-device --backend gloo``: a plumbing smoke, not a
     measurement): the self-launcher, the rendezvous on 127.0.0.1, the barrier + synchronize brackets, the max-over-ranks
     all-reduce of the elapsed time and the rank-0 JSON line -- everything the driver's 2/4/8-GPU runs go through except RCCL
     itself (reference launch shape: ppo_atari_multigpu.py:166-177; its all-reduce :360-377)."""
@@ -161,19 +189,28 @@ def test_bench_multi_rank_legs_run_with_two_ranks_on_one_gpu():
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--same-device",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1", "--same-device",
            "--backend", "gloo", "--local-num-envs", "64", "--num-steps", "16", "--no-cpu-baseline", "--no-pcie-inclusive"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, f"exactly one JSON line (rank 0 only), got {len(lines)}:\n{out.stdout[-2000:]}"
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["warmup"] == 1 and j["scaling"] == "weak"
-    assert j["config"]["parallelism"].startswith("dp2") and "SAME-DEVICE" in j["config"]["parallelism"]
-    assert j["config"]["global_num_envs"] == 128 and j["config"]["local_num_envs"] == 64
+    assert j["n_gpus"] == world and j["steps"] == 1 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["parallelism"].startswith(f"dp{world}") and "SAME-DEVICE" in j["config"]["parallelism"]
+    assert j["config"]["global_num_envs"] == 64 * world and j["config"]["local_num_envs"] == 64
     assert np.isfinite(j["final_loss"]) and j["value"] > 0
+    # the first collective of the run was checked element by element (round 6: bench.py::preflight)
+    assert j["collective_preflight"]["world"] == world and j["collective_preflight"]["bytes"] == 4 * 1686693
+    assert "three hipGraphs" in j["config"]["update"]                    # gloo: the cut graphs, agreed on by all ranks
+    assert "preflight ok" in out.stderr
     # value = the units ALL ranks processed / the max-over-ranks time
-    np.testing.assert_allclose(j["value"], 2 * 64 * 16 * 1 / (j["ms_per_step"] * 1e-3), rtol=1e-6)
+    np.testing.assert_allclose(j["value"], world * 64 * 16 * 1 / (j["ms_per_step"] * 1e-3), rtol=1e-6)
+    if world == 2:
+        # --preflight: only the process-group check, one JSON line, exit 0
+        r = subprocess.run(cmd[:2] + ["--gpus", "2", "--same-device", "--backend", "gloo", "--preflight"], cwd=ROOT, capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert r.returncode == 0 and '"preflight"' in r.stdout and "preflight ok" in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
     # without --same-device the launcher refuses to run fewer ranks than asked on a one-GPU box
     if torch.cuda.device_count() < 2:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
@@ -200,3 +237,8 @@ def test_rccl_two_gpus_readiness_guard():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and "RCCL" in j["config"]["parallelism"] and np.isfinite(j["final_loss"]) and j["value"] > 0
+    assert j["collective_preflight"]["backend"] == "nccl" and "eager launches (the default over RCCL" in j["config"]["update"]
+    # opting in to the cut graphs over RCCL goes through the captured-vs-eager self-check and the all-ranks agreement: either outcome is a pass
+    env["MI355PPO_UPDATE_GRAPHS"] = "1"
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-3000:]

@@ -337,3 +337,43 @@ def test_whole_ppo_iteration_matches_the_reference_lines():
         np.testing.assert_allclose(flat().numpy(), g["final_params"], rtol=0, atol=5e-7)       # measured 3e-8; sixteen Adam steps move 1e-3
     finally:
         torch.set_num_threads(n)
+
+
+def test_update_graph_policy_is_eager_over_rccl_unless_opted_in(monkeypatch):
+    """learner.update_graph_policy (round 6, the one place runner.train and bench.py ask): graphs on one GPU and over gloo; over nccl (RCCL)
+    the eager update unless MI355PPO_UPDATE_GRAPHS=1, which then also demands the captured-vs-eager self-check; 0 switches them off everywhere."""
+    import torch.distributed as dist
+
+    from cleanrl_amd import learner as L
+
+    monkeypatch.delenv("MI355PPO_UPDATE_GRAPHS", raising=False)
+    assert L.update_graph_policy(1) == "capture"
+    for backend, want_auto, want_on in (("gloo", "capture", "capture"), ("nccl", "off", "capture+check")):
+        monkeypatch.setattr(dist, "is_initialized", lambda: True)
+        monkeypatch.setattr(dist, "get_backend", lambda b=backend: b)
+        monkeypatch.delenv("MI355PPO_UPDATE_GRAPHS", raising=False)
+        assert L.update_graph_policy(8) == want_auto and L.update_graph_policy(1) == "capture"
+        monkeypatch.setenv("MI355PPO_UPDATE_GRAPHS", "auto")
+        assert L.update_graph_policy(2) == want_auto
+        monkeypatch.setenv("MI355PPO_UPDATE_GRAPHS", "1")
+        assert L.update_graph_policy(4) == want_on and L.update_graph_policy(1) == "capture"
+        monkeypatch.setenv("MI355PPO_UPDATE_GRAPHS", "0")
+        assert L.update_graph_policy(4) == "off" and L.update_graph_policy(1) == "off"
+
+
+def test_all_ranks_agree_takes_every_rank_back_when_one_capture_failed():
+    """learner.all_ranks_agree over a real gloo group of three CPU ranks: everybody agrees only if nobody failed (the ADVICE item of round 5:
+    runner.train used to fall back per rank, so ranks could run different routes through the update)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "MI355PPO_UPDATE_GRAPHS")}
+    for bad, want in ((-1, "True"), (1, "False")):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node", "3", "--local-addr",
+                              "127.0.0.1", os.path.join("tests", "dp_agree_worker.py"), str(bad)], cwd=root, capture_output=True, text=True,
+                             timeout=300, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        for r in range(3):
+            assert f"rank {r} agreed={want} policy=capture" in out.stdout, out.stdout

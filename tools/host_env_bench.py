@@ -89,8 +89,14 @@ def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, devic
             "ms_per_iter": el / iters * 1e3, "rollout_ms": t_roll / iters * 1e3,
             "host_env_ms_per_group": [t / iters * 1e3 for t in t_env], "update_ms": t_upd / iters * 1e3,
             "h2d_bytes_per_step": N * (7056 if delta else 28224),
-            **({"lane_step_us": {k: (v / max(roll.async_stats["lane_steps"], 1) * 1e6 if k != "lane_steps" else v) for k, v in roll.async_stats.items()}}
-               if one_thread else {})}
+            **({"lane_step_us": lane_step_us(roll.async_stats)} if one_thread else {})}
+
+
+def lane_step_us(async_stats: dict) -> dict:
+    """Microseconds PER LANE STEP the driver thread spends waiting on the GPU / on the env workers / in its own Python, from the pipeline's summed
+    seconds (``GroupedRollout.async_stats``: keys ``*_s``).  The keys say what the values are: ``gpu_wait_us``, ``env_wait_us``, ``host_us``."""
+    n = max(async_stats.get("lane_steps", 0), 1)
+    return {(k[:-2] + "_us" if k.endswith("_s") else k): (v / n * 1e6 if k != "lane_steps" else v) for k, v in async_stats.items()}
 
 
 def main():
