@@ -145,7 +145,7 @@ class AtariAgent(_DiscreteMixin, nn.Module):
         hidden = cnn.LinearReLUHwcFn.apply(feats, net[7].weight, net[7].bias, self._trunk.bufs)
         if cnn.heads_supported(self.actor, self.critic):
             return cnn.HeadsFn.apply(hidden, self.actor.weight, self.actor.bias, self.critic.weight, self.critic.bias, self._trunk.bufs)
-        return self.actor(hidden), self.critic(hidden)      # > 7 actions: library GEMMs
+        return self.actor(hidden), self.critic(hidden)      # > 18 actions: library GEMMs
 
     def act_u8(self, obs_rows, seed, offset, offset_base=None, action_f32_out=None, logprob_out=None, value_out=None, want_i64=True):
         """The learner's rollout step on uint8 rows (no autograd graph): trunk, then Linear(3136,512) + heads + Categorical draw in two

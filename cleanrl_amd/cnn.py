@@ -937,7 +937,7 @@ class LinearReLUHwcFn(torch.autograd.Function):
 
 
 def heads_supported(actor: torch.nn.Linear, critic: torch.nn.Linear) -> bool:
-    return actor.in_features == 512 and critic.in_features == 512 and critic.out_features == 1 and 1 <= actor.out_features <= 7
+    return actor.in_features == 512 and critic.in_features == 512 and critic.out_features == 1 and 1 <= actor.out_features <= 18
 
 
 class HeadsFn(torch.autograd.Function):

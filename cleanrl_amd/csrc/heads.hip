@@ -21,27 +21,70 @@ namespace mi355ppo {
 
 constexpr int kHid = 512;
 constexpr int kHeadsBlocks = 512;       // persistent workgroups of 4 waves (2 per CU)
+// Round 6: heads wider than 7 actions (Linear(512, envs.single_action_space.n), ppo_atari_multigpu.py:148: ALE games have up to 18 actions).
+// NA = A + 1 weight rows of 8 floats per lane fit the register file up to NA = 8 (the backward also keeps NA x 8 accumulators); from there on
+// the kernels are compiled ONCE for kWideNA = 19 rows with the live count a run-time (wave-uniform) argument, and the weights sit in LDS
+// (19 x 2 KB; lane l reads its 32 bytes of a row with two ds_read_b128, conflict-free) instead of registers: same arithmetic, same order.
+constexpr int kWideNA = 19;
 
 template <int NA>
 __device__ __forceinline__ void load_w(float (&w)[NA][8], const float* __restrict__ Wa, const float* __restrict__ Wc, int A,
                                        int lane) {
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-        const float* row = a < A ? Wa + (size_t)a * kHid : Wc;
-        const float4 x = *reinterpret_cast<const float4*>(row + lane * 8), y = *reinterpret_cast<const float4*>(row + lane * 8 + 4);
-        w[a][0] = x.x; w[a][1] = x.y; w[a][2] = x.z; w[a][3] = x.w; w[a][4] = y.x; w[a][5] = y.y; w[a][6] = y.z; w[a][7] = y.w;
+        if (a < A) {
+            const float* row = Wa + (size_t)a * kHid;
+            const float4 x = *reinterpret_cast<const float4*>(row + lane * 8), y = *reinterpret_cast<const float4*>(row + lane * 8 + 4);
+            w[a][0] = x.x; w[a][1] = x.y; w[a][2] = x.z; w[a][3] = x.w; w[a][4] = y.x; w[a][5] = y.y; w[a][6] = y.z; w[a][7] = y.w;
+        } else {
+            // the critic's weight row: 4-byte loads.  In the flat parameter buffer (the reference's cat order, ppo_atari_multigpu.py:360) it
+            // follows actor.bias -- A floats --, so it sits on a 16-byte boundary only when A % 4 == 0 (Breakout's 4 actions; not Pong's 6).
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[a][i] = Wc[lane * 8 + i];
+        }
     }
 }
 
-template <int NA>
+// The weight rows of a lane: registers (WIDE = false: all NA rows live) or LDS (WIDE: `na` of kWideNA rows live, rows >= na never touched).
+template <int NA, bool WIDE>
+struct HeadW {
+    float w[WIDE ? 1 : NA][8];
+    const float* l;                       // WIDE: &lds[0][lane * 8]
+    __device__ __forceinline__ void load(float* lds, const float* __restrict__ Wa, const float* __restrict__ Wc, int A, int lane) {
+        if constexpr (WIDE) {
+            for (int e = threadIdx.x; e < A * (kHid / 4); e += blockDim.x) {
+                const int a = e / (kHid / 4), q = e - a * (kHid / 4);
+                reinterpret_cast<float4*>(lds + a * kHid)[q] = reinterpret_cast<const float4*>(Wa + (size_t)a * kHid)[q];
+            }
+            for (int e = threadIdx.x; e < kHid; e += blockDim.x) lds[A * kHid + e] = Wc[e];       // (the critic's row: 4-byte aligned only, see load_w)
+            __syncthreads();
+            l = lds + lane * 8;
+        } else {
+            load_w<NA>(w, Wa, Wc, A, lane);
+            l = nullptr;
+        }
+    }
+    __device__ __forceinline__ void row(int a, float (&out)[8]) const {
+        if constexpr (WIDE) {
+            const float4 x = *reinterpret_cast<const float4*>(l + a * kHid), y = *reinterpret_cast<const float4*>(l + a * kHid + 4);
+            out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w; out[4] = y.x; out[5] = y.y; out[6] = y.z; out[7] = y.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) out[i] = w[a][i];
+        }
+    }
+};
+
+template <int NA, bool WIDE = false>
 __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ h, const float* __restrict__ Wa,
                                                         const float* __restrict__ ba, const float* __restrict__ Wc,
                                                         const float* __restrict__ bc, float* __restrict__ logits,
                                                         float* __restrict__ value, int M, int A) {
+    __shared__ __attribute__((aligned(16))) float wl[WIDE ? kWideNA * kHid : 4];
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
-    float w[NA][8];
-    load_w<NA>(w, Wa, Wc, A, lane);
+    HeadW<NA, WIDE> W;
+    W.load(wl, Wa, Wc, A, lane);
     float bias = 0.0f;
     if (lane < A) bias = ba[lane];
     else if (lane == A) bias = bc[0];
@@ -50,11 +93,15 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
         float out = 0.0f;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            float s = 0.0f;
+            if (!WIDE || a <= A) {                          // (wave-uniform; the unrolled loop keeps every row's registers static)
+                float wa[8];
+                W.row(a, wa);
+                float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += hv[i] * w[a][i];
-            s = wave_sum(s);
-            if (lane == a) out = s;
+                for (int i = 0; i < 8; ++i) s += hv[i] * wa[i];
+                s = wave_sum(s);
+                if (lane == a) out = s;
+            }
         }
         out = out + bias;
         if (lane < A) logits[(size_t)m * A + lane] = out;
@@ -80,19 +127,20 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 // the Categorical draw (catrow.h's row functions: K2's) of one row per wave iteration -- action, log-prob and value go straight
 // into their rollout-storage rows.  Four launches of a captured env step (fold, heads, sample, the value copy) become one; the
 // results are bit-identical to the four (tests/test_gpu_kernels.py).
-template <int NA>
+template <int NA, bool WIDE = false>
 __global__ __launch_bounds__(256) void heads_act_kernel(const float* __restrict__ part, int splits, size_t slab, const float* __restrict__ fc_bias,
                                                         const float* __restrict__ Wa, const float* __restrict__ ba,
                                                         const float* __restrict__ Wc, const float* __restrict__ bc,
                                                         const float* __restrict__ noise, uint64_t seed, uint64_t offset,
                                                         const uint64_t* __restrict__ offset_base, int64_t* __restrict__ action_i64,
                                                         float* __restrict__ action_f32, float* __restrict__ logprob,
-                                                        float* __restrict__ value, float* __restrict__ hidden, int M) {
-    constexpr int A = NA - 1;
+                                                        float* __restrict__ value, float* __restrict__ hidden, int M, int a_rt) {
+    __shared__ __attribute__((aligned(16))) float wl[WIDE ? kWideNA * kHid : 4];
+    const int A = WIDE ? a_rt : NA - 1;                 // (narrow heads: a compile-time constant)
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
-    float w[NA][8];
-    load_w<NA>(w, Wa, Wc, A, lane);
+    HeadW<NA, WIDE> W;
+    W.load(wl, Wa, Wc, A, lane);
     float fb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) fb[i] = fc_bias[lane * 8 + i];
@@ -113,19 +161,25 @@ __global__ __launch_bounds__(256) void heads_act_kernel(const float* __restrict_
             *reinterpret_cast<float4*>(hr) = make_float4(hv[0], hv[1], hv[2], hv[3]);
             *reinterpret_cast<float4*>(hr + 4) = make_float4(hv[4], hv[5], hv[6], hv[7]);
         }
-        float out[NA];                                  // every lane ends up with all NA sums (the butterfly is an all-reduce)
+        float out[NA], vout = 0.0f;                     // every lane ends up with all NA sums (the butterfly is an all-reduce)
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            float s = 0.0f;
+            out[a] = 0.0f;
+            if (!WIDE || a <= A) {
+                float wa[8];
+                W.row(a, wa);
+                float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += hv[i] * w[a][i];
-            out[a] = wave_sum(s) + (a < A ? ba[a] : bc[0]);
+                for (int i = 0; i < 8; ++i) s += hv[i] * wa[i];
+                out[a] = wave_sum(s) + (a < A ? ba[a] : bc[0]);
+                if (a == A) vout = out[a];
+            }
         }
         if (lane == 0) {
-            constexpr int AMAX = A <= 4 ? 4 : 8;
+            constexpr int AMAX = WIDE ? 18 : (NA - 1 <= 4 ? 4 : 8);
             float xl[AMAX];
 #pragma unroll
-            for (int j = 0; j < AMAX; ++j) xl[j] = j < A ? out[j < A ? j : 0] : -INFINITY;
+            for (int j = 0; j < AMAX; ++j) xl[j] = j < A ? out[j] : -INFINITY;
             CatRow<AMAX> c;
             categorical_row<AMAX>(xl, A, c);
             float best_lp;
@@ -133,7 +187,7 @@ __global__ __launch_bounds__(256) void heads_act_kernel(const float* __restrict_
             if (action_i64) action_i64[m] = best;
             if (action_f32) action_f32[m] = (float)best;
             logprob[m] = best_lp;
-            value[m] = out[A];
+            value[m] = vout;
         }
     }
 }
@@ -142,19 +196,22 @@ __global__ __launch_bounds__(256) void heads_act_kernel(const float* __restrict_
 // respect to that layer's PRE-activation, dz = dh * (h > 0), and its column sums (that layer's bias gradient) are
 // accumulated as one more partial row -- both for free here (h and dh are in registers), a `threshold_backward` pass over
 // 2 x 67 MB and a column reduction over 67 MB when done by the layer itself.
-template <int NA, bool RELU>
+template <int NA, bool RELU, bool WIDE = false>
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ h, const float* __restrict__ Wa,
                                                         const float* __restrict__ Wc, const float* __restrict__ dlogits,
                                                         const float* __restrict__ dvalue, float* __restrict__ dh,
                                                         float* __restrict__ part,      // [grid][NA + 1][512 + 1]
                                                         int M, int A, int lddh, unsigned* __restrict__ dh_amax) {
     __shared__ float red[NA + 1][kHid + 1];
+    __shared__ __attribute__((aligned(16))) float wl[WIDE ? kWideNA * kHid : 4];
     float accz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (the wave index in an SGPR)
     const int wv = blockIdx.x * 4 + wave, nwv = gridDim.x * 4;
-    float w[NA][8], acc[NA][8], accb[NA];
+    const int na = WIDE ? A + 1 : NA;      // live rows (narrow heads: all NA, a compile-time constant)
+    float acc[NA][8], accb[NA];
     unsigned dmax = 0u;                    // bits of the largest |dh| this lane stored: dh's amax record (f16split.h), when asked for
-    load_w<NA>(w, Wa, Wc, A, lane);
+    HeadW<NA, WIDE> W;
+    W.load(wl, Wa, Wc, A, lane);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         accb[a] = 0.0f;
@@ -167,19 +224,27 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
         // per million came out with stale lanes 48-63 of the LAST permute -- tools/gpu/heads_stress.py)
         float gv[NA];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) gv[a] = a < NA - 1 ? dlogits[(size_t)m * (NA - 1) + a] : dvalue[m];
+        for (int a = 0; a < NA; ++a) {
+            gv[a] = 0.0f;
+            if (a < na - 1) gv[a] = dlogits[(size_t)m * (na - 1) + a];
+            else if (a == na - 1) gv[a] = dvalue[m];
+        }
         const float* hr = h + (size_t)m * kHid + lane * 8;
         const float4 x = *reinterpret_cast<const float4*>(hr), y = *reinterpret_cast<const float4*>(hr + 4);
         const float hv[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
         float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const float ga = gv[a];
-            accb[a] += ga;
+            if (!WIDE || a < na) {
+                const float ga = gv[a];
+                float wa[8];
+                W.row(a, wa);
+                accb[a] += ga;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                d[i] += ga * w[a][i];
-                acc[a][i] += ga * hv[i];
+                for (int i = 0; i < 8; ++i) {
+                    d[i] += ga * wa[i];
+                    acc[a][i] += ga * hv[i];
+                }
             }
         }
         if (RELU) {
@@ -204,12 +269,14 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
         if (wave == wsel) {
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
+                if (!WIDE || a < na) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float* r = &red[a][lane * 8 + i];
-                    *r = wsel == 0 ? acc[a][i] : *r + acc[a][i];
+                    for (int i = 0; i < 8; ++i) {
+                        float* r = &red[a][lane * 8 + i];
+                        *r = wsel == 0 ? acc[a][i] : *r + acc[a][i];
+                    }
+                    if (lane == 0) red[a][kHid] = wsel == 0 ? accb[a] : red[a][kHid] + accb[a];
                 }
-                if (lane == 0) red[a][kHid] = wsel == 0 ? accb[a] : red[a][kHid] + accb[a];
             }
             if (RELU) {
 #pragma unroll
@@ -221,9 +288,13 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
         }
         __syncthreads();
     }
-    constexpr int rows = RELU ? NA + 1 : NA;
+    // partial [na (+ 1 with RELU: the column sums of dz)][513]; the wide kernel's dz row sits in red[NA], behind rows it never filled
+    const int rows = RELU ? na + 1 : na;
     float* out = part + (size_t)blockIdx.x * rows * (kHid + 1);
-    for (int e = threadIdx.x; e < rows * (kHid + 1); e += 256) out[e] = (e % (kHid + 1) == kHid && e / (kHid + 1) == NA) ? 0.0f : red[e / (kHid + 1)][e % (kHid + 1)];
+    for (int e = threadIdx.x; e < rows * (kHid + 1); e += 256) {
+        const int a = e / (kHid + 1), j = e - a * (kHid + 1);
+        out[e] = (j == kHid && a == na) ? 0.0f : red[a == na ? NA : a][j];
+    }
 }
 
 // dWa (A,512), dba (A), dWc (512), dbc (1) from the workgroup partials, fixed order.
@@ -270,7 +341,7 @@ using namespace mi355ppo;
 
 static int heads_check(const char* fn, int M, int A, int H) {
     MI355_REQUIRE(M > 0, MI355PPO_EINVAL, "%s: M=%d must be positive", fn, M);
-    MI355_REQUIRE(A >= 1 && A <= 7, MI355PPO_EINVAL, "%s: A=%d must be in 1..7 (use a library GEMM for wider heads)", fn, A);
+    MI355_REQUIRE(A >= 1 && A <= kWideNA - 1, MI355PPO_EINVAL, "%s: A=%d must be in 1..%d (use a library GEMM for wider heads)", fn, A, kWideNA - 1);
     MI355_REQUIRE(H == kHid, MI355PPO_EINVAL, "%s: hidden width %d is not supported (NatureCNN: 512)", fn, H);
     return MI355PPO_OK;
 }
@@ -282,14 +353,15 @@ extern "C" MI355PPO_API int mi355ppo_heads_fwd_f32(const float* h, const float* 
     MI355_REQUIRE(h && Wa && ba && Wc && bc && logits && value, MI355PPO_EINVAL, "%s: null pointer", fn);
     int rc = heads_check(fn, M, A, H);
     if (rc) return rc;
-    MI355_REQUIRE(aligned(h, 16) && aligned(Wa, 16) && aligned(Wc, 16) && aligned(ba, 4) && aligned(bc, 4) && aligned(logits, 4) &&
-                      aligned(value, 4), MI355PPO_EALIGN, "%s: h / Wa / Wc must be 16-byte aligned", fn);
+    MI355_REQUIRE(aligned(h, 16) && aligned(Wa, 16) && aligned(Wc, 4) && aligned(ba, 4) && aligned(bc, 4) && aligned(logits, 4) &&
+                      aligned(value, 4), MI355PPO_EALIGN, "%s: h / Wa must be 16-byte aligned", fn);
     const dim3 grid(heads_grid(M));
     hipStream_t s = as_stream(stream);
 #define LAUNCH(NA) hipLaunchKernelGGL((heads_fwd_kernel<NA>), grid, dim3(256), 0, s, h, Wa, ba, Wc, bc, logits, value, M, A)
     switch (A + 1) {
         case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break;
-        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;
+        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; case 8: LAUNCH(8); break;
+        default: hipLaunchKernelGGL((heads_fwd_kernel<kWideNA, true>), grid, dim3(256), 0, s, h, Wa, ba, Wc, bc, logits, value, M, A); break;
     }
 #undef LAUNCH
     return check_launch("heads_fwd_kernel");
@@ -303,9 +375,9 @@ static int fc_heads_act_impl(const char* fn, const float* a3, int lda, const voi
     MI355_REQUIRE(action_i64 || action_f32, MI355PPO_EINVAL, "%s: no action output", fn);
     int rc = heads_check(fn, M, A, H);
     if (rc) return rc;
-    MI355_REQUIRE(aligned(Wa, 16) && aligned(Wc, 16) && aligned(fc_bias, 4) && aligned(ba, 4) && aligned(bc, 4) && aligned(noise_exp1, 4) &&
+    MI355_REQUIRE(aligned(Wa, 16) && aligned(Wc, 4) && aligned(fc_bias, 4) && aligned(ba, 4) && aligned(bc, 4) && aligned(noise_exp1, 4) &&
                       aligned(offset_base, 8) && aligned(action_i64, 8) && aligned(action_f32, 4) && aligned(logprob, 4) && aligned(value, 4) &&
-                      aligned(hidden_out, 16), MI355PPO_EALIGN, "%s: Wa / Wc / hidden_out must be 16-byte aligned", fn);
+                      aligned(hidden_out, 16), MI355PPO_EALIGN, "%s: Wa / hidden_out must be 16-byte aligned", fn);
     int splits = 0;
     rc = z_fc_raw_launch(fn, a3, lda, fc_pack, M, H, K, workspace, workspace_bytes, &splits, as_stream(stream), a3_amax);
     if (rc) return rc;
@@ -313,10 +385,12 @@ static int fc_heads_act_impl(const char* fn, const float* a3, int lda, const voi
     const float* part = static_cast<const float*>(workspace);
     const size_t slab = (size_t)M * kHid;
 #define LAUNCH(NA) hipLaunchKernelGGL((heads_act_kernel<NA>), grid, dim3(256), 0, as_stream(stream), part, splits, slab, fc_bias, Wa, ba, Wc, bc, \
-                                      noise_exp1, seed, offset, offset_base, action_i64, action_f32, logprob, value, hidden_out, M)
+                                      noise_exp1, seed, offset, offset_base, action_i64, action_f32, logprob, value, hidden_out, M, A)
     switch (A + 1) {
         case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break;
-        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;
+        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; case 8: LAUNCH(8); break;
+        default: hipLaunchKernelGGL((heads_act_kernel<kWideNA, true>), grid, dim3(256), 0, as_stream(stream), part, splits, slab, fc_bias, Wa, ba, Wc, bc,
+                                    noise_exp1, seed, offset, offset_base, action_i64, action_f32, logprob, value, hidden_out, M, A); break;
     }
 #undef LAUNCH
     return check_launch("heads_act_kernel");
@@ -333,7 +407,7 @@ extern "C" MI355PPO_API int mi355ppo_fc_heads_act_categorical_f32(const float* a
 }
 
 extern "C" MI355PPO_API size_t mi355ppo_heads_bwd_workspace_bytes(int M, int A) {
-    if (M <= 0 || A < 1 || A > 7) return 0;
+    if (M <= 0 || A < 1 || A > kWideNA - 1) return 0;
     return (size_t)heads_grid(M) * (A + 2) * (kHid + 1) * sizeof(float);      // (A + 1 rows; one more for the ReLU variant's bias gradient)
 }
 
@@ -347,8 +421,8 @@ static int heads_bwd(const char* fn, const float* h, const float* Wa, const floa
     const size_t need = mi355ppo_heads_bwd_workspace_bytes(M, A);
     MI355_REQUIRE(workspace && workspace_bytes >= need, MI355PPO_EWORKSPACE, "%s: workspace %zu bytes < required %zu", fn,
                   workspace ? workspace_bytes : (size_t)0, need);
-    MI355_REQUIRE(aligned(h, 16) && aligned(Wa, 16) && aligned(Wc, 16) && aligned(dh, 16) && aligned(workspace, 4) &&
-                      aligned(dlogits, 4) && aligned(dvalue, 4) && aligned(dbh, 4), MI355PPO_EALIGN, "%s: h / Wa / Wc / dh must be 16-byte aligned", fn);
+    MI355_REQUIRE(aligned(h, 16) && aligned(Wa, 16) && aligned(Wc, 4) && aligned(dh, 16) && aligned(workspace, 4) &&
+                      aligned(dlogits, 4) && aligned(dvalue, 4) && aligned(dbh, 4), MI355PPO_EALIGN, "%s: h / Wa / dh must be 16-byte aligned", fn);
     const int nb = heads_grid(M);
     float* part = static_cast<float*>(workspace);
     hipStream_t s = as_stream(stream);
@@ -359,7 +433,11 @@ static int heads_bwd(const char* fn, const float* h, const float* Wa, const floa
     } while (0)
     switch (A + 1) {
         case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; case 4: LAUNCH(4); break; case 5: LAUNCH(5); break;
-        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; default: LAUNCH(8); break;
+        case 6: LAUNCH(6); break; case 7: LAUNCH(7); break; case 8: LAUNCH(8); break;
+        default:
+            if (dbh) hipLaunchKernelGGL((heads_bwd_kernel<kWideNA, true, true>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A, lddh, dh_amax);
+            else hipLaunchKernelGGL((heads_bwd_kernel<kWideNA, false, true>), dim3(nb), dim3(256), 0, s, h, Wa, Wc, dlogits, dvalue, dh, part, M, A, lddh, dh_amax);
+            break;
     }
 #undef LAUNCH
     rc = check_launch("heads_bwd_kernel");

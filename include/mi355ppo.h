@@ -531,7 +531,7 @@ MI355PPO_API int mi355ppo_cnn_conv_wgrad_f32(const void* src, const int64_t* ind
 /* ---------------------------------------------------------------------------------------------
  * Heads  actor = Linear(H, A) and critic = Linear(H, 1) of Agent (cleanrl/ppo_atari_multigpu.py:148-149,
  * used at :151,157-159), forward and backward.  Degenerate as GEMMs (A + 1 <= 8 columns); here one
- * bandwidth-bound pass over the hidden activations each.  H must be 512 (NatureCNN), 1 <= A <= 7.
+ * bandwidth-bound pass over the hidden activations each.  H must be 512 (NatureCNN), 1 <= A <= 18 (every ALE action set; from A = 8 on the weight rows sit in LDS instead of registers -- round 6).
  *   h (M,H); Wa (A,H), ba (A); Wc (H) [= critic.weight (1,H)], bc (1)   ->   logits (M,A), value (M)
  *   backward: dlogits (M,A), dvalue (M)  ->  dh (M,H), dWa (A,H), dba (A), dWc (H), dbc (1)
  * Weight gradients are summed in a fixed order (deterministic); all outputs are overwritten.

@@ -105,7 +105,7 @@ def test_cnn_and_heads_entry_points_validate_before_any_launch():
     assert lib.mi355ppo_cnn_conv_wgrad_workspace_bytes(0, 2) == 0
     assert lib.mi355ppo_cnn_conv_wgrad_f32(p, None, p, p, p, 8, 2, p, 16, None) == -4
     assert b"workspace" in lib.mi355ppo_last_error()
-    assert lib.mi355ppo_heads_fwd_f32(p, p, p, p, p, p, p, 8, 8, 512, None) == -1      # A must be 1..7
+    assert lib.mi355ppo_heads_fwd_f32(p, p, p, p, p, p, p, 8, 19, 512, None) == -1     # A must be 1..18 (round 6; 1..7 before)
     assert lib.mi355ppo_heads_fwd_f32(p, p, p, p, p, p, p, 8, 4, 256, None) == -1      # hidden width is 512
     assert lib.mi355ppo_heads_bwd_workspace_bytes(32768, 4) == 512 * 6 * 513 * 4     # A + 1 rows, + 1 for the ReLU variant's bias gradient
     assert lib.mi355ppo_heads_bwd_f32(p, p, p, p, p, p, p, p, p, p, 8, 4, 512, None, 0, None) == -4

@@ -363,7 +363,7 @@ def test_trunk_matches_reference_network_forward_backward(images):
         assert err <= max(5e-5 * scale, 4.0 * err_torch), f"grad of {name}: err {err:.3e}, torch f32 err {err_torch:.3e}, scale {scale:.3e}"
 
 
-@pytest.mark.parametrize("M,A", [(1, 4), (37, 4), (1024, 6), (4096, 1), (32768, 4), (300, 7)])
+@pytest.mark.parametrize("M,A", [(1, 4), (37, 4), (1024, 6), (4096, 1), (32768, 4), (300, 7), (5, 8), (1024, 9), (300, 13), (4100, 18), (32768, 18)])      # (A > 7, round 6: the weight rows in LDS, one instantiation for 8 .. 18 actions)
 def test_heads_forward_backward(M, A):
     """actor + critic heads (ppo_atari_multigpu.py:148-149) as one pass each way vs float64 Linear layers; the weight
     gradients are sums over M rows, so their bound scales like the f32 error of torch's own GEMM (calibrated)."""
@@ -483,7 +483,7 @@ def test_fc_weight_gradient_kernel_y_against_float64(M):
     assert torch.equal(got, cnn.fc_wgrad(dz.to(DEV), a.to(DEV)))            # deterministic
 
 
-@pytest.mark.parametrize("M,A", [(1, 4), (4100, 6), (32768, 4)])
+@pytest.mark.parametrize("M,A", [(1, 4), (4100, 6), (32768, 4), (37, 9), (4100, 18)])
 def test_heads_backward_relu_variant(M, A):
     """The ReLU variant of the heads' backward: the gradient it writes is the plain one times (h > 0), bit for bit, with a
     padded row pitch; the extra output is the column sum of that (the FC layer's bias gradient)."""

@@ -901,27 +901,32 @@ def test_captured_update_slots_cut_at_the_bucket_boundaries_are_bit_identical_to
         assert me == mg or all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
 
 
-def test_captured_update_with_wide_heads_is_bit_identical_or_falls_back_cleanly():
-    """18 actions (most ALE games): the heads are ``nn.Linear`` (library GEMMs + autograd's AccumulateGrad inside the capture).  Either
-    the capture succeeds and replays bit-identically to the eager update, or it raises and leaves a learner that trains eagerly with
-    untouched parameters, Adam state and gradients (``runner.train`` then continues eagerly)."""
+@pytest.mark.parametrize("n_actions", [6, 9, 18])      # (6: Pong -- the critic weight row is not 16-byte aligned in the flat buffer)
+def test_captured_update_with_wide_heads_runs_the_hip_heads_and_is_bit_identical(n_actions):
+    """9 / 18 actions (most ALE games; Linear(512, envs.single_action_space.n), ppo_atari_multigpu.py:148): since round 6 the heads of up to 18
+    actions run on the library's kernels (csrc/heads.hip: the weight rows in LDS from 8 actions on) -- rollout step (fused FC + heads + draw),
+    forward and backward --, so the whole update is capturable: the capture must SUCCEED and replay bit-identically to the eager update, and
+    no ``nn.Linear`` fallback may have served the heads."""
     N, T = 32, 8
+    from cleanrl_amd import cnn
+
+    def no_fallback(*a, **k):
+        raise AssertionError("the actor head ran as nn.Linear (library GEMM fallback)")
 
     def make():
         torch.manual_seed(4)
-        env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=6, n_actions=18, done_p=0.1)
+        env = E.DeviceSyntheticAtariVecEnv(N, DEV, seed=6, n_actions=n_actions, done_p=0.1)
         agent = AtariAgent(env).to(DEV)
+        assert cnn.heads_supported(agent.actor, agent.critic)
+        agent.actor.forward = no_fallback               # every use of the policy head must go through csrc/heads.hip
         args = learner_smoke.default_args(num_steps=T, num_minibatches=2, update_epochs=2)
         L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
         L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
         return L, env
 
     (Le, enve), (Lg, envg) = make(), make()
-    try:
-        Lg.capture_update()
-    except Exception as exc:
-        print("capture with 18-action heads failed, eager fallback:", type(exc).__name__, str(exc).splitlines()[0][:160])
-        assert Lg._update_graphs is None
+    Lg.capture_update()
+    assert Lg._update_graphs is not None
     assert torch.equal(Le.flat.params, Lg.flat.params) and not Lg.flat.grads.any() and not Lg.flat.exp_avg.any()
     for it in range(2):
         learner_smoke.rollout(Le, enve)
@@ -934,6 +939,7 @@ def test_captured_update_with_wide_heads_is_bit_identical_or_falls_back_cleanly(
         assert torch.equal(Le.flat.params, Lg.flat.params), it
         assert torch.equal(Le.flat.exp_avg, Lg.flat.exp_avg) and torch.equal(Le.flat.exp_avg_sq, Lg.flat.exp_avg_sq), it
         assert all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
+    assert Le.flat.params.ne(Lg.flat.params).sum() == 0 and (Le.flat.params != 0).any()
 
 
 def test_captured_update_slots_continuous_path():
