@@ -534,9 +534,8 @@ def main():
                 return f"trunk_fwd(conv1+2+3)@{images}", sum(conv_flop(l, images) for l in cnn.LAYERS), "F"
 
             def k_wgrad(src, dz, layer, inds=None, out=None, amax=None):
-                letter = chr(lib.mi355ppo_cnn_conv_wgrad_kernel(dz.shape[0], layer))
-                if amax is not None and os.environ.get("MI355PPO_CONV_U", "1") != "0" and os.environ.get({1: "MI355PPO_CONV_U1", 2: "MI355PPO_CONV_U2"}.get(layer, "MI355PPO_CONV_U"), "1") != "0":
-                    letter = "U"                             # the f16 split's weight gradients: kernel U (csrc/convu.hip), every size
+                # (the library's own decision, not a restatement of its switches: kernel U declines tensors beyond the 32-bit buffer range)
+                letter = chr(lib.mi355ppo_cnn_conv_wgrad_kernel_f16x2(dz.shape[0], layer) if amax is not None else lib.mi355ppo_cnn_conv_wgrad_kernel(dz.shape[0], layer))
                 return f"conv{layer}_wgrad@{dz.shape[0]}", conv_flop(layer, dz.shape[0]), letter + "h" if amax is not None and letter in ("V", "U") else letter
 
             timed_op("conv_fwd", k_fwd)

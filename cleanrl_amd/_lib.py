@@ -57,6 +57,7 @@ SIGNATURES = {
     "mi355ppo_cnn_conv_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mi355ppo_cnn_conv_wgrad_kernel": (c_int, [c_int64, c_int]),
     "mi355ppo_cnn_conv_packed_kernel_f16x2": (c_int, [c_int64, c_int, c_int]),
+    "mi355ppo_cnn_conv_wgrad_kernel_f16x2": (c_int, [c_int64, c_int]),
     "mi355ppo_cnn_conv_wgrad_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_size_t, _P]),
     "mi355ppo_cnn_trunk_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_cnn_conv1q_pack_bytes": (c_size_t, []),

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import os
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -581,7 +583,7 @@ class _Buffers:
     def owns(self, idx: int, t: torch.Tensor) -> torch.Tensor:
         """Record ``idx`` of t's pass, for a producer about to write ``t`` (its epilogue fills the record)."""
         key = self._amax_key(t.shape[0], t.device)
-        self._owners[key][idx] = t.data_ptr()
+        self._owners[key][idx] = (t.data_ptr(), weakref.ref(t))
         return self.by_m[key][idx]
 
     def rec_of(self, idx: int, t: torch.Tensor) -> torch.Tensor:
@@ -591,11 +593,14 @@ class _Buffers:
         rec = self.by_m.get(key)
         if rec is None:
             rec = self.begin_pass(t.shape[0], t.device)
-        owners = self._owners[key]
-        if owners.get(idx) != t.data_ptr():
+        # A record is trusted only for the tensor its PRODUCER filled it for: same address AND the producer's tensor object still alive -- once it
+        # is gone the allocator may hand the address to another tensor (a second backward over one forward, an auxiliary pass), and a record that
+        # understates a tensor overflows the f16 split.  A tensor from elsewhere is measured on every use; it never becomes an owner.
+        o = self._owners[key].get(idx)
+        if o is None or o[0] != t.data_ptr() or o[1]() is None:
+            self._owners[key].pop(idx, None)
             rec[idx].zero_()
             absmax(t if t.is_contiguous() else t.contiguous(), rec[idx])      # (module attribute at call time: the tests' stand-in)
-            owners[idx] = t.data_ptr()
         return rec[idx]
 
     def _pack_keys(self):

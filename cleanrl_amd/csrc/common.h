@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...);
 int conv1p_launch(const unsigned char* src, const int64_t* inds, const float* dz, float* part_w, float* part_b, int images, int grid,
                   hipStream_t s, const unsigned* dz_amax, float* partial_scale);
 // kernel V (convw.hip): layers 2 / 3 weight + bias gradient on the bf16 pipe; returns 1 when the batch does not qualify
-bool convw_applies(int64_t images, int layer);
+bool convw_applies(int64_t images, int layer, bool f16 = false);      // (f16: the two-tile shape of the f16 split -- 227 instead of 170 slabs on layer 3)
 int convw_parts(int64_t images, int layer);
 int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
                  const unsigned* dz_amax = nullptr, const unsigned* src_amax = nullptr);      // amax records: the two-term f16 split (f16split.h)
@@ -39,6 +39,7 @@ int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void*
                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
 // convu.hip: kernel U, the layer-3 weight gradient on the f16 split with both operands of an image group resident in LDS (-> 0 launched, 1 not applicable)
 int convu_max_parts();
+bool convu_takes(int64_t images, int layer);       // the f16x2 weight gradient of this size and layer (1, 2, 3) runs on kernel U
 int convu_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
                  const unsigned* dz_amax, const unsigned* src_amax);
 int convu1_launch(const unsigned char* frames, const int64_t* inds, const float* dz, float* part_w, float* part_b, int64_t images, int* nparts,

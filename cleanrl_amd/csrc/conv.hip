@@ -1166,6 +1166,14 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_kernel(int64_t images, int l
     return layer == 1 ? 'P' : convw_applies(images, layer) ? 'V' : 'T';
 }
 
+// 'U', 'V', 'P' or 'T': the kernel mi355ppo_cnn_conv_wgrad_f16x2_f32 (layers 2, 3) / mi355ppo_cnn_conv1_wgrad_f16x2 (layer 1) runs for this batch --
+// the launchers' own decision (convu.hip::convu_takes, convw.hip::convw_applies), not a restatement of it
+extern "C" MI355PPO_API int mi355ppo_cnn_conv_wgrad_kernel_f16x2(int64_t images, int layer) {
+    if (images <= 0 || layer < 1 || layer > 3) return 0;
+    if (convu_takes(images, layer)) return 'U';
+    return layer == 1 ? 'P' : convw_applies(images, layer, true) ? 'V' : 'T';
+}
+
 static int conv_wgrad_impl(const char* fn, const void* src, const int64_t* inds, const float* dz, float* dW, float* db, int64_t images, int layer,
                            void* workspace, size_t workspace_bytes, const unsigned* src_amax, const unsigned* dz_amax, void* stream) {
     int Cin, Cout, KH, SS, Hin, Hout;

@@ -409,11 +409,22 @@ bool convu_on(int layer) {
 
 int convu_max_parts() { return 256; }
 
+// Which f16x2 weight-gradient launches kernel U takes -- the ONE place that decides (the launchers below and the host query
+// mi355ppo_cnn_conv_wgrad_kernel_f16x2 ask it): layers 2 / 3 while the source tensor stays inside the 32-bit buffer range, layer 1 while dz does.
+bool convu_takes(int64_t images, int layer) {
+    if (images <= 0) return false;
+    if (layer == 1) {
+        const char* e = getenv("MI355PPO_CONV_U1");
+        return convu_on(3) && !(e && e[0] == '0') && (long long)images * 20 * 20 * 32 * 4 < (1LL << 32) - 8192;
+    }
+    if ((layer != 2 && layer != 3) || !convu_on(layer)) return false;
+    return (long long)images * (layer == 3 ? 9 * 9 * 64 : 20 * 20 * 32) * 4 < (1LL << 32) - 8192;
+}
+
 template <class UG>
 static int convu_launch_t(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int* nparts, hipStream_t s,
                           const unsigned* dz_amax, const unsigned* src_amax) {
     const long long srcb = (long long)images * UG::SRC_REC * UG::C * 4, dzb = (long long)images * UG::OP * UG::CO * 4;
-    if (srcb >= (1LL << 32) - 8192) return 1;
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, n = 0;
@@ -434,7 +445,7 @@ static int convu_launch_t(const float* src, const float* dz, float* part_w, floa
 // -> 0 launched (nparts partials written), 1 not applicable
 int convu_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
                  const unsigned* dz_amax, const unsigned* src_amax) {
-    if ((layer != 2 && layer != 3) || !dz_amax || !src_amax || !convu_on(layer)) return 1;
+    if (!dz_amax || !src_amax || !convu_takes(images, layer)) return 1;
     return layer == 3 ? convu_launch_t<UGeom3>(src, dz, part_w, part_b, images, nparts, s, dz_amax, src_amax)
                       : convu_launch_t<UGeom2>(src, dz, part_w, part_b, images, nparts, s, dz_amax, src_amax);
 }
@@ -442,10 +453,8 @@ int convu_launch(const float* src, const float* dz, float* part_w, float* part_b
 // Layer 1 (MI355PPO_CONV_U1=0: kernel P).  -> 0 launched (nparts partials; the reduce applies 1 / 255 only), 1 not applicable
 int convu1_launch(const unsigned char* frames, const int64_t* inds, const float* dz, float* part_w, float* part_b, int64_t images, int* nparts,
                   hipStream_t s, const unsigned* dz_amax) {
-    const char* e = getenv("MI355PPO_CONV_U1");
-    if (!dz_amax || !convu_on(3) || (e && e[0] == '0')) return 1;
+    if (!dz_amax || !convu_takes(images, 1)) return 1;
     const long long dzb = (long long)images * 20 * 20 * 32 * 4;
-    if (dzb >= (1LL << 32) - 8192) return 1;
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, n = 0;

@@ -336,22 +336,24 @@ static int convw_slabs(int layer, bool nt2 = false) {      // x 4 / x 6 wave gro
 
 // Kernel V takes a batch of layer 2 / 3 that is a multiple of 16 images, large enough for every slab to have work, with
 // tensors inside the 32-bit buffer range (MI355PPO_CONV_WGRAD=t: never -- kernel T, for A/B runs).
-bool convw_applies(int64_t images, int layer) {
+bool convw_applies(int64_t images, int layer, bool f16) {
     static const bool force_t = [] { const char* e = getenv("MI355PPO_CONV_WGRAD"); return e && e[0] == 't'; }();
     if (force_t || (layer != 2 && layer != 3) || images <= 0) return false;
     const long long P = images * (layer == 2 ? 81 : 49);
-    return images % 16 == 0 && P / 16 >= 4LL * convw_slabs(layer, convw_nt2()) &&
+    // (the slab count of the shape that would run: the f16 split's two-tile shape has more slabs -- with it asked for the bf16 path too, layer-3
+    //  batches of 224 .. 288 images fell to kernel T without reason)
+    return images % 16 == 0 && P / 16 >= 4LL * convw_slabs(layer, f16 && convw_nt2()) &&
            images * (layer == 2 ? 20 * 20 * 32 : 9 * 9 * 64) * 4 < (1LL << 32) - 8192 && P * 64 * 4 < (1LL << 32) - 8192;
 }
 
 // partials kernel V writes for this batch (0: it does not take it) -- the workspace of mi355ppo_cnn_conv_wgrad_* must hold that many
-int convw_parts(int64_t images, int layer) { return convw_applies(images, layer) ? convw_slabs(layer, convw_nt2()) : 0; }
+int convw_parts(int64_t images, int layer) { return convw_applies(images, layer) ? convw_slabs(layer, convw_nt2()) : 0; }      // (the larger count: sizes the workspace)
 
 // Launches kernel V if the batch qualifies; *nparts = partials written (part_w [nparts][64 * K], part_b [nparts][64]).
 // Returns 1 if it does not apply.
 int convw_launch(const float* src, const float* dz, float* part_w, float* part_b, int64_t images, int layer, int* nparts, hipStream_t s,
                  const unsigned* dz_amax, const unsigned* src_amax) {
-    if (!convw_applies(images, layer)) return 1;
+    if (!convw_applies(images, layer, dz_amax != nullptr)) return 1;
     const bool nt2 = dz_amax && convw_nt2();
     const int S = convw_slabs(layer, nt2);
     *nparts = S;

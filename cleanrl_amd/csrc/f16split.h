@@ -12,8 +12,9 @@
 // Where the scale comes from: every tensor that feeds a split carries an "amax record" -- kAmaxSlots uint32 slots 64 bytes apart
 // holding the bit pattern of max |x| (non-negative floats order like their bit patterns).  The kernel that PRODUCES the tensor
 // folds its epilogue values into the record (one atomic max per wave, spread over the slots by workgroup index; max is
-// order-independent, so the result is deterministic); the consumer reads the 16 slots and derives s.  The caller zeroes the
-// records before the producers run (one memset per forward / backward pass).  A record that UNDERSTATES the tensor's maximum
+// order-independent, so the result is deterministic); the consumer reads the 16 slots and derives s.  The caller zeroes the ACTIVATION /
+// GRADIENT records before the producers run (one fill kernel per forward / backward pass -- not a memset node: DESIGN 3.3); the WEIGHT tensors'
+// records are not accumulated at all: zabsmax_store_kernel (gemmz.hip) STORES every slot, 16 blocks per tensor, no zeroing, no atomics.  A record that UNDERSTATES the tensor's maximum
 // makes the f16 conversion overflow to infinity -- loud, never silently wrong.
 #pragma once
 #include "common.h"

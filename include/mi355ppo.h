@@ -613,6 +613,9 @@ MI355PPO_API int mi355ppo_fc_packed_kernel_f16x2(int M, int N, int K, int dgrad)
 MI355PPO_API int mi355ppo_cnn_conv_wgrad_f16x2_f32(const float* src, const float* dz, float* dW, float* db, int64_t images, int layer,
                                                    void* workspace, size_t workspace_bytes, const uint32_t* src_amax, const uint32_t* dz_amax,
                                                    void* stream);
+/* 'U', 'V', 'P' or 'T': the kernel the two f16x2 weight-gradient entry points run for this batch and layer (1..3) -- kernel U (csrc/convu.hip) while the
+ * tensors stay inside the 32-bit buffer range, else kernel V / P, else the f32-pipe kernel T (ABI 1.8.2; profiling aid: bench.py labels its rows with it). */
+MI355PPO_API int mi355ppo_cnn_conv_wgrad_kernel_f16x2(int64_t images, int layer);
 /* mi355ppo_cnn_conv_wgrad_f32 for layer 1 (kernel P) with dz in two f16 terms; the uint8 frames are exact f16 operands: only dz's record */
 MI355PPO_API int mi355ppo_cnn_conv1_wgrad_f16x2(const void* src_u8, const int64_t* inds, const float* dz, float* dW, float* db, int64_t images,
                                                 void* workspace, size_t workspace_bytes, const uint32_t* dz_amax, void* stream);

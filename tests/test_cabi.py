@@ -119,6 +119,31 @@ def test_cnn_and_heads_entry_points_validate_before_any_launch():
     assert lib.mi355ppo_synth_atari_step_u8(p, 0, p, 1, 1, p, p, p, 4, 0.01, 1, None) == -1
 
 
+def test_which_kernel_the_round_6_fc_and_weight_gradient_launches_take(monkeypatch):
+    """The host queries bench.py labels its rows with (round 6): kernel G for the FC forward from 16,384 rows / the bit-masked data gradient from
+    1,024; kernel H for the FC weight gradient from 8,192 rows; kernel U for every conv weight gradient that fits the 32-bit buffer range -- each
+    the launcher's own decision, with its switch read at every call."""
+    lib = _lib.load()
+    for name in ("MI355PPO_FC_G", "MI355PPO_FC_G_MIN", "MI355PPO_FC_H", "MI355PPO_FC_H_MIN", "MI355PPO_CONV_U", "MI355PPO_CONV_U1", "MI355PPO_CONV_U2"):
+        monkeypatch.delenv(name, raising=False)
+    g = lambda M, dgrad, N=512, K=3136: chr(lib.mi355ppo_fc_packed_kernel_f16x2(M, N, K, dgrad))
+    assert [g(M, 0) for M in (1024, 8192, 16383, 16384, 32768)] == ["Z", "Z", "Z", "G", "G"]
+    assert [g(M, 1, 3136, 512) for M in (128, 1023, 1024, 8192, 32768)] == ["Z", "Z", "G", "G", "G"]
+    assert g(32768, 0, 500, 3136) == "Z" and g(32768, 0, 512, 48) == "Z"                  # N % 32, K % 64: shapes kernel G does not take
+    h = lambda M: chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(M, 512, 3136))
+    assert [h(M) for M in (1000, 1024, 8191, 8192, 32768)] == ["Y", "W", "Y", "H", "H"] and chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(8192, 500, 3136)) == "Y"
+    u = lambda images, layer: chr(lib.mi355ppo_cnn_conv_wgrad_kernel_f16x2(images, layer))
+    assert [u(n, l) for n in (1, 256, 32768) for l in (1, 2, 3)] == ["U"] * 9
+    assert u(90000, 2) == "T" and u(90000, 1) == "P" and u(90000, 3) == "U" and lib.mi355ppo_cnn_conv_wgrad_kernel_f16x2(64, 4) == 0      # beyond 4 GiB: kernel U declines
+    monkeypatch.setenv("MI355PPO_FC_G", "0"); monkeypatch.setenv("MI355PPO_FC_H", "0"); monkeypatch.setenv("MI355PPO_CONV_U", "0")
+    assert g(32768, 0) == "Z" and g(32768, 1, 3136, 512) == "Z" and h(32768) == "W" and u(32768, 2) == "V" and u(32768, 1) == "P" and u(240, 3) == "V"
+    monkeypatch.setenv("MI355PPO_FC_G", "1"); monkeypatch.setenv("MI355PPO_FC_G_MIN", "1"); monkeypatch.setenv("MI355PPO_FC_H", "1"); monkeypatch.setenv("MI355PPO_FC_H_MIN", "1")
+    assert g(5, 0) == "G" and g(5, 1, 3136, 512) == "G" and h(5) == "H"
+    # kernel V's batch rule with the slab count of the shape that would run (round-5 advisor note): 224 .. 288 images of layer 3 stay on kernel V
+    # on the bf16 path (170 slabs); the f16 split's two-tile shape needs 227 slabs' worth
+    assert chr(lib.mi355ppo_cnn_conv_wgrad_kernel(240, 3)) == "V" and chr(lib.mi355ppo_cnn_conv_wgrad_kernel(208, 3)) == "T"
+
+
 def test_which_kernel_a_packed_f16x2_convolution_takes_is_a_host_side_decision(monkeypatch):
     """mi355ppo_cnn_conv_packed_kernel_f16x2 (gemmz.hip::conv_r_takes): kernel R (convr.hip) by default at every size except the
     layer-2 data gradient below 512 images; the switches of DESIGN 3.7 are read at every call."""
