@@ -136,7 +136,7 @@ def test_which_kernel_the_round_6_fc_and_weight_gradient_launches_take(monkeypat
     assert [u(n, l) for n in (1, 256, 32768) for l in (1, 2, 3)] == ["U"] * 9
     assert u(90000, 2) == "T" and u(90000, 1) == "P" and u(90000, 3) == "U" and lib.mi355ppo_cnn_conv_wgrad_kernel_f16x2(64, 4) == 0      # beyond 4 GiB: kernel U declines
     monkeypatch.setenv("MI355PPO_FC_G", "0"); monkeypatch.setenv("MI355PPO_FC_H", "0"); monkeypatch.setenv("MI355PPO_CONV_U", "0")
-    assert g(32768, 0) == "Z" and g(32768, 1, 3136, 512) == "Z" and h(32768) == "W" and u(32768, 2) == "V" and u(32768, 1) == "P" and u(240, 3) == "V"
+    assert g(32768, 0) == "Z" and g(32768, 1, 3136, 512) == "Z" and h(32768) == "W" and u(32768, 2) == "V" and u(32768, 1) == "P" and u(240, 3) == "T" and u(304, 3) == "V"
     monkeypatch.setenv("MI355PPO_FC_G", "1"); monkeypatch.setenv("MI355PPO_FC_G_MIN", "1"); monkeypatch.setenv("MI355PPO_FC_H", "1"); monkeypatch.setenv("MI355PPO_FC_H_MIN", "1")
     assert g(5, 0) == "G" and g(5, 1, 3136, 512) == "G" and h(5) == "H"
     # kernel V's batch rule with the slab count of the shape that would run (round-5 advisor note): 224 .. 288 images of layer 3 stay on kernel V
