@@ -309,7 +309,10 @@ class PPOLearner:
         bufs.cache_weights = True
         if not getattr(bufs, "_owned", False):
             bufs._owned = True
-            bufs.direct_grads = os.environ.get("MI355PPO_DIRECT_GRADS", "1") != "0"
+            # (the nodes OVERWRITE .grad instead of accumulating: only the plain learner's update -- one backward per zeroed gradient buffer -- may
+            #  ask for that; a subclass that overrides the forward / backward, e.g. an auxiliary phase with a second backward, keeps autograd's adds)
+            bufs.direct_grads = (type(self).forward_backward_hip is PPOLearner.forward_backward_hip
+                                 and os.environ.get("MI355PPO_DIRECT_GRADS", "1") != "0")
             if self._ar_early is not None:              # world > 1: the early bucket's all-reduce starts when its gradient is final
                 bufs.after_fc_wgrad = self._early_all_reduce
 
