@@ -320,7 +320,7 @@ def test_conv_weight_gradient_f16x2_against_float64(layer, images):
     assert torch.equal(dW, cnn.conv_wgrad(src, dz, layer, amax=(_rec_of(src), _rec_of(dz)))[0])
 
 
-@pytest.mark.parametrize("images,scale", [(8, 1.0), (300, 1e-6), (4096, 3e-4)])
+@pytest.mark.parametrize("images,scale", [(8, 1.0), (300, 1e-6), (4096, 3e-4), (8192, 1e-4)])      # (8,192: config D's minibatch -- the direct float64 bar behind the relaxed trajectory bar of tests/test_gpu_multirank.py)
 def test_conv1_weight_gradient_f16x2_against_float64(images, scale):
     """The layer-1 weight gradient of the f16 split (kernel U's layer-1 variant, csrc/convu.hip: one image per pass resident in LDS, the uint8
     frame as zero-extended 16-bit = exact f16 subnormals; MI355PPO_CONV_U1=0: kernel P) against float64 and against kernel P's three-term bf16
@@ -568,3 +568,29 @@ def test_trunk_autograd_under_f16x2_against_float64():
         if not (np.isfinite(err) and err <= 5e-5 * scale):
             bad.append(f"grad of {n}: err {err:.3e}, scale {scale:.3e}")
     assert not bad, "; ".join(bad)
+
+
+def test_kernels_r_and_g_equal_kernel_z_bit_for_bit_at_the_bench_size():
+    """Every tensor of one minibatch update at BASELINE configs[2]'s size (32,768 images) hashed on the torch-free driver (tools/conv_traffic:
+    order-independent 64-bit hash of the bit patterns) with kernels R / G switched off (kernel Z: the oracle kernel) and on (the default): the
+    forwards, the data gradients and -- fed by them -- every weight gradient must come out bit-identical.  (Round-5 review: this comparison
+    lived outside the suite.)"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "conv_traffic")
+    if not os.path.exists(exe):
+        pytest.skip("tools/conv_traffic not built (python -m cleanrl_amd.build)")
+
+    def hashes(extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MI355PPO_")}
+        env.update({"CONV_TRAFFIC_HASH": "1", "CONV_TRAFFIC_F16": "1"}, **extra)
+        out = subprocess.run([exe, "32768", "1"], cwd=root, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return dict(ln.split()[1:3] for ln in out.stdout.splitlines() if ln.startswith("hash "))
+
+    z = hashes({"MI355PPO_CONV_R": "0", "MI355PPO_FC_G": "0"})
+    d = hashes({})
+    assert len(z) >= 14 and set(z) == set(d)
+    assert z == d, {k: (z[k], d[k]) for k in z if z[k] != d[k]}
