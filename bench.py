@@ -849,10 +849,16 @@ def main():
             try:      # an auxiliary leg (worker processes, pinned shared memory): its failure must not cost the measured line
                 ov = host_env_bench.run(N, T, iters=2, groups=cli.pcie_env_groups, frame_delta=True, device=device)
                 se = host_env_bench.run(N, T, iters=1, groups=1, frame_delta=False, device=device)
+                # the same lanes with envs that cost (almost) nothing: what the PIPELINE sustains -- D2H of the actions, the workers' hand-off,
+                # H2D of the newest frames on the lanes' streams, the captured policy steps -- once the env cost is taken out
+                ce = host_env_bench.run(N, T, iters=2, groups=cli.pcie_env_groups, frame_delta=True, device=device, static_frames=True)
                 out["pcie_inclusive_sps"] = ov["sps"]
-                out["pcie_inclusive"] = {"overlapped": ov, "serial_reference_arrangement": se,
+                out["pcie_inclusive"] = {"overlapped": ov, "serial_reference_arrangement": se, "pipeline_ceiling_static_frames": ce,
+                                         "stand_in_env_step_us": host_env_bench.stand_in_step_us(N // cli.pcie_env_groups),
                                          "note": "whole PPO iterations with the envs on the host; not comparable with `value`, whose "
-                                                 "inputs are resident in HBM"}
+                                                 "inputs are resident in HBM.  `overlapped`: numpy stand-in envs (lane_step_us.env_wait_us is mostly the "
+                                                 "stand-in's own step, stand_in_env_step_us: materialising four-frame stacks with np.take); "
+                                                 "`pipeline_ceiling_static_frames`: the same lanes with envs that cost almost nothing"}
             except Exception as e:      # noqa: BLE001 -- reported in the line, loudly on stderr
                 print(f"bench.py: the PCIe-inclusive leg failed: {type(e).__name__}: {e}", file=sys.stderr)
                 out["pcie_inclusive_sps"] = None

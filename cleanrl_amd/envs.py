@@ -143,9 +143,13 @@ class SyntheticAtariVecEnv:
     """
 
     def __init__(self, num_envs: int, seed: int = 0, n_actions: int = 4, pool_planes: int = 2048, api: str = "gymnasium",
-                 done_p: float = 1.0 / 200.0, frames: int = 4, autoreset: str = "same_step"):
+                 done_p: float = 1.0 / 200.0, frames: int = 4, autoreset: str = "same_step", static_frames: bool = False):
         assert autoreset in ("same_step", "next_step")
         self.autoreset = autoreset
+        # static_frames: after the first observation a step leaves the caller's `out` buffer as it is (rewards / dones still drawn) -- an env
+        # that costs (almost) nothing, for measuring what the rollout PIPELINE itself sustains (tools/host_env_bench.py); materialising 256
+        # four-frame stacks is 0.65 of the stand-in's 0.9 ms per step (np.take of 7.2 MB), which says nothing about a real emulator
+        self.static_frames, self._static_filled = bool(static_frames), False
         self._pending = np.zeros(num_envs, bool)       # next_step mode: envs whose next call is their reset
         self.num_envs, self.api, self.done_p = num_envs, api, done_p
         self.single_observation_space = Box(0, 255, (frames, 84, 84), np.uint8)      # frames = 1: FrameStack(1) of ppo_atari_lstm.py:105
@@ -158,9 +162,12 @@ class SyntheticAtariVecEnv:
         self._win = np.arange(frames)[None, :]
 
     def _obs(self, out=None):
+        if self.static_frames and out is not None and self._static_filled:
+            return out
         idx = (self.cursor[:, None] + self._win) % len(self.planes)
         if out is not None:
             np.take(self.planes, idx, axis=0, out=out, mode="clip")     # (idx is in range; mode="raise" would buffer `out`)
+            self._static_filled = True
             return out
         return self.planes[idx]
 

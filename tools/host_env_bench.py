@@ -21,7 +21,7 @@ from cleanrl_amd.envs import SyntheticAtariVecEnv  # noqa: E402
 from cleanrl_amd.learner import PPOLearner  # noqa: E402
 
 
-def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, device=None, graphs=None, workers=None, pin=True):
+def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, device=None, graphs=None, workers=None, pin=True, static_frames=False):
     """PCIe-inclusive env-steps/s of the learner fed by HOST vector envs (numpy stand-ins on host threads): ``groups`` = 1 is
     the reference's serial arrangement (act -> D2H -> envs.step -> H2D of the full stacks), ``groups`` > 1 the overlapped
     env-group lanes of cleanrl_amd/pipeline.py.  Returns the dict that main() prints."""
@@ -33,10 +33,10 @@ def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, devic
     if workers:          # every group's vector env in its own process, frames through shared memory (cleanrl_amd/env_workers.py)
         from cleanrl_amd.env_workers import ProcessVecEnv
 
-        envs = split_env_groups(lambda g, n: ProcessVecEnv(("cleanrl_amd.envs", "SyntheticAtariVecEnv", dict(num_envs=n, seed=1 + g * n, api="gym"))),
-                                N, groups)
+        envs = split_env_groups(lambda g, n: ProcessVecEnv(("cleanrl_amd.envs", "SyntheticAtariVecEnv",
+                                                            dict(num_envs=n, seed=1 + g * n, api="gym", static_frames=static_frames))), N, groups)
     else:
-        envs = split_env_groups(lambda g, n: SyntheticAtariVecEnv(n, seed=1 + g * n, api="gym"), N, groups)
+        envs = split_env_groups(lambda g, n: SyntheticAtariVecEnv(n, seed=1 + g * n, api="gym", static_frames=static_frames), N, groups)
     torch.manual_seed(1)
     np.random.seed(1)
     agent = AtariAgent(envs[0]).to(dev)
@@ -82,7 +82,8 @@ def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, devic
     for e in envs:
         e.close()
     delta = roll.lanes[0].delta
-    return {"mode": f"host envs (numpy stand-ins{', one worker process per group' if workers else ''}) in {groups} env group(s): pinned uint8 staging, one stream + host thread per group"
+    kind = ", STATIC frames: an env that costs almost nothing -- the pipeline ceiling" if static_frames else ""
+    return {"mode": f"host envs (numpy stand-ins{kind}{', one worker process per group' if workers else ''}) in {groups} env group(s): pinned uint8 staging, one stream + host thread per group"
                     + (", newest-frame-only H2D" if delta else ", full-stack H2D") + (", captured lane steps" if graphs else "")
                     + (", one driver thread" + (", frames DMA'd from the workers' pinned shared memory" if pinned else "") if one_thread else ""),
             "num_envs": N, "num_steps": T, "iters": iters, "env_groups": groups, "sps": N * T * iters / el,
@@ -90,6 +91,21 @@ def run(num_envs=1024, num_steps=128, iters=2, groups=4, frame_delta=True, devic
             "host_env_ms_per_group": [t / iters * 1e3 for t in t_env], "update_ms": t_upd / iters * 1e3,
             "h2d_bytes_per_step": N * (7056 if delta else 28224),
             **({"lane_step_us": lane_step_us(roll.async_stats)} if one_thread else {})}
+
+
+def stand_in_step_us(n: int, reps: int = 50) -> float:
+    """Microseconds ONE step of the numpy stand-in takes for a group of n envs in this process (mostly np.take of n four-frame stacks): the
+    env cost inside `env_wait_us`, to be read beside it."""
+    env = SyntheticAtariVecEnv(n, seed=1, api="gym")
+    out = np.zeros((n, 4, 84, 84), np.uint8)
+    env.reset(out=out)
+    act = np.zeros(n, np.int64)
+    for _ in range(3):
+        env.step(act, out=out)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        env.step(act, out=out)
+    return (time.perf_counter() - t0) / reps * 1e6
 
 
 def lane_step_us(async_stats: dict) -> dict:
@@ -108,10 +124,11 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="eager lane steps (the arrangement before GroupedRollout.capture)")
     ap.add_argument("--no-pin", action="store_true", help="do not register the workers' shared memory as pinned host memory (stage through the lanes' buffers)")
     ap.add_argument("--no-workers", action="store_true", help="step every group's envs in the training process (threads only)")
+    ap.add_argument("--static-frames", action="store_true", help="envs that cost almost nothing (frames left as they are): the pipeline's own ceiling")
     a = ap.parse_args()
     for k in a.groups:
         print(json.dumps(run(a.num_envs, a.num_steps, a.iters, k, frame_delta=k > 1, graphs=False if a.no_graphs else None,
-                             workers=False if a.no_workers else None, pin=not a.no_pin)), flush=True)
+                             workers=False if a.no_workers else None, pin=not a.no_pin, static_frames=a.static_frames)), flush=True)
 
 
 if __name__ == "__main__":
