@@ -29,8 +29,8 @@ VARIANT_DGRAD2_CLASSES = 6
 QPACK_NUMEL = 33408 // 4            # mi355ppo_cnn_conv1q_pack_bytes() as f32 storage elements (kernel Q's integer-digit pack)
 VARIANT_Q = 6                       # layer-1 forward on the integer matrix pipe (csrc/conv1q.hip); Bt = the mode-4 pack
 _CONV_Z = os.environ.get("MI355PPO_CONV", "z") != "f"    # layers 2 / 3 forward + data gradients: kernel Z, or the f32-pipe kernel F
-_MASK_BITS = os.environ.get("MI355PPO_MASK_BITS", "1") != "0"   # ReLU masks travel to the data gradients as bits (0: as the f32 activations; A/B runs)
-_FUSED_PACKS = os.environ.get("MI355PPO_FUSED_PACKS", "1") != "0"   # all weight packs of the NatureCNN agent in one launch (0: the 13 launches; A/B runs)
+_MASK_BITS = True    # ReLU masks travel to the data gradients as bits (the A/B switch MI355PPO_MASK_BITS is gone since round 6: profiles/r03_mask_bits_ab.jsonl)
+_FUSED_PACKS = True   # all weight packs of the NatureCNN agent in one launch (the A/B switch MI355PPO_FUSED_PACKS is gone since round 6)
 BUF_LIMIT = (1 << 32) - 8192     # kernels Z / F address a tensor with 32-bit buffer offsets: larger tensors take kernel S (64-bit pointers)
 # Operand split of kernels Z / V / W (round 5): "f16x2" = two f16 terms per f32 under per-tensor power-of-two scales, three matrix
 # instructions per product (csrc/f16split.h); "bf16x3" = round 3's three bf16 terms, six instructions.  Read once per process.

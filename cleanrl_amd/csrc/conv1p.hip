@@ -311,10 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (lh == 0) part_b[(size_t)(blockIdx.x * 4 + wave) * 32 + li] = both;
 }
 
-static bool conv1p_zext() {
-    static const bool on = [] { const char* e = getenv("MI355PPO_P_ZEXT"); return !(e && e[0] == '0'); }();
-    return on;
-}
+static bool conv1p_zext() { return true; }      // (the conversion route behind MI355PPO_P_ZEXT=0 was an A/B switch of round 4: profiles/r04_*)
 
 // Launches kernel P; *partial_scale = the factor (beside 1 / 255) the reduction applies to its partial sums: 2^53 with the zero-extended
 // bf16 frame operand, 1 otherwise.  dz_amax (dz's amax record): the f16 variant.

@@ -19,7 +19,7 @@
 //     it at the top of the next group.
 // Eight or twelve waves per CU (the instances below RGeom); which row sits in which lane is a compile-time table that keeps the 16-lane groups of a
 // fragment read on 16 different bank slots (RRowTable).  What was measured on the way (each step bit-identical): profiles/
-// r05_tile_shape_experiments.txt; `MI355PPO_R_TRACE=1` prints workgroup 0's s_memtime stamps per phase and k-step.
+// r05_tile_shape_experiments.txt (the s_memtime stamps of round 5's MI355PPO_R_TRACE builds: profiles/r05_kernel_r_trace.txt; the stamp code is gone since round 6).
 // Accumulator layout and epilogue are kernel Z's (lane = channel, accumulator e = row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the tile):
 // a 4-byte store instruction writes two whole 128-byte lines.  (The transposed layout -- lane = pixel, sixteen channels per lane in four
 // 16-byte runs -- needs a quarter of the store instructions, but each touches 32 lines a quarter at a time: measured 300 - 480 cycles per
@@ -70,8 +70,6 @@ struct RArgs {
     int groups;
     const unsigned* a_amax;     // amax record of A
     unsigned* c_amax;           // amax record of C to fold into, or null
-    unsigned long long* trace;  // MI355PPO_R_TRACE=1 (diagnosis): s_memtime stamps of workgroup 0's phases, [group visit < 4][phase < 8][wave]
-    int trace_from;             // MI355PPO_R_TRACE=N > 1: the four visits from the workgroup's N-th on (steady state) instead of its first four
 };
 
 template <class RG, int EPI, bool SPREAD>
@@ -217,14 +215,6 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         __builtin_amdgcn_s_barrier();
     };
 
-    int visit = -a.trace_from;
-    auto stamp = [&](int phase) __attribute__((always_inline)) {
-        if (a.trace && blockIdx.x == 0 && visit >= 0 && visit < 4 && lane == 0) a.trace[(visit * 8 + phase) * NW + wave] = __builtin_amdgcn_s_memtime();
-    };
-    auto kstamp = [&](int which, int v) __attribute__((always_inline)) {      // visit 1, first and last wave: 0 top of the step, 1 operands requested, 2 matrix instructions issued
-        if (a.trace && blockIdx.x == 0 && visit == 1 && lane == 0 && (wave == 0 || wave == NW - 1))
-            a.trace[4 * 8 * NW + ((wave == 0 ? 0 : 3) + which) * 64 + v] = __builtin_amdgcn_s_memtime();
-    };
     constexpr bool kCarry = NSLOT % 2 == 0 && NSLOT >= 4;  // slots 0 and 1 of the next group travel in the sets across the group boundary
     r_f32x16 acc[MT][NTW];
     unsigned wm[NTW];                                  // R_MASKB*: lane L holds the mask word of slot row L of the wave's rows, per column tile
@@ -278,24 +268,19 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     auto group = [&](int grp) __attribute__((always_inline)) {
         const unsigned gbase = (unsigned)grp * kGroupC + (unsigned)joff(jg * NTW);      // (joff is additive over the waves' column-tile groups: static_assert below)
         const __amdgpu_buffer_rsrc_t rb_cur = rsrc_b_of(grp);
-        stamp(0);
         // every wave is done with the previous group's records and ring slots
         __syncthreads();
-        stamp(1);
         fill();
-        stamp(2);
         if constexpr (!kCarry) { load_slot(0); load_slot(1); }
         __builtin_amdgcn_sched_barrier(0);
         write_slot(0);
         load_slot(2);
         ring_barrier();
-        stamp(3);
         read_a(0, 0);
         read_b(0, 0);
 #pragma unroll
         for (int v = 0; v < RG::KSTEPS; ++v) {
             const int q = v & 1, slot = v / SS, h = v % SS;
-            kstamp(0, v);
             // the operands of step v + 1 are requested before the matrix instructions of step v go out (a wave cannot run ahead of the matrix
             // pipe: whatever is issued behind a step's MFMAs starts when they end)
             if (v + 1 < RG::KSTEPS) {
@@ -313,7 +298,6 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
             if (pre_lo(v + 1) > pre_lo(v)) prefetch(grp + gridDim.x, pre_lo(v), pre_lo(v + 1) - pre_lo(v));
             if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4)
                 if (v == RG::KSTEPS - 4) load_masks(gbase, rb_cur);      // this group's mask words, for its epilogue
-            kstamp(1, v);
             __builtin_amdgcn_sched_barrier(0);
             // hi hi, hi lo (weights), lo hi (pixels): kernel Z's order of the three term pairs, tiles innermost
 #pragma unroll
@@ -330,9 +314,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
                                                                            __builtin_bit_cast(s_f16x8, wb[q][j][pi == 1 ? 1 : 0]), acc[i][j], 0, 0, 0);
                     }
             __builtin_amdgcn_sched_barrier(0);
-            kstamp(2, v);
         }
-        stamp(4);
         // the group's values (kernel Z's epilogue orders: rows outermost for the masked gradients, tiles outermost for the forward's mask words)
         const __amdgpu_buffer_rsrc_t rc = rsrc_c_of(grp);
         if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
@@ -350,8 +332,6 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 #pragma unroll
                     for (int e = 0; e < 16; ++e) epi_elem(i, j, e, gbase, rc, rb_cur);
         }
-        stamp(5);
-        ++visit;
     };
 
     int grp = blockIdx.x;
@@ -363,7 +343,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     if (a.c_amax) amax_commit(a.c_amax, __float_as_uint(cmax), blockIdx.x * NW + (unsigned)wave, lane);
 }
 
-template <class RG, int EPI, int SPREAD_MODE = 0>      // 1: the prefetch spread over the k-loop unless MI355PPO_R_SPREAD=0 (the data gradients' small sources: measured +-0, not instantiated)
+template <class RG, int EPI, int SPREAD_MODE = 0>      // 1: the prefetch spread over the k-loop (the data gradients' small sources: measured +-0, not instantiated)
 static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
     RArgs a = a0;
     a.groups = (int)((a.images + RG::G - 1) / RG::G);
@@ -377,42 +357,8 @@ static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
         cus = n;
     }
     const int grid = a.groups < cus * RG::WGS ? a.groups : cus * RG::WGS;
-    static const bool tracing = getenv("MI355PPO_R_TRACE") != nullptr;
-    static unsigned long long* tbuf = nullptr;
-    if (tracing) {
-        if (!tbuf && hipMalloc(&tbuf, (4 * 8 * RG::NW + 6 * 64) * 8) != hipSuccess) tbuf = nullptr;
-        if (tbuf) (void)hipMemsetAsync(tbuf, 0, (4 * 8 * RG::NW + 6 * 64) * 8, s);
-        a.trace = tbuf;
-        a.trace_from = atoi(getenv("MI355PPO_R_TRACE")) > 1 ? atoi(getenv("MI355PPO_R_TRACE")) : 0;
-    }
-    // (MI355PPO_R_SPREAD=0: the forwards' prefetch two loads per step again -- same-box A/B runs; the results are bit-identical)
-    static const bool spread = [] { const char* e = getenv("MI355PPO_R_SPREAD"); return !(e && e[0] == '0'); }();
-    if constexpr (SPREAD_MODE != 0) {
-        if (spread) hipLaunchKernelGGL((r_kernel<RG, EPI, true>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
-        else hipLaunchKernelGGL((r_kernel<RG, EPI, false>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
-    } else {
-        hipLaunchKernelGGL((r_kernel<RG, EPI, false>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
-    }
-    if (tracing && tbuf) {
-        unsigned long long h[4 * 8 * RG::NW + 6 * 64];
-        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, tbuf, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-            const unsigned long long t0 = h[0];
-            fprintf(stderr, "[r_trace] %s groups=%d grid=%d (ticks since the first stamp; phases: 0 top, 1 past the barrier, 2 filled, 3 ring ready, 4 k-loop done, 5 stored)\n", what, a.groups, grid);
-            for (int v = 0; v < 4; ++v)
-                for (int w = 0; w < RG::NW; w += RG::NW - 1) {
-                    fprintf(stderr, "[r_trace]  visit %d wave %d:", v, w);
-                    for (int ph = 0; ph < 6; ++ph) fprintf(stderr, " %8lld", (long long)(h[(v * 8 + ph) * RG::NW + w] - t0));
-                    fprintf(stderr, "\n");
-                }
-            const unsigned long long* const ks = h + 4 * 8 * RG::NW;          // [wave 0 / last][top, operands requested, matrix instructions issued][k-step]
-            for (int w = 0; w < 2; ++w) {
-                fprintf(stderr, "[r_trace]  visit 1 %s wave, per k-step: top of the step since the k-loop's first stamp (+ until the operands of the next step are requested = ring barrier, ring writes, loads; + until the matrix instructions are issued):", w ? "last" : "first");
-                for (int v = 0; v < RG::KSTEPS; ++v)
-                    fprintf(stderr, " %lld(+%lld+%lld)", (long long)(ks[(3 * w) * 64 + v] - ks[0]), (long long)(ks[(3 * w + 1) * 64 + v] - ks[(3 * w) * 64 + v]), (long long)(ks[(3 * w + 2) * 64 + v] - ks[(3 * w + 1) * 64 + v]));
-                fprintf(stderr, "\n");
-            }
-        }
-    }
+    // (the forwards' prefetch is spread over the k-loop -- SPREAD_MODE 1; same-box A/B against two loads per step: profiles/r05_kernel_r_spread_ab.jsonl)
+    hipLaunchKernelGGL((r_kernel<RG, EPI, SPREAD_MODE != 0>), dim3((unsigned)grid), dim3(64 * RG::NW), 0, s, a);
     return check_launch(what);
 }
 

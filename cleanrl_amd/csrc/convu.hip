@@ -252,7 +252,7 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
 //     block rows are then one output line apart -- 20 dz records = 360 eight-byte chunks, and 4 frame rows = 4 * 90 slots = 360 chunks: 8 (mod
 //     32) each, the transpose reads are conflict-free -- and every address is (lane part) + (compile-time part of the step, tap row, read);
 //   * a column tile = one tap row ty: its 32 columns (tx, ci) are 32 contiguous halves of frame row 4 y + ty starting at slot 4 x.
-// Eight waves, one tap row each, two per SIMD (four waves with two tap rows each, one per SIMD: 682 us against 601; MI355PPO_U1_NW=4);
+// Eight waves, one tap row each, two per SIMD (four waves with two tap rows each, one per SIMD: 682 us against 601);
 // dW1 (32 x 256) stays in the accumulators across all images of the workgroup; 2 matrix instructions (dz hi, dz lo) per tile and k-step.  Partial sums carry 2^(e_dz - 24): removed on the way out; conv.hip's reduce applies 1 / 255.
 template <int NW_>
 struct UGeom1 {
@@ -465,13 +465,8 @@ int convu1_launch(const unsigned char* frames, const int64_t* inds, const float*
         cus = n < convu_max_parts() ? n : convu_max_parts();
     }
     const int grid = images < cus ? (int)images : cus;
-    const char* w = getenv("MI355PPO_U1_NW");
-    if (w && w[0] == '4')
-        hipLaunchKernelGGL((convu1_kernel<UGeom1<4>>), dim3((unsigned)grid), dim3(256), 0, s, frames, reinterpret_cast<const long long*>(inds), dz, part_w, part_b,
-                           (int)images, (unsigned)dzb, dz_amax);
-    else
-        hipLaunchKernelGGL((convu1_kernel<UGeom1<8>>), dim3((unsigned)grid), dim3(512), 0, s, frames, reinterpret_cast<const long long*>(inds), dz, part_w, part_b,
-                           (int)images, (unsigned)dzb, dz_amax);
+    hipLaunchKernelGGL((convu1_kernel<UGeom1<8>>), dim3((unsigned)grid), dim3(512), 0, s, frames, reinterpret_cast<const long long*>(inds), dz, part_w, part_b,
+                       (int)images, (unsigned)dzb, dz_amax);
     *nparts = grid;
     return 0;
 }

@@ -324,21 +324,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCCV, OCCV)
 }
 
 // f16 split: two tiles per wave, two waves per SIMD -- 8 / 9 wave groups: layer 3 740 -> 606 us, layer 2 872 -> 850 us at 32,768 images, layer 2
-// bit-identical (same slabs), profiles/r05_tile_shape_experiments.txt.  MI355PPO_V_NT2=0: round 3's one-wave shapes (A/B runs).
-static bool convw_nt2() {
-    static const bool on = [] { const char* e = getenv("MI355PPO_V_NT2"); return !(e && e[0] == '0'); }();
-    return on;
-}
+// bit-identical (same slabs), profiles/r05_tile_shape_experiments.txt.
+static bool convw_nt2() { return true; }
 static int convw_slabs(int layer, bool nt2 = false) {      // x 4 / x 6 wave groups = 1,024 / 1,020 waves (nt2: x 8 / x 9 = 2,048 / 2,043)
     if (nt2) return layer == 2 ? 256 : 227;
     return layer == 2 ? 256 : 170;
 }
 
 // Kernel V takes a batch of layer 2 / 3 that is a multiple of 16 images, large enough for every slab to have work, with
-// tensors inside the 32-bit buffer range (MI355PPO_CONV_WGRAD=t: never -- kernel T, for A/B runs).
+// tensors inside the 32-bit buffer range.
 bool convw_applies(int64_t images, int layer, bool f16) {
-    static const bool force_t = [] { const char* e = getenv("MI355PPO_CONV_WGRAD"); return e && e[0] == 't'; }();
-    if (force_t || (layer != 2 && layer != 3) || images <= 0) return false;
+    if ((layer != 2 && layer != 3) || images <= 0) return false;
     const long long P = images * (layer == 2 ? 81 : 49);
     // (the slab count of the shape that would run: the f16 split's two-tile shape has more slabs -- with it asked for the bf16 path too, layer-3
     //  batches of 224 .. 288 images fell to kernel T without reason)

@@ -410,11 +410,9 @@ static int fcw_slabs(int M) {
 
 using namespace mi355ppo;
 
-// kernel W takes this layer's shape at minibatch sizes (MI355PPO_FC_WGRAD=y: never -- kernel Y, for A/B runs); the operands'
-// alignment is checked at the launch
+// kernel W takes this layer's shape at minibatch sizes; the operands' alignment is checked at the launch
 static bool fcw_w_shape(int M, int N, int K) {
-    static const bool force_y = [] { const char* e = getenv("MI355PPO_FC_WGRAD"); return e && e[0] == 'y'; }();
-    return !force_y && N == 4 * kWn && K % kWk == 0 && M % 16 == 0 && M >= 1024 && (long long)M * K * 4 < (1LL << 32) - 8192;
+    return N == 4 * kWn && K % kWk == 0 && M % 16 == 0 && M >= 1024 && (long long)M * K * 4 < (1LL << 32) - 8192;
 }
 
 extern "C" MI355PPO_API size_t mi355ppo_fc_wgrad_workspace_bytes(int M, int N, int K) {

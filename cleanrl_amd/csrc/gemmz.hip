@@ -1036,14 +1036,8 @@ using namespace mi355ppo;
 
 // The convolutions share B through the workgroup's LDS ring (BLDS) from 2,048 images on; below, a launch is a single round of
 // workgroups and the ring's barriers cost what its saved L1 traffic buys (1,024 images: layer 3 forward 31.5 -> 33.8 us).
-// MI355PPO_Z_BLDS=0: every wave streams its own B fragments at every size (same-box A/B runs).  Read once.
-static bool z_blds(long long images) {
-    static const bool on = [] {
-        const char* e = getenv("MI355PPO_Z_BLDS");
-        return !(e && e[0] == '0');
-    }();
-    return on && images >= 2048;
-}
+// (Round 6: the same-box A/B switch MI355PPO_Z_BLDS is gone; profiles/r03_blds_ab.jsonl holds its runs.)
+static bool z_blds(long long images) { return images >= 2048; }
 
 static size_t zpack_bytes(int N, int K) { return (size_t)(K / 16) * (size_t)((N + 31) / 32) * kZTileBytes; }
 
@@ -1183,13 +1177,9 @@ __global__ __launch_bounds__(256) void zsplit_reduce_kernel(const float4* __rest
 static int zsplit_steps_per(int M, int N, int K) {
     const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
     const int total = K / 16;
-    static const int forced = [] { const char* e = getenv("MI355PPO_FC_SPLIT_WAVES"); return e ? atoi(e) : 0; }();      // (tuning runs)
-    int target = forced;
-    if (target <= 0) {
-        target = 2 * M;
-        if (target < 256) target = 256;
-        if (target > 1024) target = 1024;
-    }
+    int target = 2 * M;                                   // (tuning runs: profiles/r04_fcsplit_sweep.txt)
+    if (target < 256) target = 256;
+    if (target > 1024) target = 1024;
     long long want = (target + tiles - 1) / tiles;
     if (want < 1) want = 1;
     int per = (int)((total + want - 1) / want);
@@ -1200,8 +1190,8 @@ static int zsplit_steps_per(int M, int N, int K) {
 
 extern "C" MI355PPO_API size_t mi355ppo_fc_fwd_workspace_bytes(int M, int N, int K) {
     // Below 8,192 rows (round 3: 4,096) -- config B's minibatch of 4,096 rows is 512 whole-K wave tiles on 2,048 wave slots: two K splits
-    // 118 -> 79 us; at 8,192 rows a split buys nothing (134 vs 135 us; profiles/r04_fc_split_minibatch_ab.txt).  MI355PPO_FC_SPLIT_BELOW: A/B runs.
-    static const int below = [] { const char* e = getenv("MI355PPO_FC_SPLIT_BELOW"); return e ? atoi(e) : 8192; }();
+    // 118 -> 79 us; at 8,192 rows a split buys nothing (134 vs 135 us; profiles/r04_fc_split_minibatch_ab.txt).
+    constexpr int below = 8192;
     if (M <= 0 || N <= 0 || K <= 0 || K % 16 || M >= below) return 0;          // (from there on whole-K wave tiles: no workspace)
     const int per = zsplit_steps_per(M, N, K), splits = (K / 16 + per - 1) / per;
     return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
@@ -1331,9 +1321,7 @@ extern "C" MI355PPO_API int mi355ppo_fc_dgrad_maskbits_packed_f32(const float* d
 // mode 1 for the layer-3 data gradient (N = 64 input channels, K = (r, c, output channel), taps flipped), mode 2 for the
 // layer-2 data gradient (N = 4 stride-parity classes x 32 input channels, K = (r, c, output channel)).
 static bool conv_r_takes(long long images, int layer, bool dgrad) {      // which f16x2 launches kernel R (convr.hip) takes -- the one place that decides
-    static const char* const kOff[2][2] = {{"MI355PPO_CONV_R2F", "MI355PPO_CONV_R3F"}, {"MI355PPO_CONV_R2", "MI355PPO_CONV_R3"}};      // =0: this launch on kernel Z
-    const char* e = getenv(kOff[dgrad ? 1 : 0][layer - 2]);
-    return !(e && e[0] == '0') && convr_on(images, dgrad && layer == 2 ? 512 : 1);
+    return convr_on(images, dgrad && layer == 2 ? 512 : 1);      // (round 6: the per-launch switches MI355PPO_CONV_R2F / R3F / R2 / R3 are gone)
 }
 
 static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pack, const float* bias, float* dst, unsigned* bits,
@@ -1349,10 +1337,8 @@ static int conv_fwd_packed_impl(const char* fn, const float* src, const void* pa
     // Rollout-sized launches are a single, partly filled round of wave tiles, each walking all K / 16 k-steps: below 768 images 32-row
     // tiles (twice the waves, half the MFMAs per k-step) -- layer 2 / layer 3 at 256 images 23.4 -> 17.2 / 26.0 -> 18.5 us, at 128
     // images 22.3 -> 17.6 / 25.2 -> 17.8 us, bit-identical; at 1,024 images the 64-row tiles win (44.7 vs 50.9 us;
-    // profiles/r04_small_tiles_ab.txt).  MI355PPO_Z_SMALL_MT=2: 64-row tiles at every size (A/B runs).
-    static const int small_mt = [] { const char* e = getenv("MI355PPO_Z_SMALL_MT"); return e ? atoi(e) : 1; }();
-    static const long long small_below = [] { const char* e = getenv("MI355PPO_Z_SMALL_BELOW"); return e ? atoll(e) : 768LL; }();
-    const bool small = !bits && small_mt == 1 && images < small_below;
+    // profiles/r04_small_tiles_ab.txt).
+    const bool small = !bits && images < 768;
     if (layer == 2) {
         if (src_amax && conv_r_takes(images, 2, false))
             return convr_fwd2(fn, src, (unsigned)srcb, pack, bias, dst, (unsigned)((long long)images * 81 * 64 * 4), bits, images, src_amax, dst_amax, st);

@@ -36,7 +36,7 @@ import torch.optim as optim
 from . import host_ops
 
 
-_FUSED_ACT = os.environ.get("MI355PPO_FUSED_ACT", "1") != "0"      # A/B: the rollout step's FC fold + heads + sampling as one kernel
+_FUSED_ACT = True      # the rollout step's FC fold + heads + sampling as one kernel (the A/B switch MI355PPO_FUSED_ACT is gone since round 6)
 
 
 class PendingMetrics:
@@ -238,7 +238,7 @@ class PPOLearner:
         # collectives are skipped: the one-GPU test of the segmented capture against the single-graph slots)
         self._force_cut = os.environ.get("MI355PPO_UPDATE_GRAPH_CUT", "0") == "1"
         if (self.hip and (world_size > 1 or self._force_cut) and type(self).forward_backward_hip is PPOLearner.forward_backward_hip
-                and os.environ.get("MI355PPO_AR_OVERLAP", "1") != "0"):
+                ):      # (the A/B switch MI355PPO_AR_OVERLAP is gone since round 6: the early bucket always overlaps the conv backward)
             i = max(range(len(self.flat.segments)), key=lambda j: self.flat.segments[j][1])
             off, n = self.flat.segments[i]
             if n >= (1 << 18) and n * 2 > self.flat.numel:       # worth a launch of its own
@@ -304,15 +304,14 @@ class PPOLearner:
     def _own_trunk_buffers(self) -> None:
         """This learner owns the trunk's buffers: it bumps ``weights_version`` after every optimiser step (cached packs), and its
         flat gradient buffer is zeroed by the optimizer kernel before every backward, so the backward nodes may write parameter
-        gradients straight into the ``.grad`` views (``direct_grads``; MI355PPO_DIRECT_GRADS=0: through autograd's accumulation)."""
+        gradients straight into the ``.grad`` views (``direct_grads``)."""
         bufs = self.agent._trunk.bufs
         bufs.cache_weights = True
         if not getattr(bufs, "_owned", False):
             bufs._owned = True
             # (the nodes OVERWRITE .grad instead of accumulating: only the plain learner's update -- one backward per zeroed gradient buffer -- may
             #  ask for that; a subclass that overrides the forward / backward, e.g. an auxiliary phase with a second backward, keeps autograd's adds)
-            bufs.direct_grads = (type(self).forward_backward_hip is PPOLearner.forward_backward_hip
-                                 and os.environ.get("MI355PPO_DIRECT_GRADS", "1") != "0")
+            bufs.direct_grads = type(self).forward_backward_hip is PPOLearner.forward_backward_hip
             if self._ar_early is not None:              # world > 1: the early bucket's all-reduce starts when its gradient is final
                 bufs.after_fc_wgrad = self._early_all_reduce
 

@@ -148,15 +148,13 @@ def test_which_kernel_a_packed_f16x2_convolution_takes_is_a_host_side_decision(m
     """mi355ppo_cnn_conv_packed_kernel_f16x2 (gemmz.hip::conv_r_takes): kernel R (convr.hip) by default at every size except the
     layer-2 data gradient below 512 images; the switches of DESIGN 3.7 are read at every call."""
     lib = _lib.load()
-    for name in ("MI355PPO_CONV_R", "MI355PPO_CONV_R_MIN", "MI355PPO_CONV_R2F", "MI355PPO_CONV_R3F", "MI355PPO_CONV_R2", "MI355PPO_CONV_R3"):
+    for name in ("MI355PPO_CONV_R", "MI355PPO_CONV_R_MIN"):
         monkeypatch.delenv(name, raising=False)
     k = lambda images, layer, dgrad: chr(lib.mi355ppo_cnn_conv_packed_kernel_f16x2(images, layer, dgrad))
     assert [k(n, 2, 0) for n in (1, 256, 32768)] == ["R"] * 3 and [k(n, 3, 0) for n in (1, 256, 32768)] == ["R"] * 3
     assert [k(n, 3, 1) for n in (1, 32768)] == ["R", "R"]
     assert [k(n, 2, 1) for n in (1, 511, 512, 32768)] == ["Z", "Z", "R", "R"]
     assert k(0, 2, 0) == "Z" and k(64, 1, 0) == "Z" and k(64, 4, 1) == "Z"          # nothing kernel R could take
-    monkeypatch.setenv("MI355PPO_CONV_R3", "0")
-    assert k(4096, 3, 1) == "Z" and k(4096, 3, 0) == "R" and k(4096, 2, 1) == "R"
     monkeypatch.setenv("MI355PPO_CONV_R_MIN", "8192")
     assert k(4096, 3, 0) == "Z" and k(8192, 3, 0) == "R" and k(8192, 2, 1) == "R"
     monkeypatch.setenv("MI355PPO_CONV_R", "0")

@@ -258,7 +258,7 @@ def test_kernel_r_data_gradients_are_kernel_z_bit_for_bit(monkeypatch, layer, im
     pack = cnn.conv_zpack_f16x2(W, layer, cnn.MODE_DGRAD_S2 if layer == 2 else cnn.MODE_DGRAD_S1)
     rz = _rec_of(dz)
     out = {}
-    for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("R", {"MI355PPO_CONV_R": "1", "MI355PPO_CONV_R_MIN": "1", "MI355PPO_CONV_R3": "1"})):
+    for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("R", {"MI355PPO_CONV_R": "1", "MI355PPO_CONV_R_MIN": "1"})):
         for key, val in env.items():
             monkeypatch.setenv(key, val)
         rd = cnn.new_amax(1, DEV)[0]

@@ -13,4 +13,4 @@ for M in ${SIZES:-32768}; do for i in 1 2 3; do for mode in A B; do
 import json,sys
 j=json.loads(sys.stdin.read()); print('$mode', j['images'], ' '.join('%s %.1f' % (k[:-3], j[k]) for k in ('fwd2_us','fwd3_us','dgrad3_us','dgrad2_us','wgrad3_us','wgrad2_us','wgrad1_us','fwd1_us')), 'sum', j['sum_ms'])" | tee -a $O/ab.txt
 done; done; done
-if [ -n "${TRACE:-}" ]; then env $B MI355PPO_R_TRACE=$TRACE CONV_TRAFFIC_F16=1 timeout 120 tools/conv_traffic 32768 1 2>&1 >/dev/null | grep r_trace | awk '!seen[$0]++' | tee $O/trace.txt | cut -c1-400; fi
+
