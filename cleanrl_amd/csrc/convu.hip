@@ -114,7 +114,11 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
             return u < UG::SRC_UNITS ? (unsigned)((gi * UG::SRC_REC + UG::pidx(qy, qx)) * PIXS + q4 * 8) : ~0u;
         }
         const int v = (it - UG::NIS) * UG::THREADS + tid, q = v >> 4, gi = q / UG::OP, p = q - gi * UG::OP, y = p / UG::OW, x = p - y * UG::OW;
-        const int rec = UG::LW > 0 ? (gi * UG::OH + y) * UG::LW + x : q;
+        // LW > 0: line L = gi OH + y of the group; ODD lines are stored rotated by one record (pixel x in slot x + 1, the zero pad in slot 0), so that
+        // the source rows of a transpose-read block -- two of line L, two of line L + 1, read one record to the LEFT on odd lines -- sit 0, 4, 8, 12
+        // records apart (9 - 1 = 8 between the lines) = four different quarters of the 64 banks; unrotated they sat 0, 4, 9, 13 apart and the last
+        // row wrapped onto the first one's banks (tools/lds_conflicts_u.py: 2.00 -> 1.36 LDS cycles per pass; what is left: the image boundaries)
+        const int rec = UG::LW > 0 ? (gi * UG::OH + y) * UG::LW + (((gi * UG::OH + y) & 1) ? x + 1 : x) : q;
         return v < UG::DZ_UNITS ? (unsigned)(UG::SRCB + rec * PIXD + (v & 15) * 8) : ~0u;
     };
     auto prefetch = [&](int grp, int it) __attribute__((always_inline)) {        // units past the tensors (last group, groups past the end) load zeros
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
                 constexpr int OH = UG::OH;
                 const int L0 = 2 * s, L1 = 2 * s + 1;
                 const int rec0 = (L0 / OH) * UG::SRC_REC + (L0 % OH) * UG::SW, rec1 = (L1 / OH) * UG::SRC_REC + (L1 % OH) * UG::SW;
-                s0 = src_lane + (rline ? rec1 : rec0) * PIXS;
+                s0 = src_lane + (rline ? rec1 - 1 : rec0) * PIXS;      // (line 2 s + 1 is odd: its dz slots hold pixel x - 1 -- see unit_dst)
                 s1 = s0 + PIXS;
             } else {
                 s0 = src_lane + (origin[s] & 0xffffu) * PIXS;

@@ -21,6 +21,9 @@ def lanes():
         yield lane, g, i >> 2, i & 3, g >> 1          # lane, sixteen-lane group, block row r, column chunk c4, block half
 
 
+ROTATE = True      # round 6: dz's odd lines stored rotated by one record (convu.hip::unit_dst); False: round 5's layout (2.00 cycles per source pass)
+
+
 def layer3():
     SW, OH, PIX, SRC_REC, KSTEPS = 9, 7, 272, 81, 14      # UGeom3: a2 (9, 9, 64), dz3 (7, 7, 64) in lines padded to 8 records, 4 images
     dz = src = n_dz = n_src = 0
@@ -36,7 +39,7 @@ def layer3():
                         a = []
                         for _, g, r, c4, h in lanes():
                             L = 2 * s + (r >> 1)
-                            rec = (L // OH) * SRC_REC + (L % OH) * SW + 4 * (r & 1) + 2 * h + t + ty * SW + tx
+                            rec = (L // OH) * SRC_REC + (L % OH) * SW + 4 * (r & 1) + 2 * h + t + ty * SW + tx - (r >> 1 if ROTATE else 0)      # (round 6: odd lines one record to the left)
                             a.append(rec * PIX + (16 * (g & 1) + 4 * c4) * 2 + 64 * cpart + plane)
                         src += pass_cycles(a[:32]) + pass_cycles(a[32:]); n_src += 2
     return dz / n_dz, src / n_src
