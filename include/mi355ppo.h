@@ -32,11 +32,13 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 182 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 190 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2, 1.3: round 3;
                                   1.4: the *_cpu host-pointer twins; 1.5: mi355ppo_init; 1.6: round 4 -- the fused MLP family K7,
                                   mi355ppo_clip_adam_sched_f32; 1.7: mi355ppo_fc_heads_act_categorical_f32, mi355ppo_nature_packs_f32,
-                                  mi355ppo_synth_atari_step_hwc_ctr_u8; 1.8: round 5 -- the *_f16x2 / *_amax entry points and mi355ppo_absmax_f32); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
+                                  mi355ppo_synth_atari_step_hwc_ctr_u8; 1.8: round 5 -- the *_f16x2 / *_amax entry points and mi355ppo_absmax_f32;
+                                  1.9: round 6 -- the kernel queries mi355ppo_fc_packed_kernel_f16x2, mi355ppo_fc_wgrad_kernel_f16x2, mi355ppo_cnn_conv_wgrad_kernel_f16x2;
+                                  heads of up to 18 actions, a 4-byte-aligned critic row); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
 
 #if defined(__GNUC__)
 #define MI355PPO_API __attribute__((visibility("default")))
@@ -441,7 +443,7 @@ MI355PPO_API int mi355ppo_fc_dgrad_maskbits_packed_f32(const float* dz, int lddz
  * written in the reference's (c, h, w) order, i.e. directly as the gradient of Linear(3136,512).weight; 0: as computed. */
 MI355PPO_API size_t mi355ppo_fc_wgrad_workspace_bytes(int M, int N, int K);
 MI355PPO_API int mi355ppo_fc_wgrad_kernel(int M, int N, int K);      /* 'W' or 'Y': the kernel a call of this shape runs (profiling aid) */
-/* 'H', 'W' or 'Y': the kernel mi355ppo_fc_wgrad_f16x2_f32 runs for this shape with a dense dz (ABI 1.8.2).  Kernel H (csrc/gemmh.hip, round 6)
+/* 'H', 'W' or 'Y': the kernel mi355ppo_fc_wgrad_f16x2_f32 runs for this shape with a dense dz (ABI 1.9).  Kernel H (csrc/gemmh.hip, round 6)
  * streams both operands through a workgroup-wide LDS ring, split once, fragments by LDS transpose reads; from 8,192 rows on. */
 MI355PPO_API int mi355ppo_fc_wgrad_kernel_f16x2(int M, int N, int K);
 MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
@@ -606,7 +608,7 @@ MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(const float* dz, const
  * gradient at every size and the layer-2 data gradient from 512 images on; its results are kernel Z's bit for bit (same products, same order). */
 MI355PPO_API int mi355ppo_cnn_conv_packed_kernel_f16x2(int64_t images, int layer, int dgrad);
 /* 'G' or 'Z': the kernel mi355ppo_fc_fwd_relu_packed_f16x2_f32 without a K split (dgrad = 0) / mi355ppo_fc_dgrad_packed_f16x2_f32 with mask
- * bits (dgrad = 1) runs for this shape (ABI 1.8.2).  Kernel G (csrc/gemmg.hip, round 6) streams both operands through workgroup-wide LDS
+ * bits (dgrad = 1) runs for this shape (ABI 1.9).  Kernel G (csrc/gemmg.hip, round 6) streams both operands through workgroup-wide LDS
  * rings, A split once per workgroup; its results are kernel Z's bit for bit (same products, same order). */
 MI355PPO_API int mi355ppo_fc_packed_kernel_f16x2(int M, int N, int K, int dgrad);
 /* mi355ppo_cnn_conv_wgrad_f32 for layers 2 / 3 (kernel V); other batches fall to the f32-pipe kernel and ignore the records */
@@ -614,7 +616,7 @@ MI355PPO_API int mi355ppo_cnn_conv_wgrad_f16x2_f32(const float* src, const float
                                                    void* workspace, size_t workspace_bytes, const uint32_t* src_amax, const uint32_t* dz_amax,
                                                    void* stream);
 /* 'U', 'V', 'P' or 'T': the kernel the two f16x2 weight-gradient entry points run for this batch and layer (1..3) -- kernel U (csrc/convu.hip) while the
- * tensors stay inside the 32-bit buffer range, else kernel V / P, else the f32-pipe kernel T (ABI 1.8.2; profiling aid: bench.py labels its rows with it). */
+ * tensors stay inside the 32-bit buffer range, else kernel V / P, else the f32-pipe kernel T (ABI 1.9; profiling aid: bench.py labels its rows with it). */
 MI355PPO_API int mi355ppo_cnn_conv_wgrad_kernel_f16x2(int64_t images, int layer);
 /* mi355ppo_cnn_conv_wgrad_f32 for layer 1 (kernel P) with dz in two f16 terms; the uint8 frames are exact f16 operands: only dz's record */
 MI355PPO_API int mi355ppo_cnn_conv1_wgrad_f16x2(const void* src_u8, const int64_t* inds, const float* dz, float* dW, float* db, int64_t images,
