@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 IMAGES = 32768
 # the newest passes over the committed kernel set (tools/gpu/r5_final.sh; CONV_TRAFFIC_F16=1: the default split)
-FETCH_CSV, WRITE_CSV = "r05_pmc_fetch.csv", "r05_pmc_write.csv"
+FETCH_CSV, WRITE_CSV = "r06_pmc_fetch.csv", "r06_pmc_write.csv"      # round 6: tools/gpu/r6_final.sh (kernels G / H on the FC layer)
 KEYS = {   # bench key -> (kernel-name substring, geometry substring) in rocpd_pmc.py's (truncated) kernel names
     "conv1_fwd": ("conv1q_fwd_kernel", ""),
     "conv2_fwd": [("z_kernel", "ZRowsConv<20, 20, 32, 4, 4, 9, 9, 2, 0,"), ("r_kernel", "RGeom<20, 20, 0, 4, 4, 9, 9,")],
@@ -24,9 +24,9 @@ KEYS = {   # bench key -> (kernel-name substring, geometry substring) in rocpd_p
     "conv1_wgrad": [("conv1p_wgrad_kernel", ""), ("convu1_kernel", "")],
     "conv2_wgrad": [("convw_bf16_kernel", "VGeom<20, 20, 32,"), ("convu_kernel", "UGeom<20, 20, 32,")],      # (kernel U, csrc/convu.hip, replaces V / P under the f16 split)
     "conv3_wgrad": [("convw_bf16_kernel", "VGeom<9, 9, 64,"), ("convu_kernel", "UGeom<9, 9, 64,")],
-    "fc_fwd": ("z_kernel", "ZRowsLinear, 2, 4, 4, 0, true"),
-    "fc_dgrad": ("z_kernel", "ZRowsLinear, 2, 4, 4, 3, false"),     # epilogue 3 = ReLU-backward from mask bits
-    "fc_wgrad": ("fcw_", ""),                         # kernel W + the sum of its slab partials
+    "fc_fwd": [("z_kernel", "ZRowsLinear, 2, 4, 4, 0, true"), ("g_kernel<0>", "")],      # (round 6: kernel G, csrc/gemmg.hip)
+    "fc_dgrad": [("z_kernel", "ZRowsLinear, 2, 4, 4, 3, false"), ("g_kernel<1>", "")],     # epilogue 3 / <1> = ReLU-backward from mask bits
+    "fc_wgrad": [("fcw_bf16", ""), ("h_kernel", "")],      # kernel W / kernel H (csrc/gemmh.hip) -- without the partial reduce
 }
 ALGORITHMIC = {   # bytes per image the algorithm must move (inputs read once + outputs written once); the ReLU masks travel as bits
     # (1/32 of the activation's bytes): written by the forward that produces the activation, read by the data gradient above it
@@ -45,7 +45,7 @@ def load(name):
 
 def main():
     fetch, write = load(FETCH_CSV), load(WRITE_CSV)
-    out = {"source": f"profiles/{FETCH_CSV}, profiles/{WRITE_CSV} (tools/gpu/r5_final.sh): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over CONV_TRAFFIC_F16=1 tools/conv_traffic 32768 3",
+    out = {"source": f"profiles/{FETCH_CSV}, profiles/{WRITE_CSV} (tools/gpu/r6_final.sh -> tools/gpu/r6_pmc.sh): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over CONV_TRAFFIC_F16=1 tools/conv_traffic 32768 3",
            "correction": "bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950: 128-byte read requests tallied at 64 bytes)",
            "calibration_fetch_KiB_for_1GiB_read": {k[:40]: v for k, v in fetch.items() if "calib" in k},
            "calibration_write_KiB_for_1GiB_write": {k[:40]: v for k, v in write.items() if "calib" in k},
