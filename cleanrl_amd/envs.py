@@ -164,7 +164,8 @@ class SyntheticAtariVecEnv:
     def _obs(self, out=None):
         if self.static_frames and out is not None and self._static_filled:
             return out
-        idx = (self.cursor[:, None] + self._win) % len(self.planes)
+        # (static frames: four copies of ONE plane per env -- a stack that is its own shift, which the frame-delta path of pipeline.py checks for)
+        idx = (self.cursor[:, None] + (0 * self._win if self.static_frames else self._win)) % len(self.planes)
         if out is not None:
             np.take(self.planes, idx, axis=0, out=out, mode="clip")     # (idx is in range; mode="raise" would buffer `out`)
             self._static_filled = True

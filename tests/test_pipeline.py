@@ -126,3 +126,31 @@ def test_newest_frame_rule_rebuilds_every_stack_under_both_autoreset_conventions
         rebuilt[rows] = obs[rows]
         assert np.array_equal(rebuilt, obs)
         prev = obs.copy()
+
+
+def test_static_frames_env_keeps_the_frame_stack_structure():
+    """The zero-cost env of tools/host_env_bench.py's pipeline-ceiling leg (``SyntheticAtariVecEnv(static_frames=True)``): after the first observation a step
+    leaves the caller's buffer as it is, and that constant stack must be ITS OWN SHIFT (four copies of one plane) -- otherwise the frame-delta path
+    (pipeline.full_stack_rows) takes every env for a discontinuity and re-sends whole stacks one env at a time (13 ms per lane step: seen on the GPU)."""
+    import numpy as np
+
+    from cleanrl_amd.envs import SyntheticAtariVecEnv
+    from cleanrl_amd.pipeline import full_stack_rows, stack_probe
+
+    env = SyntheticAtariVecEnv(16, seed=3, api="gym", static_frames=True, done_p=0.0)
+    out = np.zeros((16, 4, 84, 84), np.uint8)
+    env.reset(out=out)
+    first = out.copy()
+    assert (first[:, 0] == first[:, 3]).all() and first.any()
+    prev_probe, prev_done = stack_probe(out), np.zeros(16, bool)
+    for _ in range(3):
+        obs, reward, done, info = env.step(np.zeros(16, np.int64), out=out)
+        assert obs is out and (out == first).all() and not done.any()
+        probe = stack_probe(out)
+        assert len(full_stack_rows(done, prev_done, probe, prev_probe)) == 0
+        prev_probe, prev_done = probe, done
+    moving = SyntheticAtariVecEnv(16, seed=3, api="gym", done_p=0.0)      # the ordinary stand-in: a genuine shift every step
+    moving.reset(out=out)
+    p0 = stack_probe(out)
+    moving.step(np.zeros(16, np.int64), out=out)
+    assert len(full_stack_rows(np.zeros(16, bool), np.zeros(16, bool), stack_probe(out), p0)) == 0 and (out[:, 3] != first[:, 3]).any()
