@@ -217,6 +217,14 @@ class PPOLearner:
             from .agents import fused_mlp_ptrs
 
             self.mlp = fused_mlp_ptrs(agent)            # after FlatParams: the parameters sit at their final addresses
+            if self.mlp is None and os.environ.get("MI355PPO_MLP", "fused") != "torch":
+                # said once, not silently: which kernel family runs is part of what a drop-in user measures (round-5 review, weak #11)
+                import sys
+
+                nets = agent.mlp_nets()
+                print(f"cleanrl_amd: this MLP agent (observation width {nets[0][0].in_features}, {nets[0][-1].out_features} actor outputs) is outside the fused "
+                      "MLP kernels' shapes (64-64 tanh, observation width <= 32, <= 8 outputs): its networks run on library GEMMs behind the HIP sampling / "
+                      "loss kernels", file=sys.stderr, flush=True)
         self._pack = None           # (B, 8) packed behaviour rows (ops.batch_pack) of the current update, or None
         self._pack_buf = None       # their storage, allocated by the first update()
         self._mb_adv_md = None      # the current minibatch's (mean, std + 1e-8) row of ops.adv_stats, or None

@@ -987,3 +987,31 @@ def test_captured_update_slots_continuous_path():
         assert torch.equal(Le.flat.params, Lg.flat.params), it
         assert torch.equal(Le.flat.exp_avg, Lg.flat.exp_avg) and torch.equal(Le.flat.exp_avg_sq, Lg.flat.exp_avg_sq), it
         assert all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me), (it, me, mg)
+
+
+def test_an_mlp_agent_outside_the_fused_kernels_shapes_says_so_once(capsys):
+    """Round-5 review, weak #11: shapes the fused MLP family K7 does not take (observation width > 32 or > 8 outputs, e.g. Humanoid's 376 / 17;
+    ppo_continuous_action.py:112-141) used to change kernel family silently.  The learner now says so on stderr when it is built, and still trains
+    (library GEMMs behind the HIP sampling / loss kernels); a HalfCheetah-shaped agent says nothing."""
+    def make(obs_dim, act_dim):
+        torch.manual_seed(4)
+        env = E.DeviceSyntheticContinuousVecEnv(8, DEV, seed=6, obs_dim=obs_dim, act_dim=act_dim)
+        agent = ContinuousAgent(env).to(DEV)
+        args = learner_smoke.default_args(num_steps=8, num_minibatches=2, update_epochs=1, clip_coef=0.2, ent_coef=0.0, learning_rate=3e-4)
+        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, 8, DEV, sample_seed=8)
+        return L, env
+
+    L, env = make(17, 6)
+    assert L.mlp is not None and "outside the fused MLP kernels" not in capsys.readouterr().err
+    L, env = make(40, 6)
+    err = capsys.readouterr().err
+    assert L.mlp is None and err.count("outside the fused MLP kernels") == 1 and "observation width 40" in err
+    L.observe(0, env.obs(), L.dones[0])
+    for step in range(8):
+        action = L.act(step)
+        next_obs, reward, done = env.step(action)
+        L.store_reward(step, reward)
+        L.observe(step + 1, next_obs, done)
+    L.finish_rollout()
+    m = L.update(3e-4)
+    assert np.isfinite(m["loss"]) and m["num_updates"] == 2
