@@ -470,8 +470,9 @@ def main():
     update_mode = "eager launches"
     use_update_graphs = not cli.no_update_graphs and learner.fused_cnn
     if use_update_graphs:
-        # one policy for every training loop (learner.update_graph_policy): graphs on one GPU and over gloo; over RCCL the eager update unless
-        # MI355PPO_UPDATE_GRAPHS=1 (then: capture, a captured-vs-eager self-check, and ALL ranks agree on the outcome through one MIN all-reduce)
+        # one policy for every training loop (learner.update_graph_policy / early_bucket_policy): graphs on one GPU and over gloo; over RCCL graphs in
+        # the reference's arrangement (one all-reduce behind the backward) behind a captured-vs-eager self-check, ALL ranks agreeing on the outcome
+        # through one MIN all-reduce; MI355PPO_UPDATE_GRAPHS=1 adds the early bucket, =0 is the eager update
         from cleanrl_amd.learner import update_graph_policy
 
         policy = update_graph_policy(world)
@@ -479,14 +480,19 @@ def main():
         if world == 1 and policy != "off" and not use_update_graphs:
             raise RuntimeError("bench.py: the update-graph capture failed on one GPU (see stderr): that is a defect, not a fallback case")
         if use_update_graphs and world > 1:
-            update_mode = ("per (epoch, minibatch) slot three hipGraphs with the gradient exchange between them: [forward + fused loss + backward to the "
-                           "FC weight's gradient] | all-reduce of that bucket, asynchronous | [conv backward] | all-reduce of the rest | [clip + Adam] "
-                           "(PPOLearner.capture_update); per-launch event brackets from an extra eager iteration after the timed region")
+            nseg = len(learner._update_graphs[0][0].segs)
+            update_mode = (("per (epoch, minibatch) slot three hipGraphs with the gradient exchange between them: [forward + fused loss + backward to the "
+                            "FC weight's gradient] | all-reduce of that bucket, asynchronous | [conv backward] | all-reduce of the rest | [clip + Adam] "
+                            if nseg == 3 else
+                            "per (epoch, minibatch) slot two hipGraphs with the gradient exchange between them (the reference's arrangement, "
+                            "ppo_atari_multigpu.py:358-377): [forward + fused loss + backward] | all-reduce of the flat gradient | [clip + Adam] ")
+                           + "(PPOLearner.capture_update" + ("; self-checked against one eager update before use" if policy == "capture+check" else "")
+                           + "); per-launch event brackets from an extra eager iteration after the timed region")
         elif use_update_graphs:
             update_mode = ("one hipGraph per (epoch, minibatch) slot: forward + fused loss + backward + clip + Adam (PPOLearner.capture_update); "
                            "per-launch event brackets from an extra eager iteration after the timed region")
         else:
-            update_mode = ("eager launches (the default over RCCL: MI355PPO_UPDATE_GRAPHS=1 opts in to graphs cut at the collectives)" if policy == "off"
+            update_mode = ("eager launches (MI355PPO_UPDATE_GRAPHS=0)" if policy == "off"
                            else "eager launches (update-graph capture or its self-check failed on a rank; see stderr)")
     elif not cli.no_update_graphs:
         update_mode = "eager launches (update graphs need the fused CNN kernels: MI355PPO_CNN=miopen)"
@@ -576,8 +582,8 @@ def main():
         ops.ppo_loss_categorical = timer.wrap("loss", real_loss)
         ops.ppo_loss_categorical_packed = timer.wrap("loss", real_loss_p)      # the learner's call: packed behaviour rows
 
-    if not cli.no_kernel_timing and not use_update_graphs:
-        install_timing_hooks()
+    # (The event brackets are NEVER installed inside the timed region -- round 6: with the eager update they were, and two event records per launch
+    #  made the host the bottleneck: 817 k instead of 1.3 M env-steps/s at config C.  They come from an extra iteration after it, below.)
     total_iters = cli.warmup + cli.steps
 
     phase_events = []
@@ -633,9 +639,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     timing_iters = cli.steps
-    if not cli.no_kernel_timing and use_update_graphs:
+    if not cli.no_kernel_timing:
         # the per-launch durations: one more iteration issued launch by launch with event brackets (outside the timed region; the
-        # same kernels on the same buffers as the replayed slots)
+        # same kernels on the same buffers as the replayed slots / the eager launches of the timed region)
         graphs, learner._update_graphs = learner._update_graphs, None
         install_timing_hooks()
         cli.sync_metrics, saved_sync = True, cli.sync_metrics
@@ -921,7 +927,7 @@ def main_continuous(cli, rank, world, device):
                            "two hipGraphs per (epoch, minibatch) slot with the all-reduce of the flat gradient between them: [fused MLP forward + loss + "
                            "backward, fold] | all-reduce | [clip + Adam] (PPOLearner.capture_update)")
         else:
-            update_mode = ("eager launches (the default over RCCL: MI355PPO_UPDATE_GRAPHS=1 opts in to graphs cut at the collectives)" if policy == "off"
+            update_mode = ("eager launches (MI355PPO_UPDATE_GRAPHS=0)" if policy == "off"
                            else "eager launches (update-graph capture or its self-check failed on a rank; see stderr)")
     timer = KernelTimer()
 
@@ -931,9 +937,7 @@ def main_continuous(cli, rank, world, device):
         ops.mlp_ppo_fwd_bwd = timer.wrap("mlp_ppo", ops.mlp_ppo_fwd_bwd)
         ops.clip_adam_ = timer.wrap("clip_adam", ops.clip_adam_)
 
-    if not cli.no_kernel_timing and not use_update_graphs:
-        install_timing_hooks()
-    total_iters = cli.warmup + cli.steps
+    total_iters = cli.warmup + cli.steps      # (event brackets: never inside the timed region, see main())
     phase_events = []
 
     def one_step(i):
@@ -973,7 +977,7 @@ def main_continuous(cli, rank, world, device):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    if not cli.no_kernel_timing and use_update_graphs:
+    if not cli.no_kernel_timing:
         graphs, learner._update_graphs = learner._update_graphs, None
         install_timing_hooks()
         one_step(total_iters - 1)          # (the eager path's first iteration allocates inside the brackets: not the one reported)

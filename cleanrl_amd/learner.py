@@ -99,22 +99,33 @@ class _SlotGraphs:
         segs[-1].replay()
 
 
+def _over_rccl(world_size: int) -> bool:
+    return world_size > 1 and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+
+
 def update_graph_policy(world_size: int) -> str:
     """What a training loop does about ``capture_update`` -- ONE place, shared by ``runner.train`` and ``bench.py``:
 
-    ``MI355PPO_UPDATE_GRAPHS`` = ``0``: never; ``1``: capture, at any world size; ``auto`` (the default): capture on one GPU and for
-    world > 1 over gloo (the backend of the CPU / one-GPU test runs); world > 1 over **nccl** (RCCL): the EAGER update.  Why: a slot's capture for
-    world > 1 is cut in the middle of an autograd backward, on the autograd engine's thread, beside the process group's watchdog thread
-    -- a path that has only ever run with several ranks on one GPU over gloo, and whose measured worth at config D's size is -0.6 ... +0 %
-    (profiles/r05_update_graphs_three_per_slot_ab.jsonl): not worth a hung multi-GPU job.  Returns "off", "capture" or "capture+check"
-    (opt-in over RCCL: capture, then ``PPOLearner.self_check_update_graphs`` before the graphs are trusted)."""
+    ``MI355PPO_UPDATE_GRAPHS`` = ``0``: never (eager launches); ``auto`` (the default) and ``1``: capture -- on one GPU and over gloo (the backend of the
+    CPU / one-GPU test runs) as it is; over **nccl (RCCL)**, which no build round could run, only behind ``PPOLearner.self_check_update_graphs`` (one update
+    from the graphs against one eager update from the same state: bit-identical or back to eager launches) and the all-ranks agreement.  What ``auto``
+    and ``1`` differ in over RCCL is the ARRANGEMENT (``early_bucket_policy``): ``auto`` keeps the reference's -- one all-reduce of the flat gradient behind
+    the whole backward (ppo_atari_multigpu.py:360-367), a slot = two graphs cut on the calling thread --, ``1`` adds the early bucket, whose cut falls in
+    the middle of the backward on the autograd engine's thread.  Why not simply eager over RCCL: at config C the eager update is host-bound on these boxes
+    (0.93 - 0.99 M against 1.31 M env-steps/s, profiles/r06_eager_vs_graphs_cfgC.txt).  Returns "off", "capture" or "capture+check"."""
     v = os.environ.get("MI355PPO_UPDATE_GRAPHS", "auto").strip().lower()
     if v in ("0", "off", "eager", "no"):
         return "off"
-    over_rccl = world_size > 1 and dist.is_initialized() and dist.get_backend() == "nccl"
-    if v in ("1", "on", "yes"):
-        return "capture+check" if over_rccl else "capture"
-    return "off" if over_rccl else "capture"
+    return "capture+check" if _over_rccl(world_size) else "capture"
+
+
+def early_bucket_policy(world_size: int) -> bool:
+    """Does the gradient exchange start early -- Linear(3136, 512).weight's gradient (95 % of the bytes) all-reduced asynchronously from a callback in
+    the middle of the backward, under the conv layers' backward (§6)?  Yes on gloo and with ``MI355PPO_UPDATE_GRAPHS=1``; over RCCL by default NO: the
+    reference's arrangement (one all-reduce behind the backward) keeps every collective and every capture begin / end on the calling thread for the
+    first runs on a multi-GPU node.  The exposed all-reduce of 6.75 MB is 0.1 - 0.25 ms per minibatch."""
+    v = os.environ.get("MI355PPO_UPDATE_GRAPHS", "auto").strip().lower()
+    return (not _over_rccl(world_size)) or v in ("1", "on", "yes")
 
 
 def all_ranks_agree(ok: bool, device: torch.device) -> bool:
@@ -246,7 +257,7 @@ class PPOLearner:
         # collectives are skipped: the one-GPU test of the segmented capture against the single-graph slots)
         self._force_cut = os.environ.get("MI355PPO_UPDATE_GRAPH_CUT", "0") == "1"
         if (self.hip and (world_size > 1 or self._force_cut) and type(self).forward_backward_hip is PPOLearner.forward_backward_hip
-                ):      # (the A/B switch MI355PPO_AR_OVERLAP is gone since round 6: the early bucket always overlaps the conv backward)
+                and early_bucket_policy(world_size)):      # (over RCCL by default: the reference's single all-reduce behind the backward)
             i = max(range(len(self.flat.segments)), key=lambda j: self.flat.segments[j][1])
             off, n = self.flat.segments[i]
             if n >= (1 << 18) and n * 2 > self.flat.numel:       # worth a launch of its own

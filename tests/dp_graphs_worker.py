@@ -19,10 +19,14 @@ from cleanrl_amd.agents import AtariAgent  # noqa: E402
 from cleanrl_amd.learner import PPOLearner  # noqa: E402
 
 
-def main(out_dir, N, T, nmb, epochs, iters):
+def main(out_dir, N, T, nmb, epochs, iters, no_early=False):
     rank, world = int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if no_early:         # the arrangement the policy chooses over RCCL: no early bucket -> one all-reduce behind the backward, two graphs per slot
+        import cleanrl_amd.learner as learner_mod
+
+        learner_mod.early_bucket_policy = lambda world_size: False
 
     def make(graphs):
         torch.manual_seed(4)                                    # same init on every rank (ppo_atari_multigpu.py:211)
@@ -38,6 +42,13 @@ def main(out_dir, N, T, nmb, epochs, iters):
     (Le, enve), (Lg, envg) = make(False), make(True)
     segs = sorted({len(s.segs) for row in Lg._update_graphs for s in row})
     early = all(s.early == Lg._ar_early and s.early is not None for row in Lg._update_graphs for s in row)
+    # the start-up check of the RCCL policy (PPOLearner.self_check_update_graphs): one captured against one eager update from the same state, state restored
+    before = Lg.flat.params.clone()
+    rng0 = np.random.get_state()[1][:4].copy()
+    checked = bool(Lg.self_check_update_graphs())
+    restored = bool(torch.equal(before, Lg.flat.params) and not Lg.flat.grads.any() and Lg.flat.step == 0 and np.array_equal(rng0, np.random.get_state()[1][:4]))
+    if no_early:         # (the eager twin issues the same single all-reduce: keep the twins' collectives in step)
+        assert Le._ar_early is None and Lg._ar_early is None
     same = [bool(torch.equal(Le.flat.params, Lg.flat.params) and not Lg.flat.grads.any())]
     scal = []
     for it in range(iters):
@@ -53,10 +64,11 @@ def main(out_dir, N, T, nmb, epochs, iters):
         scal.append(all(me[k] == mg[k] or (np.isnan(me[k]) and np.isnan(mg[k])) for k in me))
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), params=Lg.flat.params.cpu().numpy(), params_eager=Le.flat.params.cpu().numpy(),
-             same=np.array(same), scalars_same=np.array(scal), segs=np.array(segs), early=early, moved=float((Lg.flat.params != 0).float().mean()))
+             same=np.array(same), scalars_same=np.array(scal), segs=np.array(segs), early=early, moved=float((Lg.flat.params != 0).float().mean()),
+             self_check=checked, self_check_restored=restored)
     dist.barrier()
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], *(int(x) for x in sys.argv[2:7]))
+    main(sys.argv[1], *(int(x) for x in sys.argv[2:7]), no_early=len(sys.argv) > 7 and sys.argv[7] == "noearly")

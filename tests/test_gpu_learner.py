@@ -995,23 +995,22 @@ def test_an_mlp_agent_outside_the_fused_kernels_shapes_says_so_once(capsys):
     (library GEMMs behind the HIP sampling / loss kernels); a HalfCheetah-shaped agent says nothing."""
     def make(obs_dim, act_dim):
         torch.manual_seed(4)
-        env = E.DeviceSyntheticContinuousVecEnv(8, DEV, seed=6, obs_dim=obs_dim, act_dim=act_dim)
+        env = SimpleNamespace(single_observation_space=E.Box(-np.inf, np.inf, (obs_dim,), np.float32), single_action_space=E.Box(-1.0, 1.0, (act_dim,), np.float32))
         agent = ContinuousAgent(env).to(DEV)
         args = learner_smoke.default_args(num_steps=8, num_minibatches=2, update_epochs=1, clip_coef=0.2, ent_coef=0.0, learning_rate=3e-4)
-        L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, 8, DEV, sample_seed=8)
-        return L, env
+        return PPOLearner(agent, args, env.single_observation_space, env.single_action_space, 8, DEV, sample_seed=8)
 
-    L, env = make(17, 6)
+    L = make(17, 6)
     assert L.mlp is not None and "outside the fused MLP kernels" not in capsys.readouterr().err
-    L, env = make(40, 6)
+    L = make(40, 6)
     err = capsys.readouterr().err
     assert L.mlp is None and err.count("outside the fused MLP kernels") == 1 and "observation width 40" in err
-    L.observe(0, env.obs(), L.dones[0])
+    g = torch.Generator(device=DEV).manual_seed(1)
+    L.observe(0, torch.randn(8, 40, device=DEV, generator=g), L.dones[0])
     for step in range(8):
-        action = L.act(step)
-        next_obs, reward, done = env.step(action)
-        L.store_reward(step, reward)
-        L.observe(step + 1, next_obs, done)
+        L.act(step)
+        L.store_reward(step, torch.randn(8, device=DEV, generator=g))
+        L.observe(step + 1, torch.randn(8, 40, device=DEV, generator=g), torch.zeros(8, device=DEV))
     L.finish_rollout()
     m = L.update(3e-4)
     assert np.isfinite(m["loss"]) and m["num_updates"] == 2

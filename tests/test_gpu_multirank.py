@@ -129,9 +129,25 @@ def test_update_graphs_with_two_ranks_are_bit_identical_to_the_eager_two_rank_up
     r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in (0, 1))
     for r in (r0, r1):
         assert list(r["segs"]) == [3] and bool(r["early"]), "a slot was not cut at both bucket boundaries"
+        assert bool(r["self_check"]) and bool(r["self_check_restored"]), "the start-up self-check (captured vs eager update, state restored)"
         assert r["same"].all(), f"captured and eager learners diverged: {r['same']}"
         assert r["scalars_same"].all()
         assert np.array_equal(r["params"], r["params_eager"])
+    assert np.array_equal(r0["params"], r1["params"]), "the replicas diverged"
+
+
+def test_update_graphs_in_the_reference_arrangement_two_graphs_per_slot_self_checked(tmp_path):
+    """What ``learner.update_graph_policy`` / ``early_bucket_policy`` choose over RCCL by default (round 6), run here over gloo: NO early bucket -- the
+    reference's single all-reduce of the flat gradient behind the backward (ppo_atari_multigpu.py:360-367) --, so a slot is TWO graphs cut on the calling
+    thread; before use, ``self_check_update_graphs`` (one captured against one eager update from the same state and permutations, collectives included)
+    must report bit-identity and leave parameters, Adam state, gradients, step counter and numpy's stream as they were.  Then the usual: two ranks, each
+    with an eager twin, bit-equal after every iteration, replicas equal."""
+    _torchrun([os.path.join("tests", "dp_graphs_worker.py"), str(tmp_path), "32", "8", "2", "2", "2", "noearly"], timeout=1200)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in (0, 1))
+    for r in (r0, r1):
+        assert list(r["segs"]) == [2] and not bool(r["early"]), "the slots were not captured in the two-graph form"
+        assert bool(r["self_check"]) and bool(r["self_check_restored"])
+        assert r["same"].all() and r["scalars_same"].all() and np.array_equal(r["params"], r["params_eager"])
     assert np.array_equal(r0["params"], r1["params"]), "the replicas diverged"
 
 
@@ -237,8 +253,14 @@ def test_rccl_two_gpus_readiness_guard():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and "RCCL" in j["config"]["parallelism"] and np.isfinite(j["final_loss"]) and j["value"] > 0
-    assert j["collective_preflight"]["backend"] == "nccl" and "eager launches (the default over RCCL" in j["config"]["update"]
-    # opting in to the cut graphs over RCCL goes through the captured-vs-eager self-check and the all-ranks agreement: either outcome is a pass
+    upd = j["config"]["update"]
+    print("update over RCCL (default policy):", upd)
+    # the default over RCCL: two graphs per slot behind the self-check, or -- if the capture or the check failed on a rank -- everybody eager: both are a pass
+    assert j["collective_preflight"]["backend"] == "nccl" and ("two hipGraphs" in upd or "self-check failed on a rank" in upd), upd
+    # opting in to the early bucket (three graphs, the cut in the middle of the backward) goes through the same self-check and agreement
     env["MI355PPO_UPDATE_GRAPHS"] = "1"
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-3000:]
+    env["MI355PPO_UPDATE_GRAPHS"] = "0"
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "eager launches (MI355PPO_UPDATE_GRAPHS=0)" in out.stdout, out.stdout[-3000:] + "\n" + out.stderr[-3000:]

@@ -339,26 +339,29 @@ def test_whole_ppo_iteration_matches_the_reference_lines():
         torch.set_num_threads(n)
 
 
-def test_update_graph_policy_is_eager_over_rccl_unless_opted_in(monkeypatch):
-    """learner.update_graph_policy (round 6, the one place runner.train and bench.py ask): graphs on one GPU and over gloo; over nccl (RCCL)
-    the eager update unless MI355PPO_UPDATE_GRAPHS=1, which then also demands the captured-vs-eager self-check; 0 switches them off everywhere."""
+def test_update_graph_policy_over_rccl_is_self_checked_graphs_in_the_reference_arrangement(monkeypatch):
+    """learner.update_graph_policy / early_bucket_policy (round 6, the one place runner.train and bench.py ask): graphs on one GPU and over gloo as they
+    are; over nccl (RCCL) graphs only behind the captured-vs-eager self-check, and by default WITHOUT the early bucket (the reference's single all-reduce
+    behind the backward: every capture begin / end and every collective on the calling thread); MI355PPO_UPDATE_GRAPHS=1 opts in to the early bucket,
+    0 switches the graphs off everywhere."""
     import torch.distributed as dist
 
     from cleanrl_amd import learner as L
 
     monkeypatch.delenv("MI355PPO_UPDATE_GRAPHS", raising=False)
-    assert L.update_graph_policy(1) == "capture"
-    for backend, want_auto, want_on in (("gloo", "capture", "capture"), ("nccl", "off", "capture+check")):
+    assert L.update_graph_policy(1) == "capture" and L.early_bucket_policy(1)
+    for backend, want, early_auto in (("gloo", "capture", True), ("nccl", "capture+check", False)):
         monkeypatch.setattr(dist, "is_initialized", lambda: True)
         monkeypatch.setattr(dist, "get_backend", lambda b=backend: b)
         monkeypatch.delenv("MI355PPO_UPDATE_GRAPHS", raising=False)
-        assert L.update_graph_policy(8) == want_auto and L.update_graph_policy(1) == "capture"
+        assert L.update_graph_policy(8) == want and L.update_graph_policy(1) == "capture"
+        assert L.early_bucket_policy(8) is early_auto and L.early_bucket_policy(1)
         monkeypatch.setenv("MI355PPO_UPDATE_GRAPHS", "auto")
-        assert L.update_graph_policy(2) == want_auto
+        assert L.update_graph_policy(2) == want and L.early_bucket_policy(2) is early_auto
         monkeypatch.setenv("MI355PPO_UPDATE_GRAPHS", "1")
-        assert L.update_graph_policy(4) == want_on and L.update_graph_policy(1) == "capture"
+        assert L.update_graph_policy(4) == want and L.early_bucket_policy(4) and L.update_graph_policy(1) == "capture"
         monkeypatch.setenv("MI355PPO_UPDATE_GRAPHS", "0")
-        assert L.update_graph_policy(4) == "off" and L.update_graph_policy(1) == "off"
+        assert L.update_graph_policy(4) == "off" and L.update_graph_policy(1) == "off" and L.early_bucket_policy(4) is early_auto
 
 
 def test_all_ranks_agree_takes_every_rank_back_when_one_capture_failed():
