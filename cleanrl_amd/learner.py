@@ -637,16 +637,24 @@ class PPOLearner:
         if ok:
             try:
                 self.capture_update()
-                if policy == "capture+check":
-                    ok = self.self_check_update_graphs()
-                    if not ok:
-                        say("update graphs: the captured update did not reproduce the eager update's parameters on this rank; eager launches")
             except Exception as exc:      # noqa: BLE001 -- (capture_update restored the parameters, the Adam state and the zeroed gradients)
                 say(f"update graphs: capture failed ({type(exc).__name__}: {str(exc).splitlines()[0][:200] if str(exc) else ''}); eager launches")
                 ok = False
+        # agree on the CAPTURE first: the self-check below issues the update's collectives, so either every rank runs it or none does
         agreed = all_ranks_agree(ok, self.device)
         if ok and not agreed:
-            say("update graphs: another rank fell back to eager launches; this rank follows")
+            say("update graphs: another rank's capture failed; this rank follows it back to eager launches")
+        if agreed and policy == "capture+check":
+            try:
+                ok = self.self_check_update_graphs()
+            except Exception as exc:      # noqa: BLE001
+                say(f"update graphs: the self-check raised ({type(exc).__name__}: {str(exc).splitlines()[0][:200] if str(exc) else ''}); eager launches")
+                ok = False
+            if not ok:
+                say("update graphs: the captured update did not reproduce the eager update's parameters on this rank; eager launches")
+            agreed = all_ranks_agree(ok, self.device)
+            if ok and not agreed:
+                say("update graphs: another rank's self-check failed; this rank follows it back to eager launches")
         if not agreed:
             self._update_graphs = None
         return agreed

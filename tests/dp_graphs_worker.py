@@ -27,6 +27,7 @@ def main(out_dir, N, T, nmb, epochs, iters, no_early=False):
         import cleanrl_amd.learner as learner_mod
 
         learner_mod.early_bucket_policy = lambda world_size: False
+        learner_mod.update_graph_policy = lambda world_size: "capture+check"      # ... and the route bench.py / runner.train take there: capture_update_agreed
 
     def make(graphs):
         torch.manual_seed(4)                                    # same init on every rank (ppo_atari_multigpu.py:211)
@@ -35,7 +36,9 @@ def main(out_dir, N, T, nmb, epochs, iters, no_early=False):
         args = learner_smoke.default_args(num_steps=T, num_minibatches=nmb, update_epochs=epochs)
         L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, dev, world_size=world, sample_seed=8 + rank)
         L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
-        if graphs:
+        if graphs and no_early:
+            assert L.capture_update_agreed(), "capture, self-check and the all-ranks agreement (the RCCL policy's route, here over gloo)"
+        elif graphs:
             L.capture_update()
         return L, env
 
