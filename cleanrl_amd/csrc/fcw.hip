@@ -448,7 +448,7 @@ static int fc_wgrad_impl(const char* fn, const float* dz, int lddz, const float*
                   "%s: dz must be 8-byte, a and the workspace 16-byte aligned", fn);
     hipStream_t s = as_stream(stream);
     float* part = static_cast<float*>(workspace);
-    // round 6, f16 split: kernel H (gemmh.hip) from 8,192 rows on -- both operands through a workgroup-wide LDS ring, split once
+    // round 6, f16 split: kernel H (gemmh.hip) from 4,096 rows on -- both operands through a workgroup-wide LDS ring, split once
     if (dz_amax && a_amax && aligned(dz, 16) && gemmh_takes(M, N, K, lddz)) {
         int rch = gemmh_launch(dz, lddz, a, part, M, N, K, dz_amax, a_amax, s);
         if (rch) return rch;

@@ -444,7 +444,7 @@ MI355PPO_API int mi355ppo_fc_dgrad_maskbits_packed_f32(const float* dz, int lddz
 MI355PPO_API size_t mi355ppo_fc_wgrad_workspace_bytes(int M, int N, int K);
 MI355PPO_API int mi355ppo_fc_wgrad_kernel(int M, int N, int K);      /* 'W' or 'Y': the kernel a call of this shape runs (profiling aid) */
 /* 'H', 'W' or 'Y': the kernel mi355ppo_fc_wgrad_f16x2_f32 runs for this shape with a dense dz (ABI 1.9).  Kernel H (csrc/gemmh.hip, round 6)
- * streams both operands through a workgroup-wide LDS ring, split once, fragments by LDS transpose reads; from 8,192 rows on. */
+ * streams both operands through a workgroup-wide LDS ring, split once, fragments by LDS transpose reads; from 4,096 rows on. */
 MI355PPO_API int mi355ppo_fc_wgrad_kernel_f16x2(int M, int N, int K);
 MI355PPO_API int mi355ppo_fc_wgrad_f32(const float* dz, int lddz, const float* a, float* dW, int M, int N, int K, int hwc_channels,
                                        void* workspace, size_t workspace_bytes, void* stream);

@@ -121,7 +121,7 @@ def test_cnn_and_heads_entry_points_validate_before_any_launch():
 
 def test_which_kernel_the_round_6_fc_and_weight_gradient_launches_take(monkeypatch):
     """The host queries bench.py labels its rows with (round 6): kernel G for the FC forward from 16,384 rows / the bit-masked data gradient from
-    1,024; kernel H for the FC weight gradient from 8,192 rows; kernel U for every conv weight gradient that fits the 32-bit buffer range -- each
+    1,024; kernel H for the FC weight gradient from 4,096 rows; kernel U for every conv weight gradient that fits the 32-bit buffer range -- each
     the launcher's own decision, with its switch read at every call."""
     lib = _lib.load()
     for name in ("MI355PPO_FC_G", "MI355PPO_FC_G_MIN", "MI355PPO_FC_H", "MI355PPO_FC_H_MIN", "MI355PPO_CONV_U", "MI355PPO_CONV_U1", "MI355PPO_CONV_U2"):
@@ -131,7 +131,7 @@ def test_which_kernel_the_round_6_fc_and_weight_gradient_launches_take(monkeypat
     assert [g(M, 1, 3136, 512) for M in (128, 1023, 1024, 8192, 32768)] == ["Z", "Z", "G", "G", "G"]
     assert g(32768, 0, 500, 3136) == "Z" and g(32768, 0, 512, 48) == "Z"                  # N % 32, K % 64: shapes kernel G does not take
     h = lambda M: chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(M, 512, 3136))
-    assert [h(M) for M in (1000, 1024, 8191, 8192, 32768)] == ["Y", "W", "Y", "H", "H"] and chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(8192, 500, 3136)) == "Y"
+    assert [h(M) for M in (1000, 1024, 4095, 4096, 32768)] == ["Y", "W", "Y", "H", "H"] and chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(8192, 500, 3136)) == "Y"
     u = lambda images, layer: chr(lib.mi355ppo_cnn_conv_wgrad_kernel_f16x2(images, layer))
     assert [u(n, l) for n in (1, 256, 32768) for l in (1, 2, 3)] == ["U"] * 9
     assert u(90000, 2) == "T" and u(90000, 1) == "P" and u(90000, 3) == "U" and lib.mi355ppo_cnn_conv_wgrad_kernel_f16x2(64, 4) == 0      # beyond 4 GiB: kernel U declines

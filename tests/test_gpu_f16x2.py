@@ -361,7 +361,7 @@ def test_fc_weight_gradient_f16x2_against_float64(M):
 @pytest.mark.parametrize("M", [1000, 1024, 4096, 8192, 9008])
 def test_kernel_h_fc_weight_gradient_against_float64_and_kernel_w(monkeypatch, M):
     """Kernel H (csrc/gemmh.hip, round 6: both operands of Linear(3136, 512)'s weight gradient through a workgroup-wide LDS ring, split once,
-    fragments by LDS transpose reads; 8 slabs of contiguous rows; the default from 8,192 rows on) against float64 with kernel W's bar, against
+    fragments by LDS transpose reads; 8 slabs of contiguous rows; the default from 4,096 rows on) against float64 with kernel W's bar, against
     kernel W itself (another order of the same exact products), with a padded dz pitch, a batch that is not a multiple of the slot size, the
     (h, w, c) -> (c, h, w) column order, and run twice (deterministic)."""
     lib = cnn._lib.load()
@@ -384,7 +384,7 @@ def test_kernel_h_fc_weight_gradient_against_float64_and_kernel_w(monkeypatch, M
     chw = cnn.fc_wgrad(dz, a, 64, amax=(rz, ra))
     assert torch.equal(chw, got.view(512, 49, 64).permute(0, 2, 1).reshape(512, 3136))
     monkeypatch.delenv("MI355PPO_FC_H_MIN")
-    assert chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(M, 512, 3136)) == ("H" if M >= 8192 else ("W" if M % 16 == 0 and M >= 1024 else "Y"))
+    assert chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(M, 512, 3136)) == ("H" if M >= 4096 else ("W" if M % 16 == 0 and M >= 1024 else "Y"))
 
 
 @pytest.mark.parametrize("images", [5, 1024])
