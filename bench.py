@@ -481,7 +481,10 @@ def main():
             raise RuntimeError("bench.py: the update-graph capture failed on one GPU (see stderr): that is a defect, not a fallback case")
         if use_update_graphs and world > 1:
             nseg = len(learner._update_graphs[0][0].segs)
-            update_mode = (("per (epoch, minibatch) slot three hipGraphs with the gradient exchange between them: [forward + fused loss + backward to the "
+            update_mode = (("one hipGraph per (epoch, minibatch) slot with the gradient exchange INSIDE it: forward + fused loss + backward + the peer-memory all-reduce "
+                            "(five small launches over HIP IPC segments, csrc/dpcomm.hip; MI355PPO_ALLREDUCE=peer) + clip + Adam "
+                            if nseg == 1 else
+                            "per (epoch, minibatch) slot three hipGraphs with the gradient exchange between them: [forward + fused loss + backward to the "
                             "FC weight's gradient] | all-reduce of that bucket, asynchronous | [conv backward] | all-reduce of the rest | [clip + Adam] "
                             if nseg == 3 else
                             "per (epoch, minibatch) slot two hipGraphs with the gradient exchange between them (the reference's arrangement, "
@@ -675,8 +678,11 @@ def main():
                             "NatureCNN A=4, 4 epochs x 4 minibatches",
                 "baseline_config": cli.config,
                 "local_num_envs": N, "num_steps": T, "global_num_envs": world * N, "minibatch_rows": M,
-                "parallelism": f"dp{world} (one learner per GPU, RCCL all-reduce of the flat f32 gradient)" if not cli.same_device
-                               else f"dp{world} SAME-DEVICE PLUMBING SMOKE (all ranks on cuda:0, gloo): not a measurement",
+                "parallelism": (f"dp{world} (one learner per GPU, " + ("peer-memory all-reduce of the flat f32 gradient over HIP IPC segments (csrc/dpcomm.hip); RCCL for "
+                                                                         "the rendezvous and the timing only)" if getattr(learner, "_peer", None) is not None
+                                                                         else "RCCL all-reduce of the flat f32 gradient)")) if not cli.same_device
+                               else f"dp{world} SAME-DEVICE PLUMBING SMOKE (all ranks on cuda:0, gloo" + ("; gradients over HIP IPC segments" if getattr(learner, "_peer", None) is not None else "")
+                                    + "): not a measurement",
                 "env": "device-resident synthetic generator (no PCIe in the timed region)",
                 "rollout": (f"{len(learner._rollout_graphs)} hipGraph(s) of {-(-T // len(learner._rollout_graphs))} env step(s) each (policy "
                             "forward, sampling, env step, observation store)")

@@ -49,6 +49,12 @@ SIGNATURES = {
     "mi355ppo_clip_adam_f32": (
         c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, c_double, c_int64,
                 _P, _P, c_size_t, _P]),
+    "mi355ppo_dp_comm_create": (c_int, [c_int, c_int, c_int64, c_double, _P]),
+    "mi355ppo_dp_comm_handle": (c_int, [_P, _P]),
+    "mi355ppo_dp_comm_connect": (c_int, [_P, _P]),
+    "mi355ppo_dp_allreduce_sum_f32": (c_int, [_P, _P, c_int64, _P]),
+    "mi355ppo_dp_comm_status": (c_int, [_P, _P, _P, _P]),
+    "mi355ppo_dp_comm_destroy": (c_int, [_P]),
     "mi355ppo_cnn_repack_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "mi355ppo_cnn_conv_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "mi355ppo_cnn_conv_dgrad_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
@@ -139,7 +145,7 @@ SIGNATURES = {
     "mi355ppo_obs_u8_to_f32_cpu": (c_int, [_P, _P, _P, c_int64, c_int64, c_int]),
 }
 
-ABI_VERSION = 190       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 200       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

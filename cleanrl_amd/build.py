@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libmi355ppo.so")
-SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "optim.hip", "conv.hip", "convw.hip", "conv1q.hip", "conv1p.hip", "gemmz.hip", "gemmg.hip", "gemmh.hip", "convr.hip", "convu.hip", "fcw.hip", "heads.hip", "mlp.hip", "synth_env.hip", "host_twins.hip"]
+SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "optim.hip", "conv.hip", "convw.hip", "conv1q.hip", "conv1p.hip", "gemmz.hip", "gemmg.hip", "gemmh.hip", "convr.hip", "convu.hip", "fcw.hip", "heads.hip", "mlp.hip", "synth_env.hip", "dpcomm.hip", "host_twins.hip"]
 HEADERS = ["common.h", "catrow.h", "ppo_rows.h", "bf16split.h", "f16split.h", "convr_geom.h", os.path.join("..", "..", "include", "mi355ppo.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every f32 multiply/add rounds separately, as the reference's un-fused torch ops do.

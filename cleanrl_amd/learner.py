@@ -46,11 +46,14 @@ class PendingMetrics:
     def __init__(self, event, values, returns, scalars, host_last, num_updates):
         self._event, self._values, self._returns, self._scalars = event, values, returns, scalars
         self._host_last, self._k, self._out = host_last, num_updates, None
+        self.after_sync = None      # world > 1 over peer memory: PeerAllReduce.check (raises if a wait on a peer gave up during this update)
 
     def result(self) -> dict:
         if self._out is None:
             if self._event is not None:
                 self._event.synchronize()
+            if self.after_sync is not None:
+                self.after_sync()
             y_pred, y_true = self._values.numpy(), self._returns.numpy()      # :382-384
             var_y = np.var(y_true)
             explained_var = np.nan if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y
@@ -79,7 +82,7 @@ class _SlotGraphs:
 
     def replay(self, learner) -> None:
         segs = self.segs
-        if len(segs) == 1:
+        if len(segs) == 1:                  # world = 1, or world > 1 over peer memory: the exchange is five launches INSIDE the graph
             segs[0].replay()
             return
         g, multi = learner.flat.grads, learner.world_size > 1
@@ -256,8 +259,16 @@ class PPOLearner:
         # (MI355PPO_UPDATE_GRAPH_CUT=1: the bucket boundary -- and with it the cut of a captured slot -- also with world = 1, where the
         # collectives are skipped: the one-GPU test of the segmented capture against the single-graph slots)
         self._force_cut = os.environ.get("MI355PPO_UPDATE_GRAPH_CUT", "0") == "1"
+        # MI355PPO_ALLREDUCE=peer: the flat gradient is exchanged through HIP IPC segments by five small launches on the compute stream
+        # (dp_comm.PeerAllReduce, csrc/dpcomm.hip) instead of the process group's all-reduce: no early bucket, no cut -- a captured slot is one graph
+        self._peer = None
+        if self.hip and world_size > 1 and device.type == "cuda":
+            from .dp_comm import PeerAllReduce, exchange_policy
+
+            if exchange_policy(world_size) == "peer":
+                self._peer = PeerAllReduce(self.flat.numel, device)
         if (self.hip and (world_size > 1 or self._force_cut) and type(self).forward_backward_hip is PPOLearner.forward_backward_hip
-                and early_bucket_policy(world_size)):      # (over RCCL by default: the reference's single all-reduce behind the backward)
+                and self._peer is None and early_bucket_policy(world_size)):      # (over RCCL by default: the reference's single all-reduce behind the backward)
             i = max(range(len(self.flat.segments)), key=lambda j: self.flat.segments[j][1])
             off, n = self.flat.segments[i]
             if n >= (1 << 18) and n * 2 > self.flat.numel:       # worth a launch of its own
@@ -620,7 +631,10 @@ class PPOLearner:
             if on_gpu:
                 ev = torch.cuda.Event()
                 ev.record()
-            return PendingMetrics(ev, host[0], host[1], host[2], None, k)
+            pm = PendingMetrics(ev, host[0], host[1], host[2], None, k)
+            if self._peer is not None:
+                pm.after_sync = self._peer.check
+            return pm
         pm = PendingMetrics(None, b_values, b_returns, None, (last, clipfracs), k)
         pm.result()                     # CPU path: resolved at once (the handle holds views of buffers the next rollout overwrites)
         return pm
@@ -766,12 +780,14 @@ class PPOLearner:
                                       self._adam_sched[e * nmb + j], a.max_grad_norm, grad_scale=1.0 / self.world_size, eps=self.adam_eps,
                                       total_norm_out=self._total_norm)
 
-        def slot(e, j):                                                   # noqa: F811 -- forward/backward, then the optimizer step
+        def slot(e, j):                                                   # noqa: F811 -- forward/backward, (the peer-memory exchange,) the optimizer step
             slot_fb(e, j)
+            if self._peer is not None:
+                self._peer.all_reduce_sum_(self.flat.grads)
             slot_opt(e, j)
 
-        # world > 1: a slot is two or three graphs with the gradient exchange between them (_SlotGraphs)
-        segmented = self.world_size > 1 or self._force_cut
+        # world > 1 over the process group: a slot is two or three graphs with the gradient exchange between them (_SlotGraphs)
+        segmented = (self.world_size > 1 and self._peer is None) or self._force_cut
 
         state0 = [t.clone() for t in (self.flat.params, self.flat.exp_avg, self.flat.exp_avg_sq)]
         side = torch.cuda.Stream(device=dev)
@@ -946,7 +962,9 @@ class PPOLearner:
     def _minibatch_hip(self, idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, lr, scalars_out):
         self._ar_armed = self._ar_early is not None and self.world_size > 1
         self.forward_backward_hip(idx, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, scalars_out)
-        if self.world_size > 1:
+        if self._peer is not None:
+            self._peer.all_reduce_sum_(self.flat.grads)                   # :360-367 as five small launches on this stream (csrc/dpcomm.hip)
+        elif self.world_size > 1:
             g = self.flat.grads
             # Stream-ordering audit for the nccl (RCCL) backend -- every statement below was checked against
             # ProcessGroupNCCL's semantics, which differ from gloo's (gloo's wait() blocks the HOST; nccl's only orders streams):

@@ -32,13 +32,14 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 190 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 200 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2, 1.3: round 3;
                                   1.4: the *_cpu host-pointer twins; 1.5: mi355ppo_init; 1.6: round 4 -- the fused MLP family K7,
                                   mi355ppo_clip_adam_sched_f32; 1.7: mi355ppo_fc_heads_act_categorical_f32, mi355ppo_nature_packs_f32,
                                   mi355ppo_synth_atari_step_hwc_ctr_u8; 1.8: round 5 -- the *_f16x2 / *_amax entry points and mi355ppo_absmax_f32;
                                   1.9: round 6 -- the kernel queries mi355ppo_fc_packed_kernel_f16x2, mi355ppo_fc_wgrad_kernel_f16x2, mi355ppo_cnn_conv_wgrad_kernel_f16x2;
-                                  heads of up to 18 actions, a 4-byte-aligned critic row); a binding must check major AND minor (cleanrl_amd/_lib.py does) */
+                                  heads of up to 18 actions, a 4-byte-aligned critic row; 2.0: the peer-memory gradient exchange mi355ppo_dp_*);
+                                  a binding must check major AND minor (cleanrl_amd/_lib.py does) */
 
 #if defined(__GNUC__)
 #define MI355PPO_API __attribute__((visibility("default")))
@@ -57,6 +58,7 @@ extern "C" {
 #define MI355PPO_EALIGN (-2)     /* a pointer is not aligned to its element size               */
 #define MI355PPO_EHIP (-3)       /* a HIP runtime call / kernel launch failed                  */
 #define MI355PPO_EWORKSPACE (-4) /* workspace NULL or smaller than *_workspace_bytes()         */
+#define MI355PPO_ETIMEOUT (-5)   /* mi355ppo_dp_comm_status: a wait on a peer gave up          */
 
 MI355PPO_API int mi355ppo_version(void);
 MI355PPO_API const char* mi355ppo_last_error(void);
@@ -282,6 +284,38 @@ MI355PPO_API int mi355ppo_clip_adam_sched_f32(float* params, float* grads, float
                                               double grad_scale, double max_grad_norm, double beta1, double beta2, double eps,
                                               const float* sched2, float* total_norm_out, void* workspace, size_t workspace_bytes,
                                               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a9/e  The data-parallel gradient exchange over peer memory (csrc/dpcomm.hip): all_reduce(SUM) of the persistent flat gradient
+ * buffer across the ranks of ONE node without a collective library -- replaces dist.all_reduce(all_grads_list, op=SUM) of
+ * cleanrl/ppo_atari_multigpu.py:360-367 (the division by world_size of :368-374 stays grad_scale of mi355ppo_clip_adam_*).
+ * Every rank owns one device segment which its peers map through HIP IPC (xGMI between GPUs); a call is five small launches on
+ * `stream` -- publish, reduce slice `rank` of every rank's copy in rank order and push it to every rank, collect -- synchronised by
+ * flags in the segments.  No host round trip, no second stream: legal inside a hipGraph capture (the round counter lives on the
+ * device).  Every element is summed by one rank in one fixed order: all ranks receive the same bits.
+ *
+ * The communicator is the ONE object of this header that owns memory, so the conventions at the top hold for
+ * mi355ppo_dp_allreduce_sum_f32 only; create / handle / connect / destroy are set-up calls (they allocate, synchronise the device
+ * and must not run during a capture).  Set-up, on every rank, with the current HIP device = the rank's GPU:
+ *   mi355ppo_dp_comm_create(world, rank, max_floats, timeout_ms, &comm)     world <= MI355PPO_DP_MAX_WORLD
+ *   mi355ppo_dp_comm_handle(comm, handle)                                    MI355PPO_DP_HANDLE_BYTES bytes to send to every rank
+ *   ... the ranks exchange their handles (any host channel: the reference's process group, a file, a pipe) ...
+ *   mi355ppo_dp_comm_connect(comm, handles)                                  world x MI355PPO_DP_HANDLE_BYTES, in rank order
+ *   ... a host barrier: every rank has connected before the first exchange ...
+ * Every rank must then issue the same sequence of mi355ppo_dp_allreduce_sum_f32 calls (same n).  grads: (n) f32, 16-byte aligned,
+ * n <= max_floats; summed in place.  A wait on a peer gives up after timeout_ms (the peer died or skipped a call): the round, the
+ * peer and the phase (1 = reduce, 2 = collect) are recorded, every later wait of this communicator returns at once, and
+ * mi355ppo_dp_comm_status -- a HOST read, no synchronisation -- returns MI355PPO_ETIMEOUT from then on; grads then hold garbage and
+ * the communicator must be destroyed.  Ranks are processes: one communicator per process and rank. */
+#define MI355PPO_DP_MAX_WORLD 8
+#define MI355PPO_DP_HANDLE_BYTES 64
+typedef struct mi355ppo_dp_comm mi355ppo_dp_comm;
+MI355PPO_API int mi355ppo_dp_comm_create(int world, int rank, int64_t max_floats, double timeout_ms, mi355ppo_dp_comm** comm_out);
+MI355PPO_API int mi355ppo_dp_comm_handle(mi355ppo_dp_comm* comm, unsigned char* handle_out);
+MI355PPO_API int mi355ppo_dp_comm_connect(mi355ppo_dp_comm* comm, const unsigned char* handles);
+MI355PPO_API int mi355ppo_dp_allreduce_sum_f32(mi355ppo_dp_comm* comm, float* grads, int64_t n, void* stream);
+MI355PPO_API int mi355ppo_dp_comm_status(mi355ppo_dp_comm* comm, int* round_out, int* peer_out, int* phase_out);   /* outputs may be NULL */
+MI355PPO_API int mi355ppo_dp_comm_destroy(mi355ppo_dp_comm* comm);
 
 /* ---------------------------------------------------------------------------------------------
  * K7  The reference's MLP agents (two independent 64-64 tanh networks: actor and critic) as one kernel family (csrc/mlp.hip).

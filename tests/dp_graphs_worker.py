@@ -19,10 +19,13 @@ from cleanrl_amd.agents import AtariAgent  # noqa: E402
 from cleanrl_amd.learner import PPOLearner  # noqa: E402
 
 
-def main(out_dir, N, T, nmb, epochs, iters, no_early=False):
+def main(out_dir, N, T, nmb, epochs, iters, no_early=False, peer=False):
     rank, world = int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if peer:             # the flat gradient over HIP IPC segments (csrc/dpcomm.hip): gloo carries the handles and the agreement only; a slot is ONE graph
+        os.environ["MI355PPO_ALLREDUCE"] = "peer"
     if no_early:         # the arrangement the policy chooses over RCCL: no early bucket -> one all-reduce behind the backward, two graphs per slot
         import cleanrl_amd.learner as learner_mod
 
@@ -36,7 +39,8 @@ def main(out_dir, N, T, nmb, epochs, iters, no_early=False):
         args = learner_smoke.default_args(num_steps=T, num_minibatches=nmb, update_epochs=epochs)
         L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, dev, world_size=world, sample_seed=8 + rank)
         L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
-        if graphs and no_early:
+        assert (L._peer is not None) == peer
+        if graphs and (no_early or peer):
             assert L.capture_update_agreed(), "capture, self-check and the all-ranks agreement (the RCCL policy's route, here over gloo)"
         elif graphs:
             L.capture_update()
@@ -45,12 +49,19 @@ def main(out_dir, N, T, nmb, epochs, iters, no_early=False):
     (Le, enve), (Lg, envg) = make(False), make(True)
     segs = sorted({len(s.segs) for row in Lg._update_graphs for s in row})
     early = all(s.early == Lg._ar_early and s.early is not None for row in Lg._update_graphs for s in row)
+    if peer:
+        import cleanrl_amd.learner as learner_mod
+
+        def no_pg_all_reduce(*a, **k):     # from here on the gradients must not touch the process group (barriers / agreement flags still may)
+            raise AssertionError("dist.all_reduce called on the peer-memory route")
+        real_all_reduce = dist.all_reduce
+        learner_mod.dist.all_reduce = lambda t, *a, **k: real_all_reduce(t, *a, **k) if t.numel() <= 4 else no_pg_all_reduce()
     # the start-up check of the RCCL policy (PPOLearner.self_check_update_graphs): one captured against one eager update from the same state, state restored
     before = Lg.flat.params.clone()
     rng0 = np.random.get_state()[1][:4].copy()
     checked = bool(Lg.self_check_update_graphs())
     restored = bool(torch.equal(before, Lg.flat.params) and not Lg.flat.grads.any() and Lg.flat.step == 0 and np.array_equal(rng0, np.random.get_state()[1][:4]))
-    if no_early:         # (the eager twin issues the same single all-reduce: keep the twins' collectives in step)
+    if no_early or peer:         # (the eager twin issues the same single all-reduce: keep the twins' collectives in step)
         assert Le._ar_early is None and Lg._ar_early is None
     same = [bool(torch.equal(Le.flat.params, Lg.flat.params) and not Lg.flat.grads.any())]
     scal = []
@@ -68,10 +79,12 @@ def main(out_dir, N, T, nmb, epochs, iters, no_early=False):
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), params=Lg.flat.params.cpu().numpy(), params_eager=Le.flat.params.cpu().numpy(),
              same=np.array(same), scalars_same=np.array(scal), segs=np.array(segs), early=early, moved=float((Lg.flat.params != 0).float().mean()),
-             self_check=checked, self_check_restored=restored)
+             self_check=checked, self_check_restored=restored, peer_status_ok=bool(not peer or (Lg._peer.status() is None and Le._peer.status() is None)))
     dist.barrier()
+    if peer:
+        Lg._peer.close(); Le._peer.close()
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], *(int(x) for x in sys.argv[2:7]), no_early=len(sys.argv) > 7 and sys.argv[7] == "noearly")
+    main(sys.argv[1], *(int(x) for x in sys.argv[2:7]), no_early=len(sys.argv) > 7 and sys.argv[7] == "noearly", peer=len(sys.argv) > 7 and sys.argv[7] == "peer")

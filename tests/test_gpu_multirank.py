@@ -20,9 +20,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _torchrun(script_and_args, timeout=600, nproc=2):
+def _torchrun(script_and_args, timeout=600, nproc=2, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node", str(nproc), "--local-addr",
            "127.0.0.1"] + script_and_args
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
@@ -163,6 +164,67 @@ def test_update_graphs_with_four_ranks_are_bit_identical_to_the_eager_four_rank_
         assert np.array_equal(r["params"], rs[0]["params"]), "the replicas diverged"
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_memory_all_reduce_is_the_rank_order_sum_on_every_rank(tmp_path, world):
+    """The exchange that needs no collective library (round 6; include/mi355ppo.h a9/e, csrc/dpcomm.hip -- SURVEY 8b's second cut of the all-reduce
+    block ppo_atari_multigpu.py:360-367): 2 / 4 PROCESSES on one GPU, every rank's segment mapped by its peers through HIP IPC.  Checked bit for
+    bit against ((g0 + g1) + g2) + g3 in f32: 14 sizes from 1 float to the agent's 1,686,693 (partial vectors, slices shorter than a vector, guard
+    words untouched), 300 rounds back to back without a host synchronisation and with one rank held up at a time (the one-buffer protocol), the
+    call captured in a hipGraph and replayed 12 times with eager calls in between (the round counter lives on the device)."""
+    import json
+
+    _torchrun([os.path.join("tests", "dp_peer_worker.py"), str(tmp_path), "raw"], nproc=world, timeout=900)
+    rs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    for r, j in enumerate(rs):
+        bad = [n for n, ok in j["sizes"].items() if not ok]
+        assert not bad, f"rank {r}: sizes {bad} differ from the rank-order sum"
+        assert j["back_to_back"], f"rank {r}: a round of the back-to-back run differs"
+        assert j["graph_replays"], f"rank {r}: a replayed exchange differs"
+        assert j["status"] is None, f"rank {r}: a wait gave up: {j['status']}"
+    print(f"world {world}: {max(j['us_per_exchange_same_device'] for j in rs):.0f} us per exchange of 6.75 MB, all ranks on one device (no fabric)")
+
+
+def test_peer_memory_all_reduce_gives_up_on_a_missing_rank_instead_of_hanging(tmp_path):
+    """Rank 1 skips a call: rank 0's wait ends after the communicator's timeout (1.5 s here), the round / peer / phase are recorded in host-visible
+    memory, later calls on the broken communicator return at once and ``check()`` raises -- the device is never left spinning."""
+    import json
+
+    _torchrun([os.path.join("tests", "dp_peer_worker.py"), str(tmp_path), "timeout"], nproc=2, timeout=300)
+    r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in (0, 1))
+    assert r0["first_ok"] and r1["first_ok"]
+    assert r0["status"] is not None and r0["status"][0] == 2 and r0["status"][1] == 1 and r0["status"][2] == "reduce" and r0["raised"], r0
+    assert 1.0 < r0["waited_s"] < 10.0, r0
+    assert r1["status"] is None and not r1["raised"]
+
+
+def test_update_over_peer_memory_one_graph_per_slot_bit_identical_to_the_process_group_route(tmp_path):
+    """``MI355PPO_ALLREDUCE=peer`` in ``PPOLearner`` with world = 2: the flat gradient crosses HIP IPC segments by five small launches on the compute
+    stream, so a captured slot is ONE hipGraph with the exchange inside (the process group's all-reduce of the gradient is never called: the worker
+    makes it raise).  Each rank's captured learner against its eager twin after every iteration, the replicas against each other, the start-up
+    self-check -- and, because g0 + g1 is the same f32 sum whoever computes it, bit-identical parameters to the two-graph route over gloo from the
+    same seeds (ppo_atari_multigpu.py:358-377)."""
+    (tmp_path / "peer").mkdir(); (tmp_path / "pg").mkdir()
+    _torchrun([os.path.join("tests", "dp_graphs_worker.py"), str(tmp_path / "peer"), "32", "8", "2", "2", "2", "peer"], timeout=1200)
+    _torchrun([os.path.join("tests", "dp_graphs_worker.py"), str(tmp_path / "pg"), "32", "8", "2", "2", "2", "noearly"], timeout=1200)
+    r0, r1 = (np.load(tmp_path / "peer" / f"rank{r}.npz") for r in (0, 1))
+    for r in (r0, r1):
+        assert list(r["segs"]) == [1] and not bool(r["early"]), "a slot over peer memory is one graph"
+        assert bool(r["self_check"]) and bool(r["self_check_restored"]) and bool(r["peer_status_ok"])
+        assert r["same"].all() and r["scalars_same"].all() and np.array_equal(r["params"], r["params_eager"])
+        assert float(r["moved"]) > 0.9
+    assert np.array_equal(r0["params"], r1["params"]), "the replicas diverged"
+    assert np.array_equal(r0["params"], np.load(tmp_path / "pg" / "rank0.npz")["params"]), "peer-memory and process-group routes differ at world = 2"
+
+
+def test_update_over_peer_memory_with_four_ranks(tmp_path):
+    """The same at world = 4 (slices of a quarter, ((g0 + g1) + g2) + g3 on the owning rank): captured = eager on every rank, replicas bit-equal."""
+    _torchrun([os.path.join("tests", "dp_graphs_worker.py"), str(tmp_path), "16", "8", "2", "2", "2", "peer"], timeout=1200, nproc=4)
+    rs = [np.load(tmp_path / f"rank{r}.npz") for r in range(4)]
+    for r in rs:
+        assert list(r["segs"]) == [1] and r["same"].all() and r["scalars_same"].all() and bool(r["peer_status_ok"])
+        assert np.array_equal(r["params"], r["params_eager"]) and np.array_equal(r["params"], rs[0]["params"]), "the replicas diverged"
+
+
 def test_ppo_atari_multigpu_script_four_ranks_on_one_gpu():
     """The drop-in script with FOUR ranks on device 0 over gloo (ppo_atari_multigpu.py:166-177,360-377 at world = 4): replicas print the same
     actor weight sum after every update; under the default policy (gloo: graphs) every rank replays the cut graphs."""
@@ -176,6 +238,27 @@ def test_ppo_atari_multigpu_script_four_ranks_on_one_gpu():
     for it, by_rank in sums.items():
         assert len(by_rank) == 4 and len(set(by_rank.values())) == 1, f"replicas diverged at iteration {it}: {by_rank}"
     assert "eager launches" not in out, out[-2000:]
+
+
+def test_ppo_atari_multigpu_script_over_peer_memory_two_ranks_on_one_gpu():
+    """The drop-in script with ``MI355PPO_ALLREDUCE=peer``: nothing else changes on the command line (ppo_atari_multigpu.py:166-177 stays the
+    rendezvous); the replicas print the same actor weight sum after every update -- and the same sums as the process-group route (world = 2: the
+    same f32 additions)."""
+    args = [os.path.join("cleanrl_amd", "ppo_atari_multigpu.py"), "--cuda", "--backend", "gloo", "--device-ids", "0", "0",
+            "--local-num-envs", "4", "--num-steps", "8", "--num-envs", "8", "--total-timesteps", "192"]
+    pat = r"local_rank: (\d+), action\.sum\(\): (-?\d+), iteration: (\d+), agent\.actor\.weight\.sum\(\): (-?[\d.eE+-]+)"
+    by_route = {}
+    for route in ("peer", "pg"):
+        out = _torchrun(args, extra_env={"MI355PPO_ALLREDUCE": route})
+        sums = {}
+        for lr, a, it, w in re.findall(pat, out):
+            sums.setdefault(it, {})[lr] = w
+        assert len(sums) == 3, out[-2000:]
+        for it, by_rank in sums.items():
+            assert len(by_rank) == 2 and by_rank["0"] == by_rank["1"], f"{route}: replicas diverged at iteration {it}: {by_rank}"
+        assert "eager launches" not in out, out[-2000:]
+        by_route[route] = {it: v["0"] for it, v in sums.items()}
+    assert by_route["peer"] == by_route["pg"], by_route
 
 
 def test_ppo_atari_multigpu_script_two_ranks_on_one_gpu():
