@@ -877,6 +877,10 @@ def main():
                 out["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
+        if getattr(learner, "_peer", None) is not None:      # every rank is done with every segment before anybody unmaps / frees
+            torch.cuda.synchronize()
+            dist.barrier()
+            learner._peer.close()
         dist.destroy_process_group()
 
 
@@ -930,6 +934,8 @@ def main_continuous(cli, rank, world, device):
         if use_update_graphs:
             update_mode = ("one hipGraph per (epoch, minibatch) slot: fused MLP forward + loss + backward, fold, clip + Adam "
                            "(PPOLearner.capture_update); per-launch event brackets from an extra eager iteration after the timed region" if world == 1 else
+                           "one hipGraph per (epoch, minibatch) slot with the gradient exchange INSIDE it (five small launches over HIP IPC segments, csrc/dpcomm.hip; "
+                           "MI355PPO_ALLREDUCE=peer)" if getattr(learner, "_peer", None) is not None else
                            "two hipGraphs per (epoch, minibatch) slot with the all-reduce of the flat gradient between them: [fused MLP forward + loss + "
                            "backward, fold] | all-reduce | [clip + Adam] (PPOLearner.capture_update)")
         else:
@@ -1053,6 +1059,10 @@ def main_continuous(cli, rank, world, device):
                 }
         print(json.dumps(out), flush=True)
     if world > 1:
+        if getattr(learner, "_peer", None) is not None:      # every rank is done with every segment before anybody unmaps / frees
+            torch.cuda.synchronize()
+            dist.barrier()
+            learner._peer.close()
         dist.destroy_process_group()
 
 

@@ -168,7 +168,8 @@ def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: in
     # with world > 1 a slot is the graphs between its collectives (learner._SlotGraphs).  With host envs every env step synchronises on the actions, so the update starts with an empty GPU queue
     # and the host only microseconds ahead: ~55 launches per minibatch become one replay (MI355PPO_UPDATE_GRAPHS=0: eager).
     # Policy (MI355PPO_UPDATE_GRAPHS = auto | 0 | 1) and the all-ranks agreement live in ONE place: learner.update_graph_policy /
-    # PPOLearner.capture_update_agreed -- over RCCL the default is the eager update, and ranks never end up on different routes.
+    # PPOLearner.capture_update_agreed -- over RCCL the graphs are used only behind a captured-vs-eager self-check, and ranks never end up on different routes.
+    # (MI355PPO_ALLREDUCE=peer: the gradient exchange is five launches over HIP IPC segments inside the slot's one graph -- dp_comm.py.)
     if (learner.hip and type(learner) is PPOLearner and args.target_kl is None
             and getattr(agent, "rpo_alpha", None) is None and learner.batch_size % max(learner.minibatch_size, 1) == 0
             and (learner.fused_cnn or learner.mlp is not None)):
@@ -215,4 +216,8 @@ def train(args, envs, agent, device, writer, local_rank: int = 0, world_size: in
             print("SPS:", int(global_step / (time.time() - start_time)))
             writer.add_scalar("charts/SPS", int(global_step / (time.time() - start_time)), global_step)
     learner.last_metrics = metrics
+    if getattr(learner, "_peer", None) is not None:          # every rank is done with every segment before anybody unmaps / frees
+        torch.cuda.synchronize(learner.device)
+        torch.distributed.barrier()
+        learner._peer.close()
     return learner

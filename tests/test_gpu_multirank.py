@@ -317,6 +317,23 @@ def test_bench_multi_rank_legs_run_with_several_ranks_on_one_gpu(world):
         assert r.returncode == 2 and "refusing" in r.stderr
 
 
+def test_bench_two_ranks_over_peer_memory_on_one_gpu():
+    """``MI355PPO_ALLREDUCE=peer python bench.py --gpus 2 --same-device --backend gloo``: the line says which route ran -- one hipGraph per slot with
+    the exchange inside, gradients over HIP IPC segments -- and the run ends with a finite loss and no timeout."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MI355PPO_ALLREDUCE"] = "peer"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--same-device",
+           "--backend", "gloo", "--local-num-envs", "64", "--num-steps", "16", "--no-cpu-baseline", "--no-pcie-inclusive"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-3000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert "gradient exchange INSIDE" in j["config"]["update"] and "HIP IPC" in j["config"]["parallelism"], j["config"]
+    assert np.isfinite(j["final_loss"]) and j["value"] > 0
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the first multi-GPU box that runs this suite exercises RCCL")
 def test_rccl_two_gpus_readiness_guard():
     """The first time this suite runs on a box with >= 2 GPUs: ``bench.py --gpus 2`` over RCCL (backend nccl), one rank per GPU --
