@@ -59,6 +59,38 @@ def test_validation_errors_are_loud_and_precede_any_launch():
     assert lib.mi355ppo_obs_u8_to_f32(p, None, p, 4, 6, 1, None) == -1   # row_bytes % 4 != 0
 
 
+def test_peer_memory_exchange_entry_points_validate_and_fail_loudly_without_a_device(monkeypatch):
+    """``mi355ppo_dp_*`` (ABI 2.0, header section a9/e): argument checks come first; without a HIP device the communicator cannot be created -- a
+    negative status and a message, no crash, no CPU stand-in; the Python policy accepts exactly 'peer' and 'pg'."""
+    import torch
+
+    from cleanrl_amd import dp_comm
+
+    lib = _lib.load()
+    comm = ctypes.c_void_p()
+    for world, rank, n, tmo in ((0, 0, 16, 1e3), (9, 0, 16, 1e3), (2, 2, 16, 1e3), (2, -1, 16, 1e3), (2, 0, 0, 1e3), (2, 0, 16, 0.0)):
+        assert lib.mi355ppo_dp_comm_create(world, rank, n, tmo, ctypes.byref(comm)) == -1 and not comm.value
+    assert b"world in 1..8" in lib.mi355ppo_last_error()
+    assert lib.mi355ppo_dp_comm_create(2, 0, 16, 1e3, None) == -1
+    assert lib.mi355ppo_dp_comm_handle(None, None) == -1 and lib.mi355ppo_dp_comm_connect(None, None) == -1
+    assert lib.mi355ppo_dp_allreduce_sum_f32(None, None, 4, None) == -1
+    assert lib.mi355ppo_dp_comm_status(None, None, None, None) == -1
+    assert lib.mi355ppo_dp_comm_destroy(None) == 0
+    if not torch.cuda.is_available():
+        assert lib.mi355ppo_dp_comm_create(2, 0, 16, 1e3, ctypes.byref(comm)) == -3 and not comm.value
+        assert b"mi355ppo_dp_comm_create" in lib.mi355ppo_last_error()
+    assert dp_comm.MAX_WORLD == 8 and dp_comm.HANDLE_BYTES == 64
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mi355ppo.h")).read()
+    assert "#define MI355PPO_DP_MAX_WORLD 8" in hdr and "#define MI355PPO_DP_HANDLE_BYTES 64" in hdr
+    monkeypatch.delenv("MI355PPO_ALLREDUCE", raising=False)
+    assert dp_comm.exchange_policy(8) == "pg"
+    monkeypatch.setenv("MI355PPO_ALLREDUCE", "peer")
+    assert dp_comm.exchange_policy(8) == "peer" and dp_comm.exchange_policy(1) == "pg"
+    monkeypatch.setenv("MI355PPO_ALLREDUCE", "ring")
+    with pytest.raises(ValueError):
+        dp_comm.exchange_policy(2)
+
+
 def test_init_reports_a_box_without_a_device_loudly():
     """mi355ppo_init on this CPU-only box: no HIP device -> EHIP and a message; on the GPU box the same call is part of
     tests/test_gpu_kernels.py (0 for the MI355X, EINVAL for an ordinal out of range)."""
