@@ -1008,7 +1008,6 @@ static int launch_dgrad2_classes(const float* dz, const float* Bt, const float* 
     return launch_dgrad2_group<1, 1, 1, 1>(dz, Bt, act_in, dsrc, images, srcb, dstb, s);
 }
 
-// MI355PPO_CONV_CFG (tuning): 0 = MT 2 / 8 waves (default), 1 = MT 1 / 16 waves, 2 = MT 1 / 8 waves
 template <int NJT, bool U8IN, int EPI, bool PAD, bool CLS4 = false, int MT = 2>
 static int launch_stream(const void* src, const int64_t* inds, const float* Bt, const float* bias, const float* mask_src,
                          float* dst, const ConvGeom& g, hipStream_t s) {
