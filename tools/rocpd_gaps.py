@@ -1,41 +1,33 @@
-"""GPU idle time between consecutive kernels of a rocprofv3 rocpd database, per minibatch step of the update:
-python tools/rocpd_gaps.py <db>.  A step = from one `clip_adam_kernel` to the next; prints, for the steps whose length is
-within 3 % of the median, the mean wall time, kernel-busy time, idle time, launches, and the largest idle gaps by the
-kernel that FOLLOWS them."""
+"""GPU-side gaps of a rocprofv3 kernel trace (``*_results.db``): for every kernel, the idle time between the END of the previous dispatch (by start order)
+and its own START, summed per kernel name -- where a launch-bound stretch (the rollout's 8 small launches per env step) loses its time.
+    python tools/rocpd_gaps.py <db> [max_gap_us=200]     (gaps above max_gap_us -- host pauses between phases -- are left out)"""
 import sqlite3
-import statistics
 import sys
-from collections import defaultdict
 
 
 def main():
-    cur = sqlite3.connect(sys.argv[1]).cursor()
+    db, cap = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 200.0
+    cur = sqlite3.connect(db).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name = "name" if "name" in cols else "kernel_name"
     rows = cur.execute(f"select {name}, start, end from kernels order by start").fetchall()
-    marks = [i for i, r in enumerate(rows) if "clip_adam_kernel" in r[0]]
-    steps = []
-    for a, b in zip(marks[:-1], marks[1:]):
-        seg = rows[a + 1:b + 1]
-        wall = (seg[-1][2] - rows[a][2]) / 1e3
-        busy, gaps, prev_end = 0.0, [], rows[a][2]
-        for n, s, e in seg:
-            if s > prev_end:
-                gaps.append(((s - prev_end) / 1e3, n))
-            busy += (e - max(s, prev_end)) / 1e3 if e > prev_end else 0.0
-            prev_end = max(prev_end, e)
-        steps.append((wall, busy, gaps, len(seg)))
-    med = statistics.median(w for w, *_ in steps)
-    sel = [s for s in steps if abs(s[0] - med) < 0.03 * med]
-    print(f"{len(steps)} steps between optimizer kernels, median {med:.0f} us; {len(sel)} within 3 %")
-    print("mean wall %.0f us, busy %.0f us, idle %.0f us, launches %.0f" % tuple(statistics.mean(x) for x in zip(*[(s[0], s[1], s[0] - s[1], s[3]) for s in sel])))
-    by = defaultdict(list)
-    for s in sel:
-        for g, n in s[2]:
-            by[n[:90]].append(g)
-    print("idle before kernel (us per step, mean gap, count per step):")
-    for n, g in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:25]:
-        print("  %7.1f %6.1f %5.1f  %s" % (sum(g) / len(sel), statistics.mean(g), len(g) / len(sel), n))
+    acc = {}
+    prev_end = None
+    for n, s, e in rows:
+        if prev_end is not None:
+            gap = (s - prev_end) / 1e3
+            a = acc.setdefault(n[:80], [0, 0.0, 0.0, 0])
+            a[0] += 1
+            a[2] += (e - s) / 1e3
+            if 0.0 <= gap <= cap:
+                a[1] += gap
+            elif gap < 0.0:
+                a[3] += 1
+        prev_end = max(prev_end or e, e)
+    print("name,calls,gap_before_total_us,gap_before_avg_us,kernel_avg_us,overlapping_starts")
+    for n, (c, g, d, o) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:40]:
+        print('"%s",%d,%.1f,%.2f,%.2f,%d' % (n, c, g, g / c, d / c, o))
+    print('"TOTAL",%d,%.1f,,,' % (sum(a[0] for a in acc.values()), sum(a[1] for a in acc.values())))
 
 
 if __name__ == "__main__":
