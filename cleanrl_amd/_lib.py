@@ -145,7 +145,7 @@ SIGNATURES = {
     "mi355ppo_obs_u8_to_f32_cpu": (c_int, [_P, _P, _P, c_int64, c_int64, c_int]),
 }
 
-ABI_VERSION = 200       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
+ABI_VERSION = 210       # == MI355PPO_VERSION of include/mi355ppo.h this binding was written against (major*100 + minor*10 + patch)
 
 _lib = None
 

@@ -48,7 +48,7 @@ class _SampleCounter:
 
 def fused_mlp_ptrs(agent):
     """``(actor MlpNetPtrs, critic MlpNetPtrs)`` of an agent whose two networks the fused MLP kernels cover (64-64 tanh,
-    obs_dim <= 32, n_out <= 8, f32 on a HIP device), else None.  Rebuilt when the parameters moved (``.to()``, flat buffers)."""
+    obs_dim <= 512, n_out <= 20, f32 on a HIP device), else None.  Rebuilt when the parameters moved (``.to()``, flat buffers)."""
     import os
 
     if os.environ.get("MI355PPO_MLP", "fused") == "torch":       # A/B: keep the networks on library GEMMs

@@ -24,6 +24,12 @@
 // f32 v_fma throughout (the reference's MLP runs in f32 GEMMs whose summation order is unspecified): results agree with
 // torch to f32 round-off, tests/test_gpu_mlp.py.  No MFMA: at 64 x 64 the layer is 8 KFLOP per row -- the launch is bound by
 // latency, not by any pipe.
+//
+// WIDE variant (round 6: Humanoid's 376 observations / 17 actions, Ant-v2's 111 -- every agent of ppo_continuous_action.py): observation width
+// up to 512 and up to 20 outputs.  A row of W1 no longer fits the lane's registers, so layer 1 walks the observation in CHUNKS of 32 columns: the
+// lane loads 32 elements of its W1 row, adds their products with the chunk of every staged row (LDS broadcast reads) into one accumulator per row
+// (blocks of <= 32 rows), and moves on; the weight gradient of W1 does the same per chunk with 32 accumulators against the rows' dz1 (parked in H1's
+// LDS rows).  Everything behind layer 1 is the narrow code with AMAX = 20.  Shapes inside the narrow limits keep the narrow kernels.
 #include "common.h"
 #include "catrow.h"
 #include "ppo_rows.h"
@@ -80,6 +86,34 @@ __device__ __forceinline__ void stage_rows(float* xs, const float* __restrict__ 
     }
 }
 
+// WIDE: rows of runtime pitch OP (a multiple of 32, zero padded); a plain strided loop, eight loads in flight
+__device__ __forceinline__ void stage_rows_wide(float* xs, const float* __restrict__ obs, const int64_t* __restrict__ inds, int64_t row0, int nrows,
+                                                int O, int OP, int lane, float* scratch) {
+    int64_t* const ids = reinterpret_cast<int64_t*>(scratch);
+    if (inds) {
+        ids[lane] = lane < nrows ? inds[row0 + lane] : 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int total = nrows * OP;
+    for (int e0 = 0; e0 < total; e0 += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 64 * u + lane;
+            const int r = e / OP, k = e - r * OP;
+            const int rr = r < nrows ? r : 0;
+            const int64_t i = inds ? ids[rr] : row0 + rr;
+            v[u] = (e < total && k < O) ? obs[i * O + k] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 64 * u + lane;
+            if (e < total) xs[e] = v[u];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---- hidden layers, lane = hidden unit ------------------------------------------------------------------------------------------
 // layer 1 of every staged row -> H1 (pitch 64); layer 2 of every row -> H2 (pitch kH2P).  Two loops: a row's layer 2 reads what
 // layer 1 wrote through LDS, and one wave per SIMD has nobody to hide that round trip behind -- so the round trips of all rows
@@ -91,10 +125,12 @@ struct HiddenW {
 
 // Row `lane` of W1 and W2 and the two bias elements -> registers.  Called BEFORE the observation rows are staged: one memory round
 // trip for everything the forward hidden layers need.
-template <int OMAX>
+template <int OMAX, bool WIDE = false>
 __device__ __forceinline__ void hidden_load(HiddenW<OMAX>& w, const MlpNet& n, int O, int lane) {
+    if (!WIDE) {
 #pragma unroll
-    for (int k = 0; k < OMAX; ++k) w.w1[k] = k < O ? n.w1[lane * O + k] : 0.0f;
+        for (int k = 0; k < OMAX; ++k) w.w1[k] = k < O ? n.w1[lane * O + k] : 0.0f;
+    }
     if ((reinterpret_cast<uintptr_t>(n.w2) & 15) == 0) {          // (wave-uniform) rows of W2 are 256 bytes: 16-byte pieces when the base allows
         const float4* wrow = reinterpret_cast<const float4*>(n.w2 + lane * kH);
 #pragma unroll
@@ -110,9 +146,46 @@ __device__ __forceinline__ void hidden_load(HiddenW<OMAX>& w, const MlpNet& n, i
     w.b2 = n.b2[lane];
 }
 
-template <int OMAX>
-__device__ __forceinline__ void hidden_fwd(const HiddenW<OMAX>& hw, const float* xs, float* H1, float* H2, int nrows, int lane) {
-    {
+constexpr int kWideRows = 32;      // WIDE: rows per block (one layer-1 accumulator per row in registers)
+
+// WIDE layer 1: H1[r][lane] = tanh(b1 + sum over chunks c of W1[lane][32 c ..] . xs[r][32 c ..])
+__device__ __forceinline__ void layer1_wide(const MlpNet& n, float b1, const float* xs, float* H1, int nrows, int O, int OP, int lane) {
+    float z[kWideRows];
+#pragma unroll
+    for (int r = 0; r < kWideRows; ++r) z[r] = 0.0f;
+    const float* wrow = n.w1 + (int64_t)lane * O;
+    for (int c0 = 0; c0 < OP; c0 += 32) {
+        float w[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) w[k] = c0 + k < O ? wrow[c0 + k] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < kWideRows; ++r) {
+            if (r < nrows) {                                   // (uniform)
+                const float4* x4 = reinterpret_cast<const float4*>(xs + r * OP + c0);
+                float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 v = x4[q];
+                    z0 = fmaf(w[4 * q + 0], v.x, z0);
+                    z1 = fmaf(w[4 * q + 1], v.y, z1);
+                    z0 = fmaf(w[4 * q + 2], v.z, z0);
+                    z1 = fmaf(w[4 * q + 3], v.w, z1);
+                }
+                z[r] += z0 + z1;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kWideRows; ++r)
+        if (r < nrows) H1[r * kH + lane] = tanhf(z[r] + b1);
+}
+
+template <int OMAX, bool WIDE = false>
+__device__ __forceinline__ void hidden_fwd(const HiddenW<OMAX>& hw, const float* xs, float* H1, float* H2, int nrows, int lane,
+                                           const MlpNet* wide_net = nullptr, int O = 0, int OP = 0) {
+    if constexpr (WIDE) {
+        layer1_wide(*wide_net, hw.b1, xs, H1, nrows, O, OP, lane);
+    } else {
         const float (&w1)[OMAX] = hw.w1;
         const float b1 = hw.b1;
 #pragma unroll 2
@@ -199,7 +272,7 @@ struct MlpActArgs {
     float *logprob, *entropy, *value, *actor_out;      // entropy / actor_out may be NULL
 };
 
-template <int OMAX, int AMAX, bool NORMAL, int MODE>
+template <int OMAX, int AMAX, bool NORMAL, int MODE, bool WIDE = false>
 __global__ __launch_bounds__(64) void mlp_act_kernel(const MlpActArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int lane = threadIdx.x;
@@ -208,14 +281,16 @@ __global__ __launch_bounds__(64) void mlp_act_kernel(const MlpActArgs a) {
     const int nrows = (int)((a.B - row0) < (int64_t)a.R ? (a.B - row0) : (int64_t)a.R);
     const MlpNet n = a.net[netid];
     const int nout = netid ? a.nout : 1;
+    const int OP = WIDE ? (a.O + 31) / 32 * 32 : OMAX;      // pitch of a staged row
     float* xs = lds;
-    float* H1 = xs + a.R * OMAX;
+    float* H1 = xs + a.R * OP;
     float* H2 = H1 + a.R * kH;
     HiddenW<OMAX> hw;
-    hidden_load<OMAX>(hw, n, a.O, lane);
-    stage_rows<OMAX>(xs, a.obs, nullptr, row0, nrows, a.O, lane, nullptr);
+    hidden_load<OMAX, WIDE>(hw, n, a.O, lane);
+    if constexpr (WIDE) stage_rows_wide(xs, a.obs, nullptr, row0, nrows, a.O, OP, lane, nullptr);
+    else stage_rows<OMAX>(xs, a.obs, nullptr, row0, nrows, a.O, lane, nullptr);
     __builtin_amdgcn_wave_barrier();
-    hidden_fwd<OMAX>(hw, xs, H1, H2, nrows, lane);
+    hidden_fwd<OMAX, WIDE>(hw, xs, H1, H2, nrows, lane, &n, a.O, OP);
     if (lane >= nrows) return;
     const int64_t row = row0 + lane;
     float out[AMAX];
@@ -302,7 +377,7 @@ struct MlpPpoArgs {
 // internal order of a network's partial vector: W1 as [k][j], b1, W2 as [k][j], b2, W3 as [o][j], b3
 __host__ __device__ inline int mlp_part_size(int O, int nout) { return O * kH + kH + kH * kH + kH + nout * kH + nout; }
 
-template <int OMAX, int AMAX, bool NORMAL>
+template <int OMAX, int AMAX, bool NORMAL, bool WIDE = false>
 __global__ __launch_bounds__(64) void mlp_ppo_kernel(const MlpPpoArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int lane = threadIdx.x;
@@ -313,12 +388,14 @@ __global__ __launch_bounds__(64) void mlp_ppo_kernel(const MlpPpoArgs a) {
     const MlpNet n = a.net[netid];
     const int nout = netid ? a.nout : 1;
     const int O = a.O;
+    const int OP = WIDE ? (O + 31) / 32 * 32 : OMAX;        // pitch of a staged row
     float* xs = lds;
-    float* H1 = xs + a.R * OMAX;
+    float* H1 = xs + a.R * OP;
     float* H2 = H1 + a.R * kH;
     HiddenW<OMAX> hw;
-    hidden_load<OMAX>(hw, n, O, lane);
-    stage_rows<OMAX>(xs, a.obs, a.inds, row0, nrows, O, lane, H1);
+    hidden_load<OMAX, WIDE>(hw, n, O, lane);
+    if constexpr (WIDE) stage_rows_wide(xs, a.obs, a.inds, row0, nrows, O, OP, lane, H1);
+    else stage_rows<OMAX>(xs, a.obs, a.inds, row0, nrows, O, lane, H1);
     // this lane's row (lane = row phase): behaviour data, requested before the hidden layers run
     const bool valid = lane < nrows;
     const int64_t m = row0 + (valid ? lane : 0);
@@ -334,7 +411,7 @@ __global__ __launch_bounds__(64) void mlp_ppo_kernel(const MlpPpoArgs a) {
     float amean = 0.0f, aden = 1.0f;
     if (a.P.norm_adv) { amean = a.adv_mean_den[0]; aden = a.adv_mean_den[1]; }
     __builtin_amdgcn_wave_barrier();
-    hidden_fwd<OMAX>(hw, xs, H1, H2, nrows, lane);
+    hidden_fwd<OMAX, WIDE>(hw, xs, H1, H2, nrows, lane, &n, O, OP);
 
     // ---- lane = row: outputs, distribution, loss row terms, gradient with respect to the outputs ----------------------------
     float out[AMAX], dout[AMAX];
@@ -478,7 +555,48 @@ __global__ __launch_bounds__(64) void mlp_ppo_kernel(const MlpPpoArgs a) {
         }
     }
     __builtin_amdgcn_wave_barrier();
-    {
+    if constexpr (WIDE) {
+        // dz1 of every row first (parked in H1's slot of the row: h1 is not needed again), then dW1 chunk by chunk: 32 accumulators against the rows' dz1
+        float db1 = 0.0f;
+#pragma unroll 2
+        for (int r = 0; r < nrows; ++r) {
+            const float4* z4 = reinterpret_cast<const float4*>(H2 + r * kH2P);
+            float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kH / 4; ++q) {
+                const float4 v = z4[q];
+                d0 = fmaf(w2t[4 * q + 0], v.x, d0);
+                d1 = fmaf(w2t[4 * q + 1], v.y, d1);
+                d2 = fmaf(w2t[4 * q + 2], v.z, d2);
+                d3 = fmaf(w2t[4 * q + 3], v.w, d3);
+            }
+            const float h1 = H1[r * kH + lane];
+            const float dz1 = ((d0 + d1) + (d2 + d3)) * (1.0f - h1 * h1);
+            db1 += dz1;
+            H1[r * kH + lane] = dz1;                            // (the lane's own element: no other lane reads H1 from here on)
+        }
+        part[O * kH + lane] = db1;
+        for (int c0 = 0; c0 < OP; c0 += 32) {
+            float dw1[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) dw1[k] = 0.0f;
+#pragma unroll 2
+            for (int r = 0; r < nrows; ++r) {
+                const float dz1 = H1[r * kH + lane];
+                const float4* x4 = reinterpret_cast<const float4*>(xs + r * OP + c0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 v = x4[q];
+                    dw1[4 * q + 0] = fmaf(dz1, v.x, dw1[4 * q + 0]);
+                    dw1[4 * q + 1] = fmaf(dz1, v.y, dw1[4 * q + 1]);
+                    dw1[4 * q + 2] = fmaf(dz1, v.z, dw1[4 * q + 2]);
+                    dw1[4 * q + 3] = fmaf(dz1, v.w, dw1[4 * q + 3]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) if (c0 + k < O) part[(c0 + k) * kH + lane] = dw1[k];
+        }
+    } else {
         float dw1[OMAX];
 #pragma unroll
         for (int k = 0; k < OMAX; ++k) dw1[k] = 0.0f;
@@ -611,6 +729,16 @@ static inline int pick_rows(int64_t rows, int want, int target_blocks, int min_r
     return R;
 }
 static inline size_t act_lds_bytes(int R, int OMAX) { return (size_t)R * (OMAX + kH + kH2P) * sizeof(float); }
+// WIDE (observation width above 32 or more than 8 outputs): rows of pitch OP = O rounded up to 32; at most kWideRows rows per block and 64 KB of LDS
+constexpr int kMlpMaxObs = 512, kMlpMaxOut = 20;
+static inline bool mlp_wide(int O, int nout) { return O > 32 || nout > 8; }
+static inline int wide_pitch(int O) { return (O + 31) / 32 * 32; }
+static inline int wide_rows(int O, int R) {
+    const int fit = (int)(65536 / ((size_t)(wide_pitch(O) + kH + kH2P) * sizeof(float)));
+    const int cap = fit < kWideRows ? fit : kWideRows;
+    return R < cap ? R : cap;
+}
+static inline int sums_extra(int nout) { return nout > 8 ? kMlpMaxOut : 8; }
 
 static int fill_net(const char* fn, const void* const* p, MlpNet& n) {
     MI355_REQUIRE(p, MI355PPO_EINVAL, "%s: null network pointer block", fn);
@@ -624,8 +752,8 @@ static int fill_net(const char* fn, const void* const* p, MlpNet& n) {
 }
 
 static int check_dims(const char* fn, int O, int nout) {
-    MI355_REQUIRE(O > 0 && O <= 32, MI355PPO_EINVAL, "%s: obs_dim=%d must be in 1..32 (the fused MLP keeps a row of W1 in registers)", fn, O);
-    MI355_REQUIRE(nout > 0 && nout <= 8, MI355PPO_EINVAL, "%s: n_out=%d must be in 1..8", fn, nout);
+    MI355_REQUIRE(O > 0 && O <= kMlpMaxObs, MI355PPO_EINVAL, "%s: obs_dim=%d must be in 1..%d", fn, O, kMlpMaxObs);
+    MI355_REQUIRE(nout > 0 && nout <= kMlpMaxOut, MI355PPO_EINVAL, "%s: n_out=%d must be in 1..%d", fn, nout, kMlpMaxOut);
     return MI355PPO_OK;
 }
 
@@ -638,7 +766,14 @@ static int check_dims(const char* fn, int O, int nout) {
 static inline int omax_for(int O) { return O <= 8 ? 8 : O <= 20 ? 20 : 32; }
 
 template <bool NORMAL, int MODE>
-static int act_launch(const char* fn, const MlpActArgs& a, hipStream_t s) {
+static int act_launch(const char* fn, const MlpActArgs& a0, hipStream_t s) {
+    MlpActArgs a = a0;
+    if (mlp_wide(a.O, a.nout)) {
+        a.R = wide_rows(a.O, a.R);
+        const int blocks = (a.B + a.R - 1) / a.R;
+        hipLaunchKernelGGL((mlp_act_kernel<32, kMlpMaxOut, NORMAL, MODE, true>), dim3(2 * blocks), dim3(64), act_lds_bytes(a.R, wide_pitch(a.O)), s, a);
+        return check_launch(fn);
+    }
     const int blocks = (a.B + a.R - 1) / a.R;
     const size_t lds = act_lds_bytes(a.R, omax_for(a.O));
 #define LAUNCH(OM, AM) hipLaunchKernelGGL((mlp_act_kernel<OM, AM, NORMAL, MODE>), dim3(2 * blocks), dim3(64), lds, s, a)
@@ -711,10 +846,11 @@ extern "C" MI355PPO_API int mi355ppo_mlp_act_normal_f32(const float* obs, int B,
 }
 
 extern "C" MI355PPO_API size_t mi355ppo_mlp_ppo_workspace_bytes(int M, int O, int n_out, int rows_per_block) {
-    if (M <= 0 || O <= 0 || O > 32 || n_out <= 0 || n_out > 8) return 0;
-    const int R = pick_rows(M, rows_per_block, 256);
+    if (M <= 0 || O <= 0 || O > kMlpMaxObs || n_out <= 0 || n_out > kMlpMaxOut) return 0;
+    int R = pick_rows(M, rows_per_block, 256);
+    if (mlp_wide(O, n_out)) R = wide_rows(O, R);
     const size_t nb = (size_t)((M + R - 1) / R);
-    return nb * 2 * (kNumSums + 8) * sizeof(double) + nb * ((size_t)mlp_part_size(O, 1) + (size_t)mlp_part_size(O, n_out)) * sizeof(float);
+    return nb * 2 * (kNumSums + sums_extra(n_out)) * sizeof(double) + nb * ((size_t)mlp_part_size(O, 1) + (size_t)mlp_part_size(O, n_out)) * sizeof(float);
 }
 
 static int mlp_ppo_common(const char* fn, bool normal, const float* b_obs, const int64_t* mb_inds, int M, int O, const void* const* actor,
@@ -751,7 +887,8 @@ static int mlp_ppo_common(const char* fn, bool normal, const float* b_obs, const
         f.g[t].w1 = (float*)gp[t][0]; f.g[t].b1 = (float*)gp[t][1]; f.g[t].w2 = (float*)gp[t][2];
         f.g[t].b2 = (float*)gp[t][3]; f.g[t].w3 = (float*)gp[t][4]; f.g[t].b3 = (float*)gp[t][5];
     }
-    const int R = pick_rows(M, rows_per_block, 256);
+    const bool wide = mlp_wide(O, nout);
+    const int R = wide ? wide_rows(O, pick_rows(M, rows_per_block, 256)) : pick_rows(M, rows_per_block, 256);
     const int nb = (M + R - 1) / R;
     a.obs = b_obs; a.inds = mb_inds; a.M = M; a.O = O; a.nout = nout; a.R = R; a.nblocks = nb;
     a.b_actions = b_actions; a.b_logprobs = b_logprobs; a.b_adv = b_advantages; a.b_ret = b_returns; a.b_val = b_values;
@@ -760,13 +897,16 @@ static int mlp_ppo_common(const char* fn, bool normal, const float* b_obs, const
     a.P.ent_coef = (float)ent_coef; a.P.vf_coef = (float)vf_coef; a.P.norm_adv = norm_adv ? 1 : 0; a.P.clip_vloss = clip_vloss ? 1 : 0;
     a.P.M = M; a.P.stats_blocks = 0;
     a.sums = static_cast<double*>(workspace);
-    a.sum_stride = kNumSums + 8;
+    a.sum_stride = kNumSums + sums_extra(nout);
     float* pbase = reinterpret_cast<float*>(a.sums + (size_t)nb * 2 * a.sum_stride);
     a.part[0] = pbase;
     a.part[1] = pbase + (size_t)nb * mlp_part_size(O, 1);
     hipStream_t s = as_stream(stream);
-    const size_t lds = act_lds_bytes(R, omax_for(O));
-    if (normal) {
+    const size_t lds = act_lds_bytes(R, wide ? wide_pitch(O) : omax_for(O));
+    if (wide) {
+        if (normal) hipLaunchKernelGGL((mlp_ppo_kernel<32, kMlpMaxOut, true, true>), dim3(2 * nb), dim3(64), lds, s, a);
+        else hipLaunchKernelGGL((mlp_ppo_kernel<32, kMlpMaxOut, false, true>), dim3(2 * nb), dim3(64), lds, s, a);
+    } else if (normal) {
 #define LAUNCH(OM, AM) hipLaunchKernelGGL((mlp_ppo_kernel<OM, AM, true>), dim3(2 * nb), dim3(64), lds, s, a)
         MI355_MLP_DISPATCH(O, nout, LAUNCH);
 #undef LAUNCH

@@ -237,7 +237,7 @@ class PPOLearner:
 
                 nets = agent.mlp_nets()
                 print(f"cleanrl_amd: this MLP agent (observation width {nets[0][0].in_features}, {nets[0][-1].out_features} actor outputs) is outside the fused "
-                      "MLP kernels' shapes (64-64 tanh, observation width <= 32, <= 8 outputs): its networks run on library GEMMs behind the HIP sampling / "
+                      "MLP kernels' shapes (64-64 tanh, observation width <= 512, <= 20 outputs): its networks run on library GEMMs behind the HIP sampling / "
                       "loss kernels", file=sys.stderr, flush=True)
         self._pack = None           # (B, 8) packed behaviour rows (ops.batch_pack) of the current update, or None
         self._pack_buf = None       # their storage, allocated by the first update()

@@ -602,7 +602,7 @@ def clip_adam_sched_(params, grads, exp_avg, exp_avg_sq, sched2, max_grad_norm: 
 
 
 # ------------------------------------------------------------------------------------------- K7: the fused MLP agents
-MLP_MAX_OBS, MLP_MAX_OUT, MLP_HIDDEN = 32, 8, 64
+MLP_MAX_OBS, MLP_MAX_OUT, MLP_HIDDEN = 512, 20, 64      # (round 6: the WIDE kernels of csrc/mlp.hip -- Humanoid's 376 / 17; up to 32 / 8: the narrow ones)
 
 
 class MlpNetPtrs:

@@ -32,13 +32,13 @@
 extern "C" {
 #endif
 
-#define MI355PPO_VERSION 200 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
+#define MI355PPO_VERSION 210 /* major*100 + minor*10 + patch.  The minor moves whenever an exported signature changes or an entry
                                   point is added (1.1: adv_mean_den / conv1_variant arguments of round 2; 1.2, 1.3: round 3;
                                   1.4: the *_cpu host-pointer twins; 1.5: mi355ppo_init; 1.6: round 4 -- the fused MLP family K7,
                                   mi355ppo_clip_adam_sched_f32; 1.7: mi355ppo_fc_heads_act_categorical_f32, mi355ppo_nature_packs_f32,
                                   mi355ppo_synth_atari_step_hwc_ctr_u8; 1.8: round 5 -- the *_f16x2 / *_amax entry points and mi355ppo_absmax_f32;
                                   1.9: round 6 -- the kernel queries mi355ppo_fc_packed_kernel_f16x2, mi355ppo_fc_wgrad_kernel_f16x2, mi355ppo_cnn_conv_wgrad_kernel_f16x2;
-                                  heads of up to 18 actions, a 4-byte-aligned critic row; 2.0: the peer-memory gradient exchange mi355ppo_dp_*);
+                                  heads of up to 18 actions, a 4-byte-aligned critic row; 2.0: the peer-memory gradient exchange mi355ppo_dp_*; 2.1: the fused MLP family takes obs_dim <= 512, n_out <= 20);
                                   a binding must check major AND minor (cleanrl_amd/_lib.py does) */
 
 #if defined(__GNUC__)
@@ -322,8 +322,9 @@ MI355PPO_API int mi355ppo_dp_comm_destroy(mi355ppo_dp_comm* comm);
  * Agents: cleanrl/ppo.py:100-126 (Categorical head), cleanrl/ppo_continuous_action.py:112-141 (Normal head with the
  * state-independent actor_logstd).  A network is passed as a HOST array of six DEVICE pointers in torch's own layouts:
  *   {W1 (64, O), b1 (64), W2 (64, 64), b2 (64), W3 (n_out, 64), b3 (n_out)}   (nn.Linear.weight is (out, in))
- * obs_dim O <= 32 and n_out <= 8 (CartPole 4 / 2, HalfCheetah 17 / 6, Ant 27 / 8 ...): beyond that the entry points return
- * MI355PPO_EINVAL and the caller keeps the networks on library GEMMs.
+ * obs_dim O <= 512 and n_out <= 20 (ABI 2.1; CartPole 4 / 2, HalfCheetah 17 / 6, Ant 27 / 8, Humanoid 376 / 17 ...): beyond that the entry points
+ * return MI355PPO_EINVAL and the caller keeps the networks on library GEMMs.  Up to O = 32 and n_out = 8 a lane keeps its row of W1 in registers;
+ * wider shapes run the WIDE kernels (layer 1 and its weight gradient walk the observation in chunks of 32 columns, blocks of <= 32 rows).
  *
  * mi355ppo_mlp_fwd_f32: both forwards -- actor_out (B, n_out) = logits or mean, value (B) -- e.g. the bootstrap value of
  *   ppo.py:218-219.

@@ -990,9 +990,9 @@ def test_captured_update_slots_continuous_path():
 
 
 def test_an_mlp_agent_outside_the_fused_kernels_shapes_says_so_once(capsys):
-    """Round-5 review, weak #11: shapes the fused MLP family K7 does not take (observation width > 32 or > 8 outputs, e.g. Humanoid's 376 / 17;
-    ppo_continuous_action.py:112-141) used to change kernel family silently.  The learner now says so on stderr when it is built, and still trains
-    (library GEMMs behind the HIP sampling / loss kernels); a HalfCheetah-shaped agent says nothing."""
+    """Round-5 review, weak #11: shapes the fused MLP family K7 does not take used to change kernel family silently.  Round 6 widened K7 to Humanoid's
+    376 observations / 17 actions (up to 512 / 20: the WIDE kernels of csrc/mlp.hip; ppo_continuous_action.py:112-141); what is still outside (width 600
+    here) says so on stderr when the learner is built, and still trains (library GEMMs behind the HIP sampling / loss kernels)."""
     def make(obs_dim, act_dim):
         torch.manual_seed(4)
         env = SimpleNamespace(single_observation_space=E.Box(-np.inf, np.inf, (obs_dim,), np.float32), single_action_space=E.Box(-1.0, 1.0, (act_dim,), np.float32))
@@ -1000,17 +1000,24 @@ def test_an_mlp_agent_outside_the_fused_kernels_shapes_says_so_once(capsys):
         args = learner_smoke.default_args(num_steps=8, num_minibatches=2, update_epochs=1, clip_coef=0.2, ent_coef=0.0, learning_rate=3e-4)
         return PPOLearner(agent, args, env.single_observation_space, env.single_action_space, 8, DEV, sample_seed=8)
 
+    def train_once(L, width):
+        g = torch.Generator(device=DEV).manual_seed(1)
+        L.observe(0, torch.randn(8, width, device=DEV, generator=g), L.dones[0])
+        for step in range(8):
+            L.act(step)
+            L.store_reward(step, torch.randn(8, device=DEV, generator=g))
+            L.observe(step + 1, torch.randn(8, width, device=DEV, generator=g), torch.zeros(8, device=DEV))
+        L.finish_rollout()
+        return L.update(3e-4)
+
     L = make(17, 6)
     assert L.mlp is not None and "outside the fused MLP kernels" not in capsys.readouterr().err
-    L = make(40, 6)
+    L = make(376, 17)                    # Humanoid-v4: on the fused kernels since round 6
+    assert L.mlp is not None and "outside the fused MLP kernels" not in capsys.readouterr().err
+    m = train_once(L, 376)
+    assert np.isfinite(m["loss"]) and m["num_updates"] == 2
+    L = make(600, 6)
     err = capsys.readouterr().err
-    assert L.mlp is None and err.count("outside the fused MLP kernels") == 1 and "observation width 40" in err
-    g = torch.Generator(device=DEV).manual_seed(1)
-    L.observe(0, torch.randn(8, 40, device=DEV, generator=g), L.dones[0])
-    for step in range(8):
-        L.act(step)
-        L.store_reward(step, torch.randn(8, device=DEV, generator=g))
-        L.observe(step + 1, torch.randn(8, 40, device=DEV, generator=g), torch.zeros(8, device=DEV))
-    L.finish_rollout()
-    m = L.update(3e-4)
+    assert L.mlp is None and err.count("outside the fused MLP kernels") == 1 and "observation width 600" in err
+    m = train_once(L, 600)
     assert np.isfinite(m["loss"]) and m["num_updates"] == 2

@@ -40,7 +40,8 @@ def _dev(seq):
     return d
 
 
-@pytest.mark.parametrize("O,nout,B", [(4, 2, 1), (4, 2, 128), (17, 6, 64), (17, 6, 700), (27, 8, 33), (32, 1, 5), (8, 4, 4097)])
+@pytest.mark.parametrize("O,nout,B", [(4, 2, 1), (4, 2, 128), (17, 6, 64), (17, 6, 700), (27, 8, 33), (32, 1, 5), (8, 4, 4097),
+                                      (376, 17, 1), (376, 17, 700), (111, 8, 33), (33, 2, 64), (17, 9, 40), (512, 20, 129), (40, 18, 5)])      # (second line: the WIDE kernels, round 6)
 def test_mlp_forward_matches_float64(O, nout, B):
     actor, critic = _nets(O, nout, seed=B)
     x = torch.randn(B, O)
@@ -54,14 +55,14 @@ def test_mlp_forward_matches_float64(O, nout, B):
 
 
 def test_mlp_refuses_unsupported_shapes_loudly():
-    actor, critic = _nets(40, 2, seed=0)
+    actor, critic = _nets(513, 2, seed=0)
     da, dc = _dev(actor), _dev(critic)
-    assert not ops.mlp_supported(40, 2) and not ops.mlp_supported(17, 9)
-    with pytest.raises(Exception, match="obs_dim=40"):
-        ops.mlp_forward(torch.randn(3, 40, device=DEV), ops.MlpNetPtrs(da), ops.MlpNetPtrs(dc))
+    assert ops.mlp_supported(376, 17) and ops.mlp_supported(512, 20) and not ops.mlp_supported(513, 2) and not ops.mlp_supported(17, 21)
+    with pytest.raises(Exception, match="obs_dim=513"):
+        ops.mlp_forward(torch.randn(3, 513, device=DEV), ops.MlpNetPtrs(da), ops.MlpNetPtrs(dc))
 
 
-@pytest.mark.parametrize("O,A,B", [(4, 2, 4), (4, 2, 300), (12, 7, 65)])
+@pytest.mark.parametrize("O,A,B", [(4, 2, 4), (4, 2, 300), (12, 7, 65), (128, 18, 65), (40, 3, 300), (10, 18, 33)])
 def test_mlp_act_categorical_is_the_unfused_pair_of_kernels(O, A, B):
     """One launch == mlp_forward then K2 on its logits: same logits bits, same Philox stream, same row math."""
     actor, critic = _nets(O, A, seed=3)
@@ -83,7 +84,7 @@ def test_mlp_act_categorical_is_the_unfused_pair_of_kernels(O, A, B):
     assert torch.equal(n64.cpu(), TO.categorical_sample_from_noise(logits.cpu(), noise.cpu()))
 
 
-@pytest.mark.parametrize("O,D,B", [(17, 6, 64), (5, 3, 1), (27, 8, 129)])
+@pytest.mark.parametrize("O,D,B", [(17, 6, 64), (5, 3, 1), (27, 8, 129), (376, 17, 129), (376, 17, 1), (111, 8, 40)])
 def test_mlp_act_normal_is_the_unfused_pair_of_kernels(O, D, B):
     actor, critic = _nets(O, D, seed=4)
     pa, pc = ops.MlpNetPtrs(_dev(actor)), ops.MlpNetPtrs(_dev(critic))
@@ -110,7 +111,9 @@ def _behaviour(Bf, nout, normal, seed):
 
 @pytest.mark.parametrize("normal", [False, True])
 @pytest.mark.parametrize("O,nout,Bf,M,rpb", [(4, 2, 512, 128, 0), (17, 6, 5000, 4096, 0), (17, 6, 300, 131, 4), (27, 8, 200, 200, 64),
-                                            (9, 3, 64, 1, 0), (17, 6, 70000, 32768, 0)])
+                                            (9, 3, 64, 1, 0), (17, 6, 70000, 32768, 0),
+                                            (376, 17, 2048, 64, 0), (376, 17, 5000, 4096, 0), (111, 8, 300, 131, 4), (33, 2, 200, 200, 64),
+                                            (512, 20, 700, 333, 0), (20, 12, 64, 1, 0)])      # (second half: the WIDE kernels)
 def test_mlp_ppo_minibatch_against_float64_autograd(normal, O, nout, Bf, M, rpb):
     """The fused minibatch body against float64 torch autograd over the reference's loss lines (oracle/torch_oracle.ppo_loss ==
     ppo.py:253-285, pinned to the reference-line goldens): the seven scalars and every parameter gradient of both networks (and of
