@@ -70,6 +70,16 @@ inline int bf16_term_pairs() {
     return n;
 }
 
+// The library's kernel switches, ONE variable per kernel family (A/B runs and tests; read at every call, never cached -- the library keeps no state):
+//   unset / "1": the kernel takes the sizes it wins at (default_min);  "0": never;  "min:<n>": from n rows / images on.
+inline bool kernel_switch(const char* name, long long size, long long default_min) {
+    const char* e = getenv(name);
+    if (!e || !e[0]) return size >= default_min;
+    if (e[0] == '0' && !e[1]) return false;
+    if (e[0] == 'm' && e[1] == 'i' && e[2] == 'n' && e[3] == ':') return size >= atoll(e + 4);
+    return size >= default_min;
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // Launch-site check.  hipGetLastError is cheap, does not synchronise, and is legal during capture.

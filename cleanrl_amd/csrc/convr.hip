@@ -366,14 +366,8 @@ static int r_launch(const RArgs& a0, hipStream_t s, const char* what) {
 // gradient at every size (at or below kernel Z's time everywhere; at 32,768 images 0.72 x for the layer-3 forward, 0.90 x for the layer-2
 // forward -- its 51-KB source allows two images = 162 of 192 row slots per workgroup), the layer-2 data gradient from `min_images` = 512 on
 // (0.76 x at 32,768; 1.13 x at 256: one persistent workgroup per CU with two images each leaves half the chip idle there).
-// MI355PPO_CONV_R=0: never (A/B runs; the results are bit-identical either way); MI355PPO_CONV_R_MIN overrides the threshold of every layer.
-// Read at every call: tests switch them.
-bool convr_on(long long images, long long min_images) {
-    const char* e = getenv("MI355PPO_CONV_R");
-    if (e && e[0] == '0') return false;
-    const char* m = getenv("MI355PPO_CONV_R_MIN");
-    return images >= (m ? atoll(m) : min_images);
-}
+// MI355PPO_CONV_R=0: never (A/B runs; the results are bit-identical either way); =min:<n>: every layer from n images on (common.h::kernel_switch).
+bool convr_on(long long images, long long min_images) { return kernel_switch("MI355PPO_CONV_R", images, min_images); }
 
 int convr_fwd3(const char* fn, const float* src, unsigned src_bytes, const void* pack, const float* bias, float* dst, unsigned dst_bytes, unsigned* bits,
                long long images, const unsigned* src_amax, unsigned* dst_amax, hipStream_t st) {

@@ -403,12 +403,15 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
     }
 }
 
-// MI355PPO_CONV_U=0 / MI355PPO_CONV_U2=0: the layer-3 and layer-2 / the layer-2 weight gradient stay on kernel V (A/B runs).  Read at every call.
+// MI355PPO_CONV_U: unset / "1": the weight gradients of all three layers on kernel U; "0": none (kernels V / P: A/B runs); a list of layer digits -- "3",
+// "23", "13" -- those layers only.  Read at every call.
 bool convu_on(int layer) {
     const char* e = getenv("MI355PPO_CONV_U");
-    if (e && e[0] == '0') return false;
-    const char* e2 = getenv("MI355PPO_CONV_U2");
-    return layer == 3 || !(e2 && e2[0] == '0');
+    if (!e || !e[0] || (e[0] == '1' && !e[1])) return true;
+    if (e[0] == '0' && !e[1]) return false;
+    for (; *e; ++e)
+        if (*e == '0' + layer) return true;
+    return false;
 }
 
 int convu_max_parts() { return 256; }
@@ -417,10 +420,7 @@ int convu_max_parts() { return 256; }
 // mi355ppo_cnn_conv_wgrad_kernel_f16x2 ask it): layers 2 / 3 while the source tensor stays inside the 32-bit buffer range, layer 1 while dz does.
 bool convu_takes(int64_t images, int layer) {
     if (images <= 0) return false;
-    if (layer == 1) {
-        const char* e = getenv("MI355PPO_CONV_U1");
-        return convu_on(3) && !(e && e[0] == '0') && (long long)images * 20 * 20 * 32 * 4 < (1LL << 32) - 8192;
-    }
+    if (layer == 1) return convu_on(1) && (long long)images * 20 * 20 * 32 * 4 < (1LL << 32) - 8192;
     if ((layer != 2 && layer != 3) || !convu_on(layer)) return false;
     return (long long)images * (layer == 3 ? 9 * 9 * 64 : 20 * 20 * 32) * 4 < (1LL << 32) - 8192;
 }
@@ -454,7 +454,7 @@ int convu_launch(const float* src, const float* dz, float* part_w, float* part_b
                       : convu_launch_t<UGeom2>(src, dz, part_w, part_b, images, nparts, s, dz_amax, src_amax);
 }
 
-// Layer 1 (MI355PPO_CONV_U1=0: kernel P).  -> 0 launched (nparts partials; the reduce applies 1 / 255 only), 1 not applicable
+// Layer 1 (MI355PPO_CONV_U=23: kernel P).  -> 0 launched (nparts partials; the reduce applies 1 / 255 only), 1 not applicable
 int convu1_launch(const unsigned char* frames, const int64_t* inds, const float* dz, float* part_w, float* part_b, int64_t images, int* nparts,
                   hipStream_t s, const unsigned* dz_amax) {
     if (!dz_amax || !convu_takes(images, 1)) return 1;

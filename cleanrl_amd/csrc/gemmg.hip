@@ -288,14 +288,9 @@ __global__ __launch_bounds__(GGeom::THREADS) __attribute__((amdgpu_waves_per_eu(
     if (a.c_amax) amax_commit(a.c_amax, __float_as_uint(cmax), blockIdx.x * GG::NW + (unsigned)wave, lane);
 }
 
-// MI355PPO_FC_G=0: the FC forward / data gradient stay on kernel Z (A/B runs; the results are bit-identical either way);
-// MI355PPO_FC_G_MIN overrides the row threshold.  Read at every call: tests switch them.
-bool gemmg_on(long long rows, long long min_rows) {
-    const char* e = getenv("MI355PPO_FC_G");
-    if (e && e[0] == '0') return false;
-    const char* m = getenv("MI355PPO_FC_G_MIN");
-    return rows >= (m ? atoll(m) : min_rows);
-}
+// MI355PPO_FC_G=0: the FC forward / data gradient stay on kernel Z (A/B runs; the results are bit-identical either way); =min:<n>: from n rows on
+// (common.h::kernel_switch).
+bool gemmg_on(long long rows, long long min_rows) { return kernel_switch("MI355PPO_FC_G", rows, min_rows); }
 
 // -> 0 launched, 1 not applicable (shape), < 0 error
 int gemmg_launch(const char* fn, int epi, const float* A, int lda, const void* pack, const float* bias, const unsigned* bits, float* C, int M, int N,

@@ -184,14 +184,11 @@ __global__ __launch_bounds__(HGeom::THREADS) __attribute__((amdgpu_waves_per_eu(
         for (int e = 0; e < 16; ++e) pw[(size_t)(n0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * lh) * K + k0 + 32 * j + li] = acc[j][e] * un;
 }
 
-// MI355PPO_FC_H=0: the FC weight gradient stays on kernel W (A/B runs); read at every call.  Kernel H takes Linear(3136, 512)'s shape
+// MI355PPO_FC_H=0: the FC weight gradient stays on kernel W (A/B runs); =min:<n>: from n rows on (common.h::kernel_switch).  Kernel H takes Linear(3136, 512)'s shape
 // from 4,096 rows on (config B's minibatch: 82 -> 75 us; 2,048 rows: 53 = 53 us; profiles/r06_kernel_h_ab.txt).
 bool gemmh_takes(int M, int N, int K, int lddz) {
     using HG = HGeom;
-    const char* e = getenv("MI355PPO_FC_H");
-    if (e && e[0] == '0') return false;
-    const char* m = getenv("MI355PPO_FC_H_MIN");
-    return M >= (m ? atoi(m) : 4096) && N % HG::CO == 0 && K % HG::CI == 0 && lddz % 4 == 0 &&
+    return kernel_switch("MI355PPO_FC_H", M, 4096) && N % HG::CO == 0 && K % HG::CI == 0 && lddz % 4 == 0 &&
            ((long long)M + 1024) * K * 4 < (1LL << 32) - 8192 && ((long long)M + 1024) * lddz * 4 < (1LL << 32) - 8192;      // (slots past a slab's end are requested, never multiplied)
 }
 int gemmh_slabs() { return HGeom::SLABS; }

@@ -6,7 +6,8 @@ call is five small launches on the CURRENT stream, so it may sit inside a hipGra
 The process group of the reference (``dist.init_process_group``, :166-175) stays what it is for: the rendezvous.  Here it carries the
 64-byte handles once (``all_gather_object``) and one barrier; the gradients never touch it.
 
-``MI355PPO_ALLREDUCE=peer`` selects it in ``PPOLearner`` (default ``pg``: the process group's all-reduce -- RCCL on a multi-GPU node).
+``MI355PPO_ALLREDUCE=peer`` (or ``peer:<seconds>``: the wait timeout, default 20) selects it in ``PPOLearner`` (default ``pg``: the process
+group's all-reduce -- RCCL on a multi-GPU node).
 No build round could run it ACROSS GPUs (one GPU per box): tests/test_gpu_multirank.py runs 2 and 4 processes on one device."""
 from __future__ import annotations
 
@@ -25,10 +26,22 @@ _PHASE = {1: "reduce", 2: "collect"}
 
 def exchange_policy(world_size: int) -> str:
     """"peer" or "pg": which transport ``PPOLearner`` gives the flat gradient to when world > 1 (``MI355PPO_ALLREDUCE``; default "pg")."""
-    v = os.environ.get("MI355PPO_ALLREDUCE", "pg").strip().lower()
-    if v not in ("peer", "pg"):
-        raise ValueError(f"MI355PPO_ALLREDUCE={v!r}: 'peer' (HIP IPC segments, csrc/dpcomm.hip) or 'pg' (the process group's all-reduce)")
+    v = _setting()[0]
     return v if world_size > 1 else "pg"
+
+
+def _setting():
+    """``MI355PPO_ALLREDUCE`` = ``pg`` | ``peer`` | ``peer:<seconds>`` -> (route, seconds after which a wait on a peer gives up)."""
+    raw = os.environ.get("MI355PPO_ALLREDUCE", "pg").strip().lower()
+    v, _, t = raw.partition(":")
+    try:
+        timeout_s = float(t) if t else 20.0
+    except ValueError:
+        timeout_s = -1.0
+    if v not in ("peer", "pg") or timeout_s <= 0.0 or (t and v != "peer"):
+        raise ValueError(f"MI355PPO_ALLREDUCE={raw!r}: 'pg' (the process group's all-reduce), 'peer' (HIP IPC segments, csrc/dpcomm.hip) or 'peer:<seconds>' "
+                         "(the time after which a wait on a peer gives up; default 20)")
+    return v, timeout_s
 
 
 class PeerAllReduce:
@@ -45,7 +58,7 @@ class PeerAllReduce:
         self.lib = _lib.load()
         self.numel = int(numel)
         if timeout_s is None:
-            timeout_s = float(os.environ.get("MI355PPO_PEER_TIMEOUT_S", "20"))
+            timeout_s = _setting()[1]
         self._comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mi355ppo_dp_comm_create(self.world, self.rank, self.numel, float(timeout_s) * 1e3, ctypes.byref(self._comm)),

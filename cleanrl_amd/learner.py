@@ -256,9 +256,9 @@ class PPOLearner:
         self._ar_armed = False
         self._ar_work = None
         self._capture_cut = None    # capture_update() with world > 1: ends a slot's first graph / begins its second (see _SlotGraphs)
-        # (MI355PPO_UPDATE_GRAPH_CUT=1: the bucket boundary -- and with it the cut of a captured slot -- also with world = 1, where the
+        # (MI355PPO_UPDATE_GRAPHS=cut: the bucket boundary -- and with it the cut of a captured slot -- also with world = 1, where the
         # collectives are skipped: the one-GPU test of the segmented capture against the single-graph slots)
-        self._force_cut = os.environ.get("MI355PPO_UPDATE_GRAPH_CUT", "0") == "1"
+        self._force_cut = os.environ.get("MI355PPO_UPDATE_GRAPHS", "auto").strip().lower() == "cut"
         # MI355PPO_ALLREDUCE=peer: the flat gradient is exchanged through HIP IPC segments by five small launches on the compute stream
         # (dp_comm.PeerAllReduce, csrc/dpcomm.hip) instead of the process group's all-reduce: no early bucket, no cut -- a captured slot is one graph
         self._peer = None

@@ -86,6 +86,12 @@ def test_peer_memory_exchange_entry_points_validate_and_fail_loudly_without_a_de
     assert dp_comm.exchange_policy(8) == "pg"
     monkeypatch.setenv("MI355PPO_ALLREDUCE", "peer")
     assert dp_comm.exchange_policy(8) == "peer" and dp_comm.exchange_policy(1) == "pg"
+    monkeypatch.setenv("MI355PPO_ALLREDUCE", "peer:2.5")
+    assert dp_comm.exchange_policy(2) == "peer" and dp_comm._setting() == ("peer", 2.5)
+    for bad in ("pg:3", "peer:0", "peer:x"):
+        monkeypatch.setenv("MI355PPO_ALLREDUCE", bad)
+        with pytest.raises(ValueError):
+            dp_comm.exchange_policy(2)
     monkeypatch.setenv("MI355PPO_ALLREDUCE", "ring")
     with pytest.raises(ValueError):
         dp_comm.exchange_policy(2)
@@ -156,7 +162,7 @@ def test_which_kernel_the_round_6_fc_and_weight_gradient_launches_take(monkeypat
     1,024; kernel H for the FC weight gradient from 4,096 rows; kernel U for every conv weight gradient that fits the 32-bit buffer range -- each
     the launcher's own decision, with its switch read at every call."""
     lib = _lib.load()
-    for name in ("MI355PPO_FC_G", "MI355PPO_FC_G_MIN", "MI355PPO_FC_H", "MI355PPO_FC_H_MIN", "MI355PPO_CONV_U", "MI355PPO_CONV_U1", "MI355PPO_CONV_U2"):
+    for name in ("MI355PPO_FC_G", "MI355PPO_FC_H", "MI355PPO_CONV_U"):
         monkeypatch.delenv(name, raising=False)
     g = lambda M, dgrad, N=512, K=3136: chr(lib.mi355ppo_fc_packed_kernel_f16x2(M, N, K, dgrad))
     assert [g(M, 0) for M in (1024, 8192, 16383, 16384, 32768)] == ["Z", "Z", "Z", "G", "G"]
@@ -169,8 +175,17 @@ def test_which_kernel_the_round_6_fc_and_weight_gradient_launches_take(monkeypat
     assert u(90000, 2) == "T" and u(90000, 1) == "P" and u(90000, 3) == "U" and lib.mi355ppo_cnn_conv_wgrad_kernel_f16x2(64, 4) == 0      # beyond 4 GiB: kernel U declines
     monkeypatch.setenv("MI355PPO_FC_G", "0"); monkeypatch.setenv("MI355PPO_FC_H", "0"); monkeypatch.setenv("MI355PPO_CONV_U", "0")
     assert g(32768, 0) == "Z" and g(32768, 1, 3136, 512) == "Z" and h(32768) == "W" and u(32768, 2) == "V" and u(32768, 1) == "P" and u(240, 3) == "T" and u(304, 3) == "V"
-    monkeypatch.setenv("MI355PPO_FC_G", "1"); monkeypatch.setenv("MI355PPO_FC_G_MIN", "1"); monkeypatch.setenv("MI355PPO_FC_H", "1"); monkeypatch.setenv("MI355PPO_FC_H_MIN", "1")
+    monkeypatch.setenv("MI355PPO_FC_G", "min:1"); monkeypatch.setenv("MI355PPO_FC_H", "min:1")      # one variable per kernel family: "0", "1" / unset, "min:<n>"
     assert g(5, 0) == "G" and g(5, 1, 3136, 512) == "G" and h(5) == "H"
+    monkeypatch.setenv("MI355PPO_FC_G", "1"); monkeypatch.setenv("MI355PPO_FC_H", "1")
+    assert g(8192, 0) == "Z" and h(1024) == "W"
+    # MI355PPO_CONV_U as a list of layers: "23" keeps layer 1 on kernel P, "13" layer 2 on kernel V
+    monkeypatch.setenv("MI355PPO_CONV_U", "23")
+    assert [u(32768, l) for l in (1, 2, 3)] == ["P", "U", "U"]
+    monkeypatch.setenv("MI355PPO_CONV_U", "13")
+    assert [u(32768, l) for l in (1, 2, 3)] == ["U", "V", "U"]
+    monkeypatch.setenv("MI355PPO_CONV_U", "1")
+    assert [u(32768, l) for l in (1, 2, 3)] == ["U", "U", "U"]
     # kernel V's batch rule with the slab count of the shape that would run (round-5 advisor note): 224 .. 288 images of layer 3 stay on kernel V
     # on the bf16 path (170 slabs); the f16 split's two-tile shape needs 227 slabs' worth
     assert chr(lib.mi355ppo_cnn_conv_wgrad_kernel(240, 3)) == "V" and chr(lib.mi355ppo_cnn_conv_wgrad_kernel(208, 3)) == "T"
@@ -180,14 +195,13 @@ def test_which_kernel_a_packed_f16x2_convolution_takes_is_a_host_side_decision(m
     """mi355ppo_cnn_conv_packed_kernel_f16x2 (gemmz.hip::conv_r_takes): kernel R (convr.hip) by default at every size except the
     layer-2 data gradient below 512 images; the switches of DESIGN 3.7 are read at every call."""
     lib = _lib.load()
-    for name in ("MI355PPO_CONV_R", "MI355PPO_CONV_R_MIN"):
-        monkeypatch.delenv(name, raising=False)
+    monkeypatch.delenv("MI355PPO_CONV_R", raising=False)
     k = lambda images, layer, dgrad: chr(lib.mi355ppo_cnn_conv_packed_kernel_f16x2(images, layer, dgrad))
     assert [k(n, 2, 0) for n in (1, 256, 32768)] == ["R"] * 3 and [k(n, 3, 0) for n in (1, 256, 32768)] == ["R"] * 3
     assert [k(n, 3, 1) for n in (1, 32768)] == ["R", "R"]
     assert [k(n, 2, 1) for n in (1, 511, 512, 32768)] == ["Z", "Z", "R", "R"]
     assert k(0, 2, 0) == "Z" and k(64, 1, 0) == "Z" and k(64, 4, 1) == "Z"          # nothing kernel R could take
-    monkeypatch.setenv("MI355PPO_CONV_R_MIN", "8192")
+    monkeypatch.setenv("MI355PPO_CONV_R", "min:8192")
     assert k(4096, 3, 0) == "Z" and k(8192, 3, 0) == "R" and k(8192, 2, 1) == "R"
     monkeypatch.setenv("MI355PPO_CONV_R", "0")
     assert {k(n, layer, d) for n in (1, 8192, 32768) for layer in (2, 3) for d in (0, 1)} == {"Z"}

@@ -166,7 +166,7 @@ def test_kernel_g_fc_forward_and_data_gradient_are_kernel_z_bit_for_bit(monkeypa
     ra, rz = _rec_of(a), _rec_of(dz)
     lib = cnn._lib.load()
     out = {}
-    for route, env in (("Z", {"MI355PPO_FC_G": "0"}), ("G", {"MI355PPO_FC_G": "1", "MI355PPO_FC_G_MIN": "1"})):
+    for route, env in (("Z", {"MI355PPO_FC_G": "0"}), ("G", {"MI355PPO_FC_G": "min:1"})):
         for key, val in env.items():
             monkeypatch.setenv(key, val)
         rh, rd = cnn.new_amax(2, DEV)
@@ -224,7 +224,7 @@ def test_kernel_r_forwards_are_kernel_z_bit_for_bit(monkeypatch, layer, images):
     pack = cnn.conv_zpack_f16x2(W, layer, cnn.MODE_FWD)
     rx = _rec_of(x)
     out = {}
-    for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("R", {"MI355PPO_CONV_R": "1", "MI355PPO_CONV_R_MIN": "1"})):
+    for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("R", {"MI355PPO_CONV_R": "min:1"})):
         for key, val in env.items():
             monkeypatch.setenv(key, val)
         ry, ry2 = cnn.new_amax(2, DEV)
@@ -258,7 +258,7 @@ def test_kernel_r_data_gradients_are_kernel_z_bit_for_bit(monkeypatch, layer, im
     pack = cnn.conv_zpack_f16x2(W, layer, cnn.MODE_DGRAD_S2 if layer == 2 else cnn.MODE_DGRAD_S1)
     rz = _rec_of(dz)
     out = {}
-    for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("R", {"MI355PPO_CONV_R": "1", "MI355PPO_CONV_R_MIN": "1"})):
+    for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("R", {"MI355PPO_CONV_R": "min:1"})):
         for key, val in env.items():
             monkeypatch.setenv(key, val)
         rd = cnn.new_amax(1, DEV)[0]
@@ -323,7 +323,7 @@ def test_conv_weight_gradient_f16x2_against_float64(layer, images):
 @pytest.mark.parametrize("images,scale", [(8, 1.0), (300, 1e-6), (4096, 3e-4), (8192, 1e-4)])      # (8,192: config D's minibatch -- the direct float64 bar behind the relaxed trajectory bar of tests/test_gpu_multirank.py)
 def test_conv1_weight_gradient_f16x2_against_float64(images, scale):
     """The layer-1 weight gradient of the f16 split (kernel U's layer-1 variant, csrc/convu.hip: one image per pass resident in LDS, the uint8
-    frame as zero-extended 16-bit = exact f16 subnormals; MI355PPO_CONV_U1=0: kernel P) against float64 and against kernel P's three-term bf16
+    frame as zero-extended 16-bit = exact f16 subnormals; MI355PPO_CONV_U=23: kernel P) against float64 and against kernel P's three-term bf16
     variant, through a row gather; the bias gradient sums the f32 values as loaded (another order than kernel P's)."""
     g = torch.Generator(device=DEV).manual_seed(images)
     obs = torch.randint(0, 256, (images + 5, 84, 84, 4), dtype=torch.uint8, device=DEV, generator=g)
@@ -375,7 +375,7 @@ def test_kernel_h_fc_weight_gradient_against_float64_and_kernel_w(monkeypatch, M
     w = cnn.fc_wgrad(dz, a, amax=(rz, ra))
     e_w = _close(w, ref, f"fc wgrad kernel W/Y M={M}")
     monkeypatch.setenv("MI355PPO_FC_H", "1")
-    monkeypatch.setenv("MI355PPO_FC_H_MIN", "1")
+    monkeypatch.setenv("MI355PPO_FC_H", "min:1")
     assert chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(M, 512, 3136)) == "H"
     got = cnn.fc_wgrad(dz, a, amax=(rz, ra), out=torch.full((512, 3136), float("nan"), device=DEV))
     e_h = _close(got, ref, f"fc wgrad kernel H M={M}")
@@ -383,7 +383,7 @@ def test_kernel_h_fc_weight_gradient_against_float64_and_kernel_w(monkeypatch, M
     assert torch.equal(got, cnn.fc_wgrad(dz, a, amax=(rz, ra)))
     chw = cnn.fc_wgrad(dz, a, 64, amax=(rz, ra))
     assert torch.equal(chw, got.view(512, 49, 64).permute(0, 2, 1).reshape(512, 3136))
-    monkeypatch.delenv("MI355PPO_FC_H_MIN")
+    monkeypatch.delenv("MI355PPO_FC_H")
     assert chr(lib.mi355ppo_fc_wgrad_kernel_f16x2(M, 512, 3136)) == ("H" if M >= 4096 else ("W" if M % 16 == 0 and M >= 1024 else "Y"))
 
 

@@ -872,7 +872,7 @@ def test_captured_update_slots_are_bit_identical_to_the_eager_update(N, T, nmb, 
 
 @pytest.mark.parametrize("N,T,nmb,epochs", [(32, 8, 2, 2), (128, 128, 4, 4)])
 def test_captured_update_slots_cut_at_the_bucket_boundaries_are_bit_identical_to_the_eager_update(monkeypatch, N, T, nmb, epochs):
-    """The world > 1 form of a captured slot on ONE rank (MI355PPO_UPDATE_GRAPH_CUT=1: collectives skipped): three hipGraphs per slot,
+    """The world > 1 form of a captured slot on ONE rank (MI355PPO_UPDATE_GRAPHS=cut: collectives skipped): three hipGraphs per slot,
     the first ending -- and the second beginning -- on the autograd engine's thread in the middle of the backward, where the eager
     data-parallel path starts the early bucket's all-reduce.  Bit-equal to the eager update over three iterations."""
 
@@ -882,9 +882,9 @@ def test_captured_update_slots_cut_at_the_bucket_boundaries_are_bit_identical_to
         agent = AtariAgent(env).to(DEV)
         args = learner_smoke.default_args(num_steps=T, num_minibatches=nmb, update_epochs=epochs)
         if graphs:
-            monkeypatch.setenv("MI355PPO_UPDATE_GRAPH_CUT", "1")
+            monkeypatch.setenv("MI355PPO_UPDATE_GRAPHS", "cut")
         L = PPOLearner(agent, args, env.single_observation_space, env.single_action_space, N, DEV, sample_seed=8)
-        monkeypatch.delenv("MI355PPO_UPDATE_GRAPH_CUT", raising=False)
+        monkeypatch.delenv("MI355PPO_UPDATE_GRAPHS", raising=False)
         L.observe(0, env.obs_into(L.stage_obs), L.dones[0])
         if graphs:
             L.capture_update()

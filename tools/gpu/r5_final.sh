@@ -29,7 +29,7 @@ for i in 1 2; do
 done
 cut -c1-400 $O/conv_traffic_ab.jsonl
 # kernel R against kernel Z: hashes (bit-identical) and times at three sizes, then alternating timing runs (-> gpurun_out/r5convr/)
-MI355PPO_CONV_R_MIN=1 SIZES="32768 1027 61" bash tools/gpu/r5_convr.sh 2>&1 | cut -c1-260 | tail -14; echo "kernel R A/B t=$((SECONDS-T0))"
+MI355PPO_CONV_R=min:1 SIZES="32768 1027 61" bash tools/gpu/r5_convr.sh 2>&1 | cut -c1-260 | tail -14; echo "kernel R A/B t=$((SECONDS-T0))"
 cp $R/gpurun_out/r5convr/ab.jsonl $O/kernel_r_ab.jsonl 2>/dev/null; cat $R/gpurun_out/r5convr/hashdiff_*.txt > $O/kernel_r_hashdiff.txt 2>/dev/null
 # bench lines with the round's kernel families switched off one at a time (R: input-resident forwards / data gradients; U: weight gradients), alternating
 for i in 1 2; do for mode in all noU noR noRU; do
