@@ -8,12 +8,9 @@
 //     t = T-1..0, loading U rows ahead into registers.  Loads/stores are row-contiguous across lanes
 //     (4*V bytes per lane, 16 B at V=4); every input byte is read once and every output byte written
 //     once, so HBM traffic == the algorithmic 20*T*N + 8*N bytes.  HBM-bound.
-//   * gae_tile<CW>   -- small N (BASELINE.json sizes, e.g. 128 x 1024): too few columns to hide
-//     memory latency with wave parallelism, so a 256-thread workgroup stages a (TC rows x CW cols)
-//     tile of rewards/values/dones through LDS with all four waves (double-buffered, next chunk's
-//     global loads in flight during the scan) and wave 0 runs the chain out of LDS.  Narrow tiles
-//     (CW=16) spread 1024 columns over 64 CUs.  Latency-bound by construction: the floor is the
-//     T-long f32 dependency chain plus one memory round trip.
+//   * gae_staged<CW> -- small N (BASELINE.json sizes, e.g. 128 x 1024): too few columns to hide memory latency with wave
+//     parallelism; everything off the recurrence's chain is done by all 256 threads, the chain runs out of LDS (see the kernel).
+//     (Round 1's single-scanner tile kernels gae_tile<CW> -- variants 2 / 4 / 5 -- were retired in round 6: `auto` never chose them.)
 //
 // Bit-exactness: contraction is disabled so every multiply/add rounds separately, in the
 // reference's order ((g*nv)*nnt), ((r+.)-v), (((g*l)*nnt)*last); g*l is formed in double on the
@@ -102,101 +99,6 @@ __global__ __launch_bounds__(256) void gae_cols(const float* __restrict__ reward
         }
         vstore<V>(advantages + off, a);
         vstore<V>(returns + off, rt);
-    }
-}
-
-// ------------------------------------------------------------------------------------ tile kernel
-// 256 threads; tile = CW columns; time is processed from the end in chunks of TC = 1024/CW rows, so a
-// chunk is 3 x 4 KiB and the double-buffered stage is 24 KiB of LDS whatever the tile width.
-constexpr int kTileFloats = 1024;
-
-template <int CW>
-__global__ __launch_bounds__(256) void gae_tile(const float* __restrict__ rewards, const float* __restrict__ dones,
-                                                const float* __restrict__ values, const float* __restrict__ next_done,
-                                                const float* __restrict__ next_value, float* __restrict__ advantages,
-                                                float* __restrict__ returns, int T, int N, float gamma, float gl) {
-    constexpr int PER_ARRAY = kTileFloats;          // floats of one array in one chunk
-    constexpr int TC = PER_ARRAY / CW;              // rows per chunk
-    constexpr int LOADS = 3 * PER_ARRAY / 256;      // 12 elements per thread per chunk
-    static_assert(PER_ARRAY % 256 == 0 && PER_ARRAY % CW == 0, "tile must divide evenly over the workgroup");
-    __shared__ __attribute__((aligned(16))) float lds[2 * 3 * PER_ARRAY];   // [2][3][TC][CW]
-
-    const int col0 = blockIdx.x * CW;
-    const int ncols = min(CW, N - col0);
-    const int tid = threadIdx.x;
-    const int nchunks = (T + TC - 1) / TC;
-    const float* const src[3] = {rewards, values, dones};
-
-    float stage[LOADS];
-    // element e of a chunk: array a = e / PER_ARRAY, row j = (e % PER_ARRAY) / CW, column c = e % CW
-    auto issue = [&](int k) {
-        const int hi = T - k * TC, lo = max(0, hi - TC);
-#pragma unroll
-        for (int i = 0; i < LOADS; ++i) {
-            const int a = (i * 256) / PER_ARRAY;                 // compile-time after unrolling
-            const int rem = (i * 256) % PER_ARRAY + tid;
-            const int j = rem / CW, c = rem % CW;
-            const int t = lo + j;
-            stage[i] = (t < hi && c < ncols) ? src[a][(int64_t)t * N + col0 + c] : 0.0f;
-        }
-    };
-    auto commit = [&](int buf) {
-        float* dst = lds + buf * 3 * PER_ARRAY;
-#pragma unroll
-        for (int i = 0; i < LOADS; ++i) dst[tid + i * 256] = stage[i];
-    };
-
-    issue(0);
-    commit(0);
-    __syncthreads();
-
-    const bool scanner = (tid < CW) && (tid < ncols);   // CW <= 64: all scanner lanes sit in wave 0
-    float last = 0.0f, nextv = 0.0f, nextd = 0.0f;
-    if (scanner) {
-        nextv = next_value[col0 + tid];
-        nextd = next_done[col0 + tid];
-    }
-    for (int k = 0; k < nchunks; ++k) {
-        if (k + 1 < nchunks) issue(k + 1);           // global loads in flight during the scan
-        if (scanner) {
-            const float* buf = lds + (k & 1) * 3 * PER_ARRAY;
-            const int hi = T - k * TC, lo = max(0, hi - TC);
-            const int rows = hi - lo;
-            int j = rows - 1;
-            for (; j >= 7; j -= 8) {
-                float r[8], v[8], d[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    r[u] = buf[0 * PER_ARRAY + (j - u) * CW + tid];
-                    v[u] = buf[1 * PER_ARRAY + (j - u) * CW + tid];
-                    d[u] = buf[2 * PER_ARRAY + (j - u) * CW + tid];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    float rt;
-                    last = gae_step(r[u], v[u], nextv, nextd, last, gamma, gl, &rt);
-                    nextv = v[u];
-                    nextd = d[u];
-                    const int64_t off = (int64_t)(lo + j - u) * N + col0 + tid;
-                    advantages[off] = last;
-                    returns[off] = rt;
-                }
-            }
-            for (; j >= 0; --j) {
-                const float r = buf[0 * PER_ARRAY + j * CW + tid];
-                const float v = buf[1 * PER_ARRAY + j * CW + tid];
-                const float d = buf[2 * PER_ARRAY + j * CW + tid];
-                float rt;
-                last = gae_step(r, v, nextv, nextd, last, gamma, gl, &rt);
-                nextv = v;
-                nextd = d;
-                const int64_t off = (int64_t)(lo + j) * N + col0 + tid;
-                advantages[off] = last;
-                returns[off] = rt;
-            }
-        }
-        if (k + 1 < nchunks) commit((k + 1) & 1);
-        __syncthreads();
     }
 }
 
@@ -323,14 +225,6 @@ static int launch_staged(const float* r, const float* d, const float* v, const f
     return check_launch("gae_staged");
 }
 
-template <int CW>
-static int launch_tile(const float* r, const float* d, const float* v, const float* nd, const float* nv, float* adv,
-                       float* ret, int T, int N, float gamma, float gl, hipStream_t s) {
-    const int grid = (N + CW - 1) / CW;
-    hipLaunchKernelGGL((gae_tile<CW>), dim3(grid), dim3(256), 0, s, r, d, v, nd, nv, adv, ret, T, N, gamma, gl);
-    return check_launch("gae_tile");
-}
-
 template <int V, int U>
 static int launch_cols(const float* r, const float* d, const float* v, const float* nd, const float* nv, float* adv,
                        float* ret, int T, int N, float gamma, float gl, hipStream_t s) {
@@ -355,7 +249,8 @@ extern "C" MI355PPO_API int mi355ppo_gae_f32_variant(const float* rewards, const
     MI355_REQUIRE(aligned(rewards, 4) && aligned(dones, 4) && aligned(values, 4) && aligned(next_done, 4) &&
                       aligned(next_value, 4) && aligned(advantages, 4) && aligned(returns, 4),
                   MI355PPO_EALIGN, "mi355ppo_gae_f32: pointers must be 4-byte aligned");
-    MI355_REQUIRE(variant >= 0 && variant <= 6, MI355PPO_EINVAL, "mi355ppo_gae_f32: unknown variant %d", variant);
+    MI355_REQUIRE(variant == 0 || variant == 1 || variant == 3 || variant == 6, MI355PPO_EINVAL,
+                  "mi355ppo_gae_f32: unknown variant %d (0, 1, 3, 6; the single-scanner tile kernels 2 / 4 / 5 were retired in round 6: auto never chose them)", variant);
     const float g = (float)gamma;
     const float gl = (float)(gamma * gae_lambda);   // double product, one rounding (see header)
     hipStream_t s = as_stream(stream);
@@ -363,22 +258,16 @@ extern "C" MI355PPO_API int mi355ppo_gae_f32_variant(const float* rewards, const
                       aligned(next_done, 16) && aligned(next_value, 16) && aligned(advantages, 16) &&
                       aligned(returns, 16);
     if (variant == 0) {
-        // auto: tile kernel while the column kernel could not even put one wave on every SIMD
+        // auto: the staged kernel while the column kernels could not even put one wave on every SIMD
         if (N < 65536) variant = 6;     // measured (profiles/r01_kbench_gae_staged_sweep.jsonl): staged wins up to ~32K columns
         else if (vec4 && N >= 262144) variant = 3;
         else variant = 1;
     }
     switch (variant) {
         case 1: return launch_cols<1, 8>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
-        case 2:
-            if (N <= 2048) return launch_tile<16>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
-            if (N <= 6144) return launch_tile<32>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
-            return launch_tile<64>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
         case 3:
             MI355_REQUIRE(vec4, MI355PPO_EALIGN, "mi355ppo_gae_f32: variant 3 needs N%%4==0 and 16-byte aligned pointers");
             return launch_cols<4, 4>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
-        case 4: return launch_tile<64>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
-        case 5: return launch_tile<32>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
         case 6:
             if (N <= 256) return launch_staged<4>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);
             if (N <= 4096) return launch_staged<16>(rewards, dones, values, next_done, next_value, advantages, returns, T, N, g, gl, s);

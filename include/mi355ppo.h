@@ -78,8 +78,8 @@ MI355PPO_API int mi355ppo_init(int device);
  *   advantages, returns    : (T,N) f32                                  [out]
  * Bit-exact with the reference's f32 op order: ((g*nv)*nnt), ((r+.)-v), (((g*l)*nnt)*last), where
  * g*l is formed in double and then rounded to f32 (no FMA contraction).
- * `variant`: 0 = auto, 1 / 3 = column-streaming kernels (large N), 2 / 4 / 5 = single-scanner LDS tile kernels,
- * 6 = staged-scan kernel (small N: off-chain math by all threads, chain out of LDS) (tuning/testing).
+ * `variant`: 0 = auto, 1 / 3 = column-streaming kernels (large N), 6 = staged-scan kernel (small N: off-chain math by all threads, chain
+ * out of LDS) (tuning/testing; 2 / 4 / 5 -- round 1's single-scanner tile kernels -- were retired in ABI 2.1: MI355PPO_EINVAL).
  */
 MI355PPO_API int mi355ppo_gae_f32(const float* rewards, const float* dones, const float* values,
                      const float* next_done, const float* next_value,

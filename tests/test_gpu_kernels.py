@@ -21,7 +21,7 @@ def G(a, dtype=None):
 
 
 # ================================================================================== K1  GAE
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 3, 6])
 @pytest.mark.parametrize("case", sorted(load_golden("gae")))
 def test_gae_goldens_bit_exact(case, variant):
     g = load_golden("gae")[case]
@@ -42,7 +42,7 @@ def test_gae_vs_c_oracle_bit_exact_all_variants(T_, N):
     adv_o, ret_o = c_oracle.gae(*(s[k].numpy() for k in ("rewards", "dones", "values", "next_done", "next_value")),
                                 0.99, 0.95)
     args = [s[k].to(DEV) for k in ("rewards", "dones", "values", "next_done", "next_value")]
-    for variant in [0, 1, 2, 3, 4, 5, 6]:
+    for variant in [0, 1, 3, 6]:
         if variant == 3 and N % 4 != 0:
             continue
         adv, ret = ops.gae(*args, 0.99, 0.95, variant=variant)
