@@ -9,6 +9,22 @@
 #include "../../include/mi355ppo.h"
 
 #define MI355_WAVE 64
+// Cache-policy bits (the `aux` operand of the buffer loads / stores: sc0 = 1, nt = 2, sc1 = 16) of the accesses that stream a tensor through a
+// launch once.  Build-time knobs (tools/build_variant.py + tools/gpu/lib_ab.sh; same-box A/B at 32,768 images, profiles/r06_nt_ab.txt):
+//   * the operands of the weight-gradient kernels U / H (read once, nothing written beside them): non-temporal loads, -2.5 % on the layer-1 /
+//     layer-2 weight gradients, -1 % on the FC one (a read-only stream: 6.1 instead of 5.5 TB/s, profiles/r06_hbm_probe.jsonl);
+//   * kernel R's source prefetch and kernel G's A loads: default policy (nt: +-0 on R, +5 % on the FC data gradient, whose A rows are re-read
+//     from the L2 by the other column blocks of a supertile);
+//   * the epilogue stores of kernels Q / R / G: default policy (nt: +-0).
+#ifndef MI355_AUX_WGRAD_LD
+#define MI355_AUX_WGRAD_LD 2
+#endif
+#ifndef MI355_AUX_STREAM_LD
+#define MI355_AUX_STREAM_LD 0
+#endif
+#ifndef MI355_AUX_STREAM_ST
+#define MI355_AUX_STREAM_ST 0
+#endif
 // Row / element math shared by the device kernels and their host-pointer twins (host_twins.hip): one definition, compiled for
 // both sides, so "same math" is a property of the source and not of two restatements.
 #define MI355_HD __host__ __device__ __forceinline__

@@ -103,6 +103,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const unsigned char* nxt = setup(tile + nwv);
 #pragma unroll
     for (int r = 0; r < kQRows; ++r) ring[r] = *reinterpret_cast<const u32x4q*>(cur + r * kQPitch);
+    // vmcnt counts loads and stores in ONE in-order queue.  A tile's ring loads are issued in FRONT of the previous tile's 17 epilogue stores, so the
+    // wait for ring[r] at the top of a tile is vmcnt(24 - r): the loads, not the stores behind them.  The compiler merges the loop header's state
+    // with the loop entry's, though (the first tile's loads with nothing behind them: vmcnt(7 - r)), and on the back edge that count means "and the
+    // stores acknowledged": it emitted vmcnt(0) there, and every wave sat out a write's round trip per tile (round 2: ~2,000 cycles per 1,800-cycle
+    // tile).  A use of the first tile's rows in front of the loop -- the compiler waits for them HERE -- leaves the back edge's counts at its top.
+#pragma unroll
+    for (int r = 0; r < kQRows; ++r) asm volatile("" : "+v"(ring[r]));
 
     for (; tile < ntiles; tile += nwv) {
         i32x16 acc[kQDigits];
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
             v = v + bias_r;
             v = v > 0.0f ? v : 0.0f;
             vmax = __float_as_uint(v) > vmax ? __float_as_uint(v) : vmax;     // (pixels past P re-read pixel 0: real values)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_dst, off, 0, 0);   // dropped when out of range
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_dst, off, 0, MI355_AUX_STREAM_ST);   // dropped when out of range
             if constexpr (BITS) {      // ballot lanes 0..31: the 32 channels of pixel (e & 3) + 8 (e >> 2); lanes 32..63: of that pixel + 4
                 const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.0f);
                 wv = q_writelane(wv, (unsigned)bal, (e & 3) + 8 * (e >> 2));

@@ -43,6 +43,7 @@ enum { R_BIAS_RELU = 0, R_BIAS_RELU_BITS = 1, R_MASKB = 2, R_MASKB_CLS4 = 3 };
 
 constexpr unsigned kROob = 0xFFFFF000u;               // buffer offset out of range for every tensor < 4 GiB - 4 KiB
 constexpr int kRRsrcWord3 = 0x00020000;               // raw buffer, 32-bit elements
+constexpr int kRWaitVm0 = 0x0F70;                     // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
 
 // lane `l` of w := the wave-uniform value x; x where bit (lane) of {hi, lo} is set, else 0 (gemmz.hip's z_writelane / z_keep_where: the
 // s_nop covers the two wait states a VALU read of an SGPR needs behind the VALU write the compiler cannot see inside the asm)
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 #pragma unroll
         for (int it = it0; it < it0 + n && it < NI; ++it) {
             const int u = it * THREADS + tid;
-            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (any && u < RG::UNITS) ? base + (unsigned)u * 16u : kROob, 0, 0));
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (any && u < RG::UNITS) ? base + (unsigned)u * 16u : kROob, 0, MI355_AUX_STREAM_LD));
         }
     };
     auto fill = [&]() __attribute__((always_inline)) {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
             v = v < 0.0f ? 0.0f : v;                                          // (a NaN stays a NaN, as kernel Z's SPLIT epilogue)
         }
         cmax = __builtin_fmaxf(cmax, __builtin_fabsf(v));                     // (rows past the batch: zeros, or relu(bias) of a real channel -- see below)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, ro, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, ro, 0, MI355_AUX_STREAM_ST);
         if constexpr (EPI == R_BIAS_RELU_BITS) {          // lanes 0..31 of the ballot: the 32 channels of slot row (e & 3) + 8 (e >> 2); 32..63: of that row + 4
             if (e == 0) wv = 0;
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(v > 0.0f);
@@ -315,6 +316,14 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
                     }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // Every load this wave has in flight -- the next group's source, its first two ring slots, this group's mask words -- is waited for HERE, in
+        // front of the epilogue's stores: vmcnt counts loads and stores in one in-order queue, so a wait for a load placed BEHIND the 32 - 64
+        // stores (where the compiler puts it: at the fill's first use) holds the wave until the stores are acknowledged as well -- a bubble of
+        // a write's round trip per group with nothing to overlap it (one workgroup per CU).  With the loads known complete, fill and k-loop
+        // start while the stores drain.
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(kRWaitVm0);
+        __builtin_amdgcn_sched_barrier(0);
         // the group's values (kernel Z's epilogue orders: rows outermost for the masked gradients, tiles outermost for the forward's mask words)
         const __amdgpu_buffer_rsrc_t rc = rsrc_c_of(grp);
         if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
@@ -338,6 +347,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     if (grp < a.groups) {
         prefetch(grp, 0, NI);
         if constexpr (kCarry) { load_slot(0); load_slot(1); }
+        __builtin_amdgcn_s_waitcnt(kRWaitVm0);              // (the loop is entered as the back edge enters it: nothing pending, so its top needs no wait -- see group())
     }
     for (; grp < a.groups; grp += gridDim.x) group(grp);
     if (a.c_amax) amax_commit(a.c_amax, __float_as_uint(cmax), blockIdx.x * NW + (unsigned)wave, lane);

@@ -125,10 +125,10 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
         const bool any = grp < groups;
         if (it < UG::NIS) {
             const int u = it * UG::THREADS + tid;
-            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, (any && u < UG::SRC_UNITS) ? (unsigned)grp * (unsigned)(UG::SRC_UNITS * 16) + (unsigned)u * 16u : kUOob, 0, 0));
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, (any && u < UG::SRC_UNITS) ? (unsigned)grp * (unsigned)(UG::SRC_UNITS * 16) + (unsigned)u * 16u : kUOob, 0, MI355_AUX_WGRAD_LD));
         } else {
             const int v = (it - UG::NIS) * UG::THREADS + tid;
-            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_d, (any && v < UG::DZ_UNITS) ? (unsigned)grp * (unsigned)(UG::DZ_UNITS * 16) + (unsigned)v * 16u : kUOob, 0, 0));
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_d, (any && v < UG::DZ_UNITS) ? (unsigned)grp * (unsigned)(UG::DZ_UNITS * 16) + (unsigned)v * 16u : kUOob, 0, MI355_AUX_WGRAD_LD));
         }
     };
     auto fill = [&]() __attribute__((always_inline)) {
@@ -299,10 +299,10 @@ __global__ __launch_bounds__(UG::THREADS) __attribute__((amdgpu_waves_per_eu(UG:
             const long long row = any ? (inds ? inds[img] : (long long)img) : 0;
             const __amdgpu_buffer_rsrc_t rsrc_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(frames) + row * (UG::FH * UG::FW * UG::FC), 0,
                                                                                  any ? UG::FH * UG::FW * UG::FC : 0, kURsrcWord3);
-            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, u < UG::F_UNITS ? (unsigned)u * 16u : kUOob, 0, 0));
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, u < UG::F_UNITS ? (unsigned)u * 16u : kUOob, 0, MI355_AUX_WGRAD_LD));
         } else {
             const int v = (it - UG::NIF) * UG::THREADS + tid;
-            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_d, (any && v < UG::D_UNITS) ? (unsigned)img * (unsigned)(UG::D_UNITS * 16) + (unsigned)v * 16u : kUOob, 0, 0));
+            pre[it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_d, (any && v < UG::D_UNITS) ? (unsigned)img * (unsigned)(UG::D_UNITS * 16) + (unsigned)v * 16u : kUOob, 0, MI355_AUX_WGRAD_LD));
         }
     };
     auto fill = [&]() __attribute__((always_inline)) {

@@ -22,31 +22,36 @@
 
 namespace mi355ppo {
 
+typedef float gae_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gae_f32x4 __attribute__((ext_vector_type(4)));
 template <int V> struct Vec;
 template <> struct Vec<1> { using type = float; };
-template <> struct Vec<2> { using type = float2; };
-template <> struct Vec<4> { using type = float4; };
+template <> struct Vec<2> { using type = gae_f32x2; };
+template <> struct Vec<4> { using type = gae_f32x4; };
 
-template <int V>
+// NT: non-temporal (`nt`) accesses -- the column kernel in its HBM regime touches every byte once (a read-only stream reaches 6.1 instead of
+// 5.5 TB/s with them on the same box: profiles/r06_hbm_probe.jsonl)
+template <int V, bool NT = false>
 __device__ __forceinline__ void vload(float (&dst)[V], const float* p) {
     using vec = typename Vec<V>::type;
-    const vec x = *reinterpret_cast<const vec*>(p);
+    const vec x = NT ? __builtin_nontemporal_load(reinterpret_cast<const vec*>(p)) : *reinterpret_cast<const vec*>(p);
     const float* xs = reinterpret_cast<const float*>(&x);
 #pragma unroll
     for (int i = 0; i < V; ++i) dst[i] = xs[i];
 }
-template <int V>
+template <int V, bool NT = false>
 __device__ __forceinline__ void vstore(float* p, const float (&src)[V]) {
     using vec = typename Vec<V>::type;
     vec x;
     float* xs = reinterpret_cast<float*>(&x);
 #pragma unroll
     for (int i = 0; i < V; ++i) xs[i] = src[i];
-    *reinterpret_cast<vec*>(p) = x;
+    if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<vec*>(p));
+    else *reinterpret_cast<vec*>(p) = x;
 }
 
 // ---------------------------------------------------------------------------------- column kernel
-template <int V, int U>
+template <int V, int U, bool NT>
 __global__ __launch_bounds__(256) void gae_cols(const float* __restrict__ rewards, const float* __restrict__ dones,
                                                 const float* __restrict__ values, const float* __restrict__ next_done,
                                                 const float* __restrict__ next_value, float* __restrict__ advantages,
@@ -65,9 +70,9 @@ __global__ __launch_bounds__(256) void gae_cols(const float* __restrict__ reward
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t off = (int64_t)(t - u) * N + col;
-            vload<V>(rb[u], rewards + off);
-            vload<V>(vb[u], values + off);
-            vload<V>(db[u], dones + off);
+            vload<V, NT>(rb[u], rewards + off);
+            vload<V, NT>(vb[u], values + off);
+            vload<V, NT>(db[u], dones + off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -80,16 +85,16 @@ __global__ __launch_bounds__(256) void gae_cols(const float* __restrict__ reward
                 nextv[i] = vb[u][i];
                 nextd[i] = db[u][i];
             }
-            vstore<V>(advantages + off, a);
-            vstore<V>(returns + off, rt);
+            vstore<V, NT>(advantages + off, a);
+            vstore<V, NT>(returns + off, rt);
         }
     }
     for (; t >= 0; --t) {
         const int64_t off = (int64_t)t * N + col;
         float r[V], v[V], d[V], a[V], rt[V];
-        vload<V>(r, rewards + off);
-        vload<V>(v, values + off);
-        vload<V>(d, dones + off);
+        vload<V, NT>(r, rewards + off);
+        vload<V, NT>(v, values + off);
+        vload<V, NT>(d, dones + off);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             a[i] = gae_step(r[i], v[i], nextv[i], nextd[i], last[i], gamma, gl, &rt[i]);
@@ -97,8 +102,8 @@ __global__ __launch_bounds__(256) void gae_cols(const float* __restrict__ reward
             nextv[i] = v[i];
             nextd[i] = d[i];
         }
-        vstore<V>(advantages + off, a);
-        vstore<V>(returns + off, rt);
+        vstore<V, NT>(advantages + off, a);
+        vstore<V, NT>(returns + off, rt);
     }
 }
 
@@ -231,7 +236,12 @@ static int launch_cols(const float* r, const float* d, const float* v, const flo
     const int64_t threads = ((int64_t)N + V - 1) / V;
     const int block = threads >= 256 * 256 ? 256 : 64;   // small problems: one wave per workgroup -> more CUs
     const int grid = (int)((threads + block - 1) / block);
-    hipLaunchKernelGGL((gae_cols<V, U>), dim3(grid), dim3(block), 0, s, r, d, v, nd, nv, adv, ret, T, N, gamma, gl);
+    // non-temporal accesses once the five arrays are past the 256-MiB Infinity Cache (below it the consumers of `adv` / `ret` find them cached)
+#ifndef MI355_GAE_NT_BYTES
+#define MI355_GAE_NT_BYTES (256ll << 20)
+#endif
+    if (20ll * T * N > MI355_GAE_NT_BYTES) hipLaunchKernelGGL((gae_cols<V, U, true>), dim3(grid), dim3(block), 0, s, r, d, v, nd, nv, adv, ret, T, N, gamma, gl);
+    else hipLaunchKernelGGL((gae_cols<V, U, false>), dim3(grid), dim3(block), 0, s, r, d, v, nd, nv, adv, ret, T, N, gamma, gl);
     return check_launch("gae_cols");
 }
 

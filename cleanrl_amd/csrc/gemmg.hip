@@ -155,7 +155,7 @@ __global__ __launch_bounds__(GGeom::THREADS) __attribute__((amdgpu_waves_per_eu(
         const int t0 = nx ? nxt.t0 : cur.t0;
 #pragma unroll
         for (int it = 0; it < NIA; ++it)
-            prea[set][it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, nx ? nxt.aoff[it] : cur.aoff[it], slot * (SS * 64), 0));
+            prea[set][it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, nx ? nxt.aoff[it] : cur.aoff[it], slot * (SS * 64), MI355_AUX_STREAM_LD));
 #pragma unroll
         for (int u = 0; u < SHARE; ++u) {
             const int x = wave * SHARE + u, h = x / (NT * 2), jt = x - h * (NT * 2);       // (wave-uniform: scalar arithmetic)
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(GGeom::THREADS) __attribute__((amdgpu_waves_per_eu(
                     v = v < 0.0f ? 0.0f : v;                                  // (a NaN stays a NaN, as kernel Z's SPLIT epilogue)
                 }
                 cmax = __builtin_fmaxf(cmax, __builtin_fabsf(v));             // (tiles past N: zeros)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_c, off, 0, MI355_AUX_STREAM_ST);
             }
         }
         if (!nxt.ok) break;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(HGeom::THREADS) __attribute__((amdgpu_waves_per_eu(
         for (int it = 0; it < NI; ++it) {
             const unsigned so = (unsigned)(s * HG::ROWS) * (it < NID ? rowb_d : rowb_a);
             const unsigned o = goff[it] == kHOob ? kHOob : goff[it] + so;
-            pre[set][it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(it < NID ? rsrc_d : rsrc_a, o, 0, 0));
+            pre[set][it] = __builtin_bit_cast(s_u32x4, __builtin_amdgcn_raw_buffer_load_b128(it < NID ? rsrc_d : rsrc_a, o, 0, MI355_AUX_WGRAD_LD));
         }
     };
     auto write_slot = [&](int set, int buf) __attribute__((always_inline)) {
