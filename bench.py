@@ -268,6 +268,27 @@ def hbm_regime_points(device, reps=10):
     return out
 
 
+def hbm_stream_probe():
+    """What plain streams reach from HBM on THIS box (tools/hbm_probe quick: grid-stride kernels over 1 - 2 GiB, HIP events, after the timed region):
+    the measured counterpart of the 8 TB/s `peak` the roofline fractions are quoted against.  None when the binary is missing or fails."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "tools", "hbm_probe")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=60)
+        rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        by = {x["kernel"]: x["GBps_avg"] for x in rows}
+        return {"read_only_GBps": by["read16 nt U4"], "write_only_GBps": by["write4 plain"], "copy_GBps": by["copy16 ntLS U4"],
+                "mix_1r_2w_GBps": by["mix 1r:2w(4B) plain"], "peak_GBps": HBM_PEAK_GBPS,
+                "note": "tools/hbm_probe.cpp quick: 16-byte non-temporal reads of 1 GiB; 4-byte-per-lane stores of 1 GiB (the resident kernels' epilogue shape); "
+                        "a 1 GiB -> 1 GiB non-temporal copy; one 16-byte read per 32 bytes stored (kernel Q's ratio); mean of 6 launches each, HIP events"}
+    except Exception as e:      # a diagnostic leg: never in the way of the line
+        print(f"bench.py: hbm_stream_probe failed: {e!r}", file=sys.stderr, flush=True)
+        return None
+
+
 def roofline_entry(key, us, launches_timed, flops, letter, share, traffic):
     """The ``roofline`` object of the JSON line for the dominant conv / FC launch ``key`` ("conv2_dgrad@32768"): the BINDING roof of the
     two-roof model, so ``frac`` <= 1 by construction.  For the launch's algorithmic work
@@ -736,6 +757,9 @@ def main():
             }
             if world == 1:
                 out["kernels"].update(hbm_regime_points(device))            # K1 / K3 where they ARE HBM-bound (north_star's >= 60 % figure)
+                probe = hbm_stream_probe()
+                if probe is not None:
+                    out["hbm_stream_probe"] = probe
             for k in sorted(tot):
                 kus, kn = timer.mean_us(k)
                 launches = kn * (16 if k.endswith(f"@{N}") else 1)          # rollout-sized launches are sampled 1 in 16

@@ -77,6 +77,12 @@ def build_tools(verbose: bool = True) -> str:
         _run([HIPCC, "--offload-arch=gfx950", "-O3", fsrc, "-o", fexe])
         if verbose:
             print(f"[cleanrl_amd.build] built {fexe}", file=sys.stderr)
+    # what a stream reaches from HBM on the box (tools/hbm_probe.cpp; bench.py's `hbm_stream_probe` leg runs it with "quick")
+    psrc, pexe = os.path.join(root, "tools", "hbm_probe.cpp"), os.path.join(root, "tools", "hbm_probe")
+    if os.path.exists(psrc) and _stale(pexe, [psrc]):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", psrc, "-o", pexe])
+        if verbose:
+            print(f"[cleanrl_amd.build] built {pexe}", file=sys.stderr)
     # does the bf16 MFMA multiply SUBNORMAL inputs exactly? (kernel P's zero-extended uint8 operand relies on it: tools/mfma_denorm.cpp)
     dsrc, dexe = os.path.join(root, "tools", "mfma_denorm.cpp"), os.path.join(root, "tools", "mfma_denorm")
     if os.path.exists(dsrc) and _stale(dexe, [dsrc]):

@@ -34,6 +34,8 @@ def test_bench_line_says_what_ran_at_the_size_it_claims():
     g, l = j["kernels"]["gae_hbm_regime"], j["kernels"]["loss_hbm_regime"]
     assert g["N"] == 1 << 20 and g["algorithmic_bytes"] == 20 * 128 * (1 << 20) + 8 * (1 << 20) and 0.3 < g["frac"] < 1.0
     assert l["M"] == 1 << 22 and 0.2 < l["streaming"]["frac"] < 1.0 and 0.05 < l["permuted"]["frac"] < 1.0 and l["frac"] == l["streaming"]["frac"]
+    p = j["hbm_stream_probe"]          # what plain streams reach on the box (tools/hbm_probe quick), beside the 8 TB/s the fractions are quoted against
+    assert p["peak_GBps"] == 8000.0 and all(1000.0 < p[k] < 8000.0 for k in ("read_only_GBps", "write_only_GBps", "copy_GBps", "mix_1r_2w_GBps"))
     cb = j["cpu_baseline"]
     # (config B, --cpu-baseline-full off: the small whole-iteration sample; the default line -- config C -- takes the bounded sample at the metric's shapes)
     assert cb["kind"] == "port" and cb["at_metric_config"] is False and cb["value"] > 0 and "cross_check_8_cores_port_value" in cb

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); std::exit(2); } } while (0)
 
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256) void mix_1r2w(const u32x4* __restrict__ s, uns
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool quick = argc > 1 && std::string(argv[1]) == "quick";   // bench.py's leg: one configuration per access pattern, one pass (~0.1 s of GPU time)
     const size_t GiB = 1ull << 30, B = 1 * GiB;                     // 1 GiB in, up to 2 GiB out
     void *s, *d;
     CHECK(hipMalloc(&s, B)); CHECK(hipMalloc(&d, 2 * B));
@@ -87,6 +89,14 @@ int main() {
         std::fflush(stdout);
     };
     const size_t n16 = B / 16;
+    if (quick) {
+        const int grid = 8192;
+        time([&](int g) { read16<true, 4><<<g, 256>>>((const u32x4*)s, (unsigned*)d, n16); }, 1.0 * B, "read16 nt U4", grid);
+        time([&](int g) { write4<false><<<g, 256>>>((unsigned*)d, B / 4, 7u); }, 1.0 * B, "write4 plain", grid);
+        time([&](int g) { copy16<true, true, 4><<<g, 256>>>((const u32x4*)s, (u32x4*)d, n16); }, 2.0 * B, "copy16 ntLS U4", grid);
+        time([&](int g) { mix_1r2w<false, false><<<g, 256>>>((const u32x4*)s, (unsigned*)d, n16); }, 3.0 * B, "mix 1r:2w(4B) plain", grid);
+        return 0;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         for (int grid : {2048, 8192, 32768}) {
             time([&](int g) { copy16<false, false, 1><<<g, 256>>>((const u32x4*)s, (u32x4*)d, n16); }, 2.0 * B, "copy16 plain U1", grid);
