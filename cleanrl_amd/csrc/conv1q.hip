@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
                                                              const unsigned char* __restrict__ pack, const float* __restrict__ bias,
                                                              float* __restrict__ dst, unsigned* __restrict__ bits, unsigned P, int ntiles, unsigned dst_bytes,
                                                              unsigned* __restrict__ amax) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform: the tile index lives in an SGPR)
     const int li = lane & 31, lh = lane >> 5;
     // digit matrices, in operand layout, -> LDS [row][digit][lane]
     __shared__ i32x4 Bl[kQRows][kQDigits][64];
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
         const long long simg = img == img0 ? s0 : s1;
         return src + ((simg * kQH + gy * 4) * kQW + gx * 4) * (long long)kQC + 16 * lh;
     };
+    const unsigned lanebase = (unsigned)(512 * lh + 4 * li);
     unsigned vmax = 0u;                    // bits of the largest value this lane stored (>= 0 after the ReLU): dst's amax record (f16split.h)
     u32x4q ring[kQRows];
     // workgroups are dealt to the 8 XCDs round robin: give each XCD a contiguous range of tile groups, so that the waves
@@ -135,13 +136,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
             if (p < P) myoff = p * 128u;                                  // pixel-major (N,20,20,32) f32: 128 bytes per pixel
         }
         int wv = 0;                                                       // BITS: lane L (< 32) collects the mask word of pixel L of the tile
+        // accumulator row e -> pixel 32 tile + (e & 3) + 8 (e >> 2) + 4 lh: byte offset = (4096 tile + 512 lh + 4 li: one add per tile) + 128 ((e & 3) +
+        // 8 (e >> 2)) (the instruction's immediate).  Pixels past P lie past dst_bytes = 128 P: the buffer drops their stores -- which is why the tile's
+        // base travels in the VECTOR offset: a buffer instruction's scalar offset is not part of its range check.
+        const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane(tile) * 4096u + lanebase;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const unsigned off = (unsigned)__shfl((int)myoff, (e & 3) + 8 * (e >> 2) + 4 * lh, 64) + (unsigned)(li * 4);
+            const unsigned off = tl + (unsigned)(128 * ((e & 3) + 8 * (e >> 2)));
             float t = (float)(acc[3][e] + acc0[3]);                       // exact integers D_j = sum_k v[k] * d_j[k][n]
-            t = t * 0.00390625f + (float)(acc[2][e] + acc0[2]);           // exact product (power of two), one rounding per step
-            t = t * 0.00390625f + (float)(acc[1][e] + acc0[1]);
-            t = t * 0.00390625f + (float)(acc[0][e] + acc0[0]);
+            // t * 2^-8 is exact (a power of two, no underflow: |t| is 0 or >= 2^-24), so the fused multiply-add rounds exactly as the multiply followed by
+            // the add did -- one rounding per step, the same bits, one instruction instead of two (the file compiles with contraction off: explicit)
+            t = __builtin_fmaf(t, 0.00390625f, (float)(acc[2][e] + acc0[2]));
+            t = __builtin_fmaf(t, 0.00390625f, (float)(acc[1][e] + acc0[1]));
+            t = __builtin_fmaf(t, 0.00390625f, (float)(acc[0][e] + acc0[0]));
             float v = t * scale;
             v = v + bias_r;
             v = v > 0.0f ? v : 0.0f;

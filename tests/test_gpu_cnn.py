@@ -739,6 +739,26 @@ def test_conv1q_forward_also_writes_the_relu_mask_as_bits(images):
     assert 0.05 < (out > 0).float().mean().item() < 0.95
 
 
+@pytest.mark.parametrize("images", [1, 37, 1027, 1100])
+def test_conv1q_forward_writes_nothing_past_its_tensors(images):
+    """Kernel Q's tiles are 32 pixels; images x 400 pixels end inside a tile for most batch sizes (1: 400 = 12.5 tiles), and the kernel leaves the pixels past the
+    batch to the buffer's range check (round 6: the tile's base must therefore travel in the store's VECTOR offset -- a scalar offset is not range-checked).
+    Activations and mask words carved out of sentinel-filled buffers: every word behind them keeps its sentinel."""
+    g = torch.Generator().manual_seed(960 + images)
+    obs = torch.randint(0, 256, (images, 84, 84, 4), dtype=torch.uint8, generator=g).to(DEV)
+    W, b = _params(1, 13)
+    pack = cnn.repack_weights(W.to(DEV), 1, cnn.MODE_FWD_Q)
+    n, guard = images * 12800, 1 << 16
+    abuf = torch.full((n + guard,), 0x7FC0DEAD, dtype=torch.int32, device=DEV)
+    bbuf = torch.full((n // 32 + guard,), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+    out, bits = abuf[:n].view(torch.float32).view(images, 20, 20, 32), bbuf[: n // 32]
+    cnn.conv1q_fwd_bits(obs, pack, b.to(DEV), None, out, bits)
+    torch.cuda.synchronize()
+    assert bool((abuf[n:] == 0x7FC0DEAD).all()) and bool((bbuf[n // 32:] == 0x5A5A5A5A).all())
+    ref = cnn.conv_fwd(obs, pack, b.to(DEV), 1, None, variant=cnn.VARIANT_Q)
+    assert torch.equal(out, ref) and torch.equal(cnn.unpack_mask_bits(bits, out.shape), out > 0)
+
+
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 19, 2049])
 def test_conv_fwd_kernel_z_also_writes_the_relu_mask_as_bits(layer, images):
