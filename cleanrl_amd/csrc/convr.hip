@@ -176,7 +176,12 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
 
     // ---- epilogue constants
     const void* const bits_base = EPI == R_BIAS_RELU_BITS ? (const void*)a.bits_out : (const void*)a.bits_in;
-    auto rsrc_c_of = [&](int g) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (g >= 0 && g < a.groups) ? (int)a.c_bytes : 0, kRRsrcWord3); };
+    // C's descriptor of a group starts AT the group (+ the wave's column tiles): the per-value offsets are then lane constants + an immediate, no address
+    // arithmetic per store; the range shrinks with the base, so rows of images past the batch still fall out of it (a scalar offset would not be checked)
+    auto rsrc_c_of = [&](int g, unsigned gbase) __attribute__((always_inline)) {
+        const bool ok = g >= 0 && g < a.groups;
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.C) + (ok ? gbase : 0u), 0, ok ? (int)(a.c_bytes - gbase) : 0, kRRsrcWord3);
+    };
     auto rsrc_b_of = [&](int g) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(bits_base), 0, (EPI != R_BIAS_RELU && g >= 0 && g < a.groups) ? (int)(a.c_bytes >> 5) : 0, kRRsrcWord3); };
     float bj[NTW];                                        // R_BIAS_RELU*: the lane's bias element per column tile
 #pragma unroll
@@ -244,15 +249,18 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         for (int j = 0; j < NTW; ++j) wm[j] = __builtin_amdgcn_raw_buffer_load_b32(rb, (gbase + rlane + (unsigned)joff(j)) >> 5, 0, 0);
     };
     auto epi_elem = [&](int i, int j, int e, unsigned gbase, const __amdgpu_buffer_rsrc_t rc, const __amdgpu_buffer_rsrc_t rb) __attribute__((always_inline)) {
+        // (the table entry is made opaque IN PLACE: row offset + column-tile offset is loop-invariant, and hoisted out of the group loop it costs a register
+        //  per (value, column tile) -- 64 in the layer-2 data gradient, which then spills; left here, joff(j) becomes the store's immediate)
+        asm volatile("" : "+v"(roff[i][kPackRoff ? e >> 1 : e]));
         const unsigned rpk = roff[i][kPackRoff ? e >> 1 : e];
-        const unsigned ro = gbase + (kPackRoff ? ((e & 1) ? rpk >> 16 : rpk & 0xffffu) : rpk) + (unsigned)joff(j);
+        const unsigned ro = (kPackRoff ? ((e & 1) ? rpk >> 16 : rpk & 0xffffu) : rpk) + (unsigned)joff(j);      // (from the group's base: rsrc_c_of)
         float v;
         if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)wm[j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2));
             const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)wm[j], (MT == 2 ? 32 * i : 0) + (e & 3) + 8 * (e >> 2) + 4);
             v = r_keep_where(acc[i][j][e] * un, lo, hi);                // lanes 0..31 (lh = 0): bit li of `lo`, lanes 32..63: of `hi`
         } else {
-            v = acc[i][j][e] * un + bj[j];
+            v = __builtin_fmaf(acc[i][j][e], un, bj[j]);                      // (un is a power of two: the product is exact, the fused form rounds as mul + add did)
             v = v < 0.0f ? 0.0f : v;                                          // (a NaN stays a NaN, as kernel Z's SPLIT epilogue)
         }
         cmax = __builtin_fmaxf(cmax, __builtin_fabsf(v));                     // (rows past the batch: zeros, or relu(bias) of a real channel -- see below)
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         __builtin_amdgcn_s_waitcnt(kRWaitVm0);
         __builtin_amdgcn_sched_barrier(0);
         // the group's values (kernel Z's epilogue orders: rows outermost for the masked gradients, tiles outermost for the forward's mask words)
-        const __amdgpu_buffer_rsrc_t rc = rsrc_c_of(grp);
+        const __amdgpu_buffer_rsrc_t rc = rsrc_c_of(grp, gbase);
         if constexpr (EPI == R_MASKB || EPI == R_MASKB_CLS4) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
