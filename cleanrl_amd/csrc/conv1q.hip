@@ -50,8 +50,11 @@ __device__ __forceinline__ int q_writelane(int w, unsigned x, int l) {
 
 // BITS: also writes (dst > 0) as one bit per element -- word p = the 32 channels of pixel p -- the ReLU mask the layer-2 data
 // gradient needs (mi355ppo_cnn_conv_dgrad_packed_bits_f32 reads 1,600 bytes per image instead of the 51,200-byte activation).
-template <int NW, bool BITS>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv1q_fwd_kernel(const unsigned char* __restrict__ src, const int64_t* __restrict__ inds,
+// WPS: waves per SIMD the instance is compiled for = 4-wave workgroups per CU.  3 (168 VGPRs) at rollout sizes; 4 (128 VGPRs: 122 used, the epilogue's
+// per-channel constants read from LDS at the top of every epilogue instead of living in six registers across the matrix phase) from 4,096 images on:
+// -2.6 % at 32,768 images, +6 % at 1,024, where a fourth workgroup per CU is a fourth 32-KB digit copy for a quarter fewer tiles (profiles/r06_nt_ab.txt).
+template <int NW, bool BITS, int WPS>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void conv1q_fwd_kernel(const unsigned char* __restrict__ src, const int64_t* __restrict__ inds,
                                                              const unsigned char* __restrict__ pack, const float* __restrict__ bias,
                                                              float* __restrict__ dst, unsigned* __restrict__ bits, unsigned P, int ntiles, unsigned dst_bytes,
                                                              unsigned* __restrict__ amax) {
@@ -63,12 +66,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
         const i32x4* __restrict__ p4 = reinterpret_cast<const i32x4*>(pack);
         for (int e = tid; e < kQRows * kQDigits * 64; e += 64 * NW) (&Bl[0][0][0])[e] = p4[e];
     }
-    __syncthreads();
-    int acc0[kQDigits];
+    __shared__ int Cl[kQDigits + 2][32];           // digit offsets, scale, bias per channel
+    if (tid < 32) {
 #pragma unroll
-    for (int d = 0; d < kQDigits; ++d) acc0[d] = reinterpret_cast<const int*>(pack + kQAccOff)[d * 32 + li];
-    const float scale = reinterpret_cast<const float*>(pack + kQScaleOff)[li];
-    const float bias_r = bias[li];
+        for (int d = 0; d < kQDigits; ++d) Cl[d][tid] = reinterpret_cast<const int*>(pack + kQAccOff)[d * 32 + tid];
+        Cl[kQDigits][tid] = reinterpret_cast<const int*>(pack + kQScaleOff)[tid];
+        Cl[kQDigits + 1][tid] = __float_as_int(bias[tid]);
+    }
+    __syncthreads();
     const __amdgpu_buffer_rsrc_t rsrc_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, kQRsrcWord3);
     const __amdgpu_buffer_rsrc_t rsrc_bits = __builtin_amdgcn_make_buffer_rsrc(bits, 0, BITS ? (int)(dst_bytes >> 5) : 0, kQRsrcWord3);
     const int nwv = gridDim.x * NW;
@@ -136,6 +141,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
             if (p < P) myoff = p * 128u;                                  // pixel-major (N,20,20,32) f32: 128 bytes per pixel
         }
         int wv = 0;                                                       // BITS: lane L (< 32) collects the mask word of pixel L of the tile
+        int acc0[kQDigits];
+#pragma unroll
+        for (int d = 0; d < kQDigits; ++d) acc0[d] = Cl[d][li];
+        const float scale = __int_as_float(Cl[kQDigits][li]), bias_r = __int_as_float(Cl[kQDigits + 1][li]);
         // accumulator row e -> pixel 32 tile + (e & 3) + 8 (e >> 2) + 4 lh: byte offset = (4096 tile + 512 lh + 4 li: one add per tile) + 128 ((e & 3) +
         // 8 (e >> 2)) (the instruction's immediate).  Pixels past P lie past dst_bytes = 128 P: the buffer drops their stores -- which is why the tile's
         // base travels in the VECTOR offset: a buffer instruction's scalar offset is not part of its range check.
@@ -169,6 +178,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
 }
 
 static int g_q_cus = 0;
+#ifndef MI355_Q_FOUR_WAVES_FROM
+#define MI355_Q_FOUR_WAVES_FROM 4096
+#endif
+constexpr long long kQFourWavesFrom = MI355_Q_FOUR_WAVES_FROM;
 
 }  // namespace mi355ppo
 
@@ -203,16 +216,16 @@ static int conv1q_fwd_impl(const char* fn, const void* src_u8, const int64_t* in
     }
     const int ntiles = (int)((P + 31) / 32);
     constexpr int NW = 4;
-    long long wgs = (long long)g_q_cus * 3;                   // three 4-wave workgroups per CU = three waves per SIMD
+    const int wps = images >= kQFourWavesFrom ? 4 : 3;        // 4-wave workgroups per CU = waves per SIMD
+    long long wgs = (long long)g_q_cus * wps;
     if (wgs * NW > ntiles) wgs = (ntiles + NW - 1) / NW;
-    if (bits)
-        hipLaunchKernelGGL((conv1q_fwd_kernel<NW, true>), dim3((unsigned)wgs), dim3(64 * NW), 0, as_stream(stream),
-                           static_cast<const unsigned char*>(src_u8), inds, static_cast<const unsigned char*>(pack), bias, dst, bits, (unsigned)P,
-                           ntiles, (unsigned)dstb, amax);
-    else
-        hipLaunchKernelGGL((conv1q_fwd_kernel<NW, false>), dim3((unsigned)wgs), dim3(64 * NW), 0, as_stream(stream),
-                           static_cast<const unsigned char*>(src_u8), inds, static_cast<const unsigned char*>(pack), bias, dst, bits, (unsigned)P,
-                           ntiles, (unsigned)dstb, amax);
+#define MI355_Q_LAUNCH(BITS_, WPS_)                                                                                                            \
+    hipLaunchKernelGGL((conv1q_fwd_kernel<NW, BITS_, WPS_>), dim3((unsigned)wgs), dim3(64 * NW), 0, as_stream(stream),                         \
+                       static_cast<const unsigned char*>(src_u8), inds, static_cast<const unsigned char*>(pack), bias, dst, bits, (unsigned)P, \
+                       ntiles, (unsigned)dstb, amax)
+    if (bits) { if (wps == 4) MI355_Q_LAUNCH(true, 4); else MI355_Q_LAUNCH(true, 3); }
+    else { if (wps == 4) MI355_Q_LAUNCH(false, 4); else MI355_Q_LAUNCH(false, 3); }
+#undef MI355_Q_LAUNCH
     return check_launch(fn);
 }
 
