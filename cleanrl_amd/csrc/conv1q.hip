@@ -16,12 +16,12 @@
 //     chain, one for the scale, one for the bias -- instead of 256 roundings in an f32 fma chain.  Measured against a
 //     float64 convolution the result is CLOSER than the f32-MFMA kernel's (tests/test_gpu_cnn.py).
 //
-// Structure: persistent 4-wave workgroups (three per CU), a wave owns 32-pixel x 32-channel tiles.  The four digit
-// matrices sit in LDS in operand layout (32 KB per workgroup).  Holding them in registers was
-// measured first (profiles/r02_*): 128 VGPRs of digits leave two waves per SIMD, and on gfx9 a tile's epilogue stores
-// force the prefetched loads of the next tile to be waited for with vmcnt(0) (loads and stores share one out-of-order
-// counter) -- ~2,000 cycles of store acknowledgement per 1,800-cycle tile that only MORE waves per SIMD can fill
-// (3.6 TB/s with two).  No barrier after the prologue.  Per tile and tap row a lane issues one 16-byte
+// Structure: persistent 4-wave workgroups (three per CU; four from 4,096 images on: the WPS instances below), a wave owns
+// 32-pixel x 32-channel tiles.  The four digit matrices sit in LDS in operand layout (32 KB per workgroup).  Holding them in
+// registers was measured first (profiles/r02_*): 128 VGPRs of digits leave two waves per SIMD (3.6 TB/s).
+// Round 6: the compiler's wait for the next tile's rows sat behind the tile's 17 epilogue stores (vmcnt(0) at the loop
+// top: a write's round trip per tile) -- the loop is now entered with nothing pending, which leaves vmcnt(24 - r) --, and the
+// epilogue lost a third of its instructions (store offsets as immediates, exact fused multiply-adds).  No barrier after the prologue.  Per tile and tap row a lane issues one 16-byte
 // global load (its half of the pixel's 32-byte tap row, straight from the uint8 rollout rows through mb_inds), four LDS
 // reads, four xors and four MFMAs; the eight rows of the next tile are requested as the current ones are consumed.
 // 1024 matrix-pipe cycles per tile against 8192 for the f32 MFMA: the kernel is bound by HBM (28,224 B read + 51,200 B
