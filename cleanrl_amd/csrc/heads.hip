@@ -107,18 +107,25 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
         if (lane < A) logits[(size_t)m * A + lane] = out;
         else if (lane == A) value[m] = out;
     };
+    // Two rows per iteration, and the NEXT iteration's four 16-byte loads requested before this iteration's arithmetic (round 6: without that every
+    // iteration of a wave was one trip to memory followed by its five butterflies -- 27 us for 32,768 rows, a 67-MB read at 2.5 TB/s; a larger grid
+    // only multiplies the waves' prologues: 1,024 / 2,048 / 4,096 workgroups 27.8 / 37.1 / 62.8 us).  Rows past M re-read row M - 1 (never stored).
+    auto ldrow = [&](int m, float4& x, float4& y) {
+        const float* hr = h + (size_t)(m < M ? m : M - 1) * kHid + lane * 8;
+        x = *reinterpret_cast<const float4*>(hr);
+        y = *reinterpret_cast<const float4*>(hr + 4);
+    };
     int m = wv;
-    for (; m + nwv < M; m += 2 * nwv) {              // two rows per iteration: their four 16-byte loads in flight together (a row's arithmetic is unchanged)
-        const float* h0 = h + (size_t)m * kHid + lane * 8;
-        const float* h1 = h + (size_t)(m + nwv) * kHid + lane * 8;
-        const float4 x0 = *reinterpret_cast<const float4*>(h0), y0 = *reinterpret_cast<const float4*>(h0 + 4);
-        const float4 x1 = *reinterpret_cast<const float4*>(h1), y1 = *reinterpret_cast<const float4*>(h1 + 4);
+    float4 x0, y0, x1, y1;
+    ldrow(m, x0, y0);
+    ldrow(m + nwv, x1, y1);
+    for (; m < M; m += 2 * nwv) {
+        float4 nx0, ny0, nx1, ny1;
+        ldrow(m + 2 * nwv, nx0, ny0);
+        ldrow(m + 3 * nwv, nx1, ny1);
         row(m, x0, y0);
-        row(m + nwv, x1, y1);
-    }
-    if (m < M) {
-        const float* hr = h + (size_t)m * kHid + lane * 8;
-        row(m, *reinterpret_cast<const float4*>(hr), *reinterpret_cast<const float4*>(hr + 4));
+        if (m + nwv < M) row(m + nwv, x1, y1);
+        x0 = nx0; y0 = ny0; x1 = nx1; y1 = ny1;
     }
 }
 
