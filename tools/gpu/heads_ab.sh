@@ -21,7 +21,20 @@ for M in (32768, 4096):
     e0.record()
     for _ in range(50): f()
     e1.record(); e1.synchronize()
-    print(json.dumps(dict(lib=sys.argv[1], M=M, fwd_us=round(e0.elapsed_time(e1) * 20, 2), hash=int(logits.view(torch.int32).sum(dtype=torch.int64)) ^ int(value.view(torch.int32).sum(dtype=torch.int64)))), flush=True)
+    fwd_us = round(e0.elapsed_time(e1) * 20, 2)
+    # backward (the ReLU variant with the amax record: what the learner's update runs), dz with a padded row pitch of 516
+    dl = torch.randn(M, A, generator=g).to(dev); dv = torch.randn(M, generator=g).to(dev)
+    dz = torch.empty(M, 516, device=dev); dWa = torch.empty(A, H, device=dev); dba = torch.empty(A, device=dev); dWc = torch.empty(1, H, device=dev)
+    dbc = torch.empty(1, device=dev); dbh = torch.empty(H, device=dev); rec = torch.zeros(256, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.mi355ppo_heads_bwd_workspace_bytes(M, A), dtype=torch.uint8, device=dev)
+    b = lambda: lib.mi355ppo_heads_bwd_relu_amax_f32(P(h), P(Wa), P(Wc), P(dl), P(dv), P(dz), 516, P(dWa), P(dba), P(dWc), P(dbc), P(dbh), M, A, H, P(ws), ws.numel(), P(rec), st)
+    for _ in range(5): assert b() == 0
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(50): b()
+    e1.record(); e1.synchronize()
+    hb = 0
+    for t in (dz[:, :512].contiguous(), dWa, dba, dWc, dbc, dbh): hb ^= int(t.view(torch.int32).sum(dtype=torch.int64))
+    print(json.dumps(dict(lib=sys.argv[1], M=M, fwd_us=fwd_us, bwd_us=round(e0.elapsed_time(e1) * 20, 2), hash=int(logits.view(torch.int32).sum(dtype=torch.int64)) ^ int(value.view(torch.int32).sum(dtype=torch.int64)), hash_bwd=hb)), flush=True)
 PY
 for i in 1 2 3; do for v in tree ${V:-prev}; do
   if [ $v = tree ]; then cp /tmp/lib_tree.so $L; else cp tools/oldlib/$v/libmi355ppo.so $L; fi
