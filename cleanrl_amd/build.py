@@ -14,8 +14,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libmi355ppo.so")
-SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "optim.hip", "conv.hip", "convw.hip", "conv1q.hip", "conv1p.hip", "gemmz.hip", "gemmg.hip", "gemmh.hip", "convr.hip", "convu.hip", "fcw.hip", "heads.hip", "mlp.hip", "synth_env.hip", "dpcomm.hip", "host_twins.hip"]
-HEADERS = ["common.h", "catrow.h", "ppo_rows.h", "bf16split.h", "f16split.h", "convr_geom.h", os.path.join("..", "..", "include", "mi355ppo.h")]
+SOURCES = ["api.hip", "gae.hip", "distributions.hip", "loss.hip", "obs.hip", "optim.hip", "conv.hip", "convw.hip", "conv1q.hip", "conv1p.hip", "gemmz.hip", "gemmg.hip", "gemmh.hip", "convr.hip", "convrb.hip", "convu.hip", "fcw.hip", "heads.hip", "mlp.hip", "synth_env.hip", "dpcomm.hip", "host_twins.hip"]
+HEADERS = ["common.h", "catrow.h", "ppo_rows.h", "bf16split.h", "f16split.h", "convr_geom.h", "convrb_geom.h", os.path.join("..", "..", "include", "mi355ppo.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every f32 multiply/add rounds separately, as the reference's un-fused torch ops do.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fP
 # of the file compile to identical code with and without the flag.
 # gemmz.hip / fcw.hip / convw.hip: no SLP vectorizer -- it packs pairs of the split's f32 subtractions into v_pk_add_f32 (plus dead
 # halves), and packed f32 VALU beside MFMAs is an anti-lever on this chip (MI355X_MICROARCH.md, per-instruction constants).
-EXTRA_FLAGS = {"conv.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "gemmz.hip": ["-fno-slp-vectorize"], "gemmg.hip": ["-fno-slp-vectorize"], "gemmh.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"], "convr.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"], "convu.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"], "fcw.hip": ["-fno-slp-vectorize"], "convw.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"conv.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "gemmz.hip": ["-fno-slp-vectorize"], "gemmg.hip": ["-fno-slp-vectorize"], "gemmh.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"], "convr.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"], "convrb.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"], "convu.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"], "fcw.hip": ["-fno-slp-vectorize"], "convw.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target: str, deps: list[str]) -> bool:

@@ -53,6 +53,14 @@ int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void*
                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
 int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
+// convrb.hip: kernel RB, the layer-2 data gradient with a group's rows dealt to tiles by border class (three images per group, two thirds of
+// kernel R's matrix instructions, bit-identical results); convr_dgrad2 hands over from MI355_RB_MIN_IMAGES images on
+#ifndef MI355_RB_MIN_IMAGES
+#define MI355_RB_MIN_IMAGES 3072
+#endif
+bool convrb_takes(long long images);
+int convrb_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
+                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
 // convu.hip: kernel U, the layer-3 weight gradient on the f16 split with both operands of an image group resident in LDS (-> 0 launched, 1 not applicable)
 int convu_max_parts();
 bool convu_takes(int64_t images, int layer);       // the f16x2 weight gradient of this size and layer (1, 2, 3) runs on kernel U

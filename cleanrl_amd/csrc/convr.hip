@@ -413,6 +413,7 @@ int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void*
 
 int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st) {
+    if (convrb_takes(images)) return convrb_dgrad2(fn, dz, dz_bytes, pack, bits, dsrc, dsrc_bytes, images, dz_amax, dsrc_amax, st);      // kernel RB (convrb.hip)
     RArgs a{};
     a.A = dz; a.a_bytes = dz_bytes; a.pack = static_cast<const unsigned char*>(pack); a.bits_in = bits; a.C = dsrc; a.c_bytes = dsrc_bytes;
     a.images = images; a.a_amax = dz_amax; a.c_amax = dsrc_amax;
