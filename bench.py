@@ -74,6 +74,10 @@ KERNEL_INFO = {
     "Rh": ("r_kernel (csrc/convr.hip): f16 MFMA on two-term splits with the SOURCE of a group of images resident in LDS, split once (kernel Z "
            "splits every element once per tap that reads it); weights from the f16x2 pack through an LDS ring; kernel Z's epilogue; results "
            "bit-identical to kernel Z's", "f16", 3),
+    "RBh": ("rb_kernel (csrc/convrb.hip): kernel R's layer-2 data gradient with THREE images per group (padded lines share their border record) and the "
+            "group's rows dealt to 32-row tiles by border class: six interior tiles walk all 16 k-steps, four rim tiles only the 8 k-steps of the taps that can "
+            "lie inside the image (kernel R multiplies the zero border: 19 % of its products, and leaves 56 of 256 row slots empty) -- two thirds of kernel R's "
+            "matrix instructions per image; results bit-identical to kernel R's / Z's", "f16", 3),
     "Uh": ("convu_kernel / convu1_kernel (csrc/convu.hip): f16 MFMA on two-term splits with BOTH operands of a group of images resident in LDS, split once; "
            "MFMA fragments by LDS transpose reads (ds_read_b64_tr_b16), the whole weight gradient in the workgroup's accumulators; layer 1: the uint8 "
            "frame as zero-extended 16-bit = exact f16 subnormals, one plane", "f16", 3),
@@ -578,7 +582,7 @@ def main():
             def zr(images, layer, dgrad, bits, amax):       # kernel R takes some of kernel Z's f16x2 launches (csrc/convr.hip): ask the library
                 if amax is None or (dgrad and bits is None):
                     return h("Z", amax)
-                return "Rh" if chr(lib.mi355ppo_cnn_conv_packed_kernel_f16x2(images, layer, dgrad)) == "R" else "Zh"
+                return {"R": "Rh", "B": "RBh"}.get(chr(lib.mi355ppo_cnn_conv_packed_kernel_f16x2(images, layer, dgrad)), "Zh")
 
             timed_op("conv1q_fwd_bits", lambda obs, pack, bias, inds, out, bits: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))
             timed_op("conv1q_fwd_amax", lambda obs, pack, bias, inds, out, bits, dst_amax: (f"conv1_fwd@{out.shape[0]}", conv_flop(1, out.shape[0]), "Q"))

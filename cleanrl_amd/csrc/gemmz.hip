@@ -1424,7 +1424,8 @@ extern "C" MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_bits_f32(const float*
 // weight tensor's maximum), every split operand comes with its amax record, every result a consumer will split again gets its record
 // filled.  Same shapes, alignments and epilogues as the entry points above.
 extern "C" MI355PPO_API int mi355ppo_cnn_conv_packed_kernel_f16x2(int64_t images, int layer, int dgrad) {
-    return (images > 0 && (layer == 2 || layer == 3) && conv_r_takes(images, layer, dgrad != 0)) ? 'R' : 'Z';
+    if (!(images > 0 && (layer == 2 || layer == 3) && conv_r_takes(images, layer, dgrad != 0))) return 'Z';
+    return (layer == 2 && dgrad != 0 && convrb_takes(images)) ? 'B' : 'R';      // 'B': kernel RB (convrb.hip), kernel R's layer-2 data gradient by border class
 }
 
 extern "C" MI355PPO_API size_t mi355ppo_fc_pack_f16x2_bytes(int N, int K) {

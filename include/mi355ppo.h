@@ -638,9 +638,11 @@ MI355PPO_API int mi355ppo_cnn_conv_fwd_packed_f16x2_f32(const float* src, const 
 MI355PPO_API int mi355ppo_cnn_conv_dgrad_packed_f16x2_f32(const float* dz, const void* pack, const float* act_in, const uint32_t* mask_bits,
                                                           float* dsrc, int64_t images, int layer, const uint32_t* dz_amax, uint32_t* dsrc_amax,
                                                           void* stream);
-/* 'R' or 'Z': the kernel a forward (dgrad = 0) / bit-masked data-gradient (dgrad = 1) call of this size and layer runs (profiling aid).
+/* 'R', 'B' or 'Z': the kernel a forward (dgrad = 0) / bit-masked data-gradient (dgrad = 1) call of this size and layer runs (profiling aid).
  * Kernel R (csrc/convr.hip) holds the source of a group of images in LDS, split once, and takes both forwards and the layer-3 data
- * gradient at every size and the layer-2 data gradient from 512 images on; its results are kernel Z's bit for bit (same products, same order). */
+ * gradient at every size and the layer-2 data gradient from 512 images on; its results are kernel Z's bit for bit (same products, same order).
+ * 'B' = kernel RB (csrc/convrb.hip): kernel R's layer-2 data gradient from 3,072 images on with three images per group and the rows dealt to
+ * tiles by border class (the products with a zero-border operand are not issued: two thirds of the matrix instructions, the same bits). */
 MI355PPO_API int mi355ppo_cnn_conv_packed_kernel_f16x2(int64_t images, int layer, int dgrad);
 /* 'G' or 'Z': the kernel mi355ppo_fc_fwd_relu_packed_f16x2_f32 without a K split (dgrad = 0) / mi355ppo_fc_dgrad_packed_f16x2_f32 with mask
  * bits (dgrad = 1) runs for this shape (ABI 1.9).  Kernel G (csrc/gemmg.hip, round 6) streams both operands through workgroup-wide LDS

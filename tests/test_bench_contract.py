@@ -123,14 +123,14 @@ def test_the_line_describes_the_arithmetic_that_ran(monkeypatch):
     now DERIVED from the kernels the launches ran on (bench.describe_cnn), with a ``matrix_arithmetic`` field beside ``dtype``: f32."""
     bench = _load_bench(monkeypatch)
     names = ("conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "fc_wgrad", "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad", "conv1_wgrad")
-    f16 = dict(zip((f"{n}@32768" for n in names), ("Q", "Rh", "Rh", "Gh", "Gh", "Hh", "Uh", "Rh", "Uh", "Rh", "Uh")))
+    f16 = dict(zip((f"{n}@32768" for n in names), ("Q", "Rh", "Rh", "Gh", "Gh", "Hh", "Uh", "Rh", "Uh", "RBh", "Uh")))
     text, arith = bench.describe_cnn(f16, 32768)
     assert "two-term f16 split" in arith and "v_mfma_f32_32x32x16_f16" in arith and "bf16" not in arith
-    assert "fc_dgrad Gh" in text and "fc_wgrad Hh" in text and "conv2_dgrad Rh" in text and "kernel Q" in text
+    assert "fc_dgrad Gh" in text and "fc_wgrad Hh" in text and "conv2_dgrad RBh" in text and "kernel Q" in text
     bf = dict(zip((f"{n}@4096" for n in names), ("Q", "Z", "Z", "Z", "Z", "W", "V", "Z", "V", "Z", "P")))
     text, arith = bench.describe_cnn(bf, 4096)
     assert "three-term bf16 split" in arith and "two-term f16" not in arith and "conv3_wgrad V" in text
-    for letter in ("Gh", "Hh"):                       # the round-6 kernels are priced like every other f16-split kernel
+    for letter in ("Gh", "Hh", "RBh"):                       # the round-6 kernels are priced like every other f16-split kernel
         assert bench.KERNEL_INFO[letter][1:] == ("f16", 3)
 
 

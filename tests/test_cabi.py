@@ -199,10 +199,10 @@ def test_which_kernel_a_packed_f16x2_convolution_takes_is_a_host_side_decision(m
     k = lambda images, layer, dgrad: chr(lib.mi355ppo_cnn_conv_packed_kernel_f16x2(images, layer, dgrad))
     assert [k(n, 2, 0) for n in (1, 256, 32768)] == ["R"] * 3 and [k(n, 3, 0) for n in (1, 256, 32768)] == ["R"] * 3
     assert [k(n, 3, 1) for n in (1, 32768)] == ["R", "R"]
-    assert [k(n, 2, 1) for n in (1, 511, 512, 32768)] == ["Z", "Z", "R", "R"]
+    assert [k(n, 2, 1) for n in (1, 511, 512, 3071, 3072, 32768)] == ["Z", "Z", "R", "R", "B", "B"]      # ('B': kernel RB, convrb.hip)
     assert k(0, 2, 0) == "Z" and k(64, 1, 0) == "Z" and k(64, 4, 1) == "Z"          # nothing kernel R could take
     monkeypatch.setenv("MI355PPO_CONV_R", "min:8192")
-    assert k(4096, 3, 0) == "Z" and k(8192, 3, 0) == "R" and k(8192, 2, 1) == "R"
+    assert k(4096, 3, 0) == "Z" and k(8192, 3, 0) == "R" and k(8192, 2, 1) == "B"
     monkeypatch.setenv("MI355PPO_CONV_R", "0")
     assert {k(n, layer, d) for n in (1, 8192, 32768) for layer in (2, 3) for d in (0, 1)} == {"Z"}
 

@@ -570,9 +570,11 @@ def test_trunk_autograd_under_f16x2_against_float64():
     assert not bad, "; ".join(bad)
 
 
-def test_kernels_r_and_g_equal_kernel_z_bit_for_bit_at_the_bench_size():
-    """Every tensor of one minibatch update at BASELINE configs[2]'s size (32,768 images) hashed on the torch-free driver (tools/conv_traffic:
-    order-independent 64-bit hash of the bit patterns) with kernels R / G switched off (kernel Z: the oracle kernel) and on (the default): the
+@pytest.mark.parametrize("images", [32768, 3073, 3074, 3075])
+def test_kernels_r_and_g_equal_kernel_z_bit_for_bit_at_the_bench_size(images):
+    """Every tensor of one minibatch update at BASELINE configs[2]'s size (32,768 images; and at 3,073 / 3,074 / 3,075: kernel RB's three-image groups
+    with a last group of one, two and three images) hashed on the torch-free driver (tools/conv_traffic:
+    order-independent 64-bit hash of the bit patterns) with kernels R / RB / G switched off (kernel Z: the oracle kernel) and on (the default): the
     forwards, the data gradients and -- fed by them -- every weight gradient must come out bit-identical.  (Round-5 review: this comparison
     lived outside the suite.)"""
     import os
@@ -586,7 +588,7 @@ def test_kernels_r_and_g_equal_kernel_z_bit_for_bit_at_the_bench_size():
     def hashes(extra):
         env = {k: v for k, v in os.environ.items() if not k.startswith("MI355PPO_")}
         env.update({"CONV_TRAFFIC_HASH": "1", "CONV_TRAFFIC_F16": "1"}, **extra)
-        out = subprocess.run([exe, "32768", "1"], cwd=root, capture_output=True, text=True, timeout=300, env=env)
+        out = subprocess.run([exe, str(images), "1"], cwd=root, capture_output=True, text=True, timeout=300, env=env)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         return dict(ln.split()[1:3] for ln in out.stdout.splitlines() if ln.startswith("hash "))
 
