@@ -53,6 +53,12 @@ int convr_dgrad3(const char* fn, const float* dz, unsigned dz_bytes, const void*
                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
 int convr_dgrad2(const char* fn, const float* dz, unsigned dz_bytes, const void* pack, const unsigned* bits, float* dsrc, unsigned dsrc_bytes,
                  long long images, const unsigned* dz_amax, unsigned* dsrc_amax, hipStream_t st);
+// Kernels R / RB: the weights' LDS ring filled by LDS-DMA (buffer_load_dwordx4 ... lds, one slot ahead, hand-counted vmcnt waits) instead of global -> registers ->
+// ds_write (two slots ahead): bit-identical, layer-3 forward / data gradient -5 %, layer-2 launches -1.5 % at 32,768 images (profiles/r06_ring_dma_ab.txt).
+// -DMI355_RING_DMA=0 (tools/build_variant.py) builds the register ring for A/Bs.
+#ifndef MI355_RING_DMA
+#define MI355_RING_DMA 1
+#endif
 // convrb.hip: kernel RB, the layer-2 data gradient with a group's rows dealt to tiles by border class (three images per group, two thirds of
 // kernel R's matrix instructions, bit-identical results); convr_dgrad2 hands over from MI355_RB_MIN_IMAGES images on
 #ifndef MI355_RB_MIN_IMAGES

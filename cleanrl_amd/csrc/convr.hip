@@ -58,6 +58,12 @@ __device__ __forceinline__ float r_keep_where(float x, unsigned lo, unsigned hi)
     return r;
 }
 
+// one LDS-DMA piece: 16 bytes per lane from the buffer (per-lane offset `voff`, wave-uniform `soff`) to LDS at `dst` + 16 lane (buffer_load_dwordx4 ... lds).
+// (A plain function on purpose: with the builtin inside the kernel TEMPLATE the host pass drops the kernels' launch stubs without a diagnostic.)
+__device__ __forceinline__ void r_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+}
+
 struct RArgs {
     const float* A;             // source tensor (images, IH, IW, 64)
     unsigned a_bytes;
@@ -72,6 +78,25 @@ struct RArgs {
     const unsigned* a_amax;     // amax record of A
     unsigned* c_amax;           // amax record of C to fold into, or null
 };
+
+#if MI355_RING_DMA
+// vector loads a wave issues behind the LDS-DMA pieces of ring slot `slot` + 1 (requested at the slot's first step, in front of that step's prefetch round) and in
+// front of its wait (top of the slot's last step): the prefetch rounds (r_kernel's pre_lo) and the mask words of the steps in between
+template <class RG, int EPI, bool SPREAD>
+constexpr int r_dma_younger(int slot) {
+    constexpr int NI = RG::NI, kPreSpan = RG::KSTEPS - 3;
+    int n = 0;
+    for (int v = RG::SS * slot; v < RG::SS * slot + RG::SS - 1; ++v) {
+        int lo[2] = {0, 0};
+        for (int t = 0; t < 2; ++t) {
+            const int w = v + t, m = SPREAD ? ((w - 1) * NI + kPreSpan - 1) / kPreSpan : (w - 1) * 2;
+            lo[t] = w < 1 ? 0 : (m > NI ? NI : m);
+        }
+        n += (lo[1] - lo[0]) + (((EPI == 2 || EPI == 3) && v == RG::KSTEPS - 4) ? RG::NTW : 0);      // (R_MASKB, R_MASKB_CLS4)
+    }
+    return n;
+}
+#endif
 
 template <class RG, int EPI, bool SPREAD>
 __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG::NW + 3) / 4 * RG::WGS, (RG::NW + 3) / 4 * RG::WGS))) void r_kernel(RArgs a) {
@@ -220,6 +245,30 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
+#if MI355_RING_DMA
+    // The ring by LDS-DMA (buffer_load_dwordx4 ... lds): a piece = one wave instruction, global -> LDS without registers and without the ds_write pass.  Slot s + 1
+    // is requested at the first step of slot s into the buffer every wave read for the last time before the barrier of slot s - 1 (one slot of distance; slot NSLOT =
+    // the next group's slot 0, waited for in front of the epilogue); the issuing wave waits for ITS pieces in front of the barrier at the last step of slot s: vmcnt
+    // counts in order, so "all but the r_dma_younger(s) vector loads issued behind the pieces" -- the prefetch rounds and mask words of the slot's steps but the last.
+    static_assert(NSLOT % 2 == 0, "the next group's slot 0 goes to buffer 0 while the last slot is read from buffer 1");
+    auto dma_slot = [&](int slot) __attribute__((always_inline)) {                       // -> buffer slot & 1
+        if (kFetchers == NW || wave < kFetchers) {
+#pragma unroll
+            for (int u = 0; u < kShare; ++u) {
+                const int x = wave * kShare + u, h = x / (NT * 2), jt = x - h * (NT * 2);
+                r_dma16(rsrc_p, ring + (slot & 1) * RG::SLOTB + x * 1024, 16u * (unsigned)lane, kF16PackHeader + r_kstep<RG>(SS * (slot % NSLOT) + h) * RG::STEPB + jt * 1024);
+            }
+        }
+    };
+    auto dma_wait = [&](int slot) __attribute__((always_inline)) {       // s_waitcnt vmcnt(dma_younger(slot)): an immediate -- the chain folds once the k-loop is unrolled
+        const int n = r_dma_younger<RG, EPI, SPREAD>(slot);
+#define R_VMCNT_CASE(k) if (n == k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory");
+        R_VMCNT_CASE(0) R_VMCNT_CASE(1) R_VMCNT_CASE(2) R_VMCNT_CASE(3) R_VMCNT_CASE(4) R_VMCNT_CASE(5) R_VMCNT_CASE(6) R_VMCNT_CASE(7)
+        R_VMCNT_CASE(8) R_VMCNT_CASE(9) R_VMCNT_CASE(10) R_VMCNT_CASE(11) R_VMCNT_CASE(12)
+#undef R_VMCNT_CASE
+        if (n > 12) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (never more than a few rounds per slot: a full wait is always correct)
+    };
+#endif
 
     constexpr bool kCarry = NSLOT % 2 == 0 && NSLOT >= 4;  // slots 0 and 1 of the next group travel in the sets across the group boundary
     r_f32x16 acc[MT][NTW];
@@ -278,6 +327,12 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         const unsigned gbase = (unsigned)grp * kGroupC + (unsigned)joff(jg * NTW);      // (joff is additive over the waves' column-tile groups: static_assert below)
         const __amdgpu_buffer_rsrc_t rb_cur = rsrc_b_of(grp);
         // every wave is done with the previous group's records and ring slots
+#if MI355_RING_DMA
+        ring_barrier();                                   // (a bare s_barrier: __syncthreads' fence would drain vmcnt -- the previous group's stores -- while an LDS-DMA may be pending)
+        fill();
+        __builtin_amdgcn_sched_barrier(0);
+        ring_barrier();                                   // the records are written (slot 0 landed before the previous epilogue / the prologue's wait)
+#else
         __syncthreads();
         fill();
         if constexpr (!kCarry) { load_slot(0); load_slot(1); }
@@ -285,6 +340,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
         write_slot(0);
         load_slot(2);
         ring_barrier();
+#endif
         read_a(0, 0);
         read_b(0, 0);
 #pragma unroll
@@ -292,6 +348,20 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
             const int q = v & 1, slot = v / SS, h = v % SS;
             // the operands of step v + 1 are requested before the matrix instructions of step v go out (a wave cannot run ahead of the matrix
             // pipe: whatever is issued behind a step's MFMAs starts when they end)
+#if MI355_RING_DMA
+            if (v + 1 < RG::KSTEPS) {
+                if (h == SS - 1) {
+                    dma_wait(slot);                       // this wave's pieces of slot + 1 have landed
+                    ring_barrier();
+                }
+                read_b(q ^ 1, v + 1);
+                read_a(q ^ 1, v + 1);
+            }
+            if (h == 0) {
+                dma_slot(slot + 1);
+                __builtin_amdgcn_sched_barrier(0);        // (r_dma_younger assumes the pieces are issued in front of this step's prefetch round)
+            }
+#else
             if (v + 1 < RG::KSTEPS) {
                 if (h == SS - 1) ring_barrier();          // slot + 1 has landed in its buffer (written at the first step of this slot)
                 read_b(q ^ 1, v + 1);
@@ -302,6 +372,7 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
                 if (slot + 3 < NSLOT) load_slot(slot + 3);
                 else if (kCarry && slot + 3 - NSLOT < 2) load_slot(slot + 3 - NSLOT);     // (the last group fetches them for nobody)
             }
+#endif
             // the next group's source, a few loads at a time (pre_lo above): the whole group at once (104 KB per CU in the layer-3
             // forward) exceeds what a CU keeps in flight and held the issuing waves -- and the matrix pipe behind them -- for 7,000 cycles
             if (pre_lo(v + 1) > pre_lo(v)) prefetch(grp + gridDim.x, pre_lo(v), pre_lo(v + 1) - pre_lo(v));
@@ -354,7 +425,11 @@ __global__ __launch_bounds__(64 * RG::NW) __attribute__((amdgpu_waves_per_eu((RG
     int grp = blockIdx.x;
     if (grp < a.groups) {
         prefetch(grp, 0, NI);
+#if MI355_RING_DMA
+        dma_slot(0);
+#else
         if constexpr (kCarry) { load_slot(0); load_slot(1); }
+#endif
         __builtin_amdgcn_s_waitcnt(kRWaitVm0);              // (the loop is entered as the back edge enters it: nothing pending, so its top needs no wait -- see group())
     }
     for (; grp < a.groups; grp += gridDim.x) group(grp);

@@ -170,6 +170,19 @@ __global__ __launch_bounds__(RBGeom::THREADS) __attribute__((amdgpu_waves_per_eu
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
+#if MI355_RING_DMA
+    // The ring by LDS-DMA (buffer_load_dwordx4 ... lds): a piece = one wave instruction, global -> LDS without registers and without the ds_write pass.  Slot s + 1
+    // is requested at the first step of slot s into the buffer every wave read for the last time before the barrier of slot s - 1; the issuing wave waits for ITS
+    // pieces (vmcnt counts in order: `younger` = the vector loads it issued behind them) in front of the barrier at the last step of slot s.
+    auto dma_slot = [&](int slot) __attribute__((always_inline)) {                       // -> buffer slot & 1
+#pragma unroll
+        for (int u = 0; u < kShare; ++u) {
+            const int x = wave * kShare + u, h = x / (NT * 2), jt = x - h * (NT * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (__attribute__((address_space(3))) void*)(ring + (slot & 1) * RG::SLOTB + x * 1024), 16, lane16,
+                                                     kF16PackHeader + (SS * (slot % NSLOT) + h) * RG::STEPB + jt * 1024, 0, 0);
+        }
+    };
+#endif
 
     rb_f32x16 acc[MT];
     unsigned wm[3];                                       // lane L of wm[k]: the mask word of wave row 64 k + L (this wave's class)
@@ -221,12 +234,20 @@ __global__ __launch_bounds__(RBGeom::THREADS) __attribute__((amdgpu_waves_per_eu
         const unsigned gbase = (unsigned)grp * kGroupC + cls_off;
         const __amdgpu_buffer_rsrc_t rb_cur = rsrc_b_of(grp);
         // every wave is done with the previous group's records and ring slots
+#if MI355_RING_DMA
+        ring_barrier();                                   // (a bare s_barrier: __syncthreads' fence drains vmcnt -- the previous group's stores -- while an LDS-DMA may be pending)
+#else
         __syncthreads();
+#endif
         fill();
         __builtin_amdgcn_sched_barrier(0);
+#if MI355_RING_DMA
+        ring_barrier();                                   // the records are written (slot 0 landed before the previous epilogue / the prologue's wait)
+#else
         write_slot(0);
         load_slot(2);
         ring_barrier();
+#endif
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[NI3 + 1][e] = 0.0f;
         read_b(0, 0);
@@ -234,6 +255,24 @@ __global__ __launch_bounds__(RBGeom::THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int v = 0; v < RG::KSTEPS; ++v) {
             const int q = v & 1, slot = v / SS, h = v % SS;
+#if MI355_RING_DMA
+            if (v + 1 < RG::KSTEPS) {
+                if (h == SS - 1) {
+                    // this wave's pieces of slot + 1: everything but the vector loads issued behind them (the prefetch rounds of steps SS slot + 1 .. v - 1)
+                    constexpr int younger[NSLOT] = {4, 2, 0, 0};
+                    static_assert(pre_lo(SS - 1) - pre_lo(1) == 4 && pre_lo(2 * SS - 1) - pre_lo(SS) == 2 && pre_lo(2 * SS) == NI, "the hand-counted waits");
+                    if (younger[slot] == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (younger[slot] == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ring_barrier();
+                }
+                read_b(q ^ 1, v + 1);
+            }
+            if (h == 0) {
+                dma_slot(slot + 1);                       // (slot NSLOT = the next group's slot 0; the last group fetches it for nobody)
+                __builtin_amdgcn_sched_barrier(0);        // (the counts above assume the pieces are issued in front of this step's prefetch round)
+            }
+#else
             if (v + 1 < RG::KSTEPS) {
                 if (h == SS - 1) ring_barrier();          // slot + 1 has landed in its buffer (written at the first step of this slot)
                 read_b(q ^ 1, v + 1);
@@ -243,6 +282,7 @@ __global__ __launch_bounds__(RBGeom::THREADS) __attribute__((amdgpu_waves_per_eu
                 if (slot + 3 < NSLOT) load_slot(slot + 3);
                 else if (slot + 3 - NSLOT < 2) load_slot(slot + 3 - NSLOT);      // the next group's first two slots (the last group fetches them for nobody)
             }
+#endif
             if (pre_lo(v + 1) > pre_lo(v)) prefetch(grp + a.grid, pre_lo(v), pre_lo(v + 1) - pre_lo(v));
             if (v == RG::KSTEPS - 4) load_masks(gbase, rb_cur);
             if (h == 0 && (slot & 1) && rw != 0) {          // row-wave 1: the rim accumulators change places
@@ -290,8 +330,12 @@ __global__ __launch_bounds__(RBGeom::THREADS) __attribute__((amdgpu_waves_per_eu
     int grp = blockIdx.x;
     if (grp < a.groups) {
         prefetch(grp, 0, NI);
+#if MI355_RING_DMA
+        dma_slot(0);
+#else
         load_slot(0);
         load_slot(1);
+#endif
         __builtin_amdgcn_s_waitcnt(kRBWaitVm0);
     }
     for (; grp < a.groups; grp += a.grid) group(grp);
