@@ -19,7 +19,7 @@ KEYS = {   # bench key -> (kernel-name substring, geometry substring) in rocpd_p
     "conv2_fwd": [("z_kernel", "ZRowsConv<20, 20, 32, 4, 4, 9, 9, 2, 0,"), ("r_kernel", "RGeom<20, 20, 0, 4, 4, 9, 9,")],
     # (at 32,768 images kernel R runs the layer-3 forward and the layer-2 data gradient: csrc/convr.hip; one of the two names appears in a pass)
     "conv3_fwd": [("z_kernel", "ZRowsConv<9, 9, 64, 3, 3, 7, 7, 1, 0,"), ("r_kernel", "RGeom<9, 9, 0, 3, 3, 7, 7,")],
-    "conv2_dgrad": [("z_kernel", "ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1,"), ("r_kernel", "RGeom<9, 9, 1, 2, 2, 10, 10,")],
+    "conv2_dgrad": [("z_kernel", "ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1,"), ("r_kernel", "RGeom<9, 9, 1, 2, 2, 10, 10,"), ("rb_kernel", "")],
     "conv3_dgrad": [("z_kernel", "ZRowsConv<7, 7, 64, 3, 3, 9, 9, 1, -2,"), ("r_kernel", "RGeom<7, 7, 2, 3, 3, 9, 9,")],
     "conv1_wgrad": [("conv1p_wgrad_kernel", ""), ("convu1_kernel", "")],
     "conv2_wgrad": [("convw_bf16_kernel", "VGeom<20, 20, 32,"), ("convu_kernel", "UGeom<20, 20, 32,")],      # (kernel U, csrc/convu.hip, replaces V / P under the f16 split)

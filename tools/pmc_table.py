@@ -19,7 +19,7 @@ NAMES = [("conv1q_fwd_kernel", "", "Q conv1 fwd"), ("z_kernel", "ZRowsConv<20, 2
          ("z_kernel", "ZRowsConv<9, 9, 64, 3, 3, 7, 7, 1, 0,", "Z conv3 fwd"), ("r_kernel", "RGeom<9, 9, 0, 3, 3, 7, 7,", "R conv3 fwd"), ("z_kernel", "ZRowsLinear, 2, 4, 4, 0, true", "Z FC fwd"), ("g_kernel<0>", "", "G FC fwd"), ("g_kernel<1>", "", "G FC dgrad"), ("h_kernel", "", "H FC wgrad"),
          ("z_kernel", "ZRowsLinear, 2, 4, 4, 3, false", "Z FC dgrad"), ("fcw_bf16_kernel", "", "W FC wgrad"),
          ("convw_bf16_kernel", "VGeom<9, 9, 64,", "V conv3 wgrad"), ("convu_kernel", "UGeom<9, 9, 64,", "U conv3 wgrad"), ("z_kernel", "ZRowsConv<7, 7, 64, 3, 3, 9, 9, 1, -2,", "Z conv3 dgrad"), ("r_kernel", "RGeom<7, 7, 2, 3, 3, 9, 9,", "R conv3 dgrad"),
-         ("convw_bf16_kernel", "VGeom<20, 20, 32,", "V conv2 wgrad"), ("convu_kernel", "UGeom<20, 20, 32,", "U conv2 wgrad"), ("z_kernel", "ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1,", "Z conv2 dgrad"), ("r_kernel", "RGeom<9, 9, 1, 2, 2, 10, 10,", "R conv2 dgrad"),
+         ("convw_bf16_kernel", "VGeom<20, 20, 32,", "V conv2 wgrad"), ("convu_kernel", "UGeom<20, 20, 32,", "U conv2 wgrad"), ("z_kernel", "ZRowsConv<9, 9, 64, 2, 2, 10, 10, 1, -1,", "Z conv2 dgrad"), ("r_kernel", "RGeom<9, 9, 1, 2, 2, 10, 10,", "R conv2 dgrad"), ("rb_kernel", "", "RB conv2 dgrad"),
          ("conv1p_wgrad_kernel", "", "P conv1 wgrad"), ("convu1_kernel", "", "U conv1 wgrad")]
 
 
