@@ -743,6 +743,60 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce2(const float* __restric
     }
 }
 
+// Both stages in ONE launch when the partials are at most 8 chunks (256 workgroups' partials) -- taken for layer 1 only, see the launcher: a workgroup = 32 consecutive
+// elements x 8 chunks; thread (chunk c, element x) folds chunk c exactly as conv_wgrad_reduce1 does, the chunk sums meet in LDS, and the threads of chunk 0
+// add them in conv_wgrad_reduce2's order and scatter into torch's layout -- the same additions in the same order (bit-identical), one dependent launch
+// (5.9 us + the gap in front of it) less per layer and minibatch.  The last workgroup folds the bias partials the same way.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce12(const float* __restrict__ part_w, int nparts, int NK, const float* __restrict__ part_b, int N, int C,
+                                                           int KH, int KW, float scale, float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float cs[8][64];
+    const int c = threadIdx.x >> 5, x = threadIdx.x & 31, nchunks = (nparts + kRedChunk - 1) / kRedChunk;
+    const int p0 = c * kRedChunk, p1 = p0 + kRedChunk < nparts ? p0 + kRedChunk : nparts;
+    if (blockIdx.x == gridDim.x - 1) {                // bias: channels x and x + 32
+        for (int n = x; n < N; n += 32) {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int p = p0; p < p1; ++p) s4[p & 3] += part_b[(size_t)p * N + n];
+            cs[c][n] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        }
+        __syncthreads();
+        if (c == 0 && db)
+            for (int n = x; n < N; n += 32) {
+                float s = 0.0f;
+                for (int q = 0; q < nchunks; ++q) s += cs[q][n];
+                db[n] = s;
+            }
+        return;
+    }
+    const int e = blockIdx.x * 32 + x;                // NK % 32 == 0 (host-checked)
+    if (c < nchunks) {
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int p = p0;
+        if (p1 - p0 == kRedChunk) {                   // a whole chunk: its 32 loads in flight together, added in the order of the loops below
+            float v[kRedChunk];
+#pragma unroll
+            for (int u = 0; u < kRedChunk; ++u) v[u] = part_w[(size_t)(p0 + u) * NK + e];
+#pragma unroll
+            for (int u = 0; u < kRedChunk; ++u) s8[u & 7] += v[u];
+            p = p1;
+        }
+        for (; p + 8 <= p1; p += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += part_w[(size_t)(p + u) * NK + e];
+        }
+        for (; p < p1; ++p) s8[p & 7] += part_w[(size_t)p * NK + e];
+        cs[c][x] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
+    __syncthreads();
+    if (c == 0) {
+        float s = 0.0f;
+        for (int q = 0; q < nchunks; ++q) s += cs[q][x];
+        const int K = KH * KW * C;
+        const int n = e / K, k = e - n * K;
+        const int r = k / (KW * C), rem = k - r * (KW * C), cc = rem / C, ch = rem - cc * C;
+        dW[((n * C + ch) * KH + r) * KW + cc] = s * scale;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ weight repack
 // mode 0 (forward):           Bt[n=cout][(r,c,cin)]          = W[cout][cin][r][c]
 // mode 1 (dgrad, stride 1):   Bt[n=cin][(r,c,cout)]          = W[cout][cin][KH-1-r][KW-1-c]
@@ -1222,6 +1276,13 @@ static int conv_wgrad_impl(const char* fn, const void* src, const int64_t* inds,
     int rc = check_launch("conv_wgrad_kernel");
     if (rc) return rc;
     const int nchunks = (wparts + kRedChunk - 1) / kRedChunk;
+    // both stages in one launch (the same additions in the same order) where it is ahead: layer 1's 8,192 elements (weight gradient entry point 575 -> 564 us at
+    // 32,768 images, 98 -> 92 at 4,096); for the 33 - 37 k elements of layers 2 / 3 its 128-byte rows read slower than stage 1's 1-KB rows (+4 us), so they keep two launches
+    if (nchunks <= 8 && total_w % 32 == 0 && Cout <= 64 && total_w <= 8192) {
+        hipLaunchKernelGGL(conv_wgrad_reduce12, dim3(total_w / 32 + 1), dim3(256), 0, s, part_w, wparts, total_w, part_b, Cout, Cin, KH, KH,
+                           layer == 1 ? kInv255 * pscale : 1.0f, dW, db);
+        return check_launch("conv_wgrad_reduce12");
+    }
     hipLaunchKernelGGL(conv_wgrad_reduce1, dim3((total_w + 255) / 256 + 1, nchunks), dim3(256), 0, s, part_w, wparts, total_w, mid,
                        part_b, wparts, Cout, mid_b);
     rc = check_launch("conv_wgrad_reduce1");
