@@ -270,6 +270,46 @@ def test_kernel_r_data_gradients_are_kernel_z_bit_for_bit(monkeypatch, layer, im
     _close(out["R"][0], x.grad * (act > 0), f"kernel R conv{layer} dgrad, {images} images")
 
 
+@pytest.mark.parametrize("images", [3072, 3073, 3074, 4100])
+def test_kernel_rb_is_kernel_z_bit_for_bit_and_writes_nothing_past_its_tensor(monkeypatch, images):
+    """Kernel RB (csrc/convrb.hip: the layer-2 data gradient from 3,072 images on -- three images per group, the rows dealt to tiles by border class, the products
+    with a zero-border operand not issued) against kernel Z through the C ABI: gradient and amax record bit-equal, at batch sizes whose last group holds three,
+    one and two images; the gradient carved out of a sentinel-filled buffer -- the rows of the images a last group does not have are left to the buffer
+    descriptor's range check, every word behind the tensor must keep its sentinel; a slice against float64."""
+    layer = 2
+    cin, cout, k, st, hin, hout = SPEC[layer]
+    lib = cnn._lib.load()
+    monkeypatch.delenv("MI355PPO_CONV_R", raising=False)
+    assert chr(lib.mi355ppo_cnn_conv_packed_kernel_f16x2(images, 2, 1)) == "B"
+    W, _ = _params(layer, 40 + images % 7)
+    g = torch.Generator(device=DEV).manual_seed(5 * images + 1)
+    act = torch.randn(images, hin, hin, cin, device=DEV, generator=g)
+    dz = (torch.randn(images, hout, hout, cout, device=DEV, generator=g) * torch.exp2(-14 * torch.rand(images, 1, 1, 1, device=DEV, generator=g)) * 1e-3
+          * (torch.rand(images, hout, hout, cout, device=DEV, generator=g) > 0.5))
+    m = (act > 0).reshape(-1, 32).to(torch.int64)
+    w = (m << torch.arange(32, device=DEV)).sum(1)
+    bits = ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32)
+    pack = cnn.conv_zpack_f16x2(W, layer, cnn.MODE_DGRAD_S2)
+    rz = _rec_of(dz)
+    n, guard = act.numel(), 1 << 18
+    out = {}
+    for route, env in (("Z", {"MI355PPO_CONV_R": "0"}), ("B", {})):
+        monkeypatch.delenv("MI355PPO_CONV_R", raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        buf = torch.full((n + guard,), 0x7FC0DEAD, dtype=torch.int32, device=DEV)
+        rd = cnn.new_amax(1, DEV)[0]
+        got = cnn.conv_dgrad_packed(dz, pack, None, layer, buf[:n].view(torch.float32).view(act.shape), bits=bits, amax=(rz, rd))
+        torch.cuda.synchronize()
+        assert bool((buf[n:] == 0x7FC0DEAD).all()), f"route {route}: words behind the gradient were written"
+        out[route] = (got, cnn.amax_value(rd))
+    assert torch.equal(out["B"][0].view(torch.int32), out["Z"][0].view(torch.int32)) and out["B"][1] == out["Z"][1] == out["B"][0].abs().max().item()
+    sl = slice(images - 5, images)                                     # the last group(s)
+    x = act[sl].double().requires_grad_(True)
+    _conv64(x, W.double(), None, st).backward(dz[sl].double())
+    _close(out["B"][0][sl], x.grad * (act[sl] > 0), f"kernel RB conv2 dgrad, {images} images")
+
+
 @pytest.mark.parametrize("layer", [2, 3])
 @pytest.mark.parametrize("images", [1, 37, 64, 700, 2100])
 def test_conv_data_gradient_f16x2_against_float64(layer, images):
